@@ -1,0 +1,136 @@
+"""ctypes binding of libs2svc_hip.so (the C ABI declared in include/s2svc_hip.h).
+
+There is deliberately NO fallback: if the shared object is missing or fails to load, importing
+any compute op raises.  `build_library()` (used by `__graft_entry__.build()`) cross-compiles the
+HIP sources for gfx950 with hipcc; it needs no GPU.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libs2svc_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build_library(force=False, verbose=True):
+    """Compile csrc/*.hip -> csrc/libs2svc_hip.so for gfx950 (in-tree, so it travels to the GPU box)."""
+    srcs = [os.path.join(CSRC, f) for f in sources()]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(_HERE, "..", "include", "s2svc_hip.h")]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(p) for p in deps)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        hdr_time = max(os.path.getmtime(p) for p in deps[len(srcs):])
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
+                and os.path.getmtime(obj) >= hdr_time):
+            return obj
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-c", src, "-o", obj]
+        if verbose:
+            print("[s2svc build]", " ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print("[s2svc build]", " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+c_i32, c_i64, c_f32, c_u64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_void_p
+
+
+class Operand(ctypes.Structure):
+    _fields_ = [("ptr", c_vp), ("ld", c_i64), ("layout", c_i32), ("mode", c_i32), ("C", c_i32), ("T", c_i32),
+                ("pad", c_i32), ("T1", c_i32), ("F1", c_i32), ("T2", c_i32), ("F2", c_i32), ("bs0", c_i64),
+                ("bs1", c_i64)]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", Operand), ("B", Operand), ("C", c_vp), ("ldc", c_i64), ("cbs0", c_i64), ("cbs1", c_i64),
+                ("c_dtype", c_i32), ("bias", c_vp), ("res", c_vp), ("ldr", c_i64), ("rbs0", c_i64), ("rbs1", c_i64),
+                ("M", c_i32), ("N", c_i32), ("K", c_i32), ("nb0", c_i32), ("nb1", c_i32), ("act", c_i32),
+                ("alpha", c_f32), ("dtype", c_i32), ("accumulate", c_i32), ("splitk", c_i32), ("ws", c_vp)]
+
+
+_SIGS = {
+    "s2svc_gemm": [ctypes.POINTER(GemmDesc), c_vp],
+    "s2svc_layernorm_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_layernorm_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
+    "s2svc_colreduce": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
+    "s2svc_bn_finalize": [c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_rstd_from_var": [c_i32, c_f32, c_vp, c_vp, c_vp],
+    "s2svc_bn_apply": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
+    "s2svc_bn_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
+    "s2svc_attn_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_f32,
+                               c_vp, c_u64, c_vp, c_vp, c_vp],
+    "s2svc_attn_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32,
+                               c_i32, c_vp],
+    "s2svc_act_dropout_fwd": [c_i32, c_i64, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp],
+    "s2svc_act_dropout_bwd": [c_i32, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp],
+    "s2svc_posenc_fwd": [c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp],
+    "s2svc_posenc_bwd": [c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_axpby": [c_i32, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp],
+    "s2svc_add_head_bias": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_glu_fwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp],
+    "s2svc_glu_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_cast": [c_i32, c_i32, c_i64, c_vp, c_vp, c_vp],
+    "s2svc_gather3": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "s2svc_mas": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_mas_binloss_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+}
+_RET64 = {"s2svc_mas_ws_bytes": [c_i32, c_i32, c_i32]}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every symbol include/s2svc_hip.h declares (checked by the CPU-side ABI test)."""
+    return sorted(list(_SIGS) + list(_RET64) + ["s2svc_last_error", "s2svc_abi_version"])
+
+
+def lib():
+    """Load the shared object (once).  Raises if it is absent -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the seq2seq-vc HIP kernels are not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, no GPU). "
+            "There is no CPU fallback for the product path.")
+    L = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    for name, args in _RET64.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_int64
+    L.s2svc_last_error.restype = ctypes.c_char_p
+    L.s2svc_abi_version.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().s2svc_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,338 @@
+// LayerNorm (fused with residual-add + dropout), BatchNorm1d over (B*T) rows, and the chunked
+// deterministic column reductions they and the bias gradients share.  All HBM-bound: one read of
+// each input, one write of each output, statistics in fp32 registers / wave shuffles.
+#include "common.h"
+#include "../../include/s2svc_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward: one wavefront per row.
+//   s = res ? res + dropout(x) : x ;  y = (s - mean) * rstd * gamma + beta
+// reference: modules/transformer/layer_norm.py:12-42 (eps 1e-12) and the residual/dropout lines of
+// encoder_layer.py:96-113, decoder_layer.py:104-127, conformer/encoder_layer.py:118-170.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const T* __restrict__ x, const T* __restrict__ res,
+                                                     float p, const uint64_t* seed_base, uint64_t seed_off, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ y,
+                                                     T* __restrict__ s_out, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t base = (int64_t)row * D;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float sum = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    float v = ldf(x + base + c);
+    if (res) {
+      if (p > 0.f) v *= dropout_scale(seed, (uint64_t)(base + c), p, inv_keep);
+      v += ldf(res + base + c);
+      stf(s_out + base + c, v);
+      v = ldf(s_out + base + c);  // statistics on the stored (rounded) value
+    }
+    sum += v;
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  const T* s = res ? s_out : x;
+  float sq = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    float d = ldf(s + base + c) - mean;
+    sq += d * d;
+  }
+  const float var = wave_sum(sq) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int c = lane; c < D; c += 64) {
+    float v = (ldf(s + base + c) - mean) * rstd;
+    stf(y + base + c, v * gamma[c] + beta[c]);
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
+// LayerNorm backward wrt the normalised input s (+ fused residual/dropout split):
+//   g = dy*gamma ; ds = rstd*(g - mean(g) - xhat*mean(g*xhat)) + ds_extra
+//   dres = ds ; dh = ds * dropmask
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* __restrict__ dy, const T* __restrict__ s,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const T* __restrict__ ds_extra,
+                                                     float p, const uint64_t* seed_base, uint64_t seed_off, T* __restrict__ ds, T* __restrict__ dh) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t base = (int64_t)row * D;
+  const float mu = mean[row], rs = rstd[row];
+  float a = 0.f, b = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    float g = ldf(dy + base + c) * gamma[c];
+    float xh = (ldf(s + base + c) - mu) * rs;
+    a += g;
+    b += g * xh;
+  }
+  a = wave_sum(a) / (float)D;
+  b = wave_sum(b) / (float)D;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int c = lane; c < D; c += 64) {
+    float g = ldf(dy + base + c) * gamma[c];
+    float xh = (ldf(s + base + c) - mu) * rs;
+    float v = rs * (g - a - xh * b);
+    if (ds_extra) v += ldf(ds_extra + base + c);
+    stf(ds + base + c, v);
+    if (dh) {
+      float m = p > 0.f ? dropout_scale(seed, (uint64_t)(base + c), p, inv_keep) : 1.f;
+      stf(dh + base + c, v * m);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chunked column reduction over rows of a (rows, D) matrix, deterministic (fixed summation order):
+//   mode 0: sum[c] = S dy[r,c]
+//   mode 1: sum[c] = S dy[r,c];  dot[c] = S dy[r,c]*(x[r,c]-mean[r])*rstd[r]     (LayerNorm dgamma/dbeta)
+//   mode 2: sum[c] = S dy[r,c];  dot[c] = S dy[r,c]*(x[r,c]-mean[c])*rstd[c]     (BatchNorm dgamma/dbeta)
+//   mode 3: sum[c] = S (x[r,c]-mean[c])^2                                        (BatchNorm variance)
+//   mode 4: sum[c] = S dy[r,c]*x[r,c]                                            (posenc alpha etc.)
+// stage 1 writes ws[chunk][2][D]; stage 2 sums the chunks and multiplies by `scale`.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mode, const T* __restrict__ dy,
+                                                        const T* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ ws,
+                                                        int rows_per_chunk) {
+  __shared__ float sh[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int chunk = blockIdx.y;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = (r0 + rows_per_chunk < rows) ? r0 + rows_per_chunk : rows;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < D) {
+    float mc = 0.f, rc = 1.f;
+    if (mode == 2 || mode == 3) { mc = mean[c]; rc = rstd ? rstd[c] : 1.f; }
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const int64_t o = (int64_t)r * D + c;
+      if (mode == 0) {
+        s0 += ldf(dy + o);
+      } else if (mode == 1) {
+        float g = ldf(dy + o);
+        s0 += g;
+        s1 += g * (ldf(x + o) - mean[r]) * rstd[r];
+      } else if (mode == 2) {
+        float g = ldf(dy + o);
+        s0 += g;
+        s1 += g * (ldf(x + o) - mc) * rc;
+      } else if (mode == 3) {
+        float dv = ldf(x + o) - mc;
+        s0 += dv * dv;
+      } else {
+        s0 += ldf(dy + o) * ldf(x + o);
+      }
+    }
+  }
+  sh[0][rl][cl] = s0;
+  sh[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    float t0 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+    float t1 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+    ws[((int64_t)chunk * 2 + 0) * D + c] = t0;
+    ws[((int64_t)chunk * 2 + 1) * D + c] = t1;
+  }
+}
+
+__global__ void colreduce_stage2(int D, int chunks, const float* __restrict__ ws, float scale, float* __restrict__ out_sum,
+                                 float* __restrict__ out_dot, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float t0 = 0.f, t1 = 0.f;
+  for (int k = 0; k < chunks; ++k) {
+    t0 += ws[((int64_t)k * 2 + 0) * D + c];
+    t1 += ws[((int64_t)k * 2 + 1) * D + c];
+  }
+  if (out_sum) out_sum[c] = (accumulate ? out_sum[c] : 0.f) + t0 * scale;
+  if (out_dot) out_dot[c] = (accumulate ? out_dot[c] : 0.f) + t1 * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm1d apply (channel-last rows): y = dropout(act((x-mean[c])*rstd[c]*gamma[c]+beta[c]))
+// reference: modules/pre_postnets.py:108-165 (Conv1d->BatchNorm1d->Tanh->Dropout) and
+// modules/conformer/convolution.py:73-75 (BatchNorm1d -> Swish).  Padded frames are part of the
+// statistics exactly as in the reference (no masking).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bn_apply_kernel(int64_t total, int C, const T* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, int act, float p, const uint64_t* seed_base, uint64_t seed_off, T* __restrict__ y,
+                                T* __restrict__ pre_act) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float v = (ldf(x + i) - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    if (pre_act) stf(pre_act + i, v);
+    v = act_apply(v, act);
+    if (p > 0.f) v *= dropout_scale(seed, (uint64_t)i, p, inv_keep);
+    stf(y + i, v);
+  }
+}
+
+// dx = gamma*rstd*(dy - sum_dy/N - xhat*sum_dy_xhat/N)   (training-mode BatchNorm backward)
+// eval mode (use_batch_stats = 0): dx = gamma*rstd*dy
+template <typename T>
+__global__ void bn_bwd_kernel(int64_t total, int C, float inv_n, const T* __restrict__ dy, const T* __restrict__ x,
+                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                              const float* __restrict__ gamma, const float* __restrict__ sum_dy,
+                              const float* __restrict__ sum_dy_xhat, int use_batch_stats, T* __restrict__ dx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float g = ldf(dy + i);
+    float v;
+    if (use_batch_stats) {
+      float xh = (ldf(x + i) - mean[c]) * rstd[c];
+      v = gamma[c] * rstd[c] * (g - sum_dy[c] * inv_n - xh * sum_dy_xhat[c] * inv_n);
+    } else {
+      v = gamma[c] * rstd[c] * g;
+    }
+    stf(dx + i, v);
+  }
+}
+
+// var (biased) -> rstd, and the running-statistics update of torch.nn.BatchNorm1d (momentum 0.1,
+// unbiased variance in the running buffer).
+__global__ void bn_finalize_kernel(int C, int n, float eps, float momentum, const float* __restrict__ mean,
+                                   const float* __restrict__ var, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var, int64_t* __restrict__ num_batches) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches) *num_batches += 1;
+  if (c >= C) return;
+  rstd[c] = 1.0f / sqrtf(var[c] + eps);
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
+    const float unb = n > 1 ? var[c] * ((float)n / (float)(n - 1)) : var[c];
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+  }
+}
+
+__global__ void rstd_from_var_kernel(int C, float eps, const float* __restrict__ var, float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+
+inline int ew_blocks(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, const void* res, float drop_p,
+                                   const uint64_t* seed_base, uint64_t seed_off, const float* gamma, const float* beta, float eps, void* y,
+                                   void* s_out, float* mean, float* rstd, void* stream) {
+  S2S_REQUIRE(rows >= 0 && D > 0, "layernorm_fwd: bad shape");
+  S2S_REQUIRE(!res || s_out, "layernorm_fwd: s_out required with residual");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4), block(256);
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, rows, D, (const float*)x, (const float*)res, drop_p, seed_base, seed_off,
+                       gamma, beta, eps, (float*)y, (float*)s_out, mean, rstd);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, st, rows, D, (const bf16_t*)x, (const bf16_t*)res, drop_p,
+                       seed_base, seed_off, gamma, beta, eps, (bf16_t*)y, (bf16_t*)s_out, mean, rstd);
+  S2S_CHECK_LAUNCH("ln_fwd_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, const void* s, const float* mean,
+                                   const float* rstd, const float* gamma, const void* ds_extra, float drop_p,
+                                   const uint64_t* seed_base, uint64_t seed_off, void* ds, void* dh, void* stream) {
+  S2S_REQUIRE(rows >= 0 && D > 0, "layernorm_bwd: bad shape");
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4), block(256);
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, st, rows, D, (const float*)dy, (const float*)s, mean, rstd,
+                       gamma, (const float*)ds_extra, drop_p, seed_base, seed_off, (float*)ds, (float*)dh);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean,
+                       rstd, gamma, (const bf16_t*)ds_extra, drop_p, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
+  S2S_CHECK_LAUNCH("ln_bwd_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void* dy, const void* x, const float* mean,
+                               const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate,
+                               float* ws, int ws_chunks, void* stream) {
+  S2S_REQUIRE(rows >= 0 && D > 0 && ws && ws_chunks > 0, "colreduce: bad args");
+  S2S_REQUIRE(mode >= 0 && mode <= 4, "colreduce: bad mode");
+  hipStream_t st = (hipStream_t)stream;
+  int chunks = (rows + 63) / 64;
+  if (chunks > ws_chunks) chunks = ws_chunks;
+  if (chunks < 1) chunks = 1;
+  const int rpc = (rows + chunks - 1) / chunks;
+  dim3 grid((D + 63) / 64, chunks), block(256);
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(colreduce_stage1<float>, grid, block, 0, st, rows, D, mode, (const float*)dy, (const float*)x, mean,
+                       rstd, ws, rpc);
+  else
+    hipLaunchKernelGGL(colreduce_stage1<bf16_t>, grid, block, 0, st, rows, D, mode, (const bf16_t*)dy, (const bf16_t*)x,
+                       mean, rstd, ws, rpc);
+  S2S_CHECK_LAUNCH("colreduce_stage1");
+  hipLaunchKernelGGL(colreduce_stage2, dim3((D + 255) / 256), dim3(256), 0, st, D, chunks, ws, scale, out_sum, out_dot,
+                     accumulate);
+  S2S_CHECK_LAUNCH("colreduce_stage2");
+  return 0;
+}
+
+extern "C" int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean, const float* var,
+                                 float* rstd, float* run_mean, float* run_var, int64_t* num_batches, void* stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, n, eps, momentum,
+                     mean, var, rstd, run_mean, run_var, num_batches);
+  S2S_CHECK_LAUNCH("bn_finalize_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_rstd_from_var(int C, float eps, const float* var, float* rstd, void* stream) {
+  hipLaunchKernelGGL(rstd_from_var_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, eps, var, rstd);
+  S2S_CHECK_LAUNCH("rstd_from_var_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_bn_apply(int dtype, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y,
+                              void* pre_act, void* stream) {
+  const int64_t total = rows * C;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, total, C, (const float*)x, mean,
+                       rstd, gamma, beta, act, drop_p, seed_base, seed_off, (float*)y, (float*)pre_act);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, total, C, (const bf16_t*)x, mean,
+                       rstd, gamma, beta, act, drop_p, seed_base, seed_off, (bf16_t*)y, (bf16_t*)pre_act);
+  S2S_CHECK_LAUNCH("bn_apply_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_bn_bwd(int dtype, int64_t rows, int C, const void* dy, const void* x, const float* mean,
+                            const float* rstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat,
+                            int use_batch_stats, void* dx, void* stream) {
+  const int64_t total = rows * C;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const float inv_n = 1.0f / (float)rows;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(bn_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, total, C, inv_n, (const float*)dy,
+                       (const float*)x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats, (float*)dx);
+  else
+    hipLaunchKernelGGL(bn_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, total, C, inv_n, (const bf16_t*)dy,
+                       (const bf16_t*)x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats, (bf16_t*)dx);
+  S2S_CHECK_LAUNCH("bn_bwd_kernel");
+  return 0;
+}

@@ -1,0 +1,336 @@
+"""Thin, non-differentiable Python launchers over the C ABI (include/s2svc_hip.h).
+
+Every function here takes torch tensors that already live on the GPU, hands their raw device
+pointers to libs2svc_hip.so on torch's current HIP stream, and returns torch tensors.  torch is
+used for memory (caching allocator) and streams only.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+KC, RC = 0, 1
+DENSE, CONV1D, CONV2D_S2 = 0, 1, 2
+ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "swish": 3, "sigmoid": 4, "gelu": 5}
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype if isinstance(t, torch.Tensor) else t}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("seq2seq_vc_amd kernels need GPU tensors (there is no CPU path)")
+
+
+# ----------------------------------------------------------------------------------------------
+# dropout seed state: kernels read (*seed_base + seed_off); the base lives in device memory so a
+# captured hipGraph draws fresh masks on every replay once the trainer bumps it.
+# ----------------------------------------------------------------------------------------------
+class _SeedState:
+    def __init__(self):
+        self.base = {}
+        self.counter = 0
+        self.init = 0x5EED5EED
+
+    def tensor(self, device):
+        key = (device.type, device.index)
+        if key not in self.base:
+            self.base[key] = torch.full((1,), self.init, dtype=torch.int64, device=device)
+        return self.base[key]
+
+    def next_offset(self):
+        self.counter += 1
+        return (self.counter * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
+
+SEED = _SeedState()
+
+
+def manual_seed(seed, device=None):
+    SEED.init = int(seed)
+    SEED.counter = 0
+    for t in SEED.base.values():
+        t.fill_(int(seed))
+
+
+def advance_seed(device):
+    """Bump the device-resident seed base (graph-capturable)."""
+    SEED.tensor(device).add_(0x10001)
+
+
+def reset_op_counter():
+    SEED.counter = 0
+
+
+def new_seed(device):
+    return SEED.tensor(device).data_ptr(), SEED.next_offset()
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------------------------
+def operand(t, ld, layout=KC, mode=DENSE, C=0, T=0, pad=0, T1=0, F1=0, T2=0, F2=0, bs0=0, bs1=0, offset=0):
+    o = _lib.Operand()
+    o.ptr = t.data_ptr() + offset * t.element_size()
+    o.ld, o.layout, o.mode, o.C, o.T, o.pad = ld, layout, mode, C, T, pad
+    o.T1, o.F1, o.T2, o.F2, o.bs0, o.bs1 = T1, F1, T2, F2, bs0, bs1
+    return o
+
+
+def pick_splitk(M, N, K, nbatch=1):
+    tiles = ((M + 63) // 64) * ((N + 63) // 64) * nbatch
+    ktiles = (K + 31) // 32
+    if tiles >= 256 or ktiles < 16:
+        return 1
+    s = min(max(1, 512 // tiles), ktiles // 8, 64)
+    return max(1, s)
+
+
+def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
+         ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False):
+    """C = act(alpha * A.B^T + bias) + res   (see s2svc_gemm in include/s2svc_hip.h)."""
+    d = _lib.GemmDesc()
+    d.A, d.B = A, B
+    d.C = out.data_ptr() + out_offset * out.element_size()
+    d.ldc = N if ldc is None else ldc
+    d.cbs0, d.cbs1 = cbs
+    d.c_dtype = dt(out)
+    d.bias = ptr(bias)
+    d.res = ptr(res)
+    d.ldr = (N if ldr is None else ldr)
+    d.rbs0, d.rbs1 = rbs
+    d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, nb0, nb1
+    d.act = ACT[act]
+    d.alpha = alpha
+    d.dtype = _DT[in_dtype]
+    d.accumulate = 1 if accumulate else 0
+    d.splitk = splitk
+    ws = None
+    if splitk > 1:
+        ws = torch.empty(splitk * nb0 * nb1 * M * N, dtype=torch.float32, device=out.device)
+        d.ws = ws.data_ptr()
+    else:
+        d.ws = None
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("gemm bias must be fp32")
+    if res is not None and res.dtype != out.dtype:
+        raise TypeError("gemm residual must have the output dtype")
+    _lib.check(_lib.lib().s2svc_gemm(ctypes.byref(d), stream()), "s2svc_gemm")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# norms / reductions
+# ----------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, res=None, p=0.0, seed=(None, 0), need_stats=True):
+    _need_cuda(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if res is not None else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_stats else None
+    _lib.check(_lib.lib().s2svc_layernorm_fwd(dt(x), rows, D, ptr(x), ptr(res), p, seed[0], seed[1], ptr(gamma), ptr(beta),
+                                              eps, ptr(y), ptr(s), ptr(mean), ptr(rstd), stream()), "layernorm_fwd")
+    return y, s, mean, rstd
+
+
+def layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=None, p=0.0, seed=(None, 0), want_dh=False):
+    D = s.shape[-1]
+    rows = s.numel() // D
+    ds = torch.empty_like(s)
+    dh = torch.empty_like(s) if want_dh else None
+    _lib.check(_lib.lib().s2svc_layernorm_bwd(dt(s), rows, D, ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma),
+                                              ptr(ds_extra), p, seed[0], seed[1], ptr(ds), ptr(dh), stream()),
+               "layernorm_bwd")
+    return ds, dh
+
+
+_WS_CHUNKS = 64
+
+
+def colreduce(mode, dy, x=None, mean=None, rstd=None, scale=1.0, want_dot=False, rows=None, D=None):
+    t = dy if dy is not None else x
+    D = t.shape[-1] if D is None else D
+    rows = t.numel() // D if rows is None else rows
+    out_sum = torch.empty(D, dtype=torch.float32, device=t.device)
+    out_dot = torch.empty(D, dtype=torch.float32, device=t.device) if want_dot else None
+    ws = torch.empty(_WS_CHUNKS * 2 * D, dtype=torch.float32, device=t.device)
+    _lib.check(_lib.lib().s2svc_colreduce(dt(t), rows, D, mode, ptr(dy), ptr(x), ptr(mean), ptr(rstd), scale, ptr(out_sum),
+                                          ptr(out_dot), 0, ptr(ws), _WS_CHUNKS, stream()), "colreduce")
+    return out_sum, out_dot
+
+
+def bn_finalize(mean, var, n, eps, momentum, run_mean=None, run_var=None, num_batches=None):
+    C = mean.numel()
+    rstd = torch.empty_like(mean)
+    _lib.check(_lib.lib().s2svc_bn_finalize(C, n, eps, momentum, ptr(mean), ptr(var), ptr(rstd), ptr(run_mean),
+                                            ptr(run_var), ptr(num_batches), stream()), "bn_finalize")
+    return rstd
+
+
+def rstd_from_var(var, eps):
+    rstd = torch.empty_like(var)
+    _lib.check(_lib.lib().s2svc_rstd_from_var(var.numel(), eps, ptr(var), ptr(rstd), stream()), "rstd_from_var")
+    return rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, act=None, p=0.0, seed=(None, 0), want_pre=False):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    pre = torch.empty_like(x) if want_pre else None
+    _lib.check(_lib.lib().s2svc_bn_apply(dt(x), rows, C, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], p,
+                                         seed[0], seed[1], ptr(y), ptr(pre), stream()), "bn_apply")
+    return y, pre
+
+
+def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats=True):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().s2svc_bn_bwd(dt(x), rows, C, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(sum_dy),
+                                       ptr(sum_dy_xhat), 1 if use_batch_stats else 0, ptr(dx), stream()), "bn_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------
+# attention probabilities
+# ----------------------------------------------------------------------------------------------
+def attn_softmax_fwd(scores, out_dtype, scale, klen=None, causal=False, bd=None, rel_mode=0, p=0.0, seed=(None, 0)):
+    B, H, T1, T2 = scores.shape
+    attn = torch.empty(scores.shape, dtype=out_dtype, device=scores.device)
+    pdrop = torch.empty_like(attn) if p > 0.0 else None
+    Lp = bd.shape[-1] if bd is not None else 0
+    _lib.check(_lib.lib().s2svc_attn_softmax_fwd(_DT[out_dtype], B, H, T1, T2, ptr(scores), ptr(bd), Lp, rel_mode, scale,
+                                                 ptr(klen), 1 if causal else 0, p, seed[0], seed[1], ptr(attn), ptr(pdrop),
+                                                 stream()), "attn_softmax_fwd")
+    return attn, pdrop
+
+
+def attn_softmax_bwd(attn, dp, scale, p=0.0, seed=(None, 0), Lp=0, rel_mode=0):
+    B, H, T1, T2 = attn.shape
+    dscores = torch.empty_like(attn)
+    dbd = torch.empty((B, H, T1, Lp), dtype=attn.dtype, device=attn.device) if Lp else None
+    _lib.check(_lib.lib().s2svc_attn_softmax_bwd(dt(attn), B, H, T1, T2, ptr(attn), ptr(dp), scale, p, seed[0], seed[1],
+                                                 ptr(dscores), ptr(dbd), Lp, rel_mode, stream()), "attn_softmax_bwd")
+    return dscores, dbd
+
+
+# ----------------------------------------------------------------------------------------------
+# elementwise
+# ----------------------------------------------------------------------------------------------
+def act_dropout_fwd(x, act=None, p=0.0, seed=(None, 0)):
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().s2svc_act_dropout_fwd(dt(x), x.numel(), ptr(x), ACT[act], p, seed[0], seed[1], ptr(y), stream()),
+               "act_dropout_fwd")
+    return y
+
+
+def act_dropout_bwd(dz, saved, act=None, p=0.0, seed=(None, 0)):
+    dx = torch.empty_like(dz)
+    _lib.check(_lib.lib().s2svc_act_dropout_bwd(dt(dz), dz.numel(), ptr(dz), ptr(saved), ACT[act], p, seed[0], seed[1],
+                                                ptr(dx), stream()), "act_dropout_bwd")
+    return dx
+
+
+def posenc_fwd(x, xscale, alpha, pe, p=0.0, seed=(None, 0)):
+    B, T, D = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().s2svc_posenc_fwd(dt(x), B, T, D, ptr(x), xscale, ptr(alpha), ptr(pe), p, seed[0], seed[1], ptr(y),
+                                           stream()), "posenc_fwd")
+    return y
+
+
+def posenc_bwd(dy, xscale, pe, p=0.0, seed=(None, 0), want_dalpha=False):
+    B, T, D = dy.shape
+    dx = torch.empty_like(dy)
+    dalpha = torch.empty((), dtype=torch.float32, device=dy.device) if want_dalpha else None
+    part = torch.empty(2048, dtype=torch.float32, device=dy.device) if want_dalpha else None
+    _lib.check(_lib.lib().s2svc_posenc_bwd(dt(dy), B, T, D, ptr(dy), xscale, ptr(pe), p, seed[0], seed[1], ptr(dx),
+                                           ptr(dalpha), ptr(part), stream()), "posenc_bwd")
+    return dx, dalpha
+
+
+def axpby(a, x, b=0.0, y=None, out=None):
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().s2svc_axpby(dt(x), x.numel(), a, ptr(x), b, ptr(y), ptr(out), stream()), "axpby")
+    return out
+
+
+def add_head_bias(q, u, v):
+    D = q.shape[-1]
+    qu, qv = torch.empty_like(q), torch.empty_like(q)
+    _lib.check(_lib.lib().s2svc_add_head_bias(dt(q), q.numel() // D, D, ptr(q), ptr(u), ptr(v), ptr(qu), ptr(qv), stream()),
+               "add_head_bias")
+    return qu, qv
+
+
+def glu_fwd(x):
+    C = x.shape[-1] // 2
+    y = torch.empty(x.shape[:-1] + (C,), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().s2svc_glu_fwd(dt(x), y.numel() // C, C, ptr(x), ptr(y), stream()), "glu_fwd")
+    return y
+
+
+def glu_bwd(x, dy):
+    C = x.shape[-1] // 2
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().s2svc_glu_bwd(dt(x), dy.numel() // C, C, ptr(x), ptr(dy), ptr(dx), stream()), "glu_bwd")
+    return dx
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.check(_lib.lib().s2svc_cast(dt(x), _DT[dtype], x.numel(), ptr(x), ptr(y), stream()), "cast")
+    return y
+
+
+def gather3(x, n, strides, off, out_dtype):
+    """out[i0,i1,i2] = x.flat[off + i0*s0 + i1*s1 + i2*s2] (contiguous result of shape n)."""
+    y = torch.empty(n, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().s2svc_gather3(dt(x), _DT[out_dtype], n[0], n[1], n[2], strides[0], strides[1], strides[2], off,
+                                        ptr(x), ptr(y), stream()), "gather3")
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# monotonic alignment search
+# ----------------------------------------------------------------------------------------------
+def mas(log_p_attn, text_lens_i32, feat_lens_i32):
+    B, Tf, Tx = log_p_attn.shape
+    dev = log_p_attn.device
+    path = torch.empty((B, Tf), dtype=torch.int32, device=dev)
+    ds = torch.empty((B, Tx), dtype=torch.float32, device=dev)
+    binmean = torch.empty((B,), dtype=torch.float32, device=dev)
+    nbytes = _lib.lib().s2svc_mas_ws_bytes(B, Tf, Tx)
+    ws = torch.empty(nbytes // 8 + 1, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().s2svc_mas(B, Tf, Tx, ptr(log_p_attn), ptr(text_lens_i32), ptr(feat_lens_i32), ptr(path), ptr(ds),
+                                    ptr(binmean), ptr(ws), stream()), "mas")
+    return ds, path, binmean
+
+
+def mas_binloss_bwd(path, feat_lens_i32, gout, dlogp):
+    B, Tf = path.shape
+    Tx = dlogp.shape[-1]
+    _lib.check(_lib.lib().s2svc_mas_binloss_bwd(B, Tf, Tx, ptr(path), ptr(feat_lens_i32), ptr(gout), ptr(dlogp), stream()),
+               "mas_binloss_bwd")
+    return dlogp

@@ -1,0 +1,431 @@
+"""Kernel-level parity sweep (runs on the GPU box): every launcher in seq2seq_vc_amd.ops.kernels is
+compared with a plain fp32 torch formulation of the same op.  Used two ways:
+  * `python tests/gpu_kernel_check.py` prints a PASS/FAIL table for all cases and never stops early
+    (one gpurun round trip shows every broken kernel);
+  * tests/test_gpu_kernels.py imports CASES and turns each into a `@pytest.mark.gpu` test.
+"""
+import math
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from seq2seq_vc_amd.ops import kernels as K  # noqa: E402
+
+DEV = "cuda"
+CASES = []
+
+
+def case(fn):
+    CASES.append(fn)
+    return fn
+
+
+def g(seed):
+    return torch.Generator(device="cpu").manual_seed(seed)
+
+
+def rnd(*shape, seed=0, dtype=torch.float32, scale=1.0):
+    return (torch.randn(*shape, generator=g(seed)) * scale).to(DEV).to(dtype)
+
+
+def tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (3e-2, 3e-2)
+
+
+def check(name, got, ref, dtype, rtol=None, atol=None):
+    r, a = tol(dtype)
+    rtol = r if rtol is None else rtol
+    atol = a if atol is None else atol
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    if got.shape != ref.shape:
+        return False, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = (err > bound) | torch.isnan(got)
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        return False, (f"{name}: {int(bad.sum())}/{bad.numel()} bad, max_err={err.max():.3e} first_bad={idx} "
+                       f"got={got[tuple(idx)]:.6f} ref={ref[tuple(idx)]:.6f}")
+    return True, f"{name}: ok max_err={err.max():.3e}"
+
+
+def both_dtypes(fn):
+    def run():
+        out = []
+        for dtype in (torch.float32, torch.bfloat16):
+            out += fn(dtype)
+        return out
+    run.__name__ = fn.__name__
+    return run
+
+
+# ------------------------------------------------------------------------------------------------
+@case
+@both_dtypes
+def gemm_linear(dtype):
+    res = []
+    for (M, N, Kd, seed) in [(100, 70, 80, 1), (2016, 384, 384, 2), (64, 4, 384, 3), (130, 320, 256, 4),
+                             (256, 1536, 384, 5), (37, 33, 7296, 6), (512, 512, 36, 7)]:
+        x, w, b = rnd(M, Kd, seed=seed, dtype=dtype), rnd(N, Kd, seed=seed + 10, dtype=dtype, scale=0.05), rnd(N, seed=seed + 20)
+        r = rnd(M, N, seed=seed + 30, dtype=dtype)
+        out = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm(K.operand(x, Kd), K.operand(w, Kd), M, N, Kd, out, in_dtype=dtype, bias=b, act="relu", res=r)
+        ref = torch.relu(x.float() @ w.float().t() + b) + r.float()
+        res.append(check(f"linear[{dtype}] {M}x{N}x{Kd}", out, ref, dtype))
+    return res
+
+
+@case
+@both_dtypes
+def gemm_dgrad_wgrad(dtype):
+    res = []
+    for (M, N, Kd, seed) in [(100, 70, 80, 1), (2016, 384, 384, 2), (64, 4, 384, 3), (4000, 256, 80, 4)]:
+        x, w = rnd(M, Kd, seed=seed, dtype=dtype), rnd(N, Kd, seed=seed + 10, dtype=dtype, scale=0.05)
+        dy = rnd(M, N, seed=seed + 40, dtype=dtype)
+        # dgrad: dX[M,K] = dY[M,N] . W[N,K] : A = dY (KC), B(n=k', red=n') = W[n',k'] -> RC with ld=K
+        dx = torch.empty(M, Kd, dtype=dtype, device=DEV)
+        K.gemm(K.operand(dy, N), K.operand(w, Kd, layout=K.RC), M, Kd, N, dx, in_dtype=dtype)
+        res.append(check(f"dgrad[{dtype}] {M}x{N}x{Kd}", dx, dy.float() @ w.float(), dtype))
+        # wgrad: dW[N,K] = dY^T X : A(n, m) = dY[m,n] RC ld=N ; B(k, m) = X[m,k] RC ld=K ; reduction M
+        for sk in (1, K.pick_splitk(N, Kd, M), 5):
+            dw = torch.empty(N, Kd, dtype=torch.float32, device=DEV)
+            K.gemm(K.operand(dy, N, layout=K.RC), K.operand(x, Kd, layout=K.RC), N, Kd, M, dw, in_dtype=dtype, splitk=sk)
+            res.append(check(f"wgrad[{dtype}] {M}x{N}x{Kd} splitk={sk}", dw, dy.float().t() @ x.float(), dtype,
+                             rtol=None if dtype == torch.float32 else 3e-2, atol=1e-4 * math.sqrt(M) if dtype == torch.float32 else 0.3))
+    return res
+
+
+@case
+@both_dtypes
+def gemm_batched_attention(dtype):
+    res = []
+    B, H, T1, T2, dk = 3, 4, 37, 45, 96
+    D = H * dk
+    q, k, v = rnd(B, T1, D, seed=1, dtype=dtype), rnd(B, T2, D, seed=2, dtype=dtype), rnd(B, T2, D, seed=3, dtype=dtype)
+    scores = torch.empty(B, H, T1, T2, dtype=torch.float32, device=DEV)
+    K.gemm(K.operand(q, D, bs0=T1 * D, bs1=dk), K.operand(k, D, bs0=T2 * D, bs1=dk), T1, T2, dk, scores, in_dtype=dtype,
+           nb0=B, nb1=H, cbs=(H * T1 * T2, T1 * T2))
+    qh = q.float().view(B, T1, H, dk).transpose(1, 2)
+    kh = k.float().view(B, T2, H, dk).transpose(1, 2)
+    vh = v.float().view(B, T2, H, dk).transpose(1, 2)
+    ref = qh @ kh.transpose(-1, -2)
+    res.append(check(f"QK^T[{dtype}]", scores, ref, dtype, atol=1e-4 if dtype == torch.float32 else 0.3))
+    p = torch.softmax(ref / math.sqrt(dk), -1).to(dtype)
+    ctx = torch.empty(B, T1, D, dtype=dtype, device=DEV)
+    # ctx[b, t1, h*dk + d] = sum_t2 p[b,h,t1,t2] v[b,t2,h*dk+d] : B(n=d, red=t2) = v -> RC ld=D
+    K.gemm(K.operand(p, T2, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(v, D, layout=K.RC, bs0=T2 * D, bs1=dk), T1, dk, T2, ctx,
+           in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T1 * D, dk))
+    refc = (p.float() @ vh).transpose(1, 2).reshape(B, T1, D)
+    res.append(check(f"PV[{dtype}]", ctx, refc, dtype))
+    return res
+
+
+@case
+@both_dtypes
+def gemm_conv1d(dtype):
+    res = []
+    for (B, T, Cin, Cout, ks, seed) in [(3, 50, 80, 256, 5, 1), (2, 33, 256, 80, 5, 2), (4, 64, 96, 96, 3, 3), (2, 40, 24, 40, 1, 4)]:
+        pad = (ks - 1) // 2
+        x = rnd(B, T, Cin, seed=seed, dtype=dtype)
+        w = rnd(Cout, Cin, ks, seed=seed + 1, dtype=torch.float32, scale=0.05)
+        b = rnd(Cout, seed=seed + 2)
+        wp = K.gather3(w, (Cout, ks, Cin), (Cin * ks, 1, ks), 0, dtype)          # (O, k, I)
+        y = torch.empty(B, T, Cout, dtype=dtype, device=DEV)
+        K.gemm(K.operand(x, Cin, mode=K.CONV1D, C=Cin, T=T, pad=pad), K.operand(wp, ks * Cin), B * T, Cout, ks * Cin, y,
+               in_dtype=dtype, bias=b)
+        xr = x.float().transpose(1, 2).requires_grad_(True)
+        wr = w.to(dtype).float().requires_grad_(True)
+        yr = F.conv1d(xr, wr, b, padding=pad)
+        res.append(check(f"conv1d fwd[{dtype}] {B}x{T}x{Cin}->{Cout} k{ks}", y, yr.transpose(1, 2), dtype))
+        dy = rnd(B, T, Cout, seed=seed + 3, dtype=dtype)
+        yr.backward(dy.float().transpose(1, 2))
+        # dgrad: conv of dY with flipped taps; Wd[c][j'][o] = W[o, c, k-1-j']
+        wd = K.gather3(w, (Cin, ks, Cout), (ks, -1, Cin * ks), ks - 1, dtype)
+        dx = torch.empty(B, T, Cin, dtype=dtype, device=DEV)
+        K.gemm(K.operand(dy, Cout, mode=K.CONV1D, C=Cout, T=T, pad=pad), K.operand(wd, ks * Cout), B * T, Cin, ks * Cout, dx,
+               in_dtype=dtype)
+        res.append(check(f"conv1d dgrad[{dtype}] k{ks}", dx, xr.grad.transpose(1, 2), dtype))
+        # wgrad: dWp[o, (j,c)] = sum_m dY[m,o] X[m+j-pad, c]
+        dwp = torch.empty(Cout, ks * Cin, dtype=torch.float32, device=DEV)
+        K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad), Cout,
+               ks * Cin, B * T, dwp, in_dtype=dtype, splitk=3)
+        dw = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
+        res.append(check(f"conv1d wgrad[{dtype}] k{ks}", dw, wr.grad, dtype, atol=1e-4 if dtype == torch.float32 else 0.3))
+    return res
+
+
+@case
+@both_dtypes
+def gemm_conv2d(dtype):
+    res = []
+    B, T1, F1, C, O = 2, 31, 19, 32, 48
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    x = rnd(B, T1, F1, C, seed=1, dtype=dtype)          # NHWC
+    w = rnd(O, C, 3, 3, seed=2, scale=0.05)
+    b = rnd(O, seed=3)
+    wp = K.gather3(w, (O, 9, C), (C * 9, 1, 9), 0, dtype)  # (O, tap, C)
+    y = torch.empty(B, T2, F2, O, dtype=dtype, device=DEV)
+    K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(wp, 9 * C), B * T2 * F2, O, 9 * C, y,
+           in_dtype=dtype, bias=b, act="relu")
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.to(dtype).float().requires_grad_(True)
+    yr = torch.relu(F.conv2d(xr, wr, b, stride=2))
+    res.append(check(f"conv2d fwd[{dtype}]", y, yr.permute(0, 2, 3, 1), dtype))
+    dy = rnd(B, T2, F2, O, seed=4, dtype=dtype)
+    dyr = dy.float() * (yr.permute(0, 2, 3, 1) > 0)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    dym = dyr.to(dtype).contiguous()
+    dwp = torch.empty(O, 9 * C, dtype=torch.float32, device=DEV)
+    K.gemm(K.operand(dym, O, layout=K.RC), K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O,
+           9 * C, B * T2 * F2, dwp, in_dtype=dtype, splitk=2)
+    dw = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32).view(O, C, 3, 3)
+    res.append(check(f"conv2d wgrad[{dtype}]", dw, wr.grad, dtype, atol=1e-4 if dtype == torch.float32 else 0.3))
+    return res
+
+
+@case
+@both_dtypes
+def layernorm(dtype):
+    res = []
+    for (rows, D, seed) in [(37, 384, 1), (2016, 384, 2), (100, 1536, 3), (9, 50, 4)]:
+        x = rnd(rows, D, seed=seed, dtype=dtype)
+        r = rnd(rows, D, seed=seed + 1, dtype=dtype)
+        gm, bt = 1 + 0.1 * rnd(D, seed=seed + 2), 0.1 * rnd(D, seed=seed + 3)
+        dy = rnd(rows, D, seed=seed + 4, dtype=dtype)
+        for use_res in (False, True):
+            xr = x.float().requires_grad_(True)
+            rr = r.float().requires_grad_(True)
+            s_ref = xr + rr if use_res else xr
+            s_ref_q = s_ref.to(dtype).float() if use_res else s_ref
+            y_ref = F.layer_norm(s_ref_q, (D,), gm, bt, 1e-12)
+            y, s, mean, rstd = K.layernorm_fwd(x, gm, bt, 1e-12, res=r if use_res else None)
+            res.append(check(f"ln fwd[{dtype}] {rows}x{D} res={use_res}", y, y_ref, dtype, atol=1e-4 if dtype == torch.float32 else 5e-2))
+            sin = (s if use_res else x)
+            # backward against autograd on the same (rounded) LN input
+            sq = sin.float().detach().requires_grad_(True)
+            gmr, btr = gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+            F.layer_norm(sq, (D,), gmr, btr, 1e-12).backward(dy.float())
+            extra = rnd(rows, D, seed=seed + 5, dtype=dtype) if use_res else None
+            ds, dh = K.layernorm_bwd(dy, sin, mean, rstd, gm, ds_extra=extra, want_dh=use_res)
+            ds_ref = sq.grad + (extra.float() if use_res else 0)
+            res.append(check(f"ln bwd[{dtype}] {rows}x{D} res={use_res}", ds, ds_ref, dtype, atol=1e-4 if dtype == torch.float32 else 5e-2))
+            if use_res:
+                res.append(check(f"ln bwd dh[{dtype}]", dh, ds_ref, dtype, atol=1e-4 if dtype == torch.float32 else 5e-2))
+            dbeta, dgamma = K.colreduce(1, dy, sin, mean, rstd, want_dot=True)
+            res.append(check(f"ln dgamma[{dtype}] {rows}x{D}", dgamma, gmr.grad, dtype, atol=2e-4 * math.sqrt(rows) if dtype == torch.float32 else 0.5))
+            res.append(check(f"ln dbeta[{dtype}] {rows}x{D}", dbeta, btr.grad, dtype, atol=2e-4 * math.sqrt(rows) if dtype == torch.float32 else 0.5))
+    return res
+
+
+@case
+@both_dtypes
+def batchnorm(dtype):
+    res = []
+    rows, C = 3 * 50, 40
+    x = rnd(rows, C, seed=1, dtype=dtype) * 2 + 0.5
+    gm, bt = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    dz = rnd(rows, C, seed=4, dtype=dtype)
+    mean, _ = K.colreduce(0, x, scale=1.0 / rows)
+    var, _ = K.colreduce(3, None, x=x, mean=mean, scale=1.0 / rows, rows=rows, D=C)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nb = torch.zeros((), dtype=torch.int64, device=DEV)
+    rstd = K.bn_finalize(mean, var, rows, 1e-5, 0.1, rm, rv, nb)
+    y, _ = K.bn_apply(x, mean, rstd, gm, bt, act="tanh")
+    xr = x.float().requires_grad_(True)
+    gmr, btr = gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    yr = torch.tanh(F.batch_norm(xr, rm2, rv2, gmr, btr, True, 0.1, 1e-5))
+    res.append(check(f"bn fwd[{dtype}]", y, yr, dtype, atol=1e-4 if dtype == torch.float32 else 5e-2))
+    res.append(check(f"bn running_mean[{dtype}]", rm, rm2, torch.float32, atol=1e-5))
+    res.append(check(f"bn running_var[{dtype}]", rv, rv2, torch.float32, atol=1e-4))
+    res.append(check(f"bn num_batches[{dtype}]", nb.float().view(1), torch.ones(1), torch.float32))
+    yr.backward(dz.float())
+    dyp = K.act_dropout_bwd(dz, y, act="tanh")
+    sdy, sdyx = K.colreduce(2, dyp, x, mean, rstd, want_dot=True)
+    dx = K.bn_bwd(dyp, x, mean, rstd, gm, sdy, sdyx)
+    a = 2e-4 if dtype == torch.float32 else 8e-2
+    res.append(check(f"bn bwd dx[{dtype}]", dx, xr.grad, dtype, atol=a))
+    res.append(check(f"bn dgamma[{dtype}]", sdyx, gmr.grad, dtype, atol=a * 10))
+    res.append(check(f"bn dbeta[{dtype}]", sdy, btr.grad, dtype, atol=a * 10))
+    return res
+
+
+def _rel_shift_new(x):
+    b, h, t, l = x.shape
+    zp = torch.zeros((b, h, t, 1), device=x.device, dtype=x.dtype)
+    xp = torch.cat([zp, x], dim=-1).view(b, h, l + 1, t)
+    return xp[:, :, 1:].view_as(x)[:, :, :, : l // 2 + 1]
+
+
+def _rel_shift_legacy(x):
+    b, h, t, l = x.shape
+    zp = torch.zeros((b, h, t, 1), device=x.device, dtype=x.dtype)
+    xp = torch.cat([zp, x], dim=-1).view(b, h, l + 1, t)
+    return xp[:, :, 1:].view_as(x)
+
+
+@case
+@both_dtypes
+def attn_softmax(dtype):
+    res = []
+    B, H, T1, T2 = 3, 2, 21, 29
+    sc = rnd(B, H, T1, T2, seed=1) * 3
+    klen = torch.tensor([29, 17, 5], dtype=torch.int32, device=DEV)
+    scale = 1 / math.sqrt(24)
+    for causal in (False, True):
+        T2c = T1 if causal else T2
+        s = sc[..., :T2c].contiguous()
+        kl = torch.clamp(klen, max=T2c)
+        sr = s.clone().requires_grad_(True)
+        mask = (torch.arange(T2c, device=DEV)[None, None, None, :] < kl[:, None, None, None])
+        if causal:
+            mask = mask & torch.tril(torch.ones(T1, T2c, dtype=torch.bool, device=DEV))[None, None]
+        z = (sr * scale).masked_fill(~mask, torch.finfo(torch.float32).min)
+        pr = torch.softmax(z, -1).masked_fill(~mask, 0.0)
+        attn, pdrop = K.attn_softmax_fwd(s, dtype, scale, klen=kl, causal=causal)
+        res.append(check(f"softmax fwd[{dtype}] causal={causal}", attn, pr, dtype, atol=1e-6 if dtype == torch.float32 else 1e-2))
+        dp = rnd(B, H, T1, T2c, seed=5)
+        pr.backward(dp)
+        dsc, _ = K.attn_softmax_bwd(attn, dp, scale)
+        res.append(check(f"softmax bwd[{dtype}] causal={causal}", dsc, sr.grad, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
+    # relative-position variants (T1 == T2)
+    T = 19
+    ac = rnd(B, H, T, T, seed=7) * 2
+    kl = torch.tensor([19, 11, 3], dtype=torch.int32, device=DEV)
+    mask = (torch.arange(T, device=DEV)[None, None, None, :] < kl[:, None, None, None]).expand(B, H, T, T)
+    for mode, Lp, shift in ((1, 2 * T - 1, _rel_shift_new), (2, T, _rel_shift_legacy)):
+        bd = rnd(B, H, T, Lp, seed=8 + mode) * 2
+        acr, bdr = ac.clone().requires_grad_(True), bd.clone().requires_grad_(True)
+        z = ((acr + shift(bdr)) * scale).masked_fill(~mask, torch.finfo(torch.float32).min)
+        pr = torch.softmax(z, -1).masked_fill(~mask, 0.0)
+        attn, _ = K.attn_softmax_fwd(ac, dtype, scale, klen=kl, bd=bd, rel_mode=mode)
+        res.append(check(f"softmax relpos{mode} fwd[{dtype}]", attn, pr, dtype, atol=1e-6 if dtype == torch.float32 else 1e-2))
+        dp = rnd(B, H, T, T, seed=20 + mode)
+        pr.backward(dp)
+        dsc, dbd = K.attn_softmax_bwd(attn, dp, scale, Lp=Lp, rel_mode=mode)
+        res.append(check(f"softmax relpos{mode} dac[{dtype}]", dsc, acr.grad, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
+        res.append(check(f"softmax relpos{mode} dbd[{dtype}]", dbd, bdr.grad, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
+    return res
+
+
+@case
+@both_dtypes
+def elementwise(dtype):
+    res = []
+    x = rnd(7, 33, 48, seed=1, dtype=dtype)
+    for act, f in (("relu", torch.relu), ("tanh", torch.tanh), ("swish", lambda t: t * torch.sigmoid(t)),
+                   ("gelu", F.gelu), ("sigmoid", torch.sigmoid)):
+        xr = x.float().clone().requires_grad_(True)
+        yr = f(xr)
+        y = K.act_dropout_fwd(x, act=act)
+        res.append(check(f"act {act} fwd[{dtype}]", y, yr, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
+        dz = rnd(7, 33, 48, seed=2, dtype=dtype)
+        yr.backward(dz.float())
+        saved = x if act in ("swish", "gelu") else y
+        dx = K.act_dropout_bwd(dz, saved, act=act)
+        res.append(check(f"act {act} bwd[{dtype}]", dx, xr.grad, dtype, atol=1e-5 if dtype == torch.float32 else 5e-2))
+    # dropout statistics + fwd/bwd mask consistency
+    big = torch.ones(1 << 20, dtype=dtype, device=DEV)
+    seed = K.new_seed(big.device)
+    for p in (0.1, 0.5):
+        y = K.act_dropout_fwd(big, p=p, seed=seed)
+        keep = (y != 0).float().mean().item()
+        ok = abs(keep - (1 - p)) < 5e-3
+        res.append((ok, f"dropout keep-rate[{dtype}] p={p}: {keep:.4f}"))
+        val = y[y != 0].float().mean().item()
+        res.append((abs(val - 1 / (1 - p)) < 2e-2, f"dropout scale[{dtype}] p={p}: {val:.4f}"))
+        dxm = K.act_dropout_bwd(big, y, p=p, seed=seed)
+        res.append(check(f"dropout fwd/bwd same mask[{dtype}] p={p}", dxm, y, dtype))
+    # positional encodings
+    B, T, D = 3, 17, 32
+    xx = rnd(B, T, D, seed=3, dtype=dtype)
+    pe = rnd(40, D, seed=4)
+    alpha = torch.tensor(0.7, device=DEV)
+    y = K.posenc_fwd(xx, 1.0, alpha, pe)
+    res.append(check(f"scaled posenc fwd[{dtype}]", y, xx.float() + 0.7 * pe[:T], dtype))
+    y = K.posenc_fwd(xx, math.sqrt(D), None, pe)
+    res.append(check(f"abs posenc fwd[{dtype}]", y, xx.float() * math.sqrt(D) + pe[:T], dtype, atol=1e-5 if dtype == torch.float32 else 0.2))
+    dy = rnd(B, T, D, seed=5, dtype=dtype)
+    dx, dalpha = K.posenc_bwd(dy, 1.0, pe, want_dalpha=True)
+    res.append(check(f"posenc bwd dx[{dtype}]", dx, dy.float(), dtype))
+    res.append(check(f"posenc bwd dalpha[{dtype}]", dalpha.view(1), (dy.float() * pe[:T]).sum().view(1), dtype, atol=1e-3 if dtype == torch.float32 else 0.5))
+    # glu
+    xg = rnd(50, 2 * 24, seed=6, dtype=dtype)
+    xr = xg.float().requires_grad_(True)
+    yr = F.glu(xr, dim=-1)
+    y = K.glu_fwd(xg)
+    res.append(check(f"glu fwd[{dtype}]", y, yr, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
+    dyg = rnd(50, 24, seed=7, dtype=dtype)
+    yr.backward(dyg.float())
+    res.append(check(f"glu bwd[{dtype}]", K.glu_bwd(xg, dyg), xr.grad, dtype, atol=1e-6 if dtype == torch.float32 else 3e-2))
+    # head bias, axpby, cast
+    q = rnd(10, 4 * 8, seed=8, dtype=dtype)
+    u, v = rnd(32, seed=9), rnd(32, seed=10)
+    qu, qv = K.add_head_bias(q, u, v)
+    res.append(check(f"add_head_bias u[{dtype}]", qu, q.float() + u, dtype))
+    res.append(check(f"add_head_bias v[{dtype}]", qv, q.float() + v, dtype))
+    res.append(check(f"axpby[{dtype}]", K.axpby(0.5, q, 2.0, q), 2.5 * q.float(), dtype))
+    f32 = rnd(1000, seed=11)
+    res.append(check("cast f32->bf16", K.cast(f32, torch.bfloat16), f32.to(torch.bfloat16), torch.float32, atol=0, rtol=0))
+    return res
+
+
+@case
+def mas_kernel():
+    from oracle import mas as omas
+    res = []
+    rng = np.random.default_rng(0)
+    for (B, Tf, Tx, seed) in [(2, 6, 3, 7), (4, 40, 12, 1), (16, 256, 64, 2), (3, 70, 100, 3), (2, 300, 130, 4)]:
+        gen = torch.Generator().manual_seed(seed)
+        lp = torch.log_softmax(torch.randn(B, Tf, Tx, generator=gen), dim=-1)
+        tl = torch.randint(max(1, Tx // 2), Tx + 1, (B,), generator=gen)
+        fl = torch.randint(max(1, Tf // 2), Tf + 1, (B,), generator=gen)
+        tl[0], fl[0] = Tx, Tf
+        if (B, Tf, Tx) == (2, 6, 3):
+            tl, fl = torch.tensor([3, 2]), torch.tensor([6, 4])
+        ds_ref, bl_ref, paths, margin = omas.viterbi_decode(lp.numpy(), tl.numpy(), fl.numpy())
+        ds, path, binmean = K.mas(lp.to(DEV), tl.to(DEV).int(), fl.to(DEV).int())
+        ok = torch.equal(ds.cpu(), torch.from_numpy(ds_ref))
+        res.append((ok, f"mas ds B{B} Tf{Tf} Tx{Tx} bit-exact={ok} (min margin {margin:.2e})"))
+        okp = all(np.array_equal(path[b, : int(fl[b])].cpu().numpy(), paths[b]) for b in range(B))
+        res.append((okp, f"mas path B{B} Tf{Tf} Tx{Tx} bit-exact={okp}"))
+        bl = -(binmean.sum() / B).item()
+        res.append((abs(bl - bl_ref) <= 1e-5 * max(1, abs(bl_ref)), f"mas bin_loss {bl:.6f} vs {bl_ref:.6f}"))
+    # KAT2: all ties
+    lp = torch.full((1, 6, 3), math.log(1 / 3))
+    ds, path, _ = K.mas(lp.to(DEV), torch.tensor([3], dtype=torch.int32, device=DEV), torch.tensor([6], dtype=torch.int32, device=DEV))
+    ok = path[0].cpu().tolist() == [0, 0, 0, 0, 1, 2]
+    res.append((ok, f"mas KAT2 all-ties path={path[0].cpu().tolist()}"))
+    # KAT3: T_inp > T_mel
+    lp3 = torch.log_softmax(torch.from_numpy(np.random.default_rng(0).standard_normal((3, 5)).astype(np.float32)), -1)[None]
+    ds, path, _ = K.mas(lp3.to(DEV), torch.tensor([5], dtype=torch.int32, device=DEV), torch.tensor([3], dtype=torch.int32, device=DEV))
+    ok = path[0].cpu().tolist() == [2, 3, 4] and ds[0].cpu().tolist() == [0, 0, 1, 1, 1]
+    res.append((ok, f"mas KAT3 path={path[0].cpu().tolist()} ds={ds[0].cpu().tolist()}"))
+    return res
+
+
+def main():
+    torch.manual_seed(0)
+    nfail = 0
+    for fn in CASES:
+        try:
+            results = fn()
+        except Exception:
+            results = [(False, f"{fn.__name__}: EXCEPTION\n{traceback.format_exc()}")]
+        for ok, msg in results:
+            print(("PASS " if ok else "FAIL ") + msg)
+            nfail += 0 if ok else 1
+        torch.cuda.synchronize()
+    print(f"== {nfail} failures")
+    return nfail
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main() else 0)
