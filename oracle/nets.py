@@ -102,8 +102,12 @@ def rel_posenc(x, rt, drop_p):  # positional_encoding.py:293-309 -> (x*sqrt(d), 
     return rt.dropout(x * math.sqrt(x.shape[2]), drop_p), rt.dropout(pe, drop_p)
 
 
-def legacy_rel_posenc(x, rt, drop_p):  # positional_encoding.py:220-235 (reversed table, (1,T,d))
-    pe = sin_table(x.shape[1], x.shape[2], reverse=True)[None]
+def legacy_rel_posenc(x, rt, drop_p, max_len=5000):
+    """positional_encoding.py:198-235.  The reference builds the REVERSED table once for max_len=5000
+    (positions 4999..0) and slices its first T rows, so the embedding handed to the attention is for
+    positions 4999, 4998, ... -- restated as is."""
+    n = max(max_len, x.shape[1])
+    pe = sin_table(n, x.shape[2], reverse=True)[: x.shape[1]][None]
     return rt.dropout(x * math.sqrt(x.shape[2]), drop_p), rt.dropout(pe, drop_p)
 
 
@@ -306,7 +310,7 @@ def transformer_encoder(p, xs, mask, c, rt, embed):
         x, mask = conv2d_subsample(p.sub("embed"), xs, mask)
         x = scaled_posenc(p.sub("embed.out.1"), x, rt, pdp)
     else:  # Embedding (padding_idx 0) + scaled pos-enc: models/transformer_tts.py:63-77
-        x = F.embedding(xs, p["embed.0.0.weight"], padding_idx=0)
+        x = F.embedding(xs, p["embed.0.weight"], padding_idx=0)
         x = scaled_posenc(p.sub("embed.1"), x, rt, pdp)
     pre = c.get("encoder_normalize_before", True)
     for i in range(n_layers(p, "encoders")):

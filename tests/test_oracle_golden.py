@@ -1,0 +1,146 @@
+"""CPU: pin the oracle (oracle/*.py, oracle/mas.c) against golden vectors produced by the imported
+reference (tools/gen_golden.py).  No GPU, no /root/reference needed at run time."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mas as omas
+from oracle import models as OM
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = json.loads(bytes(z["__cfg__"]).decode())
+    return cfg, z
+
+
+def sd_of(z):
+    return {k[3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("sd.")}
+
+
+def model_cfg(cfg):
+    return {k: v for k, v in cfg.items() if not k.startswith("__")}
+
+
+def close(a, b, tol=2e-5):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(np.asarray(b)).double()
+    same_inf = torch.isinf(a) & torch.isinf(b) & (a == b)
+    err = torch.where(same_inf, torch.zeros_like(a), (a - b).abs()).max().item()
+    assert err <= tol, f"max err {err:.3e} > {tol}"
+
+
+def test_mas_known_answers():
+    _, z = load("mas_kats")
+    for k in [k for k in z.files if k.endswith(".logp") and z[k].ndim == 2]:
+        path, margin = omas.monotonic_alignment_search(z[k])
+        assert np.array_equal(path, z[k.replace(".logp", ".path")]), k
+    ds, bl, _, _ = omas.viterbi_decode(z["kat4.logp"], z["kat4.text_lens"], z["kat4.feat_lens"])
+    assert np.array_equal(ds, z["kat4.ds"])
+    assert abs(bl - float(z["kat4.bin_loss"])) < 1e-6
+    # survey KATs, literal expectations
+    assert z["kat1.path"].tolist() == [0, 0, 1, 1, 2, 2]
+    assert z["kat2.path"].tolist() == [0, 0, 0, 0, 1, 2]
+    assert z["kat3.path"].tolist() == [2, 3, 4]
+
+
+def test_mas_c_restatement_matches_numpy():
+    cmas = pytest.importorskip("oracle.cmas")
+    if not cmas.available():
+        pytest.skip("oracle/libmas_oracle.so not built")
+    _, z = load("mas_kats")
+    for k in [k for k in z.files if k.endswith(".logp") and z[k].ndim == 2]:
+        assert np.array_equal(cmas.mas(z[k]), z[k.replace(".logp", ".path")]), k
+
+
+def test_loss_tables():
+    _, z = load("loss_tables")
+    att = torch.ones(1, 1, 5, 5)
+    il, ol = torch.tensor([5]), torch.tensor([5])
+    # mean of W over the valid region equals the oracle loss on an all-ones attention map
+    close(OM.guided_attention_loss(att, il, ol), z["ga.mask_5_5"].mean(), 1e-6)
+    att = torch.ones(1, 1, 6, 3)
+    close(OM.guided_attention_loss(att, torch.tensor([3]), torch.tensor([6])), z["ga.mask_3_6"].mean(), 1e-6)
+    # docstring table of the reference (losses/guided_attention_loss.py:71-90)
+    assert abs(float(z["ga.mask_5_5"][0, 1]) - 0.1175) < 1e-4 and abs(float(z["ga.mask_3_6"][5, 0]) - 0.8858) < 1e-4
+    close(OM.betabinom_logprior(7, 4), z["fs.prior_7_4"][0, :7, :4], 1e-6)
+    close(OM.betabinom_logprior(5, 3), z["fs.prior_7_4"][1, :5, :3], 1e-6)
+
+
+@pytest.mark.parametrize("name", ["vtn_tiny_train", "vtn_tiny_eval", "vtn_conformer_tiny_train"])
+def test_vtn_forward_and_grads(name):
+    cfg, z = load(name)
+    sd = sd_of(z)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    sd.update(params)
+    t = lambda k: torch.from_numpy(z[k])
+    o = OM.vtn_forward(sd, model_cfg(cfg), t("in.xs"), t("in.ilens"), t("in.ys"), t("in.labels"), t("in.olens"),
+                       training=cfg["__train__"])
+    close(o[0], z["out.after"]); close(o[1], z["out.before"]); close(o[2], z["out.logits"])
+    close(o[3], z["out.ys"], 0); close(o[4], z["out.labels"], 0)
+    assert torch.equal(o[5], t("out.olens")) and torch.equal(o[6][1], t("out.ilens_ds")) and torch.equal(o[6][2], t("out.olens_in"))
+    for i, a in enumerate(o[6][0]):
+        close(a, z[f"out.att_ws.{i}"], 1e-6)
+    l1, bce = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+    close(l1, z["loss.l1"], 1e-6); close(bce, z["loss.bce"], 1e-6)
+    close(OM.guided_attention_loss(o[6][0][0], o[6][1], o[6][2]), z["loss.guided_attn"], 1e-6)
+    (l1 + bce).backward()
+    for k in [k for k in z.files if k.startswith("grad.")]:
+        close(params[k[5:]].grad, z[k], 5e-5)
+    for k in [k for k in z.files if k.startswith("sd_after.")]:
+        close(sd[k[9:]].detach(), z[k], 1e-5)
+
+
+def test_vtn_inference():
+    cfg, z = load("vtn_tiny_inference")
+    with torch.no_grad():
+        outs, probs, att = OM.vtn_inference(sd_of(z), model_cfg(cfg), torch.from_numpy(z["in.x"]), **cfg["__inference__"])
+    close(outs, z["out.outs"], 1e-5); close(probs, z["out.probs"], 1e-6); close(att, z["out.att_ws"], 1e-6)
+
+
+def test_tts_forward_and_grads():
+    cfg, z = load("tts_tiny_train")
+    sd = sd_of(z)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    sd.update(params)
+    t = lambda k: torch.from_numpy(z[k])
+    o = OM.tts_forward(sd, model_cfg(cfg), t("in.xs"), t("in.ilens"), t("in.ys"), t("in.labels"), t("in.olens"))
+    close(o[0], z["out.after"]); close(o[1], z["out.before"]); close(o[2], z["out.logits"])
+    l1, bce = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+    close(l1, z["loss.l1"], 1e-6); close(bce, z["loss.bce"], 1e-6)
+    (l1 + bce).backward()
+    for k in [k for k in z.files if k.startswith("grad.")]:
+        close(params[k[5:]].grad, z[k], 5e-5)
+
+
+@pytest.mark.parametrize("name", ["aasvc_tiny_train", "aasvc_det_tiny_train"])
+def test_aasvc_forward_and_grads(name):
+    cfg, z = load(name)
+    sd = sd_of(z)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    sd.update(params)
+    t = lambda k: torch.from_numpy(z[k])
+    noise = t("in.sdp_noise") if "in.sdp_noise" in z.files else None
+    r = OM.aasvc_forward(sd, model_cfg(cfg), t("in.xs"), t("in.ilens"), t("in.ys"), t("in.olens"), dp_inputs=t("in.xs"), noise=noise)
+    close(r["log_p_attn"], z["out.log_p_attn"]); close(r["after_outs"], z["out.after"]); close(r["before_outs"], z["out.before"])
+    assert torch.equal(r["ds"], t("out.ds")), "durations must be bit-exact"
+    for b, pth in enumerate(r["mas_paths"]):
+        assert np.array_equal(pth, z[f"out.mas_path.{b}"]), "alignment indices must be bit-exact"
+    close(r["bin_loss"], z["out.bin_loss"], 1e-6)
+    l1 = OM.l1_loss(r["after_outs"], r["before_outs"], r["ys"], r["olens"])
+    fs = OM.forward_sum_loss(r["log_p_attn"], r["ilens"], r["olens_reduced"])
+    close(l1, z["loss.l1"], 1e-6); close(fs, z["loss.forward_sum"], 1e-5)
+    total = l1 + cfg["__lambda_align__"] * (fs + r["bin_loss"])
+    if "dur_nll" in r:
+        close(r["dur_nll"], z["out.dur_nll"], 1e-4)
+        total = total + r["dur_nll"].sum()
+    else:
+        close(r["d_outs"], z["out.d_outs"])
+    close(total, z["loss.total"], 1e-4)
+    total.backward()
+    for k in [k for k in z.files if k.startswith("grad.")]:
+        close(params[k[5:]].grad, z[k], 2e-4)
