@@ -71,8 +71,8 @@ class GemmDesc(ctypes.Structure):
 
 _SIGS = {
     "s2svc_gemm": [ctypes.POINTER(GemmDesc), c_vp],
-    "s2svc_layernorm_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "s2svc_layernorm_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
+    "s2svc_layernorm_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_layernorm_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_colreduce": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "s2svc_bn_finalize": [c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_rstd_from_var": [c_i32, c_f32, c_vp, c_vp, c_vp],
@@ -80,7 +80,7 @@ _SIGS = {
     "s2svc_bn_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
     "s2svc_attn_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_f32,
                                c_vp, c_u64, c_vp, c_vp, c_vp],
-    "s2svc_attn_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32,
+    "s2svc_attn_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32,
                                c_i32, c_vp],
     "s2svc_act_dropout_fwd": [c_i32, c_i64, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp],
     "s2svc_act_dropout_bwd": [c_i32, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp],
@@ -94,6 +94,15 @@ _SIGS = {
     "s2svc_gather3": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     "s2svc_mas": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_mas_binloss_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_seq_loss_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp],
+    "s2svc_seq_loss_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
+                           c_vp, c_vp, c_vp],
+    "s2svc_guided_attn_loss_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp],
+    "s2svc_guided_attn_loss_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_adam_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp],
+    "s2svc_col2im_s2": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "s2svc_interp_nearest": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "s2svc_interp_nearest_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
 }
 _RET64 = {"s2svc_mas_ws_bytes": [c_i32, c_i32, c_i32]}
 

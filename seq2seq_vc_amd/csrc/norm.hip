@@ -14,7 +14,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const T* __restrict__ x, const T* __restrict__ res,
-                                                     float p, const uint64_t* seed_base, uint64_t seed_off, const float* __restrict__ gamma,
+                                                     float p, float hscale, const uint64_t* seed_base, uint64_t seed_off, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y,
                                                      T* __restrict__ s_out, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out) {
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const T* _
     float v = ldf(x + base + c);
     if (res) {
       if (p > 0.f) v *= dropout_scale(seed, (uint64_t)(base + c), p, inv_keep);
+      v *= hscale;
       v += ldf(res + base + c);
       stf(s_out + base + c, v);
       v = ldf(s_out + base + c);  // statistics on the stored (rounded) value
@@ -61,7 +62,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* __restrict__ dy, const T* __restrict__ s,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ ds_extra,
-                                                     float p, const uint64_t* seed_base, uint64_t seed_off, T* __restrict__ ds, T* __restrict__ dh) {
+                                                     float p, float hscale, const uint64_t* seed_base, uint64_t seed_off, T* __restrict__ ds, T* __restrict__ dh) {
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
     stf(ds + base + c, v);
     if (dh) {
       float m = p > 0.f ? dropout_scale(seed, (uint64_t)(base + c), p, inv_keep) : 1.f;
-      stf(dh + base + c, v * m);
+      stf(dh + base + c, v * m * hscale);
     }
   }
 }
@@ -231,7 +232,7 @@ inline int ew_blocks(int64_t total) {
 
 }  // namespace
 
-extern "C" int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, const void* res, float drop_p,
+extern "C" int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, const void* res, float drop_p, float hscale,
                                    const uint64_t* seed_base, uint64_t seed_off, const float* gamma, const float* beta, float eps, void* y,
                                    void* s_out, float* mean, float* rstd, void* stream) {
   S2S_REQUIRE(rows >= 0 && D > 0, "layernorm_fwd: bad shape");
@@ -240,17 +241,17 @@ extern "C" int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, co
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4), block(256);
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, rows, D, (const float*)x, (const float*)res, drop_p, seed_base, seed_off,
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, rows, D, (const float*)x, (const float*)res, drop_p, hscale, seed_base, seed_off,
                        gamma, beta, eps, (float*)y, (float*)s_out, mean, rstd);
   else
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, st, rows, D, (const bf16_t*)x, (const bf16_t*)res, drop_p,
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, st, rows, D, (const bf16_t*)x, (const bf16_t*)res, drop_p, hscale,
                        seed_base, seed_off, gamma, beta, eps, (bf16_t*)y, (bf16_t*)s_out, mean, rstd);
   S2S_CHECK_LAUNCH("ln_fwd_kernel");
   return 0;
 }
 
 extern "C" int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, const void* s, const float* mean,
-                                   const float* rstd, const float* gamma, const void* ds_extra, float drop_p,
+                                   const float* rstd, const float* gamma, const void* ds_extra, float drop_p, float hscale,
                                    const uint64_t* seed_base, uint64_t seed_off, void* ds, void* dh, void* stream) {
   S2S_REQUIRE(rows >= 0 && D > 0, "layernorm_bwd: bad shape");
   if (rows == 0) return 0;
@@ -258,10 +259,10 @@ extern "C" int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, c
   dim3 grid((rows + 3) / 4), block(256);
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, st, rows, D, (const float*)dy, (const float*)s, mean, rstd,
-                       gamma, (const float*)ds_extra, drop_p, seed_base, seed_off, (float*)ds, (float*)dh);
+                       gamma, (const float*)ds_extra, drop_p, hscale, seed_base, seed_off, (float*)ds, (float*)dh);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean,
-                       rstd, gamma, (const bf16_t*)ds_extra, drop_p, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
+                       rstd, gamma, (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
   S2S_CHECK_LAUNCH("ln_bwd_kernel");
   return 0;
 }

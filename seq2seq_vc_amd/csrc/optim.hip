@@ -1,0 +1,97 @@
+// Flat-buffer optimiser step: global grad-norm (deterministic two-stage) -> clip coefficient ->
+// WarmupLR -> Adam, plus the bf16 shadow copy of the updated weights, in three launches over ONE
+// contiguous fp32 parameter buffer (all parameters of the model are views into it).
+//
+// reference: trainers/ar_vc.py:99-107 (zero_grad / backward / clip_grad_norm_ / optimizer.step /
+// scheduler.step), torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay),
+// schedulers/warmup_lr.py:54-61.  The step counter and the learning rate live in device memory so the
+// whole training step can be replayed from a hipGraph.
+//
+// HBM traffic per step: 16 B/param read (p, g, m, v) + 12 B/param written (p, m, v) [+2 B bf16 shadow].
+#include "common.h"
+#include "../../include/s2svc_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(int64_t n, const float* __restrict__ g, double* __restrict__ partial) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (double)g[i];
+    acc += v * v;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// state[0] = step (as float, incremented here), state[1] = lr used this step, state[2] = grad norm,
+// state[3] = clip coefficient
+__global__ void adam_prepare_kernel(int nblk, const double* __restrict__ partial, float max_norm, float base_lr,
+                                    float warmup_steps, float* __restrict__ state) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 64) acc += partial[i];
+  acc = wave_sum_d(acc);
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(acc);
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+      coef = max_norm / (norm + 1e-6f);
+      if (coef > 1.f) coef = 1.f;
+    }
+    const float step = state[0] + 1.f;
+    float lr = base_lr;
+    if (warmup_steps > 0.f) {
+      // lr_k used at optimiser step k (1-based) is the scheduler's value after k-1 scheduler.step()
+      // calls: base * w^0.5 * min(k^-0.5, k * w^-1.5)
+      const float a = rsqrtf(step), b = step * powf(warmup_steps, -1.5f);
+      lr = base_lr * sqrtf(warmup_steps) * (a < b ? a : b);
+    }
+    state[0] = step;
+    state[1] = lr;
+    state[2] = norm;
+    state[3] = coef;
+  }
+}
+
+__global__ void adam_update_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                   float* __restrict__ v, bf16_t* __restrict__ shadow, float beta1, float beta2, float eps,
+                                   const float* __restrict__ state) {
+  const float step = state[0], lr = state[1], coef = state[3];
+  const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    const float pi = p[i] - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi;
+    if (shadow) shadow[i] = f2bf(pi);
+  }
+}
+
+}  // namespace
+
+// partial: >= 1024 doubles.  state: 4 floats in device memory (see adam_prepare_kernel).
+extern "C" int s2svc_adam_step(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                               void* bf16_shadow, float beta1, float beta2, float eps, float max_norm, float base_lr,
+                               float warmup_steps, double* partial, float* state, void* stream) {
+  S2S_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && partial && state, "adam_step: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  int nb = (int)((n + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, n, grads, partial);
+  S2S_CHECK_LAUNCH("sumsq_kernel");
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, st, nb, partial, max_norm, base_lr, warmup_steps, state);
+  S2S_CHECK_LAUNCH("adam_prepare_kernel");
+  int ub = (int)((n + 255) / 256);
+  if (ub > 2048) ub = 2048;
+  hipLaunchKernelGGL(adam_update_kernel, dim3(ub), dim3(256), 0, st, n, params, grads, exp_avg, exp_avg_sq,
+                     (bf16_t*)bf16_shadow, beta1, beta2, eps, state);
+  S2S_CHECK_LAUNCH("adam_update_kernel");
+  return 0;
+}

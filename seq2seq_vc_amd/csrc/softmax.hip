@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
 // dS = P * (dP*mask - sum_j P*dP*mask) ; dscores = dS*scale ; scatter of the same value into dbd
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, int T2, const T* __restrict__ attn,
-                                                          const float* __restrict__ dp, float scale, float p, const uint64_t* seed_base, uint64_t seed_off,
+                                                          const float* __restrict__ dp, const T* __restrict__ dattn, float scale, float p, const uint64_t* seed_base, uint64_t seed_off,
                                                           T* __restrict__ dscores, T* __restrict__ dbd, int Lp,
                                                           int rel_mode) {
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, 
   for (int j = lane; j < T2; j += 64) {
     const int64_t o = row * T2 + j;
     float m = p > 0.f ? dropout_scale(seed, (uint64_t)o, p, inv_keep) : 1.f;
-    dot += ldf(attn + o) * dp[o] * m;
+    dot += ldf(attn + o) * (dp[o] * m + (dattn ? ldf(dattn + o) : 0.f));
   }
   dot = wave_sum(dot);
   T* dbdb = dbd ? dbd + bh * (int64_t)T1 * Lp : nullptr;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, 
     const int64_t o = row * T2 + j;
     float m = p > 0.f ? dropout_scale(seed, (uint64_t)o, p, inv_keep) : 1.f;
     float pr = ldf(attn + o);
-    float ds = pr * (dp[o] * m - dot) * scale;
+    float ds = pr * (dp[o] * m + (dattn ? ldf(dattn + o) : 0.f) - dot) * scale;
     stf(dscores + o, ds);
     if (dbdb) {
       int si, sc;
@@ -141,7 +141,7 @@ extern "C" int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, c
   return 0;
 }
 
-extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, const void* attn, const float* dp,
+extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, const void* attn, const float* dp, const void* dattn,
                                       float scale, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dscores, void* dbd, int Lp,
                                       int rel_mode, void* stream) {
   S2S_REQUIRE(B >= 0 && H > 0 && T1 >= 0 && T2 > 0, "attn_softmax_bwd: bad shape");
@@ -157,10 +157,10 @@ extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, c
   }
   dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, (const float*)attn, dp, scale, drop_p,
+    hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, (const float*)attn, dp, (const float*)dattn, scale, drop_p,
                        seed_base, seed_off, (float*)dscores, (float*)dbd, Lp, rel_mode);
   else
-    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, (const bf16_t*)attn, dp, scale,
+    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, (const bf16_t*)attn, dp, (const bf16_t*)dattn, scale,
                        drop_p, seed_base, seed_off, (bf16_t*)dscores, (bf16_t*)dbd, Lp, rel_mode);
   S2S_CHECK_LAUNCH("softmax_bwd_kernel");
   return 0;

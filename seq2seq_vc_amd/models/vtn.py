@@ -1,0 +1,184 @@
+"""VTN -- Voice Transformer Network (mel -> mel, autoregressive), MI355X-native.
+
+Drop-in for `seq2seq_vc.models.VTN` (reference models/vtn.py): same constructor keywords
+(:15-62), same `forward` inputs / 7-tuple outputs (:207-300), same `inference` (:302-394), same
+state_dict keys.  All arithmetic runs in the HIP kernels behind seq2seq_vc_amd.ops.functional.
+"""
+import logging
+
+import torch
+from torch import nn
+
+from .. import modules as Mo
+from ..ops import functional as Fn
+from ..ops import kernels as K
+
+
+class _ARSeq2Seq(nn.Module):
+    """Shared decoder-side logic of VTN and TransformerTTS (vtn.py:227-300 == transformer_tts.py:160-229)."""
+
+    def _build_decoder_side(self, idim, odim, dprenet_layers, dprenet_units, dprenet_dropout_rate, adim, aheads, dlayers,
+                            dunits, decoder_normalize_before, decoder_concat_after, decoder_reduction_factor, postnet_layers,
+                            postnet_chans, postnet_filts, use_batch_norm):
+        decoder_input_layer = nn.Sequential(
+            Mo.Prenet(idim=odim, n_layers=dprenet_layers, n_units=dprenet_units, dropout_rate=dprenet_dropout_rate),
+            nn.Linear(dprenet_units, adim))
+        self.decoder = Mo.Decoder(odim=-1, attention_dim=adim, attention_heads=aheads, linear_units=dunits, num_blocks=dlayers,
+                                  input_layer=decoder_input_layer, use_output_layer=False,
+                                  pos_enc_class=Mo.ScaledPositionalEncoding, normalize_before=decoder_normalize_before,
+                                  concat_after=decoder_concat_after)
+        self.feat_out = nn.Linear(adim, odim * decoder_reduction_factor)
+        self.prob_out = nn.Linear(adim, decoder_reduction_factor)
+        self.postnet = Mo.Postnet(idim=idim, odim=odim, n_layers=postnet_layers, n_chans=postnet_chans, n_filts=postnet_filts,
+                                  use_batch_norm=use_batch_norm)
+
+    def _teacher_forced(self, hs, hs_lens, ys, labels, olens):
+        r, odim = self.decoder_reduction_factor, self.odim
+        dev = ys.device
+        olens_h = Mo.Lens.of(olens, dev)
+        if r > 1:
+            ys_in = ys[:, r - 1::r]
+            olens_in_h = olens_h.map(lambda v: v // r)
+        else:
+            ys_in, olens_in_h = ys, olens_h
+        ys_in = torch.cat([ys_in.new_zeros((ys_in.shape[0], 1, ys_in.shape[2])), ys_in[:, :-1]], dim=1)
+        zs, _ = self.decoder(Fn.to_compute(ys_in), olens_in_h, hs, hs_lens, causal=True)
+        before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, odim)
+        logits = Fn.linear(zs, self.prob_out.weight, self.prob_out.bias).view(zs.size(0), -1)
+        after = Fn.add_dropout(before, self.postnet(before), 0.0) if self.postnet is not None else before
+        olens_out = olens
+        if r > 1:
+            if min(olens_h.host) < r:
+                raise AssertionError("Output length must be greater than or equal to reduction factor.")
+            new = [v - v % r for v in olens_h.host]
+            olens_out = olens.new_tensor(new) if isinstance(olens, torch.Tensor) else torch.tensor(new)
+            mx = max(new)
+            ys, labels = ys[:, :mx], labels[:, :mx]
+            idx = torch.tensor(new, device=labels.device).sub_(1).unsqueeze(1)
+            labels = torch.scatter(labels, 1, idx, 1.0)
+        olens_in = olens.new_tensor(olens_in_h.host) if isinstance(olens, torch.Tensor) else torch.tensor(olens_in_h.host)
+        return after, before, logits, ys, labels, olens_out, olens_in
+
+    def _decode_loop(self, hs, threshold, minlenratio, maxlenratio):
+        """Step-wise generation with the reference's semantics (every step re-evaluates the decoder over
+        the whole prefix; the per-layer cache of the reference changes cost, not values)."""
+        r, odim = self.decoder_reduction_factor, self.odim
+        maxlen = int(hs.size(1) * maxlenratio / r)
+        minlen = int(hs.size(1) * minlenratio / r)
+        ys = torch.zeros((1, 1, odim), dtype=hs.dtype, device=hs.device)
+        outs, probs, atts = [], [], []
+        idx = 0
+        while True:
+            idx += 1
+            zs, _ = self.decoder(ys, None, hs, None, causal=True)
+            z = zs[:, -1]
+            outs.append(Fn.linear(z, self.feat_out.weight, self.feat_out.bias).view(r, odim))
+            probs.append(torch.sigmoid(Fn.linear(z, self.prob_out.weight, self.prob_out.bias).float())[0])
+            ys = torch.cat((ys, outs[-1][-1].view(1, 1, odim)), dim=1)
+            atts.append(torch.stack([d.src_attn.attn[0, :, -1] for d in self.decoder.decoders]))  # (layers, H, T)
+            if int((probs[-1] >= threshold).sum()) > 0 or idx >= maxlen:
+                if idx < minlen:
+                    continue
+                o = torch.cat(outs, dim=0).unsqueeze(0)             # (1, L, odim) channel-last
+                if self.postnet is not None:
+                    o = Fn.add_dropout(o, self.postnet(o.contiguous()), 0.0)
+                return o.squeeze(0).float(), torch.cat(probs, dim=0), torch.stack(atts, dim=2).float()
+
+
+class VTN(_ARSeq2Seq):
+    def __init__(self, idim, odim, dprenet_layers=2, dprenet_units=256, adim=384, aheads=4, encoder_type="transformer",
+                 decoder_type="transformer", elayers=6, eunits=1536, dlayers=6, dunits=1536, postnet_layers=5,
+                 postnet_filts=5, postnet_chans=256, positionwise_layer_type: str = "linear",
+                 positionwise_conv_kernel_size: int = 1, dprenet_dropout_rate=0.5,
+                 transformer_enc_dropout_rate: float = 0.1, transformer_enc_positional_dropout_rate: float = 0.1,
+                 transformer_enc_attn_dropout_rate: float = 0.1, use_batch_norm=True, encoder_normalize_before=True,
+                 decoder_normalize_before=False, encoder_concat_after=False, decoder_concat_after=False,
+                 decoder_reduction_factor=2, spk_embed_dim=None, spk_embed_integration_type="add",
+                 initial_encoder_alpha=1.0, initial_decoder_alpha=1.0, use_guided_attn_loss=False,
+                 num_heads_applied_guided_attn=2, num_layers_applied_guided_attn=2, conformer_rel_pos_type: str = "legacy",
+                 conformer_pos_enc_layer_type: str = "rel_pos", conformer_self_attn_layer_type: str = "rel_selfattn",
+                 use_macaron_style_in_conformer: bool = True, use_cnn_in_conformer: bool = True, zero_triu: bool = False,
+                 conformer_enc_kernel_size: int = 7, conformer_dec_kernel_size: int = 31):
+        nn.Module.__init__(self)
+        self.idim, self.odim = idim, odim
+        self.spk_embed_dim = spk_embed_dim
+        if spk_embed_dim is not None:
+            raise NotImplementedError("speaker-embedding integration is out of scope (no recipe config uses it)")
+        self.decoder_reduction_factor = decoder_reduction_factor
+        self.use_guided_attn_loss = use_guided_attn_loss
+        self.num_heads_applied_guided_attn = num_heads_applied_guided_attn
+        self.num_layers_applied_guided_attn = num_layers_applied_guided_attn
+        self.encoder_type, self.decoder_type = encoder_type, decoder_type
+
+        if encoder_type == "conformer":  # vtn.py:83-104 compatibility fallback
+            if conformer_rel_pos_type == "legacy":
+                if conformer_pos_enc_layer_type == "rel_pos":
+                    conformer_pos_enc_layer_type = "legacy_rel_pos"
+                    logging.warning("Fallback to conformer_pos_enc_layer_type = 'legacy_rel_pos' due to the compatibility.")
+                if conformer_self_attn_layer_type == "rel_selfattn":
+                    conformer_self_attn_layer_type = "legacy_rel_selfattn"
+                    logging.warning("Fallback to conformer_self_attn_layer_type = 'legacy_rel_selfattn' due to the compatibility.")
+            elif conformer_rel_pos_type == "latest":
+                assert conformer_pos_enc_layer_type != "legacy_rel_pos"
+                assert conformer_self_attn_layer_type != "legacy_rel_selfattn"
+            else:
+                raise ValueError(f"Unknown rel_pos_type: {conformer_rel_pos_type}")
+
+        if encoder_type == "transformer":
+            self.encoder = Mo.TransformerEncoder(
+                idim=idim, attention_dim=adim, attention_heads=aheads, linear_units=eunits, num_blocks=elayers,
+                input_layer="conv2d-scaled-pos-enc", pos_enc_class=Mo.ScaledPositionalEncoding,
+                normalize_before=encoder_normalize_before, concat_after=encoder_concat_after,
+                positionwise_layer_type=positionwise_layer_type,
+                positionwise_conv_kernel_size=positionwise_conv_kernel_size, dropout_rate=transformer_enc_dropout_rate)
+        elif encoder_type == "conformer":
+            from ..conformer import ConformerEncoder
+            self.encoder = ConformerEncoder(
+                idim=idim, attention_dim=adim, attention_heads=aheads, linear_units=eunits, num_blocks=elayers,
+                input_layer="conv2d", normalize_before=encoder_normalize_before, concat_after=encoder_concat_after,
+                positionwise_layer_type=positionwise_layer_type,
+                positionwise_conv_kernel_size=positionwise_conv_kernel_size, dropout_rate=transformer_enc_dropout_rate,
+                positional_dropout_rate=transformer_enc_positional_dropout_rate,
+                attention_dropout_rate=transformer_enc_attn_dropout_rate, macaron_style=use_macaron_style_in_conformer,
+                pos_enc_layer_type=conformer_pos_enc_layer_type, selfattention_layer_type=conformer_self_attn_layer_type,
+                use_cnn_module=use_cnn_in_conformer, cnn_module_kernel=conformer_enc_kernel_size, zero_triu=zero_triu)
+        else:
+            raise NotImplementedError
+
+        self._build_decoder_side(idim, odim, dprenet_layers, dprenet_units, dprenet_dropout_rate, adim, aheads, dlayers, dunits,
+                                 decoder_normalize_before, decoder_concat_after, decoder_reduction_factor, postnet_layers,
+                                 postnet_chans, postnet_filts, use_batch_norm)
+        self._reset_parameters(initial_encoder_alpha, initial_decoder_alpha)
+
+    def _reset_parameters(self, init_enc_alpha: float, init_dec_alpha: float):
+        if self.encoder_type == "transformer":
+            self.encoder.embed[-1].alpha.data = torch.tensor(init_enc_alpha)
+        if self.decoder_type == "transformer":
+            self.decoder.embed[-1].alpha.data = torch.tensor(init_dec_alpha)
+
+    def forward(self, xs, ilens, ys, labels, olens, spembs=None, *args, **kwargs):
+        """xs (B,Tmax,idim), ilens (B,), ys (B,Lmax,odim), labels (B,Lmax), olens (B,) ->
+        (after_outs, before_outs, logits, ys, labels, olens, (att_ws, ilens_ds_st, olens_in)).
+        `ilens`/`olens` are best passed as CPU LongTensors (as the collater yields them): lengths are
+        consumed on the host to size kernels, never to build mask tensors."""
+        dev = xs.device
+        K.reset_op_counter() if kwargs.get("_reset_seed_counter", False) else None
+        il = Mo.Lens.of(ilens, dev)
+        ol = Mo.Lens.of(olens, dev)
+        if il.max() != xs.shape[1]:
+            xs = xs[:, : il.max()]
+        if ol.max() != ys.shape[1]:
+            ys, labels = ys[:, : ol.max()], labels[:, : ol.max()]
+        hs, hs_lens = self.encoder(Fn.to_compute(xs), il)
+        after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens)
+        ilens_ds_st = torch.tensor([((v - 2 + 1) // 2 - 2 + 1) // 2 for v in il.host],
+                                   dtype=ilens.dtype if isinstance(ilens, torch.Tensor) else torch.long,
+                                   device=ilens.device if isinstance(ilens, torch.Tensor) else "cpu")
+        att_ws = [self.decoder.decoders[i].src_attn.attn for i in reversed(range(len(self.decoder.decoders)))]
+        return after, before, logits, ys_, labels_, olens_, (att_ws, ilens_ds_st, olens_in)
+
+    @torch.no_grad()
+    def inference(self, x, inference_args, spemb=None, *args, **kwargs):
+        """x (T, idim) -> (outs (L, odim), probs (L,), att_ws (#layers, #heads, L/r, T_enc))."""
+        hs, _ = self.encoder(Fn.to_compute(x.unsqueeze(0)), None)
+        return self._decode_loop(hs, inference_args["threshold"], inference_args["minlenratio"], inference_args["maxlenratio"])

@@ -1,0 +1,512 @@
+"""Building blocks with the reference's class names, constructor arguments and state_dict keys,
+whose forward passes run on the HIP kernels (ops/functional.py).
+
+torch.nn.Linear / Conv1d / Conv2d / BatchNorm1d / LayerNorm / Embedding objects are used purely as
+PARAMETER HOLDERS (so keys, shapes, buffers and default initialisation equal the reference's); their
+own forward() is never called.  Sequence masks are replaced by `Lens` objects (host tuple + cached
+int32 device vector) -- no (B,1,T) / (B,T,T) bool tensors are ever built.
+
+Reference files: seq2seq_vc/modules/transformer/*.py, modules/conformer/*.py, modules/pre_postnets.py,
+layers/positional_encoding.py.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .ops import functional as Fn
+from .ops import kernels as K
+
+# ------------------------------------------------------------------------------------------------
+# lengths instead of masks
+# ------------------------------------------------------------------------------------------------
+_LENS_CACHE = {}
+
+
+class Lens:
+    """Valid lengths of a padded batch: `.host` tuple of ints, `.dev` int32 device tensor (cached by
+    value so that steady-state steps issue no H2D copies and stay hipGraph-capturable)."""
+
+    def __init__(self, values, device):
+        self.host = tuple(int(v) for v in values)
+        self.device = torch.device(device)
+        key = (self.host, self.device.type, self.device.index)
+        t = _LENS_CACHE.get(key)
+        if t is None:
+            if len(_LENS_CACHE) > 4096:
+                _LENS_CACHE.clear()
+            t = torch.tensor(self.host, dtype=torch.int32, device=self.device)
+            _LENS_CACHE[key] = t
+        self.dev = t
+
+    @staticmethod
+    def of(lens, device):
+        if lens is None or isinstance(lens, Lens):
+            return lens
+        if isinstance(lens, torch.Tensor):
+            lens = lens.tolist()
+        return Lens(lens, device)
+
+    def map(self, fn):
+        return Lens([fn(v) for v in self.host], self.device)
+
+    def max(self):
+        return max(self.host)
+
+    def clamp(self, hi):
+        return Lens([min(v, hi) for v in self.host], self.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# positional encodings (layers/positional_encoding.py)
+# ------------------------------------------------------------------------------------------------
+def _sin_table(n, d, reverse=False):
+    pos = torch.arange(n - 1, -1, -1.0, dtype=torch.float32) if reverse else torch.arange(0, n, dtype=torch.float32)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(n, d)
+    pe[:, 0::2] = torch.sin(pos[:, None] * div)
+    pe[:, 1::2] = torch.cos(pos[:, None] * div)
+    return pe
+
+
+class PositionalEncoding(nn.Module):
+    """x*sqrt(d) + pe[:T]  (positional_encoding.py:14-70).  The fp32 table is a lazily built,
+    non-persistent attribute exactly as in the reference (not part of the state_dict)."""
+
+    def __init__(self, d_model, dropout_rate, max_len=5000, reverse=False):
+        super().__init__()
+        self.d_model, self.reverse, self.max_len = d_model, reverse, max_len
+        self.xscale = math.sqrt(d_model)
+        self.dropout_rate = dropout_rate
+        self._pe = None
+
+    def table(self, T, device):
+        if self._pe is None or self._pe.shape[0] < T or self._pe.device != device:
+            self._pe = _sin_table(max(self.max_len, T), self.d_model, self.reverse).to(device)
+        return self._pe
+
+    def forward(self, x):
+        p = self.dropout_rate if self.training else 0.0
+        return Fn.posenc(x, self.table(x.shape[1], x.device), None, self.xscale, p)
+
+
+class ScaledPositionalEncoding(PositionalEncoding):
+    """x + alpha*pe[:T]  (positional_encoding.py:73-106)."""
+
+    def __init__(self, d_model, dropout_rate, max_len=5000):
+        super().__init__(d_model, dropout_rate, max_len)
+        self.alpha = nn.Parameter(torch.tensor(1.0))
+
+    def reset_parameters(self):
+        self.alpha.data = torch.tensor(1.0)
+
+    def forward(self, x):
+        p = self.dropout_rate if self.training else 0.0
+        return Fn.posenc(x, self.table(x.shape[1], x.device), self.alpha, 1.0, p)
+
+
+class RelPositionalEncoding(nn.Module):
+    """(x*sqrt(d), pos_emb (1, 2T-1, d))  (positional_encoding.py:238-309)."""
+
+    def __init__(self, d_model, dropout_rate, max_len=5000):
+        super().__init__()
+        self.d_model, self.dropout_rate = d_model, dropout_rate
+        self.xscale = math.sqrt(d_model)
+        self._cache = {}
+
+    def pos_emb(self, T, device, dtype):
+        key = (T, str(device), dtype)
+        if key not in self._cache:
+            if len(self._cache) > 64:
+                self._cache.clear()
+            plus = torch.flip(_sin_table(T, self.d_model), [0])
+            pos = torch.arange(0, T, dtype=torch.float32)[:, None]
+            div = torch.exp(torch.arange(0, self.d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / self.d_model))
+            minus = torch.zeros(T, self.d_model)
+            minus[:, 0::2], minus[:, 1::2] = torch.sin(-pos * div), torch.cos(-pos * div)
+            self._cache[key] = torch.cat([plus, minus[1:]], dim=0)[None].to(device).to(dtype).contiguous()
+        return self._cache[key]
+
+    def forward(self, x):
+        p = self.dropout_rate if self.training else 0.0
+        pe = self.pos_emb(x.shape[1], x.device, x.dtype)
+        return Fn.posenc(x, None, None, self.xscale, p), Fn.dropout(pe, p)
+
+
+class LegacyRelPositionalEncoding(PositionalEncoding):
+    """(x*sqrt(d), first T rows of the reversed max_len table)  (positional_encoding.py:198-235)."""
+
+    def __init__(self, d_model, dropout_rate, max_len=5000):
+        super().__init__(d_model, dropout_rate, max_len, reverse=True)
+
+    def forward(self, x):
+        p = self.dropout_rate if self.training else 0.0
+        pe = K.cast(self.table(x.shape[1], x.device)[: x.shape[1]][None].contiguous(), x.dtype)
+        return Fn.posenc(x, None, None, self.xscale, p), Fn.dropout(pe, p)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention (modules/transformer/attention.py)
+# ------------------------------------------------------------------------------------------------
+class MultiHeadedAttention(nn.Module):
+    def __init__(self, n_head, n_feat, dropout_rate):
+        super().__init__()
+        assert n_feat % n_head == 0
+        self.d_k, self.h = n_feat // n_head, n_head
+        self.linear_q = nn.Linear(n_feat, n_feat)
+        self.linear_k = nn.Linear(n_feat, n_feat)
+        self.linear_v = nn.Linear(n_feat, n_feat)
+        self.linear_out = nn.Linear(n_feat, n_feat)
+        self.attn = None
+        self.dropout_rate = dropout_rate
+
+    def _p(self):
+        return self.dropout_rate if self.training else 0.0
+
+    def forward(self, query, key, value, klens=None, causal=False):
+        """klens: Lens of valid key positions (None = all valid); causal adds j<=i."""
+        q = Fn.linear(query, self.linear_q.weight, self.linear_q.bias)
+        k = Fn.linear(key, self.linear_k.weight, self.linear_k.bias)
+        v = Fn.linear(value, self.linear_v.weight, self.linear_v.bias)
+        ctx, self.attn = Fn.attention_core(q, k, v, None if klens is None else klens.dev, causal, self.h, self._p())
+        return Fn.linear(ctx, self.linear_out.weight, self.linear_out.bias)
+
+
+class RelPositionMultiHeadedAttention(MultiHeadedAttention):
+    """attention.py:209-305 (new rel_shift); `legacy=True` gives attention.py:114-206."""
+
+    legacy = False
+
+    def __init__(self, n_head, n_feat, dropout_rate, zero_triu=False):
+        super().__init__(n_head, n_feat, dropout_rate)
+        if zero_triu:
+            raise NotImplementedError("zero_triu is not supported")
+        self.zero_triu = zero_triu
+        self.linear_pos = nn.Linear(n_feat, n_feat, bias=False)
+        self.pos_bias_u = nn.Parameter(torch.Tensor(self.h, self.d_k))
+        self.pos_bias_v = nn.Parameter(torch.Tensor(self.h, self.d_k))
+        nn.init.xavier_uniform_(self.pos_bias_u)
+        nn.init.xavier_uniform_(self.pos_bias_v)
+
+    def forward(self, query, key, value, pos_emb, klens=None):
+        q = Fn.linear(query, self.linear_q.weight, self.linear_q.bias)
+        k = Fn.linear(key, self.linear_k.weight, self.linear_k.bias)
+        v = Fn.linear(value, self.linear_v.weight, self.linear_v.bias)
+        pos = Fn.linear(pos_emb, self.linear_pos.weight, None)
+        qu, qv = Fn.add_head_bias(q, self.pos_bias_u, self.pos_bias_v)
+        ctx, self.attn = Fn.rel_attention_core(qu, qv, k, v, pos, None if klens is None else klens.dev, self.h, self._p(),
+                                               2 if self.legacy else 1)
+        return Fn.linear(ctx, self.linear_out.weight, self.linear_out.bias)
+
+
+class LegacyRelPositionMultiHeadedAttention(RelPositionMultiHeadedAttention):
+    legacy = True
+
+
+# ------------------------------------------------------------------------------------------------
+# feed-forward
+# ------------------------------------------------------------------------------------------------
+class PositionwiseFeedForward(nn.Module):
+    """w_2(dropout(act(w_1 x)))  (positionwise_feed_forward.py:12-32); act 'relu' or 'swish'."""
+
+    def __init__(self, idim, hidden_units, dropout_rate, activation="relu"):
+        super().__init__()
+        self.w_1 = nn.Linear(idim, hidden_units)
+        self.w_2 = nn.Linear(hidden_units, idim)
+        self.dropout_rate = dropout_rate
+        self.activation = activation
+
+    def forward(self, x):
+        p = self.dropout_rate if self.training else 0.0
+        if self.activation == "relu":
+            h = Fn.linear(x, self.w_1.weight, self.w_1.bias, act="relu")
+            h = Fn.dropout(h, p)
+        else:
+            h = Fn.act_dropout(Fn.linear(x, self.w_1.weight, self.w_1.bias), self.activation, p)
+        return Fn.linear(h, self.w_2.weight, self.w_2.bias)
+
+
+class MultiLayeredConv1d(nn.Module):
+    """Conv1d-ReLU-dropout-Conv1d FFN (multi_layer_conv.py:12-63), channel-last in and out."""
+
+    def __init__(self, in_chans, hidden_chans, kernel_size, dropout_rate):
+        super().__init__()
+        self.w_1 = nn.Conv1d(in_chans, hidden_chans, kernel_size, stride=1, padding=(kernel_size - 1) // 2)
+        self.w_2 = nn.Conv1d(hidden_chans, in_chans, kernel_size, stride=1, padding=(kernel_size - 1) // 2)
+        self.dropout_rate = dropout_rate
+
+    def forward(self, x):
+        p = self.dropout_rate if self.training else 0.0
+        h = Fn.dropout(Fn.conv1d(x, self.w_1.weight, self.w_1.bias, act="relu"), p)
+        return Fn.conv1d(h, self.w_2.weight, self.w_2.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    """Parameter holder for LayerNorm(eps=1e-12) (layer_norm.py:12-42)."""
+
+    def __init__(self, nout, dim=-1, eps=1e-12):
+        super().__init__(nout, eps=eps)
+        self.dim = dim
+
+    def forward(self, x):
+        return Fn.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+def _res_norm(norm, res, h, p, hscale=1.0):
+    """s = res + hscale*dropout(h); returns (LayerNorm(s), s)."""
+    return Fn.add_dropout_layer_norm(res, h, norm.weight, norm.bias, norm.eps, p, hscale)
+
+
+# ------------------------------------------------------------------------------------------------
+# Transformer layers (encoder_layer.py:61-119, decoder_layer.py:63-134); concat_after unsupported
+# ------------------------------------------------------------------------------------------------
+class EncoderLayer(nn.Module):
+    def __init__(self, size, self_attn, feed_forward, dropout_rate, normalize_before=True, concat_after=False,
+                 stochastic_depth_rate=0.0):
+        super().__init__()
+        if concat_after or stochastic_depth_rate > 0:
+            raise NotImplementedError("concat_after / stochastic depth are not used by any recipe")
+        self.self_attn, self.feed_forward = self_attn, feed_forward
+        self.norm1, self.norm2 = LayerNorm(size), LayerNorm(size)
+        self.dropout_rate = dropout_rate
+        self.size, self.normalize_before = size, normalize_before
+
+    def forward(self, x, klens, normed=None):
+        """Pre-LN: takes (x, LN1(x)) and returns (x_out, None); the caller chains the next norm.
+        Implemented as explicit residual/norm steps so every add+dropout+LN is ONE fused kernel."""
+        p = self.dropout_rate if self.training else 0.0
+        if self.normalize_before:
+            y = self.norm1(x) if normed is None else normed
+            a = self.self_attn(y, y, y, klens)
+            y2, x = _res_norm(self.norm2, x, a, p)
+            f = self.feed_forward(y2)
+            return x, f  # caller adds f with dropout (fused into the next LayerNorm)
+        a = self.self_attn(x, x, x, klens)
+        x, _ = _res_norm(self.norm1, x, a, p)
+        f = self.feed_forward(x)
+        x, _ = _res_norm(self.norm2, x, f, p)
+        return x, None
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, size, self_attn, src_attn, feed_forward, dropout_rate, normalize_before=True, concat_after=False):
+        super().__init__()
+        if concat_after:
+            raise NotImplementedError("concat_after is not used by any recipe")
+        self.size = size
+        self.self_attn, self.src_attn, self.feed_forward = self_attn, src_attn, feed_forward
+        self.norm1, self.norm2, self.norm3 = LayerNorm(size), LayerNorm(size), LayerNorm(size)
+        self.dropout_rate = dropout_rate
+        self.normalize_before = normalize_before
+
+    def forward(self, x, tgt_lens, memory, mem_lens, normed=None, causal=True):
+        p = self.dropout_rate if self.training else 0.0
+        if self.normalize_before:
+            y = self.norm1(x) if normed is None else normed
+            a = self.self_attn(y, y, y, tgt_lens, causal=causal)
+            y, x = _res_norm(self.norm2, x, a, p)
+            a = self.src_attn(y, memory, memory, mem_lens)
+            y, x = _res_norm(self.norm3, x, a, p)
+            return x, self.feed_forward(y)
+        a = self.self_attn(x, x, x, tgt_lens, causal=causal)
+        x, _ = _res_norm(self.norm1, x, a, p)
+        a = self.src_attn(x, memory, memory, mem_lens)
+        x, _ = _res_norm(self.norm2, x, a, p)
+        f = self.feed_forward(x)
+        x, _ = _res_norm(self.norm3, x, f, p)
+        return x, None
+
+
+def run_stack(layers, x, after_norm, pre_ln, dropout_rate, training, *args, **kw):
+    """Run a stack of EncoderLayer/DecoderLayer.  In pre-LN mode each layer returns (x, pending FFN
+    output); `x + dropout(f)` is fused into the NEXT layer's first LayerNorm (or after_norm)."""
+    p = dropout_rate if training else 0.0
+    pending = None
+    for layer in layers:
+        if pre_ln and pending is not None:
+            normed, x = _res_norm(layer.norm1, x, pending, p)
+            x, pending = layer(x, *args, normed=normed, **kw)
+        else:
+            x, pending = layer(x, *args, **kw)
+    if pre_ln:
+        if pending is not None:
+            y, x = _res_norm(after_norm, x, pending, p)
+            return y
+        return after_norm(x)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv2d subsampling front-end (subsampling.py:44-105)
+# ------------------------------------------------------------------------------------------------
+class Conv2dSubsampling(nn.Module):
+    def __init__(self, idim, odim, dropout_rate, pos_enc=None, use_pos_enc=True):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(1, odim, 3, 2), nn.ReLU(), nn.Conv2d(odim, odim, 3, 2), nn.ReLU())
+        self.f2 = ((idim - 1) // 2 - 1) // 2
+        if use_pos_enc:
+            self.out = nn.Sequential(nn.Linear(odim * self.f2, odim),
+                                     pos_enc if pos_enc is not None else PositionalEncoding(odim, dropout_rate))
+        else:
+            self.out = nn.Linear(odim * self.f2, odim)
+        self.odim, self.use_pos_enc = odim, use_pos_enc
+
+    def __getitem__(self, key):
+        if key != -1:
+            raise NotImplementedError("Support only `-1` (for `reset_parameters`).")
+        return self.out[key]
+
+    @staticmethod
+    def out_lens(lens, t_out):
+        """mask[:, :, :-2:2][:, :, :-2:2] of a non-pad mask keeps frame t' iff 4*t' < len."""
+        return None if lens is None else lens.map(lambda v: min((v + 3) // 4, t_out))
+
+    def forward(self, x, lens):
+        B, T, idim = x.shape
+        c0, c2 = self.conv[0], self.conv[2]
+        y = Fn.conv2d_s2_relu(x.reshape(B, T, idim, 1), c0.weight, c0.bias)
+        y = Fn.conv2d_s2_relu(y, c2.weight, c2.bias)          # (B, T2, F2, C) channel-last
+        _, T2, F2, C = y.shape
+        lin = self.out[0] if self.use_pos_enc else self.out
+        y = Fn.linear_fc_permuted(y.reshape(B * T2, F2 * C), lin.weight, lin.bias, C, F2).view(B, T2, self.odim)
+        if self.use_pos_enc:
+            y = self.out[1](y)
+        return y, self.out_lens(lens, T2)
+
+
+# ------------------------------------------------------------------------------------------------
+# Tacotron2 prenet / postnet (pre_postnets.py)
+# ------------------------------------------------------------------------------------------------
+class Prenet(nn.Module):
+    """(Linear-ReLU-dropout)xN with dropout ALWAYS on (pre_postnets.py:53-66)."""
+
+    def __init__(self, idim, n_layers=2, n_units=256, dropout_rate=0.5):
+        super().__init__()
+        self.dropout_rate = dropout_rate
+        self.prenet = nn.ModuleList()
+        for layer in range(n_layers):
+            self.prenet += [nn.Sequential(nn.Linear(idim if layer == 0 else n_units, n_units), nn.ReLU())]
+
+    def forward(self, x):
+        for blk in self.prenet:
+            x = Fn.dropout(Fn.linear(x, blk[0].weight, blk[0].bias, act="relu"), self.dropout_rate)
+        return x
+
+
+class Postnet(nn.Module):
+    """5 x (Conv1d k5 no-bias -> BatchNorm1d -> tanh (not last) -> dropout) (pre_postnets.py:69-185).
+    Input/output here are channel-last (B, T, odim); padded frames are NOT masked."""
+
+    def __init__(self, idim, odim, n_layers=5, n_chans=512, n_filts=5, dropout_rate=0.5, use_batch_norm=True):
+        super().__init__()
+        self.postnet = nn.ModuleList()
+        for layer in range(n_layers):
+            ichans = odim if layer == 0 else n_chans
+            ochans = odim if layer == n_layers - 1 else n_chans
+            mods = [nn.Conv1d(ichans, ochans, n_filts, stride=1, padding=(n_filts - 1) // 2, bias=False)]
+            if use_batch_norm:
+                mods.append(nn.BatchNorm1d(ochans))
+            if layer != n_layers - 1:
+                mods.append(nn.Tanh())
+            mods.append(nn.Dropout(dropout_rate))
+            self.postnet += [nn.Sequential(*mods)]
+        self.dropout_rate, self.use_batch_norm = dropout_rate, use_batch_norm
+
+    def forward(self, xs):
+        n = len(self.postnet)
+        p = self.dropout_rate if self.training else 0.0
+        for i, blk in enumerate(self.postnet):
+            act = "tanh" if i != n - 1 else None
+            xs = Fn.conv1d(xs, blk[0].weight, None)
+            if self.use_batch_norm:
+                bn = blk[1]
+                xs = Fn.batch_norm_act(xs, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                       self.training, act, p, bn.eps, bn.momentum)
+            else:
+                xs = Fn.act_dropout(xs, act, p)
+        return xs
+
+
+# ------------------------------------------------------------------------------------------------
+# Transformer encoder / decoder stacks (transformer/encoder.py, transformer/decoder.py)
+# ------------------------------------------------------------------------------------------------
+class MultiSequential(nn.Sequential):
+    """Holder with the reference's container name; stacks are driven by run_stack()."""
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, idim, attention_dim=256, attention_heads=4, linear_units=2048, num_blocks=6, dropout_rate=0.1,
+                 positional_dropout_rate=0.1, attention_dropout_rate=0.0, input_layer="conv2d",
+                 pos_enc_class=PositionalEncoding, normalize_before=True, concat_after=False,
+                 positionwise_layer_type="linear", positionwise_conv_kernel_size=1, padding_idx=-1):
+        super().__init__()
+        if input_layer == "conv2d":
+            self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate)
+        elif input_layer == "conv2d-scaled-pos-enc":
+            self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate, pos_enc_class(attention_dim, positional_dropout_rate))
+        elif isinstance(input_layer, nn.Module):
+            self.embed = nn.Sequential(input_layer, pos_enc_class(attention_dim, positional_dropout_rate))
+        else:
+            raise ValueError("unsupported input_layer: " + str(input_layer))
+        self.normalize_before = normalize_before
+        if positionwise_layer_type == "linear":
+            ff = lambda: PositionwiseFeedForward(attention_dim, linear_units, dropout_rate)
+        elif positionwise_layer_type == "conv1d":
+            ff = lambda: MultiLayeredConv1d(attention_dim, linear_units, positionwise_conv_kernel_size, dropout_rate)
+        else:
+            raise NotImplementedError("Support only linear or conv1d.")
+        self.encoders = MultiSequential(*[
+            EncoderLayer(attention_dim, MultiHeadedAttention(attention_heads, attention_dim, attention_dropout_rate), ff(),
+                         dropout_rate, normalize_before, concat_after) for _ in range(num_blocks)])
+        if normalize_before:
+            self.after_norm = LayerNorm(attention_dim)
+        self.dropout_rate = dropout_rate
+
+    def forward(self, xs, lens):
+        if isinstance(self.embed, Conv2dSubsampling):
+            xs, lens = self.embed(xs, lens)
+        else:
+            emb = self.embed[0]
+            if isinstance(emb, nn.Embedding):
+                xs = Fn.to_compute(torch.nn.functional.embedding(xs, emb.weight, emb.padding_idx))
+            else:
+                xs = emb(xs)
+            xs = self.embed[1](xs)
+        xs = run_stack(self.encoders, xs, getattr(self, "after_norm", None), self.normalize_before, self.dropout_rate,
+                       self.training, lens)
+        return xs, lens
+
+
+class Decoder(nn.Module):
+    def __init__(self, odim, attention_dim=256, attention_heads=4, linear_units=2048, num_blocks=6, dropout_rate=0.1,
+                 positional_dropout_rate=0.1, self_attention_dropout_rate=0.0, src_attention_dropout_rate=0.0,
+                 input_layer="embed", use_output_layer=True, pos_enc_class=PositionalEncoding, normalize_before=True,
+                 concat_after=False):
+        super().__init__()
+        if not isinstance(input_layer, nn.Module):
+            raise NotImplementedError("only a torch.nn.Module input layer is supported")
+        if use_output_layer:
+            raise NotImplementedError("use_output_layer=True is not used by VTN / TTS")
+        self.embed = nn.Sequential(input_layer, pos_enc_class(attention_dim, positional_dropout_rate))
+        self.normalize_before = normalize_before
+        self.decoders = MultiSequential(*[
+            DecoderLayer(attention_dim, MultiHeadedAttention(attention_heads, attention_dim, self_attention_dropout_rate),
+                         MultiHeadedAttention(attention_heads, attention_dim, src_attention_dropout_rate),
+                         PositionwiseFeedForward(attention_dim, linear_units, dropout_rate), dropout_rate, normalize_before,
+                         concat_after) for _ in range(num_blocks)])
+        if normalize_before:
+            self.after_norm = LayerNorm(attention_dim)
+        self.output_layer = None
+        self.dropout_rate = dropout_rate
+
+    def embed_input(self, tgt):
+        x = tgt
+        for m in self.embed[0]:
+            x = m(x) if isinstance(m, Prenet) else Fn.linear(x, m.weight, m.bias)
+        return self.embed[1](x)
+
+    def forward(self, tgt, tgt_lens, memory, mem_lens, causal=True):
+        x = self.embed_input(tgt)
+        x = run_stack(self.decoders, x, getattr(self, "after_norm", None), self.normalize_before, self.dropout_rate,
+                      self.training, tgt_lens, memory, mem_lens, causal=causal)
+        return x, tgt_lens

@@ -1,0 +1,711 @@
+"""Differentiable ops of the hot path: torch.autograd.Function wrappers whose forward AND backward
+are hand-written HIP kernels (seq2seq_vc_amd/csrc) reached through the C ABI.
+
+Conventions
+  * activations are (B, T, D) channel-last, contiguous, in the compute dtype (fp32 = parity mode,
+    bf16 = benchmark mode); parameters stay fp32 in the reference's torch layouts;
+  * masks are never materialised: ops take int32 length vectors that live on the device;
+  * weight gradients are fp32.  If a parameter carries `_s2s_grad` (a view into the model's flat
+    gradient buffer, see optim.FlatAdam) the wgrad kernel accumulates straight into it and autograd
+    gets no tensor for that input.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+
+_STATE = {"dtype": torch.float32}
+
+
+def set_compute_dtype(dtype):
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32 or bfloat16")
+    _STATE["dtype"] = dtype
+
+
+def compute_dtype():
+    return _STATE["dtype"]
+
+
+def to_compute(x):
+    """Cast an input tensor to the compute dtype with the HIP cast kernel."""
+    return K.cast(x.contiguous(), _STATE["dtype"])
+
+
+def _c(x):
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def _wcast(w, dtype):
+    """fp32 master weight -> compute-dtype operand (uses the optimiser's bf16 shadow when present)."""
+    if dtype == torch.float32:
+        return w
+    sh = getattr(w, "_s2s_bf16", None)
+    if sh is not None:
+        return sh
+    return K.cast(w.detach(), dtype)
+
+
+def _emit_wgrad(param, shape, writer):
+    """Run `writer(out, accumulate)` into the flat-grad slot of `param` if it has one (returns None so
+    autograd skips it), else into a fresh fp32 tensor (returned to autograd)."""
+    slot = getattr(param, "_s2s_grad", None)
+    if slot is not None:
+        writer(slot.view(shape), True)
+        return None
+    out = torch.empty(shape, dtype=torch.float32, device=param.device)
+    writer(out, False)
+    return out
+
+
+def _emit_vgrad(param, value):
+    """Same for small vector gradients already computed in fp32 (`value`)."""
+    slot = getattr(param, "_s2s_grad", None)
+    if slot is not None:
+        K.axpby(1.0, slot.view(-1), 1.0, value.reshape(-1), out=slot.view(-1))
+        return None
+    return value.view(param.shape)
+
+
+# ================================================================================================
+# Linear (+bias, +activation)          reference: torch.nn.Linear call sites of the hot path
+# ================================================================================================
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        dtype = x.dtype
+        x2 = _c(x).view(-1, x.shape[-1])
+        M, Kd = x2.shape
+        N = weight.shape[0]
+        w = _wcast(weight, dtype)
+        y = torch.empty((M, N), dtype=dtype, device=x.device)
+        K.gemm(K.operand(x2, Kd), K.operand(w, Kd), M, N, Kd, y, in_dtype=dtype, bias=bias, act=act)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x2, w, y if act else None)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        weight, bias = ctx.params
+        M, Kd = x2.shape
+        N = w.shape[0]
+        dtype = x2.dtype
+        dy2 = _c(dy).view(M, N)
+        if ctx.act:
+            dy2 = K.act_dropout_bwd(dy2, y, act=ctx.act)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
+            K.gemm(K.operand(dy2, N), K.operand(w, Kd, layout=K.RC), M, Kd, N, dx, in_dtype=dtype)
+            dx = dx.view(ctx.xshape)
+        dw = db = None
+        if weight.requires_grad:
+            sk = K.pick_splitk(N, Kd, M)
+
+            def wr(out, acc):
+                K.gemm(K.operand(dy2, N, layout=K.RC), K.operand(x2, Kd, layout=K.RC), N, Kd, M, out, in_dtype=dtype,
+                       splitk=sk, accumulate=acc)
+            dw = _emit_wgrad(weight, (N, Kd), wr)
+        if ctx.has_bias and bias.requires_grad:
+            s, _ = K.colreduce(0, dy2)
+            db = _emit_vgrad(bias, s)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, act=None):
+    return _Linear.apply(x, weight, bias, act)
+
+
+# ================================================================================================
+# LayerNorm, optionally fused with "s = res + hscale * dropout(h)"
+# reference: modules/transformer/layer_norm.py:12-42 + residual/dropout lines of the layer classes
+# ================================================================================================
+class _AddLayerNorm(Function):
+    @staticmethod
+    def forward(ctx, h, res, gamma, beta, eps, p, hscale):
+        seed = K.new_seed(h.device) if p > 0.0 else (None, 0)
+        h = _c(h)
+        res = _c(res) if res is not None else None
+        y, s, mean, rstd = K.layernorm_fwd(h, gamma, beta, eps, res=res, p=p, seed=seed, hscale=hscale)
+        ctx.meta = (eps, p, seed, hscale, res is not None)
+        ctx.params = (gamma, beta)
+        ctx.save_for_backward(s if res is not None else h, mean, rstd)
+        ctx.set_materialize_grads(False)
+        if res is None:
+            return y
+        return y, s
+
+    @staticmethod
+    def backward(ctx, dy, ds_direct=None):
+        s, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        eps, p, seed, hscale, fused = ctx.meta
+        dy = _c(dy) if dy is not None else torch.zeros_like(s)
+        extra = _c(ds_direct) if (fused and ds_direct is not None) else None
+        ds, dh = K.layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=extra, p=p, seed=seed,
+                                 want_dh=fused and (p > 0.0 or hscale != 1.0), hscale=hscale)
+        dgamma = dbeta = None
+        if gamma.requires_grad:
+            sb, sg = K.colreduce(1, dy, s, mean, rstd, want_dot=True)
+            dgamma, dbeta = _emit_vgrad(gamma, sg), _emit_vgrad(beta, sb)
+        if fused:
+            return (dh if dh is not None else ds), ds, dgamma, dbeta, None, None, None
+        return ds, None, dgamma, dbeta, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-12):
+    return _AddLayerNorm.apply(x, None, gamma, beta, eps, 0.0, 1.0)
+
+
+def add_dropout_layer_norm(res, h, gamma, beta, eps=1e-12, p=0.0, hscale=1.0):
+    """s = res + hscale*dropout(h, p); y = LayerNorm(s).  Returns (y, s)."""
+    return _AddLayerNorm.apply(h, res, gamma, beta, eps, p, hscale)
+
+
+class _AddDropout(Function):
+    """s = res + hscale * dropout(h)   (a residual that is not followed by a LayerNorm)."""
+
+    @staticmethod
+    def forward(ctx, h, res, p, hscale):
+        seed = K.new_seed(h.device) if p > 0.0 else (None, 0)
+        hd = K.act_dropout_fwd(_c(h), p=p, seed=seed) if p > 0.0 else _c(h)
+        ctx.meta = (p, seed, hscale)
+        return K.axpby(1.0, _c(res), hscale, hd)
+
+    @staticmethod
+    def backward(ctx, ds):
+        p, seed, hscale = ctx.meta
+        ds = _c(ds)
+        dh = ds
+        if p > 0.0:
+            dh = K.act_dropout_bwd(ds, ds, act=None, p=p, seed=seed)
+        if hscale != 1.0:
+            dh = K.axpby(hscale, dh)
+        return dh, ds, None, None
+
+
+def add_dropout(res, h, p=0.0, hscale=1.0):
+    return _AddDropout.apply(h, res, p, hscale)
+
+
+# ================================================================================================
+# dropout / activations
+# ================================================================================================
+class _ActDropout(Function):
+    @staticmethod
+    def forward(ctx, x, act, p):
+        seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
+        x = _c(x)
+        y = K.act_dropout_fwd(x, act=act, p=p, seed=seed)
+        ctx.meta = (act, p, seed)
+        ctx.save_for_backward(x if act in ("swish", "gelu") else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (saved,) = ctx.saved_tensors
+        act, p, seed = ctx.meta
+        return K.act_dropout_bwd(_c(dy), saved, act=act, p=p, seed=seed), None, None
+
+
+def act_dropout(x, act=None, p=0.0):
+    if act is None and p <= 0.0:
+        return x
+    return _ActDropout.apply(x, act, p)
+
+
+def dropout(x, p, training=True):
+    return act_dropout(x, None, p if training else 0.0)
+
+
+class _Glu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return K.glu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.glu_bwd(x, _c(dy))
+
+
+def glu(x):
+    return _Glu.apply(x)
+
+
+# ================================================================================================
+# positional encodings          reference: layers/positional_encoding.py
+# ================================================================================================
+class _PosEnc(Function):
+    @staticmethod
+    def forward(ctx, x, alpha, pe, xscale, p):
+        seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
+        x = _c(x)
+        y = K.posenc_fwd(x, xscale, alpha, pe, p=p, seed=seed)
+        ctx.meta = (xscale, p, seed)
+        ctx.alpha = alpha
+        ctx.save_for_backward(pe)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (pe,) = ctx.saved_tensors
+        xscale, p, seed = ctx.meta
+        alpha = ctx.alpha
+        want = alpha is not None and alpha.requires_grad
+        dx, dalpha = K.posenc_bwd(_c(dy), xscale, pe, p=p, seed=seed, want_dalpha=want)
+        if want:
+            dalpha = _emit_vgrad(alpha, dalpha)
+        return dx, dalpha, None, None, None
+
+
+def posenc(x, pe, alpha=None, xscale=1.0, p=0.0):
+    """y = dropout(x*xscale + alpha*pe[:T])  (pe None -> scaling only)."""
+    return _PosEnc.apply(x, alpha, pe, xscale, p)
+
+
+# ================================================================================================
+# attention cores (QK^T -> masked softmax -> PV), plain and relative-position
+# reference: modules/transformer/attention.py:63-111, :262-305
+# ================================================================================================
+def _qk(q, k, B, H, T1, T2, dk, D, dtype, bs0_b=None):
+    scores = torch.empty((B, H, T1, T2), dtype=torch.float32, device=q.device)
+    K.gemm(K.operand(q, D, bs0=T1 * D, bs1=dk), K.operand(k, D, bs0=(T2 * D if bs0_b is None else bs0_b), bs1=dk), T1, T2, dk,
+           scores, in_dtype=dtype, nb0=B, nb1=H, cbs=(H * T1 * T2, T1 * T2))
+    return scores
+
+
+def _pv(pm, v, B, H, T1, T2, dk, D, dtype):
+    ctxv = torch.empty((B, T1, D), dtype=dtype, device=v.device)
+    K.gemm(K.operand(pm, T2, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(v, D, layout=K.RC, bs0=T2 * D, bs1=dk), T1, dk, T2, ctxv,
+           in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T1 * D, dk))
+    return ctxv
+
+
+def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, rel_mode=0):
+    B, T1, D = q.shape
+    T2 = k.shape[1]
+    dk = D // H
+    dtype = q.dtype
+    dctx = _c(dctx) if dctx is not None else torch.zeros_like(q)
+    # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
+    dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
+    # dV[b,j,hd] = sum_i pm[b,h,i,j] dctx[b,i,hd]
+    dv = torch.empty((B, T2, D), dtype=dtype, device=q.device)
+    K.gemm(K.operand(pm, T2, layout=K.RC, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(dctx, D, layout=K.RC, bs0=T1 * D, bs1=dk),
+           T2, dk, T1, dv, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T2 * D, dk))
+    ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode,
+                                 dattn=_c(dattn) if dattn is not None else None)
+    # dQ[b,i,hd] = sum_j dS[b,h,i,j] k[b,j,hd]
+    dq = torch.empty((B, T1, D), dtype=dtype, device=q.device)
+    K.gemm(K.operand(ds, T2, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(k, D, layout=K.RC, bs0=T2 * D, bs1=dk), T1, dk, T2, dq,
+           in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T1 * D, dk))
+    # dK[b,j,hd] = sum_i dS[b,h,i,j] q[b,i,hd]
+    dkk = torch.empty((B, T2, D), dtype=dtype, device=q.device)
+    K.gemm(K.operand(ds, T2, layout=K.RC, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(q, D, layout=K.RC, bs0=T1 * D, bs1=dk), T2,
+           dk, T1, dkk, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T2 * D, dk))
+    return dq, dkk, dv, dbd
+
+
+class _AttnCore(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, klen, causal, H, p):
+        q, k, v = _c(q), _c(k), _c(v)
+        B, T1, D = q.shape
+        T2 = k.shape[1]
+        dk = D // H
+        dtype = q.dtype
+        scale = 1.0 / math.sqrt(dk)
+        seed = K.new_seed(q.device) if p > 0.0 else (None, 0)
+        scores = _qk(q, k, B, H, T1, T2, dk, D, dtype)
+        attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed)
+        pm = pdrop if pdrop is not None else attn
+        out = _pv(pm, v, B, H, T1, T2, dk, D, dtype)
+        ctx.meta = (H, scale, p, seed)
+        ctx.save_for_backward(q, k, v, attn, pdrop)
+        ctx.set_materialize_grads(False)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dctx, dattn):
+        q, k, v, attn, pdrop = ctx.saved_tensors
+        H, scale, p, seed = ctx.meta
+        pm = pdrop if pdrop is not None else attn
+        dq, dkk, dv, _ = _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed)
+        return dq, dkk, dv, None, None, None, None
+
+
+def attention_core(q, k, v, klen, causal, H, p=0.0):
+    """(context (B,T1,D), attn (B,H,T1,T2)); klen: int32 device tensor (B,) of valid key counts or None."""
+    return _AttnCore.apply(q, k, v, klen, causal, H, p)
+
+
+class _RelAttnCore(Function):
+    """scores = (qu.k^T + rel_shift(qv.pos^T)) / sqrt(dk); rel_mode 1 = new (pos (1,2T-1,D)), 2 = legacy (pos (1,T,D))."""
+
+    @staticmethod
+    def forward(ctx, qu, qv, k, v, pos, klen, H, p, rel_mode):
+        qu, qv, k, v, pos = _c(qu), _c(qv), _c(k), _c(v), _c(pos)
+        B, T, D = qu.shape
+        dk = D // H
+        L = pos.shape[1]
+        dtype = qu.dtype
+        scale = 1.0 / math.sqrt(dk)
+        seed = K.new_seed(qu.device) if p > 0.0 else (None, 0)
+        ac = _qk(qu, k, B, H, T, T, dk, D, dtype)
+        bd = torch.empty((B, H, T, L), dtype=torch.float32, device=qu.device)
+        K.gemm(K.operand(qv, D, bs0=T * D, bs1=dk), K.operand(pos, D, bs0=0, bs1=dk), T, L, dk, bd, in_dtype=dtype, nb0=B, nb1=H,
+               cbs=(H * T * L, T * L))
+        attn, pdrop = K.attn_softmax_fwd(ac, dtype, scale, klen=klen, causal=False, bd=bd, rel_mode=rel_mode, p=p, seed=seed)
+        pm = pdrop if pdrop is not None else attn
+        out = _pv(pm, v, B, H, T, T, dk, D, dtype)
+        ctx.meta = (H, scale, p, seed, rel_mode, L)
+        ctx.save_for_backward(qu, qv, k, v, pos, attn, pdrop)
+        ctx.set_materialize_grads(False)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dctx, dattn):
+        qu, qv, k, v, pos, attn, pdrop = ctx.saved_tensors
+        H, scale, p, seed, rel_mode, L = ctx.meta
+        B, T, D = qu.shape
+        dk = D // H
+        dtype = qu.dtype
+        pm = pdrop if pdrop is not None else attn
+        dqu, dkk, dv, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, v, H, scale, p, seed, Lp=L, rel_mode=rel_mode)
+        # dQv[b,i,hd] = sum_c dbd[b,h,i,c] pos[c,hd]
+        dqv = torch.empty((B, T, D), dtype=dtype, device=qu.device)
+        K.gemm(K.operand(dbd, L, bs0=H * T * L, bs1=T * L), K.operand(pos, D, layout=K.RC, bs0=0, bs1=dk), T, dk, L, dqv,
+               in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T * D, dk))
+        # dPos[c,hd] = sum_{b,i} dbd[b,h,i,c] qv[b,i,hd]  (per-batch partials, then a deterministic sum over b)
+        part = torch.empty((B, L, D), dtype=dtype, device=qu.device)
+        K.gemm(K.operand(dbd, L, layout=K.RC, bs0=H * T * L, bs1=T * L), K.operand(qv, D, layout=K.RC, bs0=T * D, bs1=dk), L, dk,
+               T, part, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(L * D, dk))
+        dpos, _ = K.colreduce(0, part.view(B, L * D))
+        dpos = K.cast(dpos.view(1, L, D), dtype)
+        return dqu, dqv, dkk, dv, dpos, None, None, None, None
+
+
+def rel_attention_core(qu, qv, k, v, pos, klen, H, p=0.0, rel_mode=1):
+    return _RelAttnCore.apply(qu, qv, k, v, pos, klen, H, p, rel_mode)
+
+
+class _HeadBias(Function):
+    """qu = q + pos_bias_u, qv = q + pos_bias_v   (attention.py:283-286)."""
+
+    @staticmethod
+    def forward(ctx, q, u, v):
+        q = _c(q)
+        ctx.params = (u, v)
+        return K.add_head_bias(q, u.detach().reshape(-1), v.detach().reshape(-1))
+
+    @staticmethod
+    def backward(ctx, dqu, dqv):
+        u, v = ctx.params
+        dqu, dqv = _c(dqu), _c(dqv)
+        dq = K.axpby(1.0, dqu, 1.0, dqv)
+        du = dv = None
+        if u.requires_grad:
+            su, _ = K.colreduce(0, dqu.view(-1, dqu.shape[-1]))
+            sv, _ = K.colreduce(0, dqv.view(-1, dqv.shape[-1]))
+            du, dv = _emit_vgrad(u, su), _emit_vgrad(v, sv)
+        return dq, du, dv
+
+
+def add_head_bias(q, u, v):
+    return _HeadBias.apply(q, u, v)
+
+
+# ================================================================================================
+# Conv1d (stride 1, 'same' padding, channel-last activations) as an implicit GEMM
+# reference: Postnet / AlignmentModule / DurationPredictor / FFN Conv1d call sites
+# ================================================================================================
+class _Conv1d(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = _c(x)
+        B, T, Cin = x.shape
+        Cout, _, ks = weight.shape
+        pad = (ks - 1) // 2
+        dtype = x.dtype
+        wp = K.gather3(weight.detach(), (Cout, ks, Cin), (Cin * ks, 1, ks), 0, dtype)  # (O, k, I)
+        y = torch.empty((B, T, Cout), dtype=dtype, device=x.device)
+        K.gemm(K.operand(x, Cin, mode=K.CONV1D, C=Cin, T=T, pad=pad), K.operand(wp, ks * Cin), B * T, Cout, ks * Cin, y,
+               in_dtype=dtype, bias=bias, act=act)
+        ctx.act = act
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x, y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.params
+        B, T, Cin = x.shape
+        Cout, _, ks = weight.shape
+        pad = (ks - 1) // 2
+        dtype = x.dtype
+        dy = _c(dy)
+        if ctx.act:
+            dy = K.act_dropout_bwd(dy, y, act=ctx.act)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = K.gather3(weight.detach(), (Cin, ks, Cout), (ks, -1, Cin * ks), ks - 1, dtype)  # (I, k flipped, O)
+            dx = torch.empty((B, T, Cin), dtype=dtype, device=x.device)
+            K.gemm(K.operand(dy, Cout, mode=K.CONV1D, C=Cout, T=T, pad=pad), K.operand(wd, ks * Cout), B * T, Cin, ks * Cout, dx,
+                   in_dtype=dtype)
+        dw = db = None
+        if weight.requires_grad:
+            dwp = torch.empty((Cout, ks * Cin), dtype=torch.float32, device=x.device)
+            K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad), Cout,
+                   ks * Cin, B * T, dwp, in_dtype=dtype, splitk=K.pick_splitk(Cout, ks * Cin, B * T))
+            dwt = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
+            dw = _emit_vgrad(weight, dwt)
+        if bias is not None and bias.requires_grad:
+            s, _ = K.colreduce(0, dy.view(B * T, Cout))
+            db = _emit_vgrad(bias, s)
+        return dx, dw, db, None
+
+
+def conv1d(x, weight, bias=None, act=None):
+    """x (B,T,Cin) channel-last; weight (Cout,Cin,k) torch layout; returns (B,T,Cout)."""
+    return _Conv1d.apply(x, weight, bias, act)
+
+
+# ================================================================================================
+# Conv2d 3x3 stride 2 (+ReLU) on NHWC activations         reference: subsampling.py:58-63
+# ================================================================================================
+class _Conv2dS2(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        B, T1, F1, C = x.shape
+        O = weight.shape[0]
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        dtype = x.dtype
+        wp = K.gather3(weight.detach(), (O, 9, C), (C * 9, 1, 9), 0, dtype)  # (O, tap, C)
+        y = torch.empty((B, T2, F2, O), dtype=dtype, device=x.device)
+        K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(wp, 9 * C), B * T2 * F2, O, 9 * C, y,
+               in_dtype=dtype, bias=bias, act="relu")
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x, y, wp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, wp = ctx.saved_tensors
+        weight, bias = ctx.params
+        B, T1, F1, C = x.shape
+        O = weight.shape[0]
+        T2, F2 = y.shape[1], y.shape[2]
+        M2 = B * T2 * F2
+        dtype = x.dtype
+        dy = K.act_dropout_bwd(_c(dy), y, act="relu")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcols = torch.empty((M2, 9 * C), dtype=dtype, device=x.device)
+            K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), M2, 9 * C, O, dcols, in_dtype=dtype)
+            dx = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)
+        dw = db = None
+        if weight.requires_grad:
+            dwp = torch.empty((O, 9 * C), dtype=torch.float32, device=x.device)
+            K.gemm(K.operand(dy, O, layout=K.RC), K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2),
+                   O, 9 * C, M2, dwp, in_dtype=dtype, splitk=K.pick_splitk(O, 9 * C, M2))
+            dwt = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32)
+            dw = _emit_vgrad(weight, dwt)
+        if bias is not None and bias.requires_grad:
+            s, _ = K.colreduce(0, dy.view(M2, O))
+            db = _emit_vgrad(bias, s)
+        return dx, dw, db
+
+
+def conv2d_s2_relu(x_nhwc, weight, bias):
+    return _Conv2dS2.apply(x_nhwc, weight, bias)
+
+
+class _LinearPermuted(Function):
+    """y = x2d . Wp^T + b where Wp[d, f*C + c] = W[d, c*F + f]: the Linear after the conv2d front-end
+    (subsampling.py:64-70 flattens (c, f); our activations are (f, c) channel-last)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, C, Fd):
+        x = _c(x)
+        dtype = x.dtype
+        D = weight.shape[0]
+        M = x.numel() // (C * Fd)
+        wp = K.gather3(weight.detach(), (D, Fd, C), (C * Fd, 1, Fd), 0, dtype)
+        y = torch.empty((M, D), dtype=dtype, device=x.device)
+        K.gemm(K.operand(x, C * Fd), K.operand(wp, C * Fd), M, D, C * Fd, y, in_dtype=dtype, bias=bias)
+        ctx.params = (weight, bias)
+        ctx.meta = (C, Fd)
+        ctx.save_for_backward(x, wp)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        weight, bias = ctx.params
+        C, Fd = ctx.meta
+        D = weight.shape[0]
+        Kd = C * Fd
+        M = x.numel() // Kd
+        dtype = x.dtype
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, Kd), dtype=dtype, device=x.device)
+            K.gemm(K.operand(dy, D), K.operand(wp, Kd, layout=K.RC), M, Kd, D, dx, in_dtype=dtype)
+            dx = dx.view(x.shape)
+        dw = db = None
+        if weight.requires_grad:
+            dwp = torch.empty((D, Kd), dtype=torch.float32, device=x.device)
+            K.gemm(K.operand(dy, D, layout=K.RC), K.operand(x, Kd, layout=K.RC), D, Kd, M, dwp, in_dtype=dtype,
+                   splitk=K.pick_splitk(D, Kd, M))
+            dwt = K.gather3(dwp, (D, C, Fd), (Kd, 1, C), 0, torch.float32)
+            dw = _emit_vgrad(weight, dwt)
+        if bias is not None and bias.requires_grad:
+            s, _ = K.colreduce(0, dy)
+            db = _emit_vgrad(bias, s)
+        return dx, dw, db, None, None
+
+
+def linear_fc_permuted(x, weight, bias, C, Fd):
+    return _LinearPermuted.apply(x, weight, bias, C, Fd)
+
+
+# ================================================================================================
+# BatchNorm1d over (B*T) rows, channel-last, fused with activation + dropout
+# reference: pre_postnets.py:108-165, conformer/convolution.py:73-75
+# ================================================================================================
+class _BatchNormAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, num_batches, training, act, p, eps, momentum):
+        x = _c(x)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
+        if training:
+            mean, _ = K.colreduce(0, x.view(rows, C), scale=1.0 / rows)
+            var, _ = K.colreduce(3, None, x=x.view(rows, C), mean=mean, scale=1.0 / rows, rows=rows, D=C)
+            rstd = K.bn_finalize(mean, var, rows, eps, momentum, run_mean, run_var, num_batches)
+        else:
+            mean = run_mean
+            rstd = K.rstd_from_var(run_var, eps)
+        need_pre = act in ("swish", "gelu")
+        y, pre = K.bn_apply(x, mean, rstd, gamma, beta, act=act, p=p, seed=seed, want_pre=need_pre)
+        ctx.meta = (training, act, p, seed)
+        ctx.params = (gamma, beta)
+        ctx.save_for_backward(x, mean, rstd, pre if need_pre else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, mean, rstd, saved = ctx.saved_tensors
+        gamma, beta = ctx.params
+        training, act, p, seed = ctx.meta
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dy = _c(dz)
+        if act or p > 0.0:
+            dy = K.act_dropout_bwd(dy, saved, act=act, p=p, seed=seed)
+        sdy, sdyx = K.colreduce(2, dy.view(rows, C), x.view(rows, C), mean, rstd, want_dot=True)
+        dx = K.bn_bwd(dy, x, mean, rstd, gamma, sdy, sdyx, use_batch_stats=training)
+        dgamma = dbeta = None
+        if gamma.requires_grad:
+            dgamma, dbeta = _emit_vgrad(gamma, sdyx), _emit_vgrad(beta, sdy)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, run_mean, run_var, num_batches, training, act=None, p=0.0, eps=1e-5, momentum=0.1):
+    return _BatchNormAct.apply(x, gamma, beta, run_mean, run_var, num_batches, training, act, p, eps, momentum)
+
+
+# ================================================================================================
+# losses
+# ================================================================================================
+class _SeqLoss(Function):
+    @staticmethod
+    def forward(ctx, after, before, logits, ys, labels, olens_i32, pos_weight):
+        after = _c(after) if after is not None else None
+        before = _c(before)
+        logits = _c(logits) if logits is not None else None
+        ys = _c(ys.float())
+        labels = _c(labels.float()) if labels is not None else None
+        out = K.seq_loss_fwd(after, before, logits, ys, labels, olens_i32, pos_weight)
+        ctx.pos_weight = pos_weight
+        ctx.save_for_backward(after, before, logits, ys, labels, olens_i32, out)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_bce):
+        after, before, logits, ys, labels, olens_i32, out = ctx.saved_tensors
+        g1 = _c(g_l1.float()) if g_l1 is not None else None
+        g2 = _c(g_bce.float()) if g_bce is not None else None
+        if g1 is None:
+            g1 = torch.zeros((), dtype=torch.float32, device=before.device)
+        if g2 is None:
+            g2 = torch.zeros((), dtype=torch.float32, device=before.device)
+        da, db, dl = K.seq_loss_bwd(after, before, logits, ys, labels, olens_i32, ctx.pos_weight, out, g1, g2)
+        return da, db, dl, None, None, None, None
+
+
+def seq2seq_loss(after, before, logits, ys, labels, olens_i32, pos_weight=10.0):
+    """(l1, bce): losses/seq2seq_loss.py:30-59; `logits`/`labels` None -> l1 only (losses/l1_loss.py)."""
+    return _SeqLoss.apply(after, before, logits, ys, labels, olens_i32, pos_weight)
+
+
+class _GuidedAttnLoss(Function):
+    @staticmethod
+    def forward(ctx, att, ilens_i32, olens_i32, sigma, alpha):
+        att = _c(att)
+        out = K.guided_attn_loss_fwd(att, ilens_i32, olens_i32, sigma, alpha)
+        ctx.meta = (att.shape, att.dtype, sigma, alpha)
+        ctx.save_for_backward(ilens_i32, olens_i32, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ilens_i32, olens_i32, out = ctx.saved_tensors
+        shape, dtype, sigma, alpha = ctx.meta
+        return K.guided_attn_loss_bwd(shape, dtype, g.device, ilens_i32, olens_i32, sigma, alpha, out, _c(g.float())), None, None, None, None
+
+
+def guided_attention_loss(att, ilens_i32, olens_i32, sigma=0.4, alpha=1.0):
+    return _GuidedAttnLoss.apply(att, ilens_i32, olens_i32, sigma, alpha)
+
+
+# ================================================================================================
+# monotonic alignment search + binarisation loss     reference: modules/alignments.py:281-310
+# ================================================================================================
+class _Viterbi(Function):
+    @staticmethod
+    def forward(ctx, log_p_attn, text_lens_i32, feat_lens_i32):
+        lp = _c(log_p_attn.float())
+        ds, path, binmean = K.mas(lp, text_lens_i32, feat_lens_i32)
+        B = lp.shape[0]
+        bin_loss = -(binmean.sum() / B)
+        ctx.save_for_backward(path, feat_lens_i32)
+        ctx.shape = lp.shape
+        ctx.in_dtype = log_p_attn.dtype
+        ctx.mark_non_differentiable(ds, path)
+        return ds, bin_loss, path
+
+    @staticmethod
+    def backward(ctx, _dds, g, _dpath):
+        path, feat_lens_i32 = ctx.saved_tensors
+        dlogp = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        K.mas_binloss_bwd(path, feat_lens_i32, _c(g.float()), dlogp)
+        return dlogp.to(ctx.in_dtype), None, None
+
+
+def viterbi_decode(log_p_attn, text_lens_i32, feat_lens_i32):
+    """-> (ds (B,T_text) fp32, bin_loss scalar (differentiable), path (B,T_feats) int32)."""
+    return _Viterbi.apply(log_p_attn, text_lens_i32, feat_lens_i32)

@@ -138,7 +138,7 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
 # ----------------------------------------------------------------------------------------------
 # norms / reductions
 # ----------------------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps, res=None, p=0.0, seed=(None, 0), need_stats=True):
+def layernorm_fwd(x, gamma, beta, eps, res=None, p=0.0, seed=(None, 0), need_stats=True, hscale=1.0):
     _need_cuda(x)
     D = x.shape[-1]
     rows = x.numel() // D
@@ -146,18 +146,18 @@ def layernorm_fwd(x, gamma, beta, eps, res=None, p=0.0, seed=(None, 0), need_sta
     s = torch.empty_like(x) if res is not None else None
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if need_stats else None
-    _lib.check(_lib.lib().s2svc_layernorm_fwd(dt(x), rows, D, ptr(x), ptr(res), p, seed[0], seed[1], ptr(gamma), ptr(beta),
+    _lib.check(_lib.lib().s2svc_layernorm_fwd(dt(x), rows, D, ptr(x), ptr(res), p, hscale, seed[0], seed[1], ptr(gamma), ptr(beta),
                                               eps, ptr(y), ptr(s), ptr(mean), ptr(rstd), stream()), "layernorm_fwd")
     return y, s, mean, rstd
 
 
-def layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=None, p=0.0, seed=(None, 0), want_dh=False):
+def layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=None, p=0.0, seed=(None, 0), want_dh=False, hscale=1.0):
     D = s.shape[-1]
     rows = s.numel() // D
     ds = torch.empty_like(s)
     dh = torch.empty_like(s) if want_dh else None
     _lib.check(_lib.lib().s2svc_layernorm_bwd(dt(s), rows, D, ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma),
-                                              ptr(ds_extra), p, seed[0], seed[1], ptr(ds), ptr(dh), stream()),
+                                              ptr(ds_extra), p, hscale, seed[0], seed[1], ptr(ds), ptr(dh), stream()),
                "layernorm_bwd")
     return ds, dh
 
@@ -224,11 +224,11 @@ def attn_softmax_fwd(scores, out_dtype, scale, klen=None, causal=False, bd=None,
     return attn, pdrop
 
 
-def attn_softmax_bwd(attn, dp, scale, p=0.0, seed=(None, 0), Lp=0, rel_mode=0):
+def attn_softmax_bwd(attn, dp, scale, p=0.0, seed=(None, 0), Lp=0, rel_mode=0, dattn=None):
     B, H, T1, T2 = attn.shape
     dscores = torch.empty_like(attn)
     dbd = torch.empty((B, H, T1, Lp), dtype=attn.dtype, device=attn.device) if Lp else None
-    _lib.check(_lib.lib().s2svc_attn_softmax_bwd(dt(attn), B, H, T1, T2, ptr(attn), ptr(dp), scale, p, seed[0], seed[1],
+    _lib.check(_lib.lib().s2svc_attn_softmax_bwd(dt(attn), B, H, T1, T2, ptr(attn), ptr(dp), ptr(dattn), scale, p, seed[0], seed[1],
                                                  ptr(dscores), ptr(dbd), Lp, rel_mode, stream()), "attn_softmax_bwd")
     return dscores, dbd
 
@@ -334,3 +334,77 @@ def mas_binloss_bwd(path, feat_lens_i32, gout, dlogp):
     _lib.check(_lib.lib().s2svc_mas_binloss_bwd(B, Tf, Tx, ptr(path), ptr(feat_lens_i32), ptr(gout), ptr(dlogp), stream()),
                "mas_binloss_bwd")
     return dlogp
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+def seq_loss_fwd(after, before, logits, ys, labels, olens_i32, pos_weight):
+    B, Tm, D = before.shape
+    dev = before.device
+    partial = torch.empty(3 * 1024, dtype=torch.float32, device=dev)
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().s2svc_seq_loss_fwd(dt(before), B, Tm, D, ptr(after), ptr(before), ptr(logits), ptr(ys), ptr(labels),
+                                             ptr(olens_i32), pos_weight, ptr(partial), ptr(out), stream()), "seq_loss_fwd")
+    return out
+
+
+def seq_loss_bwd(after, before, logits, ys, labels, olens_i32, pos_weight, stats, g_l1, g_bce):
+    B, Tm, D = before.shape
+    d_after = torch.empty_like(after) if after is not None else None
+    d_before = torch.empty_like(before)
+    d_logits = torch.empty_like(logits) if logits is not None else None
+    _lib.check(_lib.lib().s2svc_seq_loss_bwd(dt(before), B, Tm, D, ptr(after), ptr(before), ptr(logits), ptr(ys), ptr(labels),
+                                             ptr(olens_i32), pos_weight, ptr(stats), ptr(g_l1), ptr(g_bce), ptr(d_after),
+                                             ptr(d_before), ptr(d_logits), stream()), "seq_loss_bwd")
+    return d_after, d_before, d_logits
+
+
+def guided_attn_loss_fwd(att, ilens_i32, olens_i32, sigma, alpha):
+    B, H, To, Ti = att.shape
+    partial = torch.empty(1024, dtype=torch.float32, device=att.device)
+    out = torch.empty(2, dtype=torch.float32, device=att.device)
+    _lib.check(_lib.lib().s2svc_guided_attn_loss_fwd(dt(att), B, H, To, Ti, ptr(att), ptr(ilens_i32), ptr(olens_i32), sigma, alpha,
+                                                     ptr(partial), ptr(out), stream()), "guided_attn_loss_fwd")
+    return out
+
+
+def guided_attn_loss_bwd(shape, dtype, device, ilens_i32, olens_i32, sigma, alpha, stats, gout):
+    B, H, To, Ti = shape
+    datt = torch.empty(shape, dtype=dtype, device=device)
+    _lib.check(_lib.lib().s2svc_guided_attn_loss_bwd(_DT[dtype], B, H, To, Ti, ptr(ilens_i32), ptr(olens_i32), sigma, alpha,
+                                                     ptr(stats), ptr(gout), ptr(datt), stream()), "guided_attn_loss_bwd")
+    return datt
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser
+# ----------------------------------------------------------------------------------------------
+def adam_step(params, grads, exp_avg, exp_avg_sq, shadow, state, partial, lr, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0,
+              warmup_steps=4000.0):
+    _lib.check(_lib.lib().s2svc_adam_step(params.numel(), ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), ptr(shadow),
+                                          betas[0], betas[1], eps, max_norm, lr, warmup_steps, ptr(partial), ptr(state),
+                                          stream()), "adam_step")
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution helpers
+# ----------------------------------------------------------------------------------------------
+def col2im_s2(dcols, B, T1, F1, C, T2, F2):
+    dx = torch.empty((B, T1, F1, C), dtype=dcols.dtype, device=dcols.device)
+    _lib.check(_lib.lib().s2svc_col2im_s2(dt(dcols), B, T1, F1, C, T2, F2, ptr(dcols), ptr(dx), stream()), "col2im_s2")
+    return dx
+
+
+def interp_nearest(x, Tout):
+    B, Tin, C = x.shape
+    y = torch.empty((B, Tout, C), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().s2svc_interp_nearest(dt(x), B, Tin, Tout, C, ptr(x), ptr(y), stream()), "interp_nearest")
+    return y
+
+
+def interp_nearest_bwd(dy, Tin):
+    B, Tout, C = dy.shape
+    dx = torch.empty((B, Tin, C), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.lib().s2svc_interp_nearest_bwd(dt(dy), B, Tin, Tout, C, ptr(dy), ptr(dx), stream()), "interp_nearest_bwd")
+    return dx

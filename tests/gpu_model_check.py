@@ -1,0 +1,184 @@
+"""Model-level parity on the GPU box: the HIP-backed models of seq2seq_vc_amd against the golden
+vectors that tools/gen_golden.py produced from the imported reference (tests/golden/*.npz).
+
+fp32 compute mode must match the reference's CPU outputs within the north-star tolerance
+(mel L1 <= 1e-4; bit-exact alignment indices); bf16 mode is checked with a loose tolerance.
+`python tests/gpu_model_check.py` prints a PASS/FAIL table; tests/test_gpu_models.py wraps the cases.
+"""
+import json
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from seq2seq_vc_amd.ops import functional as Fn  # noqa: E402
+from seq2seq_vc_amd.ops import kernels as K  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda"
+CASES = []
+
+
+def case(fn):
+    CASES.append(fn)
+    return fn
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = json.loads(bytes(z["__cfg__"]).decode())
+    return cfg, z
+
+
+def model_cfg(cfg):
+    return {k: v for k, v in cfg.items() if not k.startswith("__")}
+
+
+def sd_of(z):
+    return {k[3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("sd.")}
+
+
+def cmp(name, got, ref, atol, rtol=0.0, l1_tol=None):
+    got = torch.as_tensor(got).detach().float().cpu()
+    ref = torch.as_tensor(np.asarray(ref)).float()
+    if got.shape != ref.shape:
+        return False, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    same_inf = torch.isinf(got) & torch.isinf(ref) & (got == ref)
+    err = torch.where(same_inf, torch.zeros_like(got), (got - ref).abs())
+    bad = (err > atol + rtol * ref.abs()) | torch.isnan(err)
+    l1 = err[~torch.isnan(err)].mean().item() if err.numel() else 0.0
+    ok = not bool(bad.any())
+    if l1_tol is not None:
+        ok = ok and l1 <= l1_tol
+    return ok, f"{name}: max_err={err.max().item() if err.numel() else 0:.3e} mean_abs_err={l1:.3e} (atol {atol:g})"
+
+
+def grads_check(model, z, atol, rtol):
+    res = []
+    worst = (0.0, None)
+    nbad = 0
+    for k in [k for k in z.files if k.startswith("grad.")]:
+        p = dict(model.named_parameters())[k[5:]]
+        if p.grad is None:
+            res.append((False, f"grad {k[5:]}: missing"))
+            continue
+        g, r = p.grad.detach().float().cpu(), torch.from_numpy(z[k]).float()
+        err = (g - r).abs()
+        bound = atol + rtol * r.abs().max()
+        if err.max() > bound or torch.isnan(err).any():
+            nbad += 1
+            if nbad <= 6:
+                res.append((False, f"grad {k[5:]}: max_err={err.max():.3e} ref_max={r.abs().max():.3e}"))
+        rel = (err.max() / (r.abs().max() + 1e-12)).item()
+        if rel > worst[0]:
+            worst = (rel, k[5:])
+    res.append((nbad == 0, f"param grads: {nbad} of {len([k for k in z.files if k.startswith('grad.')])} off; worst rel err {worst[0]:.3e} at {worst[1]}"))
+    return res
+
+
+def run_ar(name, dtype, model_cls_name):
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    cfg, z = load(name)
+    Fn.set_compute_dtype(dtype)
+    K.manual_seed(1)
+    model = getattr(M, model_cls_name)(**model_cfg(cfg))
+    model.load_state_dict(sd_of(z))
+    model.to(DEV)
+    # deterministic: all dropout off (golden vectors were generated with dropout 0)
+    for m in model.modules():
+        if hasattr(m, "dropout_rate"):
+            m.dropout_rate = 0.0
+    model.train(cfg.get("__train__", True))
+    t = lambda k: torch.from_numpy(z[k])
+    xs = t("in.xs").to(DEV)
+    after, before, logits, ys_, labels_, olens_, (att_ws, ilens_ds, olens_in) = model(
+        xs, t("in.ilens"), t("in.ys").to(DEV), t("in.labels").to(DEV), t("in.olens"))
+    f32 = dtype == torch.float32
+    a = 1e-4 if f32 else 0.15
+    res = [cmp(f"{name}[{dtype}] after_outs", after, z["out.after"], a * (4 if f32 else 1), l1_tol=1e-4 if f32 else 0.05),
+           cmp(f"{name}[{dtype}] before_outs", before, z["out.before"], a, l1_tol=1e-4 if f32 else 0.05),
+           cmp(f"{name}[{dtype}] logits", logits, z["out.logits"], a),
+           cmp(f"{name}[{dtype}] ys", ys_, z["out.ys"], 0), cmp(f"{name}[{dtype}] labels", labels_, z["out.labels"], 0),
+           cmp(f"{name}[{dtype}] olens", olens_, z["out.olens"], 0)]
+    if "out.olens_in" in z.files:
+        res.append(cmp(f"{name}[{dtype}] olens_in", olens_in, z["out.olens_in"], 0))
+    if "out.ilens_ds" in z.files:
+        res.append(cmp(f"{name}[{dtype}] ilens_ds", ilens_ds, z["out.ilens_ds"], 0))
+    for i in range(len(att_ws) if isinstance(att_ws, list) else 0):
+        res.append(cmp(f"{name}[{dtype}] att_ws[{i}]", att_ws[i], z[f"out.att_ws.{i}"], 2e-5 if f32 else 2e-2))
+    crit = L.Seq2SeqLoss(bce_pos_weight=10.0)
+    l1, bce = crit(after, before, logits, ys_, labels_, olens_)
+    res.append(cmp(f"{name}[{dtype}] l1_loss", l1, z["loss.l1"], 2e-5 if f32 else 2e-2))
+    res.append(cmp(f"{name}[{dtype}] bce_loss", bce, z["loss.bce"], 2e-5 if f32 else 2e-2))
+    if "loss.guided_attn" in z.files:
+        ga = L.GuidedMultiHeadAttentionLoss(sigma=0.4, alpha=1.0)(att_ws[0], ilens_ds, olens_in)
+        res.append(cmp(f"{name}[{dtype}] guided_attn_loss", ga, z["loss.guided_attn"], 2e-6 if f32 else 2e-3))
+    (l1 + bce).backward()
+    res += grads_check(model, z, 2e-5 if f32 else 2e-2, 2e-3 if f32 else 0.1)
+    for k in [k for k in z.files if k.startswith("sd_after.")]:
+        v = model.state_dict()[k[9:]]
+        res.append(cmp(f"{name}[{dtype}] buffer {k[9:]}", v, z[k], 2e-5 if f32 else 2e-2))
+    Fn.set_compute_dtype(torch.float32)
+    return res
+
+
+@case
+def vtn_tiny_train_fp32():
+    return run_ar("vtn_tiny_train", torch.float32, "VTN")
+
+
+@case
+def vtn_tiny_eval_fp32():
+    return run_ar("vtn_tiny_eval", torch.float32, "VTN")
+
+
+@case
+def vtn_tiny_train_bf16():
+    return run_ar("vtn_tiny_train", torch.bfloat16, "VTN")
+
+
+@case
+def tts_tiny_train_fp32():
+    return run_ar("tts_tiny_train", torch.float32, "TransformerTTS")
+
+
+@case
+def vtn_tiny_inference_fp32():
+    from seq2seq_vc_amd import models as M
+    cfg, z = load("vtn_tiny_inference")
+    Fn.set_compute_dtype(torch.float32)
+    model = M.VTN(**model_cfg(cfg))
+    model.load_state_dict(sd_of(z))
+    model.to(DEV).eval()
+    for m in model.modules():
+        if hasattr(m, "dropout_rate"):
+            m.dropout_rate = 0.0
+    outs, probs, att = model.inference(torch.from_numpy(z["in.x"]).to(DEV), cfg["__inference__"])
+    return [cmp("vtn inference outs", outs, z["out.outs"], 4e-4, l1_tol=1e-4), cmp("vtn inference probs", probs, z["out.probs"], 1e-4),
+            cmp("vtn inference att_ws", att, z["out.att_ws"], 2e-5)]
+
+
+def main(selected=None):
+    nfail = 0
+    for fn in CASES:
+        if selected and fn.__name__ not in selected:
+            continue
+        try:
+            results = fn()
+        except Exception:
+            results = [(False, f"{fn.__name__}: EXCEPTION\n{traceback.format_exc()}")]
+        for ok, msg in results:
+            print(("PASS " if ok else "FAIL ") + msg)
+            nfail += 0 if ok else 1
+        torch.cuda.synchronize()
+    print(f"== {nfail} failures")
+    return nfail
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(sys.argv[1:]) else 0)
