@@ -119,6 +119,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported FIRST: it carries its own libamdhip64; loading ours afterwards makes the
+    # dynamic linker bind this library to the SAME HIP runtime instance (one device context, shared streams).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the seq2seq-vc HIP kernels are not built. Run "

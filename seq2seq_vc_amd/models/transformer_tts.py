@@ -48,7 +48,7 @@ class TransformerTTS(_ARSeq2Seq):
         if ol.max() != ys.shape[1]:
             ys, labels = ys[:, : ol.max()], labels[:, : ol.max()]
         xs = TF.pad(xs, [0, 1], "constant", self.padding_idx)           # transformer_tts.py:139-142: append <eos>
-        xs[torch.arange(xs.shape[0], device=xs.device), torch.tensor(il.host, device=xs.device)] = self.eos
+        xs[torch.arange(xs.shape[0], device=xs.device), il.dev.long()] = self.eos
         il1 = il.map(lambda v: v + 1)
         hs, hs_lens = self.encoder(xs, il1)
         after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens)

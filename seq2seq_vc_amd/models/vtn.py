@@ -54,7 +54,7 @@ class _ARSeq2Seq(nn.Module):
             olens_out = olens.new_tensor(new) if isinstance(olens, torch.Tensor) else torch.tensor(new)
             mx = max(new)
             ys, labels = ys[:, :mx], labels[:, :mx]
-            idx = torch.tensor(new, device=labels.device).sub_(1).unsqueeze(1)
+            idx = (Mo.Lens(new, labels.device).dev.long() - 1).unsqueeze(1)
             labels = torch.scatter(labels, 1, idx, 1.0)
         olens_in = olens.new_tensor(olens_in_h.host) if isinstance(olens, torch.Tensor) else torch.tensor(olens_in_h.host)
         return after, before, logits, ys, labels, olens_out, olens_in
