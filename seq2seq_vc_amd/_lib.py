@@ -103,8 +103,16 @@ _SIGS = {
     "s2svc_col2im_s2": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_interp_nearest": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_interp_nearest_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "s2svc_dwconv": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
+    "s2svc_dwconv_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
+    "s2svc_pairwise_l2_logsoftmax": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_pairwise_l2_bwd_g": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_rowscale": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_gauss_upsample_probs": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp],
+    "s2svc_forward_sum": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_betabinom_prior": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
 }
-_RET64 = {"s2svc_mas_ws_bytes": [c_i32, c_i32, c_i32]}
+_RET64 = {"s2svc_mas_ws_bytes": [c_i32, c_i32, c_i32], "s2svc_forward_sum_ws_bytes": [c_i32, c_i32, c_i32]}
 
 _lib = None
 

@@ -1,0 +1,194 @@
+// AAS alignment kernels: pairwise -L2 distance + masked log-softmax (and its backward), and the
+// Gaussian-upsampling attention weights.
+//
+// reference: modules/alignments.py:51-59 -- `dist = feats.unsqueeze(2) - text.unsqueeze(1)` materialises a
+// (B, T_feats, T_text, adim) tensor (1.6 GB at the vc2 config) before `torch.norm`; here the difference
+// is formed in registers and reduced with wave shuffles, so HBM sees B*(T_f+T_x)*A in and B*T_f*T_x out.
+// The direct sum of squared differences (not the GEMM form |f|^2+|t|^2-2f.t) keeps the reference's rounding.
+//            modules/length_regulator.py:111-154 (GaussianUpsampling, delta = 0.1).
+#include "common.h"
+#include "../../include/s2svc_hip.h"
+
+namespace {
+
+// one wavefront per (b, i) feature frame; block = 4 frames.  dist[b,i,j] (fp32) is saved for backward.
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise_fwd_kernel(int B, int Tf, int Tx, int A, const T* __restrict__ feats,
+                                                           const T* __restrict__ text, const int32_t* __restrict__ tlen,
+                                                           float* __restrict__ logp, float* __restrict__ dist) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Tf) return;
+  const int b = (int)(row / Tf);
+  const int tl = tlen ? (tlen[b] < Tx ? tlen[b] : Tx) : Tx;
+  extern __shared__ float shd[];  // 4 wavefronts x Tx distances
+  const T* f = feats + row * A;
+  const T* tx = text + (int64_t)b * Tx * A;
+  float* dr = shd + (threadIdx.x >> 6) * Tx;
+  float* dg = dist + row * Tx;
+  float* lr = logp + row * Tx;
+  const float NINF = -__builtin_huge_valf();
+  float mx = NINF;
+  for (int j = 0; j < Tx; ++j) {
+    float acc = 0.f;
+    const T* tj = tx + (int64_t)j * A;
+    for (int a = lane; a < A; a += 64) {
+      const float d = ldf(f + a) - ldf(tj + a);
+      acc += d * d;
+    }
+    const float dd = sqrtf(wave_sum(acc));
+    if (lane == 0) { dr[j] = dd; dg[j] = dd; }
+    if (j < tl) mx = fmaxf(mx, -dd);
+  }
+  __builtin_amdgcn_wave_barrier();  // LDS ops of one wavefront retire in order: the reads below see lane 0's writes
+  float s = 0.f;
+  for (int j = lane; j < tl; j += 64) s += expf(-dr[j] - mx);
+  const float lse = logf(wave_sum(s)) + mx;
+  for (int j = lane; j < Tx; j += 64) lr[j] = (j < tl) ? (-dr[j] - lse) : NINF;
+}
+
+// G[b,i,j] = d(loss)/d(dist) / dist, with d(loss)/d(score) = dlogp - softmax*sum_j dlogp, score = -dist.
+// Also row sums rs[b,i] = sum_j G and (via a second pass on the host side) column sums.
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise_bwd_g_kernel(int B, int Tf, int Tx, const float* __restrict__ logp,
+                                                             const float* __restrict__ dist, const float* __restrict__ dlogp,
+                                                             const int32_t* __restrict__ tlen, T* __restrict__ G,
+                                                             float* __restrict__ rowsum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Tf) return;
+  const int b = (int)(row / Tf);
+  const int tl = tlen ? (tlen[b] < Tx ? tlen[b] : Tx) : Tx;
+  float sg = 0.f;
+  for (int j = lane; j < tl; j += 64) sg += dlogp[row * Tx + j];
+  sg = wave_sum(sg);
+  float rs = 0.f;
+  for (int j = lane; j < Tx; j += 64) {
+    float g = 0.f;
+    if (j < tl) {
+      const float dscore = dlogp[row * Tx + j] - expf(logp[row * Tx + j]) * sg;
+      const float dd = dist[row * Tx + j];
+      g = dd > 0.f ? (-dscore) / dd : 0.f;
+    }
+    stf(G + row * Tx + j, g);
+    rs += g;
+  }
+  rs = wave_sum(rs);
+  if (lane == 0) rowsum[row] = rs;
+}
+
+// out[r, c] = x[r, c] * s[r]
+template <typename T>
+__global__ void rowscale_kernel(int64_t rows, int D, const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ out) {
+  const int64_t n = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    stf(out + i, ldf(x + i) * s[i / D]);
+}
+
+// Gaussian upsampling weights: c_j = cumsum(ds)_j - ds_j/2 ; e[t,j] = -delta*(t_eff - c_j)^2 with
+// t_eff = t if t < flen[b] else 0 (the reference multiplies t by the frame mask) ; softmax over valid j.
+template <typename T>
+__global__ __launch_bounds__(64) void gauss_probs_kernel(int B, int Tf, int Tx, const float* __restrict__ ds,
+                                                         const int32_t* __restrict__ tlen, const int32_t* __restrict__ flen,
+                                                         float delta, T* __restrict__ P) {
+  extern __shared__ float cpos[];  // Tx centres
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int tl = tlen ? (tlen[b] < Tx ? tlen[b] : Tx) : Tx;
+  const int fl = flen ? flen[b] : Tf;
+  if (lane == 0) {
+    float run = 0.f;
+    for (int j = 0; j < Tx; ++j) {
+      const float d = ds[(int64_t)b * Tx + j];
+      run += d;
+      cpos[j] = run - d * 0.5f;
+    }
+  }
+  __syncthreads();
+  const float NINF = -__builtin_huge_valf();
+  for (int t = 0; t < Tf; ++t) {
+    const float te = (t < fl) ? (float)t : 0.f;
+    float mx = NINF;
+    for (int j = lane; j < tl; j += 64) {
+      const float d = te - cpos[j];
+      mx = fmaxf(mx, -delta * d * d);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < tl; j += 64) {
+      const float d = te - cpos[j];
+      s += expf(-delta * d * d - mx);
+    }
+    s = wave_sum(s);
+    T* pr = P + ((int64_t)b * Tf + t) * Tx;
+    for (int j = lane; j < Tx; j += 64) {
+      float v = 0.f;
+      if (j < tl) {
+        const float d = te - cpos[j];
+        v = expf(-delta * d * d - mx) / s;
+      }
+      stf(pr + j, v);
+    }
+  }
+}
+
+inline int ew_blocks(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int s2svc_pairwise_l2_logsoftmax(int dtype, int B, int Tf, int Tx, int A, const void* feats, const void* text,
+                                            const int32_t* text_lens, float* logp, float* dist, void* stream) {
+  S2S_REQUIRE(B >= 0 && Tf > 0 && Tx > 0 && A > 0, "pairwise_l2_logsoftmax: bad shape");
+  S2S_REQUIRE(Tx <= 3072, "pairwise_l2_logsoftmax: T_text too large for the LDS row buffer");
+  const int64_t rows = (int64_t)B * Tf;
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(pairwise_fwd_kernel<float>, grid, block, 4 * Tx * sizeof(float), st, B, Tf, Tx, A, (const float*)feats, (const float*)text, text_lens, logp, dist);
+  else
+    hipLaunchKernelGGL(pairwise_fwd_kernel<bf16_t>, grid, block, 4 * Tx * sizeof(float), st, B, Tf, Tx, A, (const bf16_t*)feats, (const bf16_t*)text, text_lens, logp, dist);
+  S2S_CHECK_LAUNCH("pairwise_fwd_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_pairwise_l2_bwd_g(int dtype, int B, int Tf, int Tx, const float* logp, const float* dist,
+                                       const float* dlogp, const int32_t* text_lens, void* G, float* rowsum, void* stream) {
+  const int64_t rows = (int64_t)B * Tf;
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(pairwise_bwd_g_kernel<float>, grid, block, 0, st, B, Tf, Tx, logp, dist, dlogp, text_lens, (float*)G, rowsum);
+  else
+    hipLaunchKernelGGL(pairwise_bwd_g_kernel<bf16_t>, grid, block, 0, st, B, Tf, Tx, logp, dist, dlogp, text_lens, (bf16_t*)G, rowsum);
+  S2S_CHECK_LAUNCH("pairwise_bwd_g_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_rowscale(int dtype, int64_t rows, int D, const void* x, const float* s, void* out, void* stream) {
+  const int64_t n = rows * D;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(rowscale_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, rows, D, (const float*)x, s, (float*)out);
+  else
+    hipLaunchKernelGGL(rowscale_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, rows, D, (const bf16_t*)x, s, (bf16_t*)out);
+  S2S_CHECK_LAUNCH("rowscale_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_gauss_upsample_probs(int dtype, int B, int Tf, int Tx, const float* ds, const int32_t* text_lens,
+                                          const int32_t* feat_lens, float delta, void* P, void* stream) {
+  if (B == 0) return 0;
+  S2S_REQUIRE(Tx * 4 <= 48 * 1024, "gauss_upsample_probs: T_text too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(gauss_probs_kernel<float>, dim3(B), dim3(64), Tx * sizeof(float), st, B, Tf, Tx, ds, text_lens, feat_lens, delta, (float*)P);
+  else
+    hipLaunchKernelGGL(gauss_probs_kernel<bf16_t>, dim3(B), dim3(64), Tx * sizeof(float), st, B, Tf, Tx, ds, text_lens, feat_lens, delta, (bf16_t*)P);
+  S2S_CHECK_LAUNCH("gauss_probs_kernel");
+  return 0;
+}

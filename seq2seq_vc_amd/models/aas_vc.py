@@ -1,0 +1,260 @@
+"""AAS-VC (non-autoregressive VC with automatic alignment search), MI355X-native drop-in for
+`seq2seq_vc.models.AASVC` (reference models/aas_vc.py:39-603): same constructor keywords, `forward`
+returning the same dict, `inference`, state_dict keys, and the `viterbi_func` slot (:132).
+
+Hot-path differences that do not change results: the pairwise-distance tensor (B,T_f,T_x,adim) is never
+materialised; the alignment search, duration bincount and binarisation loss run on the GPU in one
+launch (no per-utterance device->host->device hop); masks are length vectors.
+"""
+import torch
+from torch import nn
+
+from .. import modules as Mo
+from ..conformer import ConformerEncoder
+from ..ops import functional as Fn
+from ..ops import functional_aas as FA
+from ..sdp import DurationPredictor, StochasticDurationPredictor
+
+MAX_DP_OUTPUT = 10
+
+
+class AlignmentModule(nn.Module):
+    """Alignment learning framework (reference modules/alignments.py:12-60)."""
+
+    def __init__(self, adim, odim):
+        super().__init__()
+        self.t_conv1 = nn.Conv1d(adim, adim, kernel_size=3, padding=1)
+        self.t_conv2 = nn.Conv1d(adim, adim, kernel_size=1, padding=0)
+        self.f_conv1 = nn.Conv1d(odim, adim, kernel_size=3, padding=1)
+        self.f_conv2 = nn.Conv1d(adim, adim, kernel_size=3, padding=1)
+        self.f_conv3 = nn.Conv1d(adim, adim, kernel_size=1, padding=0)
+
+    def forward(self, text, feats, text_lens=None):
+        """text (B,T_text,adim), feats (B,T_feats,odim), text_lens: Lens -> log_p_attn (B,T_feats,T_text) fp32."""
+        t = Fn.conv1d(text, self.t_conv1.weight, self.t_conv1.bias, act="relu")
+        t = Fn.linear(t, self.t_conv2.weight, self.t_conv2.bias)
+        f = Fn.conv1d(feats, self.f_conv1.weight, self.f_conv1.bias, act="relu")
+        f = Fn.conv1d(f, self.f_conv2.weight, self.f_conv2.bias, act="relu")
+        f = Fn.linear(f, self.f_conv3.weight, self.f_conv3.bias)
+        return FA.pairwise_logsoftmax(f, t, None if text_lens is None else text_lens.dev)
+
+
+def viterbi_decode(log_p_attn, text_lengths, feats_lengths):
+    """GPU replacement of modules/alignments.py:281-310: (ds (B,T_text) fp32, bin_loss scalar)."""
+    dev = log_p_attn.device
+    tl, fl = Mo.Lens.of(text_lengths, dev), Mo.Lens.of(feats_lengths, dev)
+    ds, bin_loss, _ = Fn.viterbi_decode(log_p_attn, tl.dev, fl.dev)
+    return ds, bin_loss
+
+
+class GaussianUpsampling(nn.Module):
+    def __init__(self, delta=0.1):
+        super().__init__()
+        self.delta = delta
+
+    def forward(self, hs, ds, feat_lens, text_lens, T_feats):
+        return FA.gaussian_upsample(hs, ds, None if text_lens is None else text_lens.dev,
+                                    None if feat_lens is None else feat_lens.dev, T_feats, self.delta)
+
+
+class AASVC(nn.Module):
+    def __init__(self, idim, odim, adim: int = 384, aheads: int = 4, elayers: int = 6, eunits: int = 1536, dlayers: int = 6,
+                 dunits: int = 1536, postnet_layers: int = 5, postnet_chans: int = 512, postnet_filts: int = 5,
+                 positionwise_layer_type: str = "conv1d", positionwise_conv_kernel_size: int = 1,
+                 use_scaled_pos_enc: bool = True, use_batch_norm: bool = True, encoder_input_layer: str = "linear",
+                 encoder_input_conv_kernel_size: int = 3, encoder_normalize_before: bool = False,
+                 decoder_normalize_before: bool = False, encoder_concat_after: bool = False,
+                 decoder_concat_after: bool = False, duration_predictor_use_encoder_outputs: bool = True,
+                 duration_predictor_input_dim: int = None, duration_predictor_layers: int = 2,
+                 duration_predictor_chans: int = 384, duration_predictor_kernel_size: int = 3,
+                 encoder_reduction_factor: int = 1, post_encoder_reduction_factor: int = 1,
+                 decoder_reduction_factor: int = 1, encoder_type: str = "conformer", decoder_type: str = "conformer",
+                 duration_predictor_type: str = "deterministic", conformer_pos_enc_layer_type: str = "rel_pos",
+                 conformer_self_attn_layer_type: str = "rel_selfattn", use_macaron_style_in_conformer: bool = True,
+                 use_cnn_in_conformer: bool = True, conformer_enc_kernel_size: int = 7, conformer_dec_kernel_size: int = 31,
+                 spk_embed_dim: int = None, spk_embed_integration_type: str = "add",
+                 transformer_enc_dropout_rate: float = 0.1, transformer_enc_positional_dropout_rate: float = 0.1,
+                 transformer_enc_attn_dropout_rate: float = 0.1, transformer_dec_dropout_rate: float = 0.1,
+                 transformer_dec_positional_dropout_rate: float = 0.1, transformer_dec_attn_dropout_rate: float = 0.1,
+                 duration_predictor_dropout_rate: float = 0.1, postnet_dropout_rate: float = 0.5,
+                 init_type: str = "xavier_uniform", use_masking: bool = False, use_weighted_masking: bool = False,
+                 diffsinger_denoiser_residual_channels: int = 256, prodiff_denoiser_layers: int = 20,
+                 prodiff_denoiser_channels: int = 256, prodiff_diffusion_steps: int = 1000,
+                 prodiff_diffusion_timescale: int = 1, prodiff_diffusion_beta: float = 40.0,
+                 prodiff_diffusion_scheduler: str = "vpsde", prodiff_diffusion_cycle_ln: int = 1,
+                 stochastic_duration_predictor_kernel_size: int = 3,
+                 stochastic_duration_predictor_dropout_rate: float = 0.5, stochastic_duration_predictor_flows: int = 4,
+                 stochastic_duration_predictor_dds_conv_layers: int = 3,
+                 stochastic_duration_predictor_noise_scale: float = 0.8):
+        nn.Module.__init__(self)
+        self.idim, self.odim = idim, odim
+        if spk_embed_dim is not None:
+            raise NotImplementedError("speaker-embedding integration is out of scope (no recipe config uses it)")
+        self.spk_embed_dim = None
+        self.encoder_reduction_factor = encoder_reduction_factor
+        self.post_encoder_reduction_factor = post_encoder_reduction_factor
+        self.decoder_reduction_factor = decoder_reduction_factor
+        self.encoder_type, self.decoder_type = encoder_type, decoder_type
+        self.duration_predictor_type = duration_predictor_type
+        self.use_scaled_pos_enc = use_scaled_pos_enc
+        self.encoder_input_layer = encoder_input_layer
+        self.duration_predictor_use_encoder_outputs = duration_predictor_use_encoder_outputs
+        self.viterbi_func = viterbi_decode
+        self.stochastic_duration_predictor_noise_scale = stochastic_duration_predictor_noise_scale
+        if encoder_type != "conformer" or decoder_type != "conformer":
+            raise NotImplementedError("only the conformer encoder/decoder of the vc2 recipes is supported")
+
+        self.encoder = ConformerEncoder(
+            idim=idim * encoder_reduction_factor, attention_dim=adim, attention_heads=aheads, linear_units=eunits,
+            num_blocks=elayers, input_layer=encoder_input_layer, dropout_rate=transformer_enc_dropout_rate,
+            positional_dropout_rate=transformer_enc_positional_dropout_rate,
+            attention_dropout_rate=transformer_enc_attn_dropout_rate, normalize_before=encoder_normalize_before,
+            concat_after=encoder_concat_after, positionwise_layer_type=positionwise_layer_type,
+            positionwise_conv_kernel_size=positionwise_conv_kernel_size, macaron_style=use_macaron_style_in_conformer,
+            pos_enc_layer_type=conformer_pos_enc_layer_type, selfattention_layer_type=conformer_self_attn_layer_type,
+            use_cnn_module=use_cnn_in_conformer, cnn_module_kernel=conformer_enc_kernel_size)
+        if duration_predictor_type == "deterministic":
+            self.duration_predictor = DurationPredictor(idim=adim, n_layers=duration_predictor_layers,
+                                                        n_chans=duration_predictor_chans,
+                                                        kernel_size=duration_predictor_kernel_size,
+                                                        dropout_rate=duration_predictor_dropout_rate)
+        elif duration_predictor_type == "stochastic":
+            self.duration_predictor = StochasticDurationPredictor(
+                channels=adim, kernel_size=stochastic_duration_predictor_kernel_size,
+                dropout_rate=stochastic_duration_predictor_dropout_rate, flows=stochastic_duration_predictor_flows,
+                dds_conv_layers=stochastic_duration_predictor_dds_conv_layers, global_channels=-1)
+        else:
+            raise ValueError(f"Duration predictor type: {duration_predictor_type} is not supported.")
+        if not self.duration_predictor_use_encoder_outputs:
+            self.duration_predictor_projection = Mo.Conv2dSubsampling(duration_predictor_input_dim, adim, 0.0, use_pos_enc=False)
+        self.alignment_module = AlignmentModule(adim * post_encoder_reduction_factor, odim * decoder_reduction_factor)
+        self.length_regulator = GaussianUpsampling()
+        self.decoder = ConformerEncoder(
+            idim=0, attention_dim=adim * post_encoder_reduction_factor, attention_heads=aheads, linear_units=dunits,
+            num_blocks=dlayers, input_layer=None, dropout_rate=transformer_dec_dropout_rate,
+            positional_dropout_rate=transformer_dec_positional_dropout_rate,
+            attention_dropout_rate=transformer_dec_attn_dropout_rate, normalize_before=decoder_normalize_before,
+            concat_after=decoder_concat_after, positionwise_layer_type=positionwise_layer_type,
+            positionwise_conv_kernel_size=positionwise_conv_kernel_size, macaron_style=use_macaron_style_in_conformer,
+            pos_enc_layer_type=conformer_pos_enc_layer_type, selfattention_layer_type=conformer_self_attn_layer_type,
+            use_cnn_module=use_cnn_in_conformer, cnn_module_kernel=conformer_dec_kernel_size)
+        self.feat_out = nn.Linear(adim * post_encoder_reduction_factor, odim * decoder_reduction_factor)
+        self.postnet = None if postnet_layers == 0 else Mo.Postnet(
+            idim=idim, odim=odim, n_layers=postnet_layers, n_chans=postnet_chans, n_filts=postnet_filts,
+            use_batch_norm=use_batch_norm, dropout_rate=postnet_dropout_rate)
+
+    # ---------------------------------------------------------------------------------------------
+    def _forward(self, xs, ilens, ys=None, olens=None, dp_inputs=None, dplens=None, spembs=None, is_inference=False):
+        ret = {}
+        dev = xs.device
+        il = Mo.Lens.of(ilens, dev)
+        ol = Mo.Lens.of(olens, dev) if olens is not None else None
+        er, pr, dr = self.encoder_reduction_factor, self.post_encoder_reduction_factor, self.decoder_reduction_factor
+        if er > 1:
+            b, tmax, dim = xs.shape
+            if tmax % er != 0:
+                xs = xs[:, : -(tmax % er)]
+            xs = xs.contiguous().view(b, tmax // er, dim * er)
+            il = il.map(lambda v: v // er)
+        hs, _ = self.encoder(Fn.to_compute(xs), il)
+        if self.encoder_input_layer == "conv2d":
+            il = il.map(lambda v: ((v - 2 + 1) // 2 - 2 + 1) // 2)
+        if pr > 1:
+            b, tmax, dim = hs.shape
+            if tmax % pr != 0:
+                hs = hs[:, : -(tmax % pr)]
+            hs = hs.contiguous().view(b, tmax // pr, dim * pr)
+            il = il.map(lambda v: v // pr)
+        if self.duration_predictor_use_encoder_outputs:
+            dpi = hs
+        else:
+            dpi, _ = self.duration_predictor_projection(Fn.to_compute(dp_inputs), None)
+            dpi = FA.interp_nearest(dpi, hs.shape[1])
+        olr = ol
+        if dr > 1 and ys is not None:
+            b, tmax, dim = ys.shape
+            if tmax % dr != 0:
+                ys = ys[:, : -(tmax % dr)]
+            ys = ys.contiguous().view(b, tmax // dr, dim * dr)
+            olr = ol.map(lambda v: v // dr)
+        Tx = hs.shape[1]
+        il_c = il.clamp(Tx)
+        stochastic = self.duration_predictor_type == "stochastic"
+        tmask = (torch.arange(Tx, device=dev)[None, :] < il_c.dev[:, None])     # (B, T_text) non-pad
+        if is_inference:
+            log_p_attn, ds, bin_loss = None, None, 0.0
+            if ys is not None:
+                log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c)
+                ds, bin_loss = self.viterbi_func(log_p_attn, il_c, olr)
+            if stochastic:
+                d_outs = self.duration_predictor(dpi.transpose(1, 2), tmask.unsqueeze(1), inverse=True,
+                                                 noise_scale=self.stochastic_duration_predictor_noise_scale).squeeze(1)
+            else:
+                d_outs = self.duration_predictor.inference(dpi, None)
+            d_outs = torch.clamp(d_outs, max=MAX_DP_OUTPUT)
+            ret["d_outs"] = d_outs
+            dsf = d_outs.float()
+            if float(dsf.sum()) == 0:
+                dsf = dsf.clone()
+                dsf[dsf.sum(dim=1).eq(0)] = 1
+            T_feats = int(dsf.sum())
+            hs = self.length_regulator(hs, dsf, None, il_c, T_feats)
+            dec_lens = None
+        else:
+            log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c)
+            ds, bin_loss = self.viterbi_func(log_p_attn, il_c, olr)
+            if stochastic:
+                dur_nll = self.duration_predictor(dpi.transpose(1, 2), tmask.unsqueeze(1), w=ds.unsqueeze(1))
+                ret["dur_nll"] = dur_nll / torch.sum(tmask)
+            else:
+                d_outs = self.duration_predictor(dpi, il_c)
+                ret["d_outs"] = torch.clamp(d_outs, max=MAX_DP_OUTPUT)
+            hs = self.length_regulator(hs, ds, olr, il_c, olr.max())
+            dec_lens = olr
+        zs, _ = self.decoder(hs, dec_lens)
+        before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, self.odim)
+        after = before if self.postnet is None else Fn.add_dropout(before, self.postnet(before), 0.0)
+        ret["before_outs"], ret["after_outs"] = before, after
+        ret["ds"] = ds
+        ret["ilens"] = self._lens_like(ilens, il.host)
+        ret["bin_loss"] = bin_loss
+        ret["log_p_attn"] = log_p_attn
+        ret["olens_reduced"] = self._lens_like(olens, olr.host) if olr is not None else None
+        return ret
+
+    @staticmethod
+    def _lens_like(proto, values):
+        if isinstance(proto, torch.Tensor):
+            return proto.new_tensor(list(values))
+        return torch.tensor(list(values))
+
+    def forward(self, src_speech, src_speech_lengths, tgt_speech, tgt_speech_lengths, dp_inputs=None, dp_lengths=None,
+                spembs=None):
+        """-> dict(before_outs, after_outs, ds, ilens, bin_loss, log_p_attn, olens_reduced, dur_nll | d_outs, olens, ys)."""
+        dev = src_speech.device
+        il, ol = Mo.Lens.of(src_speech_lengths, dev), Mo.Lens.of(tgt_speech_lengths, dev)
+        xs, ys = src_speech[:, : il.max()], tgt_speech[:, : ol.max()]
+        ret = self._forward(xs, src_speech_lengths, ys, tgt_speech_lengths, dp_inputs=dp_inputs, dplens=dp_lengths,
+                            spembs=spembs, is_inference=False)
+        olens = tgt_speech_lengths
+        if self.decoder_reduction_factor > 1:
+            new = [v - v % self.decoder_reduction_factor for v in ol.host]
+            olens = self._lens_like(tgt_speech_lengths, new)
+            ys = ys[:, : max(new)]
+        ret["olens"], ret["ys"] = olens, ys
+        return ret
+
+    @torch.no_grad()
+    def inference(self, src_speech, tgt_speech=None, spembs=None, dp_input=None, use_teacher_forcing=False):
+        x, y = src_speech, tgt_speech
+        ilens = torch.tensor([x.shape[0]], dtype=torch.long)
+        ys = y.unsqueeze(0) if y is not None else None
+        olens = torch.tensor([y.shape[0]], dtype=torch.long) if y is not None else None
+        if use_teacher_forcing:
+            raise NotImplementedError("teacher-forced inference is broken in the reference (models/aas_vc.py:572) and unused")
+        ret = self._forward(x.unsqueeze(0), ilens, ys=ys, olens=olens, dp_inputs=None if dp_input is None else dp_input.unsqueeze(0),
+                            is_inference=True)
+        outs, d_outs = ret["after_outs"], ret["d_outs"]
+        if ret["ds"] is None and ret["log_p_attn"] is None:
+            return outs[0].float(), d_outs[0]
+        return outs[0].float(), d_outs[0], ret["ds"][0], ret["log_p_attn"][0], ret["ilens"][0]

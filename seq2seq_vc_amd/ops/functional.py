@@ -112,6 +112,8 @@ class _Linear(Function):
                 K.gemm(K.operand(dy2, N, layout=K.RC), K.operand(x2, Kd, layout=K.RC), N, Kd, M, out, in_dtype=dtype,
                        splitk=sk, accumulate=acc)
             dw = _emit_wgrad(weight, (N, Kd), wr)
+            if dw is not None:
+                dw = dw.view(weight.shape)  # 1x1 Conv1d weights (N, K, 1) are accepted as Linear weights
         if ctx.has_bias and bias.requires_grad:
             s, _ = K.colreduce(0, dy2)
             db = _emit_vgrad(bias, s)

@@ -1,0 +1,149 @@
+"""Differentiable AAS-VC / Conformer specific ops (forward and backward are HIP kernels)."""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from . import kernels_aas as KA
+from .functional import _c, _emit_vgrad
+
+
+class _DwConv(Function):
+    """Depthwise Conv1d on channel-last activations (conformer/convolution.py:42-51; vits/flow.py:137-146)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dil):
+        x = _c(x)
+        ks = weight.shape[-1]
+        y = KA.dwconv(x, weight.detach(), bias.detach() if bias is not None else None, ks, dil)
+        ctx.params = (weight, bias)
+        ctx.meta = (ks, dil)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        weight, bias = ctx.params
+        ks, dil = ctx.meta
+        dy = _c(dy)
+        dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if weight.requires_grad:
+            dw = _emit_vgrad(weight, KA.dwconv_wgrad(x, dy, ks, dil))
+        if bias is not None and bias.requires_grad:
+            s, _ = K.colreduce(0, dy.view(-1, dy.shape[-1]))
+            db = _emit_vgrad(bias, s)
+        return dx, dw, db, None
+
+
+def dwconv1d(x, weight, bias=None, dilation=1):
+    return _DwConv.apply(x, weight, bias, dilation)
+
+
+class _PairwiseLogSoftmax(Function):
+    """log_p_attn[b,i,:] = log_softmax_j(-||feats[b,i]-text[b,j]||_2), padded text columns -inf
+    (modules/alignments.py:51-59)."""
+
+    @staticmethod
+    def forward(ctx, feats, text, text_lens_i32):
+        feats, text = _c(feats), _c(text)
+        logp, dist = KA.pairwise_l2_logsoftmax(feats, text, text_lens_i32)
+        ctx.save_for_backward(feats, text, text_lens_i32, logp, dist)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        feats, text, text_lens_i32, logp, dist = ctx.saved_tensors
+        B, Tf, A = feats.shape
+        Tx = text.shape[1]
+        dtype = feats.dtype
+        G, rowsum = KA.pairwise_l2_bwd_g(logp, dist, _c(dlogp.float()), text_lens_i32, dtype)
+        # dfeats[b,i,:] = feats[b,i,:]*sum_j G[b,i,j] - sum_j G[b,i,j] text[b,j,:]
+        r1 = KA.rowscale(feats, rowsum.view(-1))
+        dfe = torch.empty_like(feats)
+        K.gemm(K.operand(G, Tx, bs0=Tf * Tx), K.operand(text, A, layout=K.RC, bs0=Tx * A), Tf, A, Tx, dfe, in_dtype=dtype,
+               nb0=B, nb1=1, cbs=(Tf * A, 0), alpha=-1.0, res=r1, rbs=(Tf * A, 0))
+        # dtext[b,j,:] = text[b,j,:]*sum_i G[b,i,j] - sum_i G[b,i,j] feats[b,i,:]
+        cs = torch.empty((B, Tx), dtype=torch.float32, device=feats.device)
+        for b in range(B):  # column sums over the frame axis, one deterministic reduction per utterance
+            s, _ = K.colreduce(0, G[b])
+            cs[b].copy_(s)
+        r2 = KA.rowscale(text, cs.view(-1))
+        dtx = torch.empty_like(text)
+        K.gemm(K.operand(G, Tx, layout=K.RC, bs0=Tf * Tx), K.operand(feats, A, layout=K.RC, bs0=Tf * A), Tx, A, Tf, dtx,
+               in_dtype=dtype, nb0=B, nb1=1, cbs=(Tx * A, 0), alpha=-1.0, res=r2, rbs=(Tx * A, 0))
+        return dfe, dtx, None
+
+
+def pairwise_logsoftmax(feats, text, text_lens_i32):
+    return _PairwiseLogSoftmax.apply(feats, text, text_lens_i32)
+
+
+class _GaussUpsample(Function):
+    """hs_up = softmax_j(-delta (t - c_j)^2) @ hs   (modules/length_regulator.py:111-154); ds carries no grad."""
+
+    @staticmethod
+    def forward(ctx, hs, ds, text_lens_i32, feat_lens_i32, Tf, delta):
+        hs = _c(hs)
+        B, Tx, A = hs.shape
+        dtype = hs.dtype
+        P = KA.gauss_upsample_probs(_c(ds.float()), text_lens_i32, feat_lens_i32, Tf, dtype, delta)
+        out = torch.empty((B, Tf, A), dtype=dtype, device=hs.device)
+        K.gemm(K.operand(P, Tx, bs0=Tf * Tx), K.operand(hs, A, layout=K.RC, bs0=Tx * A), Tf, A, Tx, out, in_dtype=dtype, nb0=B,
+               nb1=1, cbs=(Tf * A, 0))
+        ctx.save_for_backward(P)
+        ctx.dims = (B, Tf, Tx, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (P,) = ctx.saved_tensors
+        B, Tf, Tx, A = ctx.dims
+        dout = _c(dout)
+        dhs = torch.empty((B, Tx, A), dtype=dout.dtype, device=dout.device)
+        K.gemm(K.operand(P, Tx, layout=K.RC, bs0=Tf * Tx), K.operand(dout, A, layout=K.RC, bs0=Tf * A), Tx, A, Tf, dhs,
+               in_dtype=dout.dtype, nb0=B, nb1=1, cbs=(Tx * A, 0))
+        return dhs, None, None, None, None, None
+
+
+def gaussian_upsample(hs, ds, text_lens_i32, feat_lens_i32, Tf, delta=0.1):
+    return _GaussUpsample.apply(hs, ds, text_lens_i32, feat_lens_i32, Tf, delta)
+
+
+class _ForwardSum(Function):
+    @staticmethod
+    def forward(ctx, log_p_attn, prior, text_lens_i32, feat_lens_i32, blank_prob):
+        lp = _c(log_p_attn.float())
+        loss_b, grad = KA.forward_sum(lp, prior, text_lens_i32, feat_lens_i32, blank_prob)
+        ctx.save_for_backward(grad)
+        ctx.in_dtype = log_p_attn.dtype
+        return loss_b.sum() / lp.shape[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        # d loss / d log_p_attn = g * grad  (the scalar g lives on the device: broadcast it as a row scale)
+        gs = _c(g.float()).reshape(1).expand(grad.shape[0] * grad.shape[1]).contiguous()
+        out = KA.rowscale(grad.view(-1, grad.shape[-1]), gs).view_as(grad)
+        return out.to(ctx.in_dtype), None, None, None, None
+
+
+def forward_sum_loss(log_p_attn, prior, text_lens_i32, feat_lens_i32, blank_prob):
+    return _ForwardSum.apply(log_p_attn, prior, text_lens_i32, feat_lens_i32, blank_prob)
+
+
+class _InterpNearest(Function):
+    @staticmethod
+    def forward(ctx, x, Tout):
+        x = _c(x)
+        ctx.Tin = x.shape[1]
+        return K.interp_nearest(x, Tout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.interp_nearest_bwd(_c(dy), ctx.Tin), None
+
+
+def interp_nearest(x, Tout):
+    """F.interpolate(x^T, size=Tout)^T per batch item on channel-last (B, T, C)  (models/aas_vc.py:340-349)."""
+    return _InterpNearest.apply(x, Tout)

@@ -1,0 +1,79 @@
+"""Launchers for the AAS-VC / Conformer specific kernels (csrc/dwconv.hip, align.hip, ctc.hip)."""
+import math
+
+import torch
+
+from .. import _lib
+from .kernels import _DT, dt, ptr, stream
+
+_WS_CHUNKS = 64
+
+
+def dwconv(x, w, bias, ks, dil=1, flip=False):
+    """x (B,T,C) channel-last; w fp32 (C,1,k) contiguous; flip=True gives the data gradient of dy."""
+    B, T, C = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().s2svc_dwconv(dt(x), B, T, C, ks, dil, ptr(x), ptr(w), ptr(bias), ptr(y), 1 if flip else 0, stream()),
+               "dwconv")
+    return y
+
+
+def dwconv_wgrad(x, dy, ks, dil=1):
+    B, T, C = x.shape
+    dw = torch.empty((C, 1, ks), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_WS_CHUNKS * C * ks, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().s2svc_dwconv_wgrad(dt(x), B, T, C, ks, dil, ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), _WS_CHUNKS, stream()),
+               "dwconv_wgrad")
+    return dw
+
+
+def pairwise_l2_logsoftmax(feats, text, text_lens_i32):
+    B, Tf, A = feats.shape
+    Tx = text.shape[1]
+    logp = torch.empty((B, Tf, Tx), dtype=torch.float32, device=feats.device)
+    dist = torch.empty((B, Tf, Tx), dtype=torch.float32, device=feats.device)
+    _lib.check(_lib.lib().s2svc_pairwise_l2_logsoftmax(dt(feats), B, Tf, Tx, A, ptr(feats), ptr(text), ptr(text_lens_i32),
+                                                       ptr(logp), ptr(dist), stream()), "pairwise_l2_logsoftmax")
+    return logp, dist
+
+
+def pairwise_l2_bwd_g(logp, dist, dlogp, text_lens_i32, out_dtype):
+    B, Tf, Tx = logp.shape
+    G = torch.empty((B, Tf, Tx), dtype=out_dtype, device=logp.device)
+    rowsum = torch.empty((B, Tf), dtype=torch.float32, device=logp.device)
+    _lib.check(_lib.lib().s2svc_pairwise_l2_bwd_g(_DT[out_dtype], B, Tf, Tx, ptr(logp), ptr(dist), ptr(dlogp), ptr(text_lens_i32),
+                                                  ptr(G), ptr(rowsum), stream()), "pairwise_l2_bwd_g")
+    return G, rowsum
+
+
+def rowscale(x, s):
+    D = x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().s2svc_rowscale(dt(x), x.numel() // D, D, ptr(x), ptr(s), ptr(out), stream()), "rowscale")
+    return out
+
+
+def gauss_upsample_probs(ds, text_lens_i32, feat_lens_i32, Tf, out_dtype, delta=0.1):
+    B, Tx = ds.shape
+    P = torch.empty((B, Tf, Tx), dtype=out_dtype, device=ds.device)
+    _lib.check(_lib.lib().s2svc_gauss_upsample_probs(_DT[out_dtype], B, Tf, Tx, ptr(ds), ptr(text_lens_i32), ptr(feat_lens_i32),
+                                                     delta, ptr(P), stream()), "gauss_upsample_probs")
+    return P
+
+
+def betabinom_prior(B, Tf, Tx, text_lens_i32, feat_lens_i32, device):
+    prior = torch.empty((B, Tf, Tx), dtype=torch.float32, device=device)
+    _lib.check(_lib.lib().s2svc_betabinom_prior(B, Tf, Tx, ptr(text_lens_i32), ptr(feat_lens_i32), ptr(prior), stream()),
+               "betabinom_prior")
+    return prior
+
+
+def forward_sum(log_p_attn, prior, text_lens_i32, feat_lens_i32, blank_prob=math.e ** -1):
+    B, Tf, Tx = log_p_attn.shape
+    dev = log_p_attn.device
+    ws = torch.empty(_lib.lib().s2svc_forward_sum_ws_bytes(B, Tf, Tx) // 4 + 1, dtype=torch.float32, device=dev)
+    loss_b = torch.empty((B,), dtype=torch.float32, device=dev)
+    grad = torch.empty((B, Tf, Tx), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().s2svc_forward_sum(B, Tf, Tx, ptr(log_p_attn), ptr(prior), ptr(text_lens_i32), ptr(feat_lens_i32),
+                                            math.log(blank_prob), ptr(ws), ptr(loss_b), ptr(grad), stream()), "forward_sum")
+    return loss_b, grad
