@@ -5,13 +5,18 @@
  *
  * The reference (unilight/seq2seq-vc) has no FFI layer: its hot path is stock torch ops called
  * from seq2seq_vc/modules/ and seq2seq_vc/losses/.  Each entry point below therefore names the
- * reference call site(s) it replaces (paths relative to the reference root).  All pointers are
- * DEVICE pointers unless marked "host"; `stream` is a hipStream_t passed as void*.  Every function
- * returns 0 on success, <0 on error (s2svc_last_error() gives the message).  No function
- * synchronises the device or allocates memory: callers own all buffers.
+ * reference call site(s) it replaces (paths relative to the reference root, tag 2024_08_07).
  *
- * dtype codes: 0 = float32, 1 = bfloat16 (raw uint16 storage).  Reductions, softmax/LN/BN
- * statistics and accumulators are always fp32 (MAS: fp64).
+ * Conventions
+ *   - all pointers are DEVICE pointers unless marked "host"; `stream` is a hipStream_t passed as void*;
+ *   - every function returns 0 on success, <0 on error (s2svc_last_error() gives the message);
+ *   - no function synchronises the device or allocates memory: callers own all buffers;
+ *   - dtype codes: 0 = float32, 1 = bfloat16 (raw uint16 storage).  Activations are channel-last,
+ *     contiguous (B, T, D).  Reductions / softmax / LN / BN statistics are fp32, MAS is fp64;
+ *   - masks never exist as tensors: kernels take int32 per-utterance length vectors;
+ *   - dropout: a mask is a pure function of (seed, element index) (Philox-4x32-10); kernels read
+ *     seed = *seed_base + seed_off, seed_base in device memory (may be NULL), so a captured hipGraph
+ *     draws fresh masks on every replay and backward kernels regenerate masks instead of loading them.
  */
 #ifndef S2SVC_HIP_H
 #define S2SVC_HIP_H
@@ -23,17 +28,18 @@ extern "C" {
 const char* s2svc_last_error(void);
 int s2svc_abi_version(void);
 
-/* ------------------------------------------------------------------------------------------ */
+/* ========================================================================================== */
 /* Generic tiled MFMA GEMM with implicit-convolution operand addressing.                      */
-/* C[m,n] = act(alpha * sum_k A(m,k) * B(n,k) + bias[n]) + res[m,n]                           */
+/*   C[z][m,n] = act(alpha * sum_k A_z(m,k) * B_z(n,k) + bias[n]) + res_z[m,n]                 */
 /* replaces: torch.nn.Linear / Conv1d / Conv2d / matmul call sites, e.g.                      */
 /*   modules/transformer/attention.py:54-56,63,88,110 (QKV/out Linear, QK^T, PV)              */
 /*   modules/transformer/positionwise_feed_forward.py:30-32                                   */
 /*   modules/pre_postnets.py:63-66,108-185 (Prenet Linear, Postnet Conv1d)                    */
 /*   modules/transformer/subsampling.py:58-70 (Conv2d 3x3 stride 2, Linear)                   */
-/*   modules/alignments.py:21-26 (AlignmentModule Conv1d)                                     */
+/*   modules/alignments.py:21-26 (AlignmentModule Conv1d), length_regulator.py:153 (matmul)   */
+/*   bin/preprocess.py:63-83 (STFT as windowed-DFT GEMM with overlapping rows, mel basis)     */
 /* and their autograd backward (dgrad / wgrad are the same kernel with other operand layouts) */
-/* ------------------------------------------------------------------------------------------ */
+/* ========================================================================================== */
 enum { S2SVC_LAYOUT_KC = 0,   /* element (r,k) at r*ld + k  (reduction index contiguous)   */
        S2SVC_LAYOUT_RC = 1 }; /* element (r,k) at k*ld + r  (row index contiguous)          */
 enum { S2SVC_OP_DENSE = 0,
@@ -71,6 +77,142 @@ typedef struct {
 } s2svc_gemm_desc;
 
 int s2svc_gemm(const s2svc_gemm_desc* desc /* host */, void* stream);
+
+/* ========================================================================================== */
+/* LayerNorm fused with residual-add + dropout; BatchNorm1d; deterministic column reductions  */
+/* replaces: modules/transformer/layer_norm.py:12-42 and the `residual + dropout(...)` lines   */
+/* of encoder_layer.py:96-113, decoder_layer.py:104-127, conformer/encoder_layer.py:118-170;  */
+/* torch.nn.BatchNorm1d at pre_postnets.py:124,152 and conformer/convolution.py:52,74.        */
+/* ========================================================================================== */
+/* s = res ? res + hscale*dropout(x) : x (written to s_out) ; y = LN(s)*gamma+beta ; mean/rstd [rows] fp32 */
+int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, const void* res, float drop_p, float hscale,
+                        const uint64_t* seed_base, uint64_t seed_off, const float* gamma, const float* beta, float eps,
+                        void* y, void* s_out, float* mean, float* rstd, void* stream);
+/* ds = dLN(dy) + ds_extra ; dh = ds*mask*hscale (NULL to skip) */
+int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, const void* s, const float* mean, const float* rstd,
+                        const float* gamma, const void* ds_extra, float drop_p, float hscale, const uint64_t* seed_base,
+                        uint64_t seed_off, void* ds, void* dh, void* stream);
+/* chunked column reductions over (rows, D); modes 0..4 see csrc/norm.hip; ws >= ws_chunks*2*D floats */
+int s2svc_colreduce(int dtype, int rows, int D, int mode, const void* dy, const void* x, const float* mean,
+                    const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate, float* ws,
+                    int ws_chunks, void* stream);
+int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean, const float* var, float* rstd,
+                      float* run_mean, float* run_var, int64_t* num_batches, void* stream);
+int s2svc_rstd_from_var(int C, float eps, const float* var, float* rstd, void* stream);
+int s2svc_bn_apply(int dtype, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
+                   const float* gamma, const float* beta, int act, float drop_p, const uint64_t* seed_base,
+                   uint64_t seed_off, void* y, void* pre_act, void* stream);
+int s2svc_bn_bwd(int dtype, int64_t rows, int C, const void* dy, const void* x, const float* mean, const float* rstd,
+                 const float* gamma, const float* sum_dy, const float* sum_dy_xhat, int use_batch_stats, void* dx,
+                 void* stream);
+
+/* ========================================================================================== */
+/* Attention probabilities: scale + relative shift + length/causal mask + softmax + dropout   */
+/* replaces: modules/transformer/attention.py:63-93 (forward_attention), :237-260 / :142-160  */
+/* (rel_shift new / legacy), :278-303 ((ac+bd)/sqrt(d_k)).  rel_mode 0 none, 1 new, 2 legacy. */
+/* ========================================================================================== */
+int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, const float* scores, const float* bd, int Lp,
+                           int rel_mode, float scale, const int32_t* klen, int causal, float drop_p,
+                           const uint64_t* seed_base, uint64_t seed_off, void* attn, void* pdrop, void* stream);
+int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, const void* attn, const float* dp, const void* dattn,
+                           float scale, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dscores,
+                           void* dbd, int Lp, int rel_mode, void* stream);
+
+/* ========================================================================================== */
+/* Elementwise: activations+dropout, positional encodings, head biases, GLU, casts, gathers   */
+/* replaces: F.dropout / nn.Dropout sites (pre_postnets.py:63-66 always-on prenet dropout),   */
+/* layers/positional_encoding.py:57-70,94-106,226-235,293-309, attention.py:283-286,          */
+/* conformer/convolution.py:68 (GLU), conformer/swish.py.                                     */
+/* ========================================================================================== */
+int s2svc_act_dropout_fwd(int dtype, int64_t n, const void* x, int act, float p, const uint64_t* seed_base,
+                          uint64_t seed_off, void* y, void* stream);
+int s2svc_act_dropout_bwd(int dtype, int64_t n, const void* dz, const void* saved, int act, float p,
+                          const uint64_t* seed_base, uint64_t seed_off, void* dx, void* stream);
+int s2svc_posenc_fwd(int dtype, int64_t B, int T, int D, const void* x, float xscale, const float* alpha, const float* pe,
+                     float p, const uint64_t* seed_base, uint64_t seed_off, void* y, void* stream);
+int s2svc_posenc_bwd(int dtype, int64_t B, int T, int D, const void* dy, float xscale, const float* pe, float p,
+                     const uint64_t* seed_base, uint64_t seed_off, void* dx, float* dalpha, float* partials, void* stream);
+int s2svc_axpby(int dtype, int64_t n, float a, const void* x, float b, const void* y, void* out, void* stream);
+int s2svc_add_head_bias(int dtype, int64_t rows, int D, const void* q, const float* u, const float* v, void* qu, void* qv,
+                        void* stream);
+int s2svc_glu_fwd(int dtype, int64_t rows, int C, const void* x, void* y, void* stream);
+int s2svc_glu_bwd(int dtype, int64_t rows, int C, const void* x, const void* dy, void* dx, void* stream);
+int s2svc_cast(int in_dtype, int out_dtype, int64_t n, const void* x, void* y, void* stream);
+int s2svc_gather3(int in_dtype, int out_dtype, int n0, int n1, int n2, int64_t s0, int64_t s1, int64_t s2, int64_t off,
+                  const void* in, void* out, void* stream);
+int s2svc_rowscale(int dtype, int64_t rows, int D, const void* x, const float* s, void* out, void* stream);
+
+/* ========================================================================================== */
+/* Convolution helpers                                                                         */
+/* replaces: autograd of Conv2d stride 2 (subsampling.py:58-63); F.interpolate (aas_vc.py:    */
+/* 340-349); depthwise Conv1d (conformer/convolution.py:42-51,70; vits/flow.py:137-146).      */
+/* ========================================================================================== */
+int s2svc_col2im_s2(int dtype, int B, int T1, int F1, int C, int T2, int F2, const void* dcols, void* dx, void* stream);
+int s2svc_interp_nearest(int dtype, int B, int Tin, int Tout, int C, const void* x, void* y, void* stream);
+int s2svc_interp_nearest_bwd(int dtype, int B, int Tin, int Tout, int C, const void* dy, void* dx, void* stream);
+int s2svc_dwconv(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const float* w, const float* bias,
+                 void* y, int flip, void* stream);
+int s2svc_dwconv_wgrad(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const void* dy, float* dw,
+                       int accumulate, float* ws, int ws_chunks, void* stream);
+
+/* ========================================================================================== */
+/* AAS alignment: pairwise -L2 + masked log-softmax, monotonic alignment search, Gaussian     */
+/* upsampling weights.                                                                         */
+/* replaces: modules/alignments.py:51-59 (AlignmentModule tail), :63-93 + :281-310 (numba MAS, */
+/* per-utterance host loop, bincount, binarisation loss), length_regulator.py:111-154.        */
+/* ========================================================================================== */
+int s2svc_pairwise_l2_logsoftmax(int dtype, int B, int Tf, int Tx, int A, const void* feats, const void* text,
+                                 const int32_t* text_lens, float* logp, float* dist, void* stream);
+int s2svc_pairwise_l2_bwd_g(int dtype, int B, int Tf, int Tx, const float* logp, const float* dist, const float* dlogp,
+                            const int32_t* text_lens, void* G, float* rowsum, void* stream);
+int64_t s2svc_mas_ws_bytes(int B, int Tf, int Tx);
+/* path (B,Tf) int32 (-1 beyond feat_len), ds (B,Tx) fp32 durations, binmean (B) = mean_t log_p[t, path[t]] */
+int s2svc_mas(int B, int Tf, int Tx, const float* log_p_attn, const int32_t* text_lens, const int32_t* feat_lens,
+              int32_t* path, float* ds, float* binmean, void* ws, void* stream);
+int s2svc_mas_binloss_bwd(int B, int Tf, int Tx, const int32_t* path, const int32_t* feat_lens, const float* gout,
+                          float* dlogp, void* stream);
+int s2svc_gauss_upsample_probs(int dtype, int B, int Tf, int Tx, const float* ds, const int32_t* text_lens,
+                               const int32_t* feat_lens, float delta, void* P, void* stream);
+
+/* ========================================================================================== */
+/* Losses                                                                                      */
+/* replaces: losses/seq2seq_loss.py:30-59, losses/l1_loss.py:22-49, guided_attention_loss.py: */
+/* 142-165, forward_sum_loss.py:26-116 (F.ctc_loss loop + scipy beta-binomial prior).          */
+/* ========================================================================================== */
+int s2svc_seq_loss_fwd(int dtype, int B, int Tm, int D, const void* after, const void* before, const void* logits,
+                       const float* ys, const float* labels, const int32_t* olens, float pos_weight, float* partial,
+                       float* out, void* stream);
+int s2svc_seq_loss_bwd(int dtype, int B, int Tm, int D, const void* after, const void* before, const void* logits,
+                       const float* ys, const float* labels, const int32_t* olens, float pos_weight, const float* stats,
+                       const float* g_l1, const float* g_bce, void* d_after, void* d_before, void* d_logits, void* stream);
+int s2svc_guided_attn_loss_fwd(int dtype, int B, int H, int To, int Ti, const void* att, const int32_t* ilens,
+                               const int32_t* olens, float sigma, float alpha, float* partial, float* out, void* stream);
+int s2svc_guided_attn_loss_bwd(int dtype, int B, int H, int To, int Ti, const int32_t* ilens, const int32_t* olens,
+                               float sigma, float alpha, const float* stats, const float* gout, void* datt, void* stream);
+int64_t s2svc_forward_sum_ws_bytes(int B, int Tf, int Tx);
+int s2svc_forward_sum(int B, int Tf, int Tx, const float* log_p_attn, const float* prior, const int32_t* text_lens,
+                      const int32_t* feat_lens, float log_blank, void* ws, float* loss_b, float* grad, void* stream);
+int s2svc_betabinom_prior(int B, int Tf, int Tx, const int32_t* text_lens, const int32_t* feat_lens, float* prior,
+                          void* stream);
+
+/* ========================================================================================== */
+/* Optimiser: grad-norm -> clip -> WarmupLR -> Adam (+ bf16 shadow) over one flat buffer       */
+/* replaces: trainers/ar_vc.py:99-107 (clip_grad_norm_, Adam.step, scheduler.step),            */
+/* schedulers/warmup_lr.py:54-61.  state: 4 device floats {step, lr, grad_norm, clip_coef}.    */
+/* ========================================================================================== */
+int s2svc_adam_step(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* bf16_shadow,
+                    float beta1, float beta2, float eps, float max_norm, float base_lr, float warmup_steps,
+                    double* partial, float* state, void* stream);
+
+/* ========================================================================================== */
+/* STFT -> log-mel glue (the two contractions use s2svc_gemm)                                  */
+/* replaces: bin/preprocess.py:63-92 (librosa.stft reflect padding, abs, max(eps,.), log10)    */
+/* and optionally bin/normalize.py:172-193 ((x-mean)/scale fused into the log kernel).         */
+/* ========================================================================================== */
+int s2svc_reflect_pad(int64_t n, int pad, const float* x, float* y, void* stream);
+int s2svc_magnitude(int64_t frames, int nb, const float* z, float* spc, void* stream);
+int s2svc_log_clamp(int64_t n, int D, const float* x, float eps, float inv_log_base, const float* mean,
+                    const float* inv_scale, float* y, void* stream);
 
 #ifdef __cplusplus
 }

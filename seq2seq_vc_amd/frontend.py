@@ -1,0 +1,116 @@
+"""STFT -> log-mel feature front-end on the GPU (drop-in for `logmelfilterbank`, reference
+bin/preprocess.py:30-92, and -- optionally fused -- the mean/variance normalisation of
+bin/normalize.py:172-193).
+
+    mel = logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, num_mels=80, fmin=80, fmax=7600)
+
+librosa semantics restated (librosa itself is an unpinned third-party dependency of the reference and is not
+installed here, so this path is "parity unpinned": it is checked against the independent numpy restatement
+in oracle/logmel.py, not against librosa): center=True with reflect padding of n_fft/2, periodic Hann window,
+frames = 1 + N // hop, one-sided spectrum of n_fft/2+1 bins, magnitude, Slaney-scale area-normalised mel
+basis, max(eps, .), log10.
+
+GPU formulation: the (frames x n_fft) frame matrix is never built -- the padded signal IS the A operand of the
+fp32 MFMA GEMM with leading dimension `hop` (overlapping rows); B is the windowed real-DFT basis
+[cos | -sin] (2*(n_fft/2+1) x n_fft, fp32, cached on the device).  A second small GEMM applies the mel basis.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import kernels as K
+
+_BASIS = {}
+
+
+def hz_to_mel(f):
+    f = np.asanyarray(f, dtype=float)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+
+def mel_to_hz(m):
+    m = np.asanyarray(m, dtype=float)
+    f_sp = 200.0 / 3
+    min_log_hz, min_log_mel, logstep = 1000.0, 1000.0 / f_sp, np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_basis(sr, n_fft, n_mels, fmin, fmax):
+    """Slaney mel filterbank, area-normalised (librosa.filters.mel defaults) -> (n_mels, n_fft//2+1) float32."""
+    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def dft_basis(n_fft, win_length=None):
+    """Windowed one-sided DFT basis rows [w*cos ; -w*sin] -> (2*(n_fft//2+1), n_fft) float32."""
+    win_length = n_fft if win_length is None else win_length
+    k = np.arange(win_length)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * k / win_length)         # periodic Hann (fftbins=True)
+    lp = (n_fft - win_length) // 2
+    w = np.zeros(n_fft)
+    w[lp:lp + win_length] = win
+    n = np.arange(n_fft // 2 + 1)[:, None]
+    ang = 2 * np.pi * n * np.arange(n_fft)[None, :] / n_fft
+    return np.concatenate([np.cos(ang) * w, -np.sin(ang) * w], axis=0).astype(np.float32)
+
+
+def _tables(device, sr, n_fft, win_length, n_mels, fmin, fmax):
+    key = (str(device), sr, n_fft, win_length, n_mels, fmin, fmax)
+    if key not in _BASIS:
+        _BASIS[key] = (torch.from_numpy(dft_basis(n_fft, win_length)).to(device),
+                       torch.from_numpy(mel_basis(sr, n_fft, n_mels, fmin, fmax)).to(device))
+    return _BASIS[key]
+
+
+def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80,
+                     fmin=None, fmax=None, eps=1e-10, log_base=10.0, mean=None, scale=None):
+    """audio: 1-D float tensor on the GPU (or numpy/CPU tensor, copied once) -> (frames, num_mels) fp32 tensor
+    on the GPU.  `mean`/`scale` (num_mels,) fuse `(x - mean) / scale` into the log kernel."""
+    if window != "hann":
+        raise NotImplementedError("only the hann window of the recipes is supported")
+    if not isinstance(audio, torch.Tensor):
+        audio = torch.as_tensor(np.asarray(audio, dtype=np.float32))
+    if not audio.is_cuda:
+        audio = audio.cuda()
+    audio = audio.float().contiguous()
+    dev = audio.device
+    fmin = 0 if fmin is None else fmin
+    fmax = sampling_rate / 2 if fmax is None else fmax
+    basis, melb = _tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
+    n = audio.numel()
+    pad = fft_size // 2
+    frames = 1 + n // hop_size
+    nb = fft_size // 2 + 1
+    L = _lib.lib()
+    st = K.stream()
+    padded = torch.empty(n + 2 * pad, dtype=torch.float32, device=dev)
+    _lib.check(L.s2svc_reflect_pad(n, pad, audio.data_ptr(), padded.data_ptr(), st), "reflect_pad")
+    z = torch.empty((frames, 2 * nb), dtype=torch.float32, device=dev)
+    K.gemm(K.operand(padded, hop_size), K.operand(basis, fft_size), frames, 2 * nb, fft_size, z, in_dtype=torch.float32)
+    spc = torch.empty((frames, nb), dtype=torch.float32, device=dev)
+    _lib.check(L.s2svc_magnitude(frames, nb, z.data_ptr(), spc.data_ptr(), st), "magnitude")
+    mel = torch.empty((frames, num_mels), dtype=torch.float32, device=dev)
+    K.gemm(K.operand(spc, nb), K.operand(melb, nb), frames, num_mels, nb, mel, in_dtype=torch.float32)
+    inv_log = 1.0 if log_base is None else 1.0 / math.log(log_base)
+    if log_base not in (None, 10.0, 2.0):
+        raise ValueError(f"{log_base} is not supported.")
+    out = torch.empty_like(mel)
+    m_ptr = s_ptr = None
+    if mean is not None:
+        mean_t = torch.as_tensor(mean, dtype=torch.float32, device=dev).contiguous()
+        inv_scale_t = (1.0 / torch.as_tensor(scale, dtype=torch.float32, device=dev)).contiguous()
+        m_ptr, s_ptr = mean_t.data_ptr(), inv_scale_t.data_ptr()
+    _lib.check(L.s2svc_log_clamp(mel.numel(), num_mels, mel.data_ptr(), eps, inv_log, m_ptr, s_ptr, out.data_ptr(), st), "log_clamp")
+    return out

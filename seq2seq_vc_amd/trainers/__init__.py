@@ -1,0 +1,240 @@
+"""Trainers resolved by name (`trainer_type:`), mirroring `seq2seq_vc.trainers`
+(reference trainers/base.py:18-227, ar_vc.py:28-112, ar_tts.py:22-100, aas_vc.py:22-164).
+
+Same constructor `(steps, epochs, data_loader, sampler, model, vocoder, criterion, optimizer, scheduler,
+config, device)` and `run / save_checkpoint / load_checkpoint / load_trained_modules / freeze_modules`;
+`_train_step` reproduces the reference's loss composition, gradient-accumulation scaling, clip -> step ->
+scheduler order and step counting.  Plotting / vocoding of intermediate results (matplotlib, soundfile,
+tensorboardX) is outside the hot path and not reproduced; a log callback receives the averaged losses.
+
+Host synchronisation: the reference calls `.item()` 4-6 times per step; here losses are accumulated in a
+device tensor and read once per `log_interval_steps`.
+"""
+import logging
+import os
+from collections import OrderedDict, defaultdict
+
+import torch
+
+from ..optim import FlatAdam
+from ..ops import kernels as K
+
+
+def get_partial_state_dict(model_state_dict, modules):
+    return OrderedDict((k, v) for k, v in model_state_dict.items() if any(k.startswith(m) for m in modules))
+
+
+def freeze_modules(model, modules):
+    """requires_grad=False for every parameter whose name starts with one of `modules` (utils/model_io.py:95-111)."""
+    for name, p in model.named_parameters():
+        if any(name.startswith(m) for m in modules):
+            logging.warning(f"Freezing {name}. It will not be updated during training.")
+            p.requires_grad = False
+    return model, filter(lambda x: x.requires_grad, model.parameters())
+
+
+class Trainer(object):
+    def __init__(self, steps, epochs, data_loader, sampler, model, vocoder, criterion, optimizer, scheduler, config,
+                 device=torch.device("cpu")):
+        self.steps, self.epochs = steps, epochs
+        self.data_loader, self.sampler = data_loader, sampler
+        self.model, self.vocoder = model, vocoder
+        self.criterion, self.optimizer, self.scheduler = criterion, optimizer, scheduler
+        self.config, self.device = config, torch.device(device)
+        self.finish_train = False
+        self.gradient_accumulate_steps = self.config.get("gradient_accumulate_steps", 1)
+        self.backward_steps = 0
+        self.loss_names = []
+        self.loss_acc = None            # device tensor: running sums of the logged losses
+        self.total_train_loss = defaultdict(float)
+        self.log_fn = None              # optional callable(steps, dict) -- stands in for tensorboardX
+
+    # -- core loop -------------------------------------------------------------------------------
+    def _net(self):
+        return self.model.module if hasattr(self.model, "module") else self.model
+
+    def run(self):
+        self.backward_steps = 0
+        while not self.finish_train:
+            self._train_epoch()
+        logging.info("Finished training.")
+
+    def _train_epoch(self):
+        n = 0
+        for n, batch in enumerate(self.data_loader["train"], 1):
+            self._train_step(batch)
+            if self.backward_steps % self.gradient_accumulate_steps > 0:
+                continue
+            if self.config.get("rank", 0) == 0:
+                self._check_log_interval()
+                self._check_save_interval()
+            if self.finish_train:
+                return
+        self.epochs += 1
+        self.train_steps_per_epoch = n
+        if self.config.get("distributed", False) and self.sampler and self.sampler.get("train") is not None:
+            self.sampler["train"].set_epoch(self.epochs)
+
+    def _accumulate(self, **losses):
+        """Sum losses on the device (no host sync); names are fixed by the first call."""
+        if self.loss_acc is None:
+            self.loss_names = list(losses)
+            self.loss_acc = torch.zeros(len(self.loss_names), dtype=torch.float32, device=self.device)
+        vals = torch.stack([torch.as_tensor(losses[k], dtype=torch.float32, device=self.device).detach().reshape(())
+                            for k in self.loss_names])
+        self.loss_acc += vals / self.gradient_accumulate_steps
+
+    def _optimizer_step(self):
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.step()               # clip + WarmupLR + Adam fused on the device
+        else:
+            if self.config["grad_norm"] > 0:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.config["grad_norm"])
+            self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+
+    def _check_log_interval(self):
+        if self.steps % self.config["log_interval_steps"] == 0 and self.loss_acc is not None:
+            vals = (self.loss_acc / self.config["log_interval_steps"]).tolist()   # the one host sync
+            self.total_train_loss = dict(zip(self.loss_names, vals))
+            for k, v in self.total_train_loss.items():
+                logging.info(f"(Steps: {self.steps}) {k} = {v:.4f}.")
+            if self.log_fn is not None:
+                self.log_fn(self.steps, dict(self.total_train_loss))
+            self.loss_acc.zero_()
+
+    def _check_save_interval(self):
+        if self.steps % self.config["save_interval_steps"] == 0:
+            self.save_checkpoint(os.path.join(self.config["outdir"], f"checkpoint-{self.steps}steps.pkl"))
+            logging.info(f"Successfully saved checkpoint @ {self.steps} steps.")
+
+    def _check_train_finish(self):
+        if self.steps >= self.config["train_max_steps"]:
+            self.finish_train = True
+
+    # -- checkpoints (trainers/base.py:85-124: {model, optimizer, scheduler, steps, epochs}) --------
+    def save_checkpoint(self, checkpoint_path):
+        sd = {"optimizer": self.optimizer.state_dict(),
+              "scheduler": self.scheduler.state_dict() if self.scheduler is not None else {},
+              "steps": self.steps, "epochs": self.epochs,
+              "model": OrderedDict((k, v.detach().cpu().clone()) for k, v in self._net().state_dict().items())}
+        os.makedirs(os.path.dirname(checkpoint_path) or ".", exist_ok=True)
+        torch.save(sd, checkpoint_path)
+
+    def load_checkpoint(self, checkpoint_path, load_only_params=False):
+        sd = torch.load(checkpoint_path, map_location="cpu")
+        self._net().load_state_dict(sd["model"])
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.refresh_shadow()
+        if not load_only_params:
+            self.steps, self.epochs = sd["steps"], sd["epochs"]
+            self.optimizer.load_state_dict(sd["optimizer"])
+            if self.scheduler is not None:
+                self.scheduler.load_state_dict(sd["scheduler"])
+
+    def load_trained_modules(self, checkpoint_path, init_mods):
+        """Partial (prefix-filtered, shape-verified) load: trainers/ar_vc.py:31-57 + utils/model_io.py:12-92."""
+        main = self._net().state_dict()
+        src = torch.load(checkpoint_path, map_location="cpu")["model"]
+        missing = [m for m in init_mods if not any(k.startswith(m) for k in src)]
+        if missing:
+            raise ValueError(f"Specified module(s) don't match the pre-trained model: {missing}")
+        part = get_partial_state_dict(src, init_mods)
+        want = sorted((k, tuple(v.shape)) for k, v in main.items() if any(k.startswith(m) for m in init_mods))
+        have = sorted((k, tuple(v.shape)) for k, v in part.items())
+        if want != have:
+            raise ValueError(f"modules do not match: pre-trained-only {set(have) - set(want)}, model-only {set(want) - set(have)}")
+        for k in part:
+            logging.warning(f"Overriding module {k}")
+        main.update(part)
+        self._net().load_state_dict(main)
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.refresh_shadow()
+
+    def freeze_modules(self, modules):
+        freeze_modules(self.model, modules)
+
+
+class ARVCTrainer(Trainer):
+    """trainers/ar_vc.py:59-112: loss = l1 + bce (+ guided attention); zero_grad BEFORE backward."""
+
+    def _forward_losses(self, batch):
+        dev = self.device
+        xs, ys, labels = batch["xs"].to(dev), batch["ys"].to(dev), batch["labels"].to(dev)
+        ilens, olens = batch["ilens"], batch["olens"]       # stay on the host (sizes only)
+        after, before, logits, ys_, labels_, olens_, (att_ws, ilens_ds_st, olens_in) = self.model(xs, ilens, ys, labels, olens)
+        l1, bce = self.criterion["Seq2SeqLoss"](after, before, logits, ys_, labels_, olens_)
+        loss = l1 + bce
+        logs = {"train/l1_loss": l1, "train/bce_loss": bce}
+        if self.config.get("use_guided_attn_loss", False):
+            att = att_ws if isinstance(att_ws, torch.Tensor) else att_ws[0]
+            ga = self.criterion["guided_attn"](att, ilens_ds_st, olens_in)
+            loss = loss + ga
+            logs["train/guided_attn_loss"] = ga
+        logs["train/loss"] = loss
+        return loss, logs
+
+    def _train_step(self, batch):
+        K.reset_op_counter()
+        K.advance_seed(self.device)
+        self.optimizer.zero_grad()
+        loss, logs = self._forward_losses(batch)
+        self._accumulate(**logs)
+        loss.backward()
+        self.backward_steps += 1
+        self._optimizer_step()
+        self.steps += 1
+        self._check_train_finish()
+
+
+class ARTTSTrainer(ARVCTrainer):
+    """trainers/ar_tts.py:45-100: identical composition; the TTS collater yields a tuple."""
+
+    def _forward_losses(self, batch):
+        if not isinstance(batch, dict):
+            xs, ilens, ys, labels, olens = batch[:5]
+            batch = {"xs": xs, "ilens": ilens, "ys": ys, "labels": labels, "olens": olens}
+        return super()._forward_losses(batch)
+
+
+class AASVCTrainer(Trainer):
+    """trainers/aas_vc.py:56-164: l1 + lambda_align*(forward_sum + bin) + sum(dur_nll) [after dp_train_start_steps];
+    gradient accumulation divides the loss; zero_grad AFTER the optimiser step."""
+
+    def _train_step(self, batch):
+        dev = self.device
+        K.reset_op_counter()
+        K.advance_seed(dev)
+        xs, ys, dp_inputs = batch["xs"].to(dev), batch["ys"].to(dev), batch["dp_inputs"].to(dev)
+        ret = self.model(xs, batch["ilens"], ys, batch["olens"], dp_inputs, dp_lengths=batch["dplens"])
+        zero = torch.zeros((), device=dev)
+        logs = {}
+        loss = zero
+        if "L1Loss" in self.config["criterions"]:
+            l1 = self.criterion["L1Loss"](ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+            logs["train/l1_loss"] = l1
+            loss = loss + l1
+        fs = self.criterion["ForwardSumLoss"](ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+        logs["train/forward_sum_loss"], logs["train/binary_loss"] = fs, ret["bin_loss"]
+        loss = loss + self.config["lambda_align"] * (fs + ret["bin_loss"])
+        dur = zero
+        if self.steps > self.config.get("dp_train_start_steps", 0):
+            if "DurationPredictorLoss" in self.config["criterions"]:
+                dur = self.criterion["DurationPredictorLoss"](ret["d_outs"], ret["ds"], ret["ilens"])
+            elif "StochasticDurationPredictorLoss" in self.config["criterions"]:
+                dur = torch.sum(ret["dur_nll"].float())
+        logs["train/duration_loss"] = dur
+        loss = loss + dur
+        logs["train/loss"] = loss
+        self._accumulate(**logs)
+        if self.gradient_accumulate_steps > 1:
+            loss = loss / self.gradient_accumulate_steps
+        loss.backward()
+        self.backward_steps += 1
+        if self.backward_steps % self.gradient_accumulate_steps > 0:
+            return
+        self._optimizer_step()
+        self.optimizer.zero_grad()
+        self.steps += 1
+        self._check_train_finish()

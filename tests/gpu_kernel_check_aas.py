@@ -160,6 +160,24 @@ def interpolate_nearest(dtype):
     return res
 
 
+@case
+def stft_logmel_frontend():
+    from oracle import logmel as OL
+    from seq2seq_vc_amd.frontend import logmelfilterbank
+    res = []
+    rng = np.random.default_rng(3)
+    for n in (4000, 16000, 48000 + 137, 255):
+        t = np.arange(n) / 16000.0
+        x = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+        ref = OL.logmelfilterbank(x, 16000, fft_size=1024, hop_size=256, num_mels=80, fmin=80, fmax=7600)
+        got = logmelfilterbank(torch.from_numpy(x).to(DEV), 16000, fft_size=1024, hop_size=256, num_mels=80, fmin=80, fmax=7600)
+        res.append(check(f"logmel N={n} frames={ref.shape[0]}", got, torch.from_numpy(ref), torch.float32, atol=2e-4, rtol=1e-4))
+    mean, scale = rng.standard_normal(80).astype(np.float32), (1 + rng.random(80)).astype(np.float32)
+    got = logmelfilterbank(torch.from_numpy(x).to(DEV), 16000, fmin=80, fmax=7600, mean=mean, scale=scale)
+    res.append(check("logmel + fused normalisation", got, torch.from_numpy((ref - mean) / scale), torch.float32, atol=3e-4, rtol=1e-4))
+    return res
+
+
 def main():
     nfail = 0
     for fn in CASES:

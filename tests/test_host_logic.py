@@ -1,0 +1,164 @@
+"""CPU tests of the host-side logic: C-ABI library loads and exports every declared symbol, collaters,
+schedules, length bookkeeping, the oracle's optimiser replay, and the 2-rank gloo data-parallel exchange."""
+import math
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_library_loads_and_exports_declared_symbols():
+    from seq2seq_vc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build_library(verbose=False)
+    L = _lib.lib()
+    assert L.s2svc_abi_version() >= 1
+    header = open(os.path.join(ROOT, "include", "s2svc_hip.h")).read()
+    declared = set(re.findall(r"\b(s2svc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"s2svc_operand", "s2svc_gemm_desc"}
+    assert declared, "header declares no entry points?"
+    for sym in sorted(declared):
+        assert hasattr(L, sym), f"{sym} declared in include/s2svc_hip.h but not exported"
+    # and everything the Python binding uses is declared in the header
+    for sym in _lib.exported_symbols():
+        assert sym in declared or sym in ("s2svc_last_error", "s2svc_abi_version"), f"{sym} missing from the header"
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from seq2seq_vc_amd.ops import kernels as K
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    x = torch.zeros(4, 8)
+    with pytest.raises(RuntimeError):
+        K.layernorm_fwd(x, torch.ones(8), torch.zeros(8), 1e-12)
+
+
+def test_collaters():
+    from seq2seq_vc_amd.collaters import ARTTSCollater, ARVCCollater, NARVCCollater
+    rng = np.random.default_rng(0)
+    batch = [{"src_feat": rng.standard_normal((t, 80)).astype(np.float32), "trg_feat": rng.standard_normal((u, 80)).astype(np.float32),
+              "dp_input": rng.standard_normal((t, 80)).astype(np.float32)} for t, u in [(5, 7), (9, 3), (2, 4)]]
+    it = ARVCCollater()(batch)
+    assert it["xs"].shape == (3, 9, 80) and it["ys"].shape == (3, 7, 80)
+    assert it["ilens"].tolist() == [5, 9, 2] and it["olens"].tolist() == [7, 3, 4]
+    assert torch.equal(it["xs"][0, 5:], torch.zeros(4, 80)) and it["spembs"] is None
+    assert it["labels"][1].tolist() == [0, 0, 1, 1, 1, 1, 1] and it["labels"][0].tolist() == [0] * 6 + [1]
+    nar = NARVCCollater()(batch)
+    assert set(nar) == {"xs", "ilens", "ys", "olens", "dp_inputs", "dplens", "spembs"} and nar["dplens"].tolist() == [5, 9, 2]
+    tts = ARTTSCollater()([(np.array([3, 4, 5]), np.zeros((6, 80), np.float32)), (np.array([7]), np.zeros((2, 80), np.float32))])
+    assert tts[0].dtype == torch.long and tts[0].tolist() == [[3, 4, 5], [7, 0, 0]] and tts[3][1].tolist() == [0, 1, 1, 1, 1, 1]
+
+
+def test_schedulers_match_closed_form():
+    from seq2seq_vc_amd.schedulers import WarmupLR, warmup_lr_value
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=8e-5)
+    sch = WarmupLR(opt, warmup_steps=4000)
+    lrs = []
+    for _ in range(5):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    for k, lr in enumerate(lrs, 1):  # optimiser step k runs with the value for step_num = k
+        assert math.isclose(lr, 8e-5 * 4000 ** 0.5 * min(k ** -0.5, k * 4000 ** -1.5), rel_tol=1e-12)
+        assert math.isclose(lr, warmup_lr_value(8e-5, k), rel_tol=1e-12)
+    assert math.isclose(warmup_lr_value(8e-5, 4000), 8e-5, rel_tol=1e-12)     # peak equals the base lr
+
+
+def test_subsampled_lengths_follow_the_reference_mask_slicing():
+    from seq2seq_vc_amd.modules import Conv2dSubsampling, Lens
+    for T in (7, 8, 9, 40, 41, 255, 256):
+        t_out = ((T - 1) // 2 - 1) // 2
+        for ilen in range(1, T + 1):
+            mask = (torch.arange(T) < ilen)[None, None, :]
+            ref = int(mask[:, :, :-2:2][:, :, :-2:2].sum())
+            assert mask[:, :, :-2:2][:, :, :-2:2].shape[-1] == t_out
+            got = Conv2dSubsampling.out_lens(Lens([ilen], "cpu"), t_out).host[0]
+            assert got == ref, (T, ilen, got, ref)
+
+
+def test_oracle_optimizer_replay_matches_torch_adam_with_clipping():
+    from oracle import models as OM
+    torch.manual_seed(0)
+    ps = [torch.randn(7, 5), torch.randn(11)]
+    gs = [torch.randn(7, 5) * 3, torch.randn(11) * 3]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.Adam(ref, lr=1.0)
+    mine = [p.clone() for p in ps]
+    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in ps]
+    for k in range(1, 4):
+        lr = OM.warmup_lr(8e-5, k)
+        for q, g in zip(ref, gs):
+            q.grad = (g * k).clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        OM.adam_step(mine, [g * k for g in gs], state, lr, k)
+    for a, b in zip(mine, ref):
+        assert torch.allclose(a, b.detach(), atol=1e-7)
+
+
+def test_logmel_oracle_shapes_and_basis():
+    from oracle import logmel as OL
+    from seq2seq_vc_amd import frontend as FE
+    assert np.abs(FE.mel_basis(16000, 1024, 80, 80, 7600) - OL.mel_filterbank(16000, 1024, 80, 80, 7600)).max() < 1e-7
+    x = np.sin(2 * np.pi * 440 * np.arange(8000) / 16000).astype(np.float32) * 0.5
+    m = OL.logmelfilterbank(x, 16000, fmin=80, fmax=7600)
+    assert m.shape == (1 + 8000 // 256, 80)
+    assert int(m.mean(0).argmax()) in range(8, 16)       # 440 Hz lands in the low mel bins
+    B = FE.dft_basis(1024)
+    fr = np.pad(x, 512, mode="reflect")[:1024]
+    ref = np.fft.rfft(fr * (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1024)))
+    assert np.abs(B[:513] @ fr - ref.real).max() < 1e-3 and np.abs(B[513:] @ fr - ref.imag).max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from seq2seq_vc_amd.distributed import allreduce_mean_, broadcast_
+    from oracle import models as OM
+    # identical weights everywhere (broadcast), different utterances per rank, mean all-reduce of flat grads
+    torch.manual_seed(rank)
+    w = torch.randn(1000)
+    broadcast_(w, dist, world)
+    g = torch.Generator().manual_seed(100 + rank)
+    x, y = torch.randn(8, 1000, generator=g), torch.randn(8, generator=g)
+    wr = w.clone().requires_grad_(True)
+    ((x @ wr - y) ** 2).mean().backward()
+    flat = wr.grad.clone()
+    allreduce_mean_(flat, dist, world, chunk_numel=300)        # several chunks
+    q.put((rank, w, wr.grad.clone(), flat))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce_is_the_mean_of_rank_gradients():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, g0, f0), (_, w1, g1, f1) = out
+    assert torch.equal(w0, w1), "broadcast must make the weights identical"
+    assert torch.allclose(f0, (g0 + g1) / 2, atol=1e-6) and torch.equal(f0, f1)
