@@ -74,6 +74,11 @@ typedef struct {
   int32_t accumulate;      /* 1: C += result (C read in c_dtype)                              */
   int32_t splitk;          /* >1: partial sums go to ws[splitk][batch][M][N] fp32             */
   float* ws;
+  /* optional fused row sums of A: a_rowsum[m] (+)= sum_k A(m,k)  (the bias gradient when A = dY^T in a   */
+  /* wgrad GEMM); needs nb0*nb1 == 1; a_rowsum_ws: >= splitk*M floats when splitk > 1                     */
+  float* a_rowsum;
+  float* a_rowsum_ws;
+  int32_t a_rowsum_accumulate;
 } s2svc_gemm_desc;
 
 int s2svc_gemm(const s2svc_gemm_desc* desc /* host */, void* stream);
@@ -147,6 +152,11 @@ int s2svc_rowscale(int dtype, int64_t rows, int D, const void* x, const float* s
 /* replaces: autograd of Conv2d stride 2 (subsampling.py:58-63); F.interpolate (aas_vc.py:    */
 /* 340-349); depthwise Conv1d (conformer/convolution.py:42-51,70; vits/flow.py:137-146).      */
 /* ========================================================================================== */
+/* first front-end layer: Conv2d(1->O, 3x3, s2) + ReLU on the (B,T,F) mel batch, output NHWC; fused dW + dbias */
+int s2svc_conv_in1_fwd(int dtype, int B, int Tn, int Fn, int O, const void* x, const float* w, const float* bias, void* y,
+                       void* stream);
+int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, const void* x, const void* dy, float* dw, float* db,
+                         int accumulate, float* partial, int max_chunks, void* stream);
 int s2svc_col2im_s2(int dtype, int B, int T1, int F1, int C, int T2, int F2, const void* dcols, void* dx, void* stream);
 int s2svc_interp_nearest(int dtype, int B, int Tin, int Tout, int C, const void* x, void* y, void* stream);
 int s2svc_interp_nearest_bwd(int dtype, int B, int Tin, int Tout, int C, const void* dy, void* dx, void* stream);

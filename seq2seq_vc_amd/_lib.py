@@ -66,7 +66,8 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [("A", Operand), ("B", Operand), ("C", c_vp), ("ldc", c_i64), ("cbs0", c_i64), ("cbs1", c_i64),
                 ("c_dtype", c_i32), ("bias", c_vp), ("res", c_vp), ("ldr", c_i64), ("rbs0", c_i64), ("rbs1", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("nb0", c_i32), ("nb1", c_i32), ("act", c_i32),
-                ("alpha", c_f32), ("dtype", c_i32), ("accumulate", c_i32), ("splitk", c_i32), ("ws", c_vp)]
+                ("alpha", c_f32), ("dtype", c_i32), ("accumulate", c_i32), ("splitk", c_i32), ("ws", c_vp),
+                ("a_rowsum", c_vp), ("a_rowsum_ws", c_vp), ("a_rowsum_accumulate", c_i32)]
 
 
 _SIGS = {
@@ -111,6 +112,8 @@ _SIGS = {
     "s2svc_gauss_upsample_probs": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp],
     "s2svc_forward_sum": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_betabinom_prior": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_conv_in1_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_conv_in1_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "s2svc_reflect_pad": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "s2svc_magnitude": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "s2svc_log_clamp": [c_i64, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp],

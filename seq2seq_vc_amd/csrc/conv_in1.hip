@@ -1,0 +1,125 @@
+// First layer of the Conv2d subsampling front-end: Conv2d(1 -> O, 3x3, stride 2) + ReLU on the (B, T, F) mel
+// batch itself (NHWC with C = 1), output NHWC (B, T1, F1, O).
+// reference: modules/transformer/subsampling.py:58-60.  K = 9 is far too thin for the MFMA GEMM; this layer is
+// pure HBM streaming: 4 B/input sample read (re-reads served by L1/L2) + O*s bytes written per output pixel.
+#include "common.h"
+#include "../../include/s2svc_hip.h"
+
+namespace {
+
+// each thread: one output pixel x 8 consecutive channels (one 16-byte store for bf16, two for fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in1_fwd_kernel(int B, int Tn, int Fn, int T1, int F1, int O, const T* __restrict__ x,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           T* __restrict__ y) {
+  extern __shared__ float sw[];  // O*9 weights + O biases
+  for (int i = threadIdx.x; i < O * 9; i += 256) sw[i] = w[i];
+  for (int i = threadIdx.x; i < O; i += 256) sw[O * 9 + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int og = O / 8;
+  const int64_t n = (int64_t)B * T1 * F1 * og;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % og);
+    int64_t p = i / og;
+    const int f1 = (int)(p % F1); p /= F1;
+    const int t1 = (int)(p % T1);
+    const int b = (int)(p / T1);
+    float xv[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = ldf(x + ((int64_t)b * Tn + 2 * t1 + kh) * Fn + 2 * f1 + kw);
+    T* yo = y + (i / og) * O + g * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int o = g * 8 + e;
+      float acc = sw[O * 9 + o];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc += sw[o * 9 + k] * xv[k];
+      stf(yo + e, acc > 0.f ? acc : 0.f);
+    }
+  }
+}
+
+// partial[chunk][o][0..8] = sum_p dy[p,o]*x[p,tap] ; partial[chunk][o][9] = sum_p dy[p,o]   (dy already ReLU-masked)
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in1_wgrad_kernel(int B, int Tn, int Fn, int T1, int F1, int O, const T* __restrict__ x,
+                                                             const T* __restrict__ dy, float* __restrict__ partial,
+                                                             int pix_per_chunk) {
+  const int64_t npix = (int64_t)B * T1 * F1;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_chunk;
+  const int64_t p1 = (p0 + pix_per_chunk < npix) ? p0 + pix_per_chunk : npix;
+  for (int o = threadIdx.x; o < O; o += 256) {
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    for (int64_t p = p0; p < p1; ++p) {
+      const int f1 = (int)(p % F1);
+      const int64_t q = p / F1;
+      const int t1 = (int)(q % T1);
+      const int b = (int)(q / T1);
+      const float g = ldf(dy + p * O + o);
+      const T* xb = x + ((int64_t)b * Tn + 2 * t1) * Fn + 2 * f1;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] += g * ldf(xb + kh * Fn + kw);
+      acc[9] += g;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) partial[((int64_t)blockIdx.x * O + o) * 10 + k] = acc[k];
+  }
+}
+
+__global__ void conv_in1_wgrad_final_kernel(int O, int chunks, const float* __restrict__ partial, float* __restrict__ dw,
+                                            float* __restrict__ db, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O * 10) return;
+  float t = 0.f;
+  for (int c = 0; c < chunks; ++c) t += partial[(int64_t)c * O * 10 + i];
+  const int o = i / 10, k = i % 10;
+  if (k < 9) dw[o * 9 + k] = (accumulate ? dw[o * 9 + k] : 0.f) + t;
+  else if (db) db[o] = (accumulate ? db[o] : 0.f) + t;
+}
+
+}  // namespace
+
+extern "C" int s2svc_conv_in1_fwd(int dtype, int B, int Tn, int Fn, int O, const void* x, const float* w, const float* bias,
+                                  void* y, void* stream) {
+  S2S_REQUIRE(O % 8 == 0 && Tn >= 3 && Fn >= 3, "conv_in1_fwd: need O % 8 == 0 and T,F >= 3");
+  const int T1 = (Tn - 3) / 2 + 1, F1 = (Fn - 3) / 2 + 1;
+  const int64_t n = (int64_t)B * T1 * F1 * (O / 8);
+  if (n == 0) return 0;
+  int nb = (int)((n + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  const size_t shm = (size_t)O * 10 * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(conv_in1_fwd_kernel<float>, dim3(nb), dim3(256), shm, st, B, Tn, Fn, T1, F1, O, (const float*)x, w, bias, (float*)y);
+  else
+    hipLaunchKernelGGL(conv_in1_fwd_kernel<bf16_t>, dim3(nb), dim3(256), shm, st, B, Tn, Fn, T1, F1, O, (const bf16_t*)x, w, bias, (bf16_t*)y);
+  S2S_CHECK_LAUNCH("conv_in1_fwd_kernel");
+  return 0;
+}
+
+// partial: >= chunks*O*10 floats with chunks = min(1024, ceil(npix/64)); dw (O,9), db (O) fp32
+extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, const void* x, const void* dy, float* dw, float* db,
+                                    int accumulate, float* partial, int max_chunks, void* stream) {
+  const int T1 = (Tn - 3) / 2 + 1, F1 = (Fn - 3) / 2 + 1;
+  const int64_t npix = (int64_t)B * T1 * F1;
+  if (npix == 0) return 0;
+  S2S_REQUIRE(partial && max_chunks > 0, "conv_in1_wgrad: workspace required");
+  int chunks = (int)((npix + 63) / 64);
+  if (chunks > max_chunks) chunks = max_chunks;
+  const int ppc = (int)((npix + chunks - 1) / chunks);
+  chunks = (int)((npix + ppc - 1) / ppc);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(conv_in1_wgrad_kernel<float>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const float*)x, (const float*)dy, partial, ppc);
+  else
+    hipLaunchKernelGGL(conv_in1_wgrad_kernel<bf16_t>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const bf16_t*)x, (const bf16_t*)dy, partial, ppc);
+  S2S_CHECK_LAUNCH("conv_in1_wgrad_kernel");
+  hipLaunchKernelGGL(conv_in1_wgrad_final_kernel, dim3((O * 10 + 255) / 256), dim3(256), 0, st, O, chunks, partial, dw, db, accumulate);
+  S2S_CHECK_LAUNCH("conv_in1_wgrad_final_kernel");
+  return 0;
+}

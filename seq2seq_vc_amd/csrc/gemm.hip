@@ -13,6 +13,7 @@
 //     the next K-tile's global loads are in flight while the current tile is multiplied.
 //   * K-strided ("RC") operands are transposed on their way into LDS, so fragments are always read
 //     as one 16-byte ds_read per 16x(8|4) sub-block.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/s2svc_hip.h"
 
@@ -224,11 +225,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const s2svc_gemm_desc d) {
     sb.store(Bs, d.B.layout);
   }
   __syncthreads();
+  constexpr int TPR = 256 / BM;  // threads per A row for the fused row sums (bias gradient of a wgrad GEMM)
+  const bool do_rowsum = (d.a_rowsum != nullptr) && (blockIdx.x == 0);
+  float rowsum = 0.f;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = (kt + 1 < kt_end);
     if (more) {
       sa.load(d.A, Ab, m0, (kt + 1) * BK, d.M, d.K);
       sb.load(d.B, Bb, n0, (kt + 1) * BK, d.N, d.K);
+    }
+    if (do_rowsum) {
+      const T* rp = As + (threadIdx.x / TPR) * PITCH + (threadIdx.x % TPR) * (BK / TPR);
+#pragma unroll
+      for (int e = 0; e < BK / TPR; ++e) rowsum += ldf(rp + e);
     }
     Mma<T, FM, FN>::run(As, Bs, wm, wn, acc);
     __syncthreads();
@@ -237,6 +246,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const s2svc_gemm_desc d) {
       sb.store(Bs, d.B.layout);
     }
     __syncthreads();
+  }
+  if (do_rowsum) {
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) rowsum += __shfl_xor(rowsum, o, 64);
+    const int m = m0 + threadIdx.x / TPR;
+    if ((threadIdx.x % TPR) == 0 && m < d.M) {
+      if (splitk > 1) d.a_rowsum_ws[(int64_t)zs * d.M + m] = rowsum;
+      else d.a_rowsum[m] = (d.a_rowsum_accumulate ? d.a_rowsum[m] : 0.f) + rowsum;
+    }
   }
 
   const int lane = threadIdx.x & 63, lc = lane & 15, lq = lane >> 4;
@@ -271,6 +289,13 @@ __global__ void splitk_reduce_kernel(const s2svc_gemm_desc d) {
     const int zb = (int)(t / d.M);
     epilogue_store(d, zb / d.nb1, zb % d.nb1, m, n, s);
   }
+  if (d.a_rowsum) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.M; i += (int64_t)gridDim.x * blockDim.x) {
+      float s = 0.f;
+      for (int z = 0; z < d.splitk; ++z) s += d.a_rowsum_ws[(int64_t)z * d.M + i];
+      d.a_rowsum[i] = (d.a_rowsum_accumulate ? d.a_rowsum[i] : 0.f) + s;
+    }
+  }
 }
 
 template <typename T, int BM, int BN>
@@ -291,6 +316,14 @@ int launch(const s2svc_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream);  // gemm_fast.hip
+
+static bool generic_forced() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
 extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   S2S_REQUIRE(desc != nullptr, "s2svc_gemm: null desc");
   s2svc_gemm_desc d = *desc;
@@ -302,9 +335,24 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   S2S_REQUIRE(d.dtype == S2S_F32 || d.dtype == S2S_BF16, "s2svc_gemm: bad dtype");
   S2S_REQUIRE(d.c_dtype == S2S_F32 || d.c_dtype == S2S_BF16, "s2svc_gemm: bad c_dtype");
   S2S_REQUIRE(d.splitk <= 1 || d.ws != nullptr, "s2svc_gemm: splitk needs workspace");
+  S2S_REQUIRE(!d.a_rowsum || (d.nb0 * d.nb1 == 1 && (d.splitk <= 1 || d.a_rowsum_ws)), "s2svc_gemm: a_rowsum needs nb == 1 (and a workspace with splitk)");
   S2S_REQUIRE(d.A.mode == S2SVC_OP_DENSE || d.A.C > 0, "s2svc_gemm: conv operand A needs C");
   S2S_REQUIRE(d.B.mode == S2SVC_OP_DENSE || d.B.C > 0, "s2svc_gemm: conv operand B needs C");
   hipStream_t st = (hipStream_t)stream;
+  if (!generic_forced()) {
+    const int rc = s2svc_gemm_try_fast(&d, stream);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      if (d.splitk > 1) {
+        const int64_t total = (int64_t)d.nb0 * d.nb1 * d.M * d.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, d);
+        S2S_CHECK_LAUNCH("splitk_reduce_kernel");
+      }
+      return 0;
+    }
+  }
   const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1 * (d.splitk > 1 ? d.splitk : 1);
   const bool big = tiles128 >= 384 && d.M >= 128 && d.N >= 128;
   if (d.dtype == S2S_F32) return big ? launch<float, 128, 128>(d, st) : launch<float, 64, 64>(d, st);

@@ -1,0 +1,382 @@
+// Fast paths of the MFMA GEMM (same contract as gemm.hip::gemm_kernel, which stays as the fully general
+// fallback).  What is different here:
+//   * operand addressing is specialised at compile time (dense / implicit Conv1d / implicit Conv2d-s2, for
+//     K-contiguous "KC" and row-contiguous "RC" operands): per-thread row bases are computed once, the K loop
+//     only adds 32-bit tile offsets;
+//   * deep K tiles (BK = 128 for the 64x64 tile, 64 for the 128x128 tile in bf16) so that the many small GEMMs
+//     of this workload (K = 80..1536) finish in 3-12 global round trips, each with 4 x 16 B loads in flight
+//     per thread and operand;
+//   * RC operands (dgrad weights, wgrad activations, P^T / V in attention) are transposed in REGISTERS
+//     (VECxVEC blocks, v_perm_b32 for bf16) and written to LDS as full 16-byte rows -- no scalar LDS stores.
+// Requirements checked on the host (else the generic kernel runs): 16-byte aligned bases, leading dimensions
+// and batch strides multiples of the vector length, channel counts multiples of the vector length.
+#include "common.h"
+#include "../../include/s2svc_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+namespace {
+
+enum { AM_KC = 0, AM_RC = 1 };
+
+template <typename T> struct VecCfg;
+template <> struct VecCfg<float>  { static constexpr int VEC = 4; static constexpr int PAD = 4; };
+template <> struct VecCfg<bf16_t> { static constexpr int VEC = 8; static constexpr int PAD = 8; };
+
+// ---------------------------------------------------------------------------------------------
+// KC loader: NV vectors per thread, vector = (row, kk..kk+VEC) ; element address = rowbase + f(k)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ROWS, int BK>
+struct KcLoader {
+  static constexpr int VEC = VecCfg<T>::VEC;
+  static constexpr int VPR = BK / VEC;             // vectors per row
+  static constexpr int NV = ROWS * VPR / 256;
+  static_assert(NV >= 1, "tile too small");
+  uint4 reg[NV];
+  int64_t rowbase[NV];
+  int trow[NV];      // conv1d: frame index of the row ; <0: row out of range
+  __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = threadIdx.x + i * 256;
+      const int r = r0 + v / VPR;
+      trow[i] = 0;
+      if (r >= R) { trow[i] = -1; rowbase[i] = 0; continue; }
+      if (o.mode == S2SVC_OP_DENSE) {
+        rowbase[i] = (int64_t)r * o.ld;
+      } else if (o.mode == S2SVC_OP_CONV1D) {
+        rowbase[i] = (int64_t)r * o.ld;
+        trow[i] = r % o.T;
+      } else {
+        const int f2 = r % o.F2, bt = r / o.F2;
+        const int t2 = bt % o.T2, b = bt / o.T2;
+        rowbase[i] = ((int64_t)(b * o.T1 + 2 * t2) * o.F1 + 2 * f2) * o.ld;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(const s2svc_operand& o, const T* base, int k0, int K) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = threadIdx.x + i * 256;
+      const int k = k0 + (v % VPR) * VEC;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (trow[i] >= 0 && k < K) {
+        if (o.mode == S2SVC_OP_DENSE) {
+          val = *reinterpret_cast<const uint4*>(base + rowbase[i] + k);
+        } else {
+          const int tap = k / o.C, c = k - tap * o.C;
+          if (o.mode == S2SVC_OP_CONV1D) {
+            const int tt = trow[i] + tap - o.pad;
+            if (tt >= 0 && tt < o.T) val = *reinterpret_cast<const uint4*>(base + rowbase[i] + (int64_t)(tap - o.pad) * o.ld + c);
+          } else {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            val = *reinterpret_cast<const uint4*>(base + rowbase[i] + (int64_t)(kh * o.F1 + kw) * o.ld + c);
+          }
+        }
+      }
+      reg[i] = val;
+    }
+  }
+  __device__ __forceinline__ void store(T* lds) const {
+    constexpr int PITCH = BK + VecCfg<T>::PAD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = threadIdx.x + i * 256;
+      *reinterpret_cast<uint4*>(lds + (v / VPR) * PITCH + (v % VPR) * VEC) = reg[i];
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// RC loader: VEC x VEC register-block transpose.  Block (kb, rb): VEC loads of 16 B at k = k0+kb*VEC+j,
+// rows r0+rb*VEC.. ; stored as VEC rows of 16 B.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Transposer;
+template <> struct Transposer<float> {
+  static __device__ __forceinline__ void run(const uint4 (&in)[4], uint4 (&out)[4]) {
+    out[0] = make_uint4(in[0].x, in[1].x, in[2].x, in[3].x);
+    out[1] = make_uint4(in[0].y, in[1].y, in[2].y, in[3].y);
+    out[2] = make_uint4(in[0].z, in[1].z, in[2].z, in[3].z);
+    out[3] = make_uint4(in[0].w, in[1].w, in[2].w, in[3].w);
+  }
+};
+template <> struct Transposer<bf16_t> {
+  static __device__ __forceinline__ uint32_t lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+  static __device__ __forceinline__ uint32_t hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+  static __device__ __forceinline__ void run(const uint4 (&in)[8], uint4 (&out)[8]) {
+    // out[e] = (in[0][e], in[1][e], ..., in[7][e]) ; element e of in[j] sits in dword e/2, half e%2
+    out[0] = make_uint4(lo(in[0].x, in[1].x), lo(in[2].x, in[3].x), lo(in[4].x, in[5].x), lo(in[6].x, in[7].x));
+    out[1] = make_uint4(hi(in[0].x, in[1].x), hi(in[2].x, in[3].x), hi(in[4].x, in[5].x), hi(in[6].x, in[7].x));
+    out[2] = make_uint4(lo(in[0].y, in[1].y), lo(in[2].y, in[3].y), lo(in[4].y, in[5].y), lo(in[6].y, in[7].y));
+    out[3] = make_uint4(hi(in[0].y, in[1].y), hi(in[2].y, in[3].y), hi(in[4].y, in[5].y), hi(in[6].y, in[7].y));
+    out[4] = make_uint4(lo(in[0].z, in[1].z), lo(in[2].z, in[3].z), lo(in[4].z, in[5].z), lo(in[6].z, in[7].z));
+    out[5] = make_uint4(hi(in[0].z, in[1].z), hi(in[2].z, in[3].z), hi(in[4].z, in[5].z), hi(in[6].z, in[7].z));
+    out[6] = make_uint4(lo(in[0].w, in[1].w), lo(in[2].w, in[3].w), lo(in[4].w, in[5].w), lo(in[6].w, in[7].w));
+    out[7] = make_uint4(hi(in[0].w, in[1].w), hi(in[2].w, in[3].w), hi(in[4].w, in[5].w), hi(in[6].w, in[7].w));
+  }
+};
+
+template <typename T, int ROWS, int BK>
+struct RcLoader {
+  static constexpr int VEC = VecCfg<T>::VEC;
+  static constexpr int RB = ROWS / VEC;                 // row blocks
+  static constexpr int NBLK = (BK / VEC) * RB;          // blocks per tile
+  static constexpr int NB = (NBLK + 255) / 256;         // blocks per thread (some threads idle when NBLK < 256)
+  uint4 reg[NB][VEC];
+  __device__ __forceinline__ void init(const s2svc_operand&, int, int) {}
+  __device__ __forceinline__ void load(const s2svc_operand& o, const T* base, int r0, int R, int k0, int K) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int blk = threadIdx.x + n * 256;
+      const bool active = blk < NBLK;
+      const int rb = blk % RB, kb = blk / RB;
+      const int r = r0 + rb * VEC;
+      int tap = 0, c = r;
+      if (o.mode != S2SVC_OP_DENSE) { tap = r / o.C; c = r - tap * o.C; }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int k = k0 + kb * VEC + j;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (active && r < R && k < K) {
+          if (o.mode == S2SVC_OP_DENSE) {
+            val = *reinterpret_cast<const uint4*>(base + (int64_t)k * o.ld + r);
+          } else if (o.mode == S2SVC_OP_CONV1D) {
+            const int t = k % o.T, tt = t + tap - o.pad;
+            if (tt >= 0 && tt < o.T) val = *reinterpret_cast<const uint4*>(base + (int64_t)(k + tap - o.pad) * o.ld + c);
+          } else {
+            const int f2 = k % o.F2, bt = k / o.F2;
+            const int t2 = bt % o.T2, b = bt / o.T2;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            val = *reinterpret_cast<const uint4*>(base + ((int64_t)(b * o.T1 + 2 * t2 + kh) * o.F1 + (2 * f2 + kw)) * o.ld + c);
+          }
+        }
+        reg[n][j] = val;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(T* lds) const {
+    constexpr int PITCH = BK + VecCfg<T>::PAD;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int blk = threadIdx.x + n * 256;
+      if (blk < NBLK) {
+        const int rb = blk % RB, kb = blk / RB;
+        uint4 out[VEC];
+        Transposer<T>::run(reg[n], out);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) *reinterpret_cast<uint4*>(lds + (rb * VEC + e) * PITCH + kb * VEC) = out[e];
+      }
+    }
+  }
+};
+
+template <typename T, int ROWS, int BK, int MODE> struct Loader;
+template <typename T, int ROWS, int BK> struct Loader<T, ROWS, BK, AM_KC> {
+  KcLoader<T, ROWS, BK> l;
+  __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) { l.init(o, r0, R); }
+  __device__ __forceinline__ void load(const s2svc_operand& o, const T* base, int r0, int R, int k0, int K) { l.load(o, base, k0, K); }
+  __device__ __forceinline__ void store(T* lds) const { l.store(lds); }
+};
+template <typename T, int ROWS, int BK> struct Loader<T, ROWS, BK, AM_RC> {
+  RcLoader<T, ROWS, BK> l;
+  __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) { l.init(o, r0, R); }
+  __device__ __forceinline__ void load(const s2svc_operand& o, const T* base, int r0, int R, int k0, int K) { l.load(o, base, r0, R, k0, K); }
+  __device__ __forceinline__ void store(T* lds) const { l.store(lds); }
+};
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, int FM, int FN, int BK> struct MmaF;
+template <int FM, int FN, int BK> struct MmaF<bf16_t, FM, FN, BK> {
+  static __device__ __forceinline__ void run(const bf16_t* As, const bf16_t* Bs, int wm, int wn, f32x4_t (&acc)[FM][FN]) {
+    constexpr int P = BK + VecCfg<bf16_t>::PAD;
+    const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm + i * 16 + lr) * P + ks * 32 + lg * 8);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn + j * 16 + lr) * P + ks * 32 + lg * 8);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+template <int FM, int FN, int BK> struct MmaF<float, FM, FN, BK> {
+  static __device__ __forceinline__ void run(const float* As, const float* Bs, int wm, int wn, f32x4_t (&acc)[FM][FN]) {
+    constexpr int P = BK + VecCfg<float>::PAD;
+    const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      f32x4_t a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const f32x4_t*>(As + (wm + i * 16 + lr) * P + ks * 16 + lg * 4);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const f32x4_t*>(Bs + (wn + j * 16 + lr) * P + ks * 16 + lg * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+
+__device__ __forceinline__ void epilogue_store_f(const s2svc_gemm_desc& d, int z0, int z1, int m, int n, float v) {
+  v *= d.alpha;
+  if (d.bias) v += d.bias[n];
+  v = act_apply(v, d.act);
+  const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
+  if (d.res) {
+    const int64_t ro = (int64_t)z0 * d.rbs0 + (int64_t)z1 * d.rbs1 + (int64_t)m * d.ldr + n;
+    v += d.c_dtype == S2S_F32 ? ((const float*)d.res)[ro] : bf2f(((const bf16_t*)d.res)[ro]);
+  }
+  if (d.c_dtype == S2S_F32) {
+    float* c = (float*)d.C + co;
+    *c = d.accumulate ? *c + v : v;
+  } else {
+    bf16_t* c = (bf16_t*)d.C + co;
+    *c = f2bf(d.accumulate ? bf2f(*c) + v : v);
+  }
+}
+
+template <typename T, int BM, int BN, int BK, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(const s2svc_gemm_desc d) {
+  constexpr int PITCH = BK + VecCfg<T>::PAD;
+  constexpr int FM = BM / 32, FN = BN / 32;
+  __shared__ __attribute__((aligned(16))) T As[BM * PITCH];
+  __shared__ __attribute__((aligned(16))) T Bs[BN * PITCH];
+
+  const int splitk = d.splitk > 1 ? d.splitk : 1;
+  const int zb = blockIdx.z / splitk, zs = blockIdx.z - zb * splitk;
+  const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const T* Ab = (const T*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1;
+  const T* Bb = (const T*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1;
+  const int ktiles = (d.K + BK - 1) / BK;
+  const int per = (ktiles + splitk - 1) / splitk;
+  const int kt_begin = zs * per;
+  const int kt_end = (kt_begin + per < ktiles) ? kt_begin + per : ktiles;
+  const int wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  Loader<T, BM, BK, AMODE> la;
+  Loader<T, BN, BK, BMODE> lb;
+  la.init(d.A, m0, d.M);
+  lb.init(d.B, n0, d.N);
+  if (kt_begin < kt_end) {
+    la.load(d.A, Ab, m0, d.M, kt_begin * BK, d.K);
+    lb.load(d.B, Bb, n0, d.N, kt_begin * BK, d.K);
+    la.store(As);
+    lb.store(Bs);
+  }
+  __syncthreads();
+  constexpr int TPR = 256 / BM;                  // threads per A row for the fused row sums
+  const bool do_rowsum = (d.a_rowsum != nullptr) && (blockIdx.x == 0);
+  float rowsum = 0.f;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = (kt + 1 < kt_end);
+    if (more) {
+      la.load(d.A, Ab, m0, d.M, (kt + 1) * BK, d.K);
+      lb.load(d.B, Bb, n0, d.N, (kt + 1) * BK, d.K);
+    }
+    if (do_rowsum) {
+      const T* rp = As + (threadIdx.x / TPR) * PITCH + (threadIdx.x % TPR) * (BK / TPR);
+#pragma unroll 8
+      for (int e = 0; e < BK / TPR; ++e) rowsum += ldf(rp + e);
+    }
+    MmaF<T, FM, FN, BK>::run(As, Bs, wm, wn, acc);
+    __syncthreads();
+    if (more) {
+      la.store(As);
+      lb.store(Bs);
+    }
+    __syncthreads();
+  }
+
+  if (do_rowsum) {
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) rowsum += __shfl_xor(rowsum, o, 64);
+    const int m = m0 + threadIdx.x / TPR;
+    if ((threadIdx.x % TPR) == 0 && m < d.M) {
+      if (splitk > 1) d.a_rowsum_ws[(int64_t)zs * d.M + m] = rowsum;
+      else d.a_rowsum[m] = (d.a_rowsum_accumulate ? d.a_rowsum[m] : 0.f) + rowsum;
+    }
+  }
+  const int lane = threadIdx.x & 63, lc = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + lq * 4 + r;
+        const int n = n0 + wn + j * 16 + lc;
+        if (m < d.M && n < d.N) {
+          if (splitk > 1) {
+            const int nbatch = d.nb0 * d.nb1;
+            d.ws[(((int64_t)zs * nbatch + zb) * d.M + m) * d.N + n] = acc[i][j][r];
+          } else {
+            epilogue_store_f(d, z0, z1, m, n, acc[i][j][r]);
+          }
+        }
+      }
+}
+
+template <typename T, int BM, int BN, int BK>
+void launch_modes(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
+  const bool arc = d.A.layout == S2SVC_LAYOUT_RC, brc = d.B.layout == S2SVC_LAYOUT_RC;
+  if (!arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_KC, AM_KC>), grid, dim3(256), 0, st, d);
+  else if (!arc && brc) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_KC, AM_RC>), grid, dim3(256), 0, st, d);
+  else if (arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_RC, AM_KC>), grid, dim3(256), 0, st, d);
+  else hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_RC, AM_RC>), grid, dim3(256), 0, st, d);
+}
+
+bool operand_ok(const s2svc_operand& o, int vec, size_t esz) {
+  if (((uintptr_t)o.ptr) % 16) return false;
+  if (o.ld % vec || o.bs0 % vec || o.bs1 % vec) return false;
+  if (o.mode != S2SVC_OP_DENSE && (o.C % vec)) return false;
+  (void)esz;
+  return true;
+}
+
+}  // namespace
+
+// returns 1 if the fast path was launched, 0 if the caller must use the generic kernel, <0 on error
+extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream) {
+  const s2svc_gemm_desc& d = *desc;
+  const int vec = d.dtype == S2S_F32 ? 4 : 8;
+  const size_t esz = d.dtype == S2S_F32 ? 4 : 2;
+  if (!operand_ok(d.A, vec, esz) || !operand_ok(d.B, vec, esz)) return 0;
+  // RC dense operands are read as 16-byte vectors along the row index: the row extent must be a vector multiple
+  if (d.A.layout == S2SVC_LAYOUT_RC && (d.M % vec)) return 0;
+  if (d.B.layout == S2SVC_LAYOUT_RC && (d.N % vec)) return 0;
+  // KC operands are read as 16-byte vectors along k
+  if (d.A.layout == S2SVC_LAYOUT_KC && (d.K % vec)) return 0;
+  if (d.B.layout == S2SVC_LAYOUT_KC && (d.K % vec)) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int splitk = d.splitk > 1 ? d.splitk : 1;
+  const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1 * splitk;
+  const bool big = tiles128 >= 256 && d.M >= 128 && d.N >= 128;
+  if (big) {
+    dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.nb0 * d.nb1 * splitk);
+    if (d.dtype == S2S_F32) launch_modes<float, 128, 128, 32>(d, grid, st);
+    else launch_modes<bf16_t, 128, 128, 64>(d, grid, st);
+  } else {
+    dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.nb0 * d.nb1 * splitk);
+    if (d.dtype == S2S_F32) launch_modes<float, 64, 64, 64>(d, grid, st);
+    else launch_modes<bf16_t, 64, 64, 128>(d, grid, st);
+  }
+  S2S_CHECK_LAUNCH("gemm_fast_kernel");
+  return 1;
+}

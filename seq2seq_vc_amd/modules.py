@@ -364,7 +364,10 @@ class Conv2dSubsampling(nn.Module):
     def forward(self, x, lens):
         B, T, idim = x.shape
         c0, c2 = self.conv[0], self.conv[2]
-        y = Fn.conv2d_s2_relu(x.reshape(B, T, idim, 1), c0.weight, c0.bias)
+        if c0.weight.shape[0] % 8 == 0:
+            y = Fn.conv_in1_relu(x, c0.weight, c0.bias)              # direct streaming kernel (C_in = 1)
+        else:
+            y = Fn.conv2d_s2_relu(x.reshape(B, T, idim, 1), c0.weight, c0.bias)
         y = Fn.conv2d_s2_relu(y, c2.weight, c2.bias)          # (B, T2, F2, C) channel-last
         _, T2, F2, C = y.shape
         lin = self.out[0] if self.use_pos_enc else self.out

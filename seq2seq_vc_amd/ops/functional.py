@@ -69,6 +69,30 @@ def _emit_vgrad(param, value):
     return value.view(param.shape)
 
 
+def _bias_sink(bias, n):
+    """Where a wgrad GEMM should put the fused bias gradient: (buffer, accumulate, value_for_autograd)."""
+    if bias is None or not bias.requires_grad:
+        return None, False, None
+    slot = getattr(bias, "_s2s_grad", None)
+    if slot is not None:
+        return slot.view(-1), True, None
+    buf = torch.empty(n, dtype=torch.float32, device=bias.device)
+    return buf, False, buf.view(bias.shape)
+
+
+def _reduce_to(p_sum, p_dot, mode, dy, x=None, mean=None, rstd=None):
+    """Column reduction whose results are the gradients of `p_sum` (sum_r dy) and `p_dot` (sum_r dy*xhat): written
+    (accumulated) straight into their flat-gradient slots when they have them -> (None, None) for autograd."""
+    s_slot = getattr(p_sum, "_s2s_grad", None)
+    d_slot = getattr(p_dot, "_s2s_grad", None) if p_dot is not None else None
+    if s_slot is not None and (p_dot is None or d_slot is not None):
+        K.colreduce(mode, dy, x, mean, rstd, want_dot=p_dot is not None, out_sum=s_slot.view(-1),
+                    out_dot=None if d_slot is None else d_slot.view(-1), accumulate=True)
+        return None, None
+    s, d = K.colreduce(mode, dy, x, mean, rstd, want_dot=p_dot is not None)
+    return s.view(p_sum.shape), (None if d is None else d.view(p_dot.shape))
+
+
 # ================================================================================================
 # Linear (+bias, +activation)          reference: torch.nn.Linear call sites of the hot path
 # ================================================================================================
@@ -107,16 +131,16 @@ class _Linear(Function):
         dw = db = None
         if weight.requires_grad:
             sk = K.pick_splitk(N, Kd, M)
+            rs, racc, db = _bias_sink(bias, N)     # bias gradient = row sums of dY^T, fused into the wgrad GEMM
 
             def wr(out, acc):
                 K.gemm(K.operand(dy2, N, layout=K.RC), K.operand(x2, Kd, layout=K.RC), N, Kd, M, out, in_dtype=dtype,
-                       splitk=sk, accumulate=acc)
+                       splitk=sk, accumulate=acc, a_rowsum=rs, a_rowsum_accumulate=racc)
             dw = _emit_wgrad(weight, (N, Kd), wr)
             if dw is not None:
                 dw = dw.view(weight.shape)  # 1x1 Conv1d weights (N, K, 1) are accepted as Linear weights
-        if ctx.has_bias and bias.requires_grad:
-            s, _ = K.colreduce(0, dy2)
-            db = _emit_vgrad(bias, s)
+        elif ctx.has_bias and bias.requires_grad:
+            db, _ = _reduce_to(bias, None, 0, dy2)
         return dx, dw, db, None
 
 
@@ -154,8 +178,7 @@ class _AddLayerNorm(Function):
                                  want_dh=fused and (p > 0.0 or hscale != 1.0), hscale=hscale)
         dgamma = dbeta = None
         if gamma.requires_grad:
-            sb, sg = K.colreduce(1, dy, s, mean, rstd, want_dot=True)
-            dgamma, dbeta = _emit_vgrad(gamma, sg), _emit_vgrad(beta, sb)
+            dbeta, dgamma = _reduce_to(beta, gamma, 1, dy, s, mean, rstd)
         if fused:
             return (dh if dh is not None else ds), ds, dgamma, dbeta, None, None, None
         return ds, None, dgamma, dbeta, None, None, None
@@ -467,13 +490,14 @@ class _Conv1d(Function):
         dw = db = None
         if weight.requires_grad:
             dwp = torch.empty((Cout, ks * Cin), dtype=torch.float32, device=x.device)
+            rs, racc, db = _bias_sink(bias, Cout)
             K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad), Cout,
-                   ks * Cin, B * T, dwp, in_dtype=dtype, splitk=K.pick_splitk(Cout, ks * Cin, B * T))
+                   ks * Cin, B * T, dwp, in_dtype=dtype, splitk=K.pick_splitk(Cout, ks * Cin, B * T), a_rowsum=rs,
+                   a_rowsum_accumulate=racc)
             dwt = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
             dw = _emit_vgrad(weight, dwt)
-        if bias is not None and bias.requires_grad:
-            s, _ = K.colreduce(0, dy.view(B * T, Cout))
-            db = _emit_vgrad(bias, s)
+        elif bias is not None and bias.requires_grad:
+            db, _ = _reduce_to(bias, None, 0, dy.view(B * T, Cout))
         return dx, dw, db, None
 
 
@@ -519,18 +543,48 @@ class _Conv2dS2(Function):
         dw = db = None
         if weight.requires_grad:
             dwp = torch.empty((O, 9 * C), dtype=torch.float32, device=x.device)
+            rs, racc, db = _bias_sink(bias, O)
             K.gemm(K.operand(dy, O, layout=K.RC), K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2),
-                   O, 9 * C, M2, dwp, in_dtype=dtype, splitk=K.pick_splitk(O, 9 * C, M2))
+                   O, 9 * C, M2, dwp, in_dtype=dtype, splitk=K.pick_splitk(O, 9 * C, M2), a_rowsum=rs, a_rowsum_accumulate=racc)
             dwt = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32)
             dw = _emit_vgrad(weight, dwt)
-        if bias is not None and bias.requires_grad:
-            s, _ = K.colreduce(0, dy.view(M2, O))
-            db = _emit_vgrad(bias, s)
+        elif bias is not None and bias.requires_grad:
+            db, _ = _reduce_to(bias, None, 0, dy.view(M2, O))
         return dx, dw, db
 
 
 def conv2d_s2_relu(x_nhwc, weight, bias):
     return _Conv2dS2.apply(x_nhwc, weight, bias)
+
+
+class _ConvIn1(Function):
+    """Conv2d(1 -> O, 3x3, stride 2) + ReLU straight on the (B, T, F) mel batch (subsampling.py:58-60)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _c(x)
+        y = K.conv_in1_fwd(x, weight.detach(), bias.detach() if bias is not None else None)
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.params
+        dy = K.act_dropout_bwd(_c(dy), y, act="relu")
+        wslot, bslot = getattr(weight, "_s2s_grad", None), getattr(bias, "_s2s_grad", None) if bias is not None else None
+        if wslot is not None and (bias is None or bslot is not None):
+            K.conv_in1_wgrad(x, dy, wslot, bslot, True)
+            return None, None, None
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+        db = torch.empty(bias.shape, dtype=torch.float32, device=x.device) if bias is not None else None
+        K.conv_in1_wgrad(x, dy, dw, db, False)
+        return None, dw, db
+
+
+def conv_in1_relu(x, weight, bias):
+    return _ConvIn1.apply(x, weight, bias)
 
 
 class _LinearPermuted(Function):
@@ -569,13 +623,13 @@ class _LinearPermuted(Function):
         dw = db = None
         if weight.requires_grad:
             dwp = torch.empty((D, Kd), dtype=torch.float32, device=x.device)
+            rs, racc, db = _bias_sink(bias, D)
             K.gemm(K.operand(dy, D, layout=K.RC), K.operand(x, Kd, layout=K.RC), D, Kd, M, dwp, in_dtype=dtype,
-                   splitk=K.pick_splitk(D, Kd, M))
+                   splitk=K.pick_splitk(D, Kd, M), a_rowsum=rs, a_rowsum_accumulate=racc)
             dwt = K.gather3(dwp, (D, C, Fd), (Kd, 1, C), 0, torch.float32)
             dw = _emit_vgrad(weight, dwt)
-        if bias is not None and bias.requires_grad:
-            s, _ = K.colreduce(0, dy)
-            db = _emit_vgrad(bias, s)
+        elif bias is not None and bias.requires_grad:
+            db, _ = _reduce_to(bias, None, 0, dy)
         return dx, dw, db, None, None
 
 

@@ -103,7 +103,8 @@ def pick_splitk(M, N, K, nbatch=1):
 
 
 def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
-         ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False):
+         ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False, a_rowsum=None,
+         a_rowsum_accumulate=False):
     """C = act(alpha * A.B^T + bias) + res   (see s2svc_gemm in include/s2svc_hip.h)."""
     d = _lib.GemmDesc()
     d.A, d.B = A, B
@@ -127,6 +128,13 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         d.ws = ws.data_ptr()
     else:
         d.ws = None
+    rs_ws = None
+    if a_rowsum is not None:
+        d.a_rowsum = a_rowsum.data_ptr()
+        d.a_rowsum_accumulate = 1 if a_rowsum_accumulate else 0
+        if splitk > 1:
+            rs_ws = torch.empty(splitk * M, dtype=torch.float32, device=out.device)
+            d.a_rowsum_ws = rs_ws.data_ptr()
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("gemm bias must be fp32")
     if res is not None and res.dtype != out.dtype:
@@ -165,15 +173,20 @@ def layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=None, p=0.0, seed=(None, 0)
 _WS_CHUNKS = 64
 
 
-def colreduce(mode, dy, x=None, mean=None, rstd=None, scale=1.0, want_dot=False, rows=None, D=None):
+def colreduce(mode, dy, x=None, mean=None, rstd=None, scale=1.0, want_dot=False, rows=None, D=None, out_sum=None,
+              out_dot=None, accumulate=False):
+    """Deterministic column reduction; `out_sum`/`out_dot` (fp32, D) may be given (e.g. flat-gradient slots,
+    with accumulate=True) instead of being allocated."""
     t = dy if dy is not None else x
     D = t.shape[-1] if D is None else D
     rows = t.numel() // D if rows is None else rows
-    out_sum = torch.empty(D, dtype=torch.float32, device=t.device)
-    out_dot = torch.empty(D, dtype=torch.float32, device=t.device) if want_dot else None
+    if out_sum is None:
+        out_sum = torch.empty(D, dtype=torch.float32, device=t.device)
+    if out_dot is None and want_dot:
+        out_dot = torch.empty(D, dtype=torch.float32, device=t.device)
     ws = torch.empty(_WS_CHUNKS * 2 * D, dtype=torch.float32, device=t.device)
     _lib.check(_lib.lib().s2svc_colreduce(dt(t), rows, D, mode, ptr(dy), ptr(x), ptr(mean), ptr(rstd), scale, ptr(out_sum),
-                                          ptr(out_dot), 0, ptr(ws), _WS_CHUNKS, stream()), "colreduce")
+                                          ptr(out_dot), 1 if accumulate else 0, ptr(ws), _WS_CHUNKS, stream()), "colreduce")
     return out_sum, out_dot
 
 
@@ -408,3 +421,21 @@ def interp_nearest_bwd(dy, Tin):
     dx = torch.empty((B, Tin, C), dtype=dy.dtype, device=dy.device)
     _lib.check(_lib.lib().s2svc_interp_nearest_bwd(dt(dy), B, Tin, Tout, C, ptr(dy), ptr(dx), stream()), "interp_nearest_bwd")
     return dx
+
+
+def conv_in1_fwd(x, w, bias):
+    """x (B,T,F) compute dtype; w fp32 (O,1,3,3); -> relu(conv3x3 s2) as NHWC (B,T1,F1,O)."""
+    B, T, Fd = x.shape
+    O = w.shape[0]
+    y = torch.empty((B, (T - 3) // 2 + 1, (Fd - 3) // 2 + 1, O), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().s2svc_conv_in1_fwd(dt(x), B, T, Fd, O, ptr(x), ptr(w), ptr(bias), ptr(y), stream()), "conv_in1_fwd")
+    return y
+
+
+def conv_in1_wgrad(x, dy, dw, db, accumulate):
+    B, T, Fd = x.shape
+    O = dy.shape[-1]
+    chunks = 1024
+    partial = torch.empty(chunks * O * 10, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().s2svc_conv_in1_wgrad(dt(x), B, T, Fd, O, ptr(x), ptr(dy), ptr(dw), ptr(db), 1 if accumulate else 0,
+                                               ptr(partial), chunks, stream()), "conv_in1_wgrad")
