@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3)")
+    ap.add_argument("--side-streams", type=int, default=4, help="HIP side streams for parameter-gradient kernels (0 = off)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,6 +152,7 @@ def main():
         print(json.dumps(dominant_kernel_roofline(dtype, iters=200)))
         return
     Fn.set_compute_dtype(dtype)
+    Fn.enable_side_streams(args.side_streams)
     K.manual_seed(1234 + rank)
 
     B = args.batch
@@ -179,6 +181,7 @@ def main():
         after, before, logits, ys_, labels_, olens_, _ = model(xs_d, ilens, ys_d, labels_d, olens)
         l1, bce = crit(after, before, logits, ys_, labels_, olens_)
         (l1 + bce).backward()
+        Fn.side_join()
         loss_buf[0].copy_(l1.detach())
         loss_buf[1].copy_(bce.detach())
 

@@ -69,6 +69,53 @@ def _emit_vgrad(param, value):
     return value.view(param.shape)
 
 
+# ------------------------------------------------------------------------------------------------
+# Side streams for parameter-gradient work.  Weight / bias / LayerNorm gradients are only consumed by
+# the optimiser at the end of the step, so (when they land in flat-gradient slots) their kernels are
+# issued on a small pool of side HIP streams and overlap with the data-gradient chain on the main
+# stream; `side_join()` must be called after backward() and before the optimiser step.  Under hipGraph
+# capture the cross-stream waits become graph edges, i.e. parallel branches of the captured step.
+# ------------------------------------------------------------------------------------------------
+class _Side:
+    enabled = False
+    streams = []
+    idx = 0
+    pending = []     # tensors that must stay alive until the join (their memory is in use on a side stream)
+
+
+def enable_side_streams(n=4):
+    _Side.enabled = n > 0
+    _Side.streams = [torch.cuda.Stream() for _ in range(n)] if n > 0 else []
+    _Side.idx = 0
+
+
+def _side_run(fn, keep=()):
+    if not _Side.enabled:
+        fn()
+        return
+    main = torch.cuda.current_stream()
+    st = _Side.streams[_Side.idx % len(_Side.streams)]
+    _Side.idx += 1
+    st.wait_stream(main)
+    with torch.cuda.stream(st):
+        fn()
+    _Side.pending.append(keep)
+
+
+def side_join():
+    """Make the current stream wait for all side-stream gradient work (call between backward and optimiser)."""
+    if _Side.enabled:
+        main = torch.cuda.current_stream()
+        for st in _Side.streams:
+            main.wait_stream(st)
+    _Side.pending.clear()
+    _Side.idx = 0
+
+
+def _slotted(*params):
+    return all(p is None or getattr(p, "_s2s_grad", None) is not None for p in params)
+
+
 def _bias_sink(bias, n):
     """Where a wgrad GEMM should put the fused bias gradient: (buffer, accumulate, value_for_autograd)."""
     if bias is None or not bias.requires_grad:
@@ -136,9 +183,12 @@ class _Linear(Function):
             def wr(out, acc):
                 K.gemm(K.operand(dy2, N, layout=K.RC), K.operand(x2, Kd, layout=K.RC), N, Kd, M, out, in_dtype=dtype,
                        splitk=sk, accumulate=acc, a_rowsum=rs, a_rowsum_accumulate=racc)
-            dw = _emit_wgrad(weight, (N, Kd), wr)
-            if dw is not None:
-                dw = dw.view(weight.shape)  # 1x1 Conv1d weights (N, K, 1) are accepted as Linear weights
+            if _slotted(weight, bias if ctx.has_bias else None):
+                _side_run(lambda: _emit_wgrad(weight, (N, Kd), wr), keep=(dy2, x2))
+            else:
+                dw = _emit_wgrad(weight, (N, Kd), wr)
+                if dw is not None:
+                    dw = dw.view(weight.shape)  # 1x1 Conv1d weights (N, K, 1) are accepted as Linear weights
         elif ctx.has_bias and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy2)
         return dx, dw, db, None
@@ -178,7 +228,10 @@ class _AddLayerNorm(Function):
                                  want_dh=fused and (p > 0.0 or hscale != 1.0), hscale=hscale)
         dgamma = dbeta = None
         if gamma.requires_grad:
-            dbeta, dgamma = _reduce_to(beta, gamma, 1, dy, s, mean, rstd)
+            if _slotted(gamma, beta):
+                _side_run(lambda: _reduce_to(beta, gamma, 1, dy, s, mean, rstd), keep=(dy, s, mean, rstd))
+            else:
+                dbeta, dgamma = _reduce_to(beta, gamma, 1, dy, s, mean, rstd)
         if fused:
             return (dh if dh is not None else ds), ds, dgamma, dbeta, None, None, None
         return ds, None, dgamma, dbeta, None, None, None
@@ -489,13 +542,18 @@ class _Conv1d(Function):
                    in_dtype=dtype)
         dw = db = None
         if weight.requires_grad:
-            dwp = torch.empty((Cout, ks * Cin), dtype=torch.float32, device=x.device)
-            rs, racc, db = _bias_sink(bias, Cout)
-            K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad), Cout,
-                   ks * Cin, B * T, dwp, in_dtype=dtype, splitk=K.pick_splitk(Cout, ks * Cin, B * T), a_rowsum=rs,
-                   a_rowsum_accumulate=racc)
-            dwt = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
-            dw = _emit_vgrad(weight, dwt)
+            def work():
+                dwp = torch.empty((Cout, ks * Cin), dtype=torch.float32, device=x.device)
+                rs, racc, dbv = _bias_sink(bias, Cout)
+                K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad),
+                       Cout, ks * Cin, B * T, dwp, in_dtype=dtype, splitk=K.pick_splitk(Cout, ks * Cin, B * T), a_rowsum=rs,
+                       a_rowsum_accumulate=racc)
+                dwt = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
+                return _emit_vgrad(weight, dwt), dbv
+            if _slotted(weight, bias):
+                _side_run(work, keep=(dy, x))
+            else:
+                dw, db = work()
         elif bias is not None and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy.view(B * T, Cout))
         return dx, dw, db, None
@@ -542,12 +600,18 @@ class _Conv2dS2(Function):
             dx = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)
         dw = db = None
         if weight.requires_grad:
-            dwp = torch.empty((O, 9 * C), dtype=torch.float32, device=x.device)
-            rs, racc, db = _bias_sink(bias, O)
-            K.gemm(K.operand(dy, O, layout=K.RC), K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2),
-                   O, 9 * C, M2, dwp, in_dtype=dtype, splitk=K.pick_splitk(O, 9 * C, M2), a_rowsum=rs, a_rowsum_accumulate=racc)
-            dwt = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32)
-            dw = _emit_vgrad(weight, dwt)
+            def work():
+                dwp = torch.empty((O, 9 * C), dtype=torch.float32, device=x.device)
+                rs, racc, dbv = _bias_sink(bias, O)
+                K.gemm(K.operand(dy, O, layout=K.RC),
+                       K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M2, dwp,
+                       in_dtype=dtype, splitk=K.pick_splitk(O, 9 * C, M2), a_rowsum=rs, a_rowsum_accumulate=racc)
+                dwt = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32)
+                return _emit_vgrad(weight, dwt), dbv
+            if _slotted(weight, bias):
+                _side_run(work, keep=(dy, x))
+            else:
+                dw, db = work()
         elif bias is not None and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy.view(M2, O))
         return dx, dw, db
@@ -575,7 +639,7 @@ class _ConvIn1(Function):
         dy = K.act_dropout_bwd(_c(dy), y, act="relu")
         wslot, bslot = getattr(weight, "_s2s_grad", None), getattr(bias, "_s2s_grad", None) if bias is not None else None
         if wslot is not None and (bias is None or bslot is not None):
-            K.conv_in1_wgrad(x, dy, wslot, bslot, True)
+            _side_run(lambda: K.conv_in1_wgrad(x, dy, wslot, bslot, True), keep=(x, dy))
             return None, None, None
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
         db = torch.empty(bias.shape, dtype=torch.float32, device=x.device) if bias is not None else None
@@ -622,12 +686,17 @@ class _LinearPermuted(Function):
             dx = dx.view(x.shape)
         dw = db = None
         if weight.requires_grad:
-            dwp = torch.empty((D, Kd), dtype=torch.float32, device=x.device)
-            rs, racc, db = _bias_sink(bias, D)
-            K.gemm(K.operand(dy, D, layout=K.RC), K.operand(x, Kd, layout=K.RC), D, Kd, M, dwp, in_dtype=dtype,
-                   splitk=K.pick_splitk(D, Kd, M), a_rowsum=rs, a_rowsum_accumulate=racc)
-            dwt = K.gather3(dwp, (D, C, Fd), (Kd, 1, C), 0, torch.float32)
-            dw = _emit_vgrad(weight, dwt)
+            def work():
+                dwp = torch.empty((D, Kd), dtype=torch.float32, device=x.device)
+                rs, racc, dbv = _bias_sink(bias, D)
+                K.gemm(K.operand(dy, D, layout=K.RC), K.operand(x, Kd, layout=K.RC), D, Kd, M, dwp, in_dtype=dtype,
+                       splitk=K.pick_splitk(D, Kd, M), a_rowsum=rs, a_rowsum_accumulate=racc)
+                dwt = K.gather3(dwp, (D, C, Fd), (Kd, 1, C), 0, torch.float32)
+                return _emit_vgrad(weight, dwt), dbv
+            if _slotted(weight, bias):
+                _side_run(work, keep=(dy, x))
+            else:
+                dw, db = work()
         elif bias is not None and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy)
         return dx, dw, db, None, None

@@ -17,6 +17,7 @@ from collections import OrderedDict, defaultdict
 import torch
 
 from ..optim import FlatAdam
+from ..ops import functional as Fn
 from ..ops import kernels as K
 
 
@@ -182,6 +183,7 @@ class ARVCTrainer(Trainer):
         loss, logs = self._forward_losses(batch)
         self._accumulate(**logs)
         loss.backward()
+        Fn.side_join()
         self.backward_steps += 1
         self._optimizer_step()
         self.steps += 1
@@ -231,6 +233,7 @@ class AASVCTrainer(Trainer):
         if self.gradient_accumulate_steps > 1:
             loss = loss / self.gradient_accumulate_steps
         loss.backward()
+        Fn.side_join()
         self.backward_steps += 1
         if self.backward_steps % self.gradient_accumulate_steps > 0:
             return

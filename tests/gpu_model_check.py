@@ -238,6 +238,100 @@ def aasvc_tiny_train_bf16():
     return run_aas("aasvc_tiny_train", torch.bfloat16)
 
 
+def _train_steps(n_steps, side_streams, use_graph, dtype=torch.float32):
+    """n optimiser steps of tiny VTN with FlatAdam on the golden batch; returns (flat params, losses)."""
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.optim import FlatAdam
+    cfg, z = load("vtn_tiny_train")
+    Fn.set_compute_dtype(dtype)
+    Fn.enable_side_streams(side_streams)
+    K.manual_seed(7)
+    model = M.VTN(**model_cfg(cfg))
+    model.load_state_dict(sd_of(z))
+    model.to(DEV).train()
+    for m in model.modules():
+        if hasattr(m, "dropout_rate"):
+            m.dropout_rate = 0.0
+    opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10, bf16_shadow=(dtype == torch.bfloat16))
+    crit = L.Seq2SeqLoss(10.0)
+    t = lambda k: torch.from_numpy(z[k])
+    xs, ys, labels = t("in.xs").to(DEV), t("in.ys").to(DEV), t("in.labels").to(DEV)
+    ilens, olens = t("in.ilens"), t("in.olens")
+    lossbuf = torch.zeros(2, device=DEV)
+
+    def fwd_bwd():
+        K.reset_op_counter()
+        opt.zero_grad()
+        o = model(xs, ilens, ys, labels, olens)
+        l1, bce = crit(o[0], o[1], o[2], o[3], o[4], o[5])
+        (l1 + bce).backward()
+        Fn.side_join()
+        lossbuf[0].copy_(l1.detach())
+        lossbuf[1].copy_(bce.detach())
+
+    losses = []
+    if use_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fwd_bwd()          # warm-up (no optimiser step: keeps the trajectory identical)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fwd_bwd()
+            opt.step()
+        for _ in range(n_steps):
+            g.replay()
+            losses.append(lossbuf.tolist())
+    else:
+        for _ in range(n_steps):
+            fwd_bwd()
+            opt.step()
+            losses.append(lossbuf.tolist())
+    torch.cuda.synchronize()
+    Fn.enable_side_streams(0)
+    Fn.set_compute_dtype(torch.float32)
+    return opt.flat_p.detach().clone(), losses, opt.last_stats(), model
+
+
+@case
+def training_steps_equivalence_fp32():
+    """(i) eager == side-streams == hipGraph replay, bit for bit (all kernels are deterministic);
+    (ii) the fused clip+WarmupLR+Adam step follows the oracle's replay of the reference trainer lines."""
+    from oracle import models as OM
+    res = []
+    p0, l0, st0, model = _train_steps(3, 0, False)
+    p1, l1, _, _ = _train_steps(3, 4, False)
+    p2, l2, _, _ = _train_steps(3, 4, True)
+    res.append((bool(torch.equal(p0, p1)), f"params after 3 steps: eager vs 4 side streams identical={bool(torch.equal(p0, p1))}"))
+    res.append((bool(torch.equal(p0, p2)), f"params after 3 steps: eager vs hipGraph+side streams identical={bool(torch.equal(p0, p2))}"))
+    res.append((l0 == l1 == l2, f"loss trajectories identical: {l0[-1]}"))
+    res.append((l0[-1][0] < l0[0][0], f"l1 loss decreases over 3 steps: {l0[0][0]:.5f} -> {l0[-1][0]:.5f}"))
+    # oracle trajectory on the CPU
+    cfg, z = load("vtn_tiny_train")
+    sd = sd_of(z)
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    params = [sd[k] for k in names]
+    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+    t = lambda k: torch.from_numpy(z[k])
+    for it in range(1, 4):
+        o = OM.vtn_forward(sd, model_cfg(cfg), t("in.xs"), t("in.ilens"), t("in.ys"), t("in.labels"), t("in.olens"), training=True)
+        a, b = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+        grads = torch.autograd.grad(a + b, params, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)]
+        with torch.no_grad():
+            gn = OM.adam_step(params, grads, state, OM.warmup_lr(1e-3, it, 10), it)
+    got = dict(model.named_parameters())
+    worst = max((got[k].detach().cpu() - sd[k].detach()).abs().max().item() for k in names)
+    res.append((worst < 2e-5, f"params after 3 optimiser steps vs oracle trainer replay: max abs diff {worst:.2e}"))
+    res.append((abs(st0["grad_norm"] - float(gn)) < 1e-3 * float(gn), f"grad norm {st0['grad_norm']:.5f} vs oracle {float(gn):.5f}; lr {st0['lr']:.3e}"))
+    return res
+
+
 def main(selected=None):
     nfail = 0
     for fn in CASES:
