@@ -165,10 +165,21 @@ class MultiHeadedAttention(nn.Module):
 
     def forward(self, query, key, value, klens=None, causal=False):
         """klens: Lens of valid key positions (None = all valid); causal adds j<=i."""
-        q = Fn.linear(query, self.linear_q.weight, self.linear_q.bias)
-        k = Fn.linear(key, self.linear_k.weight, self.linear_k.bias)
-        v = Fn.linear(value, self.linear_v.weight, self.linear_v.bias)
-        ctx, self.attn = Fn.attention_core(q, k, v, None if klens is None else klens.dev, causal, self.h, self._p())
+        kl = None if klens is None else klens.dev
+        f = getattr(self, "_fused", None)   # packed Q/K/V views of the flat parameter buffer (optim.FlatAdam)
+        if f is not None and key is value:
+            if query is key:
+                qkv = Fn.linear(query, f["w_qkv"], f["b_qkv"])                      # ONE GEMM, N = 3D
+                ctx, self.attn = Fn.attention_packed_qkv(qkv, kl, causal, self.h, self._p())
+            else:
+                q = Fn.linear(query, f["w_q"], f["b_q"])
+                kv = Fn.linear(key, f["w_kv"], f["b_kv"])                           # ONE GEMM, N = 2D
+                ctx, self.attn = Fn.attention_packed_kv(q, kv, kl, causal, self.h, self._p())
+        else:
+            q = Fn.linear(query, self.linear_q.weight, self.linear_q.bias)
+            k = Fn.linear(key, self.linear_k.weight, self.linear_k.bias)
+            v = Fn.linear(value, self.linear_v.weight, self.linear_v.bias)
+            ctx, self.attn = Fn.attention_core(q, k, v, kl, causal, self.h, self._p())
         return Fn.linear(ctx, self.linear_out.weight, self.linear_out.bias)
 
 

@@ -354,43 +354,127 @@ def posenc(x, pe, alpha=None, xscale=1.0, p=0.0):
 # attention cores (QK^T -> masked softmax -> PV), plain and relative-position
 # reference: modules/transformer/attention.py:63-111, :262-305
 # ================================================================================================
+def _bop(t, dk, layout=K.KC, bs0=None):
+    """GEMM operand over a (B, T, H*dk) activation that may be a column slice of a packed (B, T, n*D) tensor:
+    row stride and batch stride come from the view, heads are the second batch level."""
+    assert t.stride(-1) == 1
+    return K.operand(t, t.stride(1), layout=layout, bs0=t.stride(0) if bs0 is None else bs0, bs1=dk)
+
+
 def _qk(q, k, B, H, T1, T2, dk, D, dtype, bs0_b=None):
     scores = torch.empty((B, H, T1, T2), dtype=torch.float32, device=q.device)
-    K.gemm(K.operand(q, D, bs0=T1 * D, bs1=dk), K.operand(k, D, bs0=(T2 * D if bs0_b is None else bs0_b), bs1=dk), T1, T2, dk,
-           scores, in_dtype=dtype, nb0=B, nb1=H, cbs=(H * T1 * T2, T1 * T2))
+    K.gemm(_bop(q, dk), _bop(k, dk, bs0=bs0_b), T1, T2, dk, scores, in_dtype=dtype, nb0=B, nb1=H, cbs=(H * T1 * T2, T1 * T2))
     return scores
+
+
+def _into(out, A, Bop, M, N, Kd, dk, dtype, B, H):
+    """Batched (b, h) GEMM writing head h of batch b into columns [h*dk, (h+1)*dk) of the (B, T, .) view `out`."""
+    K.gemm(A, Bop, M, N, Kd, out, in_dtype=dtype, nb0=B, nb1=H, ldc=out.stride(1), cbs=(out.stride(0), dk))
+    return out
 
 
 def _pv(pm, v, B, H, T1, T2, dk, D, dtype):
     ctxv = torch.empty((B, T1, D), dtype=dtype, device=v.device)
-    K.gemm(K.operand(pm, T2, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(v, D, layout=K.RC, bs0=T2 * D, bs1=dk), T1, dk, T2, ctxv,
-           in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T1 * D, dk))
-    return ctxv
+    return _into(ctxv, K.operand(pm, T2, bs0=H * T1 * T2, bs1=T1 * T2), _bop(v, dk, K.RC), T1, dk, T2, dk, dtype, B, H)
 
 
-def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, rel_mode=0):
+def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, rel_mode=0, outs=None):
+    """Backward of softmax(QK^T)V.  q/k/v may be column slices of packed tensors; `outs` = (dq, dk, dv) views to
+    write into (e.g. slices of a packed gradient), allocated when None."""
     B, T1, D = q.shape
     T2 = k.shape[1]
     dk = D // H
     dtype = q.dtype
-    dctx = _c(dctx) if dctx is not None else torch.zeros_like(q)
+    dctx = _c(dctx) if dctx is not None else torch.zeros((B, T1, D), dtype=dtype, device=q.device)
+    if outs is None:
+        outs = (torch.empty((B, T1, D), dtype=dtype, device=q.device), torch.empty((B, T2, D), dtype=dtype, device=q.device),
+                torch.empty((B, T2, D), dtype=dtype, device=q.device))
+    dq, dkk, dv = outs
+    pmA = K.operand(pm, T2, bs0=H * T1 * T2, bs1=T1 * T2)
     # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
     dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
     # dV[b,j,hd] = sum_i pm[b,h,i,j] dctx[b,i,hd]
-    dv = torch.empty((B, T2, D), dtype=dtype, device=q.device)
-    K.gemm(K.operand(pm, T2, layout=K.RC, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(dctx, D, layout=K.RC, bs0=T1 * D, bs1=dk),
-           T2, dk, T1, dv, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T2 * D, dk))
+    _into(dv, K.operand(pm, T2, layout=K.RC, bs0=H * T1 * T2, bs1=T1 * T2), _bop(dctx, dk, K.RC), T2, dk, T1, dk, dtype, B, H)
     ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode,
                                  dattn=_c(dattn) if dattn is not None else None)
     # dQ[b,i,hd] = sum_j dS[b,h,i,j] k[b,j,hd]
-    dq = torch.empty((B, T1, D), dtype=dtype, device=q.device)
-    K.gemm(K.operand(ds, T2, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(k, D, layout=K.RC, bs0=T2 * D, bs1=dk), T1, dk, T2, dq,
-           in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T1 * D, dk))
+    _into(dq, K.operand(ds, T2, bs0=H * T1 * T2, bs1=T1 * T2), _bop(k, dk, K.RC), T1, dk, T2, dk, dtype, B, H)
     # dK[b,j,hd] = sum_i dS[b,h,i,j] q[b,i,hd]
-    dkk = torch.empty((B, T2, D), dtype=dtype, device=q.device)
-    K.gemm(K.operand(ds, T2, layout=K.RC, bs0=H * T1 * T2, bs1=T1 * T2), K.operand(q, D, layout=K.RC, bs0=T1 * D, bs1=dk), T2,
-           dk, T1, dkk, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T2 * D, dk))
+    _into(dkk, K.operand(ds, T2, layout=K.RC, bs0=H * T1 * T2, bs1=T1 * T2), _bop(q, dk, K.RC), T2, dk, T1, dk, dtype, B, H)
+    del pmA
     return dq, dkk, dv, dbd
+
+
+def _attn_fwd_views(q, k, v, klen, causal, H, p):
+    B, T1, D = q.shape
+    T2 = k.shape[1]
+    dk = D // H
+    dtype = q.dtype
+    scale = 1.0 / math.sqrt(dk)
+    seed = K.new_seed(q.device) if p > 0.0 else (None, 0)
+    scores = _qk(q, k, B, H, T1, T2, dk, D, dtype)
+    attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed)
+    out = _pv(pdrop if pdrop is not None else attn, v, B, H, T1, T2, dk, D, dtype)
+    return out, attn, pdrop, scale, seed
+
+
+class _AttnPackedQKV(Function):
+    """Self-attention core on ONE packed projection qkv (B, T, 3D) (fused Q/K/V GEMM); returns the gradient packed."""
+
+    @staticmethod
+    def forward(ctx, qkv, klen, causal, H, p):
+        qkv = _c(qkv)
+        D = qkv.shape[-1] // 3
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
+        ctx.meta = (H, scale, p, seed, D)
+        ctx.save_for_backward(qkv, attn, pdrop)
+        ctx.set_materialize_grads(False)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dctx, dattn):
+        qkv, attn, pdrop = ctx.saved_tensors
+        H, scale, p, seed, D = ctx.meta
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        dqkv = torch.empty_like(qkv)
+        _attn_common_bwd(dctx, dattn, attn, pdrop if pdrop is not None else attn, q, k, v, H, scale, p, seed,
+                         outs=(dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]))
+        return dqkv, None, None, None, None
+
+
+class _AttnPackedKV(Function):
+    """Source-attention core: q (B, T1, D) and ONE packed projection kv (B, T2, 2D) of the memory."""
+
+    @staticmethod
+    def forward(ctx, q, kv, klen, causal, H, p):
+        q, kv = _c(q), _c(kv)
+        D = q.shape[-1]
+        k, v = kv[..., :D], kv[..., D:]
+        out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
+        ctx.meta = (H, scale, p, seed, D)
+        ctx.save_for_backward(q, kv, attn, pdrop)
+        ctx.set_materialize_grads(False)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dctx, dattn):
+        q, kv, attn, pdrop = ctx.saved_tensors
+        H, scale, p, seed, D = ctx.meta
+        k, v = kv[..., :D], kv[..., D:]
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        _attn_common_bwd(dctx, dattn, attn, pdrop if pdrop is not None else attn, q, k, v, H, scale, p, seed,
+                         outs=(dq, dkv[..., :D], dkv[..., D:]))
+        return dq, dkv, None, None, None, None
+
+
+def attention_packed_qkv(qkv, klen, causal, H, p=0.0):
+    return _AttnPackedQKV.apply(qkv, klen, causal, H, p)
+
+
+def attention_packed_kv(q, kv, klen, causal, H, p=0.0):
+    return _AttnPackedKV.apply(q, kv, klen, causal, H, p)
 
 
 class _AttnCore(Function):

@@ -18,10 +18,25 @@ from .ops import kernels as K
 
 class FlatAdam:
     def __init__(self, model, lr=8e-5, betas=(0.9, 0.999), eps=1e-8, grad_norm=1.0, warmup_steps=4000, bf16_shadow=False,
-                 align=64):
+                 align=64, fuse_qkv=True):
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        # lay the Q/K/V weights (and biases) of every attention module out back to back, so that
+        # [Wq;Wk;Wv] is ONE (3D, D) matrix in the flat buffer (fused projection GEMMs, see modules.py)
+        groups = self._attention_groups(model) if fuse_qkv else []
+        grouped = {id(p) for g in groups for p in g["w"] + g["b"]}
+        first = {id(g["w"][0]): g for g in groups}
+        ordered, tight = [], set()     # `tight` members start right where the previous one ends (no alignment gap)
+        for p in self.params:
+            if id(p) in first:
+                g = first[id(p)]
+                ordered += g["w"] + g["b"]
+                if all(q.numel() % 8 == 0 for q in g["w"] + g["b"]):
+                    tight.update(id(q) for q in g["w"][1:] + g["b"][1:])
+            elif id(p) not in grouped:
+                ordered.append(p)
+        self.params = ordered
         dev = self.params[0].device
         if dev.type != "cuda":
             raise RuntimeError("FlatAdam needs the model on the GPU (there is no CPU path)")
@@ -29,8 +44,11 @@ class FlatAdam:
         self.grad_norm, self.warmup_steps = float(grad_norm), float(warmup_steps or 0)
         offs, n = [], 0
         for p in self.params:
+            if id(p) not in tight:
+                n = (n + align - 1) // align * align
             offs.append(n)
-            n += (p.numel() + align - 1) // align * align
+            n += p.numel()
+        n = (n + align - 1) // align * align
         self.offsets, self.numel = offs, n
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -49,6 +67,42 @@ class FlatAdam:
                 p._s2s_bf16 = self.shadow[o:o + k].view(p.shape)
         if self.shadow is not None:
             self.refresh_shadow()
+        off_of = {id(p): o for p, o in zip(self.params, offs)}
+        for g in groups:
+            ws, bs = g["w"], g["b"]
+            D = ws[0].shape[0]
+            ow, ob = off_of[id(ws[0])], off_of[id(bs[0])]
+            contiguous = all(off_of[id(ws[i])] == ow + i * D * D for i in range(3)) and \
+                all(off_of[id(bs[i])] == ob + i * D for i in range(3))
+            if contiguous:
+                g["module"]._fused = {
+                    "w_qkv": self._view(ow, (3 * D, D)), "b_qkv": self._view(ob, (3 * D,)),
+                    "w_q": self._view(ow, (D, D)), "b_q": self._view(ob, (D,)),
+                    "w_kv": self._view(ow + D * D, (2 * D, D)), "b_kv": self._view(ob + D, (2 * D,))}
+
+    @staticmethod
+    def _attention_groups(model):
+        from .modules import MultiHeadedAttention
+        groups = []
+        for m in model.modules():
+            if isinstance(m, MultiHeadedAttention):
+                ws = [m.linear_q.weight, m.linear_k.weight, m.linear_v.weight]
+                bs = [m.linear_q.bias, m.linear_k.bias, m.linear_v.bias]
+                if all(p is not None and p.requires_grad for p in ws + bs):
+                    groups.append({"module": m, "w": ws, "b": bs})
+        return groups
+
+    def _view(self, off, shape):
+        """A trainable-looking view of the flat buffers (fp32 master, flat-gradient slot, bf16 shadow)."""
+        n = 1
+        for d in shape:
+            n *= d
+        t = self.flat_p[off:off + n].view(shape)
+        t.requires_grad_(True)
+        t._s2s_grad = self.flat_g[off:off + n].view(shape)
+        if self.shadow is not None:
+            t._s2s_bf16 = self.shadow[off:off + n].view(shape)
+        return t
 
     def refresh_shadow(self):
         """bf16 copy of the fp32 master weights (after loading a checkpoint / at start)."""
