@@ -56,6 +56,10 @@ typedef struct {
   int32_t pad;             /* conv1d: left padding (kernel-1)/2                               */
   int32_t T1, F1, T2, F2;  /* conv2d: input and output spatial dims                           */
   int64_t bs0, bs1;        /* two-level batch strides (elements)                              */
+  int32_t zero_padded;     /* dense: the vectorised extent (k for KC, row for RC) is not a multiple of 16 bytes
+                              but every row is padded with ZEROS up to one (ld covers it); lets the fast
+                              kernels read whole vectors without masking                                */
+  int32_t reserved_;
 } s2svc_operand;
 
 typedef struct {
@@ -79,6 +83,7 @@ typedef struct {
   float* a_rowsum;
   float* a_rowsum_ws;
   int32_t a_rowsum_accumulate;
+  int32_t tile_hint;       /* 0 = auto, 64 or 128: output tile edge chosen by the caller's cost model */
 } s2svc_gemm_desc;
 
 int s2svc_gemm(const s2svc_gemm_desc* desc /* host */, void* stream);
@@ -116,10 +121,11 @@ int s2svc_bn_bwd(int dtype, int64_t rows, int C, const void* dy, const void* x, 
 /* replaces: modules/transformer/attention.py:63-93 (forward_attention), :237-260 / :142-160  */
 /* (rel_shift new / legacy), :278-303 ((ac+bd)/sqrt(d_k)).  rel_mode 0 none, 1 new, 2 legacy. */
 /* ========================================================================================== */
-int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, const float* scores, const float* bd, int Lp,
+/* score / probability rows are `ld` >= T2 elements apart (rows padded to a vector multiple); pad columns are written as 0 */
+int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, int ld, const float* scores, const float* bd, int Lp,
                            int rel_mode, float scale, const int32_t* klen, int causal, float drop_p,
                            const uint64_t* seed_base, uint64_t seed_off, void* attn, void* pdrop, void* stream);
-int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, const void* attn, const float* dp, const void* dattn,
+int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, int ld, const void* attn, const float* dp, const void* dattn,
                            float scale, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dscores,
                            void* dbd, int Lp, int rel_mode, void* stream);
 

@@ -59,7 +59,7 @@ c_i32, c_i64, c_f32, c_u64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_floa
 class Operand(ctypes.Structure):
     _fields_ = [("ptr", c_vp), ("ld", c_i64), ("layout", c_i32), ("mode", c_i32), ("C", c_i32), ("T", c_i32),
                 ("pad", c_i32), ("T1", c_i32), ("F1", c_i32), ("T2", c_i32), ("F2", c_i32), ("bs0", c_i64),
-                ("bs1", c_i64)]
+                ("bs1", c_i64), ("zero_padded", c_i32), ("reserved_", c_i32)]
 
 
 class GemmDesc(ctypes.Structure):
@@ -67,7 +67,7 @@ class GemmDesc(ctypes.Structure):
                 ("c_dtype", c_i32), ("bias", c_vp), ("res", c_vp), ("ldr", c_i64), ("rbs0", c_i64), ("rbs1", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("nb0", c_i32), ("nb1", c_i32), ("act", c_i32),
                 ("alpha", c_f32), ("dtype", c_i32), ("accumulate", c_i32), ("splitk", c_i32), ("ws", c_vp),
-                ("a_rowsum", c_vp), ("a_rowsum_ws", c_vp), ("a_rowsum_accumulate", c_i32)]
+                ("a_rowsum", c_vp), ("a_rowsum_ws", c_vp), ("a_rowsum_accumulate", c_i32), ("tile_hint", c_i32)]
 
 
 _SIGS = {
@@ -79,9 +79,9 @@ _SIGS = {
     "s2svc_rstd_from_var": [c_i32, c_f32, c_vp, c_vp, c_vp],
     "s2svc_bn_apply": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_bn_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
-    "s2svc_attn_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_f32,
+    "s2svc_attn_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_f32,
                                c_vp, c_u64, c_vp, c_vp, c_vp],
-    "s2svc_attn_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32,
+    "s2svc_attn_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32,
                                c_i32, c_vp],
     "s2svc_act_dropout_fwd": [c_i32, c_i64, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp],
     "s2svc_act_dropout_bwd": [c_i32, c_i64, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp],

@@ -7,6 +7,19 @@
 
 namespace {
 
+__device__ __forceinline__ void store8(float* p, const float (&r)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(r[4], r[5], r[6], r[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&r)[8]) {
+  uint4 v;
+  v.x = (uint32_t)f2bf(r[0]) | ((uint32_t)f2bf(r[1]) << 16);
+  v.y = (uint32_t)f2bf(r[2]) | ((uint32_t)f2bf(r[3]) << 16);
+  v.z = (uint32_t)f2bf(r[4]) | ((uint32_t)f2bf(r[5]) << 16);
+  v.w = (uint32_t)f2bf(r[6]) | ((uint32_t)f2bf(r[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = v;
+}
+
 // each thread: one output pixel x 8 consecutive channels (one 16-byte store for bf16, two for fp32)
 template <typename T>
 __global__ __launch_bounds__(256) void conv_in1_fwd_kernel(int B, int Tn, int Fn, int T1, int F1, int O, const T* __restrict__ x,
@@ -30,14 +43,16 @@ __global__ __launch_bounds__(256) void conv_in1_fwd_kernel(int B, int Tn, int Fn
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = ldf(x + ((int64_t)b * Tn + 2 * t1 + kh) * Fn + 2 * f1 + kw);
     T* yo = y + (i / og) * O + g * 8;
+    float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int o = g * 8 + e;
       float acc = sw[O * 9 + o];
 #pragma unroll
       for (int k = 0; k < 9; ++k) acc += sw[o * 9 + k] * xv[k];
-      stf(yo + e, acc > 0.f ? acc : 0.f);
+      r[e] = acc > 0.f ? acc : 0.f;
     }
+    store8(yo, r);   // 16-byte (bf16) / 2 x 16-byte (fp32) coalesced stores
   }
 }
 
@@ -71,15 +86,20 @@ __global__ __launch_bounds__(256) void conv_in1_wgrad_kernel(int B, int Tn, int 
   }
 }
 
-__global__ void conv_in1_wgrad_final_kernel(int O, int chunks, const float* __restrict__ partial, float* __restrict__ dw,
-                                            float* __restrict__ db, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per output element: lanes stride over the chunk partials (independent loads), fixed-order wave sum
+__global__ __launch_bounds__(256) void conv_in1_wgrad_final_kernel(int O, int chunks, const float* __restrict__ partial,
+                                                                   float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= O * 10) return;
   float t = 0.f;
-  for (int c = 0; c < chunks; ++c) t += partial[(int64_t)c * O * 10 + i];
-  const int o = i / 10, k = i % 10;
-  if (k < 9) dw[o * 9 + k] = (accumulate ? dw[o * 9 + k] : 0.f) + t;
-  else if (db) db[o] = (accumulate ? db[o] : 0.f) + t;
+  for (int c = lane; c < chunks; c += 64) t += partial[(int64_t)c * O * 10 + i];
+  t = wave_sum(t);
+  if (lane == 0) {
+    const int o = i / 10, k = i % 10;
+    if (k < 9) dw[o * 9 + k] = (accumulate ? dw[o * 9 + k] : 0.f) + t;
+    else if (db) db[o] = (accumulate ? db[o] : 0.f) + t;
+  }
 }
 
 }  // namespace
@@ -119,7 +139,7 @@ extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, con
   else
     hipLaunchKernelGGL(conv_in1_wgrad_kernel<bf16_t>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const bf16_t*)x, (const bf16_t*)dy, partial, ppc);
   S2S_CHECK_LAUNCH("conv_in1_wgrad_kernel");
-  hipLaunchKernelGGL(conv_in1_wgrad_final_kernel, dim3((O * 10 + 255) / 256), dim3(256), 0, st, O, chunks, partial, dw, db, accumulate);
+  hipLaunchKernelGGL(conv_in1_wgrad_final_kernel, dim3((O * 10 + 3) / 4), dim3(256), 0, st, O, chunks, partial, dw, db, accumulate);
   S2S_CHECK_LAUNCH("conv_in1_wgrad_final_kernel");
   return 0;
 }

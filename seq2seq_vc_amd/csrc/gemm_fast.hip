@@ -358,16 +358,22 @@ extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream) {
   const int vec = d.dtype == S2S_F32 ? 4 : 8;
   const size_t esz = d.dtype == S2S_F32 ? 4 : 2;
   if (!operand_ok(d.A, vec, esz) || !operand_ok(d.B, vec, esz)) return 0;
-  // RC dense operands are read as 16-byte vectors along the row index: the row extent must be a vector multiple
-  if (d.A.layout == S2SVC_LAYOUT_RC && (d.M % vec)) return 0;
-  if (d.B.layout == S2SVC_LAYOUT_RC && (d.N % vec)) return 0;
-  // KC operands are read as 16-byte vectors along k
-  if (d.A.layout == S2SVC_LAYOUT_KC && (d.K % vec)) return 0;
-  if (d.B.layout == S2SVC_LAYOUT_KC && (d.K % vec)) return 0;
+  // 16-byte vectors run along the row index (RC) or along k (KC): the extent must be a vector multiple, or -- for
+  // dense operands -- the caller declares the rows zero-padded up to one (whole vectors are read unmasked: the
+  // zero tail contributes nothing to the reduction and the extra rows are never stored)
+  auto extent_ok = [&](const s2svc_operand& o, int extent) {
+    if (extent % vec == 0) return true;
+    return o.mode == S2SVC_OP_DENSE && o.zero_padded && o.ld >= (int64_t)((extent + vec - 1) / vec * vec);
+  };
+  if (!extent_ok(d.A, d.A.layout == S2SVC_LAYOUT_RC ? d.M : d.K)) return 0;
+  if (!extent_ok(d.B, d.B.layout == S2SVC_LAYOUT_RC ? d.N : d.K)) return 0;
+  if (d.tile_hint != 0 && d.tile_hint != 64 && d.tile_hint != 128) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int splitk = d.splitk > 1 ? d.splitk : 1;
   const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1 * splitk;
-  const bool big = tiles128 >= 256 && d.M >= 128 && d.N >= 128;
+  bool big = tiles128 >= 256 && d.M >= 128 && d.N >= 128;
+  if (d.tile_hint == 128) big = true;
+  if (d.tile_hint == 64) big = false;
   if (big) {
     dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.nb0 * d.nb1 * splitk);
     if (d.dtype == S2S_F32) launch_modes<float, 128, 128, 32>(d, grid, st);

@@ -23,7 +23,7 @@ __device__ __forceinline__ bool rel_src(int mode, int T1, int i, int j, int& si,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, int T2, const float* __restrict__ scores,
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, int T2, int ld, const float* __restrict__ scores,
                                                           const float* __restrict__ bd, int Lp, int rel_mode, float scale,
                                                           const int32_t* __restrict__ klen, int causal, float p,
                                                           const uint64_t* seed_base, uint64_t seed_off, T* __restrict__ attn, T* __restrict__ pdrop) {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
   const int64_t bh = row / T1;
   const int b = (int)(bh / H);
   const int kl = klen ? klen[b] : T2;
-  const float* srow = scores + row * T2;
+  const float* srow = scores + row * ld;   // rows are padded to `ld` >= T2 columns (pad columns are written as 0)
   const float* bdb = bd ? bd + bh * (int64_t)T1 * Lp : nullptr;
   const float NEG = -3.4028234663852886e38f;  // torch.finfo(float32).min
 
@@ -75,18 +75,22 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
     }
     v = ok ? v * scale : NEG;
     float pr = ok ? expf(v - mx) * inv : 0.f;  // masked_fill(mask, 0.0) after softmax
-    const int64_t o = row * T2 + j;
+    const int64_t o = row * ld + j;
     stf(attn + o, pr);
     if (pdrop) {
       float m = p > 0.f ? dropout_scale(seed, (uint64_t)o, p, inv_keep) : 1.f;
       stf(pdrop + o, pr * m);
     }
   }
+  for (int j = T2 + lane; j < ld; j += 64) {
+    stf(attn + row * ld + j, 0.f);
+    if (pdrop) stf(pdrop + row * ld + j, 0.f);
+  }
 }
 
 // dS = P * (dP*mask - sum_j P*dP*mask) ; dscores = dS*scale ; scatter of the same value into dbd
 template <typename T>
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, int T2, const T* __restrict__ attn,
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, int T2, int ld, const T* __restrict__ attn,
                                                           const float* __restrict__ dp, const T* __restrict__ dattn, float scale, float p, const uint64_t* seed_base, uint64_t seed_off,
                                                           T* __restrict__ dscores, T* __restrict__ dbd, int Lp,
                                                           int rel_mode) {
@@ -100,14 +104,15 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, 
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   float dot = 0.f;
   for (int j = lane; j < T2; j += 64) {
-    const int64_t o = row * T2 + j;
+    const int64_t o = row * ld + j;
     float m = p > 0.f ? dropout_scale(seed, (uint64_t)o, p, inv_keep) : 1.f;
     dot += ldf(attn + o) * (dp[o] * m + (dattn ? ldf(dattn + o) : 0.f));
   }
   dot = wave_sum(dot);
   T* dbdb = dbd ? dbd + bh * (int64_t)T1 * Lp : nullptr;
+  for (int j = T2 + lane; j < ld; j += 64) stf(dscores + row * ld + j, 0.f);
   for (int j = lane; j < T2; j += 64) {
-    const int64_t o = row * T2 + j;
+    const int64_t o = row * ld + j;
     float m = p > 0.f ? dropout_scale(seed, (uint64_t)o, p, inv_keep) : 1.f;
     float pr = ldf(attn + o);
     float ds = pr * (dp[o] * m + (dattn ? ldf(dattn + o) : 0.f) - dot) * scale;
@@ -121,10 +126,10 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, 
 
 }  // namespace
 
-extern "C" int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, const float* scores, const float* bd,
+extern "C" int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, int ld, const float* scores, const float* bd,
                                       int Lp, int rel_mode, float scale, const int32_t* klen, int causal, float drop_p,
                                       const uint64_t* seed_base, uint64_t seed_off, void* attn, void* pdrop, void* stream) {
-  S2S_REQUIRE(B >= 0 && H > 0 && T1 >= 0 && T2 > 0, "attn_softmax_fwd: bad shape");
+  S2S_REQUIRE(B >= 0 && H > 0 && T1 >= 0 && T2 > 0 && ld >= T2, "attn_softmax_fwd: bad shape");
   S2S_REQUIRE(!bd || (rel_mode == 1 && Lp == 2 * T1 - 1 && T1 == T2) || (rel_mode == 2 && Lp == T1 && T1 == T2),
               "attn_softmax_fwd: bad relative-position shape");
   const int64_t nrows = (int64_t)B * H * T1;
@@ -132,16 +137,16 @@ extern "C" int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, c
   dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, scores, bd, Lp, rel_mode, scale, klen,
+    hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, ld, scores, bd, Lp, rel_mode, scale, klen,
                        causal, drop_p, seed_base, seed_off, (float*)attn, (float*)pdrop);
   else
-    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, scores, bd, Lp, rel_mode, scale, klen,
+    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, ld, scores, bd, Lp, rel_mode, scale, klen,
                        causal, drop_p, seed_base, seed_off, (bf16_t*)attn, (bf16_t*)pdrop);
   S2S_CHECK_LAUNCH("softmax_fwd_kernel");
   return 0;
 }
 
-extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, const void* attn, const float* dp, const void* dattn,
+extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, int ld, const void* attn, const float* dp, const void* dattn,
                                       float scale, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dscores, void* dbd, int Lp,
                                       int rel_mode, void* stream) {
   S2S_REQUIRE(B >= 0 && H > 0 && T1 >= 0 && T2 > 0, "attn_softmax_bwd: bad shape");
@@ -157,10 +162,10 @@ extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, c
   }
   dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, (const float*)attn, dp, (const float*)dattn, scale, drop_p,
+    hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, ld, (const float*)attn, dp, (const float*)dattn, scale, drop_p,
                        seed_base, seed_off, (float*)dscores, (float*)dbd, Lp, rel_mode);
   else
-    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, (const bf16_t*)attn, dp, (const bf16_t*)dattn, scale,
+    hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, ld, (const bf16_t*)attn, dp, (const bf16_t*)dattn, scale,
                        drop_p, seed_base, seed_off, (bf16_t*)dscores, (bf16_t*)dbd, Lp, rel_mode);
   S2S_CHECK_LAUNCH("softmax_bwd_kernel");
   return 0;

@@ -177,12 +177,12 @@ class _Linear(Function):
             dx = dx.view(ctx.xshape)
         dw = db = None
         if weight.requires_grad:
-            sk = K.pick_splitk(N, Kd, M)
+            tile, sk = K.plan_gemm(N, Kd, M)
             rs, racc, db = _bias_sink(bias, N)     # bias gradient = row sums of dY^T, fused into the wgrad GEMM
 
             def wr(out, acc):
                 K.gemm(K.operand(dy2, N, layout=K.RC), K.operand(x2, Kd, layout=K.RC), N, Kd, M, out, in_dtype=dtype,
-                       splitk=sk, accumulate=acc, a_rowsum=rs, a_rowsum_accumulate=racc)
+                       splitk=sk, tile=tile, accumulate=acc, a_rowsum=rs, a_rowsum_accumulate=racc)
             if _slotted(weight, bias if ctx.has_bias else None):
                 _side_run(lambda: _emit_wgrad(weight, (N, Kd), wr), keep=(dy2, x2))
             else:
@@ -361,9 +361,15 @@ def _bop(t, dk, layout=K.KC, bs0=None):
     return K.operand(t, t.stride(1), layout=layout, bs0=t.stride(0) if bs0 is None else bs0, bs1=dk)
 
 
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
 def _qk(q, k, B, H, T1, T2, dk, D, dtype, bs0_b=None):
-    scores = torch.empty((B, H, T1, T2), dtype=torch.float32, device=q.device)
-    K.gemm(_bop(q, dk), _bop(k, dk, bs0=bs0_b), T1, T2, dk, scores, in_dtype=dtype, nb0=B, nb1=H, cbs=(H * T1 * T2, T1 * T2))
+    """fp32 scores (B, H, T1, ld) with ld = T2 rounded up to 8 (16-byte rows for the bf16 consumers)."""
+    ld = _pad8(T2)
+    scores = torch.empty((B, H, T1, ld), dtype=torch.float32, device=q.device)
+    K.gemm(_bop(q, dk), _bop(k, dk, bs0=bs0_b), T1, T2, dk, scores, in_dtype=dtype, nb0=B, nb1=H, ldc=ld, cbs=(H * T1 * ld, T1 * ld))
     return scores
 
 
@@ -373,14 +379,31 @@ def _into(out, A, Bop, M, N, Kd, dk, dtype, B, H):
     return out
 
 
+def _pop(pm, T1, H, layout=K.KC):
+    """Operand over a padded probability-like tensor (B, H, T1, ld)."""
+    ld = pm.shape[-1]
+    return K.operand(pm, ld, layout=layout, bs0=H * T1 * ld, bs1=T1 * ld, zero_padded=True)
+
+
 def _pv(pm, v, B, H, T1, T2, dk, D, dtype):
     ctxv = torch.empty((B, T1, D), dtype=dtype, device=v.device)
-    return _into(ctxv, K.operand(pm, T2, bs0=H * T1 * T2, bs1=T1 * T2), _bop(v, dk, K.RC), T1, dk, T2, dk, dtype, B, H)
+    return _into(ctxv, _pop(pm, T1, H), _bop(v, dk, K.RC), T1, dk, T2, dk, dtype, B, H)
+
+
+def _pad_like(dattn, ref):
+    """External gradient wrt the (B,H,T1,T2) attention view -> the padded (B,H,T1,ld) layout of `ref`."""
+    if dattn is None:
+        return None
+    if dattn.shape[-1] == ref.shape[-1]:
+        return _c(dattn)
+    out = torch.zeros_like(ref)
+    out[..., : dattn.shape[-1]].copy_(dattn)
+    return out
 
 
 def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, rel_mode=0, outs=None):
-    """Backward of softmax(QK^T)V.  q/k/v may be column slices of packed tensors; `outs` = (dq, dk, dv) views to
-    write into (e.g. slices of a packed gradient), allocated when None."""
+    """Backward of softmax(QK^T)V.  attn/pm: padded (B,H,T1,ld) tensors; q/k/v may be column slices of packed
+    tensors; `outs` = (dq, dk, dv) views to write into (e.g. slices of a packed gradient), allocated when None."""
     B, T1, D = q.shape
     T2 = k.shape[1]
     dk = D // H
@@ -390,18 +413,15 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
         outs = (torch.empty((B, T1, D), dtype=dtype, device=q.device), torch.empty((B, T2, D), dtype=dtype, device=q.device),
                 torch.empty((B, T2, D), dtype=dtype, device=q.device))
     dq, dkk, dv = outs
-    pmA = K.operand(pm, T2, bs0=H * T1 * T2, bs1=T1 * T2)
     # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
     dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
     # dV[b,j,hd] = sum_i pm[b,h,i,j] dctx[b,i,hd]
-    _into(dv, K.operand(pm, T2, layout=K.RC, bs0=H * T1 * T2, bs1=T1 * T2), _bop(dctx, dk, K.RC), T2, dk, T1, dk, dtype, B, H)
-    ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode,
-                                 dattn=_c(dattn) if dattn is not None else None)
+    _into(dv, _pop(pm, T1, H, K.RC), _bop(dctx, dk, K.RC), T2, dk, T1, dk, dtype, B, H)
+    ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode, dattn=_pad_like(dattn, attn), T2=T2)
     # dQ[b,i,hd] = sum_j dS[b,h,i,j] k[b,j,hd]
-    _into(dq, K.operand(ds, T2, bs0=H * T1 * T2, bs1=T1 * T2), _bop(k, dk, K.RC), T1, dk, T2, dk, dtype, B, H)
+    _into(dq, _pop(ds, T1, H), _bop(k, dk, K.RC), T1, dk, T2, dk, dtype, B, H)
     # dK[b,j,hd] = sum_i dS[b,h,i,j] q[b,i,hd]
-    _into(dkk, K.operand(ds, T2, layout=K.RC, bs0=H * T1 * T2, bs1=T1 * T2), _bop(q, dk, K.RC), T2, dk, T1, dk, dtype, B, H)
-    del pmA
+    _into(dkk, _pop(ds, T1, H, K.RC), _bop(q, dk, K.RC), T2, dk, T1, dk, dtype, B, H)
     return dq, dkk, dv, dbd
 
 
@@ -413,9 +433,14 @@ def _attn_fwd_views(q, k, v, klen, causal, H, p):
     scale = 1.0 / math.sqrt(dk)
     seed = K.new_seed(q.device) if p > 0.0 else (None, 0)
     scores = _qk(q, k, B, H, T1, T2, dk, D, dtype)
-    attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed)
+    attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed, T2=T2)
     out = _pv(pdrop if pdrop is not None else attn, v, B, H, T1, T2, dk, D, dtype)
     return out, attn, pdrop, scale, seed
+
+
+def _user_attn(attn, T2):
+    """The (B,H,T1,T2) view handed to callers (`self.attn`); the padded tensor stays the saved one."""
+    return attn if attn.shape[-1] == T2 else attn[..., :T2]
 
 
 class _AttnPackedQKV(Function):
@@ -430,7 +455,7 @@ class _AttnPackedQKV(Function):
         ctx.meta = (H, scale, p, seed, D)
         ctx.save_for_backward(qkv, attn, pdrop)
         ctx.set_materialize_grads(False)
-        return out, attn
+        return out, _user_attn(attn, k.shape[1])
 
     @staticmethod
     def backward(ctx, dctx, dattn):
@@ -455,7 +480,7 @@ class _AttnPackedKV(Function):
         ctx.meta = (H, scale, p, seed, D)
         ctx.save_for_backward(q, kv, attn, pdrop)
         ctx.set_materialize_grads(False)
-        return out, attn
+        return out, _user_attn(attn, k.shape[1])
 
     @staticmethod
     def backward(ctx, dctx, dattn):
@@ -481,20 +506,11 @@ class _AttnCore(Function):
     @staticmethod
     def forward(ctx, q, k, v, klen, causal, H, p):
         q, k, v = _c(q), _c(k), _c(v)
-        B, T1, D = q.shape
-        T2 = k.shape[1]
-        dk = D // H
-        dtype = q.dtype
-        scale = 1.0 / math.sqrt(dk)
-        seed = K.new_seed(q.device) if p > 0.0 else (None, 0)
-        scores = _qk(q, k, B, H, T1, T2, dk, D, dtype)
-        attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed)
-        pm = pdrop if pdrop is not None else attn
-        out = _pv(pm, v, B, H, T1, T2, dk, D, dtype)
+        out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
         ctx.meta = (H, scale, p, seed)
         ctx.save_for_backward(q, k, v, attn, pdrop)
         ctx.set_materialize_grads(False)
-        return out, attn
+        return out, _user_attn(attn, k.shape[1])
 
     @staticmethod
     def backward(ctx, dctx, dattn):
@@ -526,13 +542,13 @@ class _RelAttnCore(Function):
         bd = torch.empty((B, H, T, L), dtype=torch.float32, device=qu.device)
         K.gemm(K.operand(qv, D, bs0=T * D, bs1=dk), K.operand(pos, D, bs0=0, bs1=dk), T, L, dk, bd, in_dtype=dtype, nb0=B, nb1=H,
                cbs=(H * T * L, T * L))
-        attn, pdrop = K.attn_softmax_fwd(ac, dtype, scale, klen=klen, causal=False, bd=bd, rel_mode=rel_mode, p=p, seed=seed)
+        attn, pdrop = K.attn_softmax_fwd(ac, dtype, scale, klen=klen, causal=False, bd=bd, rel_mode=rel_mode, p=p, seed=seed, T2=T)
         pm = pdrop if pdrop is not None else attn
         out = _pv(pm, v, B, H, T, T, dk, D, dtype)
         ctx.meta = (H, scale, p, seed, rel_mode, L)
         ctx.save_for_backward(qu, qv, k, v, pos, attn, pdrop)
         ctx.set_materialize_grads(False)
-        return out, attn
+        return out, _user_attn(attn, T)
 
     @staticmethod
     def backward(ctx, dctx, dattn):
@@ -629,9 +645,9 @@ class _Conv1d(Function):
             def work():
                 dwp = torch.empty((Cout, ks * Cin), dtype=torch.float32, device=x.device)
                 rs, racc, dbv = _bias_sink(bias, Cout)
+                tile, sk = K.plan_gemm(Cout, ks * Cin, B * T)
                 K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad),
-                       Cout, ks * Cin, B * T, dwp, in_dtype=dtype, splitk=K.pick_splitk(Cout, ks * Cin, B * T), a_rowsum=rs,
-                       a_rowsum_accumulate=racc)
+                       Cout, ks * Cin, B * T, dwp, in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc)
                 dwt = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
                 return _emit_vgrad(weight, dwt), dbv
             if _slotted(weight, bias):
@@ -687,9 +703,10 @@ class _Conv2dS2(Function):
             def work():
                 dwp = torch.empty((O, 9 * C), dtype=torch.float32, device=x.device)
                 rs, racc, dbv = _bias_sink(bias, O)
+                tile, sk = K.plan_gemm(O, 9 * C, M2)
                 K.gemm(K.operand(dy, O, layout=K.RC),
                        K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M2, dwp,
-                       in_dtype=dtype, splitk=K.pick_splitk(O, 9 * C, M2), a_rowsum=rs, a_rowsum_accumulate=racc)
+                       in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc)
                 dwt = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32)
                 return _emit_vgrad(weight, dwt), dbv
             if _slotted(weight, bias):
@@ -773,8 +790,9 @@ class _LinearPermuted(Function):
             def work():
                 dwp = torch.empty((D, Kd), dtype=torch.float32, device=x.device)
                 rs, racc, dbv = _bias_sink(bias, D)
+                tile, sk = K.plan_gemm(D, Kd, M)
                 K.gemm(K.operand(dy, D, layout=K.RC), K.operand(x, Kd, layout=K.RC), D, Kd, M, dwp, in_dtype=dtype,
-                       splitk=K.pick_splitk(D, Kd, M), a_rowsum=rs, a_rowsum_accumulate=racc)
+                       splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc)
                 dwt = K.gather3(dwp, (D, C, Fd), (Kd, 1, C), 0, torch.float32)
                 return _emit_vgrad(weight, dwt), dbv
             if _slotted(weight, bias):

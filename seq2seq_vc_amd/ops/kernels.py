@@ -85,26 +85,45 @@ def new_seed(device):
 # ----------------------------------------------------------------------------------------------
 # GEMM
 # ----------------------------------------------------------------------------------------------
-def operand(t, ld, layout=KC, mode=DENSE, C=0, T=0, pad=0, T1=0, F1=0, T2=0, F2=0, bs0=0, bs1=0, offset=0):
+def operand(t, ld, layout=KC, mode=DENSE, C=0, T=0, pad=0, T1=0, F1=0, T2=0, F2=0, bs0=0, bs1=0, offset=0, zero_padded=False):
     o = _lib.Operand()
     o.ptr = t.data_ptr() + offset * t.element_size()
     o.ld, o.layout, o.mode, o.C, o.T, o.pad = ld, layout, mode, C, T, pad
     o.T1, o.F1, o.T2, o.F2, o.bs0, o.bs1 = T1, F1, T2, F2, bs0, bs1
+    o.zero_padded = 1 if zero_padded else 0
     return o
 
 
+def plan_gemm(M, N, K, nbatch=1, allow_split=True):
+    """Tiny cost model -> (tile, splitk) for the MFMA GEMM: estimated time = waves of resident workgroups x
+    (k-tiles per workgroup x time per k-tile + fixed), plus the split-K reduction.  Numbers are microseconds
+    fitted to MI355X measurements of this kernel (profiles/)."""
+    best = None
+    for tile, bk, t_tile, resident in ((64, 128, 1.6, 3 * 256), (128, 64, 2.2, 2 * 256)):
+        if tile == 128 and (M < 128 or N < 128):
+            continue
+        tiles = ((M + tile - 1) // tile) * ((N + tile - 1) // tile) * nbatch
+        ktiles = (K + bk - 1) // bk
+        for s in ((1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64) if allow_split else (1,)):
+            if s > 1 and ktiles // s < 2:
+                break
+            per = (ktiles + s - 1) // s
+            waves = (tiles * s + resident - 1) // resident
+            cost = waves * (per * t_tile + 3.0)
+            if s > 1:
+                cost += 4.0 + M * N * nbatch * (s + 1) * 4 / 3.0e6     # reduce kernel: launch + ws traffic at ~3 TB/s
+            if best is None or cost < best[0]:
+                best = (cost, tile, s)
+    return best[1], best[2]
+
+
 def pick_splitk(M, N, K, nbatch=1):
-    tiles = ((M + 63) // 64) * ((N + 63) // 64) * nbatch
-    ktiles = (K + 31) // 32
-    if tiles >= 256 or ktiles < 16:
-        return 1
-    s = min(max(1, 512 // tiles), ktiles // 8, 64)
-    return max(1, s)
+    return plan_gemm(M, N, K, nbatch)[1]
 
 
 def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
          ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False, a_rowsum=None,
-         a_rowsum_accumulate=False):
+         a_rowsum_accumulate=False, tile=0):
     """C = act(alpha * A.B^T + bias) + res   (see s2svc_gemm in include/s2svc_hip.h)."""
     d = _lib.GemmDesc()
     d.A, d.B = A, B
@@ -122,6 +141,7 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
     d.dtype = _DT[in_dtype]
     d.accumulate = 1 if accumulate else 0
     d.splitk = splitk
+    d.tile_hint = tile
     ws = None
     if splitk > 1:
         ws = torch.empty(splitk * nb0 * nb1 * M * N, dtype=torch.float32, device=out.device)
@@ -226,23 +246,26 @@ def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats=True):
 # ----------------------------------------------------------------------------------------------
 # attention probabilities
 # ----------------------------------------------------------------------------------------------
-def attn_softmax_fwd(scores, out_dtype, scale, klen=None, causal=False, bd=None, rel_mode=0, p=0.0, seed=(None, 0)):
-    B, H, T1, T2 = scores.shape
+def attn_softmax_fwd(scores, out_dtype, scale, klen=None, causal=False, bd=None, rel_mode=0, p=0.0, seed=(None, 0), T2=None):
+    """scores: fp32 (B, H, T1, ld) with ld >= T2 (rows padded to a vector multiple); outputs share that layout."""
+    B, H, T1, ld = scores.shape
+    T2 = ld if T2 is None else T2
     attn = torch.empty(scores.shape, dtype=out_dtype, device=scores.device)
     pdrop = torch.empty_like(attn) if p > 0.0 else None
     Lp = bd.shape[-1] if bd is not None else 0
-    _lib.check(_lib.lib().s2svc_attn_softmax_fwd(_DT[out_dtype], B, H, T1, T2, ptr(scores), ptr(bd), Lp, rel_mode, scale,
+    _lib.check(_lib.lib().s2svc_attn_softmax_fwd(_DT[out_dtype], B, H, T1, T2, ld, ptr(scores), ptr(bd), Lp, rel_mode, scale,
                                                  ptr(klen), 1 if causal else 0, p, seed[0], seed[1], ptr(attn), ptr(pdrop),
                                                  stream()), "attn_softmax_fwd")
     return attn, pdrop
 
 
-def attn_softmax_bwd(attn, dp, scale, p=0.0, seed=(None, 0), Lp=0, rel_mode=0, dattn=None):
-    B, H, T1, T2 = attn.shape
+def attn_softmax_bwd(attn, dp, scale, p=0.0, seed=(None, 0), Lp=0, rel_mode=0, dattn=None, T2=None):
+    B, H, T1, ld = attn.shape
+    T2 = ld if T2 is None else T2
     dscores = torch.empty_like(attn)
     dbd = torch.empty((B, H, T1, Lp), dtype=attn.dtype, device=attn.device) if Lp else None
-    _lib.check(_lib.lib().s2svc_attn_softmax_bwd(dt(attn), B, H, T1, T2, ptr(attn), ptr(dp), ptr(dattn), scale, p, seed[0], seed[1],
-                                                 ptr(dscores), ptr(dbd), Lp, rel_mode, stream()), "attn_softmax_bwd")
+    _lib.check(_lib.lib().s2svc_attn_softmax_bwd(dt(attn), B, H, T1, T2, ld, ptr(attn), ptr(dp), ptr(dattn), scale, p, seed[0],
+                                                 seed[1], ptr(dscores), ptr(dbd), Lp, rel_mode, stream()), "attn_softmax_bwd")
     return dscores, dbd
 
 

@@ -295,6 +295,22 @@ def attn_softmax(dtype):
         pr.backward(dp)
         dsc, _ = K.attn_softmax_bwd(attn, dp, scale)
         res.append(check(f"softmax bwd[{dtype}] causal={causal}", dsc, sr.grad, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
+        # rows padded to a multiple of 8 (ld > T2): pad columns hold garbage on input and must come back zero
+        ld = (T2c + 7) // 8 * 8
+        sp = torch.full((B, H, T1, ld), 1e30, dtype=torch.float32, device=DEV)
+        sp[..., :T2c] = s
+        attn_p, _ = K.attn_softmax_fwd(sp, dtype, scale, klen=kl, causal=causal, T2=T2c)
+        res.append(check(f"softmax fwd padded[{dtype}] causal={causal}", attn_p[..., :T2c], pr, dtype,
+                         atol=1e-6 if dtype == torch.float32 else 1e-2))
+        res.append(check(f"softmax fwd pad cols zero[{dtype}]", attn_p[..., T2c:].float(), torch.zeros_like(attn_p[..., T2c:]).float(),
+                         torch.float32, atol=0.0))
+        dpp = torch.full((B, H, T1, ld), 1e30, dtype=torch.float32, device=DEV)
+        dpp[..., :T2c] = dp
+        dsp, _ = K.attn_softmax_bwd(attn_p, dpp, scale, T2=T2c)
+        res.append(check(f"softmax bwd padded[{dtype}] causal={causal}", dsp[..., :T2c], sr.grad, dtype,
+                         atol=1e-6 if dtype == torch.float32 else 2e-2))
+        res.append(check(f"softmax bwd pad cols zero[{dtype}]", dsp[..., T2c:].float(), torch.zeros_like(dsp[..., T2c:]).float(),
+                         torch.float32, atol=0.0))
     # relative-position variants (T1 == T2)
     T = 19
     ac = rnd(B, H, T, T, seed=7) * 2
