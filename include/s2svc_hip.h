@@ -212,6 +212,30 @@ int s2svc_betabinom_prior(int B, int Tf, int Tx, const int32_t* text_lens, const
                           void* stream);
 
 /* ========================================================================================== */
+/* Autoregressive decode step (static K/V cache, device-resident step index, device stop test) */
+/* replaces: models/vtn.py:344-389 / models/transformer_tts.py:268-321 (generation loop),      */
+/* modules/transformer/decoder.py:239-273 (forward_one_step), decoder_layer.py:85-132 (cache). */
+/* `pos` is one device int32 (0-based position of the frame being generated); every kernel of */
+/* a step reads it, s2svc_decode_advance bumps it: one captured hipGraph serves all steps.    */
+/* ========================================================================================== */
+/* y[b,:] = x[b,:]*xscale + alpha*pe[pos,:]   (embedding.py:73-88 / :115-125 for one position) */
+int s2svc_decode_posenc(int dtype, int B, int D, const void* x, float xscale, const float* alpha, const float* pe,
+                        const int32_t* pos, void* y, void* stream);
+/* one query row per (utterance, head) against a K/V cache (B, Tk, .) with time stride ldt and batch stride cbs.   */
+/* knew/vnew != NULL (self-attention): the row is first appended at position *pos, keys 0..*pos are attended;      */
+/* else (source attention) keys 0..klen[b]-1.  att != NULL: probabilities (zeros past the valid keys) are stored   */
+/* at att[b*att_bs + h*att_hs + *pos*att_ps + j], j < Tk  (vtn.py:364-375 collects src_attn.attn[0,:,-1]).          */
+int s2svc_decode_attn(int dtype, int B, int H, int dk, const void* q, int64_t ldq, void* kcache, void* vcache,
+                      int64_t ldt, int64_t cbs, const void* knew, const void* vnew, int64_t ldn, const int32_t* pos,
+                      const int32_t* klen, int Tk, float scale, void* ctx, int64_t ldo, float* att, int64_t att_bs,
+                      int64_t att_hs, int64_t att_ps, void* stream);
+/* outs[b, pos*r+i, :] = feat[b, i, :]; probs = sigmoid(logit); prev[b,:] = last frame; stop test vtn.py:378-381 */
+int s2svc_decode_emit(int dtype, int B, int r, int odim, const void* feat, const void* logit, float threshold,
+                      const int32_t* minlen, const int32_t* maxlen, const int32_t* pos, float* outs, int64_t outs_bs,
+                      float* probs, int64_t probs_bs, void* prev, int32_t* stop_at, void* stream);
+int s2svc_decode_advance(int32_t* pos, uint64_t* seed_base, uint64_t seed_stride, void* stream);
+
+/* ========================================================================================== */
 /* Optimiser: grad-norm -> clip -> WarmupLR -> Adam (+ bf16 shadow) over one flat buffer       */
 /* replaces: trainers/ar_vc.py:99-107 (clip_grad_norm_, Adam.step, scheduler.step),            */
 /* schedulers/warmup_lr.py:54-61.  state: 4 device floats {step, lr, grad_norm, clip_coef}.    */

@@ -114,6 +114,12 @@ _SIGS = {
     "s2svc_betabinom_prior": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_conv_in1_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_conv_in1_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
+    "s2svc_decode_posenc": [c_i32, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_decode_attn": [c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32,
+                          c_f32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],
+    "s2svc_decode_emit": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
+                          c_vp],
+    "s2svc_decode_advance": [c_vp, c_vp, c_u64, c_vp],
     "s2svc_reflect_pad": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "s2svc_magnitude": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "s2svc_log_clamp": [c_i64, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp],

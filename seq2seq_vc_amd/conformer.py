@@ -147,10 +147,10 @@ class ConformerEncoder(nn.Module):
             self.after_norm = Mo.LayerNorm(attention_dim)
         self.dropout_rate = dropout_rate
 
-    def forward(self, xs, lens):
+    def forward(self, xs, lens, exact_lens=False):
         """xs (B,T,idim) compute dtype; lens: Lens or None -> (ys (B,T',adim), lens')."""
         if self.input_layer == "conv2d":
-            xs, lens = self.embed(xs, lens)           # Conv2dSubsampling applies its positional encoding itself
+            xs, lens = self.embed(xs, lens, exact_lens)   # Conv2dSubsampling applies its positional encoding itself
         elif self.input_layer == "linear":
             lin, ln = self.embed[0], self.embed[1]
             xs = Fn.linear(xs, lin.weight, lin.bias)

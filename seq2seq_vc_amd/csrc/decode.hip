@@ -1,0 +1,184 @@
+// Autoregressive decode step kernels (one new decoder position per step, all utterances of the batch in lockstep).
+//
+// reference: models/vtn.py:344-389 (the generation loop), modules/transformer/decoder.py:239-273
+// (forward_one_step), decoder_layer.py:85-132 (per-layer cache).  The reference re-projects K/V over the whole
+// prefix every step and grows `ys` by concatenation; here K/V live in a static cache of capacity Lmax, the step
+// index is a device-resident scalar (so one captured hipGraph replays for every step), and the stop test runs
+// on the device.
+#include "common.h"
+#include "../../include/s2svc_hip.h"
+
+namespace {
+
+// y[b, :] = x[b, :] * xscale + alpha * pe[pos, :]
+template <typename T>
+__global__ __launch_bounds__(256) void decode_posenc_kernel(int B, int D, const T* __restrict__ x, float xscale,
+                                                            const float* __restrict__ alpha, const float* __restrict__ pe,
+                                                            const int32_t* __restrict__ pos, T* __restrict__ y) {
+  const int p = *pos;
+  const float a = alpha ? *alpha : 1.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * D; i += gridDim.x * blockDim.x) {
+    const int d = i % D;
+    stf(y + i, ldf(x + i) * xscale + a * pe[(int64_t)p * D + d]);
+  }
+}
+
+// One workgroup per (utterance, head): optional append of the new key/value row at *pos, scores over the valid
+// keys (one wavefront per key, lanes over d_k: coalesced rows), softmax in LDS, context = P.V (thread per d).
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(int H, int dk, const T* __restrict__ q, int64_t ldq, T* __restrict__ kc,
+                                                          T* __restrict__ vc, int64_t ldt, int64_t cbs, const T* __restrict__ knew,
+                                                          const T* __restrict__ vnew, int64_t ldn, const int32_t* __restrict__ pos,
+                                                          const int32_t* __restrict__ klen, int Tk, float scale, T* __restrict__ ctx,
+                                                          int64_t ldo, float* __restrict__ att, int64_t att_bs, int64_t att_hs,
+                                                          int64_t att_ps) {
+  extern __shared__ float sm[];   // Tk scores, then dk query values
+  float* sc = sm;
+  float* sq = sm + Tk;
+  __shared__ float red[2];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int p = *pos;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* kb = kc + (int64_t)b * cbs + h * dk;
+  T* vb = vc + (int64_t)b * cbs + h * dk;
+  int n;
+  if (knew) {                      // self-attention: append this step's key/value, attend to positions 0..pos
+    n = p + 1;
+    if (n > Tk) n = Tk;            // capacity guard (the host never replays past Lmax)
+    for (int d = threadIdx.x; d < dk; d += 256) {
+      kb[(int64_t)p * ldt + d] = knew[(int64_t)b * ldn + h * dk + d];
+      vb[(int64_t)p * ldt + d] = vnew[(int64_t)b * ldn + h * dk + d];
+    }
+  } else {
+    n = klen ? klen[b] : Tk;
+    if (n > Tk) n = Tk;
+  }
+  for (int d = threadIdx.x; d < dk; d += 256) sq[d] = ldf(q + (int64_t)b * ldq + h * dk + d);
+  __syncthreads();                 // also orders the cache append before the reads below (same workgroup)
+  for (int j = wave; j < n; j += 4) {
+    float s = 0.f;
+    for (int d = lane; d < dk; d += 64) s += sq[d] * ldf(kb + (int64_t)j * ldt + d);
+    s = wave_sum(s);
+    if (lane == 0) sc[j] = s * scale;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float mx = -3.4028234663852886e38f;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, sc[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) sum += expf(sc[j] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) { red[0] = mx; red[1] = 1.f / sum; }
+  }
+  __syncthreads();
+  const float mx = red[0], inv = red[1];
+  float* arow = att ? att + (int64_t)b * att_bs + (int64_t)h * att_hs + (int64_t)p * att_ps : nullptr;
+  for (int j = threadIdx.x; j < Tk; j += 256) {
+    const float pr = j < n ? expf(sc[j] - mx) * inv : 0.f;
+    sc[j] = pr;
+    if (arow) arow[j] = pr;
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < dk; d += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < n; ++j) acc += sc[j] * ldf(vb + (int64_t)j * ldt + d);
+    stf(ctx + (int64_t)b * ldo + h * dk + d, acc);
+  }
+}
+
+// outs[b, pos*r + i, :] = feat[b, i*odim : (i+1)*odim] ; probs[b, pos*r + i] = sigmoid(logit[b, i]) ;
+// prev[b, :] = last of the r frames ; with idx = pos+1 (the reference's 1-based step counter, vtn.py:345),
+// stop_at[b] = idx the first time (any prob >= threshold || idx >= maxlen[b]) && idx >= minlen[b]  (vtn.py:378-381)
+template <typename T>
+__global__ __launch_bounds__(256) void decode_emit_kernel(int r, int odim, const T* __restrict__ feat, const T* __restrict__ logit,
+                                                          float threshold, const int32_t* __restrict__ minlen,
+                                                          const int32_t* __restrict__ maxlen, const int32_t* __restrict__ pos,
+                                                          float* __restrict__ outs, int64_t outs_bs, float* __restrict__ probs,
+                                                          int64_t probs_bs, T* __restrict__ prev, int32_t* __restrict__ stop_at) {
+  const int b = blockIdx.x;
+  const int p = *pos;
+  for (int i = threadIdx.x; i < r * odim; i += 256) {
+    const float v = ldf(feat + (int64_t)b * r * odim + i);
+    outs[(int64_t)b * outs_bs + (int64_t)p * r * odim + i] = v;
+    if (i >= (r - 1) * odim) stf(prev + (int64_t)b * odim + (i - (r - 1) * odim), v);
+  }
+  if (threadIdx.x == 0) {
+    bool fire = false;
+    for (int i = 0; i < r; ++i) {
+      const float pr = 1.f / (1.f + expf(-ldf(logit + (int64_t)b * r + i)));
+      probs[(int64_t)b * probs_bs + (int64_t)p * r + i] = pr;
+      fire = fire || (pr >= threshold);
+    }
+    if ((fire || p + 1 >= maxlen[b]) && p + 1 >= minlen[b] && stop_at[b] == 0) stop_at[b] = p + 1;
+  }
+}
+
+__global__ void decode_advance_kernel(int32_t* pos, uint64_t* seed_base, uint64_t seed_stride) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *pos += 1;
+    if (seed_base) *seed_base += seed_stride;
+  }
+}
+
+}  // namespace
+
+extern "C" int s2svc_decode_posenc(int dtype, int B, int D, const void* x, float xscale, const float* alpha, const float* pe,
+                                   const int32_t* pos, void* y, void* stream) {
+  S2S_REQUIRE(B >= 0 && D > 0 && pos && pe, "decode_posenc: bad arguments");
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (B * D + 255) / 256;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(decode_posenc_kernel<float>, dim3(nb), dim3(256), 0, st, B, D, (const float*)x, xscale, alpha, pe, pos, (float*)y);
+  else
+    hipLaunchKernelGGL(decode_posenc_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, B, D, (const bf16_t*)x, xscale, alpha, pe, pos, (bf16_t*)y);
+  S2S_CHECK_LAUNCH("decode_posenc_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_decode_attn(int dtype, int B, int H, int dk, const void* q, int64_t ldq, void* kcache, void* vcache,
+                                 int64_t ldt, int64_t cbs, const void* knew, const void* vnew, int64_t ldn, const int32_t* pos,
+                                 const int32_t* klen, int Tk, float scale, void* ctx, int64_t ldo, float* att, int64_t att_bs,
+                                 int64_t att_hs, int64_t att_ps, void* stream) {
+  S2S_REQUIRE(B >= 0 && H > 0 && dk > 0 && Tk > 0 && pos, "decode_attn: bad arguments");
+  S2S_REQUIRE((knew == nullptr) == (vnew == nullptr), "decode_attn: knew and vnew go together");
+  const size_t shm = (size_t)(Tk + dk) * sizeof(float);
+  S2S_REQUIRE(shm <= 60 * 1024, "decode_attn: key capacity too large for the LDS score buffer");
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(decode_attn_kernel<float>, dim3(B * H), dim3(256), shm, st, H, dk, (const float*)q, ldq, (float*)kcache,
+                       (float*)vcache, ldt, cbs, (const float*)knew, (const float*)vnew, ldn, pos, klen, Tk, scale, (float*)ctx, ldo,
+                       att, att_bs, att_hs, att_ps);
+  else
+    hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, dim3(B * H), dim3(256), shm, st, H, dk, (const bf16_t*)q, ldq, (bf16_t*)kcache,
+                       (bf16_t*)vcache, ldt, cbs, (const bf16_t*)knew, (const bf16_t*)vnew, ldn, pos, klen, Tk, scale, (bf16_t*)ctx,
+                       ldo, att, att_bs, att_hs, att_ps);
+  S2S_CHECK_LAUNCH("decode_attn_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_decode_emit(int dtype, int B, int r, int odim, const void* feat, const void* logit, float threshold,
+                                 const int32_t* minlen, const int32_t* maxlen, const int32_t* pos, float* outs, int64_t outs_bs, float* probs, int64_t probs_bs, void* prev,
+                                 int32_t* stop_at, void* stream) {
+  S2S_REQUIRE(B >= 0 && r > 0 && odim > 0 && pos && outs && probs && prev && stop_at, "decode_emit: bad arguments");
+  S2S_REQUIRE(minlen && maxlen, "decode_emit: per-utterance minlen/maxlen required");
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(decode_emit_kernel<float>, dim3(B), dim3(256), 0, st, r, odim, (const float*)feat, (const float*)logit, threshold,
+                       minlen, maxlen, pos, outs, outs_bs, probs, probs_bs, (float*)prev, stop_at);
+  else
+    hipLaunchKernelGGL(decode_emit_kernel<bf16_t>, dim3(B), dim3(256), 0, st, r, odim, (const bf16_t*)feat, (const bf16_t*)logit,
+                       threshold, minlen, maxlen, pos, outs, outs_bs, probs, probs_bs, (bf16_t*)prev, stop_at);
+  S2S_CHECK_LAUNCH("decode_emit_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_decode_advance(int32_t* pos, uint64_t* seed_base, uint64_t seed_stride, void* stream) {
+  S2S_REQUIRE(pos, "decode_advance: pos required");
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pos, seed_base, seed_stride);
+  S2S_CHECK_LAUNCH("decode_advance_kernel");
+  return 0;
+}

@@ -60,8 +60,14 @@ class _ARSeq2Seq(nn.Module):
         return after, before, logits, ys, labels, olens_out, olens_in
 
     def _decode_loop(self, hs, threshold, minlenratio, maxlenratio):
-        """Step-wise generation with the reference's semantics (every step re-evaluates the decoder over
-        the whole prefix; the per-layer cache of the reference changes cost, not values)."""
+        """Step-wise generation for one utterance: static K/V cache + captured step graph (decode.py)."""
+        from ..decode import decode
+        args = {"threshold": threshold, "minlenratio": minlenratio, "maxlenratio": maxlenratio}
+        return decode(self, hs, [hs.size(1)], args)[0]
+
+    def _decode_loop_recompute(self, hs, threshold, minlenratio, maxlenratio):
+        """The reference's schedule, kept as a cross-check of the cached path: every step re-evaluates the
+        decoder over the whole prefix (the reference's per-layer cache changes cost, not values)."""
         r, odim = self.decoder_reduction_factor, self.odim
         maxlen = int(hs.size(1) * maxlenratio / r)
         minlen = int(hs.size(1) * minlenratio / r)
@@ -182,3 +188,14 @@ class VTN(_ARSeq2Seq):
         """x (T, idim) -> (outs (L, odim), probs (L,), att_ws (#layers, #heads, L/r, T_enc))."""
         hs, _ = self.encoder(Fn.to_compute(x.unsqueeze(0)), None)
         return self._decode_loop(hs, inference_args["threshold"], inference_args["minlenratio"], inference_args["maxlenratio"])
+
+    @torch.no_grad()
+    def inference_batch(self, xs, ilens, inference_args, poll=16):
+        """Several utterances in lockstep: xs (B, Tmax, idim) zero-padded, ilens (B,).  Returns one
+        `inference` result per utterance.  (Extension: the reference decodes utterance by utterance,
+        bin/vc_decode.py:264-306.  Each row is given the encoder length it has when processed alone, so
+        that padding never enters an utterance and the frames equal those of single-utterance decoding.)"""
+        from ..decode import decode
+        lens = Mo.Lens.of(ilens, xs.device)
+        hs, hlens = self.encoder(Fn.to_compute(xs), lens, exact_lens=True)
+        return decode(self, hs, list(hlens.host), inference_args, poll=poll)

@@ -368,11 +368,17 @@ class Conv2dSubsampling(nn.Module):
         return self.out[key]
 
     @staticmethod
-    def out_lens(lens, t_out):
-        """mask[:, :, :-2:2][:, :, :-2:2] of a non-pad mask keeps frame t' iff 4*t' < len."""
-        return None if lens is None else lens.map(lambda v: min((v + 3) // 4, t_out))
+    def out_lens(lens, t_out, exact=False):
+        """mask[:, :, :-2:2][:, :, :-2:2] of a non-pad mask keeps frame t' iff 4*t' < len (the reference's
+        batch semantics: frames whose receptive field reaches into the padding stay valid).  exact=True:
+        the frame count the utterance has when it is processed alone, ((len-1)//2-1)//2."""
+        if lens is None:
+            return None
+        if exact:
+            return lens.map(lambda v: min(((v - 1) // 2 - 1) // 2, t_out))
+        return lens.map(lambda v: min((v + 3) // 4, t_out))
 
-    def forward(self, x, lens):
+    def forward(self, x, lens, exact_lens=False):
         B, T, idim = x.shape
         c0, c2 = self.conv[0], self.conv[2]
         if c0.weight.shape[0] % 8 == 0:
@@ -385,7 +391,7 @@ class Conv2dSubsampling(nn.Module):
         y = Fn.linear_fc_permuted(y.reshape(B * T2, F2 * C), lin.weight, lin.bias, C, F2).view(B, T2, self.odim)
         if self.use_pos_enc:
             y = self.out[1](y)
-        return y, self.out_lens(lens, T2)
+        return y, self.out_lens(lens, T2, exact_lens)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -476,9 +482,9 @@ class TransformerEncoder(nn.Module):
             self.after_norm = LayerNorm(attention_dim)
         self.dropout_rate = dropout_rate
 
-    def forward(self, xs, lens):
+    def forward(self, xs, lens, exact_lens=False):
         if isinstance(self.embed, Conv2dSubsampling):
-            xs, lens = self.embed(xs, lens)
+            xs, lens = self.embed(xs, lens, exact_lens)
         else:
             emb = self.embed[0]
             if isinstance(emb, nn.Embedding):

@@ -1,0 +1,36 @@
+"""Launchers for the autoregressive decode-step kernels (csrc/decode.hip; C-ABI in include/s2svc_hip.h)."""
+from .. import _lib
+from .kernels import dt, ptr, stream
+
+
+def _p(t, off=0):
+    return None if t is None else t.data_ptr() + off * t.element_size()
+
+
+def decode_posenc(x, xscale, alpha, pe, pos, y):
+    B, D = x.shape
+    _lib.check(_lib.lib().s2svc_decode_posenc(dt(x), B, D, ptr(x), xscale, ptr(alpha), ptr(pe), ptr(pos), ptr(y), stream()),
+               "decode_posenc")
+    return y
+
+
+def decode_attn(q, q_off, ldq, kc, k_off, vc, v_off, ldt, cbs, new, knew_off, vnew_off, ldn, pos, klen, Tk, scale, ctx, B, H, dk,
+                att=None, att_strides=(0, 0, 0)):
+    """q/kc/vc/new are tensors, *_off element offsets into them (packed projections); see s2svc_decode_attn."""
+    _lib.check(_lib.lib().s2svc_decode_attn(dt(ctx), B, H, dk, _p(q, q_off), ldq, _p(kc, k_off), _p(vc, v_off), ldt, cbs,
+                                            _p(new, knew_off) if new is not None else None,
+                                            _p(new, vnew_off) if new is not None else None, ldn, ptr(pos), ptr(klen), Tk, scale,
+                                            ptr(ctx), ctx.shape[-1], ptr(att), att_strides[0], att_strides[1], att_strides[2],
+                                            stream()), "decode_attn")
+    return ctx
+
+
+def decode_emit(feat, logit, r, odim, threshold, minlen, maxlen, pos, outs, probs, prev, stop_at):
+    B = feat.shape[0]
+    _lib.check(_lib.lib().s2svc_decode_emit(dt(feat), B, r, odim, ptr(feat), ptr(logit), threshold, ptr(minlen), ptr(maxlen),
+                                            ptr(pos), ptr(outs), outs.stride(0), ptr(probs), probs.stride(0), ptr(prev),
+                                            ptr(stop_at), stream()), "decode_emit")
+
+
+def decode_advance(pos, seed_base_ptr=None, seed_stride=0):
+    _lib.check(_lib.lib().s2svc_decode_advance(ptr(pos), seed_base_ptr, seed_stride, stream()), "decode_advance")

@@ -163,6 +163,106 @@ def vtn_tiny_inference_fp32():
             cmp("vtn inference att_ws", att, z["out.att_ws"], 2e-5)]
 
 
+def _inference_model(name):
+    from seq2seq_vc_amd import models as M
+    cfg, z = load(name)
+    Fn.set_compute_dtype(torch.float32)
+    model = getattr(M, cfg["__model__"])(**model_cfg(cfg))
+    model.load_state_dict(sd_of(z))
+    model.to(DEV).eval()
+    for m in model.modules():
+        if hasattr(m, "dropout_rate"):
+            m.dropout_rate = 0.0
+    return model, cfg, z
+
+
+def _inference_vs_golden(name):
+    model, cfg, z = _inference_model(name)
+    outs, probs, att = model.inference(torch.from_numpy(z["in.x"]).to(DEV), cfg["__inference__"])
+    return [cmp(f"{name} outs", outs, z["out.outs"], 4e-4, l1_tol=1e-4), cmp(f"{name} probs", probs, z["out.probs"], 1e-4),
+            cmp(f"{name} att_ws", att, z["out.att_ws"], 2e-5)]
+
+
+@case
+def vtn_preln_inference_stop_fp32():
+    """Pre-LN decoder; generation ends through the stop threshold after minlen suppressed two earlier firings."""
+    return _inference_vs_golden("vtn_preln_inference_stop")
+
+
+@case
+def tts_tiny_inference_fp32():
+    return _inference_vs_golden("tts_tiny_inference")
+
+
+@case
+def decode_cached_graph_vs_eager_vs_recompute():
+    """The captured-graph K/V-cache decode, the same kernels launched eagerly, and the reference's
+    recompute-the-prefix schedule give the same frames (fp32)."""
+    from seq2seq_vc_amd import decode as D
+    res = []
+    for name in ("vtn_tiny_inference", "vtn_preln_inference_stop"):
+        model, cfg, z = _inference_model(name)
+        args = cfg["__inference__"]
+        x = torch.from_numpy(z["in.x"]).to(DEV)
+        with torch.no_grad():
+            hs, _ = model.encoder(x.unsqueeze(0), None)
+            g = D.decode(model, hs, [hs.size(1)], args)[0]
+            e = D.decode(model, hs, [hs.size(1)], args, use_graph=False, poll=3)[0]
+            rc = model._decode_loop_recompute(hs, args["threshold"], args["minlenratio"], args["maxlenratio"])
+        for nm, a, b, tol in (("graph vs eager", g, e, 0.0), ("graph vs recompute", g, rc, 2e-5)):
+            for part, u, v in zip(("outs", "probs", "att"), a, b):
+                res.append(cmp(f"{name} {nm} {part}", u, v.cpu().numpy(), tol))
+    return res
+
+
+@case
+def decode_batch_vs_single():
+    """Utterances of different lengths decoded in lockstep (different stop steps) == one at a time."""
+    model, cfg, z = _inference_model("vtn_preln_inference_stop")
+    args = dict(cfg["__inference__"])
+    g = torch.Generator().manual_seed(7)
+    lens = [68, 41, 55, 23]
+    xs = torch.zeros(len(lens), max(lens), 80)
+    for b, n in enumerate(lens):
+        xs[b, :n] = torch.randn(n, 80, generator=g)
+    xs[0, :68] = torch.from_numpy(z["in.x"])
+    xs = xs.to(DEV)
+    args["minlenratio"] = 0.5
+    batch = model.inference_batch(xs, torch.tensor(lens), args, poll=4)
+    res = []
+    for b, n in enumerate(lens):
+        single = model.inference(xs[b, :n], args)
+        for part, u, v in zip(("outs", "probs", "att"), batch[b], single):
+            res.append(cmp(f"batch[{b}] (T={n}, L={single[0].shape[0]}) {part}", u, v.cpu().numpy(), 2e-5))
+    res.append((len({r[0].shape[0] for r in batch}) > 1, f"utterances stop at different steps: {[r[0].shape[0] for r in batch]}"))
+    return res
+
+
+@case
+def decode_bf16_dropout_runs():
+    """bf16 compute with the always-on prenet dropout: finite frames, per-step masks differ between replays."""
+    from seq2seq_vc_amd import models as M
+    cfg, z = load("vtn_tiny_inference")
+    Fn.set_compute_dtype(torch.bfloat16)
+    try:
+        model = M.VTN(**model_cfg(cfg))
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).eval()
+        x = torch.from_numpy(z["in.x"]).to(DEV)
+        K.manual_seed(3)
+        o1, p1, a1 = model.inference(x, cfg["__inference__"])
+        o2, _, _ = model.inference(x, cfg["__inference__"])
+        ref = torch.from_numpy(z["out.outs"])
+        ok_shape = tuple(o1.shape) == tuple(ref.shape) and bool(torch.isfinite(o1).all())
+        differ = float((o1 - o2).abs().max()) > 0
+        steps = o1.view(-1, model.decoder_reduction_factor, o1.shape[-1])
+        return [(ok_shape, f"bf16 decode finite, shape {tuple(o1.shape)}"), (differ, "dropout masks differ between runs"),
+                (float((steps[1:] - steps[:-1]).abs().max()) > 0, "frames vary over steps"),
+                cmp("att rows sum to 1", a1.sum(-1), np.ones(a1.shape[:-1], dtype=np.float32), 1e-3)]
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+
+
 @case
 def vtn_conformer_tiny_train_fp32():
     return run_ar("vtn_conformer_tiny_train", torch.float32, "VTN")

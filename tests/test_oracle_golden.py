@@ -95,10 +95,14 @@ def test_vtn_forward_and_grads(name):
         close(sd[k[9:]].detach(), z[k], 1e-5)
 
 
-def test_vtn_inference():
-    cfg, z = load("vtn_tiny_inference")
+@pytest.mark.parametrize("name", ["vtn_tiny_inference", "vtn_preln_inference_stop", "tts_tiny_inference"])
+def test_ar_inference(name):
+    """Generation loop: run to maxlen / stop through the threshold with minlen in force (pre-LN decoder) / TTS."""
+    cfg, z = load(name)
     with torch.no_grad():
-        outs, probs, att = OM.vtn_inference(sd_of(z), model_cfg(cfg), torch.from_numpy(z["in.x"]), **cfg["__inference__"])
+        outs, probs, att = OM.vtn_inference(sd_of(z), model_cfg(cfg), torch.from_numpy(z["in.x"]),
+                                            tts=cfg["__model__"] == "TransformerTTS", **cfg["__inference__"])
+    assert tuple(outs.shape) == z["out.outs"].shape      # same stop step as the reference
     close(outs, z["out.outs"], 1e-5); close(probs, z["out.probs"], 1e-6); close(att, z["out.att_ws"], 1e-6)
 
 

@@ -138,22 +138,36 @@ def gen_vtn(M, L, name, cfg, B, Ti, To, seed, train=True):
     return model
 
 
-def gen_vtn_inference(M, name, cfg, T, seed, maxlenratio=2.0):
+def gen_vtn_inference(M, name, cfg, T, seed, maxlenratio=2.0, fire=False, minlenratio=0.0, tts=False):
+    """AR generation fixture.  fire=True: the stop threshold is placed inside the range of the stop probabilities the
+    reference itself produces, so generation ends through the threshold test (vtn.py:378-381) and not at maxlen."""
     from oracle import models as OM
     torch.manual_seed(seed)
-    model = M.VTN(**cfg)
+    model = (M.TransformerTTS if tts else M.VTN)(**cfg)
     kill_dropout(model)
     model.eval()
-    x = torch.randn(T, cfg["idim"], generator=torch.Generator().manual_seed(seed + 1))
-    args = {"threshold": 2.0, "minlenratio": 0.0, "maxlenratio": maxlenratio}
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randint(1, cfg["idim"] - 1, (T,), generator=g) if tts else torch.randn(T, cfg["idim"], generator=g)
+    args = {"threshold": 2.0, "minlenratio": minlenratio, "maxlenratio": maxlenratio}
     with torch.no_grad():
         outs, probs, att_ws = model.inference(x, args)
+        if fire:
+            r = cfg["decoder_reduction_factor"]
+            per_step = probs.view(-1, r).max(dim=1).values            # a step stops when any of its r probs fires
+            n = per_step.numel()
+            k = max(2, n // 2)                                         # aim for the middle of the utterance
+            thr = float(per_step[k]) * (1 - 1e-3)                      # clear margin: fp32 noise cannot flip the step
+            first = int((per_step >= thr).nonzero()[0])
+            assert (per_step[:first] < thr * (1 - 1e-3)).all() or first == 0
+            args = dict(args, threshold=thr)
+            outs, probs, att_ws = model.inference(x, args)
+            print(f"  {name}: threshold {thr:.6f} fires at step {first + 1} of {n}; generated {outs.shape[0]} frames")
     arr = {}
     pack(arr, "sd.", model.state_dict())
     arr.update({"in.x": to_np(x), "out.outs": to_np(outs), "out.probs": to_np(probs), "out.att_ws": to_np(att_ws)})
-    save(name, dict(cfg, __model__="VTN", __inference__=args), arr)
+    save(name, dict(cfg, __model__="TransformerTTS" if tts else "VTN", __inference__=args), arr)
     with torch.no_grad():
-        o = OM.vtn_inference({k: v.clone() for k, v in model.state_dict().items()}, cfg, x, **args)
+        o = OM.vtn_inference({k: v.clone() for k, v in model.state_dict().items()}, cfg, x, tts=tts, **args)
     print(f"  oracle-vs-ref {name}: outs {maxerr(o[0], outs):.2e} probs {maxerr(o[1], probs):.2e} att {maxerr(o[2], att_ws):.2e}")
 
 
@@ -306,18 +320,35 @@ AAS_DET_TINY = dict(AAS_TINY, duration_predictor_type="deterministic", duration_
 
 
 def main():
+    """python tools/gen_golden.py [fixture-name ...]  (no names: regenerate everything)"""
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     M, L, A = import_reference()
     torch.set_num_threads(4)
-    gen_mas_kats(A)
-    gen_loss_tables(L)
-    gen_vtn(M, L, "vtn_tiny_train", VTN_TINY, B=3, Ti=60, To=48, seed=100)
-    gen_vtn(M, L, "vtn_tiny_eval", VTN_TINY, B=2, Ti=41, To=37, seed=101, train=False)
-    gen_vtn(M, L, "vtn_conformer_tiny_train", VTN_CONF_TINY, B=2, Ti=52, To=40, seed=102)
-    gen_vtn_inference(M, "vtn_tiny_inference", VTN_TINY, T=44, seed=103)
-    gen_tts(M, L, "tts_tiny_train", TTS_TINY, B=3, Ti=14, To=50, seed=104)
-    gen_aasvc(M, L, A, "aasvc_tiny_train", AAS_TINY, B=3, Ti=64, To=72, seed=105)
-    gen_aasvc(M, L, A, "aasvc_det_tiny_train", AAS_DET_TINY, B=2, Ti=48, To=60, seed=106)
+    only = set(sys.argv[1:])
+    want = lambda n: not only or n in only
+    if want("mas_kats"):
+        gen_mas_kats(A)
+    if want("loss_tables"):
+        gen_loss_tables(L)
+    if want("vtn_tiny_train"):
+        gen_vtn(M, L, "vtn_tiny_train", VTN_TINY, B=3, Ti=60, To=48, seed=100)
+    if want("vtn_tiny_eval"):
+        gen_vtn(M, L, "vtn_tiny_eval", VTN_TINY, B=2, Ti=41, To=37, seed=101, train=False)
+    if want("vtn_conformer_tiny_train"):
+        gen_vtn(M, L, "vtn_conformer_tiny_train", VTN_CONF_TINY, B=2, Ti=52, To=40, seed=102)
+    if want("vtn_tiny_inference"):
+        gen_vtn_inference(M, "vtn_tiny_inference", VTN_TINY, T=44, seed=103)
+    if want("tts_tiny_train"):
+        gen_tts(M, L, "tts_tiny_train", TTS_TINY, B=3, Ti=14, To=50, seed=104)
+    if want("aasvc_tiny_train"):
+        gen_aasvc(M, L, A, "aasvc_tiny_train", AAS_TINY, B=3, Ti=64, To=72, seed=105)
+    if want("aasvc_det_tiny_train"):
+        gen_aasvc(M, L, A, "aasvc_det_tiny_train", AAS_DET_TINY, B=2, Ti=48, To=60, seed=106)
+    if want("vtn_preln_inference_stop"):       # pre-LN decoder, generation ended by the stop threshold, minlen > 0
+        gen_vtn_inference(M, "vtn_preln_inference_stop", dict(VTN_TINY, decoder_normalize_before=True), T=68, seed=107,
+                          maxlenratio=3.0, fire=True, minlenratio=1.6)
+    if want("tts_tiny_inference"):
+        gen_vtn_inference(M, "tts_tiny_inference", TTS_TINY, T=11, seed=108, maxlenratio=3.0, tts=True)
 
 
 if __name__ == "__main__":
