@@ -23,18 +23,40 @@ __global__ __launch_bounds__(256) void decode_posenc_kernel(int B, int D, const 
   }
 }
 
-// One workgroup per (utterance, head): optional append of the new key/value row at *pos, scores over the valid
-// keys (one wavefront per key, lanes over d_k: coalesced rows), softmax in LDS, context = P.V (thread per d).
-template <typename T>
+// vector of VEC consecutive elements -> floats
+template <typename T, int VEC> struct VLoad;
+template <> struct VLoad<bf16_t, 8> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&f)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+};
+template <> struct VLoad<float, 4> {
+  static __device__ __forceinline__ void ld(const float* p, float (&f)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+};
+template <typename T> struct VLoad<T, 1> {
+  static __device__ __forceinline__ void ld(const T* p, float (&f)[1]) { f[0] = ldf(p); }
+};
+
+// One workgroup per (utterance, head).  Optional append of the new key/value row at *pos; scores: 4 lanes per
+// key, 64 keys per pass, 16-byte row loads all in flight at once; softmax statistics by one wavefront; context:
+// (d_k / VEC) column chunks x S key-splits of threads accumulate P.V partials, summed through LDS in fixed order.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void decode_attn_kernel(int H, int dk, const T* __restrict__ q, int64_t ldq, T* __restrict__ kc,
                                                           T* __restrict__ vc, int64_t ldt, int64_t cbs, const T* __restrict__ knew,
                                                           const T* __restrict__ vnew, int64_t ldn, const int32_t* __restrict__ pos,
                                                           const int32_t* __restrict__ klen, int Tk, float scale, T* __restrict__ ctx,
                                                           int64_t ldo, float* __restrict__ att, int64_t att_bs, int64_t att_hs,
                                                           int64_t att_ps) {
-  extern __shared__ float sm[];   // Tk scores, then dk query values
+  extern __shared__ float sm[];   // Tk scores | dk query values | S x dk context partials
   float* sc = sm;
   float* sq = sm + Tk;
+  float* part = sq + dk;
   __shared__ float red[2];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int p = *pos;
@@ -44,7 +66,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(int H, int dk, const T
   int n;
   if (knew) {                      // self-attention: append this step's key/value, attend to positions 0..pos
     n = p + 1;
-    if (n > Tk) n = Tk;            // capacity guard (the host never replays past Lmax)
+    if (n > Tk) n = Tk;            // capacity guard (the host never replays past the cache capacity)
     for (int d = threadIdx.x; d < dk; d += 256) {
       kb[(int64_t)p * ldt + d] = knew[(int64_t)b * ldn + h * dk + d];
       vb[(int64_t)p * ldt + d] = vnew[(int64_t)b * ldn + h * dk + d];
@@ -55,11 +77,24 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(int H, int dk, const T
   }
   for (int d = threadIdx.x; d < dk; d += 256) sq[d] = ldf(q + (int64_t)b * ldq + h * dk + d);
   __syncthreads();                 // also orders the cache append before the reads below (same workgroup)
-  for (int j = wave; j < n; j += 4) {
-    float s = 0.f;
-    for (int d = lane; d < dk; d += 64) s += sq[d] * ldf(kb + (int64_t)j * ldt + d);
-    s = wave_sum(s);
-    if (lane == 0) sc[j] = s * scale;
+  const int nvec = dk / VEC;
+  {
+    const int c = threadIdx.x & 3;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int j = j0 + (threadIdx.x >> 2);
+      float s = 0.f;
+      if (j < n) {
+        for (int v = c; v < nvec; v += 4) {
+          float f[VEC];
+          VLoad<T, VEC>::ld(kb + (int64_t)j * ldt + v * VEC, f);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) s += sq[v * VEC + e] * f[e];
+        }
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      if (c == 0 && j < n) sc[j] = s * scale;
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -80,9 +115,28 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(int H, int dk, const T
     if (arow) arow[j] = pr;
   }
   __syncthreads();
+  const int S = 256 / nvec < 1 ? 1 : 256 / nvec;     // key splits (host sizes `part` for this)
+  {
+    const int c = threadIdx.x % nvec, sidx = threadIdx.x / nvec;
+    if (sidx < S) {
+      float acc[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+      for (int j = sidx; j < n; j += S) {
+        float f[VEC];
+        VLoad<T, VEC>::ld(vb + (int64_t)j * ldt + c * VEC, f);
+        const float pj = sc[j];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] += pj * f[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) part[sidx * dk + c * VEC + e] = acc[e];
+    }
+  }
+  __syncthreads();
   for (int d = threadIdx.x; d < dk; d += 256) {
     float acc = 0.f;
-    for (int j = 0; j < n; ++j) acc += sc[j] * ldf(vb + (int64_t)j * ldt + d);
+    for (int s2 = 0; s2 < S; ++s2) acc += part[s2 * dk + d];
     stf(ctx + (int64_t)b * ldo + h * dk + d, acc);
   }
 }
@@ -141,20 +195,30 @@ extern "C" int s2svc_decode_attn(int dtype, int B, int H, int dk, const void* q,
                                  int64_t ldt, int64_t cbs, const void* knew, const void* vnew, int64_t ldn, const int32_t* pos,
                                  const int32_t* klen, int Tk, float scale, void* ctx, int64_t ldo, float* att, int64_t att_bs,
                                  int64_t att_hs, int64_t att_ps, void* stream) {
-  S2S_REQUIRE(B >= 0 && H > 0 && dk > 0 && Tk > 0 && pos, "decode_attn: bad arguments");
+  S2S_REQUIRE(B >= 0 && H > 0 && dk > 0 && dk <= 256 && Tk > 0 && pos, "decode_attn: bad arguments");
   S2S_REQUIRE((knew == nullptr) == (vnew == nullptr), "decode_attn: knew and vnew go together");
-  const size_t shm = (size_t)(Tk + dk) * sizeof(float);
-  S2S_REQUIRE(shm <= 60 * 1024, "decode_attn: key capacity too large for the LDS score buffer");
   if (B == 0) return 0;
+  const int vec = dtype == S2S_F32 ? 4 : 8;
+  const size_t esz = dtype == S2S_F32 ? 4 : 2;
+  // 16-byte row loads need aligned rows; otherwise the element-wise instantiation runs
+  const bool vector_ok = dk % vec == 0 && ldt % vec == 0 && cbs % vec == 0 && ((uintptr_t)kcache) % 16 == 0 &&
+                         ((uintptr_t)vcache) % 16 == 0;
+  const int nvec = vector_ok ? dk / vec : dk;
+  const int S = 256 / nvec < 1 ? 1 : 256 / nvec;
+  const size_t shm = ((size_t)Tk + dk + (size_t)S * dk) * sizeof(float);
+  S2S_REQUIRE(shm <= 60 * 1024, "decode_attn: key capacity too large for the LDS score buffer");
+  (void)esz;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == S2S_F32)
-    hipLaunchKernelGGL(decode_attn_kernel<float>, dim3(B * H), dim3(256), shm, st, H, dk, (const float*)q, ldq, (float*)kcache,
-                       (float*)vcache, ldt, cbs, (const float*)knew, (const float*)vnew, ldn, pos, klen, Tk, scale, (float*)ctx, ldo,
-                       att, att_bs, att_hs, att_ps);
-  else
-    hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, dim3(B * H), dim3(256), shm, st, H, dk, (const bf16_t*)q, ldq, (bf16_t*)kcache,
-                       (bf16_t*)vcache, ldt, cbs, (const bf16_t*)knew, (const bf16_t*)vnew, ldn, pos, klen, Tk, scale, (bf16_t*)ctx,
-                       ldo, att, att_bs, att_hs, att_ps);
+#define S2S_DECODE_ATTN(T, VEC)                                                                                              \
+  hipLaunchKernelGGL((decode_attn_kernel<T, VEC>), dim3(B * H), dim3(256), shm, st, H, dk, (const T*)q, ldq, (T*)kcache,       \
+                     (T*)vcache, ldt, cbs, (const T*)knew, (const T*)vnew, ldn, pos, klen, Tk, scale, (T*)ctx, ldo, att, att_bs, \
+                     att_hs, att_ps)
+  if (dtype == S2S_F32) {
+    if (vector_ok) S2S_DECODE_ATTN(float, 4); else S2S_DECODE_ATTN(float, 1);
+  } else {
+    if (vector_ok) S2S_DECODE_ATTN(bf16_t, 8); else S2S_DECODE_ATTN(bf16_t, 1);
+  }
+#undef S2S_DECODE_ATTN
   S2S_CHECK_LAUNCH("decode_attn_kernel");
   return 0;
 }

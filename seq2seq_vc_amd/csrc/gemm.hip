@@ -316,7 +316,8 @@ int launch(const s2svc_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream);  // gemm_fast.hip
+extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream);    // gemm_fast.hip
+extern "C" int s2svc_gemm_try_skinny(const s2svc_gemm_desc* desc, void* stream);  // gemm_skinny.hip (M <= 64)
 
 static bool generic_forced() {
   static int v = -1;
@@ -340,6 +341,8 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   S2S_REQUIRE(d.B.mode == S2SVC_OP_DENSE || d.B.C > 0, "s2svc_gemm: conv operand B needs C");
   hipStream_t st = (hipStream_t)stream;
   if (!generic_forced()) {
+    const int rs = s2svc_gemm_try_skinny(&d, stream);
+    if (rs != 0) return rs < 0 ? rs : 0;
     const int rc = s2svc_gemm_try_fast(&d, stream);
     if (rc < 0) return rc;
     if (rc == 1) {

@@ -55,6 +55,64 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int D, const T* _
   }
 }
 
+// Same contract, rows held in registers (D <= 64*NV): one global read of x / res, one write of s and y -- no
+// store -> reload round trips, which dominate the latency of this kernel on short problems.
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf2f(f2bf(v)); }
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_reg_kernel(int rows, int D, const T* __restrict__ x, const T* __restrict__ res,
+                                                         float p, float hscale, const uint64_t* seed_base, uint64_t seed_off,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         T* __restrict__ y, T* __restrict__ s_out, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t base = (int64_t)row * D;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float v[NV], r[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < D ? ldf(x + base + c) : 0.f;
+    r[i] = (res && c < D) ? ldf(res + base + c) : 0.f;
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (res && c < D) {
+      float t = v[i];
+      if (p > 0.f) t *= dropout_scale(seed, (uint64_t)(base + c), p, inv_keep);
+      t = t * hscale + r[i];
+      stf(s_out + base + c, t);
+      v[i] = round_to<T>(t);     // statistics on the stored (rounded) value
+    }
+    sum += v[i];
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float d = (lane + 64 * i) < D ? v[i] - mean : 0.f;
+    sq += d * d;
+  }
+  const float var = wave_sum(sq) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) stf(y + base + c, (v[i] - mean) * rstd * gamma[c] + beta[c]);
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
 // LayerNorm backward wrt the normalised input s (+ fused residual/dropout split):
 //   g = dy*gamma ; ds = rstd*(g - mean(g) - xhat*mean(g*xhat)) + ds_extra
 //   dres = ds ; dh = ds * dropmask
@@ -240,12 +298,19 @@ extern "C" int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, co
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4), block(256);
-  if (dtype == S2S_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, rows, D, (const float*)x, (const float*)res, drop_p, hscale, seed_base, seed_off,
-                       gamma, beta, eps, (float*)y, (float*)s_out, mean, rstd);
-  else
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, block, 0, st, rows, D, (const bf16_t*)x, (const bf16_t*)res, drop_p, hscale,
-                       seed_base, seed_off, gamma, beta, eps, (bf16_t*)y, (bf16_t*)s_out, mean, rstd);
+#define S2S_LN_FWD(KERNEL, T)                                                                                            \
+  hipLaunchKernelGGL(KERNEL, grid, block, 0, st, rows, D, (const T*)x, (const T*)res, drop_p, hscale, seed_base, seed_off, \
+                     gamma, beta, eps, (T*)y, (T*)s_out, mean, rstd)
+  if (dtype == S2S_F32) {
+    if (D <= 512) S2S_LN_FWD((ln_fwd_reg_kernel<float, 8>), float);
+    else if (D <= 1024) S2S_LN_FWD((ln_fwd_reg_kernel<float, 16>), float);
+    else S2S_LN_FWD(ln_fwd_kernel<float>, float);
+  } else {
+    if (D <= 512) S2S_LN_FWD((ln_fwd_reg_kernel<bf16_t, 8>), bf16_t);
+    else if (D <= 1024) S2S_LN_FWD((ln_fwd_reg_kernel<bf16_t, 16>), bf16_t);
+    else S2S_LN_FWD(ln_fwd_kernel<bf16_t>, bf16_t);
+  }
+#undef S2S_LN_FWD
   S2S_CHECK_LAUNCH("ln_fwd_kernel");
   return 0;
 }

@@ -84,6 +84,31 @@ def gemm_linear(dtype):
 
 @case
 @both_dtypes
+def gemm_skinny(dtype):
+    """M <= 64 dense projections (the decode-step shapes) take the weight-streaming kernel; every epilogue option,
+    row counts off the 16-row MFMA tile, N off the 16-column tile, K off the k-step, fp32 output of bf16 inputs."""
+    res = []
+    for (M, N, Kd, seed) in [(1, 384, 384, 1), (16, 1152, 384, 2), (16, 384, 1536, 3), (17, 320, 384, 4), (40, 4, 384, 5),
+                             (64, 100, 264, 6), (3, 37, 40, 7), (16, 1536, 384, 8)]:
+        x, w, b = rnd(M, Kd, seed=seed, dtype=dtype), rnd(N, Kd, seed=seed + 10, dtype=dtype, scale=0.05), rnd(N, seed=seed + 20)
+        r = rnd(M, N, seed=seed + 30, dtype=dtype)
+        out = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm(K.operand(x, Kd), K.operand(w, Kd), M, N, Kd, out, in_dtype=dtype, bias=b, act="relu", res=r, alpha=0.5)
+        ref = torch.relu(0.5 * (x.float() @ w.float().t()) + b) + r.float()
+        res.append(check(f"skinny[{dtype}] {M}x{N}x{Kd} bias+relu+res", out, ref, dtype))
+        out32 = torch.full((M, N), 1.0, dtype=torch.float32, device=DEV)
+        K.gemm(K.operand(x, Kd), K.operand(w, Kd), M, N, Kd, out32, in_dtype=dtype, accumulate=True)
+        res.append(check(f"skinny[{dtype}] {M}x{N}x{Kd} fp32 accumulate", out32, x.float() @ w.float().t() + 1.0, dtype))
+    # strided operands: a column slice of a packed activation (ld > K) against a row slice of a packed weight
+    xp, wp = rnd(16, 3 * 96, seed=40, dtype=dtype), rnd(3 * 64, 96, seed=41, dtype=dtype, scale=0.1)
+    out = torch.empty(16, 64, dtype=dtype, device=DEV)
+    K.gemm(K.operand(xp, 3 * 96, offset=96), K.operand(wp, 96, offset=64 * 96), 16, 64, 96, out, in_dtype=dtype)
+    res.append(check(f"skinny[{dtype}] strided slices", out, xp[:, 96:192].float() @ wp[64:128].float().t(), dtype))
+    return res
+
+
+@case
+@both_dtypes
 def gemm_dgrad_wgrad(dtype):
     res = []
     for (M, N, Kd, seed) in [(100, 70, 80, 1), (2016, 384, 384, 2), (64, 4, 384, 3), (4000, 256, 80, 4)]:
@@ -194,7 +219,7 @@ def gemm_conv2d(dtype):
 @both_dtypes
 def layernorm(dtype):
     res = []
-    for (rows, D, seed) in [(37, 384, 1), (2016, 384, 2), (100, 1536, 3), (9, 50, 4)]:
+    for (rows, D, seed) in [(37, 384, 1), (2016, 384, 2), (100, 1536, 3), (9, 50, 4), (16, 768, 5), (5, 512, 6)]:
         x = rnd(rows, D, seed=seed, dtype=dtype)
         r = rnd(rows, D, seed=seed + 1, dtype=dtype)
         gm, bt = 1 + 0.1 * rnd(D, seed=seed + 2), 0.1 * rnd(D, seed=seed + 3)
