@@ -121,13 +121,14 @@ int s2svc_bn_bwd(int dtype, int64_t rows, int C, const void* dy, const void* x, 
 /* replaces: modules/transformer/attention.py:63-93 (forward_attention), :237-260 / :142-160  */
 /* (rel_shift new / legacy), :278-303 ((ac+bd)/sqrt(d_k)).  rel_mode 0 none, 1 new, 2 legacy. */
 /* ========================================================================================== */
-/* score / probability rows are `ld` >= T2 elements apart (rows padded to a vector multiple); pad columns are written as 0 */
+/* score / probability rows are `ld` >= T2 elements apart (rows padded to a vector multiple); pad columns are written as 0; */
+/* rows of the relative-position term bd / dbd (length Lp) are `ldb` >= Lp elements apart (dbd pad columns are written as 0) */
 int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, int ld, const float* scores, const float* bd, int Lp,
-                           int rel_mode, float scale, const int32_t* klen, int causal, float drop_p,
+                           int ldb, int rel_mode, float scale, const int32_t* klen, int causal, float drop_p,
                            const uint64_t* seed_base, uint64_t seed_off, void* attn, void* pdrop, void* stream);
 int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, int ld, const void* attn, const float* dp, const void* dattn,
                            float scale, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dscores,
-                           void* dbd, int Lp, int rel_mode, void* stream);
+                           void* dbd, int Lp, int ldb, int rel_mode, void* stream);
 
 /* ========================================================================================== */
 /* Elementwise: activations+dropout, positional encodings, head biases, GLU, casts, gathers   */

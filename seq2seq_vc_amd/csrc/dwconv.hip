@@ -29,6 +29,97 @@ __global__ void dwconv_fwd_kernel(int B, int Tn, int C, int ks, int dil, const T
   }
 }
 
+// Vectorised forward: a thread owns VEC consecutive channels and TT consecutive frames of one utterance; the
+// workgroup's weights sit in LDS tap-major.  With dilation 1 the TT + ks - 1 input rows are each loaded once
+// (16 bytes) and scattered into the outputs they touch; other dilations load per (output, tap).
+template <typename T> struct DwVec;
+template <> struct DwVec<bf16_t> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&f)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&f)[8]) {
+    uint4 v;
+    v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+    v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+};
+template <> struct DwVec<float> {
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ void ld(const float* p, float (&f)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&f)[4]) { *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]); }
+};
+
+template <typename T, int TT>
+__global__ __launch_bounds__(256) void dwconv_fwd_vec_kernel(int Tn, int C, int ks, int dil, const T* __restrict__ x,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             T* __restrict__ y, int flip, int tchunks) {
+  constexpr int VEC = DwVec<T>::VEC;
+  constexpr int CT = 8 * VEC;                 // channels per workgroup: 8 vector lanes
+  extern __shared__ float sw[];               // [ks][CT] weights (tap-major), then [CT] bias
+  const int c0 = blockIdx.x * CT;
+  const int b = blockIdx.y / tchunks, tc = blockIdx.y % tchunks;
+  const int pad = (ks - 1) / 2;
+  for (int i = threadIdx.x; i < ks * CT; i += 256) {
+    const int j = i / CT, cl = i % CT;
+    const int c = c0 + cl;
+    sw[i] = c < C ? (flip ? w[c * ks + (ks - 1 - j)] : w[c * ks + j]) : 0.f;
+  }
+  for (int i = threadIdx.x; i < CT; i += 256) sw[ks * CT + i] = (bias && !flip && c0 + i < C) ? bias[c0 + i] : 0.f;
+  __syncthreads();
+  const int vl = threadIdx.x & 7;              // vector lane within the channel tile
+  const int c = c0 + vl * VEC;
+  const int t0 = (tc * 32 + (threadIdx.x >> 3)) * TT;
+  if (c >= C || t0 >= Tn) return;
+  const T* xb = x + (int64_t)b * Tn * C + c;
+  T* yb = y + (int64_t)b * Tn * C + c;
+  float acc[TT][VEC];
+#pragma unroll
+  for (int o = 0; o < TT; ++o)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[o][e] = sw[ks * CT + vl * VEC + e];
+  if (dil == 1) {
+    for (int rr = 0; rr < TT + ks - 1; ++rr) {
+      const int tt = t0 - pad + rr;
+      if (tt < 0 || tt >= Tn) continue;
+      float f[VEC];
+      DwVec<T>::ld(xb + (int64_t)tt * C, f);
+#pragma unroll
+      for (int o = 0; o < TT; ++o) {
+        const int j = rr - o;                  // tap index for output t0+o
+        if (j >= 0 && j < ks) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[o][e] += sw[j * CT + vl * VEC + e] * f[e];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int o = 0; o < TT; ++o) {
+      for (int j = 0; j < ks; ++j) {
+        const int tt = t0 + o + (j - pad) * dil;
+        if (tt < 0 || tt >= Tn || t0 + o >= Tn) continue;
+        float f[VEC];
+        DwVec<T>::ld(xb + (int64_t)tt * C, f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[o][e] += sw[j * CT + vl * VEC + e] * f[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < TT; ++o)
+    if (t0 + o < Tn) DwVec<T>::st(yb + (int64_t)(t0 + o) * C, acc[o]);
+}
+
 // partial dw[chunk][c][j] = sum over the chunk's rows of dy[b,t,c] * x[b, t+(j-pad)*dil, c]
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(int B, int Tn, int C, int ks, int dil, const T* __restrict__ x,
@@ -77,6 +168,19 @@ extern "C" int s2svc_dwconv(int dtype, int B, int Tn, int C, int ks, int dil, co
   if (n == 0) return 0;
   S2S_REQUIRE(ks >= 1 && (ks & 1) && dil >= 1, "dwconv: kernel size must be odd, dilation >= 1");
   hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == S2S_F32 ? 4 : 8;
+  if (C % vec == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && ks <= 63) {
+    constexpr int TT = 4;
+    const int tchunks = (Tn + 32 * TT - 1) / (32 * TT);
+    dim3 grid((C + 8 * vec - 1) / (8 * vec), B * tchunks);
+    const size_t shm = (size_t)(ks + 1) * 8 * vec * sizeof(float);
+    if (dtype == S2S_F32)
+      hipLaunchKernelGGL((dwconv_fwd_vec_kernel<float, TT>), grid, dim3(256), shm, st, Tn, C, ks, dil, (const float*)x, w, bias, (float*)y, flip, tchunks);
+    else
+      hipLaunchKernelGGL((dwconv_fwd_vec_kernel<bf16_t, TT>), grid, dim3(256), shm, st, Tn, C, ks, dil, (const bf16_t*)x, w, bias, (bf16_t*)y, flip, tchunks);
+    S2S_CHECK_LAUNCH("dwconv_fwd_vec_kernel");
+    return 0;
+  }
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tn, C, ks, dil, (const float*)x, w, bias, (float*)y, flip);
   else

@@ -14,6 +14,8 @@
 //   * K-strided ("RC") operands are transposed on their way into LDS, so fragments are always read
 //     as one 16-byte ds_read per 16x(8|4) sub-block.
 #include <stdlib.h>
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/s2svc_hip.h"
 
@@ -355,6 +357,14 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
       }
       return 0;
     }
+  }
+  {  // S2SVC_GEMM_LOG=1: report every problem the specialised kernels declined (tuning aid)
+    static int log = -1;
+    if (log < 0) { const char* e = getenv("S2SVC_GEMM_LOG"); log = (e && e[0] == '1') ? 1 : 0; }
+    if (log == 1)
+      fprintf(stderr, "[s2svc_gemm generic] M=%d N=%d K=%d nb=%dx%d splitk=%d dtype=%d A(layout=%d mode=%d ld=%lld C=%d) B(layout=%d mode=%d ld=%lld C=%d)\n",
+              d.M, d.N, d.K, d.nb0, d.nb1, d.splitk, d.dtype, d.A.layout, d.A.mode, (long long)d.A.ld, d.A.C, d.B.layout, d.B.mode,
+              (long long)d.B.ld, d.B.C);
   }
   const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1 * (d.splitk > 1 ? d.splitk : 1);
   const bool big = tiles128 >= 384 && d.M >= 128 && d.N >= 128;

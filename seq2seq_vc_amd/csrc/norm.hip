@@ -205,17 +205,29 @@ __global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mod
   }
 }
 
-__global__ void colreduce_stage2(int D, int chunks, const float* __restrict__ ws, float scale, float* __restrict__ out_sum,
-                                 float* __restrict__ out_dot, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+// 64 columns x 4 chunk-groups per workgroup: each thread sums every 4th chunk partial (independent loads), the four
+// groups are combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void colreduce_stage2(int D, int chunks, const float* __restrict__ ws, float scale,
+                                                        float* __restrict__ out_sum, float* __restrict__ out_dot, int accumulate) {
+  __shared__ float sh[2][4][64];
+  const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float t0 = 0.f, t1 = 0.f;
-  for (int k = 0; k < chunks; ++k) {
-    t0 += ws[((int64_t)k * 2 + 0) * D + c];
-    t1 += ws[((int64_t)k * 2 + 1) * D + c];
+  if (c < D) {
+    for (int k = kg; k < chunks; k += 4) {
+      t0 += ws[((int64_t)k * 2 + 0) * D + c];
+      t1 += ws[((int64_t)k * 2 + 1) * D + c];
+    }
   }
-  if (out_sum) out_sum[c] = (accumulate ? out_sum[c] : 0.f) + t0 * scale;
-  if (out_dot) out_dot[c] = (accumulate ? out_dot[c] : 0.f) + t1 * scale;
+  sh[0][kg][cl] = t0;
+  sh[1][kg][cl] = t1;
+  __syncthreads();
+  if (kg == 0 && c < D) {
+    t0 = ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl];
+    t1 = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
+    if (out_sum) out_sum[c] = (accumulate ? out_sum[c] : 0.f) + t0 * scale;
+    if (out_dot) out_dot[c] = (accumulate ? out_dot[c] : 0.f) + t1 * scale;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -350,7 +362,7 @@ extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void*
     hipLaunchKernelGGL(colreduce_stage1<bf16_t>, grid, block, 0, st, rows, D, mode, (const bf16_t*)dy, (const bf16_t*)x,
                        mean, rstd, ws, rpc);
   S2S_CHECK_LAUNCH("colreduce_stage1");
-  hipLaunchKernelGGL(colreduce_stage2, dim3((D + 255) / 256), dim3(256), 0, st, D, chunks, ws, scale, out_sum, out_dot,
+  hipLaunchKernelGGL(colreduce_stage2, dim3((D + 63) / 64), dim3(256), 0, st, D, chunks, ws, scale, out_sum, out_dot,
                      accumulate);
   S2S_CHECK_LAUNCH("colreduce_stage2");
   return 0;

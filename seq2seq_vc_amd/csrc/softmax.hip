@@ -24,7 +24,7 @@ __device__ __forceinline__ bool rel_src(int mode, int T1, int i, int j, int& si,
 
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, int T2, int ld, const float* __restrict__ scores,
-                                                          const float* __restrict__ bd, int Lp, int rel_mode, float scale,
+                                                          const float* __restrict__ bd, int Lp, int ldb, int rel_mode, float scale,
                                                           const int32_t* __restrict__ klen, int causal, float p,
                                                           const uint64_t* seed_base, uint64_t seed_off, T* __restrict__ attn, T* __restrict__ pdrop) {
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
   const int b = (int)(bh / H);
   const int kl = klen ? klen[b] : T2;
   const float* srow = scores + row * ld;   // rows are padded to `ld` >= T2 columns (pad columns are written as 0)
-  const float* bdb = bd ? bd + bh * (int64_t)T1 * Lp : nullptr;
+  const float* bdb = bd ? bd + bh * (int64_t)T1 * ldb : nullptr;
   const float NEG = -3.4028234663852886e38f;  // torch.finfo(float32).min
 
   float mx = NEG;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
     float v = srow[j];
     if (bdb) {
       int si, sc;
-      if (rel_src(rel_mode, T1, i, j, si, sc)) v += bdb[(int64_t)si * Lp + sc];
+      if (rel_src(rel_mode, T1, i, j, si, sc)) v += bdb[(int64_t)si * ldb + sc];
     }
     v = ok ? v * scale : NEG;
     mx = fmaxf(mx, v);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
     float v = srow[j];
     if (bdb) {
       int si, sc;
-      if (rel_src(rel_mode, T1, i, j, si, sc)) v += bdb[(int64_t)si * Lp + sc];
+      if (rel_src(rel_mode, T1, i, j, si, sc)) v += bdb[(int64_t)si * ldb + sc];
     }
     v = ok ? v * scale : NEG;
     sum += expf(v - mx);
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
     float v = srow[j];
     if (bdb) {
       int si, sc;
-      if (rel_src(rel_mode, T1, i, j, si, sc)) v += bdb[(int64_t)si * Lp + sc];
+      if (rel_src(rel_mode, T1, i, j, si, sc)) v += bdb[(int64_t)si * ldb + sc];
     }
     v = ok ? v * scale : NEG;
     float pr = ok ? expf(v - mx) * inv : 0.f;  // masked_fill(mask, 0.0) after softmax
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, int T2, int ld, const T* __restrict__ attn,
                                                           const float* __restrict__ dp, const T* __restrict__ dattn, float scale, float p, const uint64_t* seed_base, uint64_t seed_off,
-                                                          T* __restrict__ dscores, T* __restrict__ dbd, int Lp,
+                                                          T* __restrict__ dscores, T* __restrict__ dbd, int Lp, int ldb,
                                                           int rel_mode) {
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
   const int lane = threadIdx.x & 63;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, 
     dot += ldf(attn + o) * (dp[o] * m + (dattn ? ldf(dattn + o) : 0.f));
   }
   dot = wave_sum(dot);
-  T* dbdb = dbd ? dbd + bh * (int64_t)T1 * Lp : nullptr;
+  T* dbdb = dbd ? dbd + bh * (int64_t)T1 * ldb : nullptr;
   for (int j = T2 + lane; j < ld; j += 64) stf(dscores + row * ld + j, 0.f);
   for (int j = lane; j < T2; j += 64) {
     const int64_t o = row * ld + j;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, 
     stf(dscores + o, ds);
     if (dbdb) {
       int si, sc;
-      if (rel_src(rel_mode, T1, i, j, si, sc)) stf(dbdb + (int64_t)si * Lp + sc, ds);
+      if (rel_src(rel_mode, T1, i, j, si, sc)) stf(dbdb + (int64_t)si * ldb + sc, ds);
     }
   }
 }
@@ -127,20 +127,21 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, 
 }  // namespace
 
 extern "C" int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, int ld, const float* scores, const float* bd,
-                                      int Lp, int rel_mode, float scale, const int32_t* klen, int causal, float drop_p,
+                                      int Lp, int ldb, int rel_mode, float scale, const int32_t* klen, int causal, float drop_p,
                                       const uint64_t* seed_base, uint64_t seed_off, void* attn, void* pdrop, void* stream) {
   S2S_REQUIRE(B >= 0 && H > 0 && T1 >= 0 && T2 > 0 && ld >= T2, "attn_softmax_fwd: bad shape");
   S2S_REQUIRE(!bd || (rel_mode == 1 && Lp == 2 * T1 - 1 && T1 == T2) || (rel_mode == 2 && Lp == T1 && T1 == T2),
               "attn_softmax_fwd: bad relative-position shape");
+  S2S_REQUIRE(!bd || ldb >= Lp, "attn_softmax_fwd: bd row stride smaller than its length");
   const int64_t nrows = (int64_t)B * H * T1;
   if (nrows == 0) return 0;
   dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, ld, scores, bd, Lp, rel_mode, scale, klen,
+    hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, ld, scores, bd, Lp, ldb, rel_mode, scale, klen,
                        causal, drop_p, seed_base, seed_off, (float*)attn, (float*)pdrop);
   else
-    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, ld, scores, bd, Lp, rel_mode, scale, klen,
+    hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, ld, scores, bd, Lp, ldb, rel_mode, scale, klen,
                        causal, drop_p, seed_base, seed_off, (bf16_t*)attn, (bf16_t*)pdrop);
   S2S_CHECK_LAUNCH("softmax_fwd_kernel");
   return 0;
@@ -148,14 +149,14 @@ extern "C" int s2svc_attn_softmax_fwd(int dtype, int B, int H, int T1, int T2, i
 
 extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, int ld, const void* attn, const float* dp, const void* dattn,
                                       float scale, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dscores, void* dbd, int Lp,
-                                      int rel_mode, void* stream) {
-  S2S_REQUIRE(B >= 0 && H > 0 && T1 >= 0 && T2 > 0, "attn_softmax_bwd: bad shape");
+                                      int ldb, int rel_mode, void* stream) {
+  S2S_REQUIRE(B >= 0 && H > 0 && T1 >= 0 && T2 > 0 && (!dbd || ldb >= Lp), "attn_softmax_bwd: bad shape");
   const int64_t nrows = (int64_t)B * H * T1;
   if (nrows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = dtype == S2S_F32 ? 4 : 2;
   if (dbd) {
-    if (hipMemsetAsync(dbd, 0, (size_t)B * H * T1 * Lp * esz, st) != hipSuccess) {
+    if (hipMemsetAsync(dbd, 0, (size_t)B * H * T1 * ldb * esz, st) != hipSuccess) {
       s2svc_set_error("attn_softmax_bwd: memset failed");
       return -2;
     }
@@ -163,10 +164,10 @@ extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, i
   dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, block, 0, st, B, H, T1, T2, ld, (const float*)attn, dp, (const float*)dattn, scale, drop_p,
-                       seed_base, seed_off, (float*)dscores, (float*)dbd, Lp, rel_mode);
+                       seed_base, seed_off, (float*)dscores, (float*)dbd, Lp, ldb, rel_mode);
   else
     hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, block, 0, st, B, H, T1, T2, ld, (const bf16_t*)attn, dp, (const bf16_t*)dattn, scale,
-                       drop_p, seed_base, seed_off, (bf16_t*)dscores, (bf16_t*)dbd, Lp, rel_mode);
+                       drop_p, seed_base, seed_off, (bf16_t*)dscores, (bf16_t*)dbd, Lp, ldb, rel_mode);
   S2S_CHECK_LAUNCH("softmax_bwd_kernel");
   return 0;
 }

@@ -401,7 +401,7 @@ def _pad_like(dattn, ref):
     return out
 
 
-def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, rel_mode=0, outs=None):
+def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, rel_mode=0, outs=None, ldb=None):
     """Backward of softmax(QK^T)V.  attn/pm: padded (B,H,T1,ld) tensors; q/k/v may be column slices of packed
     tensors; `outs` = (dq, dk, dv) views to write into (e.g. slices of a packed gradient), allocated when None."""
     B, T1, D = q.shape
@@ -417,7 +417,8 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
     dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
     # dV[b,j,hd] = sum_i pm[b,h,i,j] dctx[b,i,hd]
     _into(dv, _pop(pm, T1, H, K.RC), _bop(dctx, dk, K.RC), T2, dk, T1, dk, dtype, B, H)
-    ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode, dattn=_pad_like(dattn, attn), T2=T2)
+    ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode, dattn=_pad_like(dattn, attn), T2=T2,
+                                 ldb=ldb)
     # dQ[b,i,hd] = sum_j dS[b,h,i,j] k[b,j,hd]
     _into(dq, _pop(ds, T1, H), _bop(k, dk, K.RC), T1, dk, T2, dk, dtype, B, H)
     # dK[b,j,hd] = sum_i dS[b,h,i,j] q[b,i,hd]
@@ -539,10 +540,12 @@ class _RelAttnCore(Function):
         scale = 1.0 / math.sqrt(dk)
         seed = K.new_seed(qu.device) if p > 0.0 else (None, 0)
         ac = _qk(qu, k, B, H, T, T, dk, D, dtype)
-        bd = torch.empty((B, H, T, L), dtype=torch.float32, device=qu.device)
+        Lq = _pad8(L)                 # bd / dbd rows padded to 16 bytes (2T-1 is odd) so the backward GEMMs vectorise
+        bd = torch.empty((B, H, T, Lq), dtype=torch.float32, device=qu.device)
         K.gemm(K.operand(qv, D, bs0=T * D, bs1=dk), K.operand(pos, D, bs0=0, bs1=dk), T, L, dk, bd, in_dtype=dtype, nb0=B, nb1=H,
-               cbs=(H * T * L, T * L))
-        attn, pdrop = K.attn_softmax_fwd(ac, dtype, scale, klen=klen, causal=False, bd=bd, rel_mode=rel_mode, p=p, seed=seed, T2=T)
+               ldc=Lq, cbs=(H * T * Lq, T * Lq))
+        attn, pdrop = K.attn_softmax_fwd(ac, dtype, scale, klen=klen, causal=False, bd=bd, rel_mode=rel_mode, p=p, seed=seed, T2=T,
+                                         Lp=L)
         pm = pdrop if pdrop is not None else attn
         out = _pv(pm, v, B, H, T, T, dk, D, dtype)
         ctx.meta = (H, scale, p, seed, rel_mode, L)
@@ -558,15 +561,16 @@ class _RelAttnCore(Function):
         dk = D // H
         dtype = qu.dtype
         pm = pdrop if pdrop is not None else attn
-        dqu, dkk, dv, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, v, H, scale, p, seed, Lp=L, rel_mode=rel_mode)
+        Lq = _pad8(L)
+        dqu, dkk, dv, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, v, H, scale, p, seed, Lp=L, rel_mode=rel_mode, ldb=Lq)
         # dQv[b,i,hd] = sum_c dbd[b,h,i,c] pos[c,hd]
         dqv = torch.empty((B, T, D), dtype=dtype, device=qu.device)
-        K.gemm(K.operand(dbd, L, bs0=H * T * L, bs1=T * L), K.operand(pos, D, layout=K.RC, bs0=0, bs1=dk), T, dk, L, dqv,
-               in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T * D, dk))
+        K.gemm(K.operand(dbd, Lq, bs0=H * T * Lq, bs1=T * Lq, zero_padded=True), K.operand(pos, D, layout=K.RC, bs0=0, bs1=dk), T, dk,
+               L, dqv, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T * D, dk))
         # dPos[c,hd] = sum_{b,i} dbd[b,h,i,c] qv[b,i,hd]  (per-batch partials, then a deterministic sum over b)
         part = torch.empty((B, L, D), dtype=dtype, device=qu.device)
-        K.gemm(K.operand(dbd, L, layout=K.RC, bs0=H * T * L, bs1=T * L), K.operand(qv, D, layout=K.RC, bs0=T * D, bs1=dk), L, dk,
-               T, part, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(L * D, dk))
+        K.gemm(K.operand(dbd, Lq, layout=K.RC, bs0=H * T * Lq, bs1=T * Lq, zero_padded=True),
+               K.operand(qv, D, layout=K.RC, bs0=T * D, bs1=dk), L, dk, T, part, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(L * D, dk))
         dpos, _ = K.colreduce(0, part.view(B, L * D))
         dpos = K.cast(dpos.view(1, L, D), dtype)
         return dqu, dqv, dkk, dv, dpos, None, None, None, None

@@ -246,26 +246,31 @@ def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats=True):
 # ----------------------------------------------------------------------------------------------
 # attention probabilities
 # ----------------------------------------------------------------------------------------------
-def attn_softmax_fwd(scores, out_dtype, scale, klen=None, causal=False, bd=None, rel_mode=0, p=0.0, seed=(None, 0), T2=None):
-    """scores: fp32 (B, H, T1, ld) with ld >= T2 (rows padded to a vector multiple); outputs share that layout."""
+def attn_softmax_fwd(scores, out_dtype, scale, klen=None, causal=False, bd=None, rel_mode=0, p=0.0, seed=(None, 0), T2=None,
+                     Lp=None):
+    """scores: fp32 (B, H, T1, ld) with ld >= T2 (rows padded to a vector multiple); outputs share that layout.
+    bd: fp32 (B, H, T1, ldb) relative-position term whose rows hold Lp <= ldb values."""
     B, H, T1, ld = scores.shape
     T2 = ld if T2 is None else T2
     attn = torch.empty(scores.shape, dtype=out_dtype, device=scores.device)
     pdrop = torch.empty_like(attn) if p > 0.0 else None
-    Lp = bd.shape[-1] if bd is not None else 0
-    _lib.check(_lib.lib().s2svc_attn_softmax_fwd(_DT[out_dtype], B, H, T1, T2, ld, ptr(scores), ptr(bd), Lp, rel_mode, scale,
+    ldb = bd.shape[-1] if bd is not None else 0
+    Lp = ldb if Lp is None else Lp
+    _lib.check(_lib.lib().s2svc_attn_softmax_fwd(_DT[out_dtype], B, H, T1, T2, ld, ptr(scores), ptr(bd), Lp, ldb, rel_mode, scale,
                                                  ptr(klen), 1 if causal else 0, p, seed[0], seed[1], ptr(attn), ptr(pdrop),
                                                  stream()), "attn_softmax_fwd")
     return attn, pdrop
 
 
-def attn_softmax_bwd(attn, dp, scale, p=0.0, seed=(None, 0), Lp=0, rel_mode=0, dattn=None, T2=None):
+def attn_softmax_bwd(attn, dp, scale, p=0.0, seed=(None, 0), Lp=0, rel_mode=0, dattn=None, T2=None, ldb=None):
+    """Returns (dscores, dbd); dbd is (B, H, T1, ldb) with columns >= Lp zero (ldb defaults to Lp)."""
     B, H, T1, ld = attn.shape
     T2 = ld if T2 is None else T2
+    ldb = Lp if ldb is None else ldb
     dscores = torch.empty_like(attn)
-    dbd = torch.empty((B, H, T1, Lp), dtype=attn.dtype, device=attn.device) if Lp else None
+    dbd = torch.empty((B, H, T1, ldb), dtype=attn.dtype, device=attn.device) if Lp else None
     _lib.check(_lib.lib().s2svc_attn_softmax_bwd(dt(attn), B, H, T1, T2, ld, ptr(attn), ptr(dp), ptr(dattn), scale, p, seed[0],
-                                                 seed[1], ptr(dscores), ptr(dbd), Lp, rel_mode, stream()), "attn_softmax_bwd")
+                                                 seed[1], ptr(dscores), ptr(dbd), Lp, ldb, rel_mode, stream()), "attn_softmax_bwd")
     return dscores, dbd
 
 

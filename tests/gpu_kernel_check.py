@@ -353,6 +353,16 @@ def attn_softmax(dtype):
         dsc, dbd = K.attn_softmax_bwd(attn, dp, scale, Lp=Lp, rel_mode=mode)
         res.append(check(f"softmax relpos{mode} dac[{dtype}]", dsc, acr.grad, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
         res.append(check(f"softmax relpos{mode} dbd[{dtype}]", dbd, bdr.grad, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
+        # bd / dbd rows padded to a multiple of 8 (ldb > Lp): garbage in the bd pad, zeros expected in the dbd pad
+        ldb = (Lp + 7) // 8 * 8 + 8
+        bdp = torch.full((B, H, T, ldb), 1e30, dtype=torch.float32, device=DEV)
+        bdp[..., :Lp] = bd
+        attn_p, _ = K.attn_softmax_fwd(ac, dtype, scale, klen=kl, bd=bdp, rel_mode=mode, Lp=Lp)
+        res.append(check(f"softmax relpos{mode} fwd padded bd[{dtype}]", attn_p, attn, dtype, atol=0.0, rtol=0.0))
+        dsc_p, dbd_p = K.attn_softmax_bwd(attn, dp, scale, Lp=Lp, rel_mode=mode, ldb=ldb)
+        res.append(check(f"softmax relpos{mode} dbd padded[{dtype}]", dbd_p[..., :Lp], dbd, dtype, atol=0.0, rtol=0.0))
+        res.append(check(f"softmax relpos{mode} dbd pad zero[{dtype}]", dbd_p[..., Lp:].float(),
+                         torch.zeros_like(dbd_p[..., Lp:]).float(), torch.float32, atol=0.0))
     return res
 
 

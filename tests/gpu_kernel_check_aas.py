@@ -27,7 +27,8 @@ def case(fn):
 @both_dtypes
 def depthwise_conv(dtype):
     res = []
-    for (B, T, C, ks, dil, seed) in [(3, 50, 48, 7, 1, 1), (2, 64, 96, 15, 1, 2), (2, 40, 32, 3, 3, 3), (2, 40, 32, 3, 9, 4), (1, 33, 130, 31, 1, 5)]:
+    for (B, T, C, ks, dil, seed) in [(3, 50, 48, 7, 1, 1), (2, 64, 96, 15, 1, 2), (2, 40, 32, 3, 3, 3), (2, 40, 32, 3, 9, 4), (1, 33, 130, 31, 1, 5),
+                                      (2, 300, 384, 15, 1, 6), (1, 5, 64, 3, 1, 7), (2, 131, 72, 3, 3, 8)]:
         x = rnd(B, T, C, seed=seed, dtype=dtype)
         w = rnd(C, 1, ks, seed=seed + 1, scale=0.3)
         b = rnd(C, seed=seed + 2)
