@@ -102,7 +102,7 @@ int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, const void* r
 int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, const void* s, const float* mean, const float* rstd,
                         const float* gamma, const void* ds_extra, float drop_p, float hscale, const uint64_t* seed_base,
                         uint64_t seed_off, void* ds, void* dh, void* stream);
-/* chunked column reductions over (rows, D); modes 0..4 see csrc/norm.hip; ws >= ws_chunks*2*D floats */
+/* chunked column reductions over (rows, D); modes 0..5 see csrc/norm.hip (5: sum dy, sum dy*v[r] with v in `mean`); ws >= ws_chunks*2*D floats */
 int s2svc_colreduce(int dtype, int rows, int D, int mode, const void* dy, const void* x, const float* mean,
                     const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate, float* ws,
                     int ws_chunks, void* stream);
@@ -210,6 +210,50 @@ int64_t s2svc_forward_sum_ws_bytes(int B, int Tf, int Tx);
 int s2svc_forward_sum(int B, int Tf, int Tx, const float* log_p_attn, const float* prior, const int32_t* text_lens,
                       const int32_t* feat_lens, float log_blank, void* ws, float* loss_b, float* grad, void* stream);
 int s2svc_betabinom_prior(int B, int Tf, int Tx, const int32_t* text_lens, const int32_t* feat_lens, float* prior,
+                          void* stream);
+
+/* ========================================================================================== */
+/* Stochastic duration predictor (VITS flows), channel-last rows r=(b,t), mask = t < lens[b]   */
+/* replaces: modules/duration_predictor.py:211-304, modules/vits/flow.py:18-310,               */
+/* modules/vits/transform.py:17-216.  Spline / glue stages are fp32.                           */
+/* ========================================================================================== */
+int s2svc_mask_rows(int dtype, int B, int T, int C, const void* x, const int32_t* lens, void* y, void* stream);
+/* Conv1d(1->C,k=1) + conditioning, masked: y[r,c] = mask*(a[r]*w[c] + bias[c] + g[r,c])   (flow.py:290-292) */
+int s2svc_expand_fwd(int dtype, int B, int T, int C, const float* a, const float* w, const float* bias, const void* g,
+                     const int32_t* lens, void* y, void* stream);
+/* dg = mask*dy ; da[r] = sum_c dg[r,c]*w[c]   (dw, dbias: s2svc_colreduce mode 5 over dg with v = a) */
+int s2svc_expand_bwd(int dtype, int B, int T, int C, const void* dy, const float* w, const int32_t* lens, void* dg, float* da,
+                     void* stream);
+/* y = mask*(res + dropout(act(LayerNorm(x))))   (one DDS half-layer, flow.py:148-190); res / lens optional, D <= 1024 */
+int s2svc_ln_act_fwd(int dtype, int rows, int D, int T, const void* x, const float* gamma, const float* beta, float eps, int act,
+                     const void* res, const int32_t* lens, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y,
+                     float* mean, float* rstd, void* stream);
+/* du = gradient at the LayerNorm output (feeds dgamma/dbeta via colreduce mode 1), dx = LN input grad, dres = mask*dy */
+int s2svc_ln_act_bwd(int dtype, int rows, int D, int T, const void* dy, const void* x, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int act, const int32_t* lens, float drop_p,
+                     const uint64_t* seed_base, uint64_t seed_off, void* du, void* dx, void* dres, void* stream);
+/* rational-quadratic spline coupling with linear tails; h (rows, 3*bins-1); lad accumulates when asked (transform.py:96-216) */
+int s2svc_rq_spline_fwd(int B, int T, int bins, const float* x, const float* h, float hscale, float bound, const int32_t* lens,
+                        int inverse, float* out, float* lad, int lad_accumulate, void* stream);
+/* g_lad: (B) gradient shared by all rows of an utterance (the log-dets are summed over t) */
+int s2svc_rq_spline_bwd(int B, int T, int bins, const float* x, const float* h, float hscale, float bound, const int32_t* lens,
+                        const float* g_out, const float* g_lad, float* dx, float* dh, void* stream);
+/* glue: noise -> first affine flow | dequantise + log flow + affine | per-utterance NLL (duration_predictor.py:239-280) */
+int s2svc_sdp_head_fwd(int B, int T, const float* noise, const int32_t* lens, const float* m, const float* logs, float* z0,
+                       float* z1, void* stream);
+int s2svc_sdp_head_bwd(int B, int T, const float* noise, const int32_t* lens, const float* logs, const float* dz0,
+                       const float* dz1, float* part, void* stream);
+int s2svc_sdp_mid_fwd(int B, int T, const float* zu, const float* z1, const float* w, const int32_t* lens, const float* m,
+                      const float* logs, float* y0, float* y1, float* lz, void* stream);
+int s2svc_sdp_mid_bwd(int B, int T, const float* zu, const float* z1, const float* w, const int32_t* lens, const float* logs,
+                      const float* dy0, const float* dy1, const float* dlz, float* dzu, float* dz1, float* part, void* stream);
+int s2svc_sdp_tail_fwd(int B, int T, const float* noise, const int32_t* lens, const float* zu, const float* lz,
+                       const float* lad_q, const float* lad_p, const float* af, const float* bf, const float* logs_q,
+                       const float* logs_p, float* out, void* stream);
+int s2svc_sdp_tail_bwd(int B, int T, const float* g, const int32_t* lens, const float* zu, const float* af, const float* bf,
+                       float* d_af, float* d_bf, float* d_lz, float* d_zu, float* neg_g, float* part, void* stream);
+/* inference read-out: dur = ceil(exp((a - m0)*exp(-logs0)))*mask   (duration_predictor.py:300-304) */
+int s2svc_sdp_inverse_out(int B, int T, const float* a, const int32_t* lens, const float* m, const float* logs, float* dur,
                           void* stream);
 
 /* ========================================================================================== */

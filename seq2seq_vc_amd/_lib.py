@@ -114,6 +114,22 @@ _SIGS = {
     "s2svc_betabinom_prior": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_conv_in1_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_conv_in1_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
+    "s2svc_mask_rows": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_expand_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_expand_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_ln_act_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp,
+                         c_vp, c_vp],
+    "s2svc_ln_act_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_u64, c_vp,
+                         c_vp, c_vp, c_vp],
+    "s2svc_rq_spline_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp],
+    "s2svc_rq_spline_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_sdp_head_fwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_sdp_head_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_sdp_mid_fwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_sdp_mid_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_sdp_tail_fwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_sdp_tail_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_sdp_inverse_out": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_decode_posenc": [c_i32, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_decode_attn": [c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32,
                           c_f32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp],

@@ -189,6 +189,10 @@ __global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mod
       } else if (mode == 3) {
         float dv = ldf(x + o) - mc;
         s0 += dv * dv;
+      } else if (mode == 5) {          // s0 = sum dy ; s1 = sum dy * v[r]  (v handed in through `mean`)
+        float g = ldf(dy + o);
+        s0 += g;
+        s1 += g * mean[r];
       } else {
         s0 += ldf(dy + o) * ldf(x + o);
       }
@@ -348,7 +352,7 @@ extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void*
                                const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate,
                                float* ws, int ws_chunks, void* stream) {
   S2S_REQUIRE(rows >= 0 && D > 0 && ws && ws_chunks > 0, "colreduce: bad args");
-  S2S_REQUIRE(mode >= 0 && mode <= 4, "colreduce: bad mode");
+  S2S_REQUIRE(mode >= 0 && mode <= 5, "colreduce: bad mode");
   hipStream_t st = (hipStream_t)stream;
   int chunks = (rows + 63) / 64;
   if (chunks > ws_chunks) chunks = ws_chunks;

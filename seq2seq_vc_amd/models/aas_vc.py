@@ -187,8 +187,8 @@ class AASVC(nn.Module):
                 log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c)
                 ds, bin_loss = self.viterbi_func(log_p_attn, il_c, olr)
             if stochastic:
-                d_outs = self.duration_predictor(dpi.transpose(1, 2), tmask.unsqueeze(1), inverse=True,
-                                                 noise_scale=self.stochastic_duration_predictor_noise_scale).squeeze(1)
+                d_outs = self.duration_predictor.forward_cl(dpi, il_c, inverse=True,
+                                                            noise_scale=self.stochastic_duration_predictor_noise_scale)
             else:
                 d_outs = self.duration_predictor.inference(dpi, None)
             d_outs = torch.clamp(d_outs, max=MAX_DP_OUTPUT)
@@ -204,7 +204,7 @@ class AASVC(nn.Module):
             log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c)
             ds, bin_loss = self.viterbi_func(log_p_attn, il_c, olr)
             if stochastic:
-                dur_nll = self.duration_predictor(dpi.transpose(1, 2), tmask.unsqueeze(1), w=ds.unsqueeze(1))
+                dur_nll = self.duration_predictor.forward_cl(dpi, il_c, w=ds)
                 ret["dur_nll"] = dur_nll / torch.sum(tmask)
             else:
                 d_outs = self.duration_predictor(dpi, il_c)

@@ -2,19 +2,22 @@
 
 * `DurationPredictor` (reference modules/duration_predictor.py:27-128) runs on the HIP kernels.
 * `StochasticDurationPredictor` (VITS flows; reference modules/duration_predictor.py:131-304,
-  modules/vits/flow.py, modules/vits/transform.py) is ~200 launch-bound micro-ops on (B, 2..384, T_text<=64)
-  tensors.  ROUND-1 STATUS: its arithmetic is expressed with stock torch GPU ops (fp32) -- the one part of
-  the hot path not yet on hand-written kernels (SURVEY 2b K13 "leave on ATen initially"; DESIGN.md lists it
-  as open).  The noise draw is injectable so parity with the reference is exact in distribution AND value.
+  modules/vits/flow.py, modules/vits/transform.py) runs on csrc/sdp.hip (fused LayerNorm+GELU(+dropout+residual+
+  mask), rank-1 expansion, rational-quadratic spline forward / inverse / backward, fused NLL glue) plus the shared
+  GEMM and depthwise-conv kernels, in fp32.  The noise draw (torch.randn on the device, as the reference) is
+  injectable so parity with the reference is exact in distribution AND value.
 """
 import math
 
 import torch
-import torch.nn.functional as TF
 from torch import nn
 
 from . import modules as Mo
 from .ops import functional as Fn
+from .ops import functional_aas as FA
+from .ops import functional_sdp as FS
+from .ops import kernels as K
+from .ops import kernels_sdp as KS
 
 
 class DurationPredictor(nn.Module):
@@ -54,20 +57,24 @@ class DurationPredictor(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# VITS flow pieces (state_dict-compatible holders; forward in torch ops, fp32)
+# VITS flow pieces: state_dict-compatible parameter holders; the arithmetic is csrc/sdp.hip + the shared GEMM /
+# depthwise-conv kernels.  Everything is channel-last rows (B, T, C) in fp32 (the log-determinants of the flows
+# are sums of many small terms; the reference computes them in fp32 as well).
 # ---------------------------------------------------------------------------------------------------------
 class _Transpose(nn.Module):
+    """Placeholder keeping the reference's Sequential indices (flow.py:137-160); layout changes are free here."""
+
     def __init__(self, d1, d2):
         super().__init__()
         self.d1, self.d2 = d1, d2
 
-    def forward(self, x):
-        return x.transpose(self.d1, self.d2)
-
 
 class DilatedDepthSeparableConv(nn.Module):
+    """flow.py:110-190: per layer  x = (x + dropout(gelu(LN(conv1x1(gelu(LN(dwconv_dilated(x*mask)))))))) ; final * mask."""
+
     def __init__(self, channels, kernel_size, layers, dropout_rate=0.0, eps=1e-5):
         super().__init__()
+        self.dropout_rate = dropout_rate
         self.convs = nn.ModuleList()
         for i in range(layers):
             dilation = kernel_size ** i
@@ -79,65 +86,27 @@ class DilatedDepthSeparableConv(nn.Module):
                 _Transpose(1, 2), nn.LayerNorm(channels, eps=eps, elementwise_affine=True), _Transpose(1, 2), nn.GELU(),
                 nn.Dropout(dropout_rate))]
 
-    def forward(self, x, x_mask, g=None):
-        if g is not None:
-            x = x + g
-        for f in self.convs:
-            x = x + f(x * x_mask)
-        return x * x_mask
-
-
-def _rq_spline(x, uw, uh, ud, inverse, bound=5.0, min_w=1e-3, min_h=1e-3, min_d=1e-3):
-    nb = uw.shape[-1]
-    inside = (x >= -bound) & (x <= bound)
-    const = math.log(math.exp(1 - min_d) - 1)
-    ud = TF.pad(ud, (1, 1))
-    ud[..., 0] = const
-    ud[..., -1] = const
-    xin = torch.where(inside, x, torch.zeros_like(x))
-
-    def knots(u, mn):
-        s = mn + (1 - mn * nb) * TF.softmax(u, dim=-1)
-        cs = TF.pad(torch.cumsum(s, dim=-1), (1, 0), value=0.0)
-        cs = 2 * bound * cs - bound
-        cs[..., 0] = -bound
-        cs[..., -1] = bound
-        return cs, cs[..., 1:] - cs[..., :-1]
-
-    cw, w = knots(uw, min_w)
-    ch, h = knots(uh, min_h)
-    d = min_d + TF.softplus(ud)
-    loc = (ch if inverse else cw).detach().clone()
-    loc[..., -1] += 1e-6
-    idx = (torch.sum(xin[..., None] >= loc, dim=-1) - 1)[..., None]
-    pick = lambda a: a.gather(-1, idx)[..., 0]
-    in_cw, in_w, in_ch, in_h = pick(cw), pick(w), pick(ch), pick(h)
-    delta = h / w
-    in_delta, in_d, in_d1 = pick(delta), pick(d), pick(d[..., 1:])
-    if inverse:
-        a = (xin - in_ch) * (in_d + in_d1 - 2 * in_delta) + in_h * (in_delta - in_d)
-        b = in_h * in_d - (xin - in_ch) * (in_d + in_d1 - 2 * in_delta)
-        c = -in_delta * (xin - in_ch)
-        root = (2 * c) / (-b - torch.sqrt(b.pow(2) - 4 * a * c))
-        out = root * in_w + in_cw
-        tt = root * (1 - root)
-        den = in_delta + (in_d + in_d1 - 2 * in_delta) * tt
-        num = in_delta.pow(2) * (in_d1 * root.pow(2) + 2 * in_delta * tt + in_d * (1 - root).pow(2))
-        lad = -(torch.log(num) - 2 * torch.log(den))
-    else:
-        th = (xin - in_cw) / in_w
-        tt = th * (1 - th)
-        den = in_delta + (in_d + in_d1 - 2 * in_delta) * tt
-        out = in_ch + in_h * (in_delta * th.pow(2) + in_d * tt) / den
-        num = in_delta.pow(2) * (in_d1 * th.pow(2) + 2 * in_delta * tt + in_d * (1 - th).pow(2))
-        lad = torch.log(num) - 2 * torch.log(den)
-    return torch.where(inside, out, x), torch.where(inside, lad, torch.zeros_like(lad))
+    def forward(self, x, lens):
+        """x (B, T, C), already zero past each utterance (so x == x*mask at every layer input) -> same, masked."""
+        T = x.shape[1]
+        p = self.dropout_rate if self.training else 0.0
+        for blk in self.convs:
+            dw, ln1, pw, ln2 = blk[0], blk[2], blk[5], blk[7]
+            y = FA.dwconv1d(x, dw.weight, dw.bias, dilation=dw.dilation[0])
+            y = FS.ln_act(y, ln1.weight, ln1.bias, ln1.eps, "gelu")
+            y = Fn.linear(y, pw.weight, pw.bias)
+            x = FS.ln_act(y, ln2.weight, ln2.bias, ln2.eps, "gelu", res=x, lens=lens, T=T, p=p)
+        return x
 
 
 class ConvFlow(nn.Module):
+    """flow.py:250-310: (xa, xb) -> (xa, RQ-spline(xb | DDS(input_conv(xa) + g)))."""
+
     def __init__(self, in_channels, hidden_channels, kernel_size, layers, bins=10, tail_bound=5.0):
         super().__init__()
         self.half_channels = in_channels // 2
+        if self.half_channels != 1:
+            raise NotImplementedError("ConvFlow is built for 2-channel flows (the duration predictor's)")
         self.hidden_channels, self.bins, self.tail_bound = hidden_channels, bins, tail_bound
         self.input_conv = nn.Conv1d(self.half_channels, hidden_channels, 1)
         self.dds_conv = DilatedDepthSeparableConv(hidden_channels, kernel_size, layers, dropout_rate=0.0)
@@ -145,49 +114,45 @@ class ConvFlow(nn.Module):
         self.proj.weight.data.zero_()
         self.proj.bias.data.zero_()
 
-    def forward(self, x, x_mask, g=None, inverse=False):
-        xa, xb = x.split(x.size(1) // 2, 1)
-        h = self.dds_conv(self.input_conv(xa), x_mask, g=g)
-        h = self.proj(h) * x_mask
-        b, c, t = xa.shape
-        h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)
-        den = math.sqrt(self.hidden_channels)
-        xb, lad = _rq_spline(xb, h[..., : self.bins] / den, h[..., self.bins: 2 * self.bins] / den, h[..., 2 * self.bins:],
-                             inverse, self.tail_bound)
-        x = torch.cat([xa, xb], 1) * x_mask
-        return (x, torch.sum(lad * x_mask, [1, 2])) if not inverse else x
+    def params(self, xa, g, lens):
+        h = FS.expand(xa, self.input_conv.weight, self.input_conv.bias, g, lens)
+        h = self.dds_conv(h, lens)
+        return Fn.linear(h, self.proj.weight, self.proj.bias)                 # (B, T, 3*bins-1); masked inside the spline
+
+    def forward(self, xa, xb, g, lens, shared, which):
+        h = self.params(xa, g, lens)
+        return FS.spline(xb, h, 1.0 / math.sqrt(self.hidden_channels), self.tail_bound, lens, shared, which)
+
+    def inverse(self, xa, xb, g, lens):
+        h = self.params(xa, g, lens)
+        out, _ = KS.rq_spline_fwd(xb.contiguous(), h.contiguous(), 1.0 / math.sqrt(self.hidden_channels), self.tail_bound, lens,
+                                  inverse=True)
+        return out
 
 
 class ElementwiseAffineFlow(nn.Module):
+    """flow.py:66-93 (parameter holder; applied inside the fused glue kernels)."""
+
     def __init__(self, channels):
         super().__init__()
         self.channels = channels
         self.register_parameter("m", nn.Parameter(torch.zeros(channels, 1)))
         self.register_parameter("logs", nn.Parameter(torch.zeros(channels, 1)))
 
-    def forward(self, x, x_mask, inverse=False, **kwargs):
-        if not inverse:
-            return (self.m + torch.exp(self.logs) * x) * x_mask, torch.sum(self.logs * x_mask, [1, 2])
-        return (x - self.m) * torch.exp(-self.logs) * x_mask
-
 
 class FlipFlow(nn.Module):
-    def forward(self, x, *args, inverse=False, **kwargs):
-        x = torch.flip(x, [1])
-        return (x, x.new_zeros(x.size(0))) if not inverse else x
+    """flow.py:18-34: channel flip == swapping the two (B, T) halves, free."""
 
 
 class LogFlow(nn.Module):
-    def forward(self, x, x_mask, inverse=False, eps=1e-5, **kwargs):
-        if not inverse:
-            y = torch.log(torch.clamp_min(x, eps)) * x_mask
-            return y, torch.sum(-y, [1, 2])
-        return torch.exp(x) * x_mask
+    """flow.py:37-63 (inside the mid glue kernel)."""
 
 
 class StochasticDurationPredictor(nn.Module):
     def __init__(self, channels=192, kernel_size=3, dropout_rate=0.5, flows=4, dds_conv_layers=3, global_channels=-1):
         super().__init__()
+        if global_channels > 0:
+            raise NotImplementedError("global conditioning is not used by AAS-VC (aas_vc.py:186: global_channels=-1)")
         self.pre = nn.Conv1d(channels, channels, 1)
         self.dds = DilatedDepthSeparableConv(channels, kernel_size, layers=dds_conv_layers, dropout_rate=dropout_rate)
         self.proj = nn.Conv1d(channels, channels, 1)
@@ -201,50 +166,67 @@ class StochasticDurationPredictor(nn.Module):
         self.post_flows = nn.ModuleList([ElementwiseAffineFlow(2)])
         for _ in range(flows):
             self.post_flows += [ConvFlow(2, channels, kernel_size, layers=dds_conv_layers), FlipFlow()]
-        if global_channels > 0:
-            self.global_conv = nn.Conv1d(global_channels, channels, 1)
         self.noise = None   # set to a (B, 2, T) tensor to inject the draw (parity tests); consumed once
 
     def _randn(self, shape, device):
         if self.noise is not None:
-            n, self.noise = self.noise.to(device=device, dtype=torch.float32), None
+            n, self.noise = self.noise.to(device=device, dtype=torch.float32).contiguous(), None
             return n
         return torch.randn(shape, device=device, dtype=torch.float32)
 
-    def forward(self, x, x_mask, w=None, g=None, inverse=False, noise_scale=1.0):
-        """x (B, C, T) (detached: no gradient to the encoder), x_mask (B,1,T), w (B,1,T) -> NLL (B,) or durations."""
-        x = x.detach().float()
-        x_mask = x_mask.float()
-        x = self.pre(x)
-        if g is not None:
-            x = x + self.global_conv(g.detach())
-        x = self.dds(x, x_mask)
-        x = self.proj(x) * x_mask
-        if not inverse:
-            assert w is not None, "w must be provided."
-            w = w.float()
-            h_w = self.post_proj(self.post_dds(self.post_pre(w), x_mask)) * x_mask
-            e_q = self._randn((w.size(0), 2, w.size(2)), x.device) * x_mask
-            z_q, logdet_tot_q = e_q, 0.0
-            for flow in self.post_flows:
-                z_q, logdet_q = flow(z_q, x_mask, g=(x + h_w))
-                logdet_tot_q = logdet_tot_q + logdet_q
-            z_u, z1 = torch.split(z_q, [1, 1], 1)
-            u = torch.sigmoid(z_u) * x_mask
-            z0 = (w - u) * x_mask
-            logdet_tot_q = logdet_tot_q + torch.sum((TF.logsigmoid(z_u) + TF.logsigmoid(-z_u)) * x_mask, [1, 2])
-            logq = torch.sum(-0.5 * (math.log(2 * math.pi) + (e_q ** 2)) * x_mask, [1, 2]) - logdet_tot_q
-            z0, logdet_tot = self.log_flow(z0, x_mask)
-            z = torch.cat([z0, z1], 1)
-            for flow in self.flows:
-                z, logdet = flow(z, x_mask, g=x, inverse=inverse)
-                logdet_tot = logdet_tot + logdet
-            nll = torch.sum(0.5 * (math.log(2 * math.pi) + (z ** 2)) * x_mask, [1, 2]) - logdet_tot
-            return nll + logq
+    def _condition(self, x, lens):
+        """x (B, T, C) channel-last, detached (duration_predictor.py:230: no gradient to the encoder)."""
+        x = K.cast(x.detach().contiguous(), torch.float32) if x.dtype != torch.float32 else x.detach()
+        x = FS.mask_rows(Fn.linear(x, self.pre.weight, self.pre.bias), lens)
+        x = self.dds(x, lens)
+        return FS.mask_rows(Fn.linear(x, self.proj.weight, self.proj.bias), lens)
+
+    def forward_cl(self, x, x_lens, w=None, inverse=False, noise_scale=1.0):
+        """x (B, T, C) channel-last, x_lens: modules.Lens, w (B, T) durations -> NLL (B,) | durations (B, T)."""
+        lens = x_lens.dev
+        B, T, _ = x.shape
+        x = self._condition(x, lens)
+        if inverse:
+            return self._inverse(x, lens, B, T, noise_scale)
+        assert w is not None, "w must be provided."
+        w = w.detach().float().contiguous()
+        h_w = FS.expand(w, self.post_pre.weight, self.post_pre.bias, None, lens)
+        h_w = FS.mask_rows(Fn.linear(self.post_dds(h_w, lens), self.post_proj.weight, self.post_proj.bias), lens)
+        g_q = Fn.add_dropout(x, h_w, 0.0)
+        noise = self._randn((B, 2, T), x.device)
+        shared = FS.Shared()
+        aff_q, aff_p = self.post_flows[0], self.flows[0]
+        a, b = FS.head(noise, aff_q.m, aff_q.logs, lens)
+        for flow in self.post_flows[1:]:
+            if isinstance(flow, ConvFlow):            # ConvFlow then Flip: (a, b) -> (spline(b | a), a)
+                a, b = flow(a, b, g_q, lens, shared, "q"), a
+        zu, z1 = a, b
+        a, b, lz = FS.mid(zu, z1, w, aff_p.m, aff_p.logs, lens)
+        for flow in self.flows[1:]:
+            if isinstance(flow, ConvFlow):
+                a, b = flow(a, b, x, lens, shared, "p"), a
+        return FS.tail(noise, zu, lz, a, b, aff_q.logs, aff_p.logs, lens, shared)
+
+    @torch.no_grad()
+    def _inverse(self, x, lens, B, T, noise_scale):
+        """duration_predictor.py:281-304: flows reversed, the first ConvFlow dropped, z = noise * noise_scale."""
         flows = list(reversed(self.flows))
         flows = flows[:-2] + [flows[-1]]
-        z = self._randn((x.size(0), 2, x.size(2)), x.device) * noise_scale
+        z = self._randn((B, 2, T), x.device) * noise_scale
+        a, b = z[:, 0].contiguous(), z[:, 1].contiguous()
         for flow in flows:
-            z = flow(z, x_mask, g=x, inverse=inverse)
-        z0, _ = z.split(1, 1)
-        return torch.ceil(torch.exp(z0) * x_mask)
+            if isinstance(flow, FlipFlow):
+                a, b = b, a
+            elif isinstance(flow, ConvFlow):
+                b = flow.inverse(a, b, x, lens)
+            else:                                         # ElementwiseAffine inverse + exp + ceil, channel 0 only
+                return KS.sdp_inverse_out(a.contiguous(), lens, flow.m.detach().reshape(-1), flow.logs.detach().reshape(-1))
+        raise RuntimeError("flow list must end with the affine flow")
+
+    def forward(self, x, x_mask, w=None, g=None, inverse=False, noise_scale=1.0):
+        """Reference signature (duration_predictor.py:211-229): x (B, C, T), x_mask (B, 1, T), w (B, 1, T)."""
+        if g is not None:
+            raise NotImplementedError("global conditioning is not used by AAS-VC")
+        lens = Mo.Lens.of(x_mask.reshape(x_mask.shape[0], -1).sum(dim=1).long(), x.device)
+        out = self.forward_cl(x.transpose(1, 2), lens, None if w is None else w.reshape(w.shape[0], -1), inverse, noise_scale)
+        return out.unsqueeze(1) if inverse else out

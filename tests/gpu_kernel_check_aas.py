@@ -179,6 +179,177 @@ def stft_logmel_frontend():
     return res
 
 
+def _lens_mask(lens, T):
+    return (torch.arange(T, device=DEV)[None, :] < lens[:, None].long())
+
+
+@case
+@both_dtypes
+def sdp_ln_act_expand_mask(dtype):
+    """Fused LayerNorm+GELU(+residual+mask), the rank-1 Conv1d(1->C) expansion and row masking vs torch autograd."""
+    from seq2seq_vc_amd.ops import functional_sdp as FS
+    res = []
+    a_f, a_b = (1e-4, 2e-4) if dtype == torch.float32 else (5e-2, 8e-2)
+    for (B, T, C, seed) in [(3, 21, 48, 1), (2, 64, 384, 2), (2, 9, 640, 3)]:
+        lens = torch.tensor([T, max(1, T // 2), max(1, T // 3)][:B], dtype=torch.int32, device=DEV)
+        m3 = _lens_mask(lens, T)[..., None].float()
+        x, r = rnd(B, T, C, seed=seed, dtype=dtype), rnd(B, T, C, seed=seed + 1, dtype=dtype)
+        gm = (1 + 0.1 * rnd(C, seed=seed + 2)).requires_grad_(True)
+        bt = (0.1 * rnd(C, seed=seed + 3)).requires_grad_(True)
+        dy = rnd(B, T, C, seed=seed + 4, dtype=dtype)
+        for use_res in (False, True):
+            xr, rr = x.detach().float().clone().requires_grad_(True), r.detach().float().clone().requires_grad_(True)
+            gr, br = gm.detach().clone().requires_grad_(True), bt.detach().clone().requires_grad_(True)
+            ref = F.gelu(F.layer_norm(xr, (C,), gr, br, 1e-5))
+            if use_res:
+                ref = (ref + rr) * m3
+            ref.backward(dy.float())
+            xk, rk = x.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)
+            gm.grad = bt.grad = None
+            y = FS.ln_act(xk, gm, bt, 1e-5, "gelu", res=rk if use_res else None, lens=lens if use_res else None, T=T)
+            y.backward(dy)
+            tag = f"ln_act[{dtype}] {B}x{T}x{C} res={use_res}"
+            res.append(check(tag + " fwd", y, ref, dtype, atol=a_f))
+            res.append(check(tag + " dx", xk.grad, xr.grad, dtype, atol=a_b))
+            if use_res:
+                res.append(check(tag + " dres", rk.grad, rr.grad, dtype, atol=a_b))
+            res.append(check(tag + " dgamma", gm.grad, gr.grad, dtype, atol=2e-4 * math.sqrt(B * T) if dtype == torch.float32 else 0.5))
+            res.append(check(tag + " dbeta", bt.grad, br.grad, dtype, atol=2e-4 * math.sqrt(B * T) if dtype == torch.float32 else 0.5))
+        # expand: y = mask*(a w^T + b + g)
+        a = rnd(B, T, seed=seed + 5).requires_grad_(True)
+        w = (0.5 * rnd(C, 1, 1, seed=seed + 6)).requires_grad_(True)
+        b = (0.1 * rnd(C, seed=seed + 7)).requires_grad_(True)
+        g = rnd(B, T, C, seed=seed + 8, dtype=dtype).requires_grad_(True)
+        ar, wr, b2, g2 = (t.detach().float().clone().requires_grad_(True) for t in (a, w, b, g))
+        ref = (ar[..., None] * wr.view(1, 1, C) + b2 + g2) * m3
+        ref.backward(dy.float())
+        y = FS.expand(a, w, b, g, lens, dtype)
+        y.backward(dy)
+        tag = f"expand[{dtype}] {B}x{T}x{C}"
+        res.append(check(tag + " fwd", y, ref, dtype, atol=a_f))
+        res.append(check(tag + " da", a.grad, ar.grad, dtype, atol=1e-3 if dtype == torch.float32 else 0.5))
+        res.append(check(tag + " dw", w.grad, wr.grad, dtype, atol=1e-3 if dtype == torch.float32 else 0.5))
+        res.append(check(tag + " db", b.grad, b2.grad, dtype, atol=1e-3 if dtype == torch.float32 else 0.5))
+        res.append(check(tag + " dg", g.grad, g2.grad, dtype, atol=0.0, rtol=0.0))
+        xm = x.detach().clone().requires_grad_(True)
+        ym = FS.mask_rows(xm, lens)
+        ym.backward(dy)
+        res.append(check(f"mask_rows[{dtype}] fwd", ym, x.float() * m3, dtype, atol=0.0, rtol=0.0))
+        res.append(check(f"mask_rows[{dtype}] bwd", xm.grad, dy.float() * m3, dtype, atol=0.0, rtol=0.0))
+    return res
+
+
+@case
+def sdp_rq_spline():
+    """Rational-quadratic spline coupling: forward, inverse (round trip) and backward vs the oracle's torch formula."""
+    from oracle import models as OM
+    from seq2seq_vc_amd.ops import kernels_sdp as KS
+    res = []
+    B, T, nb = 3, 37, 10
+    lens = torch.tensor([37, 20, 5], dtype=torch.int32, device=DEV)
+    m = _lens_mask(lens, T).float()
+    for seed, xs, hs in ((1, 2.0, 1.0), (2, 4.0, 3.0), (3, 0.5, 0.2)):
+        x = rnd(B, T, seed=seed) * xs                       # includes |x| > 5: identity tails
+        h = rnd(B, T, 3 * nb - 1, seed=seed + 10) * hs
+        hscale = 1.0 / math.sqrt(32)
+        xr, hr = x.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        o_ref, l_ref = OM._rq_spline(xr, hr[..., :nb] * hscale, hr[..., nb:2 * nb] * hscale, hr[..., 2 * nb:], inverse=False)
+        out, lad = KS.rq_spline_fwd(x, h, hscale, 5.0, lens)
+        res.append(check(f"spline fwd out (seed {seed})", out, o_ref * m, torch.float32, atol=2e-5, rtol=2e-5))
+        res.append(check(f"spline fwd logabsdet (seed {seed})", lad, l_ref * m, torch.float32, atol=5e-5, rtol=5e-5))
+        # accumulate into a running buffer
+        _, lad2 = KS.rq_spline_fwd(x, h, hscale, 5.0, lens, lad=lad.clone(), accumulate=True)
+        res.append(check(f"spline lad accumulate (seed {seed})", lad2, 2 * l_ref * m, torch.float32, atol=1e-4, rtol=5e-5))
+        # backward: loss = sum(go * out * m) + sum_b gl[b] * sum_t lad*m
+        go, gl = rnd(B, T, seed=seed + 20), rnd(B, seed=seed + 30)
+        ((go * o_ref * m).sum() + (gl[:, None] * l_ref * m).sum()).backward()
+        dx, dh = KS.rq_spline_bwd(x, h, hscale, 5.0, lens, go, gl)
+        res.append(check(f"spline bwd dx (seed {seed})", dx, xr.grad, torch.float32, atol=2e-4, rtol=2e-4))
+        res.append(check(f"spline bwd dh (seed {seed})", dh, hr.grad, torch.float32, atol=2e-4, rtol=2e-4))
+        # inverse vs the oracle, and the round trip
+        y_ref, li_ref = OM._rq_spline(x, h[..., :nb] * hscale, h[..., nb:2 * nb] * hscale, h[..., 2 * nb:], inverse=True)
+        inv, lad_i = KS.rq_spline_fwd(x, h, hscale, 5.0, lens, inverse=True)
+        res.append(check(f"spline inverse out (seed {seed})", inv, y_ref * m, torch.float32, atol=5e-5, rtol=5e-5))
+        res.append(check(f"spline inverse logabsdet (seed {seed})", lad_i, li_ref * m, torch.float32, atol=2e-4, rtol=2e-4))
+        back, _ = KS.rq_spline_fwd(out, h, hscale, 5.0, lens, inverse=True)
+        res.append(check(f"spline round trip (seed {seed})", back, x * m, torch.float32, atol=2e-4, rtol=2e-4))
+    return res
+
+
+@case
+def sdp_module_vs_oracle():
+    """StochasticDurationPredictor NLL + every parameter gradient, and the inverse (inference) pass, vs the CPU oracle."""
+    from oracle import models as OM
+    from oracle.nets import P, Runtime
+    from seq2seq_vc_amd import modules as Mo
+    from seq2seq_vc_amd.sdp import StochasticDurationPredictor
+    res = []
+    torch.manual_seed(11)
+    C, B, T = 32, 3, 23
+    sdp = StochasticDurationPredictor(channels=C, kernel_size=3, dropout_rate=0.5, flows=4, dds_conv_layers=3)
+    with torch.no_grad():                                   # zero-initialised pieces would hide the spline / affine paths
+        for n, p in sdp.named_parameters():
+            if n.endswith("proj.weight") and "flows" in n:
+                p.copy_(torch.randn_like(p) * 0.3)
+            elif n.endswith("proj.bias") and "flows" in n:
+                p.copy_(torch.randn_like(p) * 0.3)
+            elif n.endswith(".m") or n.endswith(".logs"):
+                p.copy_(torch.randn_like(p) * 0.2)
+    sd = {k: v.detach().clone() for k, v in sdp.state_dict().items()}
+    sdp.to(DEV).eval()                                      # eval: DDS dropout off (the oracle runs with drop=False)
+    g = torch.Generator().manual_seed(5)
+    lens_h = [23, 14, 6]
+    x = torch.randn(B, T, C, generator=g)
+    w = torch.randint(1, 6, (B, T), generator=g).float()
+    noise = torch.randn(B, 2, T, generator=g)
+    mask = (torch.arange(T)[None] < torch.tensor(lens_h)[:, None]).float()[:, None]
+    w = w * mask[:, 0]
+    # oracle (CPU, autograd)
+    names = [k for k, v in sd.items() if v.dtype.is_floating_point]
+    for k in names:
+        sd[k].requires_grad_(True)
+    nll_ref = OM.sdp_forward(P(sd), x.transpose(1, 2), mask, w[:, None], noise, Runtime(False, False))
+    gout = torch.tensor([1.0, -0.5, 2.0])
+    (nll_ref * gout).sum().backward()
+    lens = Mo.Lens(lens_h, DEV)
+    sdp.noise = noise.clone()
+    nll = sdp.forward_cl(x.to(DEV), lens, w=w.to(DEV))
+    (nll * gout.to(DEV)).sum().backward()
+    res.append(check("sdp nll", nll, nll_ref.detach(), torch.float32, atol=2e-3, rtol=2e-4))
+    nbad, worst = 0, (0.0, "")
+    for k, p in sdp.named_parameters():
+        r = sd[k].grad
+        if r is None:
+            r = torch.zeros_like(sd[k])
+        if p.grad is None:
+            nbad += 1
+            res.append((False, f"sdp grad {k}: missing"))
+            continue
+        err = (p.grad.cpu() - r).abs().max().item()
+        bound = 2e-4 + 2e-3 * r.abs().max().item()
+        if err > bound:
+            nbad += 1
+            if nbad <= 8:
+                res.append((False, f"sdp grad {k}: max_err={err:.3e} ref_max={r.abs().max():.3e}"))
+        rel = err / (r.abs().max().item() + 1e-9)
+        if rel > worst[0]:
+            worst = (rel, k)
+    res.append((nbad == 0, f"sdp parameter grads: {nbad} of {len(names)} off; worst rel err {worst[0]:.3e} at {worst[1]}"))
+    # reference-signature adapter gives the same numbers
+    sdp.noise = noise.clone()
+    with torch.no_grad():
+        nll2 = sdp(x.to(DEV).transpose(1, 2), mask.to(DEV), w=w.to(DEV)[:, None])
+    res.append(check("sdp reference-signature adapter", nll2, nll.detach(), torch.float32, atol=0.0, rtol=0.0))
+    # inverse pass (durations)
+    with torch.no_grad():
+        d_ref = OM.sdp_inverse(P({k: v.detach() for k, v in sd.items()}), x.transpose(1, 2), mask, noise, Runtime(False, False), 0.8)
+    sdp.noise = noise.clone()
+    d = sdp.forward_cl(x.to(DEV), lens, inverse=True, noise_scale=0.8)
+    same = (d.cpu() == d_ref[:, 0]).float().mean().item()
+    res.append((same >= 0.98, f"sdp inverse durations: {same * 100:.1f}% identical (ceil() may flip on 1-ulp differences)"))
+    return res
+
+
 def main():
     nfail = 0
     for fn in CASES:
