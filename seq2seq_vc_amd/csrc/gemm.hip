@@ -320,6 +320,7 @@ int launch(const s2svc_gemm_desc& d, hipStream_t st) {
 
 extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream);    // gemm_fast.hip
 extern "C" int s2svc_gemm_try_skinny(const s2svc_gemm_desc* desc, void* stream);  // gemm_skinny.hip (M <= 64)
+extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream);    // gemm_glds.hip (bf16, LDS-DMA)
 
 static bool generic_forced() {
   static int v = -1;
@@ -345,7 +346,8 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   if (!generic_forced()) {
     const int rs = s2svc_gemm_try_skinny(&d, stream);
     if (rs != 0) return rs < 0 ? rs : 0;
-    const int rc = s2svc_gemm_try_fast(&d, stream);
+    int rc = s2svc_gemm_try_glds(&d, stream);
+    if (rc == 0) rc = s2svc_gemm_try_fast(&d, stream);
     if (rc < 0) return rc;
     if (rc == 1) {
       if (d.splitk > 1) {

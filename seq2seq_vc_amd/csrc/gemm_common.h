@@ -24,3 +24,92 @@ __device__ __forceinline__ void epilogue_store_f(const s2svc_gemm_desc& d, int z
     *c = f2bf(d.accumulate ? bf2f(*c) + v : v);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Vectorised epilogue: a wavefront's WTM x WTN accumulator tile goes through a wave-private fp32 LDS tile so that
+// every lane ends up with 8 consecutive columns of one row -> bias / activation / residual on 8 values and ONE
+// 16-byte (bf16) or two 16-byte (fp32) global stores per lane, 128+ contiguous bytes per row segment.  (The MFMA
+// accumulator layout gives a lane 4 rows x 1 column per fragment: stored directly that is 2-byte scattered stores,
+// which dominates short-K GEMMs.)  Same arithmetic as epilogue_store_f (fp32, one rounding).
+// Requires (checked by the caller, uniform): N % 8 == 0, ldc / batch strides % 8 == 0, 16-byte aligned C (and res).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool epilogue_vec_ok(const s2svc_gemm_desc& d) {
+  bool ok = (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.cbs0 % 8 == 0) && (d.cbs1 % 8 == 0) && (((uintptr_t)d.C) % 16 == 0);
+  if (d.res) ok = ok && (d.ldr % 8 == 0) && (d.rbs0 % 8 == 0) && (d.rbs1 % 8 == 0) && (((uintptr_t)d.res) % 16 == 0);
+  return ok;
+}
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_via_lds(const s2svc_gemm_desc& d, int z0, int z1, int m_base, int n_base,
+                                                 const f32x4_t (&acc)[WTM / 16][WTN / 16], float* cs) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < WTM / 16; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN / 16; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lg * 4 + r, col = j * 16 + lr;
+        cs[row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4))] = acc[i][j][r];
+      }
+  constexpr int LPR = WTN / 8;          // lanes per row
+  constexpr int RPP = 64 / LPR;         // rows per pass
+#pragma unroll
+  for (int p = 0; p < WTM / RPP; ++p) {
+    const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
+    const int m = m_base + row, n = n_base + col;
+    if (m >= d.M || n >= d.N) continue;
+    const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
+    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (d.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * d.alpha + bb[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
+    }
+    if (d.act != S2S_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], d.act);
+    }
+    const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
+    if (d.res) {
+      const int64_t ro = (int64_t)z0 * d.rbs0 + (int64_t)z1 * d.rbs1 + (int64_t)m * d.ldr + n;
+      if (d.c_dtype == S2S_F32) {
+        const float4 r0 = *reinterpret_cast<const float4*>((const float*)d.res + ro), r1 = *reinterpret_cast<const float4*>((const float*)d.res + ro + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      } else {
+        const uint4 rv = *reinterpret_cast<const uint4*>((const bf16_t*)d.res + ro);
+        const uint32_t w[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+      }
+    }
+    if (d.c_dtype == S2S_F32) {
+      float* c = (float*)d.C + co;
+      if (d.accumulate) {
+        const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+        v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
+      }
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      bf16_t* c = (bf16_t*)d.C + co;
+      if (d.accumulate) {
+        const uint4 cv = *reinterpret_cast<const uint4*>(c);
+        const uint32_t w[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+      }
+      uint4 o;
+      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+      o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+      *reinterpret_cast<uint4*>(c) = o;
+    }
+  }
+}

@@ -1,0 +1,520 @@
+// bf16 MFMA GEMM, LDS-DMA staged and double buffered (same contract as gemm.hip / gemm_fast.hip).
+//
+//   * K-contiguous operands (activations, weights, implicit-im2col conv inputs) go HBM -> LDS with
+//     `global_load_lds_dwordx4` (16 B per lane, no staging registers, no ds_write pass).  The LDS image of a tile is
+//     lane-linear, as that instruction requires; bank conflicts of the ds_read_b128 fragment reads are removed by an
+//     XOR swizzle applied to the per-lane SOURCE address and, identically, to the read address: the 16-byte piece
+//     c of row r lives at r*128 + ((c ^ ((r>>1)&7))<<4).  With that map every 16-lane group of a fragment read
+//     (rows r..r+15 at pieces c / c^1) hits 16 distinct 16-byte bank slots.
+//   * Row-contiguous operands (weights in dgrad, activations in wgrad) are transposed in registers (8x8 blocks,
+//     v_perm_b32) and written with ds_write_b128 into the same swizzled image.
+//   * Two LDS buffers: tile t+1 is in flight (DMA + global loads) while the MFMAs consume tile t; one barrier per
+//     K tile.  Pieces outside the matrix / the conv input are fetched from a 16-byte zero block.
+//   * 128x128 or 64x64 output tile per 4-wave workgroup (2x2 waves, 4x4 / 2x2 MFMA 16x16x32 fragments per wave),
+//     BK = 64, optional split-K (fp32 partials + splitk_reduce_kernel) and the fused A-row-sum of the wgrad GEMMs.
+#include "gemm_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+// operand kinds (compile-time: the K loop has no mode branches): layout x addressing
+enum { G_KC_DENSE = 0, G_KC_CONV1D = 1, G_KC_CONV2D = 2, G_RC_DENSE = 3, G_RC_CONV1D = 4, G_RC_CONV2D = 5 };
+
+// LDS image of an operand tile with BKT bf16 per row (16-byte pieces): piece c of row r lives at
+//   BKT = 64 (128-B rows, 8 pieces): r*128 + ((c ^ ((r>>1)&7)) << 4)
+//   BKT = 32 ( 64-B rows, 4 pieces): r*64  + ((c ^ ((-(r>>2))&3)) << 4)
+// both maps put the 16 lanes of every ds_read_b128 lane group (rows r..r+15 at pieces c / c^1) on 16 distinct
+// 16-byte bank slots of the 256-byte LDS row.
+template <int BKT> __device__ __forceinline__ int swz_of(int r) { return BKT == 64 ? ((r >> 1) & 7) : ((-(r >> 2)) & 3); }
+template <int BKT> __device__ __forceinline__ int lds_off_t(int r, int c) { return r * (BKT * 2) + ((c ^ swz_of<BKT>(r)) << 4); }
+__device__ __forceinline__ int lds_off(int r, int c) { return lds_off_t<64>(r, c); }
+
+// address of the zero block as an opaque per-lane value: keeps `ok ? src : zero` a plain 64-bit select, so ONE DMA /
+// load instruction serves valid and padding lanes alike (a visible global address makes hipcc split every load in two
+// EXEC-masked halves with a branch around each)
+__device__ __forceinline__ uint64_t zero_addr() {
+  uint64_t z = reinterpret_cast<uint64_t>(&g_zero16);
+  asm volatile("" : "+v"(z));
+  return z;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K-contiguous operand: ROWS/32 LDS-DMA instructions per wave and K tile (64 lanes x 16 B = 8 rows each).
+// All address arithmetic is select-based (no branches around the DMA); conv taps advance by compare-and-wrap
+// from the tile's uniform (tap, channel) origin instead of a per-lane division (needs C >= 64).
+// ---------------------------------------------------------------------------------------------------------
+template <int ROWS, int KIND, int BKT = 64>
+struct KcStage {
+  static constexpr int PIECES = BKT / 8;               // 16-byte pieces per row
+  static constexpr int RPI = 64 / PIECES;              // rows per DMA instruction (64 lanes x 16 B)
+  static constexpr int NI = ROWS / RPI / 4;            // DMA instructions per wave and tile
+  static_assert(NI >= 1, "tile too small for 4 waves");
+  int64_t rowbase[NI];            // element offset of the row's first tap ; < 0: row outside the matrix
+  int trow[NI];                   // conv1d: frame index of the row
+  int piece8;                     // 8 * source piece of this lane (the same for every row group, see init)
+  __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // rows of group g = 4i + wave: rl = g*RPI + lane/PIECES ; the swizzle term of rl does not depend on i
+    // (BKT 64: ((g&1)*4 + (lane>>4)) & 7 with g&1 == wave&1 ; BKT 32: (-(lane>>4)) & 3)
+    piece8 = ((lane % PIECES) ^ swz_of<BKT>(wave * RPI + lane / PIECES)) << 3;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int rl = (i * 4 + wave) * RPI + lane / PIECES;
+      const int r = r0 + rl;
+      trow[i] = 0;
+      if (KIND == G_KC_DENSE) {
+        rowbase[i] = (int64_t)r * o.ld;
+      } else if (KIND == G_KC_CONV1D) {
+        rowbase[i] = (int64_t)r * o.ld;
+        trow[i] = r % o.T;
+      } else {
+        const int f2 = r % o.F2, bt = r / o.F2;
+        const int t2 = bt % o.T2, b = bt / o.T2;
+        rowbase[i] = ((int64_t)(b * o.T1 + 2 * t2) * o.F1 + 2 * f2) * o.ld;
+      }
+      if (r >= R) rowbase[i] = -1;
+    }
+  }
+  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int k0, int K, char* lds) const {
+    const int wave = threadIdx.x >> 6;
+    const uint64_t zaddr = zero_addr();
+    const int k = k0 + piece8;
+    const bool kin = k < K;
+    int64_t koff = k;             // element offset added to the row base
+    int tap = 0;
+    if (KIND != G_KC_DENSE) {
+      const int tap0 = k0 / o.C, c0 = k0 - tap0 * o.C;      // uniform over the workgroup
+      int c = c0 + piece8;
+      tap = tap0;
+      if (c >= o.C) { c -= o.C; tap += 1; }
+      if (KIND == G_KC_CONV1D) {
+        koff = (int64_t)(tap - o.pad) * o.ld + c;
+      } else {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        koff = (int64_t)(kh * o.F1 + kw) * o.ld + c;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      bool ok = kin && rowbase[i] >= 0;
+      if (KIND == G_KC_CONV1D) {
+        const int tt = trow[i] + tap - o.pad;
+        ok = ok && tt >= 0 && tt < o.T;
+      }
+      const uint64_t src = ok ? reinterpret_cast<uint64_t>(base + rowbase[i] + koff) : zaddr;
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Row-contiguous operand: 8x8 register-block transpose (one block per thread; ROWS blocks per tile)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t perm_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+template <int ROWS, int KIND>
+struct RcStage {
+  static constexpr int RB = ROWS / 8;        // row blocks; 8 k blocks -> ROWS blocks per tile
+  uint4 reg[8];
+  __device__ __forceinline__ void load(const s2svc_operand& o, const bf16_t* base, int r0, int R, int k0, int K) {
+    const int blk = threadIdx.x;
+    if (blk >= ROWS) return;
+    const int rb = blk % RB, kb = blk / RB;
+    const int r = r0 + rb * 8;
+    int tap = 0, c = r;
+    if (KIND != G_RC_DENSE) { tap = r / o.C; c = r - tap * o.C; }
+    const uint64_t zaddr = zero_addr();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + kb * 8 + j;
+      bool ok = r < R && k < K;
+      int64_t off;
+      if (KIND == G_RC_DENSE) {
+        off = (int64_t)k * o.ld + r;
+      } else if (KIND == G_RC_CONV1D) {
+        const int t = k % o.T, tt = t + tap - o.pad;
+        ok = ok && tt >= 0 && tt < o.T;
+        off = (int64_t)(k + tap - o.pad) * o.ld + c;
+      } else {
+        const int f2 = k % o.F2, bt = k / o.F2;
+        const int t2 = bt % o.T2, b = bt / o.T2;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        off = ((int64_t)(b * o.T1 + 2 * t2 + kh) * o.F1 + (2 * f2 + kw)) * o.ld + c;
+      }
+      reg[j] = *reinterpret_cast<const uint4*>(ok ? reinterpret_cast<uint64_t>(base + off) : zaddr);
+    }
+  }
+  __device__ __forceinline__ void store(char* lds) const {
+    const int blk = threadIdx.x;
+    if (blk >= ROWS) return;
+    const int rb = blk % RB, kb = blk / RB;
+    const uint4(&in)[8] = reg;
+    uint4 out[8];     // out[e] = (in[0][e], ..., in[7][e]); element e of in[j] sits in dword e/2, half e%2
+    out[0] = make_uint4(perm_lo(in[0].x, in[1].x), perm_lo(in[2].x, in[3].x), perm_lo(in[4].x, in[5].x), perm_lo(in[6].x, in[7].x));
+    out[1] = make_uint4(perm_hi(in[0].x, in[1].x), perm_hi(in[2].x, in[3].x), perm_hi(in[4].x, in[5].x), perm_hi(in[6].x, in[7].x));
+    out[2] = make_uint4(perm_lo(in[0].y, in[1].y), perm_lo(in[2].y, in[3].y), perm_lo(in[4].y, in[5].y), perm_lo(in[6].y, in[7].y));
+    out[3] = make_uint4(perm_hi(in[0].y, in[1].y), perm_hi(in[2].y, in[3].y), perm_hi(in[4].y, in[5].y), perm_hi(in[6].y, in[7].y));
+    out[4] = make_uint4(perm_lo(in[0].z, in[1].z), perm_lo(in[2].z, in[3].z), perm_lo(in[4].z, in[5].z), perm_lo(in[6].z, in[7].z));
+    out[5] = make_uint4(perm_hi(in[0].z, in[1].z), perm_hi(in[2].z, in[3].z), perm_hi(in[4].z, in[5].z), perm_hi(in[6].z, in[7].z));
+    out[6] = make_uint4(perm_lo(in[0].w, in[1].w), perm_lo(in[2].w, in[3].w), perm_lo(in[4].w, in[5].w), perm_lo(in[6].w, in[7].w));
+    out[7] = make_uint4(perm_hi(in[0].w, in[1].w), perm_hi(in[2].w, in[3].w), perm_hi(in[4].w, in[5].w), perm_hi(in[6].w, in[7].w));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint4*>(lds + lds_off(rb * 8 + e, kb)) = out[e];
+  }
+};
+
+// XCD-aware tile order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
+// L2); handing XCD x the x-th CONTIGUOUS run of output tiles (row-major, n fastest) makes the workgroups that run
+// side by side on one XCD share A row panels and B column panels through that L2 instead of each pulling them over
+// the fabric.  Bijective for any grid size; z-planes (batch / split-K) keep the plain order unless the plane is a
+// multiple of 8 workgroups (the XCD phase of a plane would otherwise depend on z).
+__device__ __forceinline__ void tile_of_block(int& bm, int& bn) {
+  const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+  int id = blockIdx.y * gx + blockIdx.x;
+  if (gridDim.z == 1 || (nwg & 7) == 0) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = id & 7, j = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  bm = id / gx;
+  bn = id - bm * gx;
+}
+
+template <int ROWS, int KIND, bool IS_RC = (KIND >= G_RC_DENSE)> struct Stage;
+template <int ROWS, int KIND> struct Stage<ROWS, KIND, false> {
+  KcStage<ROWS, KIND> s;
+  __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) { s.init(o, r0, R); }
+  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int, int, int k0, int K, char* lds) { s.issue(o, base, k0, K, lds); }
+  __device__ __forceinline__ void finish(char*) const {}
+};
+template <int ROWS, int KIND> struct Stage<ROWS, KIND, true> {
+  RcStage<ROWS, KIND> s;
+  __device__ __forceinline__ void init(const s2svc_operand&, int, int) {}
+  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int r0, int R, int k0, int K, char*) { s.load(o, base, r0, R, k0, K); }
+  __device__ __forceinline__ void finish(char* lds) const { s.store(lds); }
+};
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const s2svc_gemm_desc d) {
+  constexpr int BK = 64;                               // bf16 per K tile: 128-B rows, 8 pieces of 16 B
+  constexpr int FM = BM / 32, FN = BN / 32;            // 16x16 fragments per wave along m / n
+  constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE_BYTES = ABYTES + BBYTES;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+
+  const int splitk = d.splitk > 1 ? d.splitk : 1;
+  const int zb = blockIdx.z / splitk, zs = blockIdx.z - zb * splitk;
+  const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
+  int tile_m, tile_n;
+  tile_of_block(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const bf16_t* Ab = (const bf16_t*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1;
+  const bf16_t* Bb = (const bf16_t*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1;
+  const int ktiles = (d.K + BK - 1) / BK;
+  const int per = (ktiles + splitk - 1) / splitk;
+  const int kt_begin = zs * per;
+  const int kt_end = (kt_begin + per < ktiles) ? kt_begin + per : ktiles;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  const int lr = lane & 15, lg = lane >> 4;
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  Stage<BM, AMODE> sa;
+  Stage<BN, BMODE> sb;
+  sa.init(d.A, m0, d.M);
+  sb.init(d.B, n0, d.N);
+  if (kt_begin < kt_end) {
+    sa.issue(d.A, Ab, m0, d.M, kt_begin * BK, d.K, smem);
+    sb.issue(d.B, Bb, n0, d.N, kt_begin * BK, d.K, smem + ABYTES);
+    sa.finish(smem);
+    sb.finish(smem + ABYTES);
+  }
+  __syncthreads();                 // (drains the DMA: the compiler places vmcnt(0) ahead of the barrier)
+
+  constexpr int TPR = 256 / BM;    // threads per A row for the fused row sums
+  const bool do_rowsum = (d.a_rowsum != nullptr) && (tile_n == 0);
+  float rowsum = 0.f;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    char* As = smem + cur * STAGE_BYTES;
+    char* Bs = As + ABYTES;
+    char* An = smem + (cur ^ 1) * STAGE_BYTES;
+    const bool more = (kt + 1 < kt_end);
+    if (more) {                    // tile kt+1 starts moving before the MFMAs of tile kt
+      sa.issue(d.A, Ab, m0, d.M, (kt + 1) * BK, d.K, An);
+      sb.issue(d.B, Bb, n0, d.N, (kt + 1) * BK, d.K, An + ABYTES);
+    }
+    if (do_rowsum) {
+      const int r = threadIdx.x / TPR, part = threadIdx.x % TPR;       // part covers 8/TPR pieces of the row
+#pragma unroll
+      for (int c = 0; c < 8 / TPR; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(As + lds_off(r, part * (8 / TPR) + c));
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowsum += __uint_as_float(w[e] << 16) + __uint_as_float(w[e] & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + i * 16 + lr, ks * 4 + lg));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + j * 16 + lr, ks * 4 + lg));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      sa.finish(An);
+      sb.finish(An + ABYTES);
+    }
+    __syncthreads();
+  }
+
+  if (do_rowsum) {
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) rowsum += __shfl_xor(rowsum, o, 64);
+    const int m = m0 + threadIdx.x / TPR;
+    if ((threadIdx.x % TPR) == 0 && m < d.M) {
+      if (splitk > 1) d.a_rowsum_ws[(int64_t)zs * d.M + m] = rowsum;
+      else d.a_rowsum[m] = (d.a_rowsum_accumulate ? d.a_rowsum[m] : 0.f) + rowsum;
+    }
+  }
+  if (sizeof(smem) >= (size_t)BM * BN * 4 && splitk == 1 && epilogue_vec_ok(d)) {
+    __syncthreads();             // every wave is done with the operand stages: reuse them as fp32 C tiles
+    float* cs = reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2);
+    epilogue_via_lds<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, cs);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + lg * 4 + r;
+        const int n = n0 + wn + j * 16 + lr;
+        if (m < d.M && n < d.N) {
+          if (splitk > 1) {
+            const int nbatch = d.nb0 * d.nb1;
+            d.ws[(((int64_t)zs * nbatch + zb) * d.M + m) * d.N + n] = acc[i][j][r];
+          } else {
+            epilogue_store_f(d, z0, z1, m, n, acc[i][j][r]);
+          }
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// All-DMA variant (both operands K-contiguous): NS LDS stages, NS-1 tiles in flight.  The wait for tile t is a
+// COUNTED s_waitcnt (the DMAs of the later tiles stay in flight across the barrier) followed by a raw s_barrier;
+// the stage freed by that barrier is refilled immediately.  One barrier per K tile, no drain in the main loop.
+// Every wave issues exactly NI_A + NI_B DMA instructions per tile, so "tile t landed" == vmcnt <= (tiles issued
+// after t) * (NI_A + NI_B).
+// ---------------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int KA, int KB, int NS, int BK>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const s2svc_gemm_desc d) {
+  constexpr int FM = BM / 32, FN = BN / 32;
+  constexpr int ABYTES = BM * BK * 2, BBYTES = BN * BK * 2, STAGE_BYTES = ABYTES + BBYTES;
+  constexpr int PER_TILE = KcStage<BM, KA, BK>::NI + KcStage<BN, KB, BK>::NI;   // DMA instructions per wave and tile
+  __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE_BYTES];
+
+  const int splitk = d.splitk > 1 ? d.splitk : 1;
+  const int zb = blockIdx.z / splitk, zs = blockIdx.z - zb * splitk;
+  const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
+  int tile_m, tile_n;
+  tile_of_block(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const bf16_t* Ab = (const bf16_t*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1;
+  const bf16_t* Bb = (const bf16_t*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1;
+  const int ktiles = (d.K + BK - 1) / BK;
+  const int per = (ktiles + splitk - 1) / splitk;
+  const int kt_begin = zs * per;
+  const int kt_end = (kt_begin + per < ktiles) ? kt_begin + per : ktiles;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  const int lr = lane & 15, lg = lane >> 4;
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  KcStage<BM, KA, BK> sa;
+  KcStage<BN, KB, BK> sb;
+  sa.init(d.A, m0, d.M);
+  sb.init(d.B, n0, d.N);
+  // prologue: NS-1 tiles in flight (tiles past the end are issued too -- they read the zero block -- so that the
+  // per-wave DMA count per stage is always PER_TILE and the counted waits below stay exact)
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    sa.issue(d.A, Ab, (kt_begin + s) * BK, (kt_begin + s) < kt_end ? d.K : 0, smem + s * STAGE_BYTES);
+    sb.issue(d.B, Bb, (kt_begin + s) * BK, (kt_begin + s) < kt_end ? d.K : 0, smem + s * STAGE_BYTES + ABYTES);
+  }
+  int cur = 0;                                          // stage of tile kt
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    wait_vmcnt<(NS - 2) * PER_TILE>();                  // tile kt has landed; NS-2 later tiles may still be moving
+    __builtin_amdgcn_s_barrier();                       // ... for every wave; and everyone is done reading tile kt-1
+    {                                                   // refill the stage tile kt-1 lived in with tile kt+NS-1
+      int nxt = cur + NS - 1;
+      if (nxt >= NS) nxt -= NS;
+      const int kn = kt + NS - 1;
+      sa.issue(d.A, Ab, kn * BK, kn < kt_end ? d.K : 0, smem + nxt * STAGE_BYTES);
+      sb.issue(d.B, Bb, kn * BK, kn < kt_end ? d.K : 0, smem + nxt * STAGE_BYTES + ABYTES);
+    }
+    const char* As = smem + cur * STAGE_BYTES;
+    const char* Bs = As + ABYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off_t<BK>(wm + i * 16 + lr, ks * 4 + lg));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off_t<BK>(wn + j * 16 + lr, ks * 4 + lg));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  wait_vmcnt<0>();                                      // the zero-block DMAs issued past the end
+
+  if (sizeof(smem) >= (size_t)BM * BN * 4 && splitk == 1 && epilogue_vec_ok(d)) {
+    __syncthreads();             // every wave is done with the operand stages: reuse them as fp32 C tiles
+    float* cs = reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2);
+    epilogue_via_lds<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, cs);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + lg * 4 + r;
+        const int n = n0 + wn + j * 16 + lr;
+        if (m < d.M && n < d.N) {
+          if (splitk > 1) {
+            const int nbatch = d.nb0 * d.nb1;
+            d.ws[(((int64_t)zs * nbatch + zb) * d.M + m) * d.N + n] = acc[i][j][r];
+          } else {
+            epilogue_store_f(d, z0, z1, m, n, acc[i][j][r]);
+          }
+        }
+      }
+}
+
+int dma_stages() {       // S2SVC_GEMM_STAGES override (0 = built-in policy), see launch_kinds
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_STAGES"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+int kind_of(const s2svc_operand& o) {
+  const int base = o.layout == S2SVC_LAYOUT_RC ? G_RC_DENSE : G_KC_DENSE;
+  return base + (o.mode == S2SVC_OP_DENSE ? 0 : (o.mode == S2SVC_OP_CONV1D ? 1 : 2));
+}
+
+// the operand-kind pairs the autograd code issues (ops/functional.py); anything else stays on the older kernels
+template <int BM, int BN>
+bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
+  const int ka = kind_of(d.A), kb = kind_of(d.B);
+#define S2S_GLDS_CASE(KA, KB)                                                                       \
+  if (ka == KA && kb == KB) {                                                                      \
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, KA, KB>), grid, dim3(256), 0, st, d);              \
+    return true;                                                                                   \
+  }
+  // all-DMA operands: the 64x64 tile runs the 3-stage counted-wait pipeline (48 KB LDS, 3 workgroups per CU); the
+  // 128x128 tile keeps two stages (64 KB, 2 workgroups per CU -- a third stage would leave one workgroup per CU and
+  // measured ~2x slower).  S2SVC_GEMM_STAGES = 2 | 3 | 4 | 13 | 14 (1x = BK 32) overrides both for A/B runs.
+#define S2S_DMA_CASE(KA, KB)                                                                        \
+  if (ka == KA && kb == KB && !d.a_rowsum) {                                                       \
+    const int cfg = dma_stages() ? dma_stages() : (BM == 64 ? 3 : 2);                              \
+    const int ns = cfg % 10, bk = cfg >= 10 ? 32 : 64;                                             \
+    if (ns >= 3) {                                                                                 \
+      if (bk == 64 && ns == 3) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, KA, KB, 3, 64>), grid, dim3(256), 0, st, d); \
+      else if (bk == 64) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, KA, KB, 4, 64>), grid, dim3(256), 0, st, d);     \
+      else if (ns == 3) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, KA, KB, 3, 32>), grid, dim3(256), 0, st, d);      \
+      else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, KA, KB, 4, 32>), grid, dim3(256), 0, st, d); \
+      return true;                                                                                 \
+    }                                                                                              \
+  }
+  S2S_DMA_CASE(G_KC_DENSE, G_KC_DENSE)
+  S2S_DMA_CASE(G_KC_CONV1D, G_KC_DENSE)
+  S2S_DMA_CASE(G_KC_CONV2D, G_KC_DENSE)
+#undef S2S_DMA_CASE
+  S2S_GLDS_CASE(G_KC_DENSE, G_KC_DENSE)      // linear forward, attention scores
+  S2S_GLDS_CASE(G_KC_DENSE, G_RC_DENSE)      // linear dgrad, P.V
+  S2S_GLDS_CASE(G_RC_DENSE, G_RC_DENSE)      // linear wgrad
+  S2S_GLDS_CASE(G_RC_DENSE, G_KC_DENSE)
+  S2S_GLDS_CASE(G_KC_CONV1D, G_KC_DENSE)     // Conv1d forward (implicit im2col)
+  S2S_GLDS_CASE(G_KC_CONV1D, G_RC_DENSE)     // Conv1d dgrad
+  S2S_GLDS_CASE(G_RC_DENSE, G_RC_CONV1D)     // Conv1d wgrad
+  S2S_GLDS_CASE(G_KC_CONV2D, G_KC_DENSE)     // Conv2d 3x3 s2 forward
+  S2S_GLDS_CASE(G_RC_DENSE, G_RC_CONV2D)     // Conv2d wgrad
+#undef S2S_GLDS_CASE
+  return false;
+}
+
+bool operand_ok(const s2svc_operand& o) {
+  if (((uintptr_t)o.ptr) % 16) return false;
+  if (o.ld % 8 || o.bs0 % 8 || o.bs1 % 8) return false;
+  if (o.mode != S2SVC_OP_DENSE && (o.C % 8 || o.C < 64)) return false;   // taps advance by one compare-and-wrap per piece
+  return true;
+}
+
+bool disabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_NO_GLDS"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
+}  // namespace
+
+// returns 1 if launched here (the caller still runs the split-K reduction), 0 if the problem is not eligible
+extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
+  const s2svc_gemm_desc& d = *desc;
+  if (disabled() || d.dtype != S2S_BF16) return 0;
+  if (!operand_ok(d.A) || !operand_ok(d.B)) return 0;
+  // 16-byte pieces run along the row index (RC) or along k (KC): the extent must be a multiple of 8, or the caller
+  // declares the rows zero-padded up to one (whole pieces are then fetched unmasked)
+  auto extent_ok = [&](const s2svc_operand& o, int extent) {
+    if (extent % 8 == 0) return true;
+    return o.mode == S2SVC_OP_DENSE && o.zero_padded && o.ld >= (int64_t)((extent + 7) / 8 * 8);
+  };
+  if (!extent_ok(d.A, d.A.layout == S2SVC_LAYOUT_RC ? d.M : d.K)) return 0;
+  if (!extent_ok(d.B, d.B.layout == S2SVC_LAYOUT_RC ? d.N : d.K)) return 0;
+  if (d.tile_hint != 0 && d.tile_hint != 64 && d.tile_hint != 128) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int splitk = d.splitk > 1 ? d.splitk : 1;
+  const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1 * splitk;
+  bool big = tiles128 >= 192 && d.M >= 128 && d.N >= 128;
+  if (d.tile_hint == 128) big = true;
+  if (d.tile_hint == 64) big = false;
+  bool launched;
+  if (big) {
+    dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.nb0 * d.nb1 * splitk);
+    launched = launch_kinds<128, 128>(d, grid, st);
+  } else {
+    dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.nb0 * d.nb1 * splitk);
+    launched = launch_kinds<64, 64>(d, grid, st);
+  }
+  if (!launched) return 0;
+  S2S_CHECK_LAUNCH("gemm_glds_kernel");
+  return 1;
+}

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of s2svc_gemm on the GEMM shapes of the two training workloads (VTN vc1, AAS-VC vc2).
+
+    python tools/gemm_bench.py [--iters 50] [--dtype bf16] [--filter substr]
+
+Each line: the operand layouts as the autograd code issues them (fwd = KC x KC, dgrad = KC x RC, wgrad = RC x RC with the
+reduction over the B*T rows), average launch time over `--iters` back-to-back launches (HIP events on the launch stream),
+achieved TFLOP/s and the fraction of the dense bf16 MFMA peak (2.5 PFLOP/s).  Inputs are uniform random in [-1, 1).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from seq2seq_vc_amd.ops import kernels as K  # noqa: E402
+
+PEAK = {torch.bfloat16: 2500.0, torch.float32: 157.3}
+
+# (name, rows = B*T, in_features, out_features)
+LINEARS = [
+    ("aas dec ffn/attn 1536x1536 (B16 T256)", 4096, 1536, 1536),
+    ("aas dec conv-pw1 1536->3072", 4096, 1536, 3072),
+    ("aas enc ffn 384->1536", 4096, 384, 1536),
+    ("aas enc ffn 1536->384", 4096, 1536, 384),
+    ("aas enc attn 384->384", 4096, 384, 384),
+    ("vtn enc attn 384->384 (B32 T63)", 2016, 384, 384),
+    ("vtn enc ffn 384->1536", 2016, 384, 1536),
+    ("vtn dec ffn 384->1536 (B32 T64)", 2048, 384, 1536),
+    ("vtn dec qkv 384->1152", 2048, 384, 1152),
+    ("vtn embed 7296->384", 2016, 7296, 384),
+    ("square 4096^3 (reference point of the CDNA4 guide)", 4096, 4096, 4096),
+]
+
+
+def bench(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--filter", default="")
+    a = ap.parse_args()
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = "cuda"
+    rnd = lambda *s: (torch.rand(*s, device=dev) * 2 - 1).to(dtype)
+    print(f"{'case':58s} {'M':>6s} {'N':>6s} {'K':>6s} {'us':>9s} {'TFLOP/s':>9s} {'%peak':>6s}")
+    tot = 0.0
+
+    def line(name, M, N, Kd, us):
+        nonlocal tot
+        tf = 2.0 * M * N * Kd / us / 1e6
+        tot += us
+        print(f"{name:58s} {M:6d} {N:6d} {Kd:6d} {us:9.1f} {tf:9.1f} {100 * tf / PEAK[dtype]:6.1f}")
+
+    for name, rows, fin, fout in LINEARS:
+        if a.filter and a.filter not in name:
+            continue
+        x, w, dy = rnd(rows, fin), rnd(fout, fin) * 0.05, rnd(rows, fout)
+        b = torch.zeros(fout, device=dev)
+        y = torch.empty(rows, fout, dtype=dtype, device=dev)
+        dx = torch.empty(rows, fin, dtype=dtype, device=dev)
+        dw = torch.empty(fout, fin, dtype=torch.float32, device=dev)
+        line("fwd   " + name, rows, fout, fin,
+             bench(lambda: K.gemm(K.operand(x, fin), K.operand(w, fin), rows, fout, fin, y, in_dtype=dtype, bias=b), a.iters))
+        line("dgrad " + name, rows, fin, fout,
+             bench(lambda: K.gemm(K.operand(dy, fout), K.operand(w, fin, layout=K.RC), rows, fin, fout, dx, in_dtype=dtype), a.iters))
+        tile, sk = K.plan_gemm(fout, fin, rows)
+        line(f"wgrad {name} [tile {tile} splitk {sk}]", fout, fin, rows,
+             bench(lambda: K.gemm(K.operand(dy, fout, layout=K.RC), K.operand(x, fin, layout=K.RC), fout, fin, rows, dw,
+                                  in_dtype=dtype, splitk=sk, tile=tile), a.iters))
+    # the FLOP-heaviest VTN op: implicit-GEMM Conv2d 3x3 stride 2 (subsampling.py:60)
+    if not a.filter or a.filter in "conv2d":
+        B, T1, F1, C, O = 32, 127, 39, 384, 384
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        M, N, Kd = B * T2 * F2, O, 9 * C
+        x, w = rnd(B, T1, F1, C), rnd(O, 9 * C) * 0.02
+        y = torch.empty(B, T2, F2, O, dtype=dtype, device=dev)
+        b = torch.zeros(O, device=dev)
+        line("fwd   vtn conv2d 3x3 s2 implicit", M, N, Kd,
+             bench(lambda: K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(w, 9 * C), M, N, Kd, y,
+                                  in_dtype=dtype, bias=b, act="relu"), a.iters))
+    # postnet Conv1d k5 256->256 as implicit GEMM (B32 T256)
+    if not a.filter or a.filter in "conv1d":
+        B, T, Cin, Cout, ks = 32, 256, 256, 256, 5
+        x, w = rnd(B, T, Cin), rnd(Cout, ks * Cin) * 0.02
+        y = torch.empty(B, T, Cout, dtype=dtype, device=dev)
+        line("fwd   vtn postnet conv1d k5 256->256 implicit", B * T, Cout, ks * Cin,
+             bench(lambda: K.gemm(K.operand(x, Cin, mode=K.CONV1D, C=Cin, T=T, pad=2), K.operand(w, ks * Cin), B * T, Cout, ks * Cin, y,
+                                  in_dtype=dtype), a.iters))
+    print(f"{'sum of averages':58s} {'':6s} {'':6s} {'':6s} {tot:9.1f}")
+
+
+if __name__ == "__main__":
+    main()
