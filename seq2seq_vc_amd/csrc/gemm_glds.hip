@@ -119,19 +119,27 @@ __device__ __forceinline__ uint32_t perm_hi(uint32_t a, uint32_t b) { return __b
 
 template <int ROWS, int KIND>
 struct RcStage {
-  static constexpr int RB = ROWS / 8;        // row blocks; 8 k blocks -> ROWS blocks per tile
-  uint4 reg[8];
+  // The tile is ROWS/8 row blocks x 8 k blocks of 8x8 elements.  All 256 threads take part: TPB threads share a
+  // block, each loading KS = 8/TPB consecutive k (16 B = 8 rows per load) and writing, per row, its KS k-values
+  // (8 or 4 bytes) into the row's 16-byte piece of the swizzled image.
+  // (Measured: for 128-row tiles one thread per block -- 8 loads, 8 ds_write_b128, half the threads idle -- is the
+  // faster arrangement, for 64-row tiles four threads per block.)
+  static constexpr int RB = ROWS / 8;
+  static constexpr int TPB = ROWS == 64 ? 4 : 1;
+  static constexpr int KS = 8 / TPB;         // k per thread
+  static constexpr int ACTIVE = ROWS * TPB;  // threads that carry a (partial) block
+  uint4 reg[KS];
   __device__ __forceinline__ void load(const s2svc_operand& o, const bf16_t* base, int r0, int R, int k0, int K) {
-    const int blk = threadIdx.x;
-    if (blk >= ROWS) return;
-    const int rb = blk % RB, kb = blk / RB;
+    if (ACTIVE < 256 && threadIdx.x >= ACTIVE) return;
+    const int rb = threadIdx.x % RB, rest = threadIdx.x / RB;
+    const int kb = rest / TPB, sub = rest % TPB;
     const int r = r0 + rb * 8;
     int tap = 0, c = r;
     if (KIND != G_RC_DENSE) { tap = r / o.C; c = r - tap * o.C; }
     const uint64_t zaddr = zero_addr();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = k0 + kb * 8 + j;
+    for (int j = 0; j < KS; ++j) {
+      const int k = k0 + kb * 8 + sub * KS + j;
       bool ok = r < R && k < K;
       int64_t off;
       if (KIND == G_RC_DENSE) {
@@ -150,21 +158,34 @@ struct RcStage {
     }
   }
   __device__ __forceinline__ void store(char* lds) const {
-    const int blk = threadIdx.x;
-    if (blk >= ROWS) return;
-    const int rb = blk % RB, kb = blk / RB;
-    const uint4(&in)[8] = reg;
-    uint4 out[8];     // out[e] = (in[0][e], ..., in[7][e]); element e of in[j] sits in dword e/2, half e%2
-    out[0] = make_uint4(perm_lo(in[0].x, in[1].x), perm_lo(in[2].x, in[3].x), perm_lo(in[4].x, in[5].x), perm_lo(in[6].x, in[7].x));
-    out[1] = make_uint4(perm_hi(in[0].x, in[1].x), perm_hi(in[2].x, in[3].x), perm_hi(in[4].x, in[5].x), perm_hi(in[6].x, in[7].x));
-    out[2] = make_uint4(perm_lo(in[0].y, in[1].y), perm_lo(in[2].y, in[3].y), perm_lo(in[4].y, in[5].y), perm_lo(in[6].y, in[7].y));
-    out[3] = make_uint4(perm_hi(in[0].y, in[1].y), perm_hi(in[2].y, in[3].y), perm_hi(in[4].y, in[5].y), perm_hi(in[6].y, in[7].y));
-    out[4] = make_uint4(perm_lo(in[0].z, in[1].z), perm_lo(in[2].z, in[3].z), perm_lo(in[4].z, in[5].z), perm_lo(in[6].z, in[7].z));
-    out[5] = make_uint4(perm_hi(in[0].z, in[1].z), perm_hi(in[2].z, in[3].z), perm_hi(in[4].z, in[5].z), perm_hi(in[6].z, in[7].z));
-    out[6] = make_uint4(perm_lo(in[0].w, in[1].w), perm_lo(in[2].w, in[3].w), perm_lo(in[4].w, in[5].w), perm_lo(in[6].w, in[7].w));
-    out[7] = make_uint4(perm_hi(in[0].w, in[1].w), perm_hi(in[2].w, in[3].w), perm_hi(in[4].w, in[5].w), perm_hi(in[6].w, in[7].w));
+    if (ACTIVE < 256 && threadIdx.x >= ACTIVE) return;
+    const int rb = threadIdx.x % RB, rest = threadIdx.x / RB;
+    const int kb = rest / TPB, sub = rest % TPB;
+    // element e (row rb*8+e) of reg[j] sits in dword e/2, half e%2
 #pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<uint4*>(lds + lds_off(rb * 8 + e, kb)) = out[e];
+    for (int e = 0; e < 8; ++e) {
+      char* dst = lds + lds_off(rb * 8 + e, kb) + sub * (KS * 2);
+      if (KS == 8) {
+        uint32_t a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (&reg[j % KS].x)[e >> 1];
+        uint4 v;
+        v.x = (e & 1) ? perm_hi(a[0], a[1]) : perm_lo(a[0], a[1]);
+        v.y = (e & 1) ? perm_hi(a[2], a[3]) : perm_lo(a[2], a[3]);
+        v.z = (e & 1) ? perm_hi(a[4], a[5]) : perm_lo(a[4], a[5]);
+        v.w = (e & 1) ? perm_hi(a[6], a[7]) : perm_lo(a[6], a[7]);
+        *reinterpret_cast<uint4*>(dst) = v;
+      } else if (KS == 4) {
+        const uint32_t a0 = (&reg[0].x)[e >> 1], a1 = (&reg[1 % KS].x)[e >> 1], a2 = (&reg[2 % KS].x)[e >> 1], a3 = (&reg[3 % KS].x)[e >> 1];
+        uint2 v;
+        v.x = (e & 1) ? perm_hi(a0, a1) : perm_lo(a0, a1);
+        v.y = (e & 1) ? perm_hi(a2, a3) : perm_lo(a2, a3);
+        *reinterpret_cast<uint2*>(dst) = v;
+      } else {
+        const uint32_t a0 = (&reg[0].x)[e >> 1], a1 = (&reg[1 % KS].x)[e >> 1];
+        *reinterpret_cast<uint32_t*>(dst) = (e & 1) ? perm_hi(a0, a1) : perm_lo(a0, a1);
+      }
+    }
   }
 };
 

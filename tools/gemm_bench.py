@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--filter", default="")
+    ap.add_argument("--sweep", action="store_true", help="also time every (tile, split-K) choice of the wgrad GEMMs")
     a = ap.parse_args()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = "cuda"
@@ -83,6 +84,18 @@ def main():
         line(f"wgrad {name} [tile {tile} splitk {sk}]", fout, fin, rows,
              bench(lambda: K.gemm(K.operand(dy, fout, layout=K.RC), K.operand(x, fin, layout=K.RC), fout, fin, rows, dw,
                                   in_dtype=dtype, splitk=sk, tile=tile), a.iters))
+        if a.sweep:        # every (tile, split-K) choice for the wgrad GEMM: the data plan_gemm's cost model is fitted to
+            cells = []
+            for t in (64, 128):
+                if t == 128 and (fout < 128 or fin < 128):
+                    continue
+                for s in (1, 2, 3, 4, 6, 8, 16):
+                    if s > 1 and rows // (64 * s) < 2:
+                        continue
+                    us = bench(lambda: K.gemm(K.operand(dy, fout, layout=K.RC), K.operand(x, fin, layout=K.RC), fout, fin, rows, dw,
+                                              in_dtype=dtype, splitk=s, tile=t), max(10, a.iters // 3))
+                    cells.append(f"{t}/{s}:{us:.1f}")
+            print("      sweep tile/splitk:us  " + "  ".join(cells))
     # the FLOP-heaviest VTN op: implicit-GEMM Conv2d 3x3 stride 2 (subsampling.py:60)
     if not a.filter or a.filter in "conv2d":
         B, T1, F1, C, O = 32, 127, 39, 384, 384
