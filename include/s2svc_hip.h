@@ -206,11 +206,25 @@ int s2svc_guided_attn_loss_fwd(int dtype, int B, int H, int To, int Ti, const vo
                                const int32_t* olens, float sigma, float alpha, float* partial, float* out, void* stream);
 int s2svc_guided_attn_loss_bwd(int dtype, int B, int H, int To, int Ti, const int32_t* ilens, const int32_t* olens,
                                float sigma, float alpha, const float* stats, const float* gout, void* datt, void* stream);
+/* masked log-domain MSE of the deterministic duration predictor (losses/duration_predictor_loss.py:38-57);   */
+/* stats[0] = number of valid tokens (kept for the backward)                                                 */
+int s2svc_duration_loss_fwd(int B, int T, const float* d_outs, const float* ds, const int32_t* lens, float offset, int mean,
+                            float* stats, float* out, void* stream);
+int s2svc_duration_loss_bwd(int B, int T, const float* d_outs, const float* ds, const int32_t* lens, float offset, int mean,
+                            const float* stats, const float* g, float* dd, void* stream);
 int64_t s2svc_forward_sum_ws_bytes(int B, int Tf, int Tx);
 int s2svc_forward_sum(int B, int Tf, int Tx, const float* log_p_attn, const float* prior, const int32_t* text_lens,
                       const int32_t* feat_lens, float log_blank, void* ws, float* loss_b, float* grad, void* stream);
 int s2svc_betabinom_prior(int B, int Tf, int Tx, const int32_t* text_lens, const int32_t* feat_lens, float* prior,
                           void* stream);
+
+/* ========================================================================================== */
+/* Token embedding of Transformer-TTS (models/transformer_tts.py:63-77, Embedding(idim, adim, */
+/* padding_idx=0)): y[i,:] = W[idx[i],:] ; dW[v,:] = sum_{idx[i]==v} dy[i,:], dW[padding]=0     */
+/* ========================================================================================== */
+int s2svc_embedding_fwd(int dtype, int64_t n, int D, int V, const int64_t* idx, const float* w, void* y, void* stream);
+int s2svc_embedding_bwd(int dtype, int64_t n, int D, int V, const int64_t* idx, const void* dy, int64_t padding_idx,
+                        float* dw, int accumulate, void* stream);
 
 /* ========================================================================================== */
 /* Stochastic duration predictor (VITS flows), channel-last rows r=(b,t), mask = t < lens[b]   */

@@ -5,6 +5,7 @@ import torch
 
 from ..modules import Lens
 from ..ops import functional_aas as FA
+from ..ops import kernels as K
 from ..ops import kernels_aas as KA
 
 
@@ -36,20 +37,42 @@ class ForwardSumLoss(torch.nn.Module):
         return FA.forward_sum_loss(log_p_attn, self._prior(il, ol, Tf, Tx, dev), il.dev, ol.dev, blank_prob)
 
 
+class _DurLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d_outs, ds, lens, offset, mean):
+        from .. import _lib
+        d, t = d_outs.float().contiguous(), ds.float().contiguous()
+        B, T = d.shape
+        stats = torch.empty(1, dtype=torch.float32, device=d.device)
+        out = torch.empty((), dtype=torch.float32, device=d.device)
+        _lib.check(_lib.lib().s2svc_duration_loss_fwd(B, T, K.ptr(d), K.ptr(t), K.ptr(lens), offset, 1 if mean else 0, K.ptr(stats),
+                                                      K.ptr(out), K.stream()), "duration_loss_fwd")
+        ctx.meta = (lens, offset, mean, d_outs.dtype)
+        ctx.save_for_backward(d, t, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib
+        d, t, stats = ctx.saved_tensors
+        lens, offset, mean, dtype = ctx.meta
+        B, T = d.shape
+        dd = torch.empty_like(d)
+        _lib.check(_lib.lib().s2svc_duration_loss_bwd(B, T, K.ptr(d), K.ptr(t), K.ptr(lens), offset, 1 if mean else 0, K.ptr(stats),
+                                                      K.ptr(g.float().contiguous()), K.ptr(dd), K.stream()), "duration_loss_bwd")
+        return (dd if dtype == torch.float32 else K.cast(dd, dtype)), None, None, None, None
+
+
 class DurationPredictorLoss(torch.nn.Module):
-    """MSE in the log domain over non-padded tokens (reference losses/duration_predictor_loss.py:5-57).
-    (B, T_text) scalars per step: evaluated with elementwise torch ops on the device."""
+    """MSE in the log domain over non-padded tokens (reference losses/duration_predictor_loss.py:5-57), one fused
+    kernel each way (csrc/loss_dur.hip)."""
 
     def __init__(self, use_masking=True, offset=1.0, reduction="mean"):
         super().__init__()
+        if reduction not in ("mean", "sum"):
+            raise NotImplementedError("reduction must be 'mean' or 'sum'")
         self.offset, self.use_masking, self.reduction = offset, use_masking, reduction
 
     def forward(self, d_outs, ds, ilens):
-        il = Lens.of(ilens, ds.device)
-        tgt = torch.log(ds.float() + self.offset)
-        err = (d_outs.float() - tgt) ** 2
-        if self.use_masking:
-            mask = torch.arange(ds.shape[1], device=ds.device)[None, :] < il.dev[:, None]
-            n = mask.sum()
-            return (err * mask).sum() / n if self.reduction == "mean" else (err * mask).sum()
-        return err.mean() if self.reduction == "mean" else err.sum()
+        lens = Lens.of(ilens, ds.device).dev if self.use_masking else None
+        return _DurLoss.apply(d_outs, ds, lens, float(self.offset), self.reduction == "mean")

@@ -488,7 +488,7 @@ class TransformerEncoder(nn.Module):
         else:
             emb = self.embed[0]
             if isinstance(emb, nn.Embedding):
-                xs = Fn.to_compute(torch.nn.functional.embedding(xs, emb.weight, emb.padding_idx))
+                xs = Fn.embedding(xs, emb.weight, emb.padding_idx)
             else:
                 xs = emb(xs)
             xs = self.embed[1](xs)

@@ -198,6 +198,31 @@ def linear(x, weight, bias=None, act=None):
     return _Linear.apply(x, weight, bias, act)
 
 
+class _Embedding(Function):
+    """Token embedding lookup (models/transformer_tts.py:63-77) in the compute dtype; deterministic weight gradient."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, padding_idx):
+        idx = idx.contiguous()
+        ctx.weight, ctx.padding_idx = weight, padding_idx
+        ctx.save_for_backward(idx)
+        return K.embedding_fwd(idx, weight.detach(), compute_dtype())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        weight = ctx.weight
+        dw = None
+        if weight.requires_grad:
+            dw = _emit_wgrad(weight, tuple(weight.shape),
+                             lambda out, acc: K.embedding_bwd(idx, _c(dy), weight.shape[0], ctx.padding_idx, out=out, accumulate=acc))
+        return None, dw, None
+
+
+def embedding(idx, weight, padding_idx=None):
+    return _Embedding.apply(idx, weight, padding_idx)
+
+
 # ================================================================================================
 # LayerNorm, optionally fused with "s = res + hscale * dropout(h)"
 # reference: modules/transformer/layer_norm.py:12-42 + residual/dropout lines of the layer classes

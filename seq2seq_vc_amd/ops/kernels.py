@@ -345,6 +345,23 @@ def cast(x, dtype):
     return y
 
 
+def embedding_fwd(idx, w, out_dtype):
+    """idx int64 (...,), w fp32 (V, D) -> (..., D)."""
+    V, D = w.shape
+    idx = idx.contiguous()
+    y = torch.empty((*idx.shape, D), dtype=out_dtype, device=w.device)
+    _lib.check(_lib.lib().s2svc_embedding_fwd(_DT[out_dtype], idx.numel(), D, V, ptr(idx), ptr(w), ptr(y), stream()), "embedding_fwd")
+    return y
+
+
+def embedding_bwd(idx, dy, V, padding_idx, out=None, accumulate=False):
+    D = dy.shape[-1]
+    dw = torch.empty((V, D), dtype=torch.float32, device=dy.device) if out is None else out
+    _lib.check(_lib.lib().s2svc_embedding_bwd(dt(dy), idx.numel(), D, V, ptr(idx), ptr(dy), -1 if padding_idx is None else padding_idx,
+                                              ptr(dw), 1 if accumulate else 0, stream()), "embedding_bwd")
+    return dw
+
+
 def gather3(x, n, strides, off, out_dtype):
     """out[i0,i1,i2] = x.flat[off + i0*s0 + i1*s1 + i2*s2] (contiguous result of shape n)."""
     y = torch.empty(n, dtype=out_dtype, device=x.device)

@@ -179,6 +179,49 @@ def stft_logmel_frontend():
     return res
 
 
+@case
+@both_dtypes
+def embedding_and_duration_loss(dtype):
+    """Transformer-TTS token embedding (padding_idx row gets no gradient) and the deterministic duration loss."""
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd.ops import functional as Fn
+    res = []
+    Fn.set_compute_dtype(dtype)
+    try:
+        V, D, B, T = 30, 48, 4, 17
+        g = torch.Generator().manual_seed(3)
+        idx = torch.randint(0, V, (B, T), generator=g).to(DEV)
+        idx[0, -3:] = 0
+        w = rnd(V, D, seed=1).requires_grad_(True)
+        wr = w.detach().clone().requires_grad_(True)
+        y = Fn.embedding(idx, w, 0)
+        yr = F.embedding(idx, wr, 0)
+        res.append(check(f"embedding fwd[{dtype}]", y, yr, dtype, atol=0.0 if dtype == torch.float32 else 1e-2))
+        dy = rnd(B, T, D, seed=2, dtype=dtype)
+        y.backward(dy)
+        yr.backward(dy.float())
+        res.append(check(f"embedding dW[{dtype}]", w.grad, wr.grad, dtype, atol=1e-5 if dtype == torch.float32 else 0.1))
+        res.append(check(f"embedding dW[padding_idx] == 0 [{dtype}]", w.grad[0], torch.zeros(D), torch.float32, atol=0.0))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    if dtype == torch.float32:
+        B, T = 3, 19
+        lens = torch.tensor([19, 11, 4])
+        d = rnd(B, T, seed=4).requires_grad_(True)
+        ds = torch.randint(0, 9, (B, T), generator=torch.Generator().manual_seed(5)).float().to(DEV)
+        dr = d.detach().clone().requires_grad_(True)
+        m = _lens_mask(lens.to(DEV).int(), T)
+        for reduction in ("mean", "sum"):
+            d.grad = dr.grad = None
+            ref = torch.nn.MSELoss(reduction=reduction)(dr.masked_select(m), torch.log(ds + 1.0).masked_select(m))
+            got = L.DurationPredictorLoss(reduction=reduction)(d, ds, lens)
+            res.append(check(f"duration loss {reduction}", got.view(1), ref.detach().view(1), torch.float32, atol=1e-5, rtol=1e-5))
+            (got * 1.7).backward()
+            (ref * 1.7).backward()
+            res.append(check(f"duration loss {reduction} grad", d.grad, dr.grad, torch.float32, atol=1e-6, rtol=1e-5))
+    return res
+
+
 def _lens_mask(lens, T):
     return (torch.arange(T, device=DEV)[None, :] < lens[:, None].long())
 
