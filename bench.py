@@ -109,9 +109,18 @@ def dominant_kernel_roofline(dtype, iters=20):
     flops = 2.0 * M * N * Kd
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == torch.bfloat16 else F32_MFMA_PEAK_TFLOPS
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<%s,128,128> conv2d-3x3-s2 implicit GEMM M=%d N=%d K=%d" %
-            ("bf16" if dtype == torch.bfloat16 else "f32", M, N, Kd), "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": None, "avg_launch_us": ms * 1e3, "flops_per_launch": flops}
+    kernel = ("gemm_glds_kernel<128,128,KC_CONV2D,KC_DENSE> (bf16, LDS-DMA staged)" if dtype == torch.bfloat16
+              else "gemm_fast_kernel<float,128,128,32> (exact-fp32 MFMA)")
+    # HBM-side bytes per launch come from rocprofv3 PMC passes of exactly this loop (they cannot be read from inside the
+    # process): profiles/roofline_pmc.json holds (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes.
+    traffic, alg_bytes = None, float((x.numel() + w.numel() + y.numel()) * x.element_size())
+    pmc = os.path.join(ROOT, "profiles", "roofline_pmc.json")
+    if dtype == torch.bfloat16 and os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
+    return {"bound": "mfma", "kernel": kernel + " conv2d-3x3-s2 implicit GEMM M=%d N=%d K=%d" % (M, N, Kd), "achieved": ach,
+            "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "algorithmic_bytes": alg_bytes,
+            "avg_launch_us": ms * 1e3, "flops_per_launch": flops}
 
 
 def main():
