@@ -84,6 +84,17 @@ typedef struct {
   float* a_rowsum_ws;
   int32_t a_rowsum_accumulate;
   int32_t tile_hint;       /* 0 = auto, 64 or 128: output tile edge chosen by the caller's cost model */
+  /* optional epilogue stage between the activation and the residual (needs nb0*nb1 == 1, ldc == N):               */
+  /*   v *= dropout_scale(*seed_base + seed_off, m*N + n, drop_p)   -- the mask the standalone dropout kernels draw */
+  /*   v  = emask[m*ldm + n] > 0 ? v : 0                            -- emask has the dtype of C                     */
+  /* fuses `dropout(relu(x W1^T))` into the forward GEMM and `dY W2 * dropmask * relu'(h)` into the dgrad GEMM of   */
+  /* positionwise_feed_forward.py:30-32, and relu' of subsampling.py:58-60 into the dgrad of the Linear after it.  */
+  const void* emask;
+  int64_t ldm;
+  float drop_p;
+  int32_t reserved2_;
+  const uint64_t* seed_base;
+  uint64_t seed_off;
 } s2svc_gemm_desc;
 
 int s2svc_gemm(const s2svc_gemm_desc* desc /* host */, void* stream);

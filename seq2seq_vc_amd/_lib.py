@@ -24,7 +24,8 @@ def sources():
 def build_library(force=False, verbose=True):
     """Compile csrc/*.hip -> csrc/libs2svc_hip.so for gfx950 (in-tree, so it travels to the GPU box)."""
     srcs = [os.path.join(CSRC, f) for f in sources()]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(_HERE, "..", "include", "s2svc_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
+                   os.path.join(_HERE, "..", "include", "s2svc_hip.h")]
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(p) for p in deps)
         if os.path.getmtime(LIB_PATH) >= newest:
@@ -67,7 +68,9 @@ class GemmDesc(ctypes.Structure):
                 ("c_dtype", c_i32), ("bias", c_vp), ("res", c_vp), ("ldr", c_i64), ("rbs0", c_i64), ("rbs1", c_i64),
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("nb0", c_i32), ("nb1", c_i32), ("act", c_i32),
                 ("alpha", c_f32), ("dtype", c_i32), ("accumulate", c_i32), ("splitk", c_i32), ("ws", c_vp),
-                ("a_rowsum", c_vp), ("a_rowsum_ws", c_vp), ("a_rowsum_accumulate", c_i32), ("tile_hint", c_i32)]
+                ("a_rowsum", c_vp), ("a_rowsum_ws", c_vp), ("a_rowsum_accumulate", c_i32), ("tile_hint", c_i32),
+                ("emask", c_vp), ("ldm", c_i64), ("drop_p", c_f32), ("reserved2_", c_i32), ("seed_base", c_vp),
+                ("seed_off", c_u64)]
 
 
 _SIGS = {

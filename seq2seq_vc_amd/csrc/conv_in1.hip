@@ -20,14 +20,17 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&r)[8]) {
   *reinterpret_cast<uint4*>(p) = v;
 }
 
-// each thread: one output pixel x 8 consecutive channels (one 16-byte store for bf16, two for fp32)
+// each thread: one output pixel x 8 consecutive channels (one 16-byte store for bf16, two for fp32).  Weights sit in
+// LDS tap-major ([tap][O], bias as a 10th row) so that the 8 channels of a thread are two 16-byte LDS reads per tap
+// and lanes with consecutive channel groups read consecutive addresses (channel-major [O][9] put lanes 72 floats
+// apart: 4-way bank conflicts on 72 scalar reads per thread, which made the kernel LDS-bound at 0.46 TB/s).
 template <typename T>
 __global__ __launch_bounds__(256) void conv_in1_fwd_kernel(int B, int Tn, int Fn, int T1, int F1, int O, const T* __restrict__ x,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
                                                            T* __restrict__ y) {
-  extern __shared__ float sw[];  // O*9 weights + O biases
-  for (int i = threadIdx.x; i < O * 9; i += 256) sw[i] = w[i];
-  for (int i = threadIdx.x; i < O; i += 256) sw[O * 9 + i] = bias ? bias[i] : 0.f;
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [10][O]: 9 taps + bias
+  for (int i = threadIdx.x; i < O * 9; i += 256) sw[(i % 9) * O + i / 9] = w[i];
+  for (int i = threadIdx.x; i < O; i += 256) sw[9 * O + i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int og = O / 8;
   const int64_t n = (int64_t)B * T1 * F1 * og;
@@ -44,14 +47,18 @@ __global__ __launch_bounds__(256) void conv_in1_fwd_kernel(int B, int Tn, int Fn
       for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = ldf(x + ((int64_t)b * Tn + 2 * t1 + kh) * Fn + 2 * f1 + kw);
     T* yo = y + (i / og) * O + g * 8;
     float r[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int o = g * 8 + e;
-      float acc = sw[O * 9 + o];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) acc += sw[o * 9 + k] * xv[k];
-      r[e] = acc > 0.f ? acc : 0.f;
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(sw + 9 * O + g * 8), b1 = *reinterpret_cast<const float4*>(sw + 9 * O + g * 8 + 4);
+      r[0] = b0.x; r[1] = b0.y; r[2] = b0.z; r[3] = b0.w; r[4] = b1.x; r[5] = b1.y; r[6] = b1.z; r[7] = b1.w;
     }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float4 w0 = *reinterpret_cast<const float4*>(sw + k * O + g * 8), w1 = *reinterpret_cast<const float4*>(sw + k * O + g * 8 + 4);
+      r[0] += w0.x * xv[k]; r[1] += w0.y * xv[k]; r[2] += w0.z * xv[k]; r[3] += w0.w * xv[k];
+      r[4] += w1.x * xv[k]; r[5] += w1.y * xv[k]; r[6] += w1.z * xv[k]; r[7] += w1.w * xv[k];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = r[e] > 0.f ? r[e] : 0.f;
     store8(yo, r);   // 16-byte (bf16) / 2 x 16-byte (fp32) coalesced stores
   }
 }

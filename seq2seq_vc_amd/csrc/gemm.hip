@@ -16,7 +16,7 @@
 #include <stdlib.h>
 #include <cstdio>
 #include <cstdlib>
-#include "common.h"
+#include "gemm_common.h"
 #include "../../include/s2svc_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -172,24 +172,6 @@ template <int FM, int FN> struct Mma<float, FM, FN> {
   }
 };
 
-__device__ __forceinline__ void epilogue_store(const s2svc_gemm_desc& d, int z0, int z1, int m, int n, float v) {
-  v *= d.alpha;
-  if (d.bias) v += d.bias[n];
-  v = act_apply(v, d.act);
-  const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
-  if (d.res) {
-    const int64_t ro = (int64_t)z0 * d.rbs0 + (int64_t)z1 * d.rbs1 + (int64_t)m * d.ldr + n;
-    v += d.c_dtype == S2S_F32 ? ((const float*)d.res)[ro] : bf2f(((const bf16_t*)d.res)[ro]);
-  }
-  if (d.c_dtype == S2S_F32) {
-    float* c = (float*)d.C + co;
-    *c = d.accumulate ? *c + v : v;
-  } else {
-    bf16_t* c = (bf16_t*)d.C + co;
-    *c = f2bf(d.accumulate ? bf2f(*c) + v : v);
-  }
-}
-
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const s2svc_gemm_desc d) {
   constexpr int PITCH = TileCfg<T>::PITCH;
@@ -273,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const s2svc_gemm_desc d) {
             const int nbatch = d.nb0 * d.nb1;
             d.ws[(((int64_t)zs * nbatch + zb) * d.M + m) * d.N + n] = acc[i][j][r];
           } else {
-            epilogue_store(d, z0, z1, m, n, acc[i][j][r]);
+            epilogue_store_f(d, z0, z1, m, n, acc[i][j][r]);
           }
         }
       }
@@ -289,7 +271,7 @@ __global__ void splitk_reduce_kernel(const s2svc_gemm_desc d) {
     const int64_t t = i / d.N;
     const int m = (int)(t % d.M);
     const int zb = (int)(t / d.M);
-    epilogue_store(d, zb / d.nb1, zb % d.nb1, m, n, s);
+    epilogue_store_f(d, zb / d.nb1, zb % d.nb1, m, n, s);
   }
   if (d.a_rowsum) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.M; i += (int64_t)gridDim.x * blockDim.x) {
@@ -298,6 +280,31 @@ __global__ void splitk_reduce_kernel(const s2svc_gemm_desc d) {
       d.a_rowsum[i] = (d.a_rowsum_accumulate ? d.a_rowsum[i] : 0.f) + s;
     }
   }
+}
+
+// second pass for the kernels whose epilogue does not carry the dropout / mask stage: C = stage(C) in place
+__global__ void gemm_stage_kernel(const s2svc_gemm_desc d) {
+  const int64_t total = (int64_t)d.M * d.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / d.N), n = (int)(i - (int64_t)m * d.N);
+    const int64_t co = (int64_t)m * d.ldc + n;
+    if (d.c_dtype == S2S_F32) {
+      float* c = (float*)d.C + co;
+      *c = epilogue_stage_f(d, m, n, *c);
+    } else {
+      bf16_t* c = (bf16_t*)d.C + co;
+      *c = f2bf(epilogue_stage_f(d, m, n, bf2f(*c)));
+    }
+  }
+}
+
+int launch_stage_pass(const s2svc_gemm_desc& d, hipStream_t st) {
+  const int64_t total = (int64_t)d.M * d.N;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gemm_stage_kernel, dim3(blocks), dim3(256), 0, st, d);
+  S2S_CHECK_LAUNCH("gemm_stage_kernel");
+  return 0;
 }
 
 template <typename T, int BM, int BN>
@@ -343,10 +350,21 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   S2S_REQUIRE(d.A.mode == S2SVC_OP_DENSE || d.A.C > 0, "s2svc_gemm: conv operand A needs C");
   S2S_REQUIRE(d.B.mode == S2SVC_OP_DENSE || d.B.C > 0, "s2svc_gemm: conv operand B needs C");
   hipStream_t st = (hipStream_t)stream;
+  // dropout / mask stage: native in the LDS-DMA kernels' epilogue; every other kernel family gets it as a second pass
+  // over C (which is only the same thing when nothing is added to C after the stage)
+  const bool staged = d.drop_p > 0.f || d.emask != nullptr;
+  S2S_REQUIRE(!staged || (d.nb0 * d.nb1 == 1 && d.ldc == d.N), "s2svc_gemm: the dropout/mask stage needs an unbatched contiguous C");
+  S2S_REQUIRE(!staged || d.drop_p < 1.f, "s2svc_gemm: drop_p must be < 1");
+  auto finish = [&](bool stage_done) -> int {
+    if (!staged || stage_done) return 0;
+    S2S_REQUIRE(!d.res && !d.accumulate, "s2svc_gemm: dropout/mask stage with residual/accumulate needs the LDS-DMA kernel");
+    return launch_stage_pass(d, st);
+  };
   if (!generic_forced()) {
     const int rs = s2svc_gemm_try_skinny(&d, stream);
-    if (rs != 0) return rs < 0 ? rs : 0;
+    if (rs != 0) return rs < 0 ? rs : finish(false);
     int rc = s2svc_gemm_try_glds(&d, stream);
+    const bool native_stage = rc == 1 && d.splitk <= 1;
     if (rc == 0) rc = s2svc_gemm_try_fast(&d, stream);
     if (rc < 0) return rc;
     if (rc == 1) {
@@ -357,7 +375,7 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, d);
         S2S_CHECK_LAUNCH("splitk_reduce_kernel");
       }
-      return 0;
+      return finish(native_stage);
     }
   }
   {  // S2SVC_GEMM_LOG=1: report every problem the specialised kernels declined (tuning aid)
@@ -370,6 +388,8 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   }
   const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1 * (d.splitk > 1 ? d.splitk : 1);
   const bool big = tiles128 >= 384 && d.M >= 128 && d.N >= 128;
-  if (d.dtype == S2S_F32) return big ? launch<float, 128, 128>(d, st) : launch<float, 64, 64>(d, st);
-  return big ? launch<bf16_t, 128, 128>(d, st) : launch<bf16_t, 64, 64>(d, st);
+  int rg;
+  if (d.dtype == S2S_F32) rg = big ? launch<float, 128, 128>(d, st) : launch<float, 64, 64>(d, st);
+  else rg = big ? launch<bf16_t, 128, 128>(d, st) : launch<bf16_t, 64, 64>(d, st);
+  return rg < 0 ? rg : finish(false);
 }

@@ -6,11 +6,30 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-// C[m, n] (batch z0, z1) = act(alpha * v + bias[n]) + res[m, n]  (+ C when accumulating), stored in c_dtype
+// the optional stage between activation and residual: v * dropmask(m*N + n) * (emask[m, n] > 0)
+__device__ __forceinline__ float epilogue_stage_f(const s2svc_gemm_desc& d, int m, int n, float v) {
+  if (d.drop_p > 0.f) {
+    const uint64_t seed = (d.seed_base ? *d.seed_base : 0ull) + d.seed_off;
+    v *= dropout_scale(seed, (uint64_t)((int64_t)m * d.N + n), d.drop_p, 1.f / (1.f - d.drop_p));
+  }
+  if (d.emask) {
+    const int64_t mo = (int64_t)m * d.ldm + n;
+    const float e = d.c_dtype == S2S_F32 ? ((const float*)d.emask)[mo] : bf2f(((const bf16_t*)d.emask)[mo]);
+    v = e > 0.f ? v : 0.f;
+  }
+  return v;
+}
+
+// C[m, n] (batch z0, z1) = act(alpha * v + bias[n]) [stage] + res[m, n]  (+ C when accumulating), stored in c_dtype.
+// STAGED = false is what the register-staged kernels (gemm.hip, gemm_fast.hip, gemm_skinny.hip) inline 64x into
+// their unrolled accumulator loops: it must stay small, or hipcc stops unrolling, indexes the accumulators at run time
+// and demotes them to scratch memory.  Those kernels get the stage from gemm_stage_kernel (gemm.hip) as a second pass.
+template <bool STAGED = false>
 __device__ __forceinline__ void epilogue_store_f(const s2svc_gemm_desc& d, int z0, int z1, int m, int n, float v) {
   v *= d.alpha;
   if (d.bias) v += d.bias[n];
   v = act_apply(v, d.act);
+  if (STAGED) v = epilogue_stage_f(d, m, n, v);
   const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
   if (d.res) {
     const int64_t ro = (int64_t)z0 * d.rbs0 + (int64_t)z1 * d.rbs1 + (int64_t)m * d.ldr + n;
@@ -36,12 +55,13 @@ __device__ __forceinline__ void epilogue_store_f(const s2svc_gemm_desc& d, int z
 __device__ __forceinline__ bool epilogue_vec_ok(const s2svc_gemm_desc& d) {
   bool ok = (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.cbs0 % 8 == 0) && (d.cbs1 % 8 == 0) && (((uintptr_t)d.C) % 16 == 0);
   if (d.res) ok = ok && (d.ldr % 8 == 0) && (d.rbs0 % 8 == 0) && (d.rbs1 % 8 == 0) && (((uintptr_t)d.res) % 16 == 0);
+  if (d.emask) ok = ok && (d.ldm % 8 == 0) && (((uintptr_t)d.emask) % 16 == 0);
   return ok;
 }
 
 template <int WTM, int WTN>
-__device__ __forceinline__ void epilogue_via_lds(const s2svc_gemm_desc& d, int z0, int z1, int m_base, int n_base,
-                                                 const f32x4_t (&acc)[WTM / 16][WTN / 16], float* cs) {
+__device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, int z1, int m_base, int n_base,
+                                              const f32x4_t (&acc)[WTM / 16][WTN / 16], float* cs, int splitk, int zs, int zb) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int i = 0; i < WTM / 16; ++i)
@@ -52,9 +72,26 @@ __device__ __forceinline__ void epilogue_via_lds(const s2svc_gemm_desc& d, int z
         const int row = i * 16 + lg * 4 + r, col = j * 16 + lr;
         cs[row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4))] = acc[i][j][r];
       }
+  if (splitk > 1 || !epilogue_vec_ok(d)) {
+    // element-wise path (split-K partials, unaligned C): still read back from LDS, so that the accumulator registers
+    // are only ever indexed by compile-time constants (a runtime-indexed acc[][] is demoted to scratch memory and
+    // spilled inside the K loop) and consecutive lanes touch consecutive columns
+#pragma unroll 1
+    for (int e = lane; e < WTM * WTN; e += 64) {
+      const int row = e / WTN, col = e - row * WTN;
+      const int m = m_base + row, n = n_base + col;
+      if (m >= d.M || n >= d.N) continue;
+      const float v = cs[row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4))];
+      if (splitk > 1) d.ws[(((int64_t)zs * (d.nb0 * d.nb1) + zb) * d.M + m) * d.N + n] = v;
+      else epilogue_store_f<true>(d, z0, z1, m, n, v);
+    }
+    return;
+  }
   constexpr int LPR = WTN / 8;          // lanes per row
   constexpr int RPP = 64 / LPR;         // rows per pass
-#pragma unroll
+  // NOT unrolled: the body is load/store bound, and unrolling it (8 passes x 8 values x Philox state) raised the
+  // register demand of the whole kernel until hipcc spilled the MFMA accumulators inside the K loop (5x slower)
+#pragma unroll 1
   for (int p = 0; p < WTM / RPP; ++p) {
     const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
     const int m = m_base + row, n = n_base + col;
@@ -74,6 +111,40 @@ __device__ __forceinline__ void epilogue_via_lds(const s2svc_gemm_desc& d, int z
     if (d.act != S2S_ACT_NONE) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], d.act);
+    }
+    if (d.drop_p > 0.f) {
+      const uint64_t seed = (d.seed_base ? *d.seed_base : 0ull) + d.seed_off;
+      const float inv_keep = 1.f / (1.f - d.drop_p);
+      const uint64_t idx = (uint64_t)((int64_t)m * d.N + n);
+      // idx is a multiple of 8 (N % 8 == 0, col % 8 == 0): two Philox calls cover the 8 values, exactly the draws
+      // dropout_scale(seed, idx + e) makes for them
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint4 r = philox4(seed, (idx >> 2) + q);
+        const uint32_t w4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float u = (float)(w4[e] >> 8) * (1.0f / 16777216.0f);
+          v[4 * q + e] *= u < d.drop_p ? 0.f : inv_keep;
+        }
+      }
+    }
+    if (d.emask) {
+      const int64_t mo = (int64_t)m * d.ldm + n;
+      if (d.c_dtype == S2S_F32) {
+        const float4 e0 = *reinterpret_cast<const float4*>((const float*)d.emask + mo), e1 = *reinterpret_cast<const float4*>((const float*)d.emask + mo + 4);
+        const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ee[e] > 0.f ? v[e] : 0.f;
+      } else {
+        const uint4 ev = *reinterpret_cast<const uint4*>((const bf16_t*)d.emask + mo);
+        const uint32_t w[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = __uint_as_float(w[e] << 16) > 0.f ? v[2 * e] : 0.f;
+          v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) > 0.f ? v[2 * e + 1] : 0.f;
+        }
+      }
     }
     const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
     if (d.res) {

@@ -312,29 +312,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const s2svc_gemm_desc d)
       else d.a_rowsum[m] = (d.a_rowsum_accumulate ? d.a_rowsum[m] : 0.f) + rowsum;
     }
   }
-  if (sizeof(smem) >= (size_t)BM * BN * 4 && splitk == 1 && epilogue_vec_ok(d)) {
-    __syncthreads();             // every wave is done with the operand stages: reuse them as fp32 C tiles
-    float* cs = reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2);
-    epilogue_via_lds<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, cs);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm + i * 16 + lg * 4 + r;
-        const int n = n0 + wn + j * 16 + lr;
-        if (m < d.M && n < d.N) {
-          if (splitk > 1) {
-            const int nbatch = d.nb0 * d.nb1;
-            d.ws[(((int64_t)zs * nbatch + zb) * d.M + m) * d.N + n] = acc[i][j][r];
-          } else {
-            epilogue_store_f(d, z0, z1, m, n, acc[i][j][r]);
-          }
-        }
-      }
+  static_assert(sizeof(smem) >= (size_t)BM * BN * 4, "the operand stages double as the fp32 C tiles of the epilogue");
+  __syncthreads();               // every wave is done with the operand stages: reuse them as fp32 C tiles
+  epilogue_tile<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2),
+                                splitk, zs, zb);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -415,29 +396,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const s2svc_gemm_desc d) 
   }
   wait_vmcnt<0>();                                      // the zero-block DMAs issued past the end
 
-  if (sizeof(smem) >= (size_t)BM * BN * 4 && splitk == 1 && epilogue_vec_ok(d)) {
-    __syncthreads();             // every wave is done with the operand stages: reuse them as fp32 C tiles
-    float* cs = reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2);
-    epilogue_via_lds<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, cs);
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm + i * 16 + lg * 4 + r;
-        const int n = n0 + wn + j * 16 + lr;
-        if (m < d.M && n < d.N) {
-          if (splitk > 1) {
-            const int nbatch = d.nb0 * d.nb1;
-            d.ws[(((int64_t)zs * nbatch + zb) * d.M + m) * d.N + n] = acc[i][j][r];
-          } else {
-            epilogue_store_f(d, z0, z1, m, n, acc[i][j][r]);
-          }
-        }
-      }
+  static_assert(sizeof(smem) >= (size_t)BM * BN * 4, "the operand stages double as the fp32 C tiles of the epilogue");
+  __syncthreads();               // every wave is done with the operand stages: reuse them as fp32 C tiles
+  epilogue_tile<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2),
+                                splitk, zs, zb);
 }
 
 int dma_stages() {       // S2SVC_GEMM_STAGES override (0 = built-in policy), see launch_kinds
@@ -461,19 +423,12 @@ bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
     return true;                                                                                   \
   }
   // all-DMA operands: the 64x64 tile runs the 3-stage counted-wait pipeline (48 KB LDS, 3 workgroups per CU); the
-  // 128x128 tile keeps two stages (64 KB, 2 workgroups per CU -- a third stage would leave one workgroup per CU and
-  // measured ~2x slower).  S2SVC_GEMM_STAGES = 2 | 3 | 4 | 13 | 14 (1x = BK 32) overrides both for A/B runs.
+  // 128x128 tile keeps two stages (64 KB, 2 workgroups per CU -- a third stage leaves one workgroup per CU and
+  // measured ~2x slower; BK = 32 with 3-4 stages measured 10-15 % slower).  S2SVC_GEMM_STAGES=2 forces two stages.
 #define S2S_DMA_CASE(KA, KB)                                                                        \
-  if (ka == KA && kb == KB && !d.a_rowsum) {                                                       \
-    const int cfg = dma_stages() ? dma_stages() : (BM == 64 ? 3 : 2);                              \
-    const int ns = cfg % 10, bk = cfg >= 10 ? 32 : 64;                                             \
-    if (ns >= 3) {                                                                                 \
-      if (bk == 64 && ns == 3) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, KA, KB, 3, 64>), grid, dim3(256), 0, st, d); \
-      else if (bk == 64) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, KA, KB, 4, 64>), grid, dim3(256), 0, st, d);     \
-      else if (ns == 3) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, KA, KB, 3, 32>), grid, dim3(256), 0, st, d);      \
-      else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, KA, KB, 4, 32>), grid, dim3(256), 0, st, d); \
-      return true;                                                                                 \
-    }                                                                                              \
+  if (ka == KA && kb == KB && !d.a_rowsum && BM == 64 && dma_stages() != 2) {                      \
+    hipLaunchKernelGGL((gemm_dma_kernel<64, 64, KA, KB, 3, 64>), grid, dim3(256), 0, st, d);       \
+    return true;                                                                                   \
   }
   S2S_DMA_CASE(G_KC_DENSE, G_KC_DENSE)
   S2S_DMA_CASE(G_KC_CONV1D, G_KC_DENSE)

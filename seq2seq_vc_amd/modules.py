@@ -229,9 +229,8 @@ class PositionwiseFeedForward(nn.Module):
 
     def forward(self, x):
         p = self.dropout_rate if self.training else 0.0
-        if self.activation == "relu":
-            h = Fn.linear(x, self.w_1.weight, self.w_1.bias, act="relu")
-            h = Fn.dropout(h, p)
+        if self.activation == "relu":      # both GEMMs + dropout / relu masks in their epilogues
+            return Fn.ffn_relu(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, p)
         else:
             h = Fn.act_dropout(Fn.linear(x, self.w_1.weight, self.w_1.bias), self.activation, p)
         return Fn.linear(h, self.w_2.weight, self.w_2.bias)
@@ -385,10 +384,11 @@ class Conv2dSubsampling(nn.Module):
             y = Fn.conv_in1_relu(x, c0.weight, c0.bias)              # direct streaming kernel (C_in = 1)
         else:
             y = Fn.conv2d_s2_relu(x.reshape(B, T, idim, 1), c0.weight, c0.bias)
-        y = Fn.conv2d_s2_relu(y, c2.weight, c2.bias)          # (B, T2, F2, C) channel-last
+        y = Fn.conv2d_s2_relu(y, c2.weight, c2.bias, grad_premasked=True)   # (B, T2, F2, C) channel-last
         _, T2, F2, C = y.shape
         lin = self.out[0] if self.use_pos_enc else self.out
-        y = Fn.linear_fc_permuted(y.reshape(B * T2, F2 * C), lin.weight, lin.bias, C, F2).view(B, T2, self.odim)
+        # the Linear is the only consumer of the ReLU output: its dgrad epilogue applies relu' (no mask pass over 15 M values)
+        y = Fn.linear_fc_permuted(y.reshape(B * T2, F2 * C), lin.weight, lin.bias, C, F2, input_is_relu=True).view(B, T2, self.odim)
         if self.use_pos_enc:
             y = self.out[1](y)
         return y, self.out_lens(lens, T2, exact_lens)

@@ -198,6 +198,67 @@ def linear(x, weight, bias=None, act=None):
     return _Linear.apply(x, weight, bias, act)
 
 
+class _FFNRelu(Function):
+    """w_2(dropout(relu(w_1 x)))  (positionwise_feed_forward.py:30-32) as two GEMMs forward and four backward: the
+    dropout mask rides in the first GEMM's epilogue, and the dgrad GEMM through w_2 applies dropmask * relu' in its
+    epilogue (h > 0 <=> relu active and kept), so no element-wise pass over the (rows, hidden) tensor remains."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p):
+        dtype = x.dtype
+        x2 = _c(x).view(-1, x.shape[-1])
+        M, Kd = x2.shape
+        Hd, N = w1.shape[0], w2.shape[0]
+        w1c, w2c = _wcast(w1, dtype), _wcast(w2, dtype)
+        seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
+        h = torch.empty((M, Hd), dtype=dtype, device=x.device)
+        K.gemm(K.operand(x2, Kd), K.operand(w1c, Kd), M, Hd, Kd, h, in_dtype=dtype, bias=b1, act="relu", drop_p=p, seed=seed)
+        y = torch.empty((M, N), dtype=dtype, device=x.device)
+        K.gemm(K.operand(h, Hd), K.operand(w2c, Hd), M, N, Hd, y, in_dtype=dtype, bias=b2)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.meta = (p, seed, x.shape)
+        ctx.save_for_backward(x2, h, w1c, w2c)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, w1c, w2c = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        p, seed, xshape = ctx.meta
+        M, Kd = x2.shape
+        Hd, N = w1c.shape[0], w2c.shape[0]
+        dtype = x2.dtype
+        dy2 = _c(dy).view(M, N)
+        # du = (dY W2) * dropmask * relu'(u): gradient at the pre-activation, straight out of the GEMM
+        du = torch.empty((M, Hd), dtype=dtype, device=dy.device)
+        K.gemm(K.operand(dy2, N), K.operand(w2c, Hd, layout=K.RC), M, Hd, N, du, in_dtype=dtype, emask=h, drop_p=p, seed=seed)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
+            K.gemm(K.operand(du, Hd), K.operand(w1c, Kd, layout=K.RC), M, Kd, Hd, dx, in_dtype=dtype)
+            dx = dx.view(xshape)
+
+        def wgrad(weight, bias, g, a, n_out, n_in):
+            tile, sk = K.plan_gemm(n_out, n_in, M)
+            rs, racc, db = _bias_sink(bias, n_out)
+
+            def wr(out, acc):
+                K.gemm(K.operand(g, n_out, layout=K.RC), K.operand(a, n_in, layout=K.RC), n_out, n_in, M, out, in_dtype=dtype,
+                       splitk=sk, tile=tile, accumulate=acc, a_rowsum=rs, a_rowsum_accumulate=racc)
+            if _slotted(weight, bias):
+                _side_run(lambda: _emit_wgrad(weight, (n_out, n_in), wr), keep=(g, a))
+                return None, None
+            dw = _emit_wgrad(weight, (n_out, n_in), wr)
+            return (dw.view(weight.shape) if dw is not None else None), db
+        dw2, db2 = wgrad(w2, b2, dy2, h, N, Hd) if w2.requires_grad else (None, None)
+        dw1, db1 = wgrad(w1, b1, du, x2, Hd, Kd) if w1.requires_grad else (None, None)
+        return dx, dw1, db1, dw2, db2, None
+
+
+def ffn_relu(x, w1, b1, w2, b2, p=0.0):
+    return _FFNRelu.apply(x, w1, b1, w2, b2, p)
+
+
 class _Embedding(Function):
     """Token embedding lookup (models/transformer_tts.py:63-77) in the compute dtype; deterministic weight gradient."""
 
@@ -698,8 +759,9 @@ def conv1d(x, weight, bias=None, act=None):
 # ================================================================================================
 class _Conv2dS2(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, grad_premasked=False):
         x = _c(x)
+        ctx.grad_premasked = grad_premasked
         B, T1, F1, C = x.shape
         O = weight.shape[0]
         T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
@@ -721,7 +783,8 @@ class _Conv2dS2(Function):
         T2, F2 = y.shape[1], y.shape[2]
         M2 = B * T2 * F2
         dtype = x.dtype
-        dy = K.act_dropout_bwd(_c(dy), y, act="relu")
+        # the consumer may already have applied relu' in its dgrad epilogue (linear_fc_permuted(..., input_is_relu=True))
+        dy = _c(dy) if ctx.grad_premasked else K.act_dropout_bwd(_c(dy), y, act="relu")
         dx = None
         if ctx.needs_input_grad[0]:
             dcols = torch.empty((M2, 9 * C), dtype=dtype, device=x.device)
@@ -744,11 +807,13 @@ class _Conv2dS2(Function):
                 dw, db = work()
         elif bias is not None and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy.view(M2, O))
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def conv2d_s2_relu(x_nhwc, weight, bias):
-    return _Conv2dS2.apply(x_nhwc, weight, bias)
+def conv2d_s2_relu(x_nhwc, weight, bias, grad_premasked=False):
+    """grad_premasked=True: the ONLY consumer of the result hands back a gradient that already carries relu'
+    (see linear_fc_permuted(input_is_relu=True)); the backward then skips its own mask pass."""
+    return _Conv2dS2.apply(x_nhwc, weight, bias, grad_premasked)
 
 
 class _ConvIn1(Function):
@@ -786,8 +851,9 @@ class _LinearPermuted(Function):
     (subsampling.py:64-70 flattens (c, f); our activations are (f, c) channel-last)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, C, Fd):
+    def forward(ctx, x, weight, bias, C, Fd, input_is_relu=False):
         x = _c(x)
+        ctx.input_is_relu = input_is_relu
         dtype = x.dtype
         D = weight.shape[0]
         M = x.numel() // (C * Fd)
@@ -812,7 +878,8 @@ class _LinearPermuted(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=x.device)
-            K.gemm(K.operand(dy, D), K.operand(wp, Kd, layout=K.RC), M, Kd, D, dx, in_dtype=dtype)
+            K.gemm(K.operand(dy, D), K.operand(wp, Kd, layout=K.RC), M, Kd, D, dx, in_dtype=dtype,
+                   emask=x.view(M, Kd) if ctx.input_is_relu else None)      # x = relu(u): hand back dL/du
             dx = dx.view(x.shape)
         dw = db = None
         if weight.requires_grad:
@@ -830,11 +897,11 @@ class _LinearPermuted(Function):
                 dw, db = work()
         elif bias is not None and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear_fc_permuted(x, weight, bias, C, Fd):
-    return _LinearPermuted.apply(x, weight, bias, C, Fd)
+def linear_fc_permuted(x, weight, bias, C, Fd, input_is_relu=False):
+    return _LinearPermuted.apply(x, weight, bias, C, Fd, input_is_relu)
 
 
 # ================================================================================================

@@ -5,6 +5,7 @@ pointers to libs2svc_hip.so on torch's current HIP stream, and returns torch ten
 used for memory (caching allocator) and streams only.
 """
 import ctypes
+import os
 
 import torch
 
@@ -94,10 +95,15 @@ def operand(t, ld, layout=KC, mode=DENSE, C=0, T=0, pad=0, T1=0, F1=0, T2=0, F2=
     return o
 
 
+_MAX_SPLITK = int(os.environ["S2SVC_MAX_SPLITK"]) if "S2SVC_MAX_SPLITK" in os.environ else None   # tuning aid
+
+
 def plan_gemm(M, N, K, nbatch=1, allow_split=True):
     """Tiny cost model -> (tile, splitk) for the MFMA GEMM: estimated time = waves of resident workgroups x
     (k-tiles per workgroup x time per k-tile + fixed), plus the split-K reduction.  Numbers are microseconds
     fitted to MI355X measurements of this kernel (profiles/)."""
+    if _MAX_SPLITK is not None:
+        allow_split = allow_split and _MAX_SPLITK > 1
     best = None
     for tile, bk, t_tile, resident in ((64, 128, 1.6, 3 * 256), (128, 64, 2.2, 2 * 256)):
         if tile == 128 and (M < 128 or N < 128):
@@ -123,8 +129,8 @@ def pick_splitk(M, N, K, nbatch=1):
 
 def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
          ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False, a_rowsum=None,
-         a_rowsum_accumulate=False, tile=0):
-    """C = act(alpha * A.B^T + bias) + res   (see s2svc_gemm in include/s2svc_hip.h)."""
+         a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0)):
+    """C = act(alpha * A.B^T + bias) [* dropmask] [* (emask > 0)] + res   (see s2svc_gemm in include/s2svc_hip.h)."""
     d = _lib.GemmDesc()
     d.A, d.B = A, B
     d.C = out.data_ptr() + out_offset * out.element_size()
@@ -142,6 +148,14 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
     d.accumulate = 1 if accumulate else 0
     d.splitk = splitk
     d.tile_hint = tile
+    if emask is not None or drop_p > 0.0:
+        if nb0 * nb1 != 1 or d.ldc != N:
+            raise ValueError("gemm: the dropout / mask epilogue needs an unbatched, contiguous (M, N) output")
+        if emask is not None:
+            if emask.dtype != out.dtype:
+                raise TypeError("gemm: emask must have the output dtype")
+            d.emask, d.ldm = emask.data_ptr(), N
+        d.drop_p, d.seed_base, d.seed_off = drop_p, seed[0], seed[1]
     ws = None
     if splitk > 1:
         ws = torch.empty(splitk * nb0 * nb1 * M * N, dtype=torch.float32, device=out.device)

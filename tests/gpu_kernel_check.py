@@ -84,6 +84,67 @@ def gemm_linear(dtype):
 
 @case
 @both_dtypes
+def gemm_epilogue_dropout_mask(dtype):
+    """Epilogue stage `* dropmask * (emask > 0)`: the mask must be the one the standalone dropout kernel draws for the same
+    (seed, element index), on every kernel family (LDS-DMA vector epilogue, scalar epilogue, skinny, split-K reduce)."""
+    res = []
+    K.manual_seed(77)
+    for (M, N, Kd, sk, seed) in [(256, 192, 128, 1, 1), (2016, 1536, 384, 1, 2), (40, 96, 64, 1, 3), (130, 70, 80, 1, 4), (256, 192, 512, 2, 5)]:
+        x, w, b = rnd(M, Kd, seed=seed, dtype=dtype), rnd(N, Kd, seed=seed + 10, dtype=dtype, scale=0.1), rnd(N, seed=seed + 20)
+        em = rnd(M, N, seed=seed + 30, dtype=dtype)
+        sd = K.new_seed(x.device)
+        p = 0.3
+        scale = K.act_dropout_fwd(torch.ones(M, N, dtype=torch.float32, device=DEV), None, p, sd)     # 0 or 1/(1-p)
+        out = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm(K.operand(x, Kd), K.operand(w, Kd), M, N, Kd, out, in_dtype=dtype, bias=b, act="relu", emask=em, drop_p=p, seed=sd,
+               splitk=sk)
+        ref = torch.relu(x.float() @ w.float().t() + b) * scale * (em.float() > 0)
+        res.append(check(f"gemm epilogue dropout+mask[{dtype}] {M}x{N}x{Kd} splitk={sk}", out, ref, dtype))
+        keep = (scale > 0).float().mean().item()
+        res.append((abs(keep - (1 - p)) < 0.02, f"keep rate {keep:.3f} (p = {p})"))
+    return res
+
+
+@case
+def ffn_relu_fused_vs_unfused():
+    """_FFNRelu (masks in GEMM epilogues) against the three-op composition, fp32, dropout off (exact) and on (same statistics)."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    res = []
+    M, D, H = 300, 64, 256
+    x = rnd(3, 100, D, seed=1)
+    w1, b1 = rnd(H, D, seed=2, scale=0.1).requires_grad_(True), rnd(H, seed=3, scale=0.1).requires_grad_(True)
+    w2, b2 = rnd(D, H, seed=4, scale=0.1).requires_grad_(True), rnd(D, seed=5, scale=0.1).requires_grad_(True)
+    dy = rnd(3, 100, D, seed=6)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = Fn.ffn_relu(xa, w1, b1, w2, b2, 0.0)
+    ya.backward(dy)
+    ga = [t.grad.clone() for t in (xa, w1, b1, w2, b2)]
+    for t in (w1, b1, w2, b2):
+        t.grad = None
+    yb = Fn.linear(Fn.dropout(Fn.linear(xb, w1, b1, act="relu"), 0.0), w2, b2)
+    yb.backward(dy)
+    gb = [t.grad for t in (xb, w1, b1, w2, b2)]
+    res.append(check("ffn fused fwd", ya, yb, torch.float32, atol=1e-6))
+    for nm, a, b_ in zip(("dx", "dw1", "db1", "dw2", "db2"), ga, gb):
+        res.append(check(f"ffn fused {nm}", a, b_, torch.float32, atol=1e-4, rtol=1e-5))
+    # dropout on: gradient of a linear functional of y wrt x must be consistent with the forward mask (finite-difference free check:
+    # y is linear in x on the kept/active set, so <dy, J v> == <J^T dy, v> for a random direction v with the SAME mask)
+    K.manual_seed(5)
+    xa = x.clone().requires_grad_(True)
+    K.reset_op_counter()
+    y1 = Fn.ffn_relu(xa, w1, b1, w2, b2, 0.4)
+    y1.backward(dy)
+    v = xa.grad * (1e-3 / xa.grad.abs().mean())                                 # along the gradient: both sides are large and positive
+    K.reset_op_counter()
+    y2 = Fn.ffn_relu((x + v).requires_grad_(True), w1, b1, w2, b2, 0.4)        # same seed offset -> same dropout mask
+    lhs = ((y2 - y1).detach() * dy).sum().item()
+    rhs = (xa.grad * v).sum().item()
+    res.append((abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1e-6) + 1e-5, f"ffn fused dropout: <dy,Jv>={lhs:.6e} vs <J^T dy,v>={rhs:.6e}"))
+    return res
+
+
+@case
+@both_dtypes
 def gemm_skinny(dtype):
     """M <= 64 dense projections (the decode-step shapes) take the weight-streaming kernel; every epilogue option,
     row counts off the 16-row MFMA tile, N off the 16-column tile, K off the k-step, fp32 output of bf16 inputs."""
