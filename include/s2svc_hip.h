@@ -230,6 +230,24 @@ int s2svc_betabinom_prior(int B, int Tf, int Tx, const int32_t* text_lens, const
                           void* stream);
 
 /* ========================================================================================== */
+/* Fused attention for short sequences (bf16, T1, T2 <= 64, d_k in {32,64,96,128}): one launch */
+/* forward (scores, mask, softmax, dropout, P.V; writes the attention map) and one backward.   */
+/* replaces: modules/transformer/attention.py:63-111 for VTN's shapes (T = 63/64, d_k = 96).   */
+/* q/k/v/out/grads: element [b*bs + t*ld + h*dk + d] (bf16; slices of packed projections are   */
+/* fine); attn / dattn: (B, H, T1, ld) bf16, pad columns >= T2 written as 0.                   */
+/* ========================================================================================== */
+int s2svc_attn_fused_supported(int dtype, int T1, int T2, int dk);
+int s2svc_attn_fused_fwd(int B, int H, int T1, int T2, int dk, const void* q, int64_t ldq, int64_t qbs, const void* k, int64_t ldk,
+                         int64_t kbs, const void* v, int64_t ldv, int64_t vbs, const int32_t* klen, int causal, float scale,
+                         float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* attn, int ld, void* out, int64_t ldo,
+                         int64_t obs, void* stream);
+int s2svc_attn_fused_bwd(int B, int H, int T1, int T2, int dk, const void* q, int64_t ldq, int64_t qbs, const void* k, int64_t ldk,
+                         int64_t kbs, const void* v, int64_t ldv, int64_t vbs, const void* dout, int64_t ldo, int64_t obs,
+                         const void* attn, const void* dattn, int ld, float scale, float drop_p, const uint64_t* seed_base,
+                         uint64_t seed_off, void* dq, int64_t lddq, int64_t dqbs, void* dk_out, int64_t lddk, int64_t dkbs, void* dv,
+                         int64_t lddv, int64_t dvbs, void* stream);
+
+/* ========================================================================================== */
 /* Token embedding of Transformer-TTS (models/transformer_tts.py:63-77, Embedding(idim, adim, */
 /* padding_idx=0)): y[i,:] = W[idx[i],:] ; dW[v,:] = sum_{idx[i]==v} dy[i,:], dW[padding]=0     */
 /* ========================================================================================== */

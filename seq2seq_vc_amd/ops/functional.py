@@ -15,6 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import kernels as K
+from . import kernels_attn as KAT
 
 _STATE = {"dtype": torch.float32}
 
@@ -499,6 +500,9 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
         outs = (torch.empty((B, T1, D), dtype=dtype, device=q.device), torch.empty((B, T2, D), dtype=dtype, device=q.device),
                 torch.empty((B, T2, D), dtype=dtype, device=q.device))
     dq, dkk, dv = outs
+    if pm is None:      # forward ran the fused kernel (no dropped copy was stored): one launch, masks regenerated
+        KAT.fused_bwd(q, k, v, dctx, attn, _pad_like(dattn, attn), H, scale, p, seed, dq, dkk, dv)
+        return dq, dkk, dv, None
     # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
     dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
     # dV[b,j,hd] = sum_i pm[b,h,i,j] dctx[b,i,hd]
@@ -512,6 +516,19 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
     return dq, dkk, dv, dbd
 
 
+_FUSED = object()        # stands in for `pdrop` when the fused kernel ran: nothing but the attention map was stored
+
+
+def _split_pdrop(ctx, pdrop):
+    ctx.fused = pdrop is _FUSED
+    return None if ctx.fused else pdrop
+
+
+def _pm(ctx, attn, pdrop):
+    """The (dropped) probabilities the unfused backward multiplies with; None = run the fused backward kernel."""
+    return None if ctx.fused else (pdrop if pdrop is not None else attn)
+
+
 def _attn_fwd_views(q, k, v, klen, causal, H, p):
     B, T1, D = q.shape
     T2 = k.shape[1]
@@ -519,6 +536,9 @@ def _attn_fwd_views(q, k, v, klen, causal, H, p):
     dtype = q.dtype
     scale = 1.0 / math.sqrt(dk)
     seed = K.new_seed(q.device) if p > 0.0 else (None, 0)
+    if KAT.supported(q, k, v, H):       # short sequences, bf16: scores + mask + softmax + dropout + P.V in ONE launch
+        out, attn = KAT.fused_fwd(q, k, v, klen, causal, H, scale, p, seed)
+        return out, attn, _FUSED, scale, seed
     scores = _qk(q, k, B, H, T1, T2, dk, D, dtype)
     attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed, T2=T2)
     out = _pv(pdrop if pdrop is not None else attn, v, B, H, T1, T2, dk, D, dtype)
@@ -540,7 +560,7 @@ class _AttnPackedQKV(Function):
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
         ctx.meta = (H, scale, p, seed, D)
-        ctx.save_for_backward(qkv, attn, pdrop)
+        ctx.save_for_backward(qkv, attn, _split_pdrop(ctx, pdrop))
         ctx.set_materialize_grads(False)
         return out, _user_attn(attn, k.shape[1])
 
@@ -550,7 +570,7 @@ class _AttnPackedQKV(Function):
         H, scale, p, seed, D = ctx.meta
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         dqkv = torch.empty_like(qkv)
-        _attn_common_bwd(dctx, dattn, attn, pdrop if pdrop is not None else attn, q, k, v, H, scale, p, seed,
+        _attn_common_bwd(dctx, dattn, attn, _pm(ctx, attn, pdrop), q, k, v, H, scale, p, seed,
                          outs=(dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]))
         return dqkv, None, None, None, None
 
@@ -565,7 +585,7 @@ class _AttnPackedKV(Function):
         k, v = kv[..., :D], kv[..., D:]
         out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
         ctx.meta = (H, scale, p, seed, D)
-        ctx.save_for_backward(q, kv, attn, pdrop)
+        ctx.save_for_backward(q, kv, attn, _split_pdrop(ctx, pdrop))
         ctx.set_materialize_grads(False)
         return out, _user_attn(attn, k.shape[1])
 
@@ -576,7 +596,7 @@ class _AttnPackedKV(Function):
         k, v = kv[..., :D], kv[..., D:]
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
-        _attn_common_bwd(dctx, dattn, attn, pdrop if pdrop is not None else attn, q, k, v, H, scale, p, seed,
+        _attn_common_bwd(dctx, dattn, attn, _pm(ctx, attn, pdrop), q, k, v, H, scale, p, seed,
                          outs=(dq, dkv[..., :D], dkv[..., D:]))
         return dq, dkv, None, None, None, None
 
@@ -595,7 +615,7 @@ class _AttnCore(Function):
         q, k, v = _c(q), _c(k), _c(v)
         out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
         ctx.meta = (H, scale, p, seed)
-        ctx.save_for_backward(q, k, v, attn, pdrop)
+        ctx.save_for_backward(q, k, v, attn, _split_pdrop(ctx, pdrop))
         ctx.set_materialize_grads(False)
         return out, _user_attn(attn, k.shape[1])
 
@@ -603,7 +623,7 @@ class _AttnCore(Function):
     def backward(ctx, dctx, dattn):
         q, k, v, attn, pdrop = ctx.saved_tensors
         H, scale, p, seed = ctx.meta
-        pm = pdrop if pdrop is not None else attn
+        pm = _pm(ctx, attn, pdrop)
         dq, dkk, dv, _ = _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed)
         return dq, dkk, dv, None, None, None, None
 

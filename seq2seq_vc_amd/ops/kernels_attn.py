@@ -1,0 +1,53 @@
+"""Launchers for the fused short-sequence attention kernels (csrc/attn_fused.hip; C-ABI in include/s2svc_hip.h)."""
+import os
+
+import torch
+
+from .. import _lib
+from .kernels import _DT, ptr, stream
+
+_DISABLED = os.environ.get("S2SVC_NO_FUSED_ATTN", "0") == "1"     # A/B switch
+
+
+def _strided_ok(t):
+    """(B, T, D') view whose last dim is contiguous and whose row / batch strides and base keep 16-byte pieces aligned."""
+    return t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+
+
+def supported(q, k, v, H):
+    if _DISABLED or q.dtype != torch.bfloat16:
+        return False
+    dk = q.shape[-1] // H
+    if not _lib.lib().s2svc_attn_fused_supported(_DT[q.dtype], q.shape[1], k.shape[1], dk):
+        return False
+    return _strided_ok(q) and _strided_ok(k) and _strided_ok(v)
+
+
+def fused_fwd(q, k, v, klen, causal, H, scale, p, seed):
+    """q (B,T1,D), k/v (B,T2,D) (possibly column slices of packed projections) -> (out (B,T1,D), attn (B,H,T1,ld))."""
+    B, T1, D = q.shape
+    T2 = k.shape[1]
+    dk = D // H
+    ld = (T2 + 7) // 8 * 8
+    attn = torch.empty((B, H, T1, ld), dtype=q.dtype, device=q.device)
+    out = torch.empty((B, T1, D), dtype=q.dtype, device=q.device)
+    _lib.check(_lib.lib().s2svc_attn_fused_fwd(B, H, T1, T2, dk, ptr(q), q.stride(1), q.stride(0), ptr(k), k.stride(1), k.stride(0),
+                                               ptr(v), v.stride(1), v.stride(0), ptr(klen), 1 if causal else 0, scale, p, seed[0],
+                                               seed[1], ptr(attn), ld, ptr(out), D, T1 * D, stream()), "attn_fused_fwd")
+    return out, attn
+
+
+def fused_bwd(q, k, v, dout, attn, dattn, H, scale, p, seed, dq, dk_out, dv):
+    """Writes dq / dk / dv (views with last dim contiguous, e.g. slices of a packed gradient)."""
+    B, T1, D = q.shape
+    T2 = k.shape[1]
+    dk = D // H
+    ld = attn.shape[-1]
+    for t in (dout, dq, dk_out, dv):
+        if t.stride(2) != 1:
+            raise ValueError("fused attention backward: last dim of gradients must be contiguous")
+    _lib.check(_lib.lib().s2svc_attn_fused_bwd(B, H, T1, T2, dk, ptr(q), q.stride(1), q.stride(0), ptr(k), k.stride(1), k.stride(0),
+                                               ptr(v), v.stride(1), v.stride(0), ptr(dout), dout.stride(1), dout.stride(0), ptr(attn),
+                                               ptr(dattn), ld, scale, p, seed[0], seed[1], ptr(dq), dq.stride(1), dq.stride(0),
+                                               ptr(dk_out), dk_out.stride(1), dk_out.stride(0), ptr(dv), dv.stride(1), dv.stride(0),
+                                               stream()), "attn_fused_bwd")

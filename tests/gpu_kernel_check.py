@@ -106,6 +106,75 @@ def gemm_epilogue_dropout_mask(dtype):
 
 
 @case
+def attention_fused_vs_reference():
+    """Fused short-sequence attention (bf16): forward / backward vs fp32 torch math, and -- with dropout on -- vs the unfused
+    kernels (same seed => same Philox masks), for self / causal / source attention on packed and separate projections."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    from seq2seq_vc_amd.ops import kernels_attn as KAT
+    res = []
+    dt_ = torch.bfloat16
+    for (B, H, T1, T2, dk, causal, seed) in [(3, 4, 63, 63, 96, False, 1), (2, 4, 64, 64, 96, True, 2), (3, 2, 64, 63, 64, False, 3),
+                                             (2, 2, 17, 40, 32, False, 4), (1, 1, 5, 9, 128, False, 5)]:
+        D = H * dk
+        q, k, v = (rnd(B, T1 if i == 0 else T2, D, seed=seed * 10 + i, dtype=dt_) for i in range(3))
+        klen = torch.tensor([T2, max(1, T2 - 7), max(1, T2 // 2)][:B], dtype=torch.int32, device=DEV)
+        dy = rnd(B, T1, D, seed=seed * 10 + 5, dtype=dt_)
+        datt = rnd(B, H, T1, T2, seed=seed * 10 + 6, dtype=dt_) * 0.1
+        scale = 1 / math.sqrt(dk)
+        # fp32 reference
+        qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+        qh = qr.view(B, T1, H, dk).transpose(1, 2)
+        kh = kr.view(B, T2, H, dk).transpose(1, 2)
+        vh = vr.view(B, T2, H, dk).transpose(1, 2)
+        mask = torch.arange(T2, device=DEV)[None, None, None, :] < klen[:, None, None, None]
+        if causal:
+            mask = mask & torch.tril(torch.ones(T1, T2, dtype=torch.bool, device=DEV))[None, None]
+        sc = (qh @ kh.transpose(-1, -2) * scale).masked_fill(~mask, torch.finfo(torch.float32).min)
+        pr = torch.softmax(sc, -1).masked_fill(~mask, 0.0)
+        outr = (pr @ vh).transpose(1, 2).reshape(B, T1, D)
+        (outr * dy.float()).sum().backward(retain_graph=True)
+        g_plain = [t.grad.clone() for t in (qr, kr, vr)]
+        for t in (qr, kr, vr):
+            t.grad = None
+        ((outr * dy.float()).sum() + (pr * datt.float()).sum()).backward()
+        g_att = [t.grad.clone() for t in (qr, kr, vr)]
+        assert KAT.supported(q, k, v, H), "shape should take the fused kernel"
+        for use_datt, gref in ((False, g_plain), (True, g_att)):
+            qf, kf, vf = (t.clone().requires_grad_(True) for t in (q, k, v))
+            out, att = Fn.attention_core(qf, kf, vf, klen, causal, H, 0.0)
+            loss = (out.float() * dy.float()).sum()
+            if use_datt:
+                loss = loss + (att.float() * datt.float()).sum()
+            loss.backward()
+            tag = f"fused attn B{B} H{H} T{T1}x{T2} dk{dk} causal={causal} datt={use_datt}"
+            if not use_datt:
+                res.append(check(tag + " out", out, outr, dt_, atol=3e-2))
+                res.append(check(tag + " attn", att, pr, dt_, atol=1e-2))
+                res.append(check(tag + " attn rows sum to 1", att.float().sum(-1), torch.ones(B, H, T1), torch.float32, atol=2e-2))
+            for nm, a, b_ in zip(("dq", "dk", "dv"), (qf.grad, kf.grad, vf.grad), gref):
+                res.append(check(tag + " " + nm, a, b_, dt_, atol=0.15, rtol=5e-2))
+        # dropout on: fused == unfused (identical masks), packed QKV path
+        qkv = torch.cat([q[:, :min(T1, T2)], k[:, :min(T1, T2)], v[:, :min(T1, T2)]], dim=-1).contiguous() if T1 != T2 else torch.cat([q, k, v], -1)
+        Tq = qkv.shape[1]
+        kl2 = torch.clamp(klen, max=Tq)
+        outs = []
+        for disabled in (False, True):
+            KAT._DISABLED = disabled
+            try:
+                K.manual_seed(123)
+                K.reset_op_counter()
+                x = qkv.clone().requires_grad_(True)
+                o, a = Fn.attention_packed_qkv(x, kl2, causal, H, 0.3)
+                (o.float() * dy[:, :Tq].float()).sum().backward()
+                outs.append((o.detach(), a.detach(), x.grad.detach()))
+            finally:
+                KAT._DISABLED = False
+        for nm, a, b_ in zip(("out", "attn", "dqkv"), outs[0], outs[1]):
+            res.append(check(f"fused vs unfused (dropout 0.3) T{Tq} dk{dk} {nm}", a, b_, dt_, atol=0.12 if nm == "dqkv" else 4e-2, rtol=5e-2))
+    return res
+
+
+@case
 def ffn_relu_fused_vs_unfused():
     """_FFNRelu (masks in GEMM epilogues) against the three-op composition, fp32, dropout off (exact) and on (same statistics)."""
     from seq2seq_vc_amd.ops import functional as Fn
