@@ -104,6 +104,7 @@ _SIGS = {
     "s2svc_guided_attn_loss_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp],
     "s2svc_guided_attn_loss_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_adam_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp],
+    "s2svc_transpose_tiles": [c_i64, c_vp, c_vp, c_vp, c_vp],
     "s2svc_col2im_s2": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_interp_nearest": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_interp_nearest_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],

@@ -95,3 +95,43 @@ extern "C" int s2svc_adam_step(int64_t n, float* params, const float* grads, flo
   S2S_CHECK_LAUNCH("adam_update_kernel");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Transposed bf16 shadow of the 2-D weights: dst[c, r] = src[r, c] for every matrix of a table, ONE launch.
+// The data-gradient GEMMs dX = dY . W read W with the reduction index (out-features) strided; with W^T kept beside
+// the bf16 shadow they become plain K-contiguous x K-contiguous products and take the all-DMA kernel.
+// tiles: one int4-sized entry per 32x32 tile, {src offset of the matrix, dst offset, rows << 32 | cols, tile index}
+// (element offsets into src / dst).  Refreshed once per optimiser step (2 B read + 2 B written per parameter).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void transpose_tiles_kernel(const int64_t* __restrict__ tiles, const bf16_t* __restrict__ src,
+                                                              bf16_t* __restrict__ dst) {
+  __shared__ bf16_t t[32][33];
+  const int64_t* e = tiles + (int64_t)blockIdx.x * 4;
+  const int64_t so = e[0], dof = e[1];
+  const int rows = (int)(e[2] >> 32), cols = (int)(e[2] & 0xffffffff);
+  const int tcols = (cols + 31) / 32;
+  const int tr = (int)(e[3] / tcols), tc = (int)(e[3] % tcols);
+  const int x = threadIdx.x & 31, y0 = threadIdx.x >> 5;          // 32 x 8 threads, 4 rows each
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = tr * 32 + y0 + i * 8, c = tc * 32 + x;
+    if (r < rows && c < cols) t[y0 + i * 8][x] = src[so + (int64_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tc * 32 + y0 + i * 8, r = tr * 32 + x;
+    if (r < rows && c < cols) dst[dof + (int64_t)c * rows + r] = t[x][y0 + i * 8];
+  }
+}
+}  // namespace
+
+extern "C" int s2svc_transpose_tiles(int64_t ntiles, const int64_t* tiles, const void* src, void* dst, void* stream) {
+  S2S_REQUIRE(ntiles >= 0 && (ntiles == 0 || (tiles && src && dst)), "transpose_tiles: bad args");
+  if (ntiles == 0) return 0;
+  hipLaunchKernelGGL(transpose_tiles_kernel, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream, tiles, (const bf16_t*)src,
+                     (bf16_t*)dst);
+  S2S_CHECK_LAUNCH("transpose_tiles_kernel");
+  return 0;
+}

@@ -49,6 +49,16 @@ def _wcast(w, dtype):
     return K.cast(w.detach(), dtype)
 
 
+def _dgrad_operand(weight, w, n_out, n_in, dtype):
+    """The weight as B operand of dX[M, n_in] = dY[M, n_out] . W[n_out, n_in]  (B(row = k', red = n') = W[n', k']).
+    With the optimiser's transposed bf16 shadow (FlatAdam, `_s2s_bf16_t` = W^T (n_in, n_out)) that operand is
+    K-contiguous and the GEMM runs on the all-DMA kernel; otherwise W is read row-contiguous (register transposes)."""
+    wt = getattr(weight, "_s2s_bf16_t", None) if dtype == torch.bfloat16 else None
+    if wt is not None:
+        return K.operand(wt, n_out)
+    return K.operand(w, n_in, layout=K.RC)
+
+
 def _emit_wgrad(param, shape, writer):
     """Run `writer(out, accumulate)` into the flat-grad slot of `param` if it has one (returns None so
     autograd skips it), else into a fresh fp32 tensor (returned to autograd)."""
@@ -174,7 +184,7 @@ class _Linear(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
-            K.gemm(K.operand(dy2, N), K.operand(w, Kd, layout=K.RC), M, Kd, N, dx, in_dtype=dtype)
+            K.gemm(K.operand(dy2, N), _dgrad_operand(weight, w, N, Kd, dtype), M, Kd, N, dx, in_dtype=dtype)
             dx = dx.view(ctx.xshape)
         dw = db = None
         if weight.requires_grad:
@@ -232,11 +242,11 @@ class _FFNRelu(Function):
         dy2 = _c(dy).view(M, N)
         # du = (dY W2) * dropmask * relu'(u): gradient at the pre-activation, straight out of the GEMM
         du = torch.empty((M, Hd), dtype=dtype, device=dy.device)
-        K.gemm(K.operand(dy2, N), K.operand(w2c, Hd, layout=K.RC), M, Hd, N, du, in_dtype=dtype, emask=h, drop_p=p, seed=seed)
+        K.gemm(K.operand(dy2, N), _dgrad_operand(w2, w2c, N, Hd, dtype), M, Hd, N, du, in_dtype=dtype, emask=h, drop_p=p, seed=seed)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
-            K.gemm(K.operand(du, Hd), K.operand(w1c, Kd, layout=K.RC), M, Kd, Hd, dx, in_dtype=dtype)
+            K.gemm(K.operand(du, Hd), _dgrad_operand(w1, w1c, Hd, Kd, dtype), M, Kd, Hd, dx, in_dtype=dtype)
             dx = dx.view(xshape)
 
         def wgrad(weight, bias, g, a, n_out, n_in):

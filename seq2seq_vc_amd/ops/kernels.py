@@ -459,6 +459,11 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, shadow, state, partial, lr, be
                                           stream()), "adam_step")
 
 
+def transpose_tiles(tiles, src, dst):
+    """tiles: int64 device tensor (ntiles, 4) built by optim.FlatAdam; src / dst: flat bf16 buffers."""
+    _lib.check(_lib.lib().s2svc_transpose_tiles(tiles.shape[0], ptr(tiles), ptr(src), ptr(dst), stream()), "transpose_tiles")
+
+
 # ----------------------------------------------------------------------------------------------
 # convolution helpers
 # ----------------------------------------------------------------------------------------------

@@ -6,7 +6,8 @@ Replaces the reference's `clip_grad_norm_` -> `torch.optim.Adam.step()` -> `Warm
 All trainable parameters of the model are re-pointed into ONE contiguous fp32 buffer (`flat_p`); their
 gradients live in a parallel buffer (`flat_g`, exposed as `p.grad` views and as `p._s2s_grad` so the
 wgrad kernels accumulate straight into it); Adam moments and the bf16 shadow used by bf16 GEMMs are
-flat as well.  The step counter, learning rate, gradient norm and clip coefficient live in a 4-float
+flat as well, and the matrix-shaped weights additionally keep a TRANSPOSED bf16 copy (refreshed by one batched tile-
+transpose launch per step) so that data-gradient GEMMs read K-contiguous operands.  The step counter, learning rate, gradient norm and clip coefficient live in a 4-float
 device tensor, so the optimiser step is hipGraph-capturable and needs no host synchronisation.  The
 flat gradient buffer is also what data-parallel training all-reduces (distributed.py): a handful of
 large RCCL collectives instead of one per tensor.
@@ -18,7 +19,7 @@ from .ops import kernels as K
 
 class FlatAdam:
     def __init__(self, model, lr=8e-5, betas=(0.9, 0.999), eps=1e-8, grad_norm=1.0, warmup_steps=4000, bf16_shadow=False,
-                 align=64, fuse_qkv=True):
+                 align=64, fuse_qkv=True, transposed_shadow=True):
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -65,9 +66,14 @@ class FlatAdam:
             p.grad = p._s2s_grad
             if self.shadow is not None:
                 p._s2s_bf16 = self.shadow[o:o + k].view(p.shape)
-        if self.shadow is not None:
-            self.refresh_shadow()
         off_of = {id(p): o for p, o in zip(self.params, offs)}
+        # transposed bf16 shadow of the matrix-shaped weights (Linear, 1x1 Conv1d): dX = dY.W then reads a K-contiguous
+        # operand and runs on the all-DMA GEMM kernel.  Matrices keep their offset; fused QKV / KV views get extra room.
+        self.shadow_t, self._t_descs, self._t_extra = None, [], n
+        if self.shadow is not None and transposed_shadow:
+            for p, o in zip(self.params, offs):
+                if p.dim() == 2 or (p.dim() == 3 and p.shape[-1] == 1):
+                    self._t_descs.append((o, o, p.shape[0], p.shape[1], p))
         for g in groups:
             ws, bs = g["w"], g["b"]
             D = ws[0].shape[0]
@@ -79,6 +85,25 @@ class FlatAdam:
                     "w_qkv": self._view(ow, (3 * D, D)), "b_qkv": self._view(ob, (3 * D,)),
                     "w_q": self._view(ow, (D, D)), "b_q": self._view(ob, (D,)),
                     "w_kv": self._view(ow + D * D, (2 * D, D)), "b_kv": self._view(ob + D, (2 * D,))}
+                if self.shadow is not None and transposed_shadow:
+                    f = g["module"]._fused
+                    for key, off, rows in (("w_qkv", ow, 3 * D), ("w_kv", ow + D * D, 2 * D)):
+                        self._t_descs.append((off, self._t_extra, rows, D, f[key]))
+                        self._t_extra += (rows * D + align - 1) // align * align
+        if self._t_descs:
+            self.shadow_t = torch.zeros(self._t_extra, dtype=torch.bfloat16, device=dev)
+            tiles = []
+            for so, do, rows, cols, t in self._t_descs:
+                t._s2s_bf16_t = self.shadow_t[do:do + rows * cols].view(cols, rows)
+                nt = ((rows + 31) // 32) * ((cols + 31) // 32)
+                tiles += [(so, do, (rows << 32) | cols, i) for i in range(nt)]
+            self.t_tiles = torch.tensor(tiles, dtype=torch.int64, device=dev)
+            for g in groups:                                                   # w_q view: the transposed copy of linear_q.weight
+                f = getattr(g["module"], "_fused", None)
+                if f is not None:
+                    f["w_q"]._s2s_bf16_t = g["w"][0]._s2s_bf16_t
+        if self.shadow is not None:
+            self.refresh_shadow()
 
     @staticmethod
     def _attention_groups(model):
@@ -108,6 +133,11 @@ class FlatAdam:
         """bf16 copy of the fp32 master weights (after loading a checkpoint / at start)."""
         if self.shadow is not None:
             self.shadow.copy_(K.cast(self.flat_p, torch.bfloat16))
+            self._refresh_transposed()
+
+    def _refresh_transposed(self):
+        if self.shadow_t is not None:
+            K.transpose_tiles(self.t_tiles, self.shadow, self.shadow_t)
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
@@ -115,6 +145,7 @@ class FlatAdam:
     def step(self):
         K.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.shadow, self.state, self.partial, self.lr,
                     self.betas, self.eps, self.grad_norm, self.warmup_steps)
+        self._refresh_transposed()
 
     # -- introspection (host sync; for logging / tests only) -------------------------------------
     def last_stats(self):

@@ -338,7 +338,7 @@ def aasvc_tiny_train_bf16():
     return run_aas("aasvc_tiny_train", torch.bfloat16)
 
 
-def _train_steps(n_steps, side_streams, use_graph, dtype=torch.float32):
+def _train_steps(n_steps, side_streams, use_graph, dtype=torch.float32, transposed_shadow=True):
     """n optimiser steps of tiny VTN with FlatAdam on the golden batch; returns (flat params, losses)."""
     from seq2seq_vc_amd import losses as L
     from seq2seq_vc_amd import models as M
@@ -353,7 +353,8 @@ def _train_steps(n_steps, side_streams, use_graph, dtype=torch.float32):
     for m in model.modules():
         if hasattr(m, "dropout_rate"):
             m.dropout_rate = 0.0
-    opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10, bf16_shadow=(dtype == torch.bfloat16))
+    opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10, bf16_shadow=(dtype == torch.bfloat16),
+                   transposed_shadow=transposed_shadow)
     crit = L.Seq2SeqLoss(10.0)
     t = lambda k: torch.from_numpy(z[k])
     xs, ys, labels = t("in.xs").to(DEV), t("in.ys").to(DEV), t("in.labels").to(DEV)
@@ -429,6 +430,38 @@ def training_steps_equivalence_fp32():
     worst = max((got[k].detach().cpu() - sd[k].detach()).abs().max().item() for k in names)
     res.append((worst < 2e-5, f"params after 3 optimiser steps vs oracle trainer replay: max abs diff {worst:.2e}"))
     res.append((abs(st0["grad_norm"] - float(gn)) < 1e-3 * float(gn), f"grad norm {st0['grad_norm']:.5f} vs oracle {float(gn):.5f}; lr {st0['lr']:.3e}"))
+    return res
+
+
+@case
+def training_steps_bf16_transposed_shadow():
+    """bf16 training with the transposed weight shadow (dgrad GEMMs on K-contiguous operands) vs without it: same trajectory
+    up to accumulation-order noise; the transposed copies equal the shadow's transposes after the optimiser steps."""
+    try:
+        p_t, l_t, _, model = _train_steps(3, 4, True, dtype=torch.bfloat16, transposed_shadow=True)
+        bad = []
+        n = 0
+        for m in model.modules():
+            for w in ([m.weight] if isinstance(m, torch.nn.Linear) else []):
+                wt = getattr(w, "_s2s_bf16_t", None)
+                if wt is None:
+                    bad.append("a Linear weight has no transposed shadow")
+                elif not torch.equal(wt, w._s2s_bf16.t()):
+                    bad.append("transposed shadow != shadow^T")
+                n += 1
+        for m in model.modules():
+            f = getattr(m, "_fused", None)
+            if f is not None:
+                for key in ("w_qkv", "w_kv", "w_q"):
+                    if not torch.equal(f[key]._s2s_bf16_t, f[key]._s2s_bf16.t()):
+                        bad.append(f"fused view {key}: transposed shadow != shadow^T")
+        p_n, l_n, _, _ = _train_steps(3, 4, True, dtype=torch.bfloat16, transposed_shadow=False)
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    res = [(not bad, f"{n} Linear weights + fused views carry W^T == shadow^T after 3 steps {bad[:2]}")]
+    diff = (p_t - p_n).abs().max().item()
+    res.append((diff < 2e-3, f"params after 3 bf16 steps, with vs without transposed shadow: max abs diff {diff:.2e}"))
+    res.append((abs(l_t[-1][0] - l_n[-1][0]) < 2e-2, f"final l1 loss {l_t[-1][0]:.4f} vs {l_n[-1][0]:.4f}"))
     return res
 
 
