@@ -173,8 +173,9 @@ int s2svc_rowscale(int dtype, int64_t rows, int D, const void* x, const float* s
 /* first front-end layer: Conv2d(1->O, 3x3, s2) + ReLU on the (B,T,F) mel batch, output NHWC; fused dW + dbias */
 int s2svc_conv_in1_fwd(int dtype, int B, int Tn, int Fn, int O, const void* x, const float* w, const float* bias, void* y,
                        void* stream);
-int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, const void* x, const void* dy, float* dw, float* db,
-                         int accumulate, float* partial, int max_chunks, void* stream);
+/* y != NULL: dy is the gradient of the ReLU output and is masked by (y > 0) on the fly */
+int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, const void* x, const void* dy, const void* y, float* dw,
+                         float* db, int accumulate, float* partial, int max_chunks, void* stream);
 int s2svc_col2im_s2(int dtype, int B, int T1, int F1, int C, int T2, int F2, const void* dcols, void* dx, void* stream);
 int s2svc_interp_nearest(int dtype, int B, int Tin, int Tout, int C, const void* x, void* y, void* stream);
 int s2svc_interp_nearest_bwd(int dtype, int B, int Tin, int Tout, int C, const void* dy, void* dx, void* stream);

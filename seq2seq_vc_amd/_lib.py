@@ -117,7 +117,7 @@ _SIGS = {
     "s2svc_forward_sum": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_betabinom_prior": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_conv_in1_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "s2svc_conv_in1_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
+    "s2svc_conv_in1_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "s2svc_attn_fused_supported": [c_i32, c_i32, c_i32, c_i32],
     "s2svc_attn_fused_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i32,
                              c_f32, c_f32, c_vp, c_u64, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp],

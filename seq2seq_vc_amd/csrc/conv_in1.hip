@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void conv_in1_fwd_kernel(int B, int Tn, int Fn
 // partial[chunk][o][0..8] = sum_p dy[p,o]*x[p,tap] ; partial[chunk][o][9] = sum_p dy[p,o]   (dy already ReLU-masked)
 template <typename T>
 __global__ __launch_bounds__(256) void conv_in1_wgrad_kernel(int B, int Tn, int Fn, int T1, int F1, int O, const T* __restrict__ x,
-                                                             const T* __restrict__ dy, float* __restrict__ partial,
-                                                             int pix_per_chunk) {
+                                                             const T* __restrict__ dy, const T* __restrict__ y,
+                                                             float* __restrict__ partial, int pix_per_chunk) {
   const int64_t npix = (int64_t)B * T1 * F1;
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_chunk;
   const int64_t p1 = (p0 + pix_per_chunk < npix) ? p0 + pix_per_chunk : npix;
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void conv_in1_wgrad_kernel(int B, int Tn, int 
       const int64_t q = p / F1;
       const int t1 = (int)(q % T1);
       const int b = (int)(q / T1);
-      const float g = ldf(dy + p * O + o);
+      float g = ldf(dy + p * O + o);
+      if (y && !(ldf(y + p * O + o) > 0.f)) g = 0.f;      // relu' of the forward output, fused (no mask pass over dy)
       const T* xb = x + ((int64_t)b * Tn + 2 * t1) * Fn + 2 * f1;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -129,9 +130,11 @@ extern "C" int s2svc_conv_in1_fwd(int dtype, int B, int Tn, int Fn, int O, const
   return 0;
 }
 
-// partial: >= chunks*O*10 floats with chunks = min(1024, ceil(npix/64)); dw (O,9), db (O) fp32
-extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, const void* x, const void* dy, float* dw, float* db,
-                                    int accumulate, float* partial, int max_chunks, void* stream) {
+// partial: >= chunks*O*10 floats with chunks = min(1024, ceil(npix/64)); dw (O,9), db (O) fp32.
+// y (nullable): the forward output; when given, dy is masked by relu'(y) on the fly (dy then is the gradient of the
+// ReLU OUTPUT, as autograd hands it over).
+extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, const void* x, const void* dy, const void* y,
+                                    float* dw, float* db, int accumulate, float* partial, int max_chunks, void* stream) {
   const int T1 = (Tn - 3) / 2 + 1, F1 = (Fn - 3) / 2 + 1;
   const int64_t npix = (int64_t)B * T1 * F1;
   if (npix == 0) return 0;
@@ -142,9 +145,9 @@ extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, con
   chunks = (int)((npix + ppc - 1) / ppc);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(conv_in1_wgrad_kernel<float>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const float*)x, (const float*)dy, partial, ppc);
+    hipLaunchKernelGGL(conv_in1_wgrad_kernel<float>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const float*)x, (const float*)dy, (const float*)y, partial, ppc);
   else
-    hipLaunchKernelGGL(conv_in1_wgrad_kernel<bf16_t>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const bf16_t*)x, (const bf16_t*)dy, partial, ppc);
+    hipLaunchKernelGGL(conv_in1_wgrad_kernel<bf16_t>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, partial, ppc);
   S2S_CHECK_LAUNCH("conv_in1_wgrad_kernel");
   hipLaunchKernelGGL(conv_in1_wgrad_final_kernel, dim3((O * 10 + 3) / 4), dim3(256), 0, st, O, chunks, partial, dw, db, accumulate);
   S2S_CHECK_LAUNCH("conv_in1_wgrad_final_kernel");

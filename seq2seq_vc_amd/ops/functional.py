@@ -861,14 +861,14 @@ class _ConvIn1(Function):
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
         weight, bias = ctx.params
-        dy = K.act_dropout_bwd(_c(dy), y, act="relu")
+        dy = _c(dy)                  # relu' is applied inside the wgrad kernel (y > 0): no mask pass over 60 M values
         wslot, bslot = getattr(weight, "_s2s_grad", None), getattr(bias, "_s2s_grad", None) if bias is not None else None
         if wslot is not None and (bias is None or bslot is not None):
-            _side_run(lambda: K.conv_in1_wgrad(x, dy, wslot, bslot, True), keep=(x, dy))
+            _side_run(lambda: K.conv_in1_wgrad(x, dy, wslot, bslot, True, y=y), keep=(x, dy, y))
             return None, None, None
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
         db = torch.empty(bias.shape, dtype=torch.float32, device=x.device) if bias is not None else None
-        K.conv_in1_wgrad(x, dy, dw, db, False)
+        K.conv_in1_wgrad(x, dy, dw, db, False, y=y)
         return None, dw, db
 
 

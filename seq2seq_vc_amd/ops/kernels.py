@@ -496,10 +496,10 @@ def conv_in1_fwd(x, w, bias):
     return y
 
 
-def conv_in1_wgrad(x, dy, dw, db, accumulate):
+def conv_in1_wgrad(x, dy, dw, db, accumulate, y=None):
     B, T, Fd = x.shape
     O = dy.shape[-1]
     chunks = 1024
     partial = torch.empty(chunks * O * 10, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().s2svc_conv_in1_wgrad(dt(x), B, T, Fd, O, ptr(x), ptr(dy), ptr(dw), ptr(db), 1 if accumulate else 0,
+    _lib.check(_lib.lib().s2svc_conv_in1_wgrad(dt(x), B, T, Fd, O, ptr(x), ptr(dy), ptr(y), ptr(dw), ptr(db), 1 if accumulate else 0,
                                                ptr(partial), chunks, stream()), "conv_in1_wgrad")
