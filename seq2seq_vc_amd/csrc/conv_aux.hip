@@ -39,6 +39,44 @@ __global__ void col2im_s2_kernel(int B, int T1, int F1, int C, int T2, int F2, c
   }
 }
 
+// 16-byte channel vectors (8 bf16): one thread = one input pixel x 8 channels, <= 4 contributing taps
+__global__ void col2im_s2_vec_kernel(int B, int T1, int F1, int C, int T2, int F2, const bf16_t* __restrict__ dcols,
+                                     bf16_t* __restrict__ dx) {
+  const int cg = C / 8;
+  const int64_t n = (int64_t)B * T1 * F1 * cg;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % cg);
+    int64_t r = i / cg;
+    const int f1 = (int)(r % F1); r /= F1;
+    const int t1 = (int)(r % T1);
+    const int b = (int)(r / T1);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int tt = t1 - kh;
+      const int t2 = tt >> 1;
+      const bool okt = tt >= 0 && !(tt & 1) && t2 < T2;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ff = f1 - kw;
+        const int f2 = ff >> 1;
+        if (!(okt && ff >= 0 && !(ff & 1) && f2 < F2)) continue;
+        const int64_t m = ((int64_t)b * T2 + t2) * F2 + f2;
+        const uint4 v = *reinterpret_cast<const uint4*>(dcols + (m * 9 + (kh * 3 + kw)) * C + g * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(w[e] << 16); acc[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+      }
+    }
+    uint4 o;
+    o.x = (uint32_t)f2bf(acc[0]) | ((uint32_t)f2bf(acc[1]) << 16);
+    o.y = (uint32_t)f2bf(acc[2]) | ((uint32_t)f2bf(acc[3]) << 16);
+    o.z = (uint32_t)f2bf(acc[4]) | ((uint32_t)f2bf(acc[5]) << 16);
+    o.w = (uint32_t)f2bf(acc[6]) | ((uint32_t)f2bf(acc[7]) << 16);
+    *reinterpret_cast<uint4*>(dx + (i / cg) * C + g * 8) = o;
+  }
+}
+
 // nearest-neighbour resampling along time of channel-last rows: y[b, t, :] = x[b, floor(t*Tin/Tout), :]
 // (F.interpolate(mode="nearest") as used at models/aas_vc.py:340-349)
 template <typename T>
@@ -93,6 +131,8 @@ extern "C" int s2svc_col2im_s2(int dtype, int B, int T1, int F1, int C, int T2, 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(col2im_s2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, B, T1, F1, C, T2, F2, (const float*)dcols, (float*)dx);
+  else if (C % 8 == 0 && ((uintptr_t)dcols) % 16 == 0 && ((uintptr_t)dx) % 16 == 0)
+    hipLaunchKernelGGL(col2im_s2_vec_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, B, T1, F1, C, T2, F2, (const bf16_t*)dcols, (bf16_t*)dx);
   else
     hipLaunchKernelGGL(col2im_s2_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, B, T1, F1, C, T2, F2, (const bf16_t*)dcols, (bf16_t*)dx);
   S2S_CHECK_LAUNCH("col2im_s2_kernel");
