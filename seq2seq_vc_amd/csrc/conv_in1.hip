@@ -94,6 +94,83 @@ __global__ __launch_bounds__(256) void conv_in1_wgrad_kernel(int B, int Tn, int 
   }
 }
 
+// bf16 streaming variant: a thread owns 8 channels (one 16-byte load of dy and of y per pixel) and every
+// (256 / (O/8))-th pixel of the chunk; 80 fp32 accumulators per thread, pixel lanes folded through LDS in a fixed
+// order at the end.  HBM-bound: 2 (dy) + 2 (y) bytes per (pixel, channel); the 9 input samples are L1 broadcasts.
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(w[e] << 16); f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+
+__global__ __launch_bounds__(256) void conv_in1_wgrad_vec_kernel(int B, int Tn, int Fn, int T1, int F1, int O,
+                                                                 const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                 const bf16_t* __restrict__ y, float* __restrict__ partial,
+                                                                 int pix_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [O/8][80]
+  const int og = O / 8, PL = 256 / og;
+  const int g = threadIdx.x % og, pl = threadIdx.x / og;
+  const int64_t npix = (int64_t)B * T1 * F1;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_chunk;
+  const int64_t p1 = (p0 + pix_per_chunk < npix) ? p0 + pix_per_chunk : npix;
+  float acc[8][10];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[e][k] = 0.f;
+  if (pl < PL) {
+#pragma unroll 2
+    for (int64_t p = p0 + pl; p < p1; p += PL) {
+      const uint4 gv = *reinterpret_cast<const uint4*>(dy + p * O + g * 8);
+      uint4 yv = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      if (y) yv = *reinterpret_cast<const uint4*>(y + p * O + g * 8);
+      const uint32_t pi = (uint32_t)p, q = pi / (uint32_t)F1;
+      const int f1 = (int)(pi - q * (uint32_t)F1);
+      const int b = (int)(q / (uint32_t)T1);
+      const int t1 = (int)(q - (uint32_t)b * (uint32_t)T1);
+      const bf16_t* xb = x + ((int64_t)b * Tn + 2 * t1) * Fn + 2 * f1;
+      float xv[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = ldf(xb + kh * Fn + kw);
+      float gf[8], yf[8];
+      unpack8(gv, gf);
+      unpack8(yv, yf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gg = yf[e] > 0.f ? gf[e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[e][k] += gg * xv[k];
+        acc[e][9] += gg;
+      }
+    }
+  }
+  for (int r = 1; r < PL; ++r) {           // fixed-order fold of the pixel lanes
+    __syncthreads();
+    if (pl == r) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) red[(e * 10 + k) * og + g] = acc[e][k];
+    }
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[e][k] += red[(e * 10 + k) * og + g];
+    }
+  }
+  if (pl == 0) {
+    float* out = partial + ((int64_t)blockIdx.x * O + g * 8) * 10;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int k = 0; k < 10; k += 2) *reinterpret_cast<float2*>(out + e * 10 + k) = make_float2(acc[e][k], acc[e][k + 1]);
+  }
+}
+
 // one wavefront per output element: lanes stride over the chunk partials (independent loads), fixed-order wave sum
 __global__ __launch_bounds__(256) void conv_in1_wgrad_final_kernel(int O, int chunks, const float* __restrict__ partial,
                                                                    float* __restrict__ dw, float* __restrict__ db, int accumulate) {
@@ -144,7 +221,11 @@ extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, con
   const int ppc = (int)((npix + chunks - 1) / chunks);
   chunks = (int)((npix + ppc - 1) / ppc);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == S2S_F32)
+  const int og = O / 8;
+  if (dtype != S2S_F32 && O % 8 == 0 && og <= 256 && npix < (int64_t)1 << 31 && (uintptr_t)dy % 16 == 0 && (!y || (uintptr_t)y % 16 == 0))
+    hipLaunchKernelGGL(conv_in1_wgrad_vec_kernel, dim3(chunks), dim3(256), (size_t)og * 80 * sizeof(float), st, B, Tn, Fn, T1, F1, O,
+                       (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, partial, ppc);
+  else if (dtype == S2S_F32)
     hipLaunchKernelGGL(conv_in1_wgrad_kernel<float>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const float*)x, (const float*)dy, (const float*)y, partial, ppc);
   else
     hipLaunchKernelGGL(conv_in1_wgrad_kernel<bf16_t>, dim3(chunks), dim3(256), 0, st, B, Tn, Fn, T1, F1, O, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, partial, ppc);

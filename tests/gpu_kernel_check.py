@@ -346,6 +346,72 @@ def gemm_conv2d(dtype):
 
 
 @case
+def conv2d_subsampling_frontend():
+    """Conv2d(1,C,3,2)+ReLU -> Conv2d(C,C,3,2)+ReLU -> Linear front-end in fp32, forward and every gradient, against torch
+    (direct C_in=1 kernels, implicit-GEMM conv, col2im, relu' fused into the consumers).  The bf16 legs of the same
+    kernels are checked one by one below (a composite bf16 run differs from torch by relu-mask flips of near-zero
+    activations, which is noise, not a defect)."""
+    from seq2seq_vc_amd.modules import Conv2dSubsampling, Lens
+    res = []
+    dtype = torch.float32
+    B, T, idim, C = 3, 67, 80, 64
+    torch.manual_seed(5)
+    m = Conv2dSubsampling(idim, C, 0.0, use_pos_enc=False).to(DEV)
+    x = rnd(B, T, idim, seed=1, dtype=dtype)
+    params = list(m.parameters())
+    y, _ = m(x, Lens([T, 50, 33], DEV))
+    dy = rnd(*y.shape, seed=2, dtype=dtype)
+    y.backward(dy)
+    got = [p.grad.clone() for p in params]
+    ws = [p.detach().clone().requires_grad_(True) for p in params]
+    h = torch.relu(F.conv2d(x.unsqueeze(1), ws[0], ws[1], stride=2))
+    h = torch.relu(F.conv2d(h, ws[2], ws[3], stride=2))
+    b_, c_, t_, f_ = h.shape
+    yr = F.linear(h.transpose(1, 2).contiguous().view(b_, t_, c_ * f_), ws[4], ws[5])
+    yr.backward(dy)
+    res.append(check("frontend fwd[fp32]", y, yr, dtype))
+    for n, a_, r in zip(["conv0.w", "conv0.b", "conv2.w", "conv2.b", "out.w", "out.b"], got, ws):
+        res.append(check(f"frontend d{n}[fp32]", a_, r.grad, dtype, rtol=1e-4, atol=2e-5 * max(float(r.grad.abs().max()), 1.0)))
+    return res
+
+
+@case
+@both_dtypes
+def conv_in1_and_col2im(dtype):
+    """The C_in = 1 streaming kernels and the stride-2 col2im gather, each against fp32 math on the SAME stored operands
+    (so bf16 differs only by the output rounding / fp32 summation order)."""
+    res = []
+    for (B, T, Fd, O, seed) in [(3, 67, 80, 64, 1), (2, 40, 80, 384, 2), (1, 9, 11, 8, 3)]:
+        x = rnd(B, T, Fd, seed=seed, dtype=dtype)
+        w, b = rnd(O, 1, 3, 3, seed=seed + 1, scale=0.3), rnd(O, seed=seed + 2, scale=0.1)
+        y = K.conv_in1_fwd(x, w, b)
+        yr = torch.relu(F.conv2d(x.float().unsqueeze(1), w, b, stride=2)).permute(0, 2, 3, 1)
+        res.append(check(f"conv_in1 fwd[{dtype}] B{B} T{T} F{Fd} O{O}", y, yr, dtype))
+        dy = rnd(*y.shape, seed=seed + 3, dtype=dtype)
+        for use_y in (True, False):
+            dw, db = torch.zeros(O, 1, 3, 3, device=DEV), torch.zeros(O, device=DEV)
+            K.conv_in1_wgrad(x, dy, dw, db, False, y=y if use_y else None)
+            gm = dy.float() * (y.float() > 0) if use_y else dy.float()
+            cols = F.unfold(x.float().unsqueeze(1), 3, stride=2)                      # (B, 9, T1*F1)
+            dwr = torch.einsum("bkp,bpo->ok", cols, gm.reshape(B, -1, O)).view(O, 1, 3, 3)
+            dbr = gm.sum((0, 1, 2))
+            sc = max(float(dwr.abs().max()), 1.0)
+            res.append(check(f"conv_in1 wgrad[{dtype}] O{O} mask={use_y} dw", dw, dwr, torch.float32, rtol=1e-4, atol=1e-4 * sc))
+            res.append(check(f"conv_in1 wgrad[{dtype}] O{O} mask={use_y} db", db, dbr, torch.float32, rtol=1e-4, atol=1e-4 * sc))
+            K.conv_in1_wgrad(x, dy, dw, db, True, y=y if use_y else None)         # accumulate: exactly twice
+            res.append(check(f"conv_in1 wgrad[{dtype}] O{O} accumulate", dw, 2 * dwr, torch.float32, rtol=1e-4, atol=2e-4 * sc))
+    for (B, T1, F1, C, seed) in [(2, 33, 39, 64, 4), (1, 10, 8, 24, 5), (2, 12, 7, 20, 6)]:
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        dcols = rnd(B * T2 * F2, 9 * C, seed=seed, dtype=dtype)
+        dx = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)
+        # fold wants (B, C*9, L) with channel-major rows; ours is tap-major (9, C)
+        cr = dcols.float().view(B, T2 * F2, 9, C).permute(0, 3, 2, 1).reshape(B, C * 9, T2 * F2)
+        dxr = F.fold(cr, (T1, F1), 3, stride=2).permute(0, 2, 3, 1)
+        res.append(check(f"col2im_s2[{dtype}] B{B} {T1}x{F1} C{C}", dx, dxr, dtype, atol=None if dtype == torch.float32 else 5e-2))
+    return res
+
+
+@case
 @both_dtypes
 def layernorm(dtype):
     res = []
