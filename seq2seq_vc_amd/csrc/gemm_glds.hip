@@ -137,22 +137,33 @@ struct RcStage {
     int tap = 0, c = r;
     if (KIND != G_RC_DENSE) { tap = r / o.C; c = r - tap * o.C; }
     const uint64_t zaddr = zero_addr();
+    // the KS consecutive k of a thread walk (b, t2, f2) / (b, t) incrementally: one division per tile, not per load
+    const int kfirst = k0 + kb * 8 + sub * KS;
+    int f2 = 0, t2 = 0, bb = 0, t = 0;
+    if (KIND == G_RC_CONV2D) {
+      const int bt = kfirst / o.F2;
+      f2 = kfirst - bt * o.F2;
+      bb = bt / o.T2;
+      t2 = bt - bb * o.T2;
+    } else if (KIND == G_RC_CONV1D) {
+      t = kfirst % o.T;
+    }
+    const int kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
-      const int k = k0 + kb * 8 + sub * KS + j;
+      const int k = kfirst + j;
       bool ok = r < R && k < K;
       int64_t off;
       if (KIND == G_RC_DENSE) {
         off = (int64_t)k * o.ld + r;
       } else if (KIND == G_RC_CONV1D) {
-        const int t = k % o.T, tt = t + tap - o.pad;
+        const int tt = t + tap - o.pad;
         ok = ok && tt >= 0 && tt < o.T;
         off = (int64_t)(k + tap - o.pad) * o.ld + c;
+        if (++t == o.T) t = 0;
       } else {
-        const int f2 = k % o.F2, bt = k / o.F2;
-        const int t2 = bt % o.T2, b = bt / o.T2;
-        const int kh = tap / 3, kw = tap - kh * 3;
-        off = ((int64_t)(b * o.T1 + 2 * t2 + kh) * o.F1 + (2 * f2 + kw)) * o.ld + c;
+        off = ((int64_t)(bb * o.T1 + 2 * t2 + kh) * o.F1 + (2 * f2 + kw)) * o.ld + c;
+        if (++f2 == o.F2) { f2 = 0; if (++t2 == o.T2) { t2 = 0; ++bb; } }
       }
       reg[j] = *reinterpret_cast<const uint4*>(ok ? reinterpret_cast<uint64_t>(base + off) : zaddr);
     }

@@ -107,6 +107,17 @@ def main():
         line("fwd   vtn conv2d 3x3 s2 implicit", M, N, Kd,
              bench(lambda: K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(w, 9 * C), M, N, Kd, y,
                                   in_dtype=dtype, bias=b, act="relu"), a.iters))
+        dy = rnd(B, T2, F2, O)
+        dcols = torch.empty(M, 9 * C, dtype=dtype, device=dev)
+        line("dgrad vtn conv2d dcols = dY.Wp", M, 9 * C, O,
+             bench(lambda: K.gemm(K.operand(dy, O), K.operand(w, 9 * C, layout=K.RC), M, 9 * C, O, dcols, in_dtype=dtype), a.iters))
+        line("dgrad vtn conv2d col2im (us only)", 0, 0, 0, bench(lambda: K.col2im_s2(dcols, B, T1, F1, C, T2, F2), a.iters))
+        dwp = torch.empty(O, 9 * C, dtype=torch.float32, device=dev)
+        for tile, sk in ((128, 4), (128, 6), (128, 8), (128, 12), (64, 4), (64, 6)):
+            line(f"wgrad vtn conv2d implicit [tile {tile} splitk {sk}] plan={K.plan_gemm(O, 9 * C, M)}", O, 9 * C, M,
+                 bench(lambda: K.gemm(K.operand(dy, O, layout=K.RC),
+                                      K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M, dwp,
+                                      in_dtype=dtype, splitk=sk, tile=tile), a.iters))
     # postnet Conv1d k5 256->256 as implicit GEMM (B32 T256)
     if not a.filter or a.filter in "conv1d":
         B, T, Cin, Cout, ks = 32, 256, 256, 256, 5
