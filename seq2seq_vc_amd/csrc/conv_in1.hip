@@ -20,46 +20,52 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&r)[8]) {
   *reinterpret_cast<uint4*>(p) = v;
 }
 
-// each thread: one output pixel x 8 consecutive channels (one 16-byte store for bf16, two for fp32).  Weights sit in
-// LDS tap-major ([tap][O], bias as a 10th row) so that the 8 channels of a thread are two 16-byte LDS reads per tap
-// and lanes with consecutive channel groups read consecutive addresses (channel-major [O][9] put lanes 72 floats
-// apart: 4-way bank conflicts on 72 scalar reads per thread, which made the kernel LDS-bound at 0.46 TB/s).
+// A thread owns 8 consecutive channels for the whole launch -- its 9x8 weights + 8 biases live in 80 registers -- and walks
+// every (256 / (O/8))-th pixel of the block's contiguous pixel range: per pixel 9 broadcast input loads, 72 FMAs and one
+// 16-byte (bf16) / two 16-byte (fp32) coalesced stores; nothing but the store stream touches memory in the loop.
+// (The first version re-read the weights from LDS for every pixel -- 320 B of LDS traffic per 16 B stored -- and ran at
+// 0.67 TB/s.)
 template <typename T>
 __global__ __launch_bounds__(256) void conv_in1_fwd_kernel(int B, int Tn, int Fn, int T1, int F1, int O, const T* __restrict__ x,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                           T* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float sw[];  // [10][O]: 9 taps + bias
+                                                           T* __restrict__ y, int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [10][O]: 9 taps + bias (coalesced staging of the weights)
   for (int i = threadIdx.x; i < O * 9; i += 256) sw[(i % 9) * O + i / 9] = w[i];
   for (int i = threadIdx.x; i < O; i += 256) sw[9 * O + i] = bias ? bias[i] : 0.f;
   __syncthreads();
-  const int og = O / 8;
-  const int64_t n = (int64_t)B * T1 * F1 * og;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int g = (int)(i % og);
-    int64_t p = i / og;
-    const int f1 = (int)(p % F1); p /= F1;
-    const int t1 = (int)(p % T1);
-    const int b = (int)(p / T1);
+  const int og = O / 8, PL = 256 / og;
+  const int g = threadIdx.x % og, pl = threadIdx.x / og;
+  if (pl >= PL) return;
+  float wr[10][8];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const float4 w0 = *reinterpret_cast<const float4*>(sw + k * O + g * 8), w1 = *reinterpret_cast<const float4*>(sw + k * O + g * 8 + 4);
+    wr[k][0] = w0.x; wr[k][1] = w0.y; wr[k][2] = w0.z; wr[k][3] = w0.w; wr[k][4] = w1.x; wr[k][5] = w1.y; wr[k][6] = w1.z; wr[k][7] = w1.w;
+  }
+  const uint32_t npix = (uint32_t)B * T1 * F1;
+  const uint32_t p0 = blockIdx.x * (uint32_t)pix_per_block;
+  const uint32_t p1 = (p0 + pix_per_block < npix) ? p0 + pix_per_block : npix;
+#pragma unroll 2
+  for (uint32_t p = p0 + pl; p < p1; p += PL) {
+    const uint32_t q = p / (uint32_t)F1;
+    const int f1 = (int)(p - q * (uint32_t)F1);
+    const int b = (int)(q / (uint32_t)T1);
+    const int t1 = (int)(q - (uint32_t)b * (uint32_t)T1);
+    const T* xb = x + ((int64_t)b * Tn + 2 * t1) * Fn + 2 * f1;
     float xv[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = ldf(x + ((int64_t)b * Tn + 2 * t1 + kh) * Fn + 2 * f1 + kw);
-    T* yo = y + (i / og) * O + g * 8;
+      for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = ldf(xb + kh * Fn + kw);
     float r[8];
-    {
-      const float4 b0 = *reinterpret_cast<const float4*>(sw + 9 * O + g * 8), b1 = *reinterpret_cast<const float4*>(sw + 9 * O + g * 8 + 4);
-      r[0] = b0.x; r[1] = b0.y; r[2] = b0.z; r[3] = b0.w; r[4] = b1.x; r[5] = b1.y; r[6] = b1.z; r[7] = b1.w;
-    }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const float4 w0 = *reinterpret_cast<const float4*>(sw + k * O + g * 8), w1 = *reinterpret_cast<const float4*>(sw + k * O + g * 8 + 4);
-      r[0] += w0.x * xv[k]; r[1] += w0.y * xv[k]; r[2] += w0.z * xv[k]; r[3] += w0.w * xv[k];
-      r[4] += w1.x * xv[k]; r[5] += w1.y * xv[k]; r[6] += w1.z * xv[k]; r[7] += w1.w * xv[k];
-    }
+    for (int e = 0; e < 8; ++e) {
+      float a = wr[9][e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = r[e] > 0.f ? r[e] : 0.f;
-    store8(yo, r);   // 16-byte (bf16) / 2 x 16-byte (fp32) coalesced stores
+      for (int k = 0; k < 9; ++k) a += wr[k][e] * xv[k];
+      r[e] = a > 0.f ? a : 0.f;
+    }
+    store8(y + (int64_t)p * O + g * 8, r);
   }
 }
 
@@ -193,16 +199,20 @@ extern "C" int s2svc_conv_in1_fwd(int dtype, int B, int Tn, int Fn, int O, const
                                   void* y, void* stream) {
   S2S_REQUIRE(O % 8 == 0 && Tn >= 3 && Fn >= 3, "conv_in1_fwd: need O % 8 == 0 and T,F >= 3");
   const int T1 = (Tn - 3) / 2 + 1, F1 = (Fn - 3) / 2 + 1;
-  const int64_t n = (int64_t)B * T1 * F1 * (O / 8);
-  if (n == 0) return 0;
-  int nb = (int)((n + 255) / 256);
-  if (nb > 4096) nb = 4096;
+  const int64_t npix = (int64_t)B * T1 * F1;
+  if (npix == 0) return 0;
+  S2S_REQUIRE(O <= 2048 && npix < ((int64_t)1 << 31), "conv_in1_fwd: need O <= 2048 and fewer than 2^31 output pixels");
+  const int lanes = 256 / (O / 8);
+  int nb = (int)((npix + lanes * 8 - 1) / (lanes * 8));        // >= 8 pixels per lane
+  if (nb > 1024) nb = 1024;
+  const int ppb = (int)((npix + nb - 1) / nb);
+  nb = (int)((npix + ppb - 1) / ppb);
   const size_t shm = (size_t)O * 10 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(conv_in1_fwd_kernel<float>, dim3(nb), dim3(256), shm, st, B, Tn, Fn, T1, F1, O, (const float*)x, w, bias, (float*)y);
+    hipLaunchKernelGGL(conv_in1_fwd_kernel<float>, dim3(nb), dim3(256), shm, st, B, Tn, Fn, T1, F1, O, (const float*)x, w, bias, (float*)y, ppb);
   else
-    hipLaunchKernelGGL(conv_in1_fwd_kernel<bf16_t>, dim3(nb), dim3(256), shm, st, B, Tn, Fn, T1, F1, O, (const bf16_t*)x, w, bias, (bf16_t*)y);
+    hipLaunchKernelGGL(conv_in1_fwd_kernel<bf16_t>, dim3(nb), dim3(256), shm, st, B, Tn, Fn, T1, F1, O, (const bf16_t*)x, w, bias, (bf16_t*)y, ppb);
   S2S_CHECK_LAUNCH("conv_in1_fwd_kernel");
   return 0;
 }
