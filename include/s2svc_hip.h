@@ -14,7 +14,7 @@
  *   - dtype codes: 0 = float32, 1 = bfloat16 (raw uint16 storage).  Activations are channel-last,
  *     contiguous (B, T, D).  Reductions / softmax / LN / BN statistics are fp32, MAS is fp64;
  *   - masks never exist as tensors: kernels take int32 per-utterance length vectors;
- *   - dropout: a mask is a pure function of (seed, element index) (Philox-4x32-10); kernels read
+ *   - dropout: a mask is a pure function of (seed, element index) (SplitMix64 output function over seed + index/4, 16 bits per element); kernels read
  *     seed = *seed_base + seed_off, seed_base in device memory (may be NULL), so a captured hipGraph
  *     draws fresh masks on every replay and backward kernels regenerate masks instead of loading them.
  */

@@ -12,7 +12,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libs2svc_hip.so")
+# S2SVC_LIB: load another build of the SAME library (A/B timing of two kernel variants on one GPU box)
+LIB_PATH = os.environ.get("S2SVC_LIB") or os.path.join(CSRC, "libs2svc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 

@@ -89,7 +89,7 @@ __device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, 
   }
   constexpr int LPR = WTN / 8;          // lanes per row
   constexpr int RPP = 64 / LPR;         // rows per pass
-  // NOT unrolled: the body is load/store bound, and unrolling it (8 passes x 8 values x Philox state) raised the
+  // NOT unrolled: the body is load/store bound, and unrolling it (8 passes x 8 values x RNG state) raised the
   // register demand of the whole kernel until hipcc spilled the MFMA accumulators inside the K loop (5x slower)
 #pragma unroll 1
   for (int p = 0; p < WTM / RPP; ++p) {
@@ -116,17 +116,14 @@ __device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, 
       const uint64_t seed = (d.seed_base ? *d.seed_base : 0ull) + d.seed_off;
       const float inv_keep = 1.f / (1.f - d.drop_p);
       const uint64_t idx = (uint64_t)((int64_t)m * d.N + n);
-      // idx is a multiple of 8 (N % 8 == 0, col % 8 == 0): two Philox calls cover the 8 values, exactly the draws
-      // dropout_scale(seed, idx + e) makes for them
+      // idx is a multiple of 8 (N % 8 == 0, col % 8 == 0): two 64-bit draws cover the 8 values, exactly the fields
+      // dropout_scale(seed, idx + e) reads for them
+      const uint32_t thr = dropout_threshold(d.drop_p);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const uint4 r = philox4(seed, (idx >> 2) + q);
-        const uint32_t w4[4] = {r.x, r.y, r.z, r.w};
+        const uint64_t r = dropout_draw(seed, (idx >> 2) + q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float u = (float)(w4[e] >> 8) * (1.0f / 16777216.0f);
-          v[4 * q + e] *= u < d.drop_p ? 0.f : inv_keep;
-        }
+        for (int e = 0; e < 4; ++e) v[4 * q + e] *= ((uint32_t)(r >> (16 * e)) & 0xffffu) < thr ? 0.f : inv_keep;
       }
     }
     if (d.emask) {

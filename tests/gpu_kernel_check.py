@@ -108,7 +108,7 @@ def gemm_epilogue_dropout_mask(dtype):
 @case
 def attention_fused_vs_reference():
     """Fused short-sequence attention (bf16): forward / backward vs fp32 torch math, and -- with dropout on -- vs the unfused
-    kernels (same seed => same Philox masks), for self / causal / source attention on packed and separate projections."""
+    kernels (same seed => same dropout masks), for self / causal / source attention on packed and separate projections."""
     from seq2seq_vc_amd.ops import functional as Fn
     from seq2seq_vc_amd.ops import kernels_attn as KAT
     res = []
