@@ -625,6 +625,37 @@ def elementwise(dtype):
 
 
 @case
+def dropout_mask_statistics():
+    """The counter-based dropout masks (csrc/common.h): keep rate within 4 sigma for several p, masks of neighbouring
+    seeds (consecutive op offsets, consecutive steps) and of neighbouring elements uncorrelated, same seed => same mask."""
+    res = []
+    n = 1 << 22
+    ones = torch.ones(n, dtype=torch.float32, device=DEV)
+    K.manual_seed(1234)
+
+    def mask(p, seed):
+        return (K.act_dropout_fwd(ones, None, p, seed) > 0).float()
+    for p in (0.1, 0.5, 0.9, 0.05):
+        sd = K.new_seed(ones.device)
+        m = mask(p, sd)
+        keep = m.mean().item()
+        sigma = math.sqrt(p * (1 - p) / n)
+        res.append((abs(keep - (1 - p)) < 4 * sigma + 2.0 ** -16, f"keep rate p={p}: {keep:.5f} (4 sigma = {4 * sigma:.5f})"))
+        res.append((torch.equal(m, mask(p, sd)), f"p={p}: same (seed, index) -> same mask"))
+        c = m - m.mean()
+        var = (c * c).mean().item()
+        for lag in (1, 2, 3, 4, 5, 8, 64, 1536):
+            r = (c[:-lag] * c[lag:]).mean().item() / var
+            res.append((abs(r) < 5 / math.sqrt(n), f"p={p}: lag-{lag} autocorrelation {r:+.2e}"))
+        for d in (1, 2, 0x10001):                           # next op in the step / the same op one step later
+            m2 = mask(p, (sd[0], sd[1] + d))
+            c2 = m2 - m2.mean()
+            r = (c * c2).mean().item() / var
+            res.append((abs(r) < 5 / math.sqrt(n), f"p={p}: correlation with seed+{d:#x} {r:+.2e}"))
+    return res
+
+
+@case
 def mas_kernel():
     from oracle import mas as omas
     res = []
