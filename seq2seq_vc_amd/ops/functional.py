@@ -10,6 +10,7 @@ Conventions
     gets no tensor for that input.
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -92,6 +93,8 @@ class _Side:
     streams = []
     idx = 0
     pending = []     # tensors that must stay alive until the join (their memory is in use on a side stream)
+    queue = []       # closures waiting for the next fork point
+    batch = int(os.environ.get("S2SVC_SIDE_BATCH", "6"))
 
 
 def enable_side_streams(n=4):
@@ -101,21 +104,35 @@ def enable_side_streams(n=4):
 
 
 def _side_run(fn, keep=()):
+    """Parameter-gradient work off the data-gradient chain: `fn` is queued and runs on a side stream in batches of
+    `_Side.batch` closures -- one fork point (cross-stream edge of the captured graph) per batch instead of one per call."""
     if not _Side.enabled:
         fn()
+        return
+    _Side.queue.append(fn)
+    _Side.pending.append(keep)
+    if len(_Side.queue) >= _Side.batch:
+        _side_flush()
+
+
+def _side_flush():
+    if not _Side.queue:
         return
     main = torch.cuda.current_stream()
     st = _Side.streams[_Side.idx % len(_Side.streams)]
     _Side.idx += 1
     st.wait_stream(main)
     with torch.cuda.stream(st):
-        fn()
-    _Side.pending.append(keep)
+        for fn in _Side.queue:
+            fn()
+    _Side.queue = []
 
 
 def side_join():
-    """Make the current stream wait for all side-stream gradient work (call between backward and optimiser)."""
+    """Run what is still queued and make the current stream wait for all side-stream gradient work (call between
+    backward and optimiser)."""
     if _Side.enabled:
+        _side_flush()
         main = torch.cuda.current_stream()
         for st in _Side.streams:
             main.wait_stream(st)
