@@ -832,11 +832,6 @@ class _Conv2dS2(Function):
         dtype = x.dtype
         # the consumer may already have applied relu' in its dgrad epilogue (linear_fc_permuted(..., input_is_relu=True))
         dy = _c(dy) if ctx.grad_premasked else K.act_dropout_bwd(_c(dy), y, act="relu")
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dcols = torch.empty((M2, 9 * C), dtype=dtype, device=x.device)
-            K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), M2, 9 * C, O, dcols, in_dtype=dtype)
-            dx = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)
         dw = db = None
         if weight.requires_grad:
             def work():
@@ -849,10 +844,18 @@ class _Conv2dS2(Function):
                 dwt = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32)
                 return _emit_vgrad(weight, dwt), dbv
             if _slotted(weight, bias):
+                # queued AND forked before the data-gradient GEMM below: this is the last big layer of the backward pass,
+                # its weight gradient would otherwise run alone after the main chain has ended
                 _side_run(work, keep=(dy, x))
+                _side_flush()
             else:
                 dw, db = work()
-        elif bias is not None and bias.requires_grad:
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcols = torch.empty((M2, 9 * C), dtype=dtype, device=x.device)
+            K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), M2, 9 * C, O, dcols, in_dtype=dtype)
+            dx = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)
+        if not weight.requires_grad and bias is not None and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy.view(M2, O))
         return dx, dw, db, None
 
