@@ -465,6 +465,12 @@ bool operand_ok(const s2svc_operand& o) {
   return true;
 }
 
+bool bm32_enabled() {    // S2SVC_GEMM_BM32=0: tuning aid
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_BM32"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 bool disabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("S2SVC_GEMM_NO_GLDS"); v = (e && e[0] == '1') ? 1 : 0; }
@@ -494,6 +500,16 @@ extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
   if (d.tile_hint == 128) big = true;
   if (d.tile_hint == 64) big = false;
   bool launched;
+  // short problems (fewer 64x64 tiles than CUs): halve the tile height, so that ~2 workgroups share a CU and cover each
+  // other's load latency -- with one resident workgroup per CU the 6-step K loop of a 2016 x 384 x 384 linear is a
+  // chain of exposed DMA latencies
+  const int64_t tiles64 = (int64_t)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nb0 * d.nb1 * splitk;
+  if (!big && bm32_enabled() && tiles64 < 256 && d.M > 64 && !d.a_rowsum && kind_of(d.A) == G_KC_DENSE && kind_of(d.B) == G_KC_DENSE) {
+    dim3 grid((d.N + 63) / 64, (d.M + 31) / 32, d.nb0 * d.nb1 * splitk);
+    hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 3, 64>), grid, dim3(256), 0, st, d);
+    S2S_CHECK_LAUNCH("gemm_dma_kernel");
+    return 1;
+  }
   if (big) {
     dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.nb0 * d.nb1 * splitk);
     launched = launch_kinds<128, 128>(d, grid, st);
