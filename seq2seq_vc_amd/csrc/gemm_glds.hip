@@ -465,6 +465,12 @@ bool operand_ok(const s2svc_operand& o) {
   return true;
 }
 
+int big_min_tiles() {     // S2SVC_GEMM_BIG_TILES: 128x128 tiles from this many of them on (tuning aid)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_BIG_TILES"); v = e ? atoi(e) : 192; }
+  return v;
+}
+
 bool bm32_enabled() {    // S2SVC_GEMM_BM32=0: tuning aid
   static int v = -1;
   if (v < 0) { const char* e = getenv("S2SVC_GEMM_BM32"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -496,7 +502,10 @@ extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int splitk = d.splitk > 1 ? d.splitk : 1;
   const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1 * splitk;
-  bool big = tiles128 >= 192 && d.M >= 128 && d.N >= 128;
+  bool big = tiles128 >= big_min_tiles() && d.M >= 128 && d.N >= 128;
+  // under one wave of 128x128 tiles AND a short reduction: the 3-stage 64x64 kernel (3 workgroups per CU) hides the
+  // few K steps better (VTN FFN 2016 x 1536 x 384: step -0.13 ms)
+  if (big && tiles128 < 256 && d.K <= 384) big = false;
   if (d.tile_hint == 128) big = true;
   if (d.tile_hint == 64) big = false;
   bool launched;
