@@ -99,6 +99,19 @@ typedef struct {
 
 int s2svc_gemm(const s2svc_gemm_desc* desc /* host */, void* stream);
 
+/* Grouped launch of independent weight-gradient GEMMs  dW[N_out, N_in] (+)= dY^T . X  (bf16, both operands dense and
+   row-contiguous -- what the backward of every Linear / 1x1 Conv1d issues; replaces the per-layer torch.nn.Linear weight
+   gradients autograd computes one by one behind trainers/ar_vc.py:99 `loss.backward()`).  The host queues the
+   descriptors of a few consecutive layers during backward and launches them as ONE grid: every workgroup runs the whole
+   reduction of its output tile, so there is no split-K workspace and no reduction pass.
+     _ok : 1 if `desc` can join a group (else launch it with s2svc_gemm);
+     s2svc_gemm_grouped : `descs` is a HOST array; descriptors travel by value in the kernel arguments (11 per launch,
+           n problems take ceil(n / 11) launches; hipGraph capture records them with the nodes), `tile` = 64 or 128 is the
+           output tile edge, every descriptor must have splitk <= 1.
+   Two descriptors of one call must not write the same C / a_rowsum (they run concurrently). */
+int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc /* host */);
+int s2svc_gemm_grouped(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream);
+
 /* ========================================================================================== */
 /* LayerNorm fused with residual-add + dropout; BatchNorm1d; deterministic column reductions  */
 /* replaces: modules/transformer/layer_norm.py:12-42 and the `residual + dropout(...)` lines   */

@@ -76,6 +76,8 @@ class GemmDesc(ctypes.Structure):
 
 _SIGS = {
     "s2svc_gemm": [ctypes.POINTER(GemmDesc), c_vp],
+    "s2svc_gemm_grouped_ok": [c_vp],
+    "s2svc_gemm_grouped": [c_vp, c_i32, c_i32, c_vp],
     "s2svc_layernorm_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_layernorm_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_colreduce": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],

@@ -12,6 +12,7 @@
 //     K tile.  Pieces outside the matrix / the conv input are fetched from a 16-byte zero block.
 //   * 128x128 or 64x64 output tile per 4-wave workgroup (2x2 waves, 4x4 / 2x2 MFMA 16x16x32 fragments per wave),
 //     BK = 64, optional split-K (fp32 partials + splitk_reduce_kernel) and the fused A-row-sum of the wgrad GEMMs.
+#include <cstring>
 #include "gemm_common.h"
 
 namespace {
@@ -231,18 +232,16 @@ template <int ROWS, int KIND> struct Stage<ROWS, KIND, true> {
   __device__ __forceinline__ void finish(char* lds) const { s.store(lds); }
 };
 
+// One output tile of one GEMM: the body shared by the plain launch (one problem per grid) and the grouped launch (several
+// independent problems in one grid, see gemm_grouped_kernel).  smem: 2 * (BM + BN) * 128 bytes, 1024-aligned.
 template <int BM, int BN, int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const s2svc_gemm_desc d) {
+__device__ __forceinline__ void gemm_glds_tile(const s2svc_gemm_desc& d, int tile_m, int tile_n, int zb, int zs, char* smem) {
   constexpr int BK = 64;                               // bf16 per K tile: 128-B rows, 8 pieces of 16 B
   constexpr int FM = BM / 32, FN = BN / 32;            // 16x16 fragments per wave along m / n
   constexpr int ABYTES = BM * 128, BBYTES = BN * 128, STAGE_BYTES = ABYTES + BBYTES;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
 
   const int splitk = d.splitk > 1 ? d.splitk : 1;
-  const int zb = blockIdx.z / splitk, zs = blockIdx.z - zb * splitk;
   const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
-  int tile_m, tile_n;
-  tile_of_block(tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const bf16_t* Ab = (const bf16_t*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1;
   const bf16_t* Bb = (const bf16_t*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1;
@@ -323,10 +322,46 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const s2svc_gemm_desc d)
       else d.a_rowsum[m] = (d.a_rowsum_accumulate ? d.a_rowsum[m] : 0.f) + rowsum;
     }
   }
-  static_assert(sizeof(smem) >= (size_t)BM * BN * 4, "the operand stages double as the fp32 C tiles of the epilogue");
+  static_assert(2 * STAGE_BYTES >= BM * BN * 4, "the operand stages double as the fp32 C tiles of the epilogue");
   __syncthreads();               // every wave is done with the operand stages: reuse them as fp32 C tiles
   epilogue_tile<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2),
                                 splitk, zs, zb);
+}
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const s2svc_gemm_desc d) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * (BM + BN) * 128];
+  const int splitk = d.splitk > 1 ? d.splitk : 1;
+  const int zb = blockIdx.z / splitk, zs = blockIdx.z - zb * splitk;
+  int tile_m, tile_n;
+  tile_of_block(tile_m, tile_n);
+  gemm_glds_tile<BM, BN, AMODE, BMODE>(d, tile_m, tile_n, zb, zs, smem);
+}
+
+// Grouped launch: up to S2S_GROUP_MAX independent GEMMs (the weight-gradient GEMMs of a few consecutive layers, queued
+// during backward) as ONE grid.  tile_start[p] .. tile_start[p+1] are the workgroups of problem p (row-major tiles).
+// The descriptors travel BY VALUE in the kernel-argument segment (nothing to upload; hipGraph capture records them with
+// the node).  Each workgroup runs the full K loop of its tile: with several problems' tiles in flight the grid fills
+// the chip without split-K, so there is no partial-sum workspace and no reduction pass.
+#define S2S_GROUP_MAX 11                                   /* 11 * 352 B + prefix sums < the 4 KB kernarg limit */
+struct group_args {
+  s2svc_gemm_desc d[S2S_GROUP_MAX];
+  int32_t tile_start[S2S_GROUP_MAX + 1];
+  int32_t n;
+};
+static_assert(sizeof(group_args) <= 4096, "kernel arguments are limited to 4 KB");
+
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(const group_args g) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * (BM + BN) * 128];
+  int p = 0;                                              // tile_start[p] <= blockIdx.x < tile_start[p + 1]
+#pragma unroll
+  for (int i = 1; i < S2S_GROUP_MAX; ++i) p += (i < g.n && g.tile_start[i] <= (int)blockIdx.x) ? 1 : 0;
+  const s2svc_gemm_desc& d = g.d[p];
+  const int t = (int)blockIdx.x - g.tile_start[p];
+  const int tiles_n = (d.N + BN - 1) / BN;
+  const int tile_m = t / tiles_n;
+  gemm_glds_tile<BM, BN, AMODE, BMODE>(d, tile_m, t - tile_m * tiles_n, 0, 0, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -483,19 +518,57 @@ bool disabled() {
   return v == 1;
 }
 
+bool extent_ok(const s2svc_operand& o, int extent) {
+  // 16-byte pieces run along the row index (RC) or along k (KC): the extent must be a multiple of 8, or the caller
+  // declares the rows zero-padded up to one (whole pieces are then fetched unmasked)
+  if (extent % 8 == 0) return true;
+  return o.mode == S2SVC_OP_DENSE && o.zero_padded && o.ld >= (int64_t)((extent + 7) / 8 * 8);
+}
+
 }  // namespace
+
+// ---- grouped weight-gradient GEMMs (C[N_out, N_in] (+)= dY^T . X, both operands row-contiguous) -------------------
+extern "C" int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc) {
+  const s2svc_gemm_desc& d = *desc;
+  if (disabled() || d.dtype != S2S_BF16 || d.nb0 * d.nb1 != 1) return 0;
+  if (kind_of(d.A) != G_RC_DENSE || kind_of(d.B) != G_RC_DENSE) return 0;
+  if (!operand_ok(d.A) || !operand_ok(d.B) || !extent_ok(d.A, d.M) || !extent_ok(d.B, d.N)) return 0;
+  if (d.emask || d.drop_p > 0.f || d.M <= 0 || d.N <= 0 || d.K <= 0) return 0;
+  return 1;
+}
+
+extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile, void* stream) {
+  S2S_REQUIRE(descs && n > 0 && (tile == 64 || tile == 128), "gemm_grouped: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += S2S_GROUP_MAX) {
+    group_args g;
+    std::memset(&g, 0, sizeof(g));
+    g.n = (n - i0 < S2S_GROUP_MAX) ? n - i0 : S2S_GROUP_MAX;
+    int64_t total = 0;
+    for (int i = 0; i < g.n; ++i) {
+      const s2svc_gemm_desc& d = descs[i0 + i];
+      S2S_REQUIRE(s2svc_gemm_grouped_ok(&d), "gemm_grouped: a descriptor is not eligible (check s2svc_gemm_grouped_ok first)");
+      S2S_REQUIRE(d.splitk <= 1, "gemm_grouped: grouped problems run unsplit (splitk must be <= 1)");
+      g.d[i] = d;
+      g.tile_start[i] = (int32_t)total;
+      total += (int64_t)((d.M + tile - 1) / tile) * ((d.N + tile - 1) / tile);
+      S2S_REQUIRE(total < (1ll << 30), "gemm_grouped: too many tiles");
+    }
+    for (int i = g.n; i <= S2S_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
+    if (tile == 128)
+      hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, G_RC_DENSE, G_RC_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, G_RC_DENSE, G_RC_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+    S2S_CHECK_LAUNCH("gemm_grouped_kernel");
+  }
+  return 0;
+}
 
 // returns 1 if launched here (the caller still runs the split-K reduction), 0 if the problem is not eligible
 extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
   const s2svc_gemm_desc& d = *desc;
   if (disabled() || d.dtype != S2S_BF16) return 0;
   if (!operand_ok(d.A) || !operand_ok(d.B)) return 0;
-  // 16-byte pieces run along the row index (RC) or along k (KC): the extent must be a multiple of 8, or the caller
-  // declares the rows zero-padded up to one (whole pieces are then fetched unmasked)
-  auto extent_ok = [&](const s2svc_operand& o, int extent) {
-    if (extent % 8 == 0) return true;
-    return o.mode == S2SVC_OP_DENSE && o.zero_padded && o.ld >= (int64_t)((extent + 7) / 8 * 8);
-  };
   if (!extent_ok(d.A, d.A.layout == S2SVC_LAYOUT_RC ? d.M : d.K)) return 0;
   if (!extent_ok(d.B, d.B.layout == S2SVC_LAYOUT_RC ? d.N : d.K)) return 0;
   if (d.tile_hint != 0 && d.tile_hint != 64 && d.tile_hint != 128) return 0;

@@ -95,6 +95,8 @@ class _Side:
     pending = []     # tensors that must stay alive until the join (their memory is in use on a side stream)
     queue = []       # closures waiting for the next fork point
     batch = int(os.environ.get("S2SVC_SIDE_BATCH", "6"))
+    grouped = []     # weight-gradient GEMM descriptors of the batch being flushed
+    group_wgrad = os.environ.get("S2SVC_NO_GROUPED_WGRAD", "0") != "1"
 
 
 def enable_side_streams(n=4):
@@ -123,8 +125,17 @@ def _side_flush():
     _Side.idx += 1
     st.wait_stream(main)
     with torch.cuda.stream(st):
-        for fn in _Side.queue:
-            fn()
+        if _Side.group_wgrad:
+            # the dense weight-gradient GEMMs of the batch become ONE grouped launch (no split-K, no reduction passes);
+            # everything else the closures launch (conv weight gradients, column reductions, ...) runs as before
+            with K.record_grouped(_Side.grouped):
+                for fn in _Side.queue:
+                    fn()
+            if _Side.grouped:
+                K.flush_grouped(_Side.grouped)
+        else:
+            for fn in _Side.queue:
+                fn()
     _Side.queue = []
 
 

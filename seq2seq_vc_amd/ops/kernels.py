@@ -156,6 +156,15 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
                 raise TypeError("gemm: emask must have the output dtype")
             d.emask, d.ldm = emask.data_ptr(), N
         d.drop_p, d.seed_base, d.seed_off = drop_p, seed[0], seed[1]
+    if _RECORDER is not None:                # queue it for the grouped launch (unsplit) if the kernel takes it
+        d.splitk, d.ws = 1, None
+        if a_rowsum is not None:
+            d.a_rowsum = a_rowsum.data_ptr()
+            d.a_rowsum_accumulate = 1 if a_rowsum_accumulate else 0
+        if _lib.lib().s2svc_gemm_grouped_ok(ctypes.addressof(d)):
+            _RECORDER.append(d)
+            return out
+        d.splitk, d.a_rowsum = splitk, None
     ws = None
     if splitk > 1:
         ws = torch.empty(splitk * nb0 * nb1 * M * N, dtype=torch.float32, device=out.device)
@@ -175,6 +184,51 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         raise TypeError("gemm residual must have the output dtype")
     _lib.check(_lib.lib().s2svc_gemm(ctypes.byref(d), stream()), "s2svc_gemm")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Grouped weight-gradient GEMMs: while a recorder is active, eligible GEMMs (bf16, both operands dense and
+# row-contiguous, i.e. dW = dY^T X) are queued instead of launched; flush_grouped() runs the queue as ONE grid per
+# <= 11 problems (s2svc_gemm_grouped).  The caller keeps the operand tensors alive until the flush.
+# ----------------------------------------------------------------------------------------------
+_RECORDER = None            # list of GemmDesc while recording
+_GROUP_TILE = int(os.environ.get("S2SVC_GROUP_TILE", "64"))      # output tile edge of the grouped kernel (64 / 128)
+
+
+class record_grouped:
+    """with record_grouped(queue): K.gemm(...) appends eligible problems to `queue` (list) instead of launching."""
+
+    def __init__(self, queue):
+        self.queue = queue
+
+    def __enter__(self):
+        global _RECORDER
+        self.prev, _RECORDER = _RECORDER, self.queue
+        return self.queue
+
+    def __exit__(self, *exc):
+        global _RECORDER
+        _RECORDER = self.prev
+        return False
+
+
+def flush_grouped(queue):
+    """Launch every queued problem on the current stream; problems that would write the same C / a_rowsum concurrently
+    go to successive launches.  Empties the queue."""
+    pending = list(queue)
+    del queue[:]
+    while pending:
+        seen, group, rest = set(), [], []
+        for d in pending:
+            keys = {d.C} | ({d.a_rowsum} if d.a_rowsum else set())
+            if keys & seen:
+                rest.append(d)
+            else:
+                seen |= keys
+                group.append(d)
+        pending = rest
+        arr = (_lib.GemmDesc * len(group))(*group)
+        _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(group), _GROUP_TILE, stream()), "s2svc_gemm_grouped")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -258,6 +258,52 @@ def gemm_dgrad_wgrad(dtype):
 
 
 @case
+def gemm_grouped_wgrad():
+    """Queued weight-gradient GEMMs run as grouped launches (no split-K) == fp32 torch, incl. ragged extents, fused bias
+    row sums, accumulation into existing gradients, more problems than one launch holds (11), two problems writing the same
+    gradient (must be serialised into successive launches) and an ineligible problem (launched directly while recording)."""
+    res = []
+    dtype = torch.bfloat16
+    shapes = [(2016, 384, 384), (2016, 384, 1536), (2048, 1536, 384), (2016, 384, 80), (1000, 256, 384), (130, 72, 40), (2016, 7296, 384)]
+    shapes += [(512, 128, 64 + 8 * i) for i in range(7)]           # 14 problems: two launches per flush
+    probs = []
+    for i, (rows, fin, fout) in enumerate(shapes):
+        x, dy = rnd(rows, fin, seed=i, dtype=dtype), rnd(rows, fout, seed=100 + i, dtype=dtype)
+        dw0, db0 = rnd(fout, fin, seed=200 + i), rnd(fout, seed=300 + i)
+        probs.append((x, dy, dw0, db0))
+    saved = K._GROUP_TILE
+    for tile in (64, 128):
+        K._GROUP_TILE = tile
+        outs = [(p[2].clone(), p[3].clone()) for p in probs]
+        queue = []
+        with K.record_grouped(queue):
+            for (x, dy, _, _), (dw, db) in zip(probs, outs):
+                rows, fin, fout = x.shape[0], x.shape[1], dy.shape[1]
+                K.gemm(K.operand(dy, fout, layout=K.RC), K.operand(x, fin, layout=K.RC), fout, fin, rows, dw, in_dtype=dtype, splitk=4,
+                       accumulate=True, a_rowsum=db, a_rowsum_accumulate=True)
+            x, dy = probs[0][0], probs[0][1]       # the first problem once more into the SAME gradient (a shared weight)
+            K.gemm(K.operand(dy, 384, layout=K.RC), K.operand(x, 384, layout=K.RC), 384, 384, 2016, outs[0][0], in_dtype=dtype,
+                   accumulate=True, a_rowsum=outs[0][1], a_rowsum_accumulate=True)
+            y_now = torch.empty(2016, 384, dtype=dtype, device=DEV)      # K-contiguous operands: not eligible, runs immediately
+            w_kc = rnd(384, 384, seed=9, dtype=dtype)
+            K.gemm(K.operand(x, 384), K.operand(w_kc, 384), 2016, 384, 384, y_now, in_dtype=dtype)
+        res.append((len(queue) == len(probs) + 1, f"tile={tile}: {len(queue)} problems queued"))
+        res.append((bool(torch.equal(outs[1][0], probs[1][2])), "nothing is written before the flush"))
+        res.append(check(f"tile={tile}: ineligible problem ran directly", y_now, x.float() @ w_kc.float().t(), dtype, atol=0.3))
+        K.flush_grouped(queue)
+        res.append((len(queue) == 0, "queue empty after the flush"))
+        for i, ((x, dy, dw0, db0), (dw, db)) in enumerate(zip(probs, outs)):
+            mult = 2.0 if i == 0 else 1.0
+            dw_ref = dw0 + mult * (dy.float().t() @ x.float())
+            db_ref = db0 + mult * dy.float().sum(0)
+            res.append(check(f"grouped wgrad tile={tile} #{i} {tuple(dw.shape)} dW", dw, dw_ref, torch.float32, rtol=1e-3,
+                             atol=2e-4 * float(dw_ref.abs().max())))
+            res.append(check(f"grouped wgrad tile={tile} #{i} db", db, db_ref, torch.float32, rtol=1e-3, atol=2e-4 * float(db_ref.abs().max())))
+    K._GROUP_TILE = saved
+    return res
+
+
+@case
 @both_dtypes
 def gemm_batched_attention(dtype):
     res = []
