@@ -161,7 +161,8 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         if a_rowsum is not None:
             d.a_rowsum = a_rowsum.data_ptr()
             d.a_rowsum_accumulate = 1 if a_rowsum_accumulate else 0
-        if _lib.lib().s2svc_gemm_grouped_ok(ctypes.addressof(d)):
+        # small outputs only: a problem with >= _GROUP_MAX_TILES 128x128 tiles fills the chip on its own
+        if ((M + 127) // 128) * ((N + 127) // 128) < _GROUP_MAX_TILES and _lib.lib().s2svc_gemm_grouped_ok(ctypes.addressof(d)):
             _RECORDER.append(d)
             return out
         d.splitk, d.a_rowsum = splitk, None
@@ -193,6 +194,7 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
 # ----------------------------------------------------------------------------------------------
 _RECORDER = None            # list of GemmDesc while recording
 _GROUP_TILE = int(os.environ.get("S2SVC_GROUP_TILE", "64"))      # output tile edge of the grouped kernel (64 / 128)
+_GROUP_MAX_TILES = int(os.environ.get("S2SVC_GROUP_MAX_TILES", "96"))
 
 
 class record_grouped:

@@ -271,7 +271,15 @@ def gemm_grouped_wgrad():
         x, dy = rnd(rows, fin, seed=i, dtype=dtype), rnd(rows, fout, seed=100 + i, dtype=dtype)
         dw0, db0 = rnd(fout, fin, seed=200 + i), rnd(fout, seed=300 + i)
         probs.append((x, dy, dw0, db0))
-    saved = K._GROUP_TILE
+    saved, saved_max = K._GROUP_TILE, K._GROUP_MAX_TILES
+    big = []
+    with K.record_grouped(big):      # default policy: an output with >= _GROUP_MAX_TILES 128x128 tiles is launched directly
+        x, dy, dw0, _ = probs[6]
+        dw = dw0.clone()
+        K.gemm(K.operand(dy, 384, layout=K.RC), K.operand(x, 7296, layout=K.RC), 384, 7296, 2016, dw, in_dtype=dtype, accumulate=True)
+    res.append((len(big) == 0, "a chip-filling problem is not queued"))
+    res.append(check("chip-filling problem launched directly", dw, dw0 + dy.float().t() @ x.float(), torch.float32, rtol=1e-3, atol=0.05))
+    K._GROUP_MAX_TILES = 1 << 30
     for tile in (64, 128):
         K._GROUP_TILE = tile
         outs = [(p[2].clone(), p[3].clone()) for p in probs]
@@ -299,7 +307,7 @@ def gemm_grouped_wgrad():
             res.append(check(f"grouped wgrad tile={tile} #{i} {tuple(dw.shape)} dW", dw, dw_ref, torch.float32, rtol=1e-3,
                              atol=2e-4 * float(dw_ref.abs().max())))
             res.append(check(f"grouped wgrad tile={tile} #{i} db", db, db_ref, torch.float32, rtol=1e-3, atol=2e-4 * float(db_ref.abs().max())))
-    K._GROUP_TILE = saved
+    K._GROUP_TILE, K._GROUP_MAX_TILES = saved, saved_max
     return res
 
 
