@@ -190,9 +190,9 @@ def main():
         after, before, logits, ys_, labels_, olens_, _ = model(xs_d, ilens, ys_d, labels_d, olens)
         l1, bce = crit(after, before, logits, ys_, labels_, olens_)
         (l1 + bce).backward()
-        Fn.side_join()
-        loss_buf[0].copy_(l1.detach())
+        loss_buf[0].copy_(l1.detach())       # (before the join: the copies run while the side streams finish)
         loss_buf[1].copy_(bce.detach())
+        Fn.side_join()
 
     def step_eager():
         fwd_bwd()

@@ -151,6 +151,166 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16, D % 8 == 0, D <= 512*NV: a lane owns NV groups of 8 CONSECUTIVE channels -- every tensor moves in 16-byte
+// loads / stores (the lane + 64*i mapping above issues one 2-byte access per element: 6 per lane and tensor at
+// D = 384).  Same arithmetic, same summation order inside a lane group; the wave reduction is the same butterfly.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack_bf16x8(const uint4& v, float (&f)[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(w[e] << 16); f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack_bf16x8(const float (&f)[8]) {
+  uint4 v;
+  v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+  v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+  v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+  v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  return v;
+}
+__device__ __forceinline__ void load_f32x8(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+// keep-scales of 8 consecutive elements starting at idx (idx % 8 == 0): two draws, the fields dropout_scale() reads
+__device__ __forceinline__ void dropout_scale8(uint64_t seed, uint64_t idx, float p, float inv_keep, float (&m)[8]) {
+  const uint32_t thr = dropout_threshold(p);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint64_t r = dropout_draw(seed, (idx >> 2) + q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[4 * q + e] = ((uint32_t)(r >> (16 * e)) & 0xffffu) < thr ? 0.f : inv_keep;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(int rows, int D, const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                         float p, float hscale, const uint64_t* seed_base, uint64_t seed_off,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         bf16_t* __restrict__ y, bf16_t* __restrict__ s_out, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t base = (int64_t)row * D;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float v[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < D) {
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + base + c), v[i]);
+      if (res) {
+        float r[8], m[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(res + base + c), r);
+        if (p > 0.f) dropout_scale8(seed, (uint64_t)(base + c), p, inv_keep, m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = v[i][e];
+          if (p > 0.f) t *= m[e];
+          v[i][e] = t * hscale + r[e];
+        }
+        const uint4 sv = pack_bf16x8(v[i]);
+        *reinterpret_cast<uint4*>(s_out + base + c) = sv;
+        unpack_bf16x8(sv, v[i]);               // statistics on the stored (rounded) value
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if ((lane + 64 * i) * 8 < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  const float var = wave_sum(sq) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < D) {
+      float g[8], b[8], o[8];
+      load_f32x8(gamma + c, g);
+      load_f32x8(beta + c, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      *reinterpret_cast<uint4*>(y + base + c) = pack_bf16x8(o);
+    }
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(int rows, int D, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const bf16_t* __restrict__ ds_extra,
+                                                         float p, float hscale, const uint64_t* seed_base, uint64_t seed_off,
+                                                         bf16_t* __restrict__ ds, bf16_t* __restrict__ dh) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t base = (int64_t)row * D;
+  const float mu = mean[row], rs = rstd[row];
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float g[NV][8], xh[NV][8];
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < D) {
+      float gm[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + base + c), g[i]);
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(s + base + c), xh[i]);
+      load_f32x8(gamma + c, gm);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        g[i][e] *= gm[e];
+        xh[i][e] = (xh[i][e] - mu) * rs;
+        a += g[i][e];
+        b += g[i][e] * xh[i][e];
+      }
+    }
+  }
+  a = wave_sum(a) / (float)D;
+  b = wave_sum(b) / (float)D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < D) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rs * (g[i][e] - a - xh[i][e] * b);
+      if (ds_extra) {
+        float ex[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(ds_extra + base + c), ex);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += ex[e];
+      }
+      *reinterpret_cast<uint4*>(ds + base + c) = pack_bf16x8(v);
+      if (dh) {
+        float m[8];
+        if (p > 0.f) dropout_scale8(seed, (uint64_t)(base + c), p, inv_keep, m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * (p > 0.f ? m[e] : 1.f) * hscale;
+        *reinterpret_cast<uint4*>(dh + base + c) = pack_bf16x8(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Chunked column reduction over rows of a (rows, D) matrix, deterministic (fixed summation order):
 //   mode 0: sum[c] = S dy[r,c]
 //   mode 1: sum[c] = S dy[r,c];  dot[c] = S dy[r,c]*(x[r,c]-mean[r])*rstd[r]     (LayerNorm dgamma/dbeta)
@@ -306,6 +466,15 @@ inline int ew_blocks(int64_t total) {
 
 }  // namespace
 
+// the 16-byte LayerNorm kernels: bf16, D a multiple of 8 and at most 1024, every tensor 16-byte aligned
+static bool ln_vec_ok(int D, const void* a, const void* b, const void* c, const void* d, const void* e) {
+  if (D % 8 != 0 || D > 1024) return false;
+  const void* ps[5] = {a, b, c, d, e};
+  for (const void* q : ps)
+    if (q && ((uintptr_t)q) % 16 != 0) return false;
+  return true;
+}
+
 extern "C" int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, const void* res, float drop_p, float hscale,
                                    const uint64_t* seed_base, uint64_t seed_off, const float* gamma, const float* beta, float eps, void* y,
                                    void* s_out, float* mean, float* rstd, void* stream) {
@@ -321,6 +490,9 @@ extern "C" int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, co
     if (D <= 512) S2S_LN_FWD((ln_fwd_reg_kernel<float, 8>), float);
     else if (D <= 1024) S2S_LN_FWD((ln_fwd_reg_kernel<float, 16>), float);
     else S2S_LN_FWD(ln_fwd_kernel<float>, float);
+  } else if (ln_vec_ok(D, x, res, y, s_out, gamma) && ((uintptr_t)beta) % 16 == 0) {
+    if (D <= 512) S2S_LN_FWD(ln_fwd_vec_kernel<1>, bf16_t);
+    else S2S_LN_FWD(ln_fwd_vec_kernel<2>, bf16_t);
   } else {
     if (D <= 512) S2S_LN_FWD((ln_fwd_reg_kernel<bf16_t, 8>), bf16_t);
     else if (D <= 1024) S2S_LN_FWD((ln_fwd_reg_kernel<bf16_t, 16>), bf16_t);
@@ -341,7 +513,14 @@ extern "C" int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, c
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, block, 0, st, rows, D, (const float*)dy, (const float*)s, mean, rstd,
                        gamma, (const float*)ds_extra, drop_p, hscale, seed_base, seed_off, (float*)ds, (float*)dh);
-  else
+  else if (ln_vec_ok(D, dy, s, ds, dh, ds_extra) && ((uintptr_t)gamma) % 16 == 0) {
+    if (D <= 512)
+      hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean, rstd, gamma,
+                         (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
+    else
+      hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean, rstd, gamma,
+                         (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
+  } else
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean,
                        rstd, gamma, (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
   S2S_CHECK_LAUNCH("ln_bwd_kernel");

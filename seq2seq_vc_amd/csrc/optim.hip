@@ -15,11 +15,22 @@ namespace {
 
 __global__ __launch_bounds__(256) void sumsq_kernel(int64_t n, const float* __restrict__ g, double* __restrict__ partial) {
   __shared__ double sh[4];
-  double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double v = (double)g[i];
-    acc += v * v;
+  // 16-byte loads, four independent fp64 accumulators per thread (the scalar version ran at 2.2 TB/s)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const int64_t n4 = (((uintptr_t)g) % 16 == 0) ? n / 4 : 0;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = g4[i];
+    a0 += (double)v.x * (double)v.x;
+    a1 += (double)v.y * (double)v.y;
+    a2 += (double)v.z * (double)v.z;
+    a3 += (double)v.w * (double)v.w;
   }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (double)g[i];
+    a0 += v * v;
+  }
+  double acc = (a0 + a1) + (a2 + a3);
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();

@@ -555,7 +555,7 @@ def conv_in1_fwd(x, w, bias):
 def conv_in1_wgrad(x, dy, dw, db, accumulate, y=None):
     B, T, Fd = x.shape
     O = dy.shape[-1]
-    chunks = 1024
+    chunks = 512
     partial = torch.empty(chunks * O * 10, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().s2svc_conv_in1_wgrad(dt(x), B, T, Fd, O, ptr(x), ptr(dy), ptr(y), ptr(dw), ptr(db), 1 if accumulate else 0,
                                                ptr(partial), chunks, stream()), "conv_in1_wgrad")
