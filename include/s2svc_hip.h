@@ -126,12 +126,13 @@ int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, const void* r
 int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, const void* s, const float* mean, const float* rstd,
                         const float* gamma, const void* ds_extra, float drop_p, float hscale, const uint64_t* seed_base,
                         uint64_t seed_off, void* ds, void* dh, void* stream);
-/* chunked column reductions over (rows, D); modes 0..5 see csrc/norm.hip (5: sum dy, sum dy*v[r] with v in `mean`); ws >= ws_chunks*2*D floats */
+/* chunked column reductions over (rows, D); modes 0..6 see csrc/norm.hip (5: sum dy, sum dy*v[r] with v in `mean`; 6: sum x, sum x^2); ws >= ws_chunks*2*D floats */
 int s2svc_colreduce(int dtype, int rows, int D, int mode, const void* dy, const void* x, const float* mean,
                     const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate, float* ws,
                     int ws_chunks, void* stream);
 int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean, const float* var, float* rstd,
-                      float* run_mean, float* run_var, int64_t* num_batches, void* stream);
+                      float* run_mean, float* run_var, int64_t* num_batches, int var_is_ex2 /* var = E[x^2], colreduce mode 6 */,
+                      void* stream);
 int s2svc_rstd_from_var(int C, float eps, const float* var, float* rstd, void* stream);
 int s2svc_bn_apply(int dtype, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
                    const float* gamma, const float* beta, int act, float drop_p, const uint64_t* seed_base,

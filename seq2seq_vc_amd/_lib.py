@@ -81,7 +81,7 @@ _SIGS = {
     "s2svc_layernorm_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_layernorm_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_colreduce": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
-    "s2svc_bn_finalize": [c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_bn_finalize": [c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_rstd_from_var": [c_i32, c_f32, c_vp, c_vp, c_vp],
     "s2svc_bn_apply": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_bn_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],

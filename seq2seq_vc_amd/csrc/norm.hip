@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(int rows, int D, const 
 //   mode 2: sum[c] = S dy[r,c];  dot[c] = S dy[r,c]*(x[r,c]-mean[c])*rstd[c]     (BatchNorm dgamma/dbeta)
 //   mode 3: sum[c] = S (x[r,c]-mean[c])^2                                        (BatchNorm variance)
 //   mode 4: sum[c] = S dy[r,c]*x[r,c]                                            (posenc alpha etc.)
+//   mode 6: sum[c] = S x[r,c];  dot[c] = S x[r,c]^2                              (BatchNorm mean and E[x^2] in ONE pass)
 // stage 1 writes ws[chunk][2][D]; stage 2 sums the chunks and multiplies by `scale`.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mod
       } else if (mode == 3) {
         float dv = ldf(x + o) - mc;
         s0 += dv * dv;
+      } else if (mode == 6) {          // one-pass moments: s0 = sum x ; s1 = sum x^2
+        const float v = ldf(x + o);
+        s0 += v;
+        s1 += v * v;
       } else if (mode == 5) {          // s0 = sum dy ; s1 = sum dy * v[r]  (v handed in through `mean`)
         float g = ldf(dy + o);
         s0 += g;
@@ -442,14 +447,19 @@ __global__ void bn_bwd_kernel(int64_t total, int C, float inv_n, const T* __rest
 // unbiased variance in the running buffer).
 __global__ void bn_finalize_kernel(int C, int n, float eps, float momentum, const float* __restrict__ mean,
                                    const float* __restrict__ var, float* __restrict__ rstd, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var, int64_t* __restrict__ num_batches) {
+                                   float* __restrict__ run_var, int64_t* __restrict__ num_batches, int var_is_ex2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches) *num_batches += 1;
   if (c >= C) return;
-  rstd[c] = 1.0f / sqrtf(var[c] + eps);
+  float vc = var[c];
+  if (var_is_ex2) {                   // `var` holds E[x^2] (one-pass statistics): biased variance = E[x^2] - mean^2
+    vc -= mean[c] * mean[c];
+    vc = vc > 0.f ? vc : 0.f;
+  }
+  rstd[c] = 1.0f / sqrtf(vc + eps);
   if (run_mean) {
     run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean[c];
-    const float unb = n > 1 ? var[c] * ((float)n / (float)(n - 1)) : var[c];
+    const float unb = n > 1 ? vc * ((float)n / (float)(n - 1)) : vc;
     run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
   }
 }
@@ -531,7 +541,7 @@ extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void*
                                const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate,
                                float* ws, int ws_chunks, void* stream) {
   S2S_REQUIRE(rows >= 0 && D > 0 && ws && ws_chunks > 0, "colreduce: bad args");
-  S2S_REQUIRE(mode >= 0 && mode <= 5, "colreduce: bad mode");
+  S2S_REQUIRE(mode >= 0 && mode <= 6, "colreduce: bad mode");
   hipStream_t st = (hipStream_t)stream;
   int chunks = (rows + 63) / 64;
   if (chunks > ws_chunks) chunks = ws_chunks;
@@ -552,9 +562,9 @@ extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void*
 }
 
 extern "C" int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean, const float* var,
-                                 float* rstd, float* run_mean, float* run_var, int64_t* num_batches, void* stream) {
+                                 float* rstd, float* run_mean, float* run_var, int64_t* num_batches, int var_is_ex2, void* stream) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, n, eps, momentum,
-                     mean, var, rstd, run_mean, run_var, num_batches);
+                     mean, var, rstd, run_mean, run_var, num_batches, var_is_ex2);
   S2S_CHECK_LAUNCH("bn_finalize_kernel");
   return 0;
 }

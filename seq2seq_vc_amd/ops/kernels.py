@@ -280,11 +280,12 @@ def colreduce(mode, dy, x=None, mean=None, rstd=None, scale=1.0, want_dot=False,
     return out_sum, out_dot
 
 
-def bn_finalize(mean, var, n, eps, momentum, run_mean=None, run_var=None, num_batches=None):
+def bn_finalize(mean, var, n, eps, momentum, run_mean=None, run_var=None, num_batches=None, var_is_ex2=False):
+    """var_is_ex2: `var` holds E[x^2] (one-pass statistics, colreduce mode 6); the variance is E[x^2] - mean^2."""
     C = mean.numel()
     rstd = torch.empty_like(mean)
     _lib.check(_lib.lib().s2svc_bn_finalize(C, n, eps, momentum, ptr(mean), ptr(var), ptr(rstd), ptr(run_mean),
-                                            ptr(run_var), ptr(num_batches), stream()), "bn_finalize")
+                                            ptr(run_var), ptr(num_batches), 1 if var_is_ex2 else 0, stream()), "bn_finalize")
     return rstd
 
 

@@ -520,6 +520,13 @@ def batchnorm(dtype):
     res.append(check(f"bn fwd[{dtype}]", y, yr, dtype, atol=1e-4 if dtype == torch.float32 else 5e-2))
     res.append(check(f"bn running_mean[{dtype}]", rm, rm2, torch.float32, atol=1e-5))
     res.append(check(f"bn running_var[{dtype}]", rv, rv2, torch.float32, atol=1e-4))
+    # one-pass moments (colreduce mode 6 + var_is_ex2; the bf16 training path) == the two-pass statistics
+    mean1, ex2 = K.colreduce(6, None, x=x, scale=1.0 / rows, rows=rows, D=C, want_dot=True)
+    rm3, rv3 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    rstd1 = K.bn_finalize(mean1, ex2, rows, 1e-5, 0.1, rm3, rv3, None, var_is_ex2=True)
+    res.append(check(f"bn one-pass mean[{dtype}]", mean1, mean, torch.float32, atol=1e-5))
+    res.append(check(f"bn one-pass rstd[{dtype}]", rstd1, rstd, torch.float32, rtol=1e-4, atol=1e-5))
+    res.append(check(f"bn one-pass running_var[{dtype}]", rv3, rv2, torch.float32, atol=1e-4))
     res.append(check(f"bn num_batches[{dtype}]", nb.float().view(1), torch.ones(1), torch.float32))
     yr.backward(dz.float())
     dyp = K.act_dropout_bwd(dz, y, act="tanh")
