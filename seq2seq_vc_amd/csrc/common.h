@@ -81,6 +81,35 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
   return w < dropout_threshold(p) ? 0.f : inv_keep;
 }
 
+// ---- 16-byte (8 x bf16 / 2 x 4 x fp32) register <-> memory helpers of the vectorised element-wise kernels ----
+__device__ __forceinline__ void unpack_bf16x8(const uint4& v, float (&f)[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(w[e] << 16); f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack_bf16x8(const float (&f)[8]) {
+  uint4 v;
+  v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+  v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+  v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+  v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  return v;
+}
+__device__ __forceinline__ void load_f32x8(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+// keep-scales of 8 consecutive elements starting at idx (idx % 8 == 0): two draws, the fields dropout_scale() reads
+__device__ __forceinline__ void dropout_scale8(uint64_t seed, uint64_t idx, float p, float inv_keep, float (&m)[8]) {
+  const uint32_t thr = dropout_threshold(p);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint64_t r = dropout_draw(seed, (idx >> 2) + q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[4 * q + e] = ((uint32_t)(r >> (16 * e)) & 0xffffu) < thr ? 0.f : inv_keep;
+  }
+}
+
 // error plumbing shared by all translation units (defined in api.hip)
 extern "C" void s2svc_set_error(const char* msg);
 #define S2S_CHECK_LAUNCH(name)                                         \

@@ -58,6 +58,53 @@ __global__ void act_dropout_bwd_kernel(int64_t n, const T* __restrict__ dz, cons
   }
 }
 
+// bf16, n % 8 == 0, 16-byte aligned: 8 consecutive elements per thread and iteration (one 16-byte load per tensor, one
+// 16-byte store, two RNG draws) -- same values as the scalar kernels above
+__device__ __forceinline__ float act_grad_from_saved(float s, float m, int act) {
+  if (act == S2S_ACT_RELU) return s > 0.f ? 1.f : 0.f;
+  if (act == S2S_ACT_TANH) { const float yv = m > 0.f ? s / m : 0.f; return 1.f - yv * yv; }
+  if (act == S2S_ACT_SIGMOID) { const float yv = m > 0.f ? s / m : 0.f; return yv * (1.f - yv); }
+  if (act == S2S_ACT_SWISH) { const float sg = 1.f / (1.f + expf(-s)); return sg * (1.f + s * (1.f - sg)); }
+  if (act == S2S_ACT_GELU) {
+    const float cdf = 0.5f * (1.f + erff(s * 0.70710678118654752f));
+    return cdf + s * 0.3989422804014327f * expf(-0.5f * s * s);
+  }
+  return 1.f;
+}
+__global__ void act_dropout_fwd_vec_kernel(int64_t n8, const bf16_t* __restrict__ x, int act, float p, const uint64_t* seed_base,
+                                           uint64_t seed_off, bf16_t* __restrict__ y) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  EW_LOOP(i, n8) {
+    float v[8], m[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(x + i * 8), v);
+    if (p > 0.f) dropout_scale8(seed, (uint64_t)(i * 8), p, inv_keep, m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = act_apply(v[e], act);
+      if (p > 0.f) v[e] *= m[e];
+    }
+    *reinterpret_cast<uint4*>(y + i * 8) = pack_bf16x8(v);
+  }
+}
+__global__ void act_dropout_bwd_vec_kernel(int64_t n8, const bf16_t* __restrict__ dz, const bf16_t* __restrict__ saved, int act, float p,
+                                           const uint64_t* seed_base, uint64_t seed_off, bf16_t* __restrict__ dx) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  EW_LOOP(i, n8) {
+    float g[8], s[8], m[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(dz + i * 8), g);
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(saved + i * 8), s);
+    if (p > 0.f) dropout_scale8(seed, (uint64_t)(i * 8), p, inv_keep, m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float mm = p > 0.f ? m[e] : 1.f;
+      g[e] = g[e] * mm * act_grad_from_saved(s[e], mm, act);
+    }
+    *reinterpret_cast<uint4*>(dx + i * 8) = pack_bf16x8(g);
+  }
+}
+
 // y = dropout(x*xscale + alpha*pe[t, :])    x: (B, T, D), pe: fp32 (>=T, D) table rows t0..t0+T-1
 // reference: layers/positional_encoding.py:57-70 (x*sqrt(d)+pe), :94-106 (x + alpha*pe),
 //            :226-235 / :293-309 (relative variants: x*sqrt(d) only, pe handed to the attention)
@@ -212,6 +259,8 @@ extern "C" int s2svc_act_dropout_fwd(int dtype, int64_t n, const void* x, int ac
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(act_dropout_fwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, n, (const float*)x, act, p, seed_base, seed_off, (float*)y);
+  else if (n % 8 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0)
+    hipLaunchKernelGGL(act_dropout_fwd_vec_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, n / 8, (const bf16_t*)x, act, p, seed_base, seed_off, (bf16_t*)y);
   else
     hipLaunchKernelGGL(act_dropout_fwd_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, n, (const bf16_t*)x, act, p, seed_base, seed_off, (bf16_t*)y);
   S2S_CHECK_LAUNCH("act_dropout_fwd_kernel");
@@ -224,6 +273,8 @@ extern "C" int s2svc_act_dropout_bwd(int dtype, int64_t n, const void* dz, const
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(act_dropout_bwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, n, (const float*)dz, (const float*)saved, act, p, seed_base, seed_off, (float*)dx);
+  else if (n % 8 == 0 && ((uintptr_t)dz) % 16 == 0 && ((uintptr_t)saved) % 16 == 0 && ((uintptr_t)dx) % 16 == 0)
+    hipLaunchKernelGGL(act_dropout_bwd_vec_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, n / 8, (const bf16_t*)dz, (const bf16_t*)saved, act, p, seed_base, seed_off, (bf16_t*)dx);
   else
     hipLaunchKernelGGL(act_dropout_bwd_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, n, (const bf16_t*)dz, (const bf16_t*)saved, act, p, seed_base, seed_off, (bf16_t*)dx);
   S2S_CHECK_LAUNCH("act_dropout_bwd_kernel");

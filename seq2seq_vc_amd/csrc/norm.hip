@@ -151,38 +151,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int D, const T* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16, D % 8 == 0, D <= 512*NV: a lane owns NV groups of 8 CONSECUTIVE channels -- every tensor moves in 16-byte
+// bf16, D % 8 == 0, D <= 512*NV (NV = 1, 2, 4): a lane owns NV groups of 8 CONSECUTIVE channels -- every tensor moves in 16-byte
 // loads / stores (the lane + 64*i mapping above issues one 2-byte access per element: 6 per lane and tensor at
 // D = 384).  Same arithmetic, same summation order inside a lane group; the wave reduction is the same butterfly.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void unpack_bf16x8(const uint4& v, float (&f)[8]) {
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { f[2 * e] = __uint_as_float(w[e] << 16); f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
-}
-__device__ __forceinline__ uint4 pack_bf16x8(const float (&f)[8]) {
-  uint4 v;
-  v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-  v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-  v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-  v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
-  return v;
-}
-__device__ __forceinline__ void load_f32x8(const float* p, float (&f)[8]) {
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-}
-// keep-scales of 8 consecutive elements starting at idx (idx % 8 == 0): two draws, the fields dropout_scale() reads
-__device__ __forceinline__ void dropout_scale8(uint64_t seed, uint64_t idx, float p, float inv_keep, float (&m)[8]) {
-  const uint32_t thr = dropout_threshold(p);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const uint64_t r = dropout_draw(seed, (idx >> 2) + q);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) m[4 * q + e] = ((uint32_t)(r >> (16 * e)) & 0xffffu) < thr ? 0.f : inv_keep;
-  }
-}
-
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(int rows, int D, const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
                                                          float p, float hscale, const uint64_t* seed_base, uint64_t seed_off,
@@ -476,9 +448,9 @@ inline int ew_blocks(int64_t total) {
 
 }  // namespace
 
-// the 16-byte LayerNorm kernels: bf16, D a multiple of 8 and at most 1024, every tensor 16-byte aligned
+// the 16-byte LayerNorm kernels: bf16, D a multiple of 8 and at most 2048, every tensor 16-byte aligned
 static bool ln_vec_ok(int D, const void* a, const void* b, const void* c, const void* d, const void* e) {
-  if (D % 8 != 0 || D > 1024) return false;
+  if (D % 8 != 0 || D > 2048) return false;
   const void* ps[5] = {a, b, c, d, e};
   for (const void* q : ps)
     if (q && ((uintptr_t)q) % 16 != 0) return false;
@@ -502,7 +474,8 @@ extern "C" int s2svc_layernorm_fwd(int dtype, int rows, int D, const void* x, co
     else S2S_LN_FWD(ln_fwd_kernel<float>, float);
   } else if (ln_vec_ok(D, x, res, y, s_out, gamma) && ((uintptr_t)beta) % 16 == 0) {
     if (D <= 512) S2S_LN_FWD(ln_fwd_vec_kernel<1>, bf16_t);
-    else S2S_LN_FWD(ln_fwd_vec_kernel<2>, bf16_t);
+    else if (D <= 1024) S2S_LN_FWD(ln_fwd_vec_kernel<2>, bf16_t);
+    else S2S_LN_FWD(ln_fwd_vec_kernel<4>, bf16_t);
   } else {
     if (D <= 512) S2S_LN_FWD((ln_fwd_reg_kernel<bf16_t, 8>), bf16_t);
     else if (D <= 1024) S2S_LN_FWD((ln_fwd_reg_kernel<bf16_t, 16>), bf16_t);
@@ -527,8 +500,11 @@ extern "C" int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, c
     if (D <= 512)
       hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean, rstd, gamma,
                          (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
-    else
+    else if (D <= 1024)
       hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean, rstd, gamma,
+                         (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
+    else
+      hipLaunchKernelGGL(ln_bwd_vec_kernel<4>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean, rstd, gamma,
                          (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, (bf16_t*)dh);
   } else
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, block, 0, st, rows, D, (const bf16_t*)dy, (const bf16_t*)s, mean,

@@ -651,6 +651,16 @@ def elementwise(dtype):
         res.append((abs(val - 1 / (1 - p)) < 2e-2, f"dropout scale[{dtype}] p={p}: {val:.4f}"))
         dxm = K.act_dropout_bwd(big, y, p=p, seed=seed)
         res.append(check(f"dropout fwd/bwd same mask[{dtype}] p={p}", dxm, y, dtype))
+    # the 16-byte kernels (n % 8 == 0) and the scalar ones (any n) draw the same masks and compute the same values
+    xs = rnd(4099, seed=7, dtype=dtype)
+    for act in ("relu", "swish"):
+        y_s = K.act_dropout_fwd(xs, act=act, p=0.3, seed=seed)            # n = 4099: scalar kernel
+        y_v = K.act_dropout_fwd(xs[:4096].clone(), act=act, p=0.3, seed=seed)
+        res.append((bool(torch.equal(y_s[:4096], y_v)), f"act+dropout fwd[{dtype}] {act}: vector == scalar kernel"))
+        sv_s = xs if act == "swish" else y_s
+        d_s = K.act_dropout_bwd(xs, sv_s, act=act, p=0.3, seed=seed)
+        d_v = K.act_dropout_bwd(xs[:4096].clone(), sv_s[:4096].clone(), act=act, p=0.3, seed=seed)
+        res.append((bool(torch.equal(d_s[:4096], d_v)), f"act+dropout bwd[{dtype}] {act}: vector == scalar kernel"))
     # positional encodings
     B, T, D = 3, 17, 32
     xx = rnd(B, T, D, seed=3, dtype=dtype)
