@@ -44,7 +44,13 @@ enum { S2SVC_LAYOUT_KC = 0,   /* element (r,k) at r*ld + k  (reduction index con
        S2SVC_LAYOUT_RC = 1 }; /* element (r,k) at k*ld + r  (row index contiguous)          */
 enum { S2SVC_OP_DENSE = 0,
        S2SVC_OP_CONV1D = 1,   /* rows/reduction index m=(b,t); taps j: x[(m+j-pad)*ld + c], valid iff 0<=t+j-pad<T */
-       S2SVC_OP_CONV2D_S2 = 2 /* NHWC input (B,T1,F1,C), 3x3 stride 2 no padding, m=(b,t2,f2)  */ };
+       S2SVC_OP_CONV2D_S2 = 2,/* NHWC input (B,T1,F1,C), 3x3 stride 2 no padding, m=(b,t2,f2)  */
+       /* A only, bf16 only: DATA gradient of that convolution for ONE parity class (pt, pf) of input pixels
+          (t1, f1) = (2i+pt, 2j+pf): rows m = (b, i, j) over the class grid T1 x F1 (= ceil((T_in-pt)/2) x ceil((F_in-pf)/2)),
+          reduction index k = tap*C + o over the (2-pt)*(2-pf) taps of the class, tap = ta*(2-pf) + fb reads the output-
+          gradient pixel (i-ta, j-fb) of the (B,T2,F2,C) tensor (zero outside); pad = 2*pt + pf.  The weight operand is
+          the class matrix s2svc_tconv2d_weights() lays out; use it with the c_map of s2svc_gemm_desc. */
+       S2SVC_OP_TCONV2D_S2 = 3 };
 
 typedef struct {
   const void* ptr;
@@ -95,9 +101,21 @@ typedef struct {
   int32_t reserved2_;
   const uint64_t* seed_base;
   uint64_t seed_off;
+  /* c_map = 1 (bf16 LDS-DMA kernels only; no res / emask / batch / split-K): GEMM row m = (b, i, j) over the class grid
+     cm_Tc x cm_Fc is stored at row (b*cm_T1 + 2i+cm_pt)*cm_F1 + 2j+cm_pf of C -- the four parity classes of a stride-2
+     transposed convolution write one NHWC tensor (B, cm_T1, cm_F1, N) without a col2im pass */
+  int32_t c_map;
+  int32_t cm_T1, cm_F1, cm_Tc, cm_Fc, cm_pt, cm_pf;
+  int32_t reserved3_;
 } s2svc_gemm_desc;
 
 int s2svc_gemm(const s2svc_gemm_desc* desc /* host */, void* stream);
+
+/* Weight matrices of the four parity classes of the 3x3 stride-2 transposed convolution (S2SVC_OP_TCONV2D_S2), from the
+   fp32 master weight w (O, C, 3, 3): out (bf16) = class (0,0) | (0,1) | (1,0) | (1,1), class (pt, pf) = [C][ntaps*O] with
+   element [c][tap*O + o] = w[o, c, pt + 2*ta, pf + 2*fb], tap = ta*(2-pf) + fb; offsets 0, 4*C*O, 6*C*O, 8*C*O; 9*C*O total.
+   Replaces the `col2im` half of autograd's conv2d input gradient (subsampling.py:58-63). */
+int s2svc_tconv2d_weights(int O, int C, const float* w, void* out_bf16, void* stream);
 
 /* Grouped launch of independent weight-gradient GEMMs  dW[N_out, N_in] (+)= dY^T . X  (bf16, both operands dense and
    row-contiguous -- what the backward of every Linear / 1x1 Conv1d issues; replaces the per-layer torch.nn.Linear weight
@@ -105,8 +123,8 @@ int s2svc_gemm(const s2svc_gemm_desc* desc /* host */, void* stream);
    descriptors of a few consecutive layers during backward and launches them as ONE grid: every workgroup runs the whole
    reduction of its output tile, so there is no split-K workspace and no reduction pass.
      _ok : 1 if `desc` can join a group (else launch it with s2svc_gemm);
-     s2svc_gemm_grouped : `descs` is a HOST array; descriptors travel by value in the kernel arguments (11 per launch,
-           n problems take ceil(n / 11) launches; hipGraph capture records them with the nodes), `tile` = 64 or 128 is the
+     s2svc_gemm_grouped : `descs` is a HOST array; descriptors travel by value in the kernel arguments (10 per launch,
+           n problems take ceil(n / 10) launches; hipGraph capture records them with the nodes), `tile` = 64 or 128 is the
            output tile edge, every descriptor must have splitk <= 1.
    Two descriptors of one call must not write the same C / a_rowsum (they run concurrently). */
 int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc /* host */);

@@ -71,12 +71,14 @@ class GemmDesc(ctypes.Structure):
                 ("alpha", c_f32), ("dtype", c_i32), ("accumulate", c_i32), ("splitk", c_i32), ("ws", c_vp),
                 ("a_rowsum", c_vp), ("a_rowsum_ws", c_vp), ("a_rowsum_accumulate", c_i32), ("tile_hint", c_i32),
                 ("emask", c_vp), ("ldm", c_i64), ("drop_p", c_f32), ("reserved2_", c_i32), ("seed_base", c_vp),
-                ("seed_off", c_u64)]
+                ("seed_off", c_u64), ("c_map", c_i32), ("cm_T1", c_i32), ("cm_F1", c_i32), ("cm_Tc", c_i32), ("cm_Fc", c_i32),
+                ("cm_pt", c_i32), ("cm_pf", c_i32), ("reserved3_", c_i32)]
 
 
 _SIGS = {
     "s2svc_gemm": [ctypes.POINTER(GemmDesc), c_vp],
     "s2svc_gemm_grouped_ok": [c_vp],
+    "s2svc_tconv2d_weights": [c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_gemm_grouped": [c_vp, c_i32, c_i32, c_vp],
     "s2svc_layernorm_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_layernorm_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],

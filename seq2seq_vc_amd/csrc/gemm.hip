@@ -350,6 +350,16 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   S2S_REQUIRE(d.A.mode == S2SVC_OP_DENSE || d.A.C > 0, "s2svc_gemm: conv operand A needs C");
   S2S_REQUIRE(d.B.mode == S2SVC_OP_DENSE || d.B.C > 0, "s2svc_gemm: conv operand B needs C");
   hipStream_t st = (hipStream_t)stream;
+  if (d.A.mode == S2SVC_OP_TCONV2D_S2 || d.B.mode == S2SVC_OP_TCONV2D_S2 || d.c_map) {
+    // transposed-convolution operand / mapped C rows: only the bf16 LDS-DMA kernels implement them
+    S2S_REQUIRE(d.B.mode != S2SVC_OP_TCONV2D_S2, "s2svc_gemm: S2SVC_OP_TCONV2D_S2 is an A-operand mode");
+    S2S_REQUIRE(d.nb0 * d.nb1 == 1 && d.splitk <= 1 && !d.res && !d.emask && d.drop_p == 0.f && !d.a_rowsum,
+                "s2svc_gemm: tconv2d / c_map GEMMs are unbatched, unsplit and have no residual / mask stage");
+    S2S_REQUIRE(!d.c_map || (d.cm_Tc > 0 && d.cm_Fc > 0 && d.M % (d.cm_Tc * d.cm_Fc) == 0), "s2svc_gemm: bad c_map grid");
+    const int rc = s2svc_gemm_try_glds(&d, stream);
+    S2S_REQUIRE(rc != 0, "s2svc_gemm: tconv2d / c_map need bf16 operands the LDS-DMA kernel accepts (16-byte aligned, C % 8 == 0, C >= 64)");
+    return rc < 0 ? rc : 0;
+  }
   // dropout / mask stage: native in the LDS-DMA kernels' epilogue; every other kernel family gets it as a second pass
   // over C (which is only the same thing when nothing is added to C after the stage)
   const bool staged = d.drop_p > 0.f || d.emask != nullptr;

@@ -24,13 +24,22 @@ __device__ __forceinline__ float epilogue_stage_f(const s2svc_gemm_desc& d, int 
 // STAGED = false is what the register-staged kernels (gemm.hip, gemm_fast.hip, gemm_skinny.hip) inline 64x into
 // their unrolled accumulator loops: it must stay small, or hipcc stops unrolling, indexes the accumulators at run time
 // and demotes them to scratch memory.  Those kernels get the stage from gemm_stage_kernel (gemm.hip) as a second pass.
+// row of C that GEMM row m is stored at (identity unless the descriptor carries a c_map, see s2svc_hip.h)
+__device__ __forceinline__ int64_t c_row_of(const s2svc_gemm_desc& d, int m) {
+  if (!d.c_map) return m;
+  const int per_b = d.cm_Tc * d.cm_Fc;
+  const int b = m / per_b, rem = m - b * per_b;
+  const int i = rem / d.cm_Fc, j = rem - i * d.cm_Fc;
+  return ((int64_t)b * d.cm_T1 + 2 * i + d.cm_pt) * d.cm_F1 + 2 * j + d.cm_pf;
+}
+
 template <bool STAGED = false>
 __device__ __forceinline__ void epilogue_store_f(const s2svc_gemm_desc& d, int z0, int z1, int m, int n, float v) {
   v *= d.alpha;
   if (d.bias) v += d.bias[n];
   v = act_apply(v, d.act);
   if (STAGED) v = epilogue_stage_f(d, m, n, v);
-  const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
+  const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (STAGED ? c_row_of(d, m) : (int64_t)m) * d.ldc + n;
   if (d.res) {
     const int64_t ro = (int64_t)z0 * d.rbs0 + (int64_t)z1 * d.rbs1 + (int64_t)m * d.ldr + n;
     v += d.c_dtype == S2S_F32 ? ((const float*)d.res)[ro] : bf2f(((const bf16_t*)d.res)[ro]);
@@ -143,7 +152,7 @@ __device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, 
         }
       }
     }
-    const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
+    const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + c_row_of(d, m) * d.ldc + n;
     if (d.res) {
       const int64_t ro = (int64_t)z0 * d.rbs0 + (int64_t)z1 * d.rbs1 + (int64_t)m * d.ldr + n;
       if (d.c_dtype == S2S_F32) {

@@ -23,7 +23,7 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 __device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 // operand kinds (compile-time: the K loop has no mode branches): layout x addressing
-enum { G_KC_DENSE = 0, G_KC_CONV1D = 1, G_KC_CONV2D = 2, G_RC_DENSE = 3, G_RC_CONV1D = 4, G_RC_CONV2D = 5 };
+enum { G_KC_DENSE = 0, G_KC_CONV1D = 1, G_KC_CONV2D = 2, G_RC_DENSE = 3, G_RC_CONV1D = 4, G_RC_CONV2D = 5, G_KC_TCONV2D = 6 };
 
 // LDS image of an operand tile with BKT bf16 per row (16-byte pieces): piece c of row r lives at
 //   BKT = 64 (128-B rows, 8 pieces): r*128 + ((c ^ ((r>>1)&7)) << 4)
@@ -55,7 +55,8 @@ struct KcStage {
   static constexpr int NI = ROWS / RPI / 4;            // DMA instructions per wave and tile
   static_assert(NI >= 1, "tile too small for 4 waves");
   int64_t rowbase[NI];            // element offset of the row's first tap ; < 0: row outside the matrix
-  int trow[NI];                   // conv1d: frame index of the row
+  int trow[NI];                   // conv1d: frame index of the row ; tconv2d: class-grid row i
+  int tcol[NI];                   // tconv2d: class-grid column j
   int piece8;                     // 8 * source piece of this lane (the same for every row group, see init)
   __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,7 +68,14 @@ struct KcStage {
       const int rl = (i * 4 + wave) * RPI + lane / PIECES;
       const int r = r0 + rl;
       trow[i] = 0;
-      if (KIND == G_KC_DENSE) {
+      tcol[i] = 0;
+      if (KIND == G_KC_TCONV2D) {       // class grid (o.T1 x o.F1) -> output-gradient pixel (i, j) of the (B, T2, F2, C) tensor
+        const int per_b = o.T1 * o.F1;
+        const int b = r / per_b, rem = r - b * per_b;
+        trow[i] = rem / o.F1;
+        tcol[i] = rem - trow[i] * o.F1;
+        rowbase[i] = ((int64_t)(b * o.T2 + trow[i]) * o.F2 + tcol[i]) * o.ld;
+      } else if (KIND == G_KC_DENSE) {
         rowbase[i] = (int64_t)r * o.ld;
       } else if (KIND == G_KC_CONV1D) {
         rowbase[i] = (int64_t)r * o.ld;
@@ -86,7 +94,7 @@ struct KcStage {
     const int k = k0 + piece8;
     const bool kin = k < K;
     int64_t koff = k;             // element offset added to the row base
-    int tap = 0;
+    int tap = 0, ta = 0, fb = 0;
     if (KIND != G_KC_DENSE) {
       const int tap0 = k0 / o.C, c0 = k0 - tap0 * o.C;      // uniform over the workgroup
       int c = c0 + piece8;
@@ -94,6 +102,11 @@ struct KcStage {
       if (c >= o.C) { c -= o.C; tap += 1; }
       if (KIND == G_KC_CONV1D) {
         koff = (int64_t)(tap - o.pad) * o.ld + c;
+      } else if (KIND == G_KC_TCONV2D) {
+        const int nf = 2 - (o.pad & 1);                     // taps along f of this parity class
+        ta = tap / nf;
+        fb = tap - ta * nf;
+        koff = -(int64_t)(ta * o.F2 + fb) * o.ld + c;
       } else {
         const int kh = tap / 3, kw = tap - kh * 3;
         koff = (int64_t)(kh * o.F1 + kw) * o.ld + c;
@@ -105,6 +118,10 @@ struct KcStage {
       if (KIND == G_KC_CONV1D) {
         const int tt = trow[i] + tap - o.pad;
         ok = ok && tt >= 0 && tt < o.T;
+      }
+      if (KIND == G_KC_TCONV2D) {
+        const int ti = trow[i] - ta, tj = tcol[i] - fb;
+        ok = ok && ti >= 0 && ti < o.T2 && tj >= 0 && tj < o.F2;
       }
       const uint64_t src = ok ? reinterpret_cast<uint64_t>(base + rowbase[i] + koff) : zaddr;
       __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
@@ -218,7 +235,7 @@ __device__ __forceinline__ void tile_of_block(int& bm, int& bn) {
   bn = id - bm * gx;
 }
 
-template <int ROWS, int KIND, bool IS_RC = (KIND >= G_RC_DENSE)> struct Stage;
+template <int ROWS, int KIND, bool IS_RC = (KIND >= G_RC_DENSE && KIND <= G_RC_CONV2D)> struct Stage;
 template <int ROWS, int KIND> struct Stage<ROWS, KIND, false> {
   KcStage<ROWS, KIND> s;
   __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) { s.init(o, r0, R); }
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const s2svc_gemm_desc d)
 // The descriptors travel BY VALUE in the kernel-argument segment (nothing to upload; hipGraph capture records them with
 // the node).  Each workgroup runs the full K loop of its tile: with several problems' tiles in flight the grid fills
 // the chip without split-K, so there is no partial-sum workspace and no reduction pass.
-#define S2S_GROUP_MAX 11                                   /* 11 * 352 B + prefix sums < the 4 KB kernarg limit */
+#define S2S_GROUP_MAX 10                                   /* 10 * 384 B + prefix sums < the 4 KB kernarg limit */
 struct group_args {
   s2svc_gemm_desc d[S2S_GROUP_MAX];
   int32_t tile_start[S2S_GROUP_MAX + 1];
@@ -455,6 +472,7 @@ int dma_stages() {       // S2SVC_GEMM_STAGES override (0 = built-in policy), se
 }
 
 int kind_of(const s2svc_operand& o) {
+  if (o.mode == S2SVC_OP_TCONV2D_S2) return o.layout == S2SVC_LAYOUT_KC ? G_KC_TCONV2D : -1;
   const int base = o.layout == S2SVC_LAYOUT_RC ? G_RC_DENSE : G_KC_DENSE;
   return base + (o.mode == S2SVC_OP_DENSE ? 0 : (o.mode == S2SVC_OP_CONV1D ? 1 : 2));
 }
@@ -479,6 +497,7 @@ bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   S2S_DMA_CASE(G_KC_DENSE, G_KC_DENSE)
   S2S_DMA_CASE(G_KC_CONV1D, G_KC_DENSE)
   S2S_DMA_CASE(G_KC_CONV2D, G_KC_DENSE)
+  S2S_DMA_CASE(G_KC_TCONV2D, G_KC_DENSE)
 #undef S2S_DMA_CASE
   S2S_GLDS_CASE(G_KC_DENSE, G_KC_DENSE)      // linear forward, attention scores
   S2S_GLDS_CASE(G_KC_DENSE, G_RC_DENSE)      // linear dgrad, P.V
@@ -489,6 +508,7 @@ bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   S2S_GLDS_CASE(G_RC_DENSE, G_RC_CONV1D)     // Conv1d wgrad
   S2S_GLDS_CASE(G_KC_CONV2D, G_KC_DENSE)     // Conv2d 3x3 s2 forward
   S2S_GLDS_CASE(G_RC_DENSE, G_RC_CONV2D)     // Conv2d wgrad
+  S2S_GLDS_CASE(G_KC_TCONV2D, G_KC_DENSE)    // Conv2d dgrad, one parity class (transposed convolution, c_map store)
 #undef S2S_GLDS_CASE
   return false;
 }
@@ -526,6 +546,40 @@ bool extent_ok(const s2svc_operand& o, int extent) {
 }
 
 }  // namespace
+
+// ---- class weight matrices of the stride-2 transposed convolution (see S2SVC_OP_TCONV2D_S2) ----------------------
+namespace {
+__global__ void tconv2d_weights_kernel(int O, int C, const float* __restrict__ w, bf16_t* __restrict__ out) {
+  const int64_t n = (int64_t)9 * C * O;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    // e walks the output: class block, then [c][tap*O + o]
+    const int64_t co = (int64_t)C * O;
+    int cls, ntaps;
+    int64_t rel;
+    if (e < 4 * co) { cls = 0; ntaps = 4; rel = e; }
+    else if (e < 6 * co) { cls = 1; ntaps = 2; rel = e - 4 * co; }
+    else if (e < 8 * co) { cls = 2; ntaps = 2; rel = e - 6 * co; }
+    else { cls = 3; ntaps = 1; rel = e - 8 * co; }
+    const int pt = cls >> 1, pf = cls & 1, nf = 2 - pf;
+    const int c = (int)(rel / ((int64_t)ntaps * O));
+    const int ko = (int)(rel - (int64_t)c * ntaps * O);
+    const int tap = ko / O, o = ko - tap * O;
+    const int ta = tap / nf, fb = tap - ta * nf;
+    const int kh = pt + 2 * ta, kw = pf + 2 * fb;
+    out[e] = f2bf(w[(((int64_t)o * C + c) * 3 + kh) * 3 + kw]);
+  }
+}
+}  // namespace
+
+extern "C" int s2svc_tconv2d_weights(int O, int C, const float* w, void* out_bf16, void* stream) {
+  S2S_REQUIRE(O > 0 && C > 0 && w && out_bf16, "tconv2d_weights: bad args");
+  const int64_t n = (int64_t)9 * C * O;
+  int nb = (int)((n + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(tconv2d_weights_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, O, C, w, (bf16_t*)out_bf16);
+  S2S_CHECK_LAUNCH("tconv2d_weights_kernel");
+  return 0;
+}
 
 // ---- grouped weight-gradient GEMMs (C[N_out, N_in] (+)= dY^T . X, both operands row-contiguous) -------------------
 extern "C" int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc) {
@@ -568,6 +622,7 @@ extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile,
 extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
   const s2svc_gemm_desc& d = *desc;
   if (disabled() || d.dtype != S2S_BF16) return 0;
+  if (kind_of(d.A) < 0 || kind_of(d.B) < 0 || kind_of(d.B) == G_KC_TCONV2D) return 0;
   if (!operand_ok(d.A) || !operand_ok(d.B)) return 0;
   if (!extent_ok(d.A, d.A.layout == S2SVC_LAYOUT_RC ? d.M : d.K)) return 0;
   if (!extent_ok(d.B, d.B.layout == S2SVC_LAYOUT_RC ? d.N : d.K)) return 0;

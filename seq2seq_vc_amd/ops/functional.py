@@ -815,6 +815,9 @@ def conv1d(x, weight, bias=None, act=None):
 # ================================================================================================
 # Conv2d 3x3 stride 2 (+ReLU) on NHWC activations         reference: subsampling.py:58-63
 # ================================================================================================
+_TCONV = os.environ.get("S2SVC_NO_TCONV", "0") != "1"      # tuning aid: fall back to dcols GEMM + col2im
+
+
 class _Conv2dS2(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, grad_premasked=False):
@@ -862,7 +865,20 @@ class _Conv2dS2(Function):
             else:
                 dw, db = work()
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and dtype == torch.bfloat16 and O % 8 == 0 and O >= 64 and C % 8 == 0 and _TCONV:
+            # transposed convolution as four implicit GEMMs, one per parity class (t1 % 2, f1 % 2) of input pixels: each
+            # gathers its 4 / 2 / 2 / 1 taps of dY straight from HBM and stores into its pixels of dX (no dcols, no col2im)
+            wts = K.tconv2d_weights(weight.detach())
+            dx = torch.empty((B, T1, F1, C), dtype=dtype, device=x.device)
+            for cls, wt in enumerate(wts):
+                pt, pf = cls >> 1, cls & 1
+                Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
+                if Tc <= 0 or Fc <= 0:
+                    continue
+                Kc = wt.shape[1]
+                K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, Kc),
+                       B * Tc * Fc, C, Kc, dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf))
+        elif ctx.needs_input_grad[0]:
             dcols = torch.empty((M2, 9 * C), dtype=dtype, device=x.device)
             K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), M2, 9 * C, O, dcols, in_dtype=dtype)
             dx = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)

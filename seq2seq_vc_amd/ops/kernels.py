@@ -12,7 +12,7 @@ import torch
 from .. import _lib
 
 KC, RC = 0, 1
-DENSE, CONV1D, CONV2D_S2 = 0, 1, 2
+DENSE, CONV1D, CONV2D_S2, TCONV2D_S2 = 0, 1, 2, 3
 ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2, "swish": 3, "sigmoid": 4, "gelu": 5}
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
@@ -129,9 +129,13 @@ def pick_splitk(M, N, K, nbatch=1):
 
 def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
          ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False, a_rowsum=None,
-         a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0)):
-    """C = act(alpha * A.B^T + bias) [* dropmask] [* (emask > 0)] + res   (see s2svc_gemm in include/s2svc_hip.h)."""
+         a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0), c_map=None):
+    """C = act(alpha * A.B^T + bias) [* dropmask] [* (emask > 0)] + res   (see s2svc_gemm in include/s2svc_hip.h).
+    c_map = (T1, F1, Tc, Fc, pt, pf): GEMM row (b, i, j) of the Tc x Fc class grid goes to row (b, 2i+pt, 2j+pf) of C."""
     d = _lib.GemmDesc()
+    if c_map is not None:
+        d.c_map = 1
+        d.cm_T1, d.cm_F1, d.cm_Tc, d.cm_Fc, d.cm_pt, d.cm_pf = c_map
     d.A, d.B = A, B
     d.C = out.data_ptr() + out_offset * out.element_size()
     d.ldc = N if ldc is None else ldc
@@ -524,6 +528,19 @@ def transpose_tiles(tiles, src, dst):
 # ----------------------------------------------------------------------------------------------
 # convolution helpers
 # ----------------------------------------------------------------------------------------------
+def tconv2d_weights(weight):
+    """fp32 (O, C, 3, 3) -> bf16 class matrices of the stride-2 transposed convolution, list of 4 views (C, ntaps*O)
+    in class order (pt, pf) = (0,0), (0,1), (1,0), (1,1)  (s2svc_tconv2d_weights)."""
+    O, C = weight.shape[0], weight.shape[1]
+    out = torch.empty(9 * C * O, dtype=torch.bfloat16, device=weight.device)
+    _lib.check(_lib.lib().s2svc_tconv2d_weights(O, C, ptr(weight), ptr(out), stream()), "tconv2d_weights")
+    views, off = [], 0
+    for ntaps in (4, 2, 2, 1):
+        views.append(out[off:off + C * ntaps * O].view(C, ntaps * O))
+        off += C * ntaps * O
+    return views
+
+
 def col2im_s2(dcols, B, T1, F1, C, T2, F2):
     dx = torch.empty((B, T1, F1, C), dtype=dcols.dtype, device=dcols.device)
     _lib.check(_lib.lib().s2svc_col2im_s2(dt(dcols), B, T1, F1, C, T2, F2, ptr(dcols), ptr(dx), stream()), "col2im_s2")

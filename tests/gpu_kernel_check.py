@@ -400,6 +400,35 @@ def gemm_conv2d(dtype):
 
 
 @case
+def conv2d_dgrad_transposed():
+    """Data gradient of the 3x3 stride-2 Conv2d as four implicit transposed-convolution GEMMs (one per parity class of
+    input pixels, stored through the c_map) vs torch's conv2d input gradient and vs the dcols GEMM + col2im path, for
+    odd / even input extents (rows the convolution never touched must come out 0)."""
+    res = []
+    dtype = torch.bfloat16
+    for (B, T1, F1, C, O, seed) in [(2, 31, 19, 64, 64, 1), (3, 32, 20, 64, 128, 2), (1, 9, 8, 128, 64, 3), (2, 127, 39, 64, 64, 4)]:
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        w = rnd(O, C, 3, 3, seed=seed, scale=0.05)
+        dy = rnd(B, T2, F2, O, seed=seed + 10, dtype=dtype)
+        dx = torch.full((B, T1, F1, C), float("nan"), dtype=dtype, device=DEV)       # every pixel must be written
+        for cls, wt in enumerate(K.tconv2d_weights(w)):
+            pt, pf = cls >> 1, cls & 1
+            Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
+            K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, wt.shape[1]),
+                   B * Tc * Fc, C, wt.shape[1], dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf))
+        xr = torch.zeros(B, C, T1, F1, device=DEV, requires_grad=True)
+        F.conv2d(xr, w.to(dtype).float(), None, stride=2).backward(dy.float().permute(0, 3, 1, 2))
+        ref = xr.grad.permute(0, 2, 3, 1)
+        res.append(check(f"tconv2d dgrad B{B} {T1}x{F1} C{C} O{O} vs torch", dx, ref, dtype, atol=3e-2 * max(1.0, float(ref.abs().max()))))
+        wp = K.gather3(w, (O, 9, C), (C * 9, 1, 9), 0, dtype)
+        dcols = torch.empty(B * T2 * F2, 9 * C, dtype=dtype, device=DEV)
+        K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), B * T2 * F2, 9 * C, O, dcols, in_dtype=dtype)
+        old = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)
+        res.append(check(f"tconv2d dgrad B{B} {T1}x{F1} vs dcols+col2im", dx, old, dtype, atol=3e-2 * max(1.0, float(ref.abs().max()))))
+    return res
+
+
+@case
 def conv2d_subsampling_frontend():
     """Conv2d(1,C,3,2)+ReLU -> Conv2d(C,C,3,2)+ReLU -> Linear front-end in fp32, forward and every gradient, against torch
     (direct C_in=1 kernels, implicit-GEMM conv, col2im, relu' fused into the consumers).  The bf16 legs of the same
