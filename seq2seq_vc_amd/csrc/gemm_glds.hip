@@ -23,7 +23,9 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 __device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 // operand kinds (compile-time: the K loop has no mode branches): layout x addressing
-enum { G_KC_DENSE = 0, G_KC_CONV1D = 1, G_KC_CONV2D = 2, G_RC_DENSE = 3, G_RC_CONV1D = 4, G_RC_CONV2D = 5, G_KC_TCONV2D = 6 };
+enum { G_KC_DENSE = 0, G_KC_CONV1D = 1, G_KC_CONV2D = 2, G_RC_DENSE = 3, G_RC_CONV1D = 4, G_RC_CONV2D = 5, G_KC_TCONV2D = 6,
+       G_TR_DENSE = 7, G_TR_CONV1D = 8, G_TR_CONV2D = 9 };   // row-contiguous operands, LDS-DMA staged + transpose reads
+#define S2S_IS_TR(KIND) ((KIND) >= G_TR_DENSE)
 
 // LDS image of an operand tile with BKT bf16 per row (16-byte pieces): piece c of row r lives at
 //   BKT = 64 (128-B rows, 8 pieces): r*128 + ((c ^ ((r>>1)&7)) << 4)
@@ -218,6 +220,67 @@ struct RcStage {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-contiguous operand WITHOUT the register transposes: the tile is DMA-ed k-major into LDS and the MFMA fragments
+// are read with ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group reads a [4 k][16 rows] block, lane
+// c of the group receives the 4 k-values of row c).  LDS image of a BK = 64 tile: 2 k-halves x ROWS/16 subtiles of
+// [32 k][16 rows] bf16 (32-byte k-rows, 1 KiB = exactly one wave DMA instruction, lane l -> k-row l/2, rows 8*(l&1)..+7).
+// A half-wave (2 lane groups) of a transpose read covers 8 consecutive 32-byte k-rows = one 256-byte bank row: no
+// conflicts.  A fragment (8 k per lane) takes two reads; lane group g gets k = 4g..4g+3 and 16+4g..16+4g+3 of the
+// k-half -- a PERMUTATION of the MFMA's k positions, harmless because both operands of the product use it
+// (S2S_IS_TR kinds are only paired with each other).
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+template <int ROWS, int KIND>
+struct TrStage {
+  static constexpr int SUB = ROWS / 16;             // subtiles per k-half
+  static constexpr int NI = 2 * SUB / 4;            // DMA instructions per wave and tile
+  static_assert(NI >= 1, "tile too small for 4 waves");
+  __device__ __forceinline__ void init(const s2svc_operand&, int, int) {}
+  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int r0, int R, int k0, int K, char* lds) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t zaddr = zero_addr();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int sidx = i * 4 + wave;                // subtile: k-half kh, row block mt
+      const int kh = sidx / SUB, mt = sidx - kh * SUB;
+      const int k = k0 + kh * 32 + (lane >> 1);
+      const int r = r0 + mt * 16 + (lane & 1) * 8;
+      bool ok = r < R && k < K;
+      int64_t off;
+      if (KIND == G_TR_DENSE) {
+        off = (int64_t)k * o.ld + r;
+      } else if (KIND == G_TR_CONV1D) {
+        const int tap = r / o.C, c = r - tap * o.C;
+        const int t = k % o.T, tt = t + tap - o.pad;
+        ok = ok && tt >= 0 && tt < o.T;
+        off = (int64_t)(k + tap - o.pad) * o.ld + c;
+      } else {
+        const int tap = r / o.C, c = r - tap * o.C;
+        const int f2 = k % o.F2, bt = k / o.F2;
+        const int t2 = bt % o.T2, b = bt / o.T2;
+        const int kh3 = tap / 3, kw = tap - kh3 * 3;
+        off = ((int64_t)(b * o.T1 + 2 * t2 + kh3) * o.F1 + (2 * f2 + kw)) * o.ld + c;
+      }
+      const uint64_t src = ok ? reinterpret_cast<uint64_t>(base + off) : zaddr;
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds + sidx * 1024), 16, 0, 0);
+    }
+  }
+};
+
+// MFMA fragment of row block `mt` (16 rows), k-half `ks` of a TR-staged tile
+template <int ROWS>
+__device__ __forceinline__ bf16x8_t tr_fragment(const char* stage, int mt, int ks, int lane) {
+  const char* p = stage + (ks * (ROWS / 16) + mt) * 1024 + ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 512));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // XCD-aware tile order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
 // L2); handing XCD x the x-th CONTIGUOUS run of output tiles (row-major, n fastest) makes the workgroups that run
 // side by side on one XCD share A row panels and B column panels through that L2 instead of each pulling them over
@@ -235,14 +298,20 @@ __device__ __forceinline__ void tile_of_block(int& bm, int& bn) {
   bn = id - bm * gx;
 }
 
-template <int ROWS, int KIND, bool IS_RC = (KIND >= G_RC_DENSE && KIND <= G_RC_CONV2D)> struct Stage;
-template <int ROWS, int KIND> struct Stage<ROWS, KIND, false> {
+template <int ROWS, int KIND, int CLS = (S2S_IS_TR(KIND) ? 2 : ((KIND >= G_RC_DENSE && KIND <= G_RC_CONV2D) ? 1 : 0))> struct Stage;
+template <int ROWS, int KIND> struct Stage<ROWS, KIND, 2> {
+  TrStage<ROWS, KIND> s;
+  __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) { s.init(o, r0, R); }
+  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int r0, int R, int k0, int K, char* lds) { s.issue(o, base, r0, R, k0, K, lds); }
+  __device__ __forceinline__ void finish(char*) const {}
+};
+template <int ROWS, int KIND> struct Stage<ROWS, KIND, 0> {
   KcStage<ROWS, KIND> s;
   __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) { s.init(o, r0, R); }
   __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int, int, int k0, int K, char* lds) { s.issue(o, base, k0, K, lds); }
   __device__ __forceinline__ void finish(char*) const {}
 };
-template <int ROWS, int KIND> struct Stage<ROWS, KIND, true> {
+template <int ROWS, int KIND> struct Stage<ROWS, KIND, 1> {
   RcStage<ROWS, KIND> s;
   __device__ __forceinline__ void init(const s2svc_operand&, int, int) {}
   __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int r0, int R, int k0, int K, char*) { s.load(o, base, r0, R, k0, K); }
@@ -301,7 +370,15 @@ __device__ __forceinline__ void gemm_glds_tile(const s2svc_gemm_desc& d, int til
       sa.issue(d.A, Ab, m0, d.M, (kt + 1) * BK, d.K, An);
       sb.issue(d.B, Bb, n0, d.N, (kt + 1) * BK, d.K, An + ABYTES);
     }
-    if (do_rowsum) {
+    if (do_rowsum && S2S_IS_TR(AMODE)) {
+      // k-major image: row r is column r%16 of the subtiles (kh, r/16); `part` takes every TPR-th k-row
+      const int r = threadIdx.x / TPR, part = threadIdx.x % TPR;
+#pragma unroll
+      for (int kk = 0; kk < 64 / TPR; ++kk) {
+        const int k = kk * TPR + part;
+        rowsum += bf2f(*reinterpret_cast<const bf16_t*>(As + ((k >> 5) * (BM / 16) + (r >> 4)) * 1024 + (k & 31) * 32 + (r & 15) * 2));
+      }
+    } else if (do_rowsum) {
       const int r = threadIdx.x / TPR, part = threadIdx.x % TPR;       // part covers 8/TPR pieces of the row
 #pragma unroll
       for (int c = 0; c < 8 / TPR; ++c) {
@@ -315,9 +392,13 @@ __device__ __forceinline__ void gemm_glds_tile(const s2svc_gemm_desc& d, int til
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t a[FM], b[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + i * 16 + lr, ks * 4 + lg));
+      for (int i = 0; i < FM; ++i)
+        a[i] = S2S_IS_TR(AMODE) ? tr_fragment<BM>(As, wm / 16 + i, ks, lane)
+                                : *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + i * 16 + lr, ks * 4 + lg));
 #pragma unroll
-      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + j * 16 + lr, ks * 4 + lg));
+      for (int j = 0; j < FN; ++j)
+        b[j] = S2S_IS_TR(BMODE) ? tr_fragment<BN>(Bs, wn / 16 + j, ks, lane)
+                                : *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + j * 16 + lr, ks * 4 + lg));
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -471,6 +552,12 @@ int dma_stages() {       // S2SVC_GEMM_STAGES override (0 = built-in policy), se
   return v;
 }
 
+bool tr_enabled() {      // S2SVC_GEMM_NO_TR=1: row-contiguous operands through the register-transpose path (tuning aid)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+
 int kind_of(const s2svc_operand& o) {
   if (o.mode == S2SVC_OP_TCONV2D_S2) return o.layout == S2SVC_LAYOUT_KC ? G_KC_TCONV2D : -1;
   const int base = o.layout == S2SVC_LAYOUT_RC ? G_RC_DENSE : G_KC_DENSE;
@@ -480,7 +567,12 @@ int kind_of(const s2svc_operand& o) {
 // the operand-kind pairs the autograd code issues (ops/functional.py); anything else stays on the older kernels
 template <int BM, int BN>
 bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
-  const int ka = kind_of(d.A), kb = kind_of(d.B);
+  int ka = kind_of(d.A), kb = kind_of(d.B);
+  // both operands row-contiguous (weight-gradient GEMMs): k-major LDS-DMA staging + transpose reads
+  if (tr_enabled() && ka >= G_RC_DENSE && ka <= G_RC_CONV2D && kb >= G_RC_DENSE && kb <= G_RC_CONV2D) {
+    ka += G_TR_DENSE - G_RC_DENSE;
+    kb += G_TR_DENSE - G_RC_DENSE;
+  }
 #define S2S_GLDS_CASE(KA, KB)                                                                       \
   if (ka == KA && kb == KB) {                                                                      \
     hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, KA, KB>), grid, dim3(256), 0, st, d);              \
@@ -509,6 +601,9 @@ bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   S2S_GLDS_CASE(G_KC_CONV2D, G_KC_DENSE)     // Conv2d 3x3 s2 forward
   S2S_GLDS_CASE(G_RC_DENSE, G_RC_CONV2D)     // Conv2d wgrad
   S2S_GLDS_CASE(G_KC_TCONV2D, G_KC_DENSE)    // Conv2d dgrad, one parity class (transposed convolution, c_map store)
+  S2S_GLDS_CASE(G_TR_DENSE, G_TR_DENSE)      // linear wgrad, transpose-read path
+  S2S_GLDS_CASE(G_TR_DENSE, G_TR_CONV1D)     // Conv1d wgrad
+  S2S_GLDS_CASE(G_TR_DENSE, G_TR_CONV2D)     // Conv2d wgrad
 #undef S2S_GLDS_CASE
   return false;
 }
@@ -609,7 +704,12 @@ extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile,
       S2S_REQUIRE(total < (1ll << 30), "gemm_grouped: too many tiles");
     }
     for (int i = g.n; i <= S2S_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
-    if (tile == 128)
+    if (tr_enabled()) {
+      if (tile == 128)
+        hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, G_TR_DENSE, G_TR_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+      else
+        hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, G_TR_DENSE, G_TR_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+    } else if (tile == 128)
       hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, G_RC_DENSE, G_RC_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
     else
       hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, G_RC_DENSE, G_RC_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
