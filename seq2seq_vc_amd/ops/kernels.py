@@ -104,6 +104,8 @@ def plan_gemm(M, N, K, nbatch=1, allow_split=True):
     fitted to MI355X measurements of this kernel (profiles/)."""
     if _MAX_SPLITK is not None:
         allow_split = allow_split and _MAX_SPLITK > 1
+    if M >= 128 and N >= 128 and ((M + 127) // 128) * ((N + 127) // 128) * nbatch >= 256:
+        return 128, 1          # a full wave of 128x128 tiles: measured best for every operand layout (tools/gemm_bench.py --sweep)
     best = None
     for tile, bk, t_tile, resident in ((64, 128, 1.6, 3 * 256), (128, 64, 2.2, 2 * 256)):
         if tile == 128 and (M < 128 or N < 128):
