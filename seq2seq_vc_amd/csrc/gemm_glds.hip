@@ -6,8 +6,10 @@
 //     XOR swizzle applied to the per-lane SOURCE address and, identically, to the read address: the 16-byte piece
 //     c of row r lives at r*128 + ((c ^ ((r>>1)&7))<<4).  With that map every 16-lane group of a fragment read
 //     (rows r..r+15 at pieces c / c^1) hits 16 distinct 16-byte bank slots.
-//   * Row-contiguous operands (weights in dgrad, activations in wgrad) are transposed in registers (8x8 blocks,
-//     v_perm_b32) and written with ds_write_b128 into the same swizzled image.
+//   * Row-contiguous operands (activations in wgrad, weights in dgrad) are DMA-ed k-major into LDS and their fragments
+//     come from ds_read_b64_tr_b16 transpose reads (TrStage / tr_fragment below); a K-contiguous partner then reads the
+//     same permuted k positions with two ds_read_b64 (kc_fragment_perm).  The register-transpose path (RcStage: 8x8
+//     blocks, v_perm_b32, ds_write_b128 into the swizzled image) remains behind S2SVC_GEMM_NO_TR=1.
 //   * Two LDS buffers: tile t+1 is in flight (DMA + global loads) while the MFMAs consume tile t; one barrier per
 //     K tile.  Pieces outside the matrix / the conv input are fetched from a 16-byte zero block.
 //   * 128x128 or 64x64 output tile per 4-wave workgroup (2x2 waves, 4x4 / 2x2 MFMA 16x16x32 fragments per wave),
@@ -228,7 +230,7 @@ struct RcStage {
 // A half-wave (2 lane groups) of a transpose read covers 8 consecutive 32-byte k-rows = one 256-byte bank row: no
 // conflicts.  A fragment (8 k per lane) takes two reads; lane group g gets k = 4g..4g+3 and 16+4g..16+4g+3 of the
 // k-half -- a PERMUTATION of the MFMA's k positions, harmless because both operands of the product use it
-// (S2S_IS_TR kinds are only paired with each other).
+// (a K-contiguous partner reads the same positions: kc_fragment_perm).
 // ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
@@ -269,6 +271,17 @@ struct TrStage {
     }
   }
 };
+
+// fragment of a K-contiguous (swizzled-piece) tile whose PARTNER is TR-staged: the same k positions as tr_fragment,
+// k = 4g..4g+3 and 16+4g..16+4g+3 of the k-half = half a 16-byte piece each (two ds_read_b64)
+__device__ __forceinline__ bf16x8_t kc_fragment_perm(const char* stage, int row, int ks, int g) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x4 lo = *reinterpret_cast<const s16x4*>(stage + lds_off(row, ks * 4 + (g >> 1)) + (g & 1) * 8);
+  const s16x4 hi = *reinterpret_cast<const s16x4*>(stage + lds_off(row, ks * 4 + 2 + (g >> 1)) + (g & 1) * 8);
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
 
 // MFMA fragment of row block `mt` (16 rows), k-half `ks` of a TR-staged tile
 template <int ROWS>
@@ -394,11 +407,13 @@ __device__ __forceinline__ void gemm_glds_tile(const s2svc_gemm_desc& d, int til
 #pragma unroll
       for (int i = 0; i < FM; ++i)
         a[i] = S2S_IS_TR(AMODE) ? tr_fragment<BM>(As, wm / 16 + i, ks, lane)
-                                : *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + i * 16 + lr, ks * 4 + lg));
+               : S2S_IS_TR(BMODE) ? kc_fragment_perm(As, wm + i * 16 + lr, ks, lg)
+                                  : *reinterpret_cast<const bf16x8_t*>(As + lds_off(wm + i * 16 + lr, ks * 4 + lg));
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         b[j] = S2S_IS_TR(BMODE) ? tr_fragment<BN>(Bs, wn / 16 + j, ks, lane)
-                                : *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + j * 16 + lr, ks * 4 + lg));
+               : S2S_IS_TR(AMODE) ? kc_fragment_perm(Bs, wn + j * 16 + lr, ks, lg)
+                                  : *reinterpret_cast<const bf16x8_t*>(Bs + lds_off(wn + j * 16 + lr, ks * 4 + lg));
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -568,10 +583,10 @@ int kind_of(const s2svc_operand& o) {
 template <int BM, int BN>
 bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   int ka = kind_of(d.A), kb = kind_of(d.B);
-  // both operands row-contiguous (weight-gradient GEMMs): k-major LDS-DMA staging + transpose reads
-  if (tr_enabled() && ka >= G_RC_DENSE && ka <= G_RC_CONV2D && kb >= G_RC_DENSE && kb <= G_RC_CONV2D) {
-    ka += G_TR_DENSE - G_RC_DENSE;
-    kb += G_TR_DENSE - G_RC_DENSE;
+  // row-contiguous operands: k-major LDS-DMA staging + transpose reads
+  if (tr_enabled()) {
+    if (ka >= G_RC_DENSE && ka <= G_RC_CONV2D) ka += G_TR_DENSE - G_RC_DENSE;
+    if (kb >= G_RC_DENSE && kb <= G_RC_CONV2D) kb += G_TR_DENSE - G_RC_DENSE;
   }
 #define S2S_GLDS_CASE(KA, KB)                                                                       \
   if (ka == KA && kb == KB) {                                                                      \
@@ -602,6 +617,9 @@ bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   S2S_GLDS_CASE(G_RC_DENSE, G_RC_CONV2D)     // Conv2d wgrad
   S2S_GLDS_CASE(G_KC_TCONV2D, G_KC_DENSE)    // Conv2d dgrad, one parity class (transposed convolution, c_map store)
   S2S_GLDS_CASE(G_TR_DENSE, G_TR_DENSE)      // linear wgrad, transpose-read path
+  S2S_GLDS_CASE(G_KC_DENSE, G_TR_DENSE)      // linear dgrad (no transposed weight copy), P.V
+  S2S_GLDS_CASE(G_TR_DENSE, G_KC_DENSE)
+  S2S_GLDS_CASE(G_KC_CONV1D, G_TR_DENSE)     // Conv1d dgrad
   S2S_GLDS_CASE(G_TR_DENSE, G_TR_CONV1D)     // Conv1d wgrad
   S2S_GLDS_CASE(G_TR_DENSE, G_TR_CONV2D)     // Conv2d wgrad
 #undef S2S_GLDS_CASE
