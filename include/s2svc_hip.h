@@ -365,7 +365,7 @@ int s2svc_adam_step(int64_t n, float* params, const float* grads, float* exp_avg
                     float beta1, float beta2, float eps, float max_norm, float base_lr, float warmup_steps,
                     double* partial, float* state, void* stream);
 
-/* dst[c, r] = src[r, c] (bf16) for every 32x32 tile listed in `tiles` (device, 4 x int64 per tile: src offset of  */
+/* dst[c, r] = src[r, c] (bf16) for every 64x64 tile listed in `tiles` (device, 4 x int64 per tile: src offset of  */
 /* the matrix, dst offset, rows<<32|cols, tile index): keeps W^T beside the bf16 weight shadow so that the data-  */
 /* gradient GEMMs read K-contiguous operands.                                                                   */
 int s2svc_transpose_tiles(int64_t ntiles, const int64_t* tiles, const void* src, void* dst, void* stream);

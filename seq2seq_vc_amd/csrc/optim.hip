@@ -111,29 +111,59 @@ extern "C" int s2svc_adam_step(int64_t n, float* params, const float* grads, flo
 // Transposed bf16 shadow of the 2-D weights: dst[c, r] = src[r, c] for every matrix of a table, ONE launch.
 // The data-gradient GEMMs dX = dY . W read W with the reduction index (out-features) strided; with W^T kept beside
 // the bf16 shadow they become plain K-contiguous x K-contiguous products and take the all-DMA kernel.
-// tiles: one int4-sized entry per 32x32 tile, {src offset of the matrix, dst offset, rows << 32 | cols, tile index}
+// tiles: one int4-sized entry per 64x64 tile, {src offset of the matrix, dst offset, rows << 32 | cols, tile index}
 // (element offsets into src / dst).  Refreshed once per optimiser step (2 B read + 2 B written per parameter).
 // ------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void transpose_tiles_kernel(const int64_t* __restrict__ tiles, const bf16_t* __restrict__ src,
                                                               bf16_t* __restrict__ dst) {
-  __shared__ bf16_t t[32][33];
+  // 64 x 64 tile through LDS (row pitch 66: the column reads of phase 2 step 33 dwords -> conflict-free); 16-byte global
+  // loads and stores when the matrix allows it (rows, cols, offsets multiples of 8), element-wise otherwise
+  __shared__ bf16_t t[64][66];
   const int64_t* e = tiles + (int64_t)blockIdx.x * 4;
   const int64_t so = e[0], dof = e[1];
   const int rows = (int)(e[2] >> 32), cols = (int)(e[2] & 0xffffffff);
-  const int tcols = (cols + 31) / 32;
+  const int tcols = (cols + 63) / 64;
   const int tr = (int)(e[3] / tcols), tc = (int)(e[3] % tcols);
-  const int x = threadIdx.x & 31, y0 = threadIdx.x >> 5;          // 32 x 8 threads, 4 rows each
+  const bool vec = (rows % 8 == 0) && (cols % 8 == 0) && (so % 8 == 0) && (dof % 8 == 0);
+  if (vec) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = tr * 32 + y0 + i * 8, c = tc * 32 + x;
-    if (r < rows && c < cols) t[y0 + i * 8][x] = src[so + (int64_t)r * cols + c];
+    for (int i = 0; i < 2; ++i) {                      // 64 rows x 8 vectors = 512 vector loads
+      const int v = threadIdx.x + i * 256;
+      const int r = tr * 64 + (v >> 3), c = tc * 64 + (v & 7) * 8;
+      if (r < rows && c < cols) {
+        const uint4 q = *reinterpret_cast<const uint4*>(src + so + (int64_t)r * cols + c);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          t[v >> 3][(v & 7) * 8 + 2 * k] = (bf16_t)(w[k] & 0xffffu);
+          t[v >> 3][(v & 7) * 8 + 2 * k + 1] = (bf16_t)(w[k] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                      // output row = source column; 8 consecutive source rows per vector
+      const int v = threadIdx.x + i * 256;
+      const int cl = v >> 3, rl = (v & 7) * 8;
+      const int c = tc * 64 + cl, r = tr * 64 + rl;
+      if (c < cols && r < rows) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = (uint32_t)t[rl + 2 * k][cl] | ((uint32_t)t[rl + 2 * k + 1][cl] << 16);
+        *reinterpret_cast<uint4*>(dst + dof + (int64_t)c * rows + r) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    return;
+  }
+  for (int v = threadIdx.x; v < 64 * 64; v += 256) {
+    const int r = tr * 64 + (v >> 6), c = tc * 64 + (v & 63);
+    if (r < rows && c < cols) t[v >> 6][v & 63] = src[so + (int64_t)r * cols + c];
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tc * 32 + y0 + i * 8, r = tr * 32 + x;
-    if (r < rows && c < cols) dst[dof + (int64_t)c * rows + r] = t[x][y0 + i * 8];
+  for (int v = threadIdx.x; v < 64 * 64; v += 256) {
+    const int c = tc * 64 + (v >> 6), r = tr * 64 + (v & 63);
+    if (r < rows && c < cols) dst[dof + (int64_t)c * rows + r] = t[v & 63][v >> 6];
   }
 }
 }  // namespace

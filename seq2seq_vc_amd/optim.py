@@ -95,7 +95,7 @@ class FlatAdam:
             tiles = []
             for so, do, rows, cols, t in self._t_descs:
                 t._s2s_bf16_t = self.shadow_t[do:do + rows * cols].view(cols, rows)
-                nt = ((rows + 31) // 32) * ((cols + 31) // 32)
+                nt = ((rows + 63) // 64) * ((cols + 63) // 64)
                 tiles += [(so, do, (rows << 32) | cols, i) for i in range(nt)]
             self.t_tiles = torch.tensor(tiles, dtype=torch.int64, device=dev)
             for g in groups:                                                   # w_q view: the transposed copy of linear_q.weight

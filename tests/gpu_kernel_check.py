@@ -725,6 +725,34 @@ def elementwise(dtype):
 
 
 @case
+def transposed_weight_copies():
+    """s2svc_transpose_tiles: every matrix of a table transposed in one launch (64x64 tiles; 16-byte path and the
+    element-wise path for extents / offsets that are not multiples of 8), bit-exact."""
+    res = []
+    shapes = [(384, 384), (1536, 384), (384, 1536), (80, 384), (384, 7296), (320, 384), (5, 7), (129, 66), (64, 72), (1, 16)]
+    offs, mats, n = [], [], 0
+    for i, (r, c) in enumerate(shapes):
+        if i == 7:
+            n += 3                                   # an offset that is not a multiple of 8
+        offs.append(n)
+        mats.append(rnd(r, c, seed=i, dtype=torch.bfloat16))
+        n += r * c
+        n = (n + 63) // 64 * 64 if i != 6 else n
+    src = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    dst = torch.full((n,), -1.0, dtype=torch.bfloat16, device=DEV)
+    tiles = []
+    for (r, c), o, m in zip(shapes, offs, mats):
+        src[o:o + r * c] = m.reshape(-1)
+        nt = ((r + 63) // 64) * ((c + 63) // 64)
+        tiles += [(o, o, (r << 32) | c, t) for t in range(nt)]
+    K.transpose_tiles(torch.tensor(tiles, dtype=torch.int64, device=DEV), src, dst)
+    for (r, c), o, m in zip(shapes, offs, mats):
+        got = dst[o:o + r * c].view(c, r)
+        res.append((bool(torch.equal(got, m.t().contiguous())), f"transpose {r}x{c} at offset {o}"))
+    return res
+
+
+@case
 def dropout_mask_statistics():
     """The counter-based dropout masks (csrc/common.h): keep rate within 4 sigma for several p, masks of neighbouring
     seeds (consecutive op offsets, consecutive steps) and of neighbouring elements uncorrelated, same seed => same mask."""
