@@ -163,11 +163,16 @@ class MultiHeadedAttention(nn.Module):
     def _p(self):
         return self.dropout_rate if self.training else 0.0
 
-    def forward(self, query, key, value, klens=None, causal=False):
-        """klens: Lens of valid key positions (None = all valid); causal adds j<=i."""
+    def forward(self, query, key, value, klens=None, causal=False, kv=None):
+        """klens: Lens of valid key positions (None = all valid); causal adds j<=i.
+        kv: the packed K/V projection of `key` (= `value`) computed by the caller (decoder stacks project the memory
+        for all their layers with ONE GEMM)."""
         kl = None if klens is None else klens.dev
         f = getattr(self, "_fused", None)   # packed Q/K/V views of the flat parameter buffer (optim.FlatAdam)
-        if f is not None and key is value:
+        if kv is not None:
+            q = Fn.linear(query, f["w_q"], f["b_q"])
+            ctx, self.attn = Fn.attention_packed_kv(q, kv, kl, causal, self.h, self._p())
+        elif f is not None and key is value and (query is not key or "w_qkv" in f):
             if query is key:
                 qkv = Fn.linear(query, f["w_qkv"], f["b_qkv"])                      # ONE GEMM, N = 3D
                 ctx, self.attn = Fn.attention_packed_qkv(qkv, kl, causal, self.h, self._p())
@@ -309,30 +314,33 @@ class DecoderLayer(nn.Module):
         self.dropout_rate = dropout_rate
         self.normalize_before = normalize_before
 
-    def forward(self, x, tgt_lens, memory, mem_lens, normed=None, causal=True):
+    def forward(self, x, tgt_lens, memory, mem_lens, normed=None, causal=True, kv=None):
         p = self.dropout_rate if self.training else 0.0
         if self.normalize_before:
             y = self.norm1(x) if normed is None else normed
             a = self.self_attn(y, y, y, tgt_lens, causal=causal)
             y, x = _res_norm(self.norm2, x, a, p)
-            a = self.src_attn(y, memory, memory, mem_lens)
+            a = self.src_attn(y, memory, memory, mem_lens, kv=kv)
             y, x = _res_norm(self.norm3, x, a, p)
             return x, self.feed_forward(y)
         a = self.self_attn(x, x, x, tgt_lens, causal=causal)
         x, _ = _res_norm(self.norm1, x, a, p)
-        a = self.src_attn(x, memory, memory, mem_lens)
+        a = self.src_attn(x, memory, memory, mem_lens, kv=kv)
         x, _ = _res_norm(self.norm2, x, a, p)
         f = self.feed_forward(x)
         x, _ = _res_norm(self.norm3, x, f, p)
         return x, None
 
 
-def run_stack(layers, x, after_norm, pre_ln, dropout_rate, training, *args, **kw):
+def run_stack(layers, x, after_norm, pre_ln, dropout_rate, training, *args, per_layer=None, **kw):
     """Run a stack of EncoderLayer/DecoderLayer.  In pre-LN mode each layer returns (x, pending FFN
-    output); `x + dropout(f)` is fused into the NEXT layer's first LayerNorm (or after_norm)."""
+    output); `x + dropout(f)` is fused into the NEXT layer's first LayerNorm (or after_norm).
+    per_layer: optional list of extra keyword arguments, one dict per layer."""
     p = dropout_rate if training else 0.0
     pending = None
-    for layer in layers:
+    for li, layer in enumerate(layers):
+        if per_layer is not None:
+            kw = dict(kw, **per_layer[li])
         if pre_ln and pending is not None:
             normed, x = _res_norm(layer.norm1, x, pending, p)
             x, pending = layer(x, *args, normed=normed, **kw)
@@ -527,6 +535,13 @@ class Decoder(nn.Module):
 
     def forward(self, tgt, tgt_lens, memory, mem_lens, causal=True):
         x = self.embed_input(tgt)
+        per_layer = None
+        f = getattr(self, "_src_kv_all", None)       # stacked K/V weights of all source-attention blocks (optim.FlatAdam)
+        if f is not None:
+            # the memory is projected for ALL layers by one GEMM (N = layers * 2D); backward: one dgrad GEMM with
+            # K = layers * 2D instead of one per layer plus the gradient adds over the memory's fan-out
+            kv_all = Fn.linear(memory, f["w"], f["b"])
+            per_layer = [{"kv": t} for t in Fn.split_cols(kv_all, len(self.decoders))]
         x = run_stack(self.decoders, x, getattr(self, "after_norm", None), self.normalize_before, self.dropout_rate,
-                      self.training, tgt_lens, memory, mem_lens, causal=causal)
+                      self.training, tgt_lens, memory, mem_lens, causal=causal, per_layer=per_layer)
         return x, tgt_lens

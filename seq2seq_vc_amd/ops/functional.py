@@ -618,8 +618,12 @@ class _AttnPackedKV(Function):
 
     @staticmethod
     def forward(ctx, q, kv, klen, causal, H, p):
-        q, kv = _c(q), _c(kv)
+        q = _c(q)
         D = q.shape[-1]
+        # a column slice of the decoder's batched K/V projection (split_cols) is used in place when the fused kernel,
+        # which takes row and batch strides, runs; everything else wants a dense (B, T2, 2D) tensor
+        if not (kv.stride(-1) == 1 and KAT.supported(q, kv[..., :D], kv[..., D:], H)):
+            kv = _c(kv)
         k, v = kv[..., :D], kv[..., D:]
         out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
         ctx.meta = (H, scale, p, seed, D)
@@ -633,10 +637,36 @@ class _AttnPackedKV(Function):
         H, scale, p, seed, D = ctx.meta
         k, v = kv[..., :D], kv[..., D:]
         dq = torch.empty_like(q)
-        dkv = torch.empty_like(kv)
+        dkv = torch.empty(kv.shape, dtype=kv.dtype, device=kv.device)
         _attn_common_bwd(dctx, dattn, attn, _pm(ctx, attn, pdrop), q, k, v, H, scale, p, seed,
                          outs=(dq, dkv[..., :D], dkv[..., D:]))
         return dq, dkv, None, None, None, None
+
+
+class _SplitCols(Function):
+    """(..., n*W) -> n column blocks (..., W) as VIEWS (no copy); the backward concatenates the n gradients with one kernel.
+    (Plain slicing would make autograd build n zero-padded full-width gradients and n-1 adds.)"""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        W = x.shape[-1] // n
+        ctx.n, ctx.W = n, W
+        ctx.meta = (x.shape, x.dtype, x.device)
+        ctx.set_materialize_grads(False)
+        return tuple(x[..., i * W:(i + 1) * W] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, dtype, device = ctx.meta
+        if all(g is None for g in grads):
+            return None, None
+        blk = shape[:-1] + (ctx.W,)
+        parts = [g if g is not None else torch.zeros(blk, dtype=dtype, device=device) for g in grads]
+        return torch.cat(parts, dim=-1), None
+
+
+def split_cols(x, n):
+    return _SplitCols.apply(x, n)
 
 
 def attention_packed_qkv(qkv, klen, causal, H, p=0.0):

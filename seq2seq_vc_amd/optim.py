@@ -25,9 +25,12 @@ class FlatAdam:
             raise ValueError("no trainable parameters")
         # lay the Q/K/V weights (and biases) of every attention module out back to back, so that
         # [Wq;Wk;Wv] is ONE (3D, D) matrix in the flat buffer (fused projection GEMMs, see modules.py)
-        groups = self._attention_groups(model) if fuse_qkv else []
-        grouped = {id(p) for g in groups for p in g["w"] + g["b"]}
+        stacks = self._source_attention_stacks(model) if fuse_qkv else []
+        in_stack = {id(m) for st in stacks for m in st["mods"]}
+        groups = self._attention_groups(model, skip=in_stack) if fuse_qkv else []
+        grouped = {id(p) for g in groups for p in g["w"] + g["b"]} | {id(p) for st in stacks for p in st["w"] + st["b"]}
         first = {id(g["w"][0]): g for g in groups}
+        first.update({id(st["w"][0]): st for st in stacks})
         ordered, tight = [], set()     # `tight` members start right where the previous one ends (no alignment gap)
         for p in self.params:
             if id(p) in first:
@@ -90,6 +93,25 @@ class FlatAdam:
                     for key, off, rows in (("w_qkv", ow, 3 * D), ("w_kv", ow + D * D, 2 * D)):
                         self._t_descs.append((off, self._t_extra, rows, D, f[key]))
                         self._t_extra += (rows * D + align - 1) // align * align
+        # decoder stacks: [Wk_1; Wv_1; ...; Wk_L; Wv_L] of the source-attention blocks is ONE (L*2D, D) matrix -- the memory is
+        # projected for all layers by a single GEMM (modules.Decoder.forward); each block keeps its own (2D, D) view
+        for st in stacks:
+            ws, bs, mods = st["w"], st["b"], st["mods"]
+            D = ws[0].shape[0]
+            ow, ob = off_of[id(ws[0])], off_of[id(bs[0])]
+            contiguous = all(off_of[id(w)] == ow + i * D * D for i, w in enumerate(ws)) and \
+                all(off_of[id(b)] == ob + i * D for i, b in enumerate(bs))
+            if not contiguous:
+                continue
+            for li, m in enumerate(mods):
+                q_w, q_b = m.linear_q.weight, m.linear_q.bias
+                m._fused = {"w_q": q_w, "b_q": q_b,
+                            "w_kv": self._view(ow + li * 2 * D * D, (2 * D, D)), "b_kv": self._view(ob + li * 2 * D, (2 * D,))}
+            allv = {"w": self._view(ow, (len(ws) * D, D)), "b": self._view(ob, (len(bs) * D,))}
+            st["decoder"]._src_kv_all = allv
+            if self.shadow is not None and transposed_shadow:
+                self._t_descs.append((ow, self._t_extra, len(ws) * D, D, allv["w"]))
+                self._t_extra += (len(ws) * D * D + align - 1) // align * align
         if self._t_descs:
             self.shadow_t = torch.zeros(self._t_extra, dtype=torch.bfloat16, device=dev)
             tiles = []
@@ -106,10 +128,31 @@ class FlatAdam:
             self.refresh_shadow()
 
     @staticmethod
-    def _attention_groups(model):
+    def _source_attention_stacks(model):
+        """Per modules.Decoder: the K / V weights and biases of the source-attention blocks of all its layers, in layer order
+        (k_1, v_1, k_2, v_2, ...)."""
+        from .modules import Decoder, MultiHeadedAttention
+        stacks = []
+        for dec in model.modules():
+            if not isinstance(dec, Decoder):
+                continue
+            mods = [layer.src_attn for layer in dec.decoders]
+            if not mods or not all(type(m) is MultiHeadedAttention for m in mods):
+                continue
+            ws = [w for m in mods for w in (m.linear_k.weight, m.linear_v.weight)]
+            bs = [b for m in mods for b in (m.linear_k.bias, m.linear_v.bias)]
+            qs = [p for m in mods for p in (m.linear_q.weight, m.linear_q.bias)]
+            if all(p is not None and p.requires_grad for p in ws + bs + qs) and len({w.shape for w in ws}) == 1:
+                stacks.append({"decoder": dec, "mods": mods, "w": ws, "b": bs})
+        return stacks
+
+    @staticmethod
+    def _attention_groups(model, skip=()):
         from .modules import MultiHeadedAttention
         groups = []
         for m in model.modules():
+            if id(m) in skip:
+                continue
             if isinstance(m, MultiHeadedAttention):
                 ws = [m.linear_q.weight, m.linear_k.weight, m.linear_v.weight]
                 bs = [m.linear_q.bias, m.linear_k.bias, m.linear_v.bias]

@@ -453,8 +453,20 @@ def training_steps_bf16_transposed_shadow():
             f = getattr(m, "_fused", None)
             if f is not None:
                 for key in ("w_qkv", "w_kv", "w_q"):
-                    if not torch.equal(f[key]._s2s_bf16_t, f[key]._s2s_bf16.t()):
+                    wt = getattr(f.get(key), "_s2s_bf16_t", None)      # source-attention blocks: the stack view carries it
+                    if wt is not None and not torch.equal(wt, f[key]._s2s_bf16.t()):
                         bad.append(f"fused view {key}: transposed shadow != shadow^T")
+            st = getattr(m, "_src_kv_all", None)
+            if st is not None:
+                n += 1
+                if not torch.equal(st["w"]._s2s_bf16_t, st["w"]._s2s_bf16.t()):
+                    bad.append("stacked source K/V weights: transposed shadow != shadow^T")
+                L = len(m.decoders)
+                for li, layer in enumerate(m.decoders):
+                    D = layer.src_attn.linear_k.weight.shape[0]
+                    ref = torch.cat([layer.src_attn.linear_k.weight, layer.src_attn.linear_v.weight], 0)
+                    if not torch.equal(st["w"][li * 2 * D:(li + 1) * 2 * D], ref):
+                        bad.append("stacked source K/V weights are not the layers' [Wk; Wv]")
         p_n, l_n, _, _ = _train_steps(3, 4, True, dtype=torch.bfloat16, transposed_shadow=False)
     finally:
         Fn.set_compute_dtype(torch.float32)
