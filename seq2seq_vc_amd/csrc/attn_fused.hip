@@ -57,6 +57,35 @@ __device__ __forceinline__ void stage_rows_t(const bf16_t* g, int64_t ld, int R,
   }
 }
 
+// A wave's 16 x DK accumulator tile -> global rows with 16-byte stores: the MFMA layout gives a lane one column of 4
+// rows per fragment (2-byte scattered stores, 24 per lane at DK = 96); staged through a wave-private LDS tile (pitch KP)
+// every lane writes 8 consecutive columns at once.  LDS ops of one wavefront execute in order: no barrier inside.
+template <int DK>
+__device__ __forceinline__ void store_tile_rows(const f32x4_t (&acc)[DK / 16], bf16_t* stage, bf16_t* dst, int64_t ld, int rows_valid,
+                                                bool vec_ok) {
+  constexpr int KP = DK + 8;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
+  if (!vec_ok) {
+#pragma unroll
+    for (int dn = 0; dn < DK / 16; ++dn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (lg * 4 + r < rows_valid) dst[(int64_t)(lg * 4 + r) * ld + dn * 16 + lr] = f2bf(acc[dn][r]);
+    return;
+  }
+#pragma unroll
+  for (int dn = 0; dn < DK / 16; ++dn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stage[(lg * 4 + r) * KP + dn * 16 + lr] = f2bf(acc[dn][r]);
+  constexpr int VPR = DK / 8;                         // 16-byte vectors per row
+#pragma unroll
+  for (int v = lane; v < 16 * VPR; v += 64) {
+    const int row = v / VPR, c8 = v - row * VPR;
+    if (row < rows_valid)
+      *reinterpret_cast<uint4*>(dst + (int64_t)row * ld + c8 * 8) = *reinterpret_cast<const uint4*>(stage + row * KP + c8 * 8);
+  }
+}
+
 template <int DK>
 __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(int H, int T1, int T2, const bf16_t* __restrict__ q, int64_t ldq, int64_t qbs,
                                                              const bf16_t* __restrict__ k, int64_t ldk, int64_t kbs,
@@ -138,13 +167,12 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(int H, int T1, int 
       o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dn], 0, 0, 0);
     }
   }
-#pragma unroll
-  for (int dn = 0; dn < DK / 16; ++dn)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = wave * 16 + lg * 4 + r;
-      if (i < T1) out[(int64_t)b * obs + (int64_t)i * ldo + h * DK + dn * 16 + lr] = f2bf(o[dn][r]);
-    }
+  __syncthreads();                                   // every wave is past its K reads: Ks becomes the output staging area
+  {
+    bf16_t* base = out + (int64_t)b * obs + (int64_t)(wave * 16) * ldo + h * DK;
+    const bool vec_ok = (ldo % 8 == 0) && (obs % 8 == 0) && (((uintptr_t)out) % 16 == 0);
+    store_tile_rows<DK>(o, Ks + wave * 16 * KP, base, ldo, T1 - wave * 16, vec_ok);
+  }
 }
 
 template <int DK>
@@ -233,13 +261,9 @@ __global__ __launch_bounds__(256) void attn_fused_bwd_kernel(int H, int T1, int 
         acc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[dn], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int dn = 0; dn < DK / 16; ++dn)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = wave * 16 + lg * 4 + r;
-        if (i < T1) dq[(int64_t)b * dqbs + (int64_t)i * lddq + h * DK + dn * 16 + lr] = f2bf(acc[dn][r]);
-      }
+    // (Vs was last read before the barrier above: its rows wave*16.. are this wave's output staging area from here on)
+    store_tile_rows<DK>(acc, Vs + wave * 16 * KP, dq + (int64_t)b * dqbs + (int64_t)(wave * 16) * lddq + h * DK, lddq, T1 - wave * 16,
+                        (lddq % 8 == 0) && (dqbs % 8 == 0) && (((uintptr_t)dq) % 16 == 0));
   }
   // dK = dS^T . Q ; dV = Pdrop^T . dO      (rows: keys wave*16 .. wave*16+15)
 #pragma unroll
@@ -259,14 +283,9 @@ __global__ __launch_bounds__(256) void attn_fused_bwd_kernel(int H, int T1, int 
       }
     }
     bf16_t* dst = which == 0 ? dkk + (int64_t)b * dkbs : dv + (int64_t)b * dvbs;
-    const int64_t ldd = which == 0 ? lddk : lddv;
-#pragma unroll
-    for (int dn = 0; dn < DK / 16; ++dn)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = wave * 16 + lg * 4 + r;
-        if (j < T2) dst[(int64_t)j * ldd + h * DK + dn * 16 + lr] = f2bf(acc[dn][r]);
-      }
+    const int64_t ldd = which == 0 ? lddk : lddv, dbs = which == 0 ? dkbs : dvbs;
+    store_tile_rows<DK>(acc, Vs + wave * 16 * KP, dst + (int64_t)(wave * 16) * ldd + h * DK, ldd, T2 - wave * 16,
+                        (ldd % 8 == 0) && (dbs % 8 == 0) && (((uintptr_t)dst) % 16 == 0));
   }
 }
 
