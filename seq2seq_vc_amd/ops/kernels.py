@@ -200,7 +200,8 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
 # ----------------------------------------------------------------------------------------------
 _RECORDER = None            # list of GemmDesc while recording
 _GROUP_TILE = int(os.environ.get("S2SVC_GROUP_TILE", "64"))      # output tile edge of the grouped kernel (64 / 128)
-_GROUP_MAX_TILES = int(os.environ.get("S2SVC_GROUP_MAX_TILES", "96"))
+_GROUP_MAX_TILES = int(os.environ.get("S2SVC_GROUP_MAX_TILES", "200"))
+_GROUP_BIG_TILES = int(os.environ.get("S2SVC_GROUP_BIG_TILES", "64"))
 
 
 class record_grouped:
@@ -235,8 +236,13 @@ def flush_grouped(queue):
                 seen |= keys
                 group.append(d)
         pending = rest
-        arr = (_lib.GemmDesc * len(group))(*group)
-        _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(group), _GROUP_TILE, stream()), "s2svc_gemm_grouped")
+        # big outputs (>= _GROUP_BIG_TILES 128x128 tiles each) share launches of 128x128 tiles, the rest of 64x64 tiles
+        big = [d for d in group if _GROUP_TILE == 64 and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= _GROUP_BIG_TILES]
+        small = [d for d in group if not any(d is b for b in big)]
+        for part, tile in ((big, 128), (small, _GROUP_TILE)):
+            if part:
+                arr = (_lib.GemmDesc * len(part))(*part)
+                _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(part), tile, stream()), "s2svc_gemm_grouped")
 
 
 # ----------------------------------------------------------------------------------------------

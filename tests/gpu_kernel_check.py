@@ -274,10 +274,10 @@ def gemm_grouped_wgrad():
     saved, saved_max = K._GROUP_TILE, K._GROUP_MAX_TILES
     big = []
     with K.record_grouped(big):      # default policy: an output with >= _GROUP_MAX_TILES 128x128 tiles is launched directly
-        x, dy, dw0, _ = probs[6]
+        x, dy, dw0 = rnd(512, 3072, seed=50, dtype=dtype), rnd(512, 1536, seed=51, dtype=dtype), rnd(1536, 3072, seed=52)
         dw = dw0.clone()
-        K.gemm(K.operand(dy, 384, layout=K.RC), K.operand(x, 7296, layout=K.RC), 384, 7296, 2016, dw, in_dtype=dtype, accumulate=True)
-    res.append((len(big) == 0, "a chip-filling problem is not queued"))
+        K.gemm(K.operand(dy, 1536, layout=K.RC), K.operand(x, 3072, layout=K.RC), 1536, 3072, 512, dw, in_dtype=dtype, accumulate=True)
+    res.append((len(big) == 0, "a chip-filling problem (288 tiles of 128x128) is not queued"))
     res.append(check("chip-filling problem launched directly", dw, dw0 + dy.float().t() @ x.float(), torch.float32, rtol=1e-3, atol=0.05))
     K._GROUP_MAX_TILES = 1 << 30
     for tile in (64, 128):
