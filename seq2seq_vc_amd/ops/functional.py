@@ -94,7 +94,7 @@ class _Side:
     idx = 0
     pending = []     # tensors that must stay alive until the join (their memory is in use on a side stream)
     queue = []       # closures waiting for the next fork point
-    batch = int(os.environ.get("S2SVC_SIDE_BATCH", "10"))
+    batch = int(os.environ.get("S2SVC_SIDE_BATCH", "12"))
     grouped = []     # weight-gradient GEMM descriptors of the batch being flushed
     group_wgrad = os.environ.get("S2SVC_NO_GROUPED_WGRAD", "0") != "1"
 
