@@ -80,7 +80,7 @@ def cpu_baseline(batch, steps=2):
             "ms_per_step": t * 1e3}
 
 
-def dominant_kernel_roofline(dtype, iters=20):
+def dominant_kernel_roofline(dtype, iters=100):
     """Times the FLOP-heaviest single launch of the step -- the implicit-GEMM 3x3 stride-2 Conv2d of the
     encoder front-end (M = 32*63*19, N = 384, K = 9*384; subsampling.py:60) -- with HIP events on the
     stream it is launched on, and rates it against the MFMA peak of its dtype."""
@@ -99,12 +99,23 @@ def dominant_kernel_roofline(dtype, iters=20):
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
+    # the `iters` launches are replayed from one hipGraph: HIP events around a Python launch loop would time the host's
+    # ~10 us per ctypes launch between 140 us kernels, not the kernel (rocprofv3's per-dispatch average is the cross-check)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(iters):
+                launch()
+        g.replay()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        g.replay()
+        e1.record(side)
+        side.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * N * Kd
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == torch.bfloat16 else F32_MFMA_PEAK_TFLOPS
