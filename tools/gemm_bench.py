@@ -4,7 +4,7 @@
     python tools/gemm_bench.py [--iters 50] [--dtype bf16] [--filter substr]
 
 Each line: the operand layouts as the autograd code issues them (fwd = KC x KC, dgrad = KC x RC, wgrad = RC x RC with the
-reduction over the B*T rows), average launch time over `--iters` back-to-back launches (HIP events on the launch stream),
+reduction over the B*T rows), average launch time over `--iters` back-to-back launches replayed from one hipGraph (HIP events around the replay),
 achieved TFLOP/s and the fraction of the dense bf16 MFMA peak (2.5 PFLOP/s).  Inputs are uniform random in [-1, 1).
 """
 import argparse
@@ -37,15 +37,26 @@ LINEARS = [
 
 
 def bench(fn, iters):
+    """Average time of one launch: `iters` launches replayed from one hipGraph (the events then bracket kernels; a Python
+    launch loop adds ~10 us of host time per ctypes launch, more than the short GEMMs take)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        g.replay()
+        e1.record(side)
+        side.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
     return e0.elapsed_time(e1) * 1e3 / iters   # us
 
 
