@@ -225,10 +225,11 @@ def main():
     if use_graph:
         try:
             g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_fb):
+            # thread_local: RCCL's watchdog thread polls events while this thread captures (N > 1)
+            with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
                 fwd_bwd()
             g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt):
+            with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
                 opt.step()
         except Exception as e:  # noqa: BLE001 -- report and fall back to eager launches, loudly
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
