@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3)")
+    ap.add_argument("--split-backward", action="store_true",
+                    help="N = 1: run the two-graph step of the data-parallel path (autograd cut at the encoder output) without collectives")
     ap.add_argument("--side-streams", type=int, default=4, help="HIP side streams for parameter-gradient kernels (0 = off)")
     args = ap.parse_args()
 
@@ -174,7 +176,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from seq2seq_vc_amd import losses as L
-    from seq2seq_vc_amd.distributed import allreduce_mean_
+    from seq2seq_vc_amd.distributed import allreduce_end, allreduce_mean_, allreduce_sum_begin
     from seq2seq_vc_amd.models import VTN
     from seq2seq_vc_amd.ops import functional as Fn
     from seq2seq_vc_amd.ops import kernels as K
@@ -218,10 +220,45 @@ def main():
         loss_buf[1].copy_(bce.detach())
         Fn.side_join()
 
+    # -- data-parallel overlap: the autograd graph is cut at the encoder output.  Graph 1 = forward + loss + the decoder-
+    # side backward; its gradients (one contiguous range of the flat buffer) start their all-reduce while graph 2, the
+    # encoder's backward, runs.  The loss carries the 1/world of the mean, so the collectives are plain sums.
+    enc_range = opt.param_range(model.encoder)
+    split = (world > 1 or args.split_backward) and enc_range is not None and enc_range[0] == 0
+    gscale = 1.0 / world
+    cut = {}
+
+    def fwd_bwd_decoder():
+        K.reset_op_counter()
+        K.advance_seed(dev)
+        opt.zero_grad()
+        cut.clear()
+        after, before, logits, ys_, labels_, olens_, _ = model(xs_d, ilens, ys_d, labels_d, olens, _memory_cut=cut)
+        l1, bce = crit(after, before, logits, ys_, labels_, olens_)
+        ((l1 + bce) * gscale if world > 1 else (l1 + bce)).backward()
+        loss_buf[0].copy_(l1.detach())
+        loss_buf[1].copy_(bce.detach())
+        Fn.side_join()
+
+    def bwd_encoder():
+        cut["encoder_out"].backward(cut["decoder_in"].grad)
+        Fn.side_join()
+
+    def reduce_begin(part):      # part 0: everything behind the encoder's parameters, part 1: the encoder's
+        lo, hi = (enc_range[1], opt.numel) if part == 0 else enc_range
+        return allreduce_sum_begin(opt.flat_g[lo:hi], dist, world)
+
     def step_eager():
-        fwd_bwd()
-        if world > 1:
-            allreduce_mean_(opt.flat_g, dist, world)
+        if split:
+            fwd_bwd_decoder()
+            h = reduce_begin(0)
+            bwd_encoder()
+            h += reduce_begin(1)
+            allreduce_end(h)
+        else:
+            fwd_bwd()
+            if world > 1:
+                allreduce_mean_(opt.flat_g, dist, world)
         opt.step()
 
     # warm-up (eager, on a side stream so that a later capture sees a quiet default stream)
@@ -234,13 +271,17 @@ def main():
     torch.cuda.synchronize()
 
     use_graph = not args.no_graph
-    g_fb = g_opt = None
+    g_fb = g_fb2 = g_opt = None
     if use_graph:
         try:
             g_fb = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread polls events while this thread captures (N > 1)
             with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
-                fwd_bwd()
+                fwd_bwd_decoder() if split else fwd_bwd()
+            if split:
+                g_fb2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb2, pool=g_fb.pool(), capture_error_mode="thread_local"):
+                    bwd_encoder()
             g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
                 opt.step()
@@ -250,13 +291,20 @@ def main():
             torch.cuda.synchronize()
 
     def step():
-        if use_graph:
+        if not use_graph:
+            step_eager()
+        elif split:
+            g_fb.replay()
+            h = reduce_begin(0)          # decoder / postnet gradients travel ...
+            g_fb2.replay()               # ... while the encoder's backward pass runs
+            h += reduce_begin(1)
+            allreduce_end(h)
+            g_opt.replay()
+        else:
             g_fb.replay()
             if world > 1:
                 allreduce_mean_(opt.flat_g, dist, world)
             g_opt.replay()
-        else:
-            step_eager()
 
     for _ in range(args.warmup):
         step()
@@ -294,7 +342,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "VTN egs/arctic/vc1 (vtn.v1.yaml) training step: fwd+Seq2SeqLoss+bwd+clip+Adam+WarmupLR",
                        "batch_per_gpu": B, "global_batch": B * world, "T_src": 256, "T_tgt": 256, "mel_dim": 80,
-                       "params_M": 30.48, "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                       "params_M": 30.48, "parallelism": f"dp{world}", "hip_graph": bool(use_graph), "split_backward": bool(split),
                        "valid_target_frames_per_step": frames},
             "final_losses": {"l1": losses[0], "bce": losses[1], "grad_norm": stats["grad_norm"], "opt_steps": stats["step"]},
             "step_mfma": {"gflop_per_step_per_gpu": FWD_BWD_GFLOP,

@@ -40,6 +40,20 @@ def allreduce_mean_(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None)
     return flat
 
 
+def allreduce_sum_begin(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None):
+    """Start the in-place SUM all-reduce of a flat buffer (or a slice of one) and return the pending handles: the
+    collectives run on the backend's own stream while the caller keeps launching compute; allreduce_end() joins."""
+    if world <= 1:
+        return []
+    return [dist.all_reduce(flat[o:o + chunk_numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            for o in range(0, flat.numel(), chunk_numel)]
+
+
+def allreduce_end(handles):
+    for h in handles:
+        h.wait()
+
+
 def broadcast_(flat, dist, world, src=0, group=None):
     """Initial parameter broadcast from rank 0 (what DDP does at wrap time)."""
     if world > 1:

@@ -176,6 +176,14 @@ class VTN(_ARSeq2Seq):
         if ol.max() != ys.shape[1]:
             ys, labels = ys[:, : ol.max()], labels[:, : ol.max()]
         hs, hs_lens = self.encoder(Fn.to_compute(xs), il)
+        cut = kwargs.get("_memory_cut")
+        if cut is not None:
+            # data-parallel overlap (bench.py): the autograd graph is cut at the encoder output, so that the decoder-side
+            # gradients are complete -- and their all-reduce can start -- before the encoder's backward pass runs:
+            #   loss.backward()  ->  cut["decoder_in"].grad ;  cut["encoder_out"].backward(cut["decoder_in"].grad)
+            cut["encoder_out"] = hs
+            hs = hs.detach().requires_grad_(True)
+            cut["decoder_in"] = hs
         after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens)
         ilens_ds_st = torch.tensor([((v - 2 + 1) // 2 - 2 + 1) // 2 for v in il.host],
                                    dtype=ilens.dtype if isinstance(ilens, torch.Tensor) else torch.long,

@@ -182,6 +182,19 @@ class FlatAdam:
         if self.shadow_t is not None:
             K.transpose_tiles(self.t_tiles, self.shadow, self.shadow_t)
 
+    def param_range(self, module):
+        """[lo, hi) of the flat buffers covered by the parameters of `module`, or None if parameters of other modules
+        lie inside that range (data-parallel bucketing by sub-network, bench.py)."""
+        mine = {id(p) for p in module.parameters()}
+        spans = [(o, o + p.numel()) for p, o in zip(self.params, self.offsets) if id(p) in mine]
+        if not spans:
+            return None
+        lo, hi = min(a for a, _ in spans), max(b for _, b in spans)
+        for p, o in zip(self.params, self.offsets):
+            if id(p) not in mine and lo <= o < hi:
+                return None
+        return lo, hi
+
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
 

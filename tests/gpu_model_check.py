@@ -338,7 +338,7 @@ def aasvc_tiny_train_bf16():
     return run_aas("aasvc_tiny_train", torch.bfloat16)
 
 
-def _train_steps(n_steps, side_streams, use_graph, dtype=torch.float32, transposed_shadow=True):
+def _train_steps(n_steps, side_streams, use_graph, dtype=torch.float32, transposed_shadow=True, memory_cut=False):
     """n optimiser steps of tiny VTN with FlatAdam on the golden batch; returns (flat params, losses)."""
     from seq2seq_vc_amd import losses as L
     from seq2seq_vc_amd import models as M
@@ -364,10 +364,15 @@ def _train_steps(n_steps, side_streams, use_graph, dtype=torch.float32, transpos
     def fwd_bwd():
         K.reset_op_counter()
         opt.zero_grad()
-        o = model(xs, ilens, ys, labels, olens)
+        cut = {} if memory_cut else None
+        o = model(xs, ilens, ys, labels, olens, _memory_cut=cut)
         l1, bce = crit(o[0], o[1], o[2], o[3], o[4], o[5])
         (l1 + bce).backward()
         Fn.side_join()
+        if memory_cut:          # bench.py's data-parallel step: the encoder's backward pass is a second autograd run
+            assert cut["encoder_out"].grad_fn is not None and cut["decoder_in"].grad is not None
+            cut["encoder_out"].backward(cut["decoder_in"].grad)
+            Fn.side_join()
         lossbuf[0].copy_(l1.detach())
         lossbuf[1].copy_(bce.detach())
 
@@ -431,6 +436,23 @@ def training_steps_equivalence_fp32():
     res.append((worst < 2e-5, f"params after 3 optimiser steps vs oracle trainer replay: max abs diff {worst:.2e}"))
     res.append((abs(st0["grad_norm"] - float(gn)) < 1e-3 * float(gn), f"grad norm {st0['grad_norm']:.5f} vs oracle {float(gn):.5f}; lr {st0['lr']:.3e}"))
     return res
+
+
+@case
+def training_steps_memory_cut_fp32():
+    """The autograd graph cut at the encoder output (decoder-side backward, then the encoder's as a second run -- the
+    data-parallel step of bench.py) gives the same parameters as one backward pass."""
+    try:
+        p_a, l_a, _, _ = _train_steps(3, 4, False, memory_cut=False)
+        p_b, l_b, _, _ = _train_steps(3, 4, False, memory_cut=True)
+        p_c, l_c, _, _ = _train_steps(3, 4, True, memory_cut=True)
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    d1, d2 = (p_a - p_b).abs().max().item(), (p_a - p_c).abs().max().item()
+    return [(d1 < 2e-6, f"params after 3 steps, cut vs single backward (eager): max abs diff {d1:.2e}"),
+            (d2 < 2e-6, f"params after 3 steps, cut + hipGraph vs single backward: max abs diff {d2:.2e}"),
+            (abs(l_a[-1][0] - l_b[-1][0]) < 1e-5, f"l1 {l_a[-1][0]:.6f} vs {l_b[-1][0]:.6f}")]
 
 
 @case

@@ -143,6 +143,15 @@ def _dp_worker(rank, world, port, q):
     ((x @ wr - y) ** 2).mean().backward()
     flat = wr.grad.clone()
     allreduce_mean_(flat, dist, world, chunk_numel=300)        # several chunks
+    # bucketed variant of bench.py: two slices reduced independently (second one started before the first is joined),
+    # gradients pre-scaled by 1/world through the loss
+    from seq2seq_vc_amd.distributed import allreduce_sum_begin, allreduce_end
+    flat2 = wr.grad.clone() / world
+    h_hi = allreduce_sum_begin(flat2[600:], dist, world, chunk_numel=250)
+    h_lo = allreduce_sum_begin(flat2[:600], dist, world, chunk_numel=250)
+    allreduce_end(h_hi)
+    allreduce_end(h_lo)
+    assert torch.allclose(flat2, flat, atol=1e-6), "bucketed async all-reduce != chunked mean all-reduce"
     q.put((rank, w, wr.grad.clone(), flat))
     dist.destroy_process_group()
 
