@@ -1,3 +1,8 @@
+// Probe of gfx950's transposing LDS read (ds_read_b64_tr_b16), the instruction behind the row-contiguous GEMM operands
+// (csrc/gemm_glds.hip: TrStage / tr_fragment).  LDS holds element index = row*stride + col; every lane of a 16-lane group
+// supplies the address of 4 consecutive bf16 of a [4 rows][16 cols] block (lane i: row i/4, cols 4*(i%4)..+3).  Output
+// on MI355X: lane c of the group receives (row 0..3, col c) -- the block's column c, i.e. 4 consecutive "k" values of
+// one "n".  Build + run on a GPU box:  hipcc --offload-arch=gfx950 -O2 tools/probe_ds_read_tr16.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
