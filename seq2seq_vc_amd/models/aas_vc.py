@@ -204,8 +204,9 @@ class AASVC(nn.Module):
             log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c)
             ds, bin_loss = self.viterbi_func(log_p_attn, il_c, olr)
             if stochastic:
-                dur_nll = self.duration_predictor.forward_cl(dpi, il_c, w=ds)
-                ret["dur_nll"] = dur_nll / torch.sum(tmask)
+                # ~330 small launches that depend on nothing the length regulator / decoder / postnet below produce: they
+                # run on the auxiliary stream beside them (forward here, backward through autograd's stream rule)
+                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dpi, il_c, w=ds) / torch.sum(tmask))
             else:
                 d_outs = self.duration_predictor(dpi, il_c)
                 ret["d_outs"] = torch.clamp(d_outs, max=MAX_DP_OUTPUT)
@@ -215,6 +216,7 @@ class AASVC(nn.Module):
         before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, self.odim)
         after = before if self.postnet is None else Fn.add_dropout(before, self.postnet(before), 0.0)
         ret["before_outs"], ret["after_outs"] = before, after
+        Fn.branch_join(ret.get("dur_nll"))
         ret["ds"] = ds
         ret["ilens"] = self._lens_like(ilens, il.host)
         ret["bin_loss"] = bin_loss

@@ -94,6 +94,7 @@ class _Side:
     idx = 0
     pending = []     # tensors that must stay alive until the join (their memory is in use on a side stream)
     queue = []       # closures waiting for the next fork point
+    origins = []     # the stream each queued closure was issued from
     batch = int(os.environ.get("S2SVC_SIDE_BATCH", "12"))
     grouped = []     # weight-gradient GEMM descriptors of the batch being flushed
     group_wgrad = os.environ.get("S2SVC_NO_GROUPED_WGRAD", "0") != "1"
@@ -107,11 +108,13 @@ def enable_side_streams(n=4):
 
 def _side_run(fn, keep=()):
     """Parameter-gradient work off the data-gradient chain: `fn` is queued and runs on a side stream in batches of
-    `_Side.batch` closures -- one fork point (cross-stream edge of the captured graph) per batch instead of one per call."""
+    `_Side.batch` closures -- one fork point (cross-stream edge of the captured graph) per batch instead of one per call.
+    The stream the caller runs on is remembered: backward nodes of a branch (branch_run) execute on the branch's stream."""
     if not _Side.enabled:
         fn()
         return
     _Side.queue.append(fn)
+    _Side.origins.append(torch.cuda.current_stream())
     _Side.pending.append(keep)
     if len(_Side.queue) >= _Side.batch:
         _side_flush()
@@ -120,10 +123,14 @@ def _side_run(fn, keep=()):
 def _side_flush():
     if not _Side.queue:
         return
-    main = torch.cuda.current_stream()
     st = _Side.streams[_Side.idx % len(_Side.streams)]
     _Side.idx += 1
-    st.wait_stream(main)
+    seen = set()
+    for origin in _Side.origins + [torch.cuda.current_stream()]:     # every stream that produced an input of the batch
+        if origin.cuda_stream not in seen:
+            seen.add(origin.cuda_stream)
+            st.wait_stream(origin)
+    _Side.origins = []
     with torch.cuda.stream(st):
         if _Side.group_wgrad:
             # the dense weight-gradient GEMMs of the batch become ONE grouped launch (no split-K, no reduction passes);
@@ -137,6 +144,44 @@ def _side_flush():
             for fn in _Side.queue:
                 fn()
     _Side.queue = []
+
+
+# ------------------------------------------------------------------------------------------------
+# Independent sub-networks (e.g. the duration predictor next to the length regulator + decoder of AAS-VC) can run on
+# an auxiliary stream: hundreds of small dependent kernels then fill the gaps of the other branch instead of extending
+# the chain.  torch's autograd engine runs every backward node on the stream of its forward op, so the backward pass of
+# the branch overlaps as well; under hipGraph capture fork and join are two graph edges.
+# ------------------------------------------------------------------------------------------------
+class _Branch:
+    stream = None
+    active = False
+
+
+def branch_run(fn):
+    """Run fn() on the auxiliary stream, after everything queued on the current stream.  Call branch_join() on the
+    current stream before anything there consumes the results."""
+    if not torch.cuda.is_available() or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
+        return fn()
+    main = torch.cuda.current_stream()
+    if _Branch.stream is None:
+        _Branch.stream = torch.cuda.Stream()
+    _Branch.stream.wait_stream(main)
+    with torch.cuda.stream(_Branch.stream):
+        out = fn()
+    _Branch.active = True
+    return out
+
+
+def branch_join(*results):
+    """Make the current stream wait for the auxiliary stream; `results` are tensors produced there that the current
+    stream goes on to use (their memory must not return to the auxiliary stream's pool while that use is pending)."""
+    if _Branch.active:
+        main = torch.cuda.current_stream()
+        main.wait_stream(_Branch.stream)
+        for t in results:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
+        _Branch.active = False
 
 
 def side_join():
