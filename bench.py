@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--split-backward", action="store_true",
                     help="N = 1: run the two-graph step of the data-parallel path (autograd cut at the encoder output) without collectives")
+    ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
     ap.add_argument("--side-streams", type=int, default=4, help="HIP side streams for parameter-gradient kernels (0 = off)")
     args = ap.parse_args()
 
@@ -187,7 +188,7 @@ def main():
         print(json.dumps(dominant_kernel_roofline(dtype, iters=200)))
         return
     Fn.set_compute_dtype(dtype)
-    Fn.enable_side_streams(args.side_streams)
+    Fn.enable_side_streams(args.side_streams, inline_batches=args.inline_batches)
     K.manual_seed(1234 + rank)
 
     B = args.batch

@@ -95,13 +95,21 @@ class _Side:
     pending = []     # tensors that must stay alive until the join (their memory is in use on a side stream)
     queue = []       # closures waiting for the next fork point
     origins = []     # the stream each queued closure was issued from
+    inline = False   # no side streams, but batched (see enable_side_streams)
+    inline_q = {}    # stream handle -> (stream, [closures])
     batch = int(os.environ.get("S2SVC_SIDE_BATCH", "12"))
     grouped = []     # weight-gradient GEMM descriptors of the batch being flushed
     group_wgrad = os.environ.get("S2SVC_NO_GROUPED_WGRAD", "0") != "1"
 
 
-def enable_side_streams(n=4):
+def enable_side_streams(n=4, inline_batches=False):
+    """n > 0: parameter-gradient work is forked to n side streams (small, latency-bound models: VTN).
+    n == 0 and inline_batches: the work stays on the stream that issued it but is still queued and run in batches, so
+    that the dense weight-gradient GEMMs of a batch become one grouped launch -- for models whose kernels fill the chip
+    anyway (AAS-VC: d = 1536) the forks cost more than the overlap gives (19.3 vs 20.9 ms/step).  Both need side_join()
+    between backward and the optimiser step; n == 0 without inline_batches runs everything immediately."""
     _Side.enabled = n > 0
+    _Side.inline = (n == 0) and inline_batches
     _Side.streams = [torch.cuda.Stream() for _ in range(n)] if n > 0 else []
     _Side.idx = 0
 
@@ -110,6 +118,14 @@ def _side_run(fn, keep=()):
     """Parameter-gradient work off the data-gradient chain: `fn` is queued and runs on a side stream in batches of
     `_Side.batch` closures -- one fork point (cross-stream edge of the captured graph) per batch instead of one per call.
     The stream the caller runs on is remembered: backward nodes of a branch (branch_run) execute on the branch's stream."""
+    if _Side.inline:
+        cur = torch.cuda.current_stream()
+        q = _Side.inline_q.setdefault(cur.cuda_stream, (cur, []))[1]
+        q.append(fn)
+        _Side.pending.append(keep)
+        if len(q) >= _Side.batch:
+            _inline_flush(cur.cuda_stream)
+        return
     if not _Side.enabled:
         fn()
         return
@@ -120,7 +136,25 @@ def _side_run(fn, keep=()):
         _side_flush()
 
 
+def _inline_flush(key):
+    """Run the closures queued from one stream ON that stream (no fork), the dense weight gradients as a grouped launch."""
+    st, q = _Side.inline_q.pop(key)
+    with torch.cuda.stream(st):
+        if _Side.group_wgrad:
+            with K.record_grouped(_Side.grouped):
+                for fn in q:
+                    fn()
+            if _Side.grouped:
+                K.flush_grouped(_Side.grouped)
+        else:
+            for fn in q:
+                fn()
+    return st
+
+
 def _side_flush():
+    if _Side.inline:
+        return
     if not _Side.queue:
         return
     st = _Side.streams[_Side.idx % len(_Side.streams)]
@@ -187,6 +221,12 @@ def branch_join(*results):
 def side_join():
     """Run what is still queued and make the current stream wait for all side-stream gradient work (call between
     backward and optimiser)."""
+    if _Side.inline:
+        main = torch.cuda.current_stream()
+        for key in list(_Side.inline_q):
+            st = _inline_flush(key)
+            if st.cuda_stream != main.cuda_stream:
+                main.wait_stream(st)
     if _Side.enabled:
         _side_flush()
         main = torch.cuda.current_stream()

@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--side-streams", type=int, default=4)
+    ap.add_argument("--side-streams", type=int, default=0, help="0 (default): gradient work stays on its stream, batched; n > 0: forked to n side streams")
+    ap.add_argument("--no-inline-batches", action="store_true")
     a = ap.parse_args()
     from bench import canonical_batch
     from seq2seq_vc_amd import losses as L
@@ -53,7 +54,7 @@ def main():
     dev = torch.device("cuda", 0)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     Fn.set_compute_dtype(dtype)
-    Fn.enable_side_streams(a.side_streams)
+    Fn.enable_side_streams(a.side_streams, inline_batches=not a.no_inline_batches)
     K.manual_seed(1234)
     xs, ilens, ys, _, olens = canonical_batch(a.batch)
     xs_d, ys_d = xs.to(dev), ys.to(dev)
