@@ -439,6 +439,91 @@ def training_steps_equivalence_fp32():
 
 
 @case
+def trainer_classes_run_the_same_steps():
+    """The Trainer classes (reference constructor / run / checkpoint surface) on the golden batches: ARVCTrainer reaches
+    the parameters of the hand-rolled loop after 3 steps and logs the golden first-step losses; a checkpoint round trip
+    restores model, optimiser and counters; AASVCTrainer steps with finite losses and logs the golden first-step L1."""
+    import tempfile
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd import trainers as T
+    from seq2seq_vc_amd.optim import FlatAdam
+    res = []
+    Fn.set_compute_dtype(torch.float32)
+    Fn.enable_side_streams(0)
+    try:
+        p_ref, l_ref, _, _ = _train_steps(3, 0, False)
+        cfg, z = load("vtn_tiny_train")
+        K.manual_seed(7)
+        model = M.VTN(**model_cfg(cfg))
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).train()
+        for m in model.modules():
+            if hasattr(m, "dropout_rate"):
+                m.dropout_rate = 0.0
+        opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10)
+        t = lambda k: torch.from_numpy(z[k])
+        batch = {"xs": t("in.xs"), "ilens": t("in.ilens"), "ys": t("in.ys"), "labels": t("in.labels"), "olens": t("in.olens")}
+        logs = []
+        with tempfile.TemporaryDirectory() as tmp:
+            conf = {"train_max_steps": 3, "log_interval_steps": 1, "save_interval_steps": 2, "grad_norm": 1.0, "outdir": tmp}
+            tr = T.ARVCTrainer(0, 0, {"train": [batch] * 5}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None,
+                               conf, device=DEV)
+            tr.log_fn = lambda step, d: logs.append((step, dict(d)))
+            tr.run()
+            res.append((tr.steps == 3 and len(logs) == 3, f"ARVCTrainer: {tr.steps} steps, {len(logs)} log calls"))
+            res.append(cmp("ARVCTrainer params after 3 steps vs the hand-rolled loop", opt.flat_p, p_ref.cpu(), 1e-6))
+            res.append(cmp("ARVCTrainer first logged l1 vs golden", logs[0][1]["train/l1_loss"], z["loss.l1"], 2e-5))
+            res.append(cmp("ARVCTrainer first logged bce vs golden", logs[0][1]["train/bce_loss"], z["loss.bce"], 2e-5))
+            ck = os.path.join(tmp, "checkpoint-2steps.pkl")
+            res.append((os.path.exists(ck), "checkpoint written at save_interval_steps"))
+            # resume from step 2 and take the third step again: same parameters as the uninterrupted run
+            model2 = M.VTN(**model_cfg(cfg)).to(DEV).train()
+            for m in model2.modules():
+                if hasattr(m, "dropout_rate"):
+                    m.dropout_rate = 0.0
+            opt2 = FlatAdam(model2, lr=1e-3, grad_norm=1.0, warmup_steps=10)
+            tr2 = T.ARVCTrainer(0, 0, {"train": [batch] * 5}, None, model2, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt2, None,
+                                dict(conf, save_interval_steps=10 ** 9), device=DEV)
+            tr2.load_checkpoint(ck)
+            res.append((tr2.steps == 2, f"resumed at step {tr2.steps}"))
+            tr2.run()
+            res.append(cmp("resumed trainer == uninterrupted trainer", opt2.flat_p, opt.flat_p.detach().cpu(), 1e-6))
+        # AAS-VC trainer
+        cfg, z = load("aasvc_tiny_train")
+        K.manual_seed(7)
+        model = M.AASVC(**model_cfg(cfg))
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).train()
+        for m in model.modules():
+            if hasattr(m, "dropout_rate"):
+                m.dropout_rate = 0.0
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        opt = FlatAdam(model, lr=1e-4, grad_norm=1.0, warmup_steps=10)
+        t = lambda k: torch.from_numpy(z[k])
+        model.duration_predictor.noise = t("in.sdp_noise")          # the noise draw the golden run captured
+        batch = {"xs": t("in.xs"), "ilens": t("in.ilens"), "ys": t("in.ys"), "olens": t("in.olens"), "dp_inputs": t("in.xs"),
+                 "dplens": t("in.ilens")}
+        logs = []
+        conf = {"train_max_steps": 2, "log_interval_steps": 1, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": ".",
+                "criterions": ["L1Loss", "ForwardSumLoss", "StochasticDurationPredictorLoss"], "lambda_align": 2.0,
+                "dp_train_start_steps": 0}
+        crit = {"L1Loss": L.L1Loss(), "ForwardSumLoss": L.ForwardSumLoss()}
+        tr = T.AASVCTrainer(0, 0, {"train": [batch] * 3}, None, model, None, crit, opt, None, conf, device=DEV)
+        tr.log_fn = lambda step, d: logs.append((step, dict(d)))
+        tr.run()
+        res.append((tr.steps == 2 and len(logs) == 2, f"AASVCTrainer: {tr.steps} steps, {len(logs)} log calls"))
+        res.append((all(v == v and abs(v) < 1e4 for _, d in logs for v in d.values()), f"AASVCTrainer losses finite: {logs[-1][1]}"))
+        res.append(cmp("AASVCTrainer first logged l1 vs golden", logs[0][1]["train/l1_loss"], z["loss.l1"], 1e-4))
+        res.append(cmp("AASVCTrainer first logged forward-sum vs golden", logs[0][1]["train/forward_sum_loss"], z["loss.forward_sum"], 2e-4))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
 def training_steps_memory_cut_fp32():
     """The autograd graph cut at the encoder output (decoder-side backward, then the encoder's as a second run -- the
     data-parallel step of bench.py) gives the same parameters as one backward pass."""
