@@ -148,6 +148,22 @@ int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, const void* 
 int s2svc_colreduce(int dtype, int rows, int D, int mode, const void* dy, const void* x, const float* mean,
                     const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate, float* ws,
                     int ws_chunks, void* stream);
+/* Several column reductions in two launches (stage 1, stage 2): the parameter gradients of the LayerNorm / BatchNorm /
+   bias vectors of a few consecutive layers, queued by the host during backward.  Same semantics per item as
+   s2svc_colreduce (ws >= ws_chunks*2*D floats each).  Two items of one call must not write the same out_sum / out_dot. */
+typedef struct {
+  const void* dy;
+  const void* x;
+  const float* mean;
+  const float* rstd;
+  float* out_sum;
+  float* out_dot;
+  float* ws;
+  int32_t dtype, rows, D, mode, accumulate, ws_chunks;
+  float scale;
+  int32_t reserved_;
+} s2svc_colreduce_item;
+int s2svc_colreduce_grouped(const s2svc_colreduce_item* items /* host */, int n, void* stream);
 int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean, const float* var, float* rstd,
                       float* run_mean, float* run_var, int64_t* num_batches, int var_is_ex2 /* var = E[x^2], colreduce mode 6 */,
                       void* stream);

@@ -75,6 +75,12 @@ class GemmDesc(ctypes.Structure):
                 ("cm_pt", c_i32), ("cm_pf", c_i32), ("reserved3_", c_i32)]
 
 
+class ColreduceItem(ctypes.Structure):
+    _fields_ = [("dy", c_vp), ("x", c_vp), ("mean", c_vp), ("rstd", c_vp), ("out_sum", c_vp), ("out_dot", c_vp), ("ws", c_vp),
+                ("dtype", c_i32), ("rows", c_i32), ("D", c_i32), ("mode", c_i32), ("accumulate", c_i32), ("ws_chunks", c_i32),
+                ("scale", c_f32), ("reserved_", c_i32)]
+
+
 _SIGS = {
     "s2svc_gemm": [ctypes.POINTER(GemmDesc), c_vp],
     "s2svc_gemm_grouped_ok": [c_vp],
@@ -82,6 +88,7 @@ _SIGS = {
     "s2svc_gemm_grouped": [c_vp, c_i32, c_i32, c_vp],
     "s2svc_layernorm_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_layernorm_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
+    "s2svc_colreduce_grouped": [c_vp, c_i32, c_vp],
     "s2svc_colreduce": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "s2svc_bn_finalize": [c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_rstd_from_var": [c_i32, c_f32, c_vp, c_vp, c_vp],

@@ -1,6 +1,7 @@
 // LayerNorm (fused with residual-add + dropout), BatchNorm1d over (B*T) rows, and the chunked
 // deterministic column reductions they and the bias gradients share.  All HBM-bound: one read of
 // each input, one write of each output, statistics in fp32 registers / wave shuffles.
+#include <cstring>
 #include "common.h"
 #include "../../include/s2svc_hip.h"
 
@@ -293,14 +294,12 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(int rows, int D, const 
 // stage 1 writes ws[chunk][2][D]; stage 2 sums the chunks and multiplies by `scale`.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mode, const T* __restrict__ dy,
-                                                        const T* __restrict__ x, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, float* __restrict__ ws,
-                                                        int rows_per_chunk) {
-  __shared__ float sh[2][4][64];
+__device__ __forceinline__ void colreduce_stage1_body(int rows, int D, int mode, const T* __restrict__ dy,
+                                                      const T* __restrict__ x, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, float* __restrict__ ws,
+                                                      int rows_per_chunk, int bx, int chunk, float (&sh)[2][4][64]) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const int chunk = blockIdx.y;
+  const int c = bx * 64 + cl;
   const int r0 = chunk * rows_per_chunk;
   const int r1 = (r0 + rows_per_chunk < rows) ? r0 + rows_per_chunk : rows;
   float s0 = 0.f, s1 = 0.f;
@@ -346,13 +345,22 @@ __global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mod
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mode, const T* __restrict__ dy,
+                                                        const T* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ ws,
+                                                        int rows_per_chunk) {
+  __shared__ float sh[2][4][64];
+  colreduce_stage1_body<T>(rows, D, mode, dy, x, mean, rstd, ws, rows_per_chunk, blockIdx.x, blockIdx.y, sh);
+}
+
 // 64 columns x 4 chunk-groups per workgroup: each thread sums every 4th chunk partial (independent loads), the four
 // groups are combined through LDS in a fixed order
-__global__ __launch_bounds__(256) void colreduce_stage2(int D, int chunks, const float* __restrict__ ws, float scale,
-                                                        float* __restrict__ out_sum, float* __restrict__ out_dot, int accumulate) {
-  __shared__ float sh[2][4][64];
+__device__ __forceinline__ void colreduce_stage2_body(int D, int chunks, const float* __restrict__ ws, float scale,
+                                                      float* __restrict__ out_sum, float* __restrict__ out_dot, int accumulate, int bx,
+                                                      float (&sh)[2][4][64]) {
   const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = bx * 64 + cl;
   float t0 = 0.f, t1 = 0.f;
   if (c < D) {
     for (int k = kg; k < chunks; k += 4) {
@@ -369,6 +377,41 @@ __global__ __launch_bounds__(256) void colreduce_stage2(int D, int chunks, const
     if (out_sum) out_sum[c] = (accumulate ? out_sum[c] : 0.f) + t0 * scale;
     if (out_dot) out_dot[c] = (accumulate ? out_dot[c] : 0.f) + t1 * scale;
   }
+}
+
+__global__ __launch_bounds__(256) void colreduce_stage2(int D, int chunks, const float* __restrict__ ws, float scale,
+                                                        float* __restrict__ out_sum, float* __restrict__ out_dot, int accumulate) {
+  __shared__ float sh[2][4][64];
+  colreduce_stage2_body(D, chunks, ws, scale, out_sum, out_dot, accumulate, blockIdx.x, sh);
+}
+
+// Grouped column reductions: up to S2S_CR_MAX independent reductions (the LayerNorm / bias / BatchNorm parameter
+// gradients of a few consecutive layers) in TWO launches (stage 1, stage 2) instead of two per reduction.  Items travel by
+// value in the kernel arguments; blockIdx.z selects the item, blocks outside its (column tiles, chunks) extent exit.
+#define S2S_CR_MAX 24
+struct cr_args {
+  s2svc_colreduce_item it[S2S_CR_MAX];
+  int32_t chunks[S2S_CR_MAX], rpc[S2S_CR_MAX];
+  int32_t n;
+};
+static_assert(sizeof(cr_args) <= 4096, "kernel arguments are limited to 4 KB");
+
+__global__ __launch_bounds__(256) void colreduce_grouped_stage1(const cr_args a) {
+  __shared__ float sh[2][4][64];
+  const s2svc_colreduce_item& it = a.it[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= it.D || (int)blockIdx.y >= a.chunks[blockIdx.z]) return;
+  if (it.dtype == S2S_F32)
+    colreduce_stage1_body<float>(it.rows, it.D, it.mode, (const float*)it.dy, (const float*)it.x, it.mean, it.rstd, it.ws,
+                                 a.rpc[blockIdx.z], blockIdx.x, blockIdx.y, sh);
+  else
+    colreduce_stage1_body<bf16_t>(it.rows, it.D, it.mode, (const bf16_t*)it.dy, (const bf16_t*)it.x, it.mean, it.rstd, it.ws,
+                                  a.rpc[blockIdx.z], blockIdx.x, blockIdx.y, sh);
+}
+__global__ __launch_bounds__(256) void colreduce_grouped_stage2(const cr_args a) {
+  __shared__ float sh[2][4][64];
+  const s2svc_colreduce_item& it = a.it[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= it.D) return;
+  colreduce_stage2_body(it.D, a.chunks[blockIdx.y], it.ws, it.scale, it.out_sum, it.out_dot, it.accumulate, blockIdx.x, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,6 +577,37 @@ extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void*
   hipLaunchKernelGGL(colreduce_stage2, dim3((D + 63) / 64), dim3(256), 0, st, D, chunks, ws, scale, out_sum, out_dot,
                      accumulate);
   S2S_CHECK_LAUNCH("colreduce_stage2");
+  return 0;
+}
+
+extern "C" int s2svc_colreduce_grouped(const s2svc_colreduce_item* items, int n, void* stream) {
+  S2S_REQUIRE(items && n > 0, "colreduce_grouped: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += S2S_CR_MAX) {
+    cr_args a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = (n - i0 < S2S_CR_MAX) ? n - i0 : S2S_CR_MAX;
+    int max_tiles = 1, max_chunks = 1;
+    for (int i = 0; i < a.n; ++i) {
+      const s2svc_colreduce_item& it = items[i0 + i];
+      S2S_REQUIRE(it.rows >= 0 && it.D > 0 && it.ws && it.ws_chunks > 0, "colreduce_grouped: bad item");
+      S2S_REQUIRE(it.mode >= 0 && it.mode <= 6, "colreduce_grouped: bad mode");
+      S2S_REQUIRE(it.dtype == S2S_F32 || it.dtype == S2S_BF16, "colreduce_grouped: bad dtype");
+      int chunks = (it.rows + 63) / 64;
+      if (chunks > it.ws_chunks) chunks = it.ws_chunks;
+      if (chunks < 1) chunks = 1;
+      a.it[i] = it;
+      a.chunks[i] = chunks;
+      a.rpc[i] = (it.rows + chunks - 1) / chunks;
+      const int tiles = (it.D + 63) / 64;
+      if (tiles > max_tiles) max_tiles = tiles;
+      if (chunks > max_chunks) max_chunks = chunks;
+    }
+    hipLaunchKernelGGL(colreduce_grouped_stage1, dim3(max_tiles, max_chunks, a.n), dim3(256), 0, st, a);
+    S2S_CHECK_LAUNCH("colreduce_grouped_stage1");
+    hipLaunchKernelGGL(colreduce_grouped_stage2, dim3(max_tiles, a.n), dim3(256), 0, st, a);
+    S2S_CHECK_LAUNCH("colreduce_grouped_stage2");
+  }
   return 0;
 }
 

@@ -99,6 +99,7 @@ class _Side:
     inline_q = {}    # stream handle -> (stream, [closures])
     batch = int(os.environ.get("S2SVC_SIDE_BATCH", "12"))
     grouped = []     # weight-gradient GEMM descriptors of the batch being flushed
+    grouped_cr = []  # column reductions of the batch being flushed
     group_wgrad = os.environ.get("S2SVC_NO_GROUPED_WGRAD", "0") != "1"
 
 
@@ -136,19 +137,28 @@ def _side_run(fn, keep=()):
         _side_flush()
 
 
+def _run_batch(closures):
+    """Run a batch of gradient closures on the current stream: their dense weight-gradient GEMMs become ONE grouped launch
+    (no split-K, no reduction passes), their column reductions into gradient slots (LayerNorm / BatchNorm / bias vectors)
+    two grouped launches; everything else they launch (conv weight gradients, ...) runs as issued."""
+    if not _Side.group_wgrad:
+        for fn in closures:
+            fn()
+        return
+    with K.record_grouped(_Side.grouped), K.record_colreduce(_Side.grouped_cr):
+        for fn in closures:
+            fn()
+    if _Side.grouped:
+        K.flush_grouped(_Side.grouped)
+    if _Side.grouped_cr:
+        K.flush_colreduce(_Side.grouped_cr)
+
+
 def _inline_flush(key):
     """Run the closures queued from one stream ON that stream (no fork), the dense weight gradients as a grouped launch."""
     st, q = _Side.inline_q.pop(key)
     with torch.cuda.stream(st):
-        if _Side.group_wgrad:
-            with K.record_grouped(_Side.grouped):
-                for fn in q:
-                    fn()
-            if _Side.grouped:
-                K.flush_grouped(_Side.grouped)
-        else:
-            for fn in q:
-                fn()
+        _run_batch(q)
     return st
 
 
@@ -166,17 +176,7 @@ def _side_flush():
             st.wait_stream(origin)
     _Side.origins = []
     with torch.cuda.stream(st):
-        if _Side.group_wgrad:
-            # the dense weight-gradient GEMMs of the batch become ONE grouped launch (no split-K, no reduction passes);
-            # everything else the closures launch (conv weight gradients, column reductions, ...) runs as before
-            with K.record_grouped(_Side.grouped):
-                for fn in _Side.queue:
-                    fn()
-            if _Side.grouped:
-                K.flush_grouped(_Side.grouped)
-        else:
-            for fn in _Side.queue:
-                fn()
+        _run_batch(_Side.queue)
     _Side.queue = []
 
 

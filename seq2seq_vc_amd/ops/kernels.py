@@ -221,6 +221,45 @@ class record_grouped:
         return False
 
 
+_CR_RECORDER = None         # list of (ColreduceItem, keepalive) while recording
+
+
+class record_colreduce:
+    """with record_colreduce(queue): accumulating K.colreduce(...) calls are queued instead of launched."""
+
+    def __init__(self, queue):
+        self.queue = queue
+
+    def __enter__(self):
+        global _CR_RECORDER
+        self.prev, _CR_RECORDER = _CR_RECORDER, self.queue
+        return self.queue
+
+    def __exit__(self, *exc):
+        global _CR_RECORDER
+        _CR_RECORDER = self.prev
+        return False
+
+
+def flush_colreduce(queue):
+    """Launch the queued column reductions on the current stream, two launches per <= 24 of them; reductions into the same
+    output go to successive launches.  Empties the queue."""
+    pending = list(queue)
+    del queue[:]
+    while pending:
+        seen, group, rest = set(), [], []
+        for it, keep in pending:
+            keys = {it.out_sum} | ({it.out_dot} if it.out_dot else set())
+            if keys & seen:
+                rest.append((it, keep))
+            else:
+                seen |= keys
+                group.append((it, keep))
+        pending = rest
+        arr = (_lib.ColreduceItem * len(group))(*[g[0] for g in group])
+        _lib.check(_lib.lib().s2svc_colreduce_grouped(ctypes.addressof(arr), len(group), stream()), "s2svc_colreduce_grouped")
+
+
 def flush_grouped(queue):
     """Launch every queued problem on the current stream; problems that would write the same C / a_rowsum concurrently
     go to successive launches.  Empties the queue."""
@@ -282,6 +321,15 @@ def colreduce(mode, dy, x=None, mean=None, rstd=None, scale=1.0, want_dot=False,
     t = dy if dy is not None else x
     D = t.shape[-1] if D is None else D
     rows = t.numel() // D if rows is None else rows
+    if _CR_RECORDER is not None and out_sum is not None and accumulate:
+        # parameter-gradient reduction into a flat-gradient slot: queued for the grouped launch (flush_colreduce)
+        ws = torch.empty(_WS_CHUNKS * 2 * D, dtype=torch.float32, device=t.device)
+        it = _lib.ColreduceItem()
+        it.dy, it.x, it.mean, it.rstd = ptr(dy), ptr(x), ptr(mean), ptr(rstd)
+        it.out_sum, it.out_dot, it.ws = ptr(out_sum), ptr(out_dot), ptr(ws)
+        it.dtype, it.rows, it.D, it.mode, it.accumulate, it.ws_chunks, it.scale = dt(t), rows, D, mode, 1, _WS_CHUNKS, scale
+        _CR_RECORDER.append((it, (dy, x, mean, rstd, out_sum, out_dot, ws)))
+        return out_sum, out_dot
     if out_sum is None:
         out_sum = torch.empty(D, dtype=torch.float32, device=t.device)
     if out_dot is None and want_dot:

@@ -725,6 +725,51 @@ def elementwise(dtype):
 
 
 @case
+def colreduce_grouped():
+    """Queued column reductions (parameter gradients of LayerNorm / bias / BatchNorm vectors) run as grouped launches ==
+    the same reductions launched one by one: mixed dtypes, modes, shapes, more items than one launch holds (24), and two
+    items accumulating into the same gradient (serialised)."""
+    res = []
+    items = []
+    for i in range(30):
+        dtype = torch.bfloat16 if i % 3 else torch.float32
+        rows, D = [(2016, 384), (100, 1536), (37, 80), (4096, 384), (9, 50)][i % 5]
+        mode = (0, 1, 2)[i % 3]
+        dy, x = rnd(rows, D, seed=i, dtype=dtype), rnd(rows, D, seed=100 + i, dtype=dtype)
+        mean = rnd(rows if mode == 1 else D, seed=200 + i)
+        rstd = rnd(rows if mode == 1 else D, seed=300 + i).abs() + 0.5
+        s0, d0 = rnd(D, seed=400 + i), rnd(D, seed=500 + i)
+        items.append((mode, dy, x, mean, rstd, s0, d0))
+    ref = []
+    for mode, dy, x, mean, rstd, s0, d0 in items:
+        a, b = s0.clone(), d0.clone()
+        K.colreduce(mode, dy, x if mode else None, mean if mode else None, rstd if mode else None, out_sum=a,
+                    out_dot=b if mode else None, accumulate=True)
+        ref.append((a, b))
+    outs = [(s0.clone(), d0.clone()) for _, _, _, _, _, s0, d0 in items]
+    queue = []
+    with K.record_colreduce(queue):
+        for (mode, dy, x, mean, rstd, _, _), (a, b) in zip(items, outs):
+            K.colreduce(mode, dy, x if mode else None, mean if mode else None, rstd if mode else None, out_sum=a,
+                        out_dot=b if mode else None, accumulate=True)
+        mode, dy, x, mean, rstd, _, _ = items[1]          # once more into the same outputs: a shared parameter
+        K.colreduce(mode, dy, x, mean, rstd, out_sum=outs[1][0], out_dot=outs[1][1], accumulate=True)
+        now, _ = K.colreduce(0, items[0][1])              # no output slot: not queued, result available immediately
+    res.append((len(queue) == 31, f"{len(queue)} reductions queued"))
+    res.append(check("unqueued reduction", now, items[0][1].float().sum(0), torch.float32, rtol=1e-4, atol=1e-2))
+    res.append((bool(torch.equal(outs[0][0], items[0][5])), "nothing is written before the flush"))
+    K.flush_colreduce(queue)
+    for i, ((a, b), (ra, rb)) in enumerate(zip(outs, ref)):
+        if i == 1:
+            ra, rb = 2 * ra - items[1][5], 2 * rb - items[1][6]
+        tol = dict(rtol=1e-5, atol=1e-3 if i == 1 else 1e-5)
+        res.append(check(f"grouped colreduce #{i} sum", a, ra, torch.float32, **tol))
+        if items[i][0]:
+            res.append(check(f"grouped colreduce #{i} dot", b, rb, torch.float32, **tol))
+    return res
+
+
+@case
 def transposed_weight_copies():
     """s2svc_transpose_tiles: every matrix of a table transposed in one launch (64x64 tiles; 16-byte path and the
     element-wise path for extents / offsets that are not multiples of 8), bit-exact."""
