@@ -489,6 +489,30 @@ def trainer_classes_run_the_same_steps():
             res.append((tr2.steps == 2, f"resumed at step {tr2.steps}"))
             tr2.run()
             res.append(cmp("resumed trainer == uninterrupted trainer", opt2.flat_p, opt.flat_p.detach().cpu(), 1e-6))
+        # TTS trainer: the collater yields a tuple (trainers/ar_tts.py:45-100)
+        cfg, z = load("tts_tiny_train")
+        K.manual_seed(7)
+        model = M.TransformerTTS(**model_cfg(cfg))
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).train()
+        for m in model.modules():
+            if hasattr(m, "dropout_rate"):
+                m.dropout_rate = 0.0
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        opt = FlatAdam(model, lr=1e-4, grad_norm=1.0, warmup_steps=10)
+        t = lambda k: torch.from_numpy(z[k])
+        tup = (t("in.xs"), t("in.ilens"), t("in.ys"), t("in.labels"), t("in.olens"))
+        logs = []
+        conf = {"train_max_steps": 2, "log_interval_steps": 1, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": "."}
+        tr = T.ARTTSTrainer(0, 0, {"train": [tup] * 3}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None, conf,
+                            device=DEV)
+        tr.log_fn = lambda step, d: logs.append((step, dict(d)))
+        tr.run()
+        res.append((tr.steps == 2 and len(logs) == 2, f"ARTTSTrainer: {tr.steps} steps, {len(logs)} log calls"))
+        res.append(cmp("ARTTSTrainer first logged l1 vs golden", logs[0][1]["train/l1_loss"], z["loss.l1"], 2e-5))
+        res.append(cmp("ARTTSTrainer first logged bce vs golden", logs[0][1]["train/bce_loss"], z["loss.bce"], 2e-5))
+        res.append((logs[1][1]["train/loss"] < logs[0][1]["train/loss"] + 1e-3, f"ARTTSTrainer loss after one update: {logs[0][1]['train/loss']:.4f} -> {logs[1][1]['train/loss']:.4f}"))
         # AAS-VC trainer
         cfg, z = load("aasvc_tiny_train")
         K.manual_seed(7)
