@@ -439,6 +439,65 @@ def training_steps_equivalence_fp32():
 
 
 @case
+def vtn_ragged_batches_vs_oracle_fp32():
+    """Shapes the golden fixtures do not have, against the CPU oracle on fresh seeded inputs: a single utterance, lengths
+    that leave one encoder frame / one decoder step, lengths that are not multiples of the subsampling (4) or the reduction
+    factor, and a batch whose longest utterance is shorter than the padded tensor.  Forward, losses and every parameter
+    gradient (fp32)."""
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    cfg, z = load("vtn_tiny_train")
+    mc = model_cfg(cfg)
+    r = mc.get("decoder_reduction_factor", 1)
+    res = []
+    Fn.set_compute_dtype(torch.float32)
+    for ci, (ilens, olens, tpad, lpad) in enumerate([([23], [3 * r + 1], 23, 3 * r + 1), ([7, 31, 12], [r, 5 * r + 1, 2 * r], 31, 5 * r + 1),
+                                                 ([40, 33], [4 * r, 7 * r + r - 1], 48, 9 * r), ([8, 9, 10, 11], [r + 1] * 4, 11, r + 1)]):
+        g = torch.Generator().manual_seed(50 + ci)
+        B = len(ilens)
+        xs = torch.randn(B, tpad, mc["idim"], generator=g)
+        ys = torch.randn(B, lpad, mc["odim"], generator=g)
+        il, ol = torch.tensor(ilens), torch.tensor(olens)
+        ar_t, ar_l = torch.arange(tpad)[None], torch.arange(lpad)[None]
+        xs[ar_t >= il[:, None]] = 0.0
+        ys[ar_l >= ol[:, None]] = 0.0
+        labels = (ar_l >= (ol[:, None] - 1)).float()
+        model = M.VTN(**mc)
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).train()
+        for m in model.modules():
+            if hasattr(m, "dropout_rate"):
+                m.dropout_rate = 0.0
+        sd = {k: v.clone() for k, v in sd_of(z).items()}
+        names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+        for k in names:
+            sd[k].requires_grad_(True)
+        o = OM.vtn_forward(sd, mc, xs, il, ys, labels, ol, training=True, drop=False)
+        l1r, bcer = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+        gr = torch.autograd.grad(l1r + bcer, [sd[k] for k in names], allow_unused=True)
+        out = model(xs.to(DEV), il, ys.to(DEV), labels.to(DEV), ol)
+        l1, bce = L.Seq2SeqLoss(10.0)(out[0], out[1], out[2], out[3], out[4], out[5])
+        (l1 + bce).backward()
+        tag = f"ragged case {ci} ilens={ilens} olens={olens}"
+        res.append(cmp(f"{tag} after_outs", out[0], o[0].detach(), 4e-4, l1_tol=1e-4))
+        res.append(cmp(f"{tag} logits", out[2], o[2].detach(), 1e-4))
+        res.append(cmp(f"{tag} olens", out[5], o[5], 0))
+        res.append(cmp(f"{tag} l1", l1, l1r.detach(), 2e-5))
+        res.append(cmp(f"{tag} bce", bce, bcer.detach(), 2e-5))
+        got = dict(model.named_parameters())
+        worst, wname = 0.0, ""
+        for k, gk in zip(names, gr):
+            ref = gk if gk is not None else torch.zeros_like(sd[k])
+            mine = got[k].grad if got[k].grad is not None else torch.zeros_like(got[k])
+            e = (mine.detach().cpu() - ref).abs().max().item() / (1.0 + ref.abs().max().item())
+            if e > worst:
+                worst, wname = e, k
+        res.append((worst < 2e-4, f"{tag}: worst parameter-gradient error {worst:.2e} ({wname})"))
+    return res
+
+
+@case
 def trainer_classes_run_the_same_steps():
     """The Trainer classes (reference constructor / run / checkpoint surface) on the golden batches: ARVCTrainer reaches
     the parameters of the hand-rolled loop after 3 steps and logs the golden first-step losses; a checkpoint round trip
