@@ -498,6 +498,54 @@ def vtn_ragged_batches_vs_oracle_fp32():
 
 
 @case
+def aasvc_ragged_batches_vs_oracle_fp32():
+    """AAS-VC on fresh seeded batches the golden fixtures do not have (single utterance; very unequal lengths; source longer
+    than needed by the target; over-padded tensors) against the CPU oracle with the same injected flow noise: alignment
+    paths / durations bit-exact, log_p_attn, mel outputs, L1 / forward-sum / duration NLL."""
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    cfg, z = load("aasvc_tiny_train")
+    mc = model_cfg(cfg)
+    res = []
+    Fn.set_compute_dtype(torch.float32)
+    for ci, (ilens, olens, tpad, lpad) in enumerate([([44], [29], 44, 29), ([24, 80, 52], [15, 41, 30], 80, 41), ([36, 37], [40, 12], 56, 44)]):
+        g = torch.Generator().manual_seed(70 + ci)
+        B = len(ilens)
+        xs = torch.randn(B, tpad, mc["idim"], generator=g)
+        ys = torch.randn(B, lpad, mc["odim"], generator=g)
+        il, ol = torch.tensor(ilens), torch.tensor(olens)
+        xs[torch.arange(tpad)[None] >= il[:, None]] = 0.0
+        ys[torch.arange(lpad)[None] >= ol[:, None]] = 0.0
+        red = mc.get("encoder_reduction_factor", 1) * mc.get("post_encoder_reduction_factor", 1)
+        noise = torch.randn(B, 2, max(ilens) // red, generator=g)                       # (B, 2, T_text)
+        model = M.AASVC(**mc)
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).train()
+        for m in model.modules():
+            if hasattr(m, "dropout_rate"):
+                m.dropout_rate = 0.0
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        model.duration_predictor.noise = noise
+        with torch.no_grad():
+            r = OM.aasvc_forward(sd_of(z), mc, xs, il, ys, ol, dp_inputs=xs, noise=noise)
+            ret = model(xs.to(DEV), il, ys.to(DEV), ol, xs.to(DEV), dp_lengths=il)
+        tag = f"aasvc ragged case {ci} ilens={ilens} olens={olens}"
+        res.append(cmp(f"{tag} durations (bit-exact)", ret["ds"], r["ds"], 0))
+        res.append(cmp(f"{tag} log_p_attn", ret["log_p_attn"], r["log_p_attn"], 2e-4))
+        res.append(cmp(f"{tag} before_outs", ret["before_outs"], r["before_outs"], 2e-4, l1_tol=1e-4))
+        res.append(cmp(f"{tag} after_outs", ret["after_outs"], r["after_outs"], 8e-4, l1_tol=1e-4))
+        res.append(cmp(f"{tag} bin_loss", ret["bin_loss"], r["bin_loss"], 2e-5))
+        res.append(cmp(f"{tag} dur_nll", ret["dur_nll"], r["dur_nll"], 5e-4, rtol=1e-4))
+        l1 = L.L1Loss()(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+        fs = L.ForwardSumLoss()(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+        res.append(cmp(f"{tag} l1", l1, OM.l1_loss(r["after_outs"], r["before_outs"], r["ys"], r["olens"]), 2e-5))
+        res.append(cmp(f"{tag} forward_sum", fs, OM.forward_sum_loss(r["log_p_attn"], r["ilens"], r["olens_reduced"]), 1e-4))
+    return res
+
+
+@case
 def trainer_classes_run_the_same_steps():
     """The Trainer classes (reference constructor / run / checkpoint surface) on the golden batches: ARVCTrainer reaches
     the parameters of the hand-rolled loop after 3 steps and logs the golden first-step losses; a checkpoint round trip
