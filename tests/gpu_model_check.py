@@ -439,6 +439,66 @@ def training_steps_equivalence_fp32():
 
 
 @case
+def vtn_full_size_properties():
+    """BASELINE.json configs[1] itself (VTN vc1: 30.5 M parameters, 32 utterance pairs of 256 frames -- bench.py's
+    workload): (a) fp32 forward losses vs the CPU oracle at full size; (b) bf16 forward+backward twice with the same seeds
+    -> bit-identical losses and gradients (side streams, grouped launches and all); (c) backward is linear in the loss
+    scale: gradients of 2 x loss are exactly 2 x the gradients; (d) bf16 losses close to fp32."""
+    import bench
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.optim import FlatAdam
+    res = []
+    xs, ilens, ys, labels, olens = bench.canonical_batch(32)
+    try:
+        def build(dtype):
+            Fn.set_compute_dtype(dtype)
+            torch.manual_seed(0)
+            model = M.VTN(**bench.VTN_VC1).to(DEV).train()
+            return model, FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=(dtype == torch.bfloat16))
+
+        def fwd_bwd(model, opt, scale=1.0, p_drop=None):
+            if p_drop is not None:
+                for m in model.modules():
+                    if hasattr(m, "dropout_rate"):
+                        m.dropout_rate = p_drop
+            K.manual_seed(99)
+            K.reset_op_counter()
+            opt.zero_grad()
+            o = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+            l1, bce = L.Seq2SeqLoss(10.0)(o[0], o[1], o[2], o[3], o[4], o[5])
+            ((l1 + bce) * scale).backward()
+            Fn.side_join()
+            return float(l1), float(bce), opt.flat_g.clone()
+
+        Fn.enable_side_streams(4)
+        model, opt = build(torch.float32)
+        l1f, bcef, _ = fwd_bwd(model, opt, p_drop=0.0)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            o = OM.vtn_forward(sd, bench.VTN_VC1, xs, ilens, ys, labels, olens, training=True, drop=False)
+            l1r, bcer = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+        res.append(cmp("full-size fp32 l1 vs CPU oracle", l1f, l1r, 2e-4))
+        res.append(cmp("full-size fp32 bce vs CPU oracle", bcef, bcer, 2e-4))
+        del model, opt
+        model, opt = build(torch.bfloat16)
+        a = fwd_bwd(model, opt)                       # train-mode dropout on: the masks are functions of (seed, index)
+        b = fwd_bwd(model, opt)
+        res.append((a[0] == b[0] and a[1] == b[1] and bool(torch.equal(a[2], b[2])), f"full-size bf16 step is reproducible bit for bit (l1 {a[0]:.6f})"))
+        c = fwd_bwd(model, opt, scale=2.0)
+        res.append((bool(torch.equal(c[2], 2 * a[2])), "gradients of 2 x loss == 2 x gradients (exact)"))
+        d = fwd_bwd(model, opt, p_drop=0.0)
+        res.append((abs(d[0] - l1f) < 2e-2 and abs(d[1] - bcef) < 2e-2, f"bf16 vs fp32 losses: l1 {d[0]:.4f} / {l1f:.4f}, bce {d[1]:.4f} / {bcef:.4f}"))
+        gn = float(a[2].double().pow(2).sum().sqrt())
+        res.append((gn == gn and 0 < gn < 1e4, f"full-size gradient norm {gn:.3f} finite"))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
 def vtn_ragged_batches_vs_oracle_fp32():
     """Shapes the golden fixtures do not have, against the CPU oracle on fresh seeded inputs: a single utterance, lengths
     that leave one encoder frame / one decoder step, lengths that are not multiples of the subsampling (4) or the reduction
