@@ -40,7 +40,13 @@ def build_library(force=False, verbose=True):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
                 and os.path.getmtime(obj) >= hdr_time):
             return obj
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-c", src, "-o", obj]
+        # -fno-slp-vectorize: no compiler-formed packed-fp32 (v_pk_fma_f32 / v_pk_mul_f32 with op_sel operand swizzles).
+        # With them the spline-gradient kernel of the duration predictor returned, a few times per thousand launches and
+        # only while another stream kept the chip busy, a wrong element in the last partially active 16-lane row of a wave
+        # (same inputs, different output); without them 0 of 800 full AAS-VC steps differ ("Reproducibility").
+        # The step times are unchanged (the arithmetic that matters is MFMA and explicit 16-byte memory operations).
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize",
+               "-c", src, "-o", obj]
         if verbose:
             print("[s2svc build]", " ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

@@ -499,6 +499,57 @@ def vtn_full_size_properties():
 
 
 @case
+def aasvc_full_size_step_is_reproducible():
+    """AAS-VC vc2 at its recipe size (157 M parameters, 16 utterance pairs) in the shipped training configuration --
+    duration predictor on the auxiliary stream, parameter-gradient work in grouped inline batches: 60 forward+backward
+    passes with the same seeds and injected flow noise give bit-identical outputs and gradients.  (This is the guard for
+    the packed-fp32 code-generation problem described in DESIGN.md "Reproducibility": before -fno-slp-vectorize about
+    1 step in 40 had a wrong row in one flow-projection gradient.)"""
+    import bench
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.optim import FlatAdam
+    from tools.bench_aasvc import AASVC_VC2
+    res = []
+    xs, ilens, ys, _, olens = bench.canonical_batch(16)
+    xs_d, ys_d = xs.to(DEV), ys.to(DEV)
+    try:
+        Fn.set_compute_dtype(torch.bfloat16)
+        Fn.enable_side_streams(0, inline_batches=True)
+        torch.manual_seed(0)
+        model = M.AASVC(**AASVC_VC2).to(DEV).train()
+        opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=True)
+        noise = torch.randn(16, 2, 64, generator=torch.Generator().manual_seed(5))
+
+        def fwd_bwd():
+            model.duration_predictor.noise = noise
+            K.manual_seed(1234)
+            K.reset_op_counter()
+            opt.zero_grad()
+            ret = model(xs_d, ilens, ys_d, olens, xs_d, dp_lengths=ilens)
+            l1 = L.L1Loss()(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+            fs = L.ForwardSumLoss()(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+            dur = torch.sum(ret["dur_nll"].float())
+            (l1 + 2.0 * (fs + ret["bin_loss"]) + dur).backward()
+            Fn.side_join()
+            torch.cuda.synchronize()
+            return torch.stack([l1.detach().float(), fs.detach().float(), dur.detach().float()]), opt.flat_g.clone()
+
+        l0, g0 = fwd_bwd()
+        bad = 0
+        for _ in range(60):
+            l, g = fwd_bwd()
+            bad += 0 if (torch.equal(l, l0) and torch.equal(g, g0)) else 1
+        res.append((bad == 0, f"AAS-VC vc2 bf16 step: {bad} of 60 repeats differ from the first (losses {l0.tolist()})"))
+        gn = float(g0.double().pow(2).sum().sqrt())
+        res.append((gn == gn and 0 < gn < 1e5, f"AAS-VC vc2 gradient norm {gn:.3f} finite"))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
 def vtn_ragged_batches_vs_oracle_fp32():
     """Shapes the golden fixtures do not have, against the CPU oracle on fresh seeded inputs: a single utterance, lengths
     that leave one encoder frame / one decoder step, lengths that are not multiples of the subsampling (4) or the reduction
