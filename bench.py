@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--split-backward", action="store_true",
                     help="N = 1: run the two-graph step of the data-parallel path (autograd cut at the encoder output) without collectives")
     ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code path (RCCL process group, split backward, overlapped all-reduce) at world size 1")
     ap.add_argument("--side-streams", type=int, default=4, help="HIP side streams for parameter-gradient kernels (0 = off)")
     args = ap.parse_args()
 
@@ -171,9 +173,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    dp = world > 1 or args.force_dist          # the data-parallel code path (also reachable at world size 1 for testing)
+    if dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     from seq2seq_vc_amd import losses as L
@@ -225,7 +231,7 @@ def main():
     # side backward; its gradients (one contiguous range of the flat buffer) start their all-reduce while graph 2, the
     # encoder's backward, runs.  The loss carries the 1/world of the mean, so the collectives are plain sums.
     enc_range = opt.param_range(model.encoder)
-    split = (world > 1 or args.split_backward) and enc_range is not None and enc_range[0] == 0
+    split = (dp or args.split_backward) and enc_range is not None and enc_range[0] == 0
     gscale = 1.0 / world
     cut = {}
 
@@ -236,7 +242,7 @@ def main():
         cut.clear()
         after, before, logits, ys_, labels_, olens_, _ = model(xs_d, ilens, ys_d, labels_d, olens, _memory_cut=cut)
         l1, bce = crit(after, before, logits, ys_, labels_, olens_)
-        ((l1 + bce) * gscale if world > 1 else (l1 + bce)).backward()
+        ((l1 + bce) * gscale if dp else (l1 + bce)).backward()
         loss_buf[0].copy_(l1.detach())
         loss_buf[1].copy_(bce.detach())
         Fn.side_join()
@@ -247,7 +253,7 @@ def main():
 
     def reduce_begin(part):      # part 0: everything behind the encoder's parameters, part 1: the encoder's
         lo, hi = (enc_range[1], opt.numel) if part == 0 else enc_range
-        return allreduce_sum_begin(opt.flat_g[lo:hi], dist, world)
+        return allreduce_sum_begin(opt.flat_g[lo:hi], dist, world, force=args.force_dist)
 
     def step_eager():
         if split:
@@ -258,8 +264,8 @@ def main():
             allreduce_end(h)
         else:
             fwd_bwd()
-            if world > 1:
-                allreduce_mean_(opt.flat_g, dist, world)
+            if dp:
+                allreduce_mean_(opt.flat_g, dist, world, force=args.force_dist)
         opt.step()
 
     # warm-up (eager, on a side stream so that a later capture sees a quiet default stream)
@@ -303,15 +309,15 @@ def main():
             g_opt.replay()
         else:
             g_fb.replay()
-            if world > 1:
-                allreduce_mean_(opt.flat_g, dist, world)
+            if dp:
+                allreduce_mean_(opt.flat_g, dist, world, force=args.force_dist)
             g_opt.replay()
 
     for _ in range(args.warmup):
         step()
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
     barrier()
     torch.cuda.synchronize()
@@ -321,7 +327,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         tt = torch.tensor([dt], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -354,8 +360,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cpu_batch)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if world > 1:
+        # RCCL writes its version banner to the C-level stdout; flush that buffer first so the JSON line stays the last line
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
+    if dp:
         dist.destroy_process_group()
 
 

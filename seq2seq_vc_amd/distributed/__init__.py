@@ -26,9 +26,10 @@ def init_from_env(backend=None):
     return dist, dist.get_rank(), dist.get_world_size()
 
 
-def allreduce_mean_(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None):
-    """In-place mean all-reduce of a flat buffer in large chunks (works on cuda/RCCL and cpu/gloo)."""
-    if world <= 1:
+def allreduce_mean_(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None, force=False):
+    """In-place mean all-reduce of a flat buffer in large chunks (works on cuda/RCCL and cpu/gloo).
+    force: issue the collectives even at world size 1 (exercises the backend on a single device)."""
+    if world <= 1 and not force:
         return flat
     n = flat.numel()
     handles = []
@@ -40,10 +41,10 @@ def allreduce_mean_(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None)
     return flat
 
 
-def allreduce_sum_begin(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None):
+def allreduce_sum_begin(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None, force=False):
     """Start the in-place SUM all-reduce of a flat buffer (or a slice of one) and return the pending handles: the
     collectives run on the backend's own stream while the caller keeps launching compute; allreduce_end() joins."""
-    if world <= 1:
+    if world <= 1 and not force:
         return []
     return [dist.all_reduce(flat[o:o + chunk_numel], op=dist.ReduceOp.SUM, group=group, async_op=True)
             for o in range(0, flat.numel(), chunk_numel)]
