@@ -62,15 +62,31 @@ struct KcStage {
   int trow[NI];                   // conv1d: frame index of the row ; tconv2d: class-grid row i
   int tcol[NI];                   // tconv2d: class-grid column j
   int piece8;                     // 8 * source piece of this lane (the same for every row group, see init)
+  // Scalar-base path (dense and conv2d rows; full k tiles; C % BKT == 0; operand below 4 GiB): the lane-dependent part of
+  // every source address is a 32-bit byte offset fixed at init (rows past the matrix clamp to its last row -- their
+  // products only reach C rows / columns that are never stored), the k-dependent part is ONE scalar added to the uniform
+  // base, so the DMA instructions take the SGPR-base + VGPR-offset form and the k loop spends no VALU work on addresses.
+  static constexpr bool SCALAR_KIND = (KIND == G_KC_DENSE || KIND == G_KC_CONV2D);
+  uint32_t rowoff[NI];
+  bool scalar_ok;                 // uniform
+  int st_k0, st_c0, st_kh, st_kw; // conv2d: the (tap, channel) position of k tile st_k0, walked without divisions
   __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    scalar_ok = false;
+    st_k0 = -1; st_c0 = 0; st_kh = 0; st_kw = 0;
+    if (SCALAR_KIND) {
+      const int64_t elems = KIND == G_KC_DENSE ? (int64_t)R * o.ld
+                                               : (int64_t)(R / (o.T2 * o.F2) + 1) * o.T1 * o.F1 * o.ld;
+      scalar_ok = elems * 2 < (1ll << 32) && R > 0 && (KIND == G_KC_DENSE || o.C % BKT == 0);
+    }
     // rows of group g = 4i + wave: rl = g*RPI + lane/PIECES ; the swizzle term of rl does not depend on i
     // (BKT 64: ((g&1)*4 + (lane>>4)) & 7 with g&1 == wave&1 ; BKT 32: (-(lane>>4)) & 3)
     piece8 = ((lane % PIECES) ^ swz_of<BKT>(wave * RPI + lane / PIECES)) << 3;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int rl = (i * 4 + wave) * RPI + lane / PIECES;
-      const int r = r0 + rl;
+      const int rr = r0 + rl;
+      const int r = (SCALAR_KIND && rr >= R) ? R - 1 : rr;     // (the other kinds mark the row invalid below)
       trow[i] = 0;
       tcol[i] = 0;
       if (KIND == G_KC_TCONV2D) {       // class grid (o.T1 x o.F1) -> output-gradient pixel (i, j) of the (B, T2, F2, C) tensor
@@ -89,11 +105,35 @@ struct KcStage {
         const int t2 = bt % o.T2, b = bt / o.T2;
         rowbase[i] = ((int64_t)(b * o.T1 + 2 * t2) * o.F1 + 2 * f2) * o.ld;
       }
-      if (r >= R) rowbase[i] = -1;
+      rowoff[i] = (uint32_t)((rowbase[i] + piece8) * 2);
+      if (rr >= R) rowbase[i] = -1;
     }
   }
-  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int k0, int K, char* lds) const {
-    const int wave = threadIdx.x >> 6;
+  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int k0, int K, char* lds) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: the LDS destinations (M0) stay on the SALU
+    if (SCALAR_KIND && scalar_ok && k0 + BKT <= K) {
+      int64_t koff = k0;
+      if (KIND == G_KC_CONV2D) {
+        if (k0 != st_k0) {                      // (first tile of this workgroup's k range)
+          const int tap = k0 / o.C;
+          st_c0 = k0 - tap * o.C;
+          st_kh = tap / 3;
+          st_kw = tap - st_kh * 3;
+        }
+        koff = (int64_t)(st_kh * o.F1 + st_kw) * o.ld + st_c0;
+        st_k0 = k0 + BKT;
+        st_c0 += BKT;
+        if (st_c0 >= o.C) {
+          st_c0 = 0;
+          if (++st_kw == 3) { st_kw = 0; ++st_kh; }
+        }
+      }
+      const char* sbase = reinterpret_cast<const char*>(base + koff);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(sbase + rowoff[i]), (lds_void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
+      return;
+    }
     const uint64_t zaddr = zero_addr();
     const int k = k0 + piece8;
     const bool kin = k < K;
@@ -240,9 +280,87 @@ struct TrStage {
   static constexpr int SUB = ROWS / 16;             // subtiles per k-half
   static constexpr int NI = 2 * SUB / 4;            // DMA instructions per wave and tile
   static_assert(NI >= 1, "tile too small for 4 waves");
-  __device__ __forceinline__ void init(const s2svc_operand&, int, int) {}
-  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int r0, int R, int k0, int K, char* lds) const {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Scalar-base path (dense and conv2d; full k tiles; operand below 4 GiB), as in KcStage: the lane's part of every
+  // source address is a 32-bit byte offset -- fixed at init for a dense operand; for conv2d the (tap, channel) part is
+  // fixed and the lane's two output pixels (one per k half) are walked from k tile to k tile with two compares instead of
+  // two divisions per DMA instruction.  Rows past the matrix clamp to its last 16-byte piece (their products only reach
+  // C rows / columns that are never stored).
+  static constexpr bool SCALAR_KIND = (KIND == G_TR_DENSE || KIND == G_TR_CONV2D);
+  uint32_t laneoff[NI];
+  int st_k0;
+  int pf2[2], pt2[2];
+  uint32_t poff[2];
+  __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) {
+    st_k0 = -1;
+    if (!SCALAR_KIND) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int sidx = i * 4 + wave;
+      const int kh = sidx / SUB, mt = sidx - kh * SUB;
+      int r = r0 + mt * 16 + (lane & 1) * 8;
+      if (r > R - 8) r = R - 8 > 0 ? R - 8 : 0;
+      if (KIND == G_TR_DENSE) {
+        laneoff[i] = (uint32_t)(((int64_t)(kh * 32 + (lane >> 1)) * o.ld + r) * 2);
+      } else {
+        const int tap = r / o.C, c = r - tap * o.C;
+        const int kh3 = tap / 3, kw = tap - kh3 * 3;
+        laneoff[i] = (uint32_t)(((int64_t)(kh3 * o.F1 + kw) * o.ld + c) * 2);
+      }
+    }
+    pf2[0] = pf2[1] = pt2[0] = pt2[1] = 0;
+    poff[0] = poff[1] = 0u;
+  }
+  __device__ __forceinline__ bool scalar_ok(const s2svc_operand& o, int R, int K) const {      // uniform
+    if (!SCALAR_KIND || R < 8) return false;
+    if (KIND == G_TR_DENSE) return (int64_t)K * o.ld * 2 < (1ll << 32);
+    const int64_t elems = (int64_t)(K / (o.T2 * o.F2) + 1) * o.T1 * o.F1 * o.ld;
+    return elems * 2 < (1ll << 32) && 64 / o.F2 + 1 <= o.T2;
+  }
+  __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int r0, int R, int k0, int K, char* lds) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (SCALAR_KIND && k0 + 64 <= K && scalar_ok(o, R, K)) {
+      if (KIND == G_TR_DENSE) {
+        const char* sbase = reinterpret_cast<const char*>(base + (int64_t)k0 * o.ld);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          __builtin_amdgcn_global_load_lds((gbl_void*)(sbase + laneoff[i]), (lds_void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
+        return;
+      }
+      if (k0 != st_k0) {                        // first tile of this workgroup's k range: place the two pixels
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = k0 + h * 32 + (lane >> 1);
+          const int bt = k / o.F2;
+          pf2[h] = k - bt * o.F2;
+          const int b = bt / o.T2;
+          pt2[h] = bt - b * o.T2;
+          poff[h] = (uint32_t)(((int64_t)(b * o.T1 + 2 * pt2[h]) * o.F1 + 2 * pf2[h]) * o.ld * 2);
+        }
+      }
+      const char* sbase = reinterpret_cast<const char*>(base);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int kh = (i * 4 + wave) / SUB;     // (uniform; a compile-time constant unless the tile has < 64 rows)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(sbase + (uint32_t)((kh ? poff[1] : poff[0]) + laneoff[i])),
+                                         (lds_void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
+      }
+      // next k tile: every pixel index grows by 64 = q * F2 + rem
+      const int q = 64 / o.F2, rem = 64 - q * o.F2;
+      const uint32_t step = (uint32_t)((int64_t)(2 * rem + 2 * q * o.F1) * o.ld * 2);
+      const uint32_t wrapf = (uint32_t)((int64_t)(2 * o.F1 - 2 * o.F2) * o.ld * 2);
+      const uint32_t wrapt = (uint32_t)((int64_t)(o.T1 - 2 * o.T2) * o.F1 * o.ld * 2);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        pf2[h] += rem;
+        pt2[h] += q;
+        poff[h] += step;
+        if (pf2[h] >= o.F2) { pf2[h] -= o.F2; pt2[h] += 1; poff[h] += wrapf; }
+        if (pt2[h] >= o.T2) { pt2[h] -= o.T2; poff[h] += wrapt; }
+      }
+      st_k0 = k0 + 64;
+      return;
+    }
     const uint64_t zaddr = zero_addr();
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
