@@ -67,9 +67,13 @@ struct KcStage {
   // products only reach C rows / columns that are never stored), the k-dependent part is ONE scalar added to the uniform
   // base, so the DMA instructions take the SGPR-base + VGPR-offset form and the k loop spends no VALU work on addresses.
   static constexpr bool SCALAR_KIND = (KIND == G_KC_DENSE || KIND == G_KC_CONV2D);
+  // The transposed-convolution rows (tconv2d) take the same scalar walk over (tap, channel); which of the <= 2 x 2 taps of
+  // the parity class fall inside the output-gradient image is a 4-bit mask per row fixed at init, so a DMA instruction
+  // costs one 64-bit add, one mask test and the select of the zero block.
   uint32_t rowoff[NI];
+  int vmask[NI];                  // tconv2d: bit (2 * ta + fb) = tap (ta, fb) of this row reads inside the image
   bool scalar_ok;                 // uniform
-  int st_k0, st_c0, st_kh, st_kw; // conv2d: the (tap, channel) position of k tile st_k0, walked without divisions
+  int st_k0, st_c0, st_kh, st_kw; // conv2d / tconv2d: the (tap, channel) position of k tile st_k0, walked without divisions
   __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     scalar_ok = false;
@@ -78,6 +82,10 @@ struct KcStage {
       const int64_t elems = KIND == G_KC_DENSE ? (int64_t)R * o.ld
                                                : (int64_t)(R / (o.T2 * o.F2) + 1) * o.T1 * o.F1 * o.ld;
       scalar_ok = elems * 2 < (1ll << 32) && R > 0 && (KIND == G_KC_DENSE || o.C % BKT == 0);
+    }
+    if (KIND == G_KC_TCONV2D) {
+      const int64_t elems = (int64_t)(R / (o.T1 * o.F1) + 1) * o.T2 * o.F2 * o.ld;
+      scalar_ok = elems * 2 < (1ll << 32) && o.C % BKT == 0;
     }
     // rows of group g = 4i + wave: rl = g*RPI + lane/PIECES ; the swizzle term of rl does not depend on i
     // (BKT 64: ((g&1)*4 + (lane>>4)) & 7 with g&1 == wave&1 ; BKT 32: (-(lane>>4)) & 3)
@@ -89,12 +97,22 @@ struct KcStage {
       const int r = (SCALAR_KIND && rr >= R) ? R - 1 : rr;     // (the other kinds mark the row invalid below)
       trow[i] = 0;
       tcol[i] = 0;
+      vmask[i] = 0;
       if (KIND == G_KC_TCONV2D) {       // class grid (o.T1 x o.F1) -> output-gradient pixel (i, j) of the (B, T2, F2, C) tensor
         const int per_b = o.T1 * o.F1;
         const int b = r / per_b, rem = r - b * per_b;
         trow[i] = rem / o.F1;
         tcol[i] = rem - trow[i] * o.F1;
         rowbase[i] = ((int64_t)(b * o.T2 + trow[i]) * o.F2 + tcol[i]) * o.ld;
+        int m = 0;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+          for (int fb = 0; fb < 2; ++fb) {
+            const int ti = trow[i] - ta, tj = tcol[i] - fb;
+            if (rr < R && ti >= 0 && ti < o.T2 && tj >= 0 && tj < o.F2) m |= 1 << (2 * ta + fb);
+          }
+        vmask[i] = m;
       } else if (KIND == G_KC_DENSE) {
         rowbase[i] = (int64_t)r * o.ld;
       } else if (KIND == G_KC_CONV1D) {
@@ -135,6 +153,30 @@ struct KcStage {
       return;
     }
     const uint64_t zaddr = zero_addr();
+    if (KIND == G_KC_TCONV2D && scalar_ok && k0 + BKT <= K) {
+      const int nf = 2 - (o.pad & 1);                       // taps along f of this parity class
+      if (k0 != st_k0) {
+        const int tap = k0 / o.C;
+        st_c0 = k0 - tap * o.C;
+        st_kh = tap / nf;
+        st_kw = tap - st_kh * nf;
+      }
+      const int64_t koff = -(int64_t)(st_kh * o.F2 + st_kw) * o.ld + st_c0;
+      const int bit = 1 << (2 * st_kh + st_kw);
+      st_k0 = k0 + BKT;
+      st_c0 += BKT;
+      if (st_c0 >= o.C) {
+        st_c0 = 0;
+        if (++st_kw == nf) { st_kw = 0; ++st_kh; }
+      }
+      const char* sbase = reinterpret_cast<const char*>(base + koff);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint64_t src = (vmask[i] & bit) ? reinterpret_cast<uint64_t>(sbase + rowoff[i]) : zaddr;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
+      }
+      return;
+    }
     const int k = k0 + piece8;
     const bool kin = k < K;
     int64_t koff = k;             // element offset added to the row base

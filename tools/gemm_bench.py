@@ -123,6 +123,18 @@ def main():
         line("dgrad vtn conv2d dcols = dY.Wp", M, 9 * C, O,
              bench(lambda: K.gemm(K.operand(dy, O), K.operand(w, 9 * C, layout=K.RC), M, 9 * C, O, dcols, in_dtype=dtype), a.iters))
         line("dgrad vtn conv2d col2im (us only)", 0, 0, 0, bench(lambda: K.col2im_s2(dcols, B, T1, F1, C, T2, F2), a.iters))
+        if dtype == torch.bfloat16:
+            w4 = (rnd(O, C, 3, 3) * 0.02).float()
+            wts = K.tconv2d_weights(w4)
+            dx = torch.empty(B, T1, F1, C, dtype=dtype, device=dev)
+
+            def tconv():
+                for cls, wt in enumerate(wts):
+                    pt, pf = cls >> 1, cls & 1
+                    Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
+                    K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, wt.shape[1]),
+                           B * Tc * Fc, C, wt.shape[1], dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf))
+            line("dgrad vtn conv2d transposed conv, 4 parity-class GEMMs", M, 9 * C, O, bench(tconv, a.iters))
         dwp = torch.empty(O, 9 * C, dtype=torch.float32, device=dev)
         for tile, sk in ((128, 4), (128, 6), (128, 8), (128, 12), (64, 4), (64, 6)):
             line(f"wgrad vtn conv2d implicit [tile {tile} splitk {sk}] plan={K.plan_gemm(O, 9 * C, M)}", O, 9 * C, M,
