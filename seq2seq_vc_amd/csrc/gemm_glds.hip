@@ -354,7 +354,7 @@ struct TrStage {
     poff[0] = poff[1] = 0u;
   }
   __device__ __forceinline__ bool scalar_ok(const s2svc_operand& o, int R, int K) const {      // uniform
-    if (!SCALAR_KIND || R < 8) return false;
+    if (!SCALAR_KIND || R < 8 || (R & 7)) return false;        // (the clamp of init moves whole 16-byte pieces)
     if (KIND == G_TR_DENSE) return (int64_t)K * o.ld * 2 < (1ll << 32);
     const int64_t elems = (int64_t)(K / (o.T2 * o.F2) + 1) * o.T1 * o.F1 * o.ld;
     return elems * 2 < (1ll << 32) && 64 / o.F2 + 1 <= o.T2;

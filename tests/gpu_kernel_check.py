@@ -400,6 +400,51 @@ def gemm_conv2d(dtype):
 
 
 @case
+def gemm_conv2d_dma_addressing():
+    """The LDS-DMA GEMM's implicit 3x3 stride-2 convolution operands (C >= 64) on geometries that take each addressing
+    path: scalar-base rows with the division-free (tap, channel) walk; the conv2d weight gradient's per-lane pixel walk
+    (wraps over f2 / t2 / utterance, F2 > 64, a split-K start in the middle of the image); the per-lane fallbacks
+    (C % 64 != 0, T2 too small for the single-wrap walk); row / column tails.  Forward and weight gradient vs torch."""
+    res = []
+    dtype = torch.bfloat16
+    for (B, T1, F1, C, O, seed) in [(3, 31, 23, 64, 64, 1), (2, 9, 135, 64, 64, 2), (5, 5, 23, 64, 64, 3), (2, 33, 21, 72, 64, 4),
+                                    (2, 127, 39, 128, 72, 5)]:
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        x = rnd(B, T1, F1, C, seed=seed, dtype=dtype)
+        w = rnd(O, C, 3, 3, seed=seed + 10, scale=0.05)
+        wp = K.gather3(w, (O, 9, C), (C * 9, 1, 9), 0, dtype)
+        y = torch.empty(B, T2, F2, O, dtype=dtype, device=DEV)
+        K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(wp, 9 * C), B * T2 * F2, O, 9 * C, y,
+               in_dtype=dtype)
+        wr = w.to(dtype).float().requires_grad_(True)
+        yr = F.conv2d(x.float().permute(0, 3, 1, 2), wr, None, stride=2)
+        tag = f"B{B} {T1}x{F1} C{C} O{O}"
+        res.append(check(f"conv2d fwd (DMA GEMM) {tag}", y, yr.permute(0, 2, 3, 1), dtype))
+        dy = rnd(B, T2, F2, O, seed=seed + 20, dtype=dtype)
+        yr.backward(dy.float().permute(0, 3, 1, 2))
+        for sk in (1, 3):
+            dwp = torch.empty(O, 9 * C, dtype=torch.float32, device=DEV)
+            K.gemm(K.operand(dy, O, layout=K.RC), K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O,
+                   9 * C, B * T2 * F2, dwp, in_dtype=dtype, splitk=sk)
+            dw = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32).view(O, C, 3, 3)
+            res.append(check(f"conv2d wgrad (DMA GEMM) {tag} splitk={sk}", dw, wr.grad, dtype, rtol=3e-2, atol=0.3))
+    # dense operands: K tail (the last k tile takes the per-lane path), row tails, a row-contiguous operand whose row count is
+    # not a multiple of 8 inside a padded buffer
+    for (M, N, Kd, seed) in [(200, 136, 200, 6), (515, 384, 448, 7)]:
+        a, b = rnd(M, Kd, seed=seed, dtype=dtype), rnd(N, Kd, seed=seed + 1, dtype=dtype, scale=0.05)
+        c = torch.empty(M, N, dtype=dtype, device=DEV)
+        K.gemm(K.operand(a, Kd), K.operand(b, Kd), M, N, Kd, c, in_dtype=dtype)
+        res.append(check(f"dense fwd (DMA GEMM) {M}x{N}x{Kd}", c, a.float() @ b.float().t(), dtype))
+    M, N, Kd = 1000, 20, 384
+    buf = rnd(M, 24, seed=8, dtype=dtype)
+    dy, x = buf[:, :N], rnd(M, Kd, seed=9, dtype=dtype)
+    dw = torch.empty(N, Kd, dtype=torch.float32, device=DEV)
+    K.gemm(K.operand(dy, 24, layout=K.RC), K.operand(x, Kd, layout=K.RC), N, Kd, M, dw, in_dtype=dtype)
+    res.append(check("wgrad with a 20-row operand in a 24-wide buffer", dw, dy.float().t() @ x.float(), dtype, rtol=3e-2, atol=0.3))
+    return res
+
+
+@case
 def conv2d_dgrad_transposed():
     """Data gradient of the 3x3 stride-2 Conv2d as four implicit transposed-convolution GEMMs (one per parity class of
     input pixels, stored through the c_map) vs torch's conv2d input gradient and vs the dcols GEMM + col2im path, for
