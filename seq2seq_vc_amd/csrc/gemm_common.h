@@ -33,6 +33,31 @@ __device__ __forceinline__ int64_t c_row_of(const s2svc_gemm_desc& d, int m) {
   return ((int64_t)b * d.cm_T1 + 2 * i + d.cm_pt) * d.cm_F1 + 2 * j + d.cm_pf;
 }
 
+// Division of row indices by image extents without the ~25-instruction integer-division sequence: q = mulhi(n, magic) is
+// exact for n * d < 2^32 (the launchers check that bound on the host, see rows_fit_fastdiv in gemm_glds.hip).
+struct fastdiv_t { uint32_t d, mg; };
+__device__ __forceinline__ fastdiv_t fastdiv_make(int d) {
+  fastdiv_t f;
+  f.d = (uint32_t)d;
+  f.mg = d > 1 ? 0xFFFFFFFFu / (uint32_t)d + 1u : 0u;
+  return f;
+}
+__device__ __forceinline__ int fastdiv(int n, const fastdiv_t& f) { return f.d > 1 ? (int)__umulhi((uint32_t)n, f.mg) : n; }
+
+struct c_map_t { fastdiv_t per_b, fc; };
+__device__ __forceinline__ c_map_t c_map_make(const s2svc_gemm_desc& d) {
+  c_map_t c;
+  c.per_b = fastdiv_make(d.c_map ? d.cm_Tc * d.cm_Fc : 1);
+  c.fc = fastdiv_make(d.c_map ? d.cm_Fc : 1);
+  return c;
+}
+__device__ __forceinline__ int64_t c_row_fast(const s2svc_gemm_desc& d, const c_map_t& c, int m) {
+  if (!d.c_map) return m;
+  const int b = fastdiv(m, c.per_b), rem = m - b * (int)c.per_b.d;
+  const int i = fastdiv(rem, c.fc), j = rem - i * (int)c.fc.d;
+  return ((int64_t)b * d.cm_T1 + 2 * i + d.cm_pt) * d.cm_F1 + 2 * j + d.cm_pf;
+}
+
 template <bool STAGED = false>
 __device__ __forceinline__ void epilogue_store_f(const s2svc_gemm_desc& d, int z0, int z1, int m, int n, float v) {
   v *= d.alpha;
@@ -98,6 +123,7 @@ __device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, 
   }
   constexpr int LPR = WTN / 8;          // lanes per row
   constexpr int RPP = 64 / LPR;         // rows per pass
+  const c_map_t cm = c_map_make(d);
   // NOT unrolled: the body is load/store bound, and unrolling it (8 passes x 8 values x RNG state) raised the
   // register demand of the whole kernel until hipcc spilled the MFMA accumulators inside the K loop (5x slower)
 #pragma unroll 1
@@ -152,7 +178,7 @@ __device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, 
         }
       }
     }
-    const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + c_row_of(d, m) * d.ldc + n;
+    const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + c_row_fast(d, cm, m) * d.ldc + n;
     if (d.res) {
       const int64_t ro = (int64_t)z0 * d.rbs0 + (int64_t)z1 * d.rbs1 + (int64_t)m * d.ldr + n;
       if (d.c_dtype == S2S_F32) {

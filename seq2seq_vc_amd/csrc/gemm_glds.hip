@@ -90,6 +90,9 @@ struct KcStage {
     // rows of group g = 4i + wave: rl = g*RPI + lane/PIECES ; the swizzle term of rl does not depend on i
     // (BKT 64: ((g&1)*4 + (lane>>4)) & 7 with g&1 == wave&1 ; BKT 32: (-(lane>>4)) & 3)
     piece8 = ((lane % PIECES) ^ swz_of<BKT>(wave * RPI + lane / PIECES)) << 3;
+    // row index -> image position by multiply-high (exact: the host checked rows * extent < 2^32, rows_fit_fastdiv)
+    const fastdiv_t fd0 = fastdiv_make(KIND == G_KC_TCONV2D ? o.T1 * o.F1 : (KIND == G_KC_CONV2D ? o.F2 : 1));
+    const fastdiv_t fd1 = fastdiv_make(KIND == G_KC_TCONV2D ? o.F1 : (KIND == G_KC_CONV2D ? o.T2 : 1));
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int rl = (i * 4 + wave) * RPI + lane / PIECES;
@@ -100,8 +103,8 @@ struct KcStage {
       vmask[i] = 0;
       if (KIND == G_KC_TCONV2D) {       // class grid (o.T1 x o.F1) -> output-gradient pixel (i, j) of the (B, T2, F2, C) tensor
         const int per_b = o.T1 * o.F1;
-        const int b = r / per_b, rem = r - b * per_b;
-        trow[i] = rem / o.F1;
+        const int b = fastdiv(r, fd0), rem = r - b * per_b;
+        trow[i] = fastdiv(rem, fd1);
         tcol[i] = rem - trow[i] * o.F1;
         rowbase[i] = ((int64_t)(b * o.T2 + trow[i]) * o.F2 + tcol[i]) * o.ld;
         int m = 0;
@@ -119,8 +122,8 @@ struct KcStage {
         rowbase[i] = (int64_t)r * o.ld;
         trow[i] = r % o.T;
       } else {
-        const int f2 = r % o.F2, bt = r / o.F2;
-        const int t2 = bt % o.T2, b = bt / o.T2;
+        const int bt = fastdiv(r, fd0), f2 = r - bt * o.F2;
+        const int b = fastdiv(bt, fd1), t2 = bt - b * o.T2;
         rowbase[i] = ((int64_t)(b * o.T1 + 2 * t2) * o.F1 + 2 * f2) * o.ld;
       }
       rowoff[i] = (uint32_t)((rowbase[i] + piece8) * 2);
@@ -811,6 +814,19 @@ bool disabled() {
   return v == 1;
 }
 
+// the kernels split row indices into image positions with multiply-high divisions, exact while rows * extent < 2^32
+bool rows_fit_fastdiv(const s2svc_gemm_desc& d) {
+  const int64_t lim = 1ll << 32;
+  const int64_t rows = (int64_t)(d.M > d.N ? d.M : d.N) + 256;
+  if (d.c_map && rows * ((int64_t)d.cm_Tc * d.cm_Fc) >= lim) return false;
+  const s2svc_operand* ops[2] = {&d.A, &d.B};
+  for (const s2svc_operand* o : ops) {
+    if (o->mode == S2SVC_OP_TCONV2D_S2 && rows * ((int64_t)o->T1 * o->F1) >= lim) return false;
+    if (o->mode == S2SVC_OP_CONV2D_S2 && rows * (int64_t)(o->F2 > o->T2 ? o->F2 : o->T2) >= lim) return false;
+  }
+  return true;
+}
+
 bool extent_ok(const s2svc_operand& o, int extent) {
   // 16-byte pieces run along the row index (RC) or along k (KC): the extent must be a multiple of 8, or the caller
   // declares the rows zero-padded up to one (whole pieces are then fetched unmasked)
@@ -864,9 +880,37 @@ extern "C" int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc) {
   return 1;
 }
 
+// the parity-class GEMMs of one transposed convolution (Conv2d data gradient) may share a launch as well: same operand
+// kinds, disjoint output pixels (c_map), reductions of 1 / 2 / 2 / 4 taps -- one grid instead of four short ones
+static bool tconv_group_ok(const s2svc_gemm_desc& d) {
+  if (disabled() || d.dtype != S2S_BF16 || d.nb0 * d.nb1 != 1 || !d.c_map) return false;
+  if (kind_of(d.A) != G_KC_TCONV2D || kind_of(d.B) != G_KC_DENSE) return false;
+  if (!operand_ok(d.A) || !operand_ok(d.B) || !extent_ok(d.A, d.K) || !extent_ok(d.B, d.K) || !rows_fit_fastdiv(d)) return false;
+  if (d.emask || d.drop_p > 0.f || d.a_rowsum || d.M <= 0 || d.N <= 0 || d.K <= 0) return false;
+  return true;
+}
+
 extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile, void* stream) {
   S2S_REQUIRE(descs && n > 0 && (tile == 64 || tile == 128), "gemm_grouped: bad args");
   hipStream_t st = (hipStream_t)stream;
+  if (tconv_group_ok(descs[0])) {
+    S2S_REQUIRE(tile == 128 && n <= S2S_GROUP_MAX, "gemm_grouped: transposed-convolution groups take 128x128 tiles, <= 10 problems");
+    group_args g;
+    std::memset(&g, 0, sizeof(g));
+    g.n = n;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+      S2S_REQUIRE(tconv_group_ok(descs[i]) && descs[i].splitk <= 1, "gemm_grouped: mixed or ineligible transposed-convolution descriptors");
+      g.d[i] = descs[i];
+      g.tile_start[i] = (int32_t)total;
+      total += (int64_t)((descs[i].M + 127) / 128) * ((descs[i].N + 127) / 128);
+      S2S_REQUIRE(total < (1ll << 30), "gemm_grouped: too many tiles");
+    }
+    for (int i = n; i <= S2S_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
+    hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, G_KC_TCONV2D, G_KC_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+    S2S_CHECK_LAUNCH("gemm_grouped_kernel (tconv2d)");
+    return 0;
+  }
   for (int i0 = 0; i0 < n; i0 += S2S_GROUP_MAX) {
     group_args g;
     std::memset(&g, 0, sizeof(g));
@@ -904,6 +948,7 @@ extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
   if (!operand_ok(d.A) || !operand_ok(d.B)) return 0;
   if (!extent_ok(d.A, d.A.layout == S2SVC_LAYOUT_RC ? d.M : d.K)) return 0;
   if (!extent_ok(d.B, d.B.layout == S2SVC_LAYOUT_RC ? d.N : d.K)) return 0;
+  if (!rows_fit_fastdiv(d)) return 0;
   if (d.tile_hint != 0 && d.tile_hint != 64 && d.tile_hint != 128) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int splitk = d.splitk > 1 ? d.splitk : 1;

@@ -931,6 +931,8 @@ def conv1d(x, weight, bias=None, act=None):
 # Conv2d 3x3 stride 2 (+ReLU) on NHWC activations         reference: subsampling.py:58-63
 # ================================================================================================
 _TCONV = os.environ.get("S2SVC_NO_TCONV", "0") != "1"      # tuning aid: fall back to dcols GEMM + col2im
+_TCONV_GROUP = os.environ.get("S2SVC_TCONV_GROUP", "0") == "1"     # one grid for the four parity classes: measured equal
+#                                                                    (189 vs 190 us), so the plain launches stay the default
 
 
 class _Conv2dS2(Function):
@@ -985,6 +987,7 @@ class _Conv2dS2(Function):
             # gathers its 4 / 2 / 2 / 1 taps of dY straight from HBM and stores into its pixels of dX (no dcols, no col2im)
             wts = K.tconv2d_weights(weight.detach())
             dx = torch.empty((B, T1, F1, C), dtype=dtype, device=x.device)
+            descs = [] if _TCONV_GROUP else None        # (opt-in) one grid for the four classes, largest reduction first
             for cls, wt in enumerate(wts):
                 pt, pf = cls >> 1, cls & 1
                 Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
@@ -992,7 +995,9 @@ class _Conv2dS2(Function):
                     continue
                 Kc = wt.shape[1]
                 K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, Kc),
-                       B * Tc * Fc, C, Kc, dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf))
+                       B * Tc * Fc, C, Kc, dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf), group=descs)
+            if descs:
+                K.launch_group(descs)
         elif ctx.needs_input_grad[0]:
             dcols = torch.empty((M2, 9 * C), dtype=dtype, device=x.device)
             K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), M2, 9 * C, O, dcols, in_dtype=dtype)

@@ -131,9 +131,10 @@ def pick_splitk(M, N, K, nbatch=1):
 
 def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
          ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False, a_rowsum=None,
-         a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0), c_map=None):
+         a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0), c_map=None, group=None):
     """C = act(alpha * A.B^T + bias) [* dropmask] [* (emask > 0)] + res   (see s2svc_gemm in include/s2svc_hip.h).
-    c_map = (T1, F1, Tc, Fc, pt, pf): GEMM row (b, i, j) of the Tc x Fc class grid goes to row (b, 2i+pt, 2j+pf) of C."""
+    c_map = (T1, F1, Tc, Fc, pt, pf): GEMM row (b, i, j) of the Tc x Fc class grid goes to row (b, 2i+pt, 2j+pf) of C.
+    group = list: the descriptor is appended instead of launched (launch_group() runs the list as one grid)."""
     d = _lib.GemmDesc()
     if c_map is not None:
         d.c_map = 1
@@ -162,6 +163,10 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
                 raise TypeError("gemm: emask must have the output dtype")
             d.emask, d.ldm = emask.data_ptr(), N
         d.drop_p, d.seed_base, d.seed_off = drop_p, seed[0], seed[1]
+    if group is not None:
+        d.splitk, d.ws = 1, None
+        group.append(d)
+        return out
     if _RECORDER is not None:                # queue it for the grouped launch (unsplit) if the kernel takes it
         d.splitk, d.ws = 1, None
         if a_rowsum is not None:
@@ -258,6 +263,12 @@ def flush_colreduce(queue):
         pending = rest
         arr = (_lib.ColreduceItem * len(group))(*[g[0] for g in group])
         _lib.check(_lib.lib().s2svc_colreduce_grouped(ctypes.addressof(arr), len(group), stream()), "s2svc_colreduce_grouped")
+
+
+def launch_group(descs, tile=128):
+    """One grid for the listed problems (K.gemm(..., group=descs)): the parity-class GEMMs of a transposed convolution."""
+    arr = (_lib.GemmDesc * len(descs))(*descs)
+    _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(descs), tile, stream()), "s2svc_gemm_grouped")
 
 
 def flush_grouped(queue):

@@ -461,6 +461,15 @@ def conv2d_dgrad_transposed():
             Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
             K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, wt.shape[1]),
                    B * Tc * Fc, C, wt.shape[1], dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf))
+        dxg = torch.full((B, T1, F1, C), float("nan"), dtype=dtype, device=DEV)      # the four classes as ONE grid
+        descs, wts = [], K.tconv2d_weights(w)
+        for cls, wt in enumerate(wts):
+            pt, pf = cls >> 1, cls & 1
+            Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
+            K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, wt.shape[1]),
+                   B * Tc * Fc, C, wt.shape[1], dxg, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf), group=descs)
+        K.launch_group(descs)
+        res.append((bool(torch.equal(dxg, dx)), f"tconv2d dgrad B{B} {T1}x{F1}: grouped launch == four launches (bit-exact)"))
         xr = torch.zeros(B, C, T1, F1, device=DEV, requires_grad=True)
         F.conv2d(xr, w.to(dtype).float(), None, stride=2).backward(dy.float().permute(0, 3, 1, 2))
         ref = xr.grad.permute(0, 2, 3, 1)

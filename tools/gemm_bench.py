@@ -135,6 +135,16 @@ def main():
                     K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, wt.shape[1]),
                            B * Tc * Fc, C, wt.shape[1], dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf))
             line("dgrad vtn conv2d transposed conv, 4 parity-class GEMMs", M, 9 * C, O, bench(tconv, a.iters))
+
+            def tconv_grouped():
+                descs = []
+                for cls, wt in enumerate(wts):
+                    pt, pf = cls >> 1, cls & 1
+                    Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
+                    K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, wt.shape[1]),
+                           B * Tc * Fc, C, wt.shape[1], dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf), group=descs)
+                K.launch_group(descs)
+            line("dgrad vtn conv2d transposed conv, the 4 classes as one grid", M, 9 * C, O, bench(tconv_grouped, a.iters))
         dwp = torch.empty(O, 9 * C, dtype=torch.float32, device=dev)
         for tile, sk in ((128, 4), (128, 6), (128, 8), (128, 12), (64, 4), (64, 6)):
             line(f"wgrad vtn conv2d implicit [tile {tile} splitk {sk}] plan={K.plan_gemm(O, 9 * C, M)}", O, 9 * C, M,
