@@ -47,6 +47,79 @@ __global__ __launch_bounds__(256) void pairwise_fwd_kernel(int B, int Tf, int Tx
   for (int j = lane; j < Tx; j += 64) lr[j] = (j < tl) ? (-dr[j] - lse) : NINF;
 }
 
+// Tiled variant (A % 8 == 0, 16-byte aligned rows): a workgroup takes PW_FRAMES frames of one utterance; a thread owns one
+// frame and every 8th text row, walks the channels in 16-byte pieces (the frame piece is shared by 8 neighbouring lanes, the
+// text rows of an utterance stay in L1 / L2 across the workgroup's frames) and accumulates (f - x)^2 in fp32 -- no
+// cross-lane reduction per pair.  The distances of the workgroup's frames sit in LDS for the log-softmax pass, which is
+// the arithmetic of the kernel above.
+constexpr int PW_FRAMES = 32;
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&f)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&f)[8]) { load_f32x8(p, f); }
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&f)[8]) {
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(p), f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pairwise_fwd_tiled_kernel(int B, int Tf, int Tx, int A, const T* __restrict__ feats,
+                                                                 const T* __restrict__ text, const int32_t* __restrict__ tlen,
+                                                                 float* __restrict__ logp, float* __restrict__ dist) {
+  extern __shared__ float shd[];          // PW_FRAMES x Tx distances
+  const int b = blockIdx.x, i0 = blockIdx.y * PW_FRAMES;
+  const int fi = threadIdx.x >> 3, jg = threadIdx.x & 7;
+  const int i = i0 + fi;
+  const int tl = tlen ? (tlen[b] < Tx ? tlen[b] : Tx) : Tx;
+  const T* tx = text + (int64_t)b * Tx * A;
+  if (i < Tf) {
+    const T* f = feats + ((int64_t)b * Tf + i) * A;
+    for (int j0 = 0; j0 < Tx; j0 += 32) {               // 4 text rows per thread and pass: j0 + jg + 8 m
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      const T* xr[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int j = j0 + jg + 8 * m;
+        xr[m] = tx + (int64_t)(j < Tx ? j : Tx - 1) * A;
+      }
+      for (int a = 0; a < A; a += 8) {
+        float fv[8];
+        load8<T>(f + a, fv);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          float xv[8];
+          load8<T>(xr[m] + a, xv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = fv[e] - xv[e];
+            acc[m] += d * d;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int j = j0 + jg + 8 * m;
+        if (j < Tx) {
+          const float dd = sqrtf(acc[m]);
+          shd[fi * Tx + j] = dd;
+          dist[((int64_t)b * Tf + i) * Tx + j] = dd;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float NINF = -__builtin_huge_valf();
+  for (int r = wave; r < PW_FRAMES && i0 + r < Tf; r += 4) {
+    const float* dr = shd + r * Tx;
+    float* lr = logp + ((int64_t)b * Tf + i0 + r) * Tx;
+    float mx = NINF;
+    for (int j = lane; j < tl; j += 64) mx = fmaxf(mx, -dr[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < tl; j += 64) sum += expf(-dr[j] - mx);
+    const float lse = logf(wave_sum(sum)) + mx;
+    for (int j = lane; j < Tx; j += 64) lr[j] = (j < tl) ? (-dr[j] - lse) : NINF;
+  }
+}
+
 // G[b,i,j] = d(loss)/d(dist) / dist, with d(loss)/d(score) = dlogp - softmax*sum_j dlogp, score = -dist.
 // Also row sums rs[b,i] = sum_j G and (via a second pass on the host side) column sums.
 template <typename T>
@@ -87,15 +160,18 @@ __global__ void rowscale_kernel(int64_t rows, int D, const T* __restrict__ x, co
 
 // Gaussian upsampling weights: c_j = cumsum(ds)_j - ds_j/2 ; e[t,j] = -delta*(t_eff - c_j)^2 with
 // t_eff = t if t < flen[b] else 0 (the reference multiplies t by the frame mask) ; softmax over valid j.
+constexpr int GAUSS_FRAMES = 16;
 template <typename T>
-__global__ __launch_bounds__(64) void gauss_probs_kernel(int B, int Tf, int Tx, const float* __restrict__ ds,
-                                                         const int32_t* __restrict__ tlen, const int32_t* __restrict__ flen,
-                                                         float delta, T* __restrict__ P) {
+__global__ __launch_bounds__(256) void gauss_probs_kernel(int B, int Tf, int Tx, const float* __restrict__ ds,
+                                                          const int32_t* __restrict__ tlen, const int32_t* __restrict__ flen,
+                                                          float delta, T* __restrict__ P) {
+  // grid (B, frame chunks): a workgroup takes GAUSS_FRAMES frames of one utterance, one wavefront per frame at a time;
+  // every workgroup rebuilds the Tx centres (the same sequential sum as a single workgroup per utterance would do)
   extern __shared__ float cpos[];  // Tx centres
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tl = tlen ? (tlen[b] < Tx ? tlen[b] : Tx) : Tx;
   const int fl = flen ? flen[b] : Tf;
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     float run = 0.f;
     for (int j = 0; j < Tx; ++j) {
       const float d = ds[(int64_t)b * Tx + j];
@@ -105,7 +181,9 @@ __global__ __launch_bounds__(64) void gauss_probs_kernel(int B, int Tf, int Tx, 
   }
   __syncthreads();
   const float NINF = -__builtin_huge_valf();
-  for (int t = 0; t < Tf; ++t) {
+  const int t_begin = blockIdx.y * GAUSS_FRAMES;
+  const int t_end = t_begin + GAUSS_FRAMES < Tf ? t_begin + GAUSS_FRAMES : Tf;
+  for (int t = t_begin + wave; t < t_end; t += 4) {
     const float te = (t < fl) ? (float)t : 0.f;
     float mx = NINF;
     for (int j = lane; j < tl; j += 64) {
@@ -145,6 +223,16 @@ extern "C" int s2svc_pairwise_l2_logsoftmax(int dtype, int B, int Tf, int Tx, in
   const int64_t rows = (int64_t)B * Tf;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (A % 8 == 0 && Tx > 0 && (size_t)PW_FRAMES * Tx * sizeof(float) <= 48 * 1024 && ((uintptr_t)feats % 16) == 0 && ((uintptr_t)text % 16) == 0) {
+    dim3 tgrid((unsigned)B, (unsigned)((Tf + PW_FRAMES - 1) / PW_FRAMES));
+    const size_t shm = (size_t)PW_FRAMES * Tx * sizeof(float);
+    if (dtype == S2S_F32)
+      hipLaunchKernelGGL(pairwise_fwd_tiled_kernel<float>, tgrid, dim3(256), shm, st, B, Tf, Tx, A, (const float*)feats, (const float*)text, text_lens, logp, dist);
+    else
+      hipLaunchKernelGGL(pairwise_fwd_tiled_kernel<bf16_t>, tgrid, dim3(256), shm, st, B, Tf, Tx, A, (const bf16_t*)feats, (const bf16_t*)text, text_lens, logp, dist);
+    S2S_CHECK_LAUNCH("pairwise_fwd_tiled_kernel");
+    return 0;
+  }
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(pairwise_fwd_kernel<float>, grid, block, 4 * Tx * sizeof(float), st, B, Tf, Tx, A, (const float*)feats, (const float*)text, text_lens, logp, dist);
@@ -182,13 +270,13 @@ extern "C" int s2svc_rowscale(int dtype, int64_t rows, int D, const void* x, con
 
 extern "C" int s2svc_gauss_upsample_probs(int dtype, int B, int Tf, int Tx, const float* ds, const int32_t* text_lens,
                                           const int32_t* feat_lens, float delta, void* P, void* stream) {
-  if (B == 0) return 0;
+  if (B == 0 || Tf == 0) return 0;
   S2S_REQUIRE(Tx * 4 <= 48 * 1024, "gauss_upsample_probs: T_text too large");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(gauss_probs_kernel<float>, dim3(B), dim3(64), Tx * sizeof(float), st, B, Tf, Tx, ds, text_lens, feat_lens, delta, (float*)P);
+    hipLaunchKernelGGL(gauss_probs_kernel<float>, dim3(B, (Tf + GAUSS_FRAMES - 1) / GAUSS_FRAMES), dim3(256), Tx * sizeof(float), st, B, Tf, Tx, ds, text_lens, feat_lens, delta, (float*)P);
   else
-    hipLaunchKernelGGL(gauss_probs_kernel<bf16_t>, dim3(B), dim3(64), Tx * sizeof(float), st, B, Tf, Tx, ds, text_lens, feat_lens, delta, (bf16_t*)P);
+    hipLaunchKernelGGL(gauss_probs_kernel<bf16_t>, dim3(B, (Tf + GAUSS_FRAMES - 1) / GAUSS_FRAMES), dim3(256), Tx * sizeof(float), st, B, Tf, Tx, ds, text_lens, feat_lens, delta, (bf16_t*)P);
   S2S_CHECK_LAUNCH("gauss_probs_kernel");
   return 0;
 }

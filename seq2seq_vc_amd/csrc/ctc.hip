@@ -16,6 +16,7 @@ namespace {
 
 constexpr int CTC_THREADS = 256;
 constexpr int CTC_KMAX = 8;  // extended length S = 2N+1 <= 2048
+constexpr int CTC_PD = 4;    // steps of prefetch distance in the one-position-per-thread path
 
 __device__ __forceinline__ float lse2(float a, float b) {
   const float m = fmaxf(a, b);
@@ -74,7 +75,35 @@ __global__ __launch_bounds__(CTC_THREADS) void forward_sum_kernel(int B, int Tf,
   __syncthreads();
   float* prev = col0;
   float* cur = col1;
-  for (int t = 1; t < Tn; ++t) {
+  // S <= CTC_THREADS (one extended position per thread, the usual case): the two global loads behind lp(t, s) are issued
+  // CTC_PD steps ahead, so a step of the recursion is an LDS round trip + one lse3, not a trip to L2 / HBM
+  const bool one_per_thread = S <= CTC_THREADS;
+  if (one_per_thread) {
+    const int s = tid;
+    const bool act = s < S;
+    float lq[CTC_PD];
+#pragma unroll
+    for (int q = 0; q < CTC_PD; ++q) lq[q] = (act && 1 + q < Tn) ? lp(1 + q, s) : 0.f;
+    for (int t = 1; t < Tn; t += CTC_PD) {
+#pragma unroll
+      for (int q = 0; q < CTC_PD; ++q) {
+        const int tt = t + q;
+        if (tt >= Tn) break;
+        const float l = lq[q];
+        if (act && tt + CTC_PD < Tn) lq[q] = lp(tt + CTC_PD, s);
+        if (act) {
+          const float a1 = prev[s], a2 = prev[s - 1];
+          const float a3 = ((s & 1) && s >= 3) ? prev[s - 2] : NINF;
+          const float v = lse3(a1, a2, a3) + l;
+          cur[s] = v;
+          aw[(int64_t)tt * Spad + s] = v;
+        }
+        __syncthreads();
+        float* tmp = prev; prev = cur; cur = tmp;
+      }
+    }
+  }
+  for (int t = 1; t < Tn && !one_per_thread; ++t) {
     for (int k = 0; k < CTC_KMAX; ++k) {
       const int s = tid + k * CTC_THREADS;
       if (s < S) {
@@ -117,7 +146,38 @@ __global__ __launch_bounds__(CTC_THREADS) void forward_sum_kernel(int B, int Tf,
     }
   }
   __syncthreads();
-  for (int t = Tn - 2; t >= 0; --t) {
+  if (one_per_thread) {
+    const int s = tid;
+    const bool act = s < S, lab = act && (s & 1);
+    const int j = (s - 1) >> 1;
+    float lq[CTC_PD], aq[CTC_PD];
+#pragma unroll
+    for (int q = 0; q < CTC_PD; ++q) {
+      const int tt = Tn - 2 - q;
+      lq[q] = (act && tt >= 0) ? lp(tt, s) : 0.f;
+      aq[q] = (lab && tt >= 0) ? aw[(int64_t)tt * Spad + s] : 0.f;
+    }
+    for (int t = Tn - 2; t >= 0; t -= CTC_PD) {
+#pragma unroll
+      for (int q = 0; q < CTC_PD; ++q) {
+        const int tt = t - q;
+        if (tt < 0) break;
+        const float l = lq[q], a = aq[q];
+        if (act && tt - CTC_PD >= 0) lq[q] = lp(tt - CTC_PD, s);
+        if (lab && tt - CTC_PD >= 0) aq[q] = aw[(int64_t)(tt - CTC_PD) * Spad + s];
+        if (act) {
+          const float b1 = bprev[s], b2 = bprev[s + 1];
+          const float b3 = ((s & 1) && s + 2 < S) ? bprev[s + 2] : NINF;
+          const float v = lse3(b1, b2, b3) + l;
+          bcur[s] = v;
+          if (lab) gb[(int64_t)tt * Tx + j] = expf(l) - expf(a + v + nll - l);
+        }
+        __syncthreads();
+        float* tmp = bprev; bprev = bcur; bcur = tmp;
+      }
+    }
+  }
+  for (int t = Tn - 2; t >= 0 && !one_per_thread; --t) {
     for (int k = 0; k < CTC_KMAX; ++k) {
       const int s = tid + k * CTC_THREADS;
       if (s < S) {
