@@ -47,61 +47,69 @@ __global__ __launch_bounds__(256) void pairwise_fwd_kernel(int B, int Tf, int Tx
   for (int j = lane; j < Tx; j += 64) lr[j] = (j < tl) ? (-dr[j] - lse) : NINF;
 }
 
-// Tiled variant (A % 8 == 0, 16-byte aligned rows): a workgroup takes PW_FRAMES frames of one utterance; a thread owns one
-// frame and every 8th text row, walks the channels in 16-byte pieces (the frame piece is shared by 8 neighbouring lanes, the
-// text rows of an utterance stay in L1 / L2 across the workgroup's frames) and accumulates (f - x)^2 in fp32 -- no
-// cross-lane reduction per pair.  The distances of the workgroup's frames sit in LDS for the log-softmax pass, which is
-// the arithmetic of the kernel above.
-constexpr int PW_FRAMES = 32;
+// Tiled variant (A % 8 == 0, 16-byte aligned rows): a workgroup takes PW_FRAMES frames of one utterance.  Channel chunks of
+// PW_CH values of the frames and of PW_ROWS text rows are staged in LDS as fp32 (coalesced 16-byte global loads, rows padded
+// by 4 floats against bank conflicts); a thread owns one (frame, text row) pair of the chunk and accumulates (f - x)^2 in
+// fp32 from float4 LDS reads -- no cross-lane reduction per pair; 8 frames per workgroup keep >= 2 workgroups on every CU
+// at the recipe sizes (16 x 256 frames).  The distances of the workgroup's frames
+// sit in LDS for the log-softmax pass, which is the arithmetic of the kernel above.
+constexpr int PW_FRAMES = 8, PW_ROWS = 32, PW_CH = 128, PW_LD = PW_CH + 4;
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&f)[8]);
 template <> __device__ __forceinline__ void load8<float>(const float* p, float (&f)[8]) { load_f32x8(p, f); }
 template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&f)[8]) {
   unpack_bf16x8(*reinterpret_cast<const uint4*>(p), f);
 }
 
+// rows [r0, r0 + 32) x channels [a0, a0 + PW_CH) of a (R, A) matrix -> LDS tile (zeros outside the matrix)
+template <typename T, int ROWS>
+__device__ __forceinline__ void pw_stage(const T* __restrict__ src, int r0, int R, int a0, int A, float* __restrict__ tile) {
+  for (int p = threadIdx.x; p < ROWS * (PW_CH / 8); p += 256) {
+    const int r = p / (PW_CH / 8), c = (p - r * (PW_CH / 8)) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r0 + r < R && a0 + c < A) load8<T>(src + (int64_t)(r0 + r) * A + a0 + c, v);
+    float* d = tile + r * PW_LD + c;
+    *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pairwise_fwd_tiled_kernel(int B, int Tf, int Tx, int A, const T* __restrict__ feats,
                                                                  const T* __restrict__ text, const int32_t* __restrict__ tlen,
                                                                  float* __restrict__ logp, float* __restrict__ dist) {
-  extern __shared__ float shd[];          // PW_FRAMES x Tx distances
+  extern __shared__ float shd[];          // PW_FRAMES x Tx distances, then the two staging tiles
+  float* ft = shd + PW_FRAMES * Tx;
+  float* xt = ft + PW_FRAMES * PW_LD;
   const int b = blockIdx.x, i0 = blockIdx.y * PW_FRAMES;
-  const int fi = threadIdx.x >> 3, jg = threadIdx.x & 7;
-  const int i = i0 + fi;
+  const int fi = threadIdx.x >> 5, jj = threadIdx.x & 31;
   const int tl = tlen ? (tlen[b] < Tx ? tlen[b] : Tx) : Tx;
+  const T* fb = feats + (int64_t)b * Tf * A;
   const T* tx = text + (int64_t)b * Tx * A;
-  if (i < Tf) {
-    const T* f = feats + ((int64_t)b * Tf + i) * A;
-    for (int j0 = 0; j0 < Tx; j0 += 32) {               // 4 text rows per thread and pass: j0 + jg + 8 m
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      const T* xr[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int j = j0 + jg + 8 * m;
-        xr[m] = tx + (int64_t)(j < Tx ? j : Tx - 1) * A;
+  for (int j0 = 0; j0 < Tx; j0 += PW_ROWS) {
+    float acc = 0.f;
+    for (int a0 = 0; a0 < A; a0 += PW_CH) {
+      __syncthreads();                                   // the previous chunk's reads are done
+      pw_stage<T, PW_FRAMES>(fb, i0, Tf, a0, A, ft);
+      pw_stage<T, PW_ROWS>(tx, j0, Tx, a0, A, xt);
+      __syncthreads();
+      const float* fr = ft + fi * PW_LD;
+      const float* xr = xt + jj * PW_LD;
+#pragma unroll 8
+      for (int c = 0; c < PW_CH; c += 4) {
+        const float4 fv = *reinterpret_cast<const float4*>(fr + c);
+        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        const float d0 = fv.x - xv.x, d1 = fv.y - xv.y, d2 = fv.z - xv.z, d3 = fv.w - xv.w;
+        acc += d0 * d0;
+        acc += d1 * d1;
+        acc += d2 * d2;
+        acc += d3 * d3;
       }
-      for (int a = 0; a < A; a += 8) {
-        float fv[8];
-        load8<T>(f + a, fv);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          float xv[8];
-          load8<T>(xr[m] + a, xv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float d = fv[e] - xv[e];
-            acc[m] += d * d;
-          }
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int j = j0 + jg + 8 * m;
-        if (j < Tx) {
-          const float dd = sqrtf(acc[m]);
-          shd[fi * Tx + j] = dd;
-          dist[((int64_t)b * Tf + i) * Tx + j] = dd;
-        }
-      }
+    }
+    const int j = j0 + jj;
+    if (j < Tx && i0 + fi < Tf) {
+      const float dd = sqrtf(acc);
+      shd[fi * Tx + j] = dd;
+      dist[((int64_t)b * Tf + i0 + fi) * Tx + j] = dd;
     }
   }
   __syncthreads();
@@ -223,9 +231,9 @@ extern "C" int s2svc_pairwise_l2_logsoftmax(int dtype, int B, int Tf, int Tx, in
   const int64_t rows = (int64_t)B * Tf;
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (A % 8 == 0 && Tx > 0 && (size_t)PW_FRAMES * Tx * sizeof(float) <= 48 * 1024 && ((uintptr_t)feats % 16) == 0 && ((uintptr_t)text % 16) == 0) {
+  if (A % 8 == 0 && Tx > 0 && (size_t)PW_FRAMES * Tx * sizeof(float) <= 24 * 1024 && ((uintptr_t)feats % 16) == 0 && ((uintptr_t)text % 16) == 0) {
     dim3 tgrid((unsigned)B, (unsigned)((Tf + PW_FRAMES - 1) / PW_FRAMES));
-    const size_t shm = (size_t)PW_FRAMES * Tx * sizeof(float);
+    const size_t shm = ((size_t)PW_FRAMES * Tx + (size_t)(PW_FRAMES + PW_ROWS) * PW_LD) * sizeof(float);
     if (dtype == S2S_F32)
       hipLaunchKernelGGL(pairwise_fwd_tiled_kernel<float>, tgrid, dim3(256), shm, st, B, Tf, Tx, A, (const float*)feats, (const float*)text, text_lens, logp, dist);
     else

@@ -29,14 +29,21 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   return logf(expf(a - m) + expf(b - m) + expf(c - m)) + m;
 }
 
-__global__ __launch_bounds__(CTC_THREADS) void forward_sum_kernel(int B, int Tf, int Tx, const float* __restrict__ logp,
-                                                                  const float* __restrict__ prior,
-                                                                  const int32_t* __restrict__ text_lens,
-                                                                  const int32_t* __restrict__ feat_lens, float log_blank,
-                                                                  float* __restrict__ alpha_ws, float* __restrict__ loss_b,
-                                                                  float* __restrict__ grad) {
+// barrier for LDS hand-offs only: __syncthreads() also drains the vector-memory counter, i.e. it would wait every step for
+// the prefetched loads of four steps ahead and for the workspace store to be acknowledged by L2
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The alpha recursion (blockIdx.y == 0, forward in t) and the beta recursion (blockIdx.y == 1, backward in t) of one
+// utterance do not depend on each other: they run as two workgroups side by side and leave alpha_t(s) / beta_t(s) in the
+// workspace; forward_sum_grad_kernel combines them.  The sequential chain is T steps instead of 2 T.
+__global__ __launch_bounds__(CTC_THREADS) void forward_sum_pass_kernel(int B, int Tf, int Tx, const float* __restrict__ logp,
+                                                                       const float* __restrict__ prior,
+                                                                       const int32_t* __restrict__ text_lens,
+                                                                       const int32_t* __restrict__ feat_lens, float log_blank,
+                                                                       float* __restrict__ ws, float* __restrict__ loss_b) {
   extern __shared__ float sh[];  // 2 columns of S_pad floats (+ 2 guard cells each side)
   const int b = blockIdx.x, tid = threadIdx.x;
+  const bool beta = blockIdx.y == 1;
   int N = text_lens[b], Tn = feat_lens[b];
   if (N > Tx) N = Tx;
   if (Tn > Tf) Tn = Tf;
@@ -45,16 +52,20 @@ __global__ __launch_bounds__(CTC_THREADS) void forward_sum_kernel(int B, int Tf,
   const float NINF = -__builtin_huge_valf();
   const float* lpb = logp + (int64_t)b * Tf * Tx;
   const float* prb = prior + (int64_t)b * Tf * Tx;
-  float* gb = grad + (int64_t)b * Tf * Tx;
-  float* aw = alpha_ws + (int64_t)b * Tf * Spad;
-  for (int i = tid; i < Tf * Tx; i += CTC_THREADS) gb[i] = 0.f;
+  float* w = ws + ((int64_t)b * 2 + (beta ? 1 : 0)) * Tf * Spad;       // alpha_t(s) or beta_t(s), row t
+  float* nll_slot = ws + (int64_t)B * 2 * Tf * Spad + b;
   if (N <= 0 || Tn <= 0) {
-    if (tid == 0) loss_b[b] = 0.f;
+    if (tid == 0 && !beta) { loss_b[b] = 0.f; *nll_slot = __builtin_huge_valf(); }
     return;
   }
   float* col0 = sh + 2;
   float* col1 = sh + 2 + (Spad + 4);
   if (tid < 2) { sh[tid] = NINF; sh[(Spad + 4) + tid] = NINF; }
+  for (int k = 0; k < CTC_KMAX; ++k) {       // guard cells above S: reads of s+1, s+2 beyond the end must see -inf
+    const int s = tid + k * CTC_THREADS;
+    if (s >= S && s < Spad + 2) { col0[s] = NINF; col1[s] = NINF; }
+  }
+  __syncthreads();
 
   // lp(t, s): log-prob of the symbol at extended position s
   auto lp = [&](int t, int s) -> float {
@@ -62,146 +73,100 @@ __global__ __launch_bounds__(CTC_THREADS) void forward_sum_kernel(int B, int Tf,
     const int j = (s - 1) >> 1;
     return lpb[(int64_t)t * Tx + j] + prb[(int64_t)t * Tx + j];
   };
-
-  // ---- alpha ----
+  // one step of either recursion at position s from the previous column
+  auto step = [&](const float* prev, int s, float l) -> float {
+    if (!beta) {
+      const float a1 = prev[s], a2 = prev[s - 1];
+      const float a3 = ((s & 1) && s >= 3) ? prev[s - 2] : NINF;
+      return lse3(a1, a2, a3) + l;
+    }
+    const float b1 = prev[s], b2 = prev[s + 1];
+    const float b3 = ((s & 1) && s + 2 < S) ? prev[s + 2] : NINF;
+    return lse3(b1, b2, b3) + l;
+  };
+  const int t_first = beta ? Tn - 1 : 0, dt = beta ? -1 : 1;       // row t_first + dt * n is the n-th row of the pass
   for (int k = 0; k < CTC_KMAX; ++k) {
     const int s = tid + k * CTC_THREADS;
     if (s < S) {
-      const float v = (s < 2) ? lp(0, s) : NINF;
+      const float v = (beta ? (s >= S - 2) : (s < 2)) ? lp(t_first, s) : NINF;
       col0[s] = v;
-      aw[s] = v;
+      w[(int64_t)t_first * Spad + s] = v;
     }
   }
   __syncthreads();
   float* prev = col0;
   float* cur = col1;
-  // S <= CTC_THREADS (one extended position per thread, the usual case): the two global loads behind lp(t, s) are issued
-  // CTC_PD steps ahead, so a step of the recursion is an LDS round trip + one lse3, not a trip to L2 / HBM
-  const bool one_per_thread = S <= CTC_THREADS;
-  if (one_per_thread) {
+  if (S <= CTC_THREADS) {
+    // one extended position per thread (the usual case): the two global loads behind lp(t, s) are issued CTC_PD steps ahead,
+    // so a step is an LDS round trip + one lse3, not a trip to L2 / HBM
     const int s = tid;
     const bool act = s < S;
     float lq[CTC_PD];
 #pragma unroll
-    for (int q = 0; q < CTC_PD; ++q) lq[q] = (act && 1 + q < Tn) ? lp(1 + q, s) : 0.f;
-    for (int t = 1; t < Tn; t += CTC_PD) {
+    for (int q = 0; q < CTC_PD; ++q) lq[q] = (act && 1 + q < Tn) ? lp(t_first + dt * (1 + q), s) : 0.f;
+    for (int n = 1; n < Tn; n += CTC_PD) {
 #pragma unroll
       for (int q = 0; q < CTC_PD; ++q) {
-        const int tt = t + q;
-        if (tt >= Tn) break;
+        const int nn = n + q;
+        if (nn >= Tn) break;
         const float l = lq[q];
-        if (act && tt + CTC_PD < Tn) lq[q] = lp(tt + CTC_PD, s);
+        if (act && nn + CTC_PD < Tn) lq[q] = lp(t_first + dt * (nn + CTC_PD), s);
         if (act) {
-          const float a1 = prev[s], a2 = prev[s - 1];
-          const float a3 = ((s & 1) && s >= 3) ? prev[s - 2] : NINF;
-          const float v = lse3(a1, a2, a3) + l;
+          const float v = step(prev, s, l);
           cur[s] = v;
-          aw[(int64_t)tt * Spad + s] = v;
+          w[(int64_t)(t_first + dt * nn) * Spad + s] = v;
         }
-        __syncthreads();
+        lds_barrier();
         float* tmp = prev; prev = cur; cur = tmp;
       }
     }
-  }
-  for (int t = 1; t < Tn && !one_per_thread; ++t) {
-    for (int k = 0; k < CTC_KMAX; ++k) {
-      const int s = tid + k * CTC_THREADS;
-      if (s < S) {
-        const float a1 = prev[s], a2 = prev[s - 1];
-        const float a3 = ((s & 1) && s >= 3) ? prev[s - 2] : NINF;
-        const float v = lse3(a1, a2, a3) + lp(t, s);
-        cur[s] = v;
-        aw[(int64_t)t * Spad + s] = v;
+  } else {
+    for (int n = 1; n < Tn; ++n) {
+      const int t = t_first + dt * n;
+      for (int k = 0; k < CTC_KMAX; ++k) {
+        const int s = tid + k * CTC_THREADS;
+        if (s < S) {
+          const float v = step(prev, s, lp(t, s));
+          cur[s] = v;
+          w[(int64_t)t * Spad + s] = v;
+        }
       }
+      __syncthreads();
+      float* tmp = prev; prev = cur; cur = tmp;
     }
-    __syncthreads();
-    float* tmp = prev; prev = cur; cur = tmp;
   }
-  const float nll = -lse2(prev[S - 1], S >= 2 ? prev[S - 2] : NINF);
-  const bool inf_loss = !(nll < __builtin_huge_valf());  // zero_infinity=True
-  if (tid == 0) loss_b[b] = inf_loss ? 0.f : nll / (float)(N < 1 ? 1 : N);
-  if (inf_loss) return;
-  __syncthreads();
+  if (!beta && tid == 0) {
+    const float nll = -lse2(prev[S - 1], S >= 2 ? prev[S - 2] : NINF);
+    const bool inf_loss = !(nll < __builtin_huge_valf());  // zero_infinity=True
+    loss_b[b] = inf_loss ? 0.f : nll / (float)(N < 1 ? 1 : N);
+    *nll_slot = inf_loss ? __builtin_huge_valf() : nll;
+  }
+}
 
-  // ---- beta + gradient ----
-  // guard cells above S: reads of s+1, s+2 beyond the end must see -inf
-  float* bprev = col0;
-  float* bcur = col1;
-  for (int k = 0; k < CTC_KMAX; ++k) {
-    const int s = tid + k * CTC_THREADS;
-    if (s < S + 2 && s < Spad + 2) { bprev[s] = NINF; bcur[s] = NINF; }
-  }
-  __syncthreads();
-  for (int k = 0; k < CTC_KMAX; ++k) {
-    const int s = tid + k * CTC_THREADS;
-    if (s < S) {
-      const float v = (s >= S - 2) ? lp(Tn - 1, s) : NINF;
-      bprev[s] = v;
-      if (s & 1) {
-        const int j = (s - 1) >> 1;
-        const float l = lp(Tn - 1, s);
-        const float ab = aw[(int64_t)(Tn - 1) * Spad + s] + v;
-        gb[(int64_t)(Tn - 1) * Tx + j] = expf(l) - expf(ab + nll - l);
-      }
+// d/d lp[t,c] = exp(lp[t,c]) - exp(alpha_t(s) + beta_t(s) + nll - lp[t,c]), s = 2c + 1, scaled by 1 / (N * B) (reduction='mean'
+// over the single-item batch divides by the target length); 0 outside the utterance and for an infinite loss
+__global__ void forward_sum_grad_kernel(int B, int Tf, int Tx, const float* __restrict__ logp, const float* __restrict__ prior,
+                                        const int32_t* __restrict__ text_lens, const int32_t* __restrict__ feat_lens,
+                                        const float* __restrict__ ws, float* __restrict__ grad) {
+  const int64_t n = (int64_t)B * Tf * Tx;
+  const int Spad = 2 * Tx + 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Tx);
+    const int64_t r = i / Tx;
+    const int t = (int)(r % Tf), b = (int)(r / Tf);
+    int N = text_lens[b], Tn = feat_lens[b];
+    if (N > Tx) N = Tx;
+    if (Tn > Tf) Tn = Tf;
+    const float nll = ws[(int64_t)B * 2 * Tf * Spad + b];
+    float g = 0.f;
+    if (j < N && t < Tn && nll < __builtin_huge_valf()) {
+      const int s = 2 * j + 1;
+      const float l = logp[i] + prior[i];
+      const float a = ws[((int64_t)b * 2 * Tf + t) * Spad + s];
+      const float v = ws[(((int64_t)b * 2 + 1) * Tf + t) * Spad + s];
+      g = (expf(l) - expf(a + v + nll - l)) * (1.f / ((float)(N < 1 ? 1 : N) * (float)B));
     }
-  }
-  __syncthreads();
-  if (one_per_thread) {
-    const int s = tid;
-    const bool act = s < S, lab = act && (s & 1);
-    const int j = (s - 1) >> 1;
-    float lq[CTC_PD], aq[CTC_PD];
-#pragma unroll
-    for (int q = 0; q < CTC_PD; ++q) {
-      const int tt = Tn - 2 - q;
-      lq[q] = (act && tt >= 0) ? lp(tt, s) : 0.f;
-      aq[q] = (lab && tt >= 0) ? aw[(int64_t)tt * Spad + s] : 0.f;
-    }
-    for (int t = Tn - 2; t >= 0; t -= CTC_PD) {
-#pragma unroll
-      for (int q = 0; q < CTC_PD; ++q) {
-        const int tt = t - q;
-        if (tt < 0) break;
-        const float l = lq[q], a = aq[q];
-        if (act && tt - CTC_PD >= 0) lq[q] = lp(tt - CTC_PD, s);
-        if (lab && tt - CTC_PD >= 0) aq[q] = aw[(int64_t)(tt - CTC_PD) * Spad + s];
-        if (act) {
-          const float b1 = bprev[s], b2 = bprev[s + 1];
-          const float b3 = ((s & 1) && s + 2 < S) ? bprev[s + 2] : NINF;
-          const float v = lse3(b1, b2, b3) + l;
-          bcur[s] = v;
-          if (lab) gb[(int64_t)tt * Tx + j] = expf(l) - expf(a + v + nll - l);
-        }
-        __syncthreads();
-        float* tmp = bprev; bprev = bcur; bcur = tmp;
-      }
-    }
-  }
-  for (int t = Tn - 2; t >= 0 && !one_per_thread; --t) {
-    for (int k = 0; k < CTC_KMAX; ++k) {
-      const int s = tid + k * CTC_THREADS;
-      if (s < S) {
-        const float b1 = bprev[s], b2 = bprev[s + 1];
-        const float b3 = ((s & 1) && s + 2 < S) ? bprev[s + 2] : NINF;
-        const float l = lp(t, s);
-        const float v = lse3(b1, b2, b3) + l;
-        bcur[s] = v;
-        if (s & 1) {
-          const int j = (s - 1) >> 1;
-          const float ab = aw[(int64_t)t * Spad + s] + v;
-          gb[(int64_t)t * Tx + j] = expf(l) - expf(ab + nll - l);
-        }
-      }
-    }
-    __syncthreads();
-    float* tmp = bprev; bprev = bcur; bcur = tmp;
-  }
-  // scale by 1 / (N * B): reduction='mean' over the single-item batch divides by target length
-  __syncthreads();
-  const float sc = 1.f / ((float)(N < 1 ? 1 : N) * (float)B);
-  for (int i = tid; i < Tn * Tx; i += CTC_THREADS) {
-    const int j = i % Tx;
-    gb[i] = (j < N) ? gb[i] * sc : 0.f;
+    grad[i] = g;
   }
 }
 
@@ -230,7 +195,7 @@ __global__ void betabinom_prior_kernel(int B, int Tf, int Tx, const int32_t* __r
 }  // namespace
 
 extern "C" int64_t s2svc_forward_sum_ws_bytes(int B, int Tf, int Tx) {
-  return (int64_t)B * Tf * (2 * Tx + 1) * 4;
+  return ((int64_t)B * 2 * Tf * (2 * Tx + 1) + B) * 4;      // alpha and beta tables + the per-utterance nll
 }
 
 // loss_b: (B,) per-utterance nll/N (sum/B is the reference loss); grad: (B,Tf,Tx) d(sum_b loss_b / B)/d(log_p_attn)
@@ -241,9 +206,15 @@ extern "C" int s2svc_forward_sum(int B, int Tf, int Tx, const float* log_p_attn,
   S2S_REQUIRE(2 * Tx + 1 <= CTC_THREADS * CTC_KMAX, "forward_sum: T_text too large");
   if (B == 0) return 0;
   const size_t shm = (size_t)2 * (2 * Tx + 1 + 4) * sizeof(float);
-  hipLaunchKernelGGL(forward_sum_kernel, dim3(B), dim3(CTC_THREADS), shm, (hipStream_t)stream, B, Tf, Tx, log_p_attn, prior,
-                     text_lens, feat_lens, log_blank, (float*)ws, loss_b, grad);
-  S2S_CHECK_LAUNCH("forward_sum_kernel");
+  hipLaunchKernelGGL(forward_sum_pass_kernel, dim3(B, 2), dim3(CTC_THREADS), shm, (hipStream_t)stream, B, Tf, Tx, log_p_attn, prior,
+                     text_lens, feat_lens, log_blank, (float*)ws, loss_b);
+  S2S_CHECK_LAUNCH("forward_sum_pass_kernel");
+  const int64_t n = (int64_t)B * Tf * Tx;
+  int nb = (int)((n + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(forward_sum_grad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, B, Tf, Tx, log_p_attn, prior, text_lens,
+                     feat_lens, (const float*)ws, grad);
+  S2S_CHECK_LAUNCH("forward_sum_grad_kernel");
   return 0;
 }
 
