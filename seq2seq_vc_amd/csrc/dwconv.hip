@@ -146,6 +146,84 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(int B, int Tn, int C,
   if (rl == 0 && c < C) ws[((int64_t)chunk * C + c) * ks + j] = sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl];
 }
 
+// Tiled variant (ks <= KSMAX, halo (ks-1)/2 * dil <= DW_HALO): a workgroup stages DW_ROWS rows of dy and the same rows of x
+// plus the halo for 64 channels in LDS (fp32, one coalesced pass over each tensor instead of one pass per tap), a thread
+// owns one channel and a quarter of the rows and keeps all ks tap sums in registers.
+constexpr int DW_ROWS = 64, DW_HALO = 32;
+template <typename T, int KSMAX>
+__global__ __launch_bounds__(256) void dwconv_wgrad_tiled_kernel(int B, int Tn, int C, int ks, int dil, const T* __restrict__ x,
+                                                                 const T* __restrict__ dy, float* __restrict__ ws,
+                                                                 int rows_per_chunk) {
+  extern __shared__ float dsh[];                    // x tile (DW_ROWS + 2 halo) x 64, dy tile DW_ROWS x 64
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int chunk = blockIdx.y;
+  const int pad = (ks - 1) / 2, halo = pad * dil;
+  float* xt = dsh;
+  float* yt = dsh + (DW_ROWS + 2 * halo) * 64;
+  const int rows = B * Tn;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = (r0 + rows_per_chunk < rows) ? r0 + rows_per_chunk : rows;
+  float acc[KSMAX];
+#pragma unroll
+  for (int j = 0; j < KSMAX; ++j) acc[j] = 0.f;
+  for (int rb = r0; rb < r1; rb += DW_ROWS) {
+    __syncthreads();
+    // batches of 8 independent loads per thread, then the LDS stores (a load-store loop would wait for every load)
+    for (int pb = 0; pb < DW_ROWS + 2 * halo; pb += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = pb + u * 4 + rl, r = rb - halo + p;
+        v[u] = (c < C && p < DW_ROWS + 2 * halo && r >= 0 && r < rows) ? ldf(x + (int64_t)r * C + c) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = pb + u * 4 + rl;
+        if (p < DW_ROWS + 2 * halo) xt[p * 64 + cl] = v[u];
+      }
+    }
+    for (int pb = 0; pb < DW_ROWS; pb += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = pb + u * 4 + rl, r = rb + p;
+        v[u] = (c < C && r < r1) ? ldf(dy + (int64_t)r * C + c) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) yt[(pb + u * 4 + rl) * 64 + cl] = v[u];
+    }
+    __syncthreads();
+    for (int p = rl * (DW_ROWS / 4); p < (rl + 1) * (DW_ROWS / 4); ++p) {
+      const int r = rb + p;
+      if (r >= r1) break;
+      const int t = r % Tn;
+      const float g = yt[p * 64 + cl];
+#pragma unroll
+      for (int j = 0; j < KSMAX; ++j) {
+        if (j < ks) {
+          const int off = (j - pad) * dil, tt = t + off;
+          if (tt >= 0 && tt < Tn) acc[j] += g * xt[(p + halo + off) * 64 + cl];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* red = dsh;                                 // [tap][row group][channel] partial sums (KSMAX x 4 x 64 <= the x tile)
+#pragma unroll
+  for (int j = 0; j < KSMAX; ++j)
+    if (j < ks) red[(j * 4 + rl) * 64 + cl] = acc[j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < ks * 64; e += 256) {
+    const int j = e >> 6, ch = e & 63;
+    const int cc = blockIdx.x * 64 + ch;
+    if (cc < C) {
+      const float* q = red + j * 256 + ch;
+      ws[((int64_t)chunk * C + cc) * ks + j] = q[0] + q[64] + q[128] + q[192];
+    }
+  }
+}
+
 __global__ void dwconv_wgrad_final_kernel(int n, int chunks, const float* __restrict__ ws, float* __restrict__ dw, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -199,6 +277,24 @@ extern "C" int s2svc_dwconv_wgrad(int dtype, int B, int Tn, int C, int ks, int d
   int chunks = (rows + 127) / 128;
   if (chunks > ws_chunks) chunks = ws_chunks;
   const int rpc = (rows + chunks - 1) / chunks;
+  const int halo = (ks - 1) / 2 * dil;
+  if (ks <= 16 && halo <= DW_HALO) {
+    chunks = (rows + DW_ROWS - 1) / DW_ROWS;
+    if (chunks > ws_chunks) chunks = ws_chunks;
+    const int rpc = ((rows + chunks - 1) / chunks + DW_ROWS - 1) / DW_ROWS * DW_ROWS;     // whole tiles per workgroup
+    chunks = (rows + rpc - 1) / rpc;
+    dim3 tgrid((C + 63) / 64, chunks);
+    const size_t shm = (size_t)(2 * DW_ROWS + 2 * halo) * 64 * sizeof(float);
+    if (dtype == S2S_F32)
+      hipLaunchKernelGGL((dwconv_wgrad_tiled_kernel<float, 16>), tgrid, dim3(256), shm, st, B, Tn, C, ks, dil, (const float*)x, (const float*)dy, ws, rpc);
+    else
+      hipLaunchKernelGGL((dwconv_wgrad_tiled_kernel<bf16_t, 16>), tgrid, dim3(256), shm, st, B, Tn, C, ks, dil, (const bf16_t*)x, (const bf16_t*)dy, ws, rpc);
+    S2S_CHECK_LAUNCH("dwconv_wgrad_tiled_kernel");
+    const int n = C * ks;
+    hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, chunks, ws, dw, accumulate);
+    S2S_CHECK_LAUNCH("dwconv_wgrad_final_kernel");
+    return 0;
+  }
   dim3 grid((C + 63) / 64, chunks, ks);
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, grid, dim3(256), 0, st, B, Tn, C, ks, dil, (const float*)x, (const float*)dy, ws, rpc);
