@@ -110,7 +110,8 @@ def gaussian_upsampling(dtype):
 def forward_sum_ctc():
     from scipy.stats import betabinom
     res = []
-    for (B, Tf, Tx, seed) in [(3, 30, 9, 1), (4, 64, 16, 2), (2, 12, 12, 3), (2, 10, 14, 4), (16, 256, 64, 5)]:
+    # (2, 200, 150): 2N+1 > 256 extended positions -> several positions per thread; (3, 6, 2): single-frame / single-token rows
+    for (B, Tf, Tx, seed) in [(3, 30, 9, 1), (4, 64, 16, 2), (2, 12, 12, 3), (2, 10, 14, 4), (16, 256, 64, 5), (2, 200, 150, 6), (3, 6, 2, 7)]:
         gen = torch.Generator().manual_seed(seed)
         lp = torch.log_softmax(torch.randn(B, Tf, Tx, generator=gen), dim=-1)
         tl = torch.randint(max(1, Tx // 2), Tx + 1, (B,), generator=gen)
@@ -118,6 +119,8 @@ def forward_sum_ctc():
         tl[0], fl[0] = Tx, Tf
         if (B, Tf, Tx) == (2, 10, 14):
             tl, fl = torch.tensor([14, 3]), torch.tensor([10, 8])   # utterance 0 is infeasible (N > T): zero_infinity
+        if (B, Tf, Tx) == (3, 6, 2):
+            tl, fl = torch.tensor([2, 1, 1]), torch.tensor([6, 1, 3])
         # CPU reference: exactly the reference's forward (losses/forward_sum_loss.py:58-76) with scipy's prior
         prior = torch.full((B, Tf, Tx), -np.inf)
         for b in range(B):
