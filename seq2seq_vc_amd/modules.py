@@ -10,6 +10,7 @@ Reference files: seq2seq_vc/modules/transformer/*.py, modules/conformer/*.py, mo
 layers/positional_encoding.py.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -163,21 +164,30 @@ class MultiHeadedAttention(nn.Module):
     def _p(self):
         return self.dropout_rate if self.training else 0.0
 
-    def forward(self, query, key, value, klens=None, causal=False, kv=None):
+    def forward(self, query, key, value, klens=None, causal=False, kv=None, passthrough=False):
         """klens: Lens of valid key positions (None = all valid); causal adds j<=i.
         kv: the packed K/V projection of `key` (= `value`) computed by the caller (decoder stacks project the memory
-        for all their layers with ONE GEMM)."""
+        for all their layers with ONE GEMM).
+        passthrough=True (only with the packed projections): returns (out, alias of query) -- a post-LN layer takes its
+        residual from the alias, whose gradient then rides in the query projection's data-gradient GEMM (Fn.linear)."""
         kl = None if klens is None else klens.dev
         f = getattr(self, "_fused", None)   # packed Q/K/V views of the flat parameter buffer (optim.FlatAdam)
+        qp = None
         if kv is not None:
-            q = Fn.linear(query, f["w_q"], f["b_q"])
+            q = Fn.linear(query, f["w_q"], f["b_q"], passthrough=passthrough)
+            if passthrough:
+                q, qp = q
             ctx, self.attn = Fn.attention_packed_kv(q, kv, kl, causal, self.h, self._p())
         elif f is not None and key is value and (query is not key or "w_qkv" in f):
             if query is key:
-                qkv = Fn.linear(query, f["w_qkv"], f["b_qkv"])                      # ONE GEMM, N = 3D
+                qkv = Fn.linear(query, f["w_qkv"], f["b_qkv"], passthrough=passthrough)   # ONE GEMM, N = 3D
+                if passthrough:
+                    qkv, qp = qkv
                 ctx, self.attn = Fn.attention_packed_qkv(qkv, kl, causal, self.h, self._p())
             else:
-                q = Fn.linear(query, f["w_q"], f["b_q"])
+                q = Fn.linear(query, f["w_q"], f["b_q"], passthrough=passthrough)
+                if passthrough:
+                    q, qp = q
                 kv = Fn.linear(key, f["w_kv"], f["b_kv"])                           # ONE GEMM, N = 2D
                 ctx, self.attn = Fn.attention_packed_kv(q, kv, kl, causal, self.h, self._p())
         else:
@@ -185,7 +195,9 @@ class MultiHeadedAttention(nn.Module):
             k = Fn.linear(key, self.linear_k.weight, self.linear_k.bias)
             v = Fn.linear(value, self.linear_v.weight, self.linear_v.bias)
             ctx, self.attn = Fn.attention_core(q, k, v, kl, causal, self.h, self._p())
-        return Fn.linear(ctx, self.linear_out.weight, self.linear_out.bias)
+            qp = query
+        out = Fn.linear(ctx, self.linear_out.weight, self.linear_out.bias)
+        return (out, qp) if passthrough else out
 
 
 class RelPositionMultiHeadedAttention(MultiHeadedAttention):
@@ -232,13 +244,18 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout_rate = dropout_rate
         self.activation = activation
 
-    def forward(self, x):
+    def forward(self, x, passthrough=False):
+        """passthrough=True -> (y, alias of x) for a post-LN residual (Fn.linear)."""
         p = self.dropout_rate if self.training else 0.0
         if self.activation == "relu":      # both GEMMs + dropout / relu masks in their epilogues
-            return Fn.ffn_relu(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, p)
+            return Fn.ffn_relu(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, p, passthrough)
+        xp = None
+        if passthrough:
+            h, xp = Fn.linear(x, self.w_1.weight, self.w_1.bias, passthrough=True)
         else:
-            h = Fn.act_dropout(Fn.linear(x, self.w_1.weight, self.w_1.bias), self.activation, p)
-        return Fn.linear(h, self.w_2.weight, self.w_2.bias)
+            h = Fn.linear(x, self.w_1.weight, self.w_1.bias)
+        y = Fn.linear(Fn.act_dropout(h, self.activation, p), self.w_2.weight, self.w_2.bias)
+        return (y, xp) if passthrough else y
 
 
 class MultiLayeredConv1d(nn.Module):
@@ -265,6 +282,17 @@ class LayerNorm(nn.LayerNorm):
 
     def forward(self, x):
         return Fn.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+_PASS = os.environ.get("S2SVC_NO_PASSTHROUGH", "0") != "1"     # tuning aid: residual gradients through autograd's add
+
+
+def _sub_pass(sub, x, *args, **kw):
+    """sublayer(x, ...) -> (output, x for the residual).  MultiHeadedAttention / PositionwiseFeedForward hand back a
+    pass-through alias of x (their first GEMM's backward absorbs the residual gradient); other sublayers get x itself."""
+    if (_PASS and type(sub) in (MultiHeadedAttention, PositionwiseFeedForward) and torch.is_grad_enabled() and x.requires_grad):
+        return sub(x, *args, passthrough=True, **kw)
+    return sub(x, *args, **kw), x
 
 
 def _res_norm(norm, res, h, p, hscale=1.0):
@@ -296,10 +324,12 @@ class EncoderLayer(nn.Module):
             y2, x = _res_norm(self.norm2, x, a, p)
             f = self.feed_forward(y2)
             return x, f  # caller adds f with dropout (fused into the next LayerNorm)
-        a = self.self_attn(x, x, x, klens)
-        x, _ = _res_norm(self.norm1, x, a, p)
-        f = self.feed_forward(x)
-        x, _ = _res_norm(self.norm2, x, f, p)
+        # post-LN: x feeds the sublayer AND the residual; the residual takes it from the sublayer's pass-through alias so
+        # that the two gradients meet inside the first data-gradient GEMM instead of in an element-wise add
+        a, xr = _sub_pass(self.self_attn, x, x, x, klens)
+        x, _ = _res_norm(self.norm1, xr, a, p)
+        f, xr = _sub_pass(self.feed_forward, x)
+        x, _ = _res_norm(self.norm2, xr, f, p)
         return x, None
 
 
@@ -323,12 +353,12 @@ class DecoderLayer(nn.Module):
             a = self.src_attn(y, memory, memory, mem_lens, kv=kv)
             y, x = _res_norm(self.norm3, x, a, p)
             return x, self.feed_forward(y)
-        a = self.self_attn(x, x, x, tgt_lens, causal=causal)
-        x, _ = _res_norm(self.norm1, x, a, p)
-        a = self.src_attn(x, memory, memory, mem_lens, kv=kv)
-        x, _ = _res_norm(self.norm2, x, a, p)
-        f = self.feed_forward(x)
-        x, _ = _res_norm(self.norm3, x, f, p)
+        a, xr = _sub_pass(self.self_attn, x, x, x, tgt_lens, causal=causal)
+        x, _ = _res_norm(self.norm1, xr, a, p)
+        a, xr = _sub_pass(self.src_attn, x, memory, memory, mem_lens, kv=kv)
+        x, _ = _res_norm(self.norm2, xr, a, p)
+        f, xr = _sub_pass(self.feed_forward, x)
+        x, _ = _res_norm(self.norm3, xr, f, p)
         return x, None
 
 

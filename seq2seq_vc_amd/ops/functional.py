@@ -268,8 +268,12 @@ def _reduce_to(p_sum, p_dot, mode, dy, x=None, mean=None, rstd=None):
 # Linear (+bias, +activation)          reference: torch.nn.Linear call sites of the hot path
 # ================================================================================================
 class _Linear(Function):
+    """y = act(x W^T + b).  passthrough=True additionally returns an alias of x: a post-LN residual that takes x from there
+    sends its gradient back through this node, where it rides in the epilogue of the data-gradient GEMM (dX = dY W + g_pass)
+    instead of costing an element-wise add on the main chain."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, passthrough=False):
         dtype = x.dtype
         x2 = _c(x).view(-1, x.shape[-1])
         M, Kd = x2.shape
@@ -282,10 +286,15 @@ class _Linear(Function):
         ctx.params = (weight, bias)
         ctx.save_for_backward(x2, w, y if act else None)
         ctx.xshape = x.shape
+        if passthrough:
+            ctx.set_materialize_grads(False)
+            return y.view(*x.shape[:-1], N), x.view_as(x)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_pass=None):
+        if dy is None:                 # only the pass-through output was used
+            return g_pass, None, None, None, None
         x2, w, y = ctx.saved_tensors
         weight, bias = ctx.params
         M, Kd = x2.shape
@@ -297,7 +306,8 @@ class _Linear(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
-            K.gemm(K.operand(dy2, N), _dgrad_operand(weight, w, N, Kd, dtype), M, Kd, N, dx, in_dtype=dtype)
+            res = _c(g_pass).view(M, Kd).to(dtype) if g_pass is not None else None
+            K.gemm(K.operand(dy2, N), _dgrad_operand(weight, w, N, Kd, dtype), M, Kd, N, dx, in_dtype=dtype, res=res)
             dx = dx.view(ctx.xshape)
         dw = db = None
         if weight.requires_grad:
@@ -315,11 +325,12 @@ class _Linear(Function):
                     dw = dw.view(weight.shape)  # 1x1 Conv1d weights (N, K, 1) are accepted as Linear weights
         elif ctx.has_bias and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy2)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear(x, weight, bias=None, act=None):
-    return _Linear.apply(x, weight, bias, act)
+def linear(x, weight, bias=None, act=None, passthrough=False):
+    """passthrough=True -> (y, x_alias), see _Linear."""
+    return _Linear.apply(x, weight, bias, act, passthrough)
 
 
 class _FFNRelu(Function):
@@ -328,7 +339,7 @@ class _FFNRelu(Function):
     epilogue (h > 0 <=> relu active and kept), so no element-wise pass over the (rows, hidden) tensor remains."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, p):
+    def forward(ctx, x, w1, b1, w2, b2, p, passthrough=False):
         dtype = x.dtype
         x2 = _c(x).view(-1, x.shape[-1])
         M, Kd = x2.shape
@@ -342,10 +353,15 @@ class _FFNRelu(Function):
         ctx.params = (w1, b1, w2, b2)
         ctx.meta = (p, seed, x.shape)
         ctx.save_for_backward(x2, h, w1c, w2c)
+        if passthrough:                # (y, alias of x): see _Linear
+            ctx.set_materialize_grads(False)
+            return y.view(*x.shape[:-1], N), x.view_as(x)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_pass=None):
+        if dy is None:
+            return g_pass, None, None, None, None, None, None
         x2, h, w1c, w2c = ctx.saved_tensors
         w1, b1, w2, b2 = ctx.params
         p, seed, xshape = ctx.meta
@@ -359,7 +375,8 @@ class _FFNRelu(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
-            K.gemm(K.operand(du, Hd), _dgrad_operand(w1, w1c, Hd, Kd, dtype), M, Kd, Hd, dx, in_dtype=dtype)
+            res = _c(g_pass).view(M, Kd).to(dtype) if g_pass is not None else None
+            K.gemm(K.operand(du, Hd), _dgrad_operand(w1, w1c, Hd, Kd, dtype), M, Kd, Hd, dx, in_dtype=dtype, res=res)
             dx = dx.view(xshape)
 
         def wgrad(weight, bias, g, a, n_out, n_in):
@@ -376,11 +393,11 @@ class _FFNRelu(Function):
             return (dw.view(weight.shape) if dw is not None else None), db
         dw2, db2 = wgrad(w2, b2, dy2, h, N, Hd) if w2.requires_grad else (None, None)
         dw1, db1 = wgrad(w1, b1, du, x2, Hd, Kd) if w1.requires_grad else (None, None)
-        return dx, dw1, db1, dw2, db2, None
+        return dx, dw1, db1, dw2, db2, None, None
 
 
-def ffn_relu(x, w1, b1, w2, b2, p=0.0):
-    return _FFNRelu.apply(x, w1, b1, w2, b2, p)
+def ffn_relu(x, w1, b1, w2, b2, p=0.0, passthrough=False):
+    return _FFNRelu.apply(x, w1, b1, w2, b2, p, passthrough)
 
 
 class _Embedding(Function):
