@@ -1161,7 +1161,10 @@ class _BatchNormAct(Function):
         dx = K.bn_bwd(dy, x, mean, rstd, gamma, sdy, sdyx, use_batch_stats=training)
         dgamma = dbeta = None
         if gamma.requires_grad:
-            dgamma, dbeta = _emit_vgrad(gamma, sdyx), _emit_vgrad(beta, sdy)
+            if _slotted(gamma, beta):      # the two accumulations into the gradient slots leave the data-gradient chain
+                _side_run(lambda: (_emit_vgrad(gamma, sdyx), _emit_vgrad(beta, sdy)), keep=(sdy, sdyx))
+            else:
+                dgamma, dbeta = _emit_vgrad(gamma, sdyx), _emit_vgrad(beta, sdy)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
