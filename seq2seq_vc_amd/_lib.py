@@ -45,8 +45,9 @@ def build_library(force=False, verbose=True):
         # only while another stream kept the chip busy, a wrong element in the last partially active 16-lane row of a wave
         # (same inputs, different output); without them 0 of 800 full AAS-VC steps differ ("Reproducibility").
         # The step times are unchanged (the arithmetic that matters is MFMA and explicit 16-byte memory operations).
+        # -fno-vectorize: the loop vectoriser forms the same packed operations in a few element-wise kernels.
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize",
-               "-c", src, "-o", obj]
+               "-fno-vectorize", "-c", src, "-o", obj]
         if verbose:
             print("[s2svc build]", " ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
