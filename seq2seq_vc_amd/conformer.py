@@ -162,7 +162,10 @@ class ConformerEncoder(nn.Module):
         pos_emb = None
         if isinstance(xs, tuple):
             xs, pos_emb = xs
-        for layer in self.encoders:
+        cut_name = getattr(self, "cut_name", None)      # data-parallel overlap: "<name>.<i>" cuts the graph at the input of layer i
+        for li, layer in enumerate(self.encoders):
+            if cut_name is not None and li > 0:
+                xs = Fn.cut_point(xs, f"{cut_name}.{li}")
             xs = layer(xs, pos_emb, lens)
         if self.normalize_before:
             xs = self.after_norm(xs)

@@ -83,7 +83,10 @@ class ARDecodeSession:
 
     @staticmethod
     def _version(model):
-        return tuple(p._version for p in model.parameters())
+        """Identity of the weights a session copied: tensor versions (in-place torch updates, load_state_dict) plus the
+        generation counter that optim.FlatAdam advances -- its fused step updates the flat buffer through a raw pointer,
+        which bumps no tensor version."""
+        return (model.__dict__.get("_s2s_weight_gen", 0),) + tuple(p._version for p in model.parameters())
 
     # -- one decoder position for all utterances (every launch reads the device-resident `pos`) -------------
     def _lin(self, x, wb, act=None):

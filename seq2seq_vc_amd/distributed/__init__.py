@@ -1,15 +1,30 @@
-"""Data-parallel helpers: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl").
+"""Data-parallel training: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl").
 
-The reference wraps the model in apex DistributedDataParallel (bin/vc_train.py:423-431), i.e. an averaged
-gradient all-reduce per step plus an initial parameter broadcast; BatchNorm statistics stay rank-local.
-Here the gradients already live in ONE flat fp32 buffer (optim.FlatAdam), so the exchange is a few large
-collectives instead of one per tensor.  xGMI is point-to-point (7 links per GPU), so large messages are
-what reaches link bandwidth; `chunk_numel` keeps each collective big (default 32 Mi elements = 128 MiB)
-while letting the first chunks start before the last are issued.
+The reference wraps the model in apex DistributedDataParallel (bin/vc_train.py:423-431): an averaged gradient all-reduce
+per optimiser step, overlapped with the backward pass through per-bucket hooks, plus a parameter broadcast at wrap time;
+BatchNorm statistics stay rank-local and rank 0's buffers are what a checkpoint holds (trainers/base.py:98-101).
+
+Here the gradients already live in ONE flat fp32 buffer (optim.FlatAdam) that the weight-gradient kernels write into
+directly -- autograd never sees them, so there are no per-parameter hooks to hang a bucket on.  Instead the model names a
+few *gradient cuts* (ops.functional.cut_point) and a stage plan (`model.dp_plan()`): the backward pass runs stage by
+stage, every stage finishes the gradients of one contiguous range of the flat buffer, and that range's all-reduce is
+started (asynchronously, on RCCL's stream) before the next stage is launched:
+
+    VTN / TTS   [decoder + heads + postnet]  ->  [encoder]                                            2 buckets, 122 MB
+    AAS-VC      [dec layer 3 + heads + postnet] -> [dec 2] -> [dec 1] -> [dec 0] -> [aligner + duration predictor]
+                -> [encoder]                                                                            6 buckets, 630 MB
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU), so large messages are what reaches link bandwidth: a bucket is one
+contiguous slice (>= 28 MB), split into 128 MiB collectives only above that.  `payload="bf16"` halves the bytes on the links:
+the slice is cast into a bf16 staging buffer, summed over the ranks in bf16 and cast back (the fp32 gradients of a rank are
+rounded once; the sum of 8 ranks then carries bf16 rounding, ~3 significant digits, which Adam's normalisation tolerates;
+fp32 is the default and the parity setting).  The 1/world of the mean rides on the loss, so the collectives are plain sums.
 """
 import os
 
 import torch
+
+from ..ops import functional as Fn
 
 
 def init_from_env(backend=None):
@@ -60,3 +75,135 @@ def broadcast_(flat, dist, world, src=0, group=None):
     if world > 1:
         dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+def broadcast_model_(model, optimizer, dist, world, src=0, group=None):
+    """Rank `src`'s parameters and buffers to everyone (apex DDP's wrap-time broadcast, bin/vc_train.py:431): the flat
+    parameter buffer in one collective (optim.FlatAdam) or tensor by tensor (torch optimisers), then the buffers
+    (BatchNorm running statistics).  Afterwards the bf16 shadows are refreshed."""
+    if world <= 1:
+        return
+    flat = getattr(optimizer, "flat_p", None)
+    if flat is not None:
+        dist.broadcast(flat, src=src, group=group)
+        listed = {id(p) for p in optimizer.params}
+        rest = [p for p in model.parameters() if id(p) not in listed]       # frozen parameters live outside the flat buffer
+    else:
+        rest = list(model.parameters())
+    for t in rest + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+    if hasattr(optimizer, "refresh_shadow"):
+        optimizer.refresh_shadow()
+
+
+class OverlappedBackward:
+    """The backward pass of one data-parallel step, stage by stage, with the gradient exchange of every finished stage in
+    flight while the next one runs (see the module docstring).
+
+        ob = OverlappedBackward(model, optimizer, dist, world)
+        with ob.forward_context():                 # activates the model's gradient cuts
+            out = model(...); losses = {"loss": l1 + bce}          # keys as named by model.dp_plan()
+        ob.backward(losses)                        # stages + asynchronous all-reduces, joined before it returns
+        optimizer.step()
+
+    For hipGraph replay the pieces are exposed separately: `run_stage(i, losses)` (capturable: launches kernels only),
+    `begin_reduce(i)` (RCCL calls, issued between graph replays) and `finish()`.
+    """
+
+    def __init__(self, model, optimizer, dist, world, payload="fp32", chunk_numel=32 * 1024 * 1024, group=None, force=False,
+                 plan=None):
+        if not hasattr(optimizer, "flat_g"):
+            raise TypeError("OverlappedBackward needs optim.FlatAdam (gradients in one flat buffer)")
+        if payload not in ("fp32", "bf16"):
+            raise ValueError("payload must be 'fp32' or 'bf16'")
+        self.model, self.opt, self.dist, self.world, self.group = model, optimizer, dist, max(1, int(world)), group
+        self.force, self.chunk, self.payload = force, chunk_numel, payload
+        self.plan = plan if plan is not None else model.dp_plan()
+        self.cuts = Fn.GradCuts([st["root"][4:] for st in self.plan if st["root"].startswith("cut:")])
+        self.ranges = [optimizer.param_ranges(st["modules"]) for st in self.plan]
+        covered = sorted(r for rs in self.ranges for r in rs)
+        pos = 0
+        for lo, hi in covered:
+            if lo != pos:
+                break
+            pos = hi
+        if pos != optimizer.numel:
+            raise RuntimeError("the model's dp_plan() does not cover every trainable parameter exactly once "
+                               f"(covered up to {pos} of {optimizer.numel} elements)")
+        self.scale = 1.0 / self.world
+        self.stage_buf = torch.empty(optimizer.numel, dtype=torch.bfloat16, device=optimizer.flat_g.device) if payload == "bf16" else None
+        self.handles, self.pending_bf16 = [], []
+
+    # -- pieces ---------------------------------------------------------------------------------------------
+    def forward_context(self):
+        return Fn.grad_cuts(self.cuts)
+
+    def active(self):
+        return self.world > 1 or self.force
+
+    def run_stage(self, i, losses, scale=None):
+        """Backward of stage i: from a loss (`loss:<key>`) or from below a cut (`cut:<name>`), then the join of the
+        parameter-gradient side work, so that the stage's slice of the flat gradient buffer is final on the current stream."""
+        root = self.plan[i]["root"]
+        if root.startswith("loss:"):
+            loss = losses.get(root[5:])
+            if loss is not None and loss.requires_grad:
+                s = self.scale if scale is None else scale
+                (loss * s if s != 1.0 else loss).backward()
+        else:
+            self.cuts.resume(root[4:])
+        Fn.side_join()
+
+    def begin_reduce(self, i):
+        if not self.active():
+            return
+        from ..ops import kernels as K
+        for lo, hi in self.ranges[i]:
+            if self.stage_buf is not None:
+                K.cast(self.opt.flat_g[lo:hi], torch.bfloat16, out=self.stage_buf[lo:hi])
+                buf = self.stage_buf[lo:hi]
+                self.pending_bf16.append((lo, hi))
+            else:
+                buf = self.opt.flat_g[lo:hi]
+            self.handles += allreduce_sum_begin(buf, self.dist, self.world, self.chunk, self.group, force=True)
+
+    def finish(self):
+        allreduce_end(self.handles)
+        self.handles = []
+        if self.pending_bf16:
+            from ..ops import kernels as K
+            for lo, hi in self.pending_bf16:
+                K.cast(self.stage_buf[lo:hi], torch.float32, out=self.opt.flat_g[lo:hi])
+            self.pending_bf16 = []
+
+    # -- the whole thing (eager; the trainers) -----------------------------------------------------------------
+    def backward(self, losses, reduce=True, scale=None):
+        """reduce=False: a gradient-accumulation micro-step (no exchange; the buffer keeps accumulating).
+        scale: factor on the loss (default 1/world; with gradient accumulation 1/(world * accumulate steps))."""
+        for i in range(len(self.plan)):
+            self.run_stage(i, losses, scale)
+            if reduce:
+                self.begin_reduce(i)
+        if reduce:
+            self.finish()
+        self.cuts.clear()
+
+    def bucket_bytes(self):
+        e = 2 if self.payload == "bf16" else 4
+        return [sum(hi - lo for lo, hi in rs) * e for rs in self.ranges]
+
+
+def allreduce_grads_(params, dist, world, group=None):
+    """Mean all-reduce of `p.grad` for torch optimisers (no flat buffer): one coalesced collective."""
+    if world <= 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    o = 0
+    for g in grads:
+        g.copy_(flat[o:o + g.numel()].view_as(g))
+        o += g.numel()

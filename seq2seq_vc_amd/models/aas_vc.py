@@ -142,6 +142,25 @@ class AASVC(nn.Module):
         self.postnet = None if postnet_layers == 0 else Mo.Postnet(
             idim=idim, odim=odim, n_layers=postnet_layers, n_chans=postnet_chans, n_filts=postnet_filts,
             use_batch_norm=use_batch_norm, dropout_rate=postnet_dropout_rate)
+        self.decoder.cut_name = "decoder"
+
+    def dp_plan(self):
+        """Stages of the data-parallel backward pass (distributed.OverlappedBackward).  The decoder holds 113 M of the 157 M
+        parameters of the vc2 configuration (4 layers x 28 M at d = 1536), so it is cut layer by layer: each layer's 113 MB of
+        fp32 gradients travels while the next layer's backward pass runs.  Two loss keys: "decoder" (the L1 loss: reaches the
+        postnet / decoder / length regulator) and "align" (forward-sum + binarisation + duration losses: reach the alignment
+        module and the duration predictor); below the cut at the encoder output both meet and the encoder runs last."""
+        dec = list(self.decoder.encoders)
+        tail = [m for m in (getattr(self.decoder, "after_norm", None), self.feat_out, self.postnet) if m is not None]
+        plan = [{"root": "loss:decoder", "modules": [dec[-1]] + tail}]
+        for li in range(len(dec) - 1, 0, -1):
+            plan.append({"root": f"cut:decoder.{li}", "modules": [dec[li - 1]]})
+        side = [self.alignment_module, self.duration_predictor]
+        if hasattr(self, "duration_predictor_projection"):
+            side.append(self.duration_predictor_projection)
+        plan.append({"root": "loss:align", "modules": side})
+        plan.append({"root": "cut:encoder_out", "modules": [self.encoder]})
+        return plan
 
     # ---------------------------------------------------------------------------------------------
     def _forward(self, xs, ilens, ys=None, olens=None, dp_inputs=None, dplens=None, spembs=None, is_inference=False):
@@ -157,6 +176,7 @@ class AASVC(nn.Module):
             xs = xs.contiguous().view(b, tmax // er, dim * er)
             il = il.map(lambda v: v // er)
         hs, _ = self.encoder(Fn.to_compute(xs), il)
+        hs = Fn.cut_point(hs, "encoder_out")
         if self.encoder_input_layer == "conv2d":
             il = il.map(lambda v: ((v - 2 + 1) // 2 - 2 + 1) // 2)
         if pr > 1:

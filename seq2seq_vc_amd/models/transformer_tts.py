@@ -51,6 +51,7 @@ class TransformerTTS(_ARSeq2Seq):
         xs[torch.arange(xs.shape[0], device=xs.device), il.dev.long()] = self.eos
         il1 = il.map(lambda v: v + 1)
         hs, hs_lens = self.encoder(xs, il1)
+        hs = Fn.cut_point(hs, "encoder_out")
         after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens)
         att_ws = []
         if self.use_guided_attn_loss:

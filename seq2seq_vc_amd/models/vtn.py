@@ -32,6 +32,13 @@ class _ARSeq2Seq(nn.Module):
         self.postnet = Mo.Postnet(idim=idim, odim=odim, n_layers=postnet_layers, n_chans=postnet_chans, n_filts=postnet_filts,
                                   use_batch_norm=use_batch_norm)
 
+    def dp_plan(self):
+        """Stages of the data-parallel backward pass (distributed.OverlappedBackward): the decoder side finishes first and its
+        gradients (2/3 of the parameters) travel while the encoder's backward pass -- below the cut at the encoder output --
+        runs.  One loss key: "loss"."""
+        dec_side = [m for m in (self.decoder, self.feat_out, self.prob_out, self.postnet) if m is not None]
+        return [{"root": "loss:loss", "modules": dec_side}, {"root": "cut:encoder_out", "modules": [self.encoder]}]
+
     def _teacher_forced(self, hs, hs_lens, ys, labels, olens):
         r, odim = self.decoder_reduction_factor, self.odim
         dev = ys.device
@@ -176,14 +183,7 @@ class VTN(_ARSeq2Seq):
         if ol.max() != ys.shape[1]:
             ys, labels = ys[:, : ol.max()], labels[:, : ol.max()]
         hs, hs_lens = self.encoder(Fn.to_compute(xs), il)
-        cut = kwargs.get("_memory_cut")
-        if cut is not None:
-            # data-parallel overlap (bench.py): the autograd graph is cut at the encoder output, so that the decoder-side
-            # gradients are complete -- and their all-reduce can start -- before the encoder's backward pass runs:
-            #   loss.backward()  ->  cut["decoder_in"].grad ;  cut["encoder_out"].backward(cut["decoder_in"].grad)
-            cut["encoder_out"] = hs
-            hs = hs.detach().requires_grad_(True)
-            cut["decoder_in"] = hs
+        hs = Fn.cut_point(hs, "encoder_out")      # data-parallel overlap: decoder-side gradients travel during the encoder's backward
         after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens)
         ilens_ds_st = torch.tensor([((v - 2 + 1) // 2 - 2 + 1) // 2 for v in il.host],
                                    dtype=ilens.dtype if isinstance(ilens, torch.Tensor) else torch.long,

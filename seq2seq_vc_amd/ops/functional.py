@@ -82,6 +82,62 @@ def _emit_vgrad(param, value):
 
 
 # ------------------------------------------------------------------------------------------------
+# Gradient cuts (data-parallel overlap).  A model's forward marks a few tensors with cut_point(x, name).  Normally that is
+# the identity.  Inside `with grad_cuts(GradCuts([...]))` the autograd graph is cut there: the consumer sees a detached leaf,
+# so loss.backward() stops at it, and `cuts.resume(name)` later continues the backward pass below the cut.  Everything
+# above a cut has then finished its parameter gradients and their all-reduce can travel while the rest of the backward
+# pass runs (distributed.OverlappedBackward); each piece can also be captured as its own hipGraph with the collectives
+# issued between the replays.  Values and gradients are exactly those of the uncut graph.
+# ------------------------------------------------------------------------------------------------
+class GradCuts:
+    def __init__(self, names):
+        self.names = set(names)
+        self.points = {}          # name -> (tensor above the cut [graph side of the producer], detached leaf the consumers see)
+
+    def cut(self, x, name):
+        if name not in self.names or not (torch.is_grad_enabled() and x.requires_grad):
+            return x
+        if name in self.points:
+            raise RuntimeError(f"gradient cut '{name}' was reached twice in one forward pass")
+        inner = x.detach().requires_grad_(True)
+        self.points[name] = (x, inner)
+        return inner
+
+    def resume(self, name):
+        """Continue the backward pass below the cut (no-op if the forward pass never reached it or nothing above it
+        needed the gradient)."""
+        outer, inner = self.points.get(name, (None, None))
+        if outer is not None and inner.grad is not None:
+            outer.backward(inner.grad)
+
+    def clear(self):
+        self.points.clear()
+
+
+_CUTS = {"active": None}
+
+
+class grad_cuts:
+    def __init__(self, cuts):
+        self.cuts = cuts
+
+    def __enter__(self):
+        self.prev, _CUTS["active"] = _CUTS["active"], self.cuts
+        if self.cuts is not None:
+            self.cuts.clear()
+        return self.cuts
+
+    def __exit__(self, *exc):
+        _CUTS["active"] = self.prev
+        return False
+
+
+def cut_point(x, name):
+    c = _CUTS["active"]
+    return x if c is None else c.cut(x, name)
+
+
+# ------------------------------------------------------------------------------------------------
 # Side streams for parameter-gradient work.  Weight / bias / LayerNorm gradients are only consumed by
 # the optimiser at the end of the step, so (when they land in flat-gradient slots) their kernels are
 # issued on a small pool of side HIP streams and overlap with the data-gradient chain on the main

@@ -479,10 +479,12 @@ def glu_bwd(x, dy):
     return dx
 
 
-def cast(x, dtype):
-    if x.dtype == dtype:
+def cast(x, dtype, out=None):
+    if x.dtype == dtype and out is None:
         return x
-    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    y = torch.empty(x.shape, dtype=dtype, device=x.device) if out is None else out
+    if out is not None and (out.dtype != dtype or out.numel() != x.numel() or not out.is_contiguous() or not x.is_contiguous()):
+        raise ValueError("cast(out=): contiguous tensors of the target dtype and the same size are required")
     _lib.check(_lib.lib().s2svc_cast(dt(x), _DT[dtype], x.numel(), ptr(x), ptr(y), stream()), "cast")
     return y
 

@@ -20,9 +20,13 @@ from .ops import kernels as K
 class FlatAdam:
     def __init__(self, model, lr=8e-5, betas=(0.9, 0.999), eps=1e-8, grad_norm=1.0, warmup_steps=4000, bf16_shadow=False,
                  align=64, fuse_qkv=True, transposed_shadow=True):
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        # torch.optim.Adam(model.parameters()) -- what the reference builds (bin/vc_train.py:405-416) -- numbers its state by
+        # position in model.parameters(), frozen parameters included; kept for checkpoint interchange (state_dict below)
+        self.all_params = list(model.parameters())
+        self.params = [p for p in self.all_params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
+        self._model = model
         # lay the Q/K/V weights (and biases) of every attention module out back to back, so that
         # [Wq;Wk;Wv] is ONE (3D, D) matrix in the flat buffer (fused projection GEMMs, see modules.py)
         stacks = self._source_attention_stacks(model) if fuse_qkv else []
@@ -172,8 +176,14 @@ class FlatAdam:
             t._s2s_bf16 = self.shadow[off:off + n].view(shape)
         return t
 
+    def _touch(self):
+        """The parameters changed through raw pointers (no tensor version bump): advance the model's weight generation so
+        that cached derived state (decode sessions with packed / bf16 weight copies, decode.py) is rebuilt."""
+        self._model.__dict__["_s2s_weight_gen"] = self._model.__dict__.get("_s2s_weight_gen", 0) + 1
+
     def refresh_shadow(self):
         """bf16 copy of the fp32 master weights (after loading a checkpoint / at start)."""
+        self._touch()
         if self.shadow is not None:
             self.shadow.copy_(K.cast(self.flat_p, torch.bfloat16))
             self._refresh_transposed()
@@ -184,16 +194,30 @@ class FlatAdam:
 
     def param_range(self, module):
         """[lo, hi) of the flat buffers covered by the parameters of `module`, or None if parameters of other modules
-        lie inside that range (data-parallel bucketing by sub-network, bench.py)."""
-        mine = {id(p) for p in module.parameters()}
-        spans = [(o, o + p.numel()) for p, o in zip(self.params, self.offsets) if id(p) in mine]
-        if not spans:
-            return None
-        lo, hi = min(a for a, _ in spans), max(b for _, b in spans)
-        for p, o in zip(self.params, self.offsets):
-            if id(p) not in mine and lo <= o < hi:
-                return None
-        return lo, hi
+        lie inside that range."""
+        r = self.param_ranges([module])
+        return r[0] if r is not None and len(r) == 1 else None
+
+    def param_ranges(self, modules):
+        """Maximal contiguous [lo, hi) ranges of the flat buffers that hold exactly the trainable parameters of `modules`
+        (alignment gaps between neighbours are absorbed): the buckets of the data-parallel gradient exchange.  Returns []
+        if the modules have no trainable parameters."""
+        mine = set()
+        for m in modules:
+            mine.update(id(p) for p in (m.parameters() if isinstance(m, torch.nn.Module) else [m]))
+        order = sorted(zip(self.offsets, self.params), key=lambda t: t[0])
+        ranges, cur = [], None
+        for i, (o, p) in enumerate(order):
+            end = order[i + 1][0] if i + 1 < len(order) else self.numel      # up to the next parameter (absorbs the padding)
+            if id(p) in mine:
+                if cur is not None and cur[1] == o:
+                    cur[1] = end
+                else:
+                    cur = [o, end]
+                    ranges.append(cur)
+            else:
+                cur = None
+        return [tuple(r) for r in ranges]
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
@@ -202,19 +226,75 @@ class FlatAdam:
         K.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.shadow, self.state, self.partial, self.lr,
                     self.betas, self.eps, self.grad_norm, self.warmup_steps)
         self._refresh_transposed()
+        self._touch()
 
     # -- introspection (host sync; for logging / tests only) -------------------------------------
     def last_stats(self):
         s = self.state.tolist()
         return {"step": int(s[0]), "lr": s[1], "grad_norm": s[2], "clip_coef": s[3]}
 
+    # -- checkpoints: the reference saves `optimizer.state_dict()` of torch.optim.Adam (trainers/base.py:85-105) --------------
     def state_dict(self):
-        return {"step": self.state.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "offsets": list(self.offsets), "lr": self.lr, "betas": self.betas, "eps": self.eps,
-                "grad_norm": self.grad_norm, "warmup_steps": self.warmup_steps}
+        """torch.optim.Adam's format -- {"state": {i: {step, exp_avg, exp_avg_sq}}, "param_groups": [...]} with i = position
+        in model.parameters() -- so that the reference (or a stock torch Adam over the same model) resumes from a checkpoint
+        written here and vice versa.  Deviation (documented): ONE step counter for all parameters, so every entry carries the
+        same `step`; torch keeps one per parameter, which only differs for parameters that joined training late."""
+        step = self.state[0].detach().cpu().clone()
+        off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+        state = {}
+        if float(step) > 0:
+            for i, p in enumerate(self.all_params):
+                o = off_of.get(id(p))
+                if o is None:
+                    continue
+                k = p.numel()
+                state[i] = {"step": step.clone(), "exp_avg": self.exp_avg[o:o + k].view(p.shape).detach().cpu().clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape).detach().cpu().clone()}
+        group = {"lr": float(self.state[1]) if float(step) > 0 else self.lr, "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "initial_lr": self.lr, "params": list(range(len(self.all_params)))}
+        return {"state": state, "param_groups": [group],
+                "s2svc": {"grad_norm": self.grad_norm, "warmup_steps": self.warmup_steps, "layout": "torch.optim.Adam"}}
 
     def load_state_dict(self, sd):
-        self.state.copy_(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """Accepts torch.optim.Adam state dicts (reference checkpoints) and the flat format of round 1."""
+        if "state" in sd and "param_groups" in sd:
+            ids = sd["param_groups"][0]["params"]
+            if len(ids) != len(self.all_params):
+                raise ValueError(f"optimizer state is for {len(ids)} parameters, the model has {len(self.all_params)}")
+            pos = {pid: i for i, pid in enumerate(ids)}
+            off_of = {id(p): o for p, o in zip(self.params, self.offsets)}
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            steps = set()
+            for pid, st in sd["state"].items():
+                i = pos[pid]
+                p = self.all_params[i]
+                o = off_of.get(id(p))
+                if o is None:
+                    continue            # state of a parameter that is frozen here
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"optimizer state {pid}: shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+                k = p.numel()
+                self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                import logging
+                logging.warning(f"per-parameter Adam steps {sorted(steps)} differ; FlatAdam keeps one counter and resumes at {max(steps)}")
+            g = sd["param_groups"][0]
+            self.lr = float(g.get("initial_lr", self.lr))
+            self.betas, self.eps = tuple(g.get("betas", self.betas)), float(g.get("eps", self.eps))
+            extra = sd.get("s2svc", {})
+            self.grad_norm = float(extra.get("grad_norm", self.grad_norm))
+            self.warmup_steps = float(extra.get("warmup_steps", self.warmup_steps))
+            self.state.zero_()
+            self.state[0] = float(max(steps)) if steps else 0.0
+        else:
+            if list(sd.get("offsets", [])) != list(self.offsets) or sd["exp_avg"].numel() != self.numel:
+                raise ValueError("flat optimizer state was written for a different parameter layout (frozen modules, fused "
+                                 "projections or alignment differ); re-save it in the torch.optim.Adam format")
+            self.state.copy_(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.refresh_shadow()

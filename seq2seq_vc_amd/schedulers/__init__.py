@@ -36,17 +36,34 @@ class NoamLR(_LRScheduler):
 
 
 class FusedWarmupLR(object):
-    """Placeholder scheduler for optim.FlatAdam (the schedule runs inside the optimiser kernel): keeps the
-    trainer's `scheduler.step()` / `state_dict()` call sites valid."""
+    """Scheduler object for optim.FlatAdam.  The WarmupLR value is computed on the device inside the fused optimiser
+    step (csrc/optim.hip) from the optimiser's own step counter, so `step()` has nothing to do; the object keeps the
+    trainer's `scheduler.step()` / `state_dict()` / `load_state_dict()` call sites valid and its state dict has the keys
+    of the reference's `WarmupLR(_LRScheduler)` (schedulers/warmup_lr.py:23-61; `last_epoch`, `_step_count`, `base_lrs`,
+    `_last_lr`, `warmup_steps`), so checkpoints written here resume in the reference and the other way round."""
 
     def __init__(self, optimizer=None, warmup_steps=4000):
+        self.optimizer = optimizer
         self.warmup_steps = warmup_steps
+        if optimizer is not None and hasattr(optimizer, "warmup_steps"):
+            optimizer.warmup_steps = float(warmup_steps)
 
     def step(self):
         pass
 
     def state_dict(self):
-        return {"warmup_steps": self.warmup_steps}
+        k, base = 0, None
+        if self.optimizer is not None and hasattr(self.optimizer, "last_stats"):
+            k, base = self.optimizer.last_stats()["step"], self.optimizer.lr
+        sd = {"warmup_steps": self.warmup_steps, "last_epoch": k, "_step_count": k + 1, "_get_lr_called_within_step": False}
+        if base is not None:
+            sd["base_lrs"] = [base]
+            sd["_last_lr"] = [warmup_lr_value(base, k + 1, self.warmup_steps)]
+        return sd
 
     def load_state_dict(self, sd):
         self.warmup_steps = sd.get("warmup_steps", self.warmup_steps)
+        if self.optimizer is not None and hasattr(self.optimizer, "warmup_steps"):
+            self.optimizer.warmup_steps = float(self.warmup_steps)
+            if sd.get("base_lrs"):
+                self.optimizer.lr = float(sd["base_lrs"][0])

@@ -10,12 +10,14 @@ tensorboardX) is outside the hot path and not reproduced; a log callback receive
 Host synchronisation: the reference calls `.item()` 4-6 times per step; here losses are accumulated in a
 device tensor and read once per `log_interval_steps`.
 """
+import contextlib
 import logging
 import os
 from collections import OrderedDict, defaultdict
 
 import torch
 
+from .. import distributed as D
 from ..optim import FlatAdam
 from ..ops import functional as Fn
 from ..ops import kernels as K
@@ -50,6 +52,7 @@ class Trainer(object):
         self.total_train_loss = defaultdict(float)
         self.log_fn = None              # optional callable(steps, dict) -- stands in for tensorboardX
         self._schedule_gradient_work()
+        self._setup_data_parallel()
 
     # how parameter-gradient kernels are scheduled (ops/functional.py, "Side streams"): (side streams, inline batches)
     GRADIENT_WORK = (4, False)
@@ -58,6 +61,45 @@ class Trainer(object):
         if self.device.type == "cuda" and isinstance(self.optimizer, FlatAdam):
             n, inline = self.GRADIENT_WORK
             Fn.enable_side_streams(self.config.get("side_streams", n), inline_batches=self.config.get("inline_batches", inline))
+
+    # -- data parallelism (reference: apex DistributedDataParallel wrap, bin/vc_train.py:423-431) ------------------------
+    def _setup_data_parallel(self):
+        """config["distributed"] (set by the launcher code as in bin/vc_train.py:197-201 after init_process_group): every rank
+        starts from rank 0's parameters and buffers, and every optimiser step averages the gradients over the ranks -- with
+        FlatAdam stage by stage, overlapped with the backward pass (distributed.OverlappedBackward); with a torch optimiser
+        one coalesced all-reduce of p.grad after backward.  BatchNorm statistics stay rank-local, rank 0 checkpoints."""
+        self.dist, self.world, self.dp = None, 1, None
+        if not self.config.get("distributed", False):
+            return
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('config["distributed"] is set but torch.distributed is not initialised '
+                               "(call init_process_group / distributed.init_from_env first, as bin/vc_train.py:197-201 does)")
+        self.dist, self.world = dist, dist.get_world_size()
+        self.config.setdefault("rank", dist.get_rank())
+        D.broadcast_model_(self._net(), self.optimizer, dist, self.world)
+        if isinstance(self.optimizer, FlatAdam) and hasattr(self._net(), "dp_plan"):
+            self.dp = D.OverlappedBackward(self._net(), self.optimizer, dist, self.world,
+                                           payload=self.config.get("dp_grad_payload", "fp32"))
+
+    def _forward_context(self):
+        """Context of the forward pass: activates the model's gradient cuts when the backward pass runs in stages."""
+        return self.dp.forward_context() if self.dp is not None else contextlib.nullcontext()
+
+    def _backward(self, total, parts, last_micro_step=True):
+        """Backward pass + (on the last micro-step of an accumulation window) the gradient exchange.
+        total: the scalar loss (already divided by gradient_accumulate_steps); parts: the same loss split by the keys of
+        model.dp_plan() (sum(parts) == total), used when the backward pass runs stage by stage."""
+        if self.dp is not None:
+            self.dp.backward(parts, reduce=last_micro_step)
+        else:
+            total.backward()
+            Fn.side_join()
+            if self.dist is not None and last_micro_step:
+                if isinstance(self.optimizer, FlatAdam):
+                    D.allreduce_mean_(self.optimizer.flat_g, self.dist, self.world)
+                else:
+                    D.allreduce_grads_(list(self._net().parameters()), self.dist, self.world)
 
     # -- core loop -------------------------------------------------------------------------------
     def _net(self):
@@ -142,6 +184,8 @@ class Trainer(object):
             self.optimizer.load_state_dict(sd["optimizer"])
             if self.scheduler is not None:
                 self.scheduler.load_state_dict(sd["scheduler"])
+        if self.dist is not None:
+            D.broadcast_model_(self._net(), self.optimizer, self.dist, self.world)
 
     def load_trained_modules(self, checkpoint_path, init_mods):
         """Partial (prefix-filtered, shape-verified) load: trainers/ar_vc.py:31-57 + utils/model_io.py:12-92."""
@@ -161,6 +205,8 @@ class Trainer(object):
         self._net().load_state_dict(main)
         if isinstance(self.optimizer, FlatAdam):
             self.optimizer.refresh_shadow()
+        if self.dist is not None:
+            D.broadcast_model_(self._net(), self.optimizer, self.dist, self.world)
 
     def freeze_modules(self, modules):
         freeze_modules(self.model, modules)
@@ -178,21 +224,33 @@ class ARVCTrainer(Trainer):
         loss = l1 + bce
         logs = {"train/l1_loss": l1, "train/bce_loss": bce}
         if self.config.get("use_guided_attn_loss", False):
-            att = att_ws if isinstance(att_ws, torch.Tensor) else att_ws[0]
-            ga = self.criterion["guided_attn"](att, ilens_ds_st, olens_in)
+            ga = self.criterion["guided_attn"](self._guided_attention_input(att_ws), ilens_ds_st, olens_in)
             loss = loss + ga
             logs["train/guided_attn_loss"] = ga
         logs["train/loss"] = loss
         return loss, logs
 
+    def _guided_attention_input(self, att_ws):
+        """The reference hands `att_ws` -- VTN returns a LIST of per-layer (B, H, T_out, T_in) maps, last layer first
+        (models/vtn.py:276-290; the torch.cat is commented out there) -- straight to the loss, which would fail on a list;
+        no recipe enables it.  Here the configured intent is built the way ESPnet (and the reference's own
+        TransformerTTS.forward, models/transformer_tts.py:205-222) does: the last `num_layers_applied_guided_attn` layers,
+        the first `num_heads_applied_guided_attn` heads of each, concatenated along the head axis."""
+        if isinstance(att_ws, torch.Tensor):
+            return att_ws
+        net = self._net()
+        n_layers = getattr(net, "num_layers_applied_guided_attn", 2)
+        n_heads = getattr(net, "num_heads_applied_guided_attn", 2)
+        return torch.cat([a[:, :n_heads] for a in att_ws[:n_layers]], dim=1)
+
     def _train_step(self, batch):
         K.reset_op_counter()
         K.advance_seed(self.device)
         self.optimizer.zero_grad()
-        loss, logs = self._forward_losses(batch)
+        with self._forward_context():
+            loss, logs = self._forward_losses(batch)
         self._accumulate(**logs)
-        loss.backward()
-        Fn.side_join()
+        self._backward(loss, {"loss": loss})
         self.backward_steps += 1
         self._optimizer_step()
         self.steps += 1
@@ -220,33 +278,37 @@ class AASVCTrainer(Trainer):
         K.reset_op_counter()
         K.advance_seed(dev)
         xs, ys, dp_inputs = batch["xs"].to(dev), batch["ys"].to(dev), batch["dp_inputs"].to(dev)
-        ret = self.model(xs, batch["ilens"], ys, batch["olens"], dp_inputs, dp_lengths=batch["dplens"])
-        zero = torch.zeros((), device=dev)
-        logs = {}
-        loss = zero
-        if "L1Loss" in self.config["criterions"]:
-            l1 = self.criterion["L1Loss"](ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
-            logs["train/l1_loss"] = l1
-            loss = loss + l1
-        fs = self.criterion["ForwardSumLoss"](ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
-        logs["train/forward_sum_loss"], logs["train/binary_loss"] = fs, ret["bin_loss"]
-        loss = loss + self.config["lambda_align"] * (fs + ret["bin_loss"])
-        dur = zero
-        if self.steps > self.config.get("dp_train_start_steps", 0):
-            if "DurationPredictorLoss" in self.config["criterions"]:
-                dur = self.criterion["DurationPredictorLoss"](ret["d_outs"], ret["ds"], ret["ilens"])
-            elif "StochasticDurationPredictorLoss" in self.config["criterions"]:
-                dur = torch.sum(ret["dur_nll"].float())
-        logs["train/duration_loss"] = dur
-        loss = loss + dur
-        logs["train/loss"] = loss
+        with self._forward_context():
+            ret = self.model(xs, batch["ilens"], ys, batch["olens"], dp_inputs, dp_lengths=batch["dplens"])
+            zero = torch.zeros((), device=dev)
+            logs = {}
+            dec_loss = zero
+            if "L1Loss" in self.config["criterions"]:
+                l1 = self.criterion["L1Loss"](ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+                logs["train/l1_loss"] = l1
+                dec_loss = dec_loss + l1
+            fs = self.criterion["ForwardSumLoss"](ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+            logs["train/forward_sum_loss"], logs["train/binary_loss"] = fs, ret["bin_loss"]
+            align_loss = self.config["lambda_align"] * (fs + ret["bin_loss"])
+            dur = zero
+            if self.steps > self.config.get("dp_train_start_steps", 0):
+                if "DurationPredictorLoss" in self.config["criterions"]:
+                    dur = self.criterion["DurationPredictorLoss"](ret["d_outs"], ret["ds"], ret["ilens"])
+                elif "StochasticDurationPredictorLoss" in self.config["criterions"]:
+                    dur = torch.sum(ret["dur_nll"].float())
+            logs["train/duration_loss"] = dur
+            align_loss = align_loss + dur
+            loss = dec_loss + align_loss
+            logs["train/loss"] = loss
         self._accumulate(**logs)
+        parts = {"decoder": dec_loss, "align": align_loss}
         if self.gradient_accumulate_steps > 1:
             loss = loss / self.gradient_accumulate_steps
-        loss.backward()
-        Fn.side_join()
+            parts = {k: v / self.gradient_accumulate_steps for k, v in parts.items()}
         self.backward_steps += 1
-        if self.backward_steps % self.gradient_accumulate_steps > 0:
+        last = self.backward_steps % self.gradient_accumulate_steps == 0
+        self._backward(loss, parts, last_micro_step=last)
+        if not last:
             return
         self._optimizer_step()
         self.optimizer.zero_grad()

@@ -826,6 +826,376 @@ def training_steps_bf16_transposed_shadow():
     return res
 
 
+
+# =================================================================================================
+# round 2: AASVC.inference, full-width single layers, and the BASELINE configurations at full size
+# =================================================================================================
+def _kill_dropout(model):
+    for m in model.modules():
+        if hasattr(m, "dropout_rate"):
+            m.dropout_rate = 0.0
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+
+
+def _aas_inference(name):
+    from seq2seq_vc_amd import models as M
+    cfg, z = load(name)
+    Fn.set_compute_dtype(torch.float32)
+    model = M.AASVC(**model_cfg(cfg))
+    model.load_state_dict(sd_of(z))
+    model.to(DEV).eval()
+    t = lambda k: torch.from_numpy(z[k])
+    if "in.sdp_noise" in z.files:
+        model.duration_predictor.noise = t("in.sdp_noise")
+    x = t("in.x").to(DEV)
+    y = t("in.y").to(DEV) if "in.y" in z.files else None
+    out = model.inference(x, tgt_speech=y, dp_input=x)
+    res = [cmp(f"{name} predicted durations (exact)", out[1].reshape(-1), z["out.d_outs"].reshape(-1), 0),
+           cmp(f"{name} outs", out[0], z["out.outs"], 4e-4, l1_tol=1e-4)]
+    res.append((len(out) == (5 if y is not None else 2), f"{name}: inference returns {len(out)} values"))
+    if y is not None:
+        res += [cmp(f"{name} ds (bit-exact)", out[2], z["out.ds"], 0), cmp(f"{name} log_p_attn", out[3], z["out.log_p_attn"], 2e-4),
+                cmp(f"{name} ilens", out[4], z["out.ilens"], 0)]
+    return res
+
+
+@case
+def aasvc_tiny_inference_fp32():
+    """AASVC.inference (reference models/aas_vc.py:531-603), decode path (no target), stochastic duration predictor's
+    inverse pass with the captured noise."""
+    return _aas_inference("aasvc_tiny_inference")
+
+
+@case
+def aasvc_tiny_inference_gt_fp32():
+    """... with a target utterance: also returns ds / log_p_attn / ilens (the reference's debug path)."""
+    return _aas_inference("aasvc_tiny_inference_gt")
+
+
+@case
+def aasvc_det_tiny_inference_fp32():
+    """... deterministic duration predictor: zero durations, the clamp at 10."""
+    return _aas_inference("aasvc_det_tiny_inference")
+
+
+def rel_l2(name, got, ref, tol, floor=0.0):
+    """||got - ref|| <= tol * ||ref|| + floor * sqrt(n)  (the floor covers tensors that are zero up to rounding, e.g. the
+    gradient of a key-projection bias: softmax is invariant to it)."""
+    got = torch.as_tensor(got).detach().double().cpu().reshape(-1)
+    ref = torch.as_tensor(np.asarray(ref)).double().reshape(-1)
+    if got.shape != ref.shape:
+        return False, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    d, r = float((got - ref).norm()), float(ref.norm())
+    e = d / (r + 1e-30)
+    ok = d == d and d <= tol * r + floor * got.numel() ** 0.5
+    return ok, f"{name}: rel-L2 err {e:.3e} (tol {tol:g}, |ref| {r:.2e})"
+
+
+def _fw_layer(c):
+    from seq2seq_vc_amd import conformer as Co
+    from seq2seq_vc_amd import modules as Mo
+    d, h, u = c["d"], c["h"], c["units"]
+    if c["kind"] == "encoder":
+        return Mo.EncoderLayer(d, Mo.MultiHeadedAttention(h, d, 0.0), Mo.PositionwiseFeedForward(d, u, 0.0), 0.0, c["pre_ln"])
+    if c["kind"] == "decoder":
+        return Mo.DecoderLayer(d, Mo.MultiHeadedAttention(h, d, 0.0), Mo.MultiHeadedAttention(h, d, 0.0),
+                               Mo.PositionwiseFeedForward(d, u, 0.0), 0.0, c["pre_ln"])
+    return Co.EncoderLayer(d, Mo.RelPositionMultiHeadedAttention(h, d, 0.0), Mo.PositionwiseFeedForward(d, u, 0.0, "swish"),
+                           Mo.PositionwiseFeedForward(d, u, 0.0, "swish"), Co.ConvolutionModule(d, c["k"], "swish"), 0.0, c["pre_ln"])
+
+
+def _fullwidth(name, dtype):
+    import fullwidth as FW
+    from seq2seq_vc_amd import modules as Mo
+    cfg, z = load(name)
+    c = FW.CASES[name]
+    res = []
+    f32 = dtype == torch.float32
+    try:
+        Fn.set_compute_dtype(dtype)
+        layer = _fw_layer(c)
+        shapes = [(k, tuple(p.shape)) for k, p in layer.named_parameters()]
+        res.append((shapes == FW.layer_param_shapes(c), f"{name}: parameter names / shapes / order equal the reference layer's"))
+        state = FW.seeded_state(FW.layer_param_shapes(c), c["seed"])
+        ok = all(FW.checksum(state[k]) == int(z["chk.w." + k]) for k in state)
+        res.append((ok, f"{name}: regenerated weights match the fixture's checksums"))
+        layer.load_state_dict(state, strict=False)
+        layer.to(DEV).train()
+        x, mem, dy = FW.inputs(c)
+        xd = Fn.to_compute(x.to(DEV)).requires_grad_(True)
+        lens = Mo.Lens(c["lens"], DEV)
+        if c["kind"] == "encoder":
+            xo, f = layer(xd, lens)
+            out = Fn.add_dropout(xo, f, 0.0)
+        elif c["kind"] == "decoder":
+            md = Fn.to_compute(mem.to(DEV)).requires_grad_(True)
+            out, _ = layer(xd, lens, md, Mo.Lens(c["mlens"], DEV))
+        else:
+            pe_mod = Mo.RelPositionalEncoding(c["d"], 0.0)
+            xs, pe = pe_mod(xd)
+            out = layer(xs, pe, lens)
+        out.backward(Fn.to_compute(dy.to(DEV)))
+        Fn.side_join()
+        if f32:
+            res.append(cmp(f"{name}[fp32] out", out, z["out"], 2e-4, l1_tol=2e-5))
+        res.append(rel_l2(f"{name}[{dtype}] out", out, z["out"], 1e-5 if f32 else 1.5e-2))
+        # bf16 tolerances: the reference's own layer run in torch.bfloat16 on the CPU (weights, activations and gradients
+        # all bf16) is off by 0.4-0.6 % (out), 2.8-3.5 % (dx) and 3-6 % (parameter gradients) from its fp32 result on
+        # these inputs -- LayerNorm's backward cancels, so rounding noise is amplified; this path (fp32 accumulation and
+        # statistics) must stay at or below that level
+        res.append(rel_l2(f"{name}[{dtype}] dx", xd.grad.float().reshape(-1)[::3], z["dx"], 2e-5 if f32 else 4e-2))
+        if c["kind"] == "decoder":
+            res.append(rel_l2(f"{name}[{dtype}] dmem", md.grad.float().reshape(-1)[::3], z["dmem"], 2e-5 if f32 else 4e-2))
+        worst, wname, nbad = 0.0, "", 0
+        tol = 1e-4 if f32 else 6.5e-2
+        for k, p in layer.named_parameters():
+            if p.grad is None:
+                res.append((False, f"{name}: no gradient for {k}"))
+                continue
+            ok, msg = rel_l2(k, p.grad.float().reshape(-1)[::FW.grad_stride(p.numel())], z["grad." + k], tol,
+                             floor=1e-6 if f32 else 1e-3)
+            e = float(msg.split("err ")[1].split(" ")[0])
+            if ok and e > worst:
+                worst, wname = e, k
+            if not ok:
+                nbad += 1
+                res.append((False, f"{name}[{dtype}] grad {msg}"))
+        res.append((nbad == 0, f"{name}[{dtype}] parameter gradients: {nbad} off (tol {tol:g}); worst rel-L2 {worst:.3e} at {wname}"))
+        for k in [k for k in z.files if k.startswith("buf.") and "num_batches" not in k]:
+            res.append(cmp(f"{name}[{dtype}] buffer {k[4:]}", dict(layer.named_buffers())[k[4:]], z[k], 2e-5 if f32 else 2e-2))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    return res
+
+
+def _fw_case(name, dtype):
+    def fn():
+        return _fullwidth(name, dtype)
+    fn.__name__ = f"{name}_{'fp32' if dtype == torch.float32 else 'bf16'}"
+    fn.__doc__ = f"Full-width single layer {name} (tests/fullwidth.py) against the reference layer's vectors, {dtype}."
+    return case(fn)
+
+
+for _n in ("fw_enc384", "fw_dec384", "fw_conf384", "fw_conf1536"):
+    for _dt in (torch.float32, torch.bfloat16):
+        _fw_case(_n, _dt)
+
+
+@case
+def aasvc_full_size_values_fp32():
+    """BASELINE configs[2] (AAS-VC vc2, 157.5 M parameters, 16 utterance pairs of up to 256 frames) in fp32 mode against the
+    CPU oracle on the canonical batch: durations bit-exact, log_p_attn, mel outputs, L1 / forward-sum / bin / duration NLL.
+    This is the only place the vc2-only shapes (A=1536 pairwise distances, d_k=768 rel-pos attention, k=15 x 1536-channel
+    depthwise convolution, 4096 x 1536 GEMMs) meet reference-derived values."""
+    import bench
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from tools.bench_aasvc import AASVC_VC2
+    res = []
+    xs, ilens, ys, _, olens = bench.canonical_batch(16)
+    try:
+        Fn.set_compute_dtype(torch.float32)
+        torch.manual_seed(0)
+        model = M.AASVC(**AASVC_VC2)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.to(DEV).train()
+        _kill_dropout(model)
+        noise = torch.randn(16, 2, 64, generator=torch.Generator().manual_seed(5))
+        model.duration_predictor.noise = noise
+        with torch.no_grad():
+            ret = model(xs.to(DEV), ilens, ys.to(DEV), olens, xs.to(DEV), dp_lengths=ilens)
+            l1 = L.L1Loss()(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+            fs = L.ForwardSumLoss()(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+            torch.cuda.synchronize()
+            r = OM.aasvc_forward(sd, AASVC_VC2, xs, ilens, ys, olens, dp_inputs=xs, noise=noise, training=True, drop=False)
+        res.append(cmp("AAS-VC vc2 log_p_attn", ret["log_p_attn"], r["log_p_attn"], 2e-4))
+        res.append((r["mas_margin"] > 1e-4, f"AAS-VC vc2 smallest alignment decision margin {r['mas_margin']:.2e} (> 1e-4: bit-exactness is defined)"))
+        res.append(cmp("AAS-VC vc2 durations (bit-exact)", ret["ds"], r["ds"], 0))
+        res.append(cmp("AAS-VC vc2 before_outs", ret["before_outs"], r["before_outs"], 1e-3, l1_tol=1e-4))
+        res.append(cmp("AAS-VC vc2 after_outs", ret["after_outs"], r["after_outs"], 2e-3, l1_tol=1e-4))
+        res.append(cmp("AAS-VC vc2 bin_loss", ret["bin_loss"], r["bin_loss"], 5e-5))
+        res.append(cmp("AAS-VC vc2 dur_nll", ret["dur_nll"], r["dur_nll"], 1e-3, rtol=2e-4))
+        res.append(cmp("AAS-VC vc2 L1", l1, OM.l1_loss(r["after_outs"], r["before_outs"], r["ys"], r["olens"]), 1e-4))
+        res.append(cmp("AAS-VC vc2 forward-sum", fs, OM.forward_sum_loss(r["log_p_attn"], r["ilens"], r["olens_reduced"]), 2e-4))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    return res
+
+
+TTS_V1 = dict(idim=78, odim=80, dprenet_layers=2, dprenet_units=256, adim=384, aheads=4, elayers=6, eunits=1536, dlayers=6,
+              dunits=1536, postnet_layers=5, postnet_filts=5, postnet_chans=256, use_batch_norm=True,
+              encoder_normalize_before=True, decoder_normalize_before=False, encoder_concat_after=False,
+              decoder_concat_after=False, decoder_reduction_factor=2)   # egs/ljspeech/tts1/conf/transformer_tts.v1.yaml:23-42
+
+
+def canonical_tts_batch(B, seed=1234):
+    """ilens in [60,150] int tokens in [1,77) padded with 0, olens in [300,640], ys randn(B,640,80)."""
+    g = torch.Generator().manual_seed(seed)
+    ilens = torch.randint(60, 151, (B,), generator=g)
+    ilens[0] = 150
+    olens = torch.randint(300, 641, (B,), generator=g)
+    olens[0] = 640
+    xs = torch.randint(1, 77, (B, 150), generator=g)
+    ys = torch.randn(B, 640, 80, generator=g)
+    xs[torch.arange(150)[None] >= ilens[:, None]] = 0
+    ar = torch.arange(640)[None]
+    ys[ar >= olens[:, None]] = 0.0
+    labels = (ar >= (olens[:, None] - 1)).float()
+    return xs, ilens, ys, labels, olens
+
+
+@case
+def tts_full_size_c4():
+    """BASELINE configs[3]: TransformerTTS at the tts1 recipe size (egs/ljspeech/tts1/conf/transformer_tts.v1.yaml:23-42,
+    idim 78, r=2, 26.3 M parameters), one rank's share of the global batch of 64 (8 utterances, 150 tokens -> 640 frames):
+    fp32 losses and outputs against the CPU oracle; the bf16 step is bit-reproducible and close to fp32."""
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.optim import FlatAdam
+    res = []
+    xs, ilens, ys, labels, olens = canonical_tts_batch(8)
+    try:
+        def build(dtype):
+            Fn.set_compute_dtype(dtype)
+            torch.manual_seed(0)
+            model = M.TransformerTTS(**TTS_V1).to(DEV).train()
+            return model, FlatAdam(model, lr=8e-4, grad_norm=1.0, warmup_steps=4000, bf16_shadow=(dtype == torch.bfloat16))
+
+        def fwd_bwd(model, opt, p_drop=None):
+            if p_drop is not None:
+                _kill_dropout(model) if p_drop == 0.0 else None
+            K.manual_seed(77)
+            K.reset_op_counter()
+            opt.zero_grad()
+            o = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+            l1, bce = L.Seq2SeqLoss(10.0)(o[0], o[1], o[2], o[3], o[4], o[5])
+            (l1 + bce).backward()
+            Fn.side_join()
+            return o, float(l1), float(bce), opt.flat_g.clone()
+
+        Fn.enable_side_streams(4)
+        model, opt = build(torch.float32)
+        o, l1f, bcef, gf = fwd_bwd(model, opt, p_drop=0.0)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            r = OM.tts_forward(sd, TTS_V1, xs, ilens, ys, labels, olens, training=True, drop=False)
+            l1r, bcer = OM.seq2seq_loss(r[0], r[1], r[2], r[3], r[4], r[5])
+        res.append(cmp("TTS tts1 fp32 after_outs vs CPU oracle", o[0], r[0], 2e-3, l1_tol=1e-4))
+        res.append(cmp("TTS tts1 fp32 logits vs CPU oracle", o[2], r[2], 1e-3))
+        res.append(cmp("TTS tts1 fp32 l1 vs CPU oracle", l1f, l1r, 1e-4))
+        res.append(cmp("TTS tts1 fp32 bce vs CPU oracle", bcef, bcer, 1e-4))
+        res.append(cmp("TTS tts1 olens", o[5], r[5], 0))
+        del model, opt
+        model, opt = build(torch.bfloat16)
+        a = fwd_bwd(model, opt)
+        b = fwd_bwd(model, opt)
+        res.append((a[1] == b[1] and a[2] == b[2] and bool(torch.equal(a[3], b[3])), f"TTS tts1 bf16 step is reproducible bit for bit (l1 {a[1]:.6f})"))
+        d = fwd_bwd(model, opt, p_drop=0.0)
+        res.append((abs(d[1] - l1f) < 2e-2 and abs(d[2] - bcef) < 2e-2, f"TTS bf16 vs fp32 losses: l1 {d[1]:.4f} / {l1f:.4f}, bce {d[2]:.4f} / {bcef:.4f}"))
+        res.append(rel_l2("TTS tts1 bf16 vs fp32 flat gradient", d[3].cpu(), gf.cpu(), 0.1))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
+def vtn_small_c1_vs_oracle():
+    """BASELINE configs[0]: VTN-small (2+2 layers, d=256, 4 heads of 64, FFN 1024; other arguments at the constructor
+    defaults, r=4), 8 utterance pairs: forward, losses and every parameter gradient against the CPU oracle (fp32), and the
+    bf16 path against fp32."""
+    import bench
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    cfgs = dict(idim=80, odim=80, adim=256, aheads=4, elayers=2, eunits=1024, dlayers=2, dunits=1024, decoder_reduction_factor=4)
+    res = []
+    xs, ilens, ys, labels, olens = bench.canonical_batch(8)
+    try:
+        Fn.set_compute_dtype(torch.float32)
+        torch.manual_seed(0)
+        model = M.VTN(**cfgs)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.to(DEV).train()
+        _kill_dropout(model)
+        names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+        for k in names:
+            sd[k].requires_grad_(True)
+        o = OM.vtn_forward(sd, cfgs, xs, ilens, ys, labels, olens, training=True, drop=False)
+        l1r, bcer = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+        gr = torch.autograd.grad(l1r + bcer, [sd[k] for k in names], allow_unused=True)
+        out = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+        l1, bce = L.Seq2SeqLoss(10.0)(out[0], out[1], out[2], out[3], out[4], out[5])
+        (l1 + bce).backward()
+        res.append(cmp("VTN-small after_outs", out[0], o[0].detach(), 1e-3, l1_tol=1e-4))
+        res.append(cmp("VTN-small logits", out[2], o[2].detach(), 5e-4))
+        res.append(cmp("VTN-small l1", l1, l1r.detach(), 2e-5))
+        res.append(cmp("VTN-small bce", bce, bcer.detach(), 2e-5))
+        for i, a in enumerate(out[6][0]):
+            res.append(cmp(f"VTN-small att_ws[{i}]", a, o[6][0][i].detach(), 5e-5))
+        got = dict(model.named_parameters())
+        worst, wname = 0.0, ""
+        for k, gk in zip(names, gr):
+            ref = gk if gk is not None else torch.zeros_like(sd[k])
+            mine = got[k].grad if got[k].grad is not None else torch.zeros_like(got[k])
+            e = (mine.detach().cpu() - ref).abs().max().item() / (1e-3 + ref.abs().max().item())
+            if e > worst:
+                worst, wname = e, k
+        res.append((worst < 2e-3, f"VTN-small: worst parameter-gradient error (relative to the tensor's max) {worst:.2e} ({wname})"))
+        Fn.set_compute_dtype(torch.bfloat16)
+        model.zero_grad()
+        out16 = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+        l1b, bceb = L.Seq2SeqLoss(10.0)(out16[0], out16[1], out16[2], out16[3], out16[4], out16[5])
+        res.append((abs(float(l1b) - float(l1)) < 2e-2 and abs(float(bceb) - float(bce)) < 2e-2,
+                    f"VTN-small bf16 vs fp32 losses: l1 {float(l1b):.4f} / {float(l1):.4f}, bce {float(bceb):.4f} / {float(bce):.4f}"))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    return res
+
+
+@case
+def decode_c5_vs_oracle():
+    """BASELINE configs[4]: VTN vc1 weights (seeded init), 16 sources of 256 frames decoded in lockstep by
+    `inference_batch`, threshold 2.0 so that every utterance runs to maxlen = int(63 * 6.0 / 4) = 94 steps = 376 frames
+    (prenet dropout 0, the parity setting): utterances 0, 7 and 15 against the CPU oracle's recompute-the-prefix loop
+    (fp32); the bf16 batch stays close to the fp32 one."""
+    import bench
+    from oracle import models as OM
+    from seq2seq_vc_amd import models as M
+    args = {"threshold": 2.0, "minlenratio": 0.0, "maxlenratio": 6.0}
+    res = []
+    try:
+        Fn.set_compute_dtype(torch.float32)
+        torch.manual_seed(0)
+        cfgs = dict(bench.VTN_VC1, dprenet_dropout_rate=0.0)
+        model = M.VTN(**cfgs)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.to(DEV).eval()
+        xs = torch.randn(16, 256, 80, generator=torch.Generator().manual_seed(1234))
+        ilens = torch.full((16,), 256)
+        with torch.no_grad():
+            got = model.inference_batch(xs.to(DEV), ilens, args)
+        res.append((len(got) == 16 and all(tuple(g[0].shape) == (376, 80) for g in got), "C5: 16 utterances x 376 frames (94 steps x r=4)"))
+        for u in (0, 7, 15):
+            with torch.no_grad():
+                o = OM.vtn_inference(sd, cfgs, xs[u], **args)
+            res.append(cmp(f"C5 utterance {u} frames vs CPU oracle", got[u][0], o[0], 2e-3, l1_tol=1e-4))
+            res.append(cmp(f"C5 utterance {u} stop probabilities", got[u][1], o[1], 1e-4))
+            res.append(cmp(f"C5 utterance {u} attention maps", got[u][2], o[2], 1e-4))
+        Fn.set_compute_dtype(torch.bfloat16)
+        model._decode_sessions = {}
+        with torch.no_grad():
+            got16 = model.inference_batch(xs.to(DEV), ilens, args)
+        e = max(float((a[0].float() - b[0].float()).abs().mean()) for a, b in zip(got16, got))
+        res.append((e < 0.05, f"C5 bf16 vs fp32 frames: mean abs diff {e:.3e} (94 autoregressive steps)"))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    return res
+
+
 def main(selected=None):
     nfail = 0
     for fn in CASES:

@@ -148,3 +148,60 @@ def test_aasvc_forward_and_grads(name):
     total.backward()
     for k in [k for k in z.files if k.startswith("grad.")]:
         close(params[k[5:]].grad, z[k], 2e-4)
+
+
+@pytest.mark.parametrize("name", ["aasvc_tiny_inference", "aasvc_tiny_inference_gt", "aasvc_det_tiny_inference"])
+def test_aasvc_inference(name):
+    """AASVC.inference (models/aas_vc.py:531-603): decode path without a target, debug path with one."""
+    cfg, z = load(name)
+    t = lambda k: torch.from_numpy(z[k])
+    x = t("in.x")
+    y = t("in.y") if "in.y" in z.files else None
+    noise = t("in.sdp_noise") if "in.sdp_noise" in z.files else None
+    with torch.no_grad():
+        r = OM.aasvc_forward(sd_of(z), model_cfg(cfg), x[None], torch.tensor([x.shape[0]]), None if y is None else y[None],
+                             None if y is None else torch.tensor([y.shape[0]]), dp_inputs=x[None], noise=noise,
+                             training=False, inference=True)
+    assert torch.equal(r["d_outs"][0].float(), t("out.d_outs").float()), "predicted durations must be identical"
+    assert tuple(r["after_outs"][0].shape) == z["out.outs"].shape
+    close(r["after_outs"][0], z["out.outs"], 1e-5)
+    if y is not None:
+        assert torch.equal(r["ds"][0], t("out.ds"))
+        close(r["log_p_attn"][0], z["out.log_p_attn"], 1e-5)
+        assert int(r["ilens"][0]) == int(z["out.ilens"])
+
+
+@pytest.mark.parametrize("name", ["fw_enc384", "fw_dec384", "fw_conf384", "fw_conf1536"])
+def test_fullwidth_layers(name):
+    """Full-width single layers (tests/fullwidth.py): the seeded weights reproduce the generator's checksums and the
+    oracle's layer functions reproduce the reference layer's output and gradients at d=384 / d=1536."""
+    import fullwidth as FW
+    from oracle import nets as N
+    cfg, z = load(name)
+    c = FW.CASES[name]
+    assert {k: v for k, v in cfg.items() if not k.startswith("__")} == c
+    names = [k[6:] for k in z.files if k.startswith("chk.w.")]
+    shapes = FW.layer_param_shapes(c)
+    assert [n for n, _ in shapes] == names
+    state = FW.seeded_state(shapes, c["seed"])
+    for k in names:
+        assert FW.checksum(state[k]) == int(z["chk.w." + k]), k
+    x, mem, dy = FW.inputs(c)
+    assert FW.checksum(x) == int(z["chk.x"]) and FW.checksum(dy) == int(z["chk.dy"])
+    sd = {k: v.requires_grad_(True) for k, v in state.items()}
+    for k in [k for k in z.files if k.startswith("buf.")]:
+        sd[k[4:]] = torch.from_numpy(z[k]).clone()
+        if "running_mean" in k:
+            sd[k[4:]].zero_()
+        elif "running_var" in k:
+            sd[k[4:]].fill_(1.0)
+        else:
+            sd[k[4:]].zero_()
+    out = FW.oracle_layer(c, sd, x.requires_grad_(True), mem.requires_grad_(True) if mem is not None else None)
+    close(out, z["out"], 2e-5)
+    (out * dy).sum().backward()
+    close(x.grad.reshape(-1)[::3], z["dx"], 2e-5)
+    if mem is not None:
+        close(mem.grad.reshape(-1)[::3], z["dmem"], 2e-5)
+    for k in names:
+        close(sd[k].grad.reshape(-1)[::FW.grad_stride(sd[k].numel())], z["grad." + k], 1e-4)

@@ -260,6 +260,135 @@ def gen_aasvc(M, L, A, name, cfg, B, Ti, To, seed, lambda_align=2.0):
     print(f"  forward_sum {maxerr(fso, fs):.2e} l1 {maxerr(OM.l1_loss(o['after_outs'], o['before_outs'], o['ys'], o['olens']), l1):.2e}")
 
 
+def gen_aasvc_inference(M, name, cfg, T, seed, To=None):
+    """AASVC.inference (models/aas_vc.py:531-603, the non-teacher-forced branch): without a target (the decode path of
+    bin/vc_decode.py) and with one (the debug path that also returns ds / log_p_attn / ilens).  eval() mode; the randn
+    draw of the stochastic duration predictor's inverse pass is captured."""
+    from oracle import models as OM
+    torch.manual_seed(seed)
+    model = M.AASVC(**cfg)
+    # default init leaves the duration heads near zero (all durations 1); scale the duration predictor so that the
+    # predicted durations spread over 0..MAX_DP_OUTPUT and the clamp / zero-duration handling is exercised
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.startswith("duration_predictor") and p.dim() > 1:
+                p.mul_(3.0)
+    kill_dropout(model)
+    model.eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(T, cfg["idim"], generator=g)
+    y = torch.randn(To, cfg["odim"], generator=g) if To else None
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    drawn = []
+    real_randn = torch.randn
+
+    def spy(*a, **k):
+        t = real_randn(*a, **k)
+        drawn.append(t.clone())
+        return t
+
+    torch.randn = spy
+    try:
+        torch.manual_seed(seed + 5)
+        with torch.no_grad():
+            out = model.inference(x, tgt_speech=y, dp_input=x)
+    finally:
+        torch.randn = real_randn
+    arr = {}
+    pack(arr, "sd.", sd0)
+    arr.update({"in.x": to_np(x), "out.outs": to_np(out[0]), "out.d_outs": to_np(out[1])})
+    if y is not None:
+        arr.update({"in.y": to_np(y), "out.ds": to_np(out[2]), "out.log_p_attn": to_np(out[3]), "out.ilens": to_np(out[4])})
+    if drawn:
+        arr["in.sdp_noise"] = to_np(drawn[0])
+    save(name, dict(cfg, __model__="AASVC", __train__=False), arr)
+    noise = drawn[0] if drawn else None
+    ilens = torch.tensor([T])
+    o = OM.aasvc_forward({k: v.clone() for k, v in sd0.items()}, cfg, x[None], ilens, None if y is None else y[None],
+                         None if y is None else torch.tensor([To]), dp_inputs=x[None], noise=noise, training=False, inference=True)
+    print(f"  oracle-vs-ref {name}: outs {maxerr(o['after_outs'][0], out[0]):.2e} d_outs equal {bool(torch.equal(o['d_outs'][0].float(), out[1].float()))} "
+          f"(durations {out[1].flatten().tolist()})")
+
+
+def _fw_reference_layer(c):
+    """The reference's own layer object for a tests/fullwidth.py case."""
+    from seq2seq_vc.layers.positional_encoding import RelPositionalEncoding
+    from seq2seq_vc.modules.conformer.convolution import ConvolutionModule
+    from seq2seq_vc.modules.conformer.encoder_layer import EncoderLayer as ConformerLayer
+    from seq2seq_vc.modules.conformer.swish import Swish
+    from seq2seq_vc.modules.transformer.attention import MultiHeadedAttention, RelPositionMultiHeadedAttention
+    from seq2seq_vc.modules.transformer.decoder_layer import DecoderLayer
+    from seq2seq_vc.modules.transformer.encoder_layer import EncoderLayer
+    from seq2seq_vc.modules.transformer.positionwise_feed_forward import PositionwiseFeedForward
+    d, h, u = c["d"], c["h"], c["units"]
+    if c["kind"] == "encoder":
+        return EncoderLayer(d, MultiHeadedAttention(h, d, 0.0), PositionwiseFeedForward(d, u, 0.0), 0.0, c["pre_ln"], False), None
+    if c["kind"] == "decoder":
+        return DecoderLayer(d, MultiHeadedAttention(h, d, 0.0), MultiHeadedAttention(h, d, 0.0), PositionwiseFeedForward(d, u, 0.0),
+                            0.0, c["pre_ln"], False), None
+    layer = ConformerLayer(d, RelPositionMultiHeadedAttention(h, d, 0.0, False), PositionwiseFeedForward(d, u, 0.0, Swish()),
+                           PositionwiseFeedForward(d, u, 0.0, Swish()), ConvolutionModule(d, c["k"], Swish()), 0.0, c["pre_ln"], False)
+    return layer, RelPositionalEncoding(d, 0.0)
+
+
+def gen_fullwidth(name):
+    """Full-width single layers (tests/fullwidth.py): reference layer, seeded weights, output + gradients."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fullwidth as FW
+    from oracle import nets as N
+    c = FW.CASES[name]
+    layer, posenc = _fw_reference_layer(c)
+    layer.train()                       # BatchNorm of the Conformer layer uses batch statistics, as in training
+    shapes = [(k, tuple(p.shape)) for k, p in layer.named_parameters()]
+    state = FW.seeded_state(shapes, c["seed"])
+    with torch.no_grad():
+        for k, p in layer.named_parameters():
+            p.copy_(state[k])
+    x, mem, dy = FW.inputs(c)
+    x.requires_grad_(True)
+    lens = torch.tensor(c["lens"])
+    T = c["T"]
+    key_mask = (torch.arange(T)[None, :] < lens[:, None]).unsqueeze(1)          # (B,1,T) True = valid
+    if c["kind"] == "encoder":
+        out, _ = layer(x, key_mask)
+    elif c["kind"] == "decoder":
+        mem.requires_grad_(True)
+        mlens = torch.tensor(c["mlens"])
+        mem_mask = (torch.arange(c["Tm"])[None, :] < mlens[:, None]).unsqueeze(1)
+        tgt_mask = key_mask & torch.tril(torch.ones(T, T, dtype=torch.bool))[None]
+        out, _, _, _ = layer(x, tgt_mask, mem, mem_mask)
+    else:
+        xs, pos_emb = posenc(x)          # (x * sqrt(d), pos_emb (1, 2T-1, d)); the layer input is the scaled x
+        (out, _), _ = layer((xs, pos_emb), key_mask)
+    (out * dy).sum().backward()
+    arr = {"out": to_np(out), "dx": to_np(x.grad).reshape(-1)[::3].copy(),
+           "chk.x": np.int64(FW.checksum(x)), "chk.dy": np.int64(FW.checksum(dy))}
+    if mem is not None:
+        arr["dmem"] = to_np(mem.grad).reshape(-1)[::3].copy()
+    for k, p in layer.named_parameters():
+        arr["chk.w." + k] = np.int64(FW.checksum(state[k]))
+        arr["grad." + k] = to_np(p.grad).reshape(-1)[::FW.grad_stride(p.numel())].copy()
+    for k, b in layer.named_buffers():
+        arr["buf." + k] = to_np(b)
+    save(name, dict({k: v for k, v in c.items()}, __model__="layer"), arr)
+    # the oracle's restatement of the same layer
+    from oracle.nets import P, Runtime
+    sd = {k: v.clone() for k, v in state.items()}
+    for k, b in _fw_reference_layer(c)[0].named_buffers():
+        sd[k] = b.clone()
+    rt = Runtime(True, False)
+    with torch.no_grad():
+        xd = x.detach()
+        if c["kind"] == "encoder":
+            o = N.encoder_layer(P(sd, ""), xd, key_mask, c["h"], rt, 0.0, 0.0, c["pre_ln"], "l")
+        elif c["kind"] == "decoder":
+            o = N.decoder_layer(P(sd, ""), xd, tgt_mask, mem.detach(), mem_mask, c["h"], rt, 0.0, c["pre_ln"], "l")
+        else:
+            xs, pe = N.rel_posenc(xd, rt, 0.0)
+            o = N.conformer_layer(P(sd, ""), xs, pe, key_mask, c["h"], rt, 0.0, 0.0, c["pre_ln"], False, "l")
+    print(f"  oracle-vs-ref {name}: out {maxerr(o, out):.2e} (|out| max {float(out.abs().max()):.2f})")
+
+
 def gen_mas_kats(A):
     """Known-answer vectors for the alignment search, from the reference's own code."""
     arr = {}
@@ -349,6 +478,15 @@ def main():
                           maxlenratio=3.0, fire=True, minlenratio=1.6)
     if want("tts_tiny_inference"):
         gen_vtn_inference(M, "tts_tiny_inference", TTS_TINY, T=11, seed=108, maxlenratio=3.0, tts=True)
+    if want("aasvc_tiny_inference"):           # decode path: no target
+        gen_aasvc_inference(M, "aasvc_tiny_inference", AAS_TINY, T=52, seed=109)
+    if want("aasvc_tiny_inference_gt"):        # debug path: with a target (alignment + durations returned as well)
+        gen_aasvc_inference(M, "aasvc_tiny_inference_gt", AAS_TINY, T=64, seed=110, To=40)
+    if want("aasvc_det_tiny_inference"):
+        gen_aasvc_inference(M, "aasvc_det_tiny_inference", AAS_DET_TINY, T=37, seed=111)
+    for n in ("fw_enc384", "fw_dec384", "fw_conf384", "fw_conf1536"):
+        if want(n):
+            gen_fullwidth(n)
 
 
 if __name__ == "__main__":
