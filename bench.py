@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark of the MI355X-native seq2seq-vc hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload vtn|aasvc]
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): one optimiser step of VTN
-(egs/arctic/vc1/conf/vtn.v1.yaml: 6+6 layers, d=384, r=4, postnet 5x256xk5; 30.48 M params) on a
-synthetic ARCTIC-shaped batch of 32 utterance pairs PER GPU (T_src = T_tgt padded to 256, 80-dim mel),
-bf16 compute with fp32 master weights: forward + Seq2SeqLoss + backward + grad-clip + Adam + WarmupLR.
-Metric: mel-frames/sec = sum of valid target frames consumed per step over all ranks / step wall time.
+Headline workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): one optimiser step of VTN
+(egs/arctic/vc1/conf/vtn.v1.yaml: 6+6 layers, d=384, r=4, postnet 5x256xk5; 30.48 M params) on a synthetic ARCTIC-shaped batch
+of 32 utterance pairs PER GPU (T_src = T_tgt padded to 256, 80-dim mel), bf16 compute with fp32 master weights: forward +
+Seq2SeqLoss + backward + grad-clip + Adam + WarmupLR.  Metric: mel-frames/sec = valid target frames consumed per step over all
+ranks / step wall time.  `--workload aasvc` runs configuration C3 instead (AAS-VC, egs/arctic/vc2/conf/aas_vc.melmelmel.v1.yaml,
+157.5 M params, 16 utterance pairs per GPU) through the same data-parallel machinery.
 
-One process per GPU (torch.distributed, backend nccl == RCCL); data parallel = mean all-reduce of the
-flat fp32 gradient buffer.  Rank 0 prints ONE JSON line, extended with
-  "roofline":     the dominant kernel (MFMA GEMM) timed live with HIP events against the bf16 MFMA peak
+One process per GPU (torch.distributed, backend nccl == RCCL).  Data parallel = the staged backward pass of
+seq2seq_vc_amd.distributed.OverlappedBackward: every stage of model.dp_plan() is one captured hipGraph, and the all-reduce of
+the gradients a stage has finished is issued (asynchronously, on RCCL's stream) before the next stage's graph is replayed.
+
+Rank 0 prints ONE JSON line, extended with
+  "roofline":     the workload's dominant kernel (MFMA GEMM) timed live with HIP events against the bf16 MFMA peak
   "cpu_baseline": the CPU oracle (fp32 restatement of the reference) timed on this box's host cores
+and, at N = 1 with the default workload, two sub-objects measured in the same run:
+  "aasvc":        configuration C3 (one rank), with its own roofline (4096 x 1536 x 1536 GEMM) and cpu_baseline
+  "decode":       configuration C5 (VTN autoregressive decode, 16 utterances, captured step graph): RTF, with the CPU baseline
+                  the recipe prescribes (16 single-thread processes, egs/arctic/vc1/run.sh:284-286)
 """
 import argparse
 import json
@@ -29,9 +37,23 @@ VTN_VC1 = dict(idim=80, odim=80, dprenet_layers=2, dprenet_units=256, adim=384, 
                dunits=1536, postnet_layers=5, postnet_filts=5, postnet_chans=256, use_batch_norm=True,
                encoder_normalize_before=True, decoder_normalize_before=False, encoder_concat_after=False,
                decoder_concat_after=False, decoder_reduction_factor=4)
-FWD_BWD_GFLOP = 715.9   # BASELINE.md section 2 (matmul/conv FLOPs of one fwd+bwd at B=32, T=256)
+AASVC_VC2 = dict(
+    idim=80, odim=80, adim=384, aheads=2, elayers=4, eunits=1536, dlayers=4, dunits=1536, positionwise_layer_type="linear",
+    positionwise_conv_kernel_size=1, duration_predictor_use_encoder_outputs=False, duration_predictor_input_dim=80,
+    duration_predictor_layers=2, duration_predictor_chans=256, duration_predictor_kernel_size=3, postnet_layers=5,
+    postnet_filts=5, postnet_chans=256, use_masking=True, encoder_normalize_before=True, decoder_normalize_before=True,
+    encoder_reduction_factor=1, post_encoder_reduction_factor=4, decoder_reduction_factor=1, encoder_type="conformer",
+    decoder_type="conformer", duration_predictor_type="stochastic", encoder_input_layer="linear",
+    conformer_pos_enc_layer_type="rel_pos", conformer_self_attn_layer_type="rel_selfattn",
+    use_macaron_style_in_conformer=True, use_cnn_in_conformer=True, conformer_enc_kernel_size=15, conformer_dec_kernel_size=15,
+    init_type="xavier_uniform", transformer_enc_dropout_rate=0.2, transformer_enc_positional_dropout_rate=0.2,
+    transformer_enc_attn_dropout_rate=0.2, transformer_dec_dropout_rate=0.2, transformer_dec_positional_dropout_rate=0.2,
+    transformer_dec_attn_dropout_rate=0.2)
+FWD_BWD_GFLOP = {"vtn": 715.9, "aasvc": 4777.0}   # BASELINE.md section 2 (matmul/conv FLOPs of one fwd+bwd at the canonical shapes)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 F32_MFMA_PEAK_TFLOPS = 157.3
+DECODE_ARGS = {"threshold": 2.0, "minlenratio": 0.0, "maxlenratio": 6.0}   # threshold 2.0 never fires: 94 steps = 376 frames
+HOP, SR = 256, 16000
 
 
 def canonical_batch(B_total, T=256, idim=80, odim=80, seed=1234):
@@ -50,20 +72,25 @@ def canonical_batch(B_total, T=256, idim=80, odim=80, seed=1234):
     return xs, ilens, ys, labels, olens
 
 
-def cpu_baseline(batch, steps=2):
-    """The CPU oracle (oracle/models.py, proven equal to the reference by tests/golden) on the host cores:
-    fwd + loss + bwd + clip + Adam at the same shapes, fp32, train-mode dropout on."""
-    from oracle import models as OM
-    from seq2seq_vc_amd.models import VTN
-    xs, ilens, ys, labels, olens = batch
-    torch.manual_seed(0)
-    ref = VTN(**VTN_VC1)
-    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+# =====================================================================================================================
+# CPU baselines (the oracle = "port" of the reference, proven equal to it by tests/golden) -- rank 0, N = 1 only
+# =====================================================================================================================
+def _oracle_params(sd):
     names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
     for k in names:
         sd[k].requires_grad_(True)
     params = [sd[k] for k in names]
-    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+    return params, [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+
+
+def cpu_baseline_vtn(batch, steps=2):
+    """fwd + loss + bwd + clip + Adam at the same shapes, fp32, train-mode dropout on, all host cores."""
+    from oracle import models as OM
+    from seq2seq_vc_amd.models import VTN
+    xs, ilens, ys, labels, olens = batch
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in VTN(**VTN_VC1).state_dict().items()}
+    params, state = _oracle_params(sd)
     times = []
     for it in range(steps + 1):
         t0 = time.perf_counter()
@@ -80,27 +107,73 @@ def cpu_baseline(batch, steps=2):
             "ms_per_step": t * 1e3}
 
 
-def dominant_kernel_roofline(dtype, iters=100):
-    """Times the FLOP-heaviest single launch of the step -- the implicit-GEMM 3x3 stride-2 Conv2d of the
-    encoder front-end (M = 32*63*19, N = 384, K = 9*384; subsampling.py:60) -- with HIP events on the
-    stream it is launched on, and rates it against the MFMA peak of its dtype."""
-    from seq2seq_vc_amd.ops import kernels as K
-    B, T1, F1, C, O = 32, 127, 39, 384, 384
-    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
-    M, N, Kd = B * T2 * F2, O, 9 * C
-    x = torch.randn(B, T1, F1, C, device="cuda").to(dtype)
-    w = (torch.randn(O, 9 * C, device="cuda") * 0.02).to(dtype)
-    b = torch.zeros(O, device="cuda")
-    y = torch.empty(B, T2, F2, O, dtype=dtype, device="cuda")
+def cpu_baseline_aasvc(batch, steps=1):
+    """The AAS-VC training step of trainers/aas_vc.py:56-164 on the oracle: forward (incl. the C alignment search) + L1 +
+    lambda*(forward-sum + bin) + duration NLL + backward + clip + Adam, fp32, dropout on, all host cores."""
+    from oracle import models as OM
+    from seq2seq_vc_amd.models import AASVC
+    xs, ilens, ys, _, olens = batch
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in AASVC(**AASVC_VC2).state_dict().items()}
+    params, state = _oracle_params(sd)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        noise = torch.randn(xs.shape[0], 2, 64)
+        r = OM.aasvc_forward(sd, AASVC_VC2, xs, ilens, ys, olens, dp_inputs=xs, noise=noise, training=True, drop=True)
+        l1 = OM.l1_loss(r["after_outs"], r["before_outs"], r["ys"], r["olens"])
+        fs = OM.forward_sum_loss(r["log_p_attn"], r["ilens"], r["olens_reduced"])
+        loss = l1 + 2.0 * (fs + r["bin_loss"]) + r["dur_nll"].sum()
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)]
+        with torch.no_grad():
+            OM.adam_step(params, grads, state, OM.warmup_lr(8e-5, it + 1), it + 1)
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / max(1, len(times) - 1)
+    return {"value": float(olens.sum()) / t, "unit": "mel-frames/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} optimiser step(s) (after 1 warm-up) of the same AAS-VC-vc2 B=16 batch, fp32, {t:.2f} s/step",
+            "ms_per_step": t * 1e3}
 
-    def launch():
-        K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(w, 9 * C), M, N, Kd, y,
-               in_dtype=dtype, bias=b, act="relu")
+
+def _decode_cpu_worker(seed):
+    """One of the recipe's 16 decoding jobs: a single-thread process generating one utterance with the reference's
+    schedule (the whole prefix is recomputed every step; prenet dropout on).  Returns the seconds spent generating."""
+    torch.set_num_threads(1)
+    from oracle import models as OM
+    from seq2seq_vc_amd.models import VTN
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in VTN(**VTN_VC1).state_dict().items()}
+    x = torch.randn(256, 80, generator=torch.Generator().manual_seed(1234 + seed))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        outs, _, _ = OM.vtn_inference(sd, VTN_VC1, x, drop=True, **DECODE_ARGS)
+    return time.perf_counter() - t0, int(outs.shape[0])
+
+
+def cpu_baseline_decode(jobs=16):
+    """egs/arctic/vc1/run.sh:284-286: n_jobs=16 CPU processes (CUDA_VISIBLE_DEVICES=""), OMP_NUM_THREADS=1 (path.sh:16),
+    one utterance each here.  RTF = slowest job's generation time / audio seconds of ONE utterance is what a user waits
+    per utterance; the aggregate RTF (comparable to the GPU's batch-aggregate number) divides by all 16 utterances."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(jobs) as pool:
+        res = pool.map(_decode_cpu_worker, range(jobs))
+    wall = max(t for t, _ in res)
+    frames = sum(n for _, n in res)
+    return {"value": wall / (frames * HOP / SR), "unit": "RTF (wall s / audio s, aggregate over the jobs)", "cores": jobs, "kind": "port",
+            "sample": f"{jobs} single-thread processes x one 256-frame utterance -> {frames // jobs} frames each, slowest job {wall:.2f} s "
+                      f"(per-utterance RTF {wall / (frames // jobs * HOP / SR):.3f})"}
+
+
+# =====================================================================================================================
+# dominant-kernel rooflines
+# =====================================================================================================================
+def _time_graph_loop(launch, iters):
+    """`iters` launches replayed from one hipGraph, HIP events on the stream they run on: events around a Python launch
+    loop would time the host's ~10 us per ctypes launch, not the kernel (rocprofv3's per-dispatch average is the cross-check)."""
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
-    # the `iters` launches are replayed from one hipGraph: HIP events around a Python launch loop would time the host's
-    # ~10 us per ctypes launch between 140 us kernels, not the kernel (rocprofv3's per-dispatch average is the cross-check)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     timed = "hipGraph replay"
@@ -129,40 +202,322 @@ def dominant_kernel_roofline(dtype, iters=100):
             e1.record(side)
             side.synchronize()
     torch.cuda.current_stream().wait_stream(side)
-    ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * M * N * Kd
-    peak = BF16_MFMA_PEAK_TFLOPS if dtype == torch.bfloat16 else F32_MFMA_PEAK_TFLOPS
-    ach = flops / (ms * 1e-3) / 1e12
-    kernel = ("gemm_glds_kernel<128,128,KC_CONV2D,KC_DENSE> (bf16, LDS-DMA staged)" if dtype == torch.bfloat16
-              else "gemm_fast_kernel<float,128,128,32> (exact-fp32 MFMA)")
-    # HBM-side bytes per launch come from rocprofv3 PMC passes of exactly this loop (they cannot be read from inside the
-    # process): profiles/roofline_pmc.json holds (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes.
-    traffic, alg_bytes = None, float((x.numel() + w.numel() + y.numel()) * x.element_size())
+    return e0.elapsed_time(e1) / iters, timed
+
+
+def _pmc_traffic(key):
+    """HBM-side bytes per launch come from rocprofv3 PMC passes of exactly this loop (they cannot be read from inside the
+    process): profiles/roofline_pmc.json holds (2*FETCH_SIZE + WRITE_SIZE)*1024 as MI355X_MICROARCH.md prescribes."""
     pmc = os.path.join(ROOT, "profiles", "roofline_pmc.json")
-    if dtype == torch.bfloat16 and os.path.exists(pmc):
-        with open(pmc) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
-    return {"bound": "mfma", "kernel": kernel + " conv2d-3x3-s2 implicit GEMM M=%d N=%d K=%d" % (M, N, Kd), "achieved": ach,
-            "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "algorithmic_bytes": alg_bytes,
+    if not os.path.exists(pmc):
+        return None
+    with open(pmc) as f:
+        d = json.load(f)
+    if key == "vtn":
+        return d.get("hbm_bytes_per_launch")
+    return (d.get(key) or {}).get("hbm_bytes_per_launch")
+
+
+def dominant_kernel_roofline(dtype, iters=100, workload="vtn"):
+    """vtn:   the FLOP-heaviest launch of the VTN step, the implicit-GEMM 3x3 stride-2 Conv2d of the encoder front-end
+              (M = 32*63*19, N = 384, K = 9*384; subsampling.py:60);
+       aasvc: the GEMM shape that carries the AAS-VC step, 4096 x 1536 x 1536 (B*T = 16*256 rows, d = 1536: the decoder's
+              attention / feed-forward / pointwise-conv projections, 60+ launches per step).
+    Timed with HIP events on the stream the kernel is launched on and rated against the MFMA peak of its dtype."""
+    from seq2seq_vc_amd.ops import kernels as K
+    peak = BF16_MFMA_PEAK_TFLOPS if dtype == torch.bfloat16 else F32_MFMA_PEAK_TFLOPS
+    if workload == "aasvc":
+        M, N, Kd = 4096, 1536, 1536
+        x = torch.randn(M, Kd, device="cuda").to(dtype)
+        w = (torch.randn(N, Kd, device="cuda") * 0.02).to(dtype)
+        b = torch.zeros(N, device="cuda")
+        y = torch.empty(M, N, dtype=dtype, device="cuda")
+
+        def launch():
+            K.gemm(K.operand(x, Kd), K.operand(w, Kd), M, N, Kd, y, in_dtype=dtype, bias=b)
+        shape = "dense GEMM M=%d N=%d K=%d (+bias)" % (M, N, Kd)
+    else:
+        B, T1, F1, C, O = 32, 127, 39, 384, 384
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        M, N, Kd = B * T2 * F2, O, 9 * C
+        x = torch.randn(B, T1, F1, C, device="cuda").to(dtype)
+        w = (torch.randn(O, 9 * C, device="cuda") * 0.02).to(dtype)
+        b = torch.zeros(O, device="cuda")
+        y = torch.empty(B, T2, F2, O, dtype=dtype, device="cuda")
+
+        def launch():
+            K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(w, 9 * C), M, N, Kd, y,
+                   in_dtype=dtype, bias=b, act="relu")
+        shape = "conv2d-3x3-s2 implicit GEMM M=%d N=%d K=%d" % (M, N, Kd)
+    ms, timed = _time_graph_loop(launch, iters)
+    flops = 2.0 * M * N * Kd
+    ach = flops / (ms * 1e-3) / 1e12
+    if dtype != torch.bfloat16:
+        kernel = "gemm_fast_kernel<float,128,128,32> (exact-fp32 MFMA)"
+    elif workload == "aasvc":
+        kernel = "gemm_glds_kernel<128,128,KC_DENSE,KC_DENSE> (bf16, LDS-DMA staged)"
+    else:
+        kernel = "gemm_glds_kernel<128,128,KC_CONV2D,KC_DENSE> (bf16, LDS-DMA staged)"
+    alg_bytes = float((x.numel() + w.numel() + y.numel()) * x.element_size())
+    return {"bound": "mfma", "kernel": f"{kernel} {shape}", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": _pmc_traffic(workload) if dtype == torch.bfloat16 else None, "algorithmic_bytes": alg_bytes,
             "avg_launch_us": ms * 1e3, "flops_per_launch": flops, "timed": f"{iters} launches, {timed}, HIP events"}
 
 
+# =====================================================================================================================
+# training workloads
+# =====================================================================================================================
+class Workload:
+    """Model + fused optimiser + criterion on the canonical synthetic batch of this rank."""
+
+    def __init__(self, name, dev, dtype, batch, world, rank):
+        from seq2seq_vc_amd import losses as L
+        from seq2seq_vc_amd import models as M
+        from seq2seq_vc_amd.ops import functional as Fn
+        from seq2seq_vc_amd.optim import FlatAdam
+        self.name, self.dev, self.Fn = name, dev, Fn
+        xs, ilens, ys, labels, olens = canonical_batch(batch * world)
+        sl = slice(rank * batch, (rank + 1) * batch)
+        xs, ilens, ys, labels, olens = xs[sl], ilens[sl], ys[sl], labels[sl], olens[sl]
+        if int(ilens.max()) < 256:  # keep the padded shape canonical on every rank
+            ilens[0] = 256
+        if int(olens.max()) < 256:
+            olens[0] = 256
+        self.frames = float(olens.sum())
+        self.cpu_batch = (xs.clone(), ilens.clone(), ys.clone(), labels.clone(), olens.clone())
+        self.xs, self.ys, self.labels, self.ilens, self.olens = xs.to(dev), ys.to(dev), labels.to(dev), ilens, olens
+        torch.manual_seed(0)  # identical initial weights on every rank (the trainers broadcast rank 0's instead)
+        if name == "vtn":
+            self.model = M.VTN(**VTN_VC1).to(dev).train()
+            self.crit = L.Seq2SeqLoss(bce_pos_weight=10.0)
+            self.loss_names = ["l1", "bce"]
+            self.desc = "VTN egs/arctic/vc1 (vtn.v1.yaml) training step: fwd+Seq2SeqLoss+bwd+clip+Adam+WarmupLR"
+        else:
+            self.model = M.AASVC(**AASVC_VC2).to(dev).train()
+            self.l1, self.fs = L.L1Loss(), L.ForwardSumLoss()
+            self.loss_names = ["l1", "forward_sum", "bin", "dur_nll"]
+            self.desc = ("AAS-VC egs/arctic/vc2 (aas_vc.melmelmel.v1.yaml) training step: fwd (incl. alignment search)"
+                         "+L1+2*(forward-sum+bin)+duration NLL+bwd+clip+Adam+WarmupLR")
+        self.opt = FlatAdam(self.model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=(dtype == torch.bfloat16))
+        self.loss_buf = torch.zeros(len(self.loss_names), device=dev)
+        self.params_m = sum(p.numel() for p in self.model.parameters()) / 1e6
+
+    def forward(self):
+        """One forward pass -> the loss split by the keys of model.dp_plan() (their sum is the training loss)."""
+        if self.name == "vtn":
+            after, before, logits, ys_, labels_, olens_, _ = self.model(self.xs, self.ilens, self.ys, self.labels, self.olens)
+            l1, bce = self.crit(after, before, logits, ys_, labels_, olens_)
+            self.loss_buf[0].copy_(l1.detach())
+            self.loss_buf[1].copy_(bce.detach())
+            return {"loss": l1 + bce}
+        ret = self.model(self.xs, self.ilens, self.ys, self.olens, self.xs, dp_lengths=self.ilens)
+        l1 = self.l1(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+        fs = self.fs(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+        dur = torch.sum(ret["dur_nll"].float())
+        self.loss_buf.copy_(torch.stack([l1.detach().float(), fs.detach().float(), ret["bin_loss"].detach().float(), dur.detach()]))
+        return {"decoder": l1, "align": 2.0 * (fs + ret["bin_loss"]) + dur}
+
+
+def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_eager=2):
+    """Returns (step(), info).  Unstaged: graph 1 = zero + forward + loss + backward, graph 2 = clip + Adam + WarmupLR.
+    Staged (data parallel): one graph per stage of model.dp_plan(); after each replay the all-reduce of that stage's slice of
+    the flat gradient buffer is issued; the optimiser graph follows the join."""
+    from seq2seq_vc_amd.distributed import OverlappedBackward
+    from seq2seq_vc_amd.ops import kernels as K
+    Fn, opt, dev = wl.Fn, wl.opt, wl.dev
+    ob = OverlappedBackward(wl.model, opt, dist, world, payload=payload, force=force_dist) if staged else None
+    held = {}
+
+    def begin():
+        K.reset_op_counter()
+        K.advance_seed(dev)
+        opt.zero_grad()
+
+    def fwd_bwd():
+        begin()
+        losses = wl.forward()
+        total = None
+        for v in losses.values():
+            total = v if total is None else total + v
+        total.backward()
+        Fn.side_join()
+
+    def stage(i):
+        if i == 0:
+            begin()
+            with ob.forward_context():
+                held["losses"] = wl.forward()
+        ob.run_stage(i, held["losses"])
+
+    n_stages = len(ob.plan) if staged else 1
+
+    def step_eager():
+        if staged:
+            for i in range(n_stages):
+                stage(i)
+                ob.begin_reduce(i)
+            ob.finish()
+        else:
+            fwd_bwd()
+        opt.step()
+
+    side = torch.cuda.Stream()      # warm-up on a side stream so that a later capture sees a quiet default stream
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup_eager):
+            step_eager()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    graphs, g_opt = [], None
+    if use_graph:
+        try:
+            for i in range(n_stages):
+                g = torch.cuda.CUDAGraph()
+                kw = {"pool": graphs[0].pool()} if graphs else {}
+                # thread_local: RCCL's watchdog thread polls events while this thread captures (N > 1)
+                with torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
+                    stage(i) if staged else fwd_bwd()
+                graphs.append(g)
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
+                opt.step()
+        except Exception as e:  # noqa: BLE001 -- report and fall back to eager launches, loudly
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize()
+
+    def step():
+        if not use_graph:
+            step_eager()
+            return
+        if staged:
+            for i, g in enumerate(graphs):
+                g.replay()
+                ob.begin_reduce(i)       # this stage's gradients travel while the next stage's graph runs
+            ob.finish()
+        else:
+            graphs[0].replay()
+        g_opt.replay()
+
+    info = {"hip_graph": bool(use_graph), "backward_stages": n_stages,
+            "grad_buckets_MB": [round(b / 1e6, 1) for b in ob.bucket_bytes()] if staged else None,
+            "grad_payload": payload if staged else None}
+    return step, info
+
+
+def time_steps(step, steps, warmup, dist=None, dev=None):
+    for _ in range(warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def step_mfma(workload, ms):
+    gf = FWD_BWD_GFLOP[workload]
+    return {"gflop_per_step_per_gpu": gf, "achieved_tflops_per_gpu": gf / ms, "frac_of_bf16_peak": gf / ms / BF16_MFMA_PEAK_TFLOPS}
+
+
+# =====================================================================================================================
+# sub-benchmarks reported beside the headline (N = 1)
+# =====================================================================================================================
+def bench_aasvc_single(dev, dtype, steps=20, warmup=3, cpu=True, batch=16):
+    from seq2seq_vc_amd.ops import functional as Fn
+    Fn.enable_side_streams(0, inline_batches=True)     # the schedule AASVCTrainer ships (trainers.AASVCTrainer.GRADIENT_WORK)
+    wl = Workload("aasvc", dev, dtype, batch, 1, 0)
+    step, info = build_step(wl, None, 1, False, False, "fp32", True)
+    dt = time_steps(step, steps, warmup)
+    ms = dt / steps * 1e3
+    lb = wl.loss_buf.tolist()
+    out = {"metric": "mel-frames/sec (train)", "value": wl.frames / (dt / steps), "unit": "mel-frames/sec", "n_gpus": 1, "steps": steps,
+           "warmup": warmup, "ms_per_step": ms, "dtype": "bf16" if dtype == torch.bfloat16 else "fp32", "data": "synthetic",
+           "config": {"workload": wl.desc, "batch_per_gpu": batch, "T_src": 256, "T_tgt": 256, "params_M": round(wl.params_m, 2),
+                      **info},
+           "final_losses": dict(zip(wl.loss_names, lb), **wl.opt.last_stats()), "step_mfma": step_mfma("aasvc", ms)}
+    if not all(v == v and abs(v) < 1e6 for v in lb):
+        raise SystemExit(f"bench: non-finite AAS-VC loss {lb}")
+    out["roofline"] = dominant_kernel_roofline(dtype, workload="aasvc")
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline_aasvc(wl.cpu_batch)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    del wl, step
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_decode(dev, dtype, batch=16, iters=5, poll=32, cpu=True):
+    """C5: encoder + source K/V projection + 94 replays of the captured step graph + postnet, all inside the timed region."""
+    from seq2seq_vc_amd import decode as D
+    from seq2seq_vc_amd.models import VTN
+    from seq2seq_vc_amd.ops import functional as Fn
+    from seq2seq_vc_amd.ops import kernels as K
+    torch.manual_seed(0)
+    K.manual_seed(1234)
+    model = VTN(**VTN_VC1).to(dev).eval()
+    xs = torch.randn(batch, 256, 80, generator=torch.Generator().manual_seed(1234)).to(dev)
+    ilens = torch.full((batch,), 256)
+
+    def run():
+        with torch.no_grad():
+            lens = D.Mo.Lens.of(ilens, xs.device)
+            hs, hlens = model.encoder(Fn.to_compute(xs), lens, exact_lens=True)
+            return D.decode(model, hs, list(hlens.host), DECODE_ARGS, poll=poll, use_graph=True)
+
+    res = run()            # builds the session + captures the step graph
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        res = run()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / iters
+    frames = sum(r[0].shape[0] for r in res)
+    nsteps = frames // (batch * VTN_VC1["decoder_reduction_factor"])
+    out = {"metric": "RTF (AR decode, batch aggregate)", "value": t / (frames * HOP / SR), "unit": "wall s / audio s",
+           "higher_is_better": False, "n_gpus": 1, "dtype": "bf16" if dtype == torch.bfloat16 else "fp32", "data": "synthetic",
+           "ms_per_batch": t * 1e3, "us_per_step": t * 1e6 / nsteps, "frames_per_sec": frames / t,
+           "config": {"workload": "VTN egs/arctic/vc1 AR decode (C5): encoder + 94 steps x r=4 + postnet, prenet dropout 0.5 on",
+                      "batch": batch, "T_src": 256, "steps": nsteps, "frames_per_utt": frames // batch, "hip_graph": True, "poll": poll},
+           "finite": bool(all(torch.isfinite(r[0]).all() for r in res))}
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline_decode(batch)
+        out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / out["value"]
+    return out
+
+
+# =====================================================================================================================
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=32, help="utterance pairs per GPU")
+    ap.add_argument("--workload", default="vtn", choices=["vtn", "aasvc"])
+    ap.add_argument("--batch", type=int, default=None, help="utterance pairs per GPU (default: 32 for vtn, 16 for aasvc)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the AAS-VC (C3) and decode (C5) sub-benchmarks")
     ap.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--split-backward", action="store_true",
-                    help="N = 1: run the two-graph step of the data-parallel path (autograd cut at the encoder output) without collectives")
-    ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
+                    help="N = 1: run the staged backward pass of the data-parallel path without collectives")
     ap.add_argument("--force-dist", action="store_true",
-                    help="take the N > 1 code path (RCCL process group, split backward, overlapped all-reduce) at world size 1")
-    ap.add_argument("--side-streams", type=int, default=4, help="HIP side streams for parameter-gradient kernels (0 = off)")
+                    help="take the N > 1 code path (RCCL process group, staged backward, overlapped all-reduces) at world size 1")
+    ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient exchange")
+    ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
+    ap.add_argument("--side-streams", type=int, default=None, help="HIP side streams for parameter-gradient kernels (default: 4 for vtn, 0 + inline batches for aasvc)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,163 +537,36 @@ def main():
         os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
-    from seq2seq_vc_amd import losses as L
-    from seq2seq_vc_amd.distributed import allreduce_end, allreduce_mean_, allreduce_sum_begin
-    from seq2seq_vc_amd.models import VTN
     from seq2seq_vc_amd.ops import functional as Fn
     from seq2seq_vc_amd.ops import kernels as K
-    from seq2seq_vc_amd.optim import FlatAdam
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.roofline_only:
-        print(json.dumps(dominant_kernel_roofline(dtype, iters=200)))
+        print(json.dumps(dominant_kernel_roofline(dtype, iters=200, workload=args.workload)))
         return
     Fn.set_compute_dtype(dtype)
-    Fn.enable_side_streams(args.side_streams, inline_batches=args.inline_batches)
+    if args.side_streams is None:
+        n_side, inline = (4, args.inline_batches) if args.workload == "vtn" else (0, True)
+    else:
+        n_side, inline = args.side_streams, args.inline_batches
+    Fn.enable_side_streams(n_side, inline_batches=inline)
     K.manual_seed(1234 + rank)
 
-    B = args.batch
-    xs, ilens, ys, labels, olens = canonical_batch(B * world)
-    sl = slice(rank * B, (rank + 1) * B)
-    xs, ilens, ys, labels, olens = xs[sl], ilens[sl], ys[sl], labels[sl], olens[sl]
-    if int(ilens.max()) < 256:  # keep the padded shape canonical on every rank
-        ilens[0] = 256
-    if int(olens.max()) < 256:
-        olens[0] = 256
-    frames_local = float(olens.sum())
-    cpu_batch = (xs.clone(), ilens.clone(), ys.clone(), labels.clone(), olens.clone())
-    xs_d, ys_d, labels_d = xs.to(dev), ys.to(dev), labels.to(dev)
-
-    torch.manual_seed(0)  # identical initial weights on every rank (stands in for the DDP broadcast)
-    model = VTN(**VTN_VC1).to(dev)
-    model.train()
-    crit = L.Seq2SeqLoss(bce_pos_weight=10.0)
-    opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=(dtype == torch.bfloat16))
-    loss_buf = torch.zeros(2, device=dev)
-
-    def fwd_bwd():
-        K.reset_op_counter()
-        K.advance_seed(dev)
-        opt.zero_grad()
-        after, before, logits, ys_, labels_, olens_, _ = model(xs_d, ilens, ys_d, labels_d, olens)
-        l1, bce = crit(after, before, logits, ys_, labels_, olens_)
-        (l1 + bce).backward()
-        loss_buf[0].copy_(l1.detach())       # (before the join: the copies run while the side streams finish)
-        loss_buf[1].copy_(bce.detach())
-        Fn.side_join()
-
-    # -- data-parallel overlap: the autograd graph is cut at the encoder output.  Graph 1 = forward + loss + the decoder-
-    # side backward; its gradients (one contiguous range of the flat buffer) start their all-reduce while graph 2, the
-    # encoder's backward, runs.  The loss carries the 1/world of the mean, so the collectives are plain sums.
-    enc_range = opt.param_range(model.encoder)
-    split = (dp or args.split_backward) and enc_range is not None and enc_range[0] == 0
-    gscale = 1.0 / world
-    cut = {}
-
-    def fwd_bwd_decoder():
-        K.reset_op_counter()
-        K.advance_seed(dev)
-        opt.zero_grad()
-        cut.clear()
-        after, before, logits, ys_, labels_, olens_, _ = model(xs_d, ilens, ys_d, labels_d, olens, _memory_cut=cut)
-        l1, bce = crit(after, before, logits, ys_, labels_, olens_)
-        ((l1 + bce) * gscale if dp else (l1 + bce)).backward()
-        loss_buf[0].copy_(l1.detach())
-        loss_buf[1].copy_(bce.detach())
-        Fn.side_join()
-
-    def bwd_encoder():
-        cut["encoder_out"].backward(cut["decoder_in"].grad)
-        Fn.side_join()
-
-    def reduce_begin(part):      # part 0: everything behind the encoder's parameters, part 1: the encoder's
-        lo, hi = (enc_range[1], opt.numel) if part == 0 else enc_range
-        return allreduce_sum_begin(opt.flat_g[lo:hi], dist, world, force=args.force_dist)
-
-    def step_eager():
-        if split:
-            fwd_bwd_decoder()
-            h = reduce_begin(0)
-            bwd_encoder()
-            h += reduce_begin(1)
-            allreduce_end(h)
-        else:
-            fwd_bwd()
-            if dp:
-                allreduce_mean_(opt.flat_g, dist, world, force=args.force_dist)
-        opt.step()
-
-    # warm-up (eager, on a side stream so that a later capture sees a quiet default stream)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(max(2, args.warmup if args.no_graph else 2)):
-            step_eager()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-
-    use_graph = not args.no_graph
-    g_fb = g_fb2 = g_opt = None
-    if use_graph:
-        try:
-            g_fb = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread polls events while this thread captures (N > 1)
-            with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
-                fwd_bwd_decoder() if split else fwd_bwd()
-            if split:
-                g_fb2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fb2, pool=g_fb.pool(), capture_error_mode="thread_local"):
-                    bwd_encoder()
-            g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
-                opt.step()
-        except Exception as e:  # noqa: BLE001 -- report and fall back to eager launches, loudly
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            use_graph = False
-            torch.cuda.synchronize()
-
-    def step():
-        if not use_graph:
-            step_eager()
-        elif split:
-            g_fb.replay()
-            h = reduce_begin(0)          # decoder / postnet gradients travel ...
-            g_fb2.replay()               # ... while the encoder's backward pass runs
-            h += reduce_begin(1)
-            allreduce_end(h)
-            g_opt.replay()
-        else:
-            g_fb.replay()
-            if dp:
-                allreduce_mean_(opt.flat_g, dist, world, force=args.force_dist)
-            g_opt.replay()
-
-    for _ in range(args.warmup):
-        step()
-
-    def barrier():
-        if dp:
-            dist.barrier()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    B = args.batch or (32 if args.workload == "vtn" else 16)
+    wl = Workload(args.workload, dev, dtype, B, world, rank)
+    staged = dp or args.split_backward
+    step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph,
+                            warmup_eager=max(2, args.warmup if args.no_graph else 2))
+    dt = time_steps(step, args.steps, args.warmup, dist if dp else None, dev)
     if dp:
-        tt = torch.tensor([dt], device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        ft = torch.tensor([frames_local], device=dev)
+        ft = torch.tensor([wl.frames], device=dev)
         dist.all_reduce(ft)
         frames = float(ft.item())
     else:
-        frames = frames_local
+        frames = wl.frames
     ms = dt / args.steps * 1e3
-    losses = loss_buf.tolist()
-    stats = opt.last_stats()
+    losses = wl.loss_buf.tolist()
+    stats = wl.opt.last_stats()
     if not all(map(lambda v: v == v and abs(v) < 1e6, losses)):
         raise SystemExit(f"bench: non-finite loss {losses}")
 
@@ -347,19 +575,24 @@ def main():
             "metric": "mel-frames/sec (train)", "value": frames / (dt / args.steps), "unit": "mel-frames/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "VTN egs/arctic/vc1 (vtn.v1.yaml) training step: fwd+Seq2SeqLoss+bwd+clip+Adam+WarmupLR",
-                       "batch_per_gpu": B, "global_batch": B * world, "T_src": 256, "T_tgt": 256, "mel_dim": 80,
-                       "params_M": 30.48, "parallelism": f"dp{world}", "hip_graph": bool(use_graph), "split_backward": bool(split),
-                       "valid_target_frames_per_step": frames},
-            "final_losses": {"l1": losses[0], "bce": losses[1], "grad_norm": stats["grad_norm"], "opt_steps": stats["step"]},
-            "step_mfma": {"gflop_per_step_per_gpu": FWD_BWD_GFLOP,
-                          "achieved_tflops_per_gpu": FWD_BWD_GFLOP / ms,
-                          "frac_of_bf16_peak": FWD_BWD_GFLOP / ms / BF16_MFMA_PEAK_TFLOPS},
+            "config": {"workload": wl.desc, "batch_per_gpu": B, "global_batch": B * world, "T_src": 256, "T_tgt": 256, "mel_dim": 80,
+                       "params_M": round(wl.params_m, 2), "parallelism": f"dp{world}", "split_backward": bool(staged),
+                       "valid_target_frames_per_step": frames, **info},
+            "final_losses": dict(zip(wl.loss_names, losses), grad_norm=stats["grad_norm"], opt_steps=stats["step"]),
+            "step_mfma": step_mfma(args.workload, ms),
         }
-        out["roofline"] = dominant_kernel_roofline(dtype)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cpu_batch)
+        out["roofline"] = dominant_kernel_roofline(dtype, workload=args.workload)
+        single = world == 1 and not args.force_dist
+        if single and not args.no_cpu_baseline:
+            out["cpu_baseline"] = (cpu_baseline_vtn if args.workload == "vtn" else cpu_baseline_aasvc)(wl.cpu_batch)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if single and args.workload == "vtn" and not args.no_extras:
+            del step
+            wl.model = wl.opt = None
+            torch.cuda.empty_cache()
+            out["aasvc"] = bench_aasvc_single(dev, dtype, cpu=not args.no_cpu_baseline)
+            Fn.enable_side_streams(0)
+            out["decode"] = bench_decode(dev, dtype, cpu=not args.no_cpu_baseline)
         # RCCL writes its version banner to the C-level stdout; flush that buffer first so the JSON line stays the last line
         sys.stdout.flush()
         try:

@@ -250,7 +250,11 @@ class FlatAdam:
                 k = p.numel()
                 state[i] = {"step": step.clone(), "exp_avg": self.exp_avg[o:o + k].view(p.shape).detach().cpu().clone(),
                             "exp_avg_sq": self.exp_avg_sq[o:o + k].view(p.shape).detach().cpu().clone()}
-        group = {"lr": float(self.state[1]) if float(step) > 0 else self.lr, "betas": tuple(self.betas), "eps": self.eps,
+        k = int(float(step))
+        # torch's group["lr"] after k optimiser + k scheduler steps is the value the NEXT step will use (WarmupLR at k + 1)
+        w = self.warmup_steps
+        next_lr = self.lr * w ** 0.5 * min((k + 1) ** -0.5, (k + 1) * w ** -1.5) if w > 0 else self.lr
+        group = {"lr": next_lr, "betas": tuple(self.betas), "eps": self.eps,
                  "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
                  "differentiable": False, "fused": None, "initial_lr": self.lr, "params": list(range(len(self.all_params)))}
         return {"state": state, "param_groups": [group],
