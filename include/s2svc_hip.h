@@ -130,6 +130,13 @@ int s2svc_tconv2d_weights(int O, int C, const float* w, void* out_bf16, void* st
 int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc /* host */);
 int s2svc_gemm_grouped(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream);
 
+/* Kernel-family switch for tests / A-B timing of s2svc_gemm's bf16 path: the 256-row, 8-wave, phase-interleaved kernel
+   (csrc/gemm_8ph.hip: K-contiguous dense or Conv2d-3x3-s2 A operand, dense B, K % 64 == 0, >= 128 tiles) is tried first.
+   mode & 15: 0 = never, 1 = default policy, 2 = policy without the half-phase skew of the two wave halves;
+   mode >> 4: 0 = tile geometry by policy, 1 = 256 x 256, 2 = 512 x 128, 3 = 256 x 128 forced (eligible problems only).
+   Returns the previous mode (mode < 0: query only).  Results do not depend on the mode beyond fp32 summation order. */
+int s2svc_gemm_set_8ph(int mode);
+
 /* ========================================================================================== */
 /* LayerNorm fused with residual-add + dropout; BatchNorm1d; deterministic column reductions  */
 /* replaces: modules/transformer/layer_norm.py:12-42 and the `residual + dropout(...)` lines   */
@@ -250,6 +257,23 @@ int s2svc_mas_binloss_bwd(int B, int Tf, int Tx, const int32_t* path, const int3
                           float* dlogp, void* stream);
 int s2svc_gauss_upsample_probs(int dtype, int B, int Tf, int Tx, const float* ds, const int32_t* text_lens,
                                const int32_t* feat_lens, float delta, void* P, void* stream);
+
+/* Length regulator of FastSpeech-style models -- replaces modules/length_regulator.py:46-97 (per-utterance
+   torch.repeat_interleave + pad_list): frame i of utterance b is repeated ds[b, i] times.
+     _index: start (B,Tx) = exclusive prefix sums of ds, idx (B,Tout) = source frame of every output frame (-1 = padding),
+             total (B) = sum of ds (may be NULL);   _fwd: y (B,Tout,D) = x[b, idx] or pad_value;
+     _bwd:   dx (B,Tx,D) = sum of dy over each frame's run (fixed order, no atomics). */
+int s2svc_length_regulate_index(int B, int Tx, int Tout, const int32_t* ds, int32_t* start, int32_t* idx, int32_t* total,
+                                void* stream);
+int s2svc_length_regulate_fwd(int dtype, int B, int Tx, int Tout, int D, const void* x, const int32_t* idx, float pad_value,
+                              void* y, void* stream);
+int s2svc_length_regulate_bwd(int dtype, int B, int Tx, int Tout, int D, const void* dy, const int32_t* start, const int32_t* ds,
+                              void* dx, void* stream);
+/* Durations from attention maps -- replaces utils/duration_calculator.py:13-65: att (NH, Tf, Tx) fp32 (NH = layers * heads,
+   or 1); picks the head with the largest mean row maximum, durations[j] (int64) = number of frames whose arg-max is j;
+   focus_rate / head (device scalars, may be NULL) = that head's score / index. */
+int s2svc_attn_durations(int NH, int Tf, int Tx, const float* att, int64_t* durations, float* focus_rate, int32_t* head,
+                         void* stream);
 
 /* ========================================================================================== */
 /* Losses                                                                                      */

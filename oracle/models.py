@@ -438,6 +438,100 @@ def aasvc_forward(sd, c, xs, ilens, ys, olens, dp_inputs=None, noise=None, train
 
 
 # =============================================================================================
+# FastSpeechVC (models/fastspeech_vc.py:244-466), LengthRegulator (modules/length_regulator.py:46-97),
+# DurationCalculator (utils/duration_calculator.py:13-65)
+# =============================================================================================
+def length_regulator(xs, ds, alpha=1.0, pad_value=0.0):
+    if alpha != 1.0:
+        ds = torch.round(ds.float() * alpha).long()
+    if ds.sum() == 0:
+        ds = ds.clone()
+        ds[ds.sum(dim=1).eq(0)] = 1
+    rep = [torch.repeat_interleave(x, d, dim=0) for x, d in zip(xs, ds)]
+    tmax = max(r.shape[0] for r in rep)
+    out = xs.new_full((len(rep), tmax) + tuple(xs.shape[2:]), pad_value)
+    for i, r in enumerate(rep):
+        out[i, : r.shape[0]] = r
+    return out
+
+
+def duration_calculator(att_ws):
+    if att_ws.dim() == 4:
+        a = att_ws.reshape(-1, att_ws.shape[-2], att_ws.shape[-1])
+        scores = a.max(dim=-1)[0].mean(dim=-1)
+        focus = scores.max()
+        a = a[scores.argmax()]
+    else:
+        a = att_ws
+        focus = a.max(dim=-1)[0].mean()
+    durations = torch.stack([a.argmax(-1).eq(i).sum() for i in range(a.shape[1])])
+    return durations.view(-1), focus
+
+
+def fastspeech_vc_forward(sd, c, xs, ilens, ys=None, olens=None, ds=None, dp_inputs=None, training=True, drop=False,
+                          inference=False, alpha=1.0):
+    rt = Runtime(training, drop)
+    adim, heads = _cfg(c, "adim", 384), _cfg(c, "aheads", 4)
+    er, dr = _cfg(c, "encoder_reduction_factor", 1), _cfg(c, "decoder_reduction_factor", 1)
+    teacher_r = _cfg(c, "teacher_model_decoder_reduction_factor", 4)
+    odim = c["odim"]
+    if not inference:
+        xs = xs[:, : int(ilens.max())]
+        ys = ys[:, : int(olens.max())]
+    if er > 1:
+        b, tmax, dim = xs.shape
+        if tmax % er:
+            xs = xs[:, : -(tmax % er)]
+        xs = xs.reshape(b, tmax // er, dim * er)
+        ilens = ilens // er
+    enc_type = c.get("encoder_type", "transformer")
+    inl = c.get("encoder_input_layer", "linear")
+    pos_type = c.get("conformer_pos_enc_layer_type", "rel_pos")
+    ff = c.get("positionwise_layer_type", "conv1d")
+    x_masks = N.non_pad_mask(ilens)[:, None, :]
+    if enc_type == "transformer":
+        hs, _ = _vtn_encoder(sd, dict(c, encoder_type="transformer"), xs, x_masks, rt)
+    else:
+        hs, _ = N.conformer_encoder(P(sd, "encoder."), xs, x_masks, c, rt, heads, inl, pos_type,
+                                    _cfg(c, "transformer_enc_dropout_rate", 0.1), _cfg(c, "transformer_enc_positional_dropout_rate", 0.1),
+                                    _cfg(c, "transformer_enc_attn_dropout_rate", 0.1), c.get("encoder_normalize_before", False),
+                                    "encoder", ff)
+    if inl == "conv2d":
+        ilens = ((ilens - 2 + 1) // 2 - 2 + 1) // 2
+    if c.get("duration_predictor_use_encoder_outputs", True):
+        dpi = hs
+    else:
+        dpi, _ = N.conv2d_subsample(P(sd, "duration_predictor_projection."), dp_inputs, None)
+        dpi = torch.stack([F.interpolate(dpi[i][None].permute(0, 2, 1), size=hs.shape[1]).permute(0, 2, 1)[0]
+                           for i in range(dpi.shape[0])])
+    dp = P(sd, "duration_predictor.")
+    if inference:
+        d_outs = duration_predictor(dp, dpi, None, rt, _cfg(c, "duration_predictor_dropout_rate", 0.1), inference=True)
+        hs = length_regulator(hs, d_outs * teacher_r, alpha)
+        h_masks = None
+    else:
+        d_outs = duration_predictor(dp, dpi, N.non_pad_mask(ilens, dpi.shape[1]), rt, _cfg(c, "duration_predictor_dropout_rate", 0.1))
+        hs = length_regulator(hs, ds * teacher_r)
+        olens_in = olens // dr if dr > 1 else olens
+        h_masks = N.non_pad_mask(olens_in)[:, None, :]
+    zs, _ = N.conformer_encoder(P(sd, "decoder."), hs, h_masks, c, rt, heads, None, pos_type,
+                                _cfg(c, "transformer_dec_dropout_rate", 0.1), _cfg(c, "transformer_dec_positional_dropout_rate", 0.1),
+                                _cfg(c, "transformer_dec_attn_dropout_rate", 0.1), c.get("decoder_normalize_before", False),
+                                "decoder", ff)
+    before = N.linear(P(sd, "feat_out."), zs).reshape(zs.shape[0], -1, odim)
+    if P(sd, "postnet.").has("postnet.0.0.weight"):
+        after = before + N.postnet(P(sd, "postnet."), before.transpose(1, 2), rt, _cfg(c, "postnet_dropout_rate", 0.5)).transpose(1, 2)
+    else:
+        after = before
+    if inference:
+        return before, after, d_outs, ilens
+    if dr > 1:
+        olens = olens - olens % dr
+        ys = ys[:, : int(olens.max())]
+    return before, after, d_outs, ilens, olens, ys
+
+
+# =============================================================================================
 # losses (losses/*.py)
 # =============================================================================================
 def seq2seq_loss(after, before, logits, ys, labels, olens, bce_pos_weight=10.0):  # losses/seq2seq_loss.py:30-59

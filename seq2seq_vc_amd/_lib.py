@@ -93,6 +93,11 @@ _SIGS = {
     "s2svc_gemm_grouped_ok": [c_vp],
     "s2svc_tconv2d_weights": [c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_gemm_grouped": [c_vp, c_i32, c_i32, c_vp],
+    "s2svc_gemm_set_8ph": [c_i32],
+    "s2svc_length_regulate_index": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_length_regulate_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp],
+    "s2svc_length_regulate_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_attn_durations": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_layernorm_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_layernorm_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_colreduce_grouped": [c_vp, c_i32, c_vp],

@@ -39,7 +39,8 @@ class NARVCCollater(object):
         if "duration" in batch[0]:
             ds = [b["duration"] for b in batch]
             items["durations"] = pad_batch(ds, torch.long)
-            items["duration_lens"] = _lens(ds)
+            # (the reference measures the lengths AFTER padding, nar_vc.py:84-88: every entry is the padded length)
+            items["duration_lens"] = torch.full((len(ds),), items["durations"].shape[1], dtype=torch.long)
         return items
 
 

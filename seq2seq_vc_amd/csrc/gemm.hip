@@ -328,6 +328,7 @@ int launch(const s2svc_gemm_desc& d, hipStream_t st) {
 extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream);    // gemm_fast.hip
 extern "C" int s2svc_gemm_try_skinny(const s2svc_gemm_desc* desc, void* stream);  // gemm_skinny.hip (M <= 64)
 extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream);    // gemm_glds.hip (bf16, LDS-DMA)
+extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream);     // gemm_8ph.hip (bf16, 256-row tiles, 8 waves)
 
 static bool generic_forced() {
   static int v = -1;
@@ -373,7 +374,8 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   if (!generic_forced()) {
     const int rs = s2svc_gemm_try_skinny(&d, stream);
     if (rs != 0) return rs < 0 ? rs : finish(false);
-    int rc = s2svc_gemm_try_glds(&d, stream);
+    int rc = d.c_map ? 0 : s2svc_gemm_try_8ph(&d, stream);
+    if (rc == 0) rc = s2svc_gemm_try_glds(&d, stream);
     const bool native_stage = rc == 1 && d.splitk <= 1;
     if (rc == 0) rc = s2svc_gemm_try_fast(&d, stream);
     if (rc < 0) return rc;

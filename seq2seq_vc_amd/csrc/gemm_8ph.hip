@@ -1,0 +1,450 @@
+// bf16 MFMA GEMM, 256-row tiles, 8 wavefronts, phase-interleaved (the guide's "256^2 8-phase" structure, written for this
+// library's operand descriptors).  Same contract as gemm_glds.hip for the operand kinds it takes:
+//   A: K-contiguous, dense or implicit-im2col Conv2d 3x3 stride 2 (activations / output gradients),
+//   B: K-contiguous dense (weights, or their transposed bf16 shadow for data gradients),  K % 64 == 0, no split-K.
+//
+// Why another kernel: the 128x128 / 4-wave kernel of gemm_glds.hip issues [DMA next tile | fragment reads | 32 MFMAs | drain |
+// barrier] once per K tile and every wave of the workgroup is in the same phase at the same time -- its SQ counters read
+// MFMA pipe busy 38 %, waves parked at s_waitcnt / barrier 36 % (profiles/r01_roofline_pmc_sq.txt).  Here
+//   * a workgroup is 8 waves (2 along M x 4 along N) on a 256 x BN tile, BN = 256 or 128: two waves per SIMD, one from
+//     each M half.  The halves run half a phase apart (one extra s_barrier for the second half before the loop), so while
+//     one wave of a SIMD issues its 16 MFMAs the other one issues LDS reads and LDS-DMA instructions;
+//   * a K tile (BK = 64) is consumed in phases of 16 MFMAs: one 64 x 32 quadrant of the wave's 128 x 64 output (BN = 256,
+//     4 phases) or one 64 x 32 half of its 128 x 32 output (BN = 128, 2 phases).  A phase reads only the fragments it
+//     newly needs (A rows of one M half: 8 ds_read_b128, B rows of one N half: 4) -- 0.375 LDS fragment reads per MFMA
+//     instead of 0.5;
+//   * staging is LDS-DMA (global_load_lds_dwordx4) in UNITS of 128 rows x 64 k (16 KB, 2 instructions per wave).  A unit
+//     holds the rows that die together: A.m0 = the first 64 rows of both wave rows, A.m1 = the second, B.n0 / B.n1 = the
+//     first / second 32 columns of all four wave columns.  A unit is re-filled, for the K tile two ahead, in the phase
+//     after its last read; the wait is a COUNTED s_waitcnt vmcnt(6) -- three units stay in flight across every
+//     barrier, nothing drains in the loop.  LDS: 2 K tiles x (256 + BN) rows x 128 B = 128 / 96 KB, one workgroup per CU.
+//   Ordering rules (see MI355X_MICROARCH.md, "Two waves per SIMD", item 7): a unit is read one phase AFTER the phase whose
+//   vmcnt wait (placed before that phase's first barrier) retired it; a unit is re-filled in the phase AFTER the one whose
+//   reads of it were retired by lgkmcnt(0) before that phase's first barrier.  Both hold for either wave half at half a
+//   phase of skew.
+//   * LDS image of a unit: lane-linear per DMA instruction (8 rows x 128 B), piece c of row r at r*128 + ((c ^ ((r>>1)&7))<<4)
+//     -- the XOR is applied to the per-lane SOURCE address and to the fragment read address (conflict-free ds_read_b128).
+//   * epilogue: the accumulators leave through wave-private fp32 LDS tiles, 64 x 32 at a time (epilogue_tile: bias /
+//     activation / dropout / residual / c_map, 16-byte stores).
+#include <cstring>
+#include "gemm_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __attribute__((aligned(16))) uint4 g_zero16_8ph = {0u, 0u, 0u, 0u};
+
+enum { P8_DENSE = 0, P8_CONV2D = 1 };
+
+template <int N> __device__ __forceinline__ void p8_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void p8_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void p8_tile_of_block(int& bm, int& bn) {     // XCD-aware tile order (see gemm_glds.hip)
+  const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+  int id = blockIdx.y * gx + blockIdx.x;
+  if (gridDim.z == 1 || (nwg & 7) == 0) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = id & 7, j = id >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  bm = id / gx;
+  bn = id - bm * gx;
+}
+
+// byte offset of (row r, piece slot for k piece c) inside a unit
+__device__ __forceinline__ int p8_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// The scalar part of a source address: byte offset of K tile kt from the operand's base (added to the uniform base pointer).
+template <int KIND>
+struct P8Walk {
+  int kt, c0, kh, kw;       // conv2d: K tile kt starts at channel c0 of tap (kh, kw); walked, no division in the loop
+  __device__ __forceinline__ void init(const s2svc_operand& o, int kt0) {
+    kt = kt0;
+    if (KIND == P8_CONV2D) {
+      const int k0 = kt0 * 64, tap = k0 / o.C;
+      c0 = k0 - tap * o.C;
+      kh = tap / 3;
+      kw = tap - kh * 3;
+    }
+  }
+  __device__ __forceinline__ int64_t off_bytes(const s2svc_operand& o) const {
+    if (KIND == P8_CONV2D) return ((int64_t)(kh * o.F1 + kw) * o.ld + c0) * 2;
+    return (int64_t)kt * 128;
+  }
+  __device__ __forceinline__ void next(const s2svc_operand& o) {
+    ++kt;
+    if (KIND == P8_CONV2D) {
+      c0 += 64;
+      if (c0 >= o.C) {
+        c0 = 0;
+        if (++kw == 3) { kw = 0; ++kh; }
+      }
+    }
+  }
+};
+
+// per-lane byte offset of tile row `r` (clamped into the matrix), source piece `c`
+template <int KIND>
+__device__ __forceinline__ uint32_t p8_rowoff(const s2svc_operand& o, int r, int R, int c) {
+  if (r >= R) r = R - 1;            // rows past the matrix: their products only reach C rows / columns that are never stored
+  int64_t e;
+  if (KIND == P8_CONV2D) {
+    const int bt = r / o.F2, f2 = r - bt * o.F2;
+    const int b = bt / o.T2, t2 = bt - b * o.T2;
+    e = ((int64_t)(b * o.T1 + 2 * t2) * o.F1 + 2 * f2) * o.ld;
+  } else {
+    e = (int64_t)r * o.ld;
+  }
+  return (uint32_t)((e + c * 8) * 2);
+}
+
+// one unit = NI DMA instructions of this wave; base == nullptr: the unit lies past the last K tile (the instructions are
+// still issued, from a zero block, so that the counted waits stay exact)
+template <int NI>
+__device__ __forceinline__ void p8_issue(const char* base, const uint32_t (&off)[NI], char* lds_unit, int wave_s) {
+  const char* b = base ? base : reinterpret_cast<const char*>(&g_zero16_8ph);
+#pragma unroll
+  for (int e = 0; e < NI; ++e) {
+    const uint32_t o = base ? off[e] : 0u;
+    __builtin_amdgcn_global_load_lds((gbl_void*)(b + o), (lds_void*)(lds_unit + (wave_s * NI + e) * 1024), 16, 0, 0);
+  }
+}
+
+// fragment reads of one unit: NF row blocks of 16 rows starting at unit row r0, both k halves of the tile
+template <int NF>
+__device__ __forceinline__ void p8_read(const char* unit, int rd_base, int p0, int p1, bf16x8_t (&f)[NF][2]) {
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    f[i][0] = *reinterpret_cast<const bf16x8_t*>(unit + rd_base + i * 2048 + p0);
+    f[i][1] = *reinterpret_cast<const bf16x8_t*>(unit + rd_base + i * 2048 + p1);
+  }
+}
+
+template <int NA, int NB>
+__device__ __forceinline__ void p8_mfma(const bf16x8_t (&a)[NA][2], const bf16x8_t (&b)[NB][2], f32x4_t (&acc)[NA][NB]) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+}
+
+#define P8_PHASE_SYNC_IN()                 \
+  p8_wait_lgkm0();                         \
+  __builtin_amdgcn_sched_barrier(0);       \
+  __builtin_amdgcn_s_barrier();            \
+  __builtin_amdgcn_sched_barrier(0)
+#define P8_PHASE_SYNC_OUT()                \
+  __builtin_amdgcn_sched_barrier(0);       \
+  __builtin_amdgcn_s_barrier();            \
+  __builtin_amdgcn_sched_barrier(0)
+
+// ---------------------------------------------------------------------------------------------------------
+// 4 phases per K tile, wave tile 128 x 64.  (WR, WC) = wave rows x wave columns: (2, 4) -> 256 x 256 tile, 128 KB LDS;
+// (4, 2) -> 512 x 128 tile for outputs with few columns (N = 384: 3 column tiles, 225 workgroups on 256 CUs), 160 KB LDS.
+// Units: A.m0 / A.m1 = WR * 64 rows (WR DMA instructions per wave), B.n0 / B.n1 = WC * 32 rows (WC / 2 per wave).
+// ---------------------------------------------------------------------------------------------------------
+template <int KA, int WR, int WC, bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d) {
+  static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
+  constexpr int BM = WR * 128, BN = WC * 64;
+  constexpr int NIA = WR, NIB = WC / 2;                      // DMA instructions per wave and unit
+  constexpr int UA = WR * 64 * 128, UB = WC * 32 * 128;      // unit bytes
+  constexpr int BUF = 2 * UA + 2 * UB;                       // A.m0 | A.m1 | B.n0 | B.n1
+  constexpr int OA0 = 0, OA1 = UA, OB0 = 2 * UA, OB1 = 2 * UA + UB;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+  const int zb = blockIdx.z;
+  const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
+  int tile_m, tile_n;
+  p8_tile_of_block(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const char* Ab = reinterpret_cast<const char*>((const bf16_t*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1);
+  const char* Bb = reinterpret_cast<const char*>((const bf16_t*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1);
+  const int nt = d.K / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int half = wave >> 2;                                 // waves w and w + 4 share a SIMD: the two halves run skewed
+  const int lr = lane & 15, lg = lane >> 4;
+
+  // source offsets of this wave's DMA instructions per unit
+  uint32_t offA[2][NIA], offB[2][NIB];
+#pragma unroll
+  for (int e = 0; e < NIA; ++e) {
+    const int ru = (wave * NIA + e) * 8 + (lane >> 3);            // unit row of this lane
+    const int c = (lane & 7) ^ ((ru >> 1) & 7);                   // source piece that belongs in this lane's slot
+#pragma unroll
+    for (int h = 0; h < 2; ++h) offA[h][e] = p8_rowoff<KA>(d.A, m0 + (ru >> 6) * 128 + h * 64 + (ru & 63), d.M, c);
+  }
+#pragma unroll
+  for (int e = 0; e < NIB; ++e) {
+    const int ru = (wave * NIB + e) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((ru >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) offB[h][e] = p8_rowoff<P8_DENSE>(d.B, n0 + (ru >> 5) * 64 + h * 32 + (ru & 31), d.N, c);
+  }
+  // fragment read addresses
+  const int sw = (lr >> 1) & 7;
+  const int p0 = (lg ^ sw) << 4, p1 = ((4 + lg) ^ sw) << 4;
+  const int rdA = (wr * 64 + lr) * 128, rdB = (wc * 32 + lr) * 128;
+
+  f32x4_t acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  P8Walk<KA> wa;          // K tile of the next A unit to issue
+  wa.init(d.A, 0);
+  // prologue: tile 0 complete, tile 1 without B.n0 (issued in phase 1 of tile 0)
+  {
+    const char* a0 = Ab + wa.off_bytes(d.A);
+    p8_issue<NIA>(a0, offA[0], smem + OA0, wave);
+    p8_issue<NIB>(Bb, offB[0], smem + OB0, wave);
+    p8_issue<NIB>(Bb, offB[1], smem + OB1, wave);
+    p8_issue<NIA>(a0, offA[1], smem + OA1, wave);
+    wa.next(d.A);
+    const bool has1 = nt > 1;
+    const char* a1 = has1 ? Ab + wa.off_bytes(d.A) : nullptr;
+    const char* b1 = has1 ? Bb + 128 : nullptr;
+    p8_issue<NIA>(a1, offA[0], smem + BUF + OA0, wave);
+    p8_issue<NIB>(b1, offB[1], smem + BUF + OB1, wave);
+    p8_issue<NIA>(a1, offA[1], smem + BUF + OA1, wave);
+    wa.next(d.A);
+  }
+  p8_wait_vmcnt<2 * NIA + NIB>();
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && half == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t & 1) ^ 1) * BUF;
+    const char* a2 = (t + 2 < nt) ? Ab + wa.off_bytes(d.A) : nullptr;        // A units of tile t + 2
+    const char* b2 = (t + 2 < nt) ? Bb + (int64_t)(t + 2) * 128 : nullptr;
+    const char* b1 = (t + 1 < nt) ? Bb + (int64_t)(t + 1) * 128 : nullptr;
+    // ---- phase 1: quadrant (m0, n0)
+    p8_read<2>(cur + OB0, rdB, p0, p1, fb0);
+    p8_read<4>(cur + OA0, rdA, p0, p1, fa);
+    p8_issue<NIB>(b1, offB[0], oth + OB0, wave);                              // B.n0 of tile t + 1
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb0, acc[0][0]);
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 2: quadrant (m0, n1)
+    p8_read<2>(cur + OB1, rdB, p0, p1, fb1);
+    p8_issue<NIA>(a2, offA[0], cur + OA0, wave);                              // A.m0 of tile t + 2
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb1, acc[0][1]);
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 3: quadrant (m1, n1)
+    p8_read<4>(cur + OA1, rdA, p0, p1, fa);
+    p8_issue<NIB>(b2, offB[1], cur + OB1, wave);                              // B.n1 of tile t + 2
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb1, acc[1][1]);
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 4: quadrant (m1, n0)   (fb0 is still live: B.n0 needs no second read, its unit died after phase 1 --
+    //      it is nevertheless re-filled only in phase 1 of the next tile, keeping one unit per phase)
+    p8_issue<NIA>(a2, offA[1], cur + OA1, wave);                              // A.m1 of tile t + 2
+    p8_wait_vmcnt<2 * NIA + NIB>();                                           // everything of tile t + 1 has landed
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb0, acc[1][0]);
+    P8_PHASE_SYNC_OUT();
+    wa.next(d.A);
+  }
+  if (STAGGER && half == 0) __builtin_amdgcn_s_barrier();
+  p8_wait_vmcnt<0>();                  // the zero-block DMAs issued past the end
+  __syncthreads();                     // every wave is done with the operand stages: reuse them as fp32 C tiles
+  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      epilogue_tile<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 64 + b * 32, acc[a][b], cs, 1, 0, zb);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BN = 128: 2 phases per K tile (wave tile 128 x 32: a phase = 64 rows x 32 columns x K 64)
+// ---------------------------------------------------------------------------------------------------------
+template <int KA, bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc d) {
+  constexpr int UNIT = 16384, BUF = 3 * UNIT;            // A.m0 | A.m1 | B
+  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+  const int zb = blockIdx.z;
+  const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
+  int tile_m, tile_n;
+  p8_tile_of_block(tile_m, tile_n);
+  const int m0 = tile_m * 256, n0 = tile_n * 128;
+  const char* Ab = reinterpret_cast<const char*>((const bf16_t*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1);
+  const char* Bb = reinterpret_cast<const char*>((const bf16_t*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1);
+  const int nt = d.K / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  uint32_t offA[2][2], offB[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int ru = (wave * 2 + e) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((ru >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) offA[h][e] = p8_rowoff<KA>(d.A, m0 + (ru >> 6) * 128 + h * 64 + (ru & 63), d.M, c);
+    offB[e] = p8_rowoff<P8_DENSE>(d.B, n0 + ru, d.N, c);
+  }
+  const int sw = (lr >> 1) & 7;
+  const int p0 = (lg ^ sw) << 4, p1 = ((4 + lg) ^ sw) << 4;
+  const int rdA = (wr * 64 + lr) * 128, rdB = (wc * 32 + lr) * 128;
+
+  f32x4_t acc[2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  P8Walk<KA> wa0, wa1;    // K tile of the next A.m0 / A.m1 unit to issue (A.m1 runs one tile behind A.m0 in issue order)
+  wa0.init(d.A, 0);
+  wa1.init(d.A, 0);
+  {
+    const char* a0 = Ab + wa0.off_bytes(d.A);
+    p8_issue<2>(a0, offA[0], smem + 0 * UNIT, wave);
+    p8_issue<2>(Bb, offB, smem + 2 * UNIT, wave);
+    p8_issue<2>(a0, offA[1], smem + 1 * UNIT, wave);
+    wa0.next(d.A);
+    wa1.next(d.A);
+    const bool has1 = nt > 1;
+    p8_issue<2>(has1 ? Ab + wa0.off_bytes(d.A) : nullptr, offA[0], smem + BUF + 0 * UNIT, wave);
+    p8_issue<2>(has1 ? Bb + 128 : nullptr, offB, smem + BUF + 2 * UNIT, wave);
+    wa0.next(d.A);
+  }
+  p8_wait_vmcnt<4>();                  // tile 0 has landed (A.m0, B of tile 1 may still be moving)
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8_t fa[4][2], fb[2][2];
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t & 1) ^ 1) * BUF;
+    // ---- phase 1: rows m0
+    p8_read<2>(cur + 2 * UNIT, rdB, p0, p1, fb);
+    p8_read<4>(cur + 0 * UNIT, rdA, p0, p1, fa);
+    p8_issue<2>((t + 1 < nt) ? Ab + wa1.off_bytes(d.A) : nullptr, offA[1], oth + 1 * UNIT, wave);     // A.m1 of tile t + 1
+    p8_wait_vmcnt<6>();                                                                             // A.m1 of tile t has landed
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb, acc[0]);
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 2: rows m1
+    p8_read<4>(cur + 1 * UNIT, rdA, p0, p1, fa);
+    p8_issue<2>((t + 2 < nt) ? Ab + wa0.off_bytes(d.A) : nullptr, offA[0], cur + 0 * UNIT, wave);     // A.m0 of tile t + 2
+    p8_issue<2>((t + 2 < nt) ? Bb + (int64_t)(t + 2) * 128 : nullptr, offB, cur + 2 * UNIT, wave);    // B of tile t + 2
+    p8_wait_vmcnt<6>();                                                                             // A.m0, B of tile t + 1 have landed
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb, acc[1]);
+    P8_PHASE_SYNC_OUT();
+    wa0.next(d.A);
+    wa1.next(d.A);
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+  p8_wait_vmcnt<0>();
+  __syncthreads();
+  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+    epilogue_tile<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, acc[a], cs, 1, 0, zb);
+}
+
+int g_p8_mode = -1;
+int p8_mode() {       // S2SVC_GEMM_8PH / s2svc_gemm_set_8ph: 0 = off, 1 = on (default), 2 = on without the half-phase skew of the wave halves
+  if (g_p8_mode < 0) { const char* e = getenv("S2SVC_GEMM_8PH"); g_p8_mode = e ? atoi(e) : 1; }
+  return g_p8_mode;
+}
+
+int p8_min_tiles() {  // S2SVC_GEMM_8PH_MIN_TILES: take the kernel from this many 256-row tiles on
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_8PH_MIN_TILES"); v = e ? atoi(e) : 128; }
+  return v;
+}
+
+int g_p8_geo = -1;
+int p8_force_bn() {   // S2SVC_GEMM_8PH_GEO=1|2|3 / s2svc_gemm_set_8ph: force the tile geometry 256x256 / 512x128 / 256x128
+  if (g_p8_geo < 0) { const char* e = getenv("S2SVC_GEMM_8PH_GEO"); g_p8_geo = e ? atoi(e) : 0; }
+  return g_p8_geo;
+}
+
+bool p8_operand_ok(const s2svc_operand& o, int rows, int K) {
+  if (o.layout != S2SVC_LAYOUT_KC || ((uintptr_t)o.ptr) % 16 || o.ld % 8 || o.bs0 % 8 || o.bs1 % 8) return false;
+  int64_t elems;
+  if (o.mode == S2SVC_OP_DENSE) {
+    elems = (int64_t)rows * o.ld;
+  } else if (o.mode == S2SVC_OP_CONV2D_S2) {
+    if (o.C % 64 || o.C < 64 || K != 9 * o.C) return false;
+    elems = (int64_t)(rows / (o.T2 * o.F2) + 1) * o.T1 * o.F1 * o.ld;
+  } else {
+    return false;
+  }
+  return elems * 2 < (1ll << 32);            // 32-bit per-lane byte offsets
+}
+
+}  // namespace
+
+// A/B switch for tests and benchmarks: returns the previous mode (see p8_mode)
+extern "C" int s2svc_gemm_set_8ph(int mode) {
+  const int prev = p8_mode() | (p8_force_bn() << 4);
+  if (mode >= 0 && (mode & 15) <= 2 && (mode >> 4) <= 3) {
+    g_p8_mode = mode & 15;
+    g_p8_geo = mode >> 4;
+  }
+  return prev;
+}
+
+// returns 1 if launched here, 0 if the problem is not eligible (the caller falls through to gemm_glds.hip)
+extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
+  const s2svc_gemm_desc& d = *desc;
+  const int mode = p8_mode();
+  if (mode == 0 || d.dtype != S2S_BF16 || d.splitk > 1 || d.a_rowsum || d.tile_hint == 64) return 0;
+  if (d.K < 128 || d.K % 64 || d.M < 256 || d.N < 64) return 0;
+  if (d.B.mode != S2SVC_OP_DENSE || !p8_operand_ok(d.A, d.M, d.K) || !p8_operand_ok(d.B, d.N, d.K)) return 0;
+  const int64_t nb = (int64_t)d.nb0 * d.nb1;
+  const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * nb;       // 256 x 256 tiles
+  const int64_t t512 = (int64_t)((d.M + 511) / 512) * ((d.N + 127) / 128) * nb;       // 512 x 128 tiles
+  const int64_t t128 = (int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128) * nb;       // 256 x 128 tiles (2-phase kernel)
+  // geometry: square tiles when the columns fill them and the grid fills the chip; tall tiles for outputs with few
+  // columns (fewer wasted columns, one round of workgroups); the 2-phase 256 x 128 kernel for what is left
+  int geo = 0;                                   // 1: 256 x 256, 2: 512 x 128, 3: 256 x 128
+  const int waste256 = (int)(((d.N + 255) / 256) * 256 - d.N), waste128 = (int)(((d.N + 127) / 128) * 128 - d.N);
+  if (waste256 <= waste128 && t256 >= 192) geo = 1;
+  else if (d.M >= 2048 && t512 >= 160 && t512 <= 256) geo = 2;
+  else if (t128 >= p8_min_tiles()) geo = 3;
+  if (p8_force_bn() >= 1 && p8_force_bn() <= 3) geo = p8_force_bn();
+  if (geo == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool conv = d.A.mode == S2SVC_OP_CONV2D_S2;
+  const int bm = geo == 2 ? 512 : 256, bn = geo == 1 ? 256 : 128;
+  dim3 grid((unsigned)((d.N + bn - 1) / bn), (unsigned)((d.M + bm - 1) / bm), (unsigned)nb);
+#define P8_LAUNCH(KERNEL, ...)                                                                            \
+  do {                                                                                                    \
+    if (mode == 2) {                                                                                      \
+      if (conv) hipLaunchKernelGGL((KERNEL<P8_CONV2D, ##__VA_ARGS__, false>), grid, dim3(512), 0, st, d); \
+      else hipLaunchKernelGGL((KERNEL<P8_DENSE, ##__VA_ARGS__, false>), grid, dim3(512), 0, st, d);       \
+    } else {                                                                                              \
+      if (conv) hipLaunchKernelGGL((KERNEL<P8_CONV2D, ##__VA_ARGS__, true>), grid, dim3(512), 0, st, d);  \
+      else hipLaunchKernelGGL((KERNEL<P8_DENSE, ##__VA_ARGS__, true>), grid, dim3(512), 0, st, d);        \
+    }                                                                                                     \
+  } while (0)
+  if (geo == 1) P8_LAUNCH(gemm_8ph_kernel_q, 2, 4);
+  else if (geo == 2) P8_LAUNCH(gemm_8ph_kernel_q, 4, 2);
+  else P8_LAUNCH(gemm_8ph_kernel_128);
+#undef P8_LAUNCH
+  S2S_CHECK_LAUNCH("gemm_8ph_kernel");
+  return 1;
+}

@@ -58,7 +58,4 @@ class StochasticDurationPredictorLoss(object):
         return None
 
 
-try:
-    from ._aas import DurationPredictorLoss, ForwardSumLoss  # noqa: F401
-except ImportError:  # pragma: no cover
-    pass
+from ._aas import DurationPredictorLoss, ForwardSumLoss  # noqa: E402,F401

@@ -147,3 +147,25 @@ class _InterpNearest(Function):
 def interp_nearest(x, Tout):
     """F.interpolate(x^T, size=Tout)^T per batch item on channel-last (B, T, C)  (models/aas_vc.py:340-349)."""
     return _InterpNearest.apply(x, Tout)
+
+
+class _LengthRegulate(Function):
+    @staticmethod
+    def forward(ctx, x, ds_i32, Tout, pad_value):
+        x = _c(x)
+        start, idx, _ = KA.length_regulate_index(ds_i32, Tout)
+        ctx.save_for_backward(start, ds_i32)
+        ctx.Tx = x.shape[1]
+        return KA.length_regulate_fwd(x, idx.contiguous(), Tout, pad_value)
+
+    @staticmethod
+    def backward(ctx, dy):
+        start, ds_i32 = ctx.saved_tensors
+        return KA.length_regulate_bwd(_c(dy), start, ds_i32, ctx.Tx), None, None, None
+
+
+def length_regulate(x, ds_i32, Tout, pad_value=0.0):
+    """Repeat frame i of utterance b ds[b, i] times along time, zero-pad to Tout (modules/length_regulator.py:67-97).
+    x (B,Tx,D) compute dtype, ds_i32 (B,Tx) int32 on the device; Tout is a host int (the caller knows the durations on the
+    host: they come from the collater / from `.tolist()` of the predicted durations, as in the reference's pad_list)."""
+    return _LengthRegulate.apply(x, ds_i32, Tout, pad_value)

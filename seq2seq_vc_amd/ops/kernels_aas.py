@@ -77,3 +77,41 @@ def forward_sum(log_p_attn, prior, text_lens_i32, feat_lens_i32, blank_prob=math
     _lib.check(_lib.lib().s2svc_forward_sum(B, Tf, Tx, ptr(log_p_attn), ptr(prior), ptr(text_lens_i32), ptr(feat_lens_i32),
                                             math.log(blank_prob), ptr(ws), ptr(loss_b), ptr(grad), stream()), "forward_sum")
     return loss_b, grad
+
+
+def length_regulate_index(ds_i32, Tout):
+    """ds (B,Tx) int32 -> start (B,Tx), idx (B,Tout), total (B) int32."""
+    B, Tx = ds_i32.shape
+    dev = ds_i32.device
+    start = torch.empty((B, Tx), dtype=torch.int32, device=dev)
+    idx = torch.empty((B, max(Tout, 1)), dtype=torch.int32, device=dev)
+    total = torch.empty((B,), dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().s2svc_length_regulate_index(B, Tx, Tout, ptr(ds_i32), ptr(start), ptr(idx), ptr(total), stream()),
+               "length_regulate_index")
+    return start, idx[:, :Tout], total
+
+
+def length_regulate_fwd(x, idx, Tout, pad_value=0.0):
+    B, Tx, D = x.shape
+    y = torch.empty((B, Tout, D), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().s2svc_length_regulate_fwd(dt(x), B, Tx, Tout, D, ptr(x), ptr(idx), float(pad_value), ptr(y), stream()),
+               "length_regulate_fwd")
+    return y
+
+
+def length_regulate_bwd(dy, start, ds_i32, Tx):
+    B, Tout, D = dy.shape
+    dx = torch.empty((B, Tx, D), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.lib().s2svc_length_regulate_bwd(dt(dy), B, Tx, Tout, D, ptr(dy), ptr(start), ptr(ds_i32), ptr(dx), stream()),
+               "length_regulate_bwd")
+    return dx
+
+
+def attn_durations(att):
+    """att (NH, Tf, Tx) fp32 -> (durations int64 (Tx,), focus rate scalar, head index)."""
+    NH, Tf, Tx = att.shape
+    dur = torch.empty((Tx,), dtype=torch.int64, device=att.device)
+    focus = torch.empty((), dtype=torch.float32, device=att.device)
+    head = torch.empty((), dtype=torch.int32, device=att.device)
+    _lib.check(_lib.lib().s2svc_attn_durations(NH, Tf, Tx, ptr(att), ptr(dur), ptr(focus), ptr(head), stream()), "attn_durations")
+    return dur, focus, head

@@ -314,3 +314,29 @@ class AASVCTrainer(Trainer):
         self.optimizer.zero_grad()
         self.steps += 1
         self._check_train_finish()
+
+
+class NARVCTrainer(Trainer):
+    """trainers/nar_vc.py:53-103 (FastSpeechVC with teacher durations): loss = l1 + duration MSE (log domain); zero_grad
+    BEFORE backward; clip -> step -> scheduler."""
+
+    GRADIENT_WORK = (0, True)
+
+    def _train_step(self, batch):
+        dev = self.device
+        K.reset_op_counter()
+        K.advance_seed(dev)
+        xs, ys, dp_inputs = batch["xs"].to(dev), batch["ys"].to(dev), batch["dp_inputs"].to(dev)
+        self.optimizer.zero_grad()
+        with self._forward_context():
+            before, after, d_outs, ilens_, olens_, ys_ = self.model(xs, batch["ilens"], ys, batch["olens"], batch["durations"],
+                                                                   batch["duration_lens"], dp_inputs, dp_lengths=batch["dplens"])
+            l1 = self.criterion["L1Loss"](after, before, ys_, olens_)
+            dur = self.criterion["DurationPredictorLoss"](d_outs, batch["durations"].to(dev), ilens_)
+            loss = l1 + dur
+        self._accumulate(**{"train/l1_loss": l1, "train/duration_loss": dur, "train/loss": loss})
+        self._backward(loss, {"decoder": l1, "duration": dur})
+        self.backward_steps += 1
+        self._optimizer_step()
+        self.steps += 1
+        self._check_train_finish()

@@ -1485,6 +1485,90 @@ def transfer_and_freeze_modules():
     return res
 
 
+
+@case
+def fs2vc_tiny_train_and_inference_fp32():
+    """FastSpeechVC + LengthRegulator + DurationCalculator against the reference's vectors: training forward
+    (Conformer encoder with the Conv2d front-end, teacher durations through the repeat-interleave kernel, Conformer decoder),
+    L1 + duration loss, every parameter gradient, BatchNorm buffers; the inference path (predicted integer durations must be
+    identical); DurationCalculator known answers; NARVCTrainer logs the golden first-step losses."""
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd import trainers as T
+    from seq2seq_vc_amd.optim import FlatAdam
+    from seq2seq_vc_amd.utils import DurationCalculator
+    res = []
+    cfg, z = load("fs2vc_tiny_train")
+    try:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+        model = M.FastSpeechVC(**model_cfg(cfg))
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).train()
+        _kill_dropout(model)
+        t = lambda k: torch.from_numpy(z[k])
+        xs = t("in.xs").to(DEV)
+        before, after, d_outs, ilens_, olens_, ys_ = model(xs, t("in.ilens"), t("in.ys").to(DEV), t("in.olens"), t("in.ds"), t("in.dlens"),
+                                                           xs, dp_lengths=t("in.ilens"))
+        res += [cmp("fs2vc before_outs", before, z["out.before"], 2e-4, l1_tol=1e-4), cmp("fs2vc after_outs", after, z["out.after"], 8e-4, l1_tol=1e-4),
+                cmp("fs2vc d_outs", d_outs, z["out.d_outs"], 1e-4), cmp("fs2vc ilens", ilens_, z["out.ilens"], 0),
+                cmp("fs2vc olens", olens_, z["out.olens"], 0), cmp("fs2vc ys", ys_, z["out.ys"], 0)]
+        l1 = L.L1Loss()(after, before, ys_, olens_)
+        dl = L.DurationPredictorLoss()(d_outs, t("in.ds").to(DEV), ilens_)
+        res += [cmp("fs2vc l1", l1, z["loss.l1"], 2e-5), cmp("fs2vc duration loss", dl, z["loss.duration"], 2e-5)]
+        (l1 + dl).backward()
+        res += grads_check(model, z, 5e-5, 5e-3)
+        for k in [k for k in z.files if k.startswith("sd_after.")]:
+            res.append(cmp(f"fs2vc buffer {k[9:]}", model.state_dict()[k[9:]], z[k], 2e-5))
+        model.eval()
+        x1 = t("inf.x").to(DEV)
+        outs, d1 = model.inference(x1, dp_input=x1)
+        res += [cmp("fs2vc inference durations (exact)", d1, z["inf.d_outs"], 0), cmp("fs2vc inference outs", outs, z["inf.outs"], 8e-4, l1_tol=1e-4)]
+        dc = DurationCalculator()
+        d4, f4 = dc(t("dc.att4").to(DEV))
+        d2, f2 = dc(t("dc.att2").to(DEV))
+        res += [cmp("DurationCalculator durations (layers x heads)", d4, z["dc.dur4"], 0), cmp("DurationCalculator focus rate", f4, z["dc.focus4"], 1e-6),
+                cmp("DurationCalculator durations (2-D)", d2, z["dc.dur2"], 0), cmp("DurationCalculator focus rate (2-D)", f2, z["dc.focus2"], 1e-6)]
+        # the trainer class on the same batch
+        model2 = M.FastSpeechVC(**model_cfg(cfg))
+        model2.load_state_dict(sd_of(z))
+        model2.to(DEV).train()
+        _kill_dropout(model2)
+        opt = FlatAdam(model2, lr=1e-4, grad_norm=1.0, warmup_steps=10)
+        batch = {"xs": t("in.xs"), "ilens": t("in.ilens"), "ys": t("in.ys"), "olens": t("in.olens"), "durations": t("in.ds"),
+                 "duration_lens": t("in.dlens"), "dp_inputs": t("in.xs"), "dplens": t("in.ilens")}
+        logs = []
+        conf = {"train_max_steps": 2, "log_interval_steps": 1, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": ".",
+                "side_streams": 0}
+        tr = T.NARVCTrainer(0, 0, {"train": [batch] * 3}, None, model2, None, {"L1Loss": L.L1Loss(), "DurationPredictorLoss": L.DurationPredictorLoss()},
+                            opt, None, conf, device=DEV)
+        tr.log_fn = lambda step, d: logs.append(dict(d))
+        tr.run()
+        res.append((tr.steps == 2 and len(logs) == 2, f"NARVCTrainer: {tr.steps} steps"))
+        res.append(cmp("NARVCTrainer first logged l1 vs golden", logs[0]["train/l1_loss"], z["loss.l1"], 2e-5))
+        res.append(cmp("NARVCTrainer first logged duration loss vs golden", logs[0]["train/duration_loss"], z["loss.duration"], 2e-5))
+        res.append((logs[1]["train/loss"] < logs[0]["train/loss"] + 1e-3, f"NARVCTrainer loss {logs[0]['train/loss']:.4f} -> {logs[1]['train/loss']:.4f}"))
+        # length regulator on ragged durations incl. an all-zero row and alpha != 1, forward + backward vs repeat_interleave
+        from oracle import models as OM
+        from seq2seq_vc_amd.models.fastspeech_vc import LengthRegulator
+        g = torch.Generator().manual_seed(5)
+        hs = torch.randn(3, 9, 24, generator=g)
+        ds = torch.tensor([[2, 0, 3, 1, 0, 0, 4, 1, 0], [0] * 9, [1, 1, 1, 1, 1, 1, 1, 1, 5]])
+        for alpha in (1.0, 1.7):
+            hr = hs.clone().requires_grad_(True)
+            ref = OM.length_regulator(hr, ds.clone(), alpha)
+            hd = hs.to(DEV).requires_grad_(True)
+            got = LengthRegulator()(hd, ds.clone(), alpha)
+            res.append(cmp(f"LengthRegulator forward alpha={alpha}", got, ref.detach(), 0))
+            w = torch.randn(ref.shape, generator=g)
+            (ref * w).sum().backward()
+            (got * w.to(DEV)).sum().backward()
+            res.append(cmp(f"LengthRegulator backward alpha={alpha}", hd.grad, hr.grad, 1e-6))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    return res
+
+
 def main(selected=None):
     nfail = 0
     for fn in CASES:

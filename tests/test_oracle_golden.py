@@ -205,3 +205,36 @@ def test_fullwidth_layers(name):
         close(mem.grad.reshape(-1)[::3], z["dmem"], 2e-5)
     for k in names:
         close(sd[k].grad.reshape(-1)[::FW.grad_stride(sd[k].numel())], z["grad." + k], 1e-4)
+
+
+def test_fastspeech_vc_forward_grads_inference_and_duration_calculator():
+    """FastSpeechVC (models/fastspeech_vc.py:244-466): training forward, L1 + duration loss, gradients, the inference path;
+    DurationCalculator (utils/duration_calculator.py:13-65) known answers for the 4-D and the 2-D case."""
+    cfg, z = load("fs2vc_tiny_train")
+    mc = model_cfg(cfg)
+    sd = sd_of(z)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    sd.update(params)
+    t = lambda k: torch.from_numpy(z[k])
+    o = OM.fastspeech_vc_forward(sd, mc, t("in.xs"), t("in.ilens"), t("in.ys"), t("in.olens"), t("in.ds"), dp_inputs=t("in.xs"))
+    close(o[0], z["out.before"]); close(o[1], z["out.after"]); close(o[2], z["out.d_outs"])
+    assert torch.equal(o[3], t("out.ilens")) and torch.equal(o[4], t("out.olens"))
+    l1 = OM.l1_loss(o[1], o[0], o[5], o[4])
+    dl = OM.duration_predictor_loss(o[2], t("in.ds"), o[3])
+    close(l1, z["loss.l1"], 1e-6); close(dl, z["loss.duration"], 1e-6)
+    (l1 + dl).backward()
+    for k in [k for k in z.files if k.startswith("grad.")]:
+        close(params[k[5:]].grad, z[k], 1e-4)
+    for k in [k for k in z.files if k.startswith("sd_after.")]:
+        close(sd[k[9:]].detach(), z[k], 1e-5)
+    sd_inf = {k: v.detach() for k, v in sd.items()}
+    x = t("inf.x")
+    with torch.no_grad():
+        oi = OM.fastspeech_vc_forward(sd_inf, mc, x[None], torch.tensor([x.shape[0]]), dp_inputs=x[None], training=False, inference=True)
+    assert torch.equal(oi[2][0], t("inf.d_outs"))
+    close(oi[1][0], z["inf.outs"], 1e-5)
+    d4, f4 = OM.duration_calculator(t("dc.att4"))
+    d2, f2 = OM.duration_calculator(t("dc.att2"))
+    assert torch.equal(d4, t("dc.dur4")) and torch.equal(d2, t("dc.dur2"))
+    close(f4, z["dc.focus4"], 1e-7); close(f2, z["dc.focus2"], 1e-7)
+    assert int(d4.sum()) == 37 and int(d2.sum()) == 29          # every output frame is counted exactly once

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""A/B timing of the bf16 GEMM kernel families on the forward / data-gradient shapes of the two workloads:
+mode 0 = 128x128 4-wave kernel (gemm_glds.hip), 1 = 8-wave phase-interleaved kernel by policy (gemm_8ph.hip), 2 = the same
+without the half-phase skew, 17 / 33 / 49 = mode 1 with the tile geometry forced to 256x256 / 512x128 / 256x128.  Variants are interleaved in rounds inside ONE process (medians reported); every timing is
+`--iters` launches replayed from one hipGraph with HIP events around the replay; operands uniform random in [-1, 1).
+
+    python tools/gemm8_bench.py [--iters 50] [--rounds 5] [--modes 0,1,2]
+"""
+import argparse
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from seq2seq_vc_amd.ops import kernels as K  # noqa: E402
+from tools.gemm_bench import bench  # noqa: E402
+
+DENSE = [("4096^3", 4096, 4096, 4096), ("8192^3", 8192, 8192, 8192), ("aas 4096x1536x1536", 4096, 1536, 1536),
+         ("aas 4096x3072x1536", 4096, 3072, 1536), ("aas 4096x1536x3072 (dgrad of pw1)", 4096, 1536, 3072),
+         ("aas 4096x1536x384", 4096, 1536, 384), ("vtn 2048x1536x384", 2048, 1536, 384), ("vtn 2016x384x7296", 2016, 384, 7296)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--modes", default="0,1,17,33,49")
+    a = ap.parse_args()
+    modes = [int(m) for m in a.modes.split(",")]
+    L = K._lib.lib()
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(1)
+    u = lambda *s: (torch.rand(*s, device="cuda", generator=g) * 2 - 1).to(dt)
+    cases = []
+    for name, M, N, Kd in DENSE:
+        x, w, y = u(M, Kd), u(N, Kd), torch.empty(M, N, dtype=dt, device="cuda")
+        b = torch.zeros(N, device="cuda")
+        cases.append((name, 2.0 * M * N * Kd, lambda x=x, w=w, y=y, b=b, M=M, N=N, Kd=Kd: K.gemm(K.operand(x, Kd), K.operand(w, Kd), M, N, Kd, y, in_dtype=dt, bias=b)))
+    B, T1, F1, C, O = 32, 127, 39, 384, 384
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    M, N, Kd = B * T2 * F2, O, 9 * C
+    x, w, y = u(B, T1, F1, C), u(O, 9 * C), torch.empty(B, T2, F2, O, dtype=dt, device="cuda")
+    b = torch.zeros(O, device="cuda")
+    cases.append(("vtn conv2d 38304x384x3456", 2.0 * M * N * Kd,
+                  lambda: K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(w, 9 * C), M, N, Kd, y,
+                                 in_dtype=dt, bias=b, act="relu")))
+    prev = L.s2svc_gemm_set_8ph(-1)
+    print(f"{'shape':40s} " + " ".join(f"{'mode ' + str(m) + ' us':>11s} {'TF':>7s} {'%peak':>6s}" for m in modes))
+    for name, flops, fn in cases:
+        t = {m: [] for m in modes}
+        for _ in range(a.rounds):
+            for m in modes:
+                L.s2svc_gemm_set_8ph(m)
+                t[m].append(bench(fn, a.iters))
+        row = f"{name:40s} "
+        for m in modes:
+            us = statistics.median(t[m])
+            tf = flops / us / 1e6
+            row += f"{us:11.1f} {tf:7.0f} {100 * tf / 2500:6.1f} "
+        print(row, flush=True)
+    L.s2svc_gemm_set_8ph(prev)
+
+
+if __name__ == "__main__":
+    main()

@@ -389,6 +389,72 @@ def gen_fullwidth(name):
     print(f"  oracle-vs-ref {name}: out {maxerr(o, out):.2e} (|out| max {float(out.abs().max()):.2f})")
 
 
+def gen_fs2vc(M, L, name, cfg, B, Ti, seed):
+    """FastSpeechVC (models/fastspeech_vc.py:244-466) with teacher durations: training forward + L1 + duration loss +
+    gradients, the inference path, and DurationCalculator (utils/duration_calculator.py) known answers."""
+    from oracle import models as OM
+    torch.manual_seed(seed)
+    model = M.FastSpeechVC(**cfg)
+    kill_dropout(model)
+    model.train()
+    g = torch.Generator().manual_seed(seed + 1)
+    ilens = torch.randint(int(Ti * 0.7), Ti + 1, (B,), generator=g)
+    ilens[0] = Ti
+    xs = torch.randn(B, Ti, cfg["idim"], generator=g)
+    xs[torch.arange(Ti)[None] >= ilens[:, None]] = 0.0
+    sub = cfg.get("encoder_input_layer") == "conv2d" or cfg.get("encoder_type", "transformer") == "transformer"
+    tlens = (((ilens - 1) // 2 - 1) // 2) if sub else ilens
+    Tx = int(tlens.max())
+    ds = torch.randint(0, 5, (B, Tx), generator=g)
+    ds[:, 0] = 2
+    ds[torch.arange(Tx)[None] >= tlens[:, None]] = 0
+    r = cfg.get("teacher_model_decoder_reduction_factor", 4)
+    olens = ds.sum(1) * r
+    ys = torch.randn(B, int(olens.max()), cfg["odim"], generator=g)
+    ys[torch.arange(ys.shape[1])[None] >= olens[:, None]] = 0.0
+    dlens = torch.full((B,), Tx)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    before, after, d_outs, ilens_, olens_, ys_ = model(xs, ilens, ys, olens, ds, dlens, xs, dp_lengths=ilens)
+    l1 = L.L1Loss()(after, before, ys_, olens_)
+    dl = L.DurationPredictorLoss()(d_outs, ds, ilens_)
+    model.zero_grad()
+    (l1 + dl).backward()
+    arr = {}
+    pack(arr, "sd.", sd0)
+    pack(arr, "grad.", {k: p.grad for k, p in model.named_parameters() if p.grad is not None})
+    pack(arr, "sd_after.", {k: v for k, v in model.state_dict().items() if "running" in k})
+    arr.update({"in.xs": to_np(xs), "in.ilens": to_np(ilens), "in.ys": to_np(ys), "in.olens": to_np(olens), "in.ds": to_np(ds),
+                "in.dlens": to_np(dlens), "out.before": to_np(before), "out.after": to_np(after), "out.d_outs": to_np(d_outs),
+                "out.ilens": to_np(ilens_), "out.olens": to_np(olens_), "out.ys": to_np(ys_), "loss.l1": to_np(l1), "loss.duration": to_np(dl)})
+    model.eval()
+    with torch.no_grad():
+        x1 = xs[1, : int(ilens[1])]
+        outs, d1 = model.inference(x1, dp_input=x1)
+    arr.update({"inf.x": to_np(x1), "inf.outs": to_np(outs), "inf.d_outs": to_np(d1)})
+    # DurationCalculator known answers (4-D transformer case and 2-D case)
+    sys.path.insert(0, REF)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_duration_calculator", os.path.join(REF, "seq2seq_vc", "utils", "duration_calculator.py"))
+    dc_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dc_mod)
+    dc = dc_mod.DurationCalculator()
+    att4 = torch.softmax(torch.randn(2, 3, 37, 11, generator=g) * 3, dim=-1)
+    att2 = torch.softmax(torch.randn(29, 9, generator=g) * 2, dim=-1)
+    d4, f4 = dc(att4)
+    d2, f2 = dc(att2)
+    arr.update({"dc.att4": to_np(att4), "dc.dur4": to_np(d4), "dc.focus4": to_np(f4), "dc.att2": to_np(att2), "dc.dur2": to_np(d2),
+                "dc.focus2": to_np(f2)})
+    save(name, dict(cfg, __model__="FastSpeechVC"), arr)
+    o = OM.fastspeech_vc_forward({k: v.clone() for k, v in sd0.items()}, cfg, xs, ilens, ys, olens, ds, dp_inputs=xs)
+    print(f"  oracle-vs-ref {name}: after {maxerr(o[1], after):.2e} d_outs {maxerr(o[2], d_outs):.2e} ilens {bool(torch.equal(o[3], ilens_))}")
+    with torch.no_grad():
+        oi = OM.fastspeech_vc_forward({k: v.clone() for k, v in model.state_dict().items()}, cfg, x1[None], torch.tensor([x1.shape[0]]),
+                                      dp_inputs=x1[None], training=False, inference=True)
+    print(f"  inference: outs {maxerr(oi[1][0], outs):.2e} durations equal {bool(torch.equal(oi[2][0], d1))} {d1.tolist()}")
+    od4, of4 = OM.duration_calculator(att4)
+    print(f"  duration calculator: {bool(torch.equal(od4, d4))} focus {maxerr(of4, f4):.2e}")
+
+
 def gen_mas_kats(A):
     """Known-answer vectors for the alignment search, from the reference's own code."""
     arr = {}
@@ -444,6 +510,14 @@ AAS_TINY = dict(idim=80, odim=80, adim=32, aheads=2, elayers=2, eunits=64, dlaye
                 conformer_pos_enc_layer_type="rel_pos", conformer_self_attn_layer_type="rel_selfattn",
                 use_macaron_style_in_conformer=True, use_cnn_in_conformer=True, conformer_enc_kernel_size=7,
                 conformer_dec_kernel_size=7, init_type="xavier_uniform")
+FS2_TINY = dict(idim=80, odim=80, adim=32, aheads=2, elayers=2, eunits=64, dlayers=2, dunits=64, positionwise_layer_type="linear",
+                positionwise_conv_kernel_size=1, duration_predictor_use_encoder_outputs=False, duration_predictor_input_dim=80,
+                duration_predictor_layers=2, duration_predictor_chans=32, duration_predictor_kernel_size=3, postnet_layers=5,
+                postnet_filts=5, postnet_chans=32, use_masking=True, encoder_normalize_before=True, decoder_normalize_before=True,
+                encoder_reduction_factor=1, decoder_reduction_factor=1, encoder_type="conformer", decoder_type="conformer",
+                encoder_input_layer="conv2d", conformer_pos_enc_layer_type="rel_pos", conformer_self_attn_layer_type="rel_selfattn",
+                use_macaron_style_in_conformer=True, use_cnn_in_conformer=True, conformer_enc_kernel_size=7,
+                conformer_dec_kernel_size=7, init_type="xavier_uniform", teacher_model_decoder_reduction_factor=1)
 AAS_DET_TINY = dict(AAS_TINY, duration_predictor_type="deterministic", duration_predictor_use_encoder_outputs=True,
                     post_encoder_reduction_factor=1, positionwise_layer_type="conv1d", positionwise_conv_kernel_size=3)
 
@@ -484,6 +558,8 @@ def main():
         gen_aasvc_inference(M, "aasvc_tiny_inference_gt", AAS_TINY, T=64, seed=110, To=40)
     if want("aasvc_det_tiny_inference"):
         gen_aasvc_inference(M, "aasvc_det_tiny_inference", AAS_DET_TINY, T=37, seed=111)
+    if want("fs2vc_tiny_train"):
+        gen_fs2vc(M, L, "fs2vc_tiny_train", FS2_TINY, B=3, Ti=76, seed=112)
     for n in ("fw_enc384", "fw_dec384", "fw_conf384", "fw_conf1536"):
         if want(n):
             gen_fullwidth(n)
