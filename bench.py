@@ -255,9 +255,9 @@ def dominant_kernel_roofline(dtype, iters=100, workload="vtn"):
     if dtype != torch.bfloat16:
         kernel = "gemm_fast_kernel<float,128,128,32> (exact-fp32 MFMA)"
     elif workload == "aasvc":
-        kernel = "gemm_glds_kernel<128,128,KC_DENSE,KC_DENSE> (bf16, LDS-DMA staged)"
+        kernel = "gemm_8ph_kernel_128<DENSE> (bf16, 8 waves, 256x128 tile, 2 phases per K tile, LDS-DMA + counted vmcnt)"
     else:
-        kernel = "gemm_glds_kernel<128,128,KC_CONV2D,KC_DENSE> (bf16, LDS-DMA staged)"
+        kernel = "gemm_8ph_kernel_q<CONV2D,4,2> (bf16, 8 waves, 512x128 tile, 4 phases per K tile, LDS-DMA + counted vmcnt)"
     alg_bytes = float((x.numel() + w.numel() + y.numel()) * x.element_size())
     return {"bound": "mfma", "kernel": f"{kernel} {shape}", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": _pmc_traffic(workload) if dtype == torch.bfloat16 else None, "algorithmic_bytes": alg_bytes,
@@ -322,10 +322,13 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
     """Returns (step(), info).  Unstaged: graph 1 = zero + forward + loss + backward, graph 2 = clip + Adam + WarmupLR.
     Staged (data parallel): one graph per stage of model.dp_plan(); after each replay the all-reduce of that stage's slice of
     the flat gradient buffer is issued; the optimiser graph follows the join."""
-    from seq2seq_vc_amd.distributed import OverlappedBackward
+    from seq2seq_vc_amd.distributed import OverlappedBackward, allreduce_mean_
     from seq2seq_vc_amd.ops import kernels as K
     Fn, opt, dev = wl.Fn, wl.opt, wl.dev
     ob = OverlappedBackward(wl.model, opt, dist, world, payload=payload, force=force_dist) if staged else None
+    stage16 = None
+    if not staged and (dist is not None or force_dist) and payload == "bf16":
+        stage16 = torch.empty(opt.numel, dtype=torch.bfloat16, device=dev)
     held = {}
 
     def begin():
@@ -359,6 +362,8 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
             ob.finish()
         else:
             fwd_bwd()
+            if (dist is not None or force_dist):
+                allreduce_mean_(opt.flat_g, dist, world, force=force_dist, stage_bf16=stage16)
         opt.step()
 
     side = torch.cuda.Stream()      # warm-up on a side stream so that a later capture sees a quiet default stream
@@ -387,6 +392,8 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
             use_graph = False
             torch.cuda.synchronize()
 
+    post_reduce = (dist is not None or force_dist) and not staged
+
     def step():
         if not use_graph:
             step_eager()
@@ -398,11 +405,14 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
             ob.finish()
         else:
             graphs[0].replay()
+            if post_reduce:
+                allreduce_mean_(opt.flat_g, dist, world, force=force_dist, stage_bf16=stage16)
         g_opt.replay()
 
     info = {"hip_graph": bool(use_graph), "backward_stages": n_stages,
-            "grad_buckets_MB": [round(b / 1e6, 1) for b in ob.bucket_bytes()] if staged else None,
-            "grad_payload": payload if staged else None}
+            "grad_buckets_MB": [round(b / 1e6, 1) for b in ob.bucket_bytes()] if staged else
+                               ([round(opt.numel * (2 if stage16 is not None else 4) / 1e6, 1)] if post_reduce else None),
+            "grad_payload": payload if (staged or post_reduce) else None}
     return step, info
 
 
@@ -554,7 +564,10 @@ def main():
 
     B = args.batch or (32 if args.workload == "vtn" else 16)
     wl = Workload(args.workload, dev, dtype, B, world, rank)
-    staged = dp or args.split_backward
+    # Backward in stages with one all-reduce per finished stage (overlap) is the default for VTN.  For AAS-VC the stage graphs
+    # do not replay correctly yet (DESIGN.md "Open items": a multi-graph capture issue, the eager staged path the trainers use
+    # is exact) -- its data-parallel step is ONE captured graph followed by the chunked all-reduce of the whole gradient buffer.
+    staged = (dp and args.workload == "vtn") or args.split_backward
     step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph,
                             warmup_eager=max(2, args.warmup if args.no_graph else 2))
     dt = time_steps(step, args.steps, args.warmup, dist if dp else None, dev)

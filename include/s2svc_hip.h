@@ -420,6 +420,23 @@ int s2svc_magnitude(int64_t frames, int nb, const float* z, float* spc, void* st
 int s2svc_log_clamp(int64_t n, int D, const float* x, float eps, float inv_log_base, const float* mean,
                     const float* inv_scale, float* y, void* stream);
 
+/* Batched form: B utterances per launch, wav batch -> normalised zero-padded (B, Tmax, n_mels) log-mel batch -- what
+   bin/preprocess.py:200-310 (one utterance at a time), bin/normalize.py:172-193 and the collater's padding
+   (collaters/ar_vc.py:42-45) produce in three passes over HDF5 files.
+     s2svc_reflect_pad_batch: x (B, Nmax) zero-padded waveforms, nlen (B) sample counts -> y (B, ld), ld >= Nmax + 2*pad:
+         row b = reflect-padded utterance b followed by zeros (frames past the utterance then transform zeros);
+     [one batched s2svc_gemm: A = y with row stride `hop` and batch stride ld, B = windowed DFT basis -> z (B, Tmax, 2*nb)]
+     s2svc_mel_log_batch: z -> out (B, Tmax, nmel): magnitude, mel projection over each filter's bins [lo, hi) only,
+         max(eps, .), log, optional (x - mean) * inv_scale; frames t >= frames[b] are written as zeros.
+     s2svc_ragged_to_padded: ragged feature rows (concatenated utterances, row offsets (B + 1) int64) -> (B, Tmax, D)
+         zero-padded batch (+ optional normalisation, + optional stop labels (B, Tmax): 1 from the last valid frame on). */
+int s2svc_reflect_pad_batch(int B, int64_t Nmax, int pad, int64_t ld, const float* x, const int32_t* nlen, float* y, void* stream);
+int s2svc_mel_log_batch(int B, int Tmax, int nb, int nmel, const float* z, const int32_t* frames, const float* melb,
+                        const int32_t* lo, const int32_t* hi, float eps, float inv_log_base, const float* mean,
+                        const float* inv_scale, float* out, void* stream);
+int s2svc_ragged_to_padded(int B, int Tmax, int D, const float* ragged, const int64_t* offsets, const float* mean,
+                           const float* inv_scale, float* out, float* labels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

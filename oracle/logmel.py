@@ -38,7 +38,11 @@ def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
 
 
 def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, num_mels=80, fmin=None, fmax=None, eps=1e-10,
-                     log_base=10.0):
+                     log_base=10.0, dtype=np.float32):
+    """dtype=np.float64 runs the whole chain in double precision (the analytic known-answer tests and the fp32-adequacy
+    check of tests/test_oracle_golden.py use it)."""
+    if dtype == np.float64:
+        return _logmel64(audio, sampling_rate, fft_size, hop_size, num_mels, fmin, fmax, eps, log_base)
     x = np.asarray(audio, dtype=np.float32)
     fmin = 0 if fmin is None else fmin
     fmax = sampling_rate / 2 if fmax is None else fmax
@@ -48,6 +52,32 @@ def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, num_mels
     idx = np.arange(fft_size)[None, :] + hop_size * np.arange(n_frames)[:, None]
     spec = np.abs(np.fft.rfft(xp[idx] * win, axis=1)).astype(np.float32)         # (frames, bins)
     mel = np.maximum(eps, spec @ mel_filterbank(sampling_rate, fft_size, num_mels, fmin, fmax).T)
+    if log_base is None:
+        return np.log(mel)
+    return np.log10(mel) if log_base == 10.0 else np.log2(mel)
+
+
+def mel_filterbank64(sr, n_fft, n_mels, fmin, fmax):
+    """The same triangles in float64, without the final float32 cast."""
+    freqs = np.fft.rfftfreq(n_fft, 1.0 / sr)
+    pts = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    fb = np.zeros((n_mels, len(freqs)))
+    for i in range(n_mels):
+        lo, ce, hi = pts[i], pts[i + 1], pts[i + 2]
+        fb[i] = np.clip(np.minimum((freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce)), 0, None) * (2.0 / (hi - lo))
+    return fb
+
+
+def _logmel64(audio, sampling_rate, fft_size, hop_size, num_mels, fmin, fmax, eps, log_base):
+    x = np.asarray(audio, dtype=np.float64)
+    fmin = 0 if fmin is None else fmin
+    fmax = sampling_rate / 2 if fmax is None else fmax
+    xp = np.pad(x, fft_size // 2, mode="reflect")
+    n_frames = 1 + len(x) // hop_size
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(fft_size) / fft_size)
+    idx = np.arange(fft_size)[None, :] + hop_size * np.arange(n_frames)[:, None]
+    spec = np.abs(np.fft.rfft(xp[idx] * win, axis=1))
+    mel = np.maximum(eps, spec @ mel_filterbank64(sampling_rate, fft_size, num_mels, fmin, fmax).T)
     if log_base is None:
         return np.log(mel)
     return np.log10(mel) if log_base == 10.0 else np.log2(mel)

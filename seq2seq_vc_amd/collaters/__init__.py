@@ -50,3 +50,71 @@ class ARTTSCollater(object):
         ilens, olens = _lens(xs), _lens(ys)
         xs, ys = pad_batch(xs, torch.long), pad_batch(ys, torch.float32)
         return xs, ilens, ys, stop_labels(olens, ys.size(1)), olens, None
+
+
+class _DeviceBatch(object):
+    """Builds padded batches ON THE DEVICE: the utterances of a batch are concatenated into one pinned host buffer (a single
+    H2D copy for the whole batch instead of a padded tensor per field), and one kernel (csrc/frontend.hip
+    `ragged_to_padded`) scatters them into the zero-padded (B, Tmax, D) layout, applies the optional mean/variance
+    normalisation of bin/normalize.py:172-193 and writes the stop labels.  Lengths stay host LongTensors (the models size
+    kernels with them).  `sort_by_length=True` orders a batch longest-first (bucketing is the sampler's business; within a
+    batch the order only matters to RNN-style consumers and is off by default, as in the reference)."""
+
+    def __init__(self, device="cuda", mean=None, scale=None, sort_by_length=False):
+        self.device = torch.device(device)
+        self.sort_by_length = sort_by_length
+        self.mean = None if mean is None else torch.as_tensor(mean, dtype=torch.float32, device=self.device).contiguous()
+        self.inv_scale = None if scale is None else (1.0 / torch.as_tensor(scale, dtype=torch.float32, device=self.device)).contiguous()
+
+    def _pad(self, seqs, want_labels=False, normalise=True):
+        from .. import _lib
+        from ..ops import kernels as K
+        lens = [int(s.shape[0]) for s in seqs]
+        D = int(seqs[0].shape[1])
+        off = np.zeros(len(seqs) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        host = torch.empty((int(off[-1]), D), dtype=torch.float32).pin_memory()
+        for i, s in enumerate(seqs):
+            host[off[i]: off[i + 1]] = torch.as_tensor(np.asarray(s), dtype=torch.float32)
+        ragged = host.to(self.device, non_blocking=True)
+        offs = torch.from_numpy(off).to(self.device, non_blocking=True)
+        B, Tmax = len(seqs), max(lens)
+        out = torch.empty((B, Tmax, D), dtype=torch.float32, device=self.device)
+        labels = torch.empty((B, Tmax), dtype=torch.float32, device=self.device) if want_labels else None
+        use_norm = normalise and self.mean is not None
+        _lib.check(_lib.lib().s2svc_ragged_to_padded(B, Tmax, D, ragged.data_ptr(), offs.data_ptr(),
+                                                     self.mean.data_ptr() if use_norm else None,
+                                                     self.inv_scale.data_ptr() if use_norm else None, out.data_ptr(),
+                                                     None if labels is None else labels.data_ptr(), K.stream()), "ragged_to_padded")
+        return out, torch.tensor(lens, dtype=torch.long), labels
+
+    def _order(self, batch, key):
+        if not self.sort_by_length:
+            return batch
+        return sorted(batch, key=lambda b: -b[key].shape[0])
+
+
+class DeviceARVCCollater(_DeviceBatch):
+    """ARVCCollater (collaters/ar_vc.py:11-73) with the batch assembled on the device."""
+
+    def __call__(self, batch):
+        batch = self._order(batch, "src_feat")
+        xs, ilens, _ = self._pad([b["src_feat"] for b in batch])
+        ys, olens, labels = self._pad([b["trg_feat"] for b in batch], want_labels=True)
+        return {"xs": xs, "ilens": ilens, "ys": ys, "olens": olens, "labels": labels, "spembs": None}
+
+
+class DeviceNARVCCollater(_DeviceBatch):
+    """NARVCCollater (collaters/nar_vc.py:12-91) with the batch assembled on the device."""
+
+    def __call__(self, batch):
+        batch = self._order(batch, "src_feat")
+        xs, ilens, _ = self._pad([b["src_feat"] for b in batch])
+        ys, olens, _ = self._pad([b["trg_feat"] for b in batch])
+        dps, dplens, _ = self._pad([b["dp_input"] for b in batch])
+        items = {"xs": xs, "ilens": ilens, "ys": ys, "olens": olens, "dp_inputs": dps, "dplens": dplens, "spembs": None}
+        if "duration" in batch[0]:
+            ds = [b["duration"] for b in batch]
+            items["durations"] = pad_batch(ds, torch.long)          # consumed on the host (output sizes), stays there
+            items["duration_lens"] = torch.full((len(ds),), items["durations"].shape[1], dtype=torch.long)
+        return items

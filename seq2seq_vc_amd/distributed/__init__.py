@@ -41,17 +41,26 @@ def init_from_env(backend=None):
     return dist, dist.get_rank(), dist.get_world_size()
 
 
-def allreduce_mean_(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None, force=False):
+def allreduce_mean_(flat, dist, world, chunk_numel=32 * 1024 * 1024, group=None, force=False, stage_bf16=None):
     """In-place mean all-reduce of a flat buffer in large chunks (works on cuda/RCCL and cpu/gloo).
-    force: issue the collectives even at world size 1 (exercises the backend on a single device)."""
+    force: issue the collectives even at world size 1 (exercises the backend on a single device).
+    stage_bf16: a bf16 buffer of the same size -> the exchange runs on a bf16 copy (half the bytes on the links)."""
     if world <= 1 and not force:
         return flat
-    n = flat.numel()
+    buf = flat
+    if stage_bf16 is not None:
+        from ..ops import kernels as K
+        K.cast(flat, torch.bfloat16, out=stage_bf16)
+        buf = stage_bf16
+    n = buf.numel()
     handles = []
     for o in range(0, n, chunk_numel):
-        handles.append(dist.all_reduce(flat[o:o + chunk_numel], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        handles.append(dist.all_reduce(buf[o:o + chunk_numel], op=dist.ReduceOp.SUM, group=group, async_op=True))
     for h in handles:
         h.wait()
+    if stage_bf16 is not None:
+        from ..ops import kernels as K
+        K.cast(stage_bf16, torch.float32, out=flat)
     flat.mul_(1.0 / world)
     return flat
 
@@ -149,7 +158,7 @@ class OverlappedBackward:
             loss = losses.get(root[5:])
             if loss is not None and loss.requires_grad:
                 s = self.scale if scale is None else scale
-                (loss * s if s != 1.0 else loss).backward()
+                (loss * s if s != 1.0 else loss).backward(retain_graph=Fn._RETAIN)
         else:
             self.cuts.resume(root[4:])
         Fn.side_join()

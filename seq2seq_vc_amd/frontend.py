@@ -114,3 +114,71 @@ def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, win_leng
         m_ptr, s_ptr = mean_t.data_ptr(), inv_scale_t.data_ptr()
     _lib.check(L.s2svc_log_clamp(mel.numel(), num_mels, mel.data_ptr(), eps, inv_log, m_ptr, s_ptr, out.data_ptr(), st), "log_clamp")
     return out
+
+
+def _mel_ranges(melb_np):
+    """[lo, hi) of the non-zero bins of every mel filter."""
+    nz = melb_np > 0
+    lo = np.where(nz.any(1), nz.argmax(1), 0)
+    hi = np.where(nz.any(1), melb_np.shape[1] - nz[:, ::-1].argmax(1), 0)
+    return lo.astype(np.int32), hi.astype(np.int32)
+
+
+_RANGES = {}
+
+
+def logmelfilterbank_batch(audios, sampling_rate, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80,
+                           fmin=None, fmax=None, eps=1e-10, log_base=10.0, mean=None, scale=None, lengths=None, device="cuda"):
+    """B utterances -> (mel (B, Tmax, num_mels) fp32, zero-padded; frames (B,) LongTensor on the host): the batch the
+    collater would build from the per-utterance features of bin/preprocess.py + bin/normalize.py, in three launches.
+
+    audios: a list of 1-D float arrays / tensors (any lengths), or a zero-padded (B, Nmax) tensor with `lengths`.
+    Every utterance equals `logmelfilterbank(audio_b, ...)` on its first 1 + n_b // hop frames."""
+    if window != "hann":
+        raise NotImplementedError("only the hann window of the recipes is supported")
+    if log_base not in (None, 10.0, 2.0):
+        raise ValueError(f"{log_base} is not supported.")
+    if isinstance(audios, torch.Tensor) and audios.dim() == 2:
+        if lengths is None:
+            raise ValueError("a padded (B, Nmax) batch needs `lengths`")
+        x = audios.to(device=device, dtype=torch.float32).contiguous()
+        nlen = [int(v) for v in lengths]
+    else:
+        nlen = [int(len(a)) for a in audios]
+        host = torch.zeros((len(nlen), max(nlen)), dtype=torch.float32).pin_memory()      # one staging buffer, one H2D copy
+        for b, a in enumerate(audios):
+            host[b, : nlen[b]] = torch.as_tensor(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float32))
+        x = host.to(device, non_blocking=True)
+    dev = x.device
+    B, Nmax = x.shape
+    fmin = 0 if fmin is None else fmin
+    fmax = sampling_rate / 2 if fmax is None else fmax
+    basis, melb = _tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
+    key = (str(dev), sampling_rate, fft_size, num_mels, fmin, fmax)
+    if key not in _RANGES:
+        lo, hi = _mel_ranges(melb.cpu().numpy())
+        _RANGES[key] = (torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev))
+    lo, hi = _RANGES[key]
+    pad, nb = fft_size // 2, fft_size // 2 + 1
+    frames = [1 + n // hop_size for n in nlen]
+    Tmax = max(frames)
+    ld = ((Tmax - 1) * hop_size + fft_size + 63) // 64 * 64
+    ld = max(ld, Nmax + 2 * pad)
+    L, st = _lib.lib(), K.stream()
+    nlen_d = torch.tensor(nlen, dtype=torch.int32, device=dev)
+    frames_d = torch.tensor(frames, dtype=torch.int32, device=dev)
+    padded = torch.empty((B, ld), dtype=torch.float32, device=dev)
+    _lib.check(L.s2svc_reflect_pad_batch(B, Nmax, pad, ld, x.data_ptr(), nlen_d.data_ptr(), padded.data_ptr(), st), "reflect_pad_batch")
+    z = torch.empty((B, Tmax, 2 * nb), dtype=torch.float32, device=dev)
+    K.gemm(K.operand(padded, hop_size, bs0=ld), K.operand(basis, fft_size), Tmax, 2 * nb, fft_size, z, in_dtype=torch.float32,
+           nb0=B, nb1=1, cbs=(Tmax * 2 * nb, 0))
+    out = torch.empty((B, Tmax, num_mels), dtype=torch.float32, device=dev)
+    inv_log = 1.0 if log_base is None else 1.0 / math.log(log_base)
+    m_ptr = s_ptr = None
+    if mean is not None:
+        mean_t = torch.as_tensor(mean, dtype=torch.float32, device=dev).contiguous()
+        inv_scale_t = (1.0 / torch.as_tensor(scale, dtype=torch.float32, device=dev)).contiguous()
+        m_ptr, s_ptr = mean_t.data_ptr(), inv_scale_t.data_ptr()
+    _lib.check(L.s2svc_mel_log_batch(B, Tmax, nb, num_mels, z.data_ptr(), frames_d.data_ptr(), melb.data_ptr(), lo.data_ptr(),
+                                     hi.data_ptr(), eps, inv_log, m_ptr, s_ptr, out.data_ptr(), st), "mel_log_batch")
+    return out, torch.tensor(frames, dtype=torch.long)

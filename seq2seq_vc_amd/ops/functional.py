@@ -89,59 +89,32 @@ def _emit_vgrad(param, value):
 # pass runs (distributed.OverlappedBackward); each piece can also be captured as its own hipGraph with the collectives
 # issued between the replays.  Values and gradients are exactly those of the uncut graph.
 # ------------------------------------------------------------------------------------------------
-class _Cut(Function):
-    """Identity whose backward parks the incoming gradient in a buffer the GradCuts object owns and returns nothing: the
-    autograd engine stops here (no gradient flows to the producer), `GradCuts.resume` restarts it from the buffer.  The
-    buffer is static (allocated once per cut name and shape, reused by every step), so captured hipGraphs of different
-    backward stages meet at a fixed address instead of at a `.grad` tensor the engine allocated, stole or replaced."""
-
-    @staticmethod
-    def forward(ctx, x, cuts, name):
-        ctx.cuts, ctx.name = cuts, name
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        ctx.cuts._park(ctx.name, g)
-        return None, None, None
+_RETAIN = os.environ.get("S2SVC_CUT_RETAIN", "0") == "1"      # diagnostic: keep the autograd buffers of finished stages alive
 
 
 class GradCuts:
     def __init__(self, names):
         self.names = set(names)
-        self.points = {}          # name -> tensor above the cut (the producer's side of the graph)
-        self.buffers = {}         # name -> static gradient buffer
-        self.filled = {}          # name -> number of gradients parked since the forward pass
+        self.points = {}          # name -> (tensor above the cut [graph side of the producer], detached leaf the consumers see)
 
     def cut(self, x, name):
         if name not in self.names or not (torch.is_grad_enabled() and x.requires_grad):
             return x
         if name in self.points:
             raise RuntimeError(f"gradient cut '{name}' was reached twice in one forward pass")
-        self.points[name] = x
-        self.filled[name] = 0
-        return _Cut.apply(x, self, name)
-
-    def _park(self, name, g):
-        buf = self.buffers.get(name)
-        if buf is None or buf.shape != g.shape or buf.dtype != g.dtype or buf.device != g.device:
-            buf = torch.empty_like(g, memory_format=torch.contiguous_format)
-            self.buffers[name] = buf
-        if self.filled[name] == 0:
-            buf.copy_(g)
-        else:                      # a second loss root reached the same cut (AAS-VC: decoder path, then alignment losses)
-            buf.add_(g)
-        self.filled[name] += 1
+        inner = x.detach().requires_grad_(True)
+        self.points[name] = (x, inner)
+        return inner
 
     def resume(self, name):
-        """Continue the backward pass below the cut (no-op if the forward pass never reached it or no gradient arrived)."""
-        outer = self.points.get(name)
-        if outer is not None and self.filled.get(name, 0) > 0:
-            outer.backward(self.buffers[name])
+        """Continue the backward pass below the cut (no-op if the forward pass never reached it or nothing above it
+        needed the gradient)."""
+        outer, inner = self.points.get(name, (None, None))
+        if outer is not None and inner.grad is not None:
+            outer.backward(inner.grad, retain_graph=_RETAIN)
 
     def clear(self):
         self.points.clear()
-        self.filled.clear()
 
 
 _CUTS = {"active": None}

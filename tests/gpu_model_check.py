@@ -1269,8 +1269,10 @@ def _dp_two_ranks(kind, payload="fp32"):
         opt.flat_g.copy_(gs[0] * 0.5 + gs[1] * 0.5)
         opt.step()
     exact = bool(torch.equal(opt.flat_p.cpu(), r0["flat_p"]))
-    tol = 1e-6 if payload == "fp32" else 2e-3
-    res.append(cmp(f"dp[{kind}, {payload}] 2-rank parameters vs the single-process replay (bit-exact: {exact})", r0["flat_p"], opt.flat_p.cpu(), tol))
+    # tolerance: parameters whose gradient is zero up to rounding get Adam updates of size ~lr from the rounding noise, which
+    # depends on the summation order (two ranks + all-reduce vs one process): a few elements move by up to ~lr, the mean by ~1e-8
+    tol, l1 = (2e-3, 1e-6) if payload == "fp32" else (5e-3, 2e-5)
+    res.append(cmp(f"dp[{kind}, {payload}] 2-rank parameters vs the single-process replay (bit-exact: {exact})", r0["flat_p"], opt.flat_p.cpu(), tol, l1_tol=l1))
     for k, v in model.named_buffers():
         if v.dtype.is_floating_point:
             ok, msg = cmp(f"dp[{kind}] rank-0 buffer {k}", r0["buffers"][k], v.detach().cpu(), 1e-6 if payload == "fp32" else 1e-3)
@@ -1566,6 +1568,76 @@ def fs2vc_tiny_train_and_inference_fp32():
             res.append(cmp(f"LengthRegulator backward alpha={alpha}", hd.grad, hr.grad, 1e-6))
     finally:
         Fn.set_compute_dtype(torch.float32)
+    return res
+
+
+
+@case
+def no_dependence_on_uninitialised_memory():
+    """The free blocks of the caching allocator are filled with NaN / 3e38 / -1e30 before a training step (every torch.empty
+    the step makes then returns poisoned memory): losses and every parameter gradient must be bit-identical to the
+    unpoisoned step -- no kernel reads an element that it or a predecessor did not write (padding columns, workspaces,
+    accumulate-into-empty, ...).  VTN, VTN-Conformer (legacy rel-pos), AAS-VC stochastic + deterministic; fp32 and bf16."""
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.optim import FlatAdam
+    res = []
+
+    def poison(val):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        blocks = [torch.full((32 << 20,), val, dtype=torch.float32, device=DEV) for _ in range(8)]          # 1 GiB of large blocks
+        small = [torch.full((n,), val, dtype=torch.float32, device=DEV) for n in (1 << 8, 1 << 12, 1 << 16, 1 << 18) for _ in range(64)]
+        torch.cuda.synchronize()
+        del blocks, small
+
+    try:
+        for name in ("vtn_tiny_train", "vtn_conformer_tiny_train", "aasvc_tiny_train", "aasvc_det_tiny_train"):
+            for dtype in (torch.float32, torch.bfloat16):
+                cfg, z = load(name)
+                Fn.set_compute_dtype(dtype)
+                Fn.enable_side_streams(0)
+                kind = cfg["__model__"]
+                model = getattr(M, kind)(**model_cfg(cfg))
+                model.load_state_dict(sd_of(z))
+                model.to(DEV).train()
+                _kill_dropout(model)
+                opt = FlatAdam(model, lr=1e-3, bf16_shadow=(dtype == torch.bfloat16))
+                t = lambda k: torch.from_numpy(z[k])
+                xs, ys, il, ol = t("in.xs").to(DEV), t("in.ys").to(DEV), t("in.ilens"), t("in.olens")
+                noise = t("in.sdp_noise").to(DEV) if "in.sdp_noise" in z.files else None
+
+                def step():
+                    opt.zero_grad()
+                    if kind == "AASVC":
+                        if noise is not None:
+                            model.duration_predictor.noise = noise.clone()
+                        ret = model(xs, il, ys, ol, xs, dp_lengths=il)
+                        loss = L.L1Loss()(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"]) + \
+                            2.0 * (L.ForwardSumLoss()(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"]) + ret["bin_loss"])
+                        loss = loss + (torch.sum(ret["dur_nll"].float()) if "dur_nll" in ret else
+                                       L.DurationPredictorLoss()(ret["d_outs"], ret["ds"], ret["ilens"]))
+                    else:
+                        o = model(xs, il, ys, t("in.labels").to(DEV), ol)
+                        l1, bce = L.Seq2SeqLoss(10.0)(o[0], o[1], o[2], o[3], o[4], o[5])
+                        loss = l1 + bce
+                    loss.backward()
+                    Fn.side_join()
+                    torch.cuda.synchronize()
+                    return loss.detach().clone(), opt.flat_g.clone()
+
+                l0, g0 = step()
+                bad = []
+                for val in (float("nan"), 3e38, -1e30):
+                    poison(val)
+                    lp, gp = step()
+                    if not (torch.equal(lp, l0) and torch.equal(gp, g0)):
+                        bad.append(val)
+                res.append((not bad, f"{name}[{dtype}]: results unchanged by poisoned free memory" + (f" -- CHANGED for fill values {bad}" if bad else "")))
+                del model, opt
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        torch.cuda.empty_cache()
     return res
 
 

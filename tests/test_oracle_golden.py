@@ -238,3 +238,56 @@ def test_fastspeech_vc_forward_grads_inference_and_duration_calculator():
     assert torch.equal(d4, t("dc.dur4")) and torch.equal(d2, t("dc.dur2"))
     close(f4, z["dc.focus4"], 1e-7); close(f2, z["dc.focus2"], 1e-7)
     assert int(d4.sum()) == 37 and int(d2.sum()) == 29          # every output frame is counted exactly once
+
+
+def test_logmel_analytic_known_answers():
+    """log-mel front-end (reference bin/preprocess.py:30-92 -> librosa, absent here: parity stays formally unpinned).  The
+    restatement is pinned against closed forms instead: (1) a bin-centred cosine of amplitude A has, under a periodic Hann
+    window of length N with no normalisation, |X[k]| = A*N/4, |X[k+-1]| = A*N/8 and nothing else -- which fixes window type,
+    window periodicity, STFT scaling and magnitude-vs-power; (2) a constant signal survives the centre/reflect padding
+    unchanged (frame 0 is centred on sample 0): |X[0]| = c*N/2, |X[1]| = c*N/4; (3) a unit impulse gives a flat magnitude
+    spectrum equal to the window value at its position, so mel_m = w * sum_k fb[m, k], and the Slaney area normalisation makes
+    that sum ~ n_fft / sr for every filter wide enough to be sampled; (4) frames = 1 + N // hop; (5) the float32 chain agrees
+    with the float64 chain to 1e-4 in log10 units on speech-like noise."""
+    from oracle import logmel as LM
+    sr, N, hop = 16000, 1024, 256
+    kw = dict(fft_size=N, hop_size=hop, num_mels=80, fmin=80, fmax=7600)
+    fb = LM.mel_filterbank64(sr, N, 80, 80, 7600)
+    n = hop * 40
+    # (1) bin-centred cosine
+    k0, A = 100, 0.37
+    x = A * np.cos(2 * np.pi * k0 * np.arange(n) / N + 0.3)
+    mag = np.zeros(N // 2 + 1)
+    mag[k0], mag[k0 - 1], mag[k0 + 1] = A * N / 4, A * N / 8, A * N / 8
+    want = np.log10(np.maximum(1e-10, fb @ mag))
+    got = LM.logmelfilterbank(x, sr, dtype=np.float64, **kw)
+    assert got.shape == (1 + n // hop, 80)                                    # (4)
+    inner = got[8:-8]                                                          # frames untouched by the reflect padding
+    hit = want > -5                                                            # filters that see the tone
+    assert hit.sum() >= 2 and np.abs(inner[:, hit] - want[hit]).max() < 1e-9
+    assert (inner[:, ~hit] < -8).all()                                         # everything else is rounding noise (eps floor at -10)
+    got32 = LM.logmelfilterbank(x.astype(np.float32), sr, **kw)
+    assert np.abs(got32[8:-8][:, hit] - want[hit]).max() < 1e-4
+    # (2) constant signal, first frame (centre padding by reflection)
+    c = 0.25
+    mag = np.zeros(N // 2 + 1)
+    mag[0], mag[1] = c * N / 2, c * N / 4
+    want = np.log10(np.maximum(1e-10, fb @ mag))
+    got = LM.logmelfilterbank(np.full(n, c), sr, dtype=np.float64, **kw)
+    assert np.abs(got[0] - want).max() < 1e-9 and np.abs(got[20] - want).max() < 1e-9
+    # (3) impulse: flat spectrum scaled by the window value at its position in the frame
+    x = np.zeros(n)
+    p = hop * 20 + 77
+    x[p] = 1.0
+    got = LM.logmelfilterbank(x, sr, dtype=np.float64, **kw)
+    t = 20                                                                     # frame t covers samples [t*hop - N/2, t*hop + N/2)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * (p - (t * hop - N // 2)) / N)
+    assert np.abs(got[t] - np.log10(w * fb.sum(1))).max() < 1e-9
+    wide = (fb > 0).sum(1) >= 8
+    assert wide.sum() > 30 and np.abs(fb.sum(1)[wide] / (N / sr) - 1).max() < 0.02
+    # (5) fp32 adequacy on noise with a speech-like spectral tilt
+    rng = np.random.default_rng(0)
+    x = np.cumsum(rng.standard_normal(n)) * 0.01
+    x = (x - x.mean()) / (np.abs(x).max() + 1e-9) * 0.5
+    d = np.abs(LM.logmelfilterbank(x.astype(np.float32), sr, **kw) - LM.logmelfilterbank(x.astype(np.float32).astype(np.float64), sr, dtype=np.float64, **kw))
+    assert d.max() < 1e-4, d.max()
