@@ -396,6 +396,64 @@ def sdp_module_vs_oracle():
     return res
 
 
+
+@case
+def stft_logmel_batched_and_device_collaters():
+    """SURVEY 8(f2) + a22: (i) the batched front-end -- B ragged utterances, three launches -- equals the per-utterance
+    path frame for frame (same DFT GEMM; the mel projection runs over each filter's non-zero bins only, so the last bits
+    may differ) and the numpy restatement (<= 2e-4 in log10 units), writes exact zeros into the padding frames and fuses the
+    mean/variance normalisation; closed-form check on the GPU path itself: a bin-centred cosine gives log10(fb @ [A*N/8,
+    A*N/4, A*N/8]) on the interior frames; (ii) the device collaters build the same batches as the host collaters
+    (collaters/ar_vc.py, nar_vc.py), bit for bit, with and without fused normalisation."""
+    from oracle import logmel as OL
+    from seq2seq_vc_amd import collaters as C
+    from seq2seq_vc_amd.frontend import logmelfilterbank, logmelfilterbank_batch
+    res = []
+    kw = dict(fft_size=1024, hop_size=256, num_mels=80, fmin=80, fmax=7600)
+    rng = np.random.default_rng(3)
+    lens = [16000, 37123, 255, 256, 48000, 9999]
+    auds = [(rng.standard_normal(n) * 0.1).astype(np.float32) for n in lens]
+    mel, frames = logmelfilterbank_batch(auds, 16000, **kw)
+    res.append((frames.tolist() == [1 + n // 256 for n in lens] and tuple(mel.shape) == (len(lens), max(frames), 80), f"batched log-mel shape {tuple(mel.shape)}, frames {frames.tolist()}"))
+    for b, a in enumerate(auds):
+        fb = int(frames[b])
+        single = logmelfilterbank(torch.from_numpy(a).to(DEV), 16000, **kw)
+        res.append(check(f"batched vs per-utterance log-mel, utterance {b} ({lens[b]} samples)", mel[b, :fb], single, torch.float32, atol=2e-5, rtol=1e-5))
+        res.append(check(f"batched log-mel vs numpy restatement, utterance {b}", mel[b, :fb], torch.from_numpy(OL.logmelfilterbank(a, 16000, **kw)), torch.float32, atol=2e-4, rtol=1e-4))
+        res.append((bool((mel[b, fb:] == 0).all()), f"utterance {b}: padding frames are exact zeros"))
+    mean, scale = rng.standard_normal(80).astype(np.float32), (0.5 + rng.random(80)).astype(np.float32)
+    meln, _ = logmelfilterbank_batch(auds, 16000, mean=mean, scale=scale, **kw)
+    for b in (1, 4):
+        fb = int(frames[b])
+        res.append(check(f"fused normalisation, utterance {b}", meln[b, :fb], (mel[b, :fb].cpu() - torch.from_numpy(mean)) / torch.from_numpy(scale), torch.float32, atol=1e-5, rtol=1e-5))
+    # closed form on the GPU path: bin-centred cosine
+    N, k0, A = 1024, 100, 0.37
+    x = (A * np.cos(2 * np.pi * k0 * np.arange(256 * 40) / N + 0.3)).astype(np.float32)
+    fbank = OL.mel_filterbank64(16000, N, 80, 80, 7600)
+    mag = np.zeros(N // 2 + 1)
+    mag[k0], mag[k0 - 1], mag[k0 + 1] = A * N / 4, A * N / 8, A * N / 8
+    want = np.log10(np.maximum(1e-10, fbank @ mag))
+    hit = want > -5
+    got, _ = logmelfilterbank_batch([x], 16000, **kw)
+    res.append(check("closed form: bin-centred cosine -> log10(fb @ [A*N/8, A*N/4, A*N/8])", got[0, 8:-8][:, torch.from_numpy(hit)],
+                     torch.from_numpy(np.broadcast_to(want[hit], (got.shape[1] - 16, int(hit.sum()))).copy()).float(), torch.float32, atol=1e-4, rtol=0))
+    # device collaters == host collaters
+    batch = [{"src_feat": rng.standard_normal((t1, 80)).astype(np.float32), "trg_feat": rng.standard_normal((t2, 80)).astype(np.float32),
+              "dp_input": rng.standard_normal((t1, 80)).astype(np.float32), "duration": rng.integers(0, 5, size=(t1 // 4,))}
+             for t1, t2 in [(57, 80), (128, 99), (3, 1), (200, 256)]]
+    h, d = C.ARVCCollater()(batch), C.DeviceARVCCollater()(batch)
+    for k in ("xs", "ys", "labels", "ilens", "olens"):
+        res.append((bool(torch.equal(d[k].cpu(), h[k])), f"DeviceARVCCollater {k} == ARVCCollater {k}"))
+    h, d = C.NARVCCollater()(batch), C.DeviceNARVCCollater()(batch)
+    for k in ("xs", "ys", "dp_inputs", "ilens", "olens", "dplens", "durations", "duration_lens"):
+        res.append((bool(torch.equal(d[k].cpu(), h[k])), f"DeviceNARVCCollater {k} == NARVCCollater {k}"))
+    dn = C.DeviceARVCCollater(mean=mean, scale=scale)(batch)
+    il = h["ilens"]
+    ref = (h["xs"] - torch.from_numpy(mean)) / torch.from_numpy(scale) * (torch.arange(h["xs"].shape[1])[None, :, None] < il[:, None, None])
+    res.append(check("DeviceARVCCollater with fused normalisation", dn["xs"], ref, torch.float32, atol=1e-6, rtol=1e-6))
+    return res
+
+
 def main():
     nfail = 0
     for fn in CASES:

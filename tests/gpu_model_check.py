@@ -1641,6 +1641,59 @@ def no_dependence_on_uninitialised_memory():
     return res
 
 
+
+@case
+def bf16_vs_fp32_loss_curves_300_steps():
+    """is the bf16 TRAJECTORY sound, not just one step?  VTN-small (configuration C1: d=256, 2+2
+    layers) trains 300 optimiser steps on the canonical 8-utterance batch, once in fp32 and once in bf16 compute (fp32
+    master weights, fp32 Adam), the same seeds, all dropouts on (the masks are functions of (seed, index), so both runs
+    draw the same masks).  Both loss curves must fall, and the bf16 curve must track the fp32 one: the 20-step moving
+    averages stay within 2 % of each other over the whole run."""
+    import bench
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.optim import FlatAdam
+    cfgs = dict(idim=80, odim=80, adim=256, aheads=4, elayers=2, eunits=1024, dlayers=2, dunits=1024, decoder_reduction_factor=4)
+    xs, ilens, ys, labels, olens = bench.canonical_batch(8)
+    res, curves, finals = [], {}, {}
+    try:
+        for dtype in (torch.float32, torch.bfloat16):
+            Fn.set_compute_dtype(dtype)
+            Fn.enable_side_streams(0)
+            torch.manual_seed(0)
+            K.manual_seed(4321)
+            model = M.VTN(**cfgs).to(DEV).train()
+            opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=100, bf16_shadow=(dtype == torch.bfloat16))
+            crit = L.Seq2SeqLoss(10.0)
+            xd, yd, ld = xs.to(DEV), ys.to(DEV), labels.to(DEV)
+            buf = torch.zeros(300, device=DEV)
+            for it in range(300):
+                K.reset_op_counter()
+                K.advance_seed(torch.device(DEV))
+                opt.zero_grad()
+                o = model(xd, ilens, yd, ld, olens)
+                l1, bce = crit(o[0], o[1], o[2], o[3], o[4], o[5])
+                (l1 + bce).backward()
+                Fn.side_join()
+                opt.step()
+                buf[it] = (l1 + bce).detach()
+            curves[dtype] = buf.cpu()
+            finals[dtype] = opt.flat_p.detach().cpu().clone()
+        f, b = curves[torch.float32], curves[torch.bfloat16]
+        res.append((bool(torch.isfinite(f).all() and torch.isfinite(b).all()), "both 300-step loss curves are finite"))
+        res.append((float(f[-20:].mean()) < 0.8 * float(f[:5].mean()) and float(b[-20:].mean()) < 0.8 * float(b[:5].mean()),
+                    f"losses fall: fp32 {float(f[:5].mean()):.4f} -> {float(f[-20:].mean()):.4f}, bf16 {float(b[:5].mean()):.4f} -> {float(b[-20:].mean()):.4f}"))
+        ma = lambda v: torch.nn.functional.avg_pool1d(v[None, None], 20, 1)[0, 0]
+        rel = ((ma(b) - ma(f)).abs() / ma(f)).max().item()
+        res.append((rel < 0.02, f"bf16 tracks fp32: largest relative gap of the 20-step moving averages {rel:.4f} (< 0.02)"))
+        # (the parameters themselves separate -- 300 Adam steps at lr 1e-3 amplify rounding differences -- so only a loose
+        # bound is asserted on them; the trajectory criterion is the loss curve above)
+        res.append(rel_l2("final parameters bf16 vs fp32 after 300 steps", finals[torch.bfloat16], finals[torch.float32], 0.15))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    return res
+
+
 def main(selected=None):
     nfail = 0
     for fn in CASES:

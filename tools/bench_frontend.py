@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Timing of the STFT -> log-mel front-end: wav batch -> normalised (B, Tmax, 80) batch.
+
+    python tools/bench_frontend.py [--batch 32] [--seconds 3.0] [--iters 20] [--cpu]
+
+Reports us per utterance for the batched path (3 launches per batch) and for the per-utterance path (5 launches each), the
+achieved fraction of the two roofs that apply -- fp32 MFMA for the DFT-as-GEMM formulation (2 * frames * 1026 * 1024 flop;
+peak 157.3 TFLOP/s) and HBM for the algorithmic traffic of the whole front-end (4 B per sample in + 320 B per frame out;
+8 TB/s) -- and, with --cpu, the numpy restatement on the host (one thread per numpy's defaults).  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seconds", type=float, default=3.0)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--cpu", action="store_true")
+    a = ap.parse_args()
+    from seq2seq_vc_amd.frontend import logmelfilterbank, logmelfilterbank_batch
+    sr, kw = 16000, dict(fft_size=1024, hop_size=256, num_mels=80, fmin=80, fmax=7600)
+    rng = np.random.default_rng(0)
+    lens = [int(sr * a.seconds * f) for f in rng.uniform(0.6, 1.0, a.batch)]
+    lens[0] = int(sr * a.seconds)
+    nmax = max(lens)
+    x = torch.zeros(a.batch, nmax)
+    for b, n in enumerate(lens):
+        x[b, :n] = torch.from_numpy((rng.standard_normal(n) * 0.1).astype(np.float32))
+    xd = x.cuda()
+    singles = [xd[b, :n].contiguous() for b, n in enumerate(lens)]
+    mean, scale = np.zeros(80, np.float32), np.ones(80, np.float32)
+
+    def batched():
+        return logmelfilterbank_batch(xd, sr, lengths=lens, mean=mean, scale=scale, **kw)
+
+    def looped():
+        return [logmelfilterbank(s, sr, mean=mean, scale=scale, **kw) for s in singles]
+
+    out = {}
+    for name, fn in (("batched", batched), ("per_utterance", looped)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / a.iters
+    frames = sum(1 + n // 256 for n in lens)
+    frames_padded = a.batch * (1 + nmax // 256)
+    flops = 2.0 * frames_padded * 1026 * 1024
+    alg_bytes = 4.0 * sum(lens) + 320.0 * frames
+    tb = out["batched"]
+    res = {"metric": "STFT->log-mel front-end", "batch": a.batch, "audio_seconds_per_utt_max": a.seconds, "frames": frames,
+           "us_per_utterance_batched": tb / a.batch * 1e6, "us_per_utterance_looped": out["per_utterance"] / a.batch * 1e6,
+           "ns_per_frame_batched": tb / frames * 1e9, "launches_per_batch": {"batched": 3, "per_utterance": 5 * a.batch},
+           "roofline": {"fp32_mfma": {"achieved_TFLOPs": flops / tb / 1e12, "peak": 157.3, "frac": flops / tb / 1e12 / 157.3,
+                                      "note": "DFT as GEMM over the padded batch: the formulation's own bound"},
+                        "hbm_algorithmic": {"bytes": alg_bytes, "achieved_GBs": alg_bytes / tb / 1e9, "peak": 8000.0,
+                                            "frac": alg_bytes / tb / 1e9 / 8000.0,
+                                            "note": "4 B/sample in + 320 B/frame out; an FFT-in-LDS kernel is what this roof asks for"}},
+           "realtime_factor": tb / (sum(lens) / sr)}
+    if a.cpu:
+        from oracle import logmel as OL
+        t0 = time.perf_counter()
+        for b, n in enumerate(lens):
+            OL.logmelfilterbank(x[b, :n].numpy(), sr, **kw)
+        tc = time.perf_counter() - t0
+        res["cpu_baseline"] = {"us_per_utterance": tc / a.batch * 1e6, "kind": "port", "cores": 1,
+                               "sample": f"{a.batch} utterances, numpy rfft restatement, one process"}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
