@@ -395,6 +395,13 @@ int s2svc_decode_emit(int dtype, int B, int r, int odim, const void* feat, const
                       const int32_t* minlen, const int32_t* maxlen, const int32_t* pos, float* outs, int64_t outs_bs,
                       float* probs, int64_t probs_bs, void* prev, int32_t* stop_at, void* stream);
 int s2svc_decode_advance(int32_t* pos, uint64_t* seed_base, uint64_t seed_stride, void* stream);
+/* LayerNorm -> Linear of a decode step, one launch: C[M <= 64, N] = act(LN(A)[M, K] . B[N, K]^T + bias) [dropout] (+ res);
+   `desc` carries A (the pre-LayerNorm rows), B, C and the epilogue fields of s2svc_gemm (dense K-contiguous operands,
+   unbatched, unsplit); gamma / beta / eps: the LayerNorm (both NULL: plain skinny linear); y_out != NULL: LN(A) is also
+   written there (row stride ldy) -- the residual input of a post-LN layer (decoder_layer.py:104-127).
+   Replaces one LayerNorm launch + one Linear launch per projection of decoder.py:239-273. */
+int s2svc_decode_ln_linear(const s2svc_gemm_desc* desc /* host */, const float* gamma, const float* beta, float eps, void* y_out,
+                           int64_t ldy, void* stream);
 
 /* ========================================================================================== */
 /* Optimiser: grad-norm -> clip -> WarmupLR -> Adam (+ bf16 shadow) over one flat buffer       */

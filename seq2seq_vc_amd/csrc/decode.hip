@@ -246,3 +246,204 @@ extern "C" int s2svc_decode_advance(int32_t* pos, uint64_t* seed_base, uint64_t 
   S2S_CHECK_LAUNCH("decode_advance_kernel");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm -> Linear for a decode step:  C[M <= 64, N] = act(LN(S)[M, K] . W[N, K]^T + bias) (+ res), optionally also
+// Y = LN(S) written out (by workgroup 0) for the residual path of a post-LN layer.  Replaces the LayerNorm launch in front
+// of every projection of decoder_layer.py:85-132 for one position: the 16..64 rows of a step are normalised by every
+// workgroup on its own (M * K <= 64 x 1536 elements, far cheaper than a launch), then stream through the same MFMA
+// fragment scheme as gemm_skinny_kernel (weights straight from global memory, 4 waves split K, LDS reduction).
+// With gamma == NULL the kernel is a plain skinny linear with the dropout stage of the prenet in its epilogue.
+// ------------------------------------------------------------------------------------------------
+#include "gemm_common.h"
+
+namespace {
+
+template <typename T> struct DFrag;
+template <> struct DFrag<bf16_t> {
+  static constexpr int VEC = 8, KSTEP = 32;
+  typedef bf16x8_t type;
+  static __device__ __forceinline__ type zero() { return (type){0, 0, 0, 0, 0, 0, 0, 0}; }
+  static __device__ __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void unpack(type v, float (&f)[8]) {
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+    const u16x8 u = __builtin_bit_cast(u16x8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = bf2f(u[e]);
+  }
+  static __device__ __forceinline__ type pack(const float (&f)[8]) {
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+    u16x8 u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] = f2bf(f[e]);
+    return __builtin_bit_cast(type, u);
+  }
+};
+template <> struct DFrag<float> {
+  static constexpr int VEC = 4, KSTEP = 16;
+  typedef f32x4_t type;
+  static __device__ __forceinline__ type zero() { return (type){0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ f32x4_t mma(type a, type b, f32x4_t c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ void unpack(type v, float (&f)[4]) { f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3]; }
+  static __device__ __forceinline__ type pack(const float (&f)[4]) { return (type){f[0], f[1], f[2], f[3]}; }
+};
+
+// NS = k-steps per wave held in registers (the whole K range of a wave is loaded up front: one exposed memory latency per
+// launch; the LayerNorm statistics come from those registers -- two-pass, partial sums through LDS across the four waves)
+template <typename T, int MT, int NS>
+__global__ __launch_bounds__(256) void ln_linear_skinny_kernel(const s2svc_gemm_desc d, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, T* __restrict__ y_out,
+                                                               int64_t ldy) {
+  typedef DFrag<T> F;
+  typedef typename F::type frag_t;
+  __shared__ float red[3][MT][256];
+  __shared__ float st_part[4][MT * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const T* A = (const T*)d.A.ptr;
+  const T* B = (const T*)d.B.ptr;
+  const int ksteps = (d.K + F::KSTEP - 1) / F::KSTEP;
+  const int per = (ksteps + 3) / 4;                      // <= NS (checked by the launcher)
+  const int ks0 = wave * per;
+  const bool brow = (n0 + lr) < d.N;
+  const T* bp = B + (int64_t)(n0 + lr) * d.B.ld + lg * F::VEC;
+  frag_t a[NS][MT], b[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int k = (ks0 + u) * F::KSTEP + lg * F::VEC;
+    const bool kin = u < per && (ks0 + u) < ksteps && k < d.K;
+    b[u] = (kin && brow) ? *reinterpret_cast<const frag_t*>(bp + (int64_t)(ks0 + u) * F::KSTEP) : F::zero();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row = i * 16 + lr;
+      a[u][i] = (kin && row < d.M) ? *reinterpret_cast<const frag_t*>(A + (int64_t)row * d.A.ld + k) : F::zero();
+    }
+  }
+  if (gamma) {
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          const int k = (ks0 + u) * F::KSTEP + lg * F::VEC;
+          if (u < per && (ks0 + u) < ksteps && k < d.K) {
+            float f[F::VEC];
+            F::unpack(a[u][i], f);
+#pragma unroll
+            for (int e = 0; e < F::VEC; ++e) { const float t = pass ? f[e] - mean[i] : f[e]; s += pass ? t * t : t; }
+          }
+        }
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lg == 0) st_part[wave][i * 16 + lr] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = i * 16 + lr;
+        const float tot = ((st_part[0][row] + st_part[1][row]) + st_part[2][row]) + st_part[3][row];
+        if (pass == 0) mean[i] = tot / (float)d.K;
+        else rstd[i] = rsqrtf(tot / (float)d.K + eps);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int k = (ks0 + u) * F::KSTEP + lg * F::VEC;
+      if (u < per && (ks0 + u) < ksteps && k < d.K) {
+        float g[F::VEC], bt[F::VEC];
+#pragma unroll
+        for (int e = 0; e < F::VEC; ++e) { g[e] = gamma[k + e]; bt[e] = beta[k + e]; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = i * 16 + lr;
+          if (row < d.M) {
+            float f[F::VEC];
+            F::unpack(a[u][i], f);
+#pragma unroll
+            for (int e = 0; e < F::VEC; ++e) f[e] = (f[e] - mean[i]) * rstd[i] * g[e] + bt[e];
+            a[u][i] = F::pack(f);
+            if (y_out && blockIdx.x == 0) *reinterpret_cast<frag_t*>(y_out + (int64_t)row * ldy + k) = a[u][i];
+          }
+        }
+      }
+    }
+  }
+  f32x4_t acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NS; ++u)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = F::mma(a[u][i], b[u], acc[i]);
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][i][r * 64 + lane] = acc[i][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ((acc[i][r] + red[0][i][r * 64 + lane]) + red[1][i][r * 64 + lane]) + red[2][i][r * 64 + lane];
+        const int m = i * 16 + lg * 4 + r, n = n0 + lr;
+        if (m < d.M && n < d.N) epilogue_store_f<true>(d, 0, 0, m, n, v);
+      }
+  }
+}
+
+template <typename T, int NS>
+void launch_ln_linear_ns(const s2svc_gemm_desc& d, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, hipStream_t st) {
+  dim3 grid((d.N + 15) / 16), block(256);
+  const int mt = (d.M + 15) / 16;
+  if (mt == 1) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 1, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+  else if (mt == 2) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 2, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+  else if (mt == 3) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 3, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+  else hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 4, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+}
+
+// k-steps per wave: K = 384 -> 3 (bf16) / 6 (fp32); up to K = 512 (bf16) / 256.. handled by the larger instantiations
+template <typename T>
+bool launch_ln_linear(const s2svc_gemm_desc& d, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, hipStream_t st) {
+  const int kstep = DFrag<T>::KSTEP;
+  const int per = ((d.K + kstep - 1) / kstep + 3) / 4;
+  if (per <= 3) launch_ln_linear_ns<T, 3>(d, gamma, beta, eps, y_out, ldy, st);
+  else if (per <= 6) launch_ln_linear_ns<T, 6>(d, gamma, beta, eps, y_out, ldy, st);
+  else if (per <= 12 && d.M <= 32) launch_ln_linear_ns<T, 12>(d, gamma, beta, eps, y_out, ldy, st);
+  else return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int s2svc_decode_ln_linear(const s2svc_gemm_desc* desc, const float* gamma, const float* beta, float eps, void* y_out,
+                                      int64_t ldy, void* stream) {
+  S2S_REQUIRE(desc != nullptr, "decode_ln_linear: null desc");
+  const s2svc_gemm_desc& d = *desc;
+  S2S_REQUIRE(d.M > 0 && d.M <= 64 && d.N > 0 && d.K > 0 && d.nb0 * d.nb1 <= 1 && d.splitk <= 1 && !d.a_rowsum && !d.c_map,
+              "decode_ln_linear: M <= 64, unbatched, unsplit");
+  S2S_REQUIRE(d.A.mode == S2SVC_OP_DENSE && d.B.mode == S2SVC_OP_DENSE && d.A.layout == S2SVC_LAYOUT_KC && d.B.layout == S2SVC_LAYOUT_KC,
+              "decode_ln_linear: dense K-contiguous operands");
+  S2S_REQUIRE((gamma == nullptr) == (beta == nullptr), "decode_ln_linear: gamma and beta come together");
+  const int vec = d.dtype == S2S_F32 ? 4 : 8;
+  S2S_REQUIRE(d.K % vec == 0 && d.A.ld % vec == 0 && d.B.ld % vec == 0 && (!y_out || ldy % vec == 0), "decode_ln_linear: K / strides must be whole 16-byte vectors");
+  S2S_REQUIRE(((uintptr_t)d.A.ptr) % 16 == 0 && ((uintptr_t)d.B.ptr) % 16 == 0 && ((uintptr_t)y_out) % 16 == 0, "decode_ln_linear: 16-byte aligned operands");
+  S2S_REQUIRE(d.drop_p < 1.f && (!(d.drop_p > 0.f || d.emask) || d.ldc == d.N), "decode_ln_linear: the dropout stage needs a contiguous C");
+  hipStream_t st = (hipStream_t)stream;
+  const bool ok = d.dtype == S2S_F32 ? launch_ln_linear<float>(d, gamma, beta, eps, y_out, ldy, st)
+                                     : launch_ln_linear<bf16_t>(d, gamma, beta, eps, y_out, ldy, st);
+  S2S_REQUIRE(ok, "decode_ln_linear: K too large for the register-resident form (use s2svc_layernorm_fwd + s2svc_gemm)");
+  S2S_CHECK_LAUNCH("ln_linear_skinny_kernel");
+  return 0;
+}

@@ -1,6 +1,10 @@
 """Launchers for the autoregressive decode-step kernels (csrc/decode.hip; C-ABI in include/s2svc_hip.h)."""
+import ctypes
+
+import torch
+
 from .. import _lib
-from .kernels import dt, ptr, stream
+from .kernels import _DT, ACT, dt, operand, ptr, stream
 
 
 def _p(t, off=0):
@@ -34,3 +38,23 @@ def decode_emit(feat, logit, r, odim, threshold, minlen, maxlen, pos, outs, prob
 
 def decode_advance(pos, seed_base_ptr=None, seed_stride=0):
     _lib.check(_lib.lib().s2svc_decode_advance(ptr(pos), seed_base_ptr, seed_stride, stream()), "decode_advance")
+
+
+def ln_linear(x, w, bias, *, norm=None, act=None, res=None, y_out=None, drop_p=0.0, seed=(None, 0)):
+    """out = act(LN(x) . w^T + bias) [dropout] (+ res) in ONE launch; norm = (gamma, beta, eps) or None (plain linear);
+    y_out: a tensor that receives LN(x) as well.  x (M <= 64, K), w (N, K) in the compute dtype; bias / gamma / beta fp32."""
+    M, Kd = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    d = _lib.GemmDesc()
+    d.A, d.B = operand(x, x.stride(0)), operand(w, w.stride(0))
+    d.C, d.ldc, d.c_dtype = out.data_ptr(), N, dt(out)
+    d.bias, d.res, d.ldr = ptr(bias), ptr(res), (res.stride(0) if res is not None else N)
+    d.M, d.N, d.K, d.nb0, d.nb1 = M, N, Kd, 1, 1
+    d.act, d.alpha, d.dtype, d.splitk = ACT[act], 1.0, _DT[x.dtype], 1
+    if drop_p > 0.0:
+        d.drop_p, d.seed_base, d.seed_off = drop_p, seed[0], seed[1]
+    g, b, eps = (None, None, 0.0) if norm is None else norm
+    _lib.check(_lib.lib().s2svc_decode_ln_linear(ctypes.byref(d), ptr(g), ptr(b), float(eps), ptr(y_out),
+                                                 y_out.stride(0) if y_out is not None else 0, stream()), "decode_ln_linear")
+    return out
