@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-collect every artefact under profiles/ on a GPU box (run from the repo root; results land in gpurun_out/profiles/,
-# copy the ones to keep into profiles/).  Counters run in their own passes, with --kernel-trace only.
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
+# copy the ones to keep into profiles/ with the round prefix).  Counters run in their own passes, with --kernel-trace only.
+#   gpurun --timeout 2700 -- 'bash tools/collect_profiles.sh'
 set -u
 cd "$(dirname "$0")/.."
 R=$PWD
@@ -9,24 +9,41 @@ OUT=$R/gpurun_out/profiles
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 db() { ls "$1"/*.db "$1"/*/*.db 2>/dev/null | head -1; }
+prof() {  # prof <dir> <rocprofv3 args...> -- <command...>
+  local d=$1; shift
+  rm -rf "$d"
+  (cd /tmp && rocprofv3 "$@" > "$d.log" 2>&1)
+}
 
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-python tools/bench_aasvc.py 2>/dev/null | tail -1 > "$OUT/bench_aasvc_vc2.json"
-python tools/bench_decode.py 2>/dev/null | tail -1 > "$OUT/bench_decode_c5.json"
+python bench.py --workload aasvc > "$OUT/bench_aasvc.json" 2>> "$OUT/bench.err"
+python bench.py --force-dist --no-cpu-baseline > "$OUT/bench_force_dist.json" 2>> "$OUT/bench.err"
 python tools/gemm_bench.py > "$OUT/gemm_bench.txt" 2>&1
+python tools/gemm8_bench.py > "$OUT/gemm8_bench.txt" 2>&1
+python tools/bench_frontend.py --cpu > "$OUT/bench_frontend.json" 2>> "$OUT/bench.err"
 
-rm -rf /tmp/prof_step /tmp/prof_roof /tmp/prof_fetch /tmp/prof_write /tmp/prof_sq1 /tmp/prof_sq2
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_step -o vtn -- python "$R/bench.py" --no-cpu-baseline --steps 24 --warmup 3 > /tmp/prof_step.log 2>&1)
+# per-kernel statistics + one-step timelines of the three workloads
+prof /tmp/prof_step --kernel-trace --stats -d /tmp/prof_step -o vtn -- python "$R/bench.py" --no-cpu-baseline --no-extras --steps 24 --warmup 3
 python tools/rocpd_stats.py "$(db /tmp/prof_step)" > "$OUT/vtn_train_bf16_kernel_stats.txt" 2>&1
 python tools/rocpd_timeline.py "$(db /tmp/prof_step)" 3 > "$OUT/vtn_train_bf16_timeline.txt" 2>&1
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_roof -o r -- python "$R/bench.py" --roofline-only > /tmp/prof_roof.log 2>&1)
-python tools/rocpd_stats.py "$(db /tmp/prof_roof)" > "$OUT/roofline_kernel_stats.txt" 2>&1
-(cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_fetch -o r -- python "$R/bench.py" --roofline-only > /tmp/prof_fetch.log 2>&1)
-python tools/rocpd_pmc.py "$(db /tmp/prof_fetch)" gemm_glds > "$OUT/roofline_pmc_fetch.txt" 2>&1
-(cd /tmp && rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write -o r -- python "$R/bench.py" --roofline-only > /tmp/prof_write.log 2>&1)
-python tools/rocpd_pmc.py "$(db /tmp/prof_write)" gemm_glds > "$OUT/roofline_pmc_write.txt" 2>&1
-(cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/prof_sq1 -o r -- python "$R/bench.py" --roofline-only > /tmp/prof_sq1.log 2>&1)
-python tools/rocpd_pmc.py "$(db /tmp/prof_sq1)" gemm_glds > "$OUT/roofline_pmc_sq.txt" 2>&1
-(cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/prof_sq2 -o r -- python "$R/bench.py" --roofline-only > /tmp/prof_sq2.log 2>&1)
-python tools/rocpd_pmc.py "$(db /tmp/prof_sq2)" gemm_glds >> "$OUT/roofline_pmc_sq.txt" 2>&1
+prof /tmp/prof_aas --kernel-trace --stats -d /tmp/prof_aas -o aas -- python "$R/bench.py" --workload aasvc --no-cpu-baseline --steps 24 --warmup 3
+python tools/rocpd_stats.py "$(db /tmp/prof_aas)" > "$OUT/aasvc_train_bf16_kernel_stats.txt" 2>&1
+python tools/rocpd_timeline.py "$(db /tmp/prof_aas)" 3 > "$OUT/aasvc_train_bf16_timeline.txt" 2>&1
+prof /tmp/prof_dec --kernel-trace --stats -d /tmp/prof_dec -o dec -- python "$R/tools/bench_decode.py" --iters 2
+python tools/rocpd_stats.py "$(db /tmp/prof_dec)" > "$OUT/decode_kernel_stats.txt" 2>&1
+python tools/rocpd_timeline.py "$(db /tmp/prof_dec)" 5 decode_advance > "$OUT/decode_step_timeline.txt" 2>&1
+
+# dominant kernel of the headline workload (and of AAS-VC): timing + counters
+for wl in vtn aasvc; do
+  prof /tmp/prof_roof_$wl --kernel-trace --stats -d /tmp/prof_roof_$wl -o r -- python "$R/bench.py" --roofline-only --workload $wl
+  python tools/rocpd_stats.py "$(db /tmp/prof_roof_$wl)" > "$OUT/roofline_${wl}_kernel_stats.txt" 2>&1
+  prof /tmp/prof_fetch_$wl --pmc FETCH_SIZE --kernel-trace -d /tmp/prof_fetch_$wl -o r -- python "$R/bench.py" --roofline-only --workload $wl
+  python tools/rocpd_pmc.py "$(db /tmp/prof_fetch_$wl)" gemm_8ph > "$OUT/roofline_${wl}_pmc_fetch.txt" 2>&1
+  prof /tmp/prof_write_$wl --pmc WRITE_SIZE --kernel-trace -d /tmp/prof_write_$wl -o r -- python "$R/bench.py" --roofline-only --workload $wl
+  python tools/rocpd_pmc.py "$(db /tmp/prof_write_$wl)" gemm_8ph > "$OUT/roofline_${wl}_pmc_write.txt" 2>&1
+done
+prof /tmp/prof_sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/prof_sq1 -o r -- python "$R/bench.py" --roofline-only
+python tools/rocpd_pmc.py "$(db /tmp/prof_sq1)" gemm_8ph > "$OUT/roofline_vtn_pmc_sq.txt" 2>&1
+prof /tmp/prof_sq2 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/prof_sq2 -o r -- python "$R/bench.py" --roofline-only
+python tools/rocpd_pmc.py "$(db /tmp/prof_sq2)" gemm_8ph >> "$OUT/roofline_vtn_pmc_sq.txt" 2>&1
 ls -la "$OUT"

@@ -1,7 +1,10 @@
 """Timeline of ONE replayed training step from a rocprofv3 (rocpd SQLite) kernel trace: which kernels ran on which
 queue/stream, in start order, with the idle gap before each one on the main stream, plus per-stream busy time.
 
-    python tools/rocpd_timeline.py /tmp/prof/vtn_results.db [step_index_from_end=1] > gpurun_out/timeline.txt
+    python tools/rocpd_timeline.py /tmp/prof/vtn_results.db [step_index_from_end=1] [marker=adam_update] > gpurun_out/timeline.txt
+
+`marker` is a substring of the kernel that ends a step (adam_update for the training steps, decode_advance for one position
+of the autoregressive decode loop).
 """
 import sqlite3
 import sys
@@ -18,7 +21,8 @@ def main():
     print("# dispatch columns:", cols)
     sid = "stream_id" if "stream_id" in cols else "queue_id"
     rows = list(c.execute(f"select d.start, d.end, d.{sid}, d.queue_id, s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
-    marks = [i for i, r in enumerate(rows) if "adam_update" in r[4]]
+    marker = sys.argv[3] if len(sys.argv) > 3 else "adam_update"
+    marks = [i for i, r in enumerate(rows) if marker in r[4]]
     if len(marks) < back + 1:
         print("not enough steps")
         return
