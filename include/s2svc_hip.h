@@ -213,6 +213,12 @@ int s2svc_posenc_bwd(int dtype, int64_t B, int T, int D, const void* dy, float x
 int s2svc_axpby(int dtype, int64_t n, float a, const void* x, float b, const void* y, void* out, void* stream);
 int s2svc_add_head_bias(int dtype, int64_t rows, int D, const void* q, const float* u, const float* v, void* qu, void* qv,
                         void* stream);
+/* the same with q a column block of a packed Q|K|V projection (row stride ldq elements); qu, qv dense (rows, D) */
+int s2svc_add_head_bias_ld(int dtype, int64_t rows, int D, const void* q, int64_t ldq, const float* u, const float* v, void* qu,
+                           void* qv, void* stream);
+/* out[r, :D] = a[r, :D] + b[r, :D] over row-strided views (e.g. dQ = dQu + dQv written into the packed gradient) */
+int s2svc_add_rows(int dtype, int64_t rows, int D, const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
+                   void* stream);
 int s2svc_glu_fwd(int dtype, int64_t rows, int C, const void* x, void* y, void* stream);
 int s2svc_glu_bwd(int dtype, int64_t rows, int C, const void* x, const void* dy, void* dx, void* stream);
 int s2svc_cast(int in_dtype, int out_dtype, int64_t n, const void* x, void* y, void* stream);

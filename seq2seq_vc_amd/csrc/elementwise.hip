@@ -179,6 +179,30 @@ __global__ void add_head_bias_kernel(int64_t n, int D, const T* __restrict__ q, 
   }
 }
 
+// the same with q a column block of a packed projection (row stride ldq): qu / qv dense (rows, D)
+template <typename T>
+__global__ void add_head_bias_ld_kernel(int64_t n, int D, const T* __restrict__ q, int64_t ldq, const float* __restrict__ u,
+                                        const float* __restrict__ v, T* __restrict__ qu, T* __restrict__ qv) {
+  EW_LOOP(i, n) {
+    const int64_t r = i / D;
+    const int d = (int)(i - r * D);
+    const float x = ldf(q + r * ldq + d);
+    stf(qu + i, x + u[d]);
+    stf(qv + i, x + v[d]);
+  }
+}
+
+// out[r, d] = a[r, d] + b[r, d] over row-strided (rows, D) views (a column block of a packed gradient as destination)
+template <typename T>
+__global__ void add_rows_kernel(int64_t n, int D, const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb,
+                                T* __restrict__ out, int64_t ldo) {
+  EW_LOOP(i, n) {
+    const int64_t r = i / D;
+    const int d = (int)(i - r * D);
+    stf(out + r * ldo + d, ldf(a + r * lda + d) + ldf(b + r * ldb + d));
+  }
+}
+
 // GLU over the channel halves of channel-last rows: y[r,c] = x[r,c] * sigmoid(x[r,C+c])
 // reference: modules/conformer/convolution.py:68 (nn.functional.glu(x, dim=1) on (B,2C,T))
 template <typename T>
@@ -336,6 +360,34 @@ extern "C" int s2svc_add_head_bias(int dtype, int64_t rows, int D, const void* q
   else
     hipLaunchKernelGGL(add_head_bias_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, n, D, (const bf16_t*)q, u, v, (bf16_t*)qu, (bf16_t*)qv);
   S2S_CHECK_LAUNCH("add_head_bias_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_add_head_bias_ld(int dtype, int64_t rows, int D, const void* q, int64_t ldq, const float* u, const float* v,
+                                      void* qu, void* qv, void* stream) {
+  S2S_REQUIRE(rows >= 0 && D > 0 && ldq >= D, "add_head_bias_ld: bad args");
+  const int64_t n = rows * D;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(add_head_bias_ld_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, n, D, (const float*)q, ldq, u, v, (float*)qu, (float*)qv);
+  else
+    hipLaunchKernelGGL(add_head_bias_ld_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, n, D, (const bf16_t*)q, ldq, u, v, (bf16_t*)qu, (bf16_t*)qv);
+  S2S_CHECK_LAUNCH("add_head_bias_ld_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_add_rows(int dtype, int64_t rows, int D, const void* a, int64_t lda, const void* b, int64_t ldb, void* out,
+                              int64_t ldo, void* stream) {
+  S2S_REQUIRE(rows >= 0 && D > 0 && lda >= D && ldb >= D && ldo >= D, "add_rows: bad args");
+  const int64_t n = rows * D;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(add_rows_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, n, D, (const float*)a, lda, (const float*)b, ldb, (float*)out, ldo);
+  else
+    hipLaunchKernelGGL(add_rows_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, n, D, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo);
+  S2S_CHECK_LAUNCH("add_rows_kernel");
   return 0;
 }
 

@@ -422,7 +422,12 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   // columns (fewer wasted columns, one round of workgroups); the 2-phase 256 x 128 kernel for what is left
   int geo = 0;                                   // 1: 256 x 256, 2: 512 x 128, 3: 256 x 128
   const int waste256 = (int)(((d.N + 255) / 256) * 256 - d.N), waste128 = (int)(((d.N + 127) / 128) * 128 - d.N);
-  if (waste256 <= waste128 && t256 >= 192) geo = 1;
+  // rounds of workgroups on the 256 CUs, in units of one 256 x 128 tile: the big tiles run ~15 % faster per flop
+  // (gemm8_bench: 4096^3 1285 vs 1099 TFLOP/s) but a second, nearly empty round of them costs two units
+  // (4096 x 4608 x 1536, the packed Q|K|V projection of the AAS-VC decoder: 288 tiles of 256 x 256 = 2 rounds = 3.4 units,
+  // 576 tiles of 256 x 128 = 3 units)
+  const double cost256 = 2.0 * 0.85 * (double)((t256 + 255) / 256), cost128 = (double)((t128 + 255) / 256);
+  if (waste256 <= waste128 && t256 >= 192 && cost256 <= cost128) geo = 1;
   else if (d.M >= 2048 && t512 >= 160 && t512 <= 256) geo = 2;
   else if (t128 >= p8_min_tiles()) geo = 3;
   if (p8_force_bn() >= 1 && p8_force_bn() <= 3) geo = p8_force_bn();

@@ -217,6 +217,14 @@ class RelPositionMultiHeadedAttention(MultiHeadedAttention):
         nn.init.xavier_uniform_(self.pos_bias_v)
 
     def forward(self, query, key, value, pos_emb, klens=None):
+        f = getattr(self, "_fused", None)   # packed Q/K/V views of the flat parameter buffer (optim.FlatAdam)
+        if f is not None and "w_qkv" in f and query is key and key is value:
+            qkv = Fn.linear(query, f["w_qkv"], f["b_qkv"])                              # ONE GEMM, N = 3D
+            pos = Fn.linear(pos_emb, self.linear_pos.weight, None)
+            ctx, self.attn = Fn.rel_attention_packed(qkv, pos, self.pos_bias_u, self.pos_bias_v,
+                                                     None if klens is None else klens.dev, self.h, self._p(),
+                                                     2 if self.legacy else 1)
+            return Fn.linear(ctx, self.linear_out.weight, self.linear_out.bias)
         q = Fn.linear(query, self.linear_q.weight, self.linear_q.bias)
         k = Fn.linear(key, self.linear_k.weight, self.linear_k.bias)
         v = Fn.linear(value, self.linear_v.weight, self.linear_v.bias)

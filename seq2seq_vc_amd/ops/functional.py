@@ -915,6 +915,75 @@ def rel_attention_core(qu, qv, k, v, pos, klen, H, p=0.0, rel_mode=1):
     return _RelAttnCore.apply(qu, qv, k, v, pos, klen, H, p, rel_mode)
 
 
+class _RelAttnPacked(Function):
+    """Relative-position self-attention on ONE packed projection qkv (B, T, 3D) (the Q | K | V GEMM of the layer):
+    qu = q + pos_bias_u, qv = q + pos_bias_v, then _RelAttnCore's arithmetic with k, v read in place as column blocks.
+    The gradient comes back packed, so the three projections also share ONE data-gradient and ONE weight-gradient GEMM
+    (K = 3D instead of three products and two additions)."""
+
+    @staticmethod
+    def forward(ctx, qkv, pos, u, v, klen, H, p, rel_mode):
+        qkv, pos = _c(qkv), _c(pos)
+        B, T, D3 = qkv.shape
+        D = D3 // 3
+        dk = D // H
+        L = pos.shape[1]
+        dtype = qkv.dtype
+        q, k, vv = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        qu, qv = K.add_head_bias_view(q, u.detach().reshape(-1), v.detach().reshape(-1))
+        scale = 1.0 / math.sqrt(dk)
+        seed = K.new_seed(qkv.device) if p > 0.0 else (None, 0)
+        ac = _qk(qu, k, B, H, T, T, dk, D, dtype)
+        Lq = _pad8(L)
+        bd = torch.empty((B, H, T, Lq), dtype=torch.float32, device=qkv.device)
+        K.gemm(K.operand(qv, D, bs0=T * D, bs1=dk), K.operand(pos, D, bs0=0, bs1=dk), T, L, dk, bd, in_dtype=dtype, nb0=B, nb1=H,
+               ldc=Lq, cbs=(H * T * Lq, T * Lq))
+        attn, pdrop = K.attn_softmax_fwd(ac, dtype, scale, klen=klen, causal=False, bd=bd, rel_mode=rel_mode, p=p, seed=seed, T2=T,
+                                         Lp=L)
+        pm = pdrop if pdrop is not None else attn
+        out = _pv(pm, vv, B, H, T, T, dk, D, dtype)
+        ctx.meta = (H, scale, p, seed, rel_mode, L, D)
+        ctx.params = (u, v)
+        ctx.save_for_backward(qkv, qu, qv, pos, attn, pdrop)
+        ctx.set_materialize_grads(False)
+        return out, _user_attn(attn, T)
+
+    @staticmethod
+    def backward(ctx, dctx, dattn):
+        qkv, qu, qv, pos, attn, pdrop = ctx.saved_tensors
+        H, scale, p, seed, rel_mode, L, D = ctx.meta
+        u, v = ctx.params
+        B, T, _ = qu.shape
+        dk = D // H
+        dtype = qu.dtype
+        k, vv = qkv[..., D:2 * D], qkv[..., 2 * D:]
+        pm = pdrop if pdrop is not None else attn
+        Lq = _pad8(L)
+        dqkv = torch.empty_like(qkv)
+        dqu = torch.empty((B, T, D), dtype=dtype, device=qu.device)
+        _, _, _, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, vv, H, scale, p, seed, Lp=L, rel_mode=rel_mode, ldb=Lq,
+                                        outs=(dqu, dqkv[..., D:2 * D], dqkv[..., 2 * D:]))
+        dqv = torch.empty((B, T, D), dtype=dtype, device=qu.device)
+        K.gemm(K.operand(dbd, Lq, bs0=H * T * Lq, bs1=T * Lq, zero_padded=True), K.operand(pos, D, layout=K.RC, bs0=0, bs1=dk), T, dk,
+               L, dqv, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T * D, dk))
+        part = torch.empty((B, L, D), dtype=dtype, device=qu.device)
+        K.gemm(K.operand(dbd, Lq, layout=K.RC, bs0=H * T * Lq, bs1=T * Lq, zero_padded=True),
+               K.operand(qv, D, layout=K.RC, bs0=T * D, bs1=dk), L, dk, T, part, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(L * D, dk))
+        dpos, _ = K.colreduce(0, part.view(B, L * D))
+        dpos = K.cast(dpos.view(1, L, D), dtype)
+        K.add_rows(dqu, dqv, dqkv[..., :D])
+        du = dv = None
+        if u.requires_grad:
+            su, _ = K.colreduce(0, dqu.view(-1, D))
+            sv, _ = K.colreduce(0, dqv.view(-1, D))
+            du, dv = _emit_vgrad(u, su), _emit_vgrad(v, sv)
+        return dqkv, dpos, du, dv, None, None, None, None
+
+
+def rel_attention_packed(qkv, pos, u, v, klen, H, p=0.0, rel_mode=1):
+    return _RelAttnPacked.apply(qkv, pos, u, v, klen, H, p, rel_mode)
+
+
 class _HeadBias(Function):
     """qu = q + pos_bias_u, qv = q + pos_bias_v   (attention.py:283-286)."""
 

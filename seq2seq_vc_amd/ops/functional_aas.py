@@ -4,7 +4,7 @@ from torch.autograd import Function
 
 from . import kernels as K
 from . import kernels_aas as KA
-from .functional import _c, _emit_vgrad
+from .functional import _c, _emit_vgrad, _reduce_to, _side_run, _slotted
 
 
 class _DwConv(Function):
@@ -29,10 +29,17 @@ class _DwConv(Function):
         dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True) if ctx.needs_input_grad[0] else None
         dw = db = None
         if weight.requires_grad:
-            dw = _emit_vgrad(weight, KA.dwconv_wgrad(x, dy, ks, dil))
+            slot = getattr(weight, "_s2s_grad", None)
+            if slot is not None and slot.is_contiguous():       # straight into the flat gradient buffer
+                KA.dwconv_wgrad(x, dy, ks, dil, out=slot)
+            else:
+                dw = _emit_vgrad(weight, KA.dwconv_wgrad(x, dy, ks, dil))
         if bias is not None and bias.requires_grad:
-            s, _ = K.colreduce(0, dy.view(-1, dy.shape[-1]))
-            db = _emit_vgrad(bias, s)
+            dy2 = dy.view(-1, dy.shape[-1])
+            if _slotted(bias):                                    # queued: joins the grouped column reductions of the batch
+                _side_run(lambda: _reduce_to(bias, None, 0, dy2), keep=(dy2,))
+            else:
+                db, _ = _reduce_to(bias, None, 0, dy2)
         return dx, dw, db, None
 
 
@@ -64,10 +71,13 @@ class _PairwiseLogSoftmax(Function):
         K.gemm(K.operand(G, Tx, bs0=Tf * Tx), K.operand(text, A, layout=K.RC, bs0=Tx * A), Tf, A, Tx, dfe, in_dtype=dtype,
                nb0=B, nb1=1, cbs=(Tf * A, 0), alpha=-1.0, res=r1, rbs=(Tf * A, 0))
         # dtext[b,j,:] = text[b,j,:]*sum_i G[b,i,j] - sum_i G[b,i,j] feats[b,i,:]
-        cs = torch.empty((B, Tx), dtype=torch.float32, device=feats.device)
-        for b in range(B):  # column sums over the frame axis, one deterministic reduction per utterance
-            s, _ = K.colreduce(0, G[b])
-            cs[b].copy_(s)
+        # column sums over the frame axis, one deterministic reduction per utterance: all of them as ONE grouped launch pair
+        cs = torch.zeros((B, Tx), dtype=torch.float32, device=feats.device)
+        queue = []
+        with K.record_colreduce(queue):
+            for b in range(B):
+                K.colreduce(0, G[b], out_sum=cs[b], accumulate=True)
+        K.flush_colreduce(queue)
         r2 = KA.rowscale(text, cs.view(-1))
         dtx = torch.empty_like(text)
         K.gemm(K.operand(G, Tx, layout=K.RC, bs0=Tf * Tx), K.operand(feats, A, layout=K.RC, bs0=Tf * A), Tx, A, Tf, dtx,

@@ -465,6 +465,27 @@ def add_head_bias(q, u, v):
     return qu, qv
 
 
+def add_head_bias_view(q, u, v):
+    """q: a (B, T, D) column block of a packed projection (unit column stride, row stride q.stride(-2)) -> dense qu, qv."""
+    D = q.shape[-1]
+    assert q.stride(-1) == 1 and q.dim() == 3 and q.stride(0) == q.shape[1] * q.stride(1)
+    qu = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    qv = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    _lib.check(_lib.lib().s2svc_add_head_bias_ld(dt(q), q.numel() // D, D, ptr(q), q.stride(1), ptr(u), ptr(v), ptr(qu), ptr(qv),
+                                                 stream()), "add_head_bias_ld")
+    return qu, qv
+
+
+def add_rows(a, b, out):
+    """out = a + b for (B, T, D) tensors that may be column blocks of packed tensors (unit column stride)."""
+    D = a.shape[-1]
+    for t in (a, b, out):
+        assert t.stride(-1) == 1 and t.stride(0) == t.shape[1] * t.stride(1)
+    _lib.check(_lib.lib().s2svc_add_rows(dt(a), a.numel() // D, D, ptr(a), a.stride(1), ptr(b), b.stride(1), ptr(out), out.stride(1),
+                                         stream()), "add_rows")
+    return out
+
+
 def glu_fwd(x):
     C = x.shape[-1] // 2
     y = torch.empty(x.shape[:-1] + (C,), dtype=x.dtype, device=x.device)

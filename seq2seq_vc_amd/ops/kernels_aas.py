@@ -18,12 +18,13 @@ def dwconv(x, w, bias, ks, dil=1, flip=False):
     return y
 
 
-def dwconv_wgrad(x, dy, ks, dil=1):
+def dwconv_wgrad(x, dy, ks, dil=1, out=None):
+    """dw (C, 1, ks) fp32; `out`: a gradient slot of that shape to ACCUMULATE into instead (no separate add launch)."""
     B, T, C = x.shape
-    dw = torch.empty((C, 1, ks), dtype=torch.float32, device=x.device)
+    dw = torch.empty((C, 1, ks), dtype=torch.float32, device=x.device) if out is None else out
     ws = torch.empty(_WS_CHUNKS * C * ks, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().s2svc_dwconv_wgrad(dt(x), B, T, C, ks, dil, ptr(x), ptr(dy), ptr(dw), 0, ptr(ws), _WS_CHUNKS, stream()),
-               "dwconv_wgrad")
+    _lib.check(_lib.lib().s2svc_dwconv_wgrad(dt(x), B, T, C, ks, dil, ptr(x), ptr(dy), ptr(dw), 0 if out is None else 1, ptr(ws),
+                                             _WS_CHUNKS, stream()), "dwconv_wgrad")
     return dw
 
 
