@@ -34,10 +34,23 @@ class _ARSeq2Seq(nn.Module):
 
     def dp_plan(self):
         """Stages of the data-parallel backward pass (distributed.OverlappedBackward): the decoder side finishes first and its
-        gradients (2/3 of the parameters) travel while the encoder's backward pass -- below the cut at the encoder output --
-        runs.  One loss key: "loss"."""
+        gradients (half of the parameters) travel while the encoder's backward pass -- below the cut at the encoder output --
+        runs; the encoder is cut twice more (in the middle of its layer stack and behind its input layer), so that the
+        bucket left over when the backward pass ends -- the only exchange nothing hides -- is the input layer's alone
+        (VTN vc1: 62.8 | 21.3 | 21.3 | 16.5 MB instead of 62.8 | 59.1).  One loss key: "loss"."""
         dec_side = [m for m in (self.decoder, self.feat_out, self.prob_out, self.postnet) if m is not None]
-        return [{"root": "loss:loss", "modules": dec_side}, {"root": "cut:encoder_out", "modules": [self.encoder]}]
+        enc = self.encoder
+        layers = list(enc.encoders)
+        tail = [m for m in (getattr(enc, "after_norm", None),) if m is not None]
+        embed = [m for n, m in enc.named_children() if n not in ("encoders", "after_norm")]
+        h = len(layers) // 2
+        if h == 0 or not embed:
+            return [{"root": "loss:loss", "modules": dec_side}, {"root": "cut:encoder_out", "modules": [enc]}]
+        enc.cut_name = "encoder"            # names the cut points inside Encoder.forward / run_stack
+        return [{"root": "loss:loss", "modules": dec_side},
+                {"root": "cut:encoder_out", "modules": layers[h:] + tail},
+                {"root": f"cut:encoder.{h}", "modules": layers[:h]},
+                {"root": "cut:encoder.0", "modules": embed}]
 
     def _teacher_forced(self, hs, hs_lens, ys, labels, olens):
         r, odim = self.decoder_reduction_factor, self.odim

@@ -376,9 +376,12 @@ def run_stack(layers, x, after_norm, pre_ln, dropout_rate, training, *args, per_
     per_layer: optional list of extra keyword arguments, one dict per layer."""
     p = dropout_rate if training else 0.0
     pending = None
+    cut_name = kw.pop("cut_name", None)      # data-parallel overlap: "<name>.<i>" cuts the graph at the input of layer i
     for li, layer in enumerate(layers):
         if per_layer is not None:
             kw = dict(kw, **per_layer[li])
+        if cut_name is not None and li > 0:
+            x, pending = Fn.cut_point((x, pending), f"{cut_name}.{li}")
         if pre_ln and pending is not None:
             normed, x = _res_norm(layer.norm1, x, pending, p)
             x, pending = layer(x, *args, normed=normed, **kw)
@@ -538,8 +541,11 @@ class TransformerEncoder(nn.Module):
             else:
                 xs = emb(xs)
             xs = self.embed[1](xs)
+        cut_name = getattr(self, "cut_name", None)      # data-parallel overlap (models' dp_plan): cut behind the input layer
+        if cut_name is not None:
+            xs = Fn.cut_point(xs, f"{cut_name}.0")
         xs = run_stack(self.encoders, xs, getattr(self, "after_norm", None), self.normalize_before, self.dropout_rate,
-                       self.training, lens)
+                       self.training, lens, cut_name=cut_name)
         return xs, lens
 
 

@@ -98,20 +98,28 @@ class GradCuts:
         self.points = {}          # name -> (tensor above the cut [graph side of the producer], detached leaf the consumers see)
 
     def cut(self, x, name):
-        if name not in self.names or not (torch.is_grad_enabled() and x.requires_grad):
+        """x: a tensor, or a tuple of tensors crossing the cut together (e.g. the residual stream of a pre-norm layer stack
+        and the feed-forward output still to be added to it); None members pass through."""
+        if name not in self.names or not torch.is_grad_enabled():
+            return x
+        xs = x if isinstance(x, tuple) else (x,)
+        if not any(t is not None and t.requires_grad for t in xs):
             return x
         if name in self.points:
             raise RuntimeError(f"gradient cut '{name}' was reached twice in one forward pass")
-        inner = x.detach().requires_grad_(True)
-        self.points[name] = (x, inner)
-        return inner
+        inner = tuple(t.detach().requires_grad_(True) if (t is not None and t.requires_grad) else t for t in xs)
+        self.points[name] = (xs, inner)
+        return inner if isinstance(x, tuple) else inner[0]
 
     def resume(self, name):
         """Continue the backward pass below the cut (no-op if the forward pass never reached it or nothing above it
         needed the gradient)."""
         outer, inner = self.points.get(name, (None, None))
-        if outer is not None and inner.grad is not None:
-            outer.backward(inner.grad, retain_graph=_RETAIN)
+        if outer is None:
+            return
+        pairs = [(o, i.grad) for o, i in zip(outer, inner) if o is not None and o.requires_grad and i is not o and i.grad is not None]
+        if pairs:
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs], retain_graph=_RETAIN)
 
     def clear(self):
         self.points.clear()
