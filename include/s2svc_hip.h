@@ -224,6 +224,17 @@ int s2svc_glu_bwd(int dtype, int64_t rows, int C, const void* x, const void* dy,
 int s2svc_cast(int in_dtype, int out_dtype, int64_t n, const void* x, void* y, void* stream);
 int s2svc_gather3(int in_dtype, int out_dtype, int n0, int n1, int n2, int64_t s0, int64_t s1, int64_t s2, int64_t off,
                   const void* in, void* out, void* stream);
+/* Several gathers of fp32 sources in one launch: the permuted compute-dtype copies of the convolution weights
+   ((O, I, k) -> (O, k, I) for the implicit-GEMM forward, (I, k reversed, O) for the data gradient, ...), refreshed once
+   after the optimiser step instead of one launch per layer and pass inside the step.  `jobs` is a HOST array. */
+typedef struct s2svc_gather3_job {
+  const void* in;      /* fp32 */
+  void* out;           /* contiguous n0 x n1 x n2, out_dtype */
+  int64_t s0, s1, s2, off;
+  int32_t n0, n1, n2;
+  int32_t out_dtype;
+} s2svc_gather3_job;
+int s2svc_gather3_grouped(const s2svc_gather3_job* jobs /* host */, int n, void* stream);
 int s2svc_rowscale(int dtype, int64_t rows, int D, const void* x, const float* s, void* out, void* stream);
 
 /* ========================================================================================== */

@@ -82,6 +82,11 @@ class GemmDesc(ctypes.Structure):
                 ("cm_pt", c_i32), ("cm_pf", c_i32), ("reserved3_", c_i32)]
 
 
+class Gather3Job(ctypes.Structure):
+    _fields_ = [("in_", c_vp), ("out", c_vp), ("s0", c_i64), ("s1", c_i64), ("s2", c_i64), ("off", c_i64), ("n0", c_i32),
+                ("n1", c_i32), ("n2", c_i32), ("out_dtype", c_i32)]
+
+
 class ColreduceItem(ctypes.Structure):
     _fields_ = [("dy", c_vp), ("x", c_vp), ("mean", c_vp), ("rstd", c_vp), ("out_sum", c_vp), ("out_dot", c_vp), ("ws", c_vp),
                 ("dtype", c_i32), ("rows", c_i32), ("D", c_i32), ("mode", c_i32), ("accumulate", c_i32), ("ws_chunks", c_i32),
@@ -122,6 +127,7 @@ _SIGS = {
     "s2svc_glu_fwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp],
     "s2svc_glu_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_cast": [c_i32, c_i32, c_i64, c_vp, c_vp, c_vp],
+    "s2svc_gather3_grouped": [c_vp, c_i32, c_vp],
     "s2svc_gather3": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     "s2svc_mas": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_mas_binloss_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],

@@ -261,6 +261,30 @@ __global__ void gather3_kernel(int n0, int n1, int n2, int64_t s0, int64_t s1, i
   }
 }
 
+// several gathers of fp32 sources in ONE launch (the permuted weight copies of every convolution, refreshed after the
+// optimiser step): blockIdx.y = job; jobs travel by value in the kernel arguments
+#define S2S_GATHER_MAX 24
+struct gather_jobs {
+  s2svc_gather3_job j[S2S_GATHER_MAX];
+  int32_t n;
+};
+static_assert(sizeof(gather_jobs) <= 4096, "kernel arguments are limited to 4 KB");
+
+__global__ void gather3_grouped_kernel(const gather_jobs g) {
+  const s2svc_gather3_job& jb = g.j[blockIdx.y];
+  const int64_t n = (int64_t)jb.n0 * jb.n1 * jb.n2;
+  const float* in = (const float*)jb.in;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int i2 = (int)(i % jb.n2);
+    const int64_t t = i / jb.n2;
+    const int i1 = (int)(t % jb.n1);
+    const int i0 = (int)(t / jb.n1);
+    const float v = in[jb.off + i0 * jb.s0 + i1 * jb.s1 + i2 * jb.s2];
+    if (jb.out_dtype == S2S_F32) ((float*)jb.out)[i] = v;
+    else ((bf16_t*)jb.out)[i] = f2bf(v);
+  }
+}
+
 template <typename T>
 int launch_typed1(int dtype);
 
@@ -429,6 +453,27 @@ extern "C" int s2svc_cast(int in_dtype, int out_dtype, int64_t n, const void* x,
   else
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, st, n, (const bf16_t*)x, (bf16_t*)y);
   S2S_CHECK_LAUNCH("cast_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_gather3_grouped(const s2svc_gather3_job* jobs, int n, void* stream) {
+  S2S_REQUIRE(n >= 0 && (n == 0 || jobs), "gather3_grouped: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += S2S_GATHER_MAX) {
+    gather_jobs g;
+    g.n = (n - i0 < S2S_GATHER_MAX) ? n - i0 : S2S_GATHER_MAX;
+    int64_t most = 0;
+    for (int i = 0; i < g.n; ++i) {
+      g.j[i] = jobs[i0 + i];
+      S2S_REQUIRE(g.j[i].in && g.j[i].out && g.j[i].n0 > 0 && g.j[i].n1 > 0 && g.j[i].n2 > 0, "gather3_grouped: bad job");
+      const int64_t e = (int64_t)g.j[i].n0 * g.j[i].n1 * g.j[i].n2;
+      most = e > most ? e : most;
+    }
+    int bx = (int)((most + 255) / 256);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(gather3_grouped_kernel, dim3(bx, g.n), dim3(256), 0, st, g);
+    S2S_CHECK_LAUNCH("gather3_grouped_kernel");
+  }
   return 0;
 }
 

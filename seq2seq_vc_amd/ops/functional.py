@@ -1030,7 +1030,7 @@ class _Conv1d(Function):
         Cout, _, ks = weight.shape
         pad = (ks - 1) // 2
         dtype = x.dtype
-        wp = K.gather3(weight.detach(), (Cout, ks, Cin), (Cin * ks, 1, ks), 0, dtype)  # (O, k, I)
+        wp = K.gather3_cached(weight, (Cout, ks, Cin), (Cin * ks, 1, ks), 0, dtype)  # (O, k, I)
         y = torch.empty((B, T, Cout), dtype=dtype, device=x.device)
         K.gemm(K.operand(x, Cin, mode=K.CONV1D, C=Cin, T=T, pad=pad), K.operand(wp, ks * Cin), B * T, Cout, ks * Cin, y,
                in_dtype=dtype, bias=bias, act=act)
@@ -1052,7 +1052,7 @@ class _Conv1d(Function):
             dy = K.act_dropout_bwd(dy, y, act=ctx.act)
         dx = None
         if ctx.needs_input_grad[0]:
-            wd = K.gather3(weight.detach(), (Cin, ks, Cout), (ks, -1, Cin * ks), ks - 1, dtype)  # (I, k flipped, O)
+            wd = K.gather3_cached(weight, (Cin, ks, Cout), (ks, -1, Cin * ks), ks - 1, dtype)  # (I, k flipped, O)
             dx = torch.empty((B, T, Cin), dtype=dtype, device=x.device)
             K.gemm(K.operand(dy, Cout, mode=K.CONV1D, C=Cout, T=T, pad=pad), K.operand(wd, ks * Cout), B * T, Cin, ks * Cout, dx,
                    in_dtype=dtype)
@@ -1097,7 +1097,7 @@ class _Conv2dS2(Function):
         O = weight.shape[0]
         T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
         dtype = x.dtype
-        wp = K.gather3(weight.detach(), (O, 9, C), (C * 9, 1, 9), 0, dtype)  # (O, tap, C)
+        wp = K.gather3_cached(weight, (O, 9, C), (C * 9, 1, 9), 0, dtype)  # (O, tap, C)
         y = torch.empty((B, T2, F2, O), dtype=dtype, device=x.device)
         K.gemm(K.operand(x, C, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), K.operand(wp, 9 * C), B * T2 * F2, O, 9 * C, y,
                in_dtype=dtype, bias=bias, act="relu")
@@ -1207,7 +1207,7 @@ class _LinearPermuted(Function):
         dtype = x.dtype
         D = weight.shape[0]
         M = x.numel() // (C * Fd)
-        wp = K.gather3(weight.detach(), (D, Fd, C), (C * Fd, 1, Fd), 0, dtype)
+        wp = K.gather3_cached(weight, (D, Fd, C), (C * Fd, 1, Fd), 0, dtype)
         y = torch.empty((M, D), dtype=dtype, device=x.device)
         K.gemm(K.operand(x, C * Fd), K.operand(wp, C * Fd), M, D, C * Fd, y, in_dtype=dtype, bias=bias)
         ctx.params = (weight, bias)

@@ -527,6 +527,39 @@ def embedding_bwd(idx, dy, V, padding_idx, out=None, accumulate=False):
     return dw
 
 
+def gather3_cached(weight, n, strides, off, out_dtype):
+    """gather3 of a PARAMETER.  When optim.FlatAdam manages it, the permuted copy lives in a persistent buffer that the
+    optimiser refreshes after every update -- ONE grouped launch for all such copies of the model (gather3_refresh) instead of
+    a launch per convolution and pass on the step's dependency chain; otherwise a plain gather3 of the current values."""
+    reg = getattr(weight, "_s2s_perm_registry", None)
+    if reg is None:
+        return gather3(weight.detach(), n, strides, off, out_dtype)
+    key = (tuple(n), tuple(strides), int(off), out_dtype)
+    ent = weight._s2s_perms.get(key)
+    if ent is None:
+        buf = gather3(weight.detach(), n, strides, off, out_dtype)
+        weight._s2s_perms[key] = [buf, weight._version]
+        reg.append((weight, key, buf))
+        return buf
+    if ent[1] != weight._version:      # changed in place by torch (load_state_dict, copy_) since the copy was taken
+        _lib.check(_lib.lib().s2svc_gather3(dt(weight), _DT[out_dtype], n[0], n[1], n[2], strides[0], strides[1], strides[2], off,
+                                            ptr(weight), ptr(ent[0]), stream()), "gather3")
+        ent[1] = weight._version
+    return ent[0]
+
+
+def gather3_refresh(registry):
+    """Recompute every registered permuted copy from the current fp32 weights (one launch per 24 of them)."""
+    if not registry:
+        return
+    jobs = (_lib.Gather3Job * len(registry))()
+    for jb, (w, (n, st, off, odt), buf) in zip(jobs, registry):
+        jb.in_, jb.out = w.data_ptr(), buf.data_ptr()
+        jb.s0, jb.s1, jb.s2, jb.off = st[0], st[1], st[2], off
+        jb.n0, jb.n1, jb.n2, jb.out_dtype = n[0], n[1], n[2], _DT[odt]
+    _lib.check(_lib.lib().s2svc_gather3_grouped(ctypes.addressof(jobs), len(registry), stream()), "gather3_grouped")
+
+
 def gather3(x, n, strides, off, out_dtype):
     """out[i0,i1,i2] = x.flat[off + i0*s0 + i1*s1 + i2*s2] (contiguous result of shape n)."""
     y = torch.empty(n, dtype=out_dtype, device=x.device)

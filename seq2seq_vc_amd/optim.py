@@ -65,12 +65,14 @@ class FlatAdam:
         self.shadow = torch.zeros(n, dtype=torch.bfloat16, device=dev) if bf16_shadow else None
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)  # step, lr, grad_norm, clip_coef
         self.partial = torch.empty(1024, dtype=torch.float64, device=dev)
+        self._perm_jobs = []          # (parameter, permutation, persistent buffer): filled by ops.kernels.gather3_cached
         for p, o in zip(self.params, offs):
             k = p.numel()
             self.flat_p[o:o + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[o:o + k].view(p.shape)
             p._s2s_grad = self.flat_g[o:o + k].view(p.shape)
             p.grad = p._s2s_grad
+            p._s2s_perm_registry, p._s2s_perms = self._perm_jobs, {}
             if self.shadow is not None:
                 p._s2s_bf16 = self.shadow[o:o + k].view(p.shape)
         off_of = {id(p): o for p, o in zip(self.params, offs)}
@@ -186,11 +188,14 @@ class FlatAdam:
         self._touch()
         if self.shadow is not None:
             self.shadow.copy_(K.cast(self.flat_p, torch.bfloat16))
-            self._refresh_transposed()
+        self._refresh_transposed()
 
     def _refresh_transposed(self):
+        """Derived copies of the weights: the transposed bf16 shadow and the permuted convolution weights that the forward /
+        backward passes registered (ops.kernels.gather3_cached) -- one launch each."""
         if self.shadow_t is not None:
             K.transpose_tiles(self.t_tiles, self.shadow, self.shadow_t)
+        K.gather3_refresh(self._perm_jobs)
 
     def param_range(self, module):
         """[lo, hi) of the flat buffers covered by the parameters of `module`, or None if parameters of other modules
