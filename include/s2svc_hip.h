@@ -95,10 +95,12 @@ typedef struct {
   /*   v  = emask[m*ldm + n] > 0 ? v : 0                            -- emask has the dtype of C                     */
   /* fuses `dropout(relu(x W1^T))` into the forward GEMM and `dY W2 * dropmask * relu'(h)` into the dgrad GEMM of   */
   /* positionwise_feed_forward.py:30-32, and relu' of subsampling.py:58-60 into the dgrad of the Linear after it.  */
+  /*   emask_mode 1: v *= swish'(emask[m*ldm + n])  -- emask holds the PRE-activation of the forward pass (the data-gradient  */
+  /*   GEMM through w_2 of a Swish feed-forward block then needs no element-wise pass either)                                  */
   const void* emask;
   int64_t ldm;
   float drop_p;
-  int32_t reserved2_;
+  int32_t emask_mode;
   const uint64_t* seed_base;
   uint64_t seed_off;
   /* c_map = 1 (bf16 LDS-DMA kernels only; no res / emask / batch / split-K): GEMM row m = (b, i, j) over the class grid
@@ -107,6 +109,9 @@ typedef struct {
   int32_t c_map;
   int32_t cm_T1, cm_F1, cm_Tc, cm_Fc, cm_pt, cm_pf;
   int32_t reserved3_;
+  /* optional second output: alpha * A.B^T + bias BEFORE the activation (same dtype, ld and batch strides as C; no c_map) -- the
+     pre-activation a Swish / GELU backward pass needs, written by the GEMM whose epilogue applies activation + dropout */
+  void* c_pre;
 } s2svc_gemm_desc;
 
 int s2svc_gemm(const s2svc_gemm_desc* desc /* host */, void* stream);

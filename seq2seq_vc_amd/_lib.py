@@ -77,9 +77,9 @@ class GemmDesc(ctypes.Structure):
                 ("M", c_i32), ("N", c_i32), ("K", c_i32), ("nb0", c_i32), ("nb1", c_i32), ("act", c_i32),
                 ("alpha", c_f32), ("dtype", c_i32), ("accumulate", c_i32), ("splitk", c_i32), ("ws", c_vp),
                 ("a_rowsum", c_vp), ("a_rowsum_ws", c_vp), ("a_rowsum_accumulate", c_i32), ("tile_hint", c_i32),
-                ("emask", c_vp), ("ldm", c_i64), ("drop_p", c_f32), ("reserved2_", c_i32), ("seed_base", c_vp),
+                ("emask", c_vp), ("ldm", c_i64), ("drop_p", c_f32), ("emask_mode", c_i32), ("seed_base", c_vp),
                 ("seed_off", c_u64), ("c_map", c_i32), ("cm_T1", c_i32), ("cm_F1", c_i32), ("cm_Tc", c_i32), ("cm_Fc", c_i32),
-                ("cm_pt", c_i32), ("cm_pf", c_i32), ("reserved3_", c_i32)]
+                ("cm_pt", c_i32), ("cm_pf", c_i32), ("reserved3_", c_i32), ("c_pre", c_vp)]
 
 
 class Gather3Job(ctypes.Structure):

@@ -363,6 +363,8 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   }
   // dropout / mask stage: native in the LDS-DMA kernels' epilogue; every other kernel family gets it as a second pass
   // over C (which is only the same thing when nothing is added to C after the stage)
+  S2S_REQUIRE(!d.c_pre || !d.c_map, "s2svc_gemm: c_pre (pre-activation output) is not available with c_map");
+  S2S_REQUIRE(d.emask_mode == 0 || (d.emask_mode == 1 && d.emask), "s2svc_gemm: emask_mode 1 needs emask (the pre-activation)");
   const bool staged = d.drop_p > 0.f || d.emask != nullptr;
   S2S_REQUIRE(!staged || (d.nb0 * d.nb1 == 1 && d.ldc == d.N), "s2svc_gemm: the dropout/mask stage needs an unbatched contiguous C");
   S2S_REQUIRE(!staged || d.drop_p < 1.f, "s2svc_gemm: drop_p must be < 1");

@@ -6,7 +6,13 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-// the optional stage between activation and residual: v * dropmask(m*N + n) * (emask[m, n] > 0)
+// d swish(x) / dx from the pre-activation (the formula of act_dropout_bwd, elementwise.hip)
+__device__ __forceinline__ float swish_grad(float x) {
+  const float sg = 1.f / (1.f + expf(-x));
+  return sg * (1.f + x * (1.f - sg));
+}
+
+// the optional stage between activation and residual: v * dropmask(m*N + n) * (emask[m, n] > 0  |  swish'(emask[m, n]))
 __device__ __forceinline__ float epilogue_stage_f(const s2svc_gemm_desc& d, int m, int n, float v) {
   if (d.drop_p > 0.f) {
     const uint64_t seed = (d.seed_base ? *d.seed_base : 0ull) + d.seed_off;
@@ -15,7 +21,7 @@ __device__ __forceinline__ float epilogue_stage_f(const s2svc_gemm_desc& d, int 
   if (d.emask) {
     const int64_t mo = (int64_t)m * d.ldm + n;
     const float e = d.c_dtype == S2S_F32 ? ((const float*)d.emask)[mo] : bf2f(((const bf16_t*)d.emask)[mo]);
-    v = e > 0.f ? v : 0.f;
+    v = d.emask_mode == 1 ? v * swish_grad(e) : (e > 0.f ? v : 0.f);
   }
   return v;
 }
@@ -62,6 +68,11 @@ template <bool STAGED = false>
 __device__ __forceinline__ void epilogue_store_f(const s2svc_gemm_desc& d, int z0, int z1, int m, int n, float v) {
   v *= d.alpha;
   if (d.bias) v += d.bias[n];
+  if (d.c_pre) {
+    const int64_t po = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
+    if (d.c_dtype == S2S_F32) ((float*)d.c_pre)[po] = v;
+    else ((bf16_t*)d.c_pre)[po] = f2bf(v);
+  }
   v = act_apply(v, d.act);
   if (STAGED) v = epilogue_stage_f(d, m, n, v);
   const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (STAGED ? c_row_of(d, m) : (int64_t)m) * d.ldc + n;
@@ -90,6 +101,7 @@ __device__ __forceinline__ bool epilogue_vec_ok(const s2svc_gemm_desc& d) {
   bool ok = (d.N % 8 == 0) && (d.ldc % 8 == 0) && (d.cbs0 % 8 == 0) && (d.cbs1 % 8 == 0) && (((uintptr_t)d.C) % 16 == 0);
   if (d.res) ok = ok && (d.ldr % 8 == 0) && (d.rbs0 % 8 == 0) && (d.rbs1 % 8 == 0) && (((uintptr_t)d.res) % 16 == 0);
   if (d.emask) ok = ok && (d.ldm % 8 == 0) && (((uintptr_t)d.emask) % 16 == 0);
+  if (d.c_pre) ok = ok && (((uintptr_t)d.c_pre) % 16 == 0);
   return ok;
 }
 
@@ -143,6 +155,21 @@ __device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
     }
+    if (d.c_pre) {
+      const int64_t po = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + (int64_t)m * d.ldc + n;
+      if (d.c_dtype == S2S_F32) {
+        float* q = (float*)d.c_pre + po;
+        *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        uint4 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>((bf16_t*)d.c_pre + po) = o;
+      }
+    }
     if (d.act != S2S_ACT_NONE) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], d.act);
@@ -167,14 +194,15 @@ __device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, 
         const float4 e0 = *reinterpret_cast<const float4*>((const float*)d.emask + mo), e1 = *reinterpret_cast<const float4*>((const float*)d.emask + mo + 4);
         const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ee[e] > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = d.emask_mode == 1 ? v[e] * swish_grad(ee[e]) : (ee[e] > 0.f ? v[e] : 0.f);
       } else {
         const uint4 ev = *reinterpret_cast<const uint4*>((const bf16_t*)d.emask + mo);
         const uint32_t w[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[2 * e] = __uint_as_float(w[e] << 16) > 0.f ? v[2 * e] : 0.f;
-          v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) > 0.f ? v[2 * e + 1] : 0.f;
+          const float e0 = __uint_as_float(w[e] << 16), e1 = __uint_as_float(w[e] & 0xffff0000u);
+          v[2 * e] = d.emask_mode == 1 ? v[2 * e] * swish_grad(e0) : (e0 > 0.f ? v[2 * e] : 0.f);
+          v[2 * e + 1] = d.emask_mode == 1 ? v[2 * e + 1] * swish_grad(e1) : (e1 > 0.f ? v[2 * e + 1] : 0.f);
         }
       }
     }

@@ -242,6 +242,9 @@ class LegacyRelPositionMultiHeadedAttention(RelPositionMultiHeadedAttention):
 # ------------------------------------------------------------------------------------------------
 # feed-forward
 # ------------------------------------------------------------------------------------------------
+_FFN_SWISH_FUSED = os.environ.get("S2SVC_FFN_SWISH_FUSED", "1") != "0"      # tuning aid: 0 = linear / act_dropout / linear
+
+
 class PositionwiseFeedForward(nn.Module):
     """w_2(dropout(act(w_1 x)))  (positionwise_feed_forward.py:12-32); act 'relu' or 'swish'."""
 
@@ -255,8 +258,8 @@ class PositionwiseFeedForward(nn.Module):
     def forward(self, x, passthrough=False):
         """passthrough=True -> (y, alias of x) for a post-LN residual (Fn.linear)."""
         p = self.dropout_rate if self.training else 0.0
-        if self.activation == "relu":      # both GEMMs + dropout / relu masks in their epilogues
-            return Fn.ffn_relu(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, p, passthrough)
+        if self.activation == "relu" or (self.activation == "swish" and _FFN_SWISH_FUSED):   # activation + dropout (and their derivatives) in the GEMM epilogues
+            return Fn.ffn_act(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, self.activation, p, passthrough)
         xp = None
         if passthrough:
             h, xp = Fn.linear(x, self.w_1.weight, self.w_1.bias, passthrough=True)

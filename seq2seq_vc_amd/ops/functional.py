@@ -401,12 +401,14 @@ def linear(x, weight, bias=None, act=None, passthrough=False):
 
 
 class _FFNRelu(Function):
-    """w_2(dropout(relu(w_1 x)))  (positionwise_feed_forward.py:30-32) as two GEMMs forward and four backward: the
-    dropout mask rides in the first GEMM's epilogue, and the dgrad GEMM through w_2 applies dropmask * relu' in its
-    epilogue (h > 0 <=> relu active and kept), so no element-wise pass over the (rows, hidden) tensor remains."""
+    """w_2(dropout(act(w_1 x)))  (positionwise_feed_forward.py:30-32), act = relu (Transformer) or swish (Conformer), as two
+    GEMMs forward and four backward: activation and dropout mask ride in the first GEMM's epilogue, and the dgrad GEMM
+    through w_2 applies dropmask * act' in its epilogue -- relu: (h > 0 <=> active and kept) read off the stored output;
+    swish: swish'(u) of the pre-activation u, which the first GEMM writes as a second output -- so no element-wise pass
+    over the (rows, hidden) tensor remains."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, p, passthrough=False):
+    def forward(ctx, x, w1, b1, w2, b2, p, passthrough=False, act="relu"):
         dtype = x.dtype
         x2 = _c(x).view(-1, x.shape[-1])
         M, Kd = x2.shape
@@ -414,12 +416,13 @@ class _FFNRelu(Function):
         w1c, w2c = _wcast(w1, dtype), _wcast(w2, dtype)
         seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
         h = torch.empty((M, Hd), dtype=dtype, device=x.device)
-        K.gemm(K.operand(x2, Kd), K.operand(w1c, Kd), M, Hd, Kd, h, in_dtype=dtype, bias=b1, act="relu", drop_p=p, seed=seed)
+        u = torch.empty((M, Hd), dtype=dtype, device=x.device) if act != "relu" else None
+        K.gemm(K.operand(x2, Kd), K.operand(w1c, Kd), M, Hd, Kd, h, in_dtype=dtype, bias=b1, act=act, drop_p=p, seed=seed, pre_out=u)
         y = torch.empty((M, N), dtype=dtype, device=x.device)
         K.gemm(K.operand(h, Hd), K.operand(w2c, Hd), M, N, Hd, y, in_dtype=dtype, bias=b2)
         ctx.params = (w1, b1, w2, b2)
         ctx.meta = (p, seed, x.shape)
-        ctx.save_for_backward(x2, h, w1c, w2c)
+        ctx.save_for_backward(x2, h, w1c, w2c, u)
         if passthrough:                # (y, alias of x): see _Linear
             ctx.set_materialize_grads(False)
             return y.view(*x.shape[:-1], N), x.view_as(x)
@@ -428,8 +431,8 @@ class _FFNRelu(Function):
     @staticmethod
     def backward(ctx, dy, g_pass=None):
         if dy is None:
-            return g_pass, None, None, None, None, None, None
-        x2, h, w1c, w2c = ctx.saved_tensors
+            return g_pass, None, None, None, None, None, None, None
+        x2, h, w1c, w2c, u = ctx.saved_tensors
         w1, b1, w2, b2 = ctx.params
         p, seed, xshape = ctx.meta
         M, Kd = x2.shape
@@ -438,7 +441,8 @@ class _FFNRelu(Function):
         dy2 = _c(dy).view(M, N)
         # du = (dY W2) * dropmask * relu'(u): gradient at the pre-activation, straight out of the GEMM
         du = torch.empty((M, Hd), dtype=dtype, device=dy.device)
-        K.gemm(K.operand(dy2, N), _dgrad_operand(w2, w2c, N, Hd, dtype), M, Hd, N, du, in_dtype=dtype, emask=h, drop_p=p, seed=seed)
+        K.gemm(K.operand(dy2, N), _dgrad_operand(w2, w2c, N, Hd, dtype), M, Hd, N, du, in_dtype=dtype, emask=h if u is None else u,
+               emask_mode=0 if u is None else 1, drop_p=p, seed=seed)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
@@ -460,11 +464,16 @@ class _FFNRelu(Function):
             return (dw.view(weight.shape) if dw is not None else None), db
         dw2, db2 = wgrad(w2, b2, dy2, h, N, Hd) if w2.requires_grad else (None, None)
         dw1, db1 = wgrad(w1, b1, du, x2, Hd, Kd) if w1.requires_grad else (None, None)
-        return dx, dw1, db1, dw2, db2, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None
 
 
 def ffn_relu(x, w1, b1, w2, b2, p=0.0, passthrough=False):
-    return _FFNRelu.apply(x, w1, b1, w2, b2, p, passthrough)
+    return _FFNRelu.apply(x, w1, b1, w2, b2, p, passthrough, "relu")
+
+
+def ffn_act(x, w1, b1, w2, b2, act, p=0.0, passthrough=False):
+    """The same block with `act` in ("relu", "swish")."""
+    return _FFNRelu.apply(x, w1, b1, w2, b2, p, passthrough, act)
 
 
 class _Embedding(Function):

@@ -131,11 +131,18 @@ def pick_splitk(M, N, K, nbatch=1):
 
 def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
          ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False, a_rowsum=None,
-         a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0), c_map=None, group=None):
+         a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0), c_map=None, group=None, pre_out=None,
+         emask_mode=0):
     """C = act(alpha * A.B^T + bias) [* dropmask] [* (emask > 0)] + res   (see s2svc_gemm in include/s2svc_hip.h).
     c_map = (T1, F1, Tc, Fc, pt, pf): GEMM row (b, i, j) of the Tc x Fc class grid goes to row (b, 2i+pt, 2j+pf) of C.
-    group = list: the descriptor is appended instead of launched (launch_group() runs the list as one grid)."""
+    group = list: the descriptor is appended instead of launched (launch_group() runs the list as one grid).
+    pre_out: a tensor like `out` that receives alpha * A.B^T + bias BEFORE the activation (Swish backward needs it);
+    emask_mode = 1: the stage multiplies by swish'(emask) (emask = that pre-activation) instead of masking by emask > 0."""
     d = _lib.GemmDesc()
+    if pre_out is not None:
+        if c_map is not None or pre_out.dtype != out.dtype or pre_out.shape != out.shape or not pre_out.is_contiguous():
+            raise ValueError("gemm: pre_out must be a contiguous tensor like `out` (and no c_map)")
+        d.c_pre = pre_out.data_ptr()
     if c_map is not None:
         d.c_map = 1
         d.cm_T1, d.cm_F1, d.cm_Tc, d.cm_Fc, d.cm_pt, d.cm_pf = c_map
@@ -161,7 +168,7 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         if emask is not None:
             if emask.dtype != out.dtype:
                 raise TypeError("gemm: emask must have the output dtype")
-            d.emask, d.ldm = emask.data_ptr(), N
+            d.emask, d.ldm, d.emask_mode = emask.data_ptr(), N, int(emask_mode)
         d.drop_p, d.seed_base, d.seed_off = drop_p, seed[0], seed[1]
     if group is not None:
         d.splitk, d.ws = 1, None

@@ -209,6 +209,37 @@ def ffn_relu_fused_vs_unfused():
     lhs = ((y2 - y1).detach() * dy).sum().item()
     rhs = (xa.grad * v).sum().item()
     res.append((abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1e-6) + 1e-5, f"ffn fused dropout: <dy,Jv>={lhs:.6e} vs <J^T dy,v>={rhs:.6e}"))
+    # Swish (the Conformer feed-forward): activation + dropout in the first GEMM's epilogue with the pre-activation as a second
+    # output, swish' * dropmask in the epilogue of the data-gradient GEMM through w_2 -- against linear / act_dropout / linear,
+    # fp32 (exact-fp32 kernels + stage pass) and bf16 (LDS-DMA kernels, vectorised epilogue; M = 4096 rows takes the 8-wave kernel)
+    for dtype, (B, T, D, H), tolf, tolg in ((torch.float32, (3, 100, 64, 256), 2e-5, 2e-4), (torch.bfloat16, (16, 256, 384, 1536), 3e-2, 6e-2)):
+        Fn.set_compute_dtype(dtype)
+        try:
+            x = rnd(B, T, D, seed=11)
+            w1, b1 = rnd(H, D, seed=12, scale=0.1).requires_grad_(True), rnd(H, seed=13, scale=0.1).requires_grad_(True)
+            w2, b2 = rnd(D, H, seed=14, scale=0.05).requires_grad_(True), rnd(D, seed=15, scale=0.1).requires_grad_(True)
+            dy = rnd(B, T, D, seed=16).to(dtype)
+            for p_drop in (0.0, 0.3):
+                outs = []
+                for fused in (True, False):
+                    for t in (w1, b1, w2, b2):
+                        t.grad = None
+                    xi = x.clone().to(dtype).requires_grad_(True)
+                    K.manual_seed(7)
+                    K.reset_op_counter()
+                    if fused:
+                        y = Fn.ffn_act(xi, w1, b1, w2, b2, "swish", p_drop)
+                    else:
+                        y = Fn.linear(Fn.act_dropout(Fn.linear(xi, w1, b1), "swish", p_drop), w2, b2)
+                    y.backward(dy)
+                    outs.append([y.detach().float()] + [t.grad.detach().float().clone() for t in (xi, w1, b1, w2, b2)])
+                names = ("y", "dx", "dw1", "db1", "dw2", "db2")
+                for nm, a, b_ in zip(names, outs[0], outs[1]):
+                    scale = float(b_.abs().max())
+                    tol_ = tolf if nm == "y" else tolg
+                    res.append(check(f"ffn swish fused vs composed {str(dtype)[6:]} p={p_drop} {nm}", a, b_, torch.float32, rtol=tol_, atol=tol_ * scale))
+        finally:
+            Fn.set_compute_dtype(torch.float32)
     return res
 
 
