@@ -66,18 +66,46 @@ __global__ void adam_prepare_kernel(int nblk, const double* __restrict__ partial
   }
 }
 
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float coef, float beta1, float beta2, float eps,
+                                         float step_size, float inv_sqrt_bc2) {
+  const float gi = g * coef;
+  m = beta1 * m + (1.f - beta1) * gi;
+  v = beta2 * v + (1.f - beta2) * gi * gi;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p = p - step_size * (m / denom);
+}
+
+// 28 (+2) bytes of traffic per parameter and nothing else: four parameters per thread and iteration, every stream in 16-byte
+// accesses (n is a multiple of 4: the flat buffers are padded to 64 elements)
 __global__ void adam_update_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                    float* __restrict__ v, bf16_t* __restrict__ shadow, float beta1, float beta2, float eps,
                                    const float* __restrict__ state) {
   const float step = state[0], lr = state[1], coef = state[3];
   const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float gi = g[i] * coef;
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    const float pi = p[i] - step_size * (mi / denom);
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<const float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<const float4*>(m)[i];
+    float4 vv = reinterpret_cast<const float4*>(v)[i];
+    adam_one(pp.x, gg.x, mm.x, vv.x, coef, beta1, beta2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.y, gg.y, mm.y, vv.y, coef, beta1, beta2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.z, gg.z, mm.z, vv.z, coef, beta1, beta2, eps, step_size, inv_sqrt_bc2);
+    adam_one(pp.w, gg.w, mm.w, vv.w, coef, beta1, beta2, eps, step_size, inv_sqrt_bc2);
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    reinterpret_cast<float4*>(p)[i] = pp;
+    if (shadow) {
+      uint2 o;
+      o.x = (uint32_t)f2bf(pp.x) | ((uint32_t)f2bf(pp.y) << 16);
+      o.y = (uint32_t)f2bf(pp.z) | ((uint32_t)f2bf(pp.w) << 16);
+      reinterpret_cast<uint2*>(shadow)[i] = o;
+    }
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_one(pi, g[i], mi, vi, coef, beta1, beta2, eps, step_size, inv_sqrt_bc2);
     m[i] = mi;
     v[i] = vi;
     p[i] = pi;
@@ -99,8 +127,11 @@ extern "C" int s2svc_adam_step(int64_t n, float* params, const float* grads, flo
   S2S_CHECK_LAUNCH("sumsq_kernel");
   hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, st, nb, partial, max_norm, base_lr, warmup_steps, state);
   S2S_CHECK_LAUNCH("adam_prepare_kernel");
-  int ub = (int)((n + 255) / 256);
-  if (ub > 2048) ub = 2048;
+  S2S_REQUIRE(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 &&
+                  (!bf16_shadow || ((uintptr_t)bf16_shadow) % 8 == 0), "adam_step: 16-byte aligned buffers");
+  int ub = (int)((n / 4 + 255) / 256);
+  if (ub > 4096) ub = 4096;
+  if (ub < 1) ub = 1;
   hipLaunchKernelGGL(adam_update_kernel, dim3(ub), dim3(256), 0, st, n, params, grads, exp_avg, exp_avg_sq,
                      (bf16_t*)bf16_shadow, beta1, beta2, eps, state);
   S2S_CHECK_LAUNCH("adam_update_kernel");

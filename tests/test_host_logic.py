@@ -171,3 +171,49 @@ def test_two_rank_gloo_gradient_allreduce_is_the_mean_of_rank_gradients():
     (_, w0, g0, f0), (_, w1, g1, f1) = out
     assert torch.equal(w0, w1), "broadcast must make the weights identical"
     assert torch.allclose(f0, (g0 + g1) / 2, atol=1e-6) and torch.equal(f0, f1)
+
+
+def test_gradient_cuts_split_the_backward_pass_without_changing_it():
+    """ops.functional.GradCuts (the stage boundaries of distributed.OverlappedBackward): a cut carrying ONE tensor and a cut
+    carrying a TUPLE (residual stream + pending feed-forward output of a pre-norm layer stack, one member may be None) give the
+    gradients of the uncut graph once every stage has been resumed; above a cut nothing below it has a gradient yet."""
+    from seq2seq_vc_amd.ops import functional as Fn
+
+    torch.manual_seed(0)
+    w = [torch.randn(6, 6, requires_grad=True) for _ in range(4)]
+    x = torch.randn(5, 6)
+
+    def net():
+        h = torch.tanh(x @ w[0])
+        h = Fn.cut_point(h, "a")
+        p = torch.relu(h @ w[1])
+        h, p = Fn.cut_point((h, p), "b")
+        h = h + p
+        h2, none = Fn.cut_point((torch.sigmoid(h @ w[2]), None), "c")
+        assert none is None
+        return (h2 @ w[3]).pow(2).sum()
+
+    net().backward()
+    ref = [t.grad.clone() for t in w]
+    for t in w:
+        t.grad = None
+    cuts = Fn.GradCuts(["a", "b", "c"])
+    with Fn.grad_cuts(cuts):
+        loss = net()
+    loss.backward()
+    assert w[3].grad is not None and all(t.grad is None for t in w[:3])          # the backward pass stopped at cut "c"
+    cuts.resume("c")
+    assert w[2].grad is not None and w[1].grad is None
+    cuts.resume("b")
+    assert w[1].grad is not None and w[0].grad is None
+    cuts.resume("a")
+    for got, want in zip([t.grad for t in w], ref):
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+    for t in w:
+        t.grad = None
+    with Fn.grad_cuts(Fn.GradCuts(["b"])):                                       # cut points that are not named stay transparent
+        loss = net()
+    assert loss.requires_grad
+    net().backward()                                                              # and outside the context all of them are
+    for got, want in zip([t.grad for t in w], ref):
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
