@@ -20,7 +20,8 @@ from seq2seq_vc_amd.ops import kernels as K  # noqa: E402
 from tools.gemm_bench import bench  # noqa: E402
 
 DENSE = [("4096^3", 4096, 4096, 4096), ("8192^3", 8192, 8192, 8192), ("aas 4096x1536x1536", 4096, 1536, 1536),
-         ("aas 4096x3072x1536", 4096, 3072, 1536), ("aas 4096x1536x3072 (dgrad of pw1)", 4096, 1536, 3072),
+         ("aas 4096x3072x1536", 4096, 3072, 1536), ("aas 4096x4608x1536 (packed Q|K|V)", 4096, 4608, 1536),
+         ("aas 4096x1536x4608 (its dgrad)", 4096, 1536, 4608), ("aas 4096x1536x3072 (dgrad of pw1)", 4096, 1536, 3072),
          ("aas 4096x1536x384", 4096, 1536, 384), ("vtn 2048x1536x384", 2048, 1536, 384), ("vtn 2016x384x7296", 2016, 384, 7296)]
 
 
