@@ -88,6 +88,15 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(int B, int H, int T1, 
   }
 }
 
+// zero `bytes` bytes at p (16-byte aligned head assumed: torch allocations; byte tail handled)
+__global__ void zero_bytes_kernel(char* __restrict__ p, size_t bytes) {
+  const size_t n16 = bytes / 16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    reinterpret_cast<uint4*>(p)[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0)
+    for (size_t i = n16 * 16 + threadIdx.x; i < bytes; i += blockDim.x) p[i] = 0;
+}
+
 // dS = P * (dP*mask - sum_j P*dP*mask) ; dscores = dS*scale ; scatter of the same value into dbd
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(int B, int H, int T1, int T2, int ld, const T* __restrict__ attn,
@@ -156,10 +165,16 @@ extern "C" int s2svc_attn_softmax_bwd(int dtype, int B, int H, int T1, int T2, i
   hipStream_t st = (hipStream_t)stream;
   const size_t esz = dtype == S2S_F32 ? 4 : 2;
   if (dbd) {
-    if (hipMemsetAsync(dbd, 0, (size_t)B * H * T1 * ldb * esz, st) != hipSuccess) {
-      s2svc_set_error("attn_softmax_bwd: memset failed");
-      return -2;
-    }
+    // dbd is a scatter target: zero it with a KERNEL.  (hipMemsetAsync here became a memset node under stream capture, and a
+    // captured step replayed more than once then returned garbage in dbd on this ROCm build -- the first replay was right, eager
+    // launches were right; every gradient below the relative-position attention inherited it.)
+    const size_t bytes = (size_t)B * H * T1 * ldb * esz;
+    const size_t n16 = bytes / 16;
+    int zb = (int)((n16 + 255) / 256);
+    if (zb > 4096) zb = 4096;
+    if (zb < 1) zb = 1;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3(zb), dim3(256), 0, st, (char*)dbd, bytes);
+    S2S_CHECK_LAUNCH("zero_bytes_kernel");
   }
   dim3 grid((unsigned)((nrows + 3) / 4)), block(256);
   if (dtype == S2S_F32)

@@ -154,6 +154,8 @@ class OverlappedBackward:
         """Backward of stage i: from a loss (`loss:<key>`) or from below a cut (`cut:<name>`), then the join of the
         parameter-gradient side work, so that the stage's slice of the flat gradient buffer is final on the current stream."""
         root = self.plan[i]["root"]
+        if os.environ.get("S2SVC_STAGE_BRANCH_SYNC", "0") in ("1", "2"):
+            Fn.branch_sync()
         if root.startswith("loss:"):
             loss = losses.get(root[5:])
             if loss is not None and loss.requires_grad:
@@ -162,6 +164,8 @@ class OverlappedBackward:
         else:
             self.cuts.resume(root[4:])
         Fn.side_join()
+        if os.environ.get("S2SVC_STAGE_BRANCH_SYNC", "0") in ("1", "3"):
+            Fn.branch_sync()
 
     def begin_reduce(self, i):
         if not self.active():

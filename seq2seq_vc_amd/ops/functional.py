@@ -285,6 +285,14 @@ def branch_join(*results):
         _Branch.active = False
 
 
+def branch_sync():
+    """Order the auxiliary stream and the current stream both ways (a stage boundary of a staged backward pass)."""
+    if _Branch.stream is not None:
+        cur = torch.cuda.current_stream()
+        _Branch.stream.wait_stream(cur)
+        cur.wait_stream(_Branch.stream)
+
+
 def side_join():
     """Run what is still queued and make the current stream wait for all side-stream gradient work (call between
     backward and optimiser)."""
