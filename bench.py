@@ -564,10 +564,9 @@ def main():
 
     B = args.batch or (32 if args.workload == "vtn" else 16)
     wl = Workload(args.workload, dev, dtype, B, world, rank)
-    # Backward in stages with one all-reduce per finished stage (overlap) is the default for VTN.  For AAS-VC the stage graphs
-    # do not replay correctly yet (DESIGN.md "Open items": a multi-graph capture issue, the eager staged path the trainers use
-    # is exact) -- its data-parallel step is ONE captured graph followed by the chunked all-reduce of the whole gradient buffer.
-    staged = (dp and args.workload == "vtn") or args.split_backward
+    # Data parallel: backward in the stages of model.dp_plan(), one captured graph per stage, the all-reduce of a finished stage's
+    # slice of the flat gradient buffer issued between the replays (overlap).  N = 1 keeps one graph (the cuts cost ~0.2 ms).
+    staged = dp or args.split_backward
     step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph,
                             warmup_eager=max(2, args.warmup if args.no_graph else 2))
     dt = time_steps(step, args.steps, args.warmup, dist if dp else None, dev)

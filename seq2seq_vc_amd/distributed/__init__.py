@@ -128,7 +128,9 @@ class OverlappedBackward:
         self.model, self.opt, self.dist, self.world, self.group = model, optimizer, dist, max(1, int(world)), group
         self.force, self.chunk, self.payload = force, chunk_numel, payload
         self.plan = plan if plan is not None else model.dp_plan()
-        self.cuts = Fn.GradCuts([st["root"][4:] for st in self.plan if st["root"].startswith("cut:")])
+        roots = [r for st in self.plan for r in ([st["root"]] if isinstance(st["root"], str) else st["root"])]
+        roots += [st["branch_root"] for st in self.plan if st.get("branch_root")]
+        self.cuts = Fn.GradCuts([r[4:] for r in roots if r.startswith("cut:")])
         self.ranges = [optimizer.param_ranges(st["modules"]) for st in self.plan]
         covered = sorted(r for rs in self.ranges for r in rs)
         pos = 0
@@ -151,21 +153,32 @@ class OverlappedBackward:
         return self.world > 1 or self.force
 
     def run_stage(self, i, losses, scale=None):
-        """Backward of stage i: from a loss (`loss:<key>`) or from below a cut (`cut:<name>`), then the join of the
-        parameter-gradient side work, so that the stage's slice of the flat gradient buffer is final on the current stream."""
-        root = self.plan[i]["root"]
-        if os.environ.get("S2SVC_STAGE_BRANCH_SYNC", "0") in ("1", "2"):
-            Fn.branch_sync()
-        if root.startswith("loss:"):
-            loss = losses.get(root[5:])
+        """Backward of stage i: from a loss (`loss:<key>`) or from below a cut (`cut:<name>`) -- or from several such roots, in
+        the order given -- then the join of the parameter-gradient side work, so that the stage's slices of the flat gradient
+        buffer are final on the current stream."""
+        roots = self.plan[i]["root"]
+        branch_root = self.plan[i].get("branch_root")           # a loss whose sub-network ran on the auxiliary stream
+        fork = None
+        if branch_root is not None and torch.cuda.is_available():
+            fork = torch.cuda.Event()
+            fork.record()                                        # before this stage queues anything: the branch starts here
+        s = self.scale if scale is None else scale
+        for root in ([roots] if isinstance(roots, str) else list(roots)):
+            if root.startswith("loss:"):
+                loss = losses.get(root[5:])
+                if loss is not None and loss.requires_grad:
+                    (loss * s if s != 1.0 else loss).backward(retain_graph=Fn._RETAIN)
+            else:
+                self.cuts.resume(root[4:])
+        if branch_root is not None:
+            loss = losses.get(branch_root[5:])
             if loss is not None and loss.requires_grad:
-                s = self.scale if scale is None else scale
-                (loss * s if s != 1.0 else loss).backward(retain_graph=Fn._RETAIN)
-        else:
-            self.cuts.resume(root[4:])
+                loss = loss * s if s != 1.0 else loss
+                if fork is not None:
+                    Fn.branch_backward(loss, fork, retain_graph=Fn._RETAIN)
+                else:
+                    loss.backward(retain_graph=Fn._RETAIN)
         Fn.side_join()
-        if os.environ.get("S2SVC_STAGE_BRANCH_SYNC", "0") in ("1", "3"):
-            Fn.branch_sync()
 
     def begin_reduce(self, i):
         if not self.active():

@@ -146,19 +146,23 @@ class AASVC(nn.Module):
 
     def dp_plan(self):
         """Stages of the data-parallel backward pass (distributed.OverlappedBackward).  The decoder holds 113 M of the 157 M
-        parameters of the vc2 configuration (4 layers x 28 M at d = 1536), so it is cut layer by layer: each layer's 113 MB of
-        fp32 gradients travels while the next layer's backward pass runs.  Two loss keys: "decoder" (the L1 loss: reaches the
+        parameters of the vc2 configuration (4 layers x 28 M at d = 1536).  Two loss keys: "decoder" (the L1 loss: reaches the
         postnet / decoder / length regulator) and "align" (forward-sum + binarisation + duration losses: reach the alignment
-        module and the duration predictor); below the cut at the encoder output both meet and the encoder runs last."""
+        module and the duration predictor); below the cut at the encoder output both meet and the encoder runs last.
+        Stage 1 runs BOTH roots: "decoder" down to the cut in the middle of the stack on the calling stream, then "align" rooted
+        on the auxiliary stream (`branch_root`, ops.functional.branch_backward: the duration predictor ran there in the forward
+        pass; its backward pass starts from an event recorded before the decoder work was queued); the lower decoder layers
+        follow one per stage, the encoder last:
+        buckets 346 | 113 | 113 | 57 MB (fp32), only the last one travels with nothing to hide behind."""
         dec = list(self.decoder.encoders)
         tail = [m for m in (getattr(self.decoder, "after_norm", None), self.feat_out, self.postnet) if m is not None]
-        plan = [{"root": "loss:decoder", "modules": [dec[-1]] + tail}]
-        for li in range(len(dec) - 1, 0, -1):
-            plan.append({"root": f"cut:decoder.{li}", "modules": [dec[li - 1]]})
         side = [self.alignment_module, self.duration_predictor]
         if hasattr(self, "duration_predictor_projection"):
             side.append(self.duration_predictor_projection)
-        plan.append({"root": "loss:align", "modules": side})
+        h = max(1, len(dec) // 2)                         # layers h.. ride with the first stage
+        plan = [{"root": "loss:decoder", "branch_root": "loss:align", "modules": dec[h:] + tail + side}]
+        for li in range(h, 0, -1):
+            plan.append({"root": f"cut:decoder.{li}", "modules": [dec[li - 1]]})
         plan.append({"root": "cut:encoder_out", "modules": [self.encoder]})
         return plan
 

@@ -285,12 +285,20 @@ def branch_join(*results):
         _Branch.active = False
 
 
-def branch_sync():
-    """Order the auxiliary stream and the current stream both ways (a stage boundary of a staged backward pass)."""
-    if _Branch.stream is not None:
-        cur = torch.cuda.current_stream()
-        _Branch.stream.wait_stream(cur)
-        cur.wait_stream(_Branch.stream)
+def branch_backward(loss, fork_event, retain_graph=False):
+    """loss.backward() rooted on the auxiliary stream, which starts from `fork_event` (recorded on the calling stream BEFORE
+    other backward work was queued there).  The backward nodes of a sub-network that ran under branch_run() then start at once
+    beside that other work instead of behind it -- a root processed on the calling stream would make the auxiliary stream wait
+    for everything queued so far, and the first main-stream node behind the branch would stall the caller until the branch
+    has finished.  The caller's stream waits for the auxiliary stream before this returns."""
+    cur = torch.cuda.current_stream()
+    if _Branch.stream is None or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
+        loss.backward(retain_graph=retain_graph)
+        return
+    _Branch.stream.wait_event(fork_event)
+    with torch.cuda.stream(_Branch.stream):
+        loss.backward(retain_graph=retain_graph)
+    cur.wait_stream(_Branch.stream)
 
 
 def side_join():
