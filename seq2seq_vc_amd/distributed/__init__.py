@@ -163,14 +163,7 @@ class OverlappedBackward:
             fork = torch.cuda.Event()
             fork.record()                                        # before this stage queues anything: the branch starts here
         s = self.scale if scale is None else scale
-        for root in ([roots] if isinstance(roots, str) else list(roots)):
-            if root.startswith("loss:"):
-                loss = losses.get(root[5:])
-                if loss is not None and loss.requires_grad:
-                    (loss * s if s != 1.0 else loss).backward(retain_graph=Fn._RETAIN)
-            else:
-                self.cuts.resume(root[4:])
-        if branch_root is not None:
+        if branch_root is not None:                              # first: the calling stream is still empty
             loss = losses.get(branch_root[5:])
             if loss is not None and loss.requires_grad:
                 loss = loss * s if s != 1.0 else loss
@@ -178,7 +171,16 @@ class OverlappedBackward:
                     Fn.branch_backward(loss, fork, retain_graph=Fn._RETAIN)
                 else:
                     loss.backward(retain_graph=Fn._RETAIN)
+        for root in ([roots] if isinstance(roots, str) else list(roots)):
+            if root.startswith("loss:"):
+                loss = losses.get(root[5:])
+                if loss is not None and loss.requires_grad:
+                    (loss * s if s != 1.0 else loss).backward(retain_graph=Fn._RETAIN)
+            else:
+                self.cuts.resume(root[4:])
         Fn.side_join()
+        if fork is not None:
+            Fn.branch_wait()
 
     def begin_reduce(self, i):
         if not self.active():

@@ -149,17 +149,20 @@ class AASVC(nn.Module):
         parameters of the vc2 configuration (4 layers x 28 M at d = 1536).  Two loss keys: "decoder" (the L1 loss: reaches the
         postnet / decoder / length regulator) and "align" (forward-sum + binarisation + duration losses: reach the alignment
         module and the duration predictor); below the cut at the encoder output both meet and the encoder runs last.
-        Stage 1 runs BOTH roots: "decoder" down to the cut in the middle of the stack on the calling stream, then "align" rooted
-        on the auxiliary stream (`branch_root`, ops.functional.branch_backward: the duration predictor ran there in the forward
-        pass; its backward pass starts from an event recorded before the decoder work was queued); the lower decoder layers
-        follow one per stage, the encoder last:
-        buckets 346 | 113 | 113 | 57 MB (fp32), only the last one travels with nothing to hide behind."""
+        Stage 1 runs BOTH roots: first "align", rooted on the auxiliary stream (`branch_root`, ops.functional.branch_backward:
+        the duration branch -- input projection + predictor -- ran there in the forward pass, so its whole backward pass runs
+        there; the main stream only gets the short alignment-module part), then "decoder" down to the cut in front of the lowest
+        decoder layer(s) on the calling stream, beside it; the stage ends with the join.  The remaining decoder layers follow one
+        per stage, the encoder last:
+        buckets 460 | 113 | 57 MB (fp32), only the last one travels with nothing to hide behind."""
         dec = list(self.decoder.encoders)
         tail = [m for m in (getattr(self.decoder, "after_norm", None), self.feat_out, self.postnet) if m is not None]
         side = [self.alignment_module, self.duration_predictor]
         if hasattr(self, "duration_predictor_projection"):
             side.append(self.duration_predictor_projection)
-        h = max(1, len(dec) // 2)                         # layers h.. ride with the first stage
+        # layers h.. ride with the first stage: enough main-stream work (3 of the 4 layers of vc2: 4.6 ms) beside the duration
+        # branch's backward pass (5.5 ms of small dependent kernels on the auxiliary stream)
+        h = max(1, len(dec) // 4)
         plan = [{"root": "loss:decoder", "branch_root": "loss:align", "modules": dec[h:] + tail + side}]
         for li in range(h, 0, -1):
             plan.append({"root": f"cut:decoder.{li}", "modules": [dec[li - 1]]})
@@ -189,11 +192,19 @@ class AASVC(nn.Module):
                 hs = hs[:, : -(tmax % pr)]
             hs = hs.contiguous().view(b, tmax // pr, dim * pr)
             il = il.map(lambda v: v // pr)
-        if self.duration_predictor_use_encoder_outputs:
-            dpi = hs
-        else:
-            dpi, _ = self.duration_predictor_projection(Fn.to_compute(dp_inputs), None)
-            dpi = FA.interp_nearest(dpi, hs.shape[1])
+        Th = hs.shape[1]
+
+        def dp_input():
+            """Input of the duration predictor: the encoder output or the projection of `dp_inputs`.  The projection belongs to
+            the duration branch: in training it runs inside branch_run, so that no node of the branch's backward pass sits on
+            the main stream (where it would stall everything queued behind it until the branch has finished)."""
+            if self.duration_predictor_use_encoder_outputs:
+                return hs
+            d, _ = self.duration_predictor_projection(Fn.to_compute(dp_inputs), None)
+            return FA.interp_nearest(d, Th)
+
+        stochastic_training = (not is_inference) and self.duration_predictor_type == "stochastic"
+        dpi = None if stochastic_training else dp_input()
         olr = ol
         if dr > 1 and ys is not None:
             b, tmax, dim = ys.shape
@@ -230,7 +241,7 @@ class AASVC(nn.Module):
             if stochastic:
                 # ~330 small launches that depend on nothing the length regulator / decoder / postnet below produce: they
                 # run on the auxiliary stream beside them (forward here, backward through autograd's stream rule)
-                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dpi, il_c, w=ds) / torch.sum(tmask))
+                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dp_input(), il_c, w=ds) / torch.sum(tmask))
             else:
                 d_outs = self.duration_predictor(dpi, il_c)
                 ret["d_outs"] = torch.clamp(d_outs, max=MAX_DP_OUTPUT)

@@ -286,19 +286,24 @@ def branch_join(*results):
 
 
 def branch_backward(loss, fork_event, retain_graph=False):
-    """loss.backward() rooted on the auxiliary stream, which starts from `fork_event` (recorded on the calling stream BEFORE
-    other backward work was queued there).  The backward nodes of a sub-network that ran under branch_run() then start at once
-    beside that other work instead of behind it -- a root processed on the calling stream would make the auxiliary stream wait
-    for everything queued so far, and the first main-stream node behind the branch would stall the caller until the branch
-    has finished.  The caller's stream waits for the auxiliary stream before this returns."""
-    cur = torch.cuda.current_stream()
+    """loss.backward() rooted on the auxiliary stream, which starts from `fork_event` (recorded on the calling stream at the
+    start of a backward stage).  Call it BEFORE the stage's other roots and branch_wait() after them: the nodes of a
+    sub-network that ran under branch_run() go to the auxiliary stream, the loss arithmetic and whatever else of this root ran on
+    the calling stream goes there while it is still empty, and the other roots then queue beside the branch.  (A root processed
+    on the calling stream after other work puts its first nodes -- and with them the whole branch -- behind that work; one
+    processed there before it stalls the caller at the first node that consumes a result of the branch.)"""
     if _Branch.stream is None or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
         loss.backward(retain_graph=retain_graph)
         return
     _Branch.stream.wait_event(fork_event)
     with torch.cuda.stream(_Branch.stream):
         loss.backward(retain_graph=retain_graph)
-    cur.wait_stream(_Branch.stream)
+
+
+def branch_wait():
+    """The current stream waits for what has been queued on the auxiliary stream (end of a stage that used branch_backward)."""
+    if _Branch.stream is not None and os.environ.get("S2SVC_NO_BRANCH", "0") != "1":
+        torch.cuda.current_stream().wait_stream(_Branch.stream)
 
 
 def side_join():
