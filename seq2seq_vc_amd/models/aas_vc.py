@@ -241,7 +241,8 @@ class AASVC(nn.Module):
             if stochastic:
                 # ~330 small launches that depend on nothing the length regulator / decoder / postnet below produce: they
                 # run on the auxiliary stream beside them (forward here, backward through autograd's stream rule)
-                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dp_input(), il_c, w=ds) / torch.sum(tmask))
+                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dp_input(), il_c, w=ds) / torch.sum(tmask),
+                                               uses=(ds, tmask, hs, dp_inputs, il_c.dev))
             else:
                 d_outs = self.duration_predictor(dpi, il_c)
                 ret["d_outs"] = torch.clamp(d_outs, max=MAX_DP_OUTPUT)

@@ -258,15 +258,25 @@ class _Branch:
     active = False
 
 
-def branch_run(fn):
+def branch_run(fn, uses=()):
     """Run fn() on the auxiliary stream, after everything queued on the current stream.  Call branch_join() on the
-    current stream before anything there consumes the results."""
+    current stream before anything there consumes the results.
+    `uses`: the tensors of the CURRENT stream that fn reads (or saves for its backward pass).  They are recorded on the auxiliary
+    stream: the caching allocator hands a block back to the stream that allocated it the moment the last reference goes, and
+    the last reference to these is dropped by the branch (autograd releasing what its nodes saved) while the kernel that
+    reads them may not have run yet -- a kernel of the allocating stream queued after that point could then overwrite the block
+    under the reader.  Eager launches hide this (the reader was launched first and the GPU keeps up); in a captured graph
+    only dependencies order the two streams (seen as wrong duration-predictor gradients in the AAS-VC stage graphs: the
+    alignment search's durations `ds`, saved by the flow's backward pass, held another tensor by the time it read them)."""
     if not torch.cuda.is_available() or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
         return fn()
     main = torch.cuda.current_stream()
     if _Branch.stream is None:
         _Branch.stream = torch.cuda.Stream()
     _Branch.stream.wait_stream(main)
+    for t in uses:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(_Branch.stream)
     with torch.cuda.stream(_Branch.stream):
         out = fn()
     _Branch.active = True

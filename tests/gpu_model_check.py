@@ -555,6 +555,89 @@ def aasvc_full_size_step_is_reproducible():
 
 
 @case
+def stage_graphs_replay_equals_eager_full_size():
+    """The data-parallel step of both bench workloads at their recipe size (bench.py --force-dist: one hipGraph per stage of
+    model.dp_plan(), bf16, the shipped stream configuration): with the dropout seeds and the duration predictor's noise draw
+    re-seeded (the noise draw fixed) before every pass, five replays of the stage graphs give the gradient and the losses of the first replay BIT FOR
+    BIT, and those equal the eager run of the same stages.  (Guard for the failure of rounds 1-2 -- a memset node inside a
+    captured stage left its target dirty from the second replay on: first replay exact, later ones garbage -- and for the
+    branch / join order of OverlappedBackward.run_stage.)"""
+    import bench
+    from seq2seq_vc_amd.distributed import OverlappedBackward
+    res = []
+    dev = torch.device("cuda", torch.cuda.current_device())
+    try:
+        Fn.set_compute_dtype(torch.bfloat16)
+        for name, batch, n_side in (("vtn", 32, 4), ("aasvc", 16, 0)):
+            Fn.enable_side_streams(n_side, inline_batches=True)
+            K.manual_seed(1234)
+            wl = bench.Workload(name, dev, torch.bfloat16, batch, 1, 0)
+            if name == "aasvc":      # one fixed noise draw for the duration predictor (device-resident: valid inside the graphs too)
+                fixed = torch.randn(batch, 2, 64, generator=torch.Generator().manual_seed(5)).to(dev)
+                wl.model.duration_predictor._randn = lambda shape, device, _n=fixed: _n
+            ob = OverlappedBackward(wl.model, wl.opt, None, 1, force=True)
+            held = {}
+            n = len(ob.plan)
+
+            def stage(i):
+                if i == 0:
+                    K.reset_op_counter()
+                    K.advance_seed(dev)
+                    wl.opt.zero_grad()
+                    with ob.forward_context():
+                        held["losses"] = wl.forward()
+                ob.run_stage(i, held["losses"])
+
+            def reseed():
+                K.manual_seed(1234)
+                torch.cuda.manual_seed(77)
+
+            def result():
+                torch.cuda.synchronize()
+                return wl.opt.flat_g.clone(), wl.loss_buf.clone()
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                eager = []
+                for _ in range(2):
+                    reseed()
+                    for i in range(n):
+                        stage(i)
+                    ob.cuts.clear()
+                    eager.append(result())
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g0, l0 = eager[0]
+            res.append((torch.equal(g0, eager[1][0]) and torch.equal(l0, eager[1][1]), f"{name}: two eager passes of the {n} stages agree bit for bit"))
+            gn = float(g0.double().pow(2).sum().sqrt())
+            res.append((gn == gn and 0 < gn < 1e5, f"{name}: eager gradient norm {gn:.4f} finite, losses {[round(v, 5) for v in l0.tolist()]}"))
+            graphs = []
+            for i in range(n):
+                g = torch.cuda.CUDAGraph()
+                kw = {"pool": graphs[0].pool()} if graphs else {}
+                with torch.cuda.graph(g, **kw):
+                    stage(i)
+                graphs.append(g)
+            bad, worst = 0, 0.0
+            for rep in range(5):
+                reseed()
+                for g in graphs:
+                    g.replay()
+                gr, lr = result()
+                if not (torch.equal(gr, g0) and torch.equal(lr, l0)):
+                    bad += 1
+                    worst = max(worst, float((gr - g0).abs().max()))
+            res.append((bad == 0, f"{name}: {bad} of 5 replays of the {n} stage graphs differ from the eager pass (max gradient diff {worst:.3e})"))
+            del graphs, wl, ob, held
+            torch.cuda.empty_cache()
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
 def vtn_ragged_batches_vs_oracle_fp32():
     """Shapes the golden fixtures do not have, against the CPU oracle on fresh seeded inputs: a single utterance, lengths
     that leave one encoder frame / one decoder step, lengths that are not multiples of the subsampling (4) or the reduction
