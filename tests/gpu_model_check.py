@@ -559,7 +559,8 @@ def stage_graphs_replay_equals_eager_full_size():
     """The data-parallel step of both bench workloads at their recipe size (bench.py --force-dist: one hipGraph per stage of
     model.dp_plan(), bf16, the shipped stream configuration): with the dropout seeds and the duration predictor's noise draw
     re-seeded (the noise draw fixed) before every pass, five replays of the stage graphs give the gradient and the losses of the first replay BIT FOR
-    BIT, and those equal the eager run of the same stages.  (Guard for the failure of rounds 1-2 -- a memset node inside a
+    BIT, and those equal the eager run of the same stages; so do the one-graph step of N = 1 and the uncut eager pass; the
+    captured optimiser step equals the eager one.  (Guard for the failure of rounds 1-2 -- a memset node inside a
     captured stage left its target dirty from the second replay on: first replay exact, later ones garbage -- and for the
     branch / join order of OverlappedBackward.run_stage.)"""
     import bench
@@ -629,7 +630,64 @@ def stage_graphs_replay_equals_eager_full_size():
                     bad += 1
                     worst = max(worst, float((gr - g0).abs().max()))
             res.append((bad == 0, f"{name}: {bad} of 5 replays of the {n} stage graphs differ from the eager pass (max gradient diff {worst:.3e})"))
-            del graphs, wl, ob, held
+            del graphs
+
+            # the one-graph step of N = 1 (zero + forward + losses + backward in one capture), against the same eager pass
+            def fwd_bwd():
+                K.reset_op_counter()
+                K.advance_seed(dev)
+                wl.opt.zero_grad()
+                total = None
+                for v in wl.forward().values():
+                    total = v if total is None else total + v
+                total.backward()
+                Fn.side_join()
+
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                reseed()
+                fwd_bwd()
+                g1, l1_ = result()
+            torch.cuda.current_stream().wait_stream(side)
+            res.append((torch.equal(g1, g0) and torch.equal(l1_, l0), f"{name}: the uncut eager pass gives the gradient of the staged one bit for bit"))
+            one = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(one):
+                fwd_bwd()
+            bad = 0
+            for rep in range(3):
+                reseed()
+                one.replay()
+                gr, lr = result()
+                bad += 0 if (torch.equal(gr, g0) and torch.equal(lr, l0)) else 1
+            res.append((bad == 0, f"{name}: {bad} of 3 replays of the one-graph step differ from the eager pass"))
+            # the optimiser graph: one replay == one eager step from the same state and gradient
+            opt_t = (wl.opt.flat_p, wl.opt.exp_avg, wl.opt.exp_avg_sq, wl.opt.state)
+            opt_saved = [t.clone() for t in opt_t]
+            p_before = opt_saved[0]
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                wl.opt.step()
+                torch.cuda.synchronize()
+                p_eager = wl.opt.flat_p.clone()
+                shadow_eager = wl.opt.shadow.clone() if wl.opt.shadow is not None else None
+            torch.cuda.current_stream().wait_stream(side)
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt):
+                wl.opt.step()
+            ok_all = True
+            for rep in range(2):
+                for t, t0 in zip(opt_t, opt_saved):
+                    t.copy_(t0)
+                wl.opt.flat_g.copy_(g0)
+                wl.opt.refresh_shadow()
+                g_opt.replay()
+                torch.cuda.synchronize()
+                ok_all &= bool(torch.equal(wl.opt.flat_p, p_eager))
+                if shadow_eager is not None:
+                    ok_all &= bool(torch.equal(wl.opt.shadow, shadow_eager))
+            moved = float((p_eager - p_before).abs().max())
+            res.append((ok_all and moved > 0, f"{name}: the replayed optimiser graph gives the parameters (and bf16 shadow) of the eager step bit for bit (max update {moved:.3e})"))
+            del one, g_opt, wl, ob, held
             torch.cuda.empty_cache()
     finally:
         Fn.set_compute_dtype(torch.float32)
