@@ -20,6 +20,8 @@ class ForwardSumLoss(torch.nn.Module):
         self._cache = {}
 
     def _prior(self, il, ol, Tf, Tx, device):
+        if il.cap is not None or ol.cap is not None:   # lengths are data of a captured step: evaluate inside the graph
+            return KA.betabinom_prior(len(il.host), Tf, Tx, il.dev, ol.dev, device)
         key = (il.host, ol.host, Tf, Tx, str(device))
         if self.cache_prior and key in self._cache:
             return self._cache[key]

@@ -254,10 +254,10 @@ class AASVC(nn.Module):
         ret["before_outs"], ret["after_outs"] = before, after
         Fn.branch_join(ret.get("dur_nll"))
         ret["ds"] = ds
-        ret["ilens"] = self._lens_like(ilens, il.host)
+        ret["ilens"] = Mo.tag_lens(self._lens_like(ilens, il.host), il)
         ret["bin_loss"] = bin_loss
         ret["log_p_attn"] = log_p_attn
-        ret["olens_reduced"] = self._lens_like(olens, olr.host) if olr is not None else None
+        ret["olens_reduced"] = Mo.tag_lens(self._lens_like(olens, olr.host), olr) if olr is not None else None
         return ret
 
     @staticmethod
@@ -276,9 +276,9 @@ class AASVC(nn.Module):
                             spembs=spembs, is_inference=False)
         olens = tgt_speech_lengths
         if self.decoder_reduction_factor > 1:
-            new = [v - v % self.decoder_reduction_factor for v in ol.host]
-            olens = self._lens_like(tgt_speech_lengths, new)
-            ys = ys[:, : max(new)]
+            ol_r = ol.map(lambda v, _r=self.decoder_reduction_factor: v - v % _r)
+            olens = Mo.tag_lens(self._lens_like(tgt_speech_lengths, ol_r.host), ol_r)
+            ys = ys[:, : ol_r.max()]
         ret["olens"], ret["ys"] = olens, ys
         return ret
 

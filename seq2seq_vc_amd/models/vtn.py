@@ -70,13 +70,15 @@ class _ARSeq2Seq(nn.Module):
         if r > 1:
             if min(olens_h.host) < r:
                 raise AssertionError("Output length must be greater than or equal to reduction factor.")
-            new = [v - v % r for v in olens_h.host]
-            olens_out = olens.new_tensor(new) if isinstance(olens, torch.Tensor) else torch.tensor(new)
-            mx = max(new)
+            olens_out_h = olens_h.map(lambda v: v - v % r)
+            new = list(olens_out_h.host)
+            olens_out = Mo.tag_lens(olens.new_tensor(new) if isinstance(olens, torch.Tensor) else torch.tensor(new), olens_out_h)
+            mx = olens_out_h.max()
             ys, labels = ys[:, :mx], labels[:, :mx]
-            idx = (Mo.Lens(new, labels.device).dev.long() - 1).unsqueeze(1)
+            idx = (olens_out_h.dev.long() - 1).unsqueeze(1)
             labels = torch.scatter(labels, 1, idx, 1.0)
-        olens_in = olens.new_tensor(olens_in_h.host) if isinstance(olens, torch.Tensor) else torch.tensor(olens_in_h.host)
+        olens_in = Mo.tag_lens(olens.new_tensor(olens_in_h.host) if isinstance(olens, torch.Tensor) else torch.tensor(olens_in_h.host),
+                               olens_in_h)
         return after, before, logits, ys, labels, olens_out, olens_in
 
     def _decode_loop(self, hs, threshold, minlenratio, maxlenratio):
@@ -198,9 +200,9 @@ class VTN(_ARSeq2Seq):
         hs, hs_lens = self.encoder(Fn.to_compute(xs), il)
         hs = Fn.cut_point(hs, "encoder_out")      # data-parallel overlap: decoder-side gradients travel during the encoder's backward
         after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens)
-        ilens_ds_st = torch.tensor([((v - 2 + 1) // 2 - 2 + 1) // 2 for v in il.host],
-                                   dtype=ilens.dtype if isinstance(ilens, torch.Tensor) else torch.long,
-                                   device=ilens.device if isinstance(ilens, torch.Tensor) else "cpu")
+        il_ds = il.map(lambda v: ((v - 2 + 1) // 2 - 2 + 1) // 2)
+        ilens_ds_st = Mo.tag_lens(torch.tensor(list(il_ds.host), dtype=ilens.dtype if isinstance(ilens, torch.Tensor) else torch.long,
+                                               device=ilens.device if isinstance(ilens, torch.Tensor) else "cpu"), il_ds)
         att_ws = [self.decoder.decoders[i].src_attn.attn for i in reversed(range(len(self.decoder.decoders)))]
         return after, before, logits, ys_, labels_, olens_, (att_ws, ilens_ds_st, olens_in)
 

@@ -22,15 +22,115 @@ from .ops import kernels as K
 # lengths instead of masks
 # ------------------------------------------------------------------------------------------------
 _LENS_CACHE = {}
+_BANK = None          # the LensBank of the training step being captured / traced (trainers: config["hip_graph"])
+
+
+class LensBank:
+    """Lengths as DATA of a captured training step.  A hipGraph bakes in what the host computed while it was captured: with
+    the by-value cache below, the int32 device vectors of one batch's lengths.  While a bank is active every `Lens` gets a
+    SLOT of one persistent device buffer instead, and remembers how it was derived (a root registered by the trainer, or
+    `map` / `clamp` of another Lens).  Before a replay `refresh()` recomputes every slot on the host from the new batch's
+    root lengths -- the same lambdas, in creation order -- and ships them with ONE copy; the kernels of the graph read the
+    slots.  Host-side uses of the lengths must not differ between batches of one graph: `max()` of a banked Lens is its
+    `cap` (the padded length of the tensor it describes: the models then do not crop a batch to its longest utterance),
+    and lengths that reach a step without provenance raise instead of being baked in."""
+
+    def __init__(self, device, max_slots=96):
+        self.device = torch.device(device)
+        self.max_slots = max_slots
+        self.B = None
+        self.buf = None               # (max_slots, B) int32 on the device
+        self.entries = []             # creation order: (lens, source): source = ("root", name) | ("map", parent, fn)
+        self.roots = {}               # id(tensor the trainer registered) -> Lens
+        self.closed = False           # after the capture: no new slots
+
+    def root(self, name, source, values, cap):
+        """Register the lengths `values` (B ints) the trainer got as `source` (the very object it hands to the model)."""
+        lens = Lens.__new__(Lens)
+        lens._init_banked(self, values, cap, ("root", name))
+        self.roots[id(source)] = (source, lens)
+        return lens
+
+    def _slot(self, lens, source):
+        if self.closed:
+            raise RuntimeError("LensBank: a Lens was created after the capture of this step finished")
+        k = len(self.entries)
+        B = len(lens.host)
+        if self.buf is None:
+            self.B = B
+            self.buf = torch.zeros((self.max_slots, B), dtype=torch.int32, device=self.device)
+        if B != self.B or k >= self.max_slots:
+            raise RuntimeError(f"LensBank: {B} lengths in a bank of batch size {self.B}, or more than {self.max_slots} slots")
+        self.entries.append((lens, source))
+        if not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            self.buf[k].copy_(torch.tensor(lens.host, dtype=torch.int32))     # eager ("traced") step: the kernels run now
+        return self.buf[k]
+
+    def upload(self):
+        """Ship the host values of every slot: one copy from a FRESH pinned block (the host may run several replays ahead of the
+        device; torch's pinned allocator does not hand a block out again while a copy from it is pending)."""
+        n = len(self.entries)
+        if n:
+            stage = torch.tensor([lens.host for lens, _ in self.entries], dtype=torch.int32)
+            if self.device.type == "cuda":
+                stage = stage.pin_memory()
+            self.buf[:n].copy_(stage, non_blocking=True)
+
+    def refresh(self, root_values):
+        """root_values: name -> B ints of the new batch.  Recomputes every slot and uploads them (current stream)."""
+        host = {}
+        for k, (lens, source) in enumerate(self.entries):
+            if source[0] == "root":
+                vals = tuple(int(v) for v in root_values[source[1]])
+                if max(vals) > lens.cap:
+                    raise ValueError(f"LensBank: length {max(vals)} of '{source[1]}' exceeds the padded length {lens.cap} of this graph")
+            else:
+                vals = tuple(source[2](v) for v in host[id(source[1])])
+            host[id(lens)] = vals
+            lens.host = vals
+        self.upload()
+
+
+class lens_bank:
+    """with lens_bank(bank): ... -- Lens objects created inside belong to `bank`."""
+
+    def __init__(self, bank):
+        self.bank = bank
+
+    def __enter__(self):
+        global _BANK
+        self.prev, _BANK = _BANK, self.bank
+        return self.bank
+
+    def __exit__(self, *exc):
+        global _BANK
+        _BANK = self.prev
+
+
+def tag_lens(tensor, lens):
+    """Attach the Lens a host-side length tensor was made from (model outputs such as `olens` after the reduction-factor
+    trim): `Lens.of` returns it instead of reading the tensor's values, so the provenance survives the trip through the
+    caller (model -> trainer -> criterion)."""
+    if _BANK is not None and isinstance(tensor, torch.Tensor):
+        tensor._s2s_lens = lens
+    return tensor
 
 
 class Lens:
     """Valid lengths of a padded batch: `.host` tuple of ints, `.dev` int32 device tensor (cached by
-    value so that steady-state steps issue no H2D copies and stay hipGraph-capturable)."""
+    value so that steady-state steps issue no H2D copies and stay hipGraph-capturable; a slot of the active LensBank
+    when a training step is captured with lengths as data)."""
 
-    def __init__(self, values, device):
+    def __init__(self, values, device, _source=None, _cap=None):
+        if _BANK is not None:
+            if _source is None:
+                raise RuntimeError("Lens: lengths without provenance inside a captured training step (register them with "
+                                   "LensBank.root, derive them with Lens.map / Lens.clamp, or tag host tensors with tag_lens)")
+            self._init_banked(_BANK, values, _cap, _source)
+            return
         self.host = tuple(int(v) for v in values)
         self.device = torch.device(device)
+        self.cap = None
         key = (self.host, self.device.type, self.device.index)
         t = _LENS_CACHE.get(key)
         if t is None:
@@ -40,22 +140,38 @@ class Lens:
             _LENS_CACHE[key] = t
         self.dev = t
 
+    def _init_banked(self, bank, values, cap, source):
+        self.host = tuple(int(v) for v in values)
+        self.device = bank.device
+        self.cap = int(cap)
+        self.dev = bank._slot(self, source)
+
     @staticmethod
     def of(lens, device):
         if lens is None or isinstance(lens, Lens):
             return lens
+        if _BANK is not None:
+            tagged = getattr(lens, "_s2s_lens", None)
+            if tagged is not None:
+                return tagged
+            reg = _BANK.roots.get(id(lens))
+            if reg is not None and reg[0] is lens:
+                return reg[1]
+            raise RuntimeError("Lens.of: these lengths were not registered with the LensBank of the captured step")
         if isinstance(lens, torch.Tensor):
             lens = lens.tolist()
         return Lens(lens, device)
 
     def map(self, fn):
+        if self.cap is not None:
+            return Lens([fn(v) for v in self.host], self.device, _source=("map", self, fn), _cap=fn(self.cap))
         return Lens([fn(v) for v in self.host], self.device)
 
     def max(self):
-        return max(self.host)
+        return self.cap if self.cap is not None else max(self.host)
 
     def clamp(self, hi):
-        return Lens([min(v, hi) for v in self.host], self.device)
+        return self.map(lambda v, _hi=hi: min(v, _hi))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -53,6 +53,26 @@ class Trainer(object):
         self.log_fn = None              # optional callable(steps, dict) -- stands in for tensorboardX
         self._schedule_gradient_work()
         self._setup_data_parallel()
+        self._capture = None            # set while a staged step is being captured (trainers/graphed.py)
+        self._graphed = None
+        if self.config.get("hip_graph", False) and self.device.type == "cuda":
+            if not isinstance(self.optimizer, FlatAdam):
+                raise ValueError('config["hip_graph"] needs the fused optimiser (optim.FlatAdam)')
+            from .graphed import GraphedStep
+            self._graphed = GraphedStep(self)
+
+    # Captured steps (trainers/graphed.py): tensor field of the batch -> (its length field, padding value), None = no captured
+    # step for this trainer; _graph_regime(): whatever host-side state changes WHAT a step launches (one set of graphs each).
+    GRAPH_BATCH = None
+
+    def _graph_regime(self):
+        return ()
+
+    def _step(self, batch):
+        if self._graphed is not None:
+            self._graphed.step(batch)
+        else:
+            self._train_step(batch)
 
     # how parameter-gradient kernels are scheduled (ops/functional.py, "Side streams"): (side streams, inline batches)
     GRADIENT_WORK = (4, False)
@@ -91,7 +111,10 @@ class Trainer(object):
         total: the scalar loss (already divided by gradient_accumulate_steps); parts: the same loss split by the keys of
         model.dp_plan() (sum(parts) == total), used when the backward pass runs stage by stage."""
         if self.dp is not None:
-            self.dp.backward(parts, reduce=last_micro_step)
+            if self._capture is not None:                    # being captured stage by stage: the exchange runs between the replays
+                self._capture.staged_backward(self.dp, parts)
+            else:
+                self.dp.backward(parts, reduce=last_micro_step)
         else:
             total.backward()
             Fn.side_join()
@@ -114,7 +137,7 @@ class Trainer(object):
     def _train_epoch(self):
         n = 0
         for n, batch in enumerate(self.data_loader["train"], 1):
-            self._train_step(batch)
+            self._step(batch)
             if self.backward_steps % self.gradient_accumulate_steps > 0:
                 continue
             if self.config.get("rank", 0) == 0:
@@ -215,6 +238,8 @@ class Trainer(object):
 class ARVCTrainer(Trainer):
     """trainers/ar_vc.py:59-112: loss = l1 + bce (+ guided attention); zero_grad BEFORE backward."""
 
+    GRAPH_BATCH = {"xs": ("ilens", 0.0), "ys": ("olens", 0.0), "labels": ("olens", 1.0)}
+
     def _forward_losses(self, batch):
         dev = self.device
         xs, ys, labels = batch["xs"].to(dev), batch["ys"].to(dev), batch["labels"].to(dev)
@@ -272,6 +297,10 @@ class AASVCTrainer(Trainer):
     gradient accumulation divides the loss; zero_grad AFTER the optimiser step."""
 
     GRADIENT_WORK = (0, True)       # chip-filling kernels: batched on the issuing stream, not forked (17.6 vs 20.9 ms/step)
+    GRAPH_BATCH = {"xs": ("ilens", 0.0), "ys": ("olens", 0.0), "dp_inputs": ("dplens", 0.0)}
+
+    def _graph_regime(self):
+        return (self.steps > self.config.get("dp_train_start_steps", 0),)
 
     def _train_step(self, batch):
         dev = self.device

@@ -1,0 +1,189 @@
+"""Captured training steps for the trainers (config["hip_graph"]).
+
+The reference has no counterpart (its step is a stream of eager torch calls, trainers/ar_vc.py:59-112, trainers/aas_vc.py:56-164);
+here the eager step is bound by the host (VTN vc1: 13.5 ms eager, 4.6 ms replayed), so the trainers can replay the step
+from hipGraphs.  What a graph bakes in is kept out of it:
+
+  * shapes -- a batch is copied into static device buffers whose time axes are rounded up to a multiple of
+    config["graph_length_quantum"] (default 64 frames); one set of graphs per (regime, batch size, rounded lengths).  The
+    models then see the padded batch: they do not crop it to its longest utterance as the reference does (models/vtn.py:229-233),
+    which only BatchNorm statistics over padded frames can tell (documented deviation of this opt-in mode);
+  * lengths -- they are DATA of the graph (modules.LensBank): every length vector a kernel reads is a slot of one device buffer
+    that is recomputed on the host from the new batch's lengths and shipped with one copy before the replay;
+  * the host bookkeeping of a step (step counters, end of training) is replayed on the host.
+
+First sighting of a key: the step runs eagerly on the static buffers ("traced": same padding, same length handling) -- that
+also builds everything lazily built for these shapes.  Second sighting: capture, then replay.  Later: replay.
+With data parallelism the backward pass is captured stage by stage (distributed.OverlappedBackward) and the all-reduce of a
+finished stage is issued between the replays, as bench.py does; the optimiser step is its own graph behind the join.
+config["hip_graph"] = "trace" never captures (the eager reference of the tests for exactly this data path).
+"""
+import torch
+
+from .. import modules as Mo
+
+
+def _round_up(n, q):
+    return ((int(n) + q - 1) // q) * q
+
+
+class _Entry:
+    def __init__(self):
+        self.static, self.lens_src, self.caps = {}, {}, {}
+        self.bank = None
+        self.graphs = []          # [(graph, stage index or None)]
+        self.deltas = None
+        self.sightings = 0
+
+
+class GraphedStep:
+    def __init__(self, trainer):
+        self.t = trainer
+        self.quantum = int(trainer.config.get("graph_length_quantum", 64))
+        self.trace_only = trainer.config.get("hip_graph") == "trace"
+        self.entries = {}
+        self.stream = torch.cuda.Stream(trainer.device)
+        self.pool = torch.cuda.graph_pool_handle()     # one memory pool for the graphs of all shapes
+        if trainer.gradient_accumulate_steps != 1:
+            raise NotImplementedError('config["hip_graph"] needs gradient_accumulate_steps == 1')
+        if trainer.dist is not None and trainer.dp is None:
+            raise NotImplementedError('config["hip_graph"] with config["distributed"] needs a model with dp_plan() (staged backward)')
+
+    # -- batch -> static buffers ------------------------------------------------------------------
+    def _fields(self, batch):
+        spec = self.t.GRAPH_BATCH
+        if spec is None:
+            raise NotImplementedError(f'{type(self.t).__name__} has no captured step (config["hip_graph"])')
+        if not isinstance(batch, dict):
+            raise NotImplementedError("captured steps take the dict batches of the VC collaters")
+        return spec
+
+    def _key(self, batch, spec):
+        shapes = tuple((name, int(batch[name].shape[0]), _round_up(batch[name].shape[1], self.quantum)) + tuple(batch[name].shape[2:])
+                       for name in spec)
+        return (self.t._graph_regime(), shapes)
+
+    def _load(self, e, batch, spec):
+        dev = self.t.device
+        for name, (lname, pad) in spec.items():
+            src = batch[name]
+            T = src.shape[1]
+            Tb = _round_up(T, self.quantum)
+            st = e.static.get(name)
+            if st is None:
+                st = torch.empty((src.shape[0], Tb) + tuple(src.shape[2:]), dtype=src.dtype, device=dev)
+                e.static[name] = st
+                e.caps.setdefault(lname, Tb)
+            st[:, :T].copy_(src, non_blocking=True)
+            if Tb > T:
+                st[:, T:].fill_(pad)
+            if lname not in e.lens_src:
+                e.lens_src[lname] = torch.zeros(src.shape[0], dtype=torch.long)
+            e.lens_src[lname].copy_(torch.as_tensor(batch[lname]).to(torch.long))
+        return {**{k: v for k, v in batch.items() if k not in e.static and k not in e.lens_src}, **e.static, **e.lens_src}
+
+    def _roots(self, e, bank):
+        for lname, src in e.lens_src.items():
+            bank.root(lname, src, src.tolist(), e.caps[lname])
+
+    # -- one step -----------------------------------------------------------------------------------
+    def step(self, batch):
+        t = self.t
+        spec = self._fields(batch)
+        key = self._key(batch, spec)
+        e = self.entries.get(key)
+        if e is None:
+            e = self.entries[key] = _Entry()
+        e.sightings += 1
+        static_batch = self._load(e, batch, spec)
+        if self.trace_only or e.sightings == 1:
+            bank = Mo.LensBank(t.device)
+            with Mo.lens_bank(bank):
+                self._roots(e, bank)
+                bank.upload()
+                t._train_step(static_batch)
+            return
+        if not e.graphs:
+            self._capture(e, static_batch)
+            e.bank.upload()
+        else:
+            e.bank.refresh({lname: src.tolist() for lname, src in e.lens_src.items()})
+            t.steps += e.deltas[0]
+            t.backward_steps += e.deltas[1]
+            t._check_train_finish()
+        self._replay(e)
+
+    def _replay(self, e):
+        dp = self.t.dp
+        for g, stage in e.graphs:
+            if stage == "opt" and dp is not None:
+                dp.finish()
+            g.replay()
+            if isinstance(stage, int) and dp is not None:
+                dp.begin_reduce(stage)
+
+    # -- capture ------------------------------------------------------------------------------------
+    def _capture(self, e, static_batch):
+        t = self.t
+        e.bank = Mo.LensBank(t.device)
+        before = (t.steps, t.backward_steps)
+        mode = "thread_local" if t.dist is not None else "global"
+        torch.cuda.synchronize()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        cap = _Capture(self, e, mode)
+        t._capture = cap if t.dp is not None else None
+        try:
+            with torch.cuda.stream(self.stream), Mo.lens_bank(e.bank):
+                self._roots(e, e.bank)
+                cap.begin(None)
+                t._train_step(static_batch)
+                cap.end()
+        except BaseException:
+            import sys
+            import traceback
+            traceback.print_exc()                   # shown even if tearing the capture down takes the process with it
+            sys.stderr.flush()
+            if cap.cur is not None:                 # leave capture mode before the exception travels (a CUDAGraph destroyed
+                try:                                # while its stream is capturing aborts the process)
+                    cap.cur[0].capture_end()
+                except Exception:  # noqa: BLE001
+                    pass
+            e.graphs = []
+            raise
+        finally:
+            t._capture = None
+        torch.cuda.current_stream().wait_stream(self.stream)
+        e.bank.closed = True
+        e.deltas = (t.steps - before[0], t.backward_steps - before[1])
+
+
+class _Capture:
+    """The sequence of graphs of one step: Trainer._backward cuts it at the stage borders when the backward pass is staged."""
+
+    def __init__(self, owner, entry, mode):
+        self.owner, self.entry, self.mode = owner, entry, mode
+        self.cur = None
+
+    def begin(self, stage):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self.owner.pool, capture_error_mode=self.mode)
+        self.cur = (g, stage)
+
+    def end(self):
+        g, stage = self.cur
+        g.capture_end()
+        self.entry.graphs.append((g, stage))
+        self.cur = None
+
+    def staged_backward(self, dp, parts):
+        """forward + stage 0 close the first graph; every further stage is its own graph; what follows (the optimiser) too."""
+        n = len(dp.plan)
+        for i in range(n):
+            if i > 0:
+                self.begin(i)
+            else:
+                self.cur = (self.cur[0], 0)
+            dp.run_stage(i, parts)
+            self.end()
+        dp.cuts.clear()
+        self.begin("opt")

@@ -696,6 +696,125 @@ def stage_graphs_replay_equals_eager_full_size():
 
 
 @case
+def trainers_replay_captured_steps():
+    """config["hip_graph"] (trainers/graphed.py): ARVCTrainer (VTN) and AASVCTrainer on batches of DIFFERENT lengths and
+    contents that fall into one padded shape, plus one batch of another shape -- the trainer that replays captured graphs
+    (lengths as data of the graph: modules.LensBank) ends with the parameters of the trainer that runs the same padded
+    batches eagerly (config["hip_graph"] = "trace"), bit for bit, and logs the same losses; dropout on.  A batch that
+    already fills its padded shape gives the same step in "trace" mode as in the plain trainer (the length bank changes no
+    value).  The staged (data-parallel) capture is run with a one-rank process group."""
+    import torch.distributed as dist
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd import trainers as T
+    from seq2seq_vc_amd.optim import FlatAdam
+    res = []
+    Fn.set_compute_dtype(torch.float32)
+
+    def batches(kind, idim, odim, n, seed):
+        g = torch.Generator().manual_seed(seed)
+        out = []
+        for k in range(n):
+            B = 4
+            hi_in, hi_out = (64, 48) if k != n - 2 else (96, 80)          # the one-before-last batch has another padded shape
+            ilens = torch.randint(hi_in - 20, hi_in + 1, (B,), generator=g)
+            olens = torch.randint(hi_out - 14, hi_out + 1, (B,), generator=g)
+            if k == 0:
+                ilens[0], olens[0] = hi_in, hi_out                         # fills the padded shape
+            Ti, To = int(ilens.max()), int(olens.max())
+            xs, ys = torch.randn(B, Ti, idim, generator=g), torch.randn(B, To, odim, generator=g)
+            for b in range(B):
+                xs[b, ilens[b]:] = 0
+                ys[b, olens[b]:] = 0
+            bt = {"xs": xs, "ilens": ilens, "ys": ys, "olens": olens}
+            if kind == "vtn":
+                labels = torch.zeros(B, To)
+                for b in range(B):
+                    labels[b, olens[b] - 1:] = 1.0
+                bt["labels"] = labels
+            else:
+                bt["dp_inputs"], bt["dplens"] = xs.clone(), ilens.clone()
+            out.append(bt)
+        return out
+
+    def run(kind, mode, data, distributed=False):
+        cfg, z = load("vtn_tiny_train" if kind == "vtn" else "aasvc_tiny_train")
+        K.manual_seed(11)
+        torch.manual_seed(3)
+        model = (M.VTN if kind == "vtn" else M.AASVC)(**model_cfg(cfg))
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).train()
+        opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10)
+        conf = {"train_max_steps": len(data), "log_interval_steps": 1, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": ".",
+                "graph_length_quantum": 16}
+        if mode is not None:
+            conf["hip_graph"] = mode
+        if distributed:
+            conf["distributed"] = True
+        logs = []
+        if kind == "vtn":
+            tr = T.ARVCTrainer(0, 0, {"train": data}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None, conf, device=DEV)
+        else:
+            noise = {}
+            gen = torch.Generator().manual_seed(5)
+
+            def fixed_noise(shape, device):          # one draw per shape, made outside any capture (first sighting is eager)
+                if tuple(shape) not in noise:
+                    noise[tuple(shape)] = torch.randn(shape, generator=gen).to(device)
+                return noise[tuple(shape)]
+
+            model.duration_predictor._randn = fixed_noise
+            conf.update({"criterions": ["L1Loss", "ForwardSumLoss", "StochasticDurationPredictorLoss"], "lambda_align": 2.0,
+                         "dp_train_start_steps": 0})
+            tr = T.AASVCTrainer(0, 0, {"train": data}, None, model, None, {"L1Loss": L.L1Loss(), "ForwardSumLoss": L.ForwardSumLoss()},
+                                opt, None, conf, device=DEV)
+        tr.log_fn = lambda step, d: logs.append(dict(d))
+        tr.run()
+        torch.cuda.synchronize()
+        n_graphs = 0 if tr._graphed is None else sum(len(e.graphs) for e in tr._graphed.entries.values())
+        return opt.flat_p.detach().clone(), logs, tr.steps, n_graphs
+
+    try:
+        for kind in ("vtn", "aasvc"):
+            cfg, z = load("vtn_tiny_train" if kind == "vtn" else "aasvc_tiny_train")
+            mc = model_cfg(cfg)
+            idim, odim = mc["idim"], mc["odim"]
+            Fn.enable_side_streams(*((4, False) if kind == "vtn" else (0, True)))
+            data = batches(kind, idim, odim, 7, 21 if kind == "vtn" else 22)
+            p_t, l_t, s_t, _ = run(kind, "trace", data)
+            p_g, l_g, s_g, n_g = run(kind, True, data)
+            res.append((s_t == s_g == len(data) and n_g >= 1, f"{kind}: {s_g} steps, {n_g} captured graph(s), {len(data) - 3} replays"))
+            res.append((torch.equal(p_t, p_g), f"{kind}: parameters after {len(data)} steps, replayed vs traced eager: max diff {float((p_t - p_g).abs().max()):.3e}"))
+            same_logs = all(abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(a[k])) for a, b in zip(l_t, l_g) for k in a)
+            res.append((same_logs and len(l_t) == len(l_g), f"{kind}: logged losses agree step by step ({[round(v, 4) for v in l_g[-1].values()]})"))
+            finite = all(v == v and abs(v) < 1e4 for d in l_g for v in d.values())
+            res.append((finite, f"{kind}: losses finite"))
+            # a batch that fills its padded shape: trace mode == plain trainer
+            full = [data[0]] * 2
+            p_a, l_a, _, _ = run(kind, None, full)
+            p_b, l_b, _, _ = run(kind, "trace", full)
+            res.append((torch.equal(p_a, p_b), f"{kind}: full-shape batch, plain vs traced trainer: max diff {float((p_a - p_b).abs().max()):.3e}"))
+        # staged capture (the data-parallel path) with a one-rank group
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
+        try:
+            for kind in ("vtn", "aasvc"):
+                cfg, z = load("vtn_tiny_train" if kind == "vtn" else "aasvc_tiny_train")
+                mc = model_cfg(cfg)
+                Fn.enable_side_streams(*((4, False) if kind == "vtn" else (0, True)))
+                data = batches(kind, mc["idim"], mc["odim"], 6, 31)
+                p_t, l_t, _, _ = run(kind, "trace", data, distributed=True)
+                p_g, l_g, _, n_g = run(kind, True, data, distributed=True)
+                res.append((torch.equal(p_t, p_g) and n_g >= 3, f"{kind}: staged capture ({n_g} graphs), replayed vs traced eager: max diff {float((p_t - p_g).abs().max()):.3e}"))
+        finally:
+            dist.destroy_process_group()
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
 def vtn_ragged_batches_vs_oracle_fp32():
     """Shapes the golden fixtures do not have, against the CPU oracle on fresh seeded inputs: a single utterance, lengths
     that leave one encoder frame / one decoder step, lengths that are not multiples of the subsampling (4) or the reduction
