@@ -22,6 +22,7 @@ python bench.py --workload aasvc --force-dist --no-cpu-baseline > "$OUT/bench_aa
 python tools/gemm_bench.py > "$OUT/gemm_bench.txt" 2>&1
 python tools/gemm8_bench.py > "$OUT/gemm8_bench.txt" 2>&1
 python tools/bench_frontend.py --cpu > "$OUT/bench_frontend.json" 2>> "$OUT/bench.err"
+(python tools/bench_trainer.py --workload vtn | tail -1; python tools/bench_trainer.py --workload aasvc --steps 40 | tail -1) > "$OUT/bench_trainer.json" 2>> "$OUT/bench.err"
 
 # per-kernel statistics + one-step timelines of the three workloads
 prof /tmp/prof_step --kernel-trace --stats -d /tmp/prof_step -o vtn -- python "$R/bench.py" --no-cpu-baseline --no-extras --steps 24 --warmup 3
