@@ -217,3 +217,39 @@ def test_gradient_cuts_split_the_backward_pass_without_changing_it():
     net().backward()                                                              # and outside the context all of them are
     for got, want in zip([t.grad for t in w], ref):
         assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
+def test_lens_bank_keeps_lengths_out_of_a_captured_step():
+    """modules.LensBank (captured trainer steps): every Lens made while a bank is active is a slot of one buffer and
+    remembers its derivation; refresh() recomputes all slots from new root lengths; max() is the padded length; lengths
+    without provenance raise; host tensors tagged with their Lens come back as that Lens."""
+    import pytest
+    from seq2seq_vc_amd import modules as Mo
+    plain = Mo.Lens([3, 5], "cpu")
+    assert plain.max() == 5 and plain.cap is None and plain.map(lambda v: v // 2).host == (1, 2) and plain.clamp(4).host == (3, 4)
+    bank = Mo.LensBank("cpu")
+    src, other = torch.tensor([3, 5]), torch.tensor([3, 5])
+    with Mo.lens_bank(bank):
+        root = bank.root("ilens", src, src.tolist(), cap=8)
+        assert Mo.Lens.of(src, "cpu") is root                      # the very object the trainer registered
+        with pytest.raises(RuntimeError):
+            Mo.Lens.of(other, "cpu")                               # equal values, no provenance
+        with pytest.raises(RuntimeError):
+            Mo.Lens([3, 5], "cpu")
+        half = root.map(lambda v: v // 2)
+        sub = half.map(lambda v: min((v + 3) // 4, 2))
+        cl = half.clamp(1)
+        assert (half.host, half.cap, half.max()) == ((1, 2), 4, 4) and sub.cap == 1 and cl.host == (1, 1)
+        tagged = Mo.tag_lens(torch.tensor(list(half.host)), half)
+        assert Mo.Lens.of(tagged, "cpu") is half
+    assert Mo.Lens.of(other, "cpu").host == (3, 5)                 # outside the bank: by value, as before
+    bank.upload()
+    assert bank.buf[:4].tolist() == [[3, 5], [1, 2], [1, 1], [1, 1]]
+    assert half.dev.data_ptr() == bank.buf[1].data_ptr()           # the kernels read the slot
+    bank.refresh({"ilens": [8, 2]})
+    assert bank.buf[:4].tolist() == [[8, 2], [4, 1], [1, 1], [1, 1]] and half.host == (4, 1)
+    with pytest.raises(ValueError):
+        bank.refresh({"ilens": [9, 2]})                            # longer than the padded length of this graph
+    bank.closed = True
+    with Mo.lens_bank(bank), pytest.raises(RuntimeError):
+        root.map(lambda v: v)
