@@ -1,6 +1,9 @@
 """One rank of a data-parallel trainer run (spawned by gpu_model_check.dp_trainers_two_ranks).
 
-    python tests/dp_worker.py <vtn|aasvc> <rank> <world> <port> <out.pt> [payload]
+    python tests/dp_worker.py <vtn|aasvc> <rank> <world> <port> <out.pt> [payload] [none|trace|graph]
+
+The last argument runs the trainer with config["hip_graph"] ("trace": the eager reference of the captured step, "graph":
+stage graphs replayed with the all-reduces between them; trainers/graphed.py), 5 steps through Trainer._step.
 
 Both ranks share the one GPU of the box and talk over gloo (RCCL refuses two ranks on one device); the product code path
 is the same one RCCL runs on a multi-GPU node: Trainer(config["distributed"]) -> broadcast of rank 0's parameters ->
@@ -67,6 +70,7 @@ def build(kind, z, cfg, perturb=False):
 def main():
     kind, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     payload = sys.argv[6] if len(sys.argv) > 6 else "fp32"
+    graph_mode = sys.argv[7] if len(sys.argv) > 7 else "none"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     import gpu_model_check as mc
@@ -81,19 +85,36 @@ def main():
     cfg, z = mc.load("vtn_tiny_train" if kind == "vtn" else "aasvc_tiny_train")
     model, crit, conf = build(kind, z, cfg, perturb=(rank != 0))
     conf = dict(conf, distributed=True, rank=rank, dp_grad_payload=payload)
+    if graph_mode != "none":
+        conf.update(hip_graph=(True if graph_mode == "graph" else "trace"), graph_length_quantum=8)
     opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10)
     batch, sl = shares(kind, z, rank, world)
     cls = T.ARVCTrainer if kind == "vtn" else T.AASVCTrainer
-    tr = cls(0, 0, {"train": [batch] * 4}, None, model, None, crit, opt, None, conf, device="cuda")
+    tr = cls(0, 0, {"train": [batch] * 6}, None, model, None, crit, opt, None, conf, device="cuda")
     logs = []
     tr.log_fn = lambda step, d: logs.append(dict(d))
-    for _ in range(3):
-        set_noise(kind, model, z, cfg, batch, sl)
-        tr._train_step(batch)
-        tr._check_log_interval()
+    if graph_mode != "none":
+        if kind == "aasvc":          # one fixed draw per shape, device-resident (the injected draw is consumed by a host copy)
+            noise, gen = {}, torch.Generator().manual_seed(5)
+
+            def fixed_noise(shape, device):
+                if tuple(shape) not in noise:
+                    noise[tuple(shape)] = torch.randn(shape, generator=gen).to(device)
+                return noise[tuple(shape)]
+
+            model.duration_predictor._randn = fixed_noise
+        for _ in range(5):
+            tr._step(batch)
+            tr._check_log_interval()
+    else:
+        for _ in range(3):
+            set_noise(kind, model, z, cfg, batch, sl)
+            tr._train_step(batch)
+            tr._check_log_interval()
     torch.cuda.synchronize()
     torch.save({"flat_p": opt.flat_p.detach().cpu(), "buffers": {k: v.detach().cpu() for k, v in model.named_buffers()},
-                "logs": logs, "stages": len(tr.dp.plan) if tr.dp is not None else 0,
+                "logs": logs, "stages": len(tr.dp.plan) if tr.dp is not None else 0, "steps": tr.steps,
+                "graphs": 0 if tr._graphed is None else sum(len(e.graphs) for e in tr._graphed.entries.values()),
                 "bucket_bytes": tr.dp.bucket_bytes() if tr.dp is not None else []}, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -1555,6 +1555,51 @@ def dp_trainers_two_ranks():
         Fn.enable_side_streams(0)
 
 
+def _dp_two_ranks_run(kind, mode, port):
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = [os.path.join(tmp, f"r{r}.pt") for r in range(2)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py"), kind, str(r), "2", str(port), outs[r], "fp32", mode],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        logs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=600)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                o, _ = p.communicate()
+            logs.append(o.decode(errors="replace")[-1500:])
+        if not (all(p.returncode == 0 for p in procs) and all(os.path.exists(o) for o in outs)):
+            return None, "\n---\n".join(logs)
+        return [torch.load(o) for o in outs], ""
+
+
+@case
+def dp_trainers_two_ranks_captured_steps():
+    """The data-parallel trainers with config["hip_graph"], 2 ranks (two processes on this GPU over gloo): stage graphs replayed
+    with the all-reduce of every finished stage issued between the replays == the same run with the stages launched eagerly
+    ("trace"), bit for bit, and both ranks hold identical parameters."""
+    res = []
+    base = 29300 + (os.getpid() % 150) * 4
+    for j, kind in enumerate(("vtn", "aasvc")):
+        tr, err = _dp_two_ranks_run(kind, "trace", base + 2 * j)
+        gr, err2 = _dp_two_ranks_run(kind, "graph", base + 2 * j + 1)
+        ok = tr is not None and gr is not None
+        res.append((ok, f"dp+graph[{kind}] all four rank processes finished" + ("" if ok else ":\n" + err + err2)))
+        if not ok:
+            continue
+        res.append((bool(torch.equal(gr[0]["flat_p"], gr[1]["flat_p"])), f"dp+graph[{kind}] ranks hold identical parameters after {gr[0]['steps']} steps "
+                    f"({gr[0]['graphs']} graphs per rank, {gr[0]['stages']} stages)"))
+        d = float((gr[0]["flat_p"] - tr[0]["flat_p"]).abs().max())
+        res.append((bool(torch.equal(gr[0]["flat_p"], tr[0]["flat_p"])) and gr[0]["graphs"] >= gr[0]["stages"] + 1,
+                    f"dp+graph[{kind}] replayed stage graphs == eager stages: max diff {d:.3e}"))
+        same_logs = all(abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(a[k])) for a, b in zip(tr[0]["logs"], gr[0]["logs"]) for k in a)
+        res.append((same_logs and len(gr[0]["logs"]) == 5, f"dp+graph[{kind}] rank-0 logs agree over 5 steps"))
+    return res
+
+
 @case
 def dp_trainer_bf16_payload():
     """The same AAS-VC run with the gradient exchange in bf16 (half the bytes on the links): parameters stay within bf16
