@@ -48,7 +48,7 @@ class TransformerTTS(_ARSeq2Seq):
         if ol.max() != ys.shape[1]:
             ys, labels = ys[:, : ol.max()], labels[:, : ol.max()]
         xs = TF.pad(xs, [0, 1], "constant", self.padding_idx)           # transformer_tts.py:139-142: append <eos>
-        xs[torch.arange(xs.shape[0], device=xs.device), il.dev.long()] = self.eos
+        xs = xs.scatter(1, il.dev.long().unsqueeze(1), self.eos)        # (no host round trip: capturable in a hipGraph)
         il1 = il.map(lambda v: v + 1)
         hs, hs_lens = self.encoder(xs, il1)
         hs = Fn.cut_point(hs, "encoder_out")
@@ -61,7 +61,7 @@ class TransformerTTS(_ARSeq2Seq):
                 if idx + 1 == self.num_layers_applied_guided_attn:
                     break
             att_ws = torch.cat(att_ws, dim=1)
-        ilens_out = (ilens + 1) if isinstance(ilens, torch.Tensor) else torch.tensor(il1.host)
+        ilens_out = Mo.tag_lens((ilens + 1) if isinstance(ilens, torch.Tensor) else torch.tensor(il1.host), il1)
         return after, before, logits, ys_, labels_, olens_, (att_ws, ilens_out, olens_in)
 
     @torch.no_grad()

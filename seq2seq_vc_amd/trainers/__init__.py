@@ -68,6 +68,11 @@ class Trainer(object):
     def _graph_regime(self):
         return ()
 
+    def _batch_dict(self, batch):
+        if not isinstance(batch, dict):
+            raise NotImplementedError(f"{type(self).__name__}: captured steps take dict batches")
+        return batch
+
     def _step(self, batch):
         if self._graphed is not None:
             self._graphed.step(batch)
@@ -285,11 +290,14 @@ class ARVCTrainer(Trainer):
 class ARTTSTrainer(ARVCTrainer):
     """trainers/ar_tts.py:45-100: identical composition; the TTS collater yields a tuple."""
 
-    def _forward_losses(self, batch):
+    def _batch_dict(self, batch):
         if not isinstance(batch, dict):
             xs, ilens, ys, labels, olens = batch[:5]
             batch = {"xs": xs, "ilens": ilens, "ys": ys, "labels": labels, "olens": olens}
-        return super()._forward_losses(batch)
+        return batch
+
+    def _forward_losses(self, batch):
+        return super()._forward_losses(self._batch_dict(batch))
 
 
 class AASVCTrainer(Trainer):

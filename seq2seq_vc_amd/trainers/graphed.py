@@ -54,8 +54,6 @@ class GraphedStep:
         spec = self.t.GRAPH_BATCH
         if spec is None:
             raise NotImplementedError(f'{type(self.t).__name__} has no captured step (config["hip_graph"])')
-        if not isinstance(batch, dict):
-            raise NotImplementedError("captured steps take the dict batches of the VC collaters")
         return spec
 
     def _key(self, batch, spec):
@@ -90,6 +88,7 @@ class GraphedStep:
     def step(self, batch):
         t = self.t
         spec = self._fields(batch)
+        batch = t._batch_dict(batch)
         key = self._key(batch, spec)
         e = self.entries.get(key)
         if e is None:

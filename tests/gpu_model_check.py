@@ -697,7 +697,7 @@ def stage_graphs_replay_equals_eager_full_size():
 
 @case
 def trainers_replay_captured_steps():
-    """config["hip_graph"] (trainers/graphed.py): ARVCTrainer (VTN) and AASVCTrainer on batches of DIFFERENT lengths and
+    """config["hip_graph"] (trainers/graphed.py): ARVCTrainer (VTN), ARTTSTrainer (tuple batches of token ids) and AASVCTrainer on batches of DIFFERENT lengths and
     contents that fall into one padded shape, plus one batch of another shape -- the trainer that replays captured graphs
     (lengths as data of the graph: modules.LensBank) ends with the parameters of the trainer that runs the same padded
     batches eagerly (config["hip_graph"] = "trace"), bit for bit, and logs the same losses; dropout on.  A batch that
@@ -723,10 +723,18 @@ def trainers_replay_captured_steps():
                 ilens[0], olens[0] = hi_in, hi_out                         # fills the padded shape
             Ti, To = int(ilens.max()), int(olens.max())
             xs, ys = torch.randn(B, Ti, idim, generator=g), torch.randn(B, To, odim, generator=g)
+            if kind == "tts":                                              # token ids, 0 = padding; the collater yields a tuple
+                xs = torch.randint(1, idim - 1, (B, Ti), generator=g)
             for b in range(B):
                 xs[b, ilens[b]:] = 0
                 ys[b, olens[b]:] = 0
             bt = {"xs": xs, "ilens": ilens, "ys": ys, "olens": olens}
+            if kind == "tts":
+                labels = torch.zeros(B, To)
+                for b in range(B):
+                    labels[b, olens[b] - 1:] = 1.0
+                out.append((xs, ilens, ys, labels, olens))
+                continue
             if kind == "vtn":
                 labels = torch.zeros(B, To)
                 for b in range(B):
@@ -738,10 +746,10 @@ def trainers_replay_captured_steps():
         return out
 
     def run(kind, mode, data, distributed=False):
-        cfg, z = load("vtn_tiny_train" if kind == "vtn" else "aasvc_tiny_train")
+        cfg, z = load({"vtn": "vtn_tiny_train", "tts": "tts_tiny_train", "aasvc": "aasvc_tiny_train"}[kind])
         K.manual_seed(11)
         torch.manual_seed(3)
-        model = (M.VTN if kind == "vtn" else M.AASVC)(**model_cfg(cfg))
+        model = {"vtn": M.VTN, "tts": M.TransformerTTS, "aasvc": M.AASVC}[kind](**model_cfg(cfg))
         model.load_state_dict(sd_of(z))
         model.to(DEV).train()
         opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10)
@@ -754,6 +762,8 @@ def trainers_replay_captured_steps():
         logs = []
         if kind == "vtn":
             tr = T.ARVCTrainer(0, 0, {"train": data}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None, conf, device=DEV)
+        elif kind == "tts":
+            tr = T.ARTTSTrainer(0, 0, {"train": data}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None, conf, device=DEV)
         else:
             noise = {}
             gen = torch.Generator().manual_seed(5)
@@ -775,12 +785,12 @@ def trainers_replay_captured_steps():
         return opt.flat_p.detach().clone(), logs, tr.steps, n_graphs
 
     try:
-        for kind in ("vtn", "aasvc"):
-            cfg, z = load("vtn_tiny_train" if kind == "vtn" else "aasvc_tiny_train")
+        for kind in ("vtn", "tts", "aasvc"):
+            cfg, z = load({"vtn": "vtn_tiny_train", "tts": "tts_tiny_train", "aasvc": "aasvc_tiny_train"}[kind])
             mc = model_cfg(cfg)
             idim, odim = mc["idim"], mc["odim"]
-            Fn.enable_side_streams(*((4, False) if kind == "vtn" else (0, True)))
-            data = batches(kind, idim, odim, 7, 21 if kind == "vtn" else 22)
+            Fn.enable_side_streams(*((0, True) if kind == "aasvc" else (4, False)))
+            data = batches(kind, idim, odim, 7, {"vtn": 21, "tts": 23, "aasvc": 22}[kind])
             p_t, l_t, s_t, _ = run(kind, "trace", data)
             p_g, l_g, s_g, n_g = run(kind, True, data)
             res.append((s_t == s_g == len(data) and n_g >= 1, f"{kind}: {s_g} steps, {n_g} captured graph(s), {len(data) - 3} replays"))
