@@ -509,6 +509,26 @@ def bench_decode(dev, dtype, batch=16, iters=5, poll=32, cpu=True):
 
 
 # =====================================================================================================================
+def bench_product_trainer(dev, dtype, steps=40):
+    """The same VTN step through the PRODUCT trainer (seq2seq_vc_amd.trainers.ARVCTrainer) on host batches whose lengths differ
+    from batch to batch: eager launches against config["hip_graph"] (captured steps, lengths as data of the graph).  The
+    host-to-device copy of every batch is inside the timed region (tools/bench_trainer.py)."""
+    from tools import bench_trainer as BT
+    try:
+        data = BT.make_batches("vtn", steps + 6, 32)
+        res = [BT.run("vtn", mode, data, dtype, dev) for mode in (False, True)]
+        return {"workload": "ARVCTrainer, VTN vc1, B = 32, lengths vary per batch, H2D inside",
+                "eager_ms_per_step": res[0]["ms_per_step"], "hip_graph_ms_per_step": res[1]["ms_per_step"],
+                "hip_graph_mel_frames_per_s": res[1]["mel_frames_per_s"], "steps": res[1]["steps"]}
+    finally:
+        Fn_reset()
+
+
+def Fn_reset():
+    from seq2seq_vc_amd.ops import functional as Fn
+    Fn.enable_side_streams(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -605,6 +625,7 @@ def main():
             out["aasvc"] = bench_aasvc_single(dev, dtype, cpu=not args.no_cpu_baseline)
             Fn.enable_side_streams(0)
             out["decode"] = bench_decode(dev, dtype, cpu=not args.no_cpu_baseline)
+            out["trainer"] = bench_product_trainer(dev, dtype)
         # RCCL writes its version banner to the C-level stdout; flush that buffer first so the JSON line stays the last line
         sys.stdout.flush()
         try:
