@@ -129,10 +129,10 @@ extern "C" int s2svc_adam_step(int64_t n, float* params, const float* grads, flo
   S2S_CHECK_LAUNCH("adam_prepare_kernel");
   S2S_REQUIRE(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0 &&
                   (!bf16_shadow || ((uintptr_t)bf16_shadow) % 8 == 0), "adam_step: 16-byte aligned buffers");
-  int ub = (int)((n / 4 + 255) / 256);
-  if (ub > 4096) ub = 4096;
-  if (ub < 1) ub = 1;
-  hipLaunchKernelGGL(adam_update_kernel, dim3(ub), dim3(256), 0, st, n, params, grads, exp_avg, exp_avg_sq,
+  // one thread per four parameters, no grid-stride cap: measured on 157.5 M / 30.5 M parameters (sumsq + prepare + update,
+  // one box) 1017 / 183 us against 1150 / 190 with 4096 blocks striding and 1085 / 199 for the one-parameter-per-thread form
+  const int64_t ub = (n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1;
+  hipLaunchKernelGGL(adam_update_kernel, dim3((unsigned)ub), dim3(256), 0, st, n, params, grads, exp_avg, exp_avg_sq,
                      (bf16_t*)bf16_shadow, beta1, beta2, eps, state);
   S2S_CHECK_LAUNCH("adam_update_kernel");
   return 0;
