@@ -59,12 +59,17 @@ __device__ __forceinline__ int p8_off(int r, int c) { return r * 128 + ((c ^ ((r
 // The scalar part of a source address: byte offset of K tile kt from the operand's base (added to the uniform base pointer).
 template <int KIND>
 struct P8Walk {
-  int kt, c0, kh, kw;       // conv2d: K tile kt starts at channel c0 of tap (kh, kw); walked, no division in the loop
+  // conv2d: K tile kt covers channels c0 .. c0+63 of tap (kh, kw); walked, no division in the loop.  The walk runs over the
+  // 9 TAPS of one 64-channel slice before it moves to the next slice (k = tap * C + c is only the storage order of the weight
+  // rows): the taps of a slice re-read the same input pixels (each is under 9/4 windows), 9 K tiles apart instead of C/64 * 9
+  // -- a 512-row tile then re-touches 150 KB, not 1.6 MB, and the re-reads stay in the XCD's L2 instead of going to the
+  // fabric (HBM-side traffic of the VTN front-end GEMM: 2.2 x -> see profiles/roofline_pmc.json).
+  int kt, c0, kh, kw;
   __device__ __forceinline__ void init(const s2svc_operand& o, int kt0) {
     kt = kt0;
     if (KIND == P8_CONV2D) {
-      const int k0 = kt0 * 64, tap = k0 / o.C;
-      c0 = k0 - tap * o.C;
+      const int cs = kt0 / 9, tap = kt0 - cs * 9;
+      c0 = cs * 64;
       kh = tap / 3;
       kw = tap - kh * 3;
     }
@@ -73,13 +78,20 @@ struct P8Walk {
     if (KIND == P8_CONV2D) return ((int64_t)(kh * o.F1 + kw) * o.ld + c0) * 2;
     return (int64_t)kt * 128;
   }
+  // the same K tile of the dense B operand (rows of K = 9 * C elements, k = tap * C + c)
+  __device__ __forceinline__ int64_t off_bytes_b(const s2svc_operand& o) const {
+    if (KIND == P8_CONV2D) return ((int64_t)(kh * 3 + kw) * o.C + c0) * 2;
+    return (int64_t)kt * 128;
+  }
   __device__ __forceinline__ void next(const s2svc_operand& o) {
     ++kt;
     if (KIND == P8_CONV2D) {
-      c0 += 64;
-      if (c0 >= o.C) {
-        c0 = 0;
-        if (++kw == 3) { kw = 0; ++kh; }
+      if (++kw == 3) {
+        kw = 0;
+        if (++kh == 3) {
+          kh = 0;
+          c0 += 64;
+        }
       }
     }
   }
@@ -203,8 +215,9 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  P8Walk<KA> wa;          // K tile of the next A unit to issue
+  P8Walk<KA> wa, wb;      // K tile of the next A unit to issue (t + 2 in the loop); wb: one behind (B.n0 of tile t + 1)
   wa.init(d.A, 0);
+  wb.init(d.A, 0);
   // prologue: tile 0 complete, tile 1 without B.n0 (issued in phase 1 of tile 0)
   {
     const char* a0 = Ab + wa.off_bytes(d.A);
@@ -213,9 +226,10 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
     p8_issue<NIB>(Bb, offB[1], smem + OB1, wave);
     p8_issue<NIA>(a0, offA[1], smem + OA1, wave);
     wa.next(d.A);
+    wb.next(d.A);
     const bool has1 = nt > 1;
     const char* a1 = has1 ? Ab + wa.off_bytes(d.A) : nullptr;
-    const char* b1 = has1 ? Bb + 128 : nullptr;
+    const char* b1 = has1 ? Bb + wa.off_bytes_b(d.A) : nullptr;
     p8_issue<NIA>(a1, offA[0], smem + BUF + OA0, wave);
     p8_issue<NIB>(b1, offB[1], smem + BUF + OB1, wave);
     p8_issue<NIA>(a1, offA[1], smem + BUF + OA1, wave);
@@ -230,8 +244,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
     char* cur = smem + (t & 1) * BUF;
     char* oth = smem + ((t & 1) ^ 1) * BUF;
     const char* a2 = (t + 2 < nt) ? Ab + wa.off_bytes(d.A) : nullptr;        // A units of tile t + 2
-    const char* b2 = (t + 2 < nt) ? Bb + (int64_t)(t + 2) * 128 : nullptr;
-    const char* b1 = (t + 1 < nt) ? Bb + (int64_t)(t + 1) * 128 : nullptr;
+    const char* b2 = (t + 2 < nt) ? Bb + wa.off_bytes_b(d.A) : nullptr;
+    const char* b1 = (t + 1 < nt) ? Bb + wb.off_bytes_b(d.A) : nullptr;
     // ---- phase 1: quadrant (m0, n0)
     p8_read<2>(cur + OB0, rdB, p0, p1, fb0);
     p8_read<4>(cur + OA0, rdA, p0, p1, fa);
@@ -259,6 +273,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
     p8_mfma<4, 2>(fa, fb0, acc[1][0]);
     P8_PHASE_SYNC_OUT();
     wa.next(d.A);
+    wb.next(d.A);
   }
   if (STAGGER && half == 0) __builtin_amdgcn_s_barrier();
   p8_wait_vmcnt<0>();                  // the zero-block DMAs issued past the end
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
     wa1.next(d.A);
     const bool has1 = nt > 1;
     p8_issue<2>(has1 ? Ab + wa0.off_bytes(d.A) : nullptr, offA[0], smem + BUF + 0 * UNIT, wave);
-    p8_issue<2>(has1 ? Bb + 128 : nullptr, offB, smem + BUF + 2 * UNIT, wave);
+    p8_issue<2>(has1 ? Bb + wa1.off_bytes_b(d.A) : nullptr, offB, smem + BUF + 2 * UNIT, wave);
     wa0.next(d.A);
   }
   p8_wait_vmcnt<4>();                  // tile 0 has landed (A.m0, B of tile 1 may still be moving)
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
     // ---- phase 2: rows m1
     p8_read<4>(cur + 1 * UNIT, rdA, p0, p1, fa);
     p8_issue<2>((t + 2 < nt) ? Ab + wa0.off_bytes(d.A) : nullptr, offA[0], cur + 0 * UNIT, wave);     // A.m0 of tile t + 2
-    p8_issue<2>((t + 2 < nt) ? Bb + (int64_t)(t + 2) * 128 : nullptr, offB, cur + 2 * UNIT, wave);    // B of tile t + 2
+    p8_issue<2>((t + 2 < nt) ? Bb + wa0.off_bytes_b(d.A) : nullptr, offB, cur + 2 * UNIT, wave);      // B of tile t + 2
     p8_wait_vmcnt<6>();                                                                             // A.m0, B of tile t + 1 have landed
     P8_PHASE_SYNC_IN();
     p8_mfma<4, 2>(fa, fb, acc[1]);
