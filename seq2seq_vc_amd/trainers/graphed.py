@@ -46,6 +46,10 @@ class GraphedStep:
         self.pool = torch.cuda.graph_pool_handle()     # one memory pool for the graphs of all shapes
         if trainer.gradient_accumulate_steps != 1:
             raise NotImplementedError('config["hip_graph"] needs gradient_accumulate_steps == 1')
+        from ..schedulers import FusedWarmupLR
+        if trainer.scheduler is not None and not isinstance(trainer.scheduler, FusedWarmupLR):
+            raise NotImplementedError('config["hip_graph"]: the learning-rate schedule must live in the fused optimiser step '
+                                      "(schedulers.FusedWarmupLR); a host-side scheduler would not run during replays")
         if trainer.dist is not None and trainer.dp is None:
             raise NotImplementedError('config["hip_graph"] with config["distributed"] needs a model with dp_plan() (staged backward)')
 
