@@ -180,6 +180,11 @@ int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean
                       float* run_mean, float* run_var, int64_t* num_batches, int var_is_ex2 /* var = E[x^2], colreduce mode 6 */,
                       void* stream);
 int s2svc_rstd_from_var(int C, float eps, const float* var, float* rstd, void* stream);
+/* The training-mode statistics of torch.nn.BatchNorm1d (pre_postnets.py:124,152, conformer/convolution.py:52,74) with the second
+   reduction stage folded into the finalisation: 2 launches instead of 3 (ws >= ws_chunks*2*C floats).
+   s2svc_bn_stats == s2svc_colreduce(mode 6, scale 1/rows) + s2svc_bn_finalize(var_is_ex2 = 1). */
+int s2svc_bn_stats(int dtype, int rows, int C, const void* x, float eps, float momentum, float* mean, float* rstd,
+                   float* run_mean, float* run_var, int64_t* num_batches, float* ws, int ws_chunks, void* stream);
 int s2svc_bn_apply(int dtype, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
                    const float* gamma, const float* beta, int act, float drop_p, const uint64_t* seed_base,
                    uint64_t seed_off, void* y, void* pre_act, void* stream);

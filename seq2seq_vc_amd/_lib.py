@@ -112,6 +112,7 @@ _SIGS = {
     "s2svc_rstd_from_var": [c_i32, c_f32, c_vp, c_vp, c_vp],
     "s2svc_bn_apply": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_bn_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
+    "s2svc_bn_stats": [c_i32, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_attn_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_f32,
                                c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_attn_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32,

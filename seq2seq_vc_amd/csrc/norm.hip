@@ -479,6 +479,41 @@ __global__ void bn_finalize_kernel(int C, int n, float eps, float momentum, cons
   }
 }
 
+// One-pass training statistics, second half: the stage-2 sum of the chunk partials (colreduce mode 6: sum x, sum x^2 -- same
+// order of additions as colreduce_stage2) and bn_finalize_kernel's arithmetic in ONE launch.
+__global__ __launch_bounds__(256) void bn_stage2_finalize_kernel(int C, int chunks, const float* __restrict__ ws, int n, float eps,
+                                                                 float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                 float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                 int64_t* __restrict__ num_batches) {
+  __shared__ float sh[2][4][64];
+  const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float t0 = 0.f, t1 = 0.f;
+  if (c < C) {
+    for (int k = kg; k < chunks; k += 4) {
+      t0 += ws[((int64_t)k * 2 + 0) * C + c];
+      t1 += ws[((int64_t)k * 2 + 1) * C + c];
+    }
+  }
+  sh[0][kg][cl] = t0;
+  sh[1][kg][cl] = t1;
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
+  if (kg != 0 || c >= C) return;
+  const float scale = 1.0f / (float)n;
+  const float m = (((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl]) * scale;
+  const float ex2 = (((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl]) * scale;
+  float vc = ex2 - m * m;
+  vc = vc > 0.f ? vc : 0.f;
+  mean[c] = m;
+  rstd[c] = 1.0f / sqrtf(vc + eps);
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * m;
+    const float unb = n > 1 ? vc * ((float)n / (float)(n - 1)) : vc;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * unb;
+  }
+}
+
 __global__ void rstd_from_var_kernel(int C, float eps, const float* __restrict__ var, float* __restrict__ rstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
@@ -616,6 +651,31 @@ extern "C" int s2svc_bn_finalize(int C, int n, float eps, float momentum, const 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, n, eps, momentum,
                      mean, var, rstd, run_mean, run_var, num_batches, var_is_ex2);
   S2S_CHECK_LAUNCH("bn_finalize_kernel");
+  return 0;
+}
+
+// mean / rstd of a training-mode BatchNorm1d over (rows, C) in TWO launches (one pass over x: fp32 sums of x and x^2 per chunk,
+// then sum of the partials + variance + rstd + running statistics); ws >= ws_chunks*2*C floats.  Same values as
+// s2svc_colreduce(mode 6, scale 1/rows) + s2svc_bn_finalize(var_is_ex2 = 1), one launch less.
+extern "C" int s2svc_bn_stats(int dtype, int rows, int C, const void* x, float eps, float momentum, float* mean, float* rstd,
+                              float* run_mean, float* run_var, int64_t* num_batches, float* ws, int ws_chunks, void* stream) {
+  S2S_REQUIRE(rows > 0 && C > 0 && x && mean && rstd && ws && ws_chunks > 0, "bn_stats: bad args");
+  S2S_REQUIRE(dtype == S2S_F32 || dtype == S2S_BF16, "bn_stats: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  int chunks = (rows + 63) / 64;
+  if (chunks > ws_chunks) chunks = ws_chunks;
+  const int rpc = (rows + chunks - 1) / chunks;
+  dim3 grid((C + 63) / 64, chunks), block(256);
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(colreduce_stage1<float>, grid, block, 0, st, rows, C, 6, (const float*)nullptr, (const float*)x,
+                       (const float*)nullptr, (const float*)nullptr, ws, rpc);
+  else
+    hipLaunchKernelGGL(colreduce_stage1<bf16_t>, grid, block, 0, st, rows, C, 6, (const bf16_t*)nullptr, (const bf16_t*)x,
+                       (const float*)nullptr, (const float*)nullptr, ws, rpc);
+  S2S_CHECK_LAUNCH("colreduce_stage1");
+  hipLaunchKernelGGL(bn_stage2_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, C, chunks, ws, rows, eps, momentum, mean,
+                     rstd, run_mean, run_var, num_batches);
+  S2S_CHECK_LAUNCH("bn_stage2_finalize_kernel");
   return 0;
 }
 

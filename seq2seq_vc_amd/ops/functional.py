@@ -1314,8 +1314,7 @@ class _BatchNormAct(Function):
         seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
         if training:
             if x.dtype == torch.bfloat16:      # one pass over x: mean and E[x^2] together (fp32 sums of bf16 values)
-                mean, ex2 = K.colreduce(6, None, x=x.view(rows, C), scale=1.0 / rows, rows=rows, D=C, want_dot=True)
-                rstd = K.bn_finalize(mean, ex2, rows, eps, momentum, run_mean, run_var, num_batches, var_is_ex2=True)
+                mean, rstd = K.bn_stats(x, rows, C, eps, momentum, run_mean, run_var, num_batches)
             else:                              # parity mode: the two-pass variance torch computes
                 mean, _ = K.colreduce(0, x.view(rows, C), scale=1.0 / rows)
                 var, _ = K.colreduce(3, None, x=x.view(rows, C), mean=mean, scale=1.0 / rows, rows=rows, D=C)

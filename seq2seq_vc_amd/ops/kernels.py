@@ -367,6 +367,16 @@ def bn_finalize(mean, var, n, eps, momentum, run_mean=None, run_var=None, num_ba
     return rstd
 
 
+def bn_stats(x, rows, C, eps, momentum, run_mean=None, run_var=None, num_batches=None):
+    """(mean, rstd) of training-mode BatchNorm over (rows, C), one pass over x, two launches (s2svc_bn_stats)."""
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(_WS_CHUNKS * 2 * C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().s2svc_bn_stats(dt(x), rows, C, ptr(x), eps, momentum, ptr(mean), ptr(rstd), ptr(run_mean), ptr(run_var),
+                                         ptr(num_batches), ptr(ws), _WS_CHUNKS, stream()), "bn_stats")
+    return mean, rstd
+
+
 def rstd_from_var(var, eps):
     rstd = torch.empty_like(var)
     _lib.check(_lib.lib().s2svc_rstd_from_var(var.numel(), eps, ptr(var), ptr(rstd), stream()), "rstd_from_var")

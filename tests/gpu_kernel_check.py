@@ -1029,6 +1029,30 @@ def gemm_8phase():
     return res
 
 
+@case
+def bn_two_launch_statistics():
+    """s2svc_bn_stats (the second reduction stage folded into the finalisation: 2 launches instead of 3) against the
+    three-launch composition it replaces -- colreduce(mode 6) + bn_finalize -- incl. the running statistics, and against
+    torch, on the shapes of the VTN postnet (8192 x 512), the AAS-VC convolution module (4096 x 1536), a ragged one and fp32."""
+    res = []
+    for (rows, C, dtype, seed) in [(8192, 512, torch.bfloat16, 1), (4096, 1536, torch.bfloat16, 2), (1000, 200, torch.bfloat16, 3),
+                                   (777, 96, torch.float32, 4)]:
+        x = rnd(rows, C, seed=seed, dtype=dtype, scale=2.0) + 0.3
+        rm0, rv0 = rnd(C, seed=seed + 30), rnd(C, seed=seed + 40).abs() + 0.5
+        rm_a, rv_a, nb_a = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
+        rm_b, rv_b, nb_b = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.int64, device=DEV)
+        mean_a, ex2 = K.colreduce(6, None, x=x, scale=1.0 / rows, rows=rows, D=C, want_dot=True)
+        rstd_a = K.bn_finalize(mean_a, ex2, rows, 1e-5, 0.1, rm_a, rv_a, nb_a, var_is_ex2=True)
+        mean_b, rstd_b = K.bn_stats(x, rows, C, 1e-5, 0.1, rm_b, rv_b, nb_b)
+        for nm, a, b in (("mean", mean_a, mean_b), ("rstd", rstd_a, rstd_b), ("running mean", rm_a, rm_b), ("running var", rv_a, rv_b)):
+            res.append(check(f"bn_stats {rows}x{C} {dtype} {nm} vs colreduce + bn_finalize", b, a, torch.float32, rtol=2e-6, atol=1e-7))
+        res.append((int(nb_b) == 1, f"bn_stats {rows}x{C}: num_batches_tracked advanced once"))
+        xf = x.float()
+        res.append(check(f"bn_stats {rows}x{C} mean vs torch", mean_b, xf.mean(0), torch.float32, rtol=1e-4, atol=1e-4))
+        res.append(check(f"bn_stats {rows}x{C} rstd vs torch", rstd_b, 1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5), torch.float32, rtol=1e-3, atol=1e-4))
+    return res
+
+
 def main():
     torch.manual_seed(0)
     nfail = 0
