@@ -114,6 +114,7 @@ class GraphedStep:
             t.steps += e.deltas[0]
             t.backward_steps += e.deltas[1]
             t._check_train_finish()
+            t.optimizer._touch()        # the weights change without a Python-side optimizer.step(): cached decode sessions etc. go stale
         self._replay(e)
 
     def _replay(self, e):

@@ -782,6 +782,8 @@ def trainers_replay_captured_steps():
         tr.run()
         torch.cuda.synchronize()
         n_graphs = 0 if tr._graphed is None else sum(len(e.graphs) for e in tr._graphed.entries.values())
+        tr.weight_gen = model.__dict__.get("_s2s_weight_gen", 0)
+        run.last = tr
         return opt.flat_p.detach().clone(), logs, tr.steps, n_graphs
 
     try:
@@ -792,7 +794,9 @@ def trainers_replay_captured_steps():
             Fn.enable_side_streams(*((0, True) if kind == "aasvc" else (4, False)))
             data = batches(kind, idim, odim, 7, {"vtn": 21, "tts": 23, "aasvc": 22}[kind])
             p_t, l_t, s_t, _ = run(kind, "trace", data)
+            gen_t = run.last.weight_gen
             p_g, l_g, s_g, n_g = run(kind, True, data)
+            res.append((run.last.weight_gen == gen_t, f"{kind}: the model's weight generation advanced on replays too ({run.last.weight_gen} vs {gen_t}: cached decode sessions are rebuilt)"))
             res.append((s_t == s_g == len(data) and n_g >= 1, f"{kind}: {s_g} steps, {n_g} captured graph(s), {len(data) - 3} replays"))
             res.append((torch.equal(p_t, p_g), f"{kind}: parameters after {len(data)} steps, replayed vs traced eager: max diff {float((p_t - p_g).abs().max()):.3e}"))
             same_logs = all(abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(a[k])) for a, b in zip(l_t, l_g) for k in a)
