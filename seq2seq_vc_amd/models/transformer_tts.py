@@ -50,9 +50,10 @@ class TransformerTTS(_ARSeq2Seq):
         xs = TF.pad(xs, [0, 1], "constant", self.padding_idx)           # transformer_tts.py:139-142: append <eos>
         xs = xs.scatter(1, il.dev.long().unsqueeze(1), self.eos)        # (no host round trip: capturable in a hipGraph)
         il1 = il.map(lambda v: v + 1)
+        pre = self._decoder_head(ys, olens)
         hs, hs_lens = self.encoder(xs, il1)
         hs = Fn.cut_point(hs, "encoder_out")
-        after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens)
+        after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens, pre=pre)
         att_ws = []
         if self.use_guided_attn_loss:
             n = len(self.decoder.decoders)

@@ -5,6 +5,7 @@ Drop-in for `seq2seq_vc.models.VTN` (reference models/vtn.py): same constructor 
 state_dict keys.  All arithmetic runs in the HIP kernels behind seq2seq_vc_amd.ops.functional.
 """
 import logging
+import os
 
 import torch
 from torch import nn
@@ -12,6 +13,9 @@ from torch import nn
 from .. import modules as Mo
 from ..ops import functional as Fn
 from ..ops import kernels as K
+
+
+_HEAD_START = os.environ.get("S2SVC_NO_HEAD_START", "0") != "1"     # A/B switch: the decoder's head on the auxiliary stream
 
 
 class _ARSeq2Seq(nn.Module):
@@ -52,8 +56,12 @@ class _ARSeq2Seq(nn.Module):
                 {"root": f"cut:encoder.{h}", "modules": layers[:h]},
                 {"root": "cut:encoder.0", "modules": embed}]
 
-    def _teacher_forced(self, hs, hs_lens, ys, labels, olens):
-        r, odim = self.decoder_reduction_factor, self.odim
+    def _decoder_head(self, ys, olens):
+        """Teacher-forcing inputs of the decoder and -- in training, on the GPU -- the part of the decoder that does not see the
+        encoder (input layer + positional encoding + the first layer's self-attention block), started on the auxiliary stream
+        so that it runs beside the encoder (forward) and beside the encoder's backward pass (autograd runs a node on the stream
+        of its forward op).  -> state for _teacher_forced(..., pre=state)."""
+        r = self.decoder_reduction_factor
         dev = ys.device
         olens_h = Mo.Lens.of(olens, dev)
         if r > 1:
@@ -62,7 +70,20 @@ class _ARSeq2Seq(nn.Module):
         else:
             ys_in, olens_in_h = ys, olens_h
         ys_in = torch.cat([ys_in.new_zeros((ys_in.shape[0], 1, ys_in.shape[2])), ys_in[:, :-1]], dim=1)
-        zs, _ = self.decoder(Fn.to_compute(ys_in), olens_in_h, hs, hs_lens, causal=True)
+        head = None
+        if _HEAD_START and self.training and ys.is_cuda and torch.is_grad_enabled():
+            head = Fn.branch_run(lambda: self.decoder.head(Fn.to_compute(ys_in), olens_in_h, causal=True),
+                                 uses=(ys_in, olens_in_h.dev))
+        return olens_h, olens_in_h, ys_in, head
+
+    def _teacher_forced(self, hs, hs_lens, ys, labels, olens, pre=None):
+        r, odim = self.decoder_reduction_factor, self.odim
+        olens_h, olens_in_h, ys_in, head = pre if pre is not None else self._decoder_head(ys, olens)
+        if head is not None:
+            Fn.branch_join(*head)
+            zs, _ = self.decoder(None, olens_in_h, hs, hs_lens, causal=True, head=head)
+        else:
+            zs, _ = self.decoder(Fn.to_compute(ys_in), olens_in_h, hs, hs_lens, causal=True)
         before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, odim)
         logits = Fn.linear(zs, self.prob_out.weight, self.prob_out.bias).view(zs.size(0), -1)
         after = Fn.add_dropout(before, self.postnet(before), 0.0) if self.postnet is not None else before
@@ -197,9 +218,10 @@ class VTN(_ARSeq2Seq):
             xs = xs[:, : il.max()]
         if ol.max() != ys.shape[1]:
             ys, labels = ys[:, : ol.max()], labels[:, : ol.max()]
+        pre = self._decoder_head(ys, olens)
         hs, hs_lens = self.encoder(Fn.to_compute(xs), il)
         hs = Fn.cut_point(hs, "encoder_out")      # data-parallel overlap: decoder-side gradients travel during the encoder's backward
-        after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens)
+        after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens, pre=pre)
         il_ds = il.map(lambda v: ((v - 2 + 1) // 2 - 2 + 1) // 2)
         ilens_ds_st = Mo.tag_lens(torch.tensor(list(il_ds.host), dtype=ilens.dtype if isinstance(ilens, torch.Tensor) else torch.long,
                                                device=ilens.device if isinstance(ilens, torch.Tensor) else "cpu"), il_ds)

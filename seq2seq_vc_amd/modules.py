@@ -471,17 +471,27 @@ class DecoderLayer(nn.Module):
         self.dropout_rate = dropout_rate
         self.normalize_before = normalize_before
 
-    def forward(self, x, tgt_lens, memory, mem_lens, normed=None, causal=True, kv=None):
+    def self_block(self, x, tgt_lens, normed=None, causal=True):
+        """The part of the layer that does not see the memory: the self-attention sub-layer up to the input of the
+        source attention.  -> (y, x): y feeds the source attention, x is the residual stream (post-LN: the same tensor)."""
         p = self.dropout_rate if self.training else 0.0
         if self.normalize_before:
             y = self.norm1(x) if normed is None else normed
             a = self.self_attn(y, y, y, tgt_lens, causal=causal)
-            y, x = _res_norm(self.norm2, x, a, p)
+            return _res_norm(self.norm2, x, a, p)
+        a, xr = _sub_pass(self.self_attn, x, x, x, tgt_lens, causal=causal)
+        x, _ = _res_norm(self.norm1, xr, a, p)
+        return x, x
+
+    def forward(self, x, tgt_lens, memory, mem_lens, normed=None, causal=True, kv=None, head=None):
+        """head: the result of self_block() when the caller ran it ahead of the encoder (Decoder.head)."""
+        p = self.dropout_rate if self.training else 0.0
+        if self.normalize_before:
+            y, x = self.self_block(x, tgt_lens, normed, causal) if head is None else head
             a = self.src_attn(y, memory, memory, mem_lens, kv=kv)
             y, x = _res_norm(self.norm3, x, a, p)
             return x, self.feed_forward(y)
-        a, xr = _sub_pass(self.self_attn, x, x, x, tgt_lens, causal=causal)
-        x, _ = _res_norm(self.norm1, xr, a, p)
+        x = self.self_block(x, tgt_lens, None, causal)[0] if head is None else head[0]
         a, xr = _sub_pass(self.src_attn, x, memory, memory, mem_lens, kv=kv)
         x, _ = _res_norm(self.norm2, xr, a, p)
         f, xr = _sub_pass(self.feed_forward, x)
@@ -497,15 +507,14 @@ def run_stack(layers, x, after_norm, pre_ln, dropout_rate, training, *args, per_
     pending = None
     cut_name = kw.pop("cut_name", None)      # data-parallel overlap: "<name>.<i>" cuts the graph at the input of layer i
     for li, layer in enumerate(layers):
-        if per_layer is not None:
-            kw = dict(kw, **per_layer[li])
+        kwl = dict(kw, **per_layer[li]) if per_layer is not None else kw      # this layer's own extras only
         if cut_name is not None and li > 0:
             x, pending = Fn.cut_point((x, pending), f"{cut_name}.{li}")
         if pre_ln and pending is not None:
             normed, x = _res_norm(layer.norm1, x, pending, p)
-            x, pending = layer(x, *args, normed=normed, **kw)
+            x, pending = layer(x, *args, normed=normed, **kwl)
         else:
-            x, pending = layer(x, *args, **kw)
+            x, pending = layer(x, *args, **kwl)
     if pre_ln:
         if pending is not None:
             y, x = _res_norm(after_norm, x, pending, p)
@@ -696,8 +705,15 @@ class Decoder(nn.Module):
             x = m(x) if isinstance(m, Prenet) else Fn.linear(x, m.weight, m.bias)
         return self.embed[1](x)
 
-    def forward(self, tgt, tgt_lens, memory, mem_lens, causal=True):
+    def head(self, tgt, tgt_lens, causal=True):
+        """Everything of the decoder that does not depend on the encoder: input layer, positional encoding and the
+        self-attention block of the first layer.  In training the AR models run it on the auxiliary stream while the encoder
+        runs (models/vtn.py); forward(..., head=...) continues from it."""
         x = self.embed_input(tgt)
+        return self.decoders[0].self_block(x, tgt_lens, None, causal)
+
+    def forward(self, tgt, tgt_lens, memory, mem_lens, causal=True, head=None):
+        x = self.embed_input(tgt) if head is None else head[1]
         per_layer = None
         f = getattr(self, "_src_kv_all", None)       # stacked K/V weights of all source-attention blocks (optim.FlatAdam)
         if f is not None:
@@ -705,6 +721,9 @@ class Decoder(nn.Module):
             # K = layers * 2D instead of one per layer plus the gradient adds over the memory's fan-out
             kv_all = Fn.linear(memory, f["w"], f["b"])
             per_layer = [{"kv": t} for t in Fn.split_cols(kv_all, len(self.decoders))]
+        if head is not None:
+            per_layer = per_layer if per_layer is not None else [{} for _ in self.decoders]
+            per_layer[0] = dict(per_layer[0], head=head)
         x = run_stack(self.decoders, x, getattr(self, "after_norm", None), self.normalize_before, self.dropout_rate,
                       self.training, tgt_lens, memory, mem_lens, causal=causal, per_layer=per_layer)
         return x, tgt_lens

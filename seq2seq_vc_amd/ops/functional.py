@@ -170,6 +170,29 @@ class _Side:
     group_wgrad = os.environ.get("S2SVC_NO_GROUPED_WGRAD", "0") != "1"
 
 
+def _taken_streams():
+    h = {st.cuda_stream for st in _Side.streams}
+    if _Branch.stream is not None:
+        h.add(_Branch.stream.cuda_stream)
+    if torch.cuda.is_available():
+        h.add(torch.cuda.current_stream().cuda_stream)
+    return h
+
+
+def distinct_stream(taken=None):
+    """A torch.cuda.Stream whose underlying stream is none of `taken` (default: the side streams, the auxiliary stream and the
+    current stream).  torch hands out Stream objects round-robin from a pool of 32 per device: a process that has created many
+    (every trainer / test / decode session creates a few) gets ALIASES of earlier ones, and two roles that the scheduling here
+    keeps apart -- e.g. the auxiliary stream of a branch and a side stream of the gradient work -- end up on one stream, which a
+    capture with forks and joins between them does not survive (seen as a segmentation fault in hipStreamEndCapture)."""
+    taken = _taken_streams() if taken is None else set(taken)
+    for _ in range(96):
+        st = torch.cuda.Stream()
+        if st.cuda_stream not in taken:
+            return st
+    raise RuntimeError("no distinct stream left in torch's stream pool")
+
+
 def enable_side_streams(n=4, inline_batches=False):
     """n > 0: parameter-gradient work is forked to n side streams (small, latency-bound models: VTN).
     n == 0 and inline_batches: the work stays on the stream that issued it but is still queued and run in batches, so
@@ -178,7 +201,13 @@ def enable_side_streams(n=4, inline_batches=False):
     between backward and the optimiser step; n == 0 without inline_batches runs everything immediately."""
     _Side.enabled = n > 0
     _Side.inline = (n == 0) and inline_batches
-    _Side.streams = [torch.cuda.Stream() for _ in range(n)] if n > 0 else []
+    old, others = _Side.streams, _taken_streams() - {st.cuda_stream for st in _Side.streams}
+    if n > 0 and len(old) == n and len({st.cuda_stream for st in old}) == n and not ({st.cuda_stream for st in old} & others):
+        pass                                     # keep the ones we have: every new Stream object eats a slot of torch's pool
+    else:
+        _Side.streams = []
+        for _ in range(n):
+            _Side.streams.append(distinct_stream())
     _Side.idx = 0
 
 
@@ -234,7 +263,11 @@ def _side_flush():
         return
     if not _Side.queue:
         return
-    st = _Side.streams[_Side.idx % len(_Side.streams)]
+    k = _Side.idx % len(_Side.streams)
+    st = _Side.streams[k]
+    cur = torch.cuda.current_stream().cuda_stream
+    if st.cuda_stream == cur or (_Branch.stream is not None and st.cuda_stream == _Branch.stream.cuda_stream):
+        st = _Side.streams[k] = distinct_stream()        # an alias (see distinct_stream): e.g. the capture stream of a later graph
     _Side.idx += 1
     seen = set()
     for origin in _Side.origins + [torch.cuda.current_stream()]:     # every stream that produced an input of the batch
@@ -256,6 +289,7 @@ def _side_flush():
 class _Branch:
     stream = None
     active = False
+    dirty = False        # work was put on the auxiliary stream since the last join of a backward pass (side_join)
 
 
 def branch_run(fn, uses=()):
@@ -271,8 +305,8 @@ def branch_run(fn, uses=()):
     if not torch.cuda.is_available() or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
         return fn()
     main = torch.cuda.current_stream()
-    if _Branch.stream is None:
-        _Branch.stream = torch.cuda.Stream()
+    if _Branch.stream is None or _Branch.stream.cuda_stream == main.cuda_stream:
+        _Branch.stream = distinct_stream()
     _Branch.stream.wait_stream(main)
     for t in uses:
         if isinstance(t, torch.Tensor) and t.is_cuda:
@@ -280,6 +314,7 @@ def branch_run(fn, uses=()):
     with torch.cuda.stream(_Branch.stream):
         out = fn()
     _Branch.active = True
+    _Branch.dirty = True
     return out
 
 
@@ -306,6 +341,7 @@ def branch_backward(loss, fork_event, retain_graph=False):
         loss.backward(retain_graph=retain_graph)
         return
     _Branch.stream.wait_event(fork_event)
+    _Branch.dirty = True
     with torch.cuda.stream(_Branch.stream):
         loss.backward(retain_graph=retain_graph)
 
@@ -330,8 +366,20 @@ def side_join():
         main = torch.cuda.current_stream()
         for st in _Side.streams:
             main.wait_stream(st)
+    _join_branch_stream()
     _Side.pending.clear()
     _Side.idx = 0
+
+
+def _join_branch_stream():
+    """Backward nodes of a sub-network that ran under branch_run() execute on the auxiliary stream; nothing guarantees that the
+    last of them is followed by work another stream waits for (autograd only joins streams that ran gradient-accumulation
+    nodes; the parameter gradients here go straight to their slots).  So the join after a backward pass (side_join) also joins
+    the auxiliary stream -- if a branch was started since the last join (a later stage graph of a staged backward pass has no
+    part of the branch in it, and must not wait for an event of another capture)."""
+    if _Branch.stream is not None and _Branch.dirty:
+        torch.cuda.current_stream().wait_stream(_Branch.stream)
+    _Branch.dirty = False
 
 
 def _slotted(*params):

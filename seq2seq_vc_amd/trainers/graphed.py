@@ -18,6 +18,8 @@ With data parallelism the backward pass is captured stage by stage (distributed.
 finished stage is issued between the replays, as bench.py does; the optimiser step is its own graph behind the join.
 config["hip_graph"] = "trace" never captures (the eager reference of the tests for exactly this data path).
 """
+import gc
+
 import torch
 
 from .. import modules as Mo
@@ -42,7 +44,7 @@ class GraphedStep:
         self.quantum = int(trainer.config.get("graph_length_quantum", 64))
         self.trace_only = trainer.config.get("hip_graph") == "trace"
         self.entries = {}
-        self.stream = torch.cuda.Stream(trainer.device)
+        self.stream = torch.cuda.Stream(trainer.device)      # replaced by a distinct one at capture time if it aliases a stream in use
         self.pool = torch.cuda.graph_pool_handle()     # one memory pool for the graphs of all shapes
         if trainer.gradient_accumulate_steps != 1:
             raise NotImplementedError('config["hip_graph"] needs gradient_accumulate_steps == 1')
@@ -133,9 +135,16 @@ class GraphedStep:
         before = (t.steps, t.backward_steps)
         mode = "thread_local" if t.dist is not None else "global"
         torch.cuda.synchronize()
+        from ..ops import functional as Fn
+        if self.stream.cuda_stream in Fn._taken_streams():          # an alias out of torch's round-robin stream pool
+            self.stream = Fn.distinct_stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         cap = _Capture(self, e, mode)
         t._capture = cap if t.dp is not None else None
+        # no cyclic garbage collection while the stream captures: the destructor of a CUDAGraph / stream of an earlier life calls
+        # the runtime, which refuses during a capture (seen as an abort from the autograd thread)
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.stream(self.stream), Mo.lens_bank(e.bank):
                 self._roots(e, e.bank)
@@ -156,6 +165,8 @@ class GraphedStep:
             raise
         finally:
             t._capture = None
+            if gc_was_on:
+                gc.enable()
         torch.cuda.current_stream().wait_stream(self.stream)
         e.bank.closed = True
         e.deltas = (t.steps - before[0], t.backward_steps - before[1])
@@ -175,6 +186,15 @@ class _Capture:
 
     def end(self):
         g, stage = self.cur
+        from ..ops import functional as Fn
+        main = torch.cuda.current_stream()
+        for st in [Fn._Branch.stream] + list(Fn._Side.streams):      # belt and braces: nothing may still be forked off
+            if st is None:
+                continue
+            with torch.cuda.stream(st):
+                forked = torch.cuda.is_current_stream_capturing()
+            if forked:
+                main.wait_stream(st)
         g.capture_end()
         self.entry.graphs.append((g, stage))
         self.cur = None
