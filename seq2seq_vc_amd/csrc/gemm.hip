@@ -357,7 +357,8 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
     S2S_REQUIRE(d.nb0 * d.nb1 == 1 && d.splitk <= 1 && !d.res && !d.emask && d.drop_p == 0.f && !d.a_rowsum,
                 "s2svc_gemm: tconv2d / c_map GEMMs are unbatched, unsplit and have no residual / mask stage");
     S2S_REQUIRE(!d.c_map || (d.cm_Tc > 0 && d.cm_Fc > 0 && d.M % (d.cm_Tc * d.cm_Fc) == 0), "s2svc_gemm: bad c_map grid");
-    const int rc = s2svc_gemm_try_glds(&d, stream);
+    int rc = s2svc_gemm_try_8ph(&d, stream);         // the 8-wave kernel takes the transposed-convolution operand and mapped C rows
+    if (rc == 0) rc = s2svc_gemm_try_glds(&d, stream);
     S2S_REQUIRE(rc != 0, "s2svc_gemm: tconv2d / c_map need bf16 operands the LDS-DMA kernel accepts (16-byte aligned, C % 8 == 0, C >= 64)");
     return rc < 0 ? rc : 0;
   }

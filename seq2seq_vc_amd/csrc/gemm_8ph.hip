@@ -36,7 +36,7 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 
 __device__ __attribute__((aligned(16))) uint4 g_zero16_8ph = {0u, 0u, 0u, 0u};
 
-enum { P8_DENSE = 0, P8_CONV2D = 1 };
+enum { P8_DENSE = 0, P8_CONV2D = 1, P8_TCONV2D = 2 };
 
 template <int N> __device__ __forceinline__ void p8_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void p8_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -64,6 +64,9 @@ struct P8Walk {
   // rows): the taps of a slice re-read the same input pixels (each is under 9/4 windows), 9 K tiles apart instead of C/64 * 9
   // -- a 512-row tile then re-touches 150 KB, not 1.6 MB, and the re-reads stay in the XCD's L2 instead of going to the
   // fabric (HBM-side traffic of the VTN front-end GEMM: 2.2 x -> see profiles/roofline_pmc.json).
+  // tconv2d (one parity class of the stride-2 transposed convolution, S2SVC_OP_TCONV2D_S2): tap (kh, kw) = (ta, fb) of the
+  // nt x nf taps of the class reads the output-gradient pixel (i - ta, j - fb); same order (taps innermost), the weight
+  // rows are k = tap * C + c with tap = ta * nf + fb.
   int kt, c0, kh, kw;
   __device__ __forceinline__ void init(const s2svc_operand& o, int kt0) {
     kt = kt0;
@@ -73,22 +76,42 @@ struct P8Walk {
       kh = tap / 3;
       kw = tap - kh * 3;
     }
+    if (KIND == P8_TCONV2D) {
+      const int nf = 2 - (o.pad & 1), ntap = (2 - (o.pad >> 1)) * nf;
+      const int cs = kt0 / ntap, tap = kt0 - cs * ntap;
+      c0 = cs * 64;
+      kh = tap / nf;
+      kw = tap - kh * nf;
+    }
   }
   __device__ __forceinline__ int64_t off_bytes(const s2svc_operand& o) const {
     if (KIND == P8_CONV2D) return ((int64_t)(kh * o.F1 + kw) * o.ld + c0) * 2;
+    if (KIND == P8_TCONV2D) return (-(int64_t)(kh * o.F2 + kw) * o.ld + c0) * 2;
     return (int64_t)kt * 128;
   }
-  // the same K tile of the dense B operand (rows of K = 9 * C elements, k = tap * C + c)
+  // the same K tile of the dense B operand (rows of K = taps * C elements, k = tap * C + c)
   __device__ __forceinline__ int64_t off_bytes_b(const s2svc_operand& o) const {
     if (KIND == P8_CONV2D) return ((int64_t)(kh * 3 + kw) * o.C + c0) * 2;
+    if (KIND == P8_TCONV2D) return ((int64_t)(kh * (2 - (o.pad & 1)) + kw) * o.C + c0) * 2;
     return (int64_t)kt * 128;
   }
+  // tconv2d: the bit of this tap in the per-row validity masks (p8_rowmask)
+  __device__ __forceinline__ int bit() const { return 1 << (2 * kh + kw); }
   __device__ __forceinline__ void next(const s2svc_operand& o) {
     ++kt;
     if (KIND == P8_CONV2D) {
       if (++kw == 3) {
         kw = 0;
         if (++kh == 3) {
+          kh = 0;
+          c0 += 64;
+        }
+      }
+    }
+    if (KIND == P8_TCONV2D) {
+      if (++kw == 2 - (o.pad & 1)) {
+        kw = 0;
+        if (++kh == 2 - (o.pad >> 1)) {
           kh = 0;
           c0 += 64;
         }
@@ -106,10 +129,31 @@ __device__ __forceinline__ uint32_t p8_rowoff(const s2svc_operand& o, int r, int
     const int bt = r / o.F2, f2 = r - bt * o.F2;
     const int b = bt / o.T2, t2 = bt - b * o.T2;
     e = ((int64_t)(b * o.T1 + 2 * t2) * o.F1 + 2 * f2) * o.ld;
+  } else if (KIND == P8_TCONV2D) {     // class grid (o.T1 x o.F1) -> output-gradient pixel (i, j) of the (B, T2, F2, C) tensor
+    const int per_b = o.T1 * o.F1;
+    const int b = r / per_b, rem = r - b * per_b;
+    const int i = rem / o.F1, j = rem - i * o.F1;
+    e = ((int64_t)(b * o.T2 + i) * o.F2 + j) * o.ld;
   } else {
     e = (int64_t)r * o.ld;
   }
   return (uint32_t)((e + c * 8) * 2);
+}
+
+// tconv2d: which of the <= 2 x 2 taps of the parity class read inside the output-gradient image for tile row r
+// (bit 2 * ta + fb); rows past the matrix read nothing
+__device__ __forceinline__ int p8_rowmask(const s2svc_operand& o, int r, int R) {
+  if (r >= R) return 0;
+  const int per_b = o.T1 * o.F1;
+  const int rem = r - (r / per_b) * per_b;
+  const int i = rem / o.F1, j = rem - i * o.F1;
+  int m = 0;
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+      if (i - ta >= 0 && i - ta < o.T2 && j - fb >= 0 && j - fb < o.F2) m |= 1 << (2 * ta + fb);
+  return m;
 }
 
 // one unit = NI DMA instructions of this wave; base == nullptr: the unit lies past the last K tile (the instructions are
@@ -122,6 +166,27 @@ __device__ __forceinline__ void p8_issue(const char* base, const uint32_t (&off)
     const uint32_t o = base ? off[e] : 0u;
     __builtin_amdgcn_global_load_lds((gbl_void*)(b + o), (lds_void*)(lds_unit + (wave_s * NI + e) * 1024), 16, 0, 0);
   }
+}
+
+// the same with a per-lane validity test (tconv2d: the tap of this K tile falls outside the image for some rows): those
+// lanes read the zero block
+template <int NI>
+__device__ __forceinline__ void p8_issue_masked(const char* base, const uint32_t (&off)[NI], const int (&mask)[NI], int bit,
+                                                char* lds_unit, int wave_s) {
+  const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
+#pragma unroll
+  for (int e = 0; e < NI; ++e) {
+    const char* src = (base && (mask[e] & bit)) ? base + off[e] : z;
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_unit + (wave_s * NI + e) * 1024), 16, 0, 0);
+  }
+}
+
+// A units go through this: masked for the transposed-convolution operand only
+template <int KA, int NI>
+__device__ __forceinline__ void p8_issue_a(const char* base, const uint32_t (&off)[NI], const int (&mask)[NI], int bit, char* lds_unit,
+                                           int wave_s) {
+  if (KA == P8_TCONV2D) p8_issue_masked<NI>(base, off, mask, bit, lds_unit, wave_s);
+  else p8_issue<NI>(base, off, lds_unit, wave_s);
 }
 
 // fragment reads of one unit: NF row blocks of 16 rows starting at unit row r0, both k halves of the tile
@@ -186,12 +251,17 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
 
   // source offsets of this wave's DMA instructions per unit
   uint32_t offA[2][NIA], offB[2][NIB];
+  int mA[2][NIA];                                                 // tconv2d: taps inside the image, per row
 #pragma unroll
   for (int e = 0; e < NIA; ++e) {
     const int ru = (wave * NIA + e) * 8 + (lane >> 3);            // unit row of this lane
     const int c = (lane & 7) ^ ((ru >> 1) & 7);                   // source piece that belongs in this lane's slot
 #pragma unroll
-    for (int h = 0; h < 2; ++h) offA[h][e] = p8_rowoff<KA>(d.A, m0 + (ru >> 6) * 128 + h * 64 + (ru & 63), d.M, c);
+    for (int h = 0; h < 2; ++h) {
+      const int row = m0 + (ru >> 6) * 128 + h * 64 + (ru & 63);
+      offA[h][e] = p8_rowoff<KA>(d.A, row, d.M, c);
+      mA[h][e] = KA == P8_TCONV2D ? p8_rowmask(d.A, row, d.M) : 0;
+    }
   }
 #pragma unroll
   for (int e = 0; e < NIB; ++e) {
@@ -221,18 +291,20 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
   // prologue: tile 0 complete, tile 1 without B.n0 (issued in phase 1 of tile 0)
   {
     const char* a0 = Ab + wa.off_bytes(d.A);
-    p8_issue<NIA>(a0, offA[0], smem + OA0, wave);
+    const int bit0 = wa.bit();
+    p8_issue_a<KA, NIA>(a0, offA[0], mA[0], bit0, smem + OA0, wave);
     p8_issue<NIB>(Bb, offB[0], smem + OB0, wave);
     p8_issue<NIB>(Bb, offB[1], smem + OB1, wave);
-    p8_issue<NIA>(a0, offA[1], smem + OA1, wave);
+    p8_issue_a<KA, NIA>(a0, offA[1], mA[1], bit0, smem + OA1, wave);
     wa.next(d.A);
     wb.next(d.A);
     const bool has1 = nt > 1;
     const char* a1 = has1 ? Ab + wa.off_bytes(d.A) : nullptr;
     const char* b1 = has1 ? Bb + wa.off_bytes_b(d.A) : nullptr;
-    p8_issue<NIA>(a1, offA[0], smem + BUF + OA0, wave);
+    const int bit1 = wa.bit();
+    p8_issue_a<KA, NIA>(a1, offA[0], mA[0], bit1, smem + BUF + OA0, wave);
     p8_issue<NIB>(b1, offB[1], smem + BUF + OB1, wave);
-    p8_issue<NIA>(a1, offA[1], smem + BUF + OA1, wave);
+    p8_issue_a<KA, NIA>(a1, offA[1], mA[1], bit1, smem + BUF + OA1, wave);
     wa.next(d.A);
   }
   p8_wait_vmcnt<2 * NIA + NIB>();
@@ -244,6 +316,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
     char* cur = smem + (t & 1) * BUF;
     char* oth = smem + ((t & 1) ^ 1) * BUF;
     const char* a2 = (t + 2 < nt) ? Ab + wa.off_bytes(d.A) : nullptr;        // A units of tile t + 2
+    const int bit2 = wa.bit();
     const char* b2 = (t + 2 < nt) ? Bb + wa.off_bytes_b(d.A) : nullptr;
     const char* b1 = (t + 1 < nt) ? Bb + wb.off_bytes_b(d.A) : nullptr;
     // ---- phase 1: quadrant (m0, n0)
@@ -255,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
     P8_PHASE_SYNC_OUT();
     // ---- phase 2: quadrant (m0, n1)
     p8_read<2>(cur + OB1, rdB, p0, p1, fb1);
-    p8_issue<NIA>(a2, offA[0], cur + OA0, wave);                              // A.m0 of tile t + 2
+    p8_issue_a<KA, NIA>(a2, offA[0], mA[0], bit2, cur + OA0, wave);            // A.m0 of tile t + 2
     P8_PHASE_SYNC_IN();
     p8_mfma<4, 2>(fa, fb1, acc[0][1]);
     P8_PHASE_SYNC_OUT();
@@ -267,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
     P8_PHASE_SYNC_OUT();
     // ---- phase 4: quadrant (m1, n0)   (fb0 is still live: B.n0 needs no second read, its unit died after phase 1 --
     //      it is nevertheless re-filled only in phase 1 of the next tile, keeping one unit per phase)
-    p8_issue<NIA>(a2, offA[1], cur + OA1, wave);                              // A.m1 of tile t + 2
+    p8_issue_a<KA, NIA>(a2, offA[1], mA[1], bit2, cur + OA1, wave);            // A.m1 of tile t + 2
     p8_wait_vmcnt<2 * NIA + NIB>();                                           // everything of tile t + 1 has landed
     P8_PHASE_SYNC_IN();
     p8_mfma<4, 2>(fa, fb0, acc[1][0]);
@@ -307,12 +380,17 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
   const int lr = lane & 15, lg = lane >> 4;
 
   uint32_t offA[2][2], offB[2];
+  int mA[2][2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const int ru = (wave * 2 + e) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((ru >> 1) & 7);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) offA[h][e] = p8_rowoff<KA>(d.A, m0 + (ru >> 6) * 128 + h * 64 + (ru & 63), d.M, c);
+    for (int h = 0; h < 2; ++h) {
+      const int row = m0 + (ru >> 6) * 128 + h * 64 + (ru & 63);
+      offA[h][e] = p8_rowoff<KA>(d.A, row, d.M, c);
+      mA[h][e] = KA == P8_TCONV2D ? p8_rowmask(d.A, row, d.M) : 0;
+    }
     offB[e] = p8_rowoff<P8_DENSE>(d.B, n0 + ru, d.N, c);
   }
   const int sw = (lr >> 1) & 7;
@@ -332,13 +410,14 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
   wa1.init(d.A, 0);
   {
     const char* a0 = Ab + wa0.off_bytes(d.A);
-    p8_issue<2>(a0, offA[0], smem + 0 * UNIT, wave);
+    const int bit0 = wa0.bit();
+    p8_issue_a<KA, 2>(a0, offA[0], mA[0], bit0, smem + 0 * UNIT, wave);
     p8_issue<2>(Bb, offB, smem + 2 * UNIT, wave);
-    p8_issue<2>(a0, offA[1], smem + 1 * UNIT, wave);
+    p8_issue_a<KA, 2>(a0, offA[1], mA[1], bit0, smem + 1 * UNIT, wave);
     wa0.next(d.A);
     wa1.next(d.A);
     const bool has1 = nt > 1;
-    p8_issue<2>(has1 ? Ab + wa0.off_bytes(d.A) : nullptr, offA[0], smem + BUF + 0 * UNIT, wave);
+    p8_issue_a<KA, 2>(has1 ? Ab + wa0.off_bytes(d.A) : nullptr, offA[0], mA[0], wa0.bit(), smem + BUF + 0 * UNIT, wave);
     p8_issue<2>(has1 ? Bb + wa1.off_bytes_b(d.A) : nullptr, offB, smem + BUF + 2 * UNIT, wave);
     wa0.next(d.A);
   }
@@ -353,14 +432,14 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
     // ---- phase 1: rows m0
     p8_read<2>(cur + 2 * UNIT, rdB, p0, p1, fb);
     p8_read<4>(cur + 0 * UNIT, rdA, p0, p1, fa);
-    p8_issue<2>((t + 1 < nt) ? Ab + wa1.off_bytes(d.A) : nullptr, offA[1], oth + 1 * UNIT, wave);     // A.m1 of tile t + 1
+    p8_issue_a<KA, 2>((t + 1 < nt) ? Ab + wa1.off_bytes(d.A) : nullptr, offA[1], mA[1], wa1.bit(), oth + 1 * UNIT, wave);     // A.m1 of tile t + 1
     p8_wait_vmcnt<6>();                                                                             // A.m1 of tile t has landed
     P8_PHASE_SYNC_IN();
     p8_mfma<4, 2>(fa, fb, acc[0]);
     P8_PHASE_SYNC_OUT();
     // ---- phase 2: rows m1
     p8_read<4>(cur + 1 * UNIT, rdA, p0, p1, fa);
-    p8_issue<2>((t + 2 < nt) ? Ab + wa0.off_bytes(d.A) : nullptr, offA[0], cur + 0 * UNIT, wave);     // A.m0 of tile t + 2
+    p8_issue_a<KA, 2>((t + 2 < nt) ? Ab + wa0.off_bytes(d.A) : nullptr, offA[0], mA[0], wa0.bit(), cur + 0 * UNIT, wave);     // A.m0 of tile t + 2
     p8_issue<2>((t + 2 < nt) ? Bb + wa0.off_bytes_b(d.A) : nullptr, offB, cur + 2 * UNIT, wave);      // B of tile t + 2
     p8_wait_vmcnt<6>();                                                                             // A.m0, B of tile t + 1 have landed
     P8_PHASE_SYNC_IN();
@@ -396,6 +475,11 @@ int p8_force_bn() {   // S2SVC_GEMM_8PH_GEO=1|2|3 / s2svc_gemm_set_8ph: force th
   return g_p8_geo;
 }
 
+bool getenv_off(const char* name) {       // "<name>=0" switches a path off (A/B aid)
+  const char* e = getenv(name);
+  return e && e[0] == '0';
+}
+
 bool p8_operand_ok(const s2svc_operand& o, int rows, int K) {
   if (o.layout != S2SVC_LAYOUT_KC || ((uintptr_t)o.ptr) % 16 || o.ld % 8 || o.bs0 % 8 || o.bs1 % 8) return false;
   int64_t elems;
@@ -404,6 +488,10 @@ bool p8_operand_ok(const s2svc_operand& o, int rows, int K) {
   } else if (o.mode == S2SVC_OP_CONV2D_S2) {
     if (o.C % 64 || o.C < 64 || K != 9 * o.C) return false;
     elems = (int64_t)(rows / (o.T2 * o.F2) + 1) * o.T1 * o.F1 * o.ld;
+  } else if (o.mode == S2SVC_OP_TCONV2D_S2) {       // one parity class of the transposed convolution (an A-operand mode)
+    const int ntap = (2 - (o.pad >> 1)) * (2 - (o.pad & 1));
+    if (o.pad < 0 || o.pad > 3 || o.C % 64 || o.C < 64 || K != ntap * o.C || o.T1 <= 0 || o.F1 <= 0) return false;
+    elems = (int64_t)(rows / (o.T1 * o.F1) + 1) * o.T2 * o.F2 * o.ld;
   } else {
     return false;
   }
@@ -429,6 +517,7 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   if (mode == 0 || d.dtype != S2S_BF16 || d.splitk > 1 || d.a_rowsum || d.tile_hint == 64) return 0;
   if (d.K < 128 || d.K % 64 || d.M < 256 || d.N < 64) return 0;
   if (d.B.mode != S2SVC_OP_DENSE || !p8_operand_ok(d.A, d.M, d.K) || !p8_operand_ok(d.B, d.N, d.K)) return 0;
+  if (d.A.mode == S2SVC_OP_TCONV2D_S2 && (d.nb0 * d.nb1 != 1 || getenv_off("S2SVC_GEMM_8PH_TCONV"))) return 0;
   const int64_t nb = (int64_t)d.nb0 * d.nb1;
   const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * nb;       // 256 x 256 tiles
   const int64_t t512 = (int64_t)((d.M + 511) / 512) * ((d.N + 127) / 128) * nb;       // 512 x 128 tiles
@@ -448,16 +537,18 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   if (p8_force_bn() >= 1 && p8_force_bn() <= 3) geo = p8_force_bn();
   if (geo == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  const bool conv = d.A.mode == S2SVC_OP_CONV2D_S2;
+  const bool conv = d.A.mode == S2SVC_OP_CONV2D_S2, tconv = d.A.mode == S2SVC_OP_TCONV2D_S2;
   const int bm = geo == 2 ? 512 : 256, bn = geo == 1 ? 256 : 128;
   dim3 grid((unsigned)((d.N + bn - 1) / bn), (unsigned)((d.M + bm - 1) / bm), (unsigned)nb);
 #define P8_LAUNCH(KERNEL, ...)                                                                            \
   do {                                                                                                    \
     if (mode == 2) {                                                                                      \
       if (conv) hipLaunchKernelGGL((KERNEL<P8_CONV2D, ##__VA_ARGS__, false>), grid, dim3(512), 0, st, d); \
+      else if (tconv) hipLaunchKernelGGL((KERNEL<P8_TCONV2D, ##__VA_ARGS__, false>), grid, dim3(512), 0, st, d); \
       else hipLaunchKernelGGL((KERNEL<P8_DENSE, ##__VA_ARGS__, false>), grid, dim3(512), 0, st, d);       \
     } else {                                                                                              \
       if (conv) hipLaunchKernelGGL((KERNEL<P8_CONV2D, ##__VA_ARGS__, true>), grid, dim3(512), 0, st, d);  \
+      else if (tconv) hipLaunchKernelGGL((KERNEL<P8_TCONV2D, ##__VA_ARGS__, true>), grid, dim3(512), 0, st, d); \
       else hipLaunchKernelGGL((KERNEL<P8_DENSE, ##__VA_ARGS__, true>), grid, dim3(512), 0, st, d);        \
     }                                                                                                     \
   } while (0)

@@ -510,6 +510,35 @@ def conv2d_dgrad_transposed():
         K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), B * T2 * F2, 9 * C, O, dcols, in_dtype=dtype)
         old = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)
         res.append(check(f"tconv2d dgrad B{B} {T1}x{F1} vs dcols+col2im", dx, old, dtype, atol=3e-2 * max(1.0, float(ref.abs().max()))))
+    # the VTN front-end at its recipe size: the four class GEMMs run on the 8-wave kernel (csrc/gemm_8ph.hip: masked DMA for the
+    # taps that fall outside the output-gradient image, c_map stores) -- against the 128 x 128 kernel and torch
+    L = K._lib.lib()
+    prev = L.s2svc_gemm_set_8ph(-1)
+    try:
+        B, T1, F1, C, O = 32, 127, 39, 384, 384
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        w = rnd(O, C, 3, 3, seed=7, scale=0.02)
+        dy = rnd(B, T2, F2, O, seed=17, dtype=dtype)
+        outs = {}
+        for mode in (0, 1, 2):
+            L.s2svc_gemm_set_8ph(mode)
+            dx = torch.full((B, T1, F1, C), float("nan"), dtype=dtype, device=DEV)
+            for cls, wt in enumerate(K.tconv2d_weights(w)):
+                pt, pf = cls >> 1, cls & 1
+                Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
+                K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, wt.shape[1]),
+                       B * Tc * Fc, C, wt.shape[1], dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf))
+            outs[mode] = dx
+        xr = torch.zeros(B, C, T1, F1, device=DEV, requires_grad=True)
+        F.conv2d(xr, w.to(dtype).float(), None, stride=2).backward(dy.float().permute(0, 3, 1, 2))
+        ref = xr.grad.permute(0, 2, 3, 1)
+        tol = 3e-2 * max(1.0, float(ref.abs().max()))
+        res.append(check("tconv2d dgrad B32 127x39 C384 (8-wave kernel) vs torch", outs[1], ref, dtype, atol=tol))
+        res.append((bool(torch.equal(outs[1], outs[2])), "tconv2d dgrad on the 8-wave kernel: skewed and lockstep wave halves agree bit for bit"))
+        same = float((outs[1].float() - outs[0].float()).abs().max())
+        res.append((same <= 0.02 * max(1.0, float(ref.abs().max())), f"tconv2d dgrad 8-wave vs 128x128 kernel: max diff {same:.3e}"))
+    finally:
+        L.s2svc_gemm_set_8ph(prev)
     return res
 
 
