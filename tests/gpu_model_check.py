@@ -829,6 +829,21 @@ def trainers_replay_captured_steps():
 
 
 @case
+def trainers_captured_steps_full_size_soak():
+    """tools/soak_trainer.py at the recipe sizes (VTN vc1 B = 32, AAS-VC vc2 B = 16, bf16, dropout on): batches of three padded
+    shapes with ever-changing lengths; the trainer that replays hipGraphs ends with the parameters of the one that launches the
+    same padded batches eagerly, bit for bit."""
+    from tools import soak_trainer as S
+    res = []
+    for name, steps in (("vtn", 30), ("aasvc", 18)):
+        r = S.soak(name, steps)
+        res.append((r["equal"] and r["finite"] and r["graphs"] >= 3,
+                    f"{name} full size, {steps} steps, {r['graphs']} graphs: replayed vs eager parameters max diff {r['max_diff']:.3e}, "
+                    f"last losses {[round(v, 4) for v in r['logs_graph'][-1].values()]}"))
+    return res
+
+
+@case
 def vtn_ragged_batches_vs_oracle_fp32():
     """Shapes the golden fixtures do not have, against the CPU oracle on fresh seeded inputs: a single utterance, lengths
     that leave one encoder frame / one decoder step, lengths that are not multiples of the subsampling (4) or the reduction
