@@ -622,10 +622,16 @@ def main():
             del step
             wl.model = wl.opt = None
             torch.cuda.empty_cache()
-            out["aasvc"] = bench_aasvc_single(dev, dtype, cpu=not args.no_cpu_baseline)
-            Fn.enable_side_streams(0)
-            out["decode"] = bench_decode(dev, dtype, cpu=not args.no_cpu_baseline)
-            out["trainer"] = bench_product_trainer(dev, dtype)
+            # the sub-objects must never cost the headline line: a failure is reported in place
+            for key, fn in (("aasvc", lambda: bench_aasvc_single(dev, dtype, cpu=not args.no_cpu_baseline)),
+                            ("decode", lambda: bench_decode(dev, dtype, cpu=not args.no_cpu_baseline)),
+                            ("trainer", lambda: bench_product_trainer(dev, dtype))):
+                try:
+                    out[key] = fn()
+                except Exception as e:  # noqa: BLE001
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
+                    print(f"[bench] sub-benchmark '{key}' failed: {type(e).__name__}: {e}", file=sys.stderr)
+                Fn.enable_side_streams(0)
         # RCCL writes its version banner to the C-level stdout; flush that buffer first so the JSON line stays the last line
         sys.stdout.flush()
         try:
