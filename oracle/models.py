@@ -166,7 +166,7 @@ def gaussian_upsampling(hs, ds, h_masks, d_masks, delta=0.1):  # modules/length_
     energy = -1 * delta * (t.unsqueeze(-1) - cpos.unsqueeze(1)) ** 2
     if d_masks is not None:
         energy = energy.masked_fill(~(d_masks.unsqueeze(1).repeat(1, T_feats, 1)), -float("inf"))
-    return torch.matmul(torch.softmax(energy, dim=2), hs)
+    return torch.matmul(torch.softmax(energy, dim=2).to(hs.dtype), hs)       # (.to: no-op in the reference's fp32)
 
 
 # --------------------------------------------------------------------------- VITS flows (modules/vits/*.py)
@@ -409,7 +409,8 @@ def aasvc_forward(sd, c, xs, ilens, ys, olens, dp_inputs=None, noise=None, train
         ds, bin_loss, paths, margin = viterbi_decode(log_p_attn, ilens, olens_red)
         ret["mas_paths"], ret["mas_margin"] = paths, margin
         if stochastic:
-            nll = sdp_forward(dp, dpi.transpose(1, 2), h_np.unsqueeze(1).float(), ds.unsqueeze(1), noise, rt,
+            # (.to(dpi.dtype): fp32 in the reference; lets the tests evaluate this restatement in float64 as their yardstick)
+            nll = sdp_forward(dp, dpi.transpose(1, 2), h_np.unsqueeze(1).to(dpi.dtype), ds.unsqueeze(1).to(dpi.dtype), noise, rt,
                               _cfg(c, "stochastic_duration_predictor_dropout_rate", 0.5))
             ret["dur_nll"] = nll / torch.sum(h_np)
         else:

@@ -98,7 +98,7 @@ def abs_posenc(x, rt, drop_p):  # positional_encoding.py:57-70
 
 
 def rel_posenc(x, rt, drop_p):  # positional_encoding.py:293-309 -> (x*sqrt(d), pos_emb (1, 2T-1, d))
-    pe = rel_table(x.shape[1], x.shape[2])[None]
+    pe = rel_table(x.shape[1], x.shape[2])[None].to(x.dtype)      # the reference keeps its table in x's dtype (positional_encoding.py:281-291)
     return rt.dropout(x * math.sqrt(x.shape[2]), drop_p), rt.dropout(pe, drop_p)
 
 
@@ -107,7 +107,7 @@ def legacy_rel_posenc(x, rt, drop_p, max_len=5000):
     (positions 4999..0) and slices its first T rows, so the embedding handed to the attention is for
     positions 4999, 4998, ... -- restated as is."""
     n = max(max_len, x.shape[1])
-    pe = sin_table(n, x.shape[2], reverse=True)[: x.shape[1]][None]
+    pe = sin_table(n, x.shape[2], reverse=True)[: x.shape[1]][None].to(x.dtype)
     return rt.dropout(x * math.sqrt(x.shape[2]), drop_p), rt.dropout(pe, drop_p)
 
 

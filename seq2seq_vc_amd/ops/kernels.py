@@ -174,7 +174,13 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         d.splitk, d.ws = 1, None
         group.append(d)
         return out
-    if _RECORDER is not None:                # queue it for the grouped launch (unsplit) if the kernel takes it
+    # queue it for the grouped launch (unsplit) if the kernel takes it -- only problems that ACCUMULATE into their output (a
+    # flat-gradient slot, final once the batch has been flushed).  A GEMM into a fresh temporary is consumed by the caller's
+    # next launch: deferring it made the permuted weight gradient of the Linear behind the Conv2d front-end (gather3 +
+    # accumulate, ops.functional._LinearPermuted) read its buffer before the GEMM had run -- found by the full-size gradient
+    # test of round 3 (tests/gpu_model_check.py: vtn_full_size_grads); steady-state training had been using the buffer's
+    # previous contents, i.e. the gradient of the step before.
+    if _RECORDER is not None and accumulate:
         d.splitk, d.ws = 1, None
         if a_rowsum is not None:
             d.a_rowsum = a_rowsum.data_ptr()

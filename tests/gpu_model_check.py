@@ -1318,6 +1318,304 @@ def aasvc_full_size_values_fp32():
     return res
 
 
+def _grad_table(model, names, ref, rel_tol, floor_frac=1e-4, top=5):
+    """Per-parameter rel-L2 error of model's .grad against the reference gradients `ref` (name -> CPU tensor or None).
+    The denominator is max(||ref||, floor_frac * ||whole reference gradient||): a tensor whose true gradient is (numerically)
+    zero is measured against the scale of the whole gradient instead of against rounding noise.
+    -> (worst, "name err, name err, ..." of the `top` worst tensors, number above rel_tol, ||whole gradient||)"""
+    got = model if isinstance(model, dict) else {k: p.grad for k, p in model.named_parameters()}
+    total = sum(float(r.double().pow(2).sum()) for r in ref.values() if r is not None) ** 0.5
+    rows = []
+    for k in names:
+        r = ref[k] if ref[k] is not None else torch.zeros(got[k].shape if got[k] is not None else (1,), dtype=torch.float64)
+        g = got[k].detach().double().cpu() if got[k] is not None else torch.zeros_like(r)
+        e = float((g - r.double()).pow(2).sum()) ** 0.5 / max(float(r.double().pow(2).sum()) ** 0.5, floor_frac * total)
+        rows.append((e if e == e else float("inf"), k))
+    rows.sort(reverse=True)
+    nbad = sum(e > rel_tol for e, _ in rows)
+    return rows[0][0], ", ".join(f"{k} {e:.2e}" for e, k in rows[:top]), nbad, total
+
+
+def _oracle_grads(fn, sd, names, dtype):
+    """Gradients of the oracle's loss in `dtype` (fn(sd, cast) -> scalar loss) -> ({name: grad}, aux)."""
+    s = {k: (v.to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    for k in names:
+        s[k].requires_grad_(True)
+    loss, aux = fn(s, lambda t: t.to(dtype) if t.dtype.is_floating_point else t)
+    gr = torch.autograd.grad(loss, [s[k] for k in names], allow_unused=True)
+    return {k: (g.detach() if g is not None else None) for k, g in zip(names, gr)}, aux
+
+
+def _flat_rel(a, b):
+    return float((a.double() - b.double()).pow(2).sum().sqrt() / b.double().pow(2).sum().sqrt())
+
+
+def _group_rel(names, g_a, g_b, key):
+    """rel-L2 of two name -> gradient dicts per group of parameters (key(name) -> group label), in first-seen order."""
+    num, den, order = {}, {}, []
+    for k in names:
+        grp = key(k)
+        if grp not in num:
+            num[grp], den[grp] = 0.0, 0.0
+            order.append(grp)
+        a = g_a[k].double().cpu() if g_a[k] is not None else None
+        b_ = g_b[k].double().cpu() if g_b[k] is not None else None
+        if a is None and b_ is None:
+            continue
+        a = a if a is not None else torch.zeros_like(b_)
+        b_ = b_ if b_ is not None else torch.zeros_like(a)
+        num[grp] += float((a - b_).pow(2).sum())
+        den[grp] += float(b_.pow(2).sum())
+    return [(g, (num[g] / max(den[g], 1e-300)) ** 0.5) for g in order]
+
+
+def _layer_group(k):
+    parts = k.split(".")
+    for i, p_ in enumerate(parts):
+        if p_ in ("encoders", "decoders", "postnet") and i + 1 < len(parts) and parts[i + 1].isdigit():
+            return ".".join(parts[: i + 2])
+    return ".".join(parts[:2])
+
+
+FP32_GRAD_TOL = 1e-4          # per-parameter rel-L2 of fp32-mode gradients against the float64 oracle (VERDICT r2 item 2)
+
+
+def _grad_verdict(res, tag, model, names, ref64, ref32):
+    """fp32-mode gradients of `model` against the float64 oracle; the fp32 CPU oracle's own distance to it is the noise
+    floor of fp32 arithmetic on this graph and is reported beside it."""
+    worst, top, nbad, total = _grad_table(model, names, ref64, FP32_GRAD_TOL)
+    w32, top32, _, _ = _grad_table(ref32, names, ref64, FP32_GRAD_TOL, top=2)
+    res.append((nbad == 0, f"{tag}: {nbad} of {len(names)} parameter gradients above rel-L2 {FP32_GRAD_TOL:g} vs the float64 CPU oracle; worst: {top} "
+                f"(|g| = {total:.4f}; the fp32 CPU oracle itself: {top32})"))
+
+
+@case
+def vtn_full_size_grads():
+    """BASELINE configs[1] (VTN vc1, 30.5 M parameters, B = 32 x 256 frames: exactly what bench.py times): EVERY parameter
+    gradient against the CPU oracle's autograd (trainers/ar_vc.py:83-107: loss = l1 + bce), dropout 0, fp32 mode -- through
+    the one-shot backward pass AND through the staged one (distributed.OverlappedBackward over model.dp_plan(), the
+    data-parallel path) -- and the bf16 gradients (the timed path) against the fp32 ones.  The reference gradient is the
+    oracle evaluated in float64; per-parameter rel-L2 <= 1e-4 in fp32 mode (worst tensors named, the fp32 CPU oracle's own
+    error beside them).  bf16: flat rel-L2 reported per layer (it grows with the depth below the loss: 12 layers of bf16
+    rounding; the reference's own layer run in torch.bfloat16 is off by 3-6 % per layer, tests/fullwidth.py) and bounded."""
+    import bench
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.distributed import OverlappedBackward
+    from seq2seq_vc_amd.optim import FlatAdam
+    res = []
+    xs, ilens, ys, labels, olens = bench.canonical_batch(32)
+    try:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(4)
+        torch.manual_seed(0)
+        model = M.VTN(**bench.VTN_VC1)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.to(DEV).train()
+        _kill_dropout(model)
+        opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000)
+        names = [k for k, _ in model.named_parameters()]
+
+        def oracle_loss(s, cast):
+            o = OM.vtn_forward(s, bench.VTN_VC1, cast(xs), ilens, cast(ys), cast(labels), olens, training=True, drop=False)
+            l1r, bcer = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+            return l1r + bcer, (float(l1r.detach()), float(bcer.detach()))
+        ref64, (l1r, bcer) = _oracle_grads(oracle_loss, sd, names, torch.float64)
+        ref32, _ = _oracle_grads(oracle_loss, sd, names, torch.float32)
+
+        def run(staged):
+            K.manual_seed(99)
+            K.reset_op_counter()
+            opt.zero_grad()
+            if staged:
+                ob = OverlappedBackward(model, opt, None, 1, force=True)
+                with ob.forward_context():
+                    out = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+                    l1, bce = L.Seq2SeqLoss(10.0)(out[0], out[1], out[2], out[3], out[4], out[5])
+                ob.backward({"loss": l1 + bce}, reduce=False, scale=1.0)
+            else:
+                out = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+                l1, bce = L.Seq2SeqLoss(10.0)(out[0], out[1], out[2], out[3], out[4], out[5])
+                (l1 + bce).backward()
+                Fn.side_join()
+            torch.cuda.synchronize()
+            return float(l1.detach()), float(bce.detach())
+
+        for staged in (False, True):
+            l1, bce = run(staged)
+            tag = "C2 fp32 staged backward (dp_plan, 4 stages)" if staged else "C2 fp32 one-shot backward"
+            res.append((abs(l1 - l1r) < 2e-4 and abs(bce - bcer) < 2e-4, f"{tag}: losses {l1:.6f}/{bce:.6f} vs oracle {l1r:.6f}/{bcer:.6f}"))
+            _grad_verdict(res, tag, model, names, ref64, ref32)
+        g32 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        del opt, model
+        Fn.set_compute_dtype(torch.bfloat16)
+        torch.manual_seed(0)
+        model = M.VTN(**bench.VTN_VC1).to(DEV).train()
+        _kill_dropout(model)
+        opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=True)
+        run(False)
+        g16 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        flat = _group_rel(names, g16, g32, lambda k: "all")[0][1]
+        flat_o = _group_rel(names, g16, ref64, lambda k: "all")[0][1]
+        per = _group_rel(names, g16, g32, _layer_group)
+        res.append((flat <= 0.25 and flat_o <= 0.25, f"C2 bf16 (the timed path) flat gradient: rel-L2 {flat:.3e} vs fp32 mode, {flat_o:.3e} vs the float64 oracle (<= 0.25)"))
+        worst = max(per, key=lambda t: t[1])
+        res.append((worst[1] <= 0.5, "C2 bf16 vs fp32 per layer: " + ", ".join(f"{g} {e:.2f}" for g, e in per)))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
+def aasvc_full_size_grads():
+    """BASELINE configs[2] (AAS-VC vc2, 157.5 M parameters, B = 16): every parameter gradient of the trainer's loss
+    (trainers/aas_vc.py:75-134: l1 + 2 * (forward-sum + bin) + sum(dur_nll)) against the CPU oracle's autograd (float64) on the
+    canonical batch -- dropout 0, injected flow noise, fp32 mode -- through the one-shot backward pass (duration branch on the
+    auxiliary stream, inline gradient batches: the shipped schedule) and through the staged data-parallel one; then the bf16
+    gradients (the path bench.py --workload aasvc times) against fp32.  Per-parameter rel-L2 <= 1e-4 (fp32), flat rel-L2 <= 0.1
+    (bf16, provided bf16 finds the same alignment)."""
+    import bench
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.distributed import OverlappedBackward
+    from seq2seq_vc_amd.optim import FlatAdam
+    from tools.bench_aasvc import AASVC_VC2
+    res = []
+    xs, ilens, ys, _, olens = bench.canonical_batch(16)
+    noise = torch.randn(16, 2, 64, generator=torch.Generator().manual_seed(5))
+    try:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0, inline_batches=True)
+        torch.manual_seed(0)
+        model = M.AASVC(**AASVC_VC2)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.to(DEV).train()
+        _kill_dropout(model)
+        opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000)
+        names = [k for k, _ in model.named_parameters()]
+
+        def oracle_loss(s, cast):
+            r = OM.aasvc_forward(s, AASVC_VC2, cast(xs), ilens, cast(ys), olens, dp_inputs=cast(xs), noise=cast(noise), training=True, drop=False)
+            l1r = OM.l1_loss(r["after_outs"], r["before_outs"], r["ys"], r["olens"])
+            fsr = OM.forward_sum_loss(r["log_p_attn"], r["ilens"], r["olens_reduced"])
+            durr = r["dur_nll"].sum()
+            return l1r + 2.0 * (fsr + r["bin_loss"]) + durr, (float(l1r.detach()), float(fsr.detach()), float(durr.detach()), r["ds"].detach().float())
+        ref64, (l1r, fsr, durr, ds_ref) = _oracle_grads(oracle_loss, sd, names, torch.float64)
+        ref32, aux32 = _oracle_grads(oracle_loss, sd, names, torch.float32)
+        res.append((bool(torch.equal(aux32[3], ds_ref)), "C3: the float64 and the fp32 oracle find the same alignment"))
+
+        def run(staged):
+            model.duration_predictor.noise = noise
+            K.manual_seed(1234)
+            K.reset_op_counter()
+            opt.zero_grad()
+            ob = OverlappedBackward(model, opt, None, 1, force=True) if staged else None
+            with (ob.forward_context() if staged else torch.enable_grad()):
+                ret = model(xs.to(DEV), ilens, ys.to(DEV), olens, xs.to(DEV), dp_lengths=ilens)
+                l1 = L.L1Loss()(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+                fs = L.ForwardSumLoss()(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+                dur = torch.sum(ret["dur_nll"].float())
+            if staged:
+                ob.backward({"decoder": l1, "align": 2.0 * (fs + ret["bin_loss"]) + dur}, reduce=False, scale=1.0)
+            else:
+                (l1 + 2.0 * (fs + ret["bin_loss"]) + dur).backward()
+                Fn.side_join()
+            torch.cuda.synchronize()
+            return ret["ds"].detach().float().cpu(), float(l1.detach()), float(fs.detach()), float(dur.detach())
+
+        for staged in (False, True):
+            ds, l1, fs, dur = run(staged)
+            tag = "C3 fp32 staged backward (dp_plan)" if staged else "C3 fp32 one-shot backward"
+            res.append(cmp(f"{tag}: durations (bit-exact)", ds, ds_ref, 0))
+            res.append((abs(l1 - l1r) < 2e-4 and abs(fs - fsr) < 5e-4 and abs(dur - durr) < 2e-3 * max(1.0, abs(durr)),
+                        f"{tag}: l1 {l1:.6f}/{l1r:.6f} forward-sum {fs:.5f}/{fsr:.5f} dur {dur:.4f}/{durr:.4f}"))
+            _grad_verdict(res, tag, model, names, ref64, ref32)
+        g32 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        del opt, model
+        torch.cuda.empty_cache()
+        Fn.set_compute_dtype(torch.bfloat16)
+        torch.manual_seed(0)
+        model = M.AASVC(**AASVC_VC2).to(DEV).train()
+        _kill_dropout(model)
+        opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=True)
+        ds16, *_ = run(False)
+        g16 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        moved = float((ds16 != ds_ref).float().mean())
+        flat = _group_rel(names, g16, g32, lambda k: "all")[0][1]
+        per = _group_rel(names, g16, g32, _layer_group)
+        res.append((flat <= 0.1 or moved > 0, f"C3 bf16 (the timed path) vs fp32 flat gradient: rel-L2 {flat:.3e} (<= 0.1 when bf16 finds the fp32 alignment; "
+                    f"{moved:.2%} of the durations differ)"))
+        res.append((moved <= 0.1 and flat <= 0.5, "C3 bf16 vs fp32 per layer: " + ", ".join(f"{g} {e:.2f}" for g, e in per)))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
+def fused_layers_match_modular_bf16():
+    """The fused transformer-layer functions (ops/fused_layers.py: one autograd node, 4 / 6 launches forward and 5 / 7 backward per
+    encoder / decoder layer) against the modular path of modules.py (one node per operation) on the SAME model, batch and
+    dropout seeds -- the masks are functions of (seed, element index) and both paths draw their seeds in the same order, so the
+    two steps differ only by bf16 rounding of intermediates: VTN vc1 at full size (D = 384, d_k = 96, B = 32) and VTN-small
+    (D = 256, d_k = 64), training mode with all dropouts on, and eval mode."""
+    import bench
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.ops import kernels_block as KB
+    from seq2seq_vc_amd.optim import FlatAdam
+    res = []
+    small = dict(idim=80, odim=80, adim=256, aheads=4, elayers=2, eunits=1024, dlayers=2, dunits=1024, decoder_reduction_factor=4)
+    try:
+        Fn.set_compute_dtype(torch.bfloat16)
+        Fn.enable_side_streams(4)
+        for name, cfgs, B in (("VTN vc1 B32", bench.VTN_VC1, 32), ("VTN-small B8", small, 8)):
+            xs, ilens, ys, labels, olens = bench.canonical_batch(B)
+            torch.manual_seed(0)
+            model = M.VTN(**cfgs).to(DEV).train()
+            opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=True)
+
+            def run(fused, train=True):
+                KB._DISABLED = not fused
+                model.train(train)
+                K.manual_seed(4242)
+                K.reset_op_counter()
+                opt.zero_grad()
+                launches0 = None
+                with torch.set_grad_enabled(train):
+                    out = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+                    l1, bce = L.Seq2SeqLoss(10.0)(out[0], out[1], out[2], out[3], out[4], out[5])
+                if train:
+                    (l1 + bce).backward()
+                    Fn.side_join()
+                torch.cuda.synchronize()
+                return out, float(l1.detach()), float(bce.detach()), opt.flat_g.clone()
+
+            of, l1f, bcef, gf = run(True)
+            of2, l1f2, bcef2, gf2 = run(True)
+            om, l1m, bcem, gm = run(False)
+            res.append((l1f == l1f2 and bcef == bcef2 and bool(torch.equal(gf, gf2)), f"{name}: fused step is reproducible bit for bit"))
+            res.append((abs(l1f - l1m) < 5e-3 and abs(bcef - bcem) < 5e-3, f"{name}: losses fused {l1f:.5f}/{bcef:.5f} vs modular {l1m:.5f}/{bcem:.5f}"))
+            rel = float((gf.double() - gm.double()).norm() / gm.double().norm())
+            res.append((rel < 0.05, f"{name}: flat gradient fused vs modular rel-L2 {rel:.3e} (< 0.05: bf16 rounding of intermediates only)"))
+            res.append(cmp(f"{name}: after_outs fused vs modular", of[0], om[0].detach().float().cpu(), 0.15, l1_tol=0.01))
+            for i in range(len(of[6][0])):
+                res.append(cmp(f"{name}: att_ws[{i}] fused vs modular", of[6][0][i], om[6][0][i].detach().float().cpu(), 3e-2))
+            oe, l1e, bcee, _ = run(True, train=False)
+            ome, l1me, bceme, _ = run(False, train=False)
+            res.append((abs(l1e - l1me) < 5e-3 and abs(bcee - bceme) < 5e-3, f"{name}: eval-mode losses fused {l1e:.5f}/{bcee:.5f} vs modular {l1me:.5f}/{bceme:.5f}"))
+            del opt, model
+    finally:
+        from seq2seq_vc_amd.ops import kernels_block as KB2
+        KB2._DISABLED = os.environ.get("S2SVC_NO_FUSED_BLOCKS", "0") == "1"
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
 TTS_V1 = dict(idim=78, odim=80, dprenet_layers=2, dprenet_units=256, adim=384, aheads=4, elayers=6, eunits=1536, dlayers=6,
               dunits=1536, postnet_layers=5, postnet_filts=5, postnet_chans=256, use_batch_norm=True,
               encoder_normalize_before=True, decoder_normalize_before=False, encoder_concat_after=False,
