@@ -349,7 +349,7 @@ int s2svc_attn_fused_bwd(int B, int H, int T1, int T2, int dk, const void* q, in
 
 /* ========================================================================================== */
 /* Fused attention SUB-LAYERS (csrc/attn_block.hip), bf16, T1, T2 <= 64, (D, d_k) in          */
-/* {(256,64),(384,96),(512,128)}: one workgroup per (utterance, head), ONE launch for          */
+/* {(256,64),(384,96)}: one workgroup per (utterance, head), ONE launch for                    */
 /*   fwd: [LayerNorm(x)] -> this head's Q (K, V) projection -> mask, softmax, dropout, P.V     */
 /*   bwd: [dropout mask | LayerNorm'] of the residual-stream gradient -> dCtx = dA.Wo -> dQ,dK,dV */
 /* replaces the norm -> self_attn / src_attn -> dropout -> residual lines of                   */

@@ -25,7 +25,7 @@ def sources():
 def build_library(force=False, verbose=True):
     """Compile csrc/*.hip -> csrc/libs2svc_hip.so for gfx950 (in-tree, so it travels to the GPU box)."""
     srcs = [os.path.join(CSRC, f) for f in sources()]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "rowblock.h"),
                    os.path.join(_HERE, "..", "include", "s2svc_hip.h")]
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(p) for p in deps)

@@ -16,11 +16,8 @@
 // image of the normalised rows.  The attention part is csrc/attn_fused.hip with its operands already in LDS.
 // Dropout masks are functions of (seed, element index) -- (seed of the residual dropout, row * D + column) and
 // (seed of the attention dropout, index in the attention map) -- exactly the masks the unfused kernels draw.
-#include "common.h"
+#include "rowblock.h"
 #include "../../include/s2svc_hip.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 namespace {
 
@@ -39,24 +36,38 @@ __device__ __forceinline__ float grp16_sum(float v) {
 }
 __device__ __forceinline__ bf16x8_t zero8() { return (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
 
-// rows [0, R) x dk of a (rows, ld) matrix -> LDS row-major with pitch dk+8 (zero rows past R)
-__device__ __forceinline__ void stage_rows(const bf16_t* g, int64_t ld, int R, int dk, bf16_t* lds) {
-  const int ppr = dk / 8;
-  for (int p = threadIdx.x; p < 64 * ppr; p += 256) {
-    const int row = p / ppr, c = p - row * ppr;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < R) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
-    *reinterpret_cast<uint4*>(lds + row * (dk + 8) + c * 8) = v;
+// rows [0, R) x DK of a (rows, ld) matrix -> LDS, in two halves so that the loads of several tiles (and of the row prologue)
+// are in flight together: stage_load puts this thread's DK / 32 16-byte pieces into registers, stage_store* writes them.
+//   row-major image: lds[row * (DK + 8) + d]     (piece p = t + 256 * i: row = p / (DK/8), c = p % (DK/8))
+//   transposed image: lds[d * TP + row]          (piece p: row = p % 64, c = p / 64: conflict-free 2-byte LDS writes)
+template <int DK, bool TRANSPOSED>
+__device__ __forceinline__ void stage_load(const bf16_t* g, int64_t ld, int R, uint4 (&v)[DK / 32]) {
+  constexpr int ppr = DK / 8;
+#pragma unroll
+  for (int i = 0; i < DK / 32; ++i) {
+    const int p = threadIdx.x + 256 * i;
+    const int row = TRANSPOSED ? p % 64 : p / ppr, c = TRANSPOSED ? p / 64 : p % ppr;
+    v[i] = make_uint4(0, 0, 0, 0);
+    if (row < R) v[i] = *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
   }
 }
-// the same rows, transposed: lds[d * TP + row] (zero columns past R)
-__device__ __forceinline__ void stage_rows_t(const bf16_t* g, int64_t ld, int R, int dk, bf16_t* lds) {
-  const int ppr = dk / 8;
-  for (int p = threadIdx.x; p < 64 * ppr; p += 256) {
-    const int row = p % 64, c = p / 64;          // consecutive threads -> consecutive rows: conflict-free 2-byte LDS writes
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < R) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+template <int DK>
+__device__ __forceinline__ void stage_store(const uint4 (&v)[DK / 32], bf16_t* lds) {
+  constexpr int ppr = DK / 8;
+#pragma unroll
+  for (int i = 0; i < DK / 32; ++i) {
+    const int p = threadIdx.x + 256 * i;
+    const int row = p / ppr, c = p % ppr;
+    *reinterpret_cast<uint4*>(lds + row * (DK + 8) + c * 8) = v[i];
+  }
+}
+template <int DK>
+__device__ __forceinline__ void stage_store_t(const uint4 (&v)[DK / 32], bf16_t* lds) {
+#pragma unroll
+  for (int i = 0; i < DK / 32; ++i) {
+    const int p = threadIdx.x + 256 * i;
+    const int row = p % 64, c = p / 64;
+    const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       lds[(c * 8 + 2 * e) * TP + row] = (bf16_t)(w[e] & 0xffffu);
@@ -118,76 +129,93 @@ struct ab_fwd_args {
   float scale, p;
   const uint64_t* seed_base;
   uint64_t seed_off;
-  bf16_t* attn;               // (B, H, T1, ld) pre-dropout probabilities
+  bf16_t* attn;               // (B, H, T1, ld) pre-dropout probabilities, ld % 8 == 0
   int ld;
   bf16_t* out;                // (B, T1, D) context vectors
 };
 
 template <int DK, int D, int NPROJ>
-__global__ __launch_bounds__(256) void attn_block_fwd_kernel(ab_fwd_args a) {
-  constexpr int KP = DK + 8, YP = D + 8;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void attn_block_fwd_kernel(ab_fwd_args a) {
+  constexpr int KP = DK + 8, YP = D + 8, KS = D / 32, VPR = D / 8;
   constexpr int NT = NPROJ * DK / 16;            // 16-column tiles of this head's projection
   constexpr int MAXT = (NT + 3) / 4;             // per wave (tile t belongs to wave t % 4)
+  constexpr int PF = MAXT * KS <= 32 ? KS : 6;   // k steps of weight fragments in flight (4 VGPRs per tile and step)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_raw);      // [64][YP] (normalised) input rows
   bf16_t* Qs = Ys + 64 * YP;                             // [64][KP]
   bf16_t* Ks = Qs + 64 * KP;                             // [64][KP]
   bf16_t* Vs = Ks + 64 * KP;                             // [64][KP]  (row-major V: only for the store of the packed projection)
   bf16_t* Vt = Vs + 64 * KP;                             // [DK][TP]
-  bf16_t* Pw = Vt + DK * TP;                             // [4][16][TP]
+  bf16_t* Pw = Vt + DK * TP;                             // [4][16][TP]  dropped probabilities (A operand of P.V)
+  bf16_t* Pa = Pw + 4 * 16 * TP;                         // [4][16][TP]  probabilities before dropout (the attention map's rows)
   const int H = a.H, T1 = a.T1, T2 = a.T2;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const uint64_t seed = (a.seed_base ? *a.seed_base : 0ull) + a.seed_off;
   const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
   const int kl = a.klen ? (a.klen[b] < T2 ? a.klen[b] : T2) : T2;
-  if (NPROJ == 1) {                                      // memory keys / values: issued first, they do not depend on the prologue
-    stage_rows(a.k + (int64_t)b * a.kbs + h * DK, a.ldk, T2, DK, Ks);
-    stage_rows_t(a.v + (int64_t)b * a.vbs + h * DK, a.ldv, T2, DK, Vt);
+  // weight fragments of this wave's tiles: the first PF k steps are in flight across the whole prologue
+  const bf16_t* wrow[MAXT];
+  bool live[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int t = j * 4 + wave;                      // tile index (may be >= NT for the last j)
+    live[j] = t < NT;
+    const int n0 = (t < NT ? t : 0) * 16;
+    const int which = n0 / DK, c0 = n0 - which * DK;
+    wrow[j] = a.w + ((int64_t)which * D + h * DK + c0 + lr) * D + lg * 8;
   }
-  // ---- prologue: rows of this utterance -> (LayerNorm) -> Ys; a wave owns rows wave, wave + 4, ... ----
+  bf16x8_t pre[PF][MAXT];
+  rowblock::preload_b<MAXT, PF>(wrow, live, pre);
   {
-    constexpr int VPR = D / 8;                           // 16-byte vectors per row (<= 64)
+    uint4 kreg[DK / 32], vreg[DK / 32], xr[D / 32];
+    if (NPROJ == 1) {                                    // memory keys / values
+      stage_load<DK, false>(a.k + (int64_t)b * a.kbs + h * DK, a.ldk, T2, kreg);
+      stage_load<DK, true>(a.v + (int64_t)b * a.vbs + h * DK, a.ldv, T2, vreg);
+    }
+    rowblock::tile_load<D>(a.x + (int64_t)b * T1 * D, T1, xr);
+    rowblock::tile_store<D>(xr, Ys);
+    if (NPROJ == 1) {
+      stage_store<DK>(kreg, Ks);
+      stage_store_t<DK>(vreg, Vt);
+    }
+  }
+  rowblock::lds_barrier();
+  // ---- prologue: LayerNorm of rows wave*16 .. +15 of the LDS image, in place (rolled loop: cold code is what costs) ----
+  if (a.gamma) {
     const bool act = lane < VPR;
     float g8[8], b8[8];
-    if (a.gamma && act) { load_f32x8(a.gamma + lane * 8, g8); load_f32x8(a.beta + lane * 8, b8); }
-#pragma unroll 4
+    if (act) { load_f32x8(a.gamma + lane * 8, g8); load_f32x8(a.beta + lane * 8, b8); }
+#pragma unroll 2
     for (int rr = 0; rr < 16; ++rr) {
-      const int row = rr * 4 + wave;
+      const int row = wave * 16 + rr;
+      bf16_t* yrow = Ys + row * YP + lane * 8;
       float vv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) vv[e] = 0.f;
-      const int64_t base = ((int64_t)b * T1 + row) * D;
-      if (row < T1 && act) unpack_bf16x8(*reinterpret_cast<const uint4*>(a.x + base + lane * 8), vv);
-      if (a.gamma) {
-        float sum = 0.f;
+      if (act) unpack_bf16x8(*reinterpret_cast<const uint4*>(yrow), vv);
+      float sum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sum += vv[e];
-        const float mean = wave_sum(sum) / (float)D;
-        float sq = 0.f;
-        if (act) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = vv[e] - mean; sq += d * d; }
-        }
-        const float var = wave_sum(sq) / (float)D;
-        const float rstd = 1.0f / sqrtf(var + a.eps);
-        if (act) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) vv[e] = (vv[e] - mean) * rstd * g8[e] + b8[e];
-        }
-        if (row < T1 && (row % H) == h) {
-          if (act) *reinterpret_cast<uint4*>(a.y + base + lane * 8) = pack_bf16x8(vv);
-          if (lane == 0) { a.mean[(int64_t)b * T1 + row] = mean; a.rstd[(int64_t)b * T1 + row] = rstd; }
-        }
-      }
+      for (int e = 0; e < 8; ++e) sum += vv[e];
+      const float mean = wave_sum(sum) / (float)D;
+      float sq = 0.f;
       if (act) {
-        uint4 o = make_uint4(0, 0, 0, 0);
-        if (row < T1) o = pack_bf16x8(vv);
-        *reinterpret_cast<uint4*>(Ys + row * YP + lane * 8) = o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = vv[e] - mean; sq += d * d; }
       }
+      const float var = wave_sum(sq) / (float)D;
+      const float rstd = 1.0f / sqrtf(var + a.eps);
+      if (act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vv[e] = (vv[e] - mean) * rstd * g8[e] + b8[e];
+        const uint4 o = row < T1 ? rowblock::pack8(vv) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(yrow) = o;
+        if (row < T1 && (row % H) == h) *reinterpret_cast<uint4*>(a.y + ((int64_t)b * T1 + row) * D + lane * 8) = o;
+      }
+      if (lane == 0 && row < T1 && (row % H) == h) { a.mean[(int64_t)b * T1 + row] = mean; a.rstd[(int64_t)b * T1 + row] = rstd; }
     }
+    rowblock::lds_barrier();
   }
-  __syncthreads();
   // ---- projection: [64 x D] . W_h^T -> Q (K, V) of this head; wave w owns tiles w, w + 4, ... ----
   {
     f32x4_t acc[MAXT][4];
@@ -195,28 +223,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(ab_fwd_args a) {
     for (int j = 0; j < MAXT; ++j)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[j][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* wrow[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const int t = j * 4 + wave;                      // tile index (may be >= NT for the last j)
-      const int n0 = (t < NT ? t : 0) * 16;
-      const int which = n0 / DK, c0 = n0 - which * DK;
-      wrow[j] = a.w + ((int64_t)which * D + h * DK + c0 + lr) * D + lg * 8;
-    }
-#pragma unroll
-    for (int ks = 0; ks < D / 32; ++ks) {
-      bf16x8_t af[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const bf16x8_t*>(Ys + (mt * 16 + lr) * YP + ks * 32 + lg * 8);
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j) {
-        if (j * 4 + wave < NT) {
-          const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(wrow[j] + ks * 32);
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[j][mt], 0, 0, 0);
-        }
-      }
-    }
+    rowblock::mma_rows64<MAXT, KS, PF>(Ys, YP, wrow, live, pre, acc);
     // bias, then into the LDS images the attention part reads (accumulator layout: row mt*16 + lg*4 + r, column c0 + lr)
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
@@ -225,26 +232,21 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(ab_fwd_args a) {
         const int n0 = t * 16;
         const int which = n0 / DK, c0 = n0 - which * DK;
         const float bs = a.bias ? a.bias[which * D + h * DK + c0 + lr] : 0.f;
-        bf16_t* dst = which == 0 ? Qs : (which == 1 ? Ks : Vs);
+        bf16_t* dst = (which == 0 ? Qs : (which == 1 ? Ks : Vs)) + (lg * 4) * KP + c0 + lr;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          bf16_t pk[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            pk[r] = f2bf(acc[j][mt][r] + bs);
-            dst[(mt * 16 + lg * 4 + r) * KP + c0 + lr] = pk[r];
-          }
-          if (which == 2) {
-            uint2 u;
-            u.x = (uint32_t)pk[0] | ((uint32_t)pk[1] << 16);
-            u.y = (uint32_t)pk[2] | ((uint32_t)pk[3] << 16);
-            *reinterpret_cast<uint2*>(Vt + (c0 + lr) * TP + mt * 16 + lg * 4) = u;
-          }
+          const uint32_t p01 = rowblock::pack2(acc[j][mt][0] + bs, acc[j][mt][1] + bs);
+          const uint32_t p23 = rowblock::pack2(acc[j][mt][2] + bs, acc[j][mt][3] + bs);
+          dst[(mt * 16 + 0) * KP] = (bf16_t)(p01 & 0xffffu);
+          dst[(mt * 16 + 1) * KP] = (bf16_t)(p01 >> 16);
+          dst[(mt * 16 + 2) * KP] = (bf16_t)(p23 & 0xffffu);
+          dst[(mt * 16 + 3) * KP] = (bf16_t)(p23 >> 16);
+          if (which == 2) *reinterpret_cast<uint2*>(Vt + (c0 + lr) * TP + mt * 16 + lg * 4) = make_uint2(p01, p23);
         }
       }
     }
   }
-  __syncthreads();
+  rowblock::lds_barrier();
   // the packed projection goes to HBM for the backward pass (rows < T1)
   {
     bf16_t* pb = a.proj + (int64_t)b * T1 * (NPROJ * D) + h * DK;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(ab_fwd_args a) {
     }
   }
   bf16_t* pw = Pw + wave * 16 * TP;
+  bf16_t* pa = Pa + wave * 16 * TP;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = wave * 16 + lg * 4 + r;
@@ -282,9 +285,10 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(ab_fwd_args a) {
       mx = fmaxf(mx, val[jn]);
     }
     mx = grp16_max(mx);
+    float ex[4];
     float sum = 0.f;
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn) sum += expf(val[jn] - mx);
+    for (int jn = 0; jn < 4; ++jn) { ex[jn] = expf(val[jn] - mx); sum += ex[jn]; }
     sum = grp16_sum(sum);
     const float inv = 1.f / sum;
     const int64_t arow = ((int64_t)(b * H + h) * T1 + i) * a.ld;
@@ -292,12 +296,21 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(ab_fwd_args a) {
     for (int jn = 0; jn < 4; ++jn) {
       const int j = jn * 16 + lr;
       const bool ok = j < kl && (!a.causal || j <= i);
-      const float pr = ok ? expf(val[jn] - mx) * inv : 0.f;          // masked_fill(mask, 0.0) after the softmax
-      const bf16_t pb = f2bf(pr);
-      if (i < T1 && j < a.ld) a.attn[arow + j] = pb;
+      const bf16_t pb = rowblock::cvt1(ok ? ex[jn] * inv : 0.f);     // masked_fill(mask, 0.0) after the softmax
+      pa[(lg * 4 + r) * TP + j] = pb;
       float pd = bf2f(pb);                                           // P.V consumes the stored (rounded) probabilities
       if (a.p > 0.f) pd *= dropout_scale(seed, (uint64_t)(arow + j), a.p, inv_keep);
-      pw[(lg * 4 + r) * TP + j] = f2bf(pd);
+      pw[(lg * 4 + r) * TP + j] = rowblock::cvt1(pd);
+    }
+  }
+  // the attention map's 16 rows of this wave: 16-byte stores from the wave-private tile (LDS ops of a wave execute in order)
+  {
+    const int vpr = a.ld / 8;                          // 16-byte vectors per row (<= 8)
+    for (int v = lane; v < 16 * vpr; v += 64) {
+      const int row = v / vpr, c8 = v - row * vpr;
+      const int i = wave * 16 + row;
+      if (i < T1)
+        *reinterpret_cast<uint4*>(a.attn + ((int64_t)(b * H + h) * T1 + i) * a.ld + c8 * 8) = *reinterpret_cast<const uint4*>(pa + row * TP + c8 * 8);
     }
   }
   f32x4_t o[DK / 16];
@@ -305,14 +318,14 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(ab_fwd_args a) {
   for (int dn = 0; dn < DK / 16; ++dn) o[dn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const bf16x8_t pa = *reinterpret_cast<const bf16x8_t*>(pw + lr * TP + ks * 32 + lg * 8);
+    const bf16x8_t pfr = *reinterpret_cast<const bf16x8_t*>(pw + lr * TP + ks * 32 + lg * 8);
 #pragma unroll
     for (int dn = 0; dn < DK / 16; ++dn) {
       const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(Vt + (dn * 16 + lr) * TP + ks * 32 + lg * 8);
-      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dn], 0, 0, 0);
+      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr, vb, o[dn], 0, 0, 0);
     }
   }
-  __syncthreads();       // the cooperative store of Qs above (all threads read all rows) is done: Qs rows of this wave become its staging area
+  rowblock::lds_barrier();       // the cooperative store of Qs above (all threads read all rows) is done: Qs rows of this wave become its staging area
   store_tile_rows<DK>(o, Qs + wave * 16 * KP, a.out + ((int64_t)b * T1 + wave * 16) * D + h * DK, D, T1 - wave * 16);
 }
 
@@ -351,12 +364,13 @@ struct ab_bwd_args {
 };
 
 template <int DK, int D>
-__global__ __launch_bounds__(256) void attn_block_bwd_kernel(ab_bwd_args a) {
-  constexpr int KP = DK + 8, YP = D + 8;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void attn_block_bwd_kernel(ab_bwd_args a) {
+  constexpr int KP = DK + 8, YP = D + 8, KS = D / 32, VPR = D / 8;
   constexpr int NT = DK / 16;
   constexpr int MAXT = (NT + 3) / 4;
+  constexpr int PF = KS <= 12 ? KS : 12;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* DAs = reinterpret_cast<bf16_t*>(smem_raw);     // [64][YP] dA rows; dead after the projection: dSt | Pt | dSw live there
+  bf16_t* DAs = reinterpret_cast<bf16_t*>(smem_raw);     // [64][YP] g rows -> dA rows; dead after the projection: dSt | Pt | dSw live there
   bf16_t* dSt = DAs;                                     // [64][TP]
   bf16_t* Pt = dSt + 64 * TP;                            // [64][TP]
   bf16_t* dSw = Pt + 64 * TP;                            // [4][16][TP]
@@ -365,42 +379,76 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(ab_bwd_args a) {
   bf16_t* Qt = Kt + DK * TP;                             // [DK][TP]
   bf16_t* dOt = Qt + DK * TP;                            // [DK][TP]
   bf16_t* dOs = dOt + DK * TP;                           // [64][KP] dO rows (A operand of dP)
+  bf16_t* Ss = DAs + 64 * YP;                            // prologue only (mode 1): [64][YP] LayerNorm input rows ...
+  bf16_t* Es = Ss + 64 * YP;                             // ... and [64][YP] directly arriving gradient rows (over Vs .. dOs and beyond)
   static_assert(64 * YP >= 2 * 64 * TP + 4 * 16 * TP, "the dS / P tiles must fit into the dA region");
   const int H = a.H, T1 = a.T1, T2 = a.T2;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const uint64_t seed = (a.seed_base ? *a.seed_base : 0ull) + a.seed_off;
   const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-  stage_rows(a.v + (int64_t)b * a.vbs + h * DK, a.ldv, T2, DK, Vs);
-  stage_rows_t(a.k + (int64_t)b * a.kbs + h * DK, a.ldk, T2, DK, Kt);
-  stage_rows_t(a.q + (int64_t)b * a.qbs + h * DK, a.ldq, T1, DK, Qt);
-  // ---- prologue: dA rows -> DAs ----
+  // everything this kernel reads from global memory before its first barrier is issued up front
+  const bf16_t* wrow[MAXT];
+  bool live[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int t = j * 4 + wave;
+    live[j] = t < NT;
+    wrow[j] = a.wo_t + ((int64_t)h * DK + (t < NT ? t : 0) * 16 + lr) * D + lg * 8;
+  }
+  bf16x8_t pre[PF][MAXT];
+  rowblock::preload_b<MAXT, PF>(wrow, live, pre);
+  uint4 vreg[DK / 32], kreg[DK / 32], qreg[DK / 32];
+  stage_load<DK, false>(a.v + (int64_t)b * a.vbs + h * DK, a.ldv, T2, vreg);
+  stage_load<DK, true>(a.k + (int64_t)b * a.kbs + h * DK, a.ldk, T2, kreg);
+  stage_load<DK, true>(a.q + (int64_t)b * a.qbs + h * DK, a.ldq, T1, qreg);
   {
-    constexpr int VPR = D / 8;
+    uint4 gr[D / 32];
+    rowblock::tile_load<D>(a.g + (int64_t)b * T1 * D, T1, gr);
+    if (a.mode == 1) {
+      uint4 sr[D / 32];
+      rowblock::tile_load<D>(a.s + (int64_t)b * T1 * D, T1, sr);
+      if (a.ds_extra) {
+        uint4 er[D / 32];
+        rowblock::tile_load<D>(a.ds_extra + (int64_t)b * T1 * D, T1, er);
+        rowblock::tile_store<D>(er, Es);
+      }
+      rowblock::tile_store<D>(sr, Ss);
+    }
+    rowblock::tile_store<D>(gr, DAs);
+  }
+  rowblock::lds_barrier();
+  // ---- prologue: dA rows wave*16 .. +15, in place (rolled) ----
+  if (a.mode == 1 || a.p_res > 0.f || a.hscale != 1.f) {
     const bool act = lane < VPR;
     const uint64_t rseed = (a.seed_res_base ? *a.seed_res_base : 0ull) + a.seed_res_off;
     const float rkeep = a.p_res > 0.f ? 1.f / (1.f - a.p_res) : 1.f;
     float gm[8];
     if (a.mode == 1 && act) load_f32x8(a.gamma + lane * 8, gm);
-#pragma unroll 4
+    float mu_l = 0.f, rs_l = 0.f;                        // statistics of this wave's 16 rows: one load, lane rr holds row rr's
+    if (a.mode == 1 && lane < 16 && wave * 16 + lane < T1) {
+      mu_l = a.mean[(int64_t)b * T1 + wave * 16 + lane];
+      rs_l = a.rstd[(int64_t)b * T1 + wave * 16 + lane];
+    }
+#pragma unroll 2
     for (int rr = 0; rr < 16; ++rr) {
-      const int row = rr * 4 + wave;
+      const int row = wave * 16 + rr;
       const int64_t grow = (int64_t)b * T1 + row;
       const int64_t base = grow * D;
+      const bool live_r = row < T1 && act;
+      bf16_t* drow = DAs + row * YP + lane * 8;
       float vv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) vv[e] = 0.f;
-      const bool live = row < T1 && act;
-      if (live) unpack_bf16x8(*reinterpret_cast<const uint4*>(a.g + base + lane * 8), vv);
+      if (act) unpack_bf16x8(*reinterpret_cast<const uint4*>(drow), vv);
       if (a.mode == 1) {
         float xh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) xh[e] = 0.f;
-        float mu = 0.f, rs = 0.f;
-        if (row < T1) { mu = a.mean[grow]; rs = a.rstd[grow]; }
-        if (live) unpack_bf16x8(*reinterpret_cast<const uint4*>(a.s + base + lane * 8), xh);
+        if (act) unpack_bf16x8(*reinterpret_cast<const uint4*>(Ss + row * YP + lane * 8), xh);
+        const float mu = rowblock::readlane_f(mu_l, rr), rs = rowblock::readlane_f(rs_l, rr);
         float sa = 0.f, sb = 0.f;
-        if (live) {
+        if (live_r) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             vv[e] *= gm[e];
@@ -411,21 +459,20 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(ab_bwd_args a) {
         }
         sa = wave_sum(sa) / (float)D;
         sb = wave_sum(sb) / (float)D;
-        if (live) {
+        if (live_r) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] = rs * (vv[e] - sa - xh[e] * sb);
           if (a.ds_extra) {
             float ex[8];
-            unpack_bf16x8(*reinterpret_cast<const uint4*>(a.ds_extra + base + lane * 8), ex);
+            unpack_bf16x8(*reinterpret_cast<const uint4*>(Es + row * YP + lane * 8), ex);
 #pragma unroll
             for (int e = 0; e < 8; ++e) vv[e] += ex[e];
           }
-          const uint4 dsv = pack_bf16x8(vv);
-          if ((row % H) == h) *reinterpret_cast<uint4*>(a.ds + base + lane * 8) = dsv;
+          if ((row % H) == h) *reinterpret_cast<uint4*>(a.ds + base + lane * 8) = rowblock::pack8(vv);
           // (the unfused LayerNorm backward derives dh from the unrounded values as well)
         }
       }
-      if (live) {
+      if (live_r) {
         if (a.p_res > 0.f) {
           float m[8];
           dropout_scale8(rseed, (uint64_t)(base + lane * 8), a.p_res, rkeep, m);
@@ -438,13 +485,16 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(ab_bwd_args a) {
         }
       }
       if (act) {
-        const uint4 o = pack_bf16x8(vv);                 // zeros for rows >= T1
-        *reinterpret_cast<uint4*>(DAs + row * YP + lane * 8) = o;
-        if (live && a.da && (row % H) == h) *reinterpret_cast<uint4*>(a.da + base + lane * 8) = o;
+        const uint4 o = live_r ? rowblock::pack8(vv) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(drow) = o;
+        if (live_r && a.da && (row % H) == h) *reinterpret_cast<uint4*>(a.da + base + lane * 8) = o;
       }
     }
+    rowblock::lds_barrier();                 // the s / extra tiles are dead: their region takes the attention operands
   }
-  __syncthreads();
+  stage_store<DK>(vreg, Vs);
+  stage_store_t<DK>(kreg, Kt);
+  stage_store_t<DK>(qreg, Qt);
   // ---- dO_h = dA . Wo[:, head columns]  (64 x DK, reduction over D); wave w owns tiles w, w + 4, ... ----
   {
     f32x4_t acc[MAXT][4];
@@ -452,48 +502,27 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(ab_bwd_args a) {
     for (int j = 0; j < MAXT; ++j)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[j][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const bf16_t* wrow[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const int t = j * 4 + wave;
-      wrow[j] = a.wo_t + ((int64_t)h * DK + (t < NT ? t : 0) * 16 + lr) * D + lg * 8;
-    }
-#pragma unroll
-    for (int ks = 0; ks < D / 32; ++ks) {
-      bf16x8_t af[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const bf16x8_t*>(DAs + (mt * 16 + lr) * YP + ks * 32 + lg * 8);
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j) {
-        if (j * 4 + wave < NT) {
-          const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(wrow[j] + ks * 32);
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[j][mt], 0, 0, 0);
-        }
-      }
-    }
+    rowblock::mma_rows64<MAXT, KS, PF>(DAs, YP, wrow, live, pre, acc);
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
       const int t = j * 4 + wave;
       if (t < NT) {
         const int c0 = t * 16;
+        bf16_t* dst = dOs + (lg * 4) * KP + c0 + lr;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          bf16_t pk[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            pk[r] = f2bf(acc[j][mt][r]);
-            dOs[(mt * 16 + lg * 4 + r) * KP + c0 + lr] = pk[r];
-          }
-          uint2 u;
-          u.x = (uint32_t)pk[0] | ((uint32_t)pk[1] << 16);
-          u.y = (uint32_t)pk[2] | ((uint32_t)pk[3] << 16);
-          *reinterpret_cast<uint2*>(dOt + (c0 + lr) * TP + mt * 16 + lg * 4) = u;
+          const uint32_t p01 = rowblock::pack2(acc[j][mt][0], acc[j][mt][1]);
+          const uint32_t p23 = rowblock::pack2(acc[j][mt][2], acc[j][mt][3]);
+          dst[(mt * 16 + 0) * KP] = (bf16_t)(p01 & 0xffffu);
+          dst[(mt * 16 + 1) * KP] = (bf16_t)(p01 >> 16);
+          dst[(mt * 16 + 2) * KP] = (bf16_t)(p23 & 0xffffu);
+          dst[(mt * 16 + 3) * KP] = (bf16_t)(p23 >> 16);
+          *reinterpret_cast<uint2*>(dOt + (c0 + lr) * TP + mt * 16 + lg * 4) = make_uint2(p01, p23);
         }
       }
     }
   }
-  __syncthreads();                 // dO complete; every wave is past its DAs reads: the region now holds dSt / Pt / dSw
+  rowblock::lds_barrier();                 // dO / V / K^T / Q^T complete; every wave is past its DAs reads: the region now holds dSt / Pt / dSw
   // ---- attention backward (csrc/attn_fused.hip) ----
   bf16x8_t da[DK / 32];
 #pragma unroll
@@ -528,14 +557,14 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(ab_bwd_args a) {
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
       const int j = jn * 16 + lr;
-      const bf16_t ds = f2bf(pv[jn] * (t[jn] - dot) * a.scale);
-      const bf16_t pd = f2bf(pv[jn] * m[jn]);
+      const bf16_t ds = rowblock::cvt1(pv[jn] * (t[jn] - dot) * a.scale);
+      const bf16_t pd = rowblock::cvt1(pv[jn] * m[jn]);
       dsw[il * TP + j] = ds;
       dSt[j * TP + i] = ds;
       Pt[j * TP + i] = pd;
     }
   }
-  __syncthreads();
+  rowblock::lds_barrier();
   {
     f32x4_t acc[DK / 16];
 #pragma unroll
@@ -575,9 +604,12 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(ab_bwd_args a) {
 }
 
 template <int DK, int D, int NPROJ>
-constexpr size_t fwd_lds_bytes() { return sizeof(bf16_t) * (64 * (D + 8) + 3 * 64 * (DK + 8) + DK * TP + 4 * 16 * TP); }
+constexpr size_t fwd_lds_bytes() { return sizeof(bf16_t) * (64 * (D + 8) + 3 * 64 * (DK + 8) + DK * TP + 2 * 4 * 16 * TP); }
 template <int DK, int D>
-constexpr size_t bwd_lds_bytes() { return sizeof(bf16_t) * (64 * (D + 8) + 2 * 64 * (DK + 8) + 3 * DK * TP); }
+constexpr size_t bwd_lds_bytes() {
+  constexpr size_t main_b = sizeof(bf16_t) * (64 * (D + 8) + 2 * 64 * (DK + 8) + 3 * DK * TP), pro_b = sizeof(bf16_t) * 3 * 64 * (D + 8);
+  return main_b > pro_b ? main_b : pro_b;          // the prologue holds three row tiles (g, s, extra) where the attention operands go later
+}
 
 template <int DK, int D, int NPROJ>
 int launch_fwd(int B, const ab_fwd_args& a, hipStream_t st) {
@@ -613,7 +645,7 @@ bool al16(const void* p) { return ((uintptr_t)p) % 16 == 0; }
 extern "C" int s2svc_attn_block_supported(int dtype, int T1, int T2, int D, int H) {
   if (dtype != S2S_BF16 || H < 1 || D % H != 0) return 0;
   const int dk = D / H;
-  return T1 >= 1 && T1 <= 64 && T2 >= 1 && T2 <= 64 && ((D == 256 && dk == 64) || (D == 384 && dk == 96) || (D == 512 && dk == 128));
+  return T1 >= 1 && T1 <= 64 && T2 >= 1 && T2 <= 64 && ((D == 256 && dk == 64) || (D == 384 && dk == 96));
 }
 
 extern "C" int s2svc_attn_block_fwd(int B, int H, int T1, int T2, int D, int nproj, const void* x, const float* gamma, const float* beta,
@@ -621,10 +653,10 @@ extern "C" int s2svc_attn_block_fwd(int B, int H, int T1, int T2, int D, int npr
                                     const void* k, int64_t ldk, int64_t kbs, const void* v, int64_t ldv, int64_t vbs,
                                     const int32_t* klen, int causal, float scale, float drop_p, const uint64_t* seed_base,
                                     uint64_t seed_off, void* attn, int ld, void* out, void* stream) {
-  S2S_REQUIRE(s2svc_attn_block_supported(S2S_BF16, T1, T2, D, H), "attn_block_fwd: unsupported shape (bf16, T <= 64, (D, d_k) in {(256,64),(384,96),(512,128)})");
+  S2S_REQUIRE(s2svc_attn_block_supported(S2S_BF16, T1, T2, D, H), "attn_block_fwd: unsupported shape (bf16, T <= 64, (D, d_k) in {(256,64),(384,96)})");
   S2S_REQUIRE(nproj == 3 || nproj == 1, "attn_block_fwd: nproj must be 3 (self-attention) or 1 (source attention)");
   S2S_REQUIRE(nproj == 1 || T1 == T2, "attn_block_fwd: self-attention needs T1 == T2");
-  S2S_REQUIRE(x && w && proj && attn && out && ld >= T2, "attn_block_fwd: missing operand");
+  S2S_REQUIRE(x && w && proj && attn && out && ld >= T2 && ld % 8 == 0 && ld <= 64 && al16(attn), "attn_block_fwd: missing operand (attn rows: ld % 8 == 0, 16-byte aligned)");
   S2S_REQUIRE(al16(x) && al16(w) && al16(proj) && al16(out) && (!gamma || (al16(gamma) && al16(beta) && al16(y) && mean && rstd)),
               "attn_block_fwd: 16-byte aligned operands (and y / mean / rstd with a LayerNorm)");
   if (nproj == 1)
@@ -641,12 +673,10 @@ extern "C" int s2svc_attn_block_fwd(int B, int H, int T1, int T2, int D, int npr
   hipStream_t st = (hipStream_t)stream;
   if (nproj == 3) {
     if (D == 256) return launch_fwd<64, 256, 3>(B, a, st);
-    if (D == 384) return launch_fwd<96, 384, 3>(B, a, st);
-    return launch_fwd<128, 512, 3>(B, a, st);
+    return launch_fwd<96, 384, 3>(B, a, st);
   }
   if (D == 256) return launch_fwd<64, 256, 1>(B, a, st);
-  if (D == 384) return launch_fwd<96, 384, 1>(B, a, st);
-  return launch_fwd<128, 512, 1>(B, a, st);
+  return launch_fwd<96, 384, 1>(B, a, st);
 }
 
 extern "C" int s2svc_attn_block_bwd(int B, int H, int T1, int T2, int D, int mode, const void* g, const void* s, const float* mean,
@@ -656,7 +686,7 @@ extern "C" int s2svc_attn_block_bwd(int B, int H, int T1, int T2, int D, int mod
                                     int64_t ldv, int64_t vbs, const void* attn, const void* dattn, int ld, float scale, float drop_p,
                                     const uint64_t* seed_base, uint64_t seed_off, void* dq, int64_t lddq, int64_t dqbs, void* dk_out,
                                     int64_t lddk, int64_t dkbs, void* dv, int64_t lddv, int64_t dvbs, void* stream) {
-  S2S_REQUIRE(s2svc_attn_block_supported(S2S_BF16, T1, T2, D, H), "attn_block_bwd: unsupported shape (bf16, T <= 64, (D, d_k) in {(256,64),(384,96),(512,128)})");
+  S2S_REQUIRE(s2svc_attn_block_supported(S2S_BF16, T1, T2, D, H), "attn_block_bwd: unsupported shape (bf16, T <= 64, (D, d_k) in {(256,64),(384,96)})");
   S2S_REQUIRE(mode == 0 || mode == 1, "attn_block_bwd: mode 0 (dropout mask) or 1 (LayerNorm backward)");
   S2S_REQUIRE(g && wo_t && q && k && v && attn && dq && dk_out && dv && ld >= T2, "attn_block_bwd: missing operand");
   S2S_REQUIRE(mode == 0 || (s && mean && rstd && gamma && ds && al16(s) && al16(gamma) && al16(ds) && (!ds_extra || al16(ds_extra))),
@@ -677,6 +707,5 @@ extern "C" int s2svc_attn_block_bwd(int B, int H, int T1, int T2, int D, int mod
   a.dq = (bf16_t*)dq; a.lddq = lddq; a.dqbs = dqbs; a.dk = (bf16_t*)dk_out; a.lddk = lddk; a.dkbs = dkbs; a.dv = (bf16_t*)dv; a.lddv = lddv; a.dvbs = dvbs;
   hipStream_t st = (hipStream_t)stream;
   if (D == 256) return launch_bwd<64, 256>(B, a, st);
-  if (D == 384) return launch_bwd<96, 384>(B, a, st);
-  return launch_bwd<128, 512>(B, a, st);
+  return launch_bwd<96, 384>(B, a, st);
 }

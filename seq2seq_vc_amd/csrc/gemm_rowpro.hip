@@ -14,6 +14,7 @@
 // second Linear.  Unfused these are a 5 us LayerNorm / element-wise launch in front of a 12 us GEMM on the dependent chain of
 // the training step; the prologue is recomputed by the N / 256 column blocks of a row tile instead (64 x D values: trivial).
 #include "gemm_common.h"
+#include "rowblock.h"
 
 namespace {
 
@@ -34,39 +35,48 @@ struct rp_args {
 };
 
 template <int D>
-__global__ __launch_bounds__(256) void gemm_rowpro_kernel(rp_args a) {
-  constexpr int YP = D + 8;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_rowpro_kernel(rp_args a) {
+  constexpr int YP = D + 8, KS = D / 32, VPR = D / 8;
+  constexpr int PF = KS <= 12 ? KS : 12;                 // k steps of weight fragments in flight (all of them up to D = 384)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_raw);              // [64][YP]; after the k loop: 4 x (32 x 64) fp32 epilogue tiles
+  bf16_t* Ys = reinterpret_cast<bf16_t*>(smem_raw);              // [64][YP]; after the k loop: 4 x (64 x 64) fp32 epilogue tiles
   const int M = a.e.M, N = a.e.N;
   const int m_base = blockIdx.x * 64, n_base = blockIdx.y * 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   // weight rows of this wave's four 16-column tiles (clamped: columns >= N are computed on a valid row and dropped by the epilogue)
   const bf16_t* wrow[4];
+  const bool live[4] = {true, true, true, true};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int n = n_base + wave * 64 + j * 16 + lr;
     n = n < N ? n : N - 1;
     wrow[j] = a.w + (int64_t)n * D + lg * 8;
   }
+  bf16x8_t pre[PF][4];
+  rowblock::preload_b<4, PF>(wrow, live, pre);           // in flight across the whole prologue
   {
-    constexpr int VPR = D / 8;
+    uint4 xr[D / 32];
+    rowblock::tile_load<D>(a.x + (int64_t)m_base * D, M - m_base, xr);
+    rowblock::tile_store<D>(xr, Ys);
+  }
+  rowblock::lds_barrier();
+  if (a.mode != 0) {                                     // rows wave*16 .. +15 of the LDS image, in place (rolled: cold code is what costs)
     const bool act = lane < VPR;
     const bool writer = blockIdx.y == 0;
     float g8[8], b8[8];
     if (a.mode == 1 && act) { load_f32x8(a.gamma + lane * 8, g8); load_f32x8(a.beta + lane * 8, b8); }
     const uint64_t aseed = (a.seed_a_base ? *a.seed_a_base : 0ull) + a.seed_a_off;
     const float akeep = a.p_a > 0.f ? 1.f / (1.f - a.p_a) : 1.f;
-#pragma unroll 4
+#pragma unroll 2
     for (int rr = 0; rr < 16; ++rr) {
-      const int row = rr * 4 + wave;
+      const int row = wave * 16 + rr;
       const int m = m_base + row;
       const int64_t base = (int64_t)m * D;
+      bf16_t* yrow = Ys + row * YP + lane * 8;
       float vv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) vv[e] = 0.f;
-      const bool live = m < M && act;
-      if (live) unpack_bf16x8(*reinterpret_cast<const uint4*>(a.x + base + lane * 8), vv);
+      if (act) unpack_bf16x8(*reinterpret_cast<const uint4*>(yrow), vv);
       if (a.mode == 1) {
         float sum = 0.f;
 #pragma unroll
@@ -83,12 +93,9 @@ __global__ __launch_bounds__(256) void gemm_rowpro_kernel(rp_args a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] = (vv[e] - mean) * rstd * g8[e] + b8[e];
         }
-        if (writer && m < M) {
-          if (act) *reinterpret_cast<uint4*>(a.y + base + lane * 8) = pack_bf16x8(vv);
-          if (lane == 0) { a.mean[m] = mean; a.rstd[m] = rstd; }
-        }
-      } else if (a.mode == 2 && live) {
-        if (a.p_a > 0.f) {
+        if (writer && m < M && lane == 0) { a.mean[m] = mean; a.rstd[m] = rstd; }
+      } else {
+        if (a.p_a > 0.f && act && m < M) {
           float mk[8];
           dropout_scale8(aseed, (uint64_t)(base + lane * 8), a.p_a, akeep, mk);
 #pragma unroll
@@ -98,45 +105,96 @@ __global__ __launch_bounds__(256) void gemm_rowpro_kernel(rp_args a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] *= a.hscale;
         }
-        if (writer && a.y) *reinterpret_cast<uint4*>(a.y + base + lane * 8) = pack_bf16x8(vv);
       }
       if (act) {
-        uint4 o = make_uint4(0, 0, 0, 0);
-        if (m < M) o = pack_bf16x8(vv);
-        *reinterpret_cast<uint4*>(Ys + row * YP + lane * 8) = o;
+        const uint4 o = rowblock::pack8(vv);
+        *reinterpret_cast<uint4*>(yrow) = o;
+        if (writer && a.y && m < M) *reinterpret_cast<uint4*>(a.y + base + lane * 8) = o;
       }
     }
+    rowblock::lds_barrier();
   }
-  __syncthreads();
-  f32x4_t acc[4][4];                                     // [16-row tile][16-column tile]
+  f32x4_t acc[4][4];                                     // [16-column tile][16-row tile]
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < D / 32; ++ks) {
-    bf16x8_t af[4], bf[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(wrow[j] + ks * 32);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const bf16x8_t*>(Ys + (mt * 16 + lr) * YP + ks * 32 + lg * 8);
+    for (int mt = 0; mt < 4; ++mt) acc[j][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  rowblock::mma_rows64<4, KS, PF>(Ys, YP, wrow, live, pre, acc);
+  rowblock::lds_barrier();                                       // every wave is past its A reads: the region becomes epilogue staging
+  // ---- epilogue (the arithmetic of gemm_common.h's epilogue_tile: bias, activation, dropout, relu' mask, residual) in two
+  // phases: every global load of the wave's 64 x 64 tile (mask and residual rows, 8 passes of 8 rows) is issued first and parked
+  // in LDS slots the same lane reads back, then a ROLLED loop does the arithmetic and the 16-byte stores -- with one wave per SIMD a
+  // load inside the pass loop would cost a memory round trip per pass ----
+  float* cs = reinterpret_cast<float*>(smem_raw) + wave * (64 * 64);
+  uint4* es = reinterpret_cast<uint4*>(smem_raw + 4 * 64 * 64 * sizeof(float)) + wave * 512;
+  uint4* rs = es + 4 * 512;
+  const int nb = n_base + wave * 64;
+  const s2svc_gemm_desc& d = a.e;
+  if (nb < N) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[j], acc[mt][j], 0, 0, 0);
-  }
-  __syncthreads();                                       // every wave is past its A reads: the region becomes epilogue staging
-  float* cs = reinterpret_cast<float*>(smem_raw) + wave * (32 * 64);
-  const int nb = n_base + wave * 64;
-  if (nb < N) {
-    epilogue_tile<32, 64>(a.e, 0, 0, m_base, nb, reinterpret_cast<const f32x4_t(&)[2][4]>(acc[0]), cs, 1, 0, 0);
-    epilogue_tile<32, 64>(a.e, 0, 0, m_base + 32, nb, reinterpret_cast<const f32x4_t(&)[2][4]>(acc[2]), cs, 1, 0, 0);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + lg * 4 + r, col = j * 16 + lr;
+          cs[row * 64 + (col ^ (((row >> 2) & 3) << 4))] = acc[j][mt][r];
+        }
+    const int prow = lane >> 3, col = (lane & 7) * 8;
+    const int n = nb + col;
+    const bool ncol = n < N;
+    if (d.emask || d.res) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int m = m_base + p * 8 + prow;
+        if (m < M && ncol) {
+          if (d.emask) es[p * 64 + lane] = *reinterpret_cast<const uint4*>((const bf16_t*)d.emask + (int64_t)m * d.ldm + n);
+          if (d.res) rs[p * 64 + lane] = *reinterpret_cast<const uint4*>((const bf16_t*)d.res + (int64_t)m * d.ldr + n);
+        }
+      }
+    }
+    float bb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bb[e] = 0.f;
+    if (d.bias && ncol) load_f32x8(d.bias + n, bb);
+    const uint64_t seed = (d.seed_base ? *d.seed_base : 0ull) + d.seed_off;
+    const float inv_keep = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
+#pragma unroll 1
+    for (int p = 0; p < 8; ++p) {
+      const int row = p * 8 + prow;
+      const int m = m_base + row;
+      if (m >= M || !ncol) continue;
+      const float* src = cs + row * 64 + (col ^ (((row >> 2) & 3) << 4));
+      const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e] + bb[e], d.act);
+      if (d.drop_p > 0.f) {
+        float mk[8];
+        dropout_scale8(seed, (uint64_t)((int64_t)m * N + n), d.drop_p, inv_keep, mk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= mk[e];
+      }
+      if (d.emask) {
+        float ee[8];
+        unpack_bf16x8(es[p * 64 + lane], ee);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ee[e] > 0.f ? v[e] : 0.f;
+      }
+      if (d.res) {
+        float rr8[8];
+        unpack_bf16x8(rs[p * 64 + lane], rr8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rr8[e];
+      }
+      *reinterpret_cast<uint4*>((bf16_t*)d.C + (int64_t)m * d.ldc + n) = rowblock::pack8(v);
+    }
   }
 }
 
 template <int D>
 int launch(const rp_args& a, hipStream_t st) {
-  constexpr size_t lds_a = sizeof(bf16_t) * 64 * (D + 8), lds_e = sizeof(float) * 4 * 32 * 64;
+  constexpr size_t lds_a = sizeof(bf16_t) * 64 * (D + 8), lds_e = sizeof(float) * 4 * 64 * 64 + 2 * 4 * 512 * sizeof(uint4);
   constexpr size_t lds = lds_a > lds_e ? lds_a : lds_e;
   static bool attr_set = false;
   if (!attr_set) {
@@ -163,8 +221,9 @@ extern "C" int s2svc_gemm_rowpro(int mode, int D, const void* x, const float* ga
   S2S_REQUIRE(mode != 1 || (gamma && beta && y && mean && rstd && ((uintptr_t)gamma) % 16 == 0 && ((uintptr_t)beta) % 16 == 0 &&
                             ((uintptr_t)y) % 16 == 0), "gemm_rowpro: LayerNorm prologue needs gamma / beta / y / mean / rstd (16-byte aligned)");
   S2S_REQUIRE(!y || ((uintptr_t)y) % 16 == 0, "gemm_rowpro: y must be 16-byte aligned");
-  S2S_REQUIRE(epi->K == D && epi->nb0 * epi->nb1 <= 1 && epi->splitk <= 1 && !epi->c_map && !epi->a_rowsum,
-              "gemm_rowpro: K must equal D; no batches / split-K / c_map / row sums");
+  S2S_REQUIRE(epi->K == D && epi->nb0 * epi->nb1 <= 1 && epi->splitk <= 1 && !epi->c_map && !epi->a_rowsum && !epi->c_pre &&
+              !epi->accumulate && epi->alpha == 1.0f && (!epi->emask || epi->emask_mode == 0),
+              "gemm_rowpro: K must equal D; no batches / split-K / c_map / row sums / c_pre / accumulate / alpha / swish mask");
   {
     const s2svc_gemm_desc& d = *epi;
     bool ok = (d.N % 8 == 0) && (d.ldc % 8 == 0) && (((uintptr_t)d.C) % 16 == 0);

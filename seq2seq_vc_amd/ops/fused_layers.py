@@ -15,7 +15,7 @@ LayerNorm / dropout-mask row prologue), the LDS-DMA GEMMs with dropout + residua
 backward.  Parameter gradients go to the flat-gradient slots of optim.FlatAdam on the side streams exactly as in
 ops/functional.py (weight-gradient GEMMs with fused bias row sums, grouped column reductions for the LayerNorm vectors).
 
-Eligibility (`enc_layer_ok` / `dec_layer_ok`): compute dtype bf16, T <= 64, (D, d_k) in {(256, 64), (384, 96), (512, 128)},
+Eligibility (`enc_layer_ok` / `dec_layer_ok`): compute dtype bf16, T <= 64, (D, d_k) in {(256, 64), (384, 96)},
 ReLU feed-forward, every parameter of the layer trainable and held by FlatAdam with bf16 + transposed shadows.  Everything
 else (fp32 parity mode, frozen layers, long sequences, Conformer) takes the modular path of modules.py, which is also the
 reference these functions are tested against (tests/gpu_kernel_check.py: fused_layers_vs_modular).

@@ -8,7 +8,12 @@ import torch
 from .. import _lib
 from .kernels import _DT, ACT, ptr, stream
 
-_DISABLED = os.environ.get("S2SVC_NO_FUSED_BLOCKS", "0") == "1"     # A/B switch: layers fall back to the modular path
+# The fused layer functions are OPT-IN (S2SVC_FUSED_BLOCKS=1): they cut the VTN step from 395 to 310 launches but measured
+# SLOWER on MI355X (4.98 vs 4.48 ms, profiles/r03_fused_layers_*): a workgroup that owns an utterance's 64 rows runs one wave per
+# SIMD on cold code and cold caches, so its LayerNorm row loop (10-15 us), epilogue and attention core run at single-wave
+# latency, where the modular kernels spread the same rows over the whole chip.  Kept tested (kernel- and
+# model-level cases toggle `_DISABLED`) as the base for a 16-wave version.
+_DISABLED = os.environ.get("S2SVC_FUSED_BLOCKS", "0") != "1"
 
 
 def block_supported(dtype, T1, T2, D, H):

@@ -1093,7 +1093,7 @@ def attn_block_kernels_vs_unfused():
     dt_ = torch.bfloat16
     for (B, T1, T2, D, H, causal, src, seed0) in [(3, 63, 63, 384, 4, False, False, 1), (2, 64, 64, 384, 4, True, False, 2),
                                                   (3, 37, 50, 384, 4, False, True, 3), (2, 64, 61, 256, 4, False, True, 4),
-                                                  (2, 40, 40, 256, 4, True, False, 5), (2, 33, 33, 512, 4, False, False, 6)]:
+                                                  (2, 40, 40, 256, 4, True, False, 5), (5, 33, 33, 384, 4, False, False, 6)]:
         dk = D // H
         x = rnd(B, T1, D, seed=seed0, dtype=dt_)
         gamma, beta = (1.0 + 0.1 * rnd(D, seed=seed0 + 1)).contiguous(), (0.1 * rnd(D, seed=seed0 + 2)).contiguous()
