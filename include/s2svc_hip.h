@@ -512,6 +512,18 @@ int s2svc_log_clamp(int64_t n, int D, const float* x, float eps, float inv_log_b
      s2svc_ragged_to_padded: ragged feature rows (concatenated utterances, row offsets (B + 1) int64) -> (B, Tmax, D)
          zero-padded batch (+ optional normalisation, + optional stop labels (B, Tmax): 1 from the last valid frame on). */
 int s2svc_reflect_pad_batch(int B, int64_t Nmax, int pad, int64_t ld, const float* x, const int32_t* nlen, float* y, void* stream);
+/* The same batch in ONE launch with the FFT in LDS (csrc/stft_fft.hip; n_fft in {512, 1024, 2048}): one wavefront per frame --
+   windowed load with the reflect padding as index arithmetic, N/2-point complex radix-4 Stockham FFT of the even/odd packed
+   frame, unpack, magnitude, sparse mel projection, clamp, log, normalisation, zero rows for the padding frames.
+     tables (16-byte aligned, fp32, zero-filled to whole 16-byte vectors): w_half [n_fft/2] complex exp(-2 pi i m / (n_fft/2)) |
+     w_full [n_fft/2 + 1] complex exp(-2 pi i k / n_fft) | win [n_fft] | melw [melw_n rounded up to even];
+     melw: the non-zero weights of filter m are melw[mel_off[m] .. mel_off[m] + mel_hi[m] - mel_lo[m]) for bins [mel_lo, mel_hi);
+     mel_maxw = the widest filter (bins); the list (melw_n values) ends with a zero tail of at least mel_maxw + 1 values. */
+int s2svc_stft_logmel_fft_supported(int n_fft, int nmel, int melw_n);
+int s2svc_stft_logmel_fft(int B, int64_t Nmax, int Tmax, int n_fft, int hop, int nmel, const float* x, const int32_t* nlen,
+                          const int32_t* frames, const float* tables, const int32_t* mel_lo, const int32_t* mel_hi, const int32_t* mel_off, int melw_n, int mel_maxw,
+                          float eps, float inv_log_base, const float* mean, const float* inv_scale, float* out, void* stream);
+
 int s2svc_mel_log_batch(int B, int Tmax, int nb, int nmel, const float* z, const int32_t* frames, const float* melb,
                         const int32_t* lo, const int32_t* hi, float eps, float inv_log_base, const float* mean,
                         const float* inv_scale, float* out, void* stream);

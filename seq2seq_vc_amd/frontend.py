@@ -75,9 +75,10 @@ def _tables(device, sr, n_fft, win_length, n_mels, fmin, fmax):
 
 
 def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80,
-                     fmin=None, fmax=None, eps=1e-10, log_base=10.0, mean=None, scale=None):
+                     fmin=None, fmax=None, eps=1e-10, log_base=10.0, mean=None, scale=None, impl=None):
     """audio: 1-D float tensor on the GPU (or numpy/CPU tensor, copied once) -> (frames, num_mels) fp32 tensor
-    on the GPU.  `mean`/`scale` (num_mels,) fuse `(x - mean) / scale` into the log kernel."""
+    on the GPU.  `mean`/`scale` (num_mels,) fuse `(x - mean) / scale` into the log kernel.
+    impl: None / "fft" = the one-launch FFT kernel (csrc/stft_fft.hip) where it applies, "gemm" = the DFT-as-GEMM path (5 launches)."""
     if window != "hann":
         raise NotImplementedError("only the hann window of the recipes is supported")
     if not isinstance(audio, torch.Tensor):
@@ -88,6 +89,20 @@ def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, win_leng
     dev = audio.device
     fmin = 0 if fmin is None else fmin
     fmax = sampling_rate / 2 if fmax is None else fmax
+    if log_base not in (None, 10.0, 2.0):
+        raise ValueError(f"{log_base} is not supported.")
+    wl_ = fft_size if win_length is None else win_length
+    if impl != "gemm" and fft_size in (512, 1024, 2048) and wl_ <= fft_size and audio.numel() > 0:
+        n_ = audio.numel()
+        fr_ = 1 + n_ // hop_size
+        mt = ist = None
+        if mean is not None:
+            mt = torch.as_tensor(mean, dtype=torch.float32, device=dev).contiguous()
+            ist = (1.0 / torch.as_tensor(scale, dtype=torch.float32, device=dev)).contiguous()
+        out = stft_logmel_fft_device(audio.view(1, n_), torch.tensor([n_], dtype=torch.int32, device=dev),
+                                     torch.tensor([fr_], dtype=torch.int32, device=dev), fr_, sampling_rate, fft_size, hop_size, win_length,
+                                     num_mels, fmin, fmax, eps, 1.0 if log_base is None else 1.0 / math.log(log_base), mt, ist)
+        return out[0]
     basis, melb = _tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
     n = audio.numel()
     pad = fft_size // 2
@@ -127,13 +142,64 @@ def _mel_ranges(melb_np):
 _RANGES = {}
 
 
+_FFT_TABLES = {}
+
+
+def _fft_tables(device, sr, n_fft, win_length, n_mels, fmin, fmax):
+    """Tables of the FFT-in-LDS kernel (csrc/stft_fft.hip), built in float64 and rounded once: window (zero-padded to n_fft),
+    twiddles of the n_fft/2-point FFT and of the real-FFT unpack step, the mel filters' non-zero weights back to back."""
+    key = (str(device), sr, n_fft, win_length, n_mels, fmin, fmax)
+    if key not in _FFT_TABLES:
+        wl = n_fft if win_length is None else win_length
+        win = np.zeros(n_fft)
+        lp = (n_fft - wl) // 2
+        win[lp:lp + wl] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(wl) / wl)
+        h = n_fft // 2
+        a = -2 * np.pi * np.arange(h) / h
+        w_half = np.stack([np.cos(a), np.sin(a)], 1)
+        a = -2 * np.pi * np.arange(h + 1) / n_fft
+        w_full = np.stack([np.cos(a), np.sin(a)], 1)
+        melb = mel_basis(sr, n_fft, n_mels, fmin, fmax)
+        lo, hi = _mel_ranges(melb)
+        off = np.concatenate([[0], np.cumsum(hi - lo)]).astype(np.int32)
+        maxw = int((hi - lo).max()) + 1                   # (+1: the kernel's loop advances two bins at a time)
+        melw = np.concatenate([melb[m, lo[m]:hi[m]] for m in range(n_mels)] + [np.zeros(maxw + 2, np.float32)]).astype(np.float32)
+        t = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x.astype(dt))).to(device)
+        melw_n = int(len(melw))
+        packed = np.concatenate([w_half.reshape(-1), w_full.reshape(-1), win, melw, np.zeros(melw_n % 2)]).astype(np.float32)
+        packed = np.concatenate([packed, np.zeros((-len(packed)) % 4, np.float32)])           # whole 16-byte vectors
+        _FFT_TABLES[key] = (t(packed, np.float32), t(lo, np.int32), t(hi, np.int32), t(off[:-1], np.int32), melw_n, maxw)
+    return _FFT_TABLES[key]
+
+
+def stft_logmel_fft_device(x, nlen_d, frames_d, Tmax, sampling_rate, fft_size, hop_size, win_length, num_mels, fmin, fmax, eps, inv_log,
+                           mean_t=None, inv_scale_t=None, out=None):
+    """The ONE launch of the FFT front-end on device-resident arguments (x (B, Nmax) fp32, nlen_d / frames_d (B) int32):
+    capturable, no host work beyond the launch.  -> (B, Tmax, num_mels) fp32."""
+    dev = x.device
+    B, Nmax = x.shape
+    tables, lo, hi, off, melw_n, maxw = _fft_tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
+    if out is None:
+        out = torch.empty((B, Tmax, num_mels), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().s2svc_stft_logmel_fft(B, Nmax, Tmax, fft_size, hop_size, num_mels, x.data_ptr(), nlen_d.data_ptr(),
+                                                frames_d.data_ptr(), tables.data_ptr(),
+                                                lo.data_ptr(), hi.data_ptr(), off.data_ptr(), melw_n, maxw, eps, inv_log,
+                                                None if mean_t is None else mean_t.data_ptr(),
+                                                None if inv_scale_t is None else inv_scale_t.data_ptr(), out.data_ptr(), K.stream()),
+               "stft_logmel_fft")
+    return out
+
+
 def logmelfilterbank_batch(audios, sampling_rate, fft_size=1024, hop_size=256, win_length=None, window="hann", num_mels=80,
-                           fmin=None, fmax=None, eps=1e-10, log_base=10.0, mean=None, scale=None, lengths=None, device="cuda"):
+                           fmin=None, fmax=None, eps=1e-10, log_base=10.0, mean=None, scale=None, lengths=None, device="cuda",
+                           impl=None):
     """B utterances -> (mel (B, Tmax, num_mels) fp32, zero-padded; frames (B,) LongTensor on the host): the batch the
     collater would build from the per-utterance features of bin/preprocess.py + bin/normalize.py, in three launches.
 
     audios: a list of 1-D float arrays / tensors (any lengths), or a zero-padded (B, Nmax) tensor with `lengths`.
-    Every utterance equals `logmelfilterbank(audio_b, ...)` on its first 1 + n_b // hop frames."""
+    Every utterance equals `logmelfilterbank(audio_b, ...)` on its first 1 + n_b // hop frames.
+    impl: "fft" (ONE launch, FFT in LDS: csrc/stft_fft.hip; n_fft in {512, 1024, 2048}), "gemm" (the DFT-as-GEMM formulation of
+    round 2: 3 launches) or None = "fft" where it applies."""
     if window != "hann":
         raise NotImplementedError("only the hann window of the recipes is supported")
     if log_base not in (None, 10.0, 2.0):
@@ -153,32 +219,42 @@ def logmelfilterbank_batch(audios, sampling_rate, fft_size=1024, hop_size=256, w
     B, Nmax = x.shape
     fmin = 0 if fmin is None else fmin
     fmax = sampling_rate / 2 if fmax is None else fmax
-    basis, melb = _tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
-    key = (str(dev), sampling_rate, fft_size, num_mels, fmin, fmax)
-    if key not in _RANGES:
-        lo, hi = _mel_ranges(melb.cpu().numpy())
-        _RANGES[key] = (torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev))
-    lo, hi = _RANGES[key]
     pad, nb = fft_size // 2, fft_size // 2 + 1
     frames = [1 + n // hop_size for n in nlen]
     Tmax = max(frames)
-    ld = ((Tmax - 1) * hop_size + fft_size + 63) // 64 * 64
-    ld = max(ld, Nmax + 2 * pad)
     L, st = _lib.lib(), K.stream()
-    nlen_d = torch.tensor(nlen, dtype=torch.int32, device=dev)
-    frames_d = torch.tensor(frames, dtype=torch.int32, device=dev)
-    padded = torch.empty((B, ld), dtype=torch.float32, device=dev)
-    _lib.check(L.s2svc_reflect_pad_batch(B, Nmax, pad, ld, x.data_ptr(), nlen_d.data_ptr(), padded.data_ptr(), st), "reflect_pad_batch")
-    z = torch.empty((B, Tmax, 2 * nb), dtype=torch.float32, device=dev)
-    K.gemm(K.operand(padded, hop_size, bs0=ld), K.operand(basis, fft_size), Tmax, 2 * nb, fft_size, z, in_dtype=torch.float32,
-           nb0=B, nb1=1, cbs=(Tmax * 2 * nb, 0))
-    out = torch.empty((B, Tmax, num_mels), dtype=torch.float32, device=dev)
     inv_log = 1.0 if log_base is None else 1.0 / math.log(log_base)
     m_ptr = s_ptr = None
     if mean is not None:
         mean_t = torch.as_tensor(mean, dtype=torch.float32, device=dev).contiguous()
         inv_scale_t = (1.0 / torch.as_tensor(scale, dtype=torch.float32, device=dev)).contiguous()
         m_ptr, s_ptr = mean_t.data_ptr(), inv_scale_t.data_ptr()
+    nlen_d = torch.tensor(nlen, dtype=torch.int32, device=dev)
+    frames_d = torch.tensor(frames, dtype=torch.int32, device=dev)
+    if impl not in (None, "fft", "gemm"):
+        raise ValueError("impl must be None, 'fft' or 'gemm'")
+    wl = fft_size if win_length is None else win_length
+    fft_ok = fft_size in (512, 1024, 2048) and wl <= fft_size
+    if impl == "fft" and not fft_ok:
+        raise ValueError("the FFT front-end needs fft_size in {512, 1024, 2048} and win_length <= fft_size")
+    if impl != "gemm" and fft_ok:
+        out = stft_logmel_fft_device(x, nlen_d, frames_d, Tmax, sampling_rate, fft_size, hop_size, win_length, num_mels, fmin, fmax, eps,
+                                     inv_log, mean_t if mean is not None else None, inv_scale_t if mean is not None else None)
+        return out, torch.tensor(frames, dtype=torch.long)
+    basis, melb = _tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
+    key = (str(dev), sampling_rate, fft_size, num_mels, fmin, fmax)
+    if key not in _RANGES:
+        lo, hi = _mel_ranges(melb.cpu().numpy())
+        _RANGES[key] = (torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev))
+    lo, hi = _RANGES[key]
+    ld = ((Tmax - 1) * hop_size + fft_size + 63) // 64 * 64
+    ld = max(ld, Nmax + 2 * pad)
+    padded = torch.empty((B, ld), dtype=torch.float32, device=dev)
+    _lib.check(L.s2svc_reflect_pad_batch(B, Nmax, pad, ld, x.data_ptr(), nlen_d.data_ptr(), padded.data_ptr(), st), "reflect_pad_batch")
+    z = torch.empty((B, Tmax, 2 * nb), dtype=torch.float32, device=dev)
+    K.gemm(K.operand(padded, hop_size, bs0=ld), K.operand(basis, fft_size), Tmax, 2 * nb, fft_size, z, in_dtype=torch.float32,
+           nb0=B, nb1=1, cbs=(Tmax * 2 * nb, 0))
+    out = torch.empty((B, Tmax, num_mels), dtype=torch.float32, device=dev)
     _lib.check(L.s2svc_mel_log_batch(B, Tmax, nb, num_mels, z.data_ptr(), frames_d.data_ptr(), melb.data_ptr(), lo.data_ptr(),
                                      hi.data_ptr(), eps, inv_log, m_ptr, s_ptr, out.data_ptr(), st), "mel_log_batch")
     return out, torch.tensor(frames, dtype=torch.long)

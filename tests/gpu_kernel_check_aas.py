@@ -174,8 +174,9 @@ def stft_logmel_frontend():
         t = np.arange(n) / 16000.0
         x = (0.3 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 3100 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
         ref = OL.logmelfilterbank(x, 16000, fft_size=1024, hop_size=256, num_mels=80, fmin=80, fmax=7600)
-        got = logmelfilterbank(torch.from_numpy(x).to(DEV), 16000, fft_size=1024, hop_size=256, num_mels=80, fmin=80, fmax=7600)
-        res.append(check(f"logmel N={n} frames={ref.shape[0]}", got, torch.from_numpy(ref), torch.float32, atol=2e-4, rtol=1e-4))
+        for impl in ("fft", "gemm"):          # the one-launch FFT-in-LDS kernel (default) and the DFT-as-GEMM path of round 2
+            got = logmelfilterbank(torch.from_numpy(x).to(DEV), 16000, fft_size=1024, hop_size=256, num_mels=80, fmin=80, fmax=7600, impl=impl)
+            res.append(check(f"logmel[{impl}] N={n} frames={ref.shape[0]}", got, torch.from_numpy(ref), torch.float32, atol=2e-4, rtol=1e-4))
     mean, scale = rng.standard_normal(80).astype(np.float32), (1 + rng.random(80)).astype(np.float32)
     got = logmelfilterbank(torch.from_numpy(x).to(DEV), 16000, fmin=80, fmax=7600, mean=mean, scale=scale)
     res.append(check("logmel + fused normalisation", got, torch.from_numpy((ref - mean) / scale), torch.float32, atol=3e-4, rtol=1e-4))
@@ -417,10 +418,29 @@ def stft_logmel_batched_and_device_collaters():
     res.append((frames.tolist() == [1 + n // 256 for n in lens] and tuple(mel.shape) == (len(lens), max(frames), 80), f"batched log-mel shape {tuple(mel.shape)}, frames {frames.tolist()}"))
     for b, a in enumerate(auds):
         fb = int(frames[b])
-        single = logmelfilterbank(torch.from_numpy(a).to(DEV), 16000, **kw)
-        res.append(check(f"batched vs per-utterance log-mel, utterance {b} ({lens[b]} samples)", mel[b, :fb], single, torch.float32, atol=2e-5, rtol=1e-5))
+        single = logmelfilterbank(torch.from_numpy(a).to(DEV), 16000, impl="gemm", **kw)
+        res.append(check(f"batched (FFT in LDS) vs per-utterance (DFT as GEMM) log-mel, utterance {b} ({lens[b]} samples)", mel[b, :fb], single, torch.float32, atol=1e-4, rtol=1e-5))
         res.append(check(f"batched log-mel vs numpy restatement, utterance {b}", mel[b, :fb], torch.from_numpy(OL.logmelfilterbank(a, 16000, **kw)), torch.float32, atol=2e-4, rtol=1e-4))
         res.append((bool((mel[b, fb:] == 0).all()), f"utterance {b}: padding frames are exact zeros"))
+    melg, _ = logmelfilterbank_batch(auds, 16000, impl="gemm", **kw)
+    res.append(check("batched log-mel: FFT-in-LDS kernel vs the three-launch GEMM formulation", mel, melg, torch.float32, atol=1e-4, rtol=1e-5))
+    # the STFT of an independent third party (torch.stft on the GPU box) through the same mel basis
+    for b in (1, 4):
+        a64 = torch.from_numpy(auds[b].astype(np.float64))
+        sp = torch.stft(a64, n_fft=1024, hop_length=256, win_length=1024, window=torch.hann_window(1024, periodic=True, dtype=torch.float64),
+                        center=True, pad_mode="reflect", return_complex=True).abs().T.numpy()
+        want = np.log10(np.maximum(1e-10, sp @ OL.mel_filterbank64(16000, 1024, 80, 80, 7600).T))
+        res.append(check(f"FFT-in-LDS log-mel vs torch.stft (float64) + Slaney basis, utterance {b}", mel[b, : int(frames[b])], torch.from_numpy(want).float(),
+                         torch.float32, atol=2e-4, rtol=1e-4))
+    # other transform sizes / a window shorter than the transform
+    for n_fft, hop, wl in ((512, 128, None), (2048, 300, None), (1024, 256, 800)):
+        kw2 = dict(fft_size=n_fft, hop_size=hop, win_length=wl, num_mels=80, fmin=80, fmax=7600)
+        mf, fr = logmelfilterbank_batch(auds[:3], 16000, **kw2)
+        mg, _ = logmelfilterbank_batch(auds[:3], 16000, impl="gemm", **kw2)
+        res.append(check(f"FFT vs GEMM front-end, n_fft {n_fft} hop {hop} win {wl}", mf, mg, torch.float32, atol=1e-4, rtol=1e-5))
+        if wl is None:
+            ref = OL.logmelfilterbank(auds[1], 16000, fft_size=n_fft, hop_size=hop, num_mels=80, fmin=80, fmax=7600)
+            res.append(check(f"FFT front-end vs numpy restatement, n_fft {n_fft}", mf[1, : int(fr[1])], torch.from_numpy(ref), torch.float32, atol=2e-4, rtol=1e-4))
     mean, scale = rng.standard_normal(80).astype(np.float32), (0.5 + rng.random(80)).astype(np.float32)
     meln, _ = logmelfilterbank_batch(auds, 16000, mean=mean, scale=scale, **kw)
     for b in (1, 4):

@@ -3,7 +3,7 @@
 
     python tools/bench_frontend.py [--batch 32] [--seconds 3.0] [--iters 20] [--cpu]
 
-Reports us per utterance for the batched path (3 launches per batch) and for the per-utterance path (5 launches each), the
+Reports the FFT-in-LDS kernel alone (HIP events), us per utterance for the batched path (1 launch per batch; impl="gemm": 3) and for the per-utterance path (5 launches each), the
 achieved fraction of the two roofs that apply -- fp32 MFMA for the DFT-as-GEMM formulation (2 * frames * 1026 * 1024 flop;
 peak 157.3 TFLOP/s) and HBM for the algorithmic traffic of the whole front-end (4 B per sample in + 320 B per frame out;
 8 TB/s) -- and, with --cpu, the numpy restatement on the host (one thread per numpy's defaults).  Prints ONE JSON line.
@@ -47,8 +47,33 @@ def main():
     def looped():
         return [logmelfilterbank(s, sr, mean=mean, scale=scale, **kw) for s in singles]
 
+    def gemm_batched():
+        return logmelfilterbank_batch(xd, sr, lengths=lens, mean=mean, scale=scale, impl="gemm", **kw)
+
+    # the FFT kernel alone, device-resident arguments, HIP events around `kiters` back-to-back launches
+    from seq2seq_vc_amd.frontend import stft_logmel_fft_device
+    nlen_d = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    fr = [1 + n // 256 for n in lens]
+    frames_d = torch.tensor(fr, dtype=torch.int32, device="cuda")
+    mean_t, isc_t = torch.zeros(80, device="cuda"), torch.ones(80, device="cuda")
+    obuf = torch.empty((a.batch, max(fr), 80), dtype=torch.float32, device="cuda")
+
+    def kernel_only():
+        stft_logmel_fft_device(xd, nlen_d, frames_d, max(fr), sr, 1024, 256, None, 80, 80, 7600, 1e-10, 1.0 / np.log(10.0), mean_t, isc_t, out=obuf)
+    for _ in range(5):
+        kernel_only()
+    kiters = 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(kiters):
+        kernel_only()
+    e1.record()
+    torch.cuda.synchronize()
+    t_kernel = e0.elapsed_time(e1) * 1e-3 / kiters
+
     out = {}
-    for name, fn in (("batched", batched), ("per_utterance", looped)):
+    for name, fn in (("batched", batched), ("per_utterance", looped), ("batched_gemm", gemm_batched)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -61,16 +86,22 @@ def main():
     frames_padded = a.batch * (1 + nmax // 256)
     flops = 2.0 * frames_padded * 1026 * 1024
     alg_bytes = 4.0 * sum(lens) + 320.0 * frames
-    tb = out["batched"]
+    tb, tg = out["batched"], out["batched_gemm"]
     res = {"metric": "STFT->log-mel front-end", "batch": a.batch, "audio_seconds_per_utt_max": a.seconds, "frames": frames,
-           "us_per_utterance_batched": tb / a.batch * 1e6, "us_per_utterance_looped": out["per_utterance"] / a.batch * 1e6,
-           "ns_per_frame_batched": tb / frames * 1e9, "launches_per_batch": {"batched": 3, "per_utterance": 5 * a.batch},
-           "roofline": {"fp32_mfma": {"achieved_TFLOPs": flops / tb / 1e12, "peak": 157.3, "frac": flops / tb / 1e12 / 157.3,
-                                      "note": "DFT as GEMM over the padded batch: the formulation's own bound"},
-                        "hbm_algorithmic": {"bytes": alg_bytes, "achieved_GBs": alg_bytes / tb / 1e9, "peak": 8000.0,
-                                            "frac": alg_bytes / tb / 1e9 / 8000.0,
-                                            "note": "4 B/sample in + 320 B/frame out; an FFT-in-LDS kernel is what this roof asks for"}},
-           "realtime_factor": tb / (sum(lens) / sr)}
+           "fft_kernel": {"us_per_launch": t_kernel * 1e6, "us_per_utterance": t_kernel / a.batch * 1e6, "ns_per_frame": t_kernel / frames * 1e9,
+                          "timed": f"{kiters} back-to-back launches of s2svc_stft_logmel_fft, HIP events, device-resident arguments"},
+           "us_per_utterance_batched": tb / a.batch * 1e6, "us_per_utterance_batched_gemm": tg / a.batch * 1e6,
+           "us_per_utterance_looped": out["per_utterance"] / a.batch * 1e6,
+           "ns_per_frame_batched": tb / frames * 1e9,
+           "launches_per_batch": {"batched": 1, "batched_gemm": 3, "per_utterance": 5 * a.batch},
+           "note": "batched / batched_gemm / per_utterance are host wall times of the Python entry points (length upload + launch overhead "
+                   "included); fft_kernel is the kernel alone",
+           "roofline": {"hbm_algorithmic": {"bound": "hbm", "bytes": alg_bytes, "achieved_GBs": alg_bytes / t_kernel / 1e9, "peak": 8000.0,
+                                            "frac": alg_bytes / t_kernel / 1e9 / 8000.0,
+                                            "note": "FFT-in-LDS kernel; 4 B/sample in + 320 B/frame out"},
+                        "gemm_formulation_fp32_mfma": {"achieved_TFLOPs": flops / tg / 1e12, "peak": 157.3, "frac": flops / tg / 1e12 / 157.3,
+                                                       "note": "round 2's DFT as GEMM over the padded batch (host wall time)"}},
+           "realtime_factor": t_kernel / (sum(lens) / sr)}
     if a.cpu:
         from oracle import logmel as OL
         t0 = time.perf_counter()
