@@ -393,14 +393,14 @@ class Workload:
         return {"decoder": l1, "align": 2.0 * (fs + ret["bin_loss"]) + dur}
 
 
-def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_eager=2):
+def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_eager=2, collective="allreduce"):
     """Returns (step(), info).  Unstaged: graph 1 = zero + forward + loss + backward, graph 2 = clip + Adam + WarmupLR.
     Staged (data parallel): one graph per stage of model.dp_plan(); after each replay the all-reduce of that stage's slice of
     the flat gradient buffer is issued; the optimiser graph follows the join."""
     from seq2seq_vc_amd.distributed import OverlappedBackward, allreduce_mean_
     from seq2seq_vc_amd.ops import kernels as K
     Fn, opt, dev = wl.Fn, wl.opt, wl.dev
-    ob = OverlappedBackward(wl.model, opt, dist, world, payload=payload, force=force_dist) if staged else None
+    ob = OverlappedBackward(wl.model, opt, dist, world, payload=payload, force=force_dist, collective=collective) if staged else None
     stage16 = None
     if not staged and (dist is not None or force_dist) and payload == "bf16":
         stage16 = torch.empty(opt.numel, dtype=torch.bfloat16, device=dev)
@@ -487,7 +487,8 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
     info = {"hip_graph": bool(use_graph), "backward_stages": n_stages,
             "grad_buckets_MB": [round(b / 1e6, 1) for b in ob.bucket_bytes()] if staged else
                                ([round(opt.numel * (2 if stage16 is not None else 4) / 1e6, 1)] if post_reduce else None),
-            "grad_payload": payload if (staged or post_reduce) else None}
+            "grad_payload": payload if (staged or post_reduce) else None,
+            "collective": collective if staged else ("allreduce" if post_reduce else None)}
     return step, info
 
 
@@ -723,7 +724,10 @@ def main():
                     help="N = 1: run the staged backward pass of the data-parallel path without collectives")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code path (RCCL process group, staged backward, overlapped all-reduces) at world size 1")
-    ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient exchange")
+    ap.add_argument("--grad-payload", default=None, choices=["fp32", "bf16"],
+                    help="dtype of the gradient exchange (default: the trainers' -- fp32 for vtn, bf16 for aasvc)")
+    ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="data parallel: one all-reduce per bucket, or reduce-scatter + all-gather")
     ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
     ap.add_argument("--side-streams", type=int, default=None, help="HIP side streams for parameter-gradient kernels (default: 4 for vtn, 0 + inline batches for aasvc)")
     args = ap.parse_args()
@@ -765,7 +769,9 @@ def main():
     # Data parallel: backward in the stages of model.dp_plan(), one captured graph per stage, the all-reduce of a finished stage's
     # slice of the flat gradient buffer issued between the replays (overlap).  N = 1 keeps one graph (the cuts cost ~0.2 ms).
     staged = dp or args.split_backward
-    step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph,
+    if args.grad_payload is None:
+        args.grad_payload = "bf16" if args.workload == "aasvc" else "fp32"
+    step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
                             warmup_eager=max(2, args.warmup if args.no_graph else 2))
     dt = time_steps(step, args.steps, args.warmup, dist if dp else None, dev)
     if dp:

@@ -474,6 +474,8 @@ int s2svc_decode_advance(int32_t* pos, uint64_t* seed_base, uint64_t seed_stride
    unbatched, unsplit); gamma / beta / eps: the LayerNorm (both NULL: plain skinny linear); y_out != NULL: LN(A) is also
    written there (row stride ldy) -- the residual input of a post-LN layer (decoder_layer.py:104-127).
    Replaces one LayerNorm launch + one Linear launch per projection of decoder.py:239-273. */
+/* 1 if s2svc_decode_ln_linear takes an (M x K) input of this dtype (else: s2svc_layernorm_fwd + s2svc_gemm) */
+int s2svc_decode_ln_linear_supported(int dtype, int M, int K);
 int s2svc_decode_ln_linear(const s2svc_gemm_desc* desc /* host */, const float* gamma, const float* beta, float eps, void* y_out,
                            int64_t ldy, void* stream);
 

@@ -427,6 +427,17 @@ bool launch_ln_linear(const s2svc_gemm_desc& d, const float* gamma, const float*
 
 }  // namespace
 
+// 1 if s2svc_decode_ln_linear takes an (M x K) input of this dtype (the register-resident form: M <= 64, whole 16-byte vectors
+// along K, at most 6 k steps per wave -- 12 up to M = 32); callers fall back to s2svc_layernorm_fwd + s2svc_gemm otherwise
+extern "C" int s2svc_decode_ln_linear_supported(int dtype, int M, int K) {
+  if ((dtype != S2S_F32 && dtype != S2S_BF16) || M <= 0 || M > 64 || K <= 0) return 0;
+  const int vec = dtype == S2S_F32 ? 4 : 8;
+  if (K % vec != 0) return 0;
+  const int kstep = dtype == S2S_F32 ? DFrag<float>::KSTEP : DFrag<bf16_t>::KSTEP;
+  const int per = ((K + kstep - 1) / kstep + 3) / 4;
+  return per <= 6 || (per <= 12 && M <= 32);
+}
+
 extern "C" int s2svc_decode_ln_linear(const s2svc_gemm_desc* desc, const float* gamma, const float* beta, float eps, void* y_out,
                                       int64_t ldy, void* stream) {
   S2S_REQUIRE(desc != nullptr, "decode_ln_linear: null desc");

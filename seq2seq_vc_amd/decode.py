@@ -80,6 +80,7 @@ class ARDecodeSession:
         self.minlen, self.maxlen, self.klen = z(B, dt=torch.int32), z(B, dt=torch.int32), z(B, dt=torch.int32)
         self.threshold = None
         self.graph = None
+        self._ll_ok = {}               # (batch, K) -> the fused LayerNorm + projection kernel applies (see _ll)
 
     @staticmethod
     def _version(model):
@@ -117,8 +118,28 @@ class ARDecodeSession:
                        self.Tcap, 1.0 / math.sqrt(dk), ctx, B, H, dk, att=a, att_strides=(a.stride(0), a.stride(1), a.stride(2)))
         return ctx
 
+    def _ll(self, x, w, bias, *, norm=None, act=None, res=None, y_out=None, drop_p=0.0, seed=(None, 0)):
+        """act(LN(x) . w^T + bias) [dropout] (+ res): the fused skinny kernel where it applies (batch <= 64, K in whole 16-byte
+        vectors and short enough for its register-resident form: decided per (batch, K) once, before the step is captured),
+        else LayerNorm kernel + GEMM with the same epilogue (same values: the fused kernel normalises exactly as norm.hip)."""
+        key = (x.shape[0], x.shape[1])
+        ok = self._ll_ok.get(key)
+        if ok is None:
+            ok = self._ll_ok[key] = KD.ln_linear_supported(self.dtype, x.shape[0], x.shape[1])
+        if ok:
+            return KD.ln_linear(x, w, bias, norm=norm, act=act, res=res, y_out=y_out, drop_p=drop_p, seed=seed)
+        y = x
+        if norm is not None:
+            y, _, _, _ = K.layernorm_fwd(x, norm[0], norm[1], norm[2], need_stats=False)
+            if y_out is not None:
+                K.cast(y, self.dtype, out=y_out)         # a kernel, not a memcpy node (the step is captured)
+        N, Kd = w.shape
+        out = torch.empty((x.shape[0], N), dtype=self.dtype, device=self.device)
+        return K.gemm(K.operand(y, Kd), K.operand(w, Kd), x.shape[0], N, Kd, out, in_dtype=self.dtype, bias=bias, act=act, res=res,
+                      drop_p=drop_p, seed=seed)
+
     def _step(self):
-        ll, lin = KD.ln_linear, self._lin        # LayerNorm / dropout fused into the projection | plain skinny projection
+        ll, lin = self._ll, self._lin            # LayerNorm / dropout fused into the projection | plain skinny projection
         x = self.prev
         for wb in self.prenet:                                  # Linear-ReLU-dropout in one launch, dropout ALWAYS on (F9)
             if self.prenet_p > 0.0:
@@ -229,11 +250,19 @@ class ARDecodeSession:
         return res
 
 
+MAX_SESSION_BATCH = 64
+
+
 def decode(model, hs, hlens, inference_args, poll=16, use_graph=True):
     """Batched generation for an AR model (VTN / TransformerTTS): hs (B, Tenc, D), hlens host ints.
     Returns [(outs (L, odim), probs (L,), att_ws (layers, H, L/r, Tenc_b)), ...] exactly as the reference's
     `inference` returns for each utterance (vtn.py:391-394)."""
     B, Tenc, _ = hs.shape
+    if B > MAX_SESSION_BATCH:          # the decode-step kernels hold a batch of at most 64 rows per workgroup: larger batches in groups
+        out = []
+        for b0 in range(0, B, MAX_SESSION_BATCH):
+            out += decode(model, hs[b0:b0 + MAX_SESSION_BATCH], list(hlens)[b0:b0 + MAX_SESSION_BATCH], inference_args, poll, use_graph)
+        return out
     dtype, device = hs.dtype, hs.device
     r = model.decoder_reduction_factor
     need_L = max(1, max(max(int(t * inference_args["maxlenratio"] / r), int(t * inference_args["minlenratio"] / r)) for t in hlens))

@@ -10,15 +10,21 @@ few *gradient cuts* (ops.functional.cut_point) and a stage plan (`model.dp_plan(
 stage, every stage finishes the gradients of one contiguous range of the flat buffer, and that range's all-reduce is
 started (asynchronously, on RCCL's stream) before the next stage is launched:
 
-    VTN / TTS   [decoder + heads + postnet]  ->  [encoder]                                            2 buckets, 122 MB
-    AAS-VC      [dec layer 3 + heads + postnet] -> [dec 2] -> [dec 1] -> [dec 0] -> [aligner + duration predictor]
-                -> [encoder]                                                                            6 buckets, 630 MB
+    VTN / TTS   [decoder + heads + postnet] -> [encoder layers 3-5 + after-norm] -> [layers 0-2] -> [input layer]
+                4 buckets: 62.8 | 21.3 | 21.3 | 16.5 MB fp32 (VTN vc1) -- only the last one travels with nothing to hide behind
+    AAS-VC      [decoder layers 3, 2, 1 + heads + postnet, and -- rooted on the auxiliary stream -- aligner + duration
+                predictor] -> [decoder layer 0] -> [encoder]                 3 buckets: 460 | 113 | 57 MB fp32 (vc2)
+                (models/*.dp_plan() is the authority; these are the shipped recipes' numbers)
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU), so large messages are what reaches link bandwidth: a bucket is one
 contiguous slice (>= 28 MB), split into 128 MiB collectives only above that.  `payload="bf16"` halves the bytes on the links:
 the slice is cast into a bf16 staging buffer, summed over the ranks in bf16 and cast back (the fp32 gradients of a rank are
 rounded once; the sum of 8 ranks then carries bf16 rounding, ~3 significant digits, which Adam's normalisation tolerates;
-fp32 is the default and the parity setting).  The 1/world of the mean rides on the loss, so the collectives are plain sums.
+fp32 is the parity setting and the default of the VTN / TTS trainers; the AAS-VC trainer defaults to bf16: 630 MB fp32 per step
+is 7 ms of ring time on one 153 GB/s link against a 15 ms step).  The 1/world of the mean rides on the loss, so the collectives
+are plain sums.  `collective="rs_ag"` runs every bucket as reduce-scatter + all-gather (each rank sums 1/world of the slice, then
+the shards are gathered) instead of one all-reduce -- the same bytes per link for a ring, but two half-size collectives that
+RCCL can place on different channels, and the shape a sharded optimiser step would need; same results (a sum is a sum).
 """
 import os
 
@@ -79,6 +85,48 @@ def allreduce_end(handles):
         h.wait()
 
 
+class _RsAg:
+    """One bucket as reduce-scatter + all-gather: begin() starts the reduce-scatter of the (padded) slice into this rank's
+    shard; finish() waits for it, gathers the shards and copies the result back.  Backends without reduce_scatter (gloo) fall
+    back to an all-reduce of the slice, from which every rank keeps its shard -- the data path the test suite can run on CPU."""
+
+    def __init__(self, buf, dist, world, group=None):
+        self.buf, self.dist, self.world, self.group = buf, dist, world, group
+        n = buf.numel()
+        self.shard_n = (n + world - 1) // world
+        self.padded = None
+        src = buf
+        if self.shard_n * world != n:
+            self.padded = torch.zeros(self.shard_n * world, dtype=buf.dtype, device=buf.device)
+            self.padded[:n].copy_(buf)
+            src = self.padded
+        self.src = src
+        self.shard = torch.empty(self.shard_n, dtype=buf.dtype, device=buf.device)
+        self.emulated = False
+        try:
+            self.h = dist.reduce_scatter_tensor(self.shard, src, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        except (RuntimeError, NotImplementedError):
+            self.emulated = True
+            self.h = dist.all_reduce(src, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def finish(self):
+        self.h.wait()
+        if self.emulated:
+            r = self.dist.get_rank(self.group)
+            self.shard.copy_(self.src[r * self.shard_n:(r + 1) * self.shard_n])
+        self.dist.all_gather_into_tensor(self.src, self.shard, group=self.group)
+        if self.padded is not None:
+            self.buf.copy_(self.padded[: self.buf.numel()])
+
+
+class _Waiter:
+    def __init__(self, h):
+        self.h = h
+
+    def finish(self):
+        self.h.wait()
+
+
 def broadcast_(flat, dist, world, src=0, group=None):
     """Initial parameter broadcast from rank 0 (what DDP does at wrap time)."""
     if world > 1:
@@ -120,11 +168,14 @@ class OverlappedBackward:
     """
 
     def __init__(self, model, optimizer, dist, world, payload="fp32", chunk_numel=32 * 1024 * 1024, group=None, force=False,
-                 plan=None):
+                 plan=None, collective="allreduce"):
         if not hasattr(optimizer, "flat_g"):
             raise TypeError("OverlappedBackward needs optim.FlatAdam (gradients in one flat buffer)")
         if payload not in ("fp32", "bf16"):
             raise ValueError("payload must be 'fp32' or 'bf16'")
+        if collective not in ("allreduce", "rs_ag"):
+            raise ValueError("collective must be 'allreduce' or 'rs_ag'")
+        self.collective = collective
         self.model, self.opt, self.dist, self.world, self.group = model, optimizer, dist, max(1, int(world)), group
         self.force, self.chunk, self.payload = force, chunk_numel, payload
         self.plan = plan if plan is not None else model.dp_plan()
@@ -193,10 +244,14 @@ class OverlappedBackward:
                 self.pending_bf16.append((lo, hi))
             else:
                 buf = self.opt.flat_g[lo:hi]
-            self.handles += allreduce_sum_begin(buf, self.dist, self.world, self.chunk, self.group, force=True)
+            if self.collective == "rs_ag":
+                self.handles.append(_RsAg(buf, self.dist, self.world, self.group))
+            else:
+                self.handles += [_Waiter(h) for h in allreduce_sum_begin(buf, self.dist, self.world, self.chunk, self.group, force=True)]
 
     def finish(self):
-        allreduce_end(self.handles)
+        for h in self.handles:
+            h.finish()
         self.handles = []
         if self.pending_bf16:
             from ..ops import kernels as K

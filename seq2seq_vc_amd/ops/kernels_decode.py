@@ -40,6 +40,11 @@ def decode_advance(pos, seed_base_ptr=None, seed_stride=0):
     _lib.check(_lib.lib().s2svc_decode_advance(ptr(pos), seed_base_ptr, seed_stride, stream()), "decode_advance")
 
 
+def ln_linear_supported(dtype, M, K):
+    """True if the fused LayerNorm + skinny projection kernel takes an (M, K) input (decode.py falls back to LayerNorm + GEMM)."""
+    return bool(_lib.lib().s2svc_decode_ln_linear_supported(_DT[dtype], M, K))
+
+
 def ln_linear(x, w, bias, *, norm=None, act=None, res=None, y_out=None, drop_p=0.0, seed=(None, 0)):
     """out = act(LN(x) . w^T + bias) [dropout] (+ res) in ONE launch; norm = (gamma, beta, eps) or None (plain linear);
     y_out: a tensor that receives LN(x) as well.  x (M <= 64, K), w (N, K) in the compute dtype; bias / gamma / beta fp32."""

@@ -81,6 +81,7 @@ class Trainer(object):
 
     # how parameter-gradient kernels are scheduled (ops/functional.py, "Side streams"): (side streams, inline batches)
     GRADIENT_WORK = (4, False)
+    DP_GRAD_PAYLOAD = "fp32"        # dtype of the data-parallel gradient exchange (config["dp_grad_payload"] overrides)
 
     def _schedule_gradient_work(self):
         if self.device.type == "cuda" and isinstance(self.optimizer, FlatAdam):
@@ -105,7 +106,8 @@ class Trainer(object):
         D.broadcast_model_(self._net(), self.optimizer, dist, self.world)
         if isinstance(self.optimizer, FlatAdam) and hasattr(self._net(), "dp_plan"):
             self.dp = D.OverlappedBackward(self._net(), self.optimizer, dist, self.world,
-                                           payload=self.config.get("dp_grad_payload", "fp32"))
+                                           payload=self.config.get("dp_grad_payload", self.DP_GRAD_PAYLOAD),
+                                           collective=self.config.get("dp_collective", "allreduce"))
 
     def _forward_context(self):
         """Context of the forward pass: activates the model's gradient cuts when the backward pass runs in stages."""
@@ -305,6 +307,8 @@ class AASVCTrainer(Trainer):
     gradient accumulation divides the loss; zero_grad AFTER the optimiser step."""
 
     GRADIENT_WORK = (0, True)       # chip-filling kernels: batched on the issuing stream, not forked (17.6 vs 20.9 ms/step)
+    DP_GRAD_PAYLOAD = "bf16"        # 630 MB of fp32 gradients per step (vc2) = 7 ms on one xGMI link against a 15 ms step: the
+    #                                 exchange runs on a bf16 copy by default; config["dp_grad_payload"] = "fp32" is the parity setting
     GRAPH_BATCH = {"xs": ("ilens", 0.0), "ys": ("olens", 0.0), "dp_inputs": ("dplens", 0.0)}
 
     def _graph_regime(self):

@@ -17,8 +17,16 @@ also builds everything lazily built for these shapes.  Second sighting: capture,
 With data parallelism the backward pass is captured stage by stage (distributed.OverlappedBackward) and the all-reduce of a
 finished stage is issued between the replays, as bench.py does; the optimiser step is its own graph behind the join.
 config["hip_graph"] = "trace" never captures (the eager reference of the tests for exactly this data path).
+
+The set of captured shapes is BOUNDED: at most config["graph_cache_size"] (default 16) keys keep their static buffers, length
+bank and graphs; reaching a new key beyond that evicts the least recently used one (its graphs return their blocks to the shared
+pool), and a key is only captured on its config["graph_capture_after"]-th sighting (default 2: the first one runs eagerly and
+builds everything that is built lazily for the shape).  With lengths rounded to 64 frames a corpus such as ARCTIC yields a
+handful of keys per model; a sampler that buckets utterances by length keeps the hit rate high on corpora with a wide spread.
 """
 import gc
+import logging
+from collections import OrderedDict
 
 import torch
 
@@ -43,7 +51,10 @@ class GraphedStep:
         self.t = trainer
         self.quantum = int(trainer.config.get("graph_length_quantum", 64))
         self.trace_only = trainer.config.get("hip_graph") == "trace"
-        self.entries = {}
+        self.entries = OrderedDict()                    # key -> _Entry, least recently used first
+        self.max_entries = max(1, int(trainer.config.get("graph_cache_size", 16)))
+        self.capture_after = max(2, int(trainer.config.get("graph_capture_after", 2)))
+        self.evictions = 0
         self.stream = torch.cuda.Stream(trainer.device)      # replaced by a distinct one at capture time if it aliases a stream in use
         self.pool = torch.cuda.graph_pool_handle()     # one memory pool for the graphs of all shapes
         if trainer.gradient_accumulate_steps != 1:
@@ -98,10 +109,18 @@ class GraphedStep:
         key = self._key(batch, spec)
         e = self.entries.get(key)
         if e is None:
+            while len(self.entries) >= self.max_entries:          # bounded: drop the least recently used shape
+                old_key, old = self.entries.popitem(last=False)
+                old.graphs, old.static, old.bank = [], {}, None       # graphs first: their blocks go back to the shared pool
+                self.evictions += 1
+                logging.info(f"hip_graph: evicted the captured step of {old_key[1]} ({self.evictions} evictions so far; "
+                             f'config["graph_cache_size"] = {self.max_entries})')
             e = self.entries[key] = _Entry()
+        else:
+            self.entries.move_to_end(key)
         e.sightings += 1
         static_batch = self._load(e, batch, spec)
-        if self.trace_only or e.sightings == 1:
+        if self.trace_only or e.sightings < self.capture_after:
             bank = Mo.LensBank(t.device)
             with Mo.lens_bank(bank):
                 self._roots(e, bank)
@@ -111,6 +130,7 @@ class GraphedStep:
         if not e.graphs:
             self._capture(e, static_batch)
             e.bank.upload()
+            logging.info(f"hip_graph: captured the step for {key[1]} ({len(self.entries)} of at most {self.max_entries} shapes cached)")
         else:
             e.bank.refresh({lname: src.tolist() for lname, src in e.lens_src.items()})
             t.steps += e.deltas[0]

@@ -1,6 +1,6 @@
 """One rank of a data-parallel trainer run (spawned by gpu_model_check.dp_trainers_two_ranks).
 
-    python tests/dp_worker.py <vtn|aasvc> <rank> <world> <port> <out.pt> [payload] [none|trace|graph]
+    python tests/dp_worker.py <vtn|aasvc> <rank> <world> <port> <out.pt> [payload] [none|trace|graph] [allreduce|rs_ag]
 
 The last argument runs the trainer with config["hip_graph"] ("trace": the eager reference of the captured step, "graph":
 stage graphs replayed with the all-reduces between them; trainers/graphed.py), 5 steps through Trainer._step.
@@ -71,6 +71,7 @@ def main():
     kind, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     payload = sys.argv[6] if len(sys.argv) > 6 else "fp32"
     graph_mode = sys.argv[7] if len(sys.argv) > 7 else "none"
+    collective = sys.argv[8] if len(sys.argv) > 8 else "allreduce"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     import gpu_model_check as mc
@@ -84,7 +85,7 @@ def main():
     K.manual_seed(7)
     cfg, z = mc.load("vtn_tiny_train" if kind == "vtn" else "aasvc_tiny_train")
     model, crit, conf = build(kind, z, cfg, perturb=(rank != 0))
-    conf = dict(conf, distributed=True, rank=rank, dp_grad_payload=payload)
+    conf = dict(conf, distributed=True, rank=rank, dp_grad_payload=payload, dp_collective=collective)
     if graph_mode != "none":
         conf.update(hip_graph=(True if graph_mode == "graph" else "trace"), graph_length_quantum=8)
     opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10)

@@ -239,6 +239,48 @@ def decode_batch_vs_single():
 
 
 @case
+def decode_large_batch_and_wide_model():
+    """(i) more than 64 utterances in one inference_batch call (the decode-step kernels take a batch of at most 64 rows:
+    the call runs in groups) == the same utterances decoded one at a time; (ii) an fp32 model with adim = 512 at a batch of 40 --
+    LayerNorm + projection no longer fit the fused skinny kernel's register-resident form (K = 512 fp32, batch > 32), so the step
+    takes the LayerNorm kernel + GEMM instead, decided before the step is captured -- == one utterance at a time (pre- and post-norm
+    decoder); (iii) an output dimension that is not a multiple of 8 (odim = 20: the prenet's first projection has K = 20)."""
+    from seq2seq_vc_amd import models as M
+    res = []
+    try:
+        Fn.set_compute_dtype(torch.float32)
+        args = {"threshold": 0.5, "minlenratio": 0.3, "maxlenratio": 1.5}
+        g = torch.Generator().manual_seed(3)
+        for tag, cfgs, B in (("70 utterances, d=64", dict(idim=80, odim=80, adim=64, aheads=2, elayers=1, eunits=128, dlayers=1, dunits=128,
+                                                          decoder_reduction_factor=2, dprenet_dropout_rate=0.0), 70),
+                             ("fp32 adim=512, batch 40, post-norm decoder", dict(idim=80, odim=80, adim=512, aheads=4, elayers=1, eunits=512, dlayers=2,
+                                                                             dunits=512, decoder_reduction_factor=2, dprenet_dropout_rate=0.0), 40),
+                             ("fp32 adim=512, batch 40, pre-norm decoder", dict(idim=80, odim=80, adim=512, aheads=4, elayers=1, eunits=512, dlayers=1,
+                                                                            dunits=512, decoder_reduction_factor=2, dprenet_dropout_rate=0.0,
+                                                                            decoder_normalize_before=True), 40),
+                             ("odim=20 (K = 20 in the prenet)", dict(idim=20, odim=20, adim=64, aheads=2, elayers=1, eunits=128, dlayers=1, dunits=128,
+                                                                     decoder_reduction_factor=2, dprenet_dropout_rate=0.0), 5)):
+            torch.manual_seed(1)
+            model = M.VTN(**cfgs).to(DEV).eval()
+            lens = [int(v) for v in torch.randint(24, 49, (B,), generator=g)]
+            xs = torch.zeros(B, max(lens), cfgs["idim"])
+            for b, n in enumerate(lens):
+                xs[b, :n] = torch.randn(n, cfgs["idim"], generator=g)
+            xs = xs.to(DEV)
+            with torch.no_grad():
+                batch = model.inference_batch(xs, torch.tensor(lens), args, poll=4)
+                res.append((len(batch) == B, f"{tag}: {len(batch)} results for {B} utterances"))
+                for b in sorted({0, 1, B // 2, B - 1}):
+                    single = model.inference(xs[b, :lens[b]], args)
+                    for part, u, v in zip(("outs", "probs", "att"), batch[b], single):
+                        res.append(cmp(f"{tag}: batch[{b}] (T={lens[b]}, L={single[0].shape[0]}) {part}", u, v.cpu().numpy(), 5e-5))
+            del model
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+    return res
+
+
+@case
 def decode_bf16_dropout_runs():
     """bf16 compute with the always-on prenet dropout: finite frames, per-step masks differ between replays."""
     from seq2seq_vc_amd import models as M
@@ -745,7 +787,7 @@ def trainers_replay_captured_steps():
             out.append(bt)
         return out
 
-    def run(kind, mode, data, distributed=False):
+    def run(kind, mode, data, distributed=False, extra=None):
         cfg, z = load({"vtn": "vtn_tiny_train", "tts": "tts_tiny_train", "aasvc": "aasvc_tiny_train"}[kind])
         K.manual_seed(11)
         torch.manual_seed(3)
@@ -759,6 +801,7 @@ def trainers_replay_captured_steps():
             conf["hip_graph"] = mode
         if distributed:
             conf["distributed"] = True
+        conf.update(extra or {})
         logs = []
         if kind == "vtn":
             tr = T.ARVCTrainer(0, 0, {"train": data}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None, conf, device=DEV)
@@ -803,6 +846,11 @@ def trainers_replay_captured_steps():
             res.append((same_logs and len(l_t) == len(l_g), f"{kind}: logged losses agree step by step ({[round(v, 4) for v in l_g[-1].values()]})"))
             finite = all(v == v and abs(v) < 1e4 for d in l_g for v in d.values())
             res.append((finite, f"{kind}: losses finite"))
+            if kind == "vtn":        # bounded cache: one shape at a time -> the other shape's arrival evicts and re-traces
+                p_e, _, s_e, _ = run(kind, True, data, extra={"graph_cache_size": 1})
+                ev = run.last._graphed.evictions
+                res.append((torch.equal(p_t, p_e) and ev >= 2 and len(run.last._graphed.entries) == 1,
+                            f"{kind}: graph_cache_size = 1: {ev} evictions, {s_e} steps, parameters equal to the traced run: {bool(torch.equal(p_t, p_e))}"))
             # a batch that fills its padded shape: trace mode == plain trainer
             full = [data[0]] * 2
             p_a, l_a, _, _ = run(kind, None, full)
@@ -1794,8 +1842,8 @@ def decode_c5_vs_oracle():
 
 
 
-def _dp_two_ranks(kind, payload="fp32"):
-    """Two trainer processes (tests/dp_worker.py) on this one GPU over gloo vs a single-process replay of what data
+def _dp_two_ranks(kind, payload="fp32", world=2, collective="allreduce"):
+    """`world` trainer processes (tests/dp_worker.py) on this one GPU over gloo vs a single-process replay of what data
     parallelism must compute: per-rank gradients of the rank's own share (rank-local BatchNorm statistics), averaged, one
     optimiser step on the average; rank 0's BatchNorm buffers are the ones that count."""
     import subprocess
@@ -1805,11 +1853,11 @@ def _dp_two_ranks(kind, payload="fp32"):
     from seq2seq_vc_amd.optim import FlatAdam
     res = []
     here = os.path.dirname(os.path.abspath(__file__))
-    port = str(29700 + (os.getpid() % 200) + (0 if kind == "vtn" else 1) + (2 if payload == "bf16" else 0))
+    port = str(29700 + (os.getpid() % 200) + (0 if kind == "vtn" else 1) + (2 if payload == "bf16" else 0) + (4 if world != 2 else 0))
     with tempfile.TemporaryDirectory() as tmp:
-        outs = [os.path.join(tmp, f"r{r}.pt") for r in range(2)]
-        procs = [subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py"), kind, str(r), "2", port, outs[r], payload],
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [os.path.join(tmp, f"r{r}.pt") for r in range(world)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py"), kind, str(r), str(world), port, outs[r], payload, "none",
+                                   collective], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
         logs = []
         for p in procs:
             try:
@@ -1819,11 +1867,12 @@ def _dp_two_ranks(kind, payload="fp32"):
                 o, _ = p.communicate()
             logs.append(o.decode(errors="replace")[-1500:])
         ok = all(p.returncode == 0 for p in procs) and all(os.path.exists(o) for o in outs)
-        res.append((ok, f"dp[{kind}] both ranks finished" + ("" if ok else ":\n" + "\n---\n".join(logs))))
+        res.append((ok, f"dp[{kind}] all {world} ranks finished" + ("" if ok else ":\n" + "\n---\n".join(logs))))
         if not ok:
             return res
-        r0, r1 = (torch.load(o) for o in outs)
-    res.append((bool(torch.equal(r0["flat_p"], r1["flat_p"])), f"dp[{kind}] ranks hold identical parameters after 3 steps "
+        rs_ = [torch.load(o) for o in outs]
+        r0 = rs_[0]
+    res.append((all(bool(torch.equal(r0["flat_p"], r["flat_p"])) for r in rs_[1:]), f"dp[{kind}, {collective}] {world} ranks hold identical parameters after 3 steps "
                 f"({r0['stages']} backward stages, buckets {[round(b / 1e6, 2) for b in r0['bucket_bytes']]} MB)"))
     # single-process replay
     Fn.set_compute_dtype(torch.float32)
@@ -1834,8 +1883,8 @@ def _dp_two_ranks(kind, payload="fp32"):
     losses0 = []
     for step in range(3):
         gs, keep = [], None
-        for r in range(2):
-            batch, sl = W.shares(kind, z, r, 2)
+        for r in range(world):
+            batch, sl = W.shares(kind, z, r, world)
             W.set_noise(kind, model, z, cfg, batch, sl)
             if r == 1:
                 keep = {k: v.clone() for k, v in model.named_buffers()}
@@ -1858,13 +1907,13 @@ def _dp_two_ranks(kind, payload="fp32"):
         with torch.no_grad():
             for k, v in model.named_buffers():
                 v.copy_(keep[k])                      # rank 0 never saw rank 1's share
-        opt.flat_g.copy_(gs[0] * 0.5 + gs[1] * 0.5)
+        opt.flat_g.copy_(sum(g_ * (1.0 / world) for g_ in gs))
         opt.step()
     exact = bool(torch.equal(opt.flat_p.cpu(), r0["flat_p"]))
     # tolerance: parameters whose gradient is zero up to rounding get Adam updates of size ~lr from the rounding noise, which
     # depends on the summation order (two ranks + all-reduce vs one process): a few elements move by up to ~lr, the mean by ~1e-8
     tol, l1 = (2e-3, 1e-6) if payload == "fp32" else (5e-3, 2e-5)
-    res.append(cmp(f"dp[{kind}, {payload}] 2-rank parameters vs the single-process replay (bit-exact: {exact})", r0["flat_p"], opt.flat_p.cpu(), tol, l1_tol=l1))
+    res.append(cmp(f"dp[{kind}, {payload}, {collective}] {world}-rank parameters vs the single-process replay (bit-exact: {exact})", r0["flat_p"], opt.flat_p.cpu(), tol, l1_tol=l1))
     for k, v in model.named_buffers():
         if v.dtype.is_floating_point:
             ok, msg = cmp(f"dp[{kind}] rank-0 buffer {k}", r0["buffers"][k], v.detach().cpu(), 1e-6 if payload == "fp32" else 1e-3)
@@ -1930,6 +1979,18 @@ def dp_trainers_two_ranks_captured_steps():
         same_logs = all(abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(a[k])) for a, b in zip(tr[0]["logs"], gr[0]["logs"]) for k in a)
         res.append((same_logs and len(gr[0]["logs"]) == 5, f"dp+graph[{kind}] rank-0 logs agree over 5 steps"))
     return res
+
+
+@case
+def dp_trainers_three_ranks_rs_ag():
+    """Three ranks (a world size that does not divide the buckets: the reduce-scatter shards are padded) with every bucket
+    exchanged as reduce-scatter + all-gather (config["dp_collective"] = "rs_ag"; over gloo the reduce-scatter is emulated,
+    the sharding / padding / gather path is the product's): VTN in fp32 and AAS-VC with its default bf16 payload."""
+    try:
+        return _dp_two_ranks("vtn", world=3, collective="rs_ag") + _dp_two_ranks("aasvc", payload="bf16", world=3, collective="rs_ag")
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
 
 
 @case

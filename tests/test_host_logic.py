@@ -173,6 +173,50 @@ def test_two_rank_gloo_gradient_allreduce_is_the_mean_of_rank_gradients():
     assert torch.allclose(f0, (g0 + g1) / 2, atol=1e-6) and torch.equal(f0, f1)
 
 
+def _rsag_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from seq2seq_vc_amd.distributed import _RsAg, allreduce_mean_
+    out = []
+    for n in (1000, 1003, 7):                               # divisible by the world size, not divisible, smaller than a shard row
+        g = torch.Generator().manual_seed(10 * n + rank)
+        a = torch.randn(n, generator=g)
+        want = a.clone()
+        dist.all_reduce(want)                               # the plain sum
+        buckets = [_RsAg(a[: n // 2], dist, world), _RsAg(a[n // 2:], dist, world)]      # two buckets in flight, slices of one buffer
+        for b_ in buckets:
+            b_.finish()
+        out.append((n, a.clone(), want))
+    m = torch.arange(12, dtype=torch.float32) * (rank + 1)
+    allreduce_mean_(m, dist, world, chunk_numel=5)
+    q.put((rank, out, m))
+    dist.destroy_process_group()
+
+
+def test_four_rank_gloo_reduce_scatter_all_gather_equals_all_reduce():
+    """distributed._RsAg (OverlappedBackward(collective="rs_ag")): a bucket reduced as reduce-scatter + all-gather holds the
+    all-reduce's sum on every rank -- sizes that the world size divides and that it does not (padded shards), several buckets of
+    one buffer in flight; and the chunked mean all-reduce at world size 4."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 4
+    procs = [ctx.Process(target=_rsag_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, m in res:
+        for n, got, want in out:
+            assert torch.allclose(got, want, rtol=1e-6, atol=1e-6), (rank, n)
+            assert torch.equal(got, res[0][1][[k for k, _, _ in res[0][1]].index(n)][1])        # identical on every rank
+        assert torch.allclose(m, torch.arange(12, dtype=torch.float32) * 2.5)
+
+
 def test_gradient_cuts_split_the_backward_pass_without_changing_it():
     """ops.functional.GradCuts (the stage boundaries of distributed.OverlappedBackward): a cut carrying ONE tensor and a cut
     carrying a TUPLE (residual stream + pending feed-forward output of a pre-norm layer stack, one member may be None) give the
