@@ -60,13 +60,26 @@ class _DeviceBatch(object):
     kernels with them).  `sort_by_length=True` orders a batch longest-first (bucketing is the sampler's business; within a
     batch the order only matters to RNN-style consumers and is off by default, as in the reference)."""
 
-    def __init__(self, device="cuda", mean=None, scale=None, sort_by_length=False):
+    def __init__(self, device="cuda", mean=None, scale=None, sort_by_length=False, stats=None):
+        """mean / scale: statistics applied to every field (one stats file for source and target, as when both sides share a
+        feature extractor).  stats: {"src": (mean, scale), "trg": (...), "dp": (...)} -- per-field statistics as the reference's
+        recipes keep them (separate source / target stats files, bin/normalize.py:172-193); a field without an entry is not
+        normalised.  The feature dimension of a field must equal the length of its statistics."""
         self.device = torch.device(device)
         self.sort_by_length = sort_by_length
-        self.mean = None if mean is None else torch.as_tensor(mean, dtype=torch.float32, device=self.device).contiguous()
-        self.inv_scale = None if scale is None else (1.0 / torch.as_tensor(scale, dtype=torch.float32, device=self.device)).contiguous()
+        dev_pair = lambda m, sc: (torch.as_tensor(m, dtype=torch.float32, device=self.device).contiguous(),
+                                  (1.0 / torch.as_tensor(sc, dtype=torch.float32, device=self.device)).contiguous())
+        self.stats = {}
+        if mean is not None:
+            if scale is None:
+                raise ValueError("device collater: `mean` needs `scale`")
+            self.stats = {k: dev_pair(mean, scale) for k in ("src", "trg", "dp")}
+        for k, (m, sc) in (stats or {}).items():
+            if k not in ("src", "trg", "dp"):
+                raise ValueError(f"device collater: unknown statistics field '{k}' (src / trg / dp)")
+            self.stats[k] = dev_pair(m, sc)
 
-    def _pad(self, seqs, want_labels=False, normalise=True):
+    def _pad(self, seqs, want_labels=False, field=None):
         from .. import _lib
         from ..ops import kernels as K
         lens = [int(s.shape[0]) for s in seqs]
@@ -81,10 +94,12 @@ class _DeviceBatch(object):
         B, Tmax = len(seqs), max(lens)
         out = torch.empty((B, Tmax, D), dtype=torch.float32, device=self.device)
         labels = torch.empty((B, Tmax), dtype=torch.float32, device=self.device) if want_labels else None
-        use_norm = normalise and self.mean is not None
+        st = self.stats.get(field)
+        if st is not None and (st[0].numel() != D or st[1].numel() != D):
+            raise ValueError(f"device collater: '{field}' features have {D} dimensions but their statistics {st[0].numel()}")
         _lib.check(_lib.lib().s2svc_ragged_to_padded(B, Tmax, D, ragged.data_ptr(), offs.data_ptr(),
-                                                     self.mean.data_ptr() if use_norm else None,
-                                                     self.inv_scale.data_ptr() if use_norm else None, out.data_ptr(),
+                                                     st[0].data_ptr() if st is not None else None,
+                                                     st[1].data_ptr() if st is not None else None, out.data_ptr(),
                                                      None if labels is None else labels.data_ptr(), K.stream()), "ragged_to_padded")
         return out, torch.tensor(lens, dtype=torch.long), labels
 
@@ -99,8 +114,8 @@ class DeviceARVCCollater(_DeviceBatch):
 
     def __call__(self, batch):
         batch = self._order(batch, "src_feat")
-        xs, ilens, _ = self._pad([b["src_feat"] for b in batch])
-        ys, olens, labels = self._pad([b["trg_feat"] for b in batch], want_labels=True)
+        xs, ilens, _ = self._pad([b["src_feat"] for b in batch], field="src")
+        ys, olens, labels = self._pad([b["trg_feat"] for b in batch], want_labels=True, field="trg")
         return {"xs": xs, "ilens": ilens, "ys": ys, "olens": olens, "labels": labels, "spembs": None}
 
 
@@ -109,9 +124,9 @@ class DeviceNARVCCollater(_DeviceBatch):
 
     def __call__(self, batch):
         batch = self._order(batch, "src_feat")
-        xs, ilens, _ = self._pad([b["src_feat"] for b in batch])
-        ys, olens, _ = self._pad([b["trg_feat"] for b in batch])
-        dps, dplens, _ = self._pad([b["dp_input"] for b in batch])
+        xs, ilens, _ = self._pad([b["src_feat"] for b in batch], field="src")
+        ys, olens, _ = self._pad([b["trg_feat"] for b in batch], field="trg")
+        dps, dplens, _ = self._pad([b["dp_input"] for b in batch], field="dp")
         items = {"xs": xs, "ilens": ilens, "ys": ys, "olens": olens, "dp_inputs": dps, "dplens": dplens, "spembs": None}
         if "duration" in batch[0]:
             ds = [b["duration"] for b in batch]

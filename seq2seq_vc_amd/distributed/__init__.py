@@ -280,13 +280,20 @@ def allreduce_grads_(params, dist, world, group=None):
     """Mean all-reduce of `p.grad` for torch optimisers (no flat buffer): one coalesced collective."""
     if world <= 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    # every trainable parameter takes part, with zeros where this rank produced no gradient (a branch that did not run here,
+    # e.g. a duration predictor before dp_train_start_steps): the buffer layout must not depend on which gradients exist, or
+    # the ranks' collectives mismatch in size
+    ps = [p for p in params if p.requires_grad]
+    if not ps:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.mul_(1.0 / world)
     o = 0
-    for g in grads:
-        g.copy_(flat[o:o + g.numel()].view_as(g))
-        o += g.numel()
+    for p in ps:
+        n = p.numel()
+        if p.grad is None:
+            p.grad = flat[o:o + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[o:o + n].view_as(p))
+        o += n

@@ -471,6 +471,18 @@ def stft_logmel_batched_and_device_collaters():
     il = h["ilens"]
     ref = (h["xs"] - torch.from_numpy(mean)) / torch.from_numpy(scale) * (torch.arange(h["xs"].shape[1])[None, :, None] < il[:, None, None])
     res.append(check("DeviceARVCCollater with fused normalisation", dn["xs"], ref, torch.float32, atol=1e-6, rtol=1e-6))
+    # per-field statistics (separate source / target stats files): the target side is normalised with its own, the source left alone
+    m2, s2 = rng.standard_normal(80).astype(np.float32), (0.5 + rng.random(80)).astype(np.float32)
+    dn = C.DeviceARVCCollater(stats={"trg": (m2, s2)})(batch)
+    ol = h["olens"]
+    ref = (h["ys"] - torch.from_numpy(m2)) / torch.from_numpy(s2) * (torch.arange(h["ys"].shape[1])[None, :, None] < ol[:, None, None])
+    res.append(check("DeviceARVCCollater, per-field statistics: target normalised", dn["ys"], ref, torch.float32, atol=1e-6, rtol=1e-6))
+    res.append((bool(torch.equal(dn["xs"].cpu(), h["xs"])), "DeviceARVCCollater, per-field statistics: source untouched"))
+    try:
+        C.DeviceARVCCollater(mean=mean[:40], scale=scale[:40])(batch)
+        res.append((False, "statistics of the wrong dimension must raise"))
+    except ValueError as e:
+        res.append((True, f"statistics of the wrong dimension raise: {e}"))
     return res
 
 
