@@ -352,11 +352,17 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
   p8_wait_vmcnt<0>();                  // the zero-block DMAs issued past the end
   __syncthreads();                     // every wave is done with the operand stages: reuse them as fp32 C tiles
   float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-      epilogue_tile<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 64 + b * 32, acc[a][b], cs, 1, 0, zb);
+  // the four 64 x 32 sub-tiles in a ROLLED loop: staging is per sub-tile (constant register indices), the flush code exists once
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    switch (q) {
+      case 0: epilogue_stage<64, 32>(acc[0][0], cs); break;
+      case 1: epilogue_stage<64, 32>(acc[0][1], cs); break;
+      case 2: epilogue_stage<64, 32>(acc[1][0], cs); break;
+      default: epilogue_stage<64, 32>(acc[1][1], cs); break;
+    }
+    epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + (q >> 1) * 64, n0 + wc * 64 + (q & 1) * 32, cs, 1, 0, zb);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -452,9 +458,12 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
   p8_wait_vmcnt<0>();
   __syncthreads();
   float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-    epilogue_tile<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, acc[a], cs, 1, 0, zb);
+#pragma unroll 1
+  for (int a = 0; a < 2; ++a) {          // rolled: one copy of the flush code (see epilogue_stage)
+    if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
+    else epilogue_stage<64, 32>(acc[1], cs);
+    epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, cs, 1, 0, zb);
+  }
 }
 
 int g_p8_mode = -1;

@@ -105,9 +105,13 @@ __device__ __forceinline__ bool epilogue_vec_ok(const s2svc_gemm_desc& d) {
   return ok;
 }
 
+// The two halves of epilogue_tile: `stage` copies a wave's accumulator tile into its fp32 LDS tile (register indices are
+// compile-time constants: it must be expanded per sub-tile), `flush` does everything else from LDS.  A kernel with several
+// sub-tiles per wave (gemm_8ph.hip) stages them inside a `switch` of a ROLLED loop and shares ONE copy of the flush code: the
+// epilogue is cold code (the instruction cache is invalidated per dispatch) and four inlined copies of it were most of the
+// "fixed" ~11 us of every launch of those kernels.
 template <int WTM, int WTN>
-__device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, int z1, int m_base, int n_base,
-                                              const f32x4_t (&acc)[WTM / 16][WTN / 16], float* cs, int splitk, int zs, int zb) {
+__device__ __forceinline__ void epilogue_stage(const f32x4_t (&acc)[WTM / 16][WTN / 16], float* cs) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int i = 0; i < WTM / 16; ++i)
@@ -118,6 +122,23 @@ __device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, 
         const int row = i * 16 + lg * 4 + r, col = j * 16 + lr;
         cs[row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4))] = acc[i][j][r];
       }
+}
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0, int z1, int m_base, int n_base, const float* cs,
+                                               int splitk, int zs, int zb);
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_tile(const s2svc_gemm_desc& d, int z0, int z1, int m_base, int n_base,
+                                              const f32x4_t (&acc)[WTM / 16][WTN / 16], float* cs, int splitk, int zs, int zb) {
+  epilogue_stage<WTM, WTN>(acc, cs);
+  epilogue_flush<WTM, WTN>(d, z0, z1, m_base, n_base, cs, splitk, zs, zb);
+}
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0, int z1, int m_base, int n_base, const float* cs,
+                                               int splitk, int zs, int zb) {
+  const int lane = threadIdx.x & 63;
   if (splitk > 1 || !epilogue_vec_ok(d)) {
     // element-wise path (split-K partials, unaligned C): still read back from LDS, so that the accumulator registers
     // are only ever indexed by compile-time constants (a runtime-indexed acc[][] is demoted to scratch memory and
