@@ -486,6 +486,24 @@ def stft_logmel_batched_and_device_collaters():
     return res
 
 
+@case
+def c_abi_driver_without_python():
+    """the MAS / forward-sum / STFT entry points driven from a C++ binary (tools/cabi_driver.cpp: hipMalloc'ed buffers,
+    the functions called as include/s2svc_hip.h declares them) -- alignment-search known answers KAT1 / KAT2, the CTC loss against a
+    double-precision alpha recursion, the FFT front-end against the closed form of a bin-centred cosine."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "cabi_driver.bin")
+    if not os.path.exists(exe):
+        return [(False, "tools/cabi_driver.bin is missing: run __graft_entry__.build()")]
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = p.stdout.decode(errors="replace")
+    res = [(p.returncode == 0, f"cabi_driver exit code {p.returncode}:\n{out[-1500:]}")]
+    res += [(line.startswith("PASS"), line.strip()) for line in out.splitlines() if line[:4] in ("PASS", "FAIL")]
+    res.append((sum(1 for ok, _ in res[1:] if ok) >= 4, "four checks ran"))
+    return res
+
+
 def main():
     nfail = 0
     for fn in CASES:
