@@ -30,25 +30,56 @@ __device__ __forceinline__ float grp16_sum(float v) {
   return v;
 }
 __device__ __forceinline__ bf16x8_t zero8() { return (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
+// component r (wave-uniform, from a ROLLED loop) of an accumulator: these kernels run once per launch on a cold instruction
+// cache with one workgroup per CU, so code size is time (~0.45 us per KB executed, tools/kernel_code_sizes.py) -- the row
+// loops of the softmax and the three output GEMMs of the backward are rolled, not unrolled
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+__device__ __forceinline__ uint32_t comp4(const u32x4_t& v, int r) { return r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : v[3]; }
+__device__ __forceinline__ float comp(const f32x4_t& v, int r) { return r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : v[3]; }
 
-// rows [0, R) x dk of a (rows, ld) matrix -> LDS row-major with pitch dk+8 (zero rows past R)
-__device__ __forceinline__ void stage_rows(const bf16_t* g, int64_t ld, int R, int dk, bf16_t* lds) {
-  const int ppr = dk / 8;
-  for (int p = threadIdx.x; p < 64 * ppr; p += 256) {
+// Operand staging, split into "issue every global load" / "write LDS".  load_rows / put_rows: rows [0, R) x DK of a (rows, ld)
+// matrix -> LDS row-major with pitch DK + 8 (zero rows past R); load_rows_t / put_rows_t: the same rows transposed,
+// lds[d * TP + row] (zero columns past R).  A workgroup of these kernels is alone on its CU
+// with cold caches, and a rolled load -> LDS-store loop pays one memory round trip (~1-2 us) per iteration and per matrix
+// (12 in the backward).  With the pieces of ALL matrices in registers before the first LDS store the prologue is one round trip.
+template <int DK>
+__device__ __forceinline__ void load_rows(const bf16_t* g, int64_t ld, int R, uint4 (&r)[DK / 32]) {
+  constexpr int ppr = DK / 8;
+#pragma unroll
+  for (int i = 0; i < DK / 32; ++i) {
+    const int p = threadIdx.x + 256 * i;
     const int row = p / ppr, c = p - row * ppr;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < R) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
-    *reinterpret_cast<uint4*>(lds + row * (dk + 8) + c * 8) = v;
+    r[i] = make_uint4(0, 0, 0, 0);
+    if (row < R) r[i] = *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
   }
 }
-// the same rows, transposed: lds[d * TP + row] (zero columns past R)
-__device__ __forceinline__ void stage_rows_t(const bf16_t* g, int64_t ld, int R, int dk, bf16_t* lds) {
-  const int ppr = dk / 8;
-  for (int p = threadIdx.x; p < 64 * ppr; p += 256) {
-    const int row = p % 64, c = p / 64;          // consecutive threads -> consecutive rows: conflict-free 2-byte LDS writes
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < R) v = *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+template <int DK>
+__device__ __forceinline__ void load_rows_t(const bf16_t* g, int64_t ld, int R, uint4 (&r)[DK / 32]) {
+#pragma unroll
+  for (int i = 0; i < DK / 32; ++i) {
+    const int p = threadIdx.x + 256 * i;
+    const int row = p & 63, c = p >> 6;
+    r[i] = make_uint4(0, 0, 0, 0);
+    if (row < R) r[i] = *reinterpret_cast<const uint4*>(g + (int64_t)row * ld + c * 8);
+  }
+}
+template <int DK>
+__device__ __forceinline__ void put_rows(const uint4 (&r)[DK / 32], bf16_t* lds) {
+  constexpr int ppr = DK / 8;
+#pragma unroll
+  for (int i = 0; i < DK / 32; ++i) {
+    const int p = threadIdx.x + 256 * i;
+    const int row = p / ppr, c = p - row * ppr;
+    *reinterpret_cast<uint4*>(lds + row * (DK + 8) + c * 8) = r[i];
+  }
+}
+template <int DK>
+__device__ __forceinline__ void put_rows_t(const uint4 (&r)[DK / 32], bf16_t* lds) {
+#pragma unroll
+  for (int i = 0; i < DK / 32; ++i) {
+    const int p = threadIdx.x + 256 * i;
+    const int row = p & 63, c = p >> 6;          // consecutive threads -> consecutive rows: conflict-free 2-byte LDS writes
+    const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       lds[(c * 8 + 2 * e) * TP + row] = (bf16_t)(w[e] & 0xffffu);
@@ -102,14 +133,17 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(int H, int T1, int 
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const int kl = klen ? (klen[b] < T2 ? klen[b] : T2) : T2;
-  stage_rows(k + (int64_t)b * kbs + h * DK, ldk, T2, DK, Ks);
-  stage_rows_t(v + (int64_t)b * vbs + h * DK, ldv, T2, DK, Vt);
+  uint4 rk[DK / 32], rv[DK / 32];
+  load_rows<DK>(k + (int64_t)b * kbs + h * DK, ldk, T2, rk);
+  load_rows_t<DK>(v + (int64_t)b * vbs + h * DK, ldv, T2, rv);
   // Q fragments of this wave's 16 rows, straight from global
   const int qi = wave * 16 + lr;
   bf16x8_t qa[DK / 32];
 #pragma unroll
   for (int ks = 0; ks < DK / 32; ++ks)
     qa[ks] = qi < T1 ? *reinterpret_cast<const bf16x8_t*>(q + (int64_t)b * qbs + (int64_t)qi * ldq + h * DK + ks * 32 + lg * 8) : zero8();
+  put_rows<DK>(rk, Ks);
+  put_rows_t<DK>(rv, Vt);
   __syncthreads();
   f32x4_t s[4];
 #pragma unroll
@@ -123,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(int H, int T1, int 
   }
   // softmax over the 64 keys of each of this lane's 4 rows (row = wave*16 + lg*4 + r ; column of s[jn][r] = jn*16 + lr)
   bf16_t* pw = Pw[wave];
-#pragma unroll
+#pragma unroll 1
   for (int r = 0; r < 4; ++r) {
     const int i = wave * 16 + lg * 4 + r;
     float val[4];
@@ -132,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(int H, int T1, int 
     for (int jn = 0; jn < 4; ++jn) {
       const int j = jn * 16 + lr;
       const bool ok = j < kl && (!causal || j <= i);
-      val[jn] = ok ? s[jn][r] * scale : NEG;
+      val[jn] = ok ? comp(s[jn], r) * scale : NEG;
       mx = fmaxf(mx, val[jn]);
     }
     mx = grp16_max(mx);
@@ -167,7 +201,9 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(int H, int T1, int 
       o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dn], 0, 0, 0);
     }
   }
-  __syncthreads();                                   // every wave is past its K reads: Ks becomes the output staging area
+  // every wave is past its K reads: Ks becomes the output staging area (LDS-only barrier: __syncthreads() would also wait for
+  // the attention-map stores above to be acknowledged)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   {
     bf16_t* base = out + (int64_t)b * obs + (int64_t)(wave * 16) * ldo + h * DK;
     const bool vec_ok = (ldo % 8 == 0) && (obs % 8 == 0) && (((uintptr_t)out) % 16 == 0);
@@ -197,15 +233,35 @@ __global__ __launch_bounds__(256) void attn_fused_bwd_kernel(int H, int T1, int 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  stage_rows(v + (int64_t)b * vbs + h * DK, ldv, T2, DK, Vs);
-  stage_rows_t(k + (int64_t)b * kbs + h * DK, ldk, T2, DK, Kt);
-  stage_rows_t(q + (int64_t)b * qbs + h * DK, ldq, T1, DK, Qt);
-  stage_rows_t(dout + (int64_t)b * obs + h * DK, ldo, T1, DK, dOt);
+  // every global read of the kernel is issued here, before the first LDS store (see load_rows): the four operand tiles, this
+  // wave's dO fragments, and the lane's 16 attention-map / map-gradient elements of the softmax backward
+  uint4 rv[DK / 32], rk[DK / 32], rq[DK / 32], rdo[DK / 32];
+  load_rows<DK>(v + (int64_t)b * vbs + h * DK, ldv, T2, rv);
+  load_rows_t<DK>(k + (int64_t)b * kbs + h * DK, ldk, T2, rk);
+  load_rows_t<DK>(q + (int64_t)b * qbs + h * DK, ldq, T1, rq);
+  load_rows_t<DK>(dout + (int64_t)b * obs + h * DK, ldo, T1, rdo);
   const int qi = wave * 16 + lr;
   bf16x8_t da[DK / 32];
 #pragma unroll
   for (int ks = 0; ks < DK / 32; ++ks)
     da[ks] = qi < T1 ? *reinterpret_cast<const bf16x8_t*>(dout + (int64_t)b * obs + (int64_t)qi * ldo + h * DK + ks * 32 + lg * 8) : zero8();
+  u32x4_t praw[4], graw[4];            // [jn][r]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = wave * 16 + lg * 4 + r;
+    const int64_t arow = ((int64_t)(b * H + h) * T1 + i) * ld;
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      const int j = jn * 16 + lr;
+      const bool in = i < T1 && j < T2;
+      praw[jn][r] = in ? attn[arow + j] : 0u;
+      graw[jn][r] = (dattn && in) ? dattn[arow + j] : 0u;
+    }
+  }
+  put_rows<DK>(rv, Vs);
+  put_rows_t<DK>(rk, Kt);
+  put_rows_t<DK>(rq, Qt);
+  put_rows_t<DK>(rdo, dOt);
   __syncthreads();
   // dP = dO . V^T
   f32x4_t dp[4];
@@ -220,7 +276,7 @@ __global__ __launch_bounds__(256) void attn_fused_bwd_kernel(int H, int T1, int 
   }
   // dS = P * (dP*mask + dattn - rowdot) * scale ; Pdrop = P * mask      (accumulator layout: row lg*4+r, column jn*16+lr)
   bf16_t* dsw = dSw[wave];
-#pragma unroll
+#pragma unroll 1
   for (int r = 0; r < 4; ++r) {
     const int il = lg * 4 + r, i = wave * 16 + il;
     const int64_t arow = ((int64_t)(b * H + h) * T1 + i) * ld;
@@ -230,9 +286,9 @@ __global__ __launch_bounds__(256) void attn_fused_bwd_kernel(int H, int T1, int 
     for (int jn = 0; jn < 4; ++jn) {
       const int j = jn * 16 + lr;
       const bool in = i < T1 && j < T2;
-      pv[jn] = in ? bf2f(attn[arow + j]) : 0.f;
+      pv[jn] = bf2f((bf16_t)(comp4(praw[jn], r)));
       m[jn] = (p > 0.f && in) ? dropout_scale(seed, (uint64_t)(arow + j), p, inv_keep) : 1.f;
-      t[jn] = dp[jn][r] * m[jn] + ((dattn && in) ? bf2f(dattn[arow + j]) : 0.f);
+      t[jn] = comp(dp[jn], r) * m[jn] + bf2f((bf16_t)(comp4(graw[jn], r)));
       dot += pv[jn] * t[jn];
     }
     dot = grp16_sum(dot);
@@ -247,44 +303,28 @@ __global__ __launch_bounds__(256) void attn_fused_bwd_kernel(int H, int T1, int 
     }
   }
   __syncthreads();
-  // dQ = dS . K      (rows: this wave's queries)
-  {
+  // dQ = dS . K (rows: this wave's queries) ; dK = dS^T . Q ; dV = Pdrop^T . dO (rows: keys wave*16 .. wave*16+15): the same
+  // 16 x 64 by 64 x DK product on three operand pairs -- ONE copy of the code, rolled
+  // (Vs was last read before the barrier above: its rows wave*16.. are this wave's output staging area from here on)
+#pragma unroll 1
+  for (int which = 0; which < 3; ++which) {
+    const bf16_t* At = which == 0 ? dsw : (which == 1 ? dSt : Pt) + wave * 16 * TP;
+    const bf16_t* Bt = which == 0 ? Kt : which == 1 ? Qt : dOt;
     f32x4_t acc[DK / 16];
 #pragma unroll
     for (int dn = 0; dn < DK / 16; ++dn) acc[dn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(dsw + lr * TP + ks * 32 + lg * 8);
-#pragma unroll
-      for (int dn = 0; dn < DK / 16; ++dn) {
-        const bf16x8_t bb = *reinterpret_cast<const bf16x8_t*>(Kt + (dn * 16 + lr) * TP + ks * 32 + lg * 8);
-        acc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[dn], 0, 0, 0);
-      }
-    }
-    // (Vs was last read before the barrier above: its rows wave*16.. are this wave's output staging area from here on)
-    store_tile_rows<DK>(acc, Vs + wave * 16 * KP, dq + (int64_t)b * dqbs + (int64_t)(wave * 16) * lddq + h * DK, lddq, T1 - wave * 16,
-                        (lddq % 8 == 0) && (dqbs % 8 == 0) && (((uintptr_t)dq) % 16 == 0));
-  }
-  // dK = dS^T . Q ; dV = Pdrop^T . dO      (rows: keys wave*16 .. wave*16+15)
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    const bf16_t* At = which == 0 ? dSt : Pt;
-    const bf16_t* Bt = which == 0 ? Qt : dOt;
-    f32x4_t acc[DK / 16];
-#pragma unroll
-    for (int dn = 0; dn < DK / 16; ++dn) acc[dn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(At + (wave * 16 + lr) * TP + ks * 32 + lg * 8);
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(At + lr * TP + ks * 32 + lg * 8);
 #pragma unroll
       for (int dn = 0; dn < DK / 16; ++dn) {
         const bf16x8_t bb = *reinterpret_cast<const bf16x8_t*>(Bt + (dn * 16 + lr) * TP + ks * 32 + lg * 8);
         acc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[dn], 0, 0, 0);
       }
     }
-    bf16_t* dst = which == 0 ? dkk + (int64_t)b * dkbs : dv + (int64_t)b * dvbs;
-    const int64_t ldd = which == 0 ? lddk : lddv, dbs = which == 0 ? dkbs : dvbs;
-    store_tile_rows<DK>(acc, Vs + wave * 16 * KP, dst + (int64_t)(wave * 16) * ldd + h * DK, ldd, T2 - wave * 16,
+    bf16_t* dst = which == 0 ? dq + (int64_t)b * dqbs : which == 1 ? dkk + (int64_t)b * dkbs : dv + (int64_t)b * dvbs;
+    const int64_t ldd = which == 0 ? lddq : which == 1 ? lddk : lddv, dbs = which == 0 ? dqbs : which == 1 ? dkbs : dvbs;
+    store_tile_rows<DK>(acc, Vs + wave * 16 * KP, dst + (int64_t)(wave * 16) * ldd + h * DK, ldd, (which == 0 ? T1 : T2) - wave * 16,
                         (ldd % 8 == 0) && (dbs % 8 == 0) && (((uintptr_t)dst) % 16 == 0));
   }
 }

@@ -13,13 +13,17 @@ enum { S2S_ACT_NONE = 0, S2S_ACT_RELU = 1, S2S_ACT_TANH = 2, S2S_ACT_SWISH = 3, 
 typedef uint16_t bf16_t;  // raw bf16 storage
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16 cast)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// float -> bf16 with the hardware converter (v_cvt_pk_bf16_f32, gfx950): round-to-nearest-even, NaN stays NaN -- the values
+// torch's float->bfloat16 cast produces.  One instruction per PAIR; the integer formulation it replaces (~12 VALU
+// instructions per value with its NaN branch) was a third of the code of the small bf16 kernels, and these run cold code
+// (see tools/kernel_code_sizes.py).
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {          // two values -> one dword (lo in bits 0..15)
+  typedef __attribute__((ext_vector_type(2))) __bf16 s2s_bf2_t;
+  typedef __attribute__((ext_vector_type(2))) float s2s_f2_t;
+  const s2s_f2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, s2s_bf2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(f2bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
@@ -89,10 +93,10 @@ __device__ __forceinline__ void unpack_bf16x8(const uint4& v, float (&f)[8]) {
 }
 __device__ __forceinline__ uint4 pack_bf16x8(const float (&f)[8]) {
   uint4 v;
-  v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-  v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-  v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-  v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  v.x = f2bf2(f[0], f[1]);
+  v.y = f2bf2(f[2], f[3]);
+  v.z = f2bf2(f[4], f[5]);
+  v.w = f2bf2(f[6], f[7]);
   return v;
 }
 __device__ __forceinline__ void load_f32x8(const float* p, float (&f)[8]) {

@@ -69,10 +69,10 @@ __global__ void col2im_s2_vec_kernel(int B, int T1, int F1, int C, int T2, int F
       }
     }
     uint4 o;
-    o.x = (uint32_t)f2bf(acc[0]) | ((uint32_t)f2bf(acc[1]) << 16);
-    o.y = (uint32_t)f2bf(acc[2]) | ((uint32_t)f2bf(acc[3]) << 16);
-    o.z = (uint32_t)f2bf(acc[4]) | ((uint32_t)f2bf(acc[5]) << 16);
-    o.w = (uint32_t)f2bf(acc[6]) | ((uint32_t)f2bf(acc[7]) << 16);
+    o.x = f2bf2(acc[0], acc[1]);
+    o.y = f2bf2(acc[2], acc[3]);
+    o.z = f2bf2(acc[4], acc[5]);
+    o.w = f2bf2(acc[6], acc[7]);
     *reinterpret_cast<uint4*>(dx + (i / cg) * C + g * 8) = o;
   }
 }

@@ -13,10 +13,10 @@ __device__ __forceinline__ void store8(float* p, const float (&r)[8]) {
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&r)[8]) {
   uint4 v;
-  v.x = (uint32_t)f2bf(r[0]) | ((uint32_t)f2bf(r[1]) << 16);
-  v.y = (uint32_t)f2bf(r[2]) | ((uint32_t)f2bf(r[3]) << 16);
-  v.z = (uint32_t)f2bf(r[4]) | ((uint32_t)f2bf(r[5]) << 16);
-  v.w = (uint32_t)f2bf(r[6]) | ((uint32_t)f2bf(r[7]) << 16);
+  v.x = f2bf2(r[0], r[1]);
+  v.y = f2bf2(r[2], r[3]);
+  v.z = f2bf2(r[4], r[5]);
+  v.w = f2bf2(r[6], r[7]);
   *reinterpret_cast<uint4*>(p) = v;
 }
 

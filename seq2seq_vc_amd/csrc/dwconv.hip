@@ -43,10 +43,10 @@ template <> struct DwVec<bf16_t> {
   }
   static __device__ __forceinline__ void st(bf16_t* p, const float (&f)[8]) {
     uint4 v;
-    v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-    v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-    v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-    v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    v.x = f2bf2(f[0], f[1]);
+    v.y = f2bf2(f[2], f[3]);
+    v.z = f2bf2(f[4], f[5]);
+    v.w = f2bf2(f[6], f[7]);
     *reinterpret_cast<uint4*>(p) = v;
   }
 };

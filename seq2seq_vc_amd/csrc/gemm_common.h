@@ -184,10 +184,10 @@ __device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0,
         *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
       } else {
         uint4 o;
-        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        o.x = f2bf2(v[0], v[1]);
+        o.y = f2bf2(v[2], v[3]);
+        o.z = f2bf2(v[4], v[5]);
+        o.w = f2bf2(v[6], v[7]);
         *reinterpret_cast<uint4*>((bf16_t*)d.c_pre + po) = o;
       }
     }
@@ -257,10 +257,10 @@ __device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0,
         for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
       }
       uint4 o;
-      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-      o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-      o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+      o.x = f2bf2(v[0], v[1]);
+      o.y = f2bf2(v[2], v[3]);
+      o.z = f2bf2(v[4], v[5]);
+      o.w = f2bf2(v[6], v[7]);
       *reinterpret_cast<uint4*>(c) = o;
     }
   }

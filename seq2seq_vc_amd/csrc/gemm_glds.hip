@@ -730,6 +730,12 @@ int dma_stages() {       // S2SVC_GEMM_STAGES override (0 = built-in policy), se
   return v;
 }
 
+bool deep_stages() {     // S2SVC_GEMM_DEEP=0: no 5-stage variant of the 32x64 kernel for long reductions (tuning aid)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_DEEP"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
 bool tr_enabled() {      // S2SVC_GEMM_NO_TR=1: row-contiguous operands through the register-transpose path (tuning aid)
   static int v = -1;
   if (v < 0) { const char* e = getenv("S2SVC_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -966,7 +972,13 @@ extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
   const int64_t tiles64 = (int64_t)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nb0 * d.nb1 * splitk;
   if (!big && bm32_enabled() && tiles64 < 256 && d.M > 64 && !d.a_rowsum && kind_of(d.A) == G_KC_DENSE && kind_of(d.B) == G_KC_DENSE) {
     dim3 grid((d.N + 63) / 64, (d.M + 31) / 32, d.nb0 * d.nb1 * splitk);
-    hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 3, 64>), grid, dim3(256), 0, st, d);
+    // long reductions (K >= 1024: the feed-forward / packed-projection data gradients of VTN, 18-24 K tiles) with few workgroups:
+    // five stages in flight (60 KB) instead of three -- with 2 tiles of lookahead (~0.7 us of MFMA work) every K tile waits for
+    // its own DMA round trip; S2SVC_GEMM_DEEP=0 keeps three stages (A/B switch)
+    if (deep_stages() && (d.K + 63) / 64 / splitk >= 16)
+      hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 5, 64>), grid, dim3(256), 0, st, d);
+    else
+      hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 3, 64>), grid, dim3(256), 0, st, d);
     S2S_CHECK_LAUNCH("gemm_dma_kernel");
     return 1;
   }

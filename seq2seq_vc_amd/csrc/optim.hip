@@ -98,8 +98,8 @@ __global__ void adam_update_kernel(int64_t n, float* __restrict__ p, const float
     reinterpret_cast<float4*>(p)[i] = pp;
     if (shadow) {
       uint2 o;
-      o.x = (uint32_t)f2bf(pp.x) | ((uint32_t)f2bf(pp.y) << 16);
-      o.y = (uint32_t)f2bf(pp.z) | ((uint32_t)f2bf(pp.w) << 16);
+      o.x = f2bf2(pp.x, pp.y);
+      o.y = f2bf2(pp.z, pp.w);
       reinterpret_cast<uint2*>(shadow)[i] = o;
     }
   }

@@ -64,19 +64,10 @@ __device__ __forceinline__ void mma_rows64(const bf16_t* As, int AP, const bf16_
   }
 }
 
-// ---- bf16 packing with the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even as common.h's f2bf) ----
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
-  typedef __attribute__((ext_vector_type(2))) float f2_t;
-  const f2_t v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2_t));
-}
-__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
-  uint4 v;
-  v.x = pack2(f[0], f[1]); v.y = pack2(f[2], f[3]); v.z = pack2(f[4], f[5]); v.w = pack2(f[6], f[7]);
-  return v;
-}
-__device__ __forceinline__ bf16_t cvt1(float f) { return (bf16_t)(pack2(f, 0.f) & 0xffffu); }
+// ---- bf16 packing (common.h: the hardware converter) ----
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return f2bf2(a, b); }
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) { return pack_bf16x8(f); }
+__device__ __forceinline__ bf16_t cvt1(float f) { return f2bf(f); }
 
 // ---- a 64 x D tile of dense rows <-> LDS image [64][D + 8]: all 256 threads, piece p = t + 256 * i (row = p / (D/8)), every
 // load issued before the first store (the loads of several tiles are in flight together) ----
