@@ -103,7 +103,8 @@ typedef struct {
   int32_t emask_mode;
   const uint64_t* seed_base;
   uint64_t seed_off;
-  /* c_map = 1 (bf16 LDS-DMA kernels only; no res / emask / batch / split-K): GEMM row m = (b, i, j) over the class grid
+  /* c_map = 1 (bf16 LDS-DMA kernels only; no res / dropout / batch / split-K; emask: mode 0 only, indexed like C, i.e. by the
+     MAPPED row -- relu' of the layer below fused into the transposed convolution): GEMM row m = (b, i, j) over the class grid
      cm_Tc x cm_Fc is stored at row (b*cm_T1 + 2i+cm_pt)*cm_F1 + 2j+cm_pf of C -- the four parity classes of a stride-2
      transposed convolution write one NHWC tensor (B, cm_T1, cm_F1, N) without a col2im pass */
   int32_t c_map;

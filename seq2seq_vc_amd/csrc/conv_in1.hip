@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void conv_in1_wgrad_kernel(int B, int Tn, int 
 // bf16 streaming variant: a thread owns 8 channels (one 16-byte load of dy and of y per pixel) and every
 // (256 / (O/8))-th pixel of the chunk; 80 fp32 accumulators per thread, pixel lanes folded through LDS in a fixed
 // order at the end.  HBM-bound: 2 (dy) + 2 (y) bytes per (pixel, channel); the 9 input samples are L1 broadcasts.
+struct __attribute__((aligned(4))) u32x2_a4 { uint32_t a, b; };
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -124,6 +125,9 @@ __global__ __launch_bounds__(256) void conv_in1_wgrad_vec_kernel(int B, int Tn, 
   for (int e = 0; e < 8; ++e)
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[e][k] = 0.f;
+  // a pixel's window starts at an even column: with an even row pitch every row of it is 4-byte aligned and its 4th value
+  // (read, not used) is still inside the row (2 f1 + 3 <= Fn - 1)
+  const bool x_pairs = (Fn % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 3) == 0);
   if (pl < PL) {
 #pragma unroll 2
     for (int64_t p = p0 + pl; p < p1; p += PL) {
@@ -136,10 +140,20 @@ __global__ __launch_bounds__(256) void conv_in1_wgrad_vec_kernel(int B, int Tn, 
       const int t1 = (int)(q - (uint32_t)b * (uint32_t)T1);
       const bf16_t* xb = x + ((int64_t)b * Tn + 2 * t1) * Fn + 2 * f1;
       float xv[9];
+      if (x_pairs) {                 // (uniform) even row pitch, 4-byte aligned base: the 3 taps of a row are one 8-byte load
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh) {
+          const u32x2_a4 v = *reinterpret_cast<const u32x2_a4*>(xb + kh * Fn);
+          xv[kh * 3 + 0] = __uint_as_float(v.a << 16);
+          xv[kh * 3 + 1] = __uint_as_float(v.a & 0xffff0000u);
+          xv[kh * 3 + 2] = __uint_as_float(v.b << 16);
+        }
+      } else {
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = ldf(xb + kh * Fn + kw);
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = ldf(xb + kh * Fn + kw);
+      }
       float gf[8], yf[8];
       unpack8(gv, gf);
       unpack8(yv, yf);

@@ -354,8 +354,9 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
   if (d.A.mode == S2SVC_OP_TCONV2D_S2 || d.B.mode == S2SVC_OP_TCONV2D_S2 || d.c_map) {
     // transposed-convolution operand / mapped C rows: only the bf16 LDS-DMA kernels implement them
     S2S_REQUIRE(d.B.mode != S2SVC_OP_TCONV2D_S2, "s2svc_gemm: S2SVC_OP_TCONV2D_S2 is an A-operand mode");
-    S2S_REQUIRE(d.nb0 * d.nb1 == 1 && d.splitk <= 1 && !d.res && !d.emask && d.drop_p == 0.f && !d.a_rowsum,
-                "s2svc_gemm: tconv2d / c_map GEMMs are unbatched, unsplit and have no residual / mask stage");
+    S2S_REQUIRE(d.nb0 * d.nb1 == 1 && d.splitk <= 1 && !d.res && d.drop_p == 0.f && !d.a_rowsum,
+                "s2svc_gemm: tconv2d / c_map GEMMs are unbatched, unsplit and have no residual / dropout stage");
+    S2S_REQUIRE(!d.emask || (d.emask_mode == 0 && d.ldm == d.ldc), "s2svc_gemm: a c_map GEMM takes a relu mask with C's row layout only");
     S2S_REQUIRE(!d.c_map || (d.cm_Tc > 0 && d.cm_Fc > 0 && d.M % (d.cm_Tc * d.cm_Fc) == 0), "s2svc_gemm: bad c_map grid");
     int rc = s2svc_gemm_try_8ph(&d, stream);         // the 8-wave kernel takes the transposed-convolution operand and mapped C rows
     if (rc == 0) rc = s2svc_gemm_try_glds(&d, stream);

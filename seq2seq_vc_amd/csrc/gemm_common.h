@@ -19,7 +19,14 @@ __device__ __forceinline__ float epilogue_stage_f(const s2svc_gemm_desc& d, int 
     v *= dropout_scale(seed, (uint64_t)((int64_t)m * d.N + n), d.drop_p, 1.f / (1.f - d.drop_p));
   }
   if (d.emask) {
-    const int64_t mo = (int64_t)m * d.ldm + n;
+    int64_t er = m;                      // emask has C's row layout: with a c_map its rows are the mapped rows (see c_row_of)
+    if (d.c_map) {
+      const int per_b = d.cm_Tc * d.cm_Fc;
+      const int b = m / per_b, rem = m - b * per_b;
+      const int i = rem / d.cm_Fc, j = rem - i * d.cm_Fc;
+      er = ((int64_t)b * d.cm_T1 + 2 * i + d.cm_pt) * d.cm_F1 + 2 * j + d.cm_pf;
+    }
+    const int64_t mo = er * d.ldm + n;
     const float e = d.c_dtype == S2S_F32 ? ((const float*)d.emask)[mo] : bf2f(((const bf16_t*)d.emask)[mo]);
     v = d.emask_mode == 1 ? v * swish_grad(e) : (e > 0.f ? v : 0.f);
   }
@@ -209,8 +216,9 @@ __device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0,
         for (int e = 0; e < 4; ++e) v[4 * q + e] *= ((uint32_t)(r >> (16 * e)) & 0xffffu) < thr ? 0.f : inv_keep;
       }
     }
+    const int64_t crow = c_row_fast(d, cm, m);
     if (d.emask) {
-      const int64_t mo = (int64_t)m * d.ldm + n;
+      const int64_t mo = crow * d.ldm + n;            // emask has C's row layout (mapped rows under a c_map)
       if (d.c_dtype == S2S_F32) {
         const float4 e0 = *reinterpret_cast<const float4*>((const float*)d.emask + mo), e1 = *reinterpret_cast<const float4*>((const float*)d.emask + mo + 4);
         const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
@@ -227,7 +235,7 @@ __device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0,
         }
       }
     }
-    const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + c_row_fast(d, cm, m) * d.ldc + n;
+    const int64_t co = (int64_t)z0 * d.cbs0 + (int64_t)z1 * d.cbs1 + crow * d.ldc + n;
     if (d.res) {
       const int64_t ro = (int64_t)z0 * d.rbs0 + (int64_t)z1 * d.rbs1 + (int64_t)m * d.ldr + n;
       if (d.c_dtype == S2S_F32) {

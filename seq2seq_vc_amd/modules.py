@@ -612,10 +612,13 @@ class Conv2dSubsampling(nn.Module):
         B, T, idim = x.shape
         c0, c2 = self.conv[0], self.conv[2]
         if c0.weight.shape[0] % 8 == 0:
-            y = Fn.conv_in1_relu(x, c0.weight, c0.bias)              # direct streaming kernel (C_in = 1)
+            y = Fn.conv_in1_relu(x, c0.weight, c0.bias, grad_premasked=True)   # direct streaming kernel (C_in = 1)
+            first_relu = True
         else:
             y = Fn.conv2d_s2_relu(x.reshape(B, T, idim, 1), c0.weight, c0.bias)
-        y = Fn.conv2d_s2_relu(y, c2.weight, c2.bias, grad_premasked=True)   # (B, T2, F2, C) channel-last
+            first_relu = False
+        # (B, T2, F2, C) channel-last; relu' of the first layer rides in this layer's data-gradient epilogue
+        y = Fn.conv2d_s2_relu(y, c2.weight, c2.bias, grad_premasked=True, input_is_relu=first_relu)
         _, T2, F2, C = y.shape
         lin = self.out[0] if self.use_pos_enc else self.out
         # the Linear is the only consumer of the ReLU output: its dgrad epilogue applies relu' (no mask pass over 15 M values)

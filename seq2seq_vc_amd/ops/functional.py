@@ -211,10 +211,19 @@ def enable_side_streams(n=4, inline_batches=False):
     _Side.idx = 0
 
 
-def _side_run(fn, keep=()):
+def _side_run(fn, keep=(), solo=False):
     """Parameter-gradient work off the data-gradient chain: `fn` is queued and runs on a side stream in batches of
     `_Side.batch` closures -- one fork point (cross-stream edge of the captured graph) per batch instead of one per call.
-    The stream the caller runs on is remembered: backward nodes of a branch (branch_run) execute on the branch's stream."""
+    The stream the caller runs on is remembered: backward nodes of a branch (branch_run) execute on the branch's stream.
+    solo=True: `fn` is forked NOW as a batch of its own (long kernels at the end of the backward pass: whatever shares their
+    batch runs behind them on the same stream)."""
+    if solo and _Side.enabled and not _Side.inline:
+        held, held_o = _Side.queue, _Side.origins
+        _Side.queue, _Side.origins = [fn], [torch.cuda.current_stream()]
+        _Side.pending.append(keep)
+        _side_flush()
+        _Side.queue, _Side.origins = held, held_o
+        return
     if _Side.inline:
         cur = torch.cuda.current_stream()
         q = _Side.inline_q.setdefault(cur.cuda_stream, (cur, []))[1]
@@ -1185,9 +1194,10 @@ _TCONV_GROUP = os.environ.get("S2SVC_TCONV_GROUP", "0") == "1"     # one grid fo
 
 class _Conv2dS2(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, grad_premasked=False):
+    def forward(ctx, x, weight, bias, grad_premasked=False, input_is_relu=False):
         x = _c(x)
         ctx.grad_premasked = grad_premasked
+        ctx.input_is_relu = input_is_relu
         B, T1, F1, C = x.shape
         O = weight.shape[0]
         T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
@@ -1224,7 +1234,10 @@ class _Conv2dS2(Function):
                 return _emit_vgrad(weight, dwt), dbv
             if _slotted(weight, bias):
                 # queued AND forked before the data-gradient GEMM below: this is the last big layer of the backward pass,
-                # its weight gradient would otherwise run alone after the main chain has ended
+                # its weight gradient would otherwise run alone after the main chain has ended.  (Sending the batch queued so
+                # far to ANOTHER stream first -- so that its grouped weight gradients do not wait behind this 150-280 us GEMM --
+                # was measured: 4.24 vs 4.20 ms per VTN step, the extra concurrent work slows the transposed convolution on the
+                # main stream, which is the critical path.  Issuing it AFTER the data-gradient GEMMs instead: 4.33 ms.)
                 _side_run(work, keep=(dy, x))
                 _side_flush()
             else:
@@ -1235,7 +1248,8 @@ class _Conv2dS2(Function):
             # gathers its 4 / 2 / 2 / 1 taps of dY straight from HBM and stores into its pixels of dX (no dcols, no col2im)
             wts = K.tconv2d_weights(weight.detach())
             dx = torch.empty((B, T1, F1, C), dtype=dtype, device=x.device)
-            descs = [] if _TCONV_GROUP else None        # (opt-in) one grid for the four classes, largest reduction first
+            mask = x if ctx.input_is_relu else None     # x = relu(u): the GEMMs hand back dL/du (mask rows follow the c_map)
+            descs = [] if (_TCONV_GROUP and mask is None) else None     # (opt-in) one grid for the four classes
             for cls, wt in enumerate(wts):
                 pt, pf = cls >> 1, cls & 1
                 Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
@@ -1243,32 +1257,37 @@ class _Conv2dS2(Function):
                     continue
                 Kc = wt.shape[1]
                 K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, Kc),
-                       B * Tc * Fc, C, Kc, dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf), group=descs)
+                       B * Tc * Fc, C, Kc, dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf), group=descs, emask=mask)
             if descs:
                 K.launch_group(descs)
         elif ctx.needs_input_grad[0]:
             dcols = torch.empty((M2, 9 * C), dtype=dtype, device=x.device)
             K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), M2, 9 * C, O, dcols, in_dtype=dtype)
             dx = K.col2im_s2(dcols, B, T1, F1, C, T2, F2)
+            if ctx.input_is_relu:
+                dx = K.act_dropout_bwd(dx, x, act="relu")
         if not weight.requires_grad and bias is not None and bias.requires_grad:
             db, _ = _reduce_to(bias, None, 0, dy.view(M2, O))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def conv2d_s2_relu(x_nhwc, weight, bias, grad_premasked=False):
+def conv2d_s2_relu(x_nhwc, weight, bias, grad_premasked=False, input_is_relu=False):
     """grad_premasked=True: the ONLY consumer of the result hands back a gradient that already carries relu'
-    (see linear_fc_permuted(input_is_relu=True)); the backward then skips its own mask pass."""
-    return _Conv2dS2.apply(x_nhwc, weight, bias, grad_premasked)
+    (see linear_fc_permuted(input_is_relu=True)); the backward then skips its own mask pass.
+    input_is_relu=True: x_nhwc is a ReLU output whose producer wants dL/d(pre-activation) back (conv_in1_relu(grad_premasked=True)):
+    relu'(x) is applied in the epilogue of the data-gradient GEMMs."""
+    return _Conv2dS2.apply(x_nhwc, weight, bias, grad_premasked, input_is_relu)
 
 
 class _ConvIn1(Function):
     """Conv2d(1 -> O, 3x3, stride 2) + ReLU straight on the (B, T, F) mel batch (subsampling.py:58-60)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, grad_premasked=False):
         x = _c(x)
         y = K.conv_in1_fwd(x, weight.detach(), bias.detach() if bias is not None else None)
         ctx.params = (weight, bias)
+        ctx.grad_premasked = grad_premasked
         ctx.save_for_backward(x, y)
         return y
 
@@ -1276,19 +1295,25 @@ class _ConvIn1(Function):
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
         weight, bias = ctx.params
-        dy = _c(dy)                  # relu' is applied inside the wgrad kernel (y > 0): no mask pass over 60 M values
+        # relu' is applied inside the wgrad kernel (y > 0: no mask pass over 60 M values) -- unless the consumer's data-gradient
+        # GEMM already did it in its epilogue (conv2d_s2_relu(input_is_relu=True)): then the kernel reads dy only (122 instead of
+        # 244 MB at VTN's shapes -- this kernel is the very end of the backward pass)
+        dy = _c(dy)
+        ym = None if ctx.grad_premasked else y
         wslot, bslot = getattr(weight, "_s2s_grad", None), getattr(bias, "_s2s_grad", None) if bias is not None else None
         if wslot is not None and (bias is None or bslot is not None):
-            _side_run(lambda: K.conv_in1_wgrad(x, dy, wslot, bslot, True, y=y), keep=(x, dy, y))
-            return None, None, None
+            # its own fork: the last closure of the backward pass must not queue behind the batch it would otherwise end
+            _side_run(lambda: K.conv_in1_wgrad(x, dy, wslot, bslot, True, y=ym), keep=(x, dy, y), solo=True)
+            return None, None, None, None
         dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
         db = torch.empty(bias.shape, dtype=torch.float32, device=x.device) if bias is not None else None
-        K.conv_in1_wgrad(x, dy, dw, db, False, y=y)
-        return None, dw, db
+        K.conv_in1_wgrad(x, dy, dw, db, False, y=ym)
+        return None, dw, db, None
 
 
-def conv_in1_relu(x, weight, bias):
-    return _ConvIn1.apply(x, weight, bias)
+def conv_in1_relu(x, weight, bias, grad_premasked=False):
+    """grad_premasked=True: the ONLY consumer hands back a gradient that already carries relu' of this layer's output."""
+    return _ConvIn1.apply(x, weight, bias, grad_premasked)
 
 
 class _LinearPermuted(Function):
