@@ -466,6 +466,365 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-contiguous operands ("TR"): the weight-gradient GEMMs C[n_out, n_in] (+)= dY^T . X of the Linear layers, reduction over
+// the B*T rows of the batch, both operands stored [k][row].  Same 256 x 128 tile, units, phases and counted waits as
+// gemm_8ph_kernel_128; what changes is the image of a unit and how fragments leave it (as in gemm_glds.hip's TrStage):
+//   * a unit (128 rows x 64 k) is 16 subtiles [k half][16-row block] of 1 KiB = [32 k][16 rows], one DMA instruction each
+//     (lane l -> k row l / 2, rows 8 (l & 1) .. + 7: 16 contiguous bytes of the operand);
+//   * a fragment is two ds_read_b64_tr_b16 (lane group g gets k = 4g .. 4g+3 and 16+4g .. 16+4g+3 of the k half -- a
+//     permutation of the MFMA k positions, the same for both operands);
+//   * the fused bias gradient (a_rowsum: sum over k of every A row) is MFMA work too -- an extra product with an all-ones B
+//     fragment, the (K tile, k half) pairs dealt round-robin to the four waves of a wave row (+12.5 % MFMAs in the workgroups of
+//     the first column tile only), partial sums combined through LDS in a fixed order.
+// Exact tiles only (M % 256 == N % 128 == K % 64 == 0): AAS-VC's decoder (1536 / 3072 / 4608 features, 4096 rows).
+// The 4-wave 128 x 128 kernel it replaces there runs these at 17-25 % of the MFMA peak (one barrier per K tile, every wave in
+// the same phase); VTN's 384-feature layers keep it (grouped, 64 x 64 tiles).
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short p8_s16x4_t;
+typedef __attribute__((address_space(3))) p8_s16x4_t p8_lds_s16x4_t;
+
+// fragments of NF consecutive 16-row blocks starting at unit block `blk0`, both k halves; fo = the lane's offset inside a subtile
+template <int NF>
+__device__ __forceinline__ void p8_read_tr(const char* unit, int blk0, int fo, bf16x8_t (&f)[NF][2]) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+  for (int i = 0; i < NF; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const char* p = unit + (ks * 8 + blk0 + i) * 1024 + fo;
+      const p8_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((p8_lds_s16x4_t*)p);
+      const p8_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((p8_lds_s16x4_t*)(p + 512));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      f[i][ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+template <bool STAGGER>
+__device__ __forceinline__ void p8_tr_tile(const s2svc_gemm_desc& d, int tile_m, int tile_n, char* smem) {
+  constexpr int UNIT = 16384, BUF = 3 * UNIT;            // A.m0 | A.m1 | B
+  const int m0 = tile_m * 256, n0 = tile_n * 128;
+  const char* Ab = reinterpret_cast<const char*>(d.A.ptr);
+  const char* Bb = reinterpret_cast<const char*>(d.B.ptr);
+  const int nt = d.K / 64;
+  const int64_t stepA = (int64_t)d.A.ld * 128, stepB = (int64_t)d.B.ld * 128;      // bytes per K tile (64 k rows)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // source offsets: DMA instruction s = wave * 2 + e of a unit = subtile (k half s >> 3, row block s & 7)
+  uint32_t offA[2][2], offB[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int sidx = wave * 2 + e, kh = sidx >> 3, mt = sidx & 7;
+    const int ur = mt * 16 + (lane & 1) * 8;              // unit row of the lane's 8 values
+    const int k = kh * 32 + (lane >> 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) offA[h][e] = (uint32_t)(((int64_t)k * d.A.ld + m0 + (ur >> 6) * 128 + h * 64 + (ur & 63)) * 2);
+    offB[e] = (uint32_t)(((int64_t)k * d.B.ld + n0 + ur) * 2);
+  }
+  const int fo = ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+
+  f32x4_t acc[2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bool do_rowsum = d.a_rowsum != nullptr && tile_n == 0;      // uniform
+  f32x4_t rs[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[a][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  p8_issue<2>(Ab, offA[0], smem + 0 * UNIT, wave);
+  p8_issue<2>(Bb, offB, smem + 2 * UNIT, wave);
+  p8_issue<2>(Ab, offA[1], smem + 1 * UNIT, wave);
+  {
+    const bool has1 = nt > 1;
+    p8_issue<2>(has1 ? Ab + stepA : nullptr, offA[0], smem + BUF + 0 * UNIT, wave);
+    p8_issue<2>(has1 ? Bb + stepB : nullptr, offB, smem + BUF + 2 * UNIT, wave);
+  }
+  p8_wait_vmcnt<4>();                  // tile 0 has landed (A.m0, B of tile 1 may still be moving)
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8_t fa[4][2], fb[2][2];
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t & 1) ^ 1) * BUF;
+    const int mine = (wc - 2 * t) & 3;                   // pair (t, ks) belongs to wave column (2 t + ks) % 4: ks == mine (0 / 1 / none)
+    // ---- phase 1: rows m0
+    p8_read_tr<2>(cur + 2 * UNIT, wc * 2, fo, fb);
+    p8_read_tr<4>(cur + 0 * UNIT, wr * 4, fo, fa);
+    p8_issue<2>((t + 1 < nt) ? Ab + (int64_t)(t + 1) * stepA : nullptr, offA[1], oth + 1 * UNIT, wave);     // A.m1 of tile t + 1
+    p8_wait_vmcnt<6>();                                                                              // A.m1 of tile t has landed
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb, acc[0]);
+    if (do_rowsum && mine < 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[0][i], 0, 0, 0);
+    }
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 2: rows m1
+    p8_read_tr<4>(cur + 1 * UNIT, wr * 4, fo, fa);
+    p8_issue<2>((t + 2 < nt) ? Ab + (int64_t)(t + 2) * stepA : nullptr, offA[0], cur + 0 * UNIT, wave);     // A.m0 of tile t + 2
+    p8_issue<2>((t + 2 < nt) ? Bb + (int64_t)(t + 2) * stepB : nullptr, offB, cur + 2 * UNIT, wave);        // B of tile t + 2
+    p8_wait_vmcnt<6>();                                                                              // A.m0, B of tile t + 1 have landed
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb, acc[1]);
+    if (do_rowsum && mine < 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[1][i], 0, 0, 0);
+    }
+    P8_PHASE_SYNC_OUT();
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+  p8_wait_vmcnt<0>();
+  __syncthreads();
+  if (do_rowsum) {
+    // every column of rs[a][i] holds the partial sums of rows (a, i, lg * 4 + r): column lr == 0 writes them, then one thread
+    // per row adds the four wave columns in a fixed order
+    float* part = reinterpret_cast<float*>(smem + 2 * BUF - 4096);         // [4 wc][256 rows], above the C tiles of the epilogue
+    const int lr = lane & 15, lg = lane >> 4;
+    if (lr == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[wc * 256 + wr * 128 + a * 64 + i * 16 + lg * 4 + r] = rs[a][i][r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int m = m0 + (int)threadIdx.x;
+      const float v = ((part[threadIdx.x] + part[256 + threadIdx.x]) + part[512 + threadIdx.x]) + part[768 + threadIdx.x];
+      d.a_rowsum[m] = (d.a_rowsum_accumulate ? d.a_rowsum[m] : 0.f) + v;
+    }
+  }
+  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+#pragma unroll 1
+  for (int a = 0; a < 2; ++a) {
+    if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
+    else epilogue_stage<64, 32>(acc[1], cs);
+    epilogue_flush<64, 32>(d, 0, 0, m0 + wr * 128 + a * 64, n0 + wc * 32, cs, 1, 0, 0);
+  }
+}
+
+// the same on a 256 x 256 tile: the four-phase schedule of gemm_8ph_kernel_q<., 2, 4> (wave tile 128 x 64, units A.m0 / A.m1 /
+// B.n0 / B.n1 of 128 rows each, 128 KB of LDS).  ~15 % faster per flop than the two-phase tile; taken when its tiles fill the chip
+// (grouped launches of several layers' gradients: five AAS-VC decoder problems are 252 tiles).
+template <bool STAGGER>
+__device__ __forceinline__ void p8_tr_tile_q(const s2svc_gemm_desc& d, int tile_m, int tile_n, char* smem) {
+  constexpr int UNIT = 16384, BUF = 4 * UNIT;            // A.m0 | A.m1 | B.n0 | B.n1
+  constexpr int OA0 = 0, OA1 = UNIT, OB0 = 2 * UNIT, OB1 = 3 * UNIT;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const char* Ab = reinterpret_cast<const char*>(d.A.ptr);
+  const char* Bb = reinterpret_cast<const char*>(d.B.ptr);
+  const int nt = d.K / 64;
+  const int64_t stepA = (int64_t)d.A.ld * 128, stepB = (int64_t)d.B.ld * 128;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int half = wave >> 2;
+
+  uint32_t offA[2][2], offB[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int sidx = wave * 2 + e, kh = sidx >> 3, mt = sidx & 7;
+    const int ur = mt * 16 + (lane & 1) * 8;
+    const int k = kh * 32 + (lane >> 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      offA[h][e] = (uint32_t)(((int64_t)k * d.A.ld + m0 + (ur >> 6) * 128 + h * 64 + (ur & 63)) * 2);
+      offB[h][e] = (uint32_t)(((int64_t)k * d.B.ld + n0 + (ur >> 5) * 64 + h * 32 + (ur & 31)) * 2);
+    }
+  }
+  const int fo = ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+
+  f32x4_t acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bool do_rowsum = d.a_rowsum != nullptr && tile_n == 0;
+  f32x4_t rs[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[a][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  // prologue: tile 0 complete, tile 1 without B.n0 (issued in phase 1 of tile 0)
+  p8_issue<2>(Ab, offA[0], smem + OA0, wave);
+  p8_issue<2>(Bb, offB[0], smem + OB0, wave);
+  p8_issue<2>(Bb, offB[1], smem + OB1, wave);
+  p8_issue<2>(Ab, offA[1], smem + OA1, wave);
+  {
+    const bool has1 = nt > 1;
+    p8_issue<2>(has1 ? Ab + stepA : nullptr, offA[0], smem + BUF + OA0, wave);
+    p8_issue<2>(has1 ? Bb + stepB : nullptr, offB[1], smem + BUF + OB1, wave);
+    p8_issue<2>(has1 ? Ab + stepA : nullptr, offA[1], smem + BUF + OA1, wave);
+  }
+  p8_wait_vmcnt<6>();
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && half == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8_t fa[4][2], fb0[2][2], fb1[2][2];
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t & 1) ^ 1) * BUF;
+    const char* a2 = (t + 2 < nt) ? Ab + (int64_t)(t + 2) * stepA : nullptr;
+    const char* b2 = (t + 2 < nt) ? Bb + (int64_t)(t + 2) * stepB : nullptr;
+    const char* b1 = (t + 1 < nt) ? Bb + (int64_t)(t + 1) * stepB : nullptr;
+    const int mine = (wc - 2 * t) & 3;
+    // ---- phase 1: quadrant (m0, n0)
+    p8_read_tr<2>(cur + OB0, wc * 2, fo, fb0);
+    p8_read_tr<4>(cur + OA0, wr * 4, fo, fa);
+    p8_issue<2>(b1, offB[0], oth + OB0, wave);                                // B.n0 of tile t + 1
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb0, acc[0][0]);
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 2: quadrant (m0, n1)
+    p8_read_tr<2>(cur + OB1, wc * 2, fo, fb1);
+    p8_issue<2>(a2, offA[0], cur + OA0, wave);                                // A.m0 of tile t + 2
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb1, acc[0][1]);
+    if (do_rowsum && mine < 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[0][i], 0, 0, 0);
+    }
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 3: quadrant (m1, n1)
+    p8_read_tr<4>(cur + OA1, wr * 4, fo, fa);
+    p8_issue<2>(b2, offB[1], cur + OB1, wave);                                // B.n1 of tile t + 2
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb1, acc[1][1]);
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 4: quadrant (m1, n0)
+    p8_issue<2>(a2, offA[1], cur + OA1, wave);                                // A.m1 of tile t + 2
+    p8_wait_vmcnt<6>();                                                       // everything of tile t + 1 has landed
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 2>(fa, fb0, acc[1][0]);
+    if (do_rowsum && mine < 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[1][i], 0, 0, 0);
+    }
+    P8_PHASE_SYNC_OUT();
+  }
+  if (STAGGER && half == 0) __builtin_amdgcn_s_barrier();
+  p8_wait_vmcnt<0>();
+  __syncthreads();
+  if (do_rowsum) {
+    float* part = reinterpret_cast<float*>(smem + 2 * BUF - 4096);
+    const int lr = lane & 15, lg = lane >> 4;
+    if (lr == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[wc * 256 + wr * 128 + a * 64 + i * 16 + lg * 4 + r] = rs[a][i][r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int m = m0 + (int)threadIdx.x;
+      const float v = ((part[threadIdx.x] + part[256 + threadIdx.x]) + part[512 + threadIdx.x]) + part[768 + threadIdx.x];
+      d.a_rowsum[m] = (d.a_rowsum_accumulate ? d.a_rowsum[m] : 0.f) + v;
+    }
+  }
+  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    switch (q) {
+      case 0: epilogue_stage<64, 32>(acc[0][0], cs); break;
+      case 1: epilogue_stage<64, 32>(acc[0][1], cs); break;
+      case 2: epilogue_stage<64, 32>(acc[1][0], cs); break;
+      default: epilogue_stage<64, 32>(acc[1][1], cs); break;
+    }
+    epilogue_flush<64, 32>(d, 0, 0, m0 + wr * 128 + (q >> 1) * 64, n0 + wc * 64 + (q & 1) * 32, cs, 1, 0, 0);
+  }
+}
+
+template <bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_8ph_tr_kernel(const s2svc_gemm_desc d) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 3 * 16384];
+  int tile_m, tile_n;
+  p8_tile_of_block(tile_m, tile_n);
+  p8_tr_tile<STAGGER>(d, tile_m, tile_n, smem);
+}
+
+// Grouped launch (see gemm_grouped_kernel, gemm_glds.hip): the weight gradients of a few consecutive layers as ONE grid of
+// 256 x 128 tiles, descriptors by value in the kernel arguments.
+#define P8_GROUP_MAX 10
+struct p8_group_args {
+  s2svc_gemm_desc d[P8_GROUP_MAX];
+  int32_t tile_start[P8_GROUP_MAX + 1];
+  int32_t n;
+};
+static_assert(sizeof(p8_group_args) <= 4096, "kernel arguments are limited to 4 KB");
+
+template <bool STAGGER, int BN>
+__global__ __launch_bounds__(512) void gemm_8ph_tr_grouped_kernel(const p8_group_args g) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * (BN == 256 ? 4 : 3) * 16384];
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < P8_GROUP_MAX; ++i) p += (i < g.n && g.tile_start[i] <= (int)blockIdx.x) ? 1 : 0;
+  const s2svc_gemm_desc& d = g.d[p];
+  const int t = (int)blockIdx.x - g.tile_start[p];
+  const int tiles_n = d.N / BN;
+  const int tile_m = t / tiles_n;
+  if (BN == 256) p8_tr_tile_q<STAGGER>(d, tile_m, t - tile_m * tiles_n, smem);
+  else p8_tr_tile<STAGGER>(d, tile_m, t - tile_m * tiles_n, smem);
+}
+
+template <bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_8ph_tr_kernel_q(const s2svc_gemm_desc d) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * 16384];
+  int tile_m, tile_n;
+  p8_tile_of_block(tile_m, tile_n);
+  p8_tr_tile_q<STAGGER>(d, tile_m, tile_n, smem);
+}
+
+int p8_force_bn();
+// 256 x 256 or 256 x 128 tiles for `t256` / `t128` tiles in total: rounds of workgroups on the 256 CUs in units of one
+// 256 x 128 tile, the big tile ~15 % faster per flop (the cost model of s2svc_gemm_try_8ph)
+bool p8_tr_take_q(bool all_n256, int64_t t256, int64_t t128) {
+  const int force = p8_force_bn();
+  if (force == 1) return all_n256;
+  if (force == 3) return false;
+  if (!all_n256) return false;
+  const double cost256 = 2.0 * 0.85 * (double)((t256 + 255) / 256), cost128 = (double)((t128 + 255) / 256);
+  return t256 >= 160 && cost256 <= cost128;
+}
+
+bool p8_tr_ok(const s2svc_gemm_desc& d) {      // exact tiles of dense row-contiguous operands, fp32 or bf16 C, no batch / split-K
+  if (d.dtype != S2S_BF16 || d.nb0 * d.nb1 != 1 || d.splitk > 1) return false;
+  if (d.A.layout != S2SVC_LAYOUT_RC || d.B.layout != S2SVC_LAYOUT_RC || d.A.mode != S2SVC_OP_DENSE || d.B.mode != S2SVC_OP_DENSE) return false;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.M % 256 || d.N % 128 || d.K % 64) return false;
+  if (((uintptr_t)d.A.ptr) % 16 || ((uintptr_t)d.B.ptr) % 16 || d.A.ld % 8 || d.B.ld % 8 || d.A.ld < d.M || d.B.ld < d.N) return false;
+  if ((int64_t)64 * d.A.ld * 2 + (int64_t)d.M * 2 >= (1ll << 32) || (int64_t)64 * d.B.ld * 2 + (int64_t)d.N * 2 >= (1ll << 32)) return false;
+  if (d.emask || d.drop_p > 0.f || d.c_map || d.c_pre) return false;
+  return true;
+}
+
+int p8_tr_mode() {     // S2SVC_GEMM_8PH_TR=0: weight gradients stay on the 4-wave kernels (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_8PH_TR"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+
 int g_p8_mode = -1;
 int p8_mode() {       // S2SVC_GEMM_8PH / s2svc_gemm_set_8ph: 0 = off, 1 = on (default), 2 = on without the half-phase skew of the wave halves
   if (g_p8_mode < 0) { const char* e = getenv("S2SVC_GEMM_8PH"); g_p8_mode = e ? atoi(e) : 1; }
@@ -523,6 +882,20 @@ extern "C" int s2svc_gemm_set_8ph(int mode) {
 extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   const s2svc_gemm_desc& d = *desc;
   const int mode = p8_mode();
+  if (mode != 0 && p8_tr_mode() && d.tile_hint != 64 && p8_tr_ok(d) && (int64_t)(d.M / 256) * (d.N / 128) >= p8_min_tiles()) {
+    const int64_t t128 = (int64_t)(d.M / 256) * (d.N / 128);
+    if (p8_tr_take_q(d.N % 256 == 0, t128 / 2, t128)) {
+      dim3 grid((unsigned)(d.N / 256), (unsigned)(d.M / 256), 1);
+      if (mode == 2) hipLaunchKernelGGL((gemm_8ph_tr_kernel_q<false>), grid, dim3(512), 0, (hipStream_t)stream, d);
+      else hipLaunchKernelGGL((gemm_8ph_tr_kernel_q<true>), grid, dim3(512), 0, (hipStream_t)stream, d);
+    } else {
+      dim3 grid((unsigned)(d.N / 128), (unsigned)(d.M / 256), 1);
+      if (mode == 2) hipLaunchKernelGGL((gemm_8ph_tr_kernel<false>), grid, dim3(512), 0, (hipStream_t)stream, d);
+      else hipLaunchKernelGGL((gemm_8ph_tr_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, d);
+    }
+    S2S_CHECK_LAUNCH("gemm_8ph_tr_kernel");
+    return 1;
+  }
   if (mode == 0 || d.dtype != S2S_BF16 || d.splitk > 1 || d.a_rowsum || d.tile_hint == 64) return 0;
   if (d.K < 128 || d.K % 64 || d.M < 256 || d.N < 64) return 0;
   if (d.B.mode != S2SVC_OP_DENSE || !p8_operand_ok(d.A, d.M, d.K) || !p8_operand_ok(d.B, d.N, d.K)) return 0;
@@ -567,4 +940,49 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
 #undef P8_LAUNCH
   S2S_CHECK_LAUNCH("gemm_8ph_kernel");
   return 1;
+}
+
+// the grouped weight-gradient launch on the 8-wave kernel: runs every descriptor that has exact 256 x 128 tiles (p8_tr_ok) and
+// returns the bit mask of those (0 = none: switched off, or nothing eligible); the caller runs the others on gemm_grouped_kernel.
+// WHICH kernel a problem gets depends on its own shape only, never on what shares the launch: the two kernels sum the bias
+// row-sums in different orders, and a staged backward pass (other flush points, other groups) must give the bits of the
+// uncut one (tests/gpu_model_check.py: stage_graphs_replay_equals_eager_full_size).  The tile width (256 / 128) does depend
+// on the group -- it changes the schedule, not the order of any sum.
+extern "C" int s2svc_gemm_grouped_try_8ph(const s2svc_gemm_desc* descs, int n, void* stream) {
+  const int mode = p8_mode();
+  if (mode == 0 || !p8_tr_mode() || n <= 0 || n > P8_GROUP_MAX) return 0;
+  p8_group_args g;
+  std::memset(&g, 0, sizeof(g));
+  int64_t t128 = 0, t256 = 0;
+  bool all256 = true;
+  int mask = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    // (and at least 64 tiles of 128 x 128 of its own -- a shape-only rule as well: a 256 x 1536 output is 12 of these tiles)
+    if (!p8_tr_ok(descs[i]) || (int64_t)(descs[i].M / 128) * (descs[i].N / 128) < 64) continue;
+    mask |= 1 << i;
+    g.d[m++] = descs[i];
+    t128 += (int64_t)(descs[i].M / 256) * (descs[i].N / 128);
+    all256 = all256 && descs[i].N % 256 == 0;
+    t256 += (int64_t)(descs[i].M / 256) * (descs[i].N / 256);
+  }
+  if (m == 0) return 0;
+  S2S_REQUIRE(t128 < (1ll << 30), "gemm_grouped: too many tiles");
+  g.n = m;
+  const bool q = p8_tr_take_q(all256, t256, t128);
+  int64_t total = 0;
+  for (int i = 0; i < m; ++i) {
+    g.tile_start[i] = (int32_t)total;
+    total += (int64_t)(g.d[i].M / 256) * (g.d[i].N / (q ? 256 : 128));
+  }
+  for (int i = m; i <= P8_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
+  hipStream_t st = (hipStream_t)stream;
+  if (q) {
+    if (mode == 2) hipLaunchKernelGGL((gemm_8ph_tr_grouped_kernel<false, 256>), dim3((unsigned)total), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_8ph_tr_grouped_kernel<true, 256>), dim3((unsigned)total), dim3(512), 0, st, g);
+  } else {
+    if (mode == 2) hipLaunchKernelGGL((gemm_8ph_tr_grouped_kernel<false, 128>), dim3((unsigned)total), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_8ph_tr_grouped_kernel<true, 128>), dim3((unsigned)total), dim3(512), 0, st, g);
+  }
+  S2S_CHECK_LAUNCH("gemm_8ph_tr_grouped_kernel");
+  return mask;
 }

@@ -736,6 +736,12 @@ bool deep_stages() {     // S2SVC_GEMM_DEEP=0: no 5-stage variant of the 32x64 k
   return v == 1;
 }
 
+int deep_min_tiles() {   // S2SVC_GEMM_DEEP_MIN: K tiles from which the 5-stage variant is taken (tuning aid)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_DEEP_MIN"); v = e ? atoi(e) : 16; }
+  return v;
+}
+
 bool tr_enabled() {      // S2SVC_GEMM_NO_TR=1: row-contiguous operands through the register-transpose path (tuning aid)
   static int v = -1;
   if (v < 0) { const char* e = getenv("S2SVC_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
@@ -896,6 +902,8 @@ static bool tconv_group_ok(const s2svc_gemm_desc& d) {
   return true;
 }
 
+extern "C" int s2svc_gemm_grouped_try_8ph(const s2svc_gemm_desc* descs, int n, void* stream);
+
 extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile, void* stream) {
   S2S_REQUIRE(descs && n > 0 && (tile == 64 || tile == 128), "gemm_grouped: bad args");
   hipStream_t st = (hipStream_t)stream;
@@ -918,19 +926,29 @@ extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile,
     return 0;
   }
   for (int i0 = 0; i0 < n; i0 += S2S_GROUP_MAX) {
-    group_args g;
-    std::memset(&g, 0, sizeof(g));
-    g.n = (n - i0 < S2S_GROUP_MAX) ? n - i0 : S2S_GROUP_MAX;
-    int64_t total = 0;
-    for (int i = 0; i < g.n; ++i) {
+    const int cnt = (n - i0 < S2S_GROUP_MAX) ? n - i0 : S2S_GROUP_MAX;
+    for (int i = 0; i < cnt; ++i) {
       const s2svc_gemm_desc& d = descs[i0 + i];
       S2S_REQUIRE(s2svc_gemm_grouped_ok(&d), "gemm_grouped: a descriptor is not eligible (check s2svc_gemm_grouped_ok first)");
       S2S_REQUIRE(d.splitk <= 1, "gemm_grouped: grouped problems run unsplit (splitk must be <= 1)");
-      g.d[i] = d;
-      g.tile_start[i] = (int32_t)total;
+    }
+    int taken = 0;                                  // problems of exact 256 x 128 tiles: the 8-wave kernel (gemm_8ph.hip)
+    if (tr_enabled()) {
+      taken = s2svc_gemm_grouped_try_8ph(descs + i0, cnt, stream);
+      if (taken < 0) return taken;
+    }
+    group_args g;
+    std::memset(&g, 0, sizeof(g));
+    int64_t total = 0;
+    for (int i = 0; i < cnt; ++i) {
+      if (taken & (1 << i)) continue;
+      const s2svc_gemm_desc& d = descs[i0 + i];
+      g.d[g.n] = d;
+      g.tile_start[g.n++] = (int32_t)total;
       total += (int64_t)((d.M + tile - 1) / tile) * ((d.N + tile - 1) / tile);
       S2S_REQUIRE(total < (1ll << 30), "gemm_grouped: too many tiles");
     }
+    if (g.n == 0) continue;
     for (int i = g.n; i <= S2S_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
     if (tr_enabled()) {
       if (tile == 128)
@@ -975,7 +993,7 @@ extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
     // long reductions (K >= 1024: the feed-forward / packed-projection data gradients of VTN, 18-24 K tiles) with few workgroups:
     // five stages in flight (60 KB) instead of three -- with 2 tiles of lookahead (~0.7 us of MFMA work) every K tile waits for
     // its own DMA round trip; S2SVC_GEMM_DEEP=0 keeps three stages (A/B switch)
-    if (deep_stages() && (d.K + 63) / 64 / splitk >= 16)
+    if (deep_stages() && (d.K + 63) / 64 / splitk >= deep_min_tiles())
       hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 5, 64>), grid, dim3(256), 0, st, d);
     else
       hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 3, 64>), grid, dim3(256), 0, st, d);

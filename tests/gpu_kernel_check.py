@@ -305,10 +305,14 @@ def gemm_grouped_wgrad():
     saved, saved_max = K._GROUP_TILE, K._GROUP_MAX_TILES
     big = []
     with K.record_grouped(big):      # default policy: an output with >= _GROUP_MAX_TILES 128x128 tiles is launched directly
-        x, dy, dw0 = rnd(512, 3072, seed=50, dtype=dtype), rnd(512, 1536, seed=51, dtype=dtype), rnd(1536, 3072, seed=52)
+        x, dy, dw0 = rnd(512, 3072, seed=50, dtype=dtype), rnd(512, 1664, seed=51, dtype=dtype), rnd(1664, 3072, seed=52)
         dw = dw0.clone()
-        K.gemm(K.operand(dy, 1536, layout=K.RC), K.operand(x, 3072, layout=K.RC), 1536, 3072, 512, dw, in_dtype=dtype, accumulate=True)
-    res.append((len(big) == 0, "a chip-filling problem (288 tiles of 128x128) is not queued"))
+        K.gemm(K.operand(dy, 1664, layout=K.RC), K.operand(x, 3072, layout=K.RC), 1664, 3072, 512, dw, in_dtype=dtype, accumulate=True)
+        x8, dy8, dw8 = rnd(512, 3072, seed=53, dtype=dtype), rnd(512, 1536, seed=54, dtype=dtype), torch.zeros(1536, 3072, device=DEV)
+        K.gemm(K.operand(dy8, 1536, layout=K.RC), K.operand(x8, 3072, layout=K.RC), 1536, 3072, 512, dw8, in_dtype=dtype, accumulate=True)
+    res.append((len(big) == 1, "a chip-filling problem (312 tiles of 128x128) is not queued; one of exact 256x256 tiles is (8-wave grouped kernel)"))
+    K.flush_grouped(big)
+    res.append(check("queued 256-multiple problem after the flush", dw8, dy8.float().t() @ x8.float(), torch.float32, rtol=1e-3, atol=0.05))
     res.append(check("chip-filling problem launched directly", dw, dw0 + dy.float().t() @ x.float(), torch.float32, rtol=1e-3, atol=0.05))
     K._GROUP_MAX_TILES = 1 << 30
     for tile in (64, 128):
@@ -1053,6 +1057,92 @@ def gemm_8phase():
                 elif not torch.equal(first, c):
                     bad += 1
             res.append((bad == 0, f"8-phase {GEO[geo]}: {bad} of 29 repeated launches differ from the first"))
+    finally:
+        L.s2svc_gemm_set_8ph(prev)
+    return res
+
+
+@case
+def gemm_8phase_weight_gradients():
+    """The 8-wave kernel for row-contiguous operands (gemm_8ph_tr_kernel: C (+)= dY^T . X on 256 x 128 tiles, transpose reads,
+    bias row-sums as MFMA products with a ones fragment): single launches (odd / even K-tile counts, a single K-tile pair,
+    fp32 C with and without accumulation, bf16 C), the grouped launch, both wave-half schedules bit for bit, repeated
+    launches bit for bit -- against torch fp32 and against the 4-wave kernels (set_8ph(0))."""
+    res = []
+    dtype = torch.bfloat16
+    L = K._lib.lib()
+    prev = L.s2svc_gemm_set_8ph(-1)
+    try:
+        for (rows, fin, fout, seed) in [(4096, 1536, 4608, 1), (320, 2048, 2048, 2), (128, 1536, 3072, 3), (1088, 4096, 1024, 4)]:
+            x, dy = rnd(rows, fin, seed=seed, dtype=dtype), rnd(rows, fout, seed=seed + 50, dtype=dtype)
+            dw0, db0 = rnd(fout, fin, seed=seed + 100), rnd(fout, seed=seed + 150)
+            ref_w = dy.float().t() @ x.float()
+            ref_b = dy.float().sum(0)
+            outs = {}
+            for mode in (0, 1 | (1 << 4), 2 | (1 << 4), 1 | (3 << 4), 2 | (3 << 4)):      # off; 256x256 / 256x128 tiles, skewed / lockstep
+                L.s2svc_gemm_set_8ph(mode)
+                dw, db = dw0.clone(), db0.clone()
+                K.gemm(K.operand(dy, fout, layout=K.RC), K.operand(x, fin, layout=K.RC), fout, fin, rows, dw, in_dtype=dtype,
+                       accumulate=True, a_rowsum=db, a_rowsum_accumulate=True)
+                outs[mode] = (dw, db)
+            sc = float(ref_w.abs().max())
+            for geo, nm in ((1, "256x256"), (3, "256x128")):
+                o1, o2 = outs[1 | (geo << 4)], outs[2 | (geo << 4)]
+                res.append(check(f"8-wave wgrad {fout}x{fin}x{rows} tile {nm} dW (+=)", o1[0], dw0 + ref_w, torch.float32, rtol=1e-3, atol=2e-4 * sc))
+                res.append(check(f"8-wave wgrad {fout}x{fin}x{rows} tile {nm} db (+=)", o1[1], db0 + ref_b, torch.float32, rtol=1e-3,
+                                 atol=2e-4 * float(ref_b.abs().max())))
+                res.append((bool(torch.equal(o1[0], o2[0]) and torch.equal(o1[1], o2[1])),
+                            f"8-wave wgrad {fout}x{fin}x{rows} {nm}: skewed and lockstep wave halves agree bit for bit"))
+                dmax = float((o1[0] - outs[0][0]).abs().max())
+                res.append((dmax <= 1e-3 * sc, f"8-wave {nm} vs 4-wave wgrad {fout}x{fin}x{rows}: max diff {dmax:.3e} (scale {sc:.1f})"))
+            L.s2svc_gemm_set_8ph(1)
+            dwn = torch.full((fout, fin), float("nan"), device=DEV)
+            dbn = torch.full((fout,), float("nan"), device=DEV)
+            K.gemm(K.operand(dy, fout, layout=K.RC), K.operand(x, fin, layout=K.RC), fout, fin, rows, dwn, in_dtype=dtype, a_rowsum=dbn)
+            res.append(check(f"8-wave wgrad {fout}x{fin}x{rows} dW (=)", dwn, ref_w, torch.float32, rtol=1e-3, atol=2e-4 * sc))
+            res.append(check(f"8-wave wgrad {fout}x{fin}x{rows} db (=)", dbn, ref_b, torch.float32, rtol=1e-3, atol=2e-4 * float(ref_b.abs().max())))
+            dwb = torch.empty((fout, fin), dtype=dtype, device=DEV)
+            K.gemm(K.operand(dy, fout, layout=K.RC), K.operand(x, fin, layout=K.RC), fout, fin, rows, dwb, in_dtype=dtype)
+            res.append(check(f"8-wave wgrad {fout}x{fin}x{rows} bf16 C", dwb, ref_w, dtype, atol=0.02 * sc))
+        # grouped: five AAS-VC decoder layers' worth of shapes in one launch (the queue policy of training)
+        L.s2svc_gemm_set_8ph(1)
+        shapes = [(2048, 1536, 1536), (2048, 1536, 3072), (2048, 3072, 1536), (2048, 1536, 1536), (2048, 1536, 256)]
+        probs = []
+        for i, (rows, fin, fout) in enumerate(shapes):
+            probs.append((rnd(rows, fin, seed=60 + i, dtype=dtype), rnd(rows, fout, seed=70 + i, dtype=dtype), rnd(fout, fin, seed=80 + i),
+                          rnd(fout, seed=90 + i)))
+        saved = (K._GROUP_TILE, K._GROUP_MAX_TILES, K._GROUP_BIG_TILES)
+        K._GROUP_MAX_TILES = 1 << 30
+        results = {}
+        for mode in (0, 1, 1 | (3 << 4)):          # 4-wave; policy (256x256: 396 tiles... the cost model decides); forced 256x128
+            L.s2svc_gemm_set_8ph(mode)
+            outs = [(p[2].clone(), p[3].clone()) for p in probs]
+            queue = []
+            with K.record_grouped(queue):
+                for (x, dy, _, _), (dw, db) in zip(probs, outs):
+                    K.gemm(K.operand(dy, dy.shape[1], layout=K.RC), K.operand(x, x.shape[1], layout=K.RC), dy.shape[1], x.shape[1], x.shape[0],
+                           dw, in_dtype=dtype, accumulate=True, a_rowsum=db, a_rowsum_accumulate=True)
+            K.flush_grouped(queue)
+            results[mode] = outs
+        K._GROUP_TILE, K._GROUP_MAX_TILES, K._GROUP_BIG_TILES = saved
+        for mode in (1, 1 | (3 << 4)):
+            for i, ((x, dy, dw0, db0), (dw, db)) in enumerate(zip(probs, results[mode])):
+                ref_w, ref_b = dw0 + dy.float().t() @ x.float(), db0 + dy.float().sum(0)
+                res.append(check(f"8-wave grouped wgrad (mode {mode}) #{i} {tuple(dw.shape)} dW", dw, ref_w, torch.float32, rtol=1e-3,
+                                 atol=2e-4 * float(ref_w.abs().max())))
+                res.append(check(f"8-wave grouped wgrad (mode {mode}) #{i} db", db, ref_b, torch.float32, rtol=1e-3,
+                                 atol=2e-4 * float(ref_b.abs().max())))
+        # repeated launches give identical bits
+        x, dy = rnd(4096, 1536, seed=41, dtype=dtype), rnd(4096, 4608, seed=42, dtype=dtype)
+        first, bad = None, 0
+        for it in range(20):
+            dw, db = torch.empty(4608, 1536, device=DEV), torch.empty(4608, device=DEV)
+            K.gemm(K.operand(dy, 4608, layout=K.RC), K.operand(x, 1536, layout=K.RC), 4608, 1536, 4096, dw, in_dtype=dtype, a_rowsum=db)
+            if first is None:
+                first = (dw, db)
+            elif not (torch.equal(first[0], dw) and torch.equal(first[1], db)):
+                bad += 1
+        res.append((bad == 0, f"8-wave wgrad: {bad} of 19 repeated launches differ from the first"))
     finally:
         L.s2svc_gemm_set_8ph(prev)
     return res

@@ -151,6 +151,41 @@ def main():
                  bench(lambda: K.gemm(K.operand(dy, O, layout=K.RC),
                                       K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M, dwp,
                                       in_dtype=dtype, splitk=sk, tile=tile), a.iters))
+    # AAS-VC decoder weight gradients (4096 rows, d = 1536): un-grouped on the 8-wave kernel vs the 4-wave kernel, with the fused
+    # bias row-sums; and five layers' worth as one grouped launch
+    if (not a.filter or a.filter in "aas wgrad 8-wave") and dtype == torch.bfloat16:
+        L = K._lib.lib()
+        prev = L.s2svc_gemm_set_8ph(-1)
+        for rows, fin, fout in ((4096, 1536, 1536), (4096, 1536, 3072), (4096, 3072, 1536), (4096, 1536, 4608)):
+            x, dy = rnd(rows, fin), rnd(rows, fout)
+            dw = torch.zeros(fout, fin, device=dev)
+            db = torch.zeros(fout, device=dev)
+            for mode, nm in ((0, "4-wave 128x128"), (1 | (3 << 4), "8-wave 256x128"), (1 | (1 << 4), "8-wave 256x256"), (1, "8-wave policy")):
+                L.s2svc_gemm_set_8ph(mode)
+                line(f"wgrad aas {fout}x{fin} + bias row-sums, {nm}", fout, fin, rows,
+                     bench(lambda: K.gemm(K.operand(dy, fout, layout=K.RC), K.operand(x, fin, layout=K.RC), fout, fin, rows, dw,
+                                          in_dtype=dtype, accumulate=True, a_rowsum=db, a_rowsum_accumulate=True), a.iters))
+        probs = [(rnd(4096, fin), rnd(4096, fout), torch.zeros(fout, fin, device=dev), torch.zeros(fout, device=dev))
+                 for fin, fout in ((1536, 1536), (1536, 3072), (3072, 1536), (1536, 1536), (1536, 1536))]
+        gf = sum(2.0 * 4096 * p[0].shape[1] * p[1].shape[1] for p in probs)
+        saved = K._GROUP_MAX_TILES
+        K._GROUP_MAX_TILES = 1 << 30
+
+        def grouped():
+            q = []
+            with K.record_grouped(q):
+                for x, dy, dw, db in probs:
+                    K.gemm(K.operand(dy, dy.shape[1], layout=K.RC), K.operand(x, x.shape[1], layout=K.RC), dy.shape[1], x.shape[1], 4096, dw,
+                           in_dtype=dtype, accumulate=True, a_rowsum=db, a_rowsum_accumulate=True)
+            K.flush_grouped(q)
+        for mode, nm in ((0, "4-wave"), (1 | (3 << 4), "8-wave 256x128"), (1 | (1 << 4), "8-wave 256x256"), (1, "8-wave policy")):
+            L.s2svc_gemm_set_8ph(mode)
+            us = bench(grouped, a.iters)
+            tot += us
+            print(f"{'wgrad aas grouped launch of 5 problems, ' + nm:58s} {'':6s} {'':6s} {'':6s} {us:9.1f} {gf / us / 1e6:9.1f} "
+                  f"{100 * gf / us / 1e6 / PEAK[dtype]:6.1f}")
+        K._GROUP_MAX_TILES = saved
+        L.s2svc_gemm_set_8ph(prev)
     # postnet Conv1d k5 256->256 as implicit GEMM (B32 T256)
     if not a.filter or a.filter in "conv1d":
         B, T, Cin, Cout, ks = 32, 256, 256, 256, 5
