@@ -226,7 +226,7 @@ __device__ __forceinline__ void p8_mfma(const bf16x8_t (&a)[NA][2], const bf16x8
 // (4, 2) -> 512 x 128 tile for outputs with few columns (N = 384: 3 column tiles, 225 workgroups on 256 CUs), 160 KB LDS.
 // Units: A.m0 / A.m1 = WR * 64 rows (WR DMA instructions per wave), B.n0 / B.n1 = WC * 32 rows (WC / 2 per wave).
 // ---------------------------------------------------------------------------------------------------------
-template <int KA, int WR, int WC, bool STAGGER>
+template <int KA, int WR, int WC, bool STAGGER, bool LEAN = false>
 __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d) {
   static_assert(WR * WC == 8 && (WC == 2 || WC == 4), "8 waves");
   constexpr int BM = WR * 128, BN = WC * 64;
@@ -361,14 +361,15 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
       case 2: epilogue_stage<64, 32>(acc[1][0], cs); break;
       default: epilogue_stage<64, 32>(acc[1][1], cs); break;
     }
-    epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + (q >> 1) * 64, n0 + wc * 64 + (q & 1) * 32, cs, 1, 0, zb);
+    if (LEAN) epilogue_flush_common<64, 32>(d, m0 + wr * 128 + (q >> 1) * 64, n0 + wc * 64 + (q & 1) * 32, cs);
+    else epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + (q >> 1) * 64, n0 + wc * 64 + (q & 1) * 32, cs, 1, 0, zb);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // BN = 128: 2 phases per K tile (wave tile 128 x 32: a phase = 64 rows x 32 columns x K 64)
 // ---------------------------------------------------------------------------------------------------------
-template <int KA, bool STAGGER>
+template <int KA, bool STAGGER, bool LEAN = false>
 __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc d) {
   constexpr int UNIT = 16384, BUF = 3 * UNIT;            // A.m0 | A.m1 | B
   __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
@@ -462,7 +463,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
   for (int a = 0; a < 2; ++a) {          // rolled: one copy of the flush code (see epilogue_stage)
     if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
     else epilogue_stage<64, 32>(acc[1], cs);
-    epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, cs, 1, 0, zb);
+    if (LEAN) epilogue_flush_common<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);       // (gemm_common.h: a fraction of the code)
+    else epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, cs, 1, 0, zb);
   }
 }
 
@@ -934,7 +936,12 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
       else hipLaunchKernelGGL((KERNEL<P8_DENSE, ##__VA_ARGS__, true>), grid, dim3(512), 0, st, d);        \
     }                                                                                                     \
   } while (0)
-  if (geo == 1) P8_LAUNCH(gemm_8ph_kernel_q, 2, 4);
+  static const bool lean_on = !getenv_off("S2SVC_GEMM_LEAN");
+  if (lean_on && !conv && !tconv && mode != 2 && epilogue_common_ok(d)) {       // dense operands + the common epilogue: lean variants
+    if (geo == 1) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_DENSE, 2, 4, true, true>), grid, dim3(512), 0, st, d);
+    else if (geo == 2) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_DENSE, 4, 2, true, true>), grid, dim3(512), 0, st, d);
+    else hipLaunchKernelGGL((gemm_8ph_kernel_128<P8_DENSE, true, true>), grid, dim3(512), 0, st, d);
+  } else if (geo == 1) P8_LAUNCH(gemm_8ph_kernel_q, 2, 4);
   else if (geo == 2) P8_LAUNCH(gemm_8ph_kernel_q, 4, 2);
   else P8_LAUNCH(gemm_8ph_kernel_128);
 #undef P8_LAUNCH

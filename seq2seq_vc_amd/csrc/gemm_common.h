@@ -273,3 +273,78 @@ __device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0,
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// The COMMON epilogue: what the Linear layers of the training chains use and nothing else -- bias, ReLU, dropout, a ReLU mask
+// (emask mode 0), a residual, bf16 C, one problem (no batch, split-K, alpha, pre-activation output, row map, accumulation,
+// fp32 C, unaligned tails).  Same arithmetic and the same masks as epilogue_flush.  Why a second copy: the general flush carries
+// the tanh / GELU / sigmoid / Swish expansions (8-fold unrolled), Swish' masks, the fp32 and accumulate paths and the
+// element-wise fallback -- 17 of the 20.8 KB of gemm_dma_kernel<32, 64> -- and a launch-bound kernel pays for code it never
+// runs (2016 x 384 x 384: 5.6 -> 5.1 us with a kernel of 3.2 KB; tools/kernel_code_sizes.py).  epilogue_common_ok() is the
+// host-side test.
+// ---------------------------------------------------------------------------------------------------------
+inline bool epilogue_common_ok(const s2svc_gemm_desc& d) {
+  if (d.c_dtype != S2S_BF16 || d.nb0 * d.nb1 != 1 || d.splitk > 1 || d.alpha != 1.0f || d.c_pre || d.c_map || d.accumulate) return false;
+  if (d.act != S2S_ACT_NONE && d.act != S2S_ACT_RELU) return false;
+  if (d.emask && d.emask_mode != 0) return false;
+  if (d.N % 8 || d.ldc % 8 || ((uintptr_t)d.C) % 16) return false;
+  if (d.res && (d.ldr % 8 || ((uintptr_t)d.res) % 16)) return false;
+  if (d.emask && (d.ldm % 8 || ((uintptr_t)d.emask) % 16)) return false;
+  return true;
+}
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_flush_common(const s2svc_gemm_desc& d, int m_base, int n_base, const float* cs) {
+  const int lane = threadIdx.x & 63;
+  constexpr int LPR = WTN / 8, RPP = 64 / LPR;
+#pragma unroll 1
+  for (int p = 0; p < WTM / RPP; ++p) {
+    const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
+    const int m = m_base + row, n = n_base + col;
+    if (m >= d.M || n >= d.N) continue;
+    const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
+    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (d.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (d.act == S2S_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    if (d.drop_p > 0.f) {
+      const uint64_t seed = (d.seed_base ? *d.seed_base : 0ull) + d.seed_off;
+      const float inv_keep = 1.f / (1.f - d.drop_p);
+      const uint64_t idx = (uint64_t)((int64_t)m * d.N + n);
+      const uint32_t thr = dropout_threshold(d.drop_p);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint64_t r = dropout_draw(seed, (idx >> 2) + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] *= ((uint32_t)(r >> (16 * e)) & 0xffffu) < thr ? 0.f : inv_keep;
+      }
+    }
+    if (d.emask) {
+      const uint4 ev = *reinterpret_cast<const uint4*>((const bf16_t*)d.emask + (int64_t)m * d.ldm + n);
+      const uint32_t w[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(w[e] << 16) > 0.f ? v[2 * e] : 0.f;
+        v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) > 0.f ? v[2 * e + 1] : 0.f;
+      }
+    }
+    if (d.res) {
+      const uint4 rv = *reinterpret_cast<const uint4*>((const bf16_t*)d.res + (int64_t)m * d.ldr + n);
+      const uint32_t w[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+    }
+    uint4 o;
+    o.x = f2bf2(v[0], v[1]);
+    o.y = f2bf2(v[2], v[3]);
+    o.z = f2bf2(v[4], v[5]);
+    o.w = f2bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>((bf16_t*)d.C + (int64_t)m * d.ldc + n) = o;
+  }
+}

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const group_args g) {
 // ---------------------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int KA, int KB, int NS, int BK>
+template <int BM, int BN, int KA, int KB, int NS, int BK, bool LEAN = false>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const s2svc_gemm_desc d) {
   constexpr int FM = BM / 32, FN = BN / 32;
   constexpr int ABYTES = BM * BK * 2, BBYTES = BN * BK * 2, STAGE_BYTES = ABYTES + BBYTES;
@@ -720,8 +720,20 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const s2svc_gemm_desc d) 
 
   static_assert(sizeof(smem) >= (size_t)BM * BN * 4, "the operand stages double as the fp32 C tiles of the epilogue");
   __syncthreads();               // every wave is done with the operand stages: reuse them as fp32 C tiles
+  if (LEAN) {       // the common epilogue only (see epilogue_flush_common): a fraction of the code
+    float* cs = reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2);
+    epilogue_stage<BM / 2, BN / 2>(acc, cs);
+    epilogue_flush_common<BM / 2, BN / 2>(d, m0 + wm, n0 + wn, cs);
+    return;
+  }
   epilogue_tile<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2),
                                 splitk, zs, zb);
+}
+
+bool lean_enabled() {    // S2SVC_GEMM_LEAN=0: every launch carries the general epilogue (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_LEAN"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
 }
 
 int dma_stages() {       // S2SVC_GEMM_STAGES override (0 = built-in policy), see launch_kinds
@@ -775,6 +787,10 @@ bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   if (ka == KA && kb == KB && !d.a_rowsum && BM == 64 && dma_stages() != 2) {                      \
     hipLaunchKernelGGL((gemm_dma_kernel<64, 64, KA, KB, 3, 64>), grid, dim3(256), 0, st, d);       \
     return true;                                                                                   \
+  }
+  if (ka == G_KC_DENSE && kb == G_KC_DENSE && !d.a_rowsum && BM == 64 && dma_stages() != 2 && lean_enabled() && epilogue_common_ok(d)) {
+    hipLaunchKernelGGL((gemm_dma_kernel<64, 64, G_KC_DENSE, G_KC_DENSE, 3, 64, true>), grid, dim3(256), 0, st, d);
+    return true;
   }
   S2S_DMA_CASE(G_KC_DENSE, G_KC_DENSE)
   S2S_DMA_CASE(G_KC_CONV1D, G_KC_DENSE)
@@ -993,8 +1009,13 @@ extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
     // long reductions (K >= 1024: the feed-forward / packed-projection data gradients of VTN, 18-24 K tiles) with few workgroups:
     // five stages in flight (60 KB) instead of three -- with 2 tiles of lookahead (~0.7 us of MFMA work) every K tile waits for
     // its own DMA round trip; S2SVC_GEMM_DEEP=0 keeps three stages (A/B switch)
-    if (deep_stages() && (d.K + 63) / 64 / splitk >= deep_min_tiles())
-      hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 5, 64>), grid, dim3(256), 0, st, d);
+    const bool lean = lean_enabled() && epilogue_common_ok(d);
+    if (deep_stages() && (d.K + 63) / 64 / splitk >= deep_min_tiles()) {
+      if (lean) hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 5, 64, true>), grid, dim3(256), 0, st, d);
+      else hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 5, 64>), grid, dim3(256), 0, st, d);
+    }
+    else if (lean)
+      hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 3, 64, true>), grid, dim3(256), 0, st, d);
     else
       hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 3, 64>), grid, dim3(256), 0, st, d);
     S2S_CHECK_LAUNCH("gemm_dma_kernel");
