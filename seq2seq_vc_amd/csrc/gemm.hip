@@ -380,8 +380,8 @@ extern "C" int s2svc_gemm(const s2svc_gemm_desc* desc, void* stream) {
     if (rs != 0) return rs < 0 ? rs : finish(false);
     int rc = d.c_map ? 0 : s2svc_gemm_try_8ph(&d, stream);
     if (rc == 0) rc = s2svc_gemm_try_glds(&d, stream);
+    if (rc == 0) rc = s2svc_gemm_try_fast(&d, stream);      // (its epilogue is the staged one as well since round 3)
     const bool native_stage = rc == 1 && d.splitk <= 1;
-    if (rc == 0) rc = s2svc_gemm_try_fast(&d, stream);
     if (rc < 0) return rc;
     if (rc == 1) {
       if (d.splitk > 1) {

@@ -348,3 +348,49 @@ __device__ __forceinline__ void epilogue_flush_common(const s2svc_gemm_desc& d, 
     *reinterpret_cast<uint4*>((bf16_t*)d.C + (int64_t)m * d.ldc + n) = o;
   }
 }
+
+// the fp32 counterpart (the duration predictor's Linear layers and their gradients: bias, ReLU, fp32 residual, accumulation into
+// a gradient slot; no dropout / mask)
+inline bool epilogue_common32_ok(const s2svc_gemm_desc& d) {
+  if (d.c_dtype != S2S_F32 || d.nb0 * d.nb1 != 1 || d.splitk > 1 || d.alpha != 1.0f || d.c_pre || d.c_map) return false;
+  if (d.act != S2S_ACT_NONE && d.act != S2S_ACT_RELU) return false;
+  if (d.emask || d.drop_p > 0.f) return false;
+  if (d.N % 8 || d.ldc % 4 || ((uintptr_t)d.C) % 16) return false;
+  if (d.res && (d.ldr % 4 || ((uintptr_t)d.res) % 16)) return false;
+  if (d.bias && ((uintptr_t)d.bias) % 16) return false;
+  return true;
+}
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_flush_common32(const s2svc_gemm_desc& d, int m_base, int n_base, const float* cs) {
+  const int lane = threadIdx.x & 63;
+  constexpr int LPR = WTN / 8, RPP = 64 / LPR;
+#pragma unroll 1
+  for (int p = 0; p < WTM / RPP; ++p) {
+    const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
+    const int m = m_base + row, n = n_base + col;
+    if (m >= d.M || n >= d.N) continue;
+    const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
+    float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    if (d.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+      lo.x += b0.x; lo.y += b0.y; lo.z += b0.z; lo.w += b0.w; hi.x += b1.x; hi.y += b1.y; hi.z += b1.z; hi.w += b1.w;
+    }
+    if (d.act == S2S_ACT_RELU) {
+      lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+      hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+    }
+    if (d.res) {
+      const float* r = (const float*)d.res + (int64_t)m * d.ldr + n;
+      const float4 r0 = *reinterpret_cast<const float4*>(r), r1 = *reinterpret_cast<const float4*>(r + 4);
+      lo.x += r0.x; lo.y += r0.y; lo.z += r0.z; lo.w += r0.w; hi.x += r1.x; hi.y += r1.y; hi.z += r1.z; hi.w += r1.w;
+    }
+    float* c = (float*)d.C + (int64_t)m * d.ldc + n;
+    if (d.accumulate) {
+      const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+      lo.x += c0.x; lo.y += c0.y; lo.z += c0.z; lo.w += c0.w; hi.x += c1.x; hi.y += c1.y; hi.z += c1.z; hi.w += c1.w;
+    }
+    *reinterpret_cast<float4*>(c) = lo;
+    *reinterpret_cast<float4*>(c + 4) = hi;
+  }
+}

@@ -26,7 +26,7 @@ template <> struct VecCfg<bf16_t> { static constexpr int VEC = 8; static constex
 // ---------------------------------------------------------------------------------------------
 // KC loader: NV vectors per thread, vector = (row, kk..kk+VEC) ; element address = rowbase + f(k)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int ROWS, int BK>
+template <typename T, int ROWS, int BK, bool DENSE = false>
 struct KcLoader {
   static constexpr int VEC = VecCfg<T>::VEC;
   static constexpr int VPR = BK / VEC;             // vectors per row
@@ -42,7 +42,7 @@ struct KcLoader {
       const int r = r0 + v / VPR;
       trow[i] = 0;
       if (r >= R) { trow[i] = -1; rowbase[i] = 0; continue; }
-      if (o.mode == S2SVC_OP_DENSE) {
+      if (DENSE || o.mode == S2SVC_OP_DENSE) {
         rowbase[i] = (int64_t)r * o.ld;
       } else if (o.mode == S2SVC_OP_CONV1D) {
         rowbase[i] = (int64_t)r * o.ld;
@@ -61,7 +61,7 @@ struct KcLoader {
       const int k = k0 + (v % VPR) * VEC;
       uint4 val = make_uint4(0, 0, 0, 0);
       if (trow[i] >= 0 && k < K) {
-        if (o.mode == S2SVC_OP_DENSE) {
+        if (DENSE || o.mode == S2SVC_OP_DENSE) {
           val = *reinterpret_cast<const uint4*>(base + rowbase[i] + k);
         } else {
           const int tap = k / o.C, c = k - tap * o.C;
@@ -116,7 +116,7 @@ template <> struct Transposer<bf16_t> {
   }
 };
 
-template <typename T, int ROWS, int BK>
+template <typename T, int ROWS, int BK, bool DENSE = false>
 struct RcLoader {
   static constexpr int VEC = VecCfg<T>::VEC;
   static constexpr int RB = ROWS / VEC;                 // row blocks
@@ -132,13 +132,13 @@ struct RcLoader {
       const int rb = blk % RB, kb = blk / RB;
       const int r = r0 + rb * VEC;
       int tap = 0, c = r;
-      if (o.mode != S2SVC_OP_DENSE) { tap = r / o.C; c = r - tap * o.C; }
+      if (!DENSE && o.mode != S2SVC_OP_DENSE) { tap = r / o.C; c = r - tap * o.C; }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const int k = k0 + kb * VEC + j;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (active && r < R && k < K) {
-          if (o.mode == S2SVC_OP_DENSE) {
+          if (DENSE || o.mode == S2SVC_OP_DENSE) {
             val = *reinterpret_cast<const uint4*>(base + (int64_t)k * o.ld + r);
           } else if (o.mode == S2SVC_OP_CONV1D) {
             const int t = k % o.T, tt = t + tap - o.pad;
@@ -170,15 +170,15 @@ struct RcLoader {
   }
 };
 
-template <typename T, int ROWS, int BK, int MODE> struct Loader;
-template <typename T, int ROWS, int BK> struct Loader<T, ROWS, BK, AM_KC> {
-  KcLoader<T, ROWS, BK> l;
+template <typename T, int ROWS, int BK, int MODE, bool DENSE = false> struct Loader;
+template <typename T, int ROWS, int BK, bool DENSE> struct Loader<T, ROWS, BK, AM_KC, DENSE> {
+  KcLoader<T, ROWS, BK, DENSE> l;
   __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) { l.init(o, r0, R); }
   __device__ __forceinline__ void load(const s2svc_operand& o, const T* base, int r0, int R, int k0, int K) { l.load(o, base, k0, K); }
   __device__ __forceinline__ void store(T* lds) const { l.store(lds); }
 };
-template <typename T, int ROWS, int BK> struct Loader<T, ROWS, BK, AM_RC> {
-  RcLoader<T, ROWS, BK> l;
+template <typename T, int ROWS, int BK, bool DENSE> struct Loader<T, ROWS, BK, AM_RC, DENSE> {
+  RcLoader<T, ROWS, BK, DENSE> l;
   __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) { l.init(o, r0, R); }
   __device__ __forceinline__ void load(const s2svc_operand& o, const T* base, int r0, int R, int k0, int K) { l.load(o, base, r0, R, k0, K); }
   __device__ __forceinline__ void store(T* lds) const { l.store(lds); }
@@ -225,12 +225,17 @@ template <int FM, int FN, int BK> struct MmaF<float, FM, FN, BK> {
   }
 };
 
-template <typename T, int BM, int BN, int BK, int AMODE, int BMODE>
+// LEAN: dense operands and the common fp32 epilogue only (epilogue_flush_common32) -- the duration predictor's Linear layers
+template <typename T, int BM, int BN, int BK, int AMODE, int BMODE, bool LEAN = false>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(const s2svc_gemm_desc d) {
   constexpr int PITCH = BK + VecCfg<T>::PAD;
   constexpr int FM = BM / 32, FN = BN / 32;
-  __shared__ __attribute__((aligned(16))) T As[BM * PITCH];
-  __shared__ __attribute__((aligned(16))) T Bs[BN * PITCH];
+  // one array: the epilogue reuses it as the four waves' fp32 C tiles (BM * BN * 4 bytes: more than the operand tiles of the
+  // 128 x 128 kernel need)
+  constexpr size_t AB_BYTES = sizeof(T) * (BM + BN) * PITCH, C_BYTES = (size_t)BM * BN * 4;
+  __shared__ __attribute__((aligned(16))) T smem_ab[(AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES) / sizeof(T)];
+  T* As = smem_ab;
+  T* Bs = smem_ab + BM * PITCH;
 
   const int splitk = d.splitk > 1 ? d.splitk : 1;
   const int zb = blockIdx.z / splitk, zs = blockIdx.z - zb * splitk;
@@ -251,8 +256,8 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const s2svc_gemm_desc d)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  Loader<T, BM, BK, AMODE> la;
-  Loader<T, BN, BK, BMODE> lb;
+  Loader<T, BM, BK, AMODE, LEAN> la;
+  Loader<T, BN, BK, BMODE, LEAN> lb;
   la.init(d.A, m0, d.M);
   lb.init(d.B, n0, d.N);
   if (kt_begin < kt_end) {
@@ -294,29 +299,30 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const s2svc_gemm_desc d)
       else d.a_rowsum[m] = (d.a_rowsum_accumulate ? d.a_rowsum[m] : 0.f) + rowsum;
     }
   }
-  const int lane = threadIdx.x & 63, lc = lane & 15, lq = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm + i * 16 + lq * 4 + r;
-        const int n = n0 + wn + j * 16 + lc;
-        if (m < d.M && n < d.N) {
-          if (splitk > 1) {
-            const int nbatch = d.nb0 * d.nb1;
-            d.ws[(((int64_t)zs * nbatch + zb) * d.M + m) * d.N + n] = acc[i][j][r];
-          } else {
-            epilogue_store_f(d, z0, z1, m, n, acc[i][j][r]);
-          }
-        }
-      }
+  // the accumulators leave through wave-private fp32 LDS tiles (the operand tiles are dead): ONE rolled copy of the epilogue
+  // instead of FM * FN * 4 inlined copies of the element-wise one (each with the activation switch: 40 KB of code in the fp32
+  // 64 x 64 kernel, which the duration predictor of AAS-VC launches ~100 times per step)
+  __syncthreads();
+  float* cs = reinterpret_cast<float*>(smem_ab) + wave * (BM / 2) * (BN / 2);
+  if (LEAN) {
+    epilogue_stage<BM / 2, BN / 2>(acc, cs);
+    epilogue_flush_common32<BM / 2, BN / 2>(d, m0 + wm, n0 + wn, cs);
+  } else {
+    epilogue_tile<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, cs, splitk, zs, zb);
+  }
 }
 
 template <typename T, int BM, int BN, int BK>
 void launch_modes(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   const bool arc = d.A.layout == S2SVC_LAYOUT_RC, brc = d.B.layout == S2SVC_LAYOUT_RC;
+  static const bool lean_on = !(getenv("S2SVC_GEMM_LEAN") && getenv("S2SVC_GEMM_LEAN")[0] == '0');
+  if (lean_on && sizeof(T) == 4 && BM == 64 && d.A.mode == S2SVC_OP_DENSE && d.B.mode == S2SVC_OP_DENSE && epilogue_common32_ok(d)) {
+    if (!arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<float, 64, 64, 64, AM_KC, AM_KC, true>), grid, dim3(256), 0, st, d);
+    else if (!arc && brc) hipLaunchKernelGGL((gemm_fast_kernel<float, 64, 64, 64, AM_KC, AM_RC, true>), grid, dim3(256), 0, st, d);
+    else if (arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<float, 64, 64, 64, AM_RC, AM_KC, true>), grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL((gemm_fast_kernel<float, 64, 64, 64, AM_RC, AM_RC, true>), grid, dim3(256), 0, st, d);
+    return;
+  }
   if (!arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_KC, AM_KC>), grid, dim3(256), 0, st, d);
   else if (!arc && brc) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_KC, AM_RC>), grid, dim3(256), 0, st, d);
   else if (arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_RC, AM_KC>), grid, dim3(256), 0, st, d);
