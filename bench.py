@@ -484,7 +484,30 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
                 allreduce_mean_(opt.flat_g, dist, world, force=force_dist, stage_bf16=stage16)
         g_opt.replay()
 
-    info = {"hip_graph": bool(use_graph), "backward_stages": n_stages,
+    def probe(reps=20):
+        """Milliseconds of each piece of the staged step run ALONE (device-synchronised between pieces, so nothing overlaps):
+        the stage graphs, the gradient exchange issued after each, the join, the optimiser graph."""
+        if not (use_graph and staged):
+            return None
+        names = [f"graph{i}" for i in range(n_stages)] + [f"reduce{i}" for i in range(n_stages)] + ["finish", "opt"]
+        acc = dict.fromkeys(names, 0.0)
+
+        def timed(name, fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            acc[name] += (time.perf_counter() - t0) * 1e3 / reps
+
+        for _ in range(reps):
+            for i, g in enumerate(graphs):
+                timed(f"graph{i}", g.replay)
+                timed(f"reduce{i}", lambda i=i: ob.begin_reduce(i))
+            timed("finish", ob.finish)
+            timed("opt", g_opt.replay)
+        return {k: round(v, 3) for k, v in acc.items()}
+
+    info = {"hip_graph": bool(use_graph), "backward_stages": n_stages, "_probe": probe,
             "grad_buckets_MB": [round(b / 1e6, 1) for b in ob.bucket_bytes()] if staged else
                                ([round(opt.numel * (2 if stage16 is not None else 4) / 1e6, 1)] if post_reduce else None),
             "grad_payload": payload if (staged or post_reduce) else None,
@@ -525,6 +548,7 @@ def bench_aasvc_single(dev, dtype, steps=20, warmup=3, cpu=True, batch=16):
     Fn.enable_side_streams(0, inline_batches=True)     # the schedule AASVCTrainer ships (trainers.AASVCTrainer.GRADIENT_WORK)
     wl = Workload("aasvc", dev, dtype, batch, 1, 0)
     step, info = build_step(wl, None, 1, False, False, "fp32", True)
+    info.pop("_probe", None)
     dt = time_steps(step, steps, warmup)
     ms = dt / steps * 1e3
     lb = wl.loss_buf.tolist()
@@ -722,6 +746,8 @@ def main():
     ap.add_argument("--roofline-only", action="store_true", help="only run the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--split-backward", action="store_true",
                     help="N = 1: run the staged backward pass of the data-parallel path without collectives")
+    ap.add_argument("--stage-times", action="store_true",
+                    help="staged runs: also report the milliseconds of every stage graph / gradient exchange / optimiser graph run alone")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code path (RCCL process group, staged backward, overlapped all-reduces) at world size 1")
     ap.add_argument("--grad-payload", default=None, choices=["fp32", "bf16"],
@@ -773,7 +799,10 @@ def main():
         args.grad_payload = "bf16" if args.workload == "aasvc" else "fp32"
     step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
                             warmup_eager=max(2, args.warmup if args.no_graph else 2))
+    probe = info.pop("_probe")
     dt = time_steps(step, args.steps, args.warmup, dist if dp else None, dev)
+    if args.stage_times:
+        info["stage_ms_alone"] = probe()
     if dp:
         ft = torch.tensor([wl.frames], device=dev)
         dist.all_reduce(ft)

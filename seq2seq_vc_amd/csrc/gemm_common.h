@@ -351,8 +351,8 @@ __device__ __forceinline__ void epilogue_flush_common(const s2svc_gemm_desc& d, 
 
 // the fp32 counterpart (the duration predictor's Linear layers and their gradients: bias, ReLU, fp32 residual, accumulation into
 // a gradient slot; no dropout / mask)
-inline bool epilogue_common32_ok(const s2svc_gemm_desc& d) {
-  if (d.c_dtype != S2S_F32 || d.nb0 * d.nb1 != 1 || d.splitk > 1 || d.alpha != 1.0f || d.c_pre || d.c_map) return false;
+inline bool epilogue_common32_ok(const s2svc_gemm_desc& d) {       // (split-K: the kernel stores raw partials, see epilogue_partials)
+  if (d.c_dtype != S2S_F32 || d.nb0 * d.nb1 != 1 || d.alpha != 1.0f || d.c_pre || d.c_map) return false;
   if (d.act != S2S_ACT_NONE && d.act != S2S_ACT_RELU) return false;
   if (d.emask || d.drop_p > 0.f) return false;
   if (d.N % 8 || d.ldc % 4 || ((uintptr_t)d.C) % 16) return false;
@@ -392,5 +392,22 @@ __device__ __forceinline__ void epilogue_flush_common32(const s2svc_gemm_desc& d
     }
     *reinterpret_cast<float4*>(c) = lo;
     *reinterpret_cast<float4*>(c + 4) = hi;
+  }
+}
+
+// split-K partial sums of a wave's tile -> workspace slice zs (the reduction kernel applies the epilogue), N % 8 == 0
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_partials(const s2svc_gemm_desc& d, int zs, int m_base, int n_base, const float* cs) {
+  const int lane = threadIdx.x & 63;
+  constexpr int LPR = WTN / 8, RPP = 64 / LPR;
+#pragma unroll 1
+  for (int p = 0; p < WTM / RPP; ++p) {
+    const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
+    const int m = m_base + row, n = n_base + col;
+    if (m >= d.M || n >= d.N) continue;
+    const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
+    float* w = d.ws + ((int64_t)zs * d.M + m) * d.N + n;
+    *reinterpret_cast<float4*>(w) = *reinterpret_cast<const float4*>(src);
+    *reinterpret_cast<float4*>(w + 4) = *reinterpret_cast<const float4*>(src + 4);
   }
 }

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const s2svc_gemm_desc d)
   float* cs = reinterpret_cast<float*>(smem_ab) + wave * (BM / 2) * (BN / 2);
   if (LEAN) {
     epilogue_stage<BM / 2, BN / 2>(acc, cs);
-    epilogue_flush_common32<BM / 2, BN / 2>(d, m0 + wm, n0 + wn, cs);
+    if (splitk > 1) epilogue_partials<BM / 2, BN / 2>(d, zs, m0 + wm, n0 + wn, cs);
+    else epilogue_flush_common32<BM / 2, BN / 2>(d, m0 + wm, n0 + wn, cs);
   } else {
     epilogue_tile<BM / 2, BN / 2>(d, z0, z1, m0 + wm, n0 + wn, acc, cs, splitk, zs, zb);
   }

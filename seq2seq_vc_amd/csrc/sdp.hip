@@ -81,12 +81,15 @@ __global__ __launch_bounds__(256) void expand_bwd_kernel(int64_t rows, int Tn, i
 // y[r,:] = valid(r) * (res[r,:] + dropout(act(LayerNorm(x[r,:]))))      (res / lens optional; rows in registers)
 // flow.py:148-190: each DDS layer is conv -> LN -> GELU -> 1x1 -> LN -> GELU -> dropout, then x + y, then * mask
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NV>
+// ACT >= 0: the activation is a compile-time constant (GELU, NV = 4: the duration predictor's 192 / 256 channels -- the
+// run-time switch expands tanh / erf / exp NV times: 11.9 -> ~3 KB of code for a kernel that runs ~120 times per AAS-VC step)
+template <typename T, int NV, int ACT = -1>
 __global__ __launch_bounds__(256) void ln_act_fwd_kernel(int rows, int D, int Tn, const T* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                         int act, const T* __restrict__ res, const int32_t* __restrict__ lens,
+                                                         int act_rt, const T* __restrict__ res, const int32_t* __restrict__ lens,
                                                          float p, const uint64_t* seed_base, uint64_t seed_off, T* __restrict__ y,
                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -125,13 +128,14 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(int rows, int D, int Tn
 
 // du = valid * dy * dropmask * act'(u)  (gradient at the LN output u; dgamma / dbeta are column reductions of it),
 // dx = rstd*(du*gamma - mean(du*gamma) - xhat*mean(du*gamma*xhat)),  dres = valid * dy
-template <typename T, int NV>
+template <typename T, int NV, int ACT = -1>
 __global__ __launch_bounds__(256) void ln_act_bwd_kernel(int rows, int D, int Tn, const T* __restrict__ dy, const T* __restrict__ x,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act_rt,
                                                          const int32_t* __restrict__ lens, float p, const uint64_t* seed_base,
                                                          uint64_t seed_off, T* __restrict__ du_out, T* __restrict__ dx,
                                                          T* __restrict__ dres) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -558,11 +562,20 @@ extern "C" int s2svc_ln_act_fwd(int dtype, int rows, int D, int Tn, const void* 
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4), block(256);
-#define S2S_LNACT(T, NV)                                                                                                     \
-  hipLaunchKernelGGL((ln_act_fwd_kernel<T, NV>), grid, block, 0, st, rows, D, Tn, (const T*)x, gamma, beta, eps, act, (const T*)res, \
+#define S2S_LNACT(T, ...)                                                                                                    \
+  hipLaunchKernelGGL((ln_act_fwd_kernel<T, __VA_ARGS__>), grid, block, 0, st, rows, D, Tn, (const T*)x, gamma, beta, eps, act, (const T*)res, \
                      lens, drop_p, seed_base, seed_off, (T*)y, mean, rstd)
-  if (dtype == S2S_F32) { if (D <= 512) S2S_LNACT(float, 8); else S2S_LNACT(float, 16); }
-  else { if (D <= 512) S2S_LNACT(bf16_t, 8); else S2S_LNACT(bf16_t, 16); }
+  if (dtype == S2S_F32) {
+    if (D <= 256 && act == S2S_ACT_GELU) S2S_LNACT(float, 4, S2S_ACT_GELU);
+    else if (D <= 512 && act == S2S_ACT_GELU) S2S_LNACT(float, 8, S2S_ACT_GELU);
+    else if (D <= 512) S2S_LNACT(float, 8);
+    else S2S_LNACT(float, 16);
+  } else {
+    if (D <= 256 && act == S2S_ACT_GELU) S2S_LNACT(bf16_t, 4, S2S_ACT_GELU);
+    else if (D <= 512 && act == S2S_ACT_GELU) S2S_LNACT(bf16_t, 8, S2S_ACT_GELU);
+    else if (D <= 512) S2S_LNACT(bf16_t, 8);
+    else S2S_LNACT(bf16_t, 16);
+  }
 #undef S2S_LNACT
   S2S_CHECK_LAUNCH("ln_act_fwd_kernel");
   return 0;
@@ -576,11 +589,20 @@ extern "C" int s2svc_ln_act_bwd(int dtype, int rows, int D, int Tn, const void* 
   if (rows == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4), block(256);
-#define S2S_LNACTB(T, NV)                                                                                                    \
-  hipLaunchKernelGGL((ln_act_bwd_kernel<T, NV>), grid, block, 0, st, rows, D, Tn, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, \
+#define S2S_LNACTB(T, ...)                                                                                                   \
+  hipLaunchKernelGGL((ln_act_bwd_kernel<T, __VA_ARGS__>), grid, block, 0, st, rows, D, Tn, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, \
                      act, lens, drop_p, seed_base, seed_off, (T*)du, (T*)dx, (T*)dres)
-  if (dtype == S2S_F32) { if (D <= 512) S2S_LNACTB(float, 8); else S2S_LNACTB(float, 16); }
-  else { if (D <= 512) S2S_LNACTB(bf16_t, 8); else S2S_LNACTB(bf16_t, 16); }
+  if (dtype == S2S_F32) {
+    if (D <= 256 && act == S2S_ACT_GELU) S2S_LNACTB(float, 4, S2S_ACT_GELU);
+    else if (D <= 512 && act == S2S_ACT_GELU) S2S_LNACTB(float, 8, S2S_ACT_GELU);
+    else if (D <= 512) S2S_LNACTB(float, 8);
+    else S2S_LNACTB(float, 16);
+  } else {
+    if (D <= 256 && act == S2S_ACT_GELU) S2S_LNACTB(bf16_t, 4, S2S_ACT_GELU);
+    else if (D <= 512 && act == S2S_ACT_GELU) S2S_LNACTB(bf16_t, 8, S2S_ACT_GELU);
+    else if (D <= 512) S2S_LNACTB(bf16_t, 8);
+    else S2S_LNACTB(bf16_t, 16);
+  }
 #undef S2S_LNACTB
   S2S_CHECK_LAUNCH("ln_act_bwd_kernel");
   return 0;

@@ -6,6 +6,8 @@ Hot-path differences that do not change results: the pairwise-distance tensor (B
 materialised; the alignment search, duration bincount and binarisation loss run on the GPU in one
 launch (no per-utterance device->host->device hop); masks are length vectors.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -163,6 +165,8 @@ class AASVC(nn.Module):
         # layers h.. ride with the first stage: enough main-stream work (3 of the 4 layers of vc2: 4.6 ms) beside the duration
         # branch's backward pass (5.5 ms of small dependent kernels on the auxiliary stream)
         h = max(1, len(dec) // 4)
+        if os.environ.get("S2SVC_AAS_DP_H"):
+            h = int(os.environ["S2SVC_AAS_DP_H"])         # tuning aid: decoder layers that get a stage of their own
         plan = [{"root": "loss:decoder", "branch_root": "loss:align", "modules": dec[h:] + tail + side}]
         for li in range(h, 0, -1):
             plan.append({"root": f"cut:decoder.{li}", "modules": [dec[li - 1]]})
