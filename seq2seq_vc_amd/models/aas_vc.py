@@ -153,20 +153,23 @@ class AASVC(nn.Module):
         module and the duration predictor); below the cut at the encoder output both meet and the encoder runs last.
         Stage 1 runs BOTH roots: first "align", rooted on the auxiliary stream (`branch_root`, ops.functional.branch_backward:
         the duration branch -- input projection + predictor -- ran there in the forward pass, so its whole backward pass runs
-        there; the main stream only gets the short alignment-module part), then "decoder" down to the cut in front of the lowest
-        decoder layer(s) on the calling stream, beside it; the stage ends with the join.  The remaining decoder layers follow one
-        per stage, the encoder last:
-        buckets 460 | 113 | 57 MB (fp32), only the last one travels with nothing to hide behind."""
+        there; the main stream only gets the short alignment-module part), then "decoder" down to the encoder output on the
+        calling stream, beside it; the stage ends with the join.  Stage 2 is the encoder.
+
+        Why two stages and not one per decoder layer (round 2's plan: 3 of 4 layers in stage 1, `S2SVC_AAS_DP_H=1`): the duration
+        branch's backward pass is ~350 small dependent launches that take 4.4 ms beside the decoder's GEMMs, a decoder layer's
+        backward pass 1.2 ms -- with fewer than four layers beside it the branch is the critical path of the stage (measured on
+        one MI355X, `bench.py --split-backward --stage-times`: stage graphs 10.97 + 2.04 ms with h = 0, 10.80 + 1.20 + 2.04 with
+        h = 1, 10.28 + 1.17 + 1.26 + 2.02 with h = 2: every layer moved out of stage 1 adds ~1 ms to the step).  Buckets with two
+        stages: 573 | 57 MB fp32 (287 | 28 MB with the default bf16 payload); the first travels behind the encoder's 2.0 ms,
+        which hides it at >= 250 GB/s of all-reduce bus bandwidth, the second is exposed (as the last bucket of any plan is)."""
         dec = list(self.decoder.encoders)
         tail = [m for m in (getattr(self.decoder, "after_norm", None), self.feat_out, self.postnet) if m is not None]
         side = [self.alignment_module, self.duration_predictor]
         if hasattr(self, "duration_predictor_projection"):
             side.append(self.duration_predictor_projection)
-        # layers h.. ride with the first stage: enough main-stream work (3 of the 4 layers of vc2: 4.6 ms) beside the duration
-        # branch's backward pass (5.5 ms of small dependent kernels on the auxiliary stream)
-        h = max(1, len(dec) // 4)
-        if os.environ.get("S2SVC_AAS_DP_H"):
-            h = int(os.environ["S2SVC_AAS_DP_H"])         # tuning aid: decoder layers that get a stage of their own
+        h = int(os.environ.get("S2SVC_AAS_DP_H", "0"))        # decoder layers that get a stage of their own (tuning aid)
+        h = max(0, min(h, len(dec) - 1))
         plan = [{"root": "loss:decoder", "branch_root": "loss:align", "modules": dec[h:] + tail + side}]
         for li in range(h, 0, -1):
             plan.append({"root": f"cut:decoder.{li}", "modules": [dec[li - 1]]})
