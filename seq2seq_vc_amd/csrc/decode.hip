@@ -294,7 +294,7 @@ template <> struct DFrag<float> {
 
 // NS = k-steps per wave held in registers (the whole K range of a wave is loaded up front: one exposed memory latency per
 // launch; the LayerNorm statistics come from those registers -- two-pass, partial sums through LDS across the four waves)
-template <typename T, int MT, int NS>
+template <typename T, int MT, int NS, bool LEAN = false>       // LEAN: see gemm_skinny_kernel
 __global__ __launch_bounds__(256) void ln_linear_skinny_kernel(const s2svc_gemm_desc d, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, T* __restrict__ y_out,
                                                                int64_t ldy) {
@@ -398,7 +398,10 @@ __global__ __launch_bounds__(256) void ln_linear_skinny_kernel(const s2svc_gemm_
       for (int r = 0; r < 4; ++r) {
         const float v = ((acc[i][r] + red[0][i][r * 64 + lane]) + red[1][i][r * 64 + lane]) + red[2][i][r * 64 + lane];
         const int m = i * 16 + lg * 4 + r, n = n0 + lr;
-        if (m < d.M && n < d.N) epilogue_store_f<true>(d, 0, 0, m, n, v);
+        if (m < d.M && n < d.N) {
+          if (LEAN) epilogue_store_lean<true>(d, m, n, v);
+          else epilogue_store_f<true>(d, 0, 0, m, n, v);
+        }
       }
   }
 }
@@ -407,6 +410,12 @@ template <typename T, int NS>
 void launch_ln_linear_ns(const s2svc_gemm_desc& d, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, hipStream_t st) {
   dim3 grid((d.N + 15) / 16), block(256);
   const int mt = (d.M + 15) / 16;
+  static const bool lean_on = !(getenv("S2SVC_GEMM_LEAN") && getenv("S2SVC_GEMM_LEAN")[0] == '0');
+  if (lean_on && mt <= 2 && epilogue_lean_ok(d)) {
+    if (mt == 1) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 1, NS, true>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+    else hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 2, NS, true>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+    return;
+  }
   if (mt == 1) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 1, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
   else if (mt == 2) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 2, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
   else if (mt == 3) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 3, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);

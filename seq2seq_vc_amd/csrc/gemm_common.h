@@ -411,3 +411,26 @@ __device__ __forceinline__ void epilogue_partials(const s2svc_gemm_desc& d, int 
     *reinterpret_cast<float4*>(w + 4) = *reinterpret_cast<const float4*>(src + 4);
   }
 }
+
+// element-wise form of the common epilogue for the skinny (decode) kernels, which inline their epilogue once per accumulator
+// element: bias, ReLU, [STAGED: dropout], residual, store in C's dtype -- the arithmetic of epilogue_store_f in that order
+inline bool epilogue_lean_ok(const s2svc_gemm_desc& d) {
+  return d.nb0 * d.nb1 == 1 && d.splitk <= 1 && d.alpha == 1.0f && !d.c_pre && !d.c_map && !d.accumulate && !d.emask &&
+         (d.act == S2S_ACT_NONE || d.act == S2S_ACT_RELU);
+}
+template <bool STAGED>
+__device__ __forceinline__ void epilogue_store_lean(const s2svc_gemm_desc& d, int m, int n, float v) {
+  if (d.bias) v += d.bias[n];
+  if (d.act == S2S_ACT_RELU) v = v > 0.f ? v : 0.f;
+  if (STAGED && d.drop_p > 0.f) {
+    const uint64_t seed = (d.seed_base ? *d.seed_base : 0ull) + d.seed_off;
+    v *= dropout_scale(seed, (uint64_t)((int64_t)m * d.N + n), d.drop_p, 1.f / (1.f - d.drop_p));
+  }
+  const int64_t co = (int64_t)m * d.ldc + n;
+  if (d.res) {
+    const int64_t ro = (int64_t)m * d.ldr + n;
+    v += d.c_dtype == S2S_F32 ? ((const float*)d.res)[ro] : bf2f(((const bf16_t*)d.res)[ro]);
+  }
+  if (d.c_dtype == S2S_F32) ((float*)d.C)[co] = v;
+  else ((bf16_t*)d.C)[co] = f2bf(v);
+}

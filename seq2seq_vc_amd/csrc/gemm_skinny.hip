@@ -7,6 +7,7 @@
 // straight from global memory into MFMA fragments (16-byte loads, 4 k-steps in flight), the four K-quarters
 // are summed through LDS, and the epilogue (alpha, bias, activation, residual, dtype) is the common one.
 // Pure weight streaming: bytes = N*K*s per launch, each read exactly once.
+#include <cstdlib>
 #include "gemm_common.h"
 
 namespace {
@@ -29,7 +30,9 @@ template <> struct Frag<float> {
   }
 };
 
-template <typename T, int MT>
+// LEAN: the common epilogue only (epilogue_store_lean; MT <= 2 -- the decode batches): 7-10 KB of the general epilogue's
+// activation expansions per inlined copy are code a launch-bound kernel pays for without running it
+template <typename T, int MT, bool LEAN = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const s2svc_gemm_desc d) {
   typedef Frag<T> F;
   typedef typename F::type frag_t;
@@ -89,7 +92,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const s2svc_gemm_desc 
       for (int r = 0; r < 4; ++r) {
         const float v = ((acc[i][r] + red[0][i][r * 64 + lane]) + red[1][i][r * 64 + lane]) + red[2][i][r * 64 + lane];
         const int m = i * 16 + lg * 4 + r, n = n0 + lr;
-        if (m < d.M && n < d.N) epilogue_store_f(d, 0, 0, m, n, v);
+        if (m < d.M && n < d.N) {
+          if (LEAN) epilogue_store_lean<false>(d, m, n, v);
+          else epilogue_store_f(d, 0, 0, m, n, v);
+        }
       }
   }
 }
@@ -98,6 +104,12 @@ template <typename T>
 void launch_skinny(const s2svc_gemm_desc& d, hipStream_t st) {
   dim3 grid((d.N + 15) / 16), block(256);
   const int mt = (d.M + 15) / 16;
+  static const bool lean_on = !(getenv("S2SVC_GEMM_LEAN") && getenv("S2SVC_GEMM_LEAN")[0] == '0');
+  if (lean_on && mt <= 2 && epilogue_lean_ok(d)) {
+    if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<T, 1, true>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<T, 2, true>), grid, block, 0, st, d);
+    return;
+  }
   if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<T, 1>), grid, block, 0, st, d);
   else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_kernel<T, 2>), grid, block, 0, st, d);
   else if (mt == 3) hipLaunchKernelGGL((gemm_skinny_kernel<T, 3>), grid, block, 0, st, d);
