@@ -39,9 +39,12 @@ class _ARSeq2Seq(nn.Module):
     def dp_plan(self):
         """Stages of the data-parallel backward pass (distributed.OverlappedBackward): the decoder side finishes first and its
         gradients (half of the parameters) travel while the encoder's backward pass -- below the cut at the encoder output --
-        runs; the encoder is cut twice more (in the middle of its layer stack and behind its input layer), so that the
-        bucket left over when the backward pass ends -- the only exchange nothing hides -- is the input layer's alone
-        (VTN vc1: 62.8 | 21.3 | 21.3 | 16.5 MB instead of 62.8 | 59.1).  One loss key: "loss"."""
+        runs; the encoder is cut once more behind its input layer, so that the bucket left over when the backward pass ends
+        -- the only exchange nothing hides -- is the input layer's alone (VTN vc1: 62.8 | 42.6 | 16.5 MB instead of 62.8 | 59.1).
+        A cut costs ~0.09 ms of the step (graph boundary + lost overlap; `bench.py --force-dist --stage-times`: stage graphs
+        2.83 + 0.32 + 0.32 + 0.59 ms with the layer stack cut in the middle as well -- round 2's plan -- against 3.78 ms for the
+        uncut backward pass), more than the middle cut saves: the 42.6 MB of the layer stack travel behind the input layer's
+        0.6 ms from 75 GB/s of all-reduce bandwidth on.  `S2SVC_VTN_DP_SPLIT=1` restores the middle cut.  One loss key: "loss"."""
         dec_side = [m for m in (self.decoder, self.feat_out, self.prob_out, self.postnet) if m is not None]
         enc = self.encoder
         layers = list(enc.encoders)
@@ -51,9 +54,13 @@ class _ARSeq2Seq(nn.Module):
         if h == 0 or not embed:
             return [{"root": "loss:loss", "modules": dec_side}, {"root": "cut:encoder_out", "modules": [enc]}]
         enc.cut_name = "encoder"            # names the cut points inside Encoder.forward / run_stack
+        if os.environ.get("S2SVC_VTN_DP_SPLIT", "0") == "1":
+            return [{"root": "loss:loss", "modules": dec_side},
+                    {"root": "cut:encoder_out", "modules": layers[h:] + tail},
+                    {"root": f"cut:encoder.{h}", "modules": layers[:h]},
+                    {"root": "cut:encoder.0", "modules": embed}]
         return [{"root": "loss:loss", "modules": dec_side},
-                {"root": "cut:encoder_out", "modules": layers[h:] + tail},
-                {"root": f"cut:encoder.{h}", "modules": layers[:h]},
+                {"root": "cut:encoder_out", "modules": layers + tail},
                 {"root": "cut:encoder.0", "modules": embed}]
 
     def _decoder_head(self, ys, olens):

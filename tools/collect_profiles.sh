@@ -17,8 +17,11 @@ prof() {  # prof <dir> <rocprofv3 args...> -- <command...>
 
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --workload aasvc > "$OUT/bench_aasvc.json" 2>> "$OUT/bench.err"
-python bench.py --force-dist --no-cpu-baseline > "$OUT/bench_force_dist.json" 2>> "$OUT/bench.err"
-python bench.py --workload aasvc --force-dist --no-cpu-baseline > "$OUT/bench_aasvc_force_dist.json" 2>> "$OUT/bench.err"
+python bench.py --force-dist --no-cpu-baseline --stage-times > "$OUT/bench_force_dist.json" 2>> "$OUT/bench.err"
+python bench.py --workload aasvc --force-dist --no-cpu-baseline --stage-times > "$OUT/bench_aasvc_force_dist.json" 2>> "$OUT/bench.err"
+python bench.py --workload aasvc --split-backward --no-cpu-baseline --no-extras --stage-times > "$OUT/bench_aasvc_split_backward.json" 2>> "$OUT/bench.err"
+python tools/bench_decode.py > "$OUT/bench_decode.json" 2>> "$OUT/bench.err"
+python tools/kernel_code_sizes.py > "$OUT/kernel_code_sizes.txt" 2>&1
 python tools/gemm_bench.py > "$OUT/gemm_bench.txt" 2>&1
 python tools/gemm8_bench.py > "$OUT/gemm8_bench.txt" 2>&1
 python tools/bench_frontend.py --cpu > "$OUT/bench_frontend.json" 2>> "$OUT/bench.err"
