@@ -99,7 +99,11 @@ def run_ar(name, dtype, model_cls_name):
     after, before, logits, ys_, labels_, olens_, (att_ws, ilens_ds, olens_in) = model(
         xs, t("in.ilens"), t("in.ys").to(DEV), t("in.labels").to(DEV), t("in.olens"))
     f32 = dtype == torch.float32
+    # bf16 on the tiny fixtures is a SMOKE CHECK (the path runs, shapes / integer outputs exact, values in the right place): atol 0.15 /
+    # mean-abs 0.05 say nothing about accuracy.  The bf16 evidence is elsewhere: fw_*_bf16 (rel-L2 1.5 / 4 / 6.5 % at full width),
+    # vtn_full_size_grads / aasvc_full_size_grads (per-layer gradients against the float64 oracle and against fp32), the 300-step curve.
     a = 1e-4 if f32 else 0.15
+    name = name if f32 else name + " (bf16 smoke check)"
     res = [cmp(f"{name}[{dtype}] after_outs", after, z["out.after"], a * (4 if f32 else 1), l1_tol=1e-4 if f32 else 0.05),
            cmp(f"{name}[{dtype}] before_outs", before, z["out.before"], a, l1_tol=1e-4 if f32 else 0.05),
            cmp(f"{name}[{dtype}] logits", logits, z["out.logits"], a),
@@ -346,7 +350,7 @@ def run_aas(name, dtype):
         # different duration vector are a different (equally valid) function value, so only the scalar
         # losses are compared in that case
         moved = (ret["ds"].cpu() - t("out.ds")).abs().sum().item() / 2
-        res.append((moved <= 0.1 * float(t("out.ds").sum()), f"{name}[{dtype}] alignment differs in {moved:.0f} frames (bf16 near-ties)"))
+        res.append((moved <= 0.1 * float(t("out.ds").sum()), f"{name}[{dtype}] (bf16 smoke check) alignment differs in {moved:.0f} frames (bf16 near-ties)"))
     l1 = L.L1Loss()(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
     fs = L.ForwardSumLoss()(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
     res.append(cmp(f"{name}[{dtype}] l1_loss", l1, z["loss.l1"], 2e-5 if f32 else 0.05))
