@@ -527,6 +527,15 @@ int s2svc_stft_logmel_fft(int B, int64_t Nmax, int Tmax, int n_fft, int hop, int
                           const int32_t* frames, const float* tables, const int32_t* mel_lo, const int32_t* mel_hi, const int32_t* mel_off, int melw_n, int mel_maxw,
                           float eps, float inv_log_base, const float* mean, const float* inv_scale, float* out, void* stream);
 
+/* n_fft = 1024 and triangular mel filters (every bin has at most two non-zero weights, in neighbouring filters; n_mels <= 128): the
+   512-point FFT as three passes of in-register 8-point DFTs, per-lane tables in registers, mel projection by segments.
+     tables: the packed table of s2svc_stft_logmel_fft (w_half | w_full | win are read);
+     seg_lo / seg_len [nmel]: the contiguous bin range whose HIGHEST filter is m;  wud [513][2]: weight of that filter and of the
+     one below it at bin k;  mel[m] = sum_{k in seg m} wud[k][0] |X[k]| + sum_{k in seg m+1} wud[k][1] |X[k]|. */
+int s2svc_stft_logmel_fft8(int B, int64_t Nmax, int Tmax, int hop, int nmel, const float* x, const int32_t* nlen, const int32_t* frames,
+                           const float* tables, const int32_t* seg_lo, const int32_t* seg_len, const float* wud, float eps,
+                           float inv_log_base, const float* mean, const float* inv_scale, float* out, void* stream);
+
 int s2svc_mel_log_batch(int B, int Tmax, int nb, int nmel, const float* z, const int32_t* frames, const float* melb,
                         const int32_t* lo, const int32_t* hi, float eps, float inv_log_base, const float* mean,
                         const float* inv_scale, float* out, void* stream);

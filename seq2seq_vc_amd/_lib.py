@@ -200,6 +200,8 @@ _SIGS = {
     "s2svc_reflect_pad_batch": [c_i32, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp],
     "s2svc_mel_log_batch": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_stft_logmel_fft_supported": [c_i32, c_i32, c_i32],
+    "s2svc_stft_logmel_fft8": [c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp,
+                               c_vp],
     "s2svc_stft_logmel_fft": [c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                               c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_ragged_to_padded": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],

@@ -237,6 +237,214 @@ int launch(const fft_args& a, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// n_fft = 1024, radix-8 (round 3, second version): the 512-point complex FFT as THREE passes of in-register 8-point DFTs
+// (512 = 8^3: a lane owns one butterfly per pass), so a frame makes two LDS round trips for the FFT instead of five, the first
+// pass reads nothing (its inputs are the lane's own 8 loaded points) and the last one writes nothing (its outputs Z[lane + 64 r]
+// stay in registers).  Every table a lane needs is the same for every frame it processes -- the window values of its points, the
+// twiddles of passes 2 and 3 (k = lane & 7 resp. lane), the unpack twiddles of its 8 bins -- and lives in registers (60), loaded
+// once per kernel.  Unpack: the partner Z[(512 - k) mod 512] of bin k = lane + 64 r sits in lane (64 - lane) mod 64, register
+// 7 - r: one exchange through LDS.  Mel projection by SEGMENTS: with triangular filters a bin has at most two non-zero weights, in
+// neighbouring filters; the bins between the peaks of filters s - 1 and s form segment s (n_mels + 1 segments), lane s walks its
+// range once and forms up[s] = sum w[s][k] mag[k] and dn[s] = sum w[s-1][k] mag[k]; mel[m] = up[m] + dn[m+1].  Trip counts are
+// half the filter widths (and the host checks the structure: anything else takes the generic kernel above).
+// LDS per workgroup: 8 waves x 2 buffers x 576 points (one pad point group per 64: pass 2 stores with a stride of 64 points) +
+// 4.1 KB of bin weights = 78 KB, two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------
+struct fft8_args {
+  int B, Tmax, hop, nmel;
+  int64_t Nmax;
+  const float* x;
+  const int32_t* nlen;
+  const int32_t* frames;
+  const float* tables;         // the packed table of the generic kernel: w_half [512] complex | w_full [513] complex | win [1024] | ...
+  const int32_t* seg_lo;       // [nmel + 1] first bin of segment s: the bins between the peaks of filters s - 1 and s
+  const int32_t* seg_len;      // [nmel + 1]
+  const float* wud;            // [513][2]: weight of filter s(k) (rising side) and of filter s(k) - 1 (falling side) at bin k
+  float eps, inv_log_base;
+  const float* mean;
+  const float* inv_scale;
+  float* out;
+};
+
+__device__ __forceinline__ int pad8(int d) { return d + ((d >> 6) << 3); }
+
+// y[m] = sum_r u[r] exp(-2 pi i r m / 8), in place
+__device__ __forceinline__ void dft8(c32 (&u)[8]) {
+  const float h = 0.70710678118654752f;
+  const c32 a0 = cadd(u[0], u[4]), a1 = csub(u[0], u[4]), a2 = cadd(u[2], u[6]), a3 = mul_mi(csub(u[2], u[6]));
+  const c32 b0 = cadd(u[1], u[5]), b1 = csub(u[1], u[5]), b2 = cadd(u[3], u[7]), b3 = mul_mi(csub(u[3], u[7]));
+  const c32 e0 = cadd(a0, a2), e2 = csub(a0, a2), e1 = cadd(a1, a3), e3 = csub(a1, a3);
+  const c32 o0 = cadd(b0, b2), o2 = mul_mi(csub(b0, b2));
+  c32 o1 = cadd(b1, b3), o3 = csub(b1, b3);
+  o1 = {h * (o1.x + o1.y), h * (o1.y - o1.x)};           // * (1 - i) / sqrt 2
+  o3 = {h * (o3.y - o3.x), -h * (o3.x + o3.y)};          // * (-1 - i) / sqrt 2
+  u[0] = cadd(e0, o0); u[4] = csub(e0, o0);
+  u[1] = cadd(e1, o1); u[5] = csub(e1, o1);
+  u[2] = cadd(e2, o2); u[6] = csub(e2, o2);
+  u[3] = cadd(e3, o3); u[7] = csub(e3, o3);
+}
+
+__global__ __launch_bounds__(64 * WAVES) void stft_logmel_fft8_kernel(fft8_args a) {
+  constexpr int N = 1024, H = 512, BUF = 576;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* wud = reinterpret_cast<float2*>(smem_raw);                          // [H + 1] (+ pad to 520)
+  const int nseg = a.nmel + 1;
+  int32_t* seg_lo = reinterpret_cast<int32_t*>(wud + 520);                    // [nmel + 1]
+  int32_t* seg_len = seg_lo + nseg;
+  float* updn = reinterpret_cast<float*>(seg_len + nseg);                    // [WAVES][2][nmel + 1]
+  const int updn_n = (2 * (a.nmel + 1) + 3) & ~3;
+  c32* bufs = reinterpret_cast<c32*>(updn + WAVES * updn_n);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  c32* bx = bufs + wave * 2 * BUF;
+  c32* by = bx + BUF;
+  float* up = updn + wave * updn_n;
+  float* dn = up + a.nmel + 1;
+  for (int i = threadIdx.x; i < H + 1; i += 64 * WAVES) wud[i] = reinterpret_cast<const float2*>(a.wud)[i];
+  for (int i = threadIdx.x; i < nseg; i += 64 * WAVES) { seg_lo[i] = a.seg_lo[i]; seg_len[i] = a.seg_len[i]; }
+  // per-lane constants
+  const c32* w_half = reinterpret_cast<const c32*>(a.tables);
+  const c32* w_full = w_half + H;
+  const float* wing = reinterpret_cast<const float*>(w_full + H + 1);
+  float2 wn[8];
+  c32 tw2[7], tw3[7], tf[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    wn[q] = *reinterpret_cast<const float2*>(wing + 2 * (lane + 64 * q));
+    tf[q] = w_full[lane + 64 * q];
+  }
+#pragma unroll
+  for (int r = 1; r < 8; ++r) {
+    tw2[r - 1] = w_half[((lane & 7) * r * 8) & (H - 1)];
+    tw3[r - 1] = w_half[(lane * r) & (H - 1)];
+  }
+  __syncthreads();
+  // segment rounds: trip count of a round = its longest segment (wave-uniform), found once
+  int seg_l[3] = {0, 0, 0}, seg_n[3] = {0, 0, 0}, maxlen[3] = {0, 0, 0};
+#pragma unroll
+  for (int rd = 0; rd < 3; ++rd) {
+    const int m = rd * 64 + lane;
+    if (m < nseg) { seg_l[rd] = seg_lo[m]; seg_n[rd] = seg_len[m]; }
+    int mx = seg_n[rd];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    maxlen[rd] = mx;
+  }
+  const int gpb = (a.Tmax + WAVES - 1) / WAVES;
+#pragma unroll 1
+  for (int g = blockIdx.x; g < a.B * gpb; g += gridDim.x) {
+    const int b = g / gpb, t = (g - b * gpb) * WAVES + wave;
+    if (t >= a.Tmax) continue;
+    float* orow = a.out + ((int64_t)b * a.Tmax + t) * a.nmel;
+    if (t >= a.frames[b]) {
+      for (int m = lane; m < a.nmel; m += 64) orow[m] = 0.f;
+      continue;
+    }
+    c32 u[8];
+    {
+      const float* xb = a.x + (int64_t)b * a.Nmax;
+      const int64_t n = a.nlen[b];
+      const int64_t s0 = (int64_t)t * a.hop - H;
+      const bool inner = s0 >= 0 && s0 + N <= n;
+      if (inner && ((reinterpret_cast<uintptr_t>(xb + s0) & 7) == 0)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float2 xv = *reinterpret_cast<const float2*>(xb + s0 + 2 * (lane + 64 * q));
+          u[q] = {xv.x * wn[q].x, xv.y * wn[q].y};
+        }
+      } else {
+        const int64_t period = n > 1 ? 2 * (n - 1) : 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            int64_t j = s0 + 2 * (lane + 64 * q) + e;
+            if (!inner) {
+              if (n > 1) {
+                j %= period;
+                if (j < 0) j += period;
+                if (j >= n) j = period - j;
+              } else {
+                j = 0;
+              }
+            }
+            v[e] = xb[j];
+          }
+          u[q] = {v[0] * wn[q].x, v[1] * wn[q].y};
+        }
+      }
+    }
+    // ---- pass 1 (p = 1): butterfly i = lane on the loaded points (i + 64 r); outputs dst[8 i + r]
+    dft8(u);
+    {
+      c32* d = bx + pad8(8 * lane);
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) *reinterpret_cast<float4*>(d + r) = make_float4(u[r].x, u[r].y, u[r + 1].x, u[r + 1].y);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 2 (p = 8): inputs src[lane + 64 r] * w^(k r), k = lane & 7; outputs dst[(lane - k) * 8 + k + 8 r]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = bx[pad8(lane + 64 * r)];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw2[r - 1]);
+    dft8(u);
+    {
+      const int j = ((lane >> 3) << 6) + (lane & 7);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) by[pad8(j + 8 * r)] = u[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- pass 3 (p = 64): inputs src[lane + 64 r] * w^(lane r); outputs Z[lane + 64 r] in registers
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = by[pad8(lane + 64 * r)];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw3[r - 1]);
+    dft8(u);
+    // ---- exchange: Z[(512 - k) mod 512] for k = lane + 64 r
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bx[pad8(lane + 64 * r)] = u[r];
+    __builtin_amdgcn_wave_barrier();
+    float* mag = reinterpret_cast<float*>(by);               // [H + 1]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = lane + 64 * r;
+      c32 zc = bx[pad8((H - k) & (H - 1))];
+      zc.y = -zc.y;
+      const c32 zk = u[r];
+      const c32 xe = {0.5f * (zk.x + zc.x), 0.5f * (zk.y + zc.y)};
+      const c32 xo = mul_mi({0.5f * (zk.x - zc.x), 0.5f * (zk.y - zc.y)});
+      const c32 wx = cmul(tf[r], xo);
+      const c32 a0 = cadd(xe, wx);
+      mag[k] = sqrtf(a0.x * a0.x + a0.y * a0.y);
+      if (k == 0) mag[H] = fabsf(zk.x - zk.y);              // X[N/2] = Re Z[0] - Im Z[0]
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- mel segments
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+      if (rd * 64 >= nseg) break;
+      float su = 0.f, sd = 0.f;
+      for (int it = 0; it < maxlen[rd]; ++it) {
+        const int k = seg_l[rd] + (it < seg_n[rd] ? it : 0);
+        const float2 w = wud[k];
+        const float mg = it < seg_n[rd] ? mag[k] : 0.f;
+        su += w.x * mg;
+        sd += w.y * mg;
+      }
+      const int m = rd * 64 + lane;
+      if (m < nseg) { up[m] = su; dn[m] = sd; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int m = lane; m < a.nmel; m += 64) {
+      float v = logf(fmaxf(a.eps, up[m] + dn[m + 1])) * a.inv_log_base;
+      if (a.mean) v = (v - a.mean[m]) * a.inv_scale[m];
+      orow[m] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 extern "C" int s2svc_stft_logmel_fft_supported(int n_fft, int nmel, int melw_n) {
@@ -258,4 +466,32 @@ extern "C" int s2svc_stft_logmel_fft(int B, int64_t Nmax, int Tmax, int n_fft, i
   if (n_fft == 512) return launch<9>(a, st);
   if (n_fft == 1024) return launch<10>(a, st);
   return launch<11>(a, st);
+}
+
+// n_fft = 1024 with triangular (two-filters-per-bin) mel weights: the radix-8 kernel.  seg_lo / seg_len (nmel) and wud (513 x 2)
+// come from the host (frontend._fft8_tables), `tables` is the packed table of s2svc_stft_logmel_fft.
+extern "C" int s2svc_stft_logmel_fft8(int B, int64_t Nmax, int Tmax, int hop, int nmel, const float* x, const int32_t* nlen,
+                                      const int32_t* frames, const float* tables, const int32_t* seg_lo, const int32_t* seg_len,
+                                      const float* wud, float eps, float inv_log_base, const float* mean, const float* inv_scale,
+                                      float* out, void* stream) {
+  S2S_REQUIRE(B > 0 && Nmax > 0 && Tmax > 0 && hop > 0 && nmel >= 1 && nmel <= 128 && x && nlen && frames && tables && seg_lo && seg_len && wud && out &&
+              ((uintptr_t)tables) % 16 == 0 && ((uintptr_t)wud) % 8 == 0, "stft_logmel_fft8: bad args (n_mels <= 128)");
+  fft8_args a;
+  a.B = B; a.Tmax = Tmax; a.hop = hop; a.nmel = nmel; a.Nmax = Nmax; a.x = x; a.nlen = nlen; a.frames = frames; a.tables = tables;
+  a.seg_lo = seg_lo; a.seg_len = seg_len; a.wud = wud; a.eps = eps; a.inv_log_base = inv_log_base; a.mean = mean; a.inv_scale = inv_scale;
+  a.out = out;
+  const int updn_n = (2 * (nmel + 1) + 3) & ~3;
+  const size_t lds = 520 * 8 + (size_t)(nmel + 1) * 8 + (size_t)WAVES * updn_n * 4 + (size_t)WAVES * 2 * 576 * 8;
+  static size_t attr_set = 0;
+  if (lds > 64 * 1024 && attr_set < lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_logmel_fft8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) { s2svc_set_error("stft_logmel_fft8: cannot raise the dynamic LDS limit"); return -2; }
+    attr_set = lds;
+  }
+  const int groups = B * ((Tmax + WAVES - 1) / WAVES);
+  const int per_cu = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;
+  const int resident = 256 * (per_cu < 4 ? per_cu : 4);
+  hipLaunchKernelGGL(stft_logmel_fft8_kernel, dim3(groups < resident ? groups : resident), dim3(64 * WAVES), lds, (hipStream_t)stream, a);
+  S2S_CHECK_LAUNCH("stft_logmel_fft8_kernel");
+  return 0;
 }

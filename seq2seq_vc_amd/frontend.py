@@ -78,7 +78,8 @@ def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, win_leng
                      fmin=None, fmax=None, eps=1e-10, log_base=10.0, mean=None, scale=None, impl=None):
     """audio: 1-D float tensor on the GPU (or numpy/CPU tensor, copied once) -> (frames, num_mels) fp32 tensor
     on the GPU.  `mean`/`scale` (num_mels,) fuse `(x - mean) / scale` into the log kernel.
-    impl: None / "fft" = the one-launch FFT kernel (csrc/stft_fft.hip) where it applies, "gemm" = the DFT-as-GEMM path (5 launches)."""
+    impl: None / "fft" = the one-launch FFT kernel (csrc/stft_fft.hip) where it applies (n_fft = 1024 with triangular mel filters: its
+    radix-8 form), "fft_radix4" = the generic radix-4 kernel for any of its sizes, "gemm" = the DFT-as-GEMM path (5 launches)."""
     if window != "hann":
         raise NotImplementedError("only the hann window of the recipes is supported")
     if not isinstance(audio, torch.Tensor):
@@ -101,7 +102,8 @@ def logmelfilterbank(audio, sampling_rate, fft_size=1024, hop_size=256, win_leng
             ist = (1.0 / torch.as_tensor(scale, dtype=torch.float32, device=dev)).contiguous()
         out = stft_logmel_fft_device(audio.view(1, n_), torch.tensor([n_], dtype=torch.int32, device=dev),
                                      torch.tensor([fr_], dtype=torch.int32, device=dev), fr_, sampling_rate, fft_size, hop_size, win_length,
-                                     num_mels, fmin, fmax, eps, 1.0 if log_base is None else 1.0 / math.log(log_base), mt, ist)
+                                     num_mels, fmin, fmax, eps, 1.0 if log_base is None else 1.0 / math.log(log_base), mt, ist,
+                                     radix8=False if impl == "fft_radix4" else None)
         return out[0]
     basis, melb = _tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
     n = audio.numel()
@@ -172,8 +174,60 @@ def _fft_tables(device, sr, n_fft, win_length, n_mels, fmin, fmax):
     return _FFT_TABLES[key]
 
 
+_FFT8_TABLES = {}
+
+
+def _fft8_tables(device, sr, n_fft, n_mels, fmin, fmax):
+    """Segment form of the mel basis for the radix-8 kernel (s2svc_stft_logmel_fft8), or None if the basis does not have the
+    structure it needs: every bin has at most two non-zero weights, in neighbouring filters (true for librosa's triangular
+    filters).  Segment s (0 .. n_mels) = the bins between the peaks of filters s - 1 and s: rising side of filter s (weight
+    wud[k][0]), falling side of filter s - 1 (wud[k][1]); mel[m] = sum over segment m of wud[:, 0] |X| + sum over segment m + 1 of
+    wud[:, 1] |X|.  -> (seg_lo, seg_len (n_mels + 1), wud (bins, 2))."""
+    key = (str(device), sr, n_fft, n_mels, fmin, fmax)
+    if key not in _FFT8_TABLES:
+        melb = np.asarray(mel_basis(sr, n_fft, n_mels, fmin, fmax), dtype=np.float32)
+        nb = melb.shape[1]
+        peak = melb.argmax(axis=1)
+        seg = np.full(nb, -1, np.int64)
+        wud = np.zeros((nb, 2), np.float32)
+        ok = n_fft == 1024 and n_mels <= 128
+        for k in range(nb):
+            nz = np.nonzero(melb[:, k])[0]
+            if len(nz) == 0 or not ok:
+                continue
+            if len(nz) > 2 or (len(nz) == 2 and nz[1] != nz[0] + 1):
+                ok = False
+            elif len(nz) == 2:
+                seg[k], wud[k, 0], wud[k, 1] = nz[1], melb[nz[1], k], melb[nz[0], k]
+            elif k <= peak[nz[0]]:                     # one filter only, on its rising side (or at its peak)
+                seg[k], wud[k, 0] = nz[0], melb[nz[0], k]
+            else:                                      # ... on its falling side: the segment above
+                seg[k], wud[k, 1] = nz[0] + 1, melb[nz[0], k]
+        seg_lo, seg_len = np.zeros(n_mels + 1, np.int32), np.zeros(n_mels + 1, np.int32)
+        if ok:
+            for m in range(n_mels + 1):
+                ks = np.nonzero(seg == m)[0]
+                if len(ks) == 0:
+                    continue
+                if ks[-1] - ks[0] + 1 != len(ks):
+                    ok = False
+                    break
+                seg_lo[m], seg_len[m] = ks[0], len(ks)
+        if ok:      # the identity the kernel relies on, checked on the tables themselves
+            rec = np.zeros_like(melb)
+            for m in range(n_mels):
+                sl = slice(seg_lo[m], seg_lo[m] + seg_len[m])
+                rec[m, sl] += wud[sl, 0]
+                sl = slice(seg_lo[m + 1], seg_lo[m + 1] + seg_len[m + 1])
+                rec[m, sl] += wud[sl, 1]
+            ok = bool(np.array_equal(rec, melb))
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        _FFT8_TABLES[key] = (t(seg_lo), t(seg_len), t(wud)) if ok else None
+    return _FFT8_TABLES[key]
+
+
 def stft_logmel_fft_device(x, nlen_d, frames_d, Tmax, sampling_rate, fft_size, hop_size, win_length, num_mels, fmin, fmax, eps, inv_log,
-                           mean_t=None, inv_scale_t=None, out=None):
+                           mean_t=None, inv_scale_t=None, out=None, radix8=None):
     """The ONE launch of the FFT front-end on device-resident arguments (x (B, Nmax) fp32, nlen_d / frames_d (B) int32):
     capturable, no host work beyond the launch.  -> (B, Tmax, num_mels) fp32."""
     dev = x.device
@@ -181,6 +235,16 @@ def stft_logmel_fft_device(x, nlen_d, frames_d, Tmax, sampling_rate, fft_size, h
     tables, lo, hi, off, melw_n, maxw = _fft_tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
     if out is None:
         out = torch.empty((B, Tmax, num_mels), dtype=torch.float32, device=dev)
+    seg = _fft8_tables(dev, sampling_rate, fft_size, num_mels, fmin, fmax) if (radix8 is None or radix8) else None
+    if radix8 and seg is None:
+        raise ValueError("stft_logmel_fft_device: the radix-8 kernel needs n_fft = 1024 and triangular mel filters (n_mels <= 128)")
+    if seg is not None:                 # n_fft = 1024: three in-register radix-8 passes, mel by segments (csrc/stft_fft.hip)
+        _lib.check(_lib.lib().s2svc_stft_logmel_fft8(B, Nmax, Tmax, hop_size, num_mels, x.data_ptr(), nlen_d.data_ptr(), frames_d.data_ptr(),
+                                                     tables.data_ptr(), seg[0].data_ptr(), seg[1].data_ptr(), seg[2].data_ptr(), eps, inv_log,
+                                                     None if mean_t is None else mean_t.data_ptr(),
+                                                     None if inv_scale_t is None else inv_scale_t.data_ptr(), out.data_ptr(), K.stream()),
+                   "stft_logmel_fft8")
+        return out
     _lib.check(_lib.lib().s2svc_stft_logmel_fft(B, Nmax, Tmax, fft_size, hop_size, num_mels, x.data_ptr(), nlen_d.data_ptr(),
                                                 frames_d.data_ptr(), tables.data_ptr(),
                                                 lo.data_ptr(), hi.data_ptr(), off.data_ptr(), melw_n, maxw, eps, inv_log,
@@ -231,15 +295,16 @@ def logmelfilterbank_batch(audios, sampling_rate, fft_size=1024, hop_size=256, w
         m_ptr, s_ptr = mean_t.data_ptr(), inv_scale_t.data_ptr()
     nlen_d = torch.tensor(nlen, dtype=torch.int32, device=dev)
     frames_d = torch.tensor(frames, dtype=torch.int32, device=dev)
-    if impl not in (None, "fft", "gemm"):
-        raise ValueError("impl must be None, 'fft' or 'gemm'")
+    if impl not in (None, "fft", "fft_radix4", "gemm"):
+        raise ValueError("impl must be None, 'fft', 'fft_radix4' or 'gemm'")
     wl = fft_size if win_length is None else win_length
     fft_ok = fft_size in (512, 1024, 2048) and wl <= fft_size
-    if impl == "fft" and not fft_ok:
+    if impl in ("fft", "fft_radix4") and not fft_ok:
         raise ValueError("the FFT front-end needs fft_size in {512, 1024, 2048} and win_length <= fft_size")
     if impl != "gemm" and fft_ok:
         out = stft_logmel_fft_device(x, nlen_d, frames_d, Tmax, sampling_rate, fft_size, hop_size, win_length, num_mels, fmin, fmax, eps,
-                                     inv_log, mean_t if mean is not None else None, inv_scale_t if mean is not None else None)
+                                     inv_log, mean_t if mean is not None else None, inv_scale_t if mean is not None else None,
+                                     radix8=False if impl == "fft_radix4" else None)
         return out, torch.tensor(frames, dtype=torch.long)
     basis, melb = _tables(dev, sampling_rate, fft_size, win_length, num_mels, fmin, fmax)
     key = (str(dev), sampling_rate, fft_size, num_mels, fmin, fmax)

@@ -424,6 +424,15 @@ def stft_logmel_batched_and_device_collaters():
         res.append((bool((mel[b, fb:] == 0).all()), f"utterance {b}: padding frames are exact zeros"))
     melg, _ = logmelfilterbank_batch(auds, 16000, impl="gemm", **kw)
     res.append(check("batched log-mel: FFT-in-LDS kernel vs the three-launch GEMM formulation", mel, melg, torch.float32, atol=1e-4, rtol=1e-5))
+    mel4, _ = logmelfilterbank_batch(auds, 16000, impl="fft_radix4", **kw)
+    res.append(check("batched log-mel: radix-8 kernel (default at n_fft 1024) vs the generic radix-4 kernel", mel, mel4, torch.float32, atol=2e-5, rtol=1e-5))
+    for sr, nm, f0, f1 in ((24000, 80, 80, 7600), (22050, 100, 0, None), (16000, 128, 50, 8000)):      # other mel layouts of the radix-8 kernel
+        kw3 = dict(fft_size=1024, hop_size=300, num_mels=nm, fmin=f0, fmax=f1)
+        m8, fr8 = logmelfilterbank_batch(auds[:3], sr, **kw3)
+        mgm, _ = logmelfilterbank_batch(auds[:3], sr, impl="gemm", **kw3)
+        res.append(check(f"radix-8 front-end vs GEMM formulation, sr {sr} n_mels {nm} fmin {f0} fmax {f1}", m8, mgm, torch.float32, atol=1e-4, rtol=1e-5))
+        ref = OL.logmelfilterbank(auds[1], sr, **kw3)
+        res.append(check(f"radix-8 front-end vs numpy restatement, sr {sr} n_mels {nm}", m8[1, : int(fr8[1])], torch.from_numpy(ref), torch.float32, atol=2e-4, rtol=1e-4))
     # the STFT of an independent third party (torch.stft on the GPU box) through the same mel basis
     for b in (1, 4):
         a64 = torch.from_numpy(auds[b].astype(np.float64))

@@ -58,19 +58,35 @@ def main():
     mean_t, isc_t = torch.zeros(80, device="cuda"), torch.ones(80, device="cuda")
     obuf = torch.empty((a.batch, max(fr), 80), dtype=torch.float32, device="cuda")
 
-    def kernel_only():
-        stft_logmel_fft_device(xd, nlen_d, frames_d, max(fr), sr, 1024, 256, None, 80, 80, 7600, 1e-10, 1.0 / np.log(10.0), mean_t, isc_t, out=obuf)
-    for _ in range(5):
-        kernel_only()
-    kiters = 200
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(kiters):
-        kernel_only()
-    e1.record()
-    torch.cuda.synchronize()
-    t_kernel = e0.elapsed_time(e1) * 1e-3 / kiters
+    def kernel_only(radix8=None):
+        stft_logmel_fft_device(xd, nlen_d, frames_d, max(fr), sr, 1024, 256, None, 80, 80, 7600, 1e-10, 1.0 / np.log(10.0), mean_t, isc_t, out=obuf,
+                               radix8=radix8)
+
+    def graph_time(fn, kiters=100):
+        """seconds per launch: `kiters` launches replayed from one hipGraph (a Python launch loop costs ~10 us of host time per
+        launch, as much as the kernel takes at small batches), HIP events around the replay"""
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(kiters):
+                    fn()
+            g.replay()
+            side.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            g.replay()
+            e1.record(side)
+            side.synchronize()
+        torch.cuda.current_stream().wait_stream(side)
+        return e0.elapsed_time(e1) * 1e-3 / kiters
+    kiters = 100
+    t_kernel = graph_time(kernel_only, kiters)
+    t_kernel_r4 = graph_time(lambda: kernel_only(False), kiters)
 
     out = {}
     for name, fn in (("batched", batched), ("per_utterance", looped), ("batched_gemm", gemm_batched)):
@@ -89,7 +105,8 @@ def main():
     tb, tg = out["batched"], out["batched_gemm"]
     res = {"metric": "STFT->log-mel front-end", "batch": a.batch, "audio_seconds_per_utt_max": a.seconds, "frames": frames,
            "fft_kernel": {"us_per_launch": t_kernel * 1e6, "us_per_utterance": t_kernel / a.batch * 1e6, "ns_per_frame": t_kernel / frames * 1e9,
-                          "timed": f"{kiters} back-to-back launches of s2svc_stft_logmel_fft, HIP events, device-resident arguments"},
+                          "timed": f"{kiters} launches of s2svc_stft_logmel_fft8 (radix-8 passes) replayed from one hipGraph, HIP events, device-resident arguments",
+                          "radix4_kernel_us_per_launch": t_kernel_r4 * 1e6, "radix4_ns_per_frame": t_kernel_r4 / frames * 1e9},
            "us_per_utterance_batched": tb / a.batch * 1e6, "us_per_utterance_batched_gemm": tg / a.batch * 1e6,
            "us_per_utterance_looped": out["per_utterance"] / a.batch * 1e6,
            "ns_per_frame_batched": tb / frames * 1e9,
