@@ -267,6 +267,29 @@ int s2svc_dwconv(int dtype, int B, int Tn, int C, int ks, int dil, const void* x
 int s2svc_dwconv_wgrad(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const void* dy, float* dw,
                        int accumulate, float* ws, int ws_chunks, void* stream);
 
+/* Core of the Conformer convolution module in training mode, bf16 (csrc/convmod.hip):
+   GLU -> depthwise conv -> BatchNorm1d batch statistics -> Swish between the two pointwise convolutions.
+   replaces: modules/conformer/convolution.py:68-75 (glu, depthwise_conv, norm, activation) and their autograd backward.
+     y2 (B,Tn,2C) bf16 = output of pointwise_conv1;  w (C,1,ks) fp32, bias (C) or NULL;  z (B,Tn,C) bf16 = depthwise_conv(glu(y2));
+     mean / rstd (C): batch statistics of z over all B*Tn frames (padded frames included, like the reference); run_mean / run_var /
+     num_batches: torch.nn.BatchNorm1d's running buffers (may be NULL);  ws >= B * ceil(Tn / 64) * 2 * C floats.
+   s2svc_convmod_supported: C % 64 == 0 and ks in {7, 15, 31}; everything else takes the separate kernels. */
+int s2svc_convmod_supported(int C, int ks);
+int s2svc_convmod_fwd(int B, int Tn, int C, int ks, const void* y2, const float* w, const float* bias, void* z, float eps,
+                      float momentum, float* mean, float* rstd, float* run_mean, float* run_var, int64_t* num_batches, float* ws,
+                      void* stream);
+/* out = swish((z - mean) * rstd * gamma + beta), bf16, C % 64 == 0 */
+int s2svc_bn_swish_apply(int64_t rows, int C, const void* z, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, void* out, void* stream);
+/* da (B,Tn,C) bf16 = gradient of the Swish output -> dy2 (B,Tn,2C) bf16 = gradient of y2;  sdy / sdyx (C) = gradients of the
+   BatchNorm bias / weight (also ADDED to dbeta_acc / dgamma_acc when given);  ws_w receives the per-tile partial sums of the
+   depthwise weight and bias gradients, [B * ceil(Tn / 64)][C][ks + 1] (s2svc_convmod_wgrad_final sums them);
+   ws_stats >= ceil(B * Tn / 64) * 2 * C floats. */
+int s2svc_convmod_bwd(int B, int Tn, int C, int ks, const void* da, const void* z, const void* y2, const float* w, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, void* dy2, float* sdy, float* sdyx,
+                      float* dgamma_acc, float* dbeta_acc, float* ws_stats, float* ws_w, void* stream);
+int s2svc_convmod_wgrad_final(int C, int ks, int chunks, const float* ws_w, float* dw, float* db, int accumulate, void* stream);
+
 /* ========================================================================================== */
 /* AAS alignment: pairwise -L2 + masked log-softmax, monotonic alignment search, Gaussian     */
 /* upsampling weights.                                                                         */

@@ -145,6 +145,12 @@ _SIGS = {
     "s2svc_interp_nearest_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_dwconv": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_dwconv_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
+    "s2svc_convmod_supported": [c_i32, c_i32],
+    "s2svc_convmod_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_bn_swish_apply": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_convmod_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                          c_vp, c_vp],
+    "s2svc_convmod_wgrad_final": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_pairwise_l2_logsoftmax": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_pairwise_l2_bwd_g": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_rowscale": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],

@@ -28,6 +28,11 @@ class ConvolutionModule(nn.Module):
     def forward(self, x):
         c1, c2, bn = self.pointwise_conv1, self.pointwise_conv2, self.norm
         y = Fn.linear(x, c1.weight, c1.bias)           # 1x1 conv == Linear on channel-last ((N,K,1) weight accepted)
+        if FA.convmod_core_ok(y, self.depthwise_conv.weight, self.training, self.activation):
+            # bf16 training: GLU -> depthwise conv -> batch statistics -> BatchNorm + Swish on the fused kernels (csrc/convmod.hip)
+            y = FA.convmod_core(y, self.depthwise_conv.weight, self.depthwise_conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
+            return Fn.linear(y, c2.weight, c2.bias)
         y = Fn.glu(y)
         y = FA.dwconv1d(y, self.depthwise_conv.weight, self.depthwise_conv.bias)
         y = Fn.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, self.training,

@@ -47,6 +47,66 @@ def dwconv1d(x, weight, bias=None, dilation=1):
     return _DwConv.apply(x, weight, bias, dilation)
 
 
+class _ConvModCore(Function):
+    """GLU -> depthwise conv -> BatchNorm1d (batch statistics) -> Swish of the Conformer convolution module as ONE autograd node on the
+    fused bf16 kernels of csrc/convmod.hip (convolution.py:68-75): 3 launches forward, 3 backward (+ 1 off the chain), where the
+    separate ops take 5 and 8; only y2 and z are kept for the backward pass (g = glu(y2) and the pre-activation are recomputed)."""
+
+    @staticmethod
+    def forward(ctx, y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps, momentum):
+        y2 = _c(y2)
+        ks = dw_weight.shape[-1]
+        z, mean, rstd = KA.convmod_fwd(y2, dw_weight.detach(), None if dw_bias is None else dw_bias.detach(), ks, eps, momentum,
+                                       run_mean, run_var, num_batches)
+        out = KA.bn_swish_apply(z, mean, rstd, gamma.detach(), beta.detach())
+        ctx.params = (dw_weight, dw_bias, gamma, beta)
+        ctx.ks = ks
+        ctx.save_for_backward(y2, z, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, da):
+        y2, z, mean, rstd = ctx.saved_tensors
+        dw_weight, dw_bias, gamma, beta = ctx.params
+        ks = ctx.ks
+        C = z.shape[-1]
+        g_slot = getattr(gamma, "_s2s_grad", None) if gamma.requires_grad else None
+        b_slot = getattr(beta, "_s2s_grad", None) if beta.requires_grad else None
+        both = g_slot is not None and b_slot is not None
+        dy2, sdy, sdyx, (ws_w, chunks) = KA.convmod_bwd(_c(da), z, y2, dw_weight.detach(), mean, rstd, gamma.detach(), beta.detach(), ks,
+                                                        g_slot.view(-1) if both else None, b_slot.view(-1) if both else None)
+        dgamma = dbeta = None
+        if not both:
+            dgamma = _emit_vgrad(gamma, sdyx) if gamma.requires_grad else None
+            dbeta = _emit_vgrad(beta, sdy) if beta.requires_grad else None
+        dw = db = None
+        need_w = dw_weight.requires_grad
+        need_b = dw_bias is not None and dw_bias.requires_grad
+        if need_w or need_b:
+            w_slot = getattr(dw_weight, "_s2s_grad", None) if need_w else None
+            bi_slot = getattr(dw_bias, "_s2s_grad", None) if need_b else None
+            if (not need_w or (w_slot is not None and w_slot.is_contiguous())) and (not need_b or bi_slot is not None):
+                # straight into the flat gradient buffer, off the data-gradient chain
+                _side_run(lambda: KA.convmod_wgrad_final(ws_w, chunks, C, ks, w_slot if need_w else None,
+                                                         bi_slot.view(-1) if need_b else None, accumulate=True), keep=(ws_w,))
+            else:
+                dwv, dbv = KA.convmod_wgrad_final(ws_w, chunks, C, ks)
+                dw = _emit_vgrad(dw_weight, dwv) if need_w else None
+                db = _emit_vgrad(dw_bias, dbv) if need_b else None
+        return dy2, dw, db, dgamma, dbeta, None, None, None, None, None
+
+
+def convmod_core(y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps=1e-5, momentum=0.1):
+    """swish(batch_norm(dwconv1d(glu(y2)))) in training mode on the fused kernels; use convmod_core_ok() first."""
+    return _ConvModCore.apply(y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps, momentum)
+
+
+def convmod_core_ok(y2, dw_weight, training, activation):
+    import os
+    return (training and activation == "swish" and y2.dtype == torch.bfloat16 and os.environ.get("S2SVC_NO_CONVMOD", "0") != "1"
+            and dw_weight.shape[1] == 1 and KA.convmod_supported(dw_weight.shape[0], dw_weight.shape[-1]))
+
+
 class _PairwiseLogSoftmax(Function):
     """log_p_attn[b,i,:] = log_softmax_j(-||feats[b,i]-text[b,j]||_2), padded text columns -inf
     (modules/alignments.py:51-59)."""

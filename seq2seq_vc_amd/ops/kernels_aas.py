@@ -28,6 +28,59 @@ def dwconv_wgrad(x, dy, ks, dil=1, out=None):
     return dw
 
 
+def convmod_supported(C, ks):
+    return bool(_lib.lib().s2svc_convmod_supported(C, ks))
+
+
+def convmod_fwd(y2, w, bias, ks, eps, momentum, run_mean=None, run_var=None, num_batches=None):
+    """Conformer convolution module core, bf16 training: y2 (B,T,2C) -> z = dwconv(glu(y2)) (B,T,C) and its batch statistics
+    (mean, rstd) in two launches (csrc/convmod.hip)."""
+    B, T, C2 = y2.shape
+    C = C2 // 2
+    z = torch.empty((B, T, C), dtype=y2.dtype, device=y2.device)
+    mean = torch.empty(C, dtype=torch.float32, device=y2.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=y2.device)
+    ws = torch.empty(B * ((T + 63) // 64) * 2 * C, dtype=torch.float32, device=y2.device)
+    _lib.check(_lib.lib().s2svc_convmod_fwd(B, T, C, ks, ptr(y2), ptr(w), ptr(bias), ptr(z), eps, momentum, ptr(mean), ptr(rstd),
+                                            ptr(run_mean), ptr(run_var), ptr(num_batches), ptr(ws), stream()), "convmod_fwd")
+    return z, mean, rstd
+
+
+def bn_swish_apply(z, mean, rstd, gamma, beta):
+    C = z.shape[-1]
+    out = torch.empty_like(z)
+    _lib.check(_lib.lib().s2svc_bn_swish_apply(z.numel() // C, C, ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(out),
+                                               stream()), "bn_swish_apply")
+    return out
+
+
+def convmod_bwd(da, z, y2, w, mean, rstd, gamma, beta, ks, dgamma_acc=None, dbeta_acc=None):
+    """-> dy2 (B,T,2C), sdy, sdyx (C), (ws_w, chunks): the per-tile partial depthwise weight / bias gradients for
+    convmod_wgrad_final.  dgamma_acc / dbeta_acc: fp32 (C) gradient slots to ADD the BatchNorm parameter gradients to."""
+    B, T, C = z.shape
+    dy2 = torch.empty_like(y2)
+    sdy = torch.empty(C, dtype=torch.float32, device=z.device)
+    sdyx = torch.empty(C, dtype=torch.float32, device=z.device)
+    chunks = B * ((T + 63) // 64)
+    ws_stats = torch.empty(((B * T + 63) // 64) * 2 * C, dtype=torch.float32, device=z.device)
+    ws_w = torch.empty(chunks * C * (ks + 1), dtype=torch.float32, device=z.device)
+    _lib.check(_lib.lib().s2svc_convmod_bwd(B, T, C, ks, ptr(da), ptr(z), ptr(y2), ptr(w), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                                            ptr(dy2), ptr(sdy), ptr(sdyx), ptr(dgamma_acc), ptr(dbeta_acc), ptr(ws_stats), ptr(ws_w),
+                                            stream()), "convmod_bwd")
+    return dy2, sdy, sdyx, (ws_w, chunks)
+
+
+def convmod_wgrad_final(ws_w, chunks, C, ks, dw=None, db=None, accumulate=False):
+    """Sum the per-tile partials into dw (C,1,ks) / db (C) fp32 (allocated unless given; accumulate=True adds to them)."""
+    if dw is None:
+        dw = torch.empty((C, 1, ks), dtype=torch.float32, device=ws_w.device)
+    if db is None:
+        db = torch.empty(C, dtype=torch.float32, device=ws_w.device)
+    _lib.check(_lib.lib().s2svc_convmod_wgrad_final(C, ks, chunks, ptr(ws_w), ptr(dw), ptr(db), 1 if accumulate else 0, stream()),
+               "convmod_wgrad_final")
+    return dw, db
+
+
 def pairwise_l2_logsoftmax(feats, text, text_lens_i32):
     B, Tf, A = feats.shape
     Tx = text.shape[1]

@@ -47,6 +47,73 @@ def depthwise_conv(dtype):
     return res
 
 
+def _rel_l2(got, ref):
+    got, ref = got.float().cpu().reshape(-1), ref.float().cpu().reshape(-1)
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+@case
+def conformer_conv_module_fused():
+    """csrc/convmod.hip (GLU -> depthwise conv -> batch statistics -> BatchNorm + Swish, forward and backward, bf16) against torch in
+    fp32 on the same bf16 inputs, and against the separate kernels it replaces (glu, dwconv, bn_stats, bn_apply, ...)."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    res = []
+    bf = torch.bfloat16
+    for (B, T, C, ks, seed) in [(3, 100, 128, 15, 1), (2, 64, 64, 7, 2), (1, 5, 64, 15, 3), (2, 131, 192, 31, 4), (16, 256, 384, 15, 5),
+                                (4, 256, 1536, 15, 6)]:
+        y2 = rnd(B, T, 2 * C, seed=seed, dtype=bf)
+        w = rnd(C, 1, ks, seed=seed + 1, scale=0.3)
+        b = rnd(C, seed=seed + 2, scale=0.2)
+        gamma = 1.0 + rnd(C, seed=seed + 3, scale=0.2)
+        beta = rnd(C, seed=seed + 4, scale=0.2)
+        da = rnd(B, T, C, seed=seed + 5, dtype=bf)
+        # torch reference, fp32 arithmetic on the bf16 inputs (z is rounded to bf16 where the kernels store it)
+        yr = y2.float().clone().requires_grad_(True)
+        wr, br, gr, ber = (t.clone().requires_grad_(True) for t in (w, b, gamma, beta))
+        g = F.glu(yr, dim=-1)
+        zr = F.conv1d(g.transpose(1, 2), wr, br, padding=(ks - 1) // 2, groups=C)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        pre = F.batch_norm(zr, rm, rv, gr, ber, training=True, momentum=0.1, eps=1e-5)
+        outr = (pre * torch.sigmoid(pre)).transpose(1, 2)
+        outr.backward(da.float())
+
+        def run(fused):
+            os.environ["S2SVC_NO_CONVMOD"] = "0" if fused else "1"
+            ps = [t.clone().requires_grad_(True) for t in (w, b, gamma, beta)]
+            yy = y2.clone().requires_grad_(True)
+            m, v, nb = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+            if fused:
+                assert FA.convmod_core_ok(yy, ps[0], True, "swish")
+                out = FA.convmod_core(yy, ps[0], ps[1], ps[2], ps[3], m, v, nb, 1e-5, 0.1)
+            else:
+                h = FA.dwconv1d(Fn.glu(yy), ps[0], ps[1])
+                out = Fn.batch_norm_act(h, ps[2], ps[3], m, v, nb, True, "swish", 0.0, 1e-5, 0.1)
+            out.backward(da)
+            return out, yy.grad, [q.grad for q in ps], (m, v, nb)
+        try:
+            of, dyf, gf, (mf, vf, nbf) = run(True)
+            om, dym, gm, (mm, vm, _) = run(False)
+        finally:
+            os.environ.pop("S2SVC_NO_CONVMOD", None)
+        tag = f"convmod B{B} T{T} C{C} k{ks}"
+        refs = [("out", of, om, outr, 1e-2), ("dy2", dyf, dym, yr.grad, 2e-2), ("d dw_weight", gf[0], gm[0], wr.grad, 2e-2),
+                ("d dw_bias", gf[1], gm[1], br.grad, 2e-2), ("d gamma", gf[2], gm[2], gr.grad, 2e-2), ("d beta", gf[3], gm[3], ber.grad, 2e-2)]
+        for name, got, mod, ref, bound in refs:
+            if name == "d dw_bias":       # a bias in front of a BatchNorm has gradient 0: all three values are rounding noise
+                a, am = float(got.abs().max()), float(mod.abs().max())
+                res.append((a <= max(am, 1e-2), f"{tag} {name}: |.|max {a:.2e} (exact value 0; separate kernels {am:.2e}, torch fp32 "
+                                                  f"{float(ref.abs().max()):.2e})"))
+                continue
+            e, em = _rel_l2(got.detach(), ref), _rel_l2(mod.detach(), ref)
+            # the fused path keeps g and the pre-activation in fp32: it must be at least as close to fp32 as the separate kernels (+ slack)
+            ok = e <= bound and e <= 1.5 * em + 1e-3
+            res.append((ok, f"{tag} {name}: rel-L2 vs fp32 torch {e:.2e} (separate kernels {em:.2e}, bound {bound:.0e})"))
+        res.append(check(f"{tag} running_mean", mf, rm, torch.float32, atol=2e-3, rtol=1e-2))
+        res.append(check(f"{tag} running_var", vf, rv, torch.float32, atol=2e-3, rtol=1e-2))
+        res.append((int(nbf) == 1, f"{tag} num_batches_tracked = {int(nbf)}"))
+    return res
+
+
 @case
 @both_dtypes
 def pairwise_distance_logsoftmax(dtype):
