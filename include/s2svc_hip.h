@@ -372,6 +372,26 @@ int s2svc_attn_fused_bwd(int B, int H, int T1, int T2, int dk, const void* q, in
                          int64_t lddv, int64_t dvbs, void* stream);
 
 /* ========================================================================================== */
+/* Relative-position self-attention without the (B, H, T, 2T-1) position term in memory        */
+/* (csrc/relattn.hip): bf16, T <= 256, d_k % 32 == 0, the "new" rel_shift (pos has 2T-1 rows). */
+/* replaces: modules/transformer/attention.py:237-260 (rel_shift), :283-303 (q + pos_bias_u/v, */
+/* matrix_ac, matrix_bd, the shift, the scaling) and :63-93 (mask, softmax, mask) forward; the */
+/* backward of the same up to the gradient of the scaled scores and of matrix_bd.              */
+/*   fwd: attn / pdrop (B, H, T, ld) bf16 (pdrop = the dropped copy, NULL when drop_p == 0),   */
+/*        qu = q + pos_bias_u, qv = q + pos_bias_v (B, T, H*dk) for the backward GEMMs.        */
+/*   bwd: ds (B, H, T, ld) = d loss / d (scaled scores) * scale, dbd (B, H, T, Lq) = the same   */
+/*        values at column T-1-i+j of row i, zero elsewhere (complete rows).                   */
+/* ========================================================================================== */
+int s2svc_relattn_supported(int dtype, int T, int dk, int rel_mode);
+int s2svc_relattn_fwd(int B, int H, int T, int dk, const void* q, int64_t ldq, int64_t qbs, const void* k, int64_t ldk, int64_t kbs,
+                      const void* pos, int64_t ldp, int L, const float* u, const float* v, const int32_t* klen, float scale,
+                      float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* attn, void* pdrop, int ld, void* qu, void* qv,
+                      void* stream);
+int s2svc_relattn_bwd(int B, int H, int T, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv, int64_t vbs,
+                      const void* attn, const void* dattn, int ld, float scale, float drop_p, const uint64_t* seed_base,
+                      uint64_t seed_off, void* ds, void* dbd, int Lq, void* stream);
+
+/* ========================================================================================== */
 /* Fused attention SUB-LAYERS (csrc/attn_block.hip), bf16, T1, T2 <= 64, (D, d_k) in          */
 /* {(256,64),(384,96)}: one workgroup per (utterance, head), ONE launch for                    */
 /*   fwd: [LayerNorm(x)] -> this head's Q (K, V) projection -> mask, softmax, dropout, P.V     */

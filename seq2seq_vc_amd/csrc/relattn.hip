@@ -1,0 +1,428 @@
+// Relative-position self-attention (Transformer-XL style, the "new" rel_shift of ESPnet) without the (B, H, T, 2T-1) position
+// term in memory -- bf16, T <= 256, d_k a multiple of 32.
+//     score[i, j] = ((q_i + pos_bias_u) . k_j + (q_i + pos_bias_v) . pos_{T-1-i+j}) / sqrt(d_k)
+// reference: modules/transformer/attention.py:237-260 (rel_shift), :262-305 (RelPositionMultiHeadedAttention.forward).
+// The separate kernels run this as: add_head_bias -> GEMM (ac, fp32 (B,H,T,T)) -> GEMM (bd, fp32 (B,H,T,2T-1)) -> softmax
+// kernel with the shift as index arithmetic (forward), and GEMM (dP) -> zero fill -> softmax backward with a scatter into dbd
+// (backward).  Here:
+//   relattn_fwd_kernel   q, k, pos, u, v -> attention map (+ its dropped copy) and qu = q + u, qv = q + v for the backward GEMMs
+//   relattn_bwd_kernel   dctx, v, attention map -> dS (gradient of the scaled scores) and dbd (the same values at their
+//                        un-shifted positions, complete zero-padded rows: the operand of the d qv / d pos GEMMs)
+// One workgroup per (utterance, head, block of 64 query rows); wave w owns the key columns 64 w .. 64 w + 63 of all 64 rows
+// (16 accumulator tiles of 16 x 16).  The position term of a row block needs the 319 position rows c0 .. c0 + 318,
+// c0 = T - 64 - i0; wave w multiplies its rows with 8 of the 20 tiles of that window and the shift
+//     bd[il][63 - il + j]      (il = row inside the block)
+// is, in the MFMA accumulator layout (row = 4 lg + r, column = lr of a 16 x 16 tile), a ROTATION of the 16 columns inside a
+// lane group by 15 - 4 lg - r, with the wrapped lanes taking the next tile: one ds_bpermute per accumulator register, no trip
+// through memory.  Operands are streamed through LDS in 32-wide slices of d_k (global loads of slice s + 1 in flight while
+// slice s is multiplied); the probabilities leave through an LDS image of the tile in 16-byte stores.
+// Dropout masks are functions of (seed, element index of the attention map), the same function the separate kernels use.
+#include "common.h"
+#include "../../include/s2svc_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+namespace {
+
+constexpr int RP = 40;        // LDS row pitch (elements) of a 32-wide operand slice: 80-byte rows
+constexpr int SP = 264;       // pitch of the [64][256] bf16 staging tiles
+constexpr float NEG = -3.4028234663852886e38f;
+
+__device__ __forceinline__ float grp16_max(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float grp16_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct ra_fwd_args {
+  int H, T, dk, L, ld;
+  const bf16_t* q; int64_t ldq, qbs;
+  const bf16_t* k; int64_t ldk, kbs;
+  const bf16_t* pos; int64_t ldp;
+  const float* u; const float* v;
+  const int32_t* klen;
+  float scale, p;
+  const uint64_t* seed_base; uint64_t seed_off;
+  bf16_t* attn; bf16_t* pdrop;
+  bf16_t* qu; bf16_t* qv;       // (B, T, H * dk) contiguous
+};
+
+__global__ __launch_bounds__(256) void relattn_fwd_kernel(const ra_fwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem);      // [256][RP] keys
+  bf16_t* Pc = Kc + 256 * RP;                        // [320][RP] position window
+  bf16_t* QU = Pc + 320 * RP;                        // [64][RP]
+  bf16_t* QV = QU + 64 * RP;                         // [64][RP]
+  const int T = a.T, dk = a.dk, H = a.H;
+  const int i0 = blockIdx.x * 64;
+  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lg = lane >> 4;
+  const int c0 = T - 64 - i0;
+  const int D = H * dk;
+  const bf16_t* kg = a.k + (int64_t)b * a.kbs + h * dk;
+  const bf16_t* qg = a.q + (int64_t)b * a.qbs + h * dk;
+  const bf16_t* pg = a.pos + h * dk;
+  const int nsteps = dk / 32;
+  const int qrow = t >> 2, c4 = t & 3;
+
+  struct stage_regs { uint4 rk[4], rp[5], rq; float bu[8], bv[8]; };
+  auto issue = [&](int s, stage_regs& R) {
+    const int d0 = s * 32 + c4 * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (t + 256 * i) >> 2;
+      R.rk[i] = make_uint4(0, 0, 0, 0);
+      if (row < T) R.rk[i] = *reinterpret_cast<const uint4*>(kg + (int64_t)row * a.ldk + d0);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = c0 + ((t + 256 * i) >> 2);
+      R.rp[i] = make_uint4(0, 0, 0, 0);
+      if (c >= 0 && c < a.L) R.rp[i] = *reinterpret_cast<const uint4*>(pg + (int64_t)c * a.ldp + d0);
+    }
+    R.rq = make_uint4(0, 0, 0, 0);
+    if (i0 + qrow < T) R.rq = *reinterpret_cast<const uint4*>(qg + (int64_t)(i0 + qrow) * a.ldq + d0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { R.bu[e] = a.u[h * dk + d0 + e]; R.bv[e] = a.v[h * dk + d0 + e]; }
+  };
+  auto put = [&](int s, const stage_regs& R) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Kc + ((t + 256 * i) >> 2) * RP + c4 * 8) = R.rk[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<uint4*>(Pc + ((t + 256 * i) >> 2) * RP + c4 * 8) = R.rp[i];
+    float f[8], fu[8], fv[8];
+    unpack_bf16x8(R.rq, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { fu[e] = f[e] + R.bu[e]; fv[e] = f[e] + R.bv[e]; }
+    const uint4 vu = pack_bf16x8(fu), vv = pack_bf16x8(fv);
+    *reinterpret_cast<uint4*>(QU + qrow * RP + c4 * 8) = vu;
+    *reinterpret_cast<uint4*>(QV + qrow * RP + c4 * 8) = vv;
+    if (i0 + qrow < T) {
+      const int64_t o = ((int64_t)b * T + i0 + qrow) * D + h * dk + s * 32 + c4 * 8;
+      *reinterpret_cast<uint4*>(a.qu + o) = vu;
+      *reinterpret_cast<uint4*>(a.qv + o) = vv;
+    }
+  };
+
+  f32x4_t ac[4][4], bd[4][5];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) ac[rt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tn = 0; tn < 5; ++tn) bd[rt][tn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  // one slice: registers -> LDS, loads of slice s + 2 into the freed registers, 36 MFMAs per wave
+  auto step = [&](int s, stage_regs& R) {
+    __syncthreads();
+    put(s, R);
+    __syncthreads();
+    if (s + 2 < nsteps) issue(s + 2, R);
+    bf16x8_t qa[4], qb[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      qa[rt] = *reinterpret_cast<const bf16x8_t*>(QU + (rt * 16 + lr) * RP + lg * 8);
+      qb[rt] = *reinterpret_cast<const bf16x8_t*>(QV + (rt * 16 + lr) * RP + lg * 8);
+    }
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const bf16x8_t kb = *reinterpret_cast<const bf16x8_t*>(Kc + (64 * w + jt * 16 + lr) * RP + lg * 8);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) ac[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[rt], kb, ac[rt][jt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int uu = 0; uu < 8; ++uu) {
+      const bf16x8_t pb = *reinterpret_cast<const bf16x8_t*>(Pc + ((4 * w + uu) * 16 + lr) * RP + lg * 8);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int tn = uu - 3 + rt;
+        if (tn >= 0 && tn < 5) bd[rt][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb[rt], pb, bd[rt][tn], 0, 0, 0);
+      }
+    }
+  };
+  stage_regs RA, RB;
+  issue(0, RA);
+  if (nsteps > 1) issue(1, RB);
+#pragma unroll 1
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, RA);
+    if (s + 1 < nsteps) step(s + 1, RB);
+  }
+  __syncthreads();                                   // operand slices are dead: LDS becomes the score tile
+  // ---- shift, scale, mask -> fp32 score tile S[64][SF] in LDS.  Row il of S is later overwritten, by the wave that owns it,
+  //      with the bf16 rows of the map (first half of the row's bytes) and of its dropped copy (second half): SF * 4 = 2 * SP * 2.
+  constexpr int SF = SP;
+  float* S = reinterpret_cast<float*>(smem);
+  const int kl0 = a.klen ? a.klen[b] : T;
+  const int kl = kl0 < T ? kl0 : T;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int off = 15 - 4 * lg - r;
+      const int srcl = (lane & 48) | ((lr + off) & 15);
+      const bool wrap = lr + off >= 16;
+      float sh[5];
+#pragma unroll
+      for (int tn = 0; tn < 5; ++tn) sh[tn] = __shfl(bd[rt][tn][r], srcl, 64);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int j = 64 * w + 16 * jt + lr;
+        const float val = (ac[rt][jt][r] + (wrap ? sh[jt + 1] : sh[jt])) * a.scale;
+        S[(rt * 16 + 4 * lg + r) * SF + j] = j < kl ? val : NEG;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax, one wave per row (16 rows each, ROLLED: this kernel runs cold code), a lane owns columns lane + 64 c
+  const uint64_t seed = (a.seed_base ? *a.seed_base : 0ull) + a.seed_off;
+  const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+#pragma unroll 1
+  for (int rr = 0; rr < 16; ++rr) {
+    const int il = w * 16 + rr;
+    float val[4];
+    float mx = NEG;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { val[c] = S[il * SF + lane + 64 * c]; mx = fmaxf(mx, val[c]); }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { val[c] = expf(val[c] - mx); sum += val[c]; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    const int64_t arow = ((int64_t)blockIdx.y * T + i0 + il) * a.ld;
+    bf16_t* rowA = reinterpret_cast<bf16_t*>(S + il * SF);     // LDS operations of one wave execute in order: the row was read above
+    bf16_t* rowD = rowA + SP;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      const float pr = j < kl ? val[c] * inv : 0.f;               // masked_fill(mask, 0.0) after the softmax
+      const bf16_t pb = f2bf(pr);
+      rowA[j] = pb;
+      if (a.pdrop) {
+        float pd = bf2f(pb);
+        if (a.p > 0.f && j < a.ld) pd *= dropout_scale(seed, (uint64_t)(arow + j), a.p, inv_keep);
+        rowD[j] = f2bf(pd);
+      }
+    }
+  }
+  __syncthreads();
+  const int nv = a.ld >> 3;                           // 16-byte vectors per row of the map
+  for (int n = t; n < 64 * 32; n += 256) {
+    const int row = n >> 5, c8 = n & 31;
+    if (i0 + row < T && c8 < nv) {
+      const int64_t o = ((int64_t)blockIdx.y * T + i0 + row) * a.ld + c8 * 8;
+      const bf16_t* rowA = reinterpret_cast<const bf16_t*>(S + row * SF);
+      *reinterpret_cast<uint4*>(a.attn + o) = *reinterpret_cast<const uint4*>(rowA + c8 * 8);
+      if (a.pdrop) *reinterpret_cast<uint4*>(a.pdrop + o) = *reinterpret_cast<const uint4*>(rowA + SP + c8 * 8);
+    }
+  }
+}
+
+struct ra_bwd_args {
+  int H, T, dk, L, ld, Lq;
+  const bf16_t* dctx; int64_t ldo, obs;
+  const bf16_t* v; int64_t ldv, vbs;
+  const bf16_t* attn; const bf16_t* dattn;
+  float scale, p;
+  const uint64_t* seed_base; uint64_t seed_off;
+  bf16_t* ds; bf16_t* dbd;
+};
+
+__global__ __launch_bounds__(256) void relattn_bwd_kernel(const ra_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Vc = reinterpret_cast<bf16_t*>(smem);      // [256][RP]
+  bf16_t* Oc = Vc + 256 * RP;                        // [64][RP]
+  const int T = a.T, dk = a.dk, H = a.H;
+  const int i0 = blockIdx.x * 64;
+  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lg = lane >> 4;
+  const bf16_t* vg = a.v + (int64_t)b * a.vbs + h * dk;
+  const bf16_t* og = a.dctx + (int64_t)b * a.obs + h * dk;
+  const int nsteps = dk / 32;
+  const int qrow = t >> 2, c4 = t & 3;
+  struct stage_regs { uint4 rv[4], ro; };
+  auto issue = [&](int s, stage_regs& R) {
+    const int d0 = s * 32 + c4 * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (t + 256 * i) >> 2;
+      R.rv[i] = make_uint4(0, 0, 0, 0);
+      if (row < T) R.rv[i] = *reinterpret_cast<const uint4*>(vg + (int64_t)row * a.ldv + d0);
+    }
+    R.ro = make_uint4(0, 0, 0, 0);
+    if (i0 + qrow < T) R.ro = *reinterpret_cast<const uint4*>(og + (int64_t)(i0 + qrow) * a.ldo + d0);
+  };
+  f32x4_t dp[4][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) dp[rt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto step = [&](int s, stage_regs& R) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Vc + ((t + 256 * i) >> 2) * RP + c4 * 8) = R.rv[i];
+    *reinterpret_cast<uint4*>(Oc + qrow * RP + c4 * 8) = R.ro;
+    __syncthreads();
+    if (s + 2 < nsteps) issue(s + 2, R);
+    bf16x8_t oa[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) oa[rt] = *reinterpret_cast<const bf16x8_t*>(Oc + (rt * 16 + lr) * RP + lg * 8);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(Vc + (64 * w + jt * 16 + lr) * RP + lg * 8);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) dp[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[rt], vb, dp[rt][jt], 0, 0, 0);
+    }
+  };
+  stage_regs RA, RB;
+  issue(0, RA);
+  if (nsteps > 1) issue(1, RB);
+#pragma unroll 1
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, RA);
+    if (s + 1 < nsteps) step(s + 1, RB);
+  }
+  __syncthreads();
+  // ---- dP -> fp32 tile DP[64][SP] in LDS.  Row il of DP is later overwritten, by the wave that owns it, with row il of dbd
+  //      (bf16, pitch 2 * SP elements = the same bytes): no second tile, no barrier in between.
+  float* DP = reinterpret_cast<float*>(smem);            // [64][SP] fp32 = [64][2 * SP] bf16
+  bf16_t* stP = reinterpret_cast<bf16_t*>(smem + 64 * SP * 4);   // [64][SP] P, then dS in place
+  bf16_t* stG = stP + 64 * SP;                           // [64][SP] external gradient of the map (only if given)
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) DP[(rt * 16 + 4 * lg + r) * SP + 64 * w + 16 * jt + lr] = dp[rt][jt][r];
+  const int nv = a.ld >> 3, nb = a.Lq >> 3;
+  for (int n = t; n < 64 * 32; n += 256) {
+    const int row = n >> 5, c8 = n & 31;
+    uint4 pvv = make_uint4(0, 0, 0, 0), gvv = make_uint4(0, 0, 0, 0);
+    if (i0 + row < T && c8 < nv) {
+      const int64_t o = ((int64_t)blockIdx.y * T + i0 + row) * a.ld + c8 * 8;
+      pvv = *reinterpret_cast<const uint4*>(a.attn + o);
+      if (a.dattn) gvv = *reinterpret_cast<const uint4*>(a.dattn + o);
+    }
+    *reinterpret_cast<uint4*>(stP + row * SP + c8 * 8) = pvv;
+    if (a.dattn) *reinterpret_cast<uint4*>(stG + row * SP + c8 * 8) = gvv;
+  }
+  __syncthreads();
+  const uint64_t seed = (a.seed_base ? *a.seed_base : 0ull) + a.seed_off;
+  const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+  // ---- softmax backward, one wave per row (ROLLED), a lane owns columns lane + 64 c
+#pragma unroll 1
+  for (int rr = 0; rr < 16; ++rr) {
+    const int il = w * 16 + rr, i = i0 + il;
+    const int64_t arow = ((int64_t)blockIdx.y * T + i) * a.ld;
+    float pv[4], tt[4];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      pv[c] = bf2f(stP[il * SP + j]);
+      const float m = (a.p > 0.f && j < a.ld) ? dropout_scale(seed, (uint64_t)(arow + j), a.p, inv_keep) : 1.f;
+      tt[c] = DP[il * SP + j] * m;
+      if (a.dattn) tt[c] += bf2f(stG[il * SP + j]);
+      dot += pv[c] * tt[c];
+    }
+    dot = wave_sum(dot);
+    bf16_t* rowB = reinterpret_cast<bf16_t*>(DP + il * SP);    // the row's dP values are in registers: its bytes become the dbd row
+    for (int n = lane; n < nb; n += 64) *reinterpret_cast<uint4*>(rowB + n * 8) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = lane + 64 * c;
+      const bf16_t d = f2bf(pv[c] * (tt[c] - dot) * a.scale);
+      stP[il * SP + j] = d;
+      if (i < T && j < T) rowB[T - 1 - i + j] = d;
+    }
+  }
+  __syncthreads();
+  for (int n = t; n < 64 * 32; n += 256) {
+    const int row = n >> 5, c8 = n & 31;
+    if (i0 + row < T && c8 < nv)
+      *reinterpret_cast<uint4*>(a.ds + ((int64_t)blockIdx.y * T + i0 + row) * a.ld + c8 * 8) = *reinterpret_cast<const uint4*>(stP + row * SP + c8 * 8);
+  }
+  for (int n = t; n < 64 * nb; n += 256) {
+    const int row = n / nb, c8 = n - row * nb;
+    if (i0 + row < T)
+      *reinterpret_cast<uint4*>(a.dbd + ((int64_t)blockIdx.y * T + i0 + row) * a.Lq + c8 * 8) =
+          *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(DP + row * SP) + c8 * 8);
+  }
+}
+
+bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int s2svc_relattn_supported(int dtype, int T, int dk, int rel_mode) {
+  return (dtype == S2S_BF16 && rel_mode == 1 && T >= 1 && T <= 256 && dk >= 32 && dk % 32 == 0) ? 1 : 0;
+}
+
+// q, k: (B, T, .) views with row stride ldq / ldk and batch stride qbs / kbs (elements), head h at columns h * dk; pos (L = 2T - 1, .)
+// with row stride ldp; u, v (H * dk) fp32; klen (B) int32 or NULL; attn / pdrop (B, H, T, ld) bf16, ld = T rounded up to 8 (pdrop
+// NULL when drop_p == 0); qu, qv (B, T, H * dk) bf16 contiguous.
+extern "C" int s2svc_relattn_fwd(int B, int H, int T, int dk, const void* q, int64_t ldq, int64_t qbs, const void* k, int64_t ldk,
+                                 int64_t kbs, const void* pos, int64_t ldp, int L, const float* u, const float* v, const int32_t* klen,
+                                 float scale, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* attn, void* pdrop, int ld,
+                                 void* qu, void* qv, void* stream) {
+  S2S_REQUIRE(s2svc_relattn_supported(S2S_BF16, T, dk, 1) && L == 2 * T - 1, "relattn_fwd: bf16, T <= 256, d_k % 32 == 0, L = 2T - 1");
+  S2S_REQUIRE(q && k && pos && u && v && attn && qu && qv && (drop_p <= 0.f || pdrop) && ld >= T && ld % 8 == 0 && ld <= 256,
+              "relattn_fwd: bad args");
+  S2S_REQUIRE(ldq % 8 == 0 && qbs % 8 == 0 && ldk % 8 == 0 && kbs % 8 == 0 && ldp % 8 == 0 && al16(q) && al16(k) && al16(pos) &&
+              al16(attn) && al16(pdrop) && al16(qu) && al16(qv), "relattn_fwd: 16-byte aligned operands, strides multiples of 8");
+  if (B == 0) return 0;
+  ra_fwd_args a;
+  a.H = H; a.T = T; a.dk = dk; a.L = L; a.ld = ld;
+  a.q = (const bf16_t*)q; a.ldq = ldq; a.qbs = qbs; a.k = (const bf16_t*)k; a.ldk = ldk; a.kbs = kbs;
+  a.pos = (const bf16_t*)pos; a.ldp = ldp; a.u = u; a.v = v; a.klen = klen; a.scale = scale; a.p = drop_p;
+  a.seed_base = seed_base; a.seed_off = seed_off; a.attn = (bf16_t*)attn; a.pdrop = (bf16_t*)pdrop; a.qu = (bf16_t*)qu; a.qv = (bf16_t*)qv;
+  const size_t lds = (size_t)64 * SP * 4;                          // the score tile (67,584 B) >= the operand slices (56,320 B)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(relattn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      s2svc_set_error("relattn_fwd: cannot raise the dynamic LDS limit");
+      return -2;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(relattn_fwd_kernel, dim3((T + 63) / 64, B * H), dim3(256), lds, (hipStream_t)stream, a);
+  S2S_CHECK_LAUNCH("relattn_fwd_kernel");
+  return 0;
+}
+
+// dctx (B, T, .) / v (B, T, .) views (row strides ldo / ldv, batch strides obs / vbs); attn, dattn (or NULL), ds (B, H, T, ld);
+// dbd (B, H, T, Lq) with Lq = 2T - 1 rounded up to 8: complete rows, zero outside the shifted positions.
+extern "C" int s2svc_relattn_bwd(int B, int H, int T, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv,
+                                 int64_t vbs, const void* attn, const void* dattn, int ld, float scale, float drop_p,
+                                 const uint64_t* seed_base, uint64_t seed_off, void* ds, void* dbd, int Lq, void* stream) {
+  S2S_REQUIRE(s2svc_relattn_supported(S2S_BF16, T, dk, 1), "relattn_bwd: bf16, T <= 256, d_k % 32 == 0");
+  S2S_REQUIRE(dctx && v && attn && ds && dbd && ld >= T && ld % 8 == 0 && ld <= 256 && Lq >= 2 * T - 1 && Lq % 8 == 0 && Lq <= 512,
+              "relattn_bwd: bad args");
+  S2S_REQUIRE(ldo % 8 == 0 && obs % 8 == 0 && ldv % 8 == 0 && vbs % 8 == 0 && al16(dctx) && al16(v) && al16(attn) && al16(dattn) &&
+              al16(ds) && al16(dbd), "relattn_bwd: 16-byte aligned operands, strides multiples of 8");
+  if (B == 0) return 0;
+  ra_bwd_args a;
+  a.H = H; a.T = T; a.dk = dk; a.L = 2 * T - 1; a.ld = ld; a.Lq = Lq;
+  a.dctx = (const bf16_t*)dctx; a.ldo = ldo; a.obs = obs; a.v = (const bf16_t*)v; a.ldv = ldv; a.vbs = vbs;
+  a.attn = (const bf16_t*)attn; a.dattn = (const bf16_t*)dattn; a.scale = scale; a.p = drop_p; a.seed_base = seed_base;
+  a.seed_off = seed_off; a.ds = (bf16_t*)ds; a.dbd = (bf16_t*)dbd;
+  const size_t lds = (size_t)64 * SP * 4 + (size_t)64 * SP * 2 * (dattn ? 2 : 1);     // dP / dbd tile + P (+ external gradient)
+  static size_t attr_set = 0;
+  if (attr_set < lds) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(relattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      s2svc_set_error("relattn_bwd: cannot raise the dynamic LDS limit");
+      return -2;
+    }
+    attr_set = lds;
+  }
+  hipLaunchKernelGGL(relattn_bwd_kernel, dim3((T + 63) / 64, B * H), dim3(256), lds, (hipStream_t)stream, a);
+  S2S_CHECK_LAUNCH("relattn_bwd_kernel");
+  return 0;
+}

@@ -1050,9 +1050,18 @@ class _RelAttnPacked(Function):
         L = pos.shape[1]
         dtype = qkv.dtype
         q, k, vv = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
-        qu, qv = K.add_head_bias_view(q, u.detach().reshape(-1), v.detach().reshape(-1))
         scale = 1.0 / math.sqrt(dk)
         seed = K.new_seed(qkv.device) if p > 0.0 else (None, 0)
+        ctx.fused_rel = KAT.rel_supported(q, k, vv, pos, H, rel_mode)
+        if ctx.fused_rel:       # T <= 256, bf16: head bias + both score terms + shift + softmax + dropout in ONE launch (csrc/relattn.hip)
+            attn, pdrop, qu, qv = KAT.rel_fwd(q, k, pos, u.detach().reshape(-1), v.detach().reshape(-1), klen, H, scale, p, seed)
+            out = _pv(pdrop if pdrop is not None else attn, vv, B, H, T, T, dk, D, dtype)
+            ctx.meta = (H, scale, p, seed, rel_mode, L, D)
+            ctx.params = (u, v)
+            ctx.save_for_backward(qkv, qu, qv, pos, attn, pdrop)
+            ctx.set_materialize_grads(False)
+            return out, _user_attn(attn, T)
+        qu, qv = K.add_head_bias_view(q, u.detach().reshape(-1), v.detach().reshape(-1))
         ac = _qk(qu, k, B, H, T, T, dk, D, dtype)
         Lq = _pad8(L)
         bd = torch.empty((B, H, T, Lq), dtype=torch.float32, device=qkv.device)
@@ -1081,8 +1090,15 @@ class _RelAttnPacked(Function):
         Lq = _pad8(L)
         dqkv = torch.empty_like(qkv)
         dqu = torch.empty((B, T, D), dtype=dtype, device=qu.device)
-        _, _, _, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, vv, H, scale, p, seed, Lp=L, rel_mode=rel_mode, ldb=Lq,
-                                        outs=(dqu, dqkv[..., D:2 * D], dqkv[..., 2 * D:]))
+        if ctx.fused_rel and KAT.rel_bwd_enabled():
+            dctx = _c(dctx) if dctx is not None else torch.zeros((B, T, D), dtype=dtype, device=qu.device)
+            ds, dbd = KAT.rel_bwd(dctx, vv, attn, _pad_like(dattn, attn), H, scale, p, seed, Lq)
+            _into(dqkv[..., 2 * D:], _pop(pm, T, H, K.RC), _bop(dctx, dk, K.RC), T, dk, T, dk, dtype, B, H)        # dV = Pm^T dctx
+            _into(dqu, _pop(ds, T, H), _bop(k, dk, K.RC), T, dk, T, dk, dtype, B, H)                                # dQu = dS K
+            _into(dqkv[..., D:2 * D], _pop(ds, T, H, K.RC), _bop(qu, dk, K.RC), T, dk, T, dk, dtype, B, H)          # dK = dS^T Qu
+        else:
+            _, _, _, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, vv, H, scale, p, seed, Lp=L, rel_mode=rel_mode, ldb=Lq,
+                                            outs=(dqu, dqkv[..., D:2 * D], dqkv[..., 2 * D:]))
         dqv = torch.empty((B, T, D), dtype=dtype, device=qu.device)
         K.gemm(K.operand(dbd, Lq, bs0=H * T * Lq, bs1=T * Lq, zero_padded=True), K.operand(pos, D, layout=K.RC, bs0=0, bs1=dk), T, dk,
                L, dqv, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T * D, dk))

@@ -51,3 +51,52 @@ def fused_bwd(q, k, v, dout, attn, dattn, H, scale, p, seed, dq, dk_out, dv):
                                                ptr(dattn), ld, scale, p, seed[0], seed[1], ptr(dq), dq.stride(1), dq.stride(0),
                                                ptr(dk_out), dk_out.stride(1), dk_out.stride(0), ptr(dv), dv.stride(1), dv.stride(0),
                                                stream()), "attn_fused_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+# relative-position self-attention, T <= 256 (csrc/relattn.hip)
+# ----------------------------------------------------------------------------------------------
+_NO_REL = os.environ.get("S2SVC_NO_RELATTN", "0") == "1"           # A/B switch
+
+
+def rel_bwd_enabled():
+    """The fused backward kernel (dP + softmax' + dbd in one launch) is correct and tested, but measured SLOWER than the GEMM +
+    zero fill + softmax-backward kernels it replaces (30 / 46 vs 26 / 33 us at d_k = 192 / 768: its operand loop is bound by
+    global-load latency at one workgroup per CU, the GEMM streams through LDS-DMA): opt-in."""
+    return os.environ.get("S2SVC_RELATTN_BWD", "0") == "1"
+
+
+def rel_supported(q, k, v, pos, H, rel_mode):
+    if _NO_REL or os.environ.get("S2SVC_NO_RELATTN", "0") == "1" or q.dtype != torch.bfloat16:
+        return False
+    T, dk = q.shape[1], q.shape[-1] // H
+    if not _lib.lib().s2svc_relattn_supported(_DT[q.dtype], T, dk, rel_mode) or pos.shape[1] != 2 * T - 1:
+        return False
+    return _strided_ok(q) and _strided_ok(k) and _strided_ok(v) and pos.is_contiguous() and pos.data_ptr() % 16 == 0
+
+
+def rel_fwd(q, k, pos, u, v, klen, H, scale, p, seed):
+    """q, k: (B,T,D) column blocks of the packed projection; pos (1,2T-1,D); u, v (H*dk) fp32 -> attn, pdrop (B,H,T,ld), qu, qv."""
+    B, T, D = q.shape
+    dk = D // H
+    ld = (T + 7) // 8 * 8
+    attn = torch.empty((B, H, T, ld), dtype=q.dtype, device=q.device)
+    pdrop = torch.empty_like(attn) if p > 0.0 else None
+    qu = torch.empty((B, T, D), dtype=q.dtype, device=q.device)
+    qv = torch.empty((B, T, D), dtype=q.dtype, device=q.device)
+    _lib.check(_lib.lib().s2svc_relattn_fwd(B, H, T, dk, ptr(q), q.stride(1), q.stride(0), ptr(k), k.stride(1), k.stride(0), ptr(pos),
+                                            pos.stride(1), pos.shape[1], ptr(u), ptr(v), ptr(klen), scale, p, seed[0], seed[1],
+                                            ptr(attn), ptr(pdrop), ld, ptr(qu), ptr(qv), stream()), "relattn_fwd")
+    return attn, pdrop, qu, qv
+
+
+def rel_bwd(dctx, v, attn, dattn, H, scale, p, seed, Lq):
+    """-> ds (B,H,T,ld), dbd (B,H,T,Lq)  (what attn_softmax_bwd returns, without the dP tensor in between)."""
+    B, _, T, ld = attn.shape
+    dk = dctx.shape[-1] // H
+    ds = torch.empty_like(attn)
+    dbd = torch.empty((B, H, T, Lq), dtype=attn.dtype, device=attn.device)
+    _lib.check(_lib.lib().s2svc_relattn_bwd(B, H, T, dk, ptr(dctx), dctx.stride(1), dctx.stride(0), ptr(v), v.stride(1), v.stride(0),
+                                            ptr(attn), ptr(dattn), ld, scale, p, seed[0], seed[1], ptr(ds), ptr(dbd), Lq, stream()),
+               "relattn_bwd")
+    return ds, dbd

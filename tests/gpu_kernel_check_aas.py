@@ -48,7 +48,7 @@ def depthwise_conv(dtype):
 
 
 def _rel_l2(got, ref):
-    got, ref = got.float().cpu().reshape(-1), ref.float().cpu().reshape(-1)
+    got, ref = got.detach().float().cpu().reshape(-1), ref.detach().float().cpu().reshape(-1)
     return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
 
 
@@ -111,6 +111,72 @@ def conformer_conv_module_fused():
         res.append(check(f"{tag} running_mean", mf, rm, torch.float32, atol=2e-3, rtol=1e-2))
         res.append(check(f"{tag} running_var", vf, rv, torch.float32, atol=2e-3, rtol=1e-2))
         res.append((int(nbf) == 1, f"{tag} num_batches_tracked = {int(nbf)}"))
+    return res
+
+
+@case
+def rel_attention_fused_vs_separate():
+    """csrc/relattn.hip (relative-position self-attention, T <= 256, bf16: head bias + q.k + shifted q.pos + softmax + dropout in one
+    launch, no (B,H,T,2T-1) tensor) against fp32 torch math on the same bf16 inputs, and -- dropout on, same seeds => same masks --
+    against the separate kernels (two GEMMs + softmax kernel with the shift as index arithmetic)."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    from seq2seq_vc_amd.ops import kernels_attn as KAT
+    res = []
+    bf = torch.bfloat16
+    for (B, H, T, dk, seed) in [(2, 2, 100, 64, 1), (3, 2, 256, 192, 2), (2, 2, 256, 768, 3), (1, 4, 37, 32, 4), (2, 2, 64, 96, 5), (2, 1, 131, 64, 6)]:
+        D = H * dk
+        qkv = rnd(B, T, 3 * D, seed=seed * 10, dtype=bf, scale=0.7)
+        pos = rnd(1, 2 * T - 1, D, seed=seed * 10 + 1, dtype=bf, scale=0.7)
+        u, v = rnd(H, dk, seed=seed * 10 + 2, scale=0.3), rnd(H, dk, seed=seed * 10 + 3, scale=0.3)
+        klen = torch.tensor([T, max(1, T - 9), max(1, T // 2)][:B], dtype=torch.int32, device=DEV)
+        dy = rnd(B, T, D, seed=seed * 10 + 5, dtype=bf)
+        scale = 1 / math.sqrt(dk)
+        # fp32 reference (attention.py:237-305): matrix_bd[i, T-1-i+j] is what rel_shift puts at (i, j)
+        xr, pr_, ur, vr = (t_.float().clone().requires_grad_(True) for t_ in (qkv, pos, u, v))
+        q, k, vv = (xr[..., i * D:(i + 1) * D].view(B, T, H, dk).transpose(1, 2) for i in range(3))
+        ph = pr_.view(1, 2 * T - 1, H, dk).transpose(1, 2)
+        ac = (q + ur[None, :, None, :]) @ k.transpose(-1, -2)
+        bd = (q + vr[None, :, None, :]) @ ph.transpose(-1, -2)
+        idx = (T - 1) - torch.arange(T, device=DEV)[:, None] + torch.arange(T, device=DEV)[None, :]
+        bds = torch.gather(bd, 3, idx[None, None].expand(B, H, T, T))
+        mask = torch.arange(T, device=DEV)[None, None, None, :] < klen[:, None, None, None]
+        sc = ((ac + bds) * scale).masked_fill(~mask, torch.finfo(torch.float32).min)
+        prob = torch.softmax(sc, -1).masked_fill(~mask, 0.0)
+        outr = (prob @ vv).transpose(1, 2).reshape(B, T, D)
+        (outr * dy.float()).sum().backward()
+
+        def run(fused, p, fused_bwd=True):
+            os.environ["S2SVC_NO_RELATTN"] = "0" if fused else "1"
+            os.environ["S2SVC_RELATTN_BWD"] = "1" if fused_bwd else "0"    # the fused backward kernel is opt-in (slower than what it replaces)
+            K.manual_seed(321)
+            K.reset_op_counter()
+            x, pp, uu, vv_ = (t_.clone().requires_grad_(True) for t_ in (qkv, pos, u, v))
+            if fused:
+                assert KAT.rel_supported(x[..., :D], x[..., D:2 * D], x[..., 2 * D:], pp, H, 1), "shape should take the fused kernel"
+            o, a = Fn.rel_attention_packed(x, pp, uu, vv_, klen, H, p, 1)
+            (o.float() * dy.float()).sum().backward()
+            return o.detach(), a.detach(), x.grad, pp.grad, uu.grad, vv_.grad
+        try:
+            f0, s0, f1, s1 = run(True, 0.0), run(False, 0.0), run(True, 0.2), run(False, 0.2)
+            f2 = run(True, 0.2, fused_bwd=False)            # the default: fused forward, separate backward kernels
+        finally:
+            os.environ.pop("S2SVC_NO_RELATTN", None)
+            os.environ.pop("S2SVC_RELATTN_BWD", None)
+        tag = f"rel-attn B{B} H{H} T{T} dk{dk}"
+        names = ("out", "attn", "d qkv", "d pos", "d pos_bias_u", "d pos_bias_v")
+        refs = (outr, prob, xr.grad, pr_.grad, ur.grad, vr.grad)
+        for nm, got, sep, ref in zip(names, f0, s0, refs):
+            e, es = _rel_l2(got, ref), _rel_l2(sep, ref)
+            res.append((e <= 3e-2 and e <= 1.5 * es + 2e-3, f"{tag} {nm}: rel-L2 vs fp32 torch {e:.2e} (separate kernels {es:.2e})"))
+        res.append(check(tag + " attn rows sum to 1", f0[1].float().sum(-1), torch.ones(B, H, T), torch.float32, atol=2e-2))
+        for nm, got, sep in zip(names, f1, s1):
+            e = _rel_l2(got, sep)
+            res.append((e <= 2e-2, f"{tag} dropout 0.2, same masks, {nm}: rel-L2 fused vs separate {e:.2e}"))
+        for nm, got, sep in zip(names, f2, s1):
+            e = _rel_l2(got, sep)
+            res.append((e <= 2e-2, f"{tag} dropout 0.2, fused forward + separate backward, {nm}: rel-L2 vs separate {e:.2e}"))
+        zero_map = bool(((f1[1] == 0) == (s1[1] == 0)).all())
+        res.append((zero_map, f"{tag} masked positions of the attention map agree"))
     return res
 
 
