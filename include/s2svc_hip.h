@@ -290,6 +290,21 @@ int s2svc_convmod_bwd(int B, int Tn, int C, int ks, const void* da, const void* 
                       float* dgamma_acc, float* dbeta_acc, float* ws_stats, float* ws_w, void* stream);
 int s2svc_convmod_wgrad_final(int C, int ks, int chunks, const float* ws_w, float* dw, float* db, int accumulate, void* stream);
 
+/* BatchNorm1d (training mode) + activation + dropout on channel-last bf16 rows, C % 8 == 0, 16-byte accesses (csrc/convmod.hip).
+   replaces: modules/pre_postnets.py:108-165 (BatchNorm1d -> Tanh -> Dropout of the Postnet layers) and its autograd backward.
+     s2svc_bn_stats_vec: mean / rstd over (rows, C) + torch's running statistics; ws >= ceil(rows / 64) * 2 * C floats.
+     s2svc_bn_act_apply_vec: y = dropout(act((x - mean) * rstd * gamma + beta)); pre_act (or NULL) = the value before act.
+     s2svc_bn_act_bwd_vec: dz = d y; saved = y (relu / tanh / sigmoid) or pre_act (swish / gelu), NULL for act none and no dropout;
+       -> dx, sdy = d beta, sdyx = d gamma (also ADDED to dbeta_acc / dgamma_acc when given).  The activation / dropout derivative is
+       recomputed in both passes (no intermediate tensor).  Dropout masks: element index = row * C + channel, as s2svc_bn_apply. */
+int s2svc_bn_stats_vec(int rows, int C, const void* x, float eps, float momentum, float* mean, float* rstd, float* run_mean,
+                       float* run_var, int64_t* num_batches, float* ws, void* stream);
+int s2svc_bn_act_apply_vec(int rows, int C, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y, void* pre_act, void* stream);
+int s2svc_bn_act_bwd_vec(int rows, int C, const void* dz, const void* saved, const void* x, const float* mean, const float* rstd,
+                         const float* gamma, int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dx, float* sdy,
+                         float* sdyx, float* dgamma_acc, float* dbeta_acc, float* ws, void* stream);
+
 /* ========================================================================================== */
 /* AAS alignment: pairwise -L2 + masked log-softmax, monotonic alignment search, Gaussian     */
 /* upsampling weights.                                                                         */

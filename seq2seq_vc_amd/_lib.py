@@ -151,6 +151,10 @@ _SIGS = {
     "s2svc_convmod_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                           c_vp, c_vp],
     "s2svc_convmod_wgrad_final": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp],
+    "s2svc_bn_stats_vec": [c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_bn_act_apply_vec": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
+    "s2svc_bn_act_bwd_vec": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                             c_vp],
     "s2svc_pairwise_l2_logsoftmax": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_pairwise_l2_bwd_g": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_rowscale": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],

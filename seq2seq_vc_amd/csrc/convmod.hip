@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void convmod_bn_finalize_kernel(int C, int chu
   const int c = blockIdx.x * 64 + cl;
   float t0 = 0.f, t1 = 0.f;
   if (c < C) {
-    for (int k = kg; k < chunks; k += 4) {
+#pragma unroll 8
+    for (int k = kg; k < chunks; k += 4) {        // same order of additions, 16 loads in flight
       t0 += ws[((int64_t)k * 2 + 0) * C + c];
       t1 += ws[((int64_t)k * 2 + 1) * C + c];
     }
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(256) void convmod_sum2_kernel(int C, int chunks, co
   const int c = blockIdx.x * 64 + cl;
   float t0 = 0.f, t1 = 0.f;
   if (c < C) {
-    for (int k = kg; k < chunks; k += 4) {
+#pragma unroll 8
+    for (int k = kg; k < chunks; k += 4) {        // same order of additions, 16 loads in flight
       t0 += ws[((int64_t)k * 2 + 0) * C + c];
       t1 += ws[((int64_t)k * 2 + 1) * C + c];
     }
@@ -411,7 +413,195 @@ __global__ void convmod_wgrad_final_kernel(int C, int ks, int chunks, const floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm1d (training) + activation + dropout on channel-last rows, bf16, C % 8 == 0, in 16-byte accesses -- the Postnet layers
+// (pre_postnets.py:108-165: Conv1d -> BatchNorm1d -> Tanh -> Dropout).  Same launch count forward as the scalar kernels of norm.hip
+// (statistics, finalize, apply) but vector loads; backward 3 launches instead of 4 + 2: the activation / dropout derivative is
+// recomputed inside the statistics pass and inside the data-gradient pass instead of being written by a kernel of its own, and the
+// BatchNorm parameter gradients are added to their slots by the reduction's second stage.
+// A workgroup = 64 channels (8 vector lanes) x 64 rows; sums in a fixed order.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad_saved(float s, float m, int act) {      // elementwise.hip: act_grad_from_saved
+  if (act == S2S_ACT_RELU) return s > 0.f ? 1.f : 0.f;
+  if (act == S2S_ACT_TANH) { const float yv = m > 0.f ? s / m : 0.f; return 1.f - yv * yv; }
+  if (act == S2S_ACT_SIGMOID) { const float yv = m > 0.f ? s / m : 0.f; return yv * (1.f - yv); }
+  if (act == S2S_ACT_SWISH) { const float sg = 1.f / (1.f + expf(-s)); return sg * (1.f + s * (1.f - sg)); }
+  if (act == S2S_ACT_GELU) {
+    const float cdf = 0.5f * (1.f + erff(s * 0.70710678118654752f));
+    return cdf + s * 0.3989422804014327f * expf(-0.5f * s * s);
+  }
+  return 1.f;
+}
+
+// reduce a0 / a1 (8 channels per lane, 8 rows per wave) over the workgroup's rows -> ws[chunk][2][C]
+__device__ __forceinline__ void bn_chunk_reduce(float (&a0)[8], float (&a1)[8], float (&sh)[2][4][CT], int C, int c, float* __restrict__ ws) {
+  const int v = threadIdx.x & 7, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      a0[e] += __shfl_xor(a0[e], o, 64);
+      a1[e] += __shfl_xor(a1[e], o, 64);
+    }
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sh[0][wave][v * 8 + e] = a0[e]; sh[1][wave][v * 8 + e] = a1[e]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < CT) {
+    const int cl = threadIdx.x, cc = blockIdx.x * CT + cl;
+    if (cc < C) {
+      ws[((int64_t)blockIdx.y * 2 + 0) * C + cc] = ((sh[0][0][cl] + sh[0][1][cl]) + sh[0][2][cl]) + sh[0][3][cl];
+      ws[((int64_t)blockIdx.y * 2 + 1) * C + cc] = ((sh[1][0][cl] + sh[1][1][cl]) + sh[1][2][cl]) + sh[1][3][cl];
+    }
+  }
+  (void)c;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_vec_kernel(int rows, int C, const bf16_t* __restrict__ x, float* __restrict__ ws, int rpc) {
+  __shared__ float sh[2][4][CT];
+  const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
+  const int c = blockIdx.x * CT + v * 8;
+  const int r0 = blockIdx.y * rpc;
+  const int r1 = r0 + rpc < rows ? r0 + rpc : rows;
+  float a0[8], a1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = r0 + r8; r < r1; r += 32) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (int64_t)r * C + c), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a0[e] += f[e]; a1[e] += f[e] * f[e]; }
+    }
+  }
+  bn_chunk_reduce(a0, a1, sh, C, c, ws);
+}
+
+// y = dropout(act((x - mean) * rstd * gamma + beta)); pre_act (optional) = the BatchNorm output before the activation
+__global__ __launch_bounds__(256) void bn_act_apply_vec_kernel(int rows, int C, const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int act, float p,
+                                                               const uint64_t* seed_base, uint64_t seed_off, bf16_t* __restrict__ y,
+                                                               bf16_t* __restrict__ pre_act, int rows_per_wg) {
+  const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
+  const int c = blockIdx.x * CT + v * 8;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_wg;
+  const int r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float m[8], rs[8], ga[8], be[8];
+  ldp8(mean + c, m);
+  ldp8(rstd + c, rs);
+  ldp8(gamma + c, ga);
+  ldp8(beta + c, be);
+#pragma unroll 2
+  for (int r = r0 + r8; r < r1; r += 32) {
+    const int64_t o = (int64_t)r * C + c;
+    float f[8], mk[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(x + o), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (f[e] - m[e]) * rs[e] * ga[e] + be[e];
+    if (pre_act) *reinterpret_cast<uint4*>(pre_act + o) = pack_bf16x8(f);
+    if (p > 0.f) dropout_scale8(seed, (uint64_t)o, p, inv_keep, mk);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      f[e] = act_apply(f[e], act);
+      if (p > 0.f) f[e] *= mk[e];
+    }
+    *reinterpret_cast<uint4*>(y + o) = pack_bf16x8(f);
+  }
+}
+
+// g = dz * mask * act'(saved);  per-chunk sums of g and g * xhat
+__global__ __launch_bounds__(256) void bn_act_bwd_stats_kernel(int rows, int C, const bf16_t* __restrict__ dz, const bf16_t* __restrict__ saved,
+                                                               const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, int act, float p,
+                                                               const uint64_t* seed_base, uint64_t seed_off, float* __restrict__ ws, int rpc) {
+  __shared__ float sh[2][4][CT];
+  const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
+  const int c = blockIdx.x * CT + v * 8;
+  const int r0 = blockIdx.y * rpc;
+  const int r1 = r0 + rpc < rows ? r0 + rpc : rows;
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float a0[8], a1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+  if (c < C) {
+    float m[8], rs[8];
+    ldp8(mean + c, m);
+    ldp8(rstd + c, rs);
+#pragma unroll 2
+    for (int r = r0 + r8; r < r1; r += 32) {
+      const int64_t o = (int64_t)r * C + c;
+      float g[8], sd[8], xx[8], mk[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(dz + o), g);
+      if (saved) unpack_bf16x8(*reinterpret_cast<const uint4*>(saved + o), sd);
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + o), xx);
+      if (p > 0.f) dropout_scale8(seed, (uint64_t)o, p, inv_keep, mk);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float mm = p > 0.f ? mk[e] : 1.f;
+        const float gg = g[e] * mm * (saved ? act_grad_saved(sd[e], mm, act) : 1.f);
+        a0[e] += gg;
+        a1[e] += gg * (xx[e] - m[e]) * rs[e];
+      }
+    }
+  }
+  bn_chunk_reduce(a0, a1, sh, C, c, ws);
+}
+
+// dx = gamma * rstd * (g - sum_g / N - xhat * sum_g_xhat / N), g recomputed as above
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(int rows, int C, float inv_n, const bf16_t* __restrict__ dz,
+                                                               const bf16_t* __restrict__ saved, const bf16_t* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ sdy,
+                                                               const float* __restrict__ sdyx, int act, float p,
+                                                               const uint64_t* seed_base, uint64_t seed_off, bf16_t* __restrict__ dx,
+                                                               int rows_per_wg) {
+  const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
+  const int c = blockIdx.x * CT + v * 8;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_wg;
+  const int r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float m[8], rs[8], k1[8], k2[8], k3[8];
+  ldp8(mean + c, m);
+  ldp8(rstd + c, rs);
+  ldp8(gamma + c, k1);
+  ldp8(sdy + c, k2);
+  ldp8(sdyx + c, k3);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { k1[e] *= rs[e]; k2[e] *= inv_n; k3[e] *= inv_n; }
+#pragma unroll 2
+  for (int r = r0 + r8; r < r1; r += 32) {
+    const int64_t o = (int64_t)r * C + c;
+    float g[8], sd[8], xx[8], mk[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(dz + o), g);
+    if (saved) unpack_bf16x8(*reinterpret_cast<const uint4*>(saved + o), sd);
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(x + o), xx);
+    if (p > 0.f) dropout_scale8(seed, (uint64_t)o, p, inv_keep, mk);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float mm = p > 0.f ? mk[e] : 1.f;
+      const float gg = g[e] * mm * (saved ? act_grad_saved(sd[e], mm, act) : 1.f);
+      g[e] = k1[e] * (gg - k2[e] - (xx[e] - m[e]) * rs[e] * k3[e]);
+    }
+    *reinterpret_cast<uint4*>(dx + o) = pack_bf16x8(g);
+  }
+}
+
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// rows per statistics chunk: 64 for short inputs, more (a multiple of 32) so that there are at most 64 chunk partials to sum
+int bn_rows_per_chunk(int rows) {
+  int rpc = ((rows + 63) / 64 + 31) / 32 * 32;
+  return rpc < 64 ? 64 : rpc;
+}
 
 }  // namespace
 
@@ -483,5 +673,55 @@ extern "C" int s2svc_convmod_wgrad_final(int C, int ks, int chunks, const float*
   hipLaunchKernelGGL(convmod_wgrad_final_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, ks, chunks, ws_w, dw, db,
                      accumulate);
   S2S_CHECK_LAUNCH("convmod_wgrad_final_kernel");
+  return 0;
+}
+
+// ---- BatchNorm1d (training) + activation + dropout, bf16, C % 8 == 0 (see above) ----
+// mean / rstd of x (rows, C) + running statistics: two launches.  ws >= ceil(rows / 64) * 2 * C floats.
+extern "C" int s2svc_bn_stats_vec(int rows, int C, const void* x, float eps, float momentum, float* mean, float* rstd, float* run_mean,
+                                  float* run_var, int64_t* num_batches, float* ws, void* stream) {
+  S2S_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && x && mean && rstd && ws && aligned16(x), "bn_stats_vec: bad args (bf16, C % 8 == 0)");
+  hipStream_t st = (hipStream_t)stream;
+  const int rpc = bn_rows_per_chunk(rows), chunks = (rows + rpc - 1) / rpc, ct = (C + CT - 1) / CT;
+  hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(ct, chunks), dim3(256), 0, st, rows, C, (const bf16_t*)x, ws, rpc);
+  S2S_CHECK_LAUNCH("bn_stats_vec_kernel");
+  hipLaunchKernelGGL(convmod_bn_finalize_kernel, dim3(ct), dim3(256), 0, st, C, chunks, ws, rows, eps, momentum, mean, rstd, run_mean,
+                     run_var, num_batches);
+  S2S_CHECK_LAUNCH("convmod_bn_finalize_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_bn_act_apply_vec(int rows, int C, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                      const float* beta, int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y,
+                                      void* pre_act, void* stream) {
+  S2S_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && x && mean && rstd && gamma && beta && y && aligned16(x) && aligned16(y) &&
+              aligned16(pre_act), "bn_act_apply_vec: bad args (bf16, C % 8 == 0)");
+  const int rpw = 128;
+  hipLaunchKernelGGL(bn_act_apply_vec_kernel, dim3((C + CT - 1) / CT, (rows + rpw - 1) / rpw), dim3(256), 0, (hipStream_t)stream, rows, C,
+                     (const bf16_t*)x, mean, rstd, gamma, beta, act, drop_p, seed_base, seed_off, (bf16_t*)y, (bf16_t*)pre_act, rpw);
+  S2S_CHECK_LAUNCH("bn_act_apply_vec_kernel");
+  return 0;
+}
+
+// dz = gradient of y = dropout(act(BN(x))); saved = y (relu / tanh / sigmoid) or the pre-activation (swish / gelu), NULL for act none
+// without dropout.  -> dx, sdy = sum g, sdyx = sum g * xhat (the gradients of beta / gamma, also ADDED to dbeta_acc / dgamma_acc when
+// given).  Three launches.  ws >= ceil(rows / 64) * 2 * C floats.
+extern "C" int s2svc_bn_act_bwd_vec(int rows, int C, const void* dz, const void* saved, const void* x, const float* mean, const float* rstd,
+                                    const float* gamma, int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dx,
+                                    float* sdy, float* sdyx, float* dgamma_acc, float* dbeta_acc, float* ws, void* stream) {
+  S2S_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && dz && x && mean && rstd && gamma && dx && sdy && sdyx && ws && aligned16(dz) &&
+              aligned16(saved) && aligned16(x) && aligned16(dx) && (saved || act == S2S_ACT_NONE), "bn_act_bwd_vec: bad args (bf16, C % 8 == 0)");
+  hipStream_t st = (hipStream_t)stream;
+  const int rpc = bn_rows_per_chunk(rows), chunks = (rows + rpc - 1) / rpc, ct = (C + CT - 1) / CT;
+  hipLaunchKernelGGL(bn_act_bwd_stats_kernel, dim3(ct, chunks), dim3(256), 0, st, rows, C, (const bf16_t*)dz, (const bf16_t*)saved,
+                     (const bf16_t*)x, mean, rstd, act, drop_p, seed_base, seed_off, ws, rpc);
+  S2S_CHECK_LAUNCH("bn_act_bwd_stats_kernel");
+  hipLaunchKernelGGL(convmod_sum2_kernel, dim3(ct), dim3(256), 0, st, C, chunks, ws, sdy, sdyx, dbeta_acc, dgamma_acc);
+  S2S_CHECK_LAUNCH("convmod_sum2_kernel");
+  const int rpw = 128;
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ct, (rows + rpw - 1) / rpw), dim3(256), 0, st, rows, C, 1.0f / (float)rows,
+                     (const bf16_t*)dz, (const bf16_t*)saved, (const bf16_t*)x, mean, rstd, gamma, sdy, sdyx, act, drop_p, seed_base,
+                     seed_off, (bf16_t*)dx, rpw);
+  S2S_CHECK_LAUNCH("bn_act_bwd_apply_kernel");
   return 0;
 }

@@ -1401,6 +1401,15 @@ class _BatchNormAct(Function):
         C = x.shape[-1]
         rows = x.numel() // C
         seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
+        ctx.vec = training and K.bn_vec_ok(x)
+        if ctx.vec:     # bf16: 16-byte kernels; the backward pass recomputes the activation / dropout derivative (csrc/convmod.hip)
+            mean, rstd = K.bn_stats_vec(x, rows, C, eps, momentum, run_mean, run_var, num_batches)
+            need_pre = act in ("swish", "gelu")
+            y, pre = K.bn_act_apply_vec(x, mean, rstd, gamma.detach(), beta.detach(), act=act, p=p, seed=seed, want_pre=need_pre)
+            ctx.meta = (training, act, p, seed)
+            ctx.params = (gamma, beta)
+            ctx.save_for_backward(x, mean, rstd, (pre if need_pre else y) if (act or p > 0.0) else None)
+            return y
         if training:
             if x.dtype == torch.bfloat16:      # one pass over x: mean and E[x^2] together (fp32 sums of bf16 values)
                 mean, rstd = K.bn_stats(x, rows, C, eps, momentum, run_mean, run_var, num_batches)
@@ -1426,6 +1435,16 @@ class _BatchNormAct(Function):
         C = x.shape[-1]
         rows = x.numel() // C
         dy = _c(dz)
+        if ctx.vec:
+            g_slot = getattr(gamma, "_s2s_grad", None) if gamma.requires_grad else None
+            b_slot = getattr(beta, "_s2s_grad", None) if beta.requires_grad else None
+            both = g_slot is not None and b_slot is not None
+            dx, sdy, sdyx = K.bn_act_bwd_vec(dy, saved, x, mean, rstd, gamma.detach(), act=act, p=p, seed=seed,
+                                             dgamma_acc=g_slot.view(-1) if both else None, dbeta_acc=b_slot.view(-1) if both else None)
+            dgamma = dbeta = None
+            if gamma.requires_grad and not both:
+                dgamma, dbeta = _emit_vgrad(gamma, sdyx), _emit_vgrad(beta, sdy)
+            return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
         if act or p > 0.0:
             dy = K.act_dropout_bwd(dy, saved, act=act, p=p, seed=seed)
         sdy, sdyx = K.colreduce(2, dy.view(rows, C), x.view(rows, C), mean, rstd, want_dot=True)

@@ -403,6 +403,44 @@ def bn_apply(x, mean, rstd, gamma, beta, act=None, p=0.0, seed=(None, 0), want_p
     return y, pre
 
 
+def bn_vec_ok(x):
+    """bf16 channel-last rows with C % 8 == 0: the 16-byte BatchNorm kernels of csrc/convmod.hip apply (S2SVC_NO_BN_VEC=1: A/B switch)."""
+    return (x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0 and x.data_ptr() % 16 == 0 and x.numel() < 2 ** 31
+            and os.environ.get("S2SVC_NO_BN_VEC", "0") != "1")
+
+
+def bn_stats_vec(x, rows, C, eps, momentum, run_mean=None, run_var=None, num_batches=None):
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(((rows + 63) // 64) * 2 * C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().s2svc_bn_stats_vec(rows, C, ptr(x), eps, momentum, ptr(mean), ptr(rstd), ptr(run_mean), ptr(run_var),
+                                             ptr(num_batches), ptr(ws), stream()), "bn_stats_vec")
+    return mean, rstd
+
+
+def bn_act_apply_vec(x, mean, rstd, gamma, beta, act=None, p=0.0, seed=(None, 0), want_pre=False):
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    pre = torch.empty_like(x) if want_pre else None
+    _lib.check(_lib.lib().s2svc_bn_act_apply_vec(x.numel() // C, C, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], p,
+                                                 seed[0], seed[1], ptr(y), ptr(pre), stream()), "bn_act_apply_vec")
+    return y, pre
+
+
+def bn_act_bwd_vec(dz, saved, x, mean, rstd, gamma, act=None, p=0.0, seed=(None, 0), dgamma_acc=None, dbeta_acc=None):
+    """-> dx, sdy (= d beta), sdyx (= d gamma); dgamma_acc / dbeta_acc: fp32 (C) gradient slots the sums are ADDED to."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    sdy = torch.empty(C, dtype=torch.float32, device=x.device)
+    sdyx = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(((rows + 63) // 64) * 2 * C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().s2svc_bn_act_bwd_vec(rows, C, ptr(dz), ptr(saved), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ACT[act], p,
+                                               seed[0], seed[1], ptr(dx), ptr(sdy), ptr(sdyx), ptr(dgamma_acc), ptr(dbeta_acc),
+                                               ptr(ws), stream()), "bn_act_bwd_vec")
+    return dx, sdy, sdyx
+
+
 def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats=True):
     C = x.shape[-1]
     rows = x.numel() // C

@@ -686,6 +686,58 @@ def batchnorm(dtype):
     return res
 
 
+@case
+def batchnorm_act_dropout_vectorised():
+    """The 16-byte BatchNorm + activation + dropout kernels of csrc/convmod.hip (bf16 training path of Fn.batch_norm_act: statistics,
+    apply, and a backward pass that recomputes the activation / dropout derivative) against torch fp32 (no dropout) and against the
+    scalar kernels of norm.hip with the same seeds => same dropout masks."""
+    import os
+    from seq2seq_vc_amd.ops import functional as Fn
+    res = []
+    bf = torch.bfloat16
+
+    def rel(a, b):
+        a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    for (rows, C, act, seed) in [(150, 40, "tanh", 1), (12800, 512, "tanh", 2), (4096, 80, None, 3), (333, 1536, "swish", 4), (64, 8, "relu", 5)]:
+        x = rnd(rows, C, seed=seed, dtype=bf) * 2 + 0.5
+        gm, bt = 1 + 0.1 * rnd(C, seed=seed + 1), 0.1 * rnd(C, seed=seed + 2)
+        dz = rnd(rows, C, seed=seed + 3, dtype=bf)
+        xr = x.float().requires_grad_(True)
+        gmr, btr = gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+        rm2, rv2 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        pre = F.batch_norm(xr, rm2, rv2, gmr, btr, True, 0.1, 1e-5)
+        yr = {"tanh": torch.tanh, "swish": lambda t_: t_ * torch.sigmoid(t_), "relu": torch.relu, None: lambda t_: t_}[act](pre)
+        yr.backward(dz.float())
+
+        def run(vec, p):
+            os.environ["S2SVC_NO_BN_VEC"] = "0" if vec else "1"
+            K.manual_seed(77)
+            K.reset_op_counter()
+            xx = x.clone().requires_grad_(True)
+            g2, b2 = gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+            rm, rv, nb = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+            y = Fn.batch_norm_act(xx, g2, b2, rm, rv, nb, True, act, p, 1e-5, 0.1)
+            y.backward(dz)
+            return y.detach(), xx.grad, g2.grad, b2.grad, rm, rv, nb
+        try:
+            v0, s0, v1, s1 = run(True, 0.0), run(False, 0.0), run(True, 0.5), run(False, 0.5)
+        finally:
+            os.environ.pop("S2SVC_NO_BN_VEC", None)
+        tag = f"bn-vec {rows}x{C} {act}"
+        for nm, got, sca, ref in zip(("y", "dx", "dgamma", "dbeta"), v0, s0, (yr, xr.grad, gmr.grad, btr.grad)):
+            e, es = rel(got, ref), rel(sca, ref)
+            res.append((e <= 2e-2 and e <= 1.5 * es + 1e-3, f"{tag} {nm}: rel-L2 vs fp32 torch {e:.2e} (scalar kernels {es:.2e})"))
+        res.append(check(f"{tag} running_mean", v0[4], rm2, torch.float32, atol=2e-3, rtol=1e-2))
+        res.append(check(f"{tag} running_var", v0[5], rv2, torch.float32, atol=2e-3, rtol=1e-2))
+        res.append((int(v0[6]) == 1, f"{tag} num_batches_tracked = {int(v0[6])}"))
+        for nm, got, sca in zip(("y", "dx", "dgamma", "dbeta"), v1, s1):
+            e = rel(got, sca)
+            res.append((e <= 1e-2, f"{tag} dropout 0.5, same masks, {nm}: rel-L2 vectorised vs scalar {e:.2e}"))
+        res.append((bool(((v1[0] == 0) == (s1[0] == 0)).all()), f"{tag} dropped positions agree"))
+    return res
+
+
 def _rel_shift_new(x):
     b, h, t, l = x.shape
     zp = torch.zeros((b, h, t, 1), device=x.device, dtype=x.dtype)
