@@ -16,7 +16,7 @@ namespace {
 
 constexpr int CTC_THREADS = 256;
 constexpr int CTC_KMAX = 8;  // extended length S = 2N+1 <= 2048
-constexpr int CTC_PD = 4;    // steps of prefetch distance in the one-position-per-thread path
+constexpr int CTC_PD = 4;    // steps of prefetch distance in the one-position-per-thread path (12 measured the same: the step is the LDS round trip + lse3 chain)
 
 __device__ __forceinline__ float lse2(float a, float b) {
   const float m = fmaxf(a, b);
@@ -108,16 +108,17 @@ __global__ __launch_bounds__(CTC_THREADS) void forward_sum_pass_kernel(int B, in
 #pragma unroll
       for (int q = 0; q < CTC_PD; ++q) {
         const int nn = n + q;
-        if (nn >= Tn) break;
-        const float l = lq[q];
-        if (act && nn + CTC_PD < Tn) lq[q] = lp(t_first + dt * (nn + CTC_PD), s);
-        if (act) {
-          const float v = step(prev, s, l);
-          cur[s] = v;
-          w[(int64_t)(t_first + dt * nn) * Spad + s] = v;
+        if (nn < Tn) {                          // workgroup-uniform (no `break`: the loop must unroll, lq[] lives in registers)
+          const float l = lq[q];
+          if (act && nn + CTC_PD < Tn) lq[q] = lp(t_first + dt * (nn + CTC_PD), s);
+          if (act) {
+            const float v = step(prev, s, l);
+            cur[s] = v;
+            w[(int64_t)(t_first + dt * nn) * Spad + s] = v;
+          }
+          lds_barrier();
+          float* tmp = prev; prev = cur; cur = tmp;
         }
-        lds_barrier();
-        float* tmp = prev; prev = cur; cur = tmp;
       }
     }
   } else {

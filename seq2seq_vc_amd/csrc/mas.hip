@@ -51,16 +51,27 @@ __global__ __launch_bounds__(64) void mas_kernel(int B, int Tf, int Tx, const fl
   for (int s = 0; s < S; ++s) q[s] = NINF;
   if (lane == 0) q[0] = (double)lp[0];
 
-  constexpr int U = 4;  // columns whose log-probs are fetched ahead of the dependent chain
-  for (int j0 = 1; j0 < T_mel; j0 += U) {
-    float val[U][S];
+  // The log-probs of U columns are fetched while the U columns before them run through the dependent chain (a group's loads used
+  // to be issued only after the previous group's last step: one exposed trip to L2 / HBM per U = 4 columns, ~0.4 us per column).
+  constexpr int U = 8;
+  float nxt[U][S];
+  auto fetch = [&](int j0) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const int i = s * 64 + lane, j = j0 + u;
-        val[u][s] = (j < T_mel && i < T_inp) ? lp[(int64_t)j * Tx + i] : 0.f;
+        nxt[u][s] = (j < T_mel && i < T_inp) ? lp[(int64_t)j * Tx + i] : 0.f;
       }
+  };
+  fetch(1);
+  for (int j0 = 1; j0 < T_mel; j0 += U) {
+    float val[U][S];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int s = 0; s < S; ++s) val[u][s] = nxt[u][s];
+    if (j0 + U < T_mel) fetch(j0 + U);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = j0 + u;
@@ -95,8 +106,32 @@ __global__ __launch_bounds__(64) void mas_kernel(int B, int Tf, int Tx, const fl
   }
   __syncthreads();
 
-  // backtrack: a sequential chain, done by lane 0
-  if (lane == 0) {
+  if (DEC_LDS) {
+    // backtrack: the sequential chain only walks the decision bits in LDS (one dependent LDS read per column); the path goes to
+    // HBM and the binarisation-loss gather lp[j, path[j]] runs afterwards on all lanes -- with the gather inside the chain every
+    // column paid a dependent global load (~0.4 us: 100 of the kernel's 133 us at T_mel = 256).  The sum's order changes
+    // (per-lane fp64 partial sums + a butterfly instead of one fp64 chain); the path and the durations are bit-identical.
+    if (lane == 0) {
+      int a = T_inp - 1;
+      pth_l[T_mel - 1] = a;
+      for (int j = T_mel - 2; j >= 0; --j) {
+        if (a != 0) {
+          const uint64_t w = dec_l[j * S + (a >> 6)];
+          if ((w >> (a & 63)) & 1ull) a = a - 1;
+        }
+        pth_l[j] = a;
+      }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int j = lane; j < T_mel; j += 64) {
+      const int a = pth_l[j];
+      pth[j] = a;
+      acc += (double)lp[(int64_t)j * Tx + a];
+    }
+    acc = wave_sum_d(acc);
+    if (lane == 0) binmean[b] = (float)(acc / (double)T_mel);
+  } else if (lane == 0) {
     int a = T_inp - 1;
     double acc = (double)lp[(int64_t)(T_mel - 1) * Tx + a];
     pth[T_mel - 1] = a;
