@@ -404,7 +404,8 @@ __global__ void convmod_wgrad_final_kernel(int C, int ks, int chunks, const floa
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float t = 0.f;
-  for (int k = 0; k < chunks; ++k) t += wsw[(int64_t)k * n + i];
+#pragma unroll 16
+  for (int k = 0; k < chunks; ++k) t += wsw[(int64_t)k * n + i];      // same order of additions, 16 loads in flight
   const int c = i / (ks + 1), j = i - c * (ks + 1);
   if (j < ks) {
     if (dw) dw[c * ks + j] = (accumulate ? dw[c * ks + j] : 0.f) + t;

@@ -228,7 +228,8 @@ __global__ void dwconv_wgrad_final_kernel(int n, int chunks, const float* __rest
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float t = 0.f;
-  for (int k = 0; k < chunks; ++k) t += ws[(int64_t)k * n + i];
+#pragma unroll 16
+  for (int k = 0; k < chunks; ++k) t += ws[(int64_t)k * n + i];        // same order of additions, 16 loads in flight
   dw[i] = (accumulate ? dw[i] : 0.f) + t;
 }
 

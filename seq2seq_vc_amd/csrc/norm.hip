@@ -378,7 +378,8 @@ __device__ __forceinline__ void colreduce_stage2_body(int D, int chunks, const f
   const int c = bx * 64 + cl;
   float t0 = 0.f, t1 = 0.f;
   if (c < D) {
-    for (int k = kg; k < chunks; k += 4) {
+#pragma unroll 8
+    for (int k = kg; k < chunks; k += 4) {        // same order of additions, 16 loads in flight
       t0 += ws[((int64_t)k * 2 + 0) * D + c];
       t1 += ws[((int64_t)k * 2 + 1) * D + c];
     }
@@ -505,7 +506,8 @@ __global__ __launch_bounds__(256) void bn_stage2_finalize_kernel(int C, int chun
   const int c = blockIdx.x * 64 + cl;
   float t0 = 0.f, t1 = 0.f;
   if (c < C) {
-    for (int k = kg; k < chunks; k += 4) {
+#pragma unroll 8
+    for (int k = kg; k < chunks; k += 4) {        // same order of additions, 16 loads in flight
       t0 += ws[((int64_t)k * 2 + 0) * C + c];
       t1 += ws[((int64_t)k * 2 + 1) * C + c];
     }
