@@ -266,7 +266,8 @@ __global__ void splitk_reduce_kernel(const s2svc_gemm_desc d) {
   const int64_t total = (int64_t)nbatch * d.M * d.N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int z = 0; z < d.splitk; ++z) s += d.ws[(int64_t)z * total + i];
+#pragma unroll 8
+    for (int z = 0; z < d.splitk; ++z) s += d.ws[(int64_t)z * total + i];      // the partials' loads in flight together, same order of additions
     const int n = (int)(i % d.N);
     const int64_t t = i / d.N;
     const int m = (int)(t % d.M);

@@ -152,7 +152,8 @@ def _dp_worker(rank, world, port, q):
     allreduce_end(h_hi)
     allreduce_end(h_lo)
     assert torch.allclose(flat2, flat, atol=1e-6), "bucketed async all-reduce != chunked mean all-reduce"
-    q.put((rank, w, wr.grad.clone(), flat))
+    # numpy arrays travel through the queue by value (torch tensors go through shared-memory handles that die with this process)
+    q.put((rank, w.detach().numpy().copy(), wr.grad.numpy().copy(), flat.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -168,7 +169,7 @@ def test_two_rank_gloo_gradient_allreduce_is_the_mean_of_rank_gradients():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, w0, g0, f0), (_, w1, g1, f1) = out
+    (_, w0, g0, f0), (_, w1, g1, f1) = [(r, *(torch.from_numpy(a) for a in rest)) for r, *rest in out]
     assert torch.equal(w0, w1), "broadcast must make the weights identical"
     assert torch.allclose(f0, (g0 + g1) / 2, atol=1e-6) and torch.equal(f0, f1)
 
@@ -187,10 +188,10 @@ def _rsag_worker(rank, world, port, q):
         buckets = [_RsAg(a[: n // 2], dist, world), _RsAg(a[n // 2:], dist, world)]      # two buckets in flight, slices of one buffer
         for b_ in buckets:
             b_.finish()
-        out.append((n, a.clone(), want))
+        out.append((n, a.numpy().copy(), want.numpy().copy()))       # by value through the queue (see _dp_worker)
     m = torch.arange(12, dtype=torch.float32) * (rank + 1)
     allreduce_mean_(m, dist, world, chunk_numel=5)
-    q.put((rank, out, m))
+    q.put((rank, out, m.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -210,6 +211,7 @@ def test_four_rank_gloo_reduce_scatter_all_gather_equals_all_reduce():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    res = [(rank, [(n, torch.from_numpy(g), torch.from_numpy(w_)) for n, g, w_ in out], torch.from_numpy(m)) for rank, out, m in res]
     for rank, out, m in res:
         for n, got, want in out:
             assert torch.allclose(got, want, rtol=1e-6, atol=1e-6), (rank, n)
