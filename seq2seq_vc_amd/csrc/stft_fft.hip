@@ -285,23 +285,26 @@ __device__ __forceinline__ void dft8(c32 (&u)[8]) {
   u[3] = cadd(e3, o3); u[7] = csub(e3, o3);
 }
 
-__global__ __launch_bounds__(64 * WAVES) void stft_logmel_fft8_kernel(fft8_args a) {
+// 4 frames per workgroup: ~170 VGPRs allow three waves per SIMD, i.e. three of these workgroups (41 KB of LDS each) per CU
+constexpr int WAVES8 = 4;
+
+__global__ __launch_bounds__(64 * WAVES8) __attribute__((amdgpu_waves_per_eu(3, 3))) void stft_logmel_fft8_kernel(fft8_args a) {
   constexpr int N = 1024, H = 512, BUF = 576;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2* wud = reinterpret_cast<float2*>(smem_raw);                          // [H + 1] (+ pad to 520)
   const int nseg = a.nmel + 1;
   int32_t* seg_lo = reinterpret_cast<int32_t*>(wud + 520);                    // [nmel + 1]
   int32_t* seg_len = seg_lo + nseg;
-  float* updn = reinterpret_cast<float*>(seg_len + nseg);                    // [WAVES][2][nmel + 1]
+  float* updn = reinterpret_cast<float*>(seg_len + nseg);                    // [WAVES8][2][nmel + 1]
   const int updn_n = (2 * (a.nmel + 1) + 3) & ~3;
-  c32* bufs = reinterpret_cast<c32*>(updn + WAVES * updn_n);
+  c32* bufs = reinterpret_cast<c32*>(updn + WAVES8 * updn_n);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   c32* bx = bufs + wave * 2 * BUF;
   c32* by = bx + BUF;
   float* up = updn + wave * updn_n;
   float* dn = up + a.nmel + 1;
-  for (int i = threadIdx.x; i < H + 1; i += 64 * WAVES) wud[i] = reinterpret_cast<const float2*>(a.wud)[i];
-  for (int i = threadIdx.x; i < nseg; i += 64 * WAVES) { seg_lo[i] = a.seg_lo[i]; seg_len[i] = a.seg_len[i]; }
+  for (int i = threadIdx.x; i < H + 1; i += 64 * WAVES8) wud[i] = reinterpret_cast<const float2*>(a.wud)[i];
+  for (int i = threadIdx.x; i < nseg; i += 64 * WAVES8) { seg_lo[i] = a.seg_lo[i]; seg_len[i] = a.seg_len[i]; }
   // per-lane constants
   const c32* w_half = reinterpret_cast<const c32*>(a.tables);
   const c32* w_full = w_half + H;
@@ -330,51 +333,70 @@ __global__ __launch_bounds__(64 * WAVES) void stft_logmel_fft8_kernel(fft8_args 
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
     maxlen[rd] = mx;
   }
-  const int gpb = (a.Tmax + WAVES - 1) / WAVES;
+  const int gpb = (a.Tmax + WAVES8 - 1) / WAVES8, total = a.B * gpb;
+  // raw samples (before the window) of this wave's frame of group g: two per lane and radix-8 leg; false = nothing to transform
+  auto load = [&](int g, float2 (&xv)[8]) -> bool {
+    if (g >= total) return false;
+    const int b = g / gpb, t = (g - b * gpb) * WAVES8 + wave;
+    if (t >= a.Tmax || t >= a.frames[b]) return false;
+    const float* xb = a.x + (int64_t)b * a.Nmax;
+    const int64_t n = a.nlen[b];
+    const int64_t s0 = (int64_t)t * a.hop - H;
+    const bool inner = s0 >= 0 && s0 + N <= n;
+    if (inner && ((reinterpret_cast<uintptr_t>(xb + s0) & 7) == 0)) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xv[q] = *reinterpret_cast<const float2*>(xb + s0 + 2 * (lane + 64 * q));
+    } else {
+      const int64_t period = n > 1 ? 2 * (n - 1) : 1;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          int64_t j = s0 + 2 * (lane + 64 * q) + e;
+          if (!inner) {
+            if (n > 1) {
+              j %= period;
+              if (j < 0) j += period;
+              if (j >= n) j = period - j;
+            } else {
+              j = 0;
+            }
+          }
+          v[e] = xb[j];
+        }
+        xv[q] = make_float2(v[0], v[1]);
+      }
+    }
+    return true;
+  };
+  float2 cur[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) cur[q] = make_float2(0.f, 0.f);
+  bool have = load(blockIdx.x, cur);
 #pragma unroll 1
-  for (int g = blockIdx.x; g < a.B * gpb; g += gridDim.x) {
-    const int b = g / gpb, t = (g - b * gpb) * WAVES + wave;
-    if (t >= a.Tmax) continue;
+  for (int g = blockIdx.x; g < total; g += gridDim.x) {
+    // the next frame's samples travel while this one is transformed (a frame used to start with an exposed trip to L2 / HBM)
+    float2 nxt[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nxt[q] = make_float2(0.f, 0.f);
+    const bool have_next = load(g + gridDim.x, nxt);
+    const int b = g / gpb, t = (g - b * gpb) * WAVES8 + wave;
     float* orow = a.out + ((int64_t)b * a.Tmax + t) * a.nmel;
-    if (t >= a.frames[b]) {
-      for (int m = lane; m < a.nmel; m += 64) orow[m] = 0.f;
+    if (!have) {
+      if (t < a.Tmax)
+        for (int m = lane; m < a.nmel; m += 64) orow[m] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+      have = have_next;
       continue;
     }
     c32 u[8];
-    {
-      const float* xb = a.x + (int64_t)b * a.Nmax;
-      const int64_t n = a.nlen[b];
-      const int64_t s0 = (int64_t)t * a.hop - H;
-      const bool inner = s0 >= 0 && s0 + N <= n;
-      if (inner && ((reinterpret_cast<uintptr_t>(xb + s0) & 7) == 0)) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float2 xv = *reinterpret_cast<const float2*>(xb + s0 + 2 * (lane + 64 * q));
-          u[q] = {xv.x * wn[q].x, xv.y * wn[q].y};
-        }
-      } else {
-        const int64_t period = n > 1 ? 2 * (n - 1) : 1;
+    for (int q = 0; q < 8; ++q) u[q] = {cur[q].x * wn[q].x, cur[q].y * wn[q].y};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float v[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            int64_t j = s0 + 2 * (lane + 64 * q) + e;
-            if (!inner) {
-              if (n > 1) {
-                j %= period;
-                if (j < 0) j += period;
-                if (j >= n) j = period - j;
-              } else {
-                j = 0;
-              }
-            }
-            v[e] = xb[j];
-          }
-          u[q] = {v[0] * wn[q].x, v[1] * wn[q].y};
-        }
-      }
-    }
+    for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+    have = have_next;
     // ---- pass 1 (p = 1): butterfly i = lane on the loaded points (i + 64 r); outputs dst[8 i + r]
     dft8(u);
     {
@@ -481,17 +503,17 @@ extern "C" int s2svc_stft_logmel_fft8(int B, int64_t Nmax, int Tmax, int hop, in
   a.seg_lo = seg_lo; a.seg_len = seg_len; a.wud = wud; a.eps = eps; a.inv_log_base = inv_log_base; a.mean = mean; a.inv_scale = inv_scale;
   a.out = out;
   const int updn_n = (2 * (nmel + 1) + 3) & ~3;
-  const size_t lds = 520 * 8 + (size_t)(nmel + 1) * 8 + (size_t)WAVES * updn_n * 4 + (size_t)WAVES * 2 * 576 * 8;
+  const size_t lds = 520 * 8 + (size_t)(nmel + 1) * 8 + (size_t)WAVES8 * updn_n * 4 + (size_t)WAVES8 * 2 * 576 * 8;
   static size_t attr_set = 0;
   if (lds > 64 * 1024 && attr_set < lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(stft_logmel_fft8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess) { s2svc_set_error("stft_logmel_fft8: cannot raise the dynamic LDS limit"); return -2; }
     attr_set = lds;
   }
-  const int groups = B * ((Tmax + WAVES - 1) / WAVES);
+  const int groups = B * ((Tmax + WAVES8 - 1) / WAVES8);
   const int per_cu = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;
-  const int resident = 256 * (per_cu < 4 ? per_cu : 4);
-  hipLaunchKernelGGL(stft_logmel_fft8_kernel, dim3(groups < resident ? groups : resident), dim3(64 * WAVES), lds, (hipStream_t)stream, a);
+  const int resident = 256 * (per_cu < 3 ? per_cu : 3);
+  hipLaunchKernelGGL(stft_logmel_fft8_kernel, dim3(groups < resident ? groups : resident), dim3(64 * WAVES8), lds, (hipStream_t)stream, a);
   S2S_CHECK_LAUNCH("stft_logmel_fft8_kernel");
   return 0;
 }
