@@ -14,8 +14,11 @@
 //     bd[il][63 - il + j]      (il = row inside the block)
 // is, in the MFMA accumulator layout (row = 4 lg + r, column = lr of a 16 x 16 tile), a ROTATION of the 16 columns inside a
 // lane group by 15 - 4 lg - r, with the wrapped lanes taking the next tile: one ds_bpermute per accumulator register, no trip
-// through memory.  Operands are streamed through LDS in 32-wide slices of d_k (global loads of slice s + 1 in flight while
-// slice s is multiplied); the probabilities leave through an LDS image of the tile in 16-byte stores.
+// through memory.  Operands (k, the position window, qu, qv) are streamed in 32-wide slices of d_k by LDS-DMA
+// (`global_load_lds_dwordx4`, swizzled lane-linear image as in gemm_glds.hip) through three LDS stages with counted
+// `s_waitcnt vmcnt(n)` + one raw barrier per slice: two slices are in flight while one is multiplied.  (A first version staged through
+// registers: the compiler waits for ALL outstanding loads at the top of the loop, so every slice paid a trip to L2 -- 2 us per slice.)
+// The probabilities leave through an LDS image of the tile in 16-byte stores.
 // Dropout masks are functions of (seed, element index of the attention map), the same function the separate kernels use.
 #include "common.h"
 #include "../../include/s2svc_hip.h"
@@ -25,7 +28,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 namespace {
 
-constexpr int RP = 40;        // LDS row pitch (elements) of a 32-wide operand slice: 80-byte rows
 constexpr int SP = 264;       // pitch of the [64][256] bf16 staging tiles
 constexpr float NEG = -3.4028234663852886e38f;
 
@@ -53,15 +55,39 @@ struct ra_fwd_args {
   bf16_t* qu; bf16_t* qv;       // (B, T, H * dk) contiguous
 };
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS image of a 32-wide operand slice, as the LDS-DMA instruction writes it (lane-linear, 64-byte rows) with the XOR swizzle of
+// gemm_glds.hip applied to the per-lane SOURCE address and to the fragment read: piece c of row r lives at r*64 + ((c ^ swz(r)) << 4).
+__device__ __forceinline__ int swz32(int r) { return (-(r >> 2)) & 3; }
+__device__ __forceinline__ int frag_off(int r, int c) { return r * 64 + ((c ^ swz32(r)) << 4); }
+
+// Workgroups are handed to the 8 XCDs round-robin in linear id order, and each XCD has its own L2.  The row blocks of one
+// (utterance, head) stream the SAME k / v rows (and position window): map them to one XCD so that its L2 fetches them once
+// (identity mapping: the 4 row blocks of a pair land on 4 XCDs and every one of them pulls the pair's operands over the fabric).
+__device__ __forceinline__ void block_of(int& rb, int& pair) {
+  const int nrb = gridDim.x, npairs = gridDim.y, total = nrb * npairs;
+  const int n = blockIdx.x + nrb * blockIdx.y;
+  rb = blockIdx.x;
+  pair = blockIdx.y;
+  if ((total & 7) == 0 && ((total >> 3) % nrb) == 0) {
+    const int xcd = n & 7, slot = n >> 3;
+    pair = (slot / nrb) * 8 + xcd;
+    rb = slot - (slot / nrb) * nrb;
+  }
+}
+
+constexpr int ST_K = 0, ST_P = 256 * 64, ST_QU = ST_P + 320 * 64, ST_QV = ST_QU + 64 * 64, ST_BYTES = ST_QV + 64 * 64;   // 45,056 B
+constexpr int FWD_STAGES = 3;
+
 __global__ __launch_bounds__(256) void relattn_fwd_kernel(const ra_fwd_args a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Kc = reinterpret_cast<bf16_t*>(smem);      // [256][RP] keys
-  bf16_t* Pc = Kc + 256 * RP;                        // [320][RP] position window
-  bf16_t* QU = Pc + 320 * RP;                        // [64][RP]
-  bf16_t* QV = QU + 64 * RP;                         // [64][RP]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int T = a.T, dk = a.dk, H = a.H;
-  const int i0 = blockIdx.x * 64;
-  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  int rb_, bh;
+  block_of(rb_, bh);
+  const int i0 = rb_ * 64;
+  const int b = bh / H, h = bh % H;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lg = lane >> 4;
   const int c0 = T - 64 - i0;
   const int D = H * dk;
@@ -69,45 +95,61 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const ra_fwd_args a) {
   const bf16_t* qg = a.q + (int64_t)b * a.qbs + h * dk;
   const bf16_t* pg = a.pos + h * dk;
   const int nsteps = dk / 32;
-  const int qrow = t >> 2, c4 = t & 3;
-
-  struct stage_regs { uint4 rk[4], rp[5], rq; float bu[8], bv[8]; };
-  auto issue = [&](int s, stage_regs& R) {
-    const int d0 = s * 32 + c4 * 8;
+  // ---- qu = q + pos_bias_u, qv = q + pos_bias_v for this block's rows: written once (the backward GEMMs read them too) and then
+  //      streamed back as MFMA operands like k and pos
+  {
+    const int vpr = dk >> 3;                          // 16-byte vectors per row
+#pragma unroll 2
+    for (int idx = t; idx < 64 * vpr; idx += 256) {
+      const int row = idx / vpr, c8 = idx - row * vpr;
+      const int i = i0 + row;
+      if (i < T) {
+        float f[8], fu[8], fv[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(qg + (int64_t)i * a.ldq + c8 * 8), f);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (t + 256 * i) >> 2;
-      R.rk[i] = make_uint4(0, 0, 0, 0);
-      if (row < T) R.rk[i] = *reinterpret_cast<const uint4*>(kg + (int64_t)row * a.ldk + d0);
+        for (int e = 0; e < 8; ++e) { fu[e] = f[e] + a.u[h * dk + c8 * 8 + e]; fv[e] = f[e] + a.v[h * dk + c8 * 8 + e]; }
+        const int64_t o = ((int64_t)b * T + i) * D + h * dk + c8 * 8;
+        *reinterpret_cast<uint4*>(a.qu + o) = pack_bf16x8(fu);
+        *reinterpret_cast<uint4*>(a.qv + o) = pack_bf16x8(fv);
+      }
     }
+  }
+  __syncthreads();                                    // the stores are acknowledged (vmcnt) before any wave streams them back
+  // ---- LDS-DMA pipeline: three stages, two slices in flight, counted waits.  Rows outside the utterance / the position table
+  //      are CLAMPED, not zeroed: keys j >= T are masked, position rows outside [0, L) only meet scores with j < 0 or j >= T,
+  //      query rows >= T are never stored.  Every wave issues exactly 11 DMA instructions per slice (4 k, 5 pos, qu, qv).
+  const int wu = __builtin_amdgcn_readfirstlane(w);   // scalar: the LDS destinations (M0) stay on the SALU
+  const char* kbase = reinterpret_cast<const char*>(kg);
+  const char* pbase = reinterpret_cast<const char*>(pg);
+  const char* ubase = reinterpret_cast<const char*>(a.qu + (int64_t)b * T * D + h * dk);
+  const char* vbase = reinterpret_cast<const char*>(a.qv + (int64_t)b * T * D + h * dk);
+  int64_t koff[4], poff[5], qoff;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int c = c0 + ((t + 256 * i) >> 2);
-      R.rp[i] = make_uint4(0, 0, 0, 0);
-      if (c >= 0 && c < a.L) R.rp[i] = *reinterpret_cast<const uint4*>(pg + (int64_t)c * a.ldp + d0);
-    }
-    R.rq = make_uint4(0, 0, 0, 0);
-    if (i0 + qrow < T) R.rq = *reinterpret_cast<const uint4*>(qg + (int64_t)(i0 + qrow) * a.ldq + d0);
+  for (int i = 0; i < 4; ++i) {
+    const int r = (w * 4 + i) * 16 + (lane >> 2);
+    koff[i] = ((int64_t)min(r, T - 1) * a.ldk + (((lane & 3) ^ swz32(r)) << 3)) * 2;
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { R.bu[e] = a.u[h * dk + d0 + e]; R.bv[e] = a.v[h * dk + d0 + e]; }
-  };
-  auto put = [&](int s, const stage_regs& R) {
+  for (int i = 0; i < 5; ++i) {
+    const int r = (w * 5 + i) * 16 + (lane >> 2);
+    const int c = min(max(c0 + r, 0), a.L - 1);
+    poff[i] = ((int64_t)c * a.ldp + (((lane & 3) ^ swz32(r)) << 3)) * 2;
+  }
+  {
+    const int r = w * 16 + (lane >> 2);
+    qoff = ((int64_t)min(i0 + r, T - 1) * D + (((lane & 3) ^ swz32(r)) << 3)) * 2;
+  }
+  auto issue = [&](int s, int stage) {
+    unsigned char* st = smem + stage * ST_BYTES;
+    const int64_t dB = (int64_t)s * 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Kc + ((t + 256 * i) >> 2) * RP + c4 * 8) = R.rk[i];
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(kbase + koff[i] + dB), (lds_void*)(st + ST_K + (wu * 4 + i) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) *reinterpret_cast<uint4*>(Pc + ((t + 256 * i) >> 2) * RP + c4 * 8) = R.rp[i];
-    float f[8], fu[8], fv[8];
-    unpack_bf16x8(R.rq, f);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { fu[e] = f[e] + R.bu[e]; fv[e] = f[e] + R.bv[e]; }
-    const uint4 vu = pack_bf16x8(fu), vv = pack_bf16x8(fv);
-    *reinterpret_cast<uint4*>(QU + qrow * RP + c4 * 8) = vu;
-    *reinterpret_cast<uint4*>(QV + qrow * RP + c4 * 8) = vv;
-    if (i0 + qrow < T) {
-      const int64_t o = ((int64_t)b * T + i0 + qrow) * D + h * dk + s * 32 + c4 * 8;
-      *reinterpret_cast<uint4*>(a.qu + o) = vu;
-      *reinterpret_cast<uint4*>(a.qv + o) = vv;
-    }
+    for (int i = 0; i < 5; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(pbase + poff[i] + dB), (lds_void*)(st + ST_P + (wu * 5 + i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(ubase + qoff + dB), (lds_void*)(st + ST_QU + wu * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + qoff + dB), (lds_void*)(st + ST_QV + wu * 1024), 16, 0, 0);
   };
 
   f32x4_t ac[4][4], bd[4][5];
@@ -118,42 +160,43 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const ra_fwd_args a) {
 #pragma unroll
     for (int tn = 0; tn < 5; ++tn) bd[rt][tn] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
-  // one slice: registers -> LDS, loads of slice s + 2 into the freed registers, 36 MFMAs per wave
-  auto step = [&](int s, stage_regs& R) {
-    __syncthreads();
-    put(s, R);
-    __syncthreads();
-    if (s + 2 < nsteps) issue(s + 2, R);
+  issue(0, 0);
+  issue(nsteps > 1 ? 1 : 0, 1);                       // slices past the end are re-issued copies: the counted waits stay exact
+  int cur = 0;
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt<11>();                                 // slice s has landed (this wave's part); slice s + 1 may still be moving
+    __builtin_amdgcn_s_barrier();                     // ... for every wave; and everyone is done reading slice s - 1
+    {
+      int nxt = cur + 2;
+      if (nxt >= FWD_STAGES) nxt -= FWD_STAGES;
+      issue(s + 2 < nsteps ? s + 2 : nsteps - 1, nxt);
+    }
+    const unsigned char* st = smem + cur * ST_BYTES;
     bf16x8_t qa[4], qb[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      qa[rt] = *reinterpret_cast<const bf16x8_t*>(QU + (rt * 16 + lr) * RP + lg * 8);
-      qb[rt] = *reinterpret_cast<const bf16x8_t*>(QV + (rt * 16 + lr) * RP + lg * 8);
+      qa[rt] = *reinterpret_cast<const bf16x8_t*>(st + ST_QU + frag_off(rt * 16 + lr, lg));
+      qb[rt] = *reinterpret_cast<const bf16x8_t*>(st + ST_QV + frag_off(rt * 16 + lr, lg));
     }
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
-      const bf16x8_t kb = *reinterpret_cast<const bf16x8_t*>(Kc + (64 * w + jt * 16 + lr) * RP + lg * 8);
+      const bf16x8_t kb = *reinterpret_cast<const bf16x8_t*>(st + ST_K + frag_off(64 * w + jt * 16 + lr, lg));
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) ac[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[rt], kb, ac[rt][jt], 0, 0, 0);
     }
 #pragma unroll
     for (int uu = 0; uu < 8; ++uu) {
-      const bf16x8_t pb = *reinterpret_cast<const bf16x8_t*>(Pc + ((4 * w + uu) * 16 + lr) * RP + lg * 8);
+      const bf16x8_t pb = *reinterpret_cast<const bf16x8_t*>(st + ST_P + frag_off((4 * w + uu) * 16 + lr, lg));
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const int tn = uu - 3 + rt;
         if (tn >= 0 && tn < 5) bd[rt][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb[rt], pb, bd[rt][tn], 0, 0, 0);
       }
     }
-  };
-  stage_regs RA, RB;
-  issue(0, RA);
-  if (nsteps > 1) issue(1, RB);
-#pragma unroll 1
-  for (int s = 0; s < nsteps; s += 2) {
-    step(s, RA);
-    if (s + 1 < nsteps) step(s + 1, RB);
+    cur = cur + 1 == FWD_STAGES ? 0 : cur + 1;
   }
+  wait_vmcnt<0>();                                   // the copies issued past the end
   __syncthreads();                                   // operand slices are dead: LDS becomes the score tile
   // ---- shift, scale, mask -> fp32 score tile S[64][SF] in LDS.  Row il of S is later overwritten, by the wave that owns it,
   //      with the bf16 rows of the map (first half of the row's bytes) and of its dropped copy (second half): SF * 4 = 2 * SP * 2.
@@ -196,7 +239,7 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const ra_fwd_args a) {
     for (int c = 0; c < 4; ++c) { val[c] = expf(val[c] - mx); sum += val[c]; }
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
-    const int64_t arow = ((int64_t)blockIdx.y * T + i0 + il) * a.ld;
+    const int64_t arow = ((int64_t)bh * T + i0 + il) * a.ld;
     bf16_t* rowA = reinterpret_cast<bf16_t*>(S + il * SF);     // LDS operations of one wave execute in order: the row was read above
     bf16_t* rowD = rowA + SP;
 #pragma unroll
@@ -217,7 +260,7 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const ra_fwd_args a) {
   for (int n = t; n < 64 * 32; n += 256) {
     const int row = n >> 5, c8 = n & 31;
     if (i0 + row < T && c8 < nv) {
-      const int64_t o = ((int64_t)blockIdx.y * T + i0 + row) * a.ld + c8 * 8;
+      const int64_t o = ((int64_t)bh * T + i0 + row) * a.ld + c8 * 8;
       const bf16_t* rowA = reinterpret_cast<const bf16_t*>(S + row * SF);
       *reinterpret_cast<uint4*>(a.attn + o) = *reinterpret_cast<const uint4*>(rowA + c8 * 8);
       if (a.pdrop) *reinterpret_cast<uint4*>(a.pdrop + o) = *reinterpret_cast<const uint4*>(rowA + SP + c8 * 8);
@@ -235,60 +278,70 @@ struct ra_bwd_args {
   bf16_t* ds; bf16_t* dbd;
 };
 
+constexpr int SB_V = 0, SB_O = 256 * 64, SB_BYTES = SB_O + 64 * 64;      // 20,480 B per stage
+
 __global__ __launch_bounds__(256) void relattn_bwd_kernel(const ra_bwd_args a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* Vc = reinterpret_cast<bf16_t*>(smem);      // [256][RP]
-  bf16_t* Oc = Vc + 256 * RP;                        // [64][RP]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int T = a.T, dk = a.dk, H = a.H;
-  const int i0 = blockIdx.x * 64;
-  const int b = blockIdx.y / H, h = blockIdx.y % H;
+  int rb_, bh;
+  block_of(rb_, bh);
+  const int i0 = rb_ * 64;
+  const int b = bh / H, h = bh % H;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lg = lane >> 4;
-  const bf16_t* vg = a.v + (int64_t)b * a.vbs + h * dk;
-  const bf16_t* og = a.dctx + (int64_t)b * a.obs + h * dk;
   const int nsteps = dk / 32;
-  const int qrow = t >> 2, c4 = t & 3;
-  struct stage_regs { uint4 rv[4], ro; };
-  auto issue = [&](int s, stage_regs& R) {
-    const int d0 = s * 32 + c4 * 8;
+  // LDS-DMA pipeline as in the forward kernel: v rows (keys) and this block's dctx rows, 5 DMA instructions per wave and slice;
+  // clamped rows (P is 0 at keys j >= T, rows i >= T are never stored)
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const char* vbase = reinterpret_cast<const char*>(a.v + (int64_t)b * a.vbs + h * dk);
+  const char* obase = reinterpret_cast<const char*>(a.dctx + (int64_t)b * a.obs + h * dk);
+  int64_t voff[4], ooff;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (t + 256 * i) >> 2;
-      R.rv[i] = make_uint4(0, 0, 0, 0);
-      if (row < T) R.rv[i] = *reinterpret_cast<const uint4*>(vg + (int64_t)row * a.ldv + d0);
-    }
-    R.ro = make_uint4(0, 0, 0, 0);
-    if (i0 + qrow < T) R.ro = *reinterpret_cast<const uint4*>(og + (int64_t)(i0 + qrow) * a.ldo + d0);
+  for (int i = 0; i < 4; ++i) {
+    const int r = (w * 4 + i) * 16 + (lane >> 2);
+    voff[i] = ((int64_t)min(r, T - 1) * a.ldv + (((lane & 3) ^ swz32(r)) << 3)) * 2;
+  }
+  {
+    const int r = w * 16 + (lane >> 2);
+    ooff = ((int64_t)min(i0 + r, T - 1) * a.ldo + (((lane & 3) ^ swz32(r)) << 3)) * 2;
+  }
+  auto issue = [&](int s, int stage) {
+    unsigned char* st = smem + stage * SB_BYTES;
+    const int64_t dB = (int64_t)s * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + voff[i] + dB), (lds_void*)(st + SB_V + (wu * 4 + i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(obase + ooff + dB), (lds_void*)(st + SB_O + wu * 1024), 16, 0, 0);
   };
   f32x4_t dp[4][4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) dp[rt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  auto step = [&](int s, stage_regs& R) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Vc + ((t + 256 * i) >> 2) * RP + c4 * 8) = R.rv[i];
-    *reinterpret_cast<uint4*>(Oc + qrow * RP + c4 * 8) = R.ro;
-    __syncthreads();
-    if (s + 2 < nsteps) issue(s + 2, R);
+  issue(0, 0);
+  issue(nsteps > 1 ? 1 : 0, 1);
+  int cur = 0;
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt<5>();
+    __builtin_amdgcn_s_barrier();
+    {
+      int nxt = cur + 2;
+      if (nxt >= FWD_STAGES) nxt -= FWD_STAGES;
+      issue(s + 2 < nsteps ? s + 2 : nsteps - 1, nxt);
+    }
+    const unsigned char* st = smem + cur * SB_BYTES;
     bf16x8_t oa[4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) oa[rt] = *reinterpret_cast<const bf16x8_t*>(Oc + (rt * 16 + lr) * RP + lg * 8);
+    for (int rt = 0; rt < 4; ++rt) oa[rt] = *reinterpret_cast<const bf16x8_t*>(st + SB_O + frag_off(rt * 16 + lr, lg));
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
-      const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(Vc + (64 * w + jt * 16 + lr) * RP + lg * 8);
+      const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(st + SB_V + frag_off(64 * w + jt * 16 + lr, lg));
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) dp[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[rt], vb, dp[rt][jt], 0, 0, 0);
     }
-  };
-  stage_regs RA, RB;
-  issue(0, RA);
-  if (nsteps > 1) issue(1, RB);
-#pragma unroll 1
-  for (int s = 0; s < nsteps; s += 2) {
-    step(s, RA);
-    if (s + 1 < nsteps) step(s + 1, RB);
+    cur = cur + 1 == FWD_STAGES ? 0 : cur + 1;
   }
+  wait_vmcnt<0>();
   __syncthreads();
   // ---- dP -> fp32 tile DP[64][SP] in LDS.  Row il of DP is later overwritten, by the wave that owns it, with row il of dbd
   //      (bf16, pitch 2 * SP elements = the same bytes): no second tile, no barrier in between.
@@ -306,7 +359,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_kernel(const ra_bwd_args a) {
     const int row = n >> 5, c8 = n & 31;
     uint4 pvv = make_uint4(0, 0, 0, 0), gvv = make_uint4(0, 0, 0, 0);
     if (i0 + row < T && c8 < nv) {
-      const int64_t o = ((int64_t)blockIdx.y * T + i0 + row) * a.ld + c8 * 8;
+      const int64_t o = ((int64_t)bh * T + i0 + row) * a.ld + c8 * 8;
       pvv = *reinterpret_cast<const uint4*>(a.attn + o);
       if (a.dattn) gvv = *reinterpret_cast<const uint4*>(a.dattn + o);
     }
@@ -320,7 +373,7 @@ __global__ __launch_bounds__(256) void relattn_bwd_kernel(const ra_bwd_args a) {
 #pragma unroll 1
   for (int rr = 0; rr < 16; ++rr) {
     const int il = w * 16 + rr, i = i0 + il;
-    const int64_t arow = ((int64_t)blockIdx.y * T + i) * a.ld;
+    const int64_t arow = ((int64_t)bh * T + i) * a.ld;
     float pv[4], tt[4];
     float dot = 0.f;
 #pragma unroll
@@ -347,12 +400,12 @@ __global__ __launch_bounds__(256) void relattn_bwd_kernel(const ra_bwd_args a) {
   for (int n = t; n < 64 * 32; n += 256) {
     const int row = n >> 5, c8 = n & 31;
     if (i0 + row < T && c8 < nv)
-      *reinterpret_cast<uint4*>(a.ds + ((int64_t)blockIdx.y * T + i0 + row) * a.ld + c8 * 8) = *reinterpret_cast<const uint4*>(stP + row * SP + c8 * 8);
+      *reinterpret_cast<uint4*>(a.ds + ((int64_t)bh * T + i0 + row) * a.ld + c8 * 8) = *reinterpret_cast<const uint4*>(stP + row * SP + c8 * 8);
   }
   for (int n = t; n < 64 * nb; n += 256) {
     const int row = n / nb, c8 = n - row * nb;
     if (i0 + row < T)
-      *reinterpret_cast<uint4*>(a.dbd + ((int64_t)blockIdx.y * T + i0 + row) * a.Lq + c8 * 8) =
+      *reinterpret_cast<uint4*>(a.dbd + ((int64_t)bh * T + i0 + row) * a.Lq + c8 * 8) =
           *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(DP + row * SP) + c8 * 8);
   }
 }
@@ -383,7 +436,7 @@ extern "C" int s2svc_relattn_fwd(int B, int H, int T, int dk, const void* q, int
   a.q = (const bf16_t*)q; a.ldq = ldq; a.qbs = qbs; a.k = (const bf16_t*)k; a.ldk = ldk; a.kbs = kbs;
   a.pos = (const bf16_t*)pos; a.ldp = ldp; a.u = u; a.v = v; a.klen = klen; a.scale = scale; a.p = drop_p;
   a.seed_base = seed_base; a.seed_off = seed_off; a.attn = (bf16_t*)attn; a.pdrop = (bf16_t*)pdrop; a.qu = (bf16_t*)qu; a.qv = (bf16_t*)qv;
-  const size_t lds = (size_t)64 * SP * 4;                          // the score tile (67,584 B) >= the operand slices (56,320 B)
+  const size_t lds = (size_t)FWD_STAGES * ST_BYTES;                 // three operand stages (135,168 B) >= the score tile (67,584 B)
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(relattn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -413,7 +466,7 @@ extern "C" int s2svc_relattn_bwd(int B, int H, int T, int dk, const void* dctx, 
   a.dctx = (const bf16_t*)dctx; a.ldo = ldo; a.obs = obs; a.v = (const bf16_t*)v; a.ldv = ldv; a.vbs = vbs;
   a.attn = (const bf16_t*)attn; a.dattn = (const bf16_t*)dattn; a.scale = scale; a.p = drop_p; a.seed_base = seed_base;
   a.seed_off = seed_off; a.ds = (bf16_t*)ds; a.dbd = (bf16_t*)dbd;
-  const size_t lds = (size_t)64 * SP * 4 + (size_t)64 * SP * 2 * (dattn ? 2 : 1);     // dP / dbd tile + P (+ external gradient)
+  const size_t lds = (size_t)64 * SP * 4 + (size_t)64 * SP * 2 * (dattn ? 2 : 1);     // dP / dbd tile + P (+ external gradient) >= 3 operand stages (61,440 B)
   static size_t attr_set = 0;
   if (attr_set < lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(relattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
