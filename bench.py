@@ -695,8 +695,13 @@ def bench_memory_bound(dev):
     add("ln_fwd_vec (residual + dropout + LayerNorm)", 4 * rows * D * 2 + 8 * rows,
         lambda: K.layernorm_fwd(x, gamma, beta, 1e-12, res=res_, p=0.1, seed=seed), f"{rows} x {D} bf16: h, res in; s, y out")
     mean, rstd = torch.zeros(D, device=dev), torch.ones(D, device=dev)
-    add("bn_apply (BatchNorm apply + Swish)", 2 * rows * D * 2, lambda: K.bn_apply(x, mean, rstd, gamma, beta, act="swish"),
-        f"{rows} x {D} bf16 in, out")
+    from seq2seq_vc_amd.ops import kernels_aas as KA
+    add("bn_swish_apply (BatchNorm apply + Swish of the Conformer convolution module, csrc/convmod.hip)", 2 * rows * D * 2,
+        lambda: KA.bn_swish_apply(x, mean, rstd, gamma, beta), f"{rows} x {D} bf16 in, out")
+    y2 = torch.randn(16, 256, 2 * D, generator=g).to(dev, torch.bfloat16)
+    dww, dwb = torch.randn(D, 1, 15, generator=g).to(dev) * 0.2, torch.zeros(D, device=dev)
+    add("convmod_fwd (GLU + depthwise conv k15 + batch statistics, csrc/convmod.hip; 2 launches)", 3 * rows * D * 2,
+        lambda: KA.convmod_fwd(y2, dww, dwb, 15, 1e-5, 0.1), f"16 x 256 x {2 * D} bf16 in, 16 x 256 x {D} out")
     B, H, T = 16, 2, 256
     sc = torch.randn(B, H, T, T, generator=g).to(dev)
     klen = torch.full((B,), T, dtype=torch.int32, device=dev)

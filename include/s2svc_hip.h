@@ -264,6 +264,10 @@ int s2svc_interp_nearest(int dtype, int B, int Tin, int Tout, int C, const void*
 int s2svc_interp_nearest_bwd(int dtype, int B, int Tin, int Tout, int C, const void* dy, void* dx, void* stream);
 int s2svc_dwconv(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const float* w, const float* bias,
                  void* y, int flip, void* stream);
+/* y = dwconv(x) + add (add: a tensor of y's shape or NULL): the data gradient of a depthwise convolution whose input also feeds a
+   residual connection (flow.py:148-190) takes the residual's gradient along instead of a separate add. */
+int s2svc_dwconv_add(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const float* w, const float* bias,
+                     const void* add, void* y, int flip, void* stream);
 int s2svc_dwconv_wgrad(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const void* dy, float* dw,
                        int accumulate, float* ws, int ws_chunks, void* stream);
 

@@ -144,6 +144,7 @@ _SIGS = {
     "s2svc_interp_nearest": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_interp_nearest_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_dwconv": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
+    "s2svc_dwconv_add": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_dwconv_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "s2svc_convmod_supported": [c_i32, c_i32],
     "s2svc_convmod_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],

@@ -62,7 +62,7 @@ template <> struct DwVec<float> {
 template <typename T, int TT>
 __global__ __launch_bounds__(256) void dwconv_fwd_vec_kernel(int Tn, int C, int ks, int dil, const T* __restrict__ x,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                             T* __restrict__ y, int flip, int tchunks) {
+                                                             T* __restrict__ y, int flip, int tchunks, const T* __restrict__ add) {
   constexpr int VEC = DwVec<T>::VEC;
   constexpr int CT = 8 * VEC;                 // channels per workgroup: 8 vector lanes
   extern __shared__ float sw[];               // [ks][CT] weights (tap-major), then [CT] bias
@@ -117,7 +117,15 @@ __global__ __launch_bounds__(256) void dwconv_fwd_vec_kernel(int Tn, int C, int 
   }
 #pragma unroll
   for (int o = 0; o < TT; ++o)
-    if (t0 + o < Tn) DwVec<T>::st(yb + (int64_t)(t0 + o) * C, acc[o]);
+    if (t0 + o < Tn) {
+      if (add) {                                   // y = conv + add (a second gradient of the same tensor rides along)
+        float f[VEC];
+        DwVec<T>::ld(add + (int64_t)b * Tn * C + c + (int64_t)(t0 + o) * C, f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[o][e] += f[e];
+      }
+      DwVec<T>::st(yb + (int64_t)(t0 + o) * C, acc[o]);
+    }
 }
 
 // partial dw[chunk][c][j] = sum over the chunk's rows of dy[b,t,c] * x[b, t+(j-pad)*dil, c]
@@ -240,23 +248,34 @@ inline int ew_blocks(int64_t total) {
 
 }  // namespace
 
+extern "C" int s2svc_dwconv_add(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const float* w, const float* bias,
+                                const void* add, void* y, int flip, void* stream);
 // flip = 0: forward.  flip = 1: data gradient (same kernel on dy with reversed taps, no bias).
 extern "C" int s2svc_dwconv(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const float* w,
                             const float* bias, void* y, int flip, void* stream) {
+  return s2svc_dwconv_add(dtype, B, Tn, C, ks, dil, x, w, bias, nullptr, y, flip, stream);
+}
+
+// y = dwconv(x) + add (add: same shape as y, or NULL).  Needs the vectorised kernel when add is given (C % 4 (fp32) / 8 (bf16) == 0,
+// 16-byte aligned tensors, ks <= 63).
+extern "C" int s2svc_dwconv_add(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const float* w, const float* bias,
+                                const void* add, void* y, int flip, void* stream) {
   const int64_t n = (int64_t)B * Tn * C;
   if (n == 0) return 0;
   S2S_REQUIRE(ks >= 1 && (ks & 1) && dil >= 1, "dwconv: kernel size must be odd, dilation >= 1");
   hipStream_t st = (hipStream_t)stream;
   const int vec = dtype == S2S_F32 ? 4 : 8;
-  if (C % vec == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && ks <= 63) {
+  const bool vec_ok = C % vec == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && ((uintptr_t)add) % 16 == 0 && ks <= 63;
+  S2S_REQUIRE(!add || vec_ok, "dwconv_add: the additive input needs the vectorised kernel (aligned tensors, C % 4 / 8 == 0)");
+  if (vec_ok) {
     constexpr int TT = 4;
     const int tchunks = (Tn + 32 * TT - 1) / (32 * TT);
     dim3 grid((C + 8 * vec - 1) / (8 * vec), B * tchunks);
     const size_t shm = (size_t)(ks + 1) * 8 * vec * sizeof(float);
     if (dtype == S2S_F32)
-      hipLaunchKernelGGL((dwconv_fwd_vec_kernel<float, TT>), grid, dim3(256), shm, st, Tn, C, ks, dil, (const float*)x, w, bias, (float*)y, flip, tchunks);
+      hipLaunchKernelGGL((dwconv_fwd_vec_kernel<float, TT>), grid, dim3(256), shm, st, Tn, C, ks, dil, (const float*)x, w, bias, (float*)y, flip, tchunks, (const float*)add);
     else
-      hipLaunchKernelGGL((dwconv_fwd_vec_kernel<bf16_t, TT>), grid, dim3(256), shm, st, Tn, C, ks, dil, (const bf16_t*)x, w, bias, (bf16_t*)y, flip, tchunks);
+      hipLaunchKernelGGL((dwconv_fwd_vec_kernel<bf16_t, TT>), grid, dim3(256), shm, st, Tn, C, ks, dil, (const bf16_t*)x, w, bias, (bf16_t*)y, flip, tchunks, (const bf16_t*)add);
     S2S_CHECK_LAUNCH("dwconv_fwd_vec_kernel");
     return 0;
   }

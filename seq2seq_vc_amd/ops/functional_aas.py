@@ -11,22 +11,37 @@ class _DwConv(Function):
     """Depthwise Conv1d on channel-last activations (conformer/convolution.py:42-51; vits/flow.py:137-146)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dil):
+    def forward(ctx, x, weight, bias, dil, passthrough=False):
+        """passthrough: also return x itself as a second output.  A caller whose x feeds BOTH this convolution and a residual
+        connection uses the second output for the residual: x then has one consumer, and the two gradients are summed inside the
+        data-gradient kernel (`add`) instead of by a separate element-wise add of the autograd engine."""
         x = _c(x)
         ks = weight.shape[-1]
         y = KA.dwconv(x, weight.detach(), bias.detach() if bias is not None else None, ks, dil)
         ctx.params = (weight, bias)
         ctx.meta = (ks, dil)
         ctx.save_for_backward(x)
+        if passthrough:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_pass=None):
+        if dy is None:                 # only the pass-through output was used
+            return g_pass, None, None, None, None
         (x,) = ctx.saved_tensors
         weight, bias = ctx.params
         ks, dil = ctx.meta
         dy = _c(dy)
-        dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if g_pass is not None and KA.dwconv_add_ok(dy, ks):
+                dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True, add=_c(g_pass))
+            else:
+                dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True)
+                if g_pass is not None:
+                    dx = dx + g_pass
         dw = db = None
         if weight.requires_grad:
             slot = getattr(weight, "_s2s_grad", None)
@@ -40,11 +55,16 @@ class _DwConv(Function):
                 _side_run(lambda: _reduce_to(bias, None, 0, dy2), keep=(dy2,))
             else:
                 db, _ = _reduce_to(bias, None, 0, dy2)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def dwconv1d(x, weight, bias=None, dilation=1):
     return _DwConv.apply(x, weight, bias, dilation)
+
+
+def dwconv1d_pass(x, weight, bias=None, dilation=1):
+    """-> (dwconv(x), x): use the second output wherever x is needed again (residual connection)."""
+    return _DwConv.apply(x, weight, bias, dilation, True)
 
 
 class _ConvModCore(Function):

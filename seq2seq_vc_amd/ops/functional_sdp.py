@@ -15,7 +15,10 @@ from torch.autograd import Function
 
 from . import kernels as K
 from . import kernels_sdp as KS
-from .functional import _c, _emit_vgrad, _reduce_to
+from .functional import _c, _emit_vgrad, _reduce_to, _side_run, _slotted
+
+
+_QUEUE_LN = __import__("os").environ.get("S2SVC_SDP_UNGROUPED", "0") != "1"      # A/B switch (also sdp.py: residual pass-through)
 
 
 class Shared:
@@ -59,6 +62,14 @@ class _Expand(Function):
         weight, bias = ctx.params
         dg, da = KS.expand_bwd(_c(dy), weight.detach().reshape(-1), ctx.lens)
         C = dg.shape[-1]
+        w_slot = getattr(weight, "_s2s_grad", None) if weight.requires_grad else None
+        b_slot = getattr(bias, "_s2s_grad", None) if (bias is not None and bias.requires_grad) else None
+        if _QUEUE_LN and w_slot is not None and b_slot is not None:
+            # straight into the gradient slots, queued: joins the grouped column reductions of the batch (was 2 + 2 launches)
+            dg2, a1 = dg.view(-1, C), a.view(-1)
+            _side_run(lambda: K.colreduce(5, dg2, mean=a1, want_dot=True, out_sum=b_slot.view(-1), out_dot=w_slot.view(-1), accumulate=True),
+                      keep=(dg2, a1))
+            return (da if ctx.needs_input_grad[0] else None), None, None, (dg if ctx.has_g else None), None, None
         db, dw = K.colreduce(5, dg.view(-1, C), mean=a.view(-1), want_dot=True)
         dw = _emit_vgrad(weight, dw) if weight.requires_grad else None
         db = _emit_vgrad(bias, db) if bias is not None and bias.requires_grad else None
@@ -89,7 +100,11 @@ class _LnAct(Function):
         eps, act, lens, T, p, seed, has_res = ctx.meta
         du, dx, dres = KS.ln_act_bwd(_c(dy), x, mean, rstd, gamma.detach(), beta.detach(), act, lens, T, p, seed, want_dres=has_res)
         D = x.shape[-1]
-        dbeta, dgamma = _reduce_to(beta, gamma, 1, du.view(-1, D), x.view(-1, D), mean, rstd)
+        du2, x2 = du.view(-1, D), x.view(-1, D)
+        if _slotted(gamma, beta) and _QUEUE_LN:       # queued: joins the grouped column reductions of the batch (two launches for up to 24 of them)
+            _side_run(lambda: _reduce_to(beta, gamma, 1, du2, x2, mean, rstd), keep=(du2, x2, mean, rstd))
+            return dx, None, None, None, None, dres, None, None, None
+        dbeta, dgamma = _reduce_to(beta, gamma, 1, du2, x2, mean, rstd)
         return dx, dgamma, dbeta, None, None, dres, None, None, None
 
 

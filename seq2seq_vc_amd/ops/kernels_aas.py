@@ -9,13 +9,18 @@ from .kernels import _DT, dt, ptr, stream
 _WS_CHUNKS = 64
 
 
-def dwconv(x, w, bias, ks, dil=1, flip=False):
-    """x (B,T,C) channel-last; w fp32 (C,1,k) contiguous; flip=True gives the data gradient of dy."""
+def dwconv(x, w, bias, ks, dil=1, flip=False, add=None):
+    """x (B,T,C) channel-last; w fp32 (C,1,k) contiguous; flip=True gives the data gradient of dy; add: a tensor of the output's
+    shape added to the result (needs the vectorised kernel: dwconv_add_ok)."""
     B, T, C = x.shape
     y = torch.empty_like(x)
-    _lib.check(_lib.lib().s2svc_dwconv(dt(x), B, T, C, ks, dil, ptr(x), ptr(w), ptr(bias), ptr(y), 1 if flip else 0, stream()),
-               "dwconv")
+    _lib.check(_lib.lib().s2svc_dwconv_add(dt(x), B, T, C, ks, dil, ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), 1 if flip else 0,
+                                           stream()), "dwconv")
     return y
+
+
+def dwconv_add_ok(x, ks):
+    return x.shape[-1] % (4 if x.dtype == torch.float32 else 8) == 0 and x.data_ptr() % 16 == 0 and ks <= 63
 
 
 def dwconv_wgrad(x, dy, ks, dil=1, out=None):
