@@ -370,6 +370,7 @@ class Workload:
         else:
             self.model = M.AASVC(**AASVC_VC2).to(dev).train()
             self.l1, self.fs = L.L1Loss(), L.ForwardSumLoss()
+            self.model.forward_sum_prefetch = self.fs.prefetch          # as trainers.AASVCTrainer does
             self.loss_names = ["l1", "forward_sum", "bin", "dur_nll"]
             self.desc = ("AAS-VC egs/arctic/vc2 (aas_vc.melmelmel.v1.yaml) training step: fwd (incl. alignment search)"
                          "+L1+2*(forward-sum+bin)+duration NLL+bwd+clip+Adam+WarmupLR")
@@ -409,7 +410,7 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
     def begin():
         K.reset_op_counter()
         K.advance_seed(dev)
-        opt.zero_grad()
+        opt.begin_step()            # zero_grad + the refresh of the derived weight copies, beside the forward pass
 
     def fwd_bwd():
         begin()
@@ -417,6 +418,7 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
         total = None
         for v in losses.values():
             total = v if total is None else total + v
+        opt.join_prologue()
         total.backward()
         Fn.side_join()
 

@@ -209,6 +209,8 @@ class OverlappedBackward:
         buffer are final on the current stream."""
         roots = self.plan[i]["root"]
         branch_root = self.plan[i].get("branch_root")           # a loss whose sub-network ran on the auxiliary stream
+        if i == 0 and hasattr(self.opt, "join_prologue"):
+            self.opt.join_prologue()                             # zero-filled gradients + refreshed weight copies (FlatAdam.begin_step)
         fork = None
         if branch_root is not None and torch.cuda.is_available():
             fork = torch.cuda.Event()

@@ -1,5 +1,6 @@
 """AAS-VC losses: forward-sum (CTC over the attention matrix) and the duration-predictor MSE."""
 import math
+import os
 
 import torch
 
@@ -36,7 +37,30 @@ class ForwardSumLoss(torch.nn.Module):
         dev = log_p_attn.device
         il, ol = Lens.of(ilens, dev), Lens.of(olens, dev)
         _, Tf, Tx = log_p_attn.shape
+        pre = getattr(log_p_attn, "_s2s_fs", None)
+        if pre is not None and pre[2:] == (il.dev.data_ptr(), ol.dev.data_ptr(), blank_prob):
+            return FA.forward_sum_loss_prefetched(log_p_attn, pre[0], pre[1])
         return FA.forward_sum_loss(log_p_attn, self._prior(il, ol, Tf, Tx, dev), il.dev, ol.dev, blank_prob)
+
+    def prefetch(self, log_p_attn, ilens, olens, blank_prob: float = math.e ** -1):
+        """Hook for the model (AASVC.forward_sum_prefetch, set by the trainers): called in the training forward pass as soon as
+        the alignment module has produced `log_p_attn`.  The alpha recursion is T_feats dependent steps on one wavefront per
+        utterance (~150 us that leave the chip empty); here it runs on the auxiliary stream (ops.functional.branch_run) beside
+        the length regulator / decoder instead of after them, and forward() picks the result up from the tensor when it is
+        called with the same lengths.  The model's branch_join covers it."""
+        dev = log_p_attn.device
+        if dev.type != "cuda" or os.environ.get("S2SVC_FS_PREFETCH", "1") == "0":       # (A/B aid)
+            return
+        from ..ops import functional as Fn
+        il, ol = Lens.of(ilens, dev), Lens.of(olens, dev)
+        _, Tf, Tx = log_p_attn.shape
+        lp = log_p_attn.detach()
+
+        def run():
+            return KA.forward_sum(lp.float().contiguous(), self._prior(il, ol, Tf, Tx, dev), il.dev, ol.dev, blank_prob)
+
+        loss_b, grad = Fn.branch_run(run, uses=(lp, il.dev, ol.dev))
+        log_p_attn._s2s_fs = (loss_b, grad, il.dev.data_ptr(), ol.dev.data_ptr(), blank_prob)
 
 
 class _DurLoss(torch.autograd.Function):

@@ -18,6 +18,7 @@ from ..ops import functional_aas as FA
 from ..sdp import DurationPredictor, StochasticDurationPredictor
 
 MAX_DP_OUTPUT = 10
+_FBRANCH = os.environ.get("S2SVC_AAS_FBRANCH", "1") != "0"      # A/B aid: the alignment module's feature side on the auxiliary stream
 
 
 class AlignmentModule(nn.Module):
@@ -31,13 +32,20 @@ class AlignmentModule(nn.Module):
         self.f_conv2 = nn.Conv1d(adim, adim, kernel_size=3, padding=1)
         self.f_conv3 = nn.Conv1d(adim, adim, kernel_size=1, padding=0)
 
-    def forward(self, text, feats, text_lens=None):
-        """text (B,T_text,adim), feats (B,T_feats,odim), text_lens: Lens -> log_p_attn (B,T_feats,T_text) fp32."""
-        t = Fn.conv1d(text, self.t_conv1.weight, self.t_conv1.bias, act="relu")
-        t = Fn.linear(t, self.t_conv2.weight, self.t_conv2.bias)
+    def feats_branch(self, feats):
+        """The acoustic-feature side (f_conv1..3): depends on the target features only, so the training forward pass runs it on
+        the auxiliary stream beside the encoder (AASVC._forward) -- and autograd then runs its backward pass there too."""
         f = Fn.conv1d(feats, self.f_conv1.weight, self.f_conv1.bias, act="relu")
         f = Fn.conv1d(f, self.f_conv2.weight, self.f_conv2.bias, act="relu")
-        f = Fn.linear(f, self.f_conv3.weight, self.f_conv3.bias)
+        return Fn.linear(f, self.f_conv3.weight, self.f_conv3.bias)
+
+    def forward(self, text, feats, text_lens=None, f=None):
+        """text (B,T_text,adim), feats (B,T_feats,odim), text_lens: Lens -> log_p_attn (B,T_feats,T_text) fp32.
+        f: the result of feats_branch(feats) if the caller has it already."""
+        t = Fn.conv1d(text, self.t_conv1.weight, self.t_conv1.bias, act="relu")
+        t = Fn.linear(t, self.t_conv2.weight, self.t_conv2.bias)
+        if f is None:
+            f = self.feats_branch(feats)
         return FA.pairwise_logsoftmax(f, t, None if text_lens is None else text_lens.dev)
 
 
@@ -102,6 +110,9 @@ class AASVC(nn.Module):
         self.encoder_input_layer = encoder_input_layer
         self.duration_predictor_use_encoder_outputs = duration_predictor_use_encoder_outputs
         self.viterbi_func = viterbi_decode
+        # losses.ForwardSumLoss.prefetch of the criterion that will see `log_p_attn` (set by the trainers): the loss's dependent
+        # recursion then runs on the auxiliary stream beside the decoder
+        self.forward_sum_prefetch = None
         self.stochastic_duration_predictor_noise_scale = stochastic_duration_predictor_noise_scale
         if encoder_type != "conformer" or decoder_type != "conformer":
             raise NotImplementedError("only the conformer encoder/decoder of the vc2 recipes is supported")
@@ -189,6 +200,17 @@ class AASVC(nn.Module):
                 xs = xs[:, : -(tmax % er)]
             xs = xs.contiguous().view(b, tmax // er, dim * er)
             il = il.map(lambda v: v // er)
+        olr = ol
+        if dr > 1 and ys is not None:
+            b, tmax, dim = ys.shape
+            if tmax % dr != 0:
+                ys = ys[:, : -(tmax % dr)]
+            ys = ys.contiguous().view(b, tmax // dr, dim * dr)
+            olr = ol.map(lambda v: v // dr)
+        f_pre = None
+        if not is_inference and ys is not None and xs.is_cuda and _FBRANCH:
+            # the alignment module's feature side needs nothing from the encoder: auxiliary stream, beside it (forward and backward)
+            f_pre = Fn.branch_run(lambda: self.alignment_module.feats_branch(Fn.to_compute(ys)), uses=(ys,))
         hs, _ = self.encoder(Fn.to_compute(xs), il)
         hs = Fn.cut_point(hs, "encoder_out")
         if self.encoder_input_layer == "conv2d":
@@ -212,13 +234,6 @@ class AASVC(nn.Module):
 
         stochastic_training = (not is_inference) and self.duration_predictor_type == "stochastic"
         dpi = None if stochastic_training else dp_input()
-        olr = ol
-        if dr > 1 and ys is not None:
-            b, tmax, dim = ys.shape
-            if tmax % dr != 0:
-                ys = ys[:, : -(tmax % dr)]
-            ys = ys.contiguous().view(b, tmax // dr, dim * dr)
-            olr = ol.map(lambda v: v // dr)
         Tx = hs.shape[1]
         il_c = il.clamp(Tx)
         stochastic = self.duration_predictor_type == "stochastic"
@@ -243,7 +258,13 @@ class AASVC(nn.Module):
             hs = self.length_regulator(hs, dsf, None, il_c, T_feats)
             dec_lens = None
         else:
-            log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c)
+            if f_pre is not None:
+                Fn.branch_join(f_pre)
+                log_p_attn = self.alignment_module(hs, None, il_c, f=f_pre)
+            else:
+                log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c)
+            if self.forward_sum_prefetch is not None:
+                self.forward_sum_prefetch(log_p_attn, il, olr)
             ds, bin_loss = self.viterbi_func(log_p_attn, il_c, olr)
             if stochastic:
                 # ~330 small launches that depend on nothing the length regulator / decoder / postnet below produce: they
@@ -259,7 +280,7 @@ class AASVC(nn.Module):
         before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, self.odim)
         after = before if self.postnet is None else Fn.add_dropout(before, self.postnet(before), 0.0)
         ret["before_outs"], ret["after_outs"] = before, after
-        Fn.branch_join(ret.get("dur_nll"))
+        Fn.branch_join(ret.get("dur_nll"), *(getattr(log_p_attn, "_s2s_fs", None) or ())[:2])
         ret["ds"] = ds
         ret["ilens"] = Mo.tag_lens(self._lens_like(ilens, il.host), il)
         ret["bin_loss"] = bin_loss

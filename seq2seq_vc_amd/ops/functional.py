@@ -56,6 +56,8 @@ def _dgrad_operand(weight, w, n_out, n_in, dtype):
     K-contiguous and the GEMM runs on the all-DMA kernel; otherwise W is read row-contiguous (register transposes)."""
     wt = getattr(weight, "_s2s_bf16_t", None) if dtype == torch.bfloat16 else None
     if wt is not None:
+        weight._s2s_perm_registry.sync()       # the transposed shadow is refreshed by the step prologue (optim.FlatAdam.begin_step);
+        #                                        every tensor that carries `_s2s_bf16_t` carries the registry (optim.FlatAdam)
         return K.operand(wt, n_out)
     return K.operand(w, n_in, layout=K.RC)
 

@@ -222,6 +222,28 @@ def forward_sum_loss(log_p_attn, prior, text_lens_i32, feat_lens_i32, blank_prob
     return _ForwardSum.apply(log_p_attn, prior, text_lens_i32, feat_lens_i32, blank_prob)
 
 
+class _ForwardSumPrefetched(Function):
+    """The same loss from per-utterance losses / the gradient that losses.ForwardSumLoss.prefetch computed on the auxiliary
+    stream beside the decoder (same kernels, same inputs: same bits)."""
+
+    @staticmethod
+    def forward(ctx, log_p_attn, loss_b, grad):
+        ctx.save_for_backward(grad)
+        ctx.in_dtype = log_p_attn.dtype
+        return loss_b.sum() / log_p_attn.shape[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        gs = _c(g.float()).reshape(1).expand(grad.shape[0] * grad.shape[1]).contiguous()
+        out = KA.rowscale(grad.view(-1, grad.shape[-1]), gs).view_as(grad)
+        return out.to(ctx.in_dtype), None, None
+
+
+def forward_sum_loss_prefetched(log_p_attn, loss_b, grad):
+    return _ForwardSumPrefetched.apply(log_p_attn, loss_b, grad)
+
+
 class _InterpNearest(Function):
     @staticmethod
     def forward(ctx, x, Tout):

@@ -39,6 +39,7 @@ def _w(t):
 
 
 def _wt(t):
+    t._s2s_perm_registry.sync()            # refreshed by the step prologue (optim.FlatAdam.begin_step)
     return t._s2s_bf16_t
 
 

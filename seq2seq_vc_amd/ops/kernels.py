@@ -592,6 +592,46 @@ def embedding_bwd(idx, dy, V, padding_idx, out=None, accumulate=False):
     return dw
 
 
+class PermRegistry(list):
+    """The derived weight copies one optimiser (optim.FlatAdam) keeps fresh -- the permuted convolution weights registered
+    here by gather3_cached, and the transposed bf16 shadow -- plus the state of the step PROLOGUE: after an optimiser step
+    the copies are `due`; FlatAdam.begin_step() launches the refresh (and the zero-fill of the flat gradient buffer) on a
+    prologue stream beside the forward pass, and the consumers wait for its events (`sync`, `join`).  Nothing that reads a
+    copy can see a stale one: a consumer that arrives while the refresh is still due runs it on its own stream first.
+    `covered` = how many of the permuted copies the CAPTURED refresh launch updates on replay (None: it runs from Python
+    and updates all of them)."""
+    covered = None
+    due = False          # an optimiser step ran and the refresh has not been launched
+    refresh = None       # callable set by the optimiser: launch the refresh now, on the current stream
+    ev_perm = None       # recorded on the prologue stream behind the permuted copies / behind everything
+    ev_all = None
+    waited = ()
+
+    def sync(self, what="all"):
+        """Called by every consumer of a derived copy (what = "perm": the permuted convolution weights only)."""
+        if self.due and self.refresh is not None:
+            # no begin_step() since the optimiser step (evaluation / inference after training): refresh here.  Other streams
+            # may read the copies next without passing an event, so the host waits -- a rare path; inside a capture the
+            # refresh becomes part of the graph on the capturing stream, where its consumers are
+            self.refresh()
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().synchronize()
+        ev = self.ev_perm if what == "perm" else self.ev_all
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            key = (cur.cuda_stream, what)
+            if key not in self.waited and (cur.cuda_stream, "all") not in self.waited:
+                cur.wait_event(ev)
+                self.waited.add(key)
+
+    def join(self):
+        """The current stream waits for the whole prologue; later consumers (streams forked from this one) need not."""
+        if self.ev_all is not None:
+            torch.cuda.current_stream().wait_event(self.ev_all)
+        self.ev_perm = self.ev_all = None
+        self.waited = set()
+
+
 def gather3_cached(weight, n, strides, off, out_dtype):
     """gather3 of a PARAMETER.  When optim.FlatAdam manages it, the permuted copy lives in a persistent buffer that the
     optimiser refreshes after every update -- ONE grouped launch for all such copies of the model (gather3_refresh) instead of
@@ -599,14 +639,18 @@ def gather3_cached(weight, n, strides, off, out_dtype):
     reg = getattr(weight, "_s2s_perm_registry", None)
     if reg is None:
         return gather3(weight.detach(), n, strides, off, out_dtype)
+    reg.sync("perm")
     key = (tuple(n), tuple(strides), int(off), out_dtype)
     ent = weight._s2s_perms.get(key)
     if ent is None:
         buf = gather3(weight.detach(), n, strides, off, out_dtype)
-        weight._s2s_perms[key] = [buf, weight._version]
+        weight._s2s_perms[key] = [buf, weight._version, len(reg)]
         reg.append((weight, key, buf))
         return buf
-    if ent[1] != weight._version:      # changed in place by torch (load_state_dict, copy_) since the copy was taken
+    cov = getattr(reg, "covered", None)
+    # changed in place by torch (load_state_dict, copy_) since the copy was taken, or registered after the optimiser step
+    # was captured (replays update the weights through raw pointers and refresh only the copies they knew): gather again
+    if ent[1] != weight._version or (cov is not None and ent[2] >= cov):
         _lib.check(_lib.lib().s2svc_gather3(dt(weight), _DT[out_dtype], n[0], n[1], n[2], strides[0], strides[1], strides[2], off,
                                             ptr(weight), ptr(ent[0]), stream()), "gather3")
         ent[1] = weight._version

@@ -12,6 +12,8 @@ device tensor, so the optimiser step is hipGraph-capturable and needs no host sy
 flat gradient buffer is also what data-parallel training all-reduces (distributed.py): a handful of
 large RCCL collectives instead of one per tensor.
 """
+import os
+
 import torch
 
 from .ops import kernels as K
@@ -65,7 +67,10 @@ class FlatAdam:
         self.shadow = torch.zeros(n, dtype=torch.bfloat16, device=dev) if bf16_shadow else None
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)  # step, lr, grad_norm, clip_coef
         self.partial = torch.empty(1024, dtype=torch.float64, device=dev)
-        self._perm_jobs = []          # (parameter, permutation, persistent buffer): filled by ops.kernels.gather3_cached
+        self._perm_jobs = K.PermRegistry()   # (parameter, permutation, persistent buffer): filled by ops.kernels.gather3_cached
+        self._perm_jobs.refresh = self._refresh_transposed
+        self._zero_due = False
+        self._began = False           # begin_step() was called since the last step()
         for p, o in zip(self.params, offs):
             k = p.numel()
             self.flat_p[o:o + k].copy_(p.data.reshape(-1))
@@ -174,6 +179,7 @@ class FlatAdam:
         t = self.flat_p[off:off + n].view(shape)
         t.requires_grad_(True)
         t._s2s_grad = self.flat_g[off:off + n].view(shape)
+        t._s2s_perm_registry = self._perm_jobs
         if self.shadow is not None:
             t._s2s_bf16 = self.shadow[off:off + n].view(shape)
         return t
@@ -190,12 +196,84 @@ class FlatAdam:
             self.shadow.copy_(K.cast(self.flat_p, torch.bfloat16))
         self._refresh_transposed()
 
-    def _refresh_transposed(self):
+    def _refresh_transposed(self, record_perm=False):
         """Derived copies of the weights: the transposed bf16 shadow and the permuted convolution weights that the forward /
-        backward passes registered (ops.kernels.gather3_cached) -- one launch each."""
+        backward passes registered (ops.kernels.gather3_cached) -- one launch each.  The permuted copies first: the forward pass
+        needs them (PermRegistry.ev_perm), the transposed shadow only feeds data-gradient GEMMs."""
+        reg = self._perm_jobs
+        reg.due = False
+        K.gather3_refresh(reg)
+        if self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a captured refresh updates exactly the copies registered NOW on every replay; copies that register later (first
+            # evaluation in another dtype, a convolution first used later) are not in it
+            reg.covered = len(reg) if reg.covered is None else min(reg.covered, len(reg))
+        if record_perm:                       # launched by begin_step on the prologue stream
+            reg.ev_perm = torch.cuda.Event()
+            reg.ev_perm.record()
         if self.shadow_t is not None:
             K.transpose_tiles(self.t_tiles, self.shadow, self.shadow_t)
-        K.gather3_refresh(self._perm_jobs)
+
+    # -- the step prologue -------------------------------------------------------------------------------------------------
+    # After an optimiser step three memory-bound passes stand between it and the next backward pass: the permuted convolution
+    # weights (needed by the forward pass), the transposed bf16 shadow (data-gradient GEMMs) and the zero-fill of the flat
+    # gradient buffer (weight-gradient kernels accumulate): 136 + 144 + 80 us of a 13 ms AAS-VC step, 32 + 27 + 18 us of a
+    # 4.0 ms VTN step when they run in line.  begin_step() -- first call of a training step -- is where the zero-fill happens;
+    # with S2SVC_PROLOGUE_OVERLAP=1 step() only marks the copies as due and begin_step() launches all three on a prologue
+    # stream beside the forward pass; consumers of a copy wait for its event (ops.kernels.PermRegistry.sync, called by
+    # gather3_cached / the data-gradient operand), and join_prologue() must run on the stream that starts the backward pass
+    # before it does (Trainer._backward, distributed.OverlappedBackward, bench.py do); captured, fork and join are two edges
+    # of the step's first graph.  MEASURED (round 3, one box, bench.py --workload aasvc): 13.04 / 13.00 ms with the overlap,
+    # 12.74 ms without; VTN 4.00 vs 4.00 ms.  The three passes launch enough workgroups to fill the chip, and the forward
+    # pass is a chain of small dependent kernels that then queue for CUs behind them: what runs beside the chain is not free
+    # even when it is HBM-bound and the chain is not.  So the overlap is OFF by default and the passes stay in line (refresh at
+    # the end of step(), zero-fill in begin_step() / zero_grad()); the switch stays for the next attempt (passes restricted to
+    # a quarter of the CUs).
+    overlap_prologue = os.environ.get("S2SVC_PROLOGUE_OVERLAP", "0") == "1"
+
+    def _prologue_stream(self, main):
+        from .ops import functional as Fn
+        st = getattr(self, "_pro_stream", None)
+        taken = Fn._taken_streams() | {main.cuda_stream}
+        if st is None or st.cuda_stream in taken:
+            st = self._pro_stream = Fn.distinct_stream(taken)
+        return st
+
+    def begin_step(self, zero=True):
+        """First call of a training step (before the forward pass).  zero: True = clear the gradients, None = only if a
+        zero_grad(defer=True) is pending (gradient accumulation), False = leave them."""
+        reg = self._perm_jobs
+        if zero is None:
+            zero = self._zero_due
+        self._zero_due = False
+        self._began = True
+        if not (self.overlap_prologue and self.flat_p.is_cuda):
+            if reg.due:
+                self._refresh_transposed()
+            if zero:
+                self.flat_g.zero_()
+            return
+        if not (reg.due or zero):
+            return
+        main = torch.cuda.current_stream()
+        st = self._prologue_stream(main)
+        st.wait_stream(main)
+        reg.waited = set()
+        reg.ev_all = torch.cuda.Event()
+        with torch.cuda.stream(st):
+            if reg.due:
+                self._refresh_transposed(record_perm=True)
+            else:
+                reg.ev_perm = None
+            if zero:
+                self.flat_g.zero_()
+            reg.ev_all.record()
+
+    def join_prologue(self):
+        """The current stream (the one that starts the backward pass) waits for the prologue."""
+        if self._zero_due:                       # zero_grad(defer=True) without a begin_step() since
+            self._zero_due = False
+            self.flat_g.zero_()
+        self._perm_jobs.join()
 
     def param_range(self, module):
         """[lo, hi) of the flat buffers covered by the parameters of `module`, or None if parameters of other modules
@@ -224,13 +302,27 @@ class FlatAdam:
                 cur = None
         return [tuple(r) for r in ranges]
 
-    def zero_grad(self, set_to_none=False):
-        self.flat_g.zero_()
+    def zero_grad(self, set_to_none=False, defer=False):
+        """defer=True: the zero-fill joins the next begin_step() (trainers that clear the gradients AFTER the optimiser
+        step); the gradients must not be read in between."""
+        if defer and self.overlap_prologue and self.flat_p.is_cuda:
+            self._zero_due = True
+        else:
+            self._zero_due = False
+            self.flat_g.zero_()
 
     def step(self):
+        self.join_prologue()                     # (no-op when the backward pass joined it, as it must)
         K.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.shadow, self.state, self.partial, self.lr,
                     self.betas, self.eps, self.grad_norm, self.warmup_steps)
-        self._refresh_transposed()
+        if self.overlap_prologue and self.flat_p.is_cuda and self._began:
+            # a caller that opens its steps with begin_step(): the refresh joins the next step's prologue (or runs at the first
+            # consumer of a copy, if none follows).  Everybody else -- zero_grad / forward / backward / step, possibly captured
+            # as ONE graph that must leave the copies fresh for its next replay -- gets the refresh here, in line
+            self._perm_jobs.due = True
+        else:
+            self._refresh_transposed()
+        self._began = False
         self._touch()
 
     # -- introspection (host sync; for logging / tests only) -------------------------------------

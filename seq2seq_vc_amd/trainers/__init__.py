@@ -113,10 +113,20 @@ class Trainer(object):
         """Context of the forward pass: activates the model's gradient cuts when the backward pass runs in stages."""
         return self.dp.forward_context() if self.dp is not None else contextlib.nullcontext()
 
+    def _begin_step(self, zero=True):
+        """First call of a training step: clear the gradients (zero = None: only if a deferred zero_grad is pending) and, with
+        the fused optimiser, start the step prologue beside the forward pass (optim.FlatAdam.begin_step)."""
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.begin_step(zero=zero)
+        elif zero:
+            self.optimizer.zero_grad()
+
     def _backward(self, total, parts, last_micro_step=True):
         """Backward pass + (on the last micro-step of an accumulation window) the gradient exchange.
         total: the scalar loss (already divided by gradient_accumulate_steps); parts: the same loss split by the keys of
         model.dp_plan() (sum(parts) == total), used when the backward pass runs stage by stage."""
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.join_prologue()       # zero-fill of the gradients + refreshed weight copies: done before the first gradient
         if self.dp is not None:
             if self._capture is not None:                    # being captured stage by stage: the exchange runs between the replays
                 self._capture.staged_backward(self.dp, parts)
@@ -278,7 +288,7 @@ class ARVCTrainer(Trainer):
     def _train_step(self, batch):
         K.reset_op_counter()
         K.advance_seed(self.device)
-        self.optimizer.zero_grad()
+        self._begin_step()                      # zero_grad (the reference clears before backward: nothing reads them in between)
         with self._forward_context():
             loss, logs = self._forward_losses(batch)
         self._accumulate(**logs)
@@ -318,6 +328,10 @@ class AASVCTrainer(Trainer):
         dev = self.device
         K.reset_op_counter()
         K.advance_seed(dev)
+        self._begin_step(zero=None)             # the zero_grad deferred by the previous optimiser step runs beside this forward pass
+        net = self._net()
+        if getattr(net, "forward_sum_prefetch", 0) is None and "ForwardSumLoss" in self.criterion:
+            net.forward_sum_prefetch = self.criterion["ForwardSumLoss"].prefetch     # its recursion runs beside the decoder
         xs, ys, dp_inputs = batch["xs"].to(dev), batch["ys"].to(dev), batch["dp_inputs"].to(dev)
         with self._forward_context():
             ret = self.model(xs, batch["ilens"], ys, batch["olens"], dp_inputs, dp_lengths=batch["dplens"])
@@ -352,7 +366,10 @@ class AASVCTrainer(Trainer):
         if not last:
             return
         self._optimizer_step()
-        self.optimizer.zero_grad()
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.zero_grad(defer=True)
+        else:
+            self.optimizer.zero_grad()
         self.steps += 1
         self._check_train_finish()
 
@@ -368,7 +385,7 @@ class NARVCTrainer(Trainer):
         K.reset_op_counter()
         K.advance_seed(dev)
         xs, ys, dp_inputs = batch["xs"].to(dev), batch["ys"].to(dev), batch["dp_inputs"].to(dev)
-        self.optimizer.zero_grad()
+        self._begin_step()
         with self._forward_context():
             before, after, d_outs, ilens_, olens_, ys_ = self.model(xs, batch["ilens"], ys, batch["olens"], batch["durations"],
                                                                    batch["duration_lens"], dp_inputs, dp_lengths=batch["dplens"])

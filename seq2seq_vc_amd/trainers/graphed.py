@@ -208,7 +208,8 @@ class _Capture:
         g, stage = self.cur
         from ..ops import functional as Fn
         main = torch.cuda.current_stream()
-        for st in [Fn._Branch.stream] + list(Fn._Side.streams):      # belt and braces: nothing may still be forked off
+        pro = getattr(self.owner.t.optimizer, "_pro_stream", None)   # the step prologue (optim.FlatAdam.begin_step)
+        for st in [Fn._Branch.stream, pro] + list(Fn._Side.streams):      # belt and braces: nothing may still be forked off
             if st is None:
                 continue
             with torch.cuda.stream(st):
