@@ -135,6 +135,11 @@ int s2svc_tconv2d_weights(int O, int C, const float* w, void* out_bf16, void* st
    Two descriptors of one call must not write the same C / a_rowsum (they run concurrently). */
 int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc /* host */);
 int s2svc_gemm_grouped(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream);
+/* the same with the problems of exact 256 x 128 tiles (the 8-wave kernel's) as a BACKGROUND launch on `bg_stream`: bg_cus
+   workgroups walk all their tiles and leave the other CUs to the kernels of `stream`; *n_bg = how many problems went there.
+   The caller orders bg_stream behind the producers of the operands and joins it before the results are read. */
+int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream, void* bg_stream, int bg_cus,
+                          int* n_bg /* host, may be NULL */);
 
 /* Kernel-family switch for tests / A-B timing of s2svc_gemm's bf16 path: the 256-row, 8-wave, phase-interleaved kernel
    (csrc/gemm_8ph.hip: K-contiguous dense or Conv2d-3x3-s2 A operand, dense B, K % 64 == 0, >= 128 tiles) is tried first.

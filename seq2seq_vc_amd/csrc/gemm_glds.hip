@@ -640,6 +640,27 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const group_args g) {
   gemm_glds_tile<BM, BN, AMODE, BMODE>(d, tile_m, t - tile_m * tiles_n, 0, 0, smem);
 }
 
+// The same with a CAPPED grid: gridDim.x workgroups walk all tiles (S2SVC_GROUP_WGS).  Weight-gradient launches run on side
+// streams beside the data-gradient chain; one workgroup per tile (500-1300 of them) takes every CU slot for the length of the
+// launch and the chain's small kernels queue behind them, a capped grid leaves slots free.  Same tile code: same bits.
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_grouped_capped_kernel(const group_args g) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * (BM + BN) * 128];
+  const int total = g.tile_start[S2S_GROUP_MAX];
+#pragma unroll 1
+  for (int bt = (int)blockIdx.x; bt < total; bt += (int)gridDim.x) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < S2S_GROUP_MAX; ++i) p += (i < g.n && g.tile_start[i] <= bt) ? 1 : 0;
+    const s2svc_gemm_desc& d = g.d[p];
+    const int t = bt - g.tile_start[p];
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int tile_m = t / tiles_n;
+    gemm_glds_tile<BM, BN, AMODE, BMODE>(d, tile_m, t - tile_m * tiles_n, 0, 0, smem);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // All-DMA variant (both operands K-contiguous): NS LDS stages, NS-1 tiles in flight.  The wait for tile t is a
 // COUNTED s_waitcnt (the DMAs of the later tiles stay in flight across the barrier) followed by a raw s_barrier;
@@ -918,9 +939,17 @@ static bool tconv_group_ok(const s2svc_gemm_desc& d) {
   return true;
 }
 
-extern "C" int s2svc_gemm_grouped_try_8ph(const s2svc_gemm_desc* descs, int n, void* stream);
+extern "C" int s2svc_gemm_grouped_try_8ph_bg(const s2svc_gemm_desc* descs, int n, void* stream, int bg_cus);
 
 extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile, void* stream) {
+  return s2svc_gemm_grouped_bg(descs, n, tile, stream, nullptr, 0, nullptr);
+}
+
+// bg_cus > 0: the problems the 8-wave kernel takes run on `bg_stream` as a background launch of bg_cus workgroups (the caller
+// has made bg_stream wait for the producers of the operands, and joins it before the gradients are used); *n_bg = how many.
+extern "C" int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs, int n, int tile, void* stream, void* bg_stream, int bg_cus,
+                                     int* n_bg) {
+  if (n_bg) *n_bg = 0;
   S2S_REQUIRE(descs && n > 0 && (tile == 64 || tile == 128), "gemm_grouped: bad args");
   hipStream_t st = (hipStream_t)stream;
   if (tconv_group_ok(descs[0])) {
@@ -950,8 +979,10 @@ extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile,
     }
     int taken = 0;                                  // problems of exact 256 x 128 tiles: the 8-wave kernel (gemm_8ph.hip)
     if (tr_enabled()) {
-      taken = s2svc_gemm_grouped_try_8ph(descs + i0, cnt, stream);
+      const bool bg = bg_cus > 0 && bg_stream != nullptr;
+      taken = s2svc_gemm_grouped_try_8ph_bg(descs + i0, cnt, bg ? bg_stream : stream, bg ? bg_cus : 0);
       if (taken < 0) return taken;
+      if (bg && n_bg) *n_bg += __builtin_popcount((unsigned)taken);
     }
     group_args g;
     std::memset(&g, 0, sizeof(g));
@@ -966,7 +997,13 @@ extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile,
     }
     if (g.n == 0) continue;
     for (int i = g.n; i <= S2S_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
-    if (tr_enabled()) {
+    static const int cap = [] { const char* e = getenv("S2SVC_GROUP_WGS"); return e ? atoi(e) : 0; }();
+    if (tr_enabled() && cap > 0 && total > cap) {
+      if (tile == 128)
+        hipLaunchKernelGGL((gemm_grouped_capped_kernel<128, 128, G_TR_DENSE, G_TR_DENSE>), dim3((unsigned)cap), dim3(256), 0, st, g);
+      else
+        hipLaunchKernelGGL((gemm_grouped_capped_kernel<64, 64, G_TR_DENSE, G_TR_DENSE>), dim3((unsigned)cap), dim3(256), 0, st, g);
+    } else if (tr_enabled()) {
       if (tile == 128)
         hipLaunchKernelGGL((gemm_grouped_kernel<128, 128, G_TR_DENSE, G_TR_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
       else

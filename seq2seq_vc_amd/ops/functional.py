@@ -176,6 +176,8 @@ def _taken_streams():
     h = {st.cuda_stream for st in _Side.streams}
     if _Branch.stream is not None:
         h.add(_Branch.stream.cuda_stream)
+    if K._BG.stream is not None:
+        h.add(K._BG.stream.cuda_stream)
     if torch.cuda.is_available():
         h.add(torch.cuda.current_stream().cuda_stream)
     return h
@@ -195,12 +197,13 @@ def distinct_stream(taken=None):
     raise RuntimeError("no distinct stream left in torch's stream pool")
 
 
-def enable_side_streams(n=4, inline_batches=False):
+def enable_side_streams(n=4, inline_batches=False, wgrad_background=(0, 0)):
     """n > 0: parameter-gradient work is forked to n side streams (small, latency-bound models: VTN).
     n == 0 and inline_batches: the work stays on the stream that issued it but is still queued and run in batches, so
     that the dense weight-gradient GEMMs of a batch become one grouped launch -- for models whose kernels fill the chip
     anyway (AAS-VC: d = 1536) the forks cost more than the overlap gives (19.3 vs 20.9 ms/step).  Both need side_join()
     between backward and the optimiser step; n == 0 without inline_batches runs everything immediately."""
+    K.set_wgrad_background(*wgrad_background)     # (cus, launches): ops.kernels, "Background weight gradients"
     _Side.enabled = n > 0
     _Side.inline = (n == 0) and inline_batches
     old, others = _Side.streams, _taken_streams() - {st.cuda_stream for st in _Side.streams}
@@ -378,6 +381,7 @@ def side_join():
         for st in _Side.streams:
             main.wait_stream(st)
     _join_branch_stream()
+    K.bg_join()                      # background weight gradients (ops.kernels.set_wgrad_background)
     _Side.pending.clear()
     _Side.idx = 0
 

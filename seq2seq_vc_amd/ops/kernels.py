@@ -211,6 +211,8 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         raise TypeError("gemm bias must be fp32")
     if res is not None and res.dtype != out.dtype:
         raise TypeError("gemm residual must have the output dtype")
+    if _BG.dirty:
+        bg_wait(d.C, d.a_rowsum)
     _lib.check(_lib.lib().s2svc_gemm(ctypes.byref(d), stream()), "s2svc_gemm")
     return out
 
@@ -279,7 +281,69 @@ def flush_colreduce(queue):
                 group.append((it, keep))
         pending = rest
         arr = (_lib.ColreduceItem * len(group))(*[g[0] for g in group])
+        bg_wait(*[g[0].out_sum for g in group], *[g[0].out_dot for g in group])
         _lib.check(_lib.lib().s2svc_colreduce_grouped(ctypes.addressof(arr), len(group), stream()), "s2svc_colreduce_grouped")
+
+
+# ----------------------------------------------------------------------------------------------
+# Background weight gradients.  The grouped launches of the 8-wave kernel (exact 256 x 128 tiles: AAS-VC's 1536 / 3072 / 4608
+# feature layers, ~300 us per decoder layer) are independent of the data-gradient chain but fill the chip, so they used to run
+# in line on the chain's stream: a chip-filling launch on a side stream makes every kernel of the chain queue for a CU behind
+# ~100 us workgroups (measured in round 2: slower).  As a BACKGROUND launch -- `cus` persistent workgroups that walk all tiles,
+# on their own stream -- they hold a quarter of the CUs and the chain keeps the rest, which is what its GEMMs use anyway
+# (192 workgroups of 256 x 128 for 4096 x 1536 outputs).  Only the first `max_launches` grouped launches of a backward pass go
+# there: what is still running when the chain ends is a tail at a quarter of the chip.
+# ----------------------------------------------------------------------------------------------
+class _BG:
+    cus, max_launches = 0, 0
+    count = 0             # background launches since the last join
+    stream = None
+    dirty = False
+    keys = set()          # outputs (C / a_rowsum pointers) with a background launch in flight
+
+
+def _parse_bg(spec):
+    cus, _, n = spec.partition(":")
+    return int(cus or 0), int(n) if n else 1 << 30
+
+
+def set_wgrad_background(cus, max_launches=1 << 30):
+    """cus > 0: the first `max_launches` grouped 8-wave weight-gradient launches of every backward pass run as background
+    launches of `cus` workgroups (see above); 0 switches it off.  S2SVC_WGRAD_BG="cus:launches" overrides."""
+    env = os.environ.get("S2SVC_WGRAD_BG")
+    if env is not None:
+        cus, max_launches = _parse_bg(env)
+    _BG.cus, _BG.max_launches = int(cus), int(max_launches)
+
+
+def _bg_stream(cur):
+    from . import functional as Fn
+    st = _BG.stream
+    _BG.stream = None                                         # (_taken_streams lists it otherwise)
+    taken = Fn._taken_streams() | {cur.cuda_stream}
+    if st is None or st.cuda_stream in taken:
+        st = Fn.distinct_stream(taken)
+    _BG.stream = st
+    return st
+
+
+def bg_wait(*ptrs):
+    """The current stream is about to write `ptrs` (gradient slots): wait for a background launch that writes them too."""
+    if _BG.dirty and any(p in _BG.keys for p in ptrs if p):
+        torch.cuda.current_stream().wait_stream(_BG.stream)
+
+
+def bg_join():
+    """The current stream waits for the background weight gradients (ops.functional.side_join: end of a backward pass / stage)."""
+    if _BG.dirty:
+        torch.cuda.current_stream().wait_stream(_BG.stream)
+    _BG.dirty, _BG.count = False, 0
+    _BG.keys = set()
+
+
+def _bg_candidates(part):
+    return [d for d in part if d.dtype == _DT[torch.bfloat16] and d.M % 256 == 0 and d.N % 128 == 0 and d.K % 64 == 0 and
+            (d.M // 128) * (d.N // 128) >= 64]
 
 
 def launch_group(descs, tile=128):
@@ -309,7 +373,24 @@ def flush_grouped(queue):
         for part, tile in ((big, 128), (small, _GROUP_TILE)):
             if part:
                 arr = (_lib.GemmDesc * len(part))(*part)
-                _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(part), tile, stream()), "s2svc_gemm_grouped")
+                cand = _bg_candidates(part) if (_BG.cus > 0 and _BG.count < _BG.max_launches) else []
+                bg_wait(*[d.C for d in part], *[d.a_rowsum for d in part])
+                if cand:
+                    cur = torch.cuda.current_stream()
+                    bg = _bg_stream(cur)
+                    bg.wait_stream(cur)                     # the operands were produced on this stream
+                    nbg = ctypes.c_int(0)
+                    _lib.check(_lib.lib().s2svc_gemm_grouped_bg(ctypes.addressof(arr), len(part), tile, cur.cuda_stream,
+                                                                bg.cuda_stream, _BG.cus, ctypes.byref(nbg)), "s2svc_gemm_grouped_bg")
+                    _BG.dirty = True                       # forked (part of a capture from here on): joined by bg_join either way
+                    if nbg.value:
+                        _BG.count += 1
+                        for d in cand:
+                            _BG.keys.add(d.C)
+                            if d.a_rowsum:
+                                _BG.keys.add(d.a_rowsum)
+                else:
+                    _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(part), tile, stream()), "s2svc_gemm_grouped")
 
 
 # ----------------------------------------------------------------------------------------------

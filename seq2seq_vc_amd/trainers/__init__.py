@@ -81,12 +81,14 @@ class Trainer(object):
 
     # how parameter-gradient kernels are scheduled (ops/functional.py, "Side streams"): (side streams, inline batches)
     GRADIENT_WORK = (4, False)
+    WGRAD_BACKGROUND = (0, 0)       # (CUs, launches per backward pass) of the background weight-gradient launches (ops/kernels.py)
     DP_GRAD_PAYLOAD = "fp32"        # dtype of the data-parallel gradient exchange (config["dp_grad_payload"] overrides)
 
     def _schedule_gradient_work(self):
         if self.device.type == "cuda" and isinstance(self.optimizer, FlatAdam):
             n, inline = self.GRADIENT_WORK
-            Fn.enable_side_streams(self.config.get("side_streams", n), inline_batches=self.config.get("inline_batches", inline))
+            Fn.enable_side_streams(self.config.get("side_streams", n), inline_batches=self.config.get("inline_batches", inline),
+                                   wgrad_background=tuple(self.config.get("wgrad_background", self.WGRAD_BACKGROUND)))
 
     # -- data parallelism (reference: apex DistributedDataParallel wrap, bin/vc_train.py:423-431) ------------------------
     def _setup_data_parallel(self):
@@ -317,6 +319,9 @@ class AASVCTrainer(Trainer):
     gradient accumulation divides the loss; zero_grad AFTER the optimiser step."""
 
     GRADIENT_WORK = (0, True)       # chip-filling kernels: batched on the issuing stream, not forked (17.6 vs 20.9 ms/step)
+    WGRAD_BACKGROUND = (64, 3)      # the first three grouped 8-wave weight-gradient launches of a backward pass (decoder layers) as
+    #                                 background launches of 64 workgroups: 12.83 -> 12.55 ms per vc2 step; a fourth one is still
+    #                                 running when the chain ends (13.3 ms), 48 / 72 / 80 / 96 workgroups 12.61 / 12.62 / 12.79 / 12.71
     DP_GRAD_PAYLOAD = "bf16"        # 630 MB of fp32 gradients per step (vc2) = 7 ms on one xGMI link against a 15 ms step: the
     #                                 exchange runs on a bf16 copy by default; config["dp_grad_payload"] = "fp32" is the parity setting
     GRAPH_BATCH = {"xs": ("ilens", 0.0), "ys": ("olens", 0.0), "dp_inputs": ("dplens", 0.0)}

@@ -594,6 +594,42 @@ def aasvc_full_size_step_is_reproducible():
         res.append((bad == 0, f"AAS-VC vc2 bf16 step: {bad} of 60 repeats differ from the first (losses {l0.tolist()})"))
         gn = float(g0.double().pow(2).sum().sqrt())
         res.append((gn == gn and 0 < gn < 1e5, f"AAS-VC vc2 gradient norm {gn:.3f} finite"))
+        # the scheduling variants move work between streams, never change a sum: same bits as the pass above
+        from seq2seq_vc_amd.models import aas_vc as AV
+        crit = L.ForwardSumLoss()
+
+        def variant(name, n=4):
+            bad = 0
+            for _ in range(n):
+                l, g = fwd_bwd()
+                bad += 0 if (torch.equal(l, l0) and torch.equal(g, g0)) else 1
+            res.append((bad == 0, f"AAS-VC vc2 bf16 step, {name}: {bad} of {n} passes differ from the reference pass"))
+
+        was = AV._FBRANCH
+        try:
+            AV._FBRANCH = not was
+            variant(f"alignment module's feature side {'on the auxiliary stream' if not was else 'in line'}")
+        finally:
+            AV._FBRANCH = was
+        model.forward_sum_prefetch = crit.prefetch
+        hits = []
+        orig = L.ForwardSumLoss.forward
+
+        def spy(self, log_p_attn, *a, **k):
+            hits.append(getattr(log_p_attn, "_s2s_fs", None) is not None)
+            return orig(self, log_p_attn, *a, **k)
+
+        L.ForwardSumLoss.forward = spy
+        try:
+            variant("forward-sum recursion prefetched on the auxiliary stream")
+        finally:
+            L.ForwardSumLoss.forward = orig
+            model.forward_sum_prefetch = None
+        res.append((bool(hits) and all(hits), f"the criterion found the prefetched forward-sum result in {sum(hits)} of {len(hits)} calls"))
+        Fn.enable_side_streams(0, inline_batches=True, wgrad_background=(64, 3))
+        variant("weight gradients as background launches (64 workgroups, 3 launches)")
+        Fn.enable_side_streams(0, inline_batches=True, wgrad_background=(24, 100))
+        variant("weight gradients as background launches (24 workgroups, all launches)", n=2)
     finally:
         Fn.set_compute_dtype(torch.float32)
         Fn.enable_side_streams(0)
