@@ -640,6 +640,27 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(const group_args g) {
   gemm_glds_tile<BM, BN, AMODE, BMODE>(d, tile_m, t - tile_m * tiles_n, 0, 0, smem);
 }
 
+// Grouped launch of BATCHED problems of one operand-kind pair: the batched products of an attention backward pass
+// (dV = P^T dctx, dK = dS^T Q, d pos = dbd^T qv: row-contiguous x row-contiguous; dQ = dS K, d qv = dbd pos: K-contiguous x
+// row-contiguous) are 3-8 GFLOP each with a reduction of 256-511 -- a launch of 128-768 short tiles whose time is the launch
+// floor, the pipeline fill and a ragged last round.  tile_start[] counts tiles x batches; a workgroup decodes (problem, batch,
+// tile) and runs the same tile code as the plain launch.
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void gemm_grouped_batched_kernel(const group_args g) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * (BM + BN) * 128];
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < S2S_GROUP_MAX; ++i) p += (i < g.n && g.tile_start[i] <= (int)blockIdx.x) ? 1 : 0;
+  const s2svc_gemm_desc& d = g.d[p];
+  const int t = (int)blockIdx.x - g.tile_start[p];
+  const int tiles_n = (d.N + BN - 1) / BN;
+  const int per = ((d.M + BM - 1) / BM) * tiles_n;
+  const int zb = t / per;
+  const int r = t - zb * per;
+  const int tile_m = r / tiles_n;
+  gemm_glds_tile<BM, BN, AMODE, BMODE>(d, tile_m, r - tile_m * tiles_n, zb, 0, smem);
+}
+
 // The same with a CAPPED grid: gridDim.x workgroups walk all tiles (S2SVC_GROUP_WGS).  Weight-gradient launches run on side
 // streams beside the data-gradient chain; one workgroup per tile (500-1300 of them) takes every CU slot for the length of the
 // launch and the chain's small kernels queue behind them, a capped grid leaves slots free.  Same tile code: same bits.
@@ -1014,6 +1035,48 @@ extern "C" int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs, int n, int ti
       hipLaunchKernelGGL((gemm_grouped_kernel<64, 64, G_RC_DENSE, G_RC_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
     S2S_CHECK_LAUNCH("gemm_grouped_kernel");
   }
+  return 0;
+}
+
+// One grid for batched problems of ONE operand-kind pair (see gemm_grouped_batched_kernel).  Returns 0 = launched, 1 = not
+// eligible as a group (nothing was launched: the caller runs the problems one by one with s2svc_gemm), < 0 = error.
+extern "C" int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs, int n, void* stream) {
+  S2S_REQUIRE(descs && n > 0, "gemm_grouped_batched: bad args");
+  if (disabled() || !tr_enabled() || n > S2S_GROUP_MAX) return 1;
+  const int ka = kind_of(descs[0].A), kb = kind_of(descs[0].B);
+  if (!((ka == G_KC_DENSE || ka == G_RC_DENSE) && kb == G_RC_DENSE)) return 1;
+  group_args g;
+  std::memset(&g, 0, sizeof(g));
+  int64_t total128 = 0;
+  for (int i = 0; i < n; ++i) {
+    const s2svc_gemm_desc& d = descs[i];
+    if (d.dtype != S2S_BF16 || d.splitk > 1 || d.a_rowsum || kind_of(d.A) != ka || kind_of(d.B) != kb) return 1;
+    if (!operand_ok(d.A) || !operand_ok(d.B)) return 1;
+    if (!extent_ok(d.A, d.A.layout == S2SVC_LAYOUT_RC ? d.M : d.K) || !extent_ok(d.B, d.B.layout == S2SVC_LAYOUT_RC ? d.N : d.K)) return 1;
+    if (!rows_fit_fastdiv(d)) return 1;
+    total128 += (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1;
+  }
+  // 128 x 128 tiles once they fill the chip (the rule of the plain launch, over the group), else 64 x 64
+  const int tile = total128 >= 256 ? 128 : 64;
+  int64_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    const s2svc_gemm_desc& d = descs[i];
+    g.d[i] = d;
+    g.tile_start[i] = (int32_t)total;
+    total += (int64_t)((d.M + tile - 1) / tile) * ((d.N + tile - 1) / tile) * d.nb0 * d.nb1;
+    S2S_REQUIRE(total < (1ll << 30), "gemm_grouped_batched: too many tiles");
+  }
+  g.n = n;
+  for (int i = n; i <= S2S_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
+  hipStream_t st = (hipStream_t)stream;
+  if (ka == G_KC_DENSE) {
+    if (tile == 128) hipLaunchKernelGGL((gemm_grouped_batched_kernel<128, 128, G_KC_DENSE, G_TR_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_grouped_batched_kernel<64, 64, G_KC_DENSE, G_TR_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+  } else {
+    if (tile == 128) hipLaunchKernelGGL((gemm_grouped_batched_kernel<128, 128, G_TR_DENSE, G_TR_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_grouped_batched_kernel<64, 64, G_TR_DENSE, G_TR_DENSE>), dim3((unsigned)total), dim3(256), 0, st, g);
+  }
+  S2S_CHECK_LAUNCH("gemm_grouped_batched_kernel");
   return 0;
 }
 

@@ -352,6 +352,25 @@ def launch_group(descs, tile=128):
     _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(descs), tile, stream()), "s2svc_gemm_grouped")
 
 
+_GROUP_BATCHED = os.environ.get("S2SVC_ATTN_GROUP", "1") != "0"      # A/B aid
+
+
+def launch_group_batched(descs):
+    """The listed BATCHED problems (K.gemm(..., group=descs)) of one operand-kind pair as one grid (s2svc_gemm_grouped_batched:
+    the batched products of an attention backward pass); one by one if the library does not take them as a group."""
+    if not descs:
+        return
+    if len(descs) > 1 and _GROUP_BATCHED:
+        arr = (_lib.GemmDesc * len(descs))(*descs)
+        rc = _lib.lib().s2svc_gemm_grouped_batched(ctypes.addressof(arr), len(descs), stream())
+        if rc == 0:
+            return
+        if rc != 1:
+            _lib.check(rc, "s2svc_gemm_grouped_batched")
+    for d in descs:
+        _lib.check(_lib.lib().s2svc_gemm(ctypes.byref(d), stream()), "s2svc_gemm")
+
+
 def flush_grouped(queue):
     """Launch every queued problem on the current stream; problems that would write the same C / a_rowsum concurrently
     go to successive launches.  Empties the queue."""

@@ -156,12 +156,19 @@ def rel_attention_fused_vs_separate():
             o, a = Fn.rel_attention_packed(x, pp, uu, vv_, klen, H, p, 1)
             (o.float() * dy.float()).sum().backward()
             return o.detach(), a.detach(), x.grad, pp.grad, uu.grad, vv_.grad
+        was = K._GROUP_BATCHED
         try:
             f0, s0, f1, s1 = run(True, 0.0), run(False, 0.0), run(True, 0.2), run(False, 0.2)
             f2 = run(True, 0.2, fused_bwd=False)            # the default: fused forward, separate backward kernels
+            # the five batched products of the backward pass as two grids (s2svc_gemm_grouped_batched) vs one launch each
+            K._GROUP_BATCHED = False
+            f3, s3 = run(True, 0.2, fused_bwd=False), run(False, 0.2)
         finally:
+            K._GROUP_BATCHED = was
             os.environ.pop("S2SVC_NO_RELATTN", None)
             os.environ.pop("S2SVC_RELATTN_BWD", None)
+        same = all(torch.equal(a, b) for a, b in zip(f2, f3)) and all(torch.equal(a, b) for a, b in zip(s1, s3))
+        res.append((same and was, f"rel-attn B{B} H{H} T{T} dk{dk}: grouped batched products == one launch each, bit for bit: {same}"))
         tag = f"rel-attn B{B} H{H} T{T} dk{dk}"
         names = ("out", "attn", "d qkv", "d pos", "d pos_bias_u", "d pos_bias_v")
         refs = (outr, prob, xr.grad, pr_.grad, ur.grad, vr.grad)
