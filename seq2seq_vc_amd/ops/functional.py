@@ -803,8 +803,9 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
     """Backward of softmax(QK^T)V.  attn/pm: padded (B,H,T1,ld) tensors; q/k/v may be column slices of packed
     tensors; `outs` = (dq, dk, dv) views to write into (e.g. slices of a packed gradient), allocated when None.
     The three batched products behind the softmax backward are launched as two grids (dQ = dS K | dV = P^T dctx, dK = dS^T Q:
-    one grid per operand-kind pair, K.launch_group_batched); groups = (kc, rc): two lists the caller launches itself after
-    adding its own products (relative-position attention: d qv, d pos)."""
+    one grid per operand-kind pair, K.launch_group_batched); groups = (kc, rc, keep): two lists the caller launches itself
+    after adding its own products (relative-position attention: d qv, d pos), and a list that keeps the operands of the queued
+    products alive until then (a descriptor holds raw pointers: a temporary freed before the launch is the next allocation)."""
     B, T1, D = q.shape
     T2 = k.shape[1]
     dk = D // H
@@ -817,7 +818,7 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
     if pm is None:      # forward ran the fused kernel (no dropped copy was stored): one launch, masks regenerated
         KAT.fused_bwd(q, k, v, dctx, attn, _pad_like(dattn, attn), H, scale, p, seed, dq, dkk, dv)
         return dq, dkk, dv, None
-    gkc, grc = groups if groups is not None else ([], [])
+    gkc, grc, keep = groups if groups is not None else ([], [], [])
     # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
     dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
     ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode, dattn=_pad_like(dattn, attn), T2=T2,
@@ -828,6 +829,7 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
     _into(dq, _pop(ds, T1, H), _bop(k, dk, K.RC), T1, dk, T2, dk, dtype, B, H, group=gkc)
     # dK[b,j,hd] = sum_i dS[b,h,i,j] q[b,i,hd]
     _into(dkk, _pop(ds, T1, H, K.RC), _bop(q, dk, K.RC), T2, dk, T1, dk, dtype, B, H, group=grc)
+    keep += [dctx, ds, dbd, pm, q, k, v]
     if groups is None:
         K.launch_group_batched(gkc)
         K.launch_group_batched(grc)
@@ -1104,16 +1106,17 @@ class _RelAttnPacked(Function):
         Lq = _pad8(L)
         dqkv = torch.empty_like(qkv)
         dqu = torch.empty((B, T, D), dtype=dtype, device=qu.device)
-        gkc, grc = [], []        # the five batched products behind the softmax backward: two grids (K.launch_group_batched)
+        gkc, grc, keep = [], [], []      # the five batched products behind the softmax backward: two grids (K.launch_group_batched)
         if ctx.fused_rel and KAT.rel_bwd_enabled():
             dctx = _c(dctx) if dctx is not None else torch.zeros((B, T, D), dtype=dtype, device=qu.device)
             ds, dbd = KAT.rel_bwd(dctx, vv, attn, _pad_like(dattn, attn), H, scale, p, seed, Lq)
             _into(dqkv[..., 2 * D:], _pop(pm, T, H, K.RC), _bop(dctx, dk, K.RC), T, dk, T, dk, dtype, B, H, group=grc)     # dV = Pm^T dctx
             _into(dqu, _pop(ds, T, H), _bop(k, dk, K.RC), T, dk, T, dk, dtype, B, H, group=gkc)                             # dQu = dS K
             _into(dqkv[..., D:2 * D], _pop(ds, T, H, K.RC), _bop(qu, dk, K.RC), T, dk, T, dk, dtype, B, H, group=grc)       # dK = dS^T Qu
+            keep += [dctx, ds]
         else:
             _, _, _, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, vv, H, scale, p, seed, Lp=L, rel_mode=rel_mode, ldb=Lq,
-                                            outs=(dqu, dqkv[..., D:2 * D], dqkv[..., 2 * D:]), groups=(gkc, grc))
+                                            outs=(dqu, dqkv[..., D:2 * D], dqkv[..., 2 * D:]), groups=(gkc, grc, keep))
         dqv = torch.empty((B, T, D), dtype=dtype, device=qu.device)
         K.gemm(K.operand(dbd, Lq, bs0=H * T * Lq, bs1=T * Lq, zero_padded=True), K.operand(pos, D, layout=K.RC, bs0=0, bs1=dk), T, dk,
                L, dqv, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T * D, dk), group=gkc)
@@ -1123,6 +1126,7 @@ class _RelAttnPacked(Function):
                group=grc)
         K.launch_group_batched(gkc)
         K.launch_group_batched(grc)
+        del keep
         dpos, _ = K.colreduce(0, part.view(B, L * D))
         dpos = K.cast(dpos.view(1, L, D), dtype)
         K.add_rows(dqu, dqv, dqkv[..., :D])
