@@ -137,8 +137,7 @@ int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc /* host */);
 int s2svc_gemm_grouped(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream);
 /* the same with the problems of exact 256 x 128 tiles (the 8-wave kernel's) as a BACKGROUND launch on `bg_stream`: bg_cus
    workgroups walk all their tiles and leave the other CUs to the kernels of `stream`; *n_bg = how many problems went there.
-   bg_cus == 0 with a bg_stream: those problems as a plain full-grid launch on bg_stream, the others on `stream`.
-   The caller orders both streams behind the producers of the operands and joins them before the results are read. */
+   The caller orders bg_stream behind the producers of the operands and joins it before the results are read. */
 /* BATCHED problems of one operand-kind pair (A K-contiguous or row-contiguous, B row-contiguous; bf16, no split-K) as one
    grid: the batched products of an attention backward pass (ops/functional.py: _attn_common_bwd, _RelAttnPacked.backward;
    reference modules/transformer/attention.py:72-111, 262-305 differentiated).  0 = launched, 1 = not eligible as a group

@@ -1000,9 +1000,8 @@ extern "C" int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs, int n, int ti
     }
     int taken = 0;                                  // problems of exact 256 x 128 tiles: the 8-wave kernel (gemm_8ph.hip)
     if (tr_enabled()) {
-      // bg_stream with bg_cus == 0: the 8-wave problems as a plain (full-grid) launch on bg_stream, the others on `stream`
       const bool bg = bg_cus > 0 && bg_stream != nullptr;
-      taken = s2svc_gemm_grouped_try_8ph_bg(descs + i0, cnt, bg_stream ? bg_stream : stream, bg ? bg_cus : 0);
+      taken = s2svc_gemm_grouped_try_8ph_bg(descs + i0, cnt, bg ? bg_stream : stream, bg ? bg_cus : 0);
       if (taken < 0) return taken;
       if (bg && n_bg) *n_bg += __builtin_popcount((unsigned)taken);
     }

@@ -178,8 +178,6 @@ def _taken_streams():
         h.add(_Branch.stream.cuda_stream)
     if K._BG.stream is not None:
         h.add(K._BG.stream.cuda_stream)
-    if K._BG.side is not None:
-        h.add(K._BG.side.cuda_stream)
     if torch.cuda.is_available():
         h.add(torch.cuda.current_stream().cuda_stream)
     return h

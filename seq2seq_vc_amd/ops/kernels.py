@@ -281,15 +281,8 @@ def flush_colreduce(queue):
                 group.append((it, keep))
         pending = rest
         arr = (_lib.ColreduceItem * len(group))(*[g[0] for g in group])
-        outs = [g[0].out_sum for g in group] + [g[0].out_dot for g in group]
-        bg_wait(*outs)
-        cur = torch.cuda.current_stream()
-        side = _bg_side_stream(cur)
-        if side is not None:
-            _BG.keys.update(p for p in outs if p)
-            _BG.keep.extend(g[1] for g in group)         # operands + workspaces: not this stream's to recycle before the join
-        _lib.check(_lib.lib().s2svc_colreduce_grouped(ctypes.addressof(arr), len(group), (side or cur).cuda_stream),
-                   "s2svc_colreduce_grouped")
+        bg_wait(*[g[0].out_sum for g in group], *[g[0].out_dot for g in group])
+        _lib.check(_lib.lib().s2svc_colreduce_grouped(ctypes.addressof(arr), len(group), stream()), "s2svc_colreduce_grouped")
 
 
 # ----------------------------------------------------------------------------------------------
@@ -306,15 +299,7 @@ class _BG:
     count = 0             # background launches since the last join
     stream = None
     dirty = False
-    keys = set()          # outputs (C / a_rowsum pointers) with a background / side launch in flight
-    # The REST of a gradient batch -- grouped weight gradients on the 4-wave kernel (small outputs: AAS-VC's 384-feature encoder,
-    # leftovers of a decoder layer) and the grouped column reductions (LayerNorm / BatchNorm / bias vectors) -- on a second
-    # stream: short workgroups (~10 us tiles, HBM-bound reductions) interleave with the chain at workgroup granularity, as
-    # VTN's side streams do.  Only together with the background launches (models whose big launches stay off side streams).
-    side_small = os.environ.get("S2SVC_WGRAD_SIDE", "0") == "1"
-    side = None
-    side_dirty = False
-    keep = []             # tensors a side launch reads / writes, held until bg_join
+    keys = set()          # outputs (C / a_rowsum pointers) with a background launch in flight
 
 
 def _parse_bg(spec):
@@ -342,45 +327,18 @@ def _bg_stream(cur):
     return st
 
 
-def _bg_side_stream(cur):
-    """The stream of the small gradient work (None: it stays on the current stream)."""
-    if not (_BG.side_small and _BG.cus > 0):
-        return None
-    from . import functional as Fn
-    st = _BG.side
-    _BG.side = None
-    taken = Fn._taken_streams() | {cur.cuda_stream}
-    if _BG.stream is not None:
-        taken.add(_BG.stream.cuda_stream)
-    if st is None or st.cuda_stream in taken:
-        st = Fn.distinct_stream(taken)
-    _BG.side = st
-    if st.cuda_stream == cur.cuda_stream:
-        return None
-    st.wait_stream(cur)                                  # the operands were produced on this stream
-    _BG.side_dirty = True
-    return st
-
-
 def bg_wait(*ptrs):
-    """The current stream is about to write `ptrs` (gradient slots): wait for a background / side launch that writes them too."""
-    if (_BG.dirty or _BG.side_dirty) and any(p in _BG.keys for p in ptrs if p):
-        cur = torch.cuda.current_stream()
-        if _BG.dirty:
-            cur.wait_stream(_BG.stream)
-        if _BG.side_dirty and _BG.side.cuda_stream != cur.cuda_stream:
-            cur.wait_stream(_BG.side)
+    """The current stream is about to write `ptrs` (gradient slots): wait for a background launch that writes them too."""
+    if _BG.dirty and any(p in _BG.keys for p in ptrs if p):
+        torch.cuda.current_stream().wait_stream(_BG.stream)
 
 
 def bg_join():
     """The current stream waits for the background weight gradients (ops.functional.side_join: end of a backward pass / stage)."""
     if _BG.dirty:
         torch.cuda.current_stream().wait_stream(_BG.stream)
-    if _BG.side_dirty:
-        torch.cuda.current_stream().wait_stream(_BG.side)
-    _BG.dirty, _BG.side_dirty, _BG.count = False, False, 0
+    _BG.dirty, _BG.count = False, 0
     _BG.keys = set()
-    _BG.keep = []
 
 
 def _bg_candidates(part):
@@ -436,19 +394,12 @@ def flush_grouped(queue):
                 arr = (_lib.GemmDesc * len(part))(*part)
                 cand = _bg_candidates(part) if (_BG.cus > 0 and _BG.count < _BG.max_launches) else []
                 bg_wait(*[d.C for d in part], *[d.a_rowsum for d in part])
-                cur = torch.cuda.current_stream()
-                side = _bg_side_stream(cur)                 # where the problems the 8-wave kernel does not take run
-                if side is not None:
-                    for d in part:
-                        _BG.keys.add(d.C)
-                        if d.a_rowsum:
-                            _BG.keys.add(d.a_rowsum)
-                rest = (side or cur).cuda_stream
                 if cand:
+                    cur = torch.cuda.current_stream()
                     bg = _bg_stream(cur)
                     bg.wait_stream(cur)                     # the operands were produced on this stream
                     nbg = ctypes.c_int(0)
-                    _lib.check(_lib.lib().s2svc_gemm_grouped_bg(ctypes.addressof(arr), len(part), tile, rest,
+                    _lib.check(_lib.lib().s2svc_gemm_grouped_bg(ctypes.addressof(arr), len(part), tile, cur.cuda_stream,
                                                                 bg.cuda_stream, _BG.cus, ctypes.byref(nbg)), "s2svc_gemm_grouped_bg")
                     _BG.dirty = True                       # forked (part of a capture from here on): joined by bg_join either way
                     if nbg.value:
@@ -457,9 +408,6 @@ def flush_grouped(queue):
                             _BG.keys.add(d.C)
                             if d.a_rowsum:
                                 _BG.keys.add(d.a_rowsum)
-                elif side is not None:                      # 8-wave problems in line (full grid), the rest on the side stream
-                    _lib.check(_lib.lib().s2svc_gemm_grouped_bg(ctypes.addressof(arr), len(part), tile, rest, cur.cuda_stream, 0, None),
-                               "s2svc_gemm_grouped_bg")
                 else:
                     _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(part), tile, stream()), "s2svc_gemm_grouped")
 

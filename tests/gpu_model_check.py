@@ -630,13 +630,6 @@ def aasvc_full_size_step_is_reproducible():
         variant("weight gradients as background launches (64 workgroups, 3 launches)")
         Fn.enable_side_streams(0, inline_batches=True, wgrad_background=(24, 100))
         variant("weight gradients as background launches (24 workgroups, all launches)", n=2)
-        was_side = K._BG.side_small
-        try:
-            K._BG.side_small = True
-            Fn.enable_side_streams(0, inline_batches=True, wgrad_background=(64, 3))
-            variant("background launches + the small gradient work (4-wave grouped GEMMs, column reductions) on a side stream")
-        finally:
-            K._BG.side_small = was_side
     finally:
         Fn.set_compute_dtype(torch.float32)
         Fn.enable_side_streams(0)
