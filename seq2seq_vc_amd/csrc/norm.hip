@@ -360,6 +360,86 @@ __device__ __forceinline__ void colreduce_stage1_body(int rows, int D, int mode,
   }
 }
 
+// 16-byte variant (bf16, D % 8 == 0, 16-byte aligned tensors): a lane owns 8 consecutive columns, a wave covers 512 columns
+// of a row with one load per tensor, four rows of a row group in flight.  The scalar body moves 2 bytes per lane and load
+// (2.7 TB/s over the LayerNorm / bias reductions of an AAS-VC decoder layer: 150 MB in 55 us).  Same rows per wave, same order
+// of additions per column, same combination of the four waves as the scalar body.
+__device__ __forceinline__ void colreduce_stage1_vec_body(int rows, int D, int mode, const bf16_t* __restrict__ dy,
+                                                          const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ ws,
+                                                          int rows_per_chunk, int bx, int chunk, float (&sh)[2][4][512]) {
+  const int lane = threadIdx.x & 63;
+  const int rl = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int c = bx * 512 + lane * 8;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = (r0 + rows_per_chunk < rows) ? r0 + rows_per_chunk : rows;
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  if (c < D) {
+    float mc[8], rc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mc[e] = 0.f; rc[e] = 1.f; }
+    if (mode == 2 || mode == 3) {
+      load_f32x8(mean + c, mc);
+      if (rstd) load_f32x8(rstd + c, rc);
+    }
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const int64_t o = (int64_t)r * D + c;
+      float g[8], v[8];
+      if (mode != 3 && mode != 6) unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + o), g);
+      if (mode != 0 && mode != 5) unpack_bf16x8(*reinterpret_cast<const uint4*>(x + o), v);
+      if (mode == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[e] += g[e];
+      } else if (mode == 1) {
+        const float mr = mean[r], rr = rstd[r];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] += g[e]; s1[e] += g[e] * (v[e] - mr) * rr; }
+      } else if (mode == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] += g[e]; s1[e] += g[e] * (v[e] - mc[e]) * rc[e]; }
+      } else if (mode == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float dv = v[e] - mc[e]; s0[e] += dv * dv; }
+      } else if (mode == 6) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] += v[e]; s1[e] += v[e] * v[e]; }
+      } else if (mode == 5) {
+        const float mr = mean[r];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] += g[e]; s1[e] += g[e] * mr; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s0[e] += g[e] * v[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sh[0][rl][lane * 8 + e] = s0[e];
+    sh[1][rl][lane * 8 + e] = s1[e];
+  }
+  __syncthreads();
+  // 512 columns x 2 sums: thread t combines column t (sum 0) and column t (sum 1) of its half
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int which = i >> 9, col = i & 511;
+    if (bx * 512 + col < D)
+      ws[((int64_t)chunk * 2 + which) * D + bx * 512 + col] =
+          sh[which][0][col] + sh[which][1][col] + sh[which][2][col] + sh[which][3][col];
+  }
+}
+
+// wide rows only: at D = 384 / 512 (VTN) one workgroup per 512 columns leaves too few workgroups (4.00 -> 4.02 ms per step),
+// at D = 1536 / 3072 (AAS-VC decoder) the 16-byte loads win (12.39 -> 12.30 ms)
+__device__ __forceinline__ bool cr_vec_ok(int dtype, int D, const void* dy, const void* x) {
+  return dtype == S2S_BF16 && D >= 768 && (D & 7) == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0;
+}
+static bool cr_vec_ok_host(int dtype, int D, const void* dy, const void* x) {
+  return dtype == S2S_BF16 && D >= 768 && (D & 7) == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mode, const T* __restrict__ dy,
                                                         const T* __restrict__ x, const float* __restrict__ mean,
@@ -367,6 +447,14 @@ __global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mod
                                                         int rows_per_chunk) {
   __shared__ float sh[2][4][64];
   colreduce_stage1_body<T>(rows, D, mode, dy, x, mean, rstd, ws, rows_per_chunk, blockIdx.x, blockIdx.y, sh);
+}
+
+__global__ __launch_bounds__(256) void colreduce_stage1_vec(int rows, int D, int mode, const bf16_t* __restrict__ dy,
+                                                            const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ ws,
+                                                            int rows_per_chunk) {
+  __shared__ float shv[2][4][512];
+  colreduce_stage1_vec_body(rows, D, mode, dy, x, mean, rstd, ws, rows_per_chunk, blockIdx.x, blockIdx.y, shv);
 }
 
 // 64 columns x 4 chunk-groups per workgroup: each thread sums every 4th chunk partial (independent loads), the four
@@ -414,8 +502,16 @@ static_assert(sizeof(cr_args) <= 4096, "kernel arguments are limited to 4 KB");
 
 __global__ __launch_bounds__(256) void colreduce_grouped_stage1(const cr_args a) {
   __shared__ float sh[2][4][64];
+  __shared__ float shv[2][4][512];
   const s2svc_colreduce_item& it = a.it[blockIdx.z];
-  if ((int)blockIdx.x * 64 >= it.D || (int)blockIdx.y >= a.chunks[blockIdx.z]) return;
+  if ((int)blockIdx.y >= a.chunks[blockIdx.z]) return;
+  if (cr_vec_ok(it.dtype, it.D, it.dy, it.x)) {          // (uniform) 16-byte variant: 512 columns per workgroup
+    if ((int)blockIdx.x * 512 >= it.D) return;
+    colreduce_stage1_vec_body(it.rows, it.D, it.mode, (const bf16_t*)it.dy, (const bf16_t*)it.x, it.mean, it.rstd, it.ws,
+                              a.rpc[blockIdx.z], blockIdx.x, blockIdx.y, shv);
+    return;
+  }
+  if ((int)blockIdx.x * 64 >= it.D) return;
   if (it.dtype == S2S_F32)
     colreduce_stage1_body<float>(it.rows, it.D, it.mode, (const float*)it.dy, (const float*)it.x, it.mean, it.rstd, it.ws,
                                  a.rpc[blockIdx.z], blockIdx.x, blockIdx.y, sh);
@@ -619,7 +715,10 @@ extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void*
   if (chunks < 1) chunks = 1;
   const int rpc = (rows + chunks - 1) / chunks;
   dim3 grid((D + 63) / 64, chunks), block(256);
-  if (dtype == S2S_F32)
+  if (cr_vec_ok_host(dtype, D, dy, x))
+    hipLaunchKernelGGL(colreduce_stage1_vec, dim3((D + 511) / 512, chunks), block, 0, st, rows, D, mode, (const bf16_t*)dy,
+                       (const bf16_t*)x, mean, rstd, ws, rpc);
+  else if (dtype == S2S_F32)
     hipLaunchKernelGGL(colreduce_stage1<float>, grid, block, 0, st, rows, D, mode, (const float*)dy, (const float*)x, mean,
                        rstd, ws, rpc);
   else
@@ -639,7 +738,7 @@ extern "C" int s2svc_colreduce_grouped(const s2svc_colreduce_item* items, int n,
     cr_args a;
     std::memset(&a, 0, sizeof(a));
     a.n = (n - i0 < S2S_CR_MAX) ? n - i0 : S2S_CR_MAX;
-    int max_tiles = 1, max_chunks = 1;
+    int max_tiles = 1, max_tiles1 = 1, max_chunks = 1;
     for (int i = 0; i < a.n; ++i) {
       const s2svc_colreduce_item& it = items[i0 + i];
       S2S_REQUIRE(it.rows >= 0 && it.D > 0 && it.ws && it.ws_chunks > 0, "colreduce_grouped: bad item");
@@ -652,10 +751,12 @@ extern "C" int s2svc_colreduce_grouped(const s2svc_colreduce_item* items, int n,
       a.chunks[i] = chunks;
       a.rpc[i] = (it.rows + chunks - 1) / chunks;
       const int tiles = (it.D + 63) / 64;
+      const int tiles1 = cr_vec_ok_host(it.dtype, it.D, it.dy, it.x) ? (it.D + 511) / 512 : tiles;     // stage 1 (see its kernel)
       if (tiles > max_tiles) max_tiles = tiles;
+      if (tiles1 > max_tiles1) max_tiles1 = tiles1;
       if (chunks > max_chunks) max_chunks = chunks;
     }
-    hipLaunchKernelGGL(colreduce_grouped_stage1, dim3(max_tiles, max_chunks, a.n), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(colreduce_grouped_stage1, dim3(max_tiles1, max_chunks, a.n), dim3(256), 0, st, a);
     S2S_CHECK_LAUNCH("colreduce_grouped_stage1");
     hipLaunchKernelGGL(colreduce_grouped_stage2, dim3(max_tiles, a.n), dim3(256), 0, st, a);
     S2S_CHECK_LAUNCH("colreduce_grouped_stage2");

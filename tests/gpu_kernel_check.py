@@ -936,6 +936,24 @@ def colreduce_grouped():
         res.append(check(f"grouped colreduce #{i} sum", a, ra, torch.float32, **tol))
         if items[i][0]:
             res.append(check(f"grouped colreduce #{i} dot", b, rb, torch.float32, **tol))
+    # the 16-byte stage-1 variant (bf16 rows of >= 768 columns: a lane owns 8 columns) against fp32 torch, all modes
+    for j, (rows, D) in enumerate([(4096, 1536), (300, 3072), (65, 776)]):
+        dy, x = rnd(rows, D, seed=700 + j, dtype=torch.bfloat16), rnd(rows, D, seed=710 + j, dtype=torch.bfloat16)
+        fy, fx = dy.float(), x.float()
+        for mode in (0, 1, 2, 3, 4, 6):
+            per_row = mode == 1
+            mean = rnd(rows if per_row else D, seed=720 + j)
+            rstd = rnd(rows if per_row else D, seed=730 + j).abs() + 0.5
+            s_, d_ = K.colreduce(mode, None if mode in (3, 6) else dy, None if mode == 0 else x,
+                                 mean if mode in (1, 2, 3) else None, rstd if mode in (1, 2) else None, want_dot=mode in (1, 2, 6))
+            mb, rb_ = (mean[:, None], rstd[:, None]) if per_row else (mean[None, :], rstd[None, :])
+            want = {0: (fy.sum(0), None), 1: (fy.sum(0), (fy * (fx - mb) * rb_).sum(0)), 2: (fy.sum(0), (fy * (fx - mb) * rb_).sum(0)),
+                    3: (((fx - mb) ** 2).sum(0), None), 4: ((fy * fx).sum(0), None), 6: (fx.sum(0), (fx * fx).sum(0))}[mode]
+            sc = float(want[0].abs().max()) + 1.0
+            res.append(check(f"colreduce 16-byte {rows}x{D} mode {mode} sum", s_, want[0], torch.float32, rtol=1e-4, atol=1e-4 * sc))
+            if want[1] is not None:
+                sc = float(want[1].abs().max()) + 1.0
+                res.append(check(f"colreduce 16-byte {rows}x{D} mode {mode} dot", d_, want[1], torch.float32, rtol=1e-4, atol=1e-4 * sc))
     return res
 
 
