@@ -1057,7 +1057,8 @@ extern "C" int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs, int n, v
     total128 += (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1;
   }
   // 128 x 128 tiles once they fill the chip (the rule of the plain launch, over the group), else 64 x 64
-  const int tile = total128 >= 256 ? 128 : 64;
+  static const int force_tile = [] { const char* e = getenv("S2SVC_ATTN_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B aid
+  const int tile = force_tile == 64 || force_tile == 128 ? force_tile : (total128 >= 256 ? 128 : 64);
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {
     const s2svc_gemm_desc& d = descs[i];
