@@ -51,4 +51,9 @@ prof /tmp/prof_sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 python tools/rocpd_pmc.py "$(db /tmp/prof_sq1)" gemm_8ph > "$OUT/roofline_vtn_pmc_sq.txt" 2>&1
 prof /tmp/prof_sq2 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/prof_sq2 -o r -- python "$R/bench.py" --roofline-only
 python tools/rocpd_pmc.py "$(db /tmp/prof_sq2)" gemm_8ph >> "$OUT/roofline_vtn_pmc_sq.txt" 2>&1
+# the same two SQ passes for the GEMM that carries the AAS-VC step (4096 x 1536 x 1536, 256 x 128 tiles)
+prof /tmp/prof_sq3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/prof_sq3 -o r -- python "$R/bench.py" --roofline-only --workload aasvc
+python tools/rocpd_pmc.py "$(db /tmp/prof_sq3)" gemm_8ph > "$OUT/roofline_aasvc_pmc_sq.txt" 2>&1
+prof /tmp/prof_sq4 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/prof_sq4 -o r -- python "$R/bench.py" --roofline-only --workload aasvc
+python tools/rocpd_pmc.py "$(db /tmp/prof_sq4)" gemm_8ph >> "$OUT/roofline_aasvc_pmc_sq.txt" 2>&1
 ls -la "$OUT"
