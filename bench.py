@@ -260,11 +260,18 @@ def _time_graph_loop(launch, iters):
                     launch()
             g.replay()
             side.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(side)
-            g.replay()
-            e1.record(side)
-            side.synchronize()
+            # three timed replays, the MEDIAN reported: one replay of a 50-launch graph was once seen 45 x slower than the
+            # others (785 vs 17 us per launch, profiles/r03 collection: a stall on the host box, not the kernel)
+            ms = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                g.replay()
+                e1.record(side)
+                side.synchronize()
+                ms.append(e0.elapsed_time(e1))
+            torch.cuda.current_stream().wait_stream(side)
+            return sorted(ms)[1] / iters, timed + " (median of 3 replays)"
     except Exception as e:  # noqa: BLE001 -- report it and time a plain launch loop instead
         print(f"[bench] roofline graph capture failed ({type(e).__name__}: {e}); timing a Python launch loop", file=sys.stderr)
         timed = "python launch loop"
@@ -593,11 +600,13 @@ def bench_decode(dev, dtype, batch=16, iters=5, poll=32, cpu=True):
     res = run()            # builds the session + captures the step graph
     run()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    ts = []
+    for _ in range(iters):             # host-paced (a poll every `poll` steps): the median batch, not the mean, is reported
+        t0 = time.perf_counter()
         res = run()
-    torch.cuda.synchronize()
-    t = (time.perf_counter() - t0) / iters
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
     frames = sum(r[0].shape[0] for r in res)
     nsteps = frames // (batch * VTN_VC1["decoder_reduction_factor"])
     out = {"metric": "RTF (AR decode, batch aggregate)", "value": t / (frames * HOP / SR), "unit": "wall s / audio s",

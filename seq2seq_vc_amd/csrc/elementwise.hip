@@ -274,6 +274,41 @@ __global__ void gather3_grouped_kernel(const gather_jobs g) {
   const s2svc_gather3_job& jb = g.j[blockIdx.y];
   const int64_t n = (int64_t)jb.n0 * jb.n1 * jb.n2;
   const float* in = (const float*)jb.in;
+  // Column gathers (the innermost output index has the LARGEST source stride: the data-gradient layout (C_in, k, C_out) of a
+  // Conv1d weight (C_out, C_in, k), s2 = C_in * k) through 64 x 64 LDS tiles: read with the lanes along (i0, i1) -- a run of
+  // source addresses -- and written with the lanes along i2.  The element-wise loop below reads 4 bytes per 18 KB-apart
+  // address there (the two 1536 x 1536 x 3 aligner weights of AAS-VC: most of a 135 us launch).
+  const int64_t a0 = jb.s0 < 0 ? -jb.s0 : jb.s0, a1 = jb.s1 < 0 ? -jb.s1 : jb.s1;
+  if (jb.s2 >= 64 && jb.s2 > a0 && jb.s2 > a1 && jb.n2 >= 32) {           // (uniform per job)
+    __shared__ float tile[64][65];
+    const int R = jb.n0 * jb.n1;
+    const int tc = (jb.n2 + 63) / 64, nt = ((R + 63) / 64) * tc;
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+      const int r0 = (t / tc) * 64, c0 = (t - (t / tc) * tc) * 64;
+      const int r = r0 + x;
+      int64_t a = 0;
+      if (r < R) {
+        const int i0 = r / jb.n1, i1 = r - i0 * jb.n1;
+        a = jb.off + i0 * jb.s0 + i1 * jb.s1;
+      }
+#pragma unroll 4
+      for (int cc = y; cc < 64; cc += 4) tile[cc][x] = (r < R && c0 + cc < jb.n2) ? in[a + (int64_t)(c0 + cc) * jb.s2] : 0.f;
+      __syncthreads();
+#pragma unroll 4
+      for (int rr = y; rr < 64; rr += 4) {
+        const int ro = r0 + rr, c = c0 + x;
+        if (ro < R && c < jb.n2) {
+          const float v = tile[x][rr];
+          const int64_t o = (int64_t)ro * jb.n2 + c;
+          if (jb.out_dtype == S2S_F32) ((float*)jb.out)[o] = v;
+          else ((bf16_t*)jb.out)[o] = f2bf(v);
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int i2 = (int)(i % jb.n2);
     const int64_t t = i / jb.n2;

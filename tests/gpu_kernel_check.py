@@ -958,6 +958,37 @@ def colreduce_grouped():
 
 
 @case
+def gather3_grouped_refresh():
+    """s2svc_gather3_grouped (the one-launch refresh of every permuted convolution weight after an optimiser step) == one
+    s2svc_gather3 per copy, bit for bit: forward and data-gradient layouts of Conv1d weights (the latter takes the LDS-tile path:
+    innermost output index with the largest source stride), Conv2d taps, ragged extents, both output dtypes, > 24 jobs."""
+    res = []
+    jobs = []
+    shapes = [(1536, 512, 3), (512, 80, 5), (80, 512, 5), (384, 384, 3), (100, 37, 3), (65, 130, 1), (33, 31, 7)]
+    for i, (O, I, ks) in enumerate(shapes * 4):
+        w = rnd(O, I, ks, seed=900 + i)
+        odt = torch.bfloat16 if i % 2 else torch.float32
+        jobs.append((w, ((O, ks, I), (I * ks, 1, ks), 0, odt)))                       # (O, k, I): forward
+        jobs.append((w, ((I, ks, O), (ks, -1, I * ks), ks - 1, odt)))                 # (I, k flipped, O): data gradient
+    w2 = rnd(96, 64, 3, 3, seed=990)
+    jobs.append((w2, ((96, 9, 64), (64 * 9, 1, 9), 0, torch.bfloat16)))
+    registry = [(w, key, torch.full(key[0], float("nan"), dtype=key[3], device=DEV)) for w, key in jobs]
+    K.gather3_refresh(registry)
+    bad = []
+    for (w, (n, st, off, odt), buf) in registry:
+        ref = K.gather3(w, n, st, off, odt)
+        if not torch.equal(buf, ref):
+            bad.append((tuple(w.shape), n, st))
+    res.append((not bad, f"grouped refresh of {len(registry)} permuted copies == one gather each: {len(bad)} differ {bad[:3]}"))
+    # and the gather itself against torch indexing for one of each kind
+    w = jobs[0][0]
+    O, I, ks = w.shape
+    res.append(check("gather3 (O, k, I)", registry[0][2], w.permute(0, 2, 1).contiguous(), registry[0][2].dtype, atol=1e-2))
+    res.append(check("gather3 (I, k flipped, O)", registry[1][2], w.flip(2).permute(1, 2, 0).contiguous(), registry[1][2].dtype, atol=1e-2))
+    return res
+
+
+@case
 def transposed_weight_copies():
     """s2svc_transpose_tiles: every matrix of a table transposed in one launch (64x64 tiles; 16-byte path and the
     element-wise path for extents / offsets that are not multiples of 8), bit-exact."""
