@@ -237,7 +237,9 @@ class AASVC(nn.Module):
         Tx = hs.shape[1]
         il_c = il.clamp(Tx)
         stochastic = self.duration_predictor_type == "stochastic"
-        tmask = (torch.arange(Tx, device=dev)[None, :] < il_c.dev[:, None])     # (B, T_text) non-pad
+        def n_text():       # number of non-pad text positions (device scalar); only the duration branch divides by it
+            return torch.sum(torch.arange(Tx, device=dev)[None, :] < il_c.dev[:, None])
+
         if is_inference:
             log_p_attn, ds, bin_loss = None, None, 0.0
             if ys is not None:
@@ -269,8 +271,8 @@ class AASVC(nn.Module):
             if stochastic:
                 # ~330 small launches that depend on nothing the length regulator / decoder / postnet below produce: they
                 # run on the auxiliary stream beside them (forward here, backward through autograd's stream rule)
-                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dp_input(), il_c, w=ds) / torch.sum(tmask),
-                                               uses=(ds, tmask, hs, dp_inputs, il_c.dev))
+                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dp_input(), il_c, w=ds) / n_text(),
+                                               uses=(ds, hs, dp_inputs, il_c.dev))
             else:
                 d_outs = self.duration_predictor(dpi, il_c)
                 ret["d_outs"] = torch.clamp(d_outs, max=MAX_DP_OUTPUT)

@@ -63,11 +63,13 @@ class _ARSeq2Seq(nn.Module):
                 {"root": "cut:encoder_out", "modules": layers + tail},
                 {"root": "cut:encoder.0", "modules": embed}]
 
-    def _decoder_head(self, ys, olens):
+    def _decoder_head(self, ys, olens, labels=None):
         """Teacher-forcing inputs of the decoder and -- in training, on the GPU -- the part of the decoder that does not see the
         encoder (input layer + positional encoding + the first layer's self-attention block), started on the auxiliary stream
         so that it runs beside the encoder (forward) and beside the encoder's backward pass (autograd runs a node on the stream
-        of its forward op).  -> state for _teacher_forced(..., pre=state)."""
+        of its forward op).  The shifted decoder input and the stop labels of the trimmed targets (`labels`, a few tiny torch
+        kernels that depend on the batch only) go there with it instead of sitting on the main chain.
+        -> state for _teacher_forced(..., pre=state)."""
         r = self.decoder_reduction_factor
         dev = ys.device
         olens_h = Mo.Lens.of(olens, dev)
@@ -76,18 +78,35 @@ class _ARSeq2Seq(nn.Module):
             olens_in_h = olens_h.map(lambda v: v // r)
         else:
             ys_in, olens_in_h = ys, olens_h
-        ys_in = torch.cat([ys_in.new_zeros((ys_in.shape[0], 1, ys_in.shape[2])), ys_in[:, :-1]], dim=1)
-        head = None
+        def shifted():
+            return torch.cat([ys_in.new_zeros((ys_in.shape[0], 1, ys_in.shape[2])), ys_in[:, :-1]], dim=1)
+
+        head, stop = None, None
         if _HEAD_START and self.training and ys.is_cuda and torch.is_grad_enabled():
-            head = Fn.branch_run(lambda: self.decoder.head(Fn.to_compute(ys_in), olens_in_h, causal=True),
-                                 uses=(ys_in, olens_in_h.dev))
-        return olens_h, olens_in_h, ys_in, head
+            def run():
+                y0 = shifted()
+                lab = self._stop_labels(labels, olens_h)[1] if labels is not None else None
+                return y0, lab, self.decoder.head(Fn.to_compute(y0), olens_in_h, causal=True)
+
+            ys_in, stop, head = Fn.branch_run(run, uses=(ys, labels, olens_in_h.dev, olens_h.dev))
+        else:
+            ys_in = shifted()
+        return olens_h, olens_in_h, ys_in, head, stop
+
+    def _stop_labels(self, labels, olens_h):
+        """Targets trimmed to a multiple of the reduction factor: (trimmed lengths, labels with the stop flag at the last kept
+        frame) -- reference models/vtn.py:253-260."""
+        r = self.decoder_reduction_factor
+        olens_out_h = olens_h.map(lambda v: v - v % r)
+        mx = olens_out_h.max()
+        idx = (olens_out_h.dev.long() - 1).unsqueeze(1)
+        return olens_out_h, torch.scatter(labels[:, :mx], 1, idx, 1.0)
 
     def _teacher_forced(self, hs, hs_lens, ys, labels, olens, pre=None):
         r, odim = self.decoder_reduction_factor, self.odim
-        olens_h, olens_in_h, ys_in, head = pre if pre is not None else self._decoder_head(ys, olens)
+        olens_h, olens_in_h, ys_in, head, stop = pre if pre is not None else self._decoder_head(ys, olens)
         if head is not None:
-            Fn.branch_join(*head)
+            Fn.branch_join(*head, ys_in, stop)
             zs, _ = self.decoder(None, olens_in_h, hs, hs_lens, causal=True, head=head)
         else:
             zs, _ = self.decoder(Fn.to_compute(ys_in), olens_in_h, hs, hs_lens, causal=True)
@@ -98,13 +117,14 @@ class _ARSeq2Seq(nn.Module):
         if r > 1:
             if min(olens_h.host) < r:
                 raise AssertionError("Output length must be greater than or equal to reduction factor.")
-            olens_out_h = olens_h.map(lambda v: v - v % r)
+            if stop is not None:                 # made beside the encoder (_decoder_head)
+                olens_out_h = olens_h.map(lambda v: v - v % r)
+                labels = stop
+            else:
+                olens_out_h, labels = self._stop_labels(labels, olens_h)
             new = list(olens_out_h.host)
             olens_out = Mo.tag_lens(olens.new_tensor(new) if isinstance(olens, torch.Tensor) else torch.tensor(new), olens_out_h)
-            mx = olens_out_h.max()
-            ys, labels = ys[:, :mx], labels[:, :mx]
-            idx = (olens_out_h.dev.long() - 1).unsqueeze(1)
-            labels = torch.scatter(labels, 1, idx, 1.0)
+            ys = ys[:, :olens_out_h.max()]
         olens_in = Mo.tag_lens(olens.new_tensor(olens_in_h.host) if isinstance(olens, torch.Tensor) else torch.tensor(olens_in_h.host),
                                olens_in_h)
         return after, before, logits, ys, labels, olens_out, olens_in
@@ -225,7 +245,7 @@ class VTN(_ARSeq2Seq):
             xs = xs[:, : il.max()]
         if ol.max() != ys.shape[1]:
             ys, labels = ys[:, : ol.max()], labels[:, : ol.max()]
-        pre = self._decoder_head(ys, olens)
+        pre = self._decoder_head(ys, olens, labels if self.decoder_reduction_factor > 1 else None)
         hs, hs_lens = self.encoder(Fn.to_compute(xs), il)
         hs = Fn.cut_point(hs, "encoder_out")      # data-parallel overlap: decoder-side gradients travel during the encoder's backward
         after, before, logits, ys_, labels_, olens_, olens_in = self._teacher_forced(hs, hs_lens, ys, labels, olens, pre=pre)
