@@ -714,7 +714,7 @@ class PermRegistry(list):
             # may read the copies next without passing an event, so the host waits -- a rare path; inside a capture the
             # refresh becomes part of the graph on the capturing stream, where its consumers are
             self.refresh()
-            if not torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
                 torch.cuda.current_stream().synchronize()
         ev = self.ev_perm if what == "perm" else self.ev_all
         if ev is not None:
