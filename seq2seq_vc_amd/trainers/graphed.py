@@ -25,6 +25,7 @@ builds everything that is built lazily for the shape).  With lengths rounded to 
 handful of keys per model; a sampler that buckets utterances by length keeps the hit rate high on corpora with a wide spread.
 """
 import gc
+import os
 import logging
 from collections import OrderedDict
 
@@ -56,6 +57,11 @@ class GraphedStep:
         self.capture_after = max(2, int(trainer.config.get("graph_capture_after", 2)))
         self.evictions = 0
         self.stream = torch.cuda.Stream(trainer.device)      # replaced by a distinct one at capture time if it aliases a stream in use
+        # host batches reach the static buffers through two alternating device staging buffers filled on a COPY stream: the
+        # host-to-device copy of batch n + 1 (5 MB for VTN vc1: ~0.2 ms of the step's stream when it is issued there) runs beside
+        # the graphs of batch n, the step's stream only does a device-to-device copy.  S2SVC_TRAINER_STAGE_H2D=0: copy in line
+        self.copy_stream = "lazy" if os.environ.get("S2SVC_TRAINER_STAGE_H2D", "1") != "0" else None
+        self._stage = {}
         self.pool = torch.cuda.graph_pool_handle()     # one memory pool for the graphs of all shapes
         if trainer.gradient_accumulate_steps != 1:
             raise NotImplementedError('config["hip_graph"] needs gradient_accumulate_steps == 1')
@@ -89,13 +95,40 @@ class GraphedStep:
                 st = torch.empty((src.shape[0], Tb) + tuple(src.shape[2:]), dtype=src.dtype, device=dev)
                 e.static[name] = st
                 e.caps.setdefault(lname, Tb)
-            st[:, :T].copy_(src, non_blocking=True)
+            if self.copy_stream is not None and not src.is_cuda:
+                self._staged_copy(name, st, src, T)
+            else:
+                st[:, :T].copy_(src, non_blocking=True)
             if Tb > T:
                 st[:, T:].fill_(pad)
             if lname not in e.lens_src:
                 e.lens_src[lname] = torch.zeros(src.shape[0], dtype=torch.long)
             e.lens_src[lname].copy_(torch.as_tensor(batch[lname]).to(torch.long))
         return {**{k: v for k, v in batch.items() if k not in e.static and k not in e.lens_src}, **e.static, **e.lens_src}
+
+    def _staged_copy(self, name, st, src, T):
+        key = (name, tuple(st.shape), st.dtype)
+        slot = self._stage.get(key)
+        if slot is None:
+            slot = self._stage[key] = {"buf": [torch.empty_like(st), torch.empty_like(st)], "free": [None, None], "i": 0}
+        i = slot["i"]
+        slot["i"] ^= 1
+        if self.copy_stream == "lazy":                 # (torch hands out stream objects round-robin: take one nothing else uses)
+            from ..ops import functional as Fn
+            self.copy_stream = Fn.distinct_stream(Fn._taken_streams() | {self.stream.cuda_stream})
+        buf, cs = slot["buf"][i], self.copy_stream
+        if slot["free"][i] is not None:
+            cs.wait_event(slot["free"][i])            # the device copy that last read this staging buffer
+        with torch.cuda.stream(cs):
+            buf[:, :T].copy_(src, non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record(cs)
+        main = torch.cuda.current_stream()
+        main.wait_event(landed)
+        st[:, :T].copy_(buf[:, :T])
+        done = torch.cuda.Event()
+        done.record(main)
+        slot["free"][i] = done
 
     def _roots(self, e, bank):
         for lname, src in e.lens_src.items():
