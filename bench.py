@@ -343,7 +343,8 @@ def dominant_kernel_roofline(dtype, iters=100, workload="vtn"):
     alg_bytes = float((x.numel() + w.numel() + y.numel()) * x.element_size())
     return {"bound": "mfma", "kernel": f"{kernel} {shape}", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": _pmc_traffic(workload) if dtype == torch.bfloat16 else None, "algorithmic_bytes": alg_bytes,
-            "avg_launch_us": ms * 1e3, "flops_per_launch": flops, "timed": f"{iters} launches, {timed}, HIP events"}
+            "avg_launch_us": ms * 1e3, "flops_per_launch": flops, "timed": f"{iters} launches, {timed}, HIP events",
+            "by_time": _by_time(workload) if dtype == torch.bfloat16 else None}
 
 
 # =====================================================================================================================
@@ -745,6 +746,57 @@ def bench_product_trainer(dev, dtype, steps=40):
         Fn_reset()
 
 
+def _by_time(workload):
+    """The kernel family the STEP spends most of its time in (profiles/step_by_time.json, written by tools/step_by_time.py from the
+    rocprofv3 kernel trace + SQ counter pass of whole steps): the FLOP-heaviest launch above is a few percent of the VTN step, so the
+    headline roofline also names where the time goes and how busy the MFMA pipe is there."""
+    path = os.path.join(ROOT, "profiles", "step_by_time.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(workload)
+
+
+def _flat_front(out):
+    """The driver's record keeps top-level SCALARS (and only the key names of nested objects): the C3 / C5 figures and the rooflines
+    as flat keys in FRONT of the line; the nested objects follow unchanged."""
+    flat = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in out}
+
+    def put(key, obj, *path):
+        for p in path:
+            if not isinstance(obj, dict) or p not in obj:
+                return
+            obj = obj[p]
+        if isinstance(obj, (int, float, str, bool)) or obj is None:
+            flat[key] = obj
+    put("roofline_frac", out, "roofline", "frac")
+    put("roofline_kernel_us", out, "roofline", "avg_launch_us")
+    put("roofline_by_time_family", out, "roofline", "by_time", "family")
+    put("roofline_by_time_share", out, "roofline", "by_time", "share_of_kernel_time")
+    put("roofline_by_time_mfma_busy", out, "roofline", "by_time", "mfma_busy")
+    put("step_mfma_frac", out, "step_mfma", "frac_of_bf16_peak")
+    put("cpu_baseline_value", out, "cpu_baseline", "value")
+    put("cpu_baseline_cores", out, "cpu_baseline", "cores")
+    put("aasvc_ms_per_step", out, "aasvc", "ms_per_step")
+    put("aasvc_mel_frames_per_s", out, "aasvc", "value")
+    put("aasvc_roofline_frac", out, "aasvc", "roofline", "frac")
+    put("aasvc_step_mfma_frac", out, "aasvc", "step_mfma", "frac_of_bf16_peak")
+    put("aasvc_cpu_baseline", out, "aasvc", "cpu_baseline", "value")
+    put("aasvc_cpu_baseline_cores", out, "aasvc", "cpu_baseline", "cores")
+    put("decode_rtf", out, "decode", "value")
+    put("decode_us_per_step", out, "decode", "us_per_step")
+    put("decode_cpu_baseline_rtf", out, "decode", "cpu_baseline", "value")
+    put("trainer_hip_graph_ms_per_step", out, "trainer", "hip_graph_ms_per_step")
+    put("trainer_eager_ms_per_step", out, "trainer", "eager_ms_per_step")
+    put("mas_us_per_utterance", out, "alignment", "mas", "us_per_utterance")
+    put("forward_sum_us_per_utterance", out, "alignment", "forward_sum", "us_per_utterance")
+    for k, v in out.items():
+        if k not in flat:
+            flat[k] = v
+    return flat
+
+
 def Fn_reset():
     from seq2seq_vc_amd.ops import functional as Fn
     Fn.enable_side_streams(0)
@@ -867,6 +919,7 @@ def main():
                     out[key] = {"error": f"{type(e).__name__}: {e}"}
                     print(f"[bench] sub-benchmark '{key}' failed: {type(e).__name__}: {e}", file=sys.stderr)
                 Fn.enable_side_streams(0)
+        out = _flat_front(out)
         # RCCL writes its version banner to the C-level stdout; flush that buffer first so the JSON line stays the last line
         sys.stdout.flush()
         try:
