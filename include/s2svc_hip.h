@@ -421,53 +421,6 @@ int s2svc_relattn_bwd(int B, int H, int T, int dk, const void* dctx, int64_t ldo
                       uint64_t seed_off, void* ds, void* dbd, int Lq, void* stream);
 
 /* ========================================================================================== */
-/* Fused attention SUB-LAYERS (csrc/attn_block.hip), bf16, T1, T2 <= 64, (D, d_k) in          */
-/* {(256,64),(384,96)}: one workgroup per (utterance, head), ONE launch for                    */
-/*   fwd: [LayerNorm(x)] -> this head's Q (K, V) projection -> mask, softmax, dropout, P.V     */
-/*   bwd: [dropout mask | LayerNorm'] of the residual-stream gradient -> dCtx = dA.Wo -> dQ,dK,dV */
-/* replaces the norm -> self_attn / src_attn -> dropout -> residual lines of                   */
-/* modules/transformer/encoder_layer.py:96-107, decoder_layer.py:104-121 around                */
-/* attention.py:39-111 (three launches forward, three backward in the unfused path).           */
-/* ========================================================================================== */
-int s2svc_attn_block_supported(int dtype, int T1, int T2, int D, int H);
-/* x (B,T1,D) rows; gamma/beta != NULL: y = LayerNorm(x) is the projection's input and is written with mean / rstd (B*T1);
-   nproj 3: w = [Wq;Wk;Wv] (3D, D), proj (B,T1,3D) = packed Q|K|V (T2 == T1); nproj 1: w = Wq (D, D), proj (B,T1,D) = Q,
-   k / v = (B,T2,.) views of the memory's projection (row stride ld*, batch stride *bs, last dim contiguous).
-   attn (B,H,T1,ld) = probabilities before dropout; out (B,T1,D) = context vectors (input of the output projection). */
-int s2svc_attn_block_fwd(int B, int H, int T1, int T2, int D, int nproj, const void* x, const float* gamma, const float* beta,
-                         float eps, void* y, float* mean, float* rstd, const void* w, const float* bias, void* proj,
-                         const void* k, int64_t ldk, int64_t kbs, const void* v, int64_t ldv, int64_t vbs, const int32_t* klen,
-                         int causal, float scale, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* attn, int ld,
-                         void* out, void* stream);
-/* g (B,T1,D) = gradient of the residual stream s = res + hscale * dropout(A, p_res) behind the output projection A = ctx.Wo^T + b.
-   mode 0: dA = g * dropmask * hscale.   mode 1: g is the gradient of LayerNorm(s): dS = ds_extra + LayerNorm'(g; s, mean, rstd,
-   gamma) is written to ds, dA = dS * dropmask * hscale.  dA is written to `da` when given (operand of Wo's weight gradient).
-   wo_t = Wo^T (D, D) row-major (the optimiser's transposed bf16 shadow).  q / k / v / attn / dattn / dq / dk / dv as in
-   s2svc_attn_fused_bwd (d_k = D / H). */
-int s2svc_attn_block_bwd(int B, int H, int T1, int T2, int D, int mode, const void* g, const void* s, const float* mean,
-                         const float* rstd, const float* gamma, const void* ds_extra, void* ds, void* da, float p_res, float hscale,
-                         const uint64_t* seed_res_base, uint64_t seed_res_off, const void* wo_t, const void* q, int64_t ldq,
-                         int64_t qbs, const void* k, int64_t ldk, int64_t kbs, const void* v, int64_t ldv, int64_t vbs,
-                         const void* attn, const void* dattn, int ld, float scale, float drop_p, const uint64_t* seed_base,
-                         uint64_t seed_off, void* dq, int64_t lddq, int64_t dqbs, void* dk_out, int64_t lddk, int64_t dkbs, void* dv,
-                         int64_t lddv, int64_t dvbs, void* stream);
-
-/* ========================================================================================== */
-/* GEMM with a row prologue over the model width (csrc/gemm_rowpro.hip), bf16, K = D in         */
-/* {256, 384, 512}:  C = epilogue( prologue(x)[M, D] . w[N, D]^T )                              */
-/*   mode 0: rows as they are; mode 1: LayerNorm (y, mean, rstd are written); mode 2: rows *    */
-/*   dropmask(p_a, seed_a) * hscale (written to y when given).                                  */
-/* `epi` carries the output side of a s2svc_gemm_desc: M, N, K (= D), C, ldc, c_dtype (bf16),   */
-/* bias, act, drop_p / seed, emask, res, c_pre; A / B of the descriptor are ignored.            */
-/* replaces the LayerNorm in front of a feed-forward block (encoder_layer.py:108-113,           */
-/* decoder_layer.py:122-127) and the dropout-mask pass in front of its backward GEMM.           */
-/* ========================================================================================== */
-int s2svc_gemm_rowpro_supported(int dtype, int D);
-int s2svc_gemm_rowpro(int mode, int D, const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean,
-                      float* rstd, float p_a, float hscale, const uint64_t* seed_a_base, uint64_t seed_a_off, const void* w,
-                      const s2svc_gemm_desc* epi /* host */, void* stream);
-
-/* ========================================================================================== */
 /* Token embedding of Transformer-TTS (models/transformer_tts.py:63-77, Embedding(idim, adim, */
 /* padding_idx=0)): y[i,:] = W[idx[i],:] ; dW[v,:] = sum_{idx[i]==v} dy[i,:], dW[padding]=0     */
 /* ========================================================================================== */

@@ -25,7 +25,7 @@ def sources():
 def build_library(force=False, verbose=True):
     """Compile csrc/*.hip -> csrc/libs2svc_hip.so for gfx950 (in-tree, so it travels to the GPU box)."""
     srcs = [os.path.join(CSRC, f) for f in sources()]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "rowblock.h"),
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
                    os.path.join(_HERE, "..", "include", "s2svc_hip.h")]
     if not force and os.path.exists(LIB_PATH):
         newest = max(os.path.getmtime(p) for p in deps)
@@ -177,15 +177,6 @@ _SIGS = {
                           c_f32, c_vp, c_u64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp],
     "s2svc_relattn_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i32, c_f32, c_f32, c_vp, c_u64,
                           c_vp, c_vp, c_i32, c_vp],
-    "s2svc_attn_block_supported": [c_i32, c_i32, c_i32, c_i32, c_i32],
-    "s2svc_attn_block_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                             c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_f32, c_vp, c_u64, c_vp, c_i32, c_vp, c_vp],
-    "s2svc_attn_block_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32,
-                             c_vp, c_u64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i32, c_f32,
-                             c_f32, c_vp, c_u64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
-    "s2svc_gemm_rowpro_supported": [c_i32, c_i32],
-    "s2svc_gemm_rowpro": [c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp,
-                          ctypes.POINTER(GemmDesc), c_vp],
     "s2svc_duration_loss_fwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_duration_loss_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_embedding_fwd": [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],

@@ -16,7 +16,6 @@ import torch
 from torch import nn
 
 from .ops import functional as Fn
-from .ops import fused_layers as FL
 from .ops import kernels as K
 
 # ------------------------------------------------------------------------------------------------
@@ -472,7 +471,7 @@ class DecoderLayer(nn.Module):
         self.dropout_rate = dropout_rate
         self.normalize_before = normalize_before
 
-    def self_block(self, x, tgt_lens, normed=None, causal=True, fused_head=False):
+    def self_block(self, x, tgt_lens, normed=None, causal=True):
         """The part of the layer that does not see the memory: the self-attention sub-layer up to the input of the
         source attention.  -> (y, x): y feeds the source attention, x is the residual stream (post-LN: the same tensor)."""
         p = self.dropout_rate if self.training else 0.0
@@ -480,10 +479,6 @@ class DecoderLayer(nn.Module):
             y = self.norm1(x) if normed is None else normed
             a = self.self_attn(y, y, y, tgt_lens, causal=causal)
             return _res_norm(self.norm2, x, a, p)
-        if fused_head and normed is None and FL.dec_self_ok(self, x):
-            # (s1, s1, tag): the PRE-norm stream; the fused layer function applies norm1 in its next kernel (run_stack)
-            s1 = FL.dec_self_block(self, x, None, tgt_lens, causal)
-            return s1, s1, _FUSED_HEAD
         a, xr = _sub_pass(self.self_attn, x, x, x, tgt_lens, causal=causal)
         x, _ = _res_norm(self.norm1, xr, a, p)
         return x, x
@@ -504,31 +499,6 @@ class DecoderLayer(nn.Module):
         return x, None
 
 
-_FUSED_HEAD = object()      # third member of a head tuple: head[0] is the PRE-norm stream s1 of a fused self-attention block
-
-
-def _fused_stack(layers, x, after_norm, pre_ln, args, per_layer):
-    """"encoder" / "decoder" when every layer of the stack can run as a fused layer function (ops/fused_layers.py), else None."""
-    if x is None and per_layer is not None and per_layer[0].get("head") is not None:
-        x = per_layer[0]["head"][0]
-    if x is None or x.dtype != torch.bfloat16 or not len(layers):
-        return None
-    only = os.environ.get("S2SVC_FUSED_ONLY", "")          # tuning / debugging aid: "enc" or "dec"
-    if all(type(l) is EncoderLayer for l in layers):
-        if only != "dec" and pre_ln and after_norm is not None and len(args) == 1 and per_layer is None and all(FL.enc_layer_ok(l, x) for l in layers):
-            return "encoder"
-        return None
-    if all(type(l) is DecoderLayer for l in layers):
-        if only == "enc" or pre_ln or len(args) != 3 or per_layer is None or not all("kv" in d for d in per_layer):
-            return None
-        for li, d in enumerate(per_layer):
-            head = d.get("head")
-            if head is not None and (li != 0 or len(head) != 3):
-                return None
-        return "decoder" if all(FL.dec_layer_ok(l, x, args[1]) for l in layers) else None
-    return None
-
-
 def run_stack(layers, x, after_norm, pre_ln, dropout_rate, training, *args, per_layer=None, **kw):
     """Run a stack of EncoderLayer/DecoderLayer.  In pre-LN mode each layer returns (x, pending FFN
     output); `x + dropout(f)` is fused into the NEXT layer's first LayerNorm (or after_norm).
@@ -536,30 +506,6 @@ def run_stack(layers, x, after_norm, pre_ln, dropout_rate, training, *args, per_
     p = dropout_rate if training else 0.0
     pending = None
     cut_name = kw.pop("cut_name", None)      # data-parallel overlap: "<name>.<i>" cuts the graph at the input of layer i
-    fused = _fused_stack(layers, x, after_norm, pre_ln, args, per_layer)
-    if fused == "encoder":                   # one autograd node and 4 launches per layer (ops/fused_layers.py)
-        for li, layer in enumerate(layers):
-            if cut_name is not None and li > 0:
-                x = Fn.cut_point(x, f"{cut_name}.{li}")
-            x = FL.enc_layer(layer, x, args[0])
-        return after_norm(x)
-    if fused == "decoder":                   # post-LN: the layers exchange the pre-norm stream, 6 launches per layer
-        tgt_lens, _, mem_lens = args
-        prev = None
-        for li, layer in enumerate(layers):
-            head = per_layer[li].get("head")
-            if head is not None:
-                x = FL.dec_layer(layer, head[0], None, tgt_lens, per_layer[li]["kv"], mem_lens, kw.get("causal", True), from_s1=True)
-            else:
-                x = FL.dec_layer(layer, x, prev, tgt_lens, per_layer[li]["kv"], mem_lens, kw.get("causal", True))
-            prev = layer.norm3
-        return prev(x)
-    if per_layer is not None:                # a fused head start (pre-norm stream) meets a stack that takes the modular path
-        for li, layer in enumerate(layers):
-            head = per_layer[li].get("head")
-            if head is not None and len(head) == 3:
-                xn = layer.norm1(head[0])
-                per_layer[li] = dict(per_layer[li], head=(xn, xn))
     for li, layer in enumerate(layers):
         kwl = dict(kw, **per_layer[li]) if per_layer is not None else kw      # this layer's own extras only
         if cut_name is not None and li > 0:
@@ -767,7 +713,7 @@ class Decoder(nn.Module):
         self-attention block of the first layer.  In training the AR models run it on the auxiliary stream while the encoder
         runs (models/vtn.py); forward(..., head=...) continues from it."""
         x = self.embed_input(tgt)
-        return self.decoders[0].self_block(x, tgt_lens, None, causal, fused_head=getattr(self, "_src_kv_all", None) is not None)
+        return self.decoders[0].self_block(x, tgt_lens, None, causal)
 
     def forward(self, tgt, tgt_lens, memory, mem_lens, causal=True, head=None):
         x = self.embed_input(tgt) if head is None else head[1]

@@ -1292,148 +1292,6 @@ def bn_two_launch_statistics():
     return res
 
 
-@case
-def attn_block_kernels_vs_unfused():
-    """csrc/attn_block.hip against the composition of the kernels it fuses (LayerNorm, projection GEMM, fused attention;
-    LayerNorm backward, output-projection data gradient, fused attention backward) and against torch, bf16, dropout ON (the
-    masks are functions of (seed, index): both sides draw the same ones)."""
-    from seq2seq_vc_amd.ops import kernels_attn as KAT
-    from seq2seq_vc_amd.ops import kernels_block as KB
-    res = []
-    dt_ = torch.bfloat16
-    for (B, T1, T2, D, H, causal, src, seed0) in [(3, 63, 63, 384, 4, False, False, 1), (2, 64, 64, 384, 4, True, False, 2),
-                                                  (3, 37, 50, 384, 4, False, True, 3), (2, 64, 61, 256, 4, False, True, 4),
-                                                  (2, 40, 40, 256, 4, True, False, 5), (5, 33, 33, 384, 4, False, False, 6)]:
-        dk = D // H
-        x = rnd(B, T1, D, seed=seed0, dtype=dt_)
-        gamma, beta = (1.0 + 0.1 * rnd(D, seed=seed0 + 1)).contiguous(), (0.1 * rnd(D, seed=seed0 + 2)).contiguous()
-        nproj = 1 if src else 3
-        w = rnd(nproj * D, D, seed=seed0 + 3, dtype=dt_, scale=D ** -0.5)
-        bias = 0.1 * rnd(nproj * D, seed=seed0 + 4)
-        klen = torch.tensor([T2 - 3 * i for i in range(B)], dtype=torch.int32, device=DEV)
-        kvt = rnd(B, T2, 2 * D, seed=seed0 + 5, dtype=dt_) if src else None
-        kv = (kvt[..., :D], kvt[..., D:]) if src else None
-        p_attn = 0.1
-        K.manual_seed(17)
-        K.reset_op_counter()
-        seed = K.new_seed(x.device)
-        for use_ln in (True, False):
-            tag = f"attn_block_fwd B{B} T{T1}x{T2} D{D} {'src' if src else 'self'}{' causal' if causal else ''}{' LN' if use_ln else ''}"
-            ctx, attn, proj, y, mean, rstd = KB.attn_block_fwd(x, (gamma, beta, 1e-12) if use_ln else None, w, bias, H, klen, causal, p_attn,
-                                                               seed, kv=kv)
-            # unfused: LayerNorm kernel -> GEMM -> fused attention kernel
-            if use_ln:
-                y_r, _, mean_r, rstd_r = K.layernorm_fwd(x, gamma, beta, 1e-12)
-                res.append(check(tag + " y", y, y_r, dt_, 0, 1e-6))
-                res.append(check(tag + " mean", mean, mean_r, torch.float32, 1e-5, 1e-6))
-                res.append(check(tag + " rstd", rstd, rstd_r, torch.float32, 1e-5, 1e-6))
-            else:
-                y_r = x
-            proj_r = torch.empty(B * T1, nproj * D, dtype=dt_, device=DEV)
-            K.gemm(K.operand(y_r.view(-1, D), D), K.operand(w, D), B * T1, nproj * D, D, proj_r, in_dtype=dt_, bias=bias)
-            proj_r = proj_r.view(B, T1, nproj * D)
-            res.append(check(tag + " proj", proj, proj_r, dt_, 2e-2, 2e-2))
-            # the attention part is compared on the fused kernel's OWN projection (so that only that part is measured)
-            q = proj[..., :D]
-            kk, vv = (proj[..., D:2 * D], proj[..., 2 * D:]) if not src else kv
-            ctx_r, attn_r = KAT.fused_fwd(q, kk, vv, klen, causal, H, 1.0 / math.sqrt(dk), p_attn, seed)
-            res.append(check(tag + " attn", attn, attn_r, dt_, 0, 1e-6))
-            res.append(check(tag + " ctx", ctx, ctx_r, dt_, 0, 1e-6))
-            # torch: softmax(q k^T / sqrt(dk)) with the masks, on the unfused projection
-            qf = proj_r[..., :D].float().view(B, T1, H, dk).transpose(1, 2)
-            kf = (proj_r[..., D:2 * D] if not src else kv[0]).float().reshape(B, T2, H, dk).transpose(1, 2)
-            sc = qf @ kf.transpose(-1, -2) / math.sqrt(dk)
-            ar = torch.arange(T2, device=DEV)
-            msk = ar[None, None, None, :] < klen[:, None, None, None]
-            if causal:
-                msk = msk & (ar[None, None, None, :] <= torch.arange(T1, device=DEV)[None, None, :, None])
-            pr = torch.softmax(sc.masked_fill(~msk, float("-inf")), dim=-1).masked_fill(~msk, 0.0)
-            res.append(check(tag + " attn vs torch", attn[..., :T2], pr, dt_, 2e-2, 6e-3))
-        # ---- backward: mode 1 (LayerNorm' prologue) and mode 0 (mask only) ----
-        wo = rnd(D, D, seed=seed0 + 6, dtype=dt_, scale=D ** -0.5)
-        wo_t = wo.t().contiguous()
-        s = rnd(B, T1, D, seed=seed0 + 7, dtype=dt_)
-        _, _, mean2, rstd2 = K.layernorm_fwd(s, gamma, beta, 1e-12)
-        gy = rnd(B, T1, D, seed=seed0 + 8, dtype=dt_, scale=0.3)
-        extra = rnd(B, T1, D, seed=seed0 + 9, dtype=dt_, scale=0.3)
-        dattn = (0.05 * rnd(B, H, T1, attn.shape[-1], seed=seed0 + 10)).to(dt_)
-        seed_r = K.new_seed(x.device)
-        p_res = 0.1
-        q = proj[..., :D]
-        kk, vv = (proj[..., D:2 * D], proj[..., 2 * D:]) if not src else kv
-        for mode in (1, 0):
-            tag = f"attn_block_bwd mode {mode} B{B} T{T1}x{T2} D{D} {'src' if src else 'self'}"
-            dq, dk_, dv = (torch.empty(B, T1, D, dtype=dt_, device=DEV), torch.empty(B, T2, D, dtype=dt_, device=DEV),
-                           torch.empty(B, T2, D, dtype=dt_, device=DEV))
-            ds, da = KB.attn_block_bwd(gy, (s, mean2, rstd2, gamma) if mode == 1 else None, extra if mode == 1 else None, p_res, 1.0, seed_r,
-                                       wo_t, q, kk, vv, attn, dattn, H, p_attn, seed, dq, dk_, dv)
-            if mode == 1:
-                ds_r, da_r = K.layernorm_bwd(gy, s, mean2, rstd2, gamma, ds_extra=extra, p=p_res, seed=seed_r, want_dh=True)
-                res.append(check(tag + " ds", ds, ds_r, dt_, 0, 1e-6))
-            else:
-                da_r = K.act_dropout_bwd(gy.view(-1, D), gy.view(-1, D), act=None, p=p_res, seed=seed_r).view(B, T1, D)
-            res.append(check(tag + " da", da, da_r, dt_, 0, 1e-6))
-            dctx_r = torch.empty(B * T1, D, dtype=dt_, device=DEV)
-            K.gemm(K.operand(da_r.reshape(-1, D), D), K.operand(wo_t, D), B * T1, D, D, dctx_r, in_dtype=dt_)
-            dq_r, dk_r, dv_r = torch.empty_like(dq), torch.empty_like(dk_), torch.empty_like(dv)
-            KAT.fused_bwd(q, kk, vv, dctx_r.view(B, T1, D), attn, dattn, H, 1.0 / math.sqrt(dk), p_attn, seed, dq_r, dk_r, dv_r)
-            for nm, a_, b_ in (("dq", dq, dq_r), ("dk", dk_, dk_r), ("dv", dv, dv_r)):
-                rel = float((a_.float() - b_.float()).norm() / (b_.float().norm() + 1e-12))
-                res.append((rel < 1.5e-2, f"{tag} {nm}: rel-L2 vs unfused {rel:.2e}"))
-                res.append(check(tag + " " + nm, a_, b_, dt_, 4e-2, 4e-2 * float(b_.float().abs().max())))
-    return res
-
-
-@case
-def gemm_rowpro_vs_unfused():
-    """csrc/gemm_rowpro.hip against LayerNorm / dropout kernels followed by the plain GEMM (bf16): LayerNorm prologue with
-    bias + ReLU + dropout epilogue (the first feed-forward GEMM), dropout-mask prologue with relu' * dropmask epilogue (the
-    data gradient through the second one), plain rows with a residual."""
-    from seq2seq_vc_amd.ops import kernels_block as KB
-    res = []
-    dt_ = torch.bfloat16
-    for (M, D, N, seed0) in [(2016, 384, 1536, 1), (2048, 384, 1536, 2), (500, 256, 1024, 3), (130, 512, 2048, 4), (64, 384, 200, 5)]:
-        x = rnd(M, D, seed=seed0, dtype=dt_)
-        gamma, beta = (1.0 + 0.1 * rnd(D, seed=seed0 + 1)).contiguous(), (0.1 * rnd(D, seed=seed0 + 2)).contiguous()
-        w = rnd(N, D, seed=seed0 + 3, dtype=dt_, scale=D ** -0.5)
-        bias = 0.1 * rnd(N, seed=seed0 + 4)
-        K.manual_seed(23)
-        K.reset_op_counter()
-        seed_h, seed_a = K.new_seed(x.device), K.new_seed(x.device)
-        # mode 1
-        out = torch.empty(M, N, dtype=dt_, device=DEV)
-        y, mean, rstd = KB.gemm_rowpro(x, w, N, out, mode=1, norm=(gamma, beta, 1e-12), bias=bias, act="relu", drop_p=0.1, seed=seed_h)
-        y_r, _, mean_r, rstd_r = K.layernorm_fwd(x, gamma, beta, 1e-12)
-        out_r = torch.empty(M, N, dtype=dt_, device=DEV)
-        K.gemm(K.operand(y_r, D), K.operand(w, D), M, N, D, out_r, in_dtype=dt_, bias=bias, act="relu", drop_p=0.1, seed=seed_h)
-        tag = f"gemm_rowpro M{M} D{D} N{N}"
-        res.append(check(tag + " LN y", y, y_r, dt_, 0, 1e-6))
-        res.append(check(tag + " LN mean", mean, mean_r, torch.float32, 1e-5, 1e-6))
-        res.append(check(tag + " LN rstd", rstd, rstd_r, torch.float32, 1e-5, 1e-6))
-        res.append(check(tag + " LN out", out, out_r, dt_, 2e-2, 2e-2))
-        # mode 2
-        gin = rnd(M, D, seed=seed0 + 5, dtype=dt_, scale=0.3)
-        hmid = torch.relu(rnd(M, N, seed=seed0 + 6, dtype=dt_))
-        out2 = torch.empty(M, N, dtype=dt_, device=DEV)
-        da, _, _ = KB.gemm_rowpro(gin, w, N, out2, mode=2, p_a=0.1, seed_a=seed_a, write_rows=True, emask=hmid, drop_p=0.1, seed=seed_h)
-        da_r = K.act_dropout_bwd(gin, gin, act=None, p=0.1, seed=seed_a)
-        out2_r = torch.empty(M, N, dtype=dt_, device=DEV)
-        K.gemm(K.operand(da_r, D), K.operand(w, D), M, N, D, out2_r, in_dtype=dt_, emask=hmid, drop_p=0.1, seed=seed_h)
-        res.append(check(tag + " mask rows", da, da_r, dt_, 0, 1e-6))
-        res.append(check(tag + " mask out", out2, out2_r, dt_, 2e-2, 2e-2))
-        # mode 0 + residual
-        r = rnd(M, N, seed=seed0 + 7, dtype=dt_)
-        out3 = torch.empty(M, N, dtype=dt_, device=DEV)
-        KB.gemm_rowpro(x, w, N, out3, mode=0, bias=bias, res=r)
-        out3_r = torch.empty(M, N, dtype=dt_, device=DEV)
-        K.gemm(K.operand(x, D), K.operand(w, D), M, N, D, out3_r, in_dtype=dt_, bias=bias, res=r)
-        res.append(check(tag + " rows + res", out3, out3_r, dt_, 2e-2, 2e-2))
-        ref = torch.relu(y_r.float() @ w.float().t() + bias)
-        live = out.float() != 0
-        res.append(check(tag + " LN out vs torch (kept elements)", torch.where(live, out.float(), ref / 0.9) * 0.9, ref, dt_, 3e-2, 3e-2))
-    return res
-
-
 def main():
     torch.manual_seed(0)
     nfail = 0

@@ -1567,12 +1567,14 @@ def aasvc_full_size_grads():
     (trainers/aas_vc.py:75-134: l1 + 2 * (forward-sum + bin) + sum(dur_nll)) against the CPU oracle's autograd (float64) on the
     canonical batch -- dropout 0, injected flow noise, fp32 mode -- through the one-shot backward pass (duration branch on the
     auxiliary stream, inline gradient batches: the shipped schedule) and through the staged data-parallel one; then the bf16
-    gradients (the path bench.py --workload aasvc times) against fp32.  Per-parameter rel-L2 <= 1e-4 (fp32), flat rel-L2 <= 0.1
-    (bf16, provided bf16 finds the same alignment)."""
+    gradients (the path bench.py --workload aasvc times) against fp32 with the fp32 run's durations injected, so that the comparison
+    is always alignment-equal.  Per-parameter rel-L2 <= 3e-4 (fp32), flat rel-L2 <= 0.1 and per layer <= 0.15 (bf16), and -- a
+    separate assertion -- bf16's own alignment moves <= 10 % of the durations."""
     import bench
     from oracle import models as OM
     from seq2seq_vc_amd import losses as L
     from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd import modules as Mo
     from seq2seq_vc_amd.distributed import OverlappedBackward
     from seq2seq_vc_amd.optim import FlatAdam
     from tools.bench_aasvc import AASVC_VC2
@@ -1634,101 +1636,40 @@ def aasvc_full_size_grads():
         model = M.AASVC(**AASVC_VC2).to(DEV).train()
         _kill_dropout(model)
         opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=True)
+        # (a) bf16 finds its own alignment: a SEPARATE assertion on how far it moves from the fp32 one
         ds16, *_ = run(False)
-        g16 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
         moved = float((ds16 != ds_ref).float().mean())
+        res.append((moved <= 0.1, f"C3 bf16 finds its own alignment: {moved:.2%} of the durations differ from fp32 / the oracle (<= 10 %)"))
+        # (b) the gradient comparison proper, ALWAYS alignment-equal: the bf16 pass runs with the fp32 run's durations injected
+        # through the model's `viterbi_func` slot (models/aas_vc.py:132 of the reference) -- the search still runs (its durations
+        # are discarded), the binarisation loss is taken on the injected path
+        real_viterbi = model.viterbi_func
+        ds_inj = ds_ref.to(DEV)
+
+        def injected(log_p_attn, text_lengths, feats_lengths):
+            real_viterbi(log_p_attn, text_lengths, feats_lengths)
+            Bq, Tf, _ = log_p_attn.shape
+            fl = Mo.Lens.of(feats_lengths, log_p_attn.device).dev.long()
+            ends = torch.cumsum(ds_inj.long(), dim=1)                                  # (B, T_text): first frame AFTER token j
+            t = torch.arange(Tf, device=log_p_attn.device)
+            path = (t[None, :, None] >= ends[:, None, :]).sum(-1).clamp(max=ds_inj.shape[1] - 1)      # token of frame t
+            picked = log_p_attn.float().gather(2, path[:, :, None]).squeeze(2)
+            valid = (t[None, :] < fl[:, None]).float()
+            bin_loss = -((picked * valid).sum(1) / fl.float()).sum() / Bq
+            return ds_inj.clone(), bin_loss
+        model.viterbi_func = injected
+        ds_b, *_ = run(False)
+        model.viterbi_func = real_viterbi
+        g16 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
         flat = _group_rel(names, g16, g32, lambda k: "all")[0][1]
         per = _group_rel(names, g16, g32, _layer_group)
-        res.append((flat <= 0.1 or moved > 0, f"C3 bf16 (the timed path) vs fp32 flat gradient: rel-L2 {flat:.3e} (<= 0.1 when bf16 finds the fp32 alignment; "
-                    f"{moved:.2%} of the durations differ)"))
-        res.append((moved <= 0.1 and flat <= 0.5, "C3 bf16 vs fp32 per layer: " + ", ".join(f"{g} {e:.3f}" for g, e in per)))
+        worst = max(per, key=lambda t: t[1])
+        res.append((bool(torch.equal(ds_b, ds_ref)) and flat <= 0.1, f"C3 bf16 (the timed path, fp32 alignment injected) vs fp32 flat gradient: rel-L2 {flat:.3e} (<= 0.1)"))
+        res.append((worst[1] <= 0.15, f"C3 bf16 vs fp32 per layer (<= 0.15, worst {worst[0]} {worst[1]:.3f}): " + ", ".join(f"{g} {e:.3f}" for g, e in per)))
     finally:
         Fn.set_compute_dtype(torch.float32)
         Fn.enable_side_streams(0)
     return res
-
-
-@case
-def fused_layers_match_modular_bf16():
-    """The fused transformer-layer functions (ops/fused_layers.py: one autograd node, 4 / 6 launches forward and 5 / 7 backward per
-    encoder / decoder layer) against the modular path of modules.py (one node per operation) on the SAME model, batch and
-    dropout seeds -- the masks are functions of (seed, element index) and both paths draw their seeds in the same order, so the
-    two steps differ only by bf16 rounding of intermediates: VTN vc1 at full size (D = 384, d_k = 96, B = 32) and VTN-small
-    (D = 256, d_k = 64), training mode with all dropouts on, and eval mode."""
-    import bench
-    from seq2seq_vc_amd import losses as L
-    from seq2seq_vc_amd import models as M
-    from seq2seq_vc_amd.ops import kernels_block as KB
-    from seq2seq_vc_amd.optim import FlatAdam
-    res = []
-    small = dict(idim=80, odim=80, adim=256, aheads=4, elayers=2, eunits=1024, dlayers=2, dunits=1024, decoder_reduction_factor=4)
-    try:
-        Fn.set_compute_dtype(torch.bfloat16)
-        Fn.enable_side_streams(4)
-        for name, cfgs, B in (("VTN vc1 B32", bench.VTN_VC1, 32), ("VTN-small B8", small, 8)):
-            xs, ilens, ys, labels, olens = bench.canonical_batch(B)
-            torch.manual_seed(0)
-            model = M.VTN(**cfgs).to(DEV).train()
-            opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=True)
-
-            def run(fused, train=True):
-                KB._DISABLED = not fused
-                model.train(train)
-                K.manual_seed(4242)
-                K.reset_op_counter()
-                opt.zero_grad()
-                launches0 = None
-                with torch.set_grad_enabled(train):
-                    out = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
-                    l1, bce = L.Seq2SeqLoss(10.0)(out[0], out[1], out[2], out[3], out[4], out[5])
-                if train:
-                    (l1 + bce).backward()
-                    Fn.side_join()
-                torch.cuda.synchronize()
-                return out, float(l1.detach()), float(bce.detach()), opt.flat_g.clone()
-
-            of, l1f, bcef, gf = run(True)
-            of2, l1f2, bcef2, gf2 = run(True)
-            om, l1m, bcem, gm = run(False)
-            res.append((l1f == l1f2 and bcef == bcef2 and bool(torch.equal(gf, gf2)), f"{name}: fused step is reproducible bit for bit"))
-            res.append((abs(l1f - l1m) < 5e-3 and abs(bcef - bcem) < 5e-3, f"{name}: losses fused {l1f:.5f}/{bcef:.5f} vs modular {l1m:.5f}/{bcem:.5f}"))
-            rel = float((gf.double() - gm.double()).norm() / gm.double().norm())
-            res.append((rel < 0.05, f"{name}: flat gradient fused vs modular rel-L2 {rel:.3e} (< 0.05: bf16 rounding of intermediates only)"))
-            res.append(cmp(f"{name}: after_outs fused vs modular", of[0], om[0].detach().float().cpu(), 0.3, l1_tol=0.03))
-            for i in range(len(of[6][0])):
-                res.append(cmp(f"{name}: att_ws[{i}] fused vs modular", of[6][0][i], om[6][0][i].detach().float().cpu(), 3e-2))
-            oe, l1e, bcee, _ = run(True, train=False)
-            ome, l1me, bceme, _ = run(False, train=False)
-            res.append((abs(l1e - l1me) < 5e-3 and abs(bcee - bceme) < 5e-3, f"{name}: eval-mode losses fused {l1e:.5f}/{bcee:.5f} vs modular {l1me:.5f}/{bceme:.5f}"))
-            del opt, model
-    finally:
-        from seq2seq_vc_amd.ops import kernels_block as KB2
-        KB2._DISABLED = os.environ.get("S2SVC_FUSED_BLOCKS", "0") != "1"
-        Fn.set_compute_dtype(torch.float32)
-        Fn.enable_side_streams(0)
-    return res
-
-
-TTS_V1 = dict(idim=78, odim=80, dprenet_layers=2, dprenet_units=256, adim=384, aheads=4, elayers=6, eunits=1536, dlayers=6,
-              dunits=1536, postnet_layers=5, postnet_filts=5, postnet_chans=256, use_batch_norm=True,
-              encoder_normalize_before=True, decoder_normalize_before=False, encoder_concat_after=False,
-              decoder_concat_after=False, decoder_reduction_factor=2)   # egs/ljspeech/tts1/conf/transformer_tts.v1.yaml:23-42
-
-
-def canonical_tts_batch(B, seed=1234):
-    """ilens in [60,150] int tokens in [1,77) padded with 0, olens in [300,640], ys randn(B,640,80)."""
-    g = torch.Generator().manual_seed(seed)
-    ilens = torch.randint(60, 151, (B,), generator=g)
-    ilens[0] = 150
-    olens = torch.randint(300, 641, (B,), generator=g)
-    olens[0] = 640
-    xs = torch.randint(1, 77, (B, 150), generator=g)
-    ys = torch.randn(B, 640, 80, generator=g)
-    xs[torch.arange(150)[None] >= ilens[:, None]] = 0
-    ar = torch.arange(640)[None]
-    ys[ar >= olens[:, None]] = 0.0
-    labels = (ar >= (olens[:, None] - 1)).float()
-    return xs, ilens, ys, labels, olens
 
 
 @case
