@@ -821,7 +821,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code path (RCCL process group, staged backward, overlapped all-reduces) at world size 1")
     ap.add_argument("--grad-payload", default=None, choices=["fp32", "bf16"],
-                    help="dtype of the gradient exchange (default: the trainers' -- fp32 for vtn, bf16 for aasvc)")
+                    help="dtype of the gradient exchange (default: fp32 for vtn = the trainers' default; bf16 for aasvc = the opt-in "
+                         "config['dp_grad_payload'] the AAS-VC multi-GPU recipe sets; reported in config.grad_payload)")
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="data parallel: one all-reduce per bucket, or reduce-scatter + all-gather")
     ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")

@@ -10,18 +10,18 @@ few *gradient cuts* (ops.functional.cut_point) and a stage plan (`model.dp_plan(
 stage, every stage finishes the gradients of one contiguous range of the flat buffer, and that range's all-reduce is
 started (asynchronously, on RCCL's stream) before the next stage is launched:
 
-    VTN / TTS   [decoder + heads + postnet] -> [encoder layers 3-5 + after-norm] -> [layers 0-2] -> [input layer]
-                4 buckets: 62.8 | 21.3 | 21.3 | 16.5 MB fp32 (VTN vc1) -- only the last one travels with nothing to hide behind
-    AAS-VC      [decoder layers 3, 2, 1 + heads + postnet, and -- rooted on the auxiliary stream -- aligner + duration
-                predictor] -> [decoder layer 0] -> [encoder]                 3 buckets: 460 | 113 | 57 MB fp32 (vc2)
+    VTN / TTS   [decoder + heads + postnet] -> [encoder layers + after-norm] -> [input layer]
+                3 buckets: 62.8 | 42.6 | 16.5 MB fp32 (VTN vc1) -- only the last one travels with nothing to hide behind
+    AAS-VC      [all decoder layers + heads + postnet, and -- rooted on the auxiliary stream -- aligner + duration
+                predictor] -> [encoder]                                      2 buckets: 573 | 57 MB fp32 (vc2)
                 (models/*.dp_plan() is the authority; these are the shipped recipes' numbers)
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU), so large messages are what reaches link bandwidth: a bucket is one
 contiguous slice (>= 28 MB), split into 128 MiB collectives only above that.  `payload="bf16"` halves the bytes on the links:
 the slice is cast into a bf16 staging buffer, summed over the ranks in bf16 and cast back (the fp32 gradients of a rank are
 rounded once; the sum of 8 ranks then carries bf16 rounding, ~3 significant digits, which Adam's normalisation tolerates;
-fp32 is the parity setting and the default of the VTN / TTS trainers; the AAS-VC trainer defaults to bf16: 630 MB fp32 per step
-is 7 ms of ring time on one 153 GB/s link against a 15 ms step).  The 1/world of the mean rides on the loss, so the collectives
+fp32 is the parity setting -- the reference's DDP all-reduces fp32 -- and the default of EVERY trainer; `dp_grad_payload: bf16` is a
+per-recipe opt-in, worth it for AAS-VC: 630 MB fp32 per step is 7 ms of ring time on one 153 GB/s link against a 12 ms step).  The 1/world of the mean rides on the loss, so the collectives
 are plain sums.  `collective="rs_ag"` runs every bucket as reduce-scatter + all-gather (each rank sums 1/world of the slice, then
 the shards are gathered) instead of one all-reduce -- the same bytes per link for a ring, but two half-size collectives that
 RCCL can place on different channels, and the shape a sharded optimiser step would need; same results (a sum is a sum).
@@ -86,37 +86,50 @@ def allreduce_end(handles):
 
 
 class _RsAg:
-    """One bucket as reduce-scatter + all-gather: begin() starts the reduce-scatter of the (padded) slice into this rank's
-    shard; finish() waits for it, gathers the shards and copies the result back.  Backends without reduce_scatter (gloo) fall
-    back to an all-reduce of the slice, from which every rank keeps its shard -- the data path the test suite can run on CPU."""
+    """One bucket as reduce-scatter + all-gather, in chunks of at most `chunk_numel` elements: begin (the constructor) starts the
+    reduce-scatter of every (padded) chunk into this rank's shard and, chained behind it on the backend's stream, the ASYNCHRONOUS
+    all-gather of the shards -- both halves overlap with the backward stages that follow; finish() only waits and copies a padded
+    tail back.  Backends without reduce_scatter_tensor (gloo -- chosen from dist.get_backend(), an asynchronous failure could not be
+    caught) run an all-reduce of the chunk, from which every rank keeps its shard: the data path the test suite runs on CPU."""
 
-    def __init__(self, buf, dist, world, group=None):
+    def __init__(self, buf, dist, world, group=None, chunk_numel=None):
         self.buf, self.dist, self.world, self.group = buf, dist, world, group
+        self.emulated = str(dist.get_backend(group)).lower() not in ("nccl", "rccl")
         n = buf.numel()
-        self.shard_n = (n + world - 1) // world
-        self.padded = None
-        src = buf
-        if self.shard_n * world != n:
-            self.padded = torch.zeros(self.shard_n * world, dtype=buf.dtype, device=buf.device)
-            self.padded[:n].copy_(buf)
-            src = self.padded
-        self.src = src
-        self.shard = torch.empty(self.shard_n, dtype=buf.dtype, device=buf.device)
-        self.emulated = False
-        try:
-            self.h = dist.reduce_scatter_tensor(self.shard, src, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        except (RuntimeError, NotImplementedError):
-            self.emulated = True
-            self.h = dist.all_reduce(src, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        chunk = n if not chunk_numel else max(world, (int(chunk_numel) // world) * world)
+        self.parts = []
+        for o in range(0, n, chunk):
+            piece = buf[o:o + chunk]
+            m = piece.numel()
+            shard_n = (m + world - 1) // world
+            padded = None
+            src = piece
+            if shard_n * world != m:
+                padded = torch.zeros(shard_n * world, dtype=buf.dtype, device=buf.device)
+                padded[:m].copy_(piece)
+                src = padded
+            shard = torch.empty(shard_n, dtype=buf.dtype, device=buf.device)
+            if self.emulated:
+                h = dist.all_reduce(src, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                self.parts.append([piece, padded, src, shard, shard_n, h, None])
+            else:
+                h = dist.reduce_scatter_tensor(shard, src, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                # same process group -> same communication stream: the gather is ordered behind the scatter without a host wait
+                g = dist.all_gather_into_tensor(src, shard, group=group, async_op=True)
+                self.parts.append([piece, padded, src, shard, shard_n, h, g])
 
     def finish(self):
-        self.h.wait()
-        if self.emulated:
-            r = self.dist.get_rank(self.group)
-            self.shard.copy_(self.src[r * self.shard_n:(r + 1) * self.shard_n])
-        self.dist.all_gather_into_tensor(self.src, self.shard, group=self.group)
-        if self.padded is not None:
-            self.buf.copy_(self.padded[: self.buf.numel()])
+        for part in self.parts:
+            piece, padded, src, shard, shard_n, h, g = part
+            h.wait()
+            if self.emulated:
+                r = self.dist.get_rank(self.group)
+                shard.copy_(src[r * shard_n:(r + 1) * shard_n])
+                g = self.dist.all_gather_into_tensor(src, shard, group=self.group, async_op=True)
+            g.wait()
+            if padded is not None:
+                piece.copy_(padded[: piece.numel()])
+        self.parts = []
 
 
 class _Waiter:
@@ -260,7 +273,7 @@ class OverlappedBackward:
             else:
                 buf = self.opt.flat_g[lo:hi]
             if self.collective == "rs_ag":
-                self.handles.append(_RsAg(buf, self.dist, self.world, self.group))
+                self.handles.append(_RsAg(buf, self.dist, self.world, self.group, self.chunk))
             else:
                 self.handles += [_Waiter(h) for h in allreduce_sum_begin(buf, self.dist, self.world, self.chunk, self.group, force=True)]
 
@@ -297,18 +310,25 @@ def allreduce_grads_(params, dist, world, group=None):
         return
     # every trainable parameter takes part, with zeros where this rank produced no gradient (a branch that did not run here,
     # e.g. a duration predictor before dp_train_start_steps): the buffer layout must not depend on which gradients exist, or
-    # the ranks' collectives mismatch in size
+    # the ranks' collectives mismatch in size.  A has-gradient flag per parameter travels at the end of the same buffer: a
+    # parameter NO rank produced a gradient for keeps `grad = None` afterwards, as in a single-GPU run -- torch optimisers skip it
+    # (no Adam state, no step count, no weight decay), so world = 1 and world > 1 stay in step when the branch switches on later.
     ps = [p for p in params if p.requires_grad]
     if not ps:
         return
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
+    dev, dt = ps[0].device, ps[0].dtype
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], dtype=dt, device=dev)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in ps] + [has])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    any_grad = (flat[-len(ps):] > 0).tolist()
     flat.mul_(1.0 / world)
     o = 0
-    for p in ps:
+    for p, live in zip(ps, any_grad):
         n = p.numel()
-        if p.grad is None:
-            p.grad = flat[o:o + n].view_as(p).clone()
+        if not live:
+            p.grad = None
+        elif p.grad is None:
+            p.grad = flat[o:o + n].view_as(p).to(p.dtype).clone()
         else:
             p.grad.copy_(flat[o:o + n].view_as(p))
         o += n

@@ -322,8 +322,10 @@ class AASVCTrainer(Trainer):
     WGRAD_BACKGROUND = (64, 3)      # the first three grouped 8-wave weight-gradient launches of a backward pass (decoder layers) as
     #                                 background launches of 64 workgroups: 12.83 -> 12.55 ms per vc2 step; a fourth one is still
     #                                 running when the chain ends (13.3 ms), 48 / 72 / 80 / 96 workgroups 12.61 / 12.62 / 12.79 / 12.71
-    DP_GRAD_PAYLOAD = "bf16"        # 630 MB of fp32 gradients per step (vc2) = 7 ms on one xGMI link against a 15 ms step: the
-    #                                 exchange runs on a bf16 copy by default; config["dp_grad_payload"] = "fp32" is the parity setting
+    DP_GRAD_PAYLOAD = "fp32"        # the reference's DDP all-reduces fp32 gradients: the parity setting is the default.  630 MB of fp32
+    #                                 gradients per step (vc2) are 7 ms on one xGMI link against a 12 ms step: a multi-GPU recipe opts
+    #                                 into config["dp_grad_payload"] = "bf16" (the exchange runs on a bf16 copy, ~3 significant digits
+    #                                 in the 8-rank sum; multi-GPU runs then no longer match single-GPU runs bit for bit)
     GRAPH_BATCH = {"xs": ("ilens", 0.0), "ys": ("olens", 0.0), "dp_inputs": ("dplens", 0.0)}
 
     def _graph_regime(self):

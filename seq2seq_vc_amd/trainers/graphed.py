@@ -109,13 +109,19 @@ class GraphedStep:
     def _staged_copy(self, name, st, src, T):
         key = (name, tuple(st.shape), st.dtype)
         slot = self._stage.get(key)
-        if slot is None:
-            slot = self._stage[key] = {"buf": [torch.empty_like(st), torch.empty_like(st)], "free": [None, None], "i": 0}
-        i = slot["i"]
-        slot["i"] ^= 1
         if self.copy_stream == "lazy":                 # (torch hands out stream objects round-robin: take one nothing else uses)
             from ..ops import functional as Fn
             self.copy_stream = Fn.distinct_stream(Fn._taken_streams() | {self.stream.cuda_stream})
+        if slot is None:
+            slot = self._stage[key] = {"buf": [torch.empty_like(st), torch.empty_like(st)], "free": [None, None], "i": 0}
+            # the buffers were allocated on the step's stream: a block the caching allocator has just recycled may still be in
+            # use by kernels queued there -- the copy stream's first write waits for them once, and the allocator learns that
+            # the copy stream uses the blocks (so they are not handed out again while a copy is in flight)
+            self.copy_stream.wait_stream(torch.cuda.current_stream())
+            for b in slot["buf"]:
+                b.record_stream(self.copy_stream)
+        i = slot["i"]
+        slot["i"] ^= 1
         buf, cs = slot["buf"][i], self.copy_stream
         if slot["free"][i] is not None:
             cs.wait_event(slot["free"][i])            # the device copy that last read this staging buffer
@@ -144,7 +150,12 @@ class GraphedStep:
         if e is None:
             while len(self.entries) >= self.max_entries:          # bounded: drop the least recently used shape
                 old_key, old = self.entries.popitem(last=False)
+                gone = {(n, tuple(v.shape), v.dtype) for n, v in old.static.items()}
                 old.graphs, old.static, old.bank = [], {}, None       # graphs first: their blocks go back to the shared pool
+                # the staging buffers (2 x the batch per field and shape) of shapes no remaining entry uses go with it
+                live = {(n, tuple(v.shape), v.dtype) for ent in self.entries.values() for n, v in ent.static.items()}
+                for k in gone - live:
+                    self._stage.pop(k, None)
                 self.evictions += 1
                 logging.info(f"hip_graph: evicted the captured step of {old_key[1]} ({self.evictions} evictions so far; "
                              f'config["graph_cache_size"] = {self.max_entries})')

@@ -189,8 +189,28 @@ def _rsag_worker(rank, world, port, q):
         for b_ in buckets:
             b_.finish()
         out.append((n, a.numpy().copy(), want.numpy().copy()))       # by value through the queue (see _dp_worker)
+    # chunked buckets (chunk_numel honoured: several collectives per bucket, the last chunk padded)
+    g = torch.Generator().manual_seed(999 + rank)
+    a = torch.randn(1003, generator=g)
+    want = a.clone()
+    dist.all_reduce(want)
+    b_ = _RsAg(a, dist, world, chunk_numel=250)
+    assert len(b_.parts) == 5                                 # 248-element chunks (a multiple of the world size): 4 full + 1 ragged
+    b_.finish()
+    out.append((-1003, a.numpy().copy(), want.numpy().copy()))
     m = torch.arange(12, dtype=torch.float32) * (rank + 1)
     allreduce_mean_(m, dist, world, chunk_numel=5)
+    # torch-optimiser path: a parameter no rank produced a gradient for keeps grad = None (single-GPU semantics: the optimiser skips
+    # it); one that only SOME ranks produced gets the mean with zeros for the others
+    from seq2seq_vc_amd.distributed import allreduce_grads_
+    ps = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(4)),
+          torch.nn.Parameter(torch.zeros(5), requires_grad=False)]
+    ps[0].grad = torch.full((3,), float(rank + 1))
+    if rank == 1:
+        ps[2].grad = torch.full((4,), 8.0)
+    allreduce_grads_(ps, dist, world)
+    assert ps[1].grad is None and ps[3].grad is None, "a gradient nobody produced must stay None"
+    assert torch.allclose(ps[0].grad, torch.full((3,), (1 + 2 + 3 + 4) / 4.0)) and torch.allclose(ps[2].grad, torch.full((4,), 2.0))
     q.put((rank, out, m.numpy().copy()))
     dist.destroy_process_group()
 
