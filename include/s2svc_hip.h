@@ -143,6 +143,18 @@ int s2svc_gemm_grouped(const s2svc_gemm_desc* descs /* host */, int n, int tile,
    reference modules/transformer/attention.py:72-111, 262-305 differentiated).  0 = launched, 1 = not eligible as a group
    (nothing launched: run them with s2svc_gemm), < 0 = error. */
 int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs /* host */, int n, void* stream);
+/* RAGGED weight gradients on the 8-wave kernel (csrc/gemm_8ph.hip, "W8"): C[M, N] fp32 (+)= A^T . B for dense row-contiguous bf16
+   operands with M % 8 == N % 8 == 0 and ANY K (the Linear weight gradients dW = dY^T . X of the backward pass,
+   /root/reference trainers/ar_vc.py:99-107: loss.backward() fills every parameter's .grad), as ONE grid of (problem, K chunk,
+   256 x 128 tile) units, up to 40 problems per launch.  A reduction longer than 32 K tiles of 64 rows is cut into chunks -- a
+   function of K only -- whose fp32 partial tiles go through `ws` and are added in chunk order by a second launch (deterministic).
+     _ok        : 1 if the kernel takes `desc` (a function of the descriptor only; exact-256 problems with >= 64 tiles of
+                  128 x 128 stay with s2svc_gemm_grouped's 8-wave path);
+     _ws_floats : fp32 elements of workspace the listed problems need (0 = none);
+     _grouped   : launch; `ws` device memory (16-byte aligned) the caller keeps untouched until the launches have run. */
+int s2svc_gemm_wgrad_ok(const s2svc_gemm_desc* desc /* host */);
+int64_t s2svc_gemm_wgrad_ws_floats(const s2svc_gemm_desc* descs /* host */, int n);
+int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs /* host */, int n, float* ws, void* stream);
 int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream, void* bg_stream, int bg_cus,
                           int* n_bg /* host, may be NULL */);
 

@@ -815,6 +815,272 @@ __global__ __launch_bounds__(512) void gemm_8ph_tr_grouped_persistent_kernel(con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// RAGGED weight-gradient tiles ("W8", round 4): the same 256 x 128 two-phase schedule for ANY dense row-contiguous weight
+// gradient C[M, N] (+)= A^T . B (M, N multiples of 8; any K) -- VTN's 384 / 1152 / 1536 / 4608 / 7296-feature layers with
+// reductions of 2016 / 2048 rows, which used to run on gemm_grouped_kernel<64, 64> (4 waves, one barrier + a drained DMA per
+// K tile, 32 flop per staged byte: MFMA pipe 10 % busy, waves parked 69 % of their cycles, profiles/r03_step_mfma_busy.txt).
+// What it adds to p8_tr_tile:
+//   * raggedness is a property of the DMA SOURCE only: a lane whose 8 rows lie past M / N, or whose k row lies past K (or past
+//     the end of its K chunk), reads the 16-byte zero block instead -- the LDS image, fragments, phases and counted waits are
+//     those of the exact kernel; rows past the matrix are never stored.  A wave whose 64-row half (or 32-column slice) is
+//     entirely outside the matrix skips its fragment reads and MFMAs (it still issues its DMA share and meets the barriers),
+//     so the half-empty second row tile of a 384-row output leaves the SIMD's matrix pipe to the partner wave;
+//   * WORK UNITS (problem, K chunk, tile): a problem's reduction is cut into chunks of kt_chunk K tiles -- a function of K
+//     ONLY, so a staged backward pass (other groups) sums in the order of the uncut one.  One chunk: the unit accumulates
+//     straight into C (the flat-gradient slot).  Several: every unit stores its fp32 partial tile (and partial bias row sums)
+//     to a workspace slice and w8_reduce_kernel adds the slices in chunk order -- deterministic, no atomics;
+//   * compact problem records (96 bytes instead of the 384-byte descriptor): 40 problems per launch.
+// Unit order inside a problem: chunk-major, then row tile, column tile innermost -- neighbours share the A panel of their
+// (chunk, row tile); the launch deals unit ids to XCDs in contiguous runs (as p8_tile_of_block does for one problem).
+// ---------------------------------------------------------------------------------------------------------
+#define W8_MAX 40
+struct w8_prob {
+  const void* A;                 // [K][lda]  (dY: row-contiguous, element (k, m) at A[k * lda + m])
+  const void* B;                 // [K][ldb]  (X)
+  float* C;                      // [M][ldc] fp32
+  float* rowsum;                 // [M] bias gradient (sum over k of A[k][m]) or null
+  float* ws;                     // nchunks > 1: [nchunks][M][N] partial tiles
+  float* rs_ws;                  // nchunks > 1 and rowsum: [nchunks][M]
+  int32_t lda, ldb, ldc, M, N, K;
+  int32_t tiles_m, tiles_n, nchunks, kt_chunk;
+  int32_t flags;                 // bit 0: accumulate into C, bit 1: accumulate into rowsum
+  int32_t reserved_;
+};
+struct w8_args {
+  w8_prob p[W8_MAX];
+  int32_t unit_start[W8_MAX + 1];
+  int32_t n, total;
+};
+static_assert(sizeof(w8_prob) == 96, "w8_prob layout");
+static_assert(sizeof(w8_args) <= 4096, "kernel arguments are limited to 4 KB");
+
+// one unit = 2 DMA instructions of this wave; a lane reads the zero block unless its rows (ok[e]) and its k row (kok) exist
+__device__ __forceinline__ void w8_issue(const char* base, const uint32_t (&off)[2], const bool (&ok)[2], bool kok, char* lds_unit,
+                                         int wave) {
+  const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const char* src = (ok[e] && kok) ? base + off[e] : z;
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_unit + (wave * 2 + e) * 1024), 16, 0, 0);
+  }
+}
+
+// fp32 C tile of one wave (64 x 32, staged in `cs` by epilogue_stage): accumulate into C, or store the chunk's partial
+__device__ __forceinline__ void w8_flush(const w8_prob& q, int chunk, int m_base, int n_base, const float* cs) {
+  const int lane = threadIdx.x & 63;
+  const bool partial = q.nchunks > 1;
+#pragma unroll 1
+  for (int p = 0; p < 4; ++p) {
+    const int row = p * 16 + (lane >> 2), col = (lane & 3) * 8;
+    const int m = m_base + row, n = n_base + col;
+    if (m >= q.M || n >= q.N) continue;
+    const float* src = cs + row * 32 + (col ^ (((row >> 2) & 1) << 4));
+    float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    float* c = partial ? q.ws + ((int64_t)chunk * q.M + m) * q.N + n : q.C + (int64_t)m * q.ldc + n;
+    if (!partial && (q.flags & 1)) {
+      const float4 c0 = *reinterpret_cast<const float4*>(c), c1 = *reinterpret_cast<const float4*>(c + 4);
+      lo.x += c0.x; lo.y += c0.y; lo.z += c0.z; lo.w += c0.w; hi.x += c1.x; hi.y += c1.y; hi.z += c1.z; hi.w += c1.w;
+    }
+    *reinterpret_cast<float4*>(c) = lo;
+    *reinterpret_cast<float4*>(c + 4) = hi;
+  }
+}
+
+template <bool STAGGER>
+__device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n, int chunk, char* smem) {
+  constexpr int UNIT = 16384, BUF = 3 * UNIT;            // A.m0 | A.m1 | B
+  const int m0 = tile_m * 256, n0 = tile_n * 128;
+  const int ktiles = (q.K + 63) >> 6;
+  const int kt0 = chunk * q.kt_chunk;
+  const int nt = (ktiles - kt0 < q.kt_chunk) ? ktiles - kt0 : q.kt_chunk;          // K tiles of this chunk (>= 1)
+  const int64_t stepA = (int64_t)q.lda * 128, stepB = (int64_t)q.ldb * 128;        // bytes per K tile (64 k rows)
+  const char* Ab = reinterpret_cast<const char*>(q.A) + (int64_t)kt0 * stepA;
+  const char* Bb = reinterpret_cast<const char*>(q.B) + (int64_t)kt0 * stepB;
+  const int krem = q.K - kt0 * 64;                       // k rows that exist from the chunk's first one on
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // DMA instruction s = wave * 2 + e of a unit = subtile (k half s >> 3 = wave >> 2, row block s & 7): the lane's k row inside a
+  // K tile is the same for both instructions
+  const int kin = (wave >> 2) * 32 + (lane >> 1);
+  uint32_t offA[2][2], offB[2];
+  bool okA[2][2], okB[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int mt = (wave * 2 + e) & 7;
+    const int ur = mt * 16 + (lane & 1) * 8;              // unit row of the lane's 8 values
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = m0 + (ur >> 6) * 128 + h * 64 + (ur & 63);
+      okA[h][e] = row < q.M;                              // (M % 8 == 0: the 8 rows exist together)
+      offA[h][e] = (uint32_t)(((int64_t)kin * q.lda + row) * 2);
+    }
+    okB[e] = n0 + ur < q.N;
+    offB[e] = (uint32_t)(((int64_t)kin * q.ldb + n0 + ur) * 2);
+  }
+  const int fo = ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  // what this wave owns of the matrix: its column slice, the first / second 64 rows of its row block (uniform per wave)
+  const bool liveN = n0 + wc * 32 < q.N;
+  const bool live0 = liveN && (m0 + wr * 128 < q.M), live1 = liveN && (m0 + wr * 128 + 64 < q.M);
+
+  f32x4_t acc[2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bool do_rowsum = q.rowsum != nullptr && tile_n == 0;      // uniform
+  f32x4_t rs[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[a][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  // k rows of K tile t (chunk-relative) that exist: all 64, the head of the matrix's last tile, or none past the chunk
+#define W8_KOK(t) (kin < (((t) < nt) ? krem - (t) * 64 : 0))
+  w8_issue(Ab, offA[0], okA[0], W8_KOK(0), smem + 0 * UNIT, wave);
+  w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave);
+  w8_issue(Ab, offA[1], okA[1], W8_KOK(0), smem + 1 * UNIT, wave);
+  w8_issue(Ab + stepA, offA[0], okA[0], W8_KOK(1), smem + BUF + 0 * UNIT, wave);
+  w8_issue(Bb + stepB, offB, okB, W8_KOK(1), smem + BUF + 2 * UNIT, wave);
+  p8_wait_vmcnt<4>();                  // tile 0 has landed (A.m0, B of tile 1 may still be moving)
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8_t fa[4][2], fb[2][2];
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t & 1) ^ 1) * BUF;
+    const int mine = (wc - 2 * t) & 3;                   // row-sum pair (t, ks) belongs to wave column (2 t + ks) % 4
+    // ---- phase 1: rows m0
+    if (live0) {
+      p8_read_tr<2>(cur + 2 * UNIT, wc * 2, fo, fb);
+      p8_read_tr<4>(cur + 0 * UNIT, wr * 4, fo, fa);
+    }
+    w8_issue(Ab + (int64_t)(t + 1) * stepA, offA[1], okA[1], W8_KOK(t + 1), oth + 1 * UNIT, wave);      // A.m1 of tile t + 1
+    p8_wait_vmcnt<6>();                                                                               // A.m1 of tile t has landed
+    P8_PHASE_SYNC_IN();
+    if (live0) {
+      p8_mfma<4, 2>(fa, fb, acc[0]);
+      if (do_rowsum && mine < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[0][i], 0, 0, 0);
+      }
+    }
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 2: rows m1
+    if (live1) p8_read_tr<4>(cur + 1 * UNIT, wr * 4, fo, fa);
+    w8_issue(Ab + (int64_t)(t + 2) * stepA, offA[0], okA[0], W8_KOK(t + 2), cur + 0 * UNIT, wave);      // A.m0 of tile t + 2
+    w8_issue(Bb + (int64_t)(t + 2) * stepB, offB, okB, W8_KOK(t + 2), cur + 2 * UNIT, wave);            // B of tile t + 2
+    p8_wait_vmcnt<6>();                                                                               // A.m0, B of tile t + 1 have landed
+    P8_PHASE_SYNC_IN();
+    if (live1) {
+      p8_mfma<4, 2>(fa, fb, acc[1]);
+      if (do_rowsum && mine < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[1][i], 0, 0, 0);
+      }
+    }
+    P8_PHASE_SYNC_OUT();
+  }
+#undef W8_KOK
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+  p8_wait_vmcnt<0>();
+  __syncthreads();
+  if (do_rowsum) {
+    float* part = reinterpret_cast<float*>(smem + 2 * BUF - 4096);         // [4 wc][256 rows], above the C tiles of the epilogue
+    const int lr = lane & 15, lg = lane >> 4;
+    if (lr == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[wc * 256 + wr * 128 + a * 64 + i * 16 + lg * 4 + r] = rs[a][i][r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int m = m0 + (int)threadIdx.x;
+      if (m < q.M) {
+        const float v = ((part[threadIdx.x] + part[256 + threadIdx.x]) + part[512 + threadIdx.x]) + part[768 + threadIdx.x];
+        if (q.nchunks > 1) q.rs_ws[(int64_t)chunk * q.M + m] = v;
+        else q.rowsum[m] = ((q.flags & 2) ? q.rowsum[m] : 0.f) + v;
+      }
+    }
+  }
+  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+#pragma unroll 1
+  for (int a = 0; a < 2; ++a) {
+    if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
+    else epilogue_stage<64, 32>(acc[1], cs);
+    w8_flush(q, chunk, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
+  }
+}
+
+// one workgroup per unit; gridDim.x = total units (or a cap: the workgroups then walk the units)
+template <bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_w8_kernel(const w8_args g) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * 3 * 16384];
+#pragma unroll 1
+  for (int id = (int)blockIdx.x; id < g.total; id += (int)gridDim.x) {
+    int u = id;
+    if (gridDim.x == (unsigned)g.total) {                // XCD x gets the x-th contiguous run of units
+      const int q8 = g.total >> 3, r8 = g.total & 7;
+      const int xcd = id & 7, j = id >> 3;
+      u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    int p = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.n; ++i) p += (g.unit_start[i] <= u) ? 1 : 0;
+    const w8_prob& q = g.p[p];
+    int r = u - g.unit_start[p];
+    const int per_chunk = q.tiles_m * q.tiles_n;
+    const int chunk = r / per_chunk;
+    r -= chunk * per_chunk;
+    const int tile_m = r / q.tiles_n;
+    w8_tile<STAGGER>(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
+    __syncthreads();               // (capped grid) the next unit's first DMA overwrites the epilogue's staging tiles
+  }
+}
+
+// C (+)= sum over chunks of the partial tiles, in chunk order; the same for the bias row sums.  blockIdx.y = problem.
+__global__ __launch_bounds__(256) void w8_reduce_kernel(const w8_args g) {
+  const w8_prob& q = g.p[blockIdx.y];
+  if (q.nchunks <= 1) return;
+  const int n4 = q.N >> 2;
+  const int64_t total4 = (int64_t)q.M * n4, plane = (int64_t)q.M * q.N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+    const float* w = q.ws + (int64_t)m * q.N + n;
+    float4 s = *reinterpret_cast<const float4*>(w);
+#pragma unroll 1
+    for (int c = 1; c < q.nchunks; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(w + c * plane);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* cp = q.C + (int64_t)m * q.ldc + n;
+    if (q.flags & 1) {
+      const float4 c0 = *reinterpret_cast<const float4*>(cp);
+      s.x += c0.x; s.y += c0.y; s.z += c0.z; s.w += c0.w;
+    }
+    *reinterpret_cast<float4*>(cp) = s;
+  }
+  if (q.rowsum && blockIdx.x == 0) {
+    for (int m = (int)threadIdx.x; m < q.M; m += 256) {
+      float s = q.rs_ws[m];
+#pragma unroll 1
+      for (int c = 1; c < q.nchunks; ++c) s += q.rs_ws[(int64_t)c * q.M + m];
+      q.rowsum[m] = ((q.flags & 2) ? q.rowsum[m] : 0.f) + s;
+    }
+  }
+}
+
 template <bool STAGGER>
 __global__ __launch_bounds__(512) void gemm_8ph_tr_kernel_q(const s2svc_gemm_desc d) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * 16384];
@@ -1029,6 +1295,113 @@ extern "C" int s2svc_gemm_grouped_try_8ph_bg(const s2svc_gemm_desc* descs, int n
   }
   S2S_CHECK_LAUNCH("gemm_8ph_tr_grouped_kernel");
   return mask;
+}
+
+// ---- ragged weight gradients on the 8-wave kernel (W8) -----------------------------------------------------------
+namespace {
+int w8_mode() {       // S2SVC_GEMM_W8=0: these problems stay on gemm_grouped_kernel<64, 64> (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_W8"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+int w8_kt_chunk_env() {   // S2SVC_W8_KT_CHUNK: K tiles (of 64 rows) per chunk; reductions up to this long run unsplit
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_W8_KT_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 1; }
+  return v;
+}
+// the chunking of a reduction: a function of K only (see the kernel's header)
+void w8_chunks(int K, int& nchunks, int& kt_chunk) {
+  const int ktiles = (K + 63) / 64;
+  kt_chunk = w8_kt_chunk_env();
+  nchunks = (ktiles + kt_chunk - 1) / kt_chunk;
+  if (nchunks > 16) {
+    kt_chunk = (ktiles + 15) / 16;
+    nchunks = (ktiles + kt_chunk - 1) / kt_chunk;
+  }
+}
+bool w8_ok(const s2svc_gemm_desc& d) {
+  if (p8_mode() == 0 || !p8_tr_mode() || !w8_mode()) return false;
+  if (d.dtype != S2S_BF16 || d.c_dtype != S2S_F32 || d.nb0 * d.nb1 != 1 || d.splitk > 1) return false;
+  if (d.A.layout != S2SVC_LAYOUT_RC || d.B.layout != S2SVC_LAYOUT_RC || d.A.mode != S2SVC_OP_DENSE || d.B.mode != S2SVC_OP_DENSE) return false;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.M % 8 || d.N % 8) return false;
+  if (((uintptr_t)d.A.ptr) % 16 || ((uintptr_t)d.B.ptr) % 16 || d.A.ld % 8 || d.B.ld % 8 || d.A.ld < d.M || d.B.ld < d.N) return false;
+  if ((int64_t)64 * d.A.ld * 2 + (int64_t)d.M * 2 >= (1ll << 32) || (int64_t)64 * d.B.ld * 2 + (int64_t)d.N * 2 >= (1ll << 32)) return false;
+  if (((uintptr_t)d.C) % 16 || d.ldc % 4 || d.ldc < d.N) return false;
+  if (d.bias || d.res || d.act != S2S_ACT_NONE || d.alpha != 1.0f || d.emask || d.drop_p > 0.f || d.c_map || d.c_pre) return false;
+  // the exact-256 problems with >= 64 tiles of 128 x 128 keep p8_tr_tile / p8_tr_tile_q (grouped or background launches)
+  if (p8_tr_ok(d) && (int64_t)(d.M / 128) * (d.N / 128) >= 64) return false;
+  return true;
+}
+int64_t w8_ws_floats(const s2svc_gemm_desc& d) {
+  int nc, kc;
+  w8_chunks(d.K, nc, kc);
+  if (nc <= 1) return 0;
+  int64_t f = (int64_t)nc * d.M * d.N;
+  if (d.a_rowsum) f += (((int64_t)nc * d.M + 3) / 4) * 4;
+  return f;
+}
+}  // namespace
+
+// 1 if the 8-wave ragged weight-gradient kernel takes this problem (a function of the descriptor only)
+extern "C" int s2svc_gemm_wgrad_ok(const s2svc_gemm_desc* desc) { return desc && w8_ok(*desc) ? 1 : 0; }
+
+// fp32 elements of workspace s2svc_gemm_wgrad_grouped needs for these problems (0: every reduction runs unsplit)
+extern "C" int64_t s2svc_gemm_wgrad_ws_floats(const s2svc_gemm_desc* descs, int n) {
+  int64_t f = 0;
+  for (int i = 0; i < n; ++i) f += w8_ws_floats(descs[i]);
+  return f;
+}
+
+// every descriptor must satisfy s2svc_gemm_wgrad_ok; no two of them may write the same C / a_rowsum; `ws` (device, 16-byte
+// aligned, s2svc_gemm_wgrad_ws_floats(...) floats, may be NULL if that is 0) must stay untouched until the launches have run
+extern "C" int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs, int n, float* ws, void* stream) {
+  S2S_REQUIRE(descs && n > 0, "gemm_wgrad_grouped: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int mode = p8_mode();
+  static const int cap = [] { const char* e = getenv("S2SVC_W8_WGS"); return e ? atoi(e) : 0; }();
+  int64_t ws_off = 0;
+  for (int i0 = 0; i0 < n; i0 += W8_MAX) {
+    const int cnt = (n - i0 < W8_MAX) ? n - i0 : W8_MAX;
+    w8_args g;
+    std::memset(&g, 0, sizeof(g));
+    int64_t total = 0;
+    bool any_split = false;
+    for (int i = 0; i < cnt; ++i) {
+      const s2svc_gemm_desc& d = descs[i0 + i];
+      S2S_REQUIRE(w8_ok(d), "gemm_wgrad_grouped: a descriptor is not eligible (check s2svc_gemm_wgrad_ok first)");
+      w8_prob& q = g.p[i];
+      q.A = d.A.ptr; q.B = d.B.ptr; q.C = (float*)d.C; q.rowsum = d.a_rowsum;
+      q.lda = (int32_t)d.A.ld; q.ldb = (int32_t)d.B.ld; q.ldc = (int32_t)d.ldc;
+      q.M = d.M; q.N = d.N; q.K = d.K;
+      q.tiles_m = (d.M + 255) / 256; q.tiles_n = (d.N + 127) / 128;
+      int nc, kc;
+      w8_chunks(d.K, nc, kc);
+      q.nchunks = nc; q.kt_chunk = kc;
+      q.flags = (d.accumulate ? 1 : 0) | (d.a_rowsum_accumulate ? 2 : 0);
+      if (nc > 1) {
+        S2S_REQUIRE(ws != nullptr && ((uintptr_t)ws) % 16 == 0, "gemm_wgrad_grouped: split reductions need a 16-byte aligned workspace");
+        any_split = true;
+        q.ws = ws + ws_off;
+        ws_off += (int64_t)nc * d.M * d.N;
+        if (d.a_rowsum) { q.rs_ws = ws + ws_off; ws_off += (((int64_t)nc * d.M + 3) / 4) * 4; }
+      }
+      g.unit_start[i] = (int32_t)total;
+      total += (int64_t)q.tiles_m * q.tiles_n * nc;
+      S2S_REQUIRE(total < (1ll << 30), "gemm_wgrad_grouped: too many units");
+    }
+    for (int i = cnt; i <= W8_MAX; ++i) g.unit_start[i] = (int32_t)total;
+    g.n = cnt;
+    g.total = (int32_t)total;
+    const unsigned wgs = (unsigned)((cap > 0 && total > cap) ? cap : total);
+    if (mode == 2) hipLaunchKernelGGL((gemm_w8_kernel<false>), dim3(wgs), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_w8_kernel<true>), dim3(wgs), dim3(512), 0, st, g);
+    S2S_CHECK_LAUNCH("gemm_w8_kernel");
+    if (any_split) {
+      hipLaunchKernelGGL(w8_reduce_kernel, dim3(48, (unsigned)cnt), dim3(256), 0, st, g);
+      S2S_CHECK_LAUNCH("w8_reduce_kernel");
+    }
+  }
+  return 0;
 }
 
 extern "C" int s2svc_gemm_grouped_try_8ph(const s2svc_gemm_desc* descs, int n, void* stream) {

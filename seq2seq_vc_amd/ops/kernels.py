@@ -386,6 +386,17 @@ def flush_grouped(queue):
                 seen |= keys
                 group.append(d)
         pending = rest
+        # ragged dense weight gradients (any M, N % 8 == 0: VTN's 384 / 1152 / 1536-feature layers): the 8-wave kernel on (problem,
+        # K chunk, 256 x 128 tile) units (csrc/gemm_8ph.hip "W8"); WHICH kernel a problem gets depends on its descriptor only
+        L = _lib.lib()
+        w8 = [d for d in group if L.s2svc_gemm_wgrad_ok(ctypes.addressof(d))]
+        if w8:
+            group = [d for d in group if not any(d is w for w in w8)]
+            arr = (_lib.GemmDesc * len(w8))(*w8)
+            nws = L.s2svc_gemm_wgrad_ws_floats(ctypes.addressof(arr), len(w8))
+            ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
+            bg_wait(*[d.C for d in w8], *[d.a_rowsum for d in w8])
+            _lib.check(L.s2svc_gemm_wgrad_grouped(ctypes.addressof(arr), len(w8), ptr(ws), stream()), "s2svc_gemm_wgrad_grouped")
         # big outputs (>= _GROUP_BIG_TILES 128x128 tiles each) share launches of 128x128 tiles, the rest of 64x64 tiles
         big = [d for d in group if _GROUP_TILE == 64 and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= _GROUP_BIG_TILES]
         small = [d for d in group if not any(d is b for b in big)]

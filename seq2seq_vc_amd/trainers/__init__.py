@@ -64,6 +64,7 @@ class Trainer(object):
     # Captured steps (trainers/graphed.py): tensor field of the batch -> (its length field, padding value), None = no captured
     # step for this trainer; _graph_regime(): whatever host-side state changes WHAT a step launches (one set of graphs each).
     GRAPH_BATCH = None
+    GRAPH_ACCUMULATE = False        # True: the trainer's _graph_regime() names the micro-step's role in an accumulation window
 
     def _graph_regime(self):
         return ()
@@ -130,7 +131,7 @@ class Trainer(object):
         if isinstance(self.optimizer, FlatAdam):
             self.optimizer.join_prologue()       # zero-fill of the gradients + refreshed weight copies: done before the first gradient
         if self.dp is not None:
-            if self._capture is not None:                    # being captured stage by stage: the exchange runs between the replays
+            if self._capture is not None and last_micro_step:   # being captured stage by stage: the exchange runs between the replays
                 self._capture.staged_backward(self.dp, parts)
             else:
                 self.dp.backward(parts, reduce=last_micro_step)
@@ -328,8 +329,14 @@ class AASVCTrainer(Trainer):
     #                                 in the 8-rank sum; multi-GPU runs then no longer match single-GPU runs bit for bit)
     GRAPH_BATCH = {"xs": ("ilens", 0.0), "ys": ("olens", 0.0), "dp_inputs": ("dplens", 0.0)}
 
+    GRAPH_ACCUMULATE = True         # micro-steps of an accumulation window are captured by role (trainers/graphed.py)
+
     def _graph_regime(self):
-        return (self.steps > self.config.get("dp_train_start_steps", 0),)
+        """What the captured step depends on besides shapes: whether the duration loss is on, and the ROLE of the coming micro-step
+        in its accumulation window -- a deferred zero-fill is due at its start / the optimiser step follows its backward pass."""
+        last = (self.backward_steps + 1) % self.gradient_accumulate_steps == 0
+        zero_due = bool(getattr(self.optimizer, "_zero_due", False))
+        return (self.steps > self.config.get("dp_train_start_steps", 0), zero_due, last)
 
     def _train_step(self, batch):
         dev = self.device

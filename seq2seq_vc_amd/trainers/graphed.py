@@ -18,6 +18,14 @@ With data parallelism the backward pass is captured stage by stage (distributed.
 finished stage is issued between the replays, as bench.py does; the optimiser step is its own graph behind the join.
 config["hip_graph"] = "trace" never captures (the eager reference of the tests for exactly this data path).
 
+Gradient accumulation (trainers/aas_vc.py:141-149 of the reference; AASVCTrainer.GRAPH_ACCUMULATE): a MICRO-step is what gets
+captured, and its ROLE is part of the key -- (gradients cleared at its start?, optimiser step at its end?) as
+`Trainer._graph_regime()` reports it before the step runs.  An accumulation window of k micro-steps replays the "accumulate"
+graph (forward + backward into the flat gradient buffer, no zero-fill, no exchange: staged data-parallel passes run their stages
+inside this one graph) k - 1 times and the "last" graph(s) (forward + backward [+ the staged exchange] + clip / Adam / WarmupLR
++ the zero-fill for the next window) once; the host-side counters (`backward_steps`, `steps`) advance by the deltas recorded at
+capture time.  Every role keeps its own static buffers and length bank.
+
 The set of captured shapes is BOUNDED: at most config["graph_cache_size"] (default 16) keys keep their static buffers, length
 bank and graphs; reaching a new key beyond that evicts the least recently used one (its graphs return their blocks to the shared
 pool), and a key is only captured on its config["graph_capture_after"]-th sighting (default 2: the first one runs eagerly and
@@ -63,8 +71,9 @@ class GraphedStep:
         self.copy_stream = "lazy" if os.environ.get("S2SVC_TRAINER_STAGE_H2D", "1") != "0" else None
         self._stage = {}
         self.pool = torch.cuda.graph_pool_handle()     # one memory pool for the graphs of all shapes
-        if trainer.gradient_accumulate_steps != 1:
-            raise NotImplementedError('config["hip_graph"] needs gradient_accumulate_steps == 1')
+        if trainer.gradient_accumulate_steps != 1 and not trainer.GRAPH_ACCUMULATE:
+            raise NotImplementedError(f'config["hip_graph"]: {type(trainer).__name__} has no captured micro-steps '
+                                      "(gradient_accumulate_steps must be 1)")
         from ..schedulers import FusedWarmupLR
         if trainer.scheduler is not None and not isinstance(trainer.scheduler, FusedWarmupLR):
             raise NotImplementedError('config["hip_graph"]: the learning-rate schedule must live in the fused optimiser step '

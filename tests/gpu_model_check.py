@@ -896,6 +896,23 @@ def trainers_replay_captured_steps():
             p_a, l_a, _, _ = run(kind, None, full)
             p_b, l_b, _, _ = run(kind, "trace", full)
             res.append((torch.equal(p_a, p_b), f"{kind}: full-shape batch, plain vs traced trainer: max diff {float((p_a - p_b).abs().max()):.3e}"))
+        # gradient accumulation (trainers/aas_vc.py:141-149): micro-steps captured by role (accumulate | last), 4 per optimiser step
+        cfg, z = load("aasvc_tiny_train")
+        mc = model_cfg(cfg)
+        Fn.enable_side_streams(0, True)
+        data = batches("aasvc", mc["idim"], mc["odim"], 16, 41)
+        acc = {"gradient_accumulate_steps": 4, "train_max_steps": 4}
+        p_e, l_e, s_e, _ = run("aasvc", None, [data[0]] * 8, extra=dict(acc, train_max_steps=2))
+        p_f, l_f, _, _ = run("aasvc", "trace", [data[0]] * 8, extra=dict(acc, train_max_steps=2))
+        res.append((torch.equal(p_e, p_f) and s_e == 2, f"aasvc accumulate 4, full-shape batch, plain vs traced trainer: max diff {float((p_e - p_f).abs().max()):.3e}"))
+        p_t, l_t, s_t, _ = run("aasvc", "trace", data, extra=acc)
+        p_g, l_g, s_g, n_g = run("aasvc", True, data, extra=acc)
+        roles = sorted({k[0][1:] for k in run.last._graphed.entries})
+        res.append((s_t == s_g == 4 and n_g >= 2 and len(roles) >= 2,
+                    f"aasvc accumulate 4: {s_g} optimiser steps over {len(data)} micro-steps, {n_g} captured graphs, roles (zero due, last) {roles}"))
+        res.append((torch.equal(p_t, p_g), f"aasvc accumulate 4: parameters, replayed vs traced eager: max diff {float((p_t - p_g).abs().max()):.3e}"))
+        same_logs = len(l_t) == len(l_g) and all(abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(a[k])) for a, b in zip(l_t, l_g) for k in a)
+        res.append((same_logs, f"aasvc accumulate 4: logged losses agree ({[round(v, 4) for v in l_g[-1].values()]})"))
         # staged capture (the data-parallel path) with a one-rank group
         if not dist.is_initialized():
             dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29617", rank=0, world_size=1)
@@ -908,6 +925,11 @@ def trainers_replay_captured_steps():
                 p_t, l_t, _, _ = run(kind, "trace", data, distributed=True)
                 p_g, l_g, _, n_g = run(kind, True, data, distributed=True)
                 res.append((torch.equal(p_t, p_g) and n_g >= 3, f"{kind}: staged capture ({n_g} graphs), replayed vs traced eager: max diff {float((p_t - p_g).abs().max()):.3e}"))
+            data = batches("aasvc", mc["idim"], mc["odim"], 12, 43)
+            acc = {"gradient_accumulate_steps": 3, "train_max_steps": 4}
+            p_t, _, _, _ = run("aasvc", "trace", data, distributed=True, extra=acc)
+            p_g, _, s_g, n_g = run("aasvc", True, data, distributed=True, extra=acc)
+            res.append((torch.equal(p_t, p_g) and s_g == 4, f"aasvc accumulate 3, staged capture ({n_g} graphs): replayed vs traced eager: max diff {float((p_t - p_g).abs().max()):.3e}"))
         finally:
             dist.destroy_process_group()
     finally:

@@ -48,13 +48,16 @@ def make_batches(workload, n, B, seed=7):
     return out
 
 
-def run(workload, mode, data, dtype, dev):
+def run(workload, mode, data, dtype, dev, accum=1):
     Fn.set_compute_dtype(dtype)
     K.manual_seed(1234)
     torch.manual_seed(0)
     conf = {"train_max_steps": len(data), "log_interval_steps": 10 ** 9, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": "."}
     if mode:
         conf["hip_graph"] = True
+    if accum > 1:                           # micro-steps: the recipes' batch 2 x accumulation 8 (egs/hificaptain_jp/vc2/README.md:11)
+        conf["gradient_accumulate_steps"] = accum
+        conf["train_max_steps"] = len(data) // accum
     if workload == "vtn":
         model = M.VTN(**bench.VTN_VC1).to(dev).train()
         opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=(dtype == torch.bfloat16))
@@ -66,7 +69,7 @@ def run(workload, mode, data, dtype, dev):
                      "dp_train_start_steps": 0})
         tr = T.AASVCTrainer(0, 0, {"train": data}, None, model, None, {"L1Loss": L.L1Loss(), "ForwardSumLoss": L.ForwardSumLoss()},
                             opt, None, conf, device=dev)
-    warm = 6
+    warm = 6 if accum == 1 else 3 * accum       # every role of a micro-step is seen (eager), captured and replayed once
     it = iter(data)
     for _ in range(warm):
         tr._step(next(it))
@@ -79,7 +82,11 @@ def run(workload, mode, data, dtype, dev):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     frames = sum(float(b["olens"].sum()) for b in data[warm:]) / n
-    return {"mode": "hip_graph" if mode else "eager", "ms_per_step": dt * 1e3, "mel_frames_per_s": frames / dt, "steps": n}
+    out = {"mode": "hip_graph" if mode else "eager", "ms_per_step": dt * 1e3, "mel_frames_per_s": frames / dt, "steps": n}
+    if accum > 1:
+        out = {"mode": out["mode"], "ms_per_micro_step": dt * 1e3, "ms_per_optimizer_step": dt * 1e3 * accum, "mel_frames_per_s": frames / dt,
+               "micro_steps": n, "gradient_accumulate_steps": accum}
+    return out
 
 
 def main():
@@ -87,12 +94,15 @@ def main():
     ap.add_argument("--workload", default="vtn")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--accum", type=int, default=1, help="gradient_accumulate_steps (AAS-VC trainer: captured micro-steps)")
+    ap.add_argument("--batch", type=int, default=None)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    B = 32 if a.workload == "vtn" else 16
-    data = make_batches(a.workload, a.steps + 6, B)
-    res = [run(a.workload, mode, data, dtype, dev) for mode in (False, True)]
+    B = a.batch or (32 if a.workload == "vtn" else 16)
+    n = a.steps + 6 if a.accum == 1 else (a.steps // a.accum + 3) * a.accum
+    data = make_batches(a.workload, n, B)
+    res = [run(a.workload, mode, data, dtype, dev, accum=a.accum) for mode in (False, True)]
     print(json.dumps({"workload": a.workload, "batch": B, "dtype": a.dtype, "data": "synthetic, lengths vary per batch, host batches (H2D inside)",
                       "results": res}))
 
