@@ -155,6 +155,9 @@ int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs /* host */, int n, v
 int s2svc_gemm_wgrad_ok(const s2svc_gemm_desc* desc /* host */);
 int64_t s2svc_gemm_wgrad_ws_floats(const s2svc_gemm_desc* descs /* host */, int n);
 int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs /* host */, int n, float* ws, void* stream);
+/* A/B switch (tests, benchmarks): on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles of 64 rows per chunk (<= 0: unchanged; default 32,
+   S2SVC_GEMM_W8 / S2SVC_W8_KT_CHUNK); returns the previous on | kt_chunk << 8. */
+int s2svc_gemm_set_w8(int on, int kt_chunk);
 int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream, void* bg_stream, int bg_cus,
                           int* n_bg /* host, may be NULL */);
 

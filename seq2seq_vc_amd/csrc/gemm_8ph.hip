@@ -472,8 +472,12 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
 // Row-contiguous operands ("TR"): the weight-gradient GEMMs C[n_out, n_in] (+)= dY^T . X of the Linear layers, reduction over
 // the B*T rows of the batch, both operands stored [k][row].  Same 256 x 128 tile, units, phases and counted waits as
 // gemm_8ph_kernel_128; what changes is the image of a unit and how fragments leave it (as in gemm_glds.hip's TrStage):
-//   * a unit (128 rows x 64 k) is 16 subtiles [k half][16-row block] of 1 KiB = [32 k][16 rows], one DMA instruction each
-//     (lane l -> k row l / 2, rows 8 (l & 1) .. + 7: 16 contiguous bytes of the operand);
+//   * a unit (128 rows x 64 k) is 16 pieces of 1 KiB, one DMA instruction each: piece s = (64-row half s >> 3, k block s & 7)
+//     holds 8 k rows x 64 rows, a k row = 128 contiguous bytes of the operand = 8 slots of 16 bytes (round 4; until round 3 a
+//     piece was [32 k][16 rows]: 32 bytes per k row, i.e. 32 cache lines per DMA instruction instead of 8 -- the K loop of the
+//     transposed kernels ran at 1.05 us per K tile against 0.72 us for the K-contiguous kernel of the same schedule).  Slot j
+//     of k row kin holds the 16-row block (j >> 1) ^ ((kin >> 1) & 3), rows 8 (j & 1) .. + 7 of it: the XOR (applied to the
+//     per-lane SOURCE address and to the fragment address) spreads the four k rows a 16-lane group reads over all banks;
 //   * a fragment is two ds_read_b64_tr_b16 (lane group g gets k = 4g .. 4g+3 and 16+4g .. 16+4g+3 of the k half -- a
 //     permutation of the MFMA k positions, the same for both operands);
 //   * the fused bias gradient (a_rowsum: sum over k of every A row) is MFMA work too -- an extra product with an all-ones B
@@ -486,17 +490,31 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
 typedef __attribute__((ext_vector_type(4))) short p8_s16x4_t;
 typedef __attribute__((address_space(3))) p8_s16x4_t p8_lds_s16x4_t;
 
-// fragments of NF consecutive 16-row blocks starting at unit block `blk0`, both k halves; fo = the lane's offset inside a subtile
+// source of DMA piece s (0 .. 15) of a unit for this lane: its k row inside the K tile and the unit row of its 8 values
+__device__ __forceinline__ void p8_tr_src(int s, int lane, int& k, int& ur) {
+  const int kin = lane >> 3, j = lane & 7;
+  k = (s & 7) * 8 + kin;
+  ur = (s >> 3) * 64 + (((j >> 1) ^ ((kin >> 1) & 3)) << 4) + (j & 1) * 8;
+}
+
+// per-lane byte offset of the fragment reads of 16-row block b (0 .. 7) inside a unit, first k half, first 16 k
+__device__ __forceinline__ int p8_tr_frag_off(int b, int lane) {
+  const int g = lane >> 4, r = lane & 15;
+  const int kin = (g & 1) * 4 + (r >> 2);               // k row inside its block of 8 (k = 4 g + (r >> 2) of the 16)
+  return (b >> 2) * 8192 + (g >> 1) * 1024 + kin * 128 + ((((b & 3) ^ ((kin >> 1) & 3))) << 5) + (r & 3) * 8;
+}
+
+// fragments of NF 16-row blocks (per-lane offsets foff[], see p8_tr_frag_off), both k halves
 template <int NF>
-__device__ __forceinline__ void p8_read_tr(const char* unit, int blk0, int fo, bf16x8_t (&f)[NF][2]) {
+__device__ __forceinline__ void p8_read_tr(const char* unit, const int (&foff)[NF], bf16x8_t (&f)[NF][2]) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
 #pragma unroll
   for (int i = 0; i < NF; ++i)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const char* p = unit + (ks * 8 + blk0 + i) * 1024 + fo;
+      const char* p = unit + foff[i] + ks * 4096;
       const p8_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((p8_lds_s16x4_t*)p);
-      const p8_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((p8_lds_s16x4_t*)(p + 512));
+      const p8_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((p8_lds_s16x4_t*)(p + 2048));
       const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       f[i][ks] = __builtin_bit_cast(bf16x8_t, v);
     }
@@ -514,18 +532,21 @@ __device__ __forceinline__ void p8_tr_tile(const s2svc_gemm_desc& d, int tile_m,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  // source offsets: DMA instruction s = wave * 2 + e of a unit = subtile (k half s >> 3, row block s & 7)
+  // source offsets: DMA instruction s = wave * 2 + e of a unit = piece s (p8_tr_src)
   uint32_t offA[2][2], offB[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    const int sidx = wave * 2 + e, kh = sidx >> 3, mt = sidx & 7;
-    const int ur = mt * 16 + (lane & 1) * 8;              // unit row of the lane's 8 values
-    const int k = kh * 32 + (lane >> 1);
+    int k, ur;                                            // k row inside the K tile, unit row of the lane's 8 values
+    p8_tr_src(wave * 2 + e, lane, k, ur);
 #pragma unroll
     for (int h = 0; h < 2; ++h) offA[h][e] = (uint32_t)(((int64_t)k * d.A.ld + m0 + (ur >> 6) * 128 + h * 64 + (ur & 63)) * 2);
     offB[e] = (uint32_t)(((int64_t)k * d.B.ld + n0 + ur) * 2);
   }
-  const int fo = ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  int foA[4], foB[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) foA[i] = p8_tr_frag_off(wr * 4 + i, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) foB[j] = p8_tr_frag_off(wc * 2 + j, lane);
 
   f32x4_t acc[2][4][2];
 #pragma unroll
@@ -562,8 +583,8 @@ __device__ __forceinline__ void p8_tr_tile(const s2svc_gemm_desc& d, int tile_m,
     char* oth = smem + ((t & 1) ^ 1) * BUF;
     const int mine = (wc - 2 * t) & 3;                   // pair (t, ks) belongs to wave column (2 t + ks) % 4: ks == mine (0 / 1 / none)
     // ---- phase 1: rows m0
-    p8_read_tr<2>(cur + 2 * UNIT, wc * 2, fo, fb);
-    p8_read_tr<4>(cur + 0 * UNIT, wr * 4, fo, fa);
+    p8_read_tr<2>(cur + 2 * UNIT, foB, fb);
+    p8_read_tr<4>(cur + 0 * UNIT, foA, fa);
     p8_issue<2>((t + 1 < nt) ? Ab + (int64_t)(t + 1) * stepA : nullptr, offA[1], oth + 1 * UNIT, wave);     // A.m1 of tile t + 1
     p8_wait_vmcnt<6>();                                                                              // A.m1 of tile t has landed
     P8_PHASE_SYNC_IN();
@@ -574,7 +595,7 @@ __device__ __forceinline__ void p8_tr_tile(const s2svc_gemm_desc& d, int tile_m,
     }
     P8_PHASE_SYNC_OUT();
     // ---- phase 2: rows m1
-    p8_read_tr<4>(cur + 1 * UNIT, wr * 4, fo, fa);
+    p8_read_tr<4>(cur + 1 * UNIT, foA, fa);
     p8_issue<2>((t + 2 < nt) ? Ab + (int64_t)(t + 2) * stepA : nullptr, offA[0], cur + 0 * UNIT, wave);     // A.m0 of tile t + 2
     p8_issue<2>((t + 2 < nt) ? Bb + (int64_t)(t + 2) * stepB : nullptr, offB, cur + 2 * UNIT, wave);        // B of tile t + 2
     p8_wait_vmcnt<6>();                                                                              // A.m0, B of tile t + 1 have landed
@@ -638,16 +659,19 @@ __device__ __forceinline__ void p8_tr_tile_q(const s2svc_gemm_desc& d, int tile_
   uint32_t offA[2][2], offB[2][2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    const int sidx = wave * 2 + e, kh = sidx >> 3, mt = sidx & 7;
-    const int ur = mt * 16 + (lane & 1) * 8;
-    const int k = kh * 32 + (lane >> 1);
+    int k, ur;
+    p8_tr_src(wave * 2 + e, lane, k, ur);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       offA[h][e] = (uint32_t)(((int64_t)k * d.A.ld + m0 + (ur >> 6) * 128 + h * 64 + (ur & 63)) * 2);
       offB[h][e] = (uint32_t)(((int64_t)k * d.B.ld + n0 + (ur >> 5) * 64 + h * 32 + (ur & 31)) * 2);
     }
   }
-  const int fo = ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  int foA[4], foB[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) foA[i] = p8_tr_frag_off(wr * 4 + i, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) foB[j] = p8_tr_frag_off(wc * 2 + j, lane);
 
   f32x4_t acc[2][2][4][2];
 #pragma unroll
@@ -692,14 +716,14 @@ __device__ __forceinline__ void p8_tr_tile_q(const s2svc_gemm_desc& d, int tile_
     const char* b1 = (t + 1 < nt) ? Bb + (int64_t)(t + 1) * stepB : nullptr;
     const int mine = (wc - 2 * t) & 3;
     // ---- phase 1: quadrant (m0, n0)
-    p8_read_tr<2>(cur + OB0, wc * 2, fo, fb0);
-    p8_read_tr<4>(cur + OA0, wr * 4, fo, fa);
+    p8_read_tr<2>(cur + OB0, foB, fb0);
+    p8_read_tr<4>(cur + OA0, foA, fa);
     p8_issue<2>(b1, offB[0], oth + OB0, wave);                                // B.n0 of tile t + 1
     P8_PHASE_SYNC_IN();
     p8_mfma<4, 2>(fa, fb0, acc[0][0]);
     P8_PHASE_SYNC_OUT();
     // ---- phase 2: quadrant (m0, n1)
-    p8_read_tr<2>(cur + OB1, wc * 2, fo, fb1);
+    p8_read_tr<2>(cur + OB1, foB, fb1);
     p8_issue<2>(a2, offA[0], cur + OA0, wave);                                // A.m0 of tile t + 2
     P8_PHASE_SYNC_IN();
     p8_mfma<4, 2>(fa, fb1, acc[0][1]);
@@ -709,7 +733,7 @@ __device__ __forceinline__ void p8_tr_tile_q(const s2svc_gemm_desc& d, int tile_
     }
     P8_PHASE_SYNC_OUT();
     // ---- phase 3: quadrant (m1, n1)
-    p8_read_tr<4>(cur + OA1, wr * 4, fo, fa);
+    p8_read_tr<4>(cur + OA1, foA, fa);
     p8_issue<2>(b2, offB[1], cur + OB1, wave);                                // B.n1 of tile t + 2
     P8_PHASE_SYNC_IN();
     p8_mfma<4, 2>(fa, fb1, acc[1][1]);
@@ -855,13 +879,13 @@ struct w8_args {
 static_assert(sizeof(w8_prob) == 96, "w8_prob layout");
 static_assert(sizeof(w8_args) <= 4096, "kernel arguments are limited to 4 KB");
 
-// one unit = 2 DMA instructions of this wave; a lane reads the zero block unless its rows (ok[e]) and its k row (kok) exist
-__device__ __forceinline__ void w8_issue(const char* base, const uint32_t (&off)[2], const bool (&ok)[2], bool kok, char* lds_unit,
-                                         int wave) {
+// one unit = 2 DMA instructions of this wave; a lane reads the zero block unless its rows (ok[e]) and its k row (kin[e] < klim) exist
+__device__ __forceinline__ void w8_issue(const char* base, const uint32_t (&off)[2], const bool (&ok)[2], const int (&kin)[2], int klim,
+                                         char* lds_unit, int wave) {
   const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    const char* src = (ok[e] && kok) ? base + off[e] : z;
+    const char* src = (ok[e] && kin[e] < klim) ? base + off[e] : z;
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_unit + (wave * 2 + e) * 1024), 16, 0, 0);
   }
 }
@@ -887,7 +911,7 @@ __device__ __forceinline__ void w8_flush(const w8_prob& q, int chunk, int m_base
   }
 }
 
-template <bool STAGGER>
+template <bool STAGGER, bool PIPE>
 __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n, int chunk, char* smem) {
   constexpr int UNIT = 16384, BUF = 3 * UNIT;            // A.m0 | A.m1 | B
   const int m0 = tile_m * 256, n0 = tile_n * 128;
@@ -902,27 +926,32 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  // DMA instruction s = wave * 2 + e of a unit = subtile (k half s >> 3 = wave >> 2, row block s & 7): the lane's k row inside a
-  // K tile is the same for both instructions
-  const int kin = (wave >> 2) * 32 + (lane >> 1);
+  // DMA instruction s = wave * 2 + e of a unit = piece s (p8_tr_src): kin[e] = the lane's k row inside a K tile
+  int kin[2];
   uint32_t offA[2][2], offB[2];
   bool okA[2][2], okB[2];
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    const int mt = (wave * 2 + e) & 7;
-    const int ur = mt * 16 + (lane & 1) * 8;              // unit row of the lane's 8 values
+    int ur;                                               // unit row of the lane's 8 values
+    p8_tr_src(wave * 2 + e, lane, kin[e], ur);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int row = m0 + (ur >> 6) * 128 + h * 64 + (ur & 63);
       okA[h][e] = row < q.M;                              // (M % 8 == 0: the 8 rows exist together)
-      offA[h][e] = (uint32_t)(((int64_t)kin * q.lda + row) * 2);
+      offA[h][e] = (uint32_t)(((int64_t)kin[e] * q.lda + row) * 2);
     }
     okB[e] = n0 + ur < q.N;
-    offB[e] = (uint32_t)(((int64_t)kin * q.ldb + n0 + ur) * 2);
+    offB[e] = (uint32_t)(((int64_t)kin[e] * q.ldb + n0 + ur) * 2);
   }
-  const int fo = ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+  int foA[4], foB[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) foA[i] = p8_tr_frag_off(wr * 4 + i, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) foB[j] = p8_tr_frag_off(wc * 2 + j, lane);
   // what this wave owns of the matrix: its column slice, the first / second 64 rows of its row block (uniform per wave)
-  const bool liveN = n0 + wc * 32 < q.N;
+  const bool do_rowsum = q.rowsum != nullptr && tile_n == 0;      // uniform
+  // (the bias row sums are dealt to ALL four wave columns: a column slice past N still takes part in them)
+  const bool liveN = (n0 + wc * 32 < q.N) || do_rowsum;
   const bool live0 = liveN && (m0 + wr * 128 < q.M), live1 = liveN && (m0 + wr * 128 + 64 < q.M);
 
   f32x4_t acc[2][4][2];
@@ -932,7 +961,6 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const bool do_rowsum = q.rowsum != nullptr && tile_n == 0;      // uniform
   f32x4_t rs[2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -943,7 +971,81 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
   // k rows of K tile t (chunk-relative) that exist: all 64, the head of the matrix's last tile, or none past the chunk
-#define W8_KOK(t) (kin < (((t) < nt) ? krem - (t) * 64 : 0))
+#define W8_KOK(t) kin, (((t) < nt) ? krem - (t) * 64 : 0)
+  if constexpr (PIPE) {
+    // FRAGMENT PREFETCH (round 4): a wave fetches the fragments of phase p + 1 while it issues the MFMAs of phase p (two A register
+    // sets fa0 / fa1 alternate by phase, two B sets by K tile), so the LDS round trip of a phase hides behind that phase's matrix
+    // work instead of standing in front of it: ONE barrier per phase (lgkmcnt(0) + the counted vmcnt wait in front of it), no
+    // half-phase skew.  Measured before the change: 1.05 us per K tile for 0.43 us of MFMA issue per SIMD -- the four slots of a K
+    // tile each paid [read issue + LDS latency + barrier] before their MFMAs.
+    //   phase 1 of tile t: MFMA rows m0 (fa0 x fb) | fetch fa1 <- A.m1(t)             | DMA A.m0(t+2), B(t+2) -> cur | wait A.m0, B of t+1
+    //   phase 2 of tile t: MFMA rows m1 (fa1 x fb) | fetch fa0, fb' <- A.m0, B of t+1 | DMA A.m1(t+2) -> cur         | wait A.m1 of t+1
+    // RAW: a unit is fetched one phase after the phase whose vmcnt wait + barrier retired it.  WAR: a unit is re-filled one phase
+    // after the phase that fetched it (its lgkmcnt(0) + barrier retired the reads of every wave).
+    w8_issue(Ab, offA[0], okA[0], W8_KOK(0), smem + 0 * UNIT, wave);
+    w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave);
+    w8_issue(Ab, offA[1], okA[1], W8_KOK(0), smem + 1 * UNIT, wave);
+    w8_issue(Ab + stepA, offA[0], okA[0], W8_KOK(1), smem + BUF + 0 * UNIT, wave);
+    w8_issue(Bb + stepB, offB, okB, W8_KOK(1), smem + BUF + 2 * UNIT, wave);
+    w8_issue(Ab + stepA, offA[1], okA[1], W8_KOK(1), smem + BUF + 1 * UNIT, wave);
+    p8_wait_vmcnt<6>();                // tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+    bf16x8_t fa0[4][2], fa1[4][2], fbX[2][2], fbY[2][2];
+    if (live0) {
+      p8_read_tr<2>(smem + 2 * UNIT, foB, fbX);
+      p8_read_tr<4>(smem + 0 * UNIT, foA, fa0);
+    }
+    p8_wait_lgkm0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();      // every wave has fetched A.m0 / B of tile 0: phase 1 of tile 0 may re-fill them
+#define W8_KTILE(t, FBU, FBL)                                                                                                   \
+    {                                                                                                                             \
+      char* cur = smem + ((t) & 1) * BUF;                                                                                         \
+      char* oth = smem + (((t) & 1) ^ 1) * BUF;                                                                                   \
+      const int mine = (wc - 2 * (t)) & 3;              /* row-sum pair (t, ks) belongs to wave column (2 t + ks) % 4 */          \
+      if (live1) p8_read_tr<4>(cur + 1 * UNIT, foA, fa1);                                                                         \
+      w8_issue(Ab + (int64_t)((t) + 2) * stepA, offA[0], okA[0], W8_KOK((t) + 2), cur + 0 * UNIT, wave);                          \
+      w8_issue(Bb + (int64_t)((t) + 2) * stepB, offB, okB, W8_KOK((t) + 2), cur + 2 * UNIT, wave);                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                                          \
+      if (live0) {                                                                                                                \
+        p8_mfma<4, 2>(fa0, FBU, acc[0]);                                                                                          \
+        if (do_rowsum && mine < 2) {                                                                                              \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                           \
+            rs[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa0[i][1] : fa0[i][0], ones, rs[0][i], 0, 0, 0);            \
+        }                                                                                                                         \
+      }                                                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                                          \
+      p8_wait_vmcnt<6>();                               /* A.m0, B of tile t + 1 have landed */                                   \
+      p8_wait_lgkm0();                                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                          \
+      __builtin_amdgcn_s_barrier();                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                                          \
+      if (live0) {                                                                                                                \
+        p8_read_tr<2>(oth + 2 * UNIT, foB, FBL);                                                                                  \
+        p8_read_tr<4>(oth + 0 * UNIT, foA, fa0);                                                                                  \
+      }                                                                                                                           \
+      w8_issue(Ab + (int64_t)((t) + 2) * stepA, offA[1], okA[1], W8_KOK((t) + 2), cur + 1 * UNIT, wave);                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                                          \
+      if (live1) {                                                                                                                \
+        p8_mfma<4, 2>(fa1, FBU, acc[1]);                                                                                          \
+        if (do_rowsum && mine < 2) {                                                                                              \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                           \
+            rs[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa1[i][1] : fa1[i][0], ones, rs[1][i], 0, 0, 0);            \
+        }                                                                                                                         \
+      }                                                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                                          \
+      p8_wait_vmcnt<6>();                               /* A.m1 of tile t + 1 has landed */                                       \
+      p8_wait_lgkm0();                                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                          \
+      __builtin_amdgcn_s_barrier();                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    }
+    for (int t = 0; t < nt; t += 2) {
+      W8_KTILE(t, fbX, fbY);
+      if (t + 1 < nt) W8_KTILE(t + 1, fbY, fbX);
+    }
+#undef W8_KTILE
+  } else {
   w8_issue(Ab, offA[0], okA[0], W8_KOK(0), smem + 0 * UNIT, wave);
   w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave);
   w8_issue(Ab, offA[1], okA[1], W8_KOK(0), smem + 1 * UNIT, wave);
@@ -960,8 +1062,8 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
     const int mine = (wc - 2 * t) & 3;                   // row-sum pair (t, ks) belongs to wave column (2 t + ks) % 4
     // ---- phase 1: rows m0
     if (live0) {
-      p8_read_tr<2>(cur + 2 * UNIT, wc * 2, fo, fb);
-      p8_read_tr<4>(cur + 0 * UNIT, wr * 4, fo, fa);
+      p8_read_tr<2>(cur + 2 * UNIT, foB, fb);
+      p8_read_tr<4>(cur + 0 * UNIT, foA, fa);
     }
     w8_issue(Ab + (int64_t)(t + 1) * stepA, offA[1], okA[1], W8_KOK(t + 1), oth + 1 * UNIT, wave);      // A.m1 of tile t + 1
     p8_wait_vmcnt<6>();                                                                               // A.m1 of tile t has landed
@@ -975,7 +1077,7 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
     }
     P8_PHASE_SYNC_OUT();
     // ---- phase 2: rows m1
-    if (live1) p8_read_tr<4>(cur + 1 * UNIT, wr * 4, fo, fa);
+    if (live1) p8_read_tr<4>(cur + 1 * UNIT, foA, fa);
     w8_issue(Ab + (int64_t)(t + 2) * stepA, offA[0], okA[0], W8_KOK(t + 2), cur + 0 * UNIT, wave);      // A.m0 of tile t + 2
     w8_issue(Bb + (int64_t)(t + 2) * stepB, offB, okB, W8_KOK(t + 2), cur + 2 * UNIT, wave);            // B of tile t + 2
     p8_wait_vmcnt<6>();                                                                               // A.m0, B of tile t + 1 have landed
@@ -989,8 +1091,9 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
     }
     P8_PHASE_SYNC_OUT();
   }
+  }
 #undef W8_KOK
-  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+  if (!PIPE && STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
   p8_wait_vmcnt<0>();
   __syncthreads();
   if (do_rowsum) {
@@ -1024,7 +1127,7 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
 }
 
 // one workgroup per unit; gridDim.x = total units (or a cap: the workgroups then walk the units)
-template <bool STAGGER>
+template <bool STAGGER, bool PIPE>
 __global__ __launch_bounds__(512) void gemm_w8_kernel(const w8_args g) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 3 * 16384];
 #pragma unroll 1
@@ -1044,7 +1147,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(const w8_args g) {
     const int chunk = r / per_chunk;
     r -= chunk * per_chunk;
     const int tile_m = r / q.tiles_n;
-    w8_tile<STAGGER>(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
+    w8_tile<STAGGER, PIPE>(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
     __syncthreads();               // (capped grid) the next unit's first DMA overwrites the epilogue's staging tiles
   }
 }
@@ -1299,15 +1402,14 @@ extern "C" int s2svc_gemm_grouped_try_8ph_bg(const s2svc_gemm_desc* descs, int n
 
 // ---- ragged weight gradients on the 8-wave kernel (W8) -----------------------------------------------------------
 namespace {
-int w8_mode() {       // S2SVC_GEMM_W8=0: these problems stay on gemm_grouped_kernel<64, 64> (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_W8"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v;
+int g_w8_mode = -1, g_w8_kt = -1;
+int w8_mode() {       // S2SVC_GEMM_W8=0 / s2svc_gemm_set_w8: these problems stay on gemm_grouped_kernel<64, 64> (A/B switch)
+  if (g_w8_mode < 0) { const char* e = getenv("S2SVC_GEMM_W8"); g_w8_mode = (e && e[0] == '0') ? 0 : 1; }
+  return g_w8_mode;
 }
-int w8_kt_chunk_env() {   // S2SVC_W8_KT_CHUNK: K tiles (of 64 rows) per chunk; reductions up to this long run unsplit
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_W8_KT_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 1; }
-  return v;
+int w8_kt_chunk_env() {   // S2SVC_W8_KT_CHUNK / s2svc_gemm_set_w8: K tiles (of 64 rows) per chunk; reductions up to this long run unsplit
+  if (g_w8_kt < 0) { const char* e = getenv("S2SVC_W8_KT_CHUNK"); g_w8_kt = e ? atoi(e) : 32; if (g_w8_kt < 1) g_w8_kt = 1; }
+  return g_w8_kt;
 }
 // the chunking of a reduction: a function of K only (see the kernel's header)
 void w8_chunks(int K, int& nchunks, int& kt_chunk) {
@@ -1329,7 +1431,7 @@ bool w8_ok(const s2svc_gemm_desc& d) {
   if (((uintptr_t)d.C) % 16 || d.ldc % 4 || d.ldc < d.N) return false;
   if (d.bias || d.res || d.act != S2S_ACT_NONE || d.alpha != 1.0f || d.emask || d.drop_p > 0.f || d.c_map || d.c_pre) return false;
   // the exact-256 problems with >= 64 tiles of 128 x 128 keep p8_tr_tile / p8_tr_tile_q (grouped or background launches)
-  if (p8_tr_ok(d) && (int64_t)(d.M / 128) * (d.N / 128) >= 64) return false;
+  if (w8_mode() != 2 && p8_tr_ok(d) && (int64_t)(d.M / 128) * (d.N / 128) >= 64) return false;      // (mode 2: benchmarks)
   return true;
 }
 int64_t w8_ws_floats(const s2svc_gemm_desc& d) {
@@ -1341,6 +1443,15 @@ int64_t w8_ws_floats(const s2svc_gemm_desc& d) {
   return f;
 }
 }  // namespace
+
+// A/B switch for tests and benchmarks: on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles per chunk (<= 0: unchanged).  Returns the
+// previous (on | kt_chunk << 8).  A process that trains keeps both fixed: the chunking decides the order of summation.
+extern "C" int s2svc_gemm_set_w8(int on, int kt_chunk) {
+  const int prev = w8_mode() | (w8_kt_chunk_env() << 8);
+  if (on >= 0) g_w8_mode = on > 2 ? 1 : on;
+  if (kt_chunk > 0) g_w8_kt = kt_chunk;
+  return prev;
+}
 
 // 1 if the 8-wave ragged weight-gradient kernel takes this problem (a function of the descriptor only)
 extern "C" int s2svc_gemm_wgrad_ok(const s2svc_gemm_desc* desc) { return desc && w8_ok(*desc) ? 1 : 0; }
@@ -1393,8 +1504,10 @@ extern "C" int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs, int n, flo
     g.n = cnt;
     g.total = (int32_t)total;
     const unsigned wgs = (unsigned)((cap > 0 && total > cap) ? cap : total);
-    if (mode == 2) hipLaunchKernelGGL((gemm_w8_kernel<false>), dim3(wgs), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((gemm_w8_kernel<true>), dim3(wgs), dim3(512), 0, st, g);
+    static const bool pipe = !getenv_off("S2SVC_W8_PIPE");
+    if (pipe) hipLaunchKernelGGL((gemm_w8_kernel<false, true>), dim3(wgs), dim3(512), 0, st, g);
+    else if (mode == 2) hipLaunchKernelGGL((gemm_w8_kernel<false, false>), dim3(wgs), dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((gemm_w8_kernel<true, false>), dim3(wgs), dim3(512), 0, st, g);
     S2S_CHECK_LAUNCH("gemm_w8_kernel");
     if (any_split) {
       hipLaunchKernelGGL(w8_reduce_kernel, dim3(48, (unsigned)cnt), dim3(256), 0, st, g);

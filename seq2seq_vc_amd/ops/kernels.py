@@ -352,6 +352,16 @@ def launch_group(descs, tile=128):
     _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(descs), tile, stream()), "s2svc_gemm_grouped")
 
 
+def launch_wgrad_group(descs):
+    """The listed weight-gradient problems (every one s2svc_gemm_wgrad_ok) on the ragged 8-wave kernel, one grid per <= 40 of
+    them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`)."""
+    L = _lib.lib()
+    arr = (_lib.GemmDesc * len(descs))(*descs)
+    nws = L.s2svc_gemm_wgrad_ws_floats(ctypes.addressof(arr), len(descs))
+    ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
+    _lib.check(L.s2svc_gemm_wgrad_grouped(ctypes.addressof(arr), len(descs), ptr(ws), stream()), "s2svc_gemm_wgrad_grouped")
+
+
 _GROUP_BATCHED = os.environ.get("S2SVC_ATTN_GROUP", "1") != "0"      # A/B aid
 
 
@@ -392,11 +402,8 @@ def flush_grouped(queue):
         w8 = [d for d in group if L.s2svc_gemm_wgrad_ok(ctypes.addressof(d))]
         if w8:
             group = [d for d in group if not any(d is w for w in w8)]
-            arr = (_lib.GemmDesc * len(w8))(*w8)
-            nws = L.s2svc_gemm_wgrad_ws_floats(ctypes.addressof(arr), len(w8))
-            ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
             bg_wait(*[d.C for d in w8], *[d.a_rowsum for d in w8])
-            _lib.check(L.s2svc_gemm_wgrad_grouped(ctypes.addressof(arr), len(w8), ptr(ws), stream()), "s2svc_gemm_wgrad_grouped")
+            launch_wgrad_group(w8)
         # big outputs (>= _GROUP_BIG_TILES 128x128 tiles each) share launches of 128x128 tiles, the rest of 64x64 tiles
         big = [d for d in group if _GROUP_TILE == 64 and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= _GROUP_BIG_TILES]
         small = [d for d in group if not any(d is b for b in big)]

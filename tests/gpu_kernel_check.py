@@ -1269,6 +1269,90 @@ def gemm_8phase_weight_gradients():
 
 
 @case
+def gemm_w8_ragged_weight_gradients():
+    """The ragged 8-wave weight-gradient kernel (csrc/gemm_8ph.hip "W8": (problem, K chunk, 256 x 128 tile) units, zero-filled DMA
+    sources past M / N / K, idle wave halves skip their MFMAs): VTN's layer shapes (K = 2016 = 31.5 K tiles), shapes that are ragged
+    in every dimension, a reduction shorter than one K tile, reductions cut into 2 and 16 chunks (partial tiles through the
+    workspace + the ordered reduction launch) -- dW and the bias row sums, accumulating and not, against torch fp32 and the 4-wave
+    kernels; a group of all problems gives the bits of one launch per problem; repeated launches agree bit for bit."""
+    res = []
+    dtype = torch.bfloat16
+    L = K._lib.lib()
+    prev = L.s2svc_gemm_set_w8(-1, 0)
+    shapes = [(2016, 384, 384), (2016, 384, 1152), (2016, 1536, 384), (2048, 384, 1536), (2016, 7296, 384), (2048, 384, 320),
+              (777, 72, 200), (100, 8, 8), (63, 320, 256), (4096, 384, 1536), (4160, 256, 136), (40000, 128, 264)]
+    try:
+        L.s2svc_gemm_set_w8(1, 32)
+        probs = []
+        for i, (rows, fin, fout) in enumerate(shapes):
+            x, dy = rnd(rows, fin, seed=300 + i, dtype=dtype), rnd(rows, fout, seed=330 + i, dtype=dtype)
+            probs.append((x, dy, rnd(fout, fin, seed=360 + i), rnd(fout, seed=390 + i)))
+
+        def descs_for(outs, accumulate):
+            ds = []
+            for (x, dy, _, _), (dw, db) in zip(probs, outs):
+                K.gemm(K.operand(dy, dy.shape[1], layout=K.RC), K.operand(x, x.shape[1], layout=K.RC), dy.shape[1], x.shape[1], x.shape[0], dw,
+                       in_dtype=dtype, accumulate=accumulate, group=ds)
+                ds[-1].a_rowsum, ds[-1].a_rowsum_accumulate = db.data_ptr(), 1 if accumulate else 0
+            return ds
+
+        takes = [bool(L.s2svc_gemm_wgrad_ok(K.ctypes.addressof(d))) for d in descs_for([(p[2], p[3]) for p in probs], True)]
+        res.append((all(takes), f"W8 takes all {len(shapes)} shapes: {takes}"))
+        for accumulate in (True, False):
+            outs = [(p[2].clone(), p[3].clone()) if accumulate else (torch.full_like(p[2], float("nan")), torch.full_like(p[3], float("nan")))
+                    for p in probs]
+            K.launch_wgrad_group(descs_for(outs, accumulate))                      # one group
+            singles = [(p[2].clone(), p[3].clone()) if accumulate else (torch.full_like(p[2], float("nan")), torch.full_like(p[3], float("nan")))
+                       for p in probs]
+            for d in descs_for(singles, accumulate):                               # one launch per problem
+                K.launch_wgrad_group([d])
+            for (rows, fin, fout), (x, dy, dw0, db0), (dw, db), (dw1, db1) in zip(shapes, probs, outs, singles):
+                ref_w, ref_b = dy.float().t() @ x.float(), dy.float().sum(0)
+                if accumulate:
+                    ref_w, ref_b = ref_w + dw0, ref_b + db0
+                sc, scb = float(ref_w.abs().max()), float(ref_b.abs().max())
+                tag = f"W8 wgrad {fout}x{fin}x{rows} {'(+=)' if accumulate else '(=)'}"
+                res.append(check(tag + " dW", dw, ref_w, torch.float32, rtol=1e-3, atol=3e-4 * sc))
+                res.append(check(tag + " db", db, ref_b, torch.float32, rtol=1e-3, atol=3e-4 * scb))
+                res.append((bool(torch.equal(dw, dw1) and torch.equal(db, db1)), tag + ": the grouped launch gives the bits of the single launch"))
+        # against the 4-wave grouped kernel (the path these problems took until round 3) through the training-time queue
+        results = {}
+        for on in (0, 1):
+            L.s2svc_gemm_set_w8(on, 0)
+            outs = [(p[2].clone(), p[3].clone()) for p in probs]
+            queue = []
+            with K.record_grouped(queue):
+                for (x, dy, _, _), (dw, db) in zip(probs, outs):
+                    K.gemm(K.operand(dy, dy.shape[1], layout=K.RC), K.operand(x, x.shape[1], layout=K.RC), dy.shape[1], x.shape[1], x.shape[0], dw,
+                           in_dtype=dtype, accumulate=True, a_rowsum=db, a_rowsum_accumulate=True)
+            nq = len(queue)
+            K.flush_grouped(queue)
+            results[on] = outs
+        res.append((nq >= len(shapes) - 2, f"W8: {nq} of {len(shapes)} problems were queued for the grouped launch"))
+        worst = 0.0
+        for (dw_a, db_a), (dw_b, db_b), p in zip(results[0], results[1], probs):
+            sc = float((dw_a - p[2]).abs().max()) + 1e-6
+            worst = max(worst, float((dw_a - dw_b).abs().max()) / sc, float((db_a - db_b).abs().max()) / (float((db_a - p[3]).abs().max()) + 1e-6))
+        res.append((worst <= 1e-3, f"W8 vs the 4-wave grouped kernel through flush_grouped: largest relative difference {worst:.3e} (<= 1e-3)"))
+        L.s2svc_gemm_set_w8(1, 0)
+        bad = 0
+        for _ in range(10):
+            outs = [(p[2].clone(), p[3].clone()) for p in probs]
+            K.launch_wgrad_group(descs_for(outs, True))
+            bad += sum(0 if (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])) else 1 for a, b in zip(outs, results[1]))
+        res.append((bad == 0, f"W8: {bad} outputs of 10 repeated grouped launches differ from the first"))
+        # chunk length 8: every VTN reduction is cut into 4 chunks -- same values within fp32 rounding of a different summation order
+        L.s2svc_gemm_set_w8(1, 8)
+        outs = [(p[2].clone(), p[3].clone()) for p in probs]
+        K.launch_wgrad_group(descs_for(outs, True))
+        worst = max(float((a[0] - b[0]).abs().max()) / (float((b[0] - p[2]).abs().max()) + 1e-6) for a, b, p in zip(outs, results[1], probs))
+        res.append((worst <= 1e-4, f"W8 with 8-tile chunks vs 32-tile chunks: largest relative difference {worst:.3e} (<= 1e-4)"))
+    finally:
+        L.s2svc_gemm_set_w8(prev & 1, prev >> 8)
+    return res
+
+
+@case
 def bn_two_launch_statistics():
     """s2svc_bn_stats (the second reduction stage folded into the finalisation: 2 launches instead of 3) against the
     three-launch composition it replaces -- colreduce(mode 6) + bn_finalize -- incl. the running statistics, and against

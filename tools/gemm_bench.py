@@ -186,6 +186,34 @@ def main():
                   f"{100 * gf / us / 1e6 / PEAK[dtype]:6.1f}")
         K._GROUP_MAX_TILES = saved
         L.s2svc_gemm_set_8ph(prev)
+    # VTN weight gradients as training launches them: the dense problems of two encoder layers (8) / one decoder layer + the stacked
+    # K|V projection (7) as ONE grouped launch -- the 4-wave 64 x 64 kernel (until round 3) against the ragged 8-wave kernel (W8)
+    if (not a.filter or a.filter in "vtn wgrad grouped w8") and dtype == torch.bfloat16:
+        L = K._lib.lib()
+        prev = L.s2svc_gemm_set_w8(-1, 0)
+        groups = {"2 encoder layers (8 problems, K 2016)": [(2016, 384, 1152), (2016, 384, 384), (2016, 384, 1536), (2016, 1536, 384)] * 2,
+                  "decoder layer + stacked K|V (8 problems, K 2048)": [(2048, 384, 1152), (2048, 384, 384), (2048, 384, 384), (2048, 384, 384),
+                                                                       (2048, 384, 1536), (2048, 1536, 384), (2016, 384, 4608)],
+                  "embed 7296->384 alone": [(2016, 7296, 384)],
+                  "aas encoder layer (K 4096)": [(4096, 384, 1152), (4096, 384, 384), (4096, 384, 1536), (4096, 1536, 384), (4096, 384, 1536),
+                                                 (4096, 1536, 384), (4096, 384, 768), (4096, 384, 384)]}
+        for gname, shapes in groups.items():
+            probs = [(rnd(rows, fin), rnd(rows, fout), torch.zeros(fout, fin, device=dev), torch.zeros(fout, device=dev)) for rows, fin, fout in shapes]
+            gf = sum(2.0 * x.shape[0] * x.shape[1] * dy.shape[1] for x, dy, _, _ in probs)
+
+            def grouped():
+                q = []
+                with K.record_grouped(q):
+                    for x, dy, dw, db in probs:
+                        K.gemm(K.operand(dy, dy.shape[1], layout=K.RC), K.operand(x, x.shape[1], layout=K.RC), dy.shape[1], x.shape[1], x.shape[0],
+                               dw, in_dtype=dtype, accumulate=True, a_rowsum=db, a_rowsum_accumulate=True)
+                K.flush_grouped(q)
+            for on, kt, nm in ((0, 0, "4-wave 64x64"), (1, 64, "W8 unsplit"), (1, 32, "W8 32-tile chunks"), (1, 16, "W8 16-tile chunks"), (1, 8, "W8 8-tile chunks")):
+                L.s2svc_gemm_set_w8(on, kt)
+                us = bench(grouped, a.iters)
+                tot += us
+                print(f"{'wgrad ' + gname + ', ' + nm:90s} {us:9.1f} {gf / us / 1e6:9.1f} {100 * gf / us / 1e6 / PEAK[dtype]:6.1f}")
+        L.s2svc_gemm_set_w8(prev & 1, prev >> 8)
     # postnet Conv1d k5 256->256 as implicit GEMM (B32 T256)
     if not a.filter or a.filter in "conv1d":
         B, T, Cin, Cout, ks = 32, 256, 256, 256, 5
