@@ -382,6 +382,7 @@ def side_join():
             main.wait_stream(st)
     _join_branch_stream()
     K.bg_join()                      # background weight gradients (ops.kernels.set_wgrad_background)
+    K.audit_reset()                  # (writer audit, ops.kernels._Audit: a join -- every slot may change hands)
     _Side.pending.clear()
     _Side.idx = 0
 

@@ -129,6 +129,51 @@ def pick_splitk(M, N, K, nbatch=1):
     return plan_gemm(M, N, K, nbatch)[1]
 
 
+# ----------------------------------------------------------------------------------------------
+# Writer audit (S2SVC_AUDIT_SLOTS=1 / audit_slots(True); tests).  Gradient slots are accumulated into by several kernels of a
+# backward pass (weight-gradient GEMMs, fused bias row sums, column reductions) that run on the issuing stream, on side streams
+# or as background launches.  Two accumulating writers of ONE slot on DIFFERENT streams with no wait between them are a race that
+# eager launches hide (the GPU happens to keep issue order) and a captured graph exposes (only edges order its branches) --
+# the signature of round 3's "second side stream" experiment, whose gradient norm moved under capture only.  With the audit on,
+# every accumulating launch records (slot pointer -> stream); a second writer from another stream raises unless a join
+# (ops.functional.side_join / bg_wait on that slot) came in between.
+# ----------------------------------------------------------------------------------------------
+class _Audit:
+    on = os.environ.get("S2SVC_AUDIT_SLOTS", "0") == "1"
+    writers = {}          # slot pointer -> (stream handle, what)
+    checked = 0
+
+
+def audit_slots(on=True):
+    _Audit.on = bool(on)
+    _Audit.writers = {}
+    _Audit.checked = 0
+
+
+def audit_reset(ptrs=None):
+    """A join: every slot (or the listed ones) may be written from any stream again."""
+    if ptrs is None:
+        _Audit.writers = {}
+    else:
+        for p in ptrs:
+            _Audit.writers.pop(p, None)
+
+
+def _audit_write(what, *ptrs, st=None):
+    if not _Audit.on:
+        return
+    st = stream() if st is None else st
+    for p in ptrs:
+        if not p:
+            continue
+        _Audit.checked += 1
+        prev = _Audit.writers.get(p)
+        if prev is not None and prev[0] != st:
+            raise RuntimeError(f"gradient-slot race: {what} accumulates into {p:#x} on stream {st:#x} while {prev[1]} wrote it on "
+                               f"stream {prev[0]:#x} with no join in between")
+        _Audit.writers[p] = (st, what)
+
+
 def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
          ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False, a_rowsum=None,
          a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0), c_map=None, group=None, pre_out=None,
@@ -213,6 +258,8 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         raise TypeError("gemm residual must have the output dtype")
     if _BG.dirty:
         bg_wait(d.C, d.a_rowsum)
+    if _Audit.on and (accumulate or a_rowsum_accumulate):
+        _audit_write("gemm", d.C if accumulate else None, d.a_rowsum if a_rowsum_accumulate else None)
     _lib.check(_lib.lib().s2svc_gemm(ctypes.byref(d), stream()), "s2svc_gemm")
     return out
 
@@ -282,6 +329,8 @@ def flush_colreduce(queue):
         pending = rest
         arr = (_lib.ColreduceItem * len(group))(*[g[0] for g in group])
         bg_wait(*[g[0].out_sum for g in group], *[g[0].out_dot for g in group])
+        if _Audit.on:
+            _audit_write("grouped column reduction", *[g[0].out_sum for g in group], *[g[0].out_dot for g in group])
         _lib.check(_lib.lib().s2svc_colreduce_grouped(ctypes.addressof(arr), len(group), stream()), "s2svc_colreduce_grouped")
 
 
@@ -331,6 +380,8 @@ def bg_wait(*ptrs):
     """The current stream is about to write `ptrs` (gradient slots): wait for a background launch that writes them too."""
     if _BG.dirty and any(p in _BG.keys for p in ptrs if p):
         torch.cuda.current_stream().wait_stream(_BG.stream)
+        if _Audit.on:
+            audit_reset([p for p in ptrs if p])
 
 
 def bg_join():
@@ -403,6 +454,8 @@ def flush_grouped(queue):
         if w8:
             group = [d for d in group if not any(d is w for w in w8)]
             bg_wait(*[d.C for d in w8], *[d.a_rowsum for d in w8])
+            if _Audit.on:
+                _audit_write("grouped weight gradient (W8)", *[d.C for d in w8], *[d.a_rowsum for d in w8])
             launch_wgrad_group(w8)
         # big outputs (>= _GROUP_BIG_TILES 128x128 tiles each) share launches of 128x128 tiles, the rest of 64x64 tiles
         big = [d for d in group if _GROUP_TILE == 64 and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= _GROUP_BIG_TILES]
@@ -412,6 +465,11 @@ def flush_grouped(queue):
                 arr = (_lib.GemmDesc * len(part))(*part)
                 cand = _bg_candidates(part) if (_BG.cus > 0 and _BG.count < _BG.max_launches) else []
                 bg_wait(*[d.C for d in part], *[d.a_rowsum for d in part])
+                if _Audit.on:       # (a background launch writes its slots on the background stream: recorded under that stream)
+                    cand_ids = {id(d) for d in cand}
+                    for d in part:
+                        bgst = _bg_stream(torch.cuda.current_stream()).cuda_stream if id(d) in cand_ids else None
+                        _audit_write("grouped weight gradient", d.C, d.a_rowsum, st=bgst)
                 if cand:
                     cur = torch.cuda.current_stream()
                     bg = _bg_stream(cur)
@@ -481,6 +539,8 @@ def colreduce(mode, dy, x=None, mean=None, rstd=None, scale=1.0, want_dot=False,
     if out_dot is None and want_dot:
         out_dot = torch.empty(D, dtype=torch.float32, device=t.device)
     ws = torch.empty(_WS_CHUNKS * 2 * D, dtype=torch.float32, device=t.device)
+    if _Audit.on and accumulate:
+        _audit_write("column reduction", ptr(out_sum), ptr(out_dot))
     _lib.check(_lib.lib().s2svc_colreduce(dt(t), rows, D, mode, ptr(dy), ptr(x), ptr(mean), ptr(rstd), scale, ptr(out_sum),
                                           ptr(out_dot), 1 if accumulate else 0, ptr(ws), _WS_CHUNKS, stream()), "colreduce")
     return out_sum, out_dot

@@ -490,6 +490,74 @@ def training_steps_equivalence_fp32():
 
 
 @case
+def gradient_slot_writers_audit():
+    """Every accumulating write into a flat-gradient slot (weight-gradient GEMMs, fused bias row sums, column reductions) between two
+    joins comes from ONE stream (ops.kernels._Audit): the VTN vc1 step with 4 side streams, the AAS-VC vc2 step with inline batches +
+    background weight-gradient launches, the staged (data-parallel) backward pass of both -- bf16, full size, eager launches (the
+    audit is host-side bookkeeping of what is launched where; a captured step launches the same sequence).  Two writers of one slot
+    on different streams with no wait between them are a race that only a captured graph exposes (round 3's removed second-side-
+    stream experiment moved the gradient norm under capture only)."""
+    import bench
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.distributed import OverlappedBackward
+    from seq2seq_vc_amd.optim import FlatAdam
+    from seq2seq_vc_amd.trainers import AASVCTrainer
+    from tools.bench_aasvc import AASVC_VC2
+    res = []
+    try:
+        Fn.set_compute_dtype(torch.bfloat16)
+        K.audit_slots(True)
+        for name in ("vtn", "aasvc"):
+            if name == "vtn":
+                Fn.enable_side_streams(4)
+                xs, ilens, ys, labels, olens = bench.canonical_batch(32)
+                torch.manual_seed(0)
+                model = M.VTN(**bench.VTN_VC1).to(DEV).train()
+            else:
+                Fn.enable_side_streams(0, inline_batches=True, wgrad_background=AASVCTrainer.WGRAD_BACKGROUND)
+                xs, ilens, ys, labels, olens = bench.canonical_batch(16)
+                torch.manual_seed(0)
+                model = M.AASVC(**AASVC_VC2).to(DEV).train()
+            opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=True)
+            for staged in (False, True):
+                K.manual_seed(1234)
+                K.reset_op_counter()
+                opt.zero_grad()
+                K._Audit.checked = 0
+                ob = OverlappedBackward(model, opt, None, 1, force=True) if staged else None
+                with (ob.forward_context() if staged else torch.enable_grad()):
+                    if name == "vtn":
+                        out = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+                        l1, bce = L.Seq2SeqLoss()(out[0], out[1], out[2], out[3], out[4], out[5])
+                        parts = {"loss": l1 + bce}
+                    else:
+                        ret = model(xs.to(DEV), ilens, ys.to(DEV), olens, xs.to(DEV), dp_lengths=ilens)
+                        l1 = L.L1Loss()(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+                        fs = L.ForwardSumLoss()(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+                        parts = {"decoder": l1, "align": 2.0 * (fs + ret["bin_loss"]) + torch.sum(ret["dur_nll"].float())}
+                try:
+                    if staged:
+                        ob.backward(parts, reduce=False, scale=1.0)
+                    else:
+                        sum(parts.values()).backward()
+                        Fn.side_join()
+                    torch.cuda.synchronize()
+                    res.append((K._Audit.checked > 50, f"{name} {'staged' if staged else 'one-shot'} backward: {K._Audit.checked} accumulating slot writes, "
+                                "each slot written from one stream between joins"))
+                except RuntimeError as e:
+                    res.append((False, f"{name} {'staged' if staged else 'one-shot'} backward: {e}"))
+                    Fn.side_join()
+            del opt, model
+            torch.cuda.empty_cache()
+    finally:
+        K.audit_slots(False)
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
 def vtn_full_size_properties():
     """BASELINE.json configs[1] itself (VTN vc1: 30.5 M parameters, 32 utterance pairs of 256 frames -- bench.py's
     workload): (a) fp32 forward losses vs the CPU oracle at full size; (b) bf16 forward+backward twice with the same seeds
