@@ -464,23 +464,6 @@ int s2svc_ln_act_bwd(int dtype, int rows, int D, int T, const void* dy, const vo
                      const float* gamma, const float* beta, int act, const int32_t* lens, float drop_p,
                      const uint64_t* seed_base, uint64_t seed_off, void* du, void* dx, void* dres, void* stream);
 
-/* One DilatedDepthSeparableConv LAYER (modules/vits/flow.py:148-190; 30 of them per NLL evaluation of the stochastic duration
-   predictor, modules/duration_predictor.py:211-304) as one launch per direction (csrc/dds.hip), fp32, channel-last rows:
-     fwd: y1 = depthwise dilated conv (k = 3) of x ; y2 = GELU(LayerNorm1(y1)) ; y3 = y2 . W^T + bias ;
-          out = mask * (x + dropout(GELU(LayerNorm2(y3))))            -- y1, y2, y3 and both row statistics are written
-     bwd: g = d out -> dres = mask * g ; du2 (gradient at LayerNorm2's output: its gamma / beta reductions read it) ; dy3 (gradient
-          at y3: the 1x1 weight / bias gradients read it) ; dy2 = dy3 . W (Wt = W^T, [in][out]) ; du1 ; dy1 (gradient at y1: the
-          depthwise convolution's data / weight gradients read it).
-   _supported: C in {192, 256, 384, 512}, kernel size 3.  x must be zero past each utterance (it is: every producer masks). */
-int s2svc_dds_layer_supported(int C, int ks);
-int s2svc_dds_layer_fwd(int B, int T, int C, int ks, int dil, const float* x, const int32_t* lens, const float* dw_w, const float* dw_b,
-                        const float* g1, const float* b1, const float* W, const float* bias, const float* g2, const float* b2, float eps,
-                        float drop_p, const uint64_t* seed_base, uint64_t seed_off, float* y1, float* mean1, float* rstd1, float* y2,
-                        float* y3, float* mean2, float* rstd2, float* out, void* stream);
-int s2svc_dds_layer_bwd(int B, int T, int C, const float* g, const int32_t* lens, const float* y3, const float* mean2, const float* rstd2,
-                        const float* g2, const float* b2, float drop_p, const uint64_t* seed_base, uint64_t seed_off, const float* Wt,
-                        const float* y1, const float* mean1, const float* rstd1, const float* g1, const float* b1, float* dres,
-                        float* du2, float* dy3, float* du1, float* dy1, void* stream);
 /* rational-quadratic spline coupling with linear tails; h (rows, 3*bins-1); lad accumulates when asked (transform.py:96-216) */
 int s2svc_rq_spline_fwd(int B, int T, int bins, const float* x, const float* h, float hscale, float bound, const int32_t* lens,
                         int inverse, float* out, float* lad, int lad_accumulate, void* stream);

@@ -187,11 +187,6 @@ _SIGS = {
     "s2svc_mask_rows": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_expand_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_expand_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "s2svc_dds_layer_supported": [c_i32, c_i32],
-    "s2svc_dds_layer_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32,
-                            c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "s2svc_dds_layer_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp,
-                            c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_ln_act_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp,
                          c_vp, c_vp],
     "s2svc_ln_act_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_u64, c_vp,

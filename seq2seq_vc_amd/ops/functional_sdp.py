@@ -15,8 +15,7 @@ from torch.autograd import Function
 
 from . import kernels as K
 from . import kernels_sdp as KS
-from . import kernels_aas as KA
-from .functional import _bias_sink, _c, _emit_vgrad, _emit_wgrad, _reduce_to, _side_run, _slotted
+from .functional import _c, _emit_vgrad, _reduce_to, _side_run, _slotted
 
 
 _QUEUE_LN = __import__("os").environ.get("S2SVC_SDP_UNGROUPED", "0") != "1"      # A/B switch (also sdp.py: residual pass-through)
@@ -111,103 +110,6 @@ class _LnAct(Function):
 
 def ln_act(x, gamma, beta, eps, act, res=None, lens=None, T=0, p=0.0):
     return _LnAct.apply(x, gamma, beta, eps, act, res, lens, T, p)
-
-
-_DDS_FUSED = __import__("os").environ.get("S2SVC_DDS_FUSED", "1") != "0"      # A/B switch: one launch per DDS layer and direction
-
-
-def dds_layer_ok(x, dw, pw):
-    """The fused layer kernels take it: fp32 rows on the GPU, kernel size 3, 192 / 256 / 384 / 512 channels, all parameters of the layer
-    either in flat-gradient slots or not (the gradient bookkeeping below is written for the two clean cases)."""
-    return (_DDS_FUSED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and dw.weight.shape[-1] == 3 and
-            KS.dds_layer_supported(x.shape[-1], dw.weight.shape[-1]))
-
-
-class _DDSLayer(Function):
-    """x -> mask * (x + dropout(gelu(LN2(conv1x1(gelu(LN1(dwconv_dilated(x)))))))): one DilatedDepthSeparableConv layer
-    (flow.py:148-190) on csrc/dds.hip -- 1 launch forward, 1 + the depthwise data gradient backward; the weight-gradient work
-    (1x1 weight + bias, the two LayerNorms' gamma / beta, the depthwise weight + bias) is queued off the chain exactly as the
-    separate ops queue theirs (_Linear / _LnAct / _DwConv), reading the tensors the fused kernels wrote."""
-
-    @staticmethod
-    def forward(ctx, x, dw_w, dw_b, g1, b1, pw_w, pw_b, g2, b2, eps, dil, lens, p):
-        x = _c(x)
-        C = x.shape[-1]
-        seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
-        W = pw_w.detach().reshape(C, C)
-        out, y1, mean1, rstd1, y2, y3, mean2, rstd2 = KS.dds_layer_fwd(
-            x, lens, dil, dw_w.detach().reshape(C, 3), None if dw_b is None else dw_b.detach(), g1.detach(), b1.detach(), W,
-            None if pw_b is None else pw_b.detach(), g2.detach(), b2.detach(), eps, p, seed)
-        ctx.params = (dw_w, dw_b, g1, b1, pw_w, pw_b, g2, b2)
-        ctx.meta = (dil, lens, p, seed)
-        ctx.save_for_backward(x, y1, mean1, rstd1, y2, y3, mean2, rstd2)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        x, y1, mean1, rstd1, y2, y3, mean2, rstd2 = ctx.saved_tensors
-        dw_w, dw_b, g1, b1, pw_w, pw_b, g2, b2 = ctx.params
-        dil, lens, p, seed = ctx.meta
-        B, T, C = x.shape
-        rows = B * T
-        # W^T for the data gradient: a cached copy the optimiser refreshes with the other derived weight copies (one grouped launch)
-        Wt = K.gather3_cached(pw_w, (1, C, C), (0, 1, C), 0, torch.float32).view(C, C)
-        dres, du2, dy3, du1, dy1 = KS.dds_layer_bwd(_c(g), lens, y3, mean2, rstd2, g2.detach(), b2.detach(), p, seed, Wt, y1, mean1, rstd1,
-                                                    g1.detach(), b1.detach())
-        # data gradient of the depthwise convolution + the residual path, one launch (dres rides in as `add`)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if KA.dwconv_add_ok(dy1, 3):
-                dx = KA.dwconv(dy1, dw_w.detach(), None, 3, dil, flip=True, add=dres)
-            else:
-                dx = KA.dwconv(dy1, dw_w.detach(), None, 3, dil, flip=True) + dres
-        grads = [None] * 8
-        # -- LayerNorm 2 / 1: gamma, beta = column reductions of du * xhat, du
-        for (gam, bet, du, xin, mean, rstd, gi) in ((g2, b2, du2, y3, mean2, rstd2, 6), (g1, b1, du1, y1, mean1, rstd1, 2)):
-            du_, x_ = du.view(rows, C), xin.view(rows, C)
-            if _slotted(gam, bet) and _QUEUE_LN:
-                _side_run(lambda bet=bet, gam=gam, du_=du_, x_=x_, mean=mean, rstd=rstd: _reduce_to(bet, gam, 1, du_, x_, mean, rstd),
-                          keep=(du_, x_, mean, rstd))
-            else:
-                dbeta, dgamma = _reduce_to(bet, gam, 1, du_, x_, mean, rstd)
-                grads[gi], grads[gi + 1] = dgamma, dbeta
-        # -- 1x1 convolution: dW (+)= dy3^T . y2, bias = row sums of dy3^T (fused into the weight-gradient GEMM)
-        dy3_, y2_ = dy3.view(rows, C), y2.view(rows, C)
-        if pw_w.requires_grad:
-            tile, sk = K.plan_gemm(C, C, rows)
-            rs, racc, db = _bias_sink(pw_b, C)
-
-            def wr(out, acc):
-                K.gemm(K.operand(dy3_, C, layout=K.RC), K.operand(y2_, C, layout=K.RC), C, C, rows, out, in_dtype=torch.float32, splitk=sk,
-                       tile=tile, accumulate=acc, a_rowsum=rs, a_rowsum_accumulate=racc)
-            if _slotted(pw_w, pw_b):
-                _side_run(lambda: _emit_wgrad(pw_w, (C, C), wr), keep=(dy3_, y2_))
-            else:
-                dw = _emit_wgrad(pw_w, (C, C), wr)
-                grads[4] = dw.view(pw_w.shape) if dw is not None else None
-                grads[5] = db
-        elif pw_b is not None and pw_b.requires_grad:
-            grads[5], _ = _reduce_to(pw_b, None, 0, dy3_)
-        # -- depthwise convolution: weight / bias gradients from (x, dy1), as _DwConv does
-        if dw_w.requires_grad:
-            slot = getattr(dw_w, "_s2s_grad", None)
-            if slot is not None and slot.is_contiguous():
-                KA.dwconv_wgrad(x, dy1, 3, dil, out=slot)
-            else:
-                grads[0] = _emit_vgrad(dw_w, KA.dwconv_wgrad(x, dy1, 3, dil))
-        if dw_b is not None and dw_b.requires_grad:
-            dy1_ = dy1.view(rows, C)
-            if _slotted(dw_b):
-                _side_run(lambda: _reduce_to(dw_b, None, 0, dy1_), keep=(dy1_,))
-            else:
-                grads[1], _ = _reduce_to(dw_b, None, 0, dy1_)
-        return (dx, *grads, None, None, None, None)
-
-
-def dds_layer(x, dw, ln1, pw, ln2, lens, p):
-    """One DDS layer on the fused kernels (modules: depthwise Conv1d, LayerNorm, 1x1 Conv1d, LayerNorm of the reference's Sequential)."""
-    return _DDSLayer.apply(x, dw.weight, dw.bias, ln1.weight, ln1.bias, pw.weight, pw.bias, ln2.weight, ln2.bias, ln1.eps, dw.dilation[0],
-                           lens, p)
 
 
 class _Spline(Function):

@@ -57,34 +57,6 @@ def ln_act_bwd(dy, x, mean, rstd, gamma, beta, act, lens=None, T=0, p=0.0, seed=
     return du, dx, dres
 
 
-def dds_layer_supported(C, ks):
-    return bool(_lib.lib().s2svc_dds_layer_supported(int(C), int(ks)))
-
-
-def dds_layer_fwd(x, lens, dil, dw_w, dw_b, g1, b1, W, bias, g2, b2, eps, p=0.0, seed=(None, 0)):
-    """One DilatedDepthSeparableConv layer forward (csrc/dds.hip) -> (out, y1, mean1, rstd1, y2, y3, mean2, rstd2)."""
-    _f32(x, dw_w, g1, b1, W, g2, b2)
-    B, T, C = x.shape
-    rows = B * T
-    y1, y2, y3, out = (torch.empty_like(x) for _ in range(4))
-    mean1, rstd1, mean2, rstd2 = (torch.empty(rows, dtype=torch.float32, device=x.device) for _ in range(4))
-    _lib.check(_lib.lib().s2svc_dds_layer_fwd(B, T, C, dw_w.shape[-1], dil, ptr(x), ptr(lens), ptr(dw_w), ptr(dw_b), ptr(g1), ptr(b1), ptr(W),
-                                              ptr(bias), ptr(g2), ptr(b2), eps, p, seed[0], seed[1], ptr(y1), ptr(mean1), ptr(rstd1), ptr(y2),
-                                              ptr(y3), ptr(mean2), ptr(rstd2), ptr(out), stream()), "dds_layer_fwd")
-    return out, y1, mean1, rstd1, y2, y3, mean2, rstd2
-
-
-def dds_layer_bwd(g, lens, y3, mean2, rstd2, g2, b2, p, seed, Wt, y1, mean1, rstd1, g1, b1):
-    """-> (dres, du2, dy3, du1, dy1), see include/s2svc_hip.h."""
-    _f32(g, y3, Wt, y1)
-    B, T, C = g.shape
-    dres, du2, dy3, du1, dy1 = (torch.empty_like(g) for _ in range(5))
-    _lib.check(_lib.lib().s2svc_dds_layer_bwd(B, T, C, ptr(g), ptr(lens), ptr(y3), ptr(mean2), ptr(rstd2), ptr(g2), ptr(b2), p, seed[0], seed[1],
-                                              ptr(Wt), ptr(y1), ptr(mean1), ptr(rstd1), ptr(g1), ptr(b1), ptr(dres), ptr(du2), ptr(dy3),
-                                              ptr(du1), ptr(dy1), stream()), "dds_layer_bwd")
-    return dres, du2, dy3, du1, dy1
-
-
 def rq_spline_fwd(x, h, hscale, bound, lens, inverse=False, lad=None, accumulate=False):
     """x (B,T), h (B,T,3*bins-1) fp32 -> (out (B,T), lad (B,T)); `lad` may be a running buffer (accumulate=True)."""
     _f32(x, h, lad)

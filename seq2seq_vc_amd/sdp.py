@@ -92,9 +92,6 @@ class DilatedDepthSeparableConv(nn.Module):
         p = self.dropout_rate if self.training else 0.0
         for blk in self.convs:
             dw, ln1, pw, ln2 = blk[0], blk[2], blk[5], blk[7]
-            if ln1.eps == ln2.eps and FS.dds_layer_ok(x, dw, pw):           # one launch per layer and direction (csrc/dds.hip)
-                x = FS.dds_layer(x, dw, ln1, pw, ln2, lens, p)
-                continue
             if FS._QUEUE_LN:
                 y, xr = FA.dwconv1d_pass(x, dw.weight, dw.bias, dilation=dw.dilation[0])      # xr = x for the residual (one consumer of x)
             else:

@@ -471,8 +471,19 @@ def sdp_module_vs_oracle():
     from seq2seq_vc_amd import modules as Mo
     from seq2seq_vc_amd.sdp import StochasticDurationPredictor
     res = []
+    for C in (32, 192):                   # two widths: NV = 1 / 3 channel groups per lane in the row kernels
+        res += _sdp_module_vs_oracle(C)
+    return res
+
+
+def _sdp_module_vs_oracle(C):
+    from oracle import models as OM
+    from oracle.nets import P, Runtime
+    from seq2seq_vc_amd import modules as Mo
+    from seq2seq_vc_amd.sdp import StochasticDurationPredictor
+    res = []
     torch.manual_seed(11)
-    C, B, T = 32, 3, 23
+    B, T = 3, 23
     sdp = StochasticDurationPredictor(channels=C, kernel_size=3, dropout_rate=0.5, flows=4, dds_conv_layers=3)
     with torch.no_grad():                                   # zero-initialised pieces would hide the spline / affine paths
         for n, p in sdp.named_parameters():
@@ -502,7 +513,7 @@ def sdp_module_vs_oracle():
     sdp.noise = noise.clone()
     nll = sdp.forward_cl(x.to(DEV), lens, w=w.to(DEV))
     (nll * gout.to(DEV)).sum().backward()
-    res.append(check("sdp nll", nll, nll_ref.detach(), torch.float32, atol=2e-3, rtol=2e-4))
+    res.append(check(f"sdp C={C} nll", nll, nll_ref.detach(), torch.float32, atol=2e-3, rtol=2e-4))
     nbad, worst = 0, (0.0, "")
     for k, p in sdp.named_parameters():
         r = sd[k].grad
@@ -510,30 +521,30 @@ def sdp_module_vs_oracle():
             r = torch.zeros_like(sd[k])
         if p.grad is None:
             nbad += 1
-            res.append((False, f"sdp grad {k}: missing"))
+            res.append((False, f"sdp C={C} grad {k}: missing"))
             continue
         err = (p.grad.cpu() - r).abs().max().item()
         bound = 2e-4 + 2e-3 * r.abs().max().item()
         if err > bound:
             nbad += 1
             if nbad <= 8:
-                res.append((False, f"sdp grad {k}: max_err={err:.3e} ref_max={r.abs().max():.3e}"))
+                res.append((False, f"sdp C={C} grad {k}: max_err={err:.3e} ref_max={r.abs().max():.3e}"))
         rel = err / (r.abs().max().item() + 1e-9)
         if rel > worst[0]:
             worst = (rel, k)
-    res.append((nbad == 0, f"sdp parameter grads: {nbad} of {len(names)} off; worst rel err {worst[0]:.3e} at {worst[1]}"))
+    res.append((nbad == 0, f"sdp C={C} parameter grads: {nbad} of {len(names)} off; worst rel err {worst[0]:.3e} at {worst[1]}"))
     # reference-signature adapter gives the same numbers
     sdp.noise = noise.clone()
     with torch.no_grad():
         nll2 = sdp(x.to(DEV).transpose(1, 2), mask.to(DEV), w=w.to(DEV)[:, None])
-    res.append(check("sdp reference-signature adapter", nll2, nll.detach(), torch.float32, atol=0.0, rtol=0.0))
+    res.append(check(f"sdp C={C} reference-signature adapter", nll2, nll.detach(), torch.float32, atol=0.0, rtol=0.0))
     # inverse pass (durations)
     with torch.no_grad():
         d_ref = OM.sdp_inverse(P({k: v.detach() for k, v in sd.items()}), x.transpose(1, 2), mask, noise, Runtime(False, False), 0.8)
     sdp.noise = noise.clone()
     d = sdp.forward_cl(x.to(DEV), lens, inverse=True, noise_scale=0.8)
     same = (d.cpu() == d_ref[:, 0]).float().mean().item()
-    res.append((same >= 0.98, f"sdp inverse durations: {same * 100:.1f}% identical (ceil() may flip on 1-ulp differences)"))
+    res.append((same >= 0.98, f"sdp C={C} inverse durations: {same * 100:.1f}% identical (ceil() may flip on 1-ulp differences)"))
     return res
 
 
