@@ -881,11 +881,11 @@ static_assert(sizeof(w8_args) <= 4096, "kernel arguments are limited to 4 KB");
 
 // one unit = 2 DMA instructions of this wave; a lane reads the zero block unless its rows (ok[e]) and its k row (kin[e] < klim) exist
 __device__ __forceinline__ void w8_issue(const char* base, const uint32_t (&off)[2], const bool (&ok)[2], const int (&kin)[2], int klim,
-                                         char* lds_unit, int wave) {
+                                         char* lds_unit, int wave, const uint32_t (&px)[2]) {
   const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    const char* src = (ok[e] && kin[e] < klim) ? base + off[e] : z;
+    const char* src = (ok[e] && kin[e] < klim) ? base + (uint32_t)(off[e] + px[e]) : z;
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_unit + (wave * 2 + e) * 1024), 16, 0, 0);
   }
 }
@@ -982,12 +982,14 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
     //   phase 2 of tile t: MFMA rows m1 (fa1 x fb) | fetch fa0, fb' <- A.m0, B of t+1 | DMA A.m1(t+2) -> cur         | wait A.m1 of t+1
     // RAW: a unit is fetched one phase after the phase whose vmcnt wait + barrier retired it.  WAR: a unit is re-filled one phase
     // after the phase that fetched it (its lgkmcnt(0) + barrier retired the reads of every wave).
-    w8_issue(Ab, offA[0], okA[0], W8_KOK(0), smem + 0 * UNIT, wave);
-    w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave);
-    w8_issue(Ab, offA[1], okA[1], W8_KOK(0), smem + 1 * UNIT, wave);
-    w8_issue(Ab + stepA, offA[0], okA[0], W8_KOK(1), smem + BUF + 0 * UNIT, wave);
-    w8_issue(Bb + stepB, offB, okB, W8_KOK(1), smem + BUF + 2 * UNIT, wave);
-    w8_issue(Ab + stepA, offA[1], okA[1], W8_KOK(1), smem + BUF + 1 * UNIT, wave);
+    const uint32_t px0[2] = {0u, 0u};
+#define W8_ISSUE_A(T, H, DST) w8_issue(Ab + (int64_t)(T) * stepA, offA[H], okA[H], W8_KOK(T), DST, wave, px0)
+    W8_ISSUE_A(0, 0, smem + 0 * UNIT);
+    w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave, px0);
+    W8_ISSUE_A(0, 1, smem + 1 * UNIT);
+    W8_ISSUE_A(1, 0, smem + BUF + 0 * UNIT);
+    w8_issue(Bb + stepB, offB, okB, W8_KOK(1), smem + BUF + 2 * UNIT, wave, px0);
+    W8_ISSUE_A(1, 1, smem + BUF + 1 * UNIT);
     p8_wait_vmcnt<6>();                // tile 0 has landed
     __builtin_amdgcn_s_barrier();
     bf16x8_t fa0[4][2], fa1[4][2], fbX[2][2], fbY[2][2];
@@ -1004,8 +1006,8 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
       char* oth = smem + (((t) & 1) ^ 1) * BUF;                                                                                   \
       const int mine = (wc - 2 * (t)) & 3;              /* row-sum pair (t, ks) belongs to wave column (2 t + ks) % 4 */          \
       if (live1) p8_read_tr<4>(cur + 1 * UNIT, foA, fa1);                                                                         \
-      w8_issue(Ab + (int64_t)((t) + 2) * stepA, offA[0], okA[0], W8_KOK((t) + 2), cur + 0 * UNIT, wave);                          \
-      w8_issue(Bb + (int64_t)((t) + 2) * stepB, offB, okB, W8_KOK((t) + 2), cur + 2 * UNIT, wave);                                \
+      W8_ISSUE_A((t) + 2, 0, cur + 0 * UNIT);                                                                                     \
+      w8_issue(Bb + (int64_t)((t) + 2) * stepB, offB, okB, W8_KOK((t) + 2), cur + 2 * UNIT, wave, px0);                           \
       __builtin_amdgcn_sched_barrier(0);                                                                                          \
       if (live0) {                                                                                                                \
         p8_mfma<4, 2>(fa0, FBU, acc[0]);                                                                                          \
@@ -1024,7 +1026,7 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
         p8_read_tr<2>(oth + 2 * UNIT, foB, FBL);                                                                                  \
         p8_read_tr<4>(oth + 0 * UNIT, foA, fa0);                                                                                  \
       }                                                                                                                           \
-      w8_issue(Ab + (int64_t)((t) + 2) * stepA, offA[1], okA[1], W8_KOK((t) + 2), cur + 1 * UNIT, wave);                          \
+      W8_ISSUE_A((t) + 2, 1, cur + 1 * UNIT);                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                                          \
       if (live1) {                                                                                                                \
         p8_mfma<4, 2>(fa1, FBU, acc[1]);                                                                                          \
@@ -1045,12 +1047,14 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
       if (t + 1 < nt) W8_KTILE(t + 1, fbY, fbX);
     }
 #undef W8_KTILE
+#undef W8_ISSUE_A
   } else {
-  w8_issue(Ab, offA[0], okA[0], W8_KOK(0), smem + 0 * UNIT, wave);
-  w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave);
-  w8_issue(Ab, offA[1], okA[1], W8_KOK(0), smem + 1 * UNIT, wave);
-  w8_issue(Ab + stepA, offA[0], okA[0], W8_KOK(1), smem + BUF + 0 * UNIT, wave);
-  w8_issue(Bb + stepB, offB, okB, W8_KOK(1), smem + BUF + 2 * UNIT, wave);
+    const uint32_t px0[2] = {0u, 0u};
+  w8_issue(Ab, offA[0], okA[0], W8_KOK(0), smem + 0 * UNIT, wave, px0);
+  w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave, px0);
+  w8_issue(Ab, offA[1], okA[1], W8_KOK(0), smem + 1 * UNIT, wave, px0);
+  w8_issue(Ab + stepA, offA[0], okA[0], W8_KOK(1), smem + BUF + 0 * UNIT, wave, px0);
+  w8_issue(Bb + stepB, offB, okB, W8_KOK(1), smem + BUF + 2 * UNIT, wave, px0);
   p8_wait_vmcnt<4>();                  // tile 0 has landed (A.m0, B of tile 1 may still be moving)
   __builtin_amdgcn_s_barrier();
   if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
@@ -1065,7 +1069,7 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
       p8_read_tr<2>(cur + 2 * UNIT, foB, fb);
       p8_read_tr<4>(cur + 0 * UNIT, foA, fa);
     }
-    w8_issue(Ab + (int64_t)(t + 1) * stepA, offA[1], okA[1], W8_KOK(t + 1), oth + 1 * UNIT, wave);      // A.m1 of tile t + 1
+    w8_issue(Ab + (int64_t)(t + 1) * stepA, offA[1], okA[1], W8_KOK(t + 1), oth + 1 * UNIT, wave, px0);      // A.m1 of tile t + 1
     p8_wait_vmcnt<6>();                                                                               // A.m1 of tile t has landed
     P8_PHASE_SYNC_IN();
     if (live0) {
@@ -1078,8 +1082,8 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
     P8_PHASE_SYNC_OUT();
     // ---- phase 2: rows m1
     if (live1) p8_read_tr<4>(cur + 1 * UNIT, foA, fa);
-    w8_issue(Ab + (int64_t)(t + 2) * stepA, offA[0], okA[0], W8_KOK(t + 2), cur + 0 * UNIT, wave);      // A.m0 of tile t + 2
-    w8_issue(Bb + (int64_t)(t + 2) * stepB, offB, okB, W8_KOK(t + 2), cur + 2 * UNIT, wave);            // B of tile t + 2
+    w8_issue(Ab + (int64_t)(t + 2) * stepA, offA[0], okA[0], W8_KOK(t + 2), cur + 0 * UNIT, wave, px0);      // A.m0 of tile t + 2
+    w8_issue(Bb + (int64_t)(t + 2) * stepB, offB, okB, W8_KOK(t + 2), cur + 2 * UNIT, wave, px0);            // B of tile t + 2
     p8_wait_vmcnt<6>();                                                                               // A.m0, B of tile t + 1 have landed
     P8_PHASE_SYNC_IN();
     if (live1) {

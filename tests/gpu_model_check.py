@@ -1762,6 +1762,28 @@ def aasvc_full_size_grads():
     return res
 
 
+TTS_V1 = dict(idim=78, odim=80, dprenet_layers=2, dprenet_units=256, adim=384, aheads=4, elayers=6, eunits=1536, dlayers=6,
+              dunits=1536, postnet_layers=5, postnet_filts=5, postnet_chans=256, use_batch_norm=True,
+              encoder_normalize_before=True, decoder_normalize_before=False, encoder_concat_after=False,
+              decoder_concat_after=False, decoder_reduction_factor=2)   # egs/ljspeech/tts1/conf/transformer_tts.v1.yaml:23-42
+
+
+def canonical_tts_batch(B, seed=1234):
+    """ilens in [60,150] int tokens in [1,77) padded with 0, olens in [300,640], ys randn(B,640,80)."""
+    g = torch.Generator().manual_seed(seed)
+    ilens = torch.randint(60, 151, (B,), generator=g)
+    ilens[0] = 150
+    olens = torch.randint(300, 641, (B,), generator=g)
+    olens[0] = 640
+    xs = torch.randint(1, 77, (B, 150), generator=g)
+    ys = torch.randn(B, 640, 80, generator=g)
+    xs[torch.arange(150)[None] >= ilens[:, None]] = 0
+    ar = torch.arange(640)[None]
+    ys[ar >= olens[:, None]] = 0.0
+    labels = (ar >= (olens[:, None] - 1)).float()
+    return xs, ilens, ys, labels, olens
+
+
 @case
 def tts_full_size_c4():
     """BASELINE configs[3]: TransformerTTS at the tts1 recipe size (egs/ljspeech/tts1/conf/transformer_tts.v1.yaml:23-42,
