@@ -1130,6 +1130,200 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// LOADER-SPECIALISED W8 tile (round 4, "LS"): 12 waves -- 8 CONSUMER waves (the 2 x 4 wave grid of the 256 x 128 tile: fragment
+// reads + MFMAs, nothing else) and 4 LOADER waves (one per SIMD: all LDS-DMA instructions, the address masks, the counted vmcnt
+// waits) over a ring of THREE K-tile stages (144 KB) with ONE s_barrier per K tile.
+// Why: timing builds of the 8-wave kernel with one of {MFMA, fragment reads, DMA} removed put the three at
+// 0.44 / 0.27 / 0.35 us per K tile above a 0.18 us loop floor, and all three together at 1.04 us -- nearly their sum: a wave that issues
+// its share of the DMAs (6 instructions of 60-185 cycles each: MI355X_MICROARCH.md, "LDS-DMA piece issue cost") and waits for
+// its reads is not issuing MFMAs, and the two barriers per phase keep all eight waves in that lock step.  With the DMA issue on
+// waves of their own the consumers' loop is [20 fragment reads, 32 MFMAs, barrier]; the loaders run a full K tile ahead.
+//   barrier B(t) (t = 0 .. nt): loaders arrive when THEIR share of tile t has landed (counted vmcnt: the 12 instructions of the tile
+//   issued last may still be in flight) -- so tile t is complete for every reader behind B(t); consumers arrive at B(t + 1) with
+//   every read of tile t retired (lgkmcnt(0)) -- so behind B(t + 1) the loaders may overwrite stage t % 3 with tile t + 3.
+// Same LDS image, fragment offsets, masks, chunking, row sums and epilogue as w8_tile: the results are bit-identical to it.
+// Measured (tools/_scratch sweep, one problem of 72-96 tiles): 0.83 us per K tile against 1.07 (8 waves, fragment prefetch) and 1.05
+// (p8_tr_tile); a variant with four sub-phases and the next sub-phase's fragments requested ahead of the MFMAs needs 12 registers
+// more than the 168 that three waves per SIMD allow (spills: slower with the row sums, +3 % without) -- not kept.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile_n, int chunk, char* smem) {
+  constexpr int UNIT = 16384, BUF = 3 * UNIT, NS = 3;    // A.m0 | A.m1 | B per stage
+  const int m0 = tile_m * 256, n0 = tile_n * 128;
+  const int ktiles = (q.K + 63) >> 6;
+  const int kt0 = chunk * q.kt_chunk;
+  const int nt = (ktiles - kt0 < q.kt_chunk) ? ktiles - kt0 : q.kt_chunk;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool do_rowsum = q.rowsum != nullptr && tile_n == 0;      // uniform
+  if (wave >= 8) {
+    // ================= loader =================
+    const int lw = wave - 8;
+    const int64_t stepA = (int64_t)q.lda * 128, stepB = (int64_t)q.ldb * 128;
+    const char* Ab = reinterpret_cast<const char*>(q.A) + (int64_t)kt0 * stepA;
+    const char* Bb = reinterpret_cast<const char*>(q.B) + (int64_t)kt0 * stepB;
+    const int krem = q.K - kt0 * 64;
+    int kin[4];
+    uint32_t offA[2][4], offB[4];
+    bool okA[2][4], okB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                        // pieces lw * 4 + i of every unit
+      int ur;
+      p8_tr_src(lw * 4 + i, lane, kin[i], ur);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = m0 + (ur >> 6) * 128 + h * 64 + (ur & 63);
+        okA[h][i] = row < q.M;
+        offA[h][i] = (uint32_t)(((int64_t)kin[i] * q.lda + row) * 2);
+      }
+      okB[i] = n0 + ur < q.N;
+      offB[i] = (uint32_t)(((int64_t)kin[i] * q.ldb + n0 + ur) * 2);
+    }
+    const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
+    // the 12 DMA instructions of this loader for chunk-relative K tile T into stage T % 3
+#define W8LS_ISSUE(T)                                                                                                         \
+    {                                                                                                                         \
+      const int tt_ = (T);                                                                                                    \
+      const int klim_ = (tt_ < nt) ? krem - tt_ * 64 : 0;                                                                     \
+      char* st_ = smem + (tt_ % NS) * BUF;                                                                                    \
+      const char* ab_ = Ab + (int64_t)tt_ * stepA;                                                                            \
+      const char* bb_ = Bb + (int64_t)tt_ * stepB;                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                         \
+        const bool kok_ = kin[i] < klim_;                                                                                     \
+        const char* s0_ = (okA[0][i] && kok_) ? ab_ + offA[0][i] : z;                                                         \
+        const char* s1_ = (okA[1][i] && kok_) ? ab_ + offA[1][i] : z;                                                         \
+        const char* s2_ = (okB[i] && kok_) ? bb_ + offB[i] : z;                                                               \
+        __builtin_amdgcn_global_load_lds((gbl_void*)s0_, (lds_void*)(st_ + 0 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds((gbl_void*)s1_, (lds_void*)(st_ + 1 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds((gbl_void*)s2_, (lds_void*)(st_ + 2 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
+      }                                                                                                                       \
+    }
+    W8LS_ISSUE(0);
+    W8LS_ISSUE(1);
+    p8_wait_vmcnt<12>();               // this loader's share of tile 0 has landed
+    __builtin_amdgcn_s_barrier();      // B(0)
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+      W8LS_ISSUE(t + 2);               // stage (t + 2) % 3 = (t - 1) % 3: every consumer retired its reads of tile t - 1 before B(t)
+      p8_wait_vmcnt<12>();             // tile t + 1 has landed
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();    // B(t + 1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef W8LS_ISSUE
+    p8_wait_vmcnt<0>();                // (the zero-block DMAs issued past the end)
+    __builtin_amdgcn_s_barrier();      // the consumers' barrier in front of the epilogue: the stages become C tiles
+    if (do_rowsum) __builtin_amdgcn_s_barrier();
+    return;
+  }
+  // ================= consumer =================
+  const int wr = wave >> 2, wc = wave & 3;
+  int foA[4], foB[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) foA[i] = p8_tr_frag_off(wr * 4 + i, lane);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) foB[j] = p8_tr_frag_off(wc * 2 + j, lane);
+  const bool liveN = (n0 + wc * 32 < q.N) || do_rowsum;
+  const bool live0 = liveN && (m0 + wr * 128 < q.M), live1 = liveN && (m0 + wr * 128 + 64 < q.M);
+  f32x4_t acc[2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  f32x4_t rs[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[a][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+  bf16x8_t fa[4][2], fb[2][2];
+  __builtin_amdgcn_s_barrier();        // B(0): tile 0 is complete
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    const char* st = smem + (t % NS) * BUF;
+    const int mine = (wc - 2 * t) & 3;                   // row-sum pair (t, ks) belongs to wave column (2 t + ks) % 4
+    if (live0) {
+      p8_read_tr<2>(st + 2 * UNIT, foB, fb);
+      p8_read_tr<4>(st + 0 * UNIT, foA, fa);
+      p8_wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      p8_mfma<4, 2>(fa, fb, acc[0]);
+      if (do_rowsum && mine < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[0][i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (live1) {
+      p8_read_tr<4>(st + 1 * UNIT, foA, fa);
+      p8_wait_lgkm0();
+      __builtin_amdgcn_sched_barrier(0);
+      p8_mfma<4, 2>(fa, fb, acc[1]);
+      if (do_rowsum && mine < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[1][i], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();      // B(t + 1): every read of tile t is retired (lgkmcnt(0) above); tile t + 1 is complete
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_s_barrier();        // (with the loaders' vmcnt(0)) the operand stages are dead: reuse them as fp32 C tiles
+  if (do_rowsum) {
+    float* part = reinterpret_cast<float*>(smem + 2 * BUF - 4096);         // [4 wc][256 rows], above the C tiles of the epilogue
+    const int lr = lane & 15, lg = lane >> 4;
+    if (lr == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[wc * 256 + wr * 128 + a * 64 + i * 16 + lg * 4 + r] = rs[a][i][r];
+    }
+    p8_wait_lgkm0();                                     // the partial sums are in LDS
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x < 256) {
+      const int m = m0 + (int)threadIdx.x;
+      if (m < q.M) {
+        const float v = ((part[threadIdx.x] + part[256 + threadIdx.x]) + part[512 + threadIdx.x]) + part[768 + threadIdx.x];
+        if (q.nchunks > 1) q.rs_ws[(int64_t)chunk * q.M + m] = v;
+        else q.rowsum[m] = ((q.flags & 2) ? q.rowsum[m] : 0.f) + v;
+      }
+    }
+  }
+  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+#pragma unroll 1
+  for (int a = 0; a < 2; ++a) {
+    if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
+    else epilogue_stage<64, 32>(acc[1], cs);
+    w8_flush(q, chunk, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
+  }
+}
+
+__global__ __launch_bounds__(768) void gemm_w8ls_kernel(const w8_args g) {
+  __shared__ __attribute__((aligned(1024))) char smem[3 * 3 * 16384];
+  int u = (int)blockIdx.x;
+  {
+    const int q8 = g.total >> 3, r8 = g.total & 7;       // XCD x gets the x-th contiguous run of units
+    const int xcd = u & 7, j = u >> 3;
+    u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+  }
+  int p = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.n; ++i) p += (g.unit_start[i] <= u) ? 1 : 0;
+  const w8_prob& q = g.p[p];
+  int r = u - g.unit_start[p];
+  const int per_chunk = q.tiles_m * q.tiles_n;
+  const int chunk = r / per_chunk;
+  r -= chunk * per_chunk;
+  const int tile_m = r / q.tiles_n;
+  w8ls_tile(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
+}
+
 // one workgroup per unit; gridDim.x = total units (or a cap: the workgroups then walk the units)
 template <bool STAGGER, bool PIPE>
 __global__ __launch_bounds__(512) void gemm_w8_kernel(const w8_args g) {
@@ -1509,7 +1703,9 @@ extern "C" int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs, int n, flo
     g.total = (int32_t)total;
     const unsigned wgs = (unsigned)((cap > 0 && total > cap) ? cap : total);
     static const bool pipe = !getenv_off("S2SVC_W8_PIPE");
-    if (pipe) hipLaunchKernelGGL((gemm_w8_kernel<false, true>), dim3(wgs), dim3(512), 0, st, g);
+    static const bool ls = !getenv_off("S2SVC_W8_LS");       // loader-specialised tile (12 waves): one workgroup per unit
+    if (ls && wgs == (unsigned)total) hipLaunchKernelGGL(gemm_w8ls_kernel, dim3(wgs), dim3(768), 0, st, g);
+    else if (pipe) hipLaunchKernelGGL((gemm_w8_kernel<false, true>), dim3(wgs), dim3(512), 0, st, g);
     else if (mode == 2) hipLaunchKernelGGL((gemm_w8_kernel<false, false>), dim3(wgs), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((gemm_w8_kernel<true, false>), dim3(wgs), dim3(512), 0, st, g);
     S2S_CHECK_LAUNCH("gemm_w8_kernel");
