@@ -155,6 +155,9 @@ int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs /* host */, int n, v
 int s2svc_gemm_wgrad_ok(const s2svc_gemm_desc* desc /* host */);
 int64_t s2svc_gemm_wgrad_ws_floats(const s2svc_gemm_desc* descs /* host */, int n);
 int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs /* host */, int n, float* ws, void* stream);
+/* the same as a BACKGROUND launch: at most `wgs_cap` workgroups walk the units (a quarter of the CUs, say) on `stream` and leave the
+   rest of the chip to the kernels of the stream beside it; same sums, same bits (wgs_cap <= 0: one workgroup per unit) */
+int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, float* ws, void* stream, int wgs_cap);
 /* A/B switch (tests, benchmarks): on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles of 64 rows per chunk (<= 0: unchanged; default 32,
    S2SVC_GEMM_W8 / S2SVC_W8_KT_CHUNK); returns the previous on | kt_chunk << 8. */
 int s2svc_gemm_set_w8(int on, int kt_chunk);

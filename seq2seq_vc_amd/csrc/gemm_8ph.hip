@@ -1214,6 +1214,7 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile
     p8_wait_vmcnt<0>();                // (the zero-block DMAs issued past the end)
     __builtin_amdgcn_s_barrier();      // the consumers' barrier in front of the epilogue: the stages become C tiles
     if (do_rowsum) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();      // end of the unit (the consumers' epilogue has left the stages)
     return;
   }
   // ================= consumer =================
@@ -1302,26 +1303,33 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile
     else epilogue_stage<64, 32>(acc[1], cs);
     w8_flush(q, chunk, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
   }
+  p8_wait_lgkm0();
+  __builtin_amdgcn_s_barrier();        // end of the unit: a further unit's DMAs may overwrite the C tiles
 }
 
+// one workgroup per unit, or -- gridDim.x < total: a BACKGROUND launch (ops.kernels.set_wgrad_background) -- gridDim.x workgroups that
+// walk the units and leave the other CUs to the stream beside them
 __global__ __launch_bounds__(768) void gemm_w8ls_kernel(const w8_args g) {
   __shared__ __attribute__((aligned(1024))) char smem[3 * 3 * 16384];
-  int u = (int)blockIdx.x;
-  {
-    const int q8 = g.total >> 3, r8 = g.total & 7;       // XCD x gets the x-th contiguous run of units
-    const int xcd = u & 7, j = u >> 3;
-    u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
-  }
-  int p = 0;
 #pragma unroll 1
-  for (int i = 1; i < g.n; ++i) p += (g.unit_start[i] <= u) ? 1 : 0;
-  const w8_prob& q = g.p[p];
-  int r = u - g.unit_start[p];
-  const int per_chunk = q.tiles_m * q.tiles_n;
-  const int chunk = r / per_chunk;
-  r -= chunk * per_chunk;
-  const int tile_m = r / q.tiles_n;
-  w8ls_tile(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
+  for (int id = (int)blockIdx.x; id < g.total; id += (int)gridDim.x) {
+    int u = id;
+    if (gridDim.x == (unsigned)g.total) {                // XCD x gets the x-th contiguous run of units
+      const int q8 = g.total >> 3, r8 = g.total & 7;
+      const int xcd = id & 7, j = id >> 3;
+      u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
+    }
+    int p = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.n; ++i) p += (g.unit_start[i] <= u) ? 1 : 0;
+    const w8_prob& q = g.p[p];
+    int r = u - g.unit_start[p];
+    const int per_chunk = q.tiles_m * q.tiles_n;
+    const int chunk = r / per_chunk;
+    r -= chunk * per_chunk;
+    const int tile_m = r / q.tiles_n;
+    w8ls_tile(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
+  }
 }
 
 // one workgroup per unit; gridDim.x = total units (or a cap: the workgroups then walk the units)
@@ -1602,16 +1610,23 @@ extern "C" int s2svc_gemm_grouped_try_8ph_bg(const s2svc_gemm_desc* descs, int n
 namespace {
 int g_w8_mode = -1, g_w8_kt = -1;
 int w8_mode() {       // S2SVC_GEMM_W8=0 / s2svc_gemm_set_w8: these problems stay on gemm_grouped_kernel<64, 64> (A/B switch)
-  if (g_w8_mode < 0) { const char* e = getenv("S2SVC_GEMM_W8"); g_w8_mode = (e && e[0] == '0') ? 0 : 1; }
+  if (g_w8_mode < 0) { const char* e = getenv("S2SVC_GEMM_W8"); g_w8_mode = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1; }
   return g_w8_mode;
 }
 int w8_kt_chunk_env() {   // S2SVC_W8_KT_CHUNK / s2svc_gemm_set_w8: K tiles (of 64 rows) per chunk; reductions up to this long run unsplit
   if (g_w8_kt < 0) { const char* e = getenv("S2SVC_W8_KT_CHUNK"); g_w8_kt = e ? atoi(e) : 32; if (g_w8_kt < 1) g_w8_kt = 1; }
   return g_w8_kt;
 }
-// the chunking of a reduction: a function of K only (see the kernel's header)
-void w8_chunks(int K, int& nchunks, int& kt_chunk) {
+// the chunking of a reduction: a function of the problem's OWN shape only (see the kernel's header) -- outputs of >= 64 tiles fill the
+// chip unsplit (and their partial tiles would be hundreds of MB of workspace traffic: AAS-VC's 4608 x 1536 gradients), smaller ones
+// are cut by K
+void w8_chunks(int M, int N, int K, int& nchunks, int& kt_chunk) {
   const int ktiles = (K + 63) / 64;
+  if ((int64_t)((M + 255) / 256) * ((N + 127) / 128) >= 64) {
+    nchunks = 1;
+    kt_chunk = ktiles;
+    return;
+  }
   kt_chunk = w8_kt_chunk_env();
   nchunks = (ktiles + kt_chunk - 1) / kt_chunk;
   if (nchunks > 16) {
@@ -1629,12 +1644,15 @@ bool w8_ok(const s2svc_gemm_desc& d) {
   if (((uintptr_t)d.C) % 16 || d.ldc % 4 || d.ldc < d.N) return false;
   if (d.bias || d.res || d.act != S2S_ACT_NONE || d.alpha != 1.0f || d.emask || d.drop_p > 0.f || d.c_map || d.c_pre) return false;
   // the exact-256 problems with >= 64 tiles of 128 x 128 keep p8_tr_tile / p8_tr_tile_q (grouped or background launches)
-  if (w8_mode() != 2 && p8_tr_ok(d) && (int64_t)(d.M / 128) * (d.N / 128) >= 64) return false;      // (mode 2: benchmarks)
+  // the exact-256 problems with >= 64 tiles of 128 x 128 (AAS-VC's decoder) ran on p8_tr_tile / p8_tr_tile_q until the loader-
+  // specialised tile beat both per flop (0.83 us per 256 x 128 K tile against 1.05); S2SVC_W8_EXACT=0 sends them back there
+  static const bool exact_too = !getenv_off("S2SVC_W8_EXACT");
+  if (!exact_too && w8_mode() != 2 && p8_tr_ok(d) && (int64_t)(d.M / 128) * (d.N / 128) >= 64) return false;
   return true;
 }
 int64_t w8_ws_floats(const s2svc_gemm_desc& d) {
   int nc, kc;
-  w8_chunks(d.K, nc, kc);
+  w8_chunks(d.M, d.N, d.K, nc, kc);
   if (nc <= 1) return 0;
   int64_t f = (int64_t)nc * d.M * d.N;
   if (d.a_rowsum) f += (((int64_t)nc * d.M + 3) / 4) * 4;
@@ -1663,11 +1681,19 @@ extern "C" int64_t s2svc_gemm_wgrad_ws_floats(const s2svc_gemm_desc* descs, int 
 
 // every descriptor must satisfy s2svc_gemm_wgrad_ok; no two of them may write the same C / a_rowsum; `ws` (device, 16-byte
 // aligned, s2svc_gemm_wgrad_ws_floats(...) floats, may be NULL if that is 0) must stay untouched until the launches have run
+extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, float* ws, void* stream, int wgs_cap);
+
 extern "C" int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs, int n, float* ws, void* stream) {
+  return s2svc_gemm_wgrad_grouped_bg(descs, n, ws, stream, 0);
+}
+
+// wgs_cap > 0: a background launch of at most that many workgroups (they walk the units), on `stream`
+extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, float* ws, void* stream, int wgs_cap) {
   S2S_REQUIRE(descs && n > 0, "gemm_wgrad_grouped: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int mode = p8_mode();
-  static const int cap = [] { const char* e = getenv("S2SVC_W8_WGS"); return e ? atoi(e) : 0; }();
+  static const int cap_env = [] { const char* e = getenv("S2SVC_W8_WGS"); return e ? atoi(e) : 0; }();
+  const int cap = wgs_cap > 0 ? wgs_cap : cap_env;
   int64_t ws_off = 0;
   for (int i0 = 0; i0 < n; i0 += W8_MAX) {
     const int cnt = (n - i0 < W8_MAX) ? n - i0 : W8_MAX;
@@ -1684,7 +1710,7 @@ extern "C" int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs, int n, flo
       q.M = d.M; q.N = d.N; q.K = d.K;
       q.tiles_m = (d.M + 255) / 256; q.tiles_n = (d.N + 127) / 128;
       int nc, kc;
-      w8_chunks(d.K, nc, kc);
+      w8_chunks(d.M, d.N, d.K, nc, kc);
       q.nchunks = nc; q.kt_chunk = kc;
       q.flags = (d.accumulate ? 1 : 0) | (d.a_rowsum_accumulate ? 2 : 0);
       if (nc > 1) {
@@ -1704,7 +1730,7 @@ extern "C" int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs, int n, flo
     const unsigned wgs = (unsigned)((cap > 0 && total > cap) ? cap : total);
     static const bool pipe = !getenv_off("S2SVC_W8_PIPE");
     static const bool ls = !getenv_off("S2SVC_W8_LS");       // loader-specialised tile (12 waves): one workgroup per unit
-    if (ls && wgs == (unsigned)total) hipLaunchKernelGGL(gemm_w8ls_kernel, dim3(wgs), dim3(768), 0, st, g);
+    if (ls) hipLaunchKernelGGL(gemm_w8ls_kernel, dim3(wgs), dim3(768), 0, st, g);
     else if (pipe) hipLaunchKernelGGL((gemm_w8_kernel<false, true>), dim3(wgs), dim3(512), 0, st, g);
     else if (mode == 2) hipLaunchKernelGGL((gemm_w8_kernel<false, false>), dim3(wgs), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((gemm_w8_kernel<true, false>), dim3(wgs), dim3(512), 0, st, g);

@@ -166,7 +166,7 @@ class _Side:
     origins = []     # the stream each queued closure was issued from
     inline = False   # no side streams, but batched (see enable_side_streams)
     inline_q = {}    # stream handle -> (stream, [closures])
-    batch = int(os.environ.get("S2SVC_SIDE_BATCH", "12"))
+    batch = int(os.environ.get("S2SVC_SIDE_BATCH", "16"))
     grouped = []     # weight-gradient GEMM descriptors of the batch being flushed
     grouped_cr = []  # column reductions of the batch being flushed
     group_wgrad = os.environ.get("S2SVC_NO_GROUPED_WGRAD", "0") != "1"
@@ -197,8 +197,14 @@ def distinct_stream(taken=None):
     raise RuntimeError("no distinct stream left in torch's stream pool")
 
 
-def enable_side_streams(n=4, inline_batches=False, wgrad_background=(0, 0)):
-    """n > 0: parameter-gradient work is forked to n side streams (small, latency-bound models: VTN).
+_SIDE_BATCH_ENV = os.environ.get("S2SVC_SIDE_BATCH")
+
+
+def enable_side_streams(n=4, inline_batches=False, wgrad_background=(0, 0), batch=None):
+    """batch: closures per gradient batch (default: 16 forked / 64 inline; S2SVC_SIDE_BATCH overrides).  Round 4 re-measured both with
+    the 8-wave weight-gradient kernel that takes 40 problems per launch: VTN 12 -> 16: 3.95 -> 3.86 ms, AAS-VC 12 -> 48 ... 160:
+    11.85 -> 11.6-11.7 ms (larger grids, fewer ragged last rounds; the operands stay alive a little longer).
+    n > 0: parameter-gradient work is forked to n side streams (small, latency-bound models: VTN).
     n == 0 and inline_batches: the work stays on the stream that issued it but is still queued and run in batches, so
     that the dense weight-gradient GEMMs of a batch become one grouped launch -- for models whose kernels fill the chip
     anyway (AAS-VC: d = 1536) the forks cost more than the overlap gives (19.3 vs 20.9 ms/step).  Both need side_join()
@@ -206,6 +212,7 @@ def enable_side_streams(n=4, inline_batches=False, wgrad_background=(0, 0)):
     K.set_wgrad_background(*wgrad_background)     # (cus, launches): ops.kernels, "Background weight gradients"
     _Side.enabled = n > 0
     _Side.inline = (n == 0) and inline_batches
+    _Side.batch = int(_SIDE_BATCH_ENV) if _SIDE_BATCH_ENV else int(batch) if batch else (64 if _Side.inline else 16)
     old, others = _Side.streams, _taken_streams() - {st.cuda_stream for st in _Side.streams}
     if n > 0 and len(old) == n and len({st.cuda_stream for st in old}) == n and not ({st.cuda_stream for st in old} & others):
         pass                                     # keep the ones we have: every new Stream object eats a slot of torch's pool

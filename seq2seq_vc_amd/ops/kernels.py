@@ -239,6 +239,20 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
             _RECORDER.append(d)
             return out
         d.splitk, d.a_rowsum = splitk, None
+    if accumulate and in_dtype == torch.bfloat16 and group is None:
+        # a weight gradient launched on its own (no batch is being recorded: immediate mode): the same kernel, chunking and sums as in a
+        # grouped launch (csrc/gemm_8ph.hip "W8") -- WHICH kernel a problem gets depends on its descriptor only
+        d.splitk, d.ws = 1, None
+        if a_rowsum is not None:
+            d.a_rowsum = a_rowsum.data_ptr()
+            d.a_rowsum_accumulate = 1 if a_rowsum_accumulate else 0
+        if _lib.lib().s2svc_gemm_wgrad_ok(ctypes.addressof(d)):
+            bg_wait(d.C, d.a_rowsum)
+            if _Audit.on:
+                _audit_write("weight gradient (W8)", d.C, d.a_rowsum if a_rowsum_accumulate else None)
+            launch_wgrad_group([d])
+            return out
+        d.splitk, d.a_rowsum = splitk, None
     ws = None
     if splitk > 1:
         ws = torch.empty(splitk * nb0 * nb1 * M * N, dtype=torch.float32, device=out.device)
@@ -403,12 +417,20 @@ def launch_group(descs, tile=128):
     _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(descs), tile, stream()), "s2svc_gemm_grouped")
 
 
-def launch_wgrad_group(descs):
+def launch_wgrad_group(descs, bg_stream=None, bg_wgs=0):
     """The listed weight-gradient problems (every one s2svc_gemm_wgrad_ok) on the ragged 8-wave kernel, one grid per <= 40 of
-    them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`)."""
+    them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`).
+    bg_stream / bg_wgs: as a background launch of at most bg_wgs workgroups on that stream (the caller has ordered it behind the
+    producers of the operands and joins it before the gradients are read)."""
     L = _lib.lib()
     arr = (_lib.GemmDesc * len(descs))(*descs)
     nws = L.s2svc_gemm_wgrad_ws_floats(ctypes.addressof(arr), len(descs))
+    if bg_stream is not None:
+        with torch.cuda.stream(bg_stream):
+            ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
+            _lib.check(L.s2svc_gemm_wgrad_grouped_bg(ctypes.addressof(arr), len(descs), ptr(ws), bg_stream.cuda_stream, int(bg_wgs)),
+                       "s2svc_gemm_wgrad_grouped_bg")
+        return
     ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
     _lib.check(L.s2svc_gemm_wgrad_grouped(ctypes.addressof(arr), len(descs), ptr(ws), stream()), "s2svc_gemm_wgrad_grouped")
 
@@ -454,9 +476,27 @@ def flush_grouped(queue):
         if w8:
             group = [d for d in group if not any(d is w for w in w8)]
             bg_wait(*[d.C for d in w8], *[d.a_rowsum for d in w8])
-            if _Audit.on:
-                _audit_write("grouped weight gradient (W8)", *[d.C for d in w8], *[d.a_rowsum for d in w8])
-            launch_wgrad_group(w8)
+            # the big exact-256 problems of the first `max_launches` batches of a backward pass (AAS-VC's decoder layers) as a
+            # BACKGROUND launch of `cus` workgroups on their own stream (see "Background weight gradients" below)
+            cand = _bg_candidates(w8) if (_BG.cus > 0 and _BG.count < _BG.max_launches) else []
+            rest = [d for d in w8 if not any(d is c for c in cand)]
+            if cand:
+                cur = torch.cuda.current_stream()
+                bg = _bg_stream(cur)
+                bg.wait_stream(cur)                         # the operands were produced on this stream
+                if _Audit.on:
+                    _audit_write("background weight gradient (W8)", *[d.C for d in cand], *[d.a_rowsum for d in cand], st=bg.cuda_stream)
+                launch_wgrad_group(cand, bg_stream=bg, bg_wgs=_BG.cus)
+                _BG.dirty = True
+                _BG.count += 1
+                for d in cand:
+                    _BG.keys.add(d.C)
+                    if d.a_rowsum:
+                        _BG.keys.add(d.a_rowsum)
+            if rest:
+                if _Audit.on:
+                    _audit_write("grouped weight gradient (W8)", *[d.C for d in rest], *[d.a_rowsum for d in rest])
+                launch_wgrad_group(rest)
         # big outputs (>= _GROUP_BIG_TILES 128x128 tiles each) share launches of 128x128 tiles, the rest of 64x64 tiles
         big = [d for d in group if _GROUP_TILE == 64 and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= _GROUP_BIG_TILES]
         small = [d for d in group if not any(d is b for b in big)]

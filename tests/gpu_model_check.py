@@ -515,7 +515,7 @@ def gradient_slot_writers_audit():
                 torch.manual_seed(0)
                 model = M.VTN(**bench.VTN_VC1).to(DEV).train()
             else:
-                Fn.enable_side_streams(0, inline_batches=True, wgrad_background=AASVCTrainer.WGRAD_BACKGROUND)
+                Fn.enable_side_streams(0, inline_batches=True, wgrad_background=(64, 3))      # (the opt-in background launches too)
                 xs, ilens, ys, labels, olens = bench.canonical_batch(16)
                 torch.manual_seed(0)
                 model = M.AASVC(**AASVC_VC2).to(DEV).train()
