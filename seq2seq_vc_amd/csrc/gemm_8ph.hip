@@ -469,126 +469,6 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// BN = 128, LOADER-SPECIALISED ("LS", round 4): the 256 x 128 tile of gemm_8ph_kernel_128 with the work split by ROLE instead of
-// by phase -- waves 0..7 are consumers (the 2 x 4 wave grid: fragment reads + MFMAs only), waves 8..11 loaders (one per SIMD: every
-// LDS-DMA instruction of the workgroup, the conv / tconv address walk, the counted vmcnt waits) over a ring of THREE K-tile stages
-// (144 KB) with ONE s_barrier per K tile.  See w8ls_tile below for the measurements that led here and the barrier protocol:
-//   B(t): loaders arrive when their share of tile t has landed (vmcnt(12): the tile issued last may be in flight), consumers arrive at
-//   B(t + 1) with every read of tile t retired -- behind B(t) tile t is complete, behind B(t + 1) stage t % 3 may be re-filled (tile t + 3).
-// Same LDS image (swizzled lane-linear rows), operand kinds and epilogue as the 8-wave kernel.
-// ---------------------------------------------------------------------------------------------------------
-template <int KA, bool LEAN = false>
-__global__ __launch_bounds__(768) void gemm_ls_kernel_128(const s2svc_gemm_desc d) {
-  constexpr int UNIT = 16384, BUF = 3 * UNIT, NS = 3;    // A.m0 | A.m1 | B per stage
-  __shared__ __attribute__((aligned(1024))) char smem[NS * BUF];
-  const int zb = blockIdx.z;
-  const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
-  int tile_m, tile_n;
-  p8_tile_of_block(tile_m, tile_n);
-  const int m0 = tile_m * 256, n0 = tile_n * 128;
-  const int nt = d.K / 64;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave >= 8) {
-    // ================= loader: instructions lw * 4 + i (8 rows each) of every unit =================
-    const int lw = wave - 8;
-    const char* Ab = reinterpret_cast<const char*>((const bf16_t*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1);
-    const char* Bb = reinterpret_cast<const char*>((const bf16_t*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1);
-    uint32_t offA[2][4], offB[4];
-    int mA[2][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ru = (lw * 4 + i) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((ru >> 1) & 7);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = m0 + (ru >> 6) * 128 + h * 64 + (ru & 63);
-        offA[h][i] = p8_rowoff<KA>(d.A, row, d.M, c);
-        mA[h][i] = KA == P8_TCONV2D ? p8_rowmask(d.A, row, d.M) : 0;
-      }
-      offB[i] = p8_rowoff<P8_DENSE>(d.B, n0 + ru, d.N, c);
-    }
-    const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
-    P8Walk<KA> wk;                                      // K tile of the next tile to issue
-    wk.init(d.A, 0);
-    // the 12 DMA instructions of this loader for K tile T (the walk stands at T) into stage T % 3; past the last tile: the zero block
-#define LS_ISSUE(T)                                                                                                           \
-    {                                                                                                                         \
-      const int tt_ = (T);                                                                                                    \
-      const bool in_ = tt_ < nt;                                                                                              \
-      char* st_ = smem + (tt_ % NS) * BUF;                                                                                    \
-      const char* ab_ = Ab + wk.off_bytes(d.A);                                                                               \
-      const char* bb_ = Bb + wk.off_bytes_b(d.A);                                                                             \
-      const int bit_ = wk.bit();                                                                                              \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                         \
-        const char* s0_ = (in_ && (KA != P8_TCONV2D || (mA[0][i] & bit_))) ? ab_ + offA[0][i] : z;                            \
-        const char* s1_ = (in_ && (KA != P8_TCONV2D || (mA[1][i] & bit_))) ? ab_ + offA[1][i] : z;                            \
-        const char* s2_ = in_ ? bb_ + offB[i] : z;                                                                            \
-        __builtin_amdgcn_global_load_lds((gbl_void*)s0_, (lds_void*)(st_ + 0 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
-        __builtin_amdgcn_global_load_lds((gbl_void*)s1_, (lds_void*)(st_ + 1 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
-        __builtin_amdgcn_global_load_lds((gbl_void*)s2_, (lds_void*)(st_ + 2 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
-      }                                                                                                                       \
-      wk.next(d.A);                                                                                                           \
-    }
-    LS_ISSUE(0);
-    LS_ISSUE(1);
-    p8_wait_vmcnt<12>();               // this loader's share of tile 0 has landed
-    __builtin_amdgcn_s_barrier();      // B(0)
-#pragma unroll 1
-    for (int t = 0; t < nt; ++t) {
-      LS_ISSUE(t + 2);                 // stage (t + 2) % 3 = (t - 1) % 3: its readers arrived at B(t) with their reads retired
-      p8_wait_vmcnt<12>();             // tile t + 1 has landed
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();    // B(t + 1)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#undef LS_ISSUE
-    p8_wait_vmcnt<0>();                // (the zero-block DMAs issued past the end)
-    __builtin_amdgcn_s_barrier();      // the consumers' barrier in front of the epilogue
-    return;
-  }
-  // ================= consumer =================
-  const int wr = wave >> 2, wc = wave & 3;
-  const int lr = lane & 15, lg = lane >> 4;
-  const int sw = (lr >> 1) & 7;
-  const int p0 = (lg ^ sw) << 4, p1 = ((4 + lg) ^ sw) << 4;
-  const int rdA = (wr * 64 + lr) * 128, rdB = (wc * 32 + lr) * 128;
-  f32x4_t acc[2][4][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  bf16x8_t fa[4][2], fa1[4][2], fb[2][2];
-  __builtin_amdgcn_s_barrier();        // B(0): tile 0 is complete
-#pragma unroll 1
-  for (int t = 0; t < nt; ++t) {
-    const char* st = smem + (t % NS) * BUF;
-    p8_read<2>(st + 2 * UNIT, rdB, p0, p1, fb);
-    p8_read<4>(st + 0 * UNIT, rdA, p0, p1, fa);
-    __builtin_amdgcn_sched_barrier(0);
-    p8_read<4>(st + 1 * UNIT, rdA, p0, p1, fa1);      // rows m1: lands behind the MFMAs of rows m0
-    __builtin_amdgcn_sched_barrier(0);
-    p8_mfma<4, 2>(fa, fb, acc[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    p8_mfma<4, 2>(fa1, fb, acc[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();      // B(t + 1): every read of tile t is retired (the MFMAs above consumed them); tile t + 1 is complete
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __builtin_amdgcn_s_barrier();        // (with the loaders' vmcnt(0)) the operand stages are dead: reuse them as fp32 C tiles
-  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
-#pragma unroll 1
-  for (int a = 0; a < 2; ++a) {
-    if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
-    else epilogue_stage<64, 32>(acc[1], cs);
-    if (LEAN) epilogue_flush_common<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
-    else epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, cs, 1, 0, zb);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Row-contiguous operands ("TR"): the weight-gradient GEMMs C[n_out, n_in] (+)= dY^T . X of the Linear layers, reduction over
 // the B*T rows of the batch, both operands stored [k][row].  Same 256 x 128 tile, units, phases and counted waits as
 // gemm_8ph_kernel_128; what changes is the image of a unit and how fragments leave it (as in gemm_glds.hip's TrStage):
@@ -1656,19 +1536,13 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
     }                                                                                                     \
   } while (0)
   static const bool lean_on = !getenv_off("S2SVC_GEMM_LEAN");
-  static const bool ls_on = !getenv_off("S2SVC_GEMM_LS");             // loader-specialised 256 x 128 tile (gemm_ls_kernel_128)
   if (lean_on && !conv && !tconv && mode != 2 && epilogue_common_ok(d)) {       // dense operands + the common epilogue: lean variants
     if (geo == 1) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_DENSE, 2, 4, true, true>), grid, dim3(512), 0, st, d);
     else if (geo == 2) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_DENSE, 4, 2, true, true>), grid, dim3(512), 0, st, d);
-    else if (ls_on) hipLaunchKernelGGL((gemm_ls_kernel_128<P8_DENSE, true>), grid, dim3(768), 0, st, d);
     else hipLaunchKernelGGL((gemm_8ph_kernel_128<P8_DENSE, true, true>), grid, dim3(512), 0, st, d);
   } else if (geo == 1) P8_LAUNCH(gemm_8ph_kernel_q, 2, 4);
   else if (geo == 2) P8_LAUNCH(gemm_8ph_kernel_q, 4, 2);
-  else if (ls_on) {
-    if (conv) hipLaunchKernelGGL((gemm_ls_kernel_128<P8_CONV2D>), grid, dim3(768), 0, st, d);
-    else if (tconv) hipLaunchKernelGGL((gemm_ls_kernel_128<P8_TCONV2D>), grid, dim3(768), 0, st, d);
-    else hipLaunchKernelGGL((gemm_ls_kernel_128<P8_DENSE>), grid, dim3(768), 0, st, d);
-  } else P8_LAUNCH(gemm_8ph_kernel_128);
+  else P8_LAUNCH(gemm_8ph_kernel_128);
 #undef P8_LAUNCH
   S2S_CHECK_LAUNCH("gemm_8ph_kernel");
   return 1;
