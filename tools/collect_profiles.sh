@@ -56,4 +56,13 @@ prof /tmp/prof_sq3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 python tools/rocpd_pmc.py "$(db /tmp/prof_sq3)" gemm_8ph > "$OUT/roofline_aasvc_pmc_sq.txt" 2>&1
 prof /tmp/prof_sq4 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/prof_sq4 -o r -- python "$R/bench.py" --roofline-only --workload aasvc
 python tools/rocpd_pmc.py "$(db /tmp/prof_sq4)" gemm_8ph >> "$OUT/roofline_aasvc_pmc_sq.txt" 2>&1
+# MFMA-pipe busy per GEMM-shaped kernel over WHOLE steps (eager launches: every dispatch is its own counter sample)
+HDR="# MFMA-pipe busy fraction per GEMM-shaped kernel over WHOLE training steps (eager launches of bench.py --no-graph under\n# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace; tools/step_mfma_busy.py).\n# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x avg us x 2400 cycles/us); wait/wave = SQ_WAIT_ANY / SQ_WAVE_CYCLES."
+printf "$HDR\n" > "$OUT/step_mfma_busy.txt"
+for wl in vtn aasvc; do
+  prof /tmp/prof_busy_$wl --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d /tmp/prof_busy_$wl -o r -- python "$R/bench.py" --workload $wl --no-graph --no-cpu-baseline --no-extras --steps 8 --warmup 2
+  python tools/step_mfma_busy.py $wl "$(db /tmp/prof_busy_$wl)" >> "$OUT/step_mfma_busy.txt" 2>&1
+done
+python tools/gemm_bench.py --filter "vtn wgrad grouped w8" > "$OUT/w8_grouped_bench.txt" 2>&1
+(python tools/bench_trainer.py --workload aasvc --accum 8 --batch 2 --steps 64 | tail -1) > "$OUT/bench_trainer_accum8.json" 2>> "$OUT/bench.err"
 ls -la "$OUT"
