@@ -161,16 +161,6 @@ int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, 
 /* A/B switch (tests, benchmarks): on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles of 64 rows per chunk (<= 0: unchanged; default 32,
    S2SVC_GEMM_W8 / S2SVC_W8_KT_CHUNK); returns the previous on | kt_chunk << 8. */
 int s2svc_gemm_set_w8(int on, int kt_chunk);
-/* Conv2d 3x3 stride-2 WEIGHT gradient (the encoder front-end's second convolution, modules/transformer/subsampling.py:58-63;
-   autograd's conv2d weight gradient in the reference) on the loader-specialised 8-wave tile with an implicit-im2col operand:
-   dW[o][c][kh][kw] (fp32, the parameter's layout) (+)= sum over output pixels of dY[b,t2,f2,o] * x[b, 2 t2 + kh, 2 f2 + kw, c].
-   x (B, T1, F1, C), dy (B, T2, F2, O) bf16 contiguous (T2 = (T1 - 3) / 2 + 1 ...); the reduction over the output pixels is cut
-   into chunks (a function of the shape) whose partial tiles go through `ws` (_ws_floats floats, 16-byte aligned); a second
-   launch adds them in order and writes the transposed, permuted result. */
-int s2svc_conv2d_s2_wgrad_supported(int B, int T1, int F1, int C, int O);
-int64_t s2svc_conv2d_s2_wgrad_ws_floats(int B, int T1, int F1, int C, int O);
-int s2svc_conv2d_s2_wgrad(int B, int T1, int F1, int C, int O, const void* x, const void* dy, float* dw, int accumulate, float* ws,
-                          void* stream);
 int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream, void* bg_stream, int bg_cus,
                           int* n_bg /* host, may be NULL */);
 

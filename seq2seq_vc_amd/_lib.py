@@ -103,8 +103,6 @@ _SIGS = {
     "s2svc_gemm_wgrad_grouped": [c_vp, c_i32, c_vp, c_vp],
     "s2svc_gemm_wgrad_grouped_bg": [c_vp, c_i32, c_vp, c_vp, c_i32],
     "s2svc_gemm_set_w8": [c_i32, c_i32],
-    "s2svc_conv2d_s2_wgrad_supported": [c_i32, c_i32, c_i32, c_i32, c_i32],
-    "s2svc_conv2d_s2_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
     "s2svc_gemm_grouped_bg": [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp],
     "s2svc_gemm_set_8ph": [c_i32],
     "s2svc_decode_ln_linear_supported": [c_i32, c_i32, c_i32],
@@ -221,7 +219,7 @@ _SIGS = {
                               c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_ragged_to_padded": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
 }
-_RET64 = {"s2svc_gemm_wgrad_ws_floats": [c_vp, c_i32], "s2svc_conv2d_s2_wgrad_ws_floats": [c_i32, c_i32, c_i32, c_i32, c_i32], "s2svc_mas_ws_bytes": [c_i32, c_i32, c_i32], "s2svc_forward_sum_ws_bytes": [c_i32, c_i32, c_i32]}
+_RET64 = {"s2svc_gemm_wgrad_ws_floats": [c_vp, c_i32], "s2svc_mas_ws_bytes": [c_i32, c_i32, c_i32], "s2svc_forward_sum_ws_bytes": [c_i32, c_i32, c_i32]}
 
 _lib = None
 

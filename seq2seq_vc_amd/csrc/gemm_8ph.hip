@@ -1147,45 +1147,7 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
 // (p8_tr_tile); a variant with four sub-phases and the next sub-phase's fragments requested ahead of the MFMAs needs 12 registers
 // more than the 168 that three waves per SIMD allow (spills: slower with the row sums, +3 % without) -- not kept.
 // ---------------------------------------------------------------------------------------------------------
-// Implicit-im2col A operand of the loader-specialised tile (the Conv2d 3x3 stride-2 weight gradient, K = output pixels): row
-// m = tap * C + c of reduction row k = output pixel (b, t2, f2) is x[b, 2 t2 + kh, 2 f2 + kw, c] -- per lane a fixed (tap, channel)
-// offset plus the pixel's offset, which a loader walks from K tile to K tile (64 pixels further: two compares, no division; as
-// TrStage<G_TR_CONV2D> of gemm_glds.hip does).  The consumers never see the difference.
-struct w8_conv {
-  int32_t C, T1, F1, T2, F2, ld;           // ld = elements per input pixel (C for a contiguous NHWC tensor)
-};
-struct W8PixelWalk {                         // the pixels of a loader's four pieces (four k rows per lane)
-  int pf2[4], pt2[4];
-  uint32_t poff[4];
-  uint32_t step, wrapf, wrapt;
-  int q, rem, T2, F2;
-  __device__ __forceinline__ void init(const w8_conv& c, const int (&k)[4]) {
-    T2 = c.T2; F2 = c.F2;
-    q = 64 / c.F2; rem = 64 - q * c.F2;
-    step = (uint32_t)((int64_t)(2 * rem + 2 * q * c.F1) * c.ld * 2);
-    wrapf = (uint32_t)((int64_t)(2 * c.F1 - 2 * c.F2) * c.ld * 2);
-    wrapt = (uint32_t)((int64_t)(c.T1 - 2 * c.T2) * c.F1 * c.ld * 2);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int bt = k[e] / c.F2;
-      pf2[e] = k[e] - bt * c.F2;
-      const int b = bt / c.T2;
-      pt2[e] = bt - b * c.T2;
-      poff[e] = (uint32_t)(((int64_t)(b * c.T1 + 2 * pt2[e]) * c.F1 + 2 * pf2[e]) * c.ld * 2);
-    }
-  }
-  __device__ __forceinline__ void next() {      // every pixel index grows by 64 = q * F2 + rem
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      pf2[e] += rem; pt2[e] += q; poff[e] += step;
-      if (pf2[e] >= F2) { pf2[e] -= F2; pt2[e] += 1; poff[e] += wrapf; }
-      if (pt2[e] >= T2) { pt2[e] -= T2; poff[e] += wrapt; }
-    }
-  }
-};
-
-template <bool ACONV = false>
-__device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile_n, int chunk, char* smem, const w8_conv* cv = nullptr) {
+__device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile_n, int chunk, char* smem) {
   constexpr int UNIT = 16384, BUF = 3 * UNIT, NS = 3;    // A.m0 | A.m1 | B per stage
   const int m0 = tile_m * 256, n0 = tile_n * 128;
   const int ktiles = (q.K + 63) >> 6;
@@ -1198,7 +1160,7 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile
     // ================= loader =================
     const int lw = wave - 8;
     const int64_t stepA = (int64_t)q.lda * 128, stepB = (int64_t)q.ldb * 128;
-    const char* Ab = reinterpret_cast<const char*>(q.A) + (ACONV ? 0 : (int64_t)kt0 * stepA);
+    const char* Ab = reinterpret_cast<const char*>(q.A) + (int64_t)kt0 * stepA;
     const char* Bb = reinterpret_cast<const char*>(q.B) + (int64_t)kt0 * stepB;
     const int krem = q.K - kt0 * 64;
     int kin[4];
@@ -1212,42 +1174,29 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile
       for (int h = 0; h < 2; ++h) {
         const int row = m0 + (ur >> 6) * 128 + h * 64 + (ur & 63);
         okA[h][i] = row < q.M;
-        if (ACONV) {                                      // (tap, channel) part; the pixel part comes from the walk
-          const int tap = row / cv->C, c = row - tap * cv->C;
-          const int kh3 = tap / 3, kw = tap - kh3 * 3;
-          offA[h][i] = (uint32_t)(((int64_t)(kh3 * cv->F1 + kw) * cv->ld + c) * 2);
-        } else {
-          offA[h][i] = (uint32_t)(((int64_t)kin[i] * q.lda + row) * 2);
-        }
+        offA[h][i] = (uint32_t)(((int64_t)kin[i] * q.lda + row) * 2);
       }
       okB[i] = n0 + ur < q.N;
       offB[i] = (uint32_t)(((int64_t)kin[i] * q.ldb + n0 + ur) * 2);
     }
     const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
-    W8PixelWalk walk;                                    // (ACONV) pixel offsets of the K tile issued next (the issues go tile by tile)
-    if (ACONV) {
-      const int k0[4] = {kt0 * 64 + kin[0], kt0 * 64 + kin[1], kt0 * 64 + kin[2], kt0 * 64 + kin[3]};
-      walk.init(*cv, k0);
-    }
     // the 12 DMA instructions of this loader for chunk-relative K tile T into stage T % 3
 #define W8LS_ISSUE(T)                                                                                                         \
     {                                                                                                                         \
       const int tt_ = (T);                                                                                                    \
       const int klim_ = (tt_ < nt) ? krem - tt_ * 64 : 0;                                                                     \
       char* st_ = smem + (tt_ % NS) * BUF;                                                                                    \
-      const char* ab_ = Ab + (ACONV ? 0 : (int64_t)tt_ * stepA);                                                              \
+      const char* ab_ = Ab + (int64_t)tt_ * stepA;                                                                            \
       const char* bb_ = Bb + (int64_t)tt_ * stepB;                                                                            \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                         \
         const bool kok_ = kin[i] < klim_;                                                                                     \
-        const uint32_t px_ = ACONV ? walk.poff[i] : 0u;                                                                       \
-        const char* s0_ = (okA[0][i] && kok_) ? ab_ + (uint32_t)(offA[0][i] + px_) : z;                                       \
-        const char* s1_ = (okA[1][i] && kok_) ? ab_ + (uint32_t)(offA[1][i] + px_) : z;                                       \
+        const char* s0_ = (okA[0][i] && kok_) ? ab_ + offA[0][i] : z;                                                         \
+        const char* s1_ = (okA[1][i] && kok_) ? ab_ + offA[1][i] : z;                                                         \
         const char* s2_ = (okB[i] && kok_) ? bb_ + offB[i] : z;                                                               \
         __builtin_amdgcn_global_load_lds((gbl_void*)s0_, (lds_void*)(st_ + 0 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
         __builtin_amdgcn_global_load_lds((gbl_void*)s1_, (lds_void*)(st_ + 1 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
         __builtin_amdgcn_global_load_lds((gbl_void*)s2_, (lds_void*)(st_ + 2 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
       }                                                                                                                       \
-      if (ACONV) walk.next();                                                                                                 \
     }
     W8LS_ISSUE(0);
     W8LS_ISSUE(1);
@@ -1379,66 +1328,7 @@ __global__ __launch_bounds__(768) void gemm_w8ls_kernel(const w8_args g) {
     const int chunk = r / per_chunk;
     r -= chunk * per_chunk;
     const int tile_m = r / q.tiles_n;
-    w8ls_tile<false>(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
-  }
-}
-
-// Conv2d 3x3 stride-2 WEIGHT GRADIENT on the loader-specialised tile: C'[m = tap * C + c][n = o] = sum over output pixels k of
-// x_im2col[k][m] * dY[k][o] (the tall side -- 9 C rows -- on the 256-row tile dimension, the O output channels on the 128-wide one:
-// 14 x 3 tiles for VTN's 384 -> 384 layer with 3.6 % padding, where the (O, 9 C) orientation pads 384 rows to 512).  One problem per
-// launch; units = (K chunk, tile); every unit stores its fp32 partial tile, w8c_reduce_kernel adds the chunks in order and writes the
-// result TRANSPOSED AND PERMUTED into the parameter's own layout dW[o][c][kh][kw] (accumulating into the flat-gradient slot): the
-// permuted temporary, the gather and the accumulate launch of the 4-wave path are gone.
-struct w8c_args {
-  w8_prob p;
-  w8_conv cv;
-};
-
-__global__ __launch_bounds__(768) void gemm_w8c_kernel(const w8c_args g) {
-  __shared__ __attribute__((aligned(1024))) char smem[3 * 3 * 16384];
-  const w8_prob& q = g.p;
-  const int total = q.tiles_m * q.tiles_n * q.nchunks;
-  int u = (int)blockIdx.x;
-  {
-    const int q8 = total >> 3, r8 = total & 7;           // XCD x gets the x-th contiguous run of units
-    const int xcd = u & 7, j = u >> 3;
-    u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
-  }
-  const int per_chunk = q.tiles_m * q.tiles_n;
-  const int chunk = u / per_chunk;
-  const int r = u - chunk * per_chunk;
-  const int tile_m = r / q.tiles_n;
-  w8ls_tile<true>(q, tile_m, r - tile_m * q.tiles_n, chunk, smem, &g.cv);
-}
-
-// dW[o][c][tap] (+)= sum over chunks of ws[chunk][tap * C + c][o]: a block owns 8 channels x 64 output channels (72 rows of the
-// partial tiles: read along o, 256-byte runs), sums the chunks in order into LDS and writes 72 consecutive floats per o
-__global__ __launch_bounds__(256) void w8c_reduce_kernel(const float* __restrict__ ws, int nchunks, int C, int O, float* __restrict__ dw,
-                                                         int accumulate) {
-  __shared__ float tile[72][65];
-  const int c0 = blockIdx.x * 8, o0 = blockIdx.y * 64;
-  const int64_t plane = (int64_t)9 * C * O;
-  for (int i = threadIdx.x; i < 72 * 64; i += 256) {
-    const int rr = i >> 6, oo = i & 63;                  // rr = tap * 8 + dc
-    const int tap = rr >> 3, dc = rr & 7;
-    float v = 0.f;
-    if (c0 + dc < C && o0 + oo < O) {
-      const float* w = ws + (int64_t)(tap * C + c0 + dc) * O + o0 + oo;
-      v = w[0];
-#pragma unroll 1
-      for (int k = 1; k < nchunks; ++k) v += w[k * plane];
-    }
-    tile[rr][oo] = v;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 64 * 72; i += 256) {
-    const int oo = i / 72, j = i - oo * 72;              // j = dc * 9 + tap: 72 consecutive floats of dW[o][c0 ..][.]
-    const int dc = j / 9, tap = j - dc * 9;
-    if (c0 + dc < C && o0 + oo < O) {
-      float* d = dw + ((int64_t)(o0 + oo) * C + c0 + dc) * 9 + tap;
-      const float v = tile[tap * 8 + dc][oo];
-      *d = accumulate ? *d + v : v;
-    }
+    w8ls_tile(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
   }
 }
 
@@ -1850,67 +1740,6 @@ extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, 
       S2S_CHECK_LAUNCH("w8_reduce_kernel");
     }
   }
-  return 0;
-}
-
-// ---- Conv2d 3x3 stride-2 weight gradient on the loader-specialised tile ---------------------------------------------
-namespace {
-bool w8c_supported(int B, int T1, int F1, int C, int O) {
-  static const bool on = !getenv_off("S2SVC_GEMM_W8_CONV");
-  if (!on || p8_mode() == 0 || !p8_tr_mode() || !w8_mode() || getenv_off("S2SVC_W8_LS")) return false;
-  if (B <= 0 || T1 < 3 || F1 < 3 || C < 8 || C % 8 || O < 8 || O % 8) return false;
-  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
-  if (64 / F2 + 1 > T2) return false;                                   // the pixel walk wraps at most one row / one image per K tile
-  if ((int64_t)B * T1 * F1 * C * 2 >= (1ll << 32)) return false;        // 32-bit per-lane byte offsets into x
-  if ((int64_t)64 * O * 2 + (int64_t)O * 2 >= (1ll << 32)) return false;
-  return (int64_t)B * T2 * F2 >= 4096;                                  // a long reduction: what the chunked launch is for
-}
-void w8c_plan(int B, int T1, int F1, int C, int O, int& K, int& nchunks, int& kt_chunk, int& tiles_m, int& tiles_n) {
-  const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
-  K = B * T2 * F2;
-  tiles_m = (9 * C + 255) / 256;
-  tiles_n = (O + 127) / 128;
-  const int ktiles = (K + 63) / 64, tiles = tiles_m * tiles_n;
-  nchunks = 256 / tiles;                                                // one round of workgroups on the 256 CUs (a function of the
-  if (nchunks < 2) nchunks = 2;                                         // problem's own shape); always >= 2: the reduction launch does the
-  if (nchunks > 16) nchunks = 16;                                       // transposition into the parameter layout
-  if (nchunks > ktiles) nchunks = ktiles > 1 ? ktiles : 2;
-  kt_chunk = (ktiles + nchunks - 1) / nchunks;
-  nchunks = (ktiles + kt_chunk - 1) / kt_chunk;
-  if (nchunks < 2) { nchunks = 2; kt_chunk = (ktiles + 1) / 2; }
-}
-}  // namespace
-
-extern "C" int s2svc_conv2d_s2_wgrad_supported(int B, int T1, int F1, int C, int O) { return w8c_supported(B, T1, F1, C, O) ? 1 : 0; }
-
-extern "C" int64_t s2svc_conv2d_s2_wgrad_ws_floats(int B, int T1, int F1, int C, int O) {
-  int K, nc, kc, tm, tn;
-  w8c_plan(B, T1, F1, C, O, K, nc, kc, tm, tn);
-  return (int64_t)nc * 9 * C * O;
-}
-
-// dW[o][c][kh][kw] (fp32, the parameter's layout) (+)= sum over output pixels of dY[b, t2, f2, o] * x[b, 2 t2 + kh, 2 f2 + kw, c];
-// x (B, T1, F1, C), dy (B, T2, F2, O) bf16 contiguous; ws: s2svc_conv2d_s2_wgrad_ws_floats(...) floats, 16-byte aligned
-extern "C" int s2svc_conv2d_s2_wgrad(int B, int T1, int F1, int C, int O, const void* x, const void* dy, float* dw, int accumulate,
-                                     float* ws, void* stream) {
-  S2S_REQUIRE(w8c_supported(B, T1, F1, C, O), "conv2d_s2_wgrad: unsupported shape (check s2svc_conv2d_s2_wgrad_supported)");
-  S2S_REQUIRE(x && dy && dw && ws && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)dy) % 16 == 0 && ((uintptr_t)ws) % 16 == 0,
-              "conv2d_s2_wgrad: missing / unaligned operand");
-  w8c_args g;
-  std::memset(&g, 0, sizeof(g));
-  int K, nc, kc, tm, tn;
-  w8c_plan(B, T1, F1, C, O, K, nc, kc, tm, tn);
-  w8_prob& q = g.p;
-  q.A = x; q.B = dy; q.C = nullptr; q.rowsum = nullptr; q.ws = ws; q.rs_ws = nullptr;
-  q.lda = C; q.ldb = O; q.ldc = O;
-  q.M = 9 * C; q.N = O; q.K = K;
-  q.tiles_m = tm; q.tiles_n = tn; q.nchunks = nc; q.kt_chunk = kc; q.flags = 0;
-  g.cv.C = C; g.cv.T1 = T1; g.cv.F1 = F1; g.cv.T2 = (T1 - 3) / 2 + 1; g.cv.F2 = (F1 - 3) / 2 + 1; g.cv.ld = C;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gemm_w8c_kernel, dim3((unsigned)(tm * tn * nc)), dim3(768), 0, st, g);
-  S2S_CHECK_LAUNCH("gemm_w8c_kernel");
-  hipLaunchKernelGGL(w8c_reduce_kernel, dim3((unsigned)((C + 7) / 8), (unsigned)((O + 63) / 64)), dim3(256), 0, st, ws, nc, C, O, dw, accumulate);
-  S2S_CHECK_LAUNCH("w8c_reduce_kernel");
   return 0;
 }
 

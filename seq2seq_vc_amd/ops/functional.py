@@ -1269,23 +1269,7 @@ class _Conv2dS2(Function):
         dy = _c(dy) if ctx.grad_premasked else K.act_dropout_bwd(_c(dy), y, act="relu")
         dw = db = None
         if weight.requires_grad:
-            w8c = K.conv2d_s2_wgrad_supported(x, O) and dy.is_contiguous() and x.is_contiguous()
-
-            def work_w8():
-                # the loader-specialised 8-wave tile with an implicit-im2col operand: partial tiles per K chunk, then ONE launch that adds
-                # them and writes dW in the parameter's layout straight into its gradient slot (no permuted temporary, gather, axpby)
-                slot = getattr(weight, "_s2s_grad", None)
-                dbv = None
-                if bias is not None and bias.requires_grad:
-                    dbv, _ = _reduce_to(bias, None, 0, dy.view(M2, O))
-                if slot is not None and slot.is_contiguous():
-                    K.conv2d_s2_wgrad(x, dy, slot.view(O, C, 3, 3), True)
-                    return None, dbv
-                return K.conv2d_s2_wgrad(x, dy, torch.empty((O, C, 3, 3), dtype=torch.float32, device=x.device), False), dbv
-
             def work():
-                if w8c:
-                    return work_w8()
                 dwp = torch.empty((O, 9 * C), dtype=torch.float32, device=x.device)
                 rs, racc, dbv = _bias_sink(bias, O)
                 tile, sk = K.plan_gemm(O, 9 * C, M2)

@@ -417,25 +417,6 @@ def launch_group(descs, tile=128):
     _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(descs), tile, stream()), "s2svc_gemm_grouped")
 
 
-def conv2d_s2_wgrad_supported(x, O):
-    B, T1, F1, C = x.shape
-    return x.dtype == torch.bfloat16 and bool(_lib.lib().s2svc_conv2d_s2_wgrad_supported(B, T1, F1, C, O))
-
-
-def conv2d_s2_wgrad(x, dy, dw, accumulate):
-    """dW (O, C, 3, 3) fp32 (+)= conv2d weight gradient of the 3x3 stride-2 convolution from x (B, T1, F1, C) and dy (B, T2, F2, O),
-    bf16 (csrc/gemm_8ph.hip: gemm_w8c_kernel + w8c_reduce_kernel)."""
-    B, T1, F1, C = x.shape
-    O = dy.shape[-1]
-    L = _lib.lib()
-    ws = torch.empty(L.s2svc_conv2d_s2_wgrad_ws_floats(B, T1, F1, C, O), dtype=torch.float32, device=x.device)
-    if _Audit.on and accumulate:
-        _audit_write("conv2d weight gradient", dw.data_ptr())
-    _lib.check(L.s2svc_conv2d_s2_wgrad(B, T1, F1, C, O, ptr(x), ptr(dy), ptr(dw), 1 if accumulate else 0, ptr(ws), stream()),
-               "s2svc_conv2d_s2_wgrad")
-    return dw
-
-
 def launch_wgrad_group(descs, bg_stream=None, bg_wgs=0):
     """The listed weight-gradient problems (every one s2svc_gemm_wgrad_ok) on the ragged 8-wave kernel, one grid per <= 40 of
     them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`).

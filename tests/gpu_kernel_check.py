@@ -1353,47 +1353,6 @@ def gemm_w8_ragged_weight_gradients():
 
 
 @case
-def conv2d_s2_wgrad_w8():
-    """s2svc_conv2d_s2_wgrad (gemm_w8c_kernel: the loader-specialised 8-wave tile with an implicit-im2col operand, K chunks, + the
-    reduction launch that writes dW in the parameter's layout): VTN's front-end shape (32 x 127 x 39 x 384 -> 384, K = 38304 = 598.5 K
-    tiles) and a ragged one (72 -> 40 channels: partial row / column tiles), accumulating and not, against torch's conv2d weight
-    gradient on the bf16-rounded operands (fp32), and against the 4-wave split-K path it replaces."""
-    res = []
-    for (B, T1, F1, C, O, seed) in ((32, 127, 39, 384, 384, 1), (8, 63, 39, 72, 40, 2)):
-        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
-        x = rnd(B, T1, F1, C, seed=seed, dtype=torch.bfloat16)
-        dy = rnd(B, T2, F2, O, seed=seed + 10, dtype=torch.bfloat16)
-        ok = K.conv2d_s2_wgrad_supported(x, O)
-        res.append((ok, f"conv2d wgrad W8 takes B{B} {T1}x{F1} C{C} O{O}"))
-        if not ok:
-            continue
-        xt = x.float().permute(0, 3, 1, 2).contiguous()
-        w = torch.zeros(O, C, 3, 3, device=DEV, requires_grad=True)
-        torch.nn.functional.conv2d(xt, w, stride=2).backward(dy.float().permute(0, 3, 1, 2))
-        ref = w.grad
-        sc = float(ref.abs().max())
-        dw = torch.full((O, C, 3, 3), float("nan"), device=DEV)
-        K.conv2d_s2_wgrad(x, dy, dw, False)
-        res.append(check(f"conv2d wgrad W8 B{B} C{C} O{O} (=)", dw, ref, torch.float32, rtol=1e-3, atol=3e-4 * sc))
-        dw0 = rnd(O, C, 3, 3, seed=seed + 20)
-        dwa = dw0.clone()
-        K.conv2d_s2_wgrad(x, dy, dwa, True)
-        res.append(check(f"conv2d wgrad W8 B{B} C{C} O{O} (+=)", dwa, dw0 + ref, torch.float32, rtol=1e-3, atol=3e-4 * sc))
-        dw2 = torch.empty_like(dw)
-        K.conv2d_s2_wgrad(x, dy, dw2, False)
-        res.append((bool(torch.equal(dw, dw2)), f"conv2d wgrad W8 B{B} C{C} O{O}: repeated launches agree bit for bit"))
-        M2 = B * T2 * F2
-        dwp = torch.empty((O, 9 * C), dtype=torch.float32, device=DEV)
-        tile, sk = K.plan_gemm(O, 9 * C, M2)
-        K.gemm(K.operand(dy, O, layout=K.RC), K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M2, dwp,
-               in_dtype=torch.bfloat16, splitk=sk, tile=tile)
-        old = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32).view(O, C, 3, 3)
-        d = float((old - dw).abs().max())
-        res.append((d <= 1e-3 * sc, f"conv2d wgrad W8 vs the 4-wave split-K path: max diff {d:.3e} (scale {sc:.1f})"))
-    return res
-
-
-@case
 def bn_two_launch_statistics():
     """s2svc_bn_stats (the second reduction stage folded into the finalisation: 2 launches instead of 3) against the
     three-launch composition it replaces -- colreduce(mode 6) + bn_finalize -- incl. the running statistics, and against

@@ -151,10 +151,6 @@ def main():
                  bench(lambda: K.gemm(K.operand(dy, O, layout=K.RC),
                                       K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M, dwp,
                                       in_dtype=dtype, splitk=sk, tile=tile), a.iters))
-        if dtype == torch.bfloat16 and K.conv2d_s2_wgrad_supported(x, O):
-            dwn = torch.zeros(O, C, 3, 3, dtype=torch.float32, device=dev)
-            line("wgrad vtn conv2d implicit, loader-specialised W8 (K chunks + reduce into the parameter layout)", O, 9 * C, M,
-                 bench(lambda: K.conv2d_s2_wgrad(x, dy, dwn, True), a.iters))
     # AAS-VC decoder weight gradients (4096 rows, d = 1536): un-grouped on the 8-wave kernel vs the 4-wave kernel, with the fused
     # bias row-sums; and five layers' worth as one grouped launch
     if (not a.filter or a.filter in "aas wgrad 8-wave") and dtype == torch.bfloat16:
