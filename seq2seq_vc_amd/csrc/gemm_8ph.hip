@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
 // ---------------------------------------------------------------------------------------------------------
 // BN = 128: 2 phases per K tile (wave tile 128 x 32: a phase = 64 rows x 32 columns x K 64)
 // ---------------------------------------------------------------------------------------------------------
-template <int KA, bool STAGGER, bool LEAN = false>
+template <int KA, bool STAGGER, int LEAN = 0>            // LEAN: 0 = the general epilogue, 1 = the common one, 2 = the Swish pair
 __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc d) {
   constexpr int UNIT = 16384, BUF = 3 * UNIT;            // A.m0 | A.m1 | B
   __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
@@ -463,7 +463,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
   for (int a = 0; a < 2; ++a) {          // rolled: one copy of the flush code (see epilogue_stage)
     if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
     else epilogue_stage<64, 32>(acc[1], cs);
-    if (LEAN) epilogue_flush_common<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);       // (gemm_common.h: a fraction of the code)
+    if (LEAN == 2) epilogue_flush_swish<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
+    else if (LEAN == 1) epilogue_flush_common<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);       // (gemm_common.h: a fraction of the code)
     else epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, cs, 1, 0, zb);
   }
 }
@@ -1539,7 +1540,9 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   if (lean_on && !conv && !tconv && mode != 2 && epilogue_common_ok(d)) {       // dense operands + the common epilogue: lean variants
     if (geo == 1) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_DENSE, 2, 4, true, true>), grid, dim3(512), 0, st, d);
     else if (geo == 2) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_DENSE, 4, 2, true, true>), grid, dim3(512), 0, st, d);
-    else hipLaunchKernelGGL((gemm_8ph_kernel_128<P8_DENSE, true, true>), grid, dim3(512), 0, st, d);
+    else hipLaunchKernelGGL((gemm_8ph_kernel_128<P8_DENSE, true, 1>), grid, dim3(512), 0, st, d);
+  } else if (lean_on && geo == 3 && !conv && !tconv && mode != 2 && !getenv_off("S2SVC_GEMM_LEAN_SWISH") && epilogue_swish_ok(d)) {        // the Conformer feed-forward pair
+    hipLaunchKernelGGL((gemm_8ph_kernel_128<P8_DENSE, true, 2>), grid, dim3(512), 0, st, d);
   } else if (geo == 1) P8_LAUNCH(gemm_8ph_kernel_q, 2, 4);
   else if (geo == 2) P8_LAUNCH(gemm_8ph_kernel_q, 4, 2);
   else P8_LAUNCH(gemm_8ph_kernel_128);

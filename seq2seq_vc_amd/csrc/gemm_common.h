@@ -349,6 +349,80 @@ __device__ __forceinline__ void epilogue_flush_common(const s2svc_gemm_desc& d, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The SWISH epilogues of the Conformer feed-forward blocks (bf16, one problem): forward = bias, pre-activation as a second
+// output (c_pre), Swish, dropout; data gradient through w_2 = dropout mask x swish'(pre-activation) (emask mode 1).  The general
+// flush spends ~9 us per 4096 x 1536 output on them (IEEE divisions, expf, its 19 KB of code) -- 32 launches per AAS-VC step;
+// here the sigmoid is v_exp_f32 + v_rcp_f32 (1 ulp; the results are rounded to bf16) and nothing else is carried.
+// ---------------------------------------------------------------------------------------------------------
+inline bool epilogue_swish_ok(const s2svc_gemm_desc& d) {
+  if (d.c_dtype != S2S_BF16 || d.nb0 * d.nb1 != 1 || d.splitk > 1 || d.alpha != 1.0f || d.c_map || d.accumulate || d.res) return false;
+  if (d.N % 8 || d.ldc % 8 || ((uintptr_t)d.C) % 16) return false;
+  const bool fwd = d.act == S2S_ACT_SWISH && d.c_pre && !d.emask && ((uintptr_t)d.c_pre) % 16 == 0;
+  const bool bwd = d.act == S2S_ACT_NONE && !d.c_pre && d.emask && d.emask_mode == 1 && d.ldm % 8 == 0 && ((uintptr_t)d.emask) % 16 == 0;
+  return fwd || bwd;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_flush_swish(const s2svc_gemm_desc& d, int m_base, int n_base, const float* cs) {
+  const int lane = threadIdx.x & 63;
+  constexpr int LPR = WTN / 8, RPP = 64 / LPR;
+#pragma unroll 1
+  for (int p = 0; p < WTM / RPP; ++p) {
+    const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
+    const int m = m_base + row, n = n_base + col;
+    if (m >= d.M || n >= d.N) continue;
+    const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
+    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (d.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (d.c_pre) {                       // forward: the pre-activation leaves as it is, then Swish
+      uint4 o;
+      o.x = f2bf2(v[0], v[1]);
+      o.y = f2bf2(v[2], v[3]);
+      o.z = f2bf2(v[4], v[5]);
+      o.w = f2bf2(v[6], v[7]);
+      *reinterpret_cast<uint4*>((bf16_t*)d.c_pre + (int64_t)m * d.ldc + n) = o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= fast_sigmoid(v[e]);
+    }
+    if (d.drop_p > 0.f) {
+      const uint64_t seed = (d.seed_base ? *d.seed_base : 0ull) + d.seed_off;
+      const float inv_keep = 1.f / (1.f - d.drop_p);
+      const uint64_t idx = (uint64_t)((int64_t)m * d.N + n);
+      const uint32_t thr = dropout_threshold(d.drop_p);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint64_t r = dropout_draw(seed, (idx >> 2) + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] *= ((uint32_t)(r >> (16 * e)) & 0xffffu) < thr ? 0.f : inv_keep;
+      }
+    }
+    if (d.emask) {                       // data gradient: x swish'(pre-activation)
+      const uint4 ev = *reinterpret_cast<const uint4*>((const bf16_t*)d.emask + (int64_t)m * d.ldm + n);
+      const uint32_t w[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u0 = __uint_as_float(w[e] << 16), u1 = __uint_as_float(w[e] & 0xffff0000u);
+        const float s0 = fast_sigmoid(u0), s1 = fast_sigmoid(u1);
+        v[2 * e] *= s0 * (1.f + u0 * (1.f - s0));
+        v[2 * e + 1] *= s1 * (1.f + u1 * (1.f - s1));
+      }
+    }
+    uint4 o;
+    o.x = f2bf2(v[0], v[1]);
+    o.y = f2bf2(v[2], v[3]);
+    o.z = f2bf2(v[4], v[5]);
+    o.w = f2bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>((bf16_t*)d.C + (int64_t)m * d.ldc + n) = o;
+  }
+}
+
 // the fp32 counterpart (the duration predictor's Linear layers and their gradients: bias, ReLU, fp32 residual, accumulation into
 // a gradient slot; no dropout / mask)
 inline bool epilogue_common32_ok(const s2svc_gemm_desc& d) {       // (split-K: the kernel stores raw partials, see epilogue_partials)

@@ -1164,6 +1164,48 @@ def gemm_8phase():
 
 
 @case
+def gemm_8phase_swish_epilogues():
+    """The Swish epilogue pair of the 8-wave 256 x 128 kernel (epilogue_flush_swish: forward = bias, pre-activation output, Swish,
+    dropout; data gradient = dropout mask x swish'(pre-activation)) at the Conformer feed-forward shapes of AAS-VC (4096 x 1536 x 1536
+    decoder, 4096 x 1536 x 384 encoder): values against fp32 torch, the dropout mask of the backward launch equal to the forward's
+    (same seed), kept elements scaled by 1 / (1 - p)."""
+    res = []
+    dtype = torch.bfloat16
+    for (M, N, Kd, seed) in ((4096, 1536, 1536, 1), (4096, 1536, 384, 2)):
+        a, w = rnd(M, Kd, seed=seed, dtype=dtype), rnd(N, Kd, seed=seed + 10, dtype=dtype, scale=0.05)
+        b = rnd(N, seed=seed + 20, scale=0.1)
+        z = a.float() @ w.float().t() + b
+        sd = K.new_seed(a.device)
+        outs = {}
+        for p_drop in (0.0, 0.25):
+            y = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+            pre = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+            K.gemm(K.operand(a, Kd), K.operand(w, Kd), M, N, Kd, y, in_dtype=dtype, bias=b, act="swish", drop_p=p_drop, seed=sd, pre_out=pre)
+            dy = rnd(M, Kd, seed=seed + 30, dtype=dtype)
+            du = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+            K.gemm(K.operand(dy, Kd), K.operand(w, Kd), M, N, Kd, du, in_dtype=dtype, emask=pre, emask_mode=1, drop_p=p_drop, seed=sd)
+            outs[p_drop] = (y, pre, du)
+        y0, pre0, du0 = outs[0.0]
+        res.append(check(f"8-phase swish fwd {M}x{N}x{Kd}: pre-activation", pre0, z, dtype))
+        res.append(check(f"8-phase swish fwd {M}x{N}x{Kd}: output", y0, z * torch.sigmoid(z), dtype))
+        u = pre0.float()
+        sg = torch.sigmoid(u)
+        g = dy.float() @ w.float().t()
+        res.append(check(f"8-phase swish' data gradient {M}x{N}x{Kd}", du0, g * sg * (1 + u * (1 - sg)), dtype))
+        y1, pre1, du1 = outs[0.25]
+        res.append((bool(torch.equal(pre1, pre0)), f"8-phase swish {M}x{N}x{Kd}: the pre-activation does not depend on the dropout"))
+        keep = y1 != 0
+        frac = 1.0 - float(keep.float().mean())
+        res.append((abs(frac - 0.25) < 0.01 + float((y0 == 0).float().mean()), f"8-phase swish {M}x{N}x{Kd}: dropped fraction {frac:.4f} (p = 0.25)"))
+        res.append(check(f"8-phase swish {M}x{N}x{Kd}: kept outputs scaled by 1 / (1 - p)", y1, torch.where(keep, y0.float() / 0.75, torch.zeros_like(z)), dtype))
+        both = (du0 != 0) & (y0 != 0)
+        same_mask = float(((du1 != 0) == keep)[both].float().mean())
+        res.append((same_mask == 1.0, f"8-phase swish {M}x{N}x{Kd}: backward mask == forward mask on {same_mask:.6f} of the elements"))
+        res.append(check(f"8-phase swish' {M}x{N}x{Kd}: kept gradients scaled by 1 / (1 - p)", du1, torch.where(du1 != 0, du0.float() / 0.75, torch.zeros_like(z)), dtype))
+    return res
+
+
+@case
 def gemm_8phase_weight_gradients():
     """The 8-wave kernel for row-contiguous operands (gemm_8ph_tr_kernel: C (+)= dY^T . X on 256 x 128 tiles, transpose reads,
     bias row-sums as MFMA products with a ones fragment): single launches (odd / even K-tile counts, a single K-tile pair,

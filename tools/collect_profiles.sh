@@ -62,6 +62,7 @@ printf "$HDR\n" > "$OUT/step_mfma_busy.txt"
 for wl in vtn aasvc; do
   prof /tmp/prof_busy_$wl --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d /tmp/prof_busy_$wl -o r -- python "$R/bench.py" --workload $wl --no-graph --no-cpu-baseline --no-extras --steps 8 --warmup 2
   python tools/step_mfma_busy.py $wl "$(db /tmp/prof_busy_$wl)" >> "$OUT/step_mfma_busy.txt" 2>&1
+  python tools/step_mfma_busy.py $wl "$(db /tmp/prof_busy_$wl)" by-grid >> "$OUT/step_mfma_busy_by_grid.txt" 2>&1
 done
 python tools/gemm_bench.py --filter "vtn wgrad grouped w8" > "$OUT/w8_grouped_bench.txt" 2>&1
 (python tools/bench_trainer.py --workload aasvc --accum 8 --batch 2 --steps 64 | tail -1) > "$OUT/bench_trainer_accum8.json" 2>> "$OUT/bench.err"
