@@ -29,6 +29,19 @@ def test_abi_library_loads_and_exports_declared_symbols():
         assert sym in declared or sym in ("s2svc_last_error", "s2svc_abi_version"), f"{sym} missing from the header"
 
 
+def test_shipped_library_holds_no_packed_fp32_instructions():
+    """The library is built without the SLP / loop vectorisers: SLP-formed v_pk_{add,mul,fma}_f32 code gave a wrong high-half
+    result in the last 16-lane quarter of a partially active wave, rarely and only inside a full training step (DESIGN.md
+    section 4; tools/repro_spline_slp.py).  Whatever the build flags say, the machine code must hold none of them."""
+    from tools import check_no_packed_f32 as chk
+    if not os.path.exists(chk.OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    from seq2seq_vc_amd import _lib
+    _lib.lib()                                                     # builds the library if it is missing
+    total, per_kernel = chk.count(os.path.join(ROOT, "seq2seq_vc_amd", "csrc", "libs2svc_hip.so"))
+    assert not total, f"packed fp32 instructions in the shipped library: {total} in {list(per_kernel)[:5]}"
+
+
 def test_product_path_fails_loudly_without_gpu():
     from seq2seq_vc_amd.ops import kernels as K
     if torch.cuda.is_available():
