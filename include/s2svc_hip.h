@@ -146,7 +146,7 @@ int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs /* host */, int n, v
 /* RAGGED weight gradients on the 8-wave kernel (csrc/gemm_8ph.hip, "W8"): C[M, N] fp32 (+)= A^T . B for dense row-contiguous bf16
    operands with M % 8 == N % 8 == 0 and ANY K (the Linear weight gradients dW = dY^T . X of the backward pass,
    /root/reference trainers/ar_vc.py:99-107: loss.backward() fills every parameter's .grad), as ONE grid of (problem, K chunk,
-   256 x 128 tile) units, up to 40 problems per launch.  A reduction longer than 32 K tiles of 64 rows is cut into chunks -- a
+   256 x 128 tile) units, up to 40 problems per launch.  A reduction longer than 64 K tiles of 64 rows is cut into chunks -- a
    function of K only -- whose fp32 partial tiles go through `ws` and are added in chunk order by a second launch (deterministic).
      _ok        : 1 if the kernel takes `desc` (a function of the descriptor only; exact-256 problems with >= 64 tiles of
                   128 x 128 stay with s2svc_gemm_grouped's 8-wave path);
@@ -158,7 +158,7 @@ int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs /* host */, int n, flo
 /* the same as a BACKGROUND launch: at most `wgs_cap` workgroups walk the units (a quarter of the CUs, say) on `stream` and leave the
    rest of the chip to the kernels of the stream beside it; same sums, same bits (wgs_cap <= 0: one workgroup per unit) */
 int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, float* ws, void* stream, int wgs_cap);
-/* A/B switch (tests, benchmarks): on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles of 64 rows per chunk (<= 0: unchanged; default 32,
+/* A/B switch (tests, benchmarks): on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles of 64 rows per chunk (<= 0: unchanged; default 64,
    S2SVC_GEMM_W8 / S2SVC_W8_KT_CHUNK); returns the previous on | kt_chunk << 8. */
 int s2svc_gemm_set_w8(int on, int kt_chunk);
 int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream, void* bg_stream, int bg_cus,

@@ -1617,12 +1617,14 @@ int w8_mode() {       // S2SVC_GEMM_W8=0 / s2svc_gemm_set_w8: these problems sta
   return g_w8_mode;
 }
 int w8_kt_chunk_env() {   // S2SVC_W8_KT_CHUNK / s2svc_gemm_set_w8: K tiles (of 64 rows) per chunk; reductions up to this long run unsplit
-  if (g_w8_kt < 0) { const char* e = getenv("S2SVC_W8_KT_CHUNK"); g_w8_kt = e ? atoi(e) : 32; if (g_w8_kt < 1) g_w8_kt = 1; }
+  if (g_w8_kt < 0) { const char* e = getenv("S2SVC_W8_KT_CHUNK"); g_w8_kt = e ? atoi(e) : 64; if (g_w8_kt < 1) g_w8_kt = 1; }
   return g_w8_kt;
 }
 // the chunking of a reduction: a function of the problem's OWN shape only (see the kernel's header) -- outputs of >= 64 tiles fill the
 // chip unsplit (and their partial tiles would be hundreds of MB of workspace traffic: AAS-VC's 4608 x 1536 gradients), smaller ones
-// are cut by K
+// are cut by K.  Chunk length 64 K tiles (4096 rows): measured in the steps -- VTN's 2016 / 2048-row reductions are one chunk at 32 or 64
+// (3.80 ms either way; 16 / 8 / 4: 3.87 / 3.94 / 4.10), AAS-VC's 4096-row reductions run unsplit at 64 (11.47 vs 11.68 ms at 32: no
+// partial tiles, no reduction launch; 128: the same)
 void w8_chunks(int M, int N, int K, int& nchunks, int& kt_chunk) {
   const int ktiles = (K + 63) / 64;
   if ((int64_t)((M + 255) / 256) * ((N + 127) / 128) >= 64) {
