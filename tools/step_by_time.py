@@ -5,7 +5,9 @@ headline roofline times is a few percent of the VTN step; this names where the t
     python tools/step_by_time.py <round prefix, e.g. r04>
 
 Inputs (committed summaries, made by tools/collect_profiles.sh on a GPU box):
-    profiles/<r>_{vtn,aasvc}_train_bf16_kernel_stats.txt   rocprofv3 --kernel-trace --stats of bench.py (tools/rocpd_stats.py)
+    profiles/<r>_{vtn,aasvc}_train_bf16_timeline.txt       ONE step's launch sequence of a rocprofv3 --kernel-trace run of bench.py
+                                                           (tools/rocpd_timeline.py; falls back to the per-kernel table
+                                                           <r>_..._kernel_stats.txt, which also holds the dominant-kernel loop)
     profiles/<r>_step_mfma_busy.txt                        SQ_VALU_MFMA_BUSY_CYCLES pass over whole steps (tools/step_mfma_busy.py)
 """
 import json
@@ -48,6 +50,24 @@ def kernel_stats(path):
     return fam, total
 
 
+def timeline_stats(path):
+    """family -> [launches, us] of ONE step, from the launch sequence tools/rocpd_timeline.py wrote (the kernel-stats table of the same
+    profiling run also holds the dominant-kernel loop and the sub-benchmarks of bench.py: the timeline is the step and nothing else)"""
+    rows = []
+    for line in open(path):
+        m = re.match(r"\s*[0-9.]+ \S+\s+dur\s+([0-9.]+) gap\s+-?[0-9.]+ idle\s+[0-9.]+\s+(\S.*)", line)
+        if m:
+            rows.append((m.group(2).strip(), float(m.group(1))))
+    names = demangle([n if n.startswith("_Z") else "_ZN12_GLOBAL__N_1" + n for n, _ in rows])
+    fam, total = {}, 0.0
+    for (_, us), n in zip(rows, names):
+        f = fam.setdefault(family(n), [0, 0.0])
+        f[0] += 1
+        f[1] += us
+        total += us
+    return fam, total
+
+
 def mfma_busy(path, section):
     """launch-time-weighted MFMA busy per family from the '# <section>' block of <r>_step_mfma_busy.txt"""
     fam, on = {}, False
@@ -72,15 +92,21 @@ def main():
         ks = os.path.join(ROOT, "profiles", f"{r}_{wl}_train_bf16_kernel_stats.txt")
         if not os.path.exists(ks):
             continue
-        fam, total = kernel_stats(ks)
+        tl = os.path.join(ROOT, "profiles", f"{r}_{wl}_train_bf16_timeline.txt")
+        src = ks
+        if os.path.exists(tl):
+            fam, total = timeline_stats(tl)
+            src = tl
+        else:
+            fam, total = kernel_stats(ks)
         busy_path = os.path.join(ROOT, "profiles", f"{r}_step_mfma_busy.txt")
         busy = mfma_busy(busy_path, wl) if os.path.exists(busy_path) else {}
         top = sorted(fam.items(), key=lambda kv: -kv[1][1])
         name, (calls, us) = top[0]
         b = busy.get(name)
-        out[wl] = {"family": name, "share_of_kernel_time": us / total, "launches_in_profile": calls,
+        out[wl] = {"family": name, "share_of_kernel_time": us / total, "launches_per_step" if src != ks else "launches_in_profile": calls,
                    "mfma_busy": b[0] if b else None, "wait_per_wave": b[1] if b else None,
-                   "source": f"profiles/{r}_{wl}_train_bf16_kernel_stats.txt + profiles/{r}_step_mfma_busy.txt",
+                   "source": f"profiles/{os.path.basename(src)} + profiles/{r}_step_mfma_busy.txt",
                    "top5": [{"family": n, "share_of_kernel_time": u / total, "mfma_busy": (busy.get(n) or (None,))[0]} for n, (c, u) in top[:5]]}
     path = os.path.join(ROOT, "profiles", "step_by_time.json")
     with open(path, "w") as f:
