@@ -236,13 +236,18 @@ class OverlappedBackward:
 
     def _run_stage(self, i, losses, scale=None):
         roots = self.plan[i]["root"]
-        branch_root = self.plan[i].get("branch_root")           # a loss whose sub-network ran on the auxiliary stream
+        branch_root = self.plan[i].get("branch_root")           # a loss (or a cut) whose sub-network ran on the auxiliary stream
         fork = None
         if branch_root is not None and torch.cuda.is_available():
             fork = torch.cuda.Event()
             fork.record()                                        # before this stage queues anything: the branch starts here
         s = self.scale if scale is None else scale
-        if branch_root is not None:                              # first: the calling stream is still empty
+        if branch_root is not None and branch_root.startswith("cut:"):      # the rest of a branch below a cut of an earlier stage
+            if fork is not None:
+                Fn.branch_resume(self.cuts, branch_root[4:], fork)
+            else:
+                self.cuts.resume(branch_root[4:])
+        elif branch_root is not None:                            # first: the calling stream is still empty
             loss = losses.get(branch_root[5:])
             if loss is not None and loss.requires_grad:
                 loss = loss * s if s != 1.0 else loss

@@ -167,6 +167,8 @@ class AASVC(nn.Module):
         there; the main stream only gets the short alignment-module part), then "decoder" down to the encoder output on the
         calling stream, beside it; the stage ends with the join.  Stage 2 is the encoder.
 
+        Round 4: the stochastic predictor's two conditioning networks run in the LAST stage (cut "sdp_cond", see below).
+
         Why two stages and not one per decoder layer (round 2's plan: 3 of 4 layers in stage 1, `S2SVC_AAS_DP_H=1`): the duration
         branch's backward pass is ~350 small dependent launches that take 4.4 ms beside the decoder's GEMMs, a decoder layer's
         backward pass 1.2 ms -- with fewer than four layers beside it the branch is the critical path of the stage (measured on
@@ -181,10 +183,24 @@ class AASVC(nn.Module):
             side.append(self.duration_predictor_projection)
         h = int(os.environ.get("S2SVC_AAS_DP_H", "0"))        # decoder layers that get a stage of their own (tuning aid)
         h = max(0, min(h, len(dec) - 1))
+        last = {"root": "cut:encoder_out", "modules": [self.encoder]}
+        sdp = self.duration_predictor
+        # 0: no cut, 1: the network behind x, 2: both conditioning networks.  bench.py --workload aasvc --split-backward, one box, ms per
+        # staged step (stage graphs): 12.28 (9.49 + 1.45) / 12.00 (9.18 + 1.73) / 11.76-11.85 (8.87 + 1.91) against 11.46 for the one-graph step
+        sdp_cut = os.environ.get("S2SVC_AAS_DP_SDP_CUT", "2")
+        if self.duration_predictor_type == "stochastic" and sdp_cut != "0":
+            # Round 4: the duration branch's backward pass (~ 4 ms of small launches on the auxiliary stream) had become the critical path
+            # of stage 1 once the decoder's backward pass beside it got shorter; its last part -- the two conditioning networks
+            # below the "sdp_cond" cut (sdp.py) -- now runs in the LAST stage, on the auxiliary stream beside the encoder's backward
+            # pass, and their parameters travel with the encoder's bucket.
+            cond = [sdp.pre, sdp.dds, sdp.proj] + ([sdp.post_pre, sdp.post_dds, sdp.post_proj] if sdp_cut == "2" else [])
+            inner = {id(p) for m in cond for p in m.parameters()}
+            side = [m for m in side if m is not sdp] + [p for p in sdp.parameters() if id(p) not in inner]
+            last = {"root": "cut:encoder_out", "branch_root": "cut:sdp_cond" if sdp_cut == "2" else "cut:sdp_cond_x", "modules": [self.encoder] + cond}
         plan = [{"root": "loss:decoder", "branch_root": "loss:align", "modules": dec[h:] + tail + side}]
         for li in range(h, 0, -1):
             plan.append({"root": f"cut:decoder.{li}", "modules": [dec[li - 1]]})
-        plan.append({"root": "cut:encoder_out", "modules": [self.encoder]})
+        plan.append(last)
         return plan
 
     # ---------------------------------------------------------------------------------------------

@@ -367,6 +367,18 @@ def branch_backward(loss, fork_event, retain_graph=False):
         loss.backward(retain_graph=retain_graph)
 
 
+def branch_resume(cuts, name, fork_event):
+    """cuts.resume(name) rooted on the auxiliary stream (see branch_backward): the part of a branch below a gradient cut, run one
+    stage after the part above it."""
+    if _Branch.stream is None or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
+        cuts.resume(name)
+        return
+    _Branch.stream.wait_event(fork_event)
+    _Branch.dirty = True
+    with torch.cuda.stream(_Branch.stream):
+        cuts.resume(name)
+
+
 def branch_wait():
     """The current stream waits for what has been queued on the auxiliary stream (end of a stage that used branch_backward)."""
     if _Branch.stream is not None and os.environ.get("S2SVC_NO_BRANCH", "0") != "1":

@@ -195,6 +195,12 @@ class StochasticDurationPredictor(nn.Module):
         w = w.detach().float().contiguous()
         h_w = FS.expand(w, self.post_pre.weight, self.post_pre.bias, None, lens)
         h_w = FS.mask_rows(Fn.linear(self.post_dds(h_w, lens), self.post_proj.weight, self.post_proj.bias), lens)
+        # gradient cut for the staged (data-parallel) backward pass: the two conditioning networks above -- input projection, DDS
+        # stack, output projection, each -- are the last ~ 80 launches of this branch's backward pass and depend on nothing but the
+        # gradients the flows accumulate in x and h_w: a stage plan may run them one stage later, beside the encoder's backward
+        # pass (models/aas_vc.py: dp_plan).  Inactive (identity) outside distributed.OverlappedBackward.
+        x, h_w = Fn.cut_point((x, h_w), "sdp_cond")              # both networks one stage later
+        x = Fn.cut_point(x, "sdp_cond_x")                        # only the one behind x (the plan names ONE of the two cuts)
         g_q = Fn.add_dropout(x, h_w, 0.0)
         noise = self._randn((B, 2, T), x.device)
         shared = FS.Shared()
