@@ -51,16 +51,30 @@ class _ARSeq2Seq(nn.Module):
         tail = [m for m in (getattr(enc, "after_norm", None),) if m is not None]
         embed = [m for n, m in enc.named_children() if n not in ("encoders", "after_norm")]
         h = len(layers) // 2
+        head_stage = {}
+        if _HEAD_START and os.environ.get("S2SVC_VTN_DP_HEAD_CUT", "1") != "0":
+            # Round 4: the decoder's head (input layer + positional encoding + the first layer's self-attention block: what ran on the
+            # auxiliary stream beside the encoder) is cut off the decoder's stage: its backward pass runs in the ENCODER's stage, on the
+            # auxiliary stream beside the layer stack's, as it does in the one-graph step; its parameters travel with that bucket.
+            d0 = self.decoder.decoders[0]
+            hm = [self.decoder.embed, d0.self_attn, d0.norm1] + ([d0.norm2] if d0.normalize_before else [])
+            hp = {id(p) for m in hm for p in m.parameters()}
+            dec_side = [p for m in dec_side for p in m.parameters() if id(p) not in hp]
+            head_stage = {"branch_root": "cut:decoder_head", "head": hm}
         if h == 0 or not embed:
-            return [{"root": "loss:loss", "modules": dec_side}, {"root": "cut:encoder_out", "modules": [enc]}]
+            return [{"root": "loss:loss", "modules": dec_side},
+                    dict({"root": "cut:encoder_out", "modules": [enc] + head_stage.get("head", [])},
+                         **({"branch_root": head_stage["branch_root"]} if head_stage else {}))]
         enc.cut_name = "encoder"            # names the cut points inside Encoder.forward / run_stack
         if os.environ.get("S2SVC_VTN_DP_SPLIT", "0") == "1":
             return [{"root": "loss:loss", "modules": dec_side},
-                    {"root": "cut:encoder_out", "modules": layers[h:] + tail},
+                    dict({"root": "cut:encoder_out", "modules": layers[h:] + tail + head_stage.get("head", [])},
+                         **({"branch_root": head_stage["branch_root"]} if head_stage else {})),
                     {"root": f"cut:encoder.{h}", "modules": layers[:h]},
                     {"root": "cut:encoder.0", "modules": embed}]
         return [{"root": "loss:loss", "modules": dec_side},
-                {"root": "cut:encoder_out", "modules": layers + tail},
+                dict({"root": "cut:encoder_out", "modules": layers + tail + head_stage.get("head", [])},
+                     **({"branch_root": head_stage["branch_root"]} if head_stage else {})),
                 {"root": "cut:encoder.0", "modules": embed}]
 
     def _decoder_head(self, ys, olens, labels=None):
@@ -107,6 +121,10 @@ class _ARSeq2Seq(nn.Module):
         olens_h, olens_in_h, ys_in, head, stop = pre if pre is not None else self._decoder_head(ys, olens)
         if head is not None:
             Fn.branch_join(*head, ys_in, stop)
+            # gradient cut for the staged (data-parallel) backward pass: the head's backward pass -- the last thing of the decoder's,
+            # on the auxiliary stream -- overlaps the encoder's in the one-graph step; a stage plan may run it in the encoder's stage
+            # (dp_plan).  Identity outside distributed.OverlappedBackward.
+            head = Fn.cut_point(tuple(head), "decoder_head")
             zs, _ = self.decoder(None, olens_in_h, hs, hs_lens, causal=True, head=head)
         else:
             zs, _ = self.decoder(Fn.to_compute(ys_in), olens_in_h, hs, hs_lens, causal=True)
