@@ -205,6 +205,15 @@ typedef struct {
   int32_t reserved_;
 } s2svc_colreduce_item;
 int s2svc_colreduce_grouped(const s2svc_colreduce_item* items /* host */, int n, void* stream);
+/* LayerNorm backward (layer_norm.py:12-42 under autograd) together with the FIRST reduction stage of its parameter gradients
+   (round 4): the launch also writes `chunks` partial row pairs ws[chunk][2][D] (sum of dy | sum of dy * xhat over the chunk's
+   rows), which enter s2svc_colreduce_grouped as an item of mode 7 (partials ready: ws, ws_chunks = chunks, D, out_sum = d beta,
+   out_dot = d gamma).  _pg_chunks: 0 = not eligible (use s2svc_layernorm_bwd and a mode-1 reduction), else the chunk count. */
+int s2svc_layernorm_bwd_pg_chunks(int dtype, int rows, int D, const void* dy, const void* s, const float* gamma, const void* ds_extra,
+                                  const void* ds, const void* dh);
+int s2svc_layernorm_bwd_pg(int dtype, int rows, int D, const void* dy, const void* s, const float* mean, const float* rstd,
+                           const float* gamma, const void* ds_extra, float drop_p, float hscale, const uint64_t* seed_base,
+                           uint64_t seed_off, void* ds, void* dh, float* ws, void* stream);
 int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean, const float* var, float* rstd,
                       float* run_mean, float* run_var, int64_t* num_batches, int var_is_ex2 /* var = E[x^2], colreduce mode 6 */,
                       void* stream);

@@ -230,16 +230,15 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(int rows, int D, const 
   }
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(int rows, int D, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s,
-                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ gamma, const bf16_t* __restrict__ ds_extra,
-                                                         float p, float hscale, const uint64_t* seed_base, uint64_t seed_off,
-                                                         bf16_t* __restrict__ ds, bf16_t* __restrict__ dh) {
-  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+// one row of the vectorised LayerNorm backward pass (a wave per row, a lane owns 8 consecutive channels per 512-channel group);
+// PG: also adds the row's contribution to the parameter gradients (d beta += dy, d gamma += dy * xhat) into the lane's accumulators
+template <int NV, bool PG>
+__device__ __forceinline__ void ln_bwd_vec_row(int row, int D, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s,
+                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                               const float* __restrict__ gamma, const bf16_t* __restrict__ ds_extra, float p, float hscale,
+                                               uint64_t seed, bf16_t* __restrict__ ds, bf16_t* __restrict__ dh, float (&accb)[NV][8],
+                                               float (&accg)[NV][8]) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
   const int64_t base = (int64_t)row * D;
   const float mu = mean[row], rs = rstd[row];
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
@@ -264,8 +263,12 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(int rows, int D, const 
       load_f32x8(gamma + c, gm);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        g[i][e] *= gm[e];
         xh[i][e] = (xh[i][e] - mu) * rs;
+        if (PG) {
+          accb[i][e] += g[i][e];
+          accg[i][e] += g[i][e] * xh[i][e];
+        }
+        g[i][e] *= gm[e];
         a += g[i][e];
         b += g[i][e] * xh[i][e];
       }
@@ -298,6 +301,65 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(int rows, int D, const 
   }
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(int rows, int D, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const bf16_t* __restrict__ ds_extra,
+                                                         float p, float hscale, const uint64_t* seed_base, uint64_t seed_off,
+                                                         bf16_t* __restrict__ ds, bf16_t* __restrict__ dh) {
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float nb[NV][8], ng[NV][8];               // (unused without PG)
+  ln_bwd_vec_row<NV, false>(row, D, dy, s, mean, rstd, gamma, ds_extra, p, hscale, seed, ds, dh, nb, ng);
+}
+
+// The same backward pass WITH the parameter gradients' first reduction stage (round 4): a block of 8 waves owns 8 * rpw consecutive rows
+// (a wave rpw of them, one after the other), every lane adds dy and dy * xhat of its channels over its rows in registers, the eight
+// waves' sums are combined through LDS in wave order and the block writes ONE partial row pair ws[block][2][D] -- the layout of
+// colreduce_stage1's chunk partials, so the (grouped) second stage finishes the job (colreduce mode 7 = "partials ready").  The separate
+// first stage re-read dy and the LayerNorm input: 25 MB per 4096 x 1536 site, 0.29 ms of the AAS-VC step (timing-only build).
+template <int NV>
+__global__ __launch_bounds__(512) void ln_bwd_vec_pg_kernel(int rows, int D, int rpw, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ s,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const bf16_t* __restrict__ ds_extra,
+                                                            float p, float hscale, const uint64_t* seed_base, uint64_t seed_off,
+                                                            bf16_t* __restrict__ ds, bf16_t* __restrict__ dh, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float pg_sh[];      // [8 waves][2][Dp], Dp = NV * 512
+  constexpr int Dp = NV * 512;
+  const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float accb[NV][8], accg[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) accb[i][e] = accg[i][e] = 0.f;
+  const int row0 = ((int)blockIdx.x * 8 + wave) * rpw;
+  for (int j = 0; j < rpw; ++j)
+    if (row0 + j < rows) ln_bwd_vec_row<NV, true>(row0 + j, D, dy, s, mean, rstd, gamma, ds_extra, p, hscale, seed, ds, dh, accb, accg);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    float* qb = pg_sh + (wave * 2 + 0) * Dp + c;
+    float* qg = pg_sh + (wave * 2 + 1) * Dp + c;
+    *reinterpret_cast<float4*>(qb) = make_float4(accb[i][0], accb[i][1], accb[i][2], accb[i][3]);
+    *reinterpret_cast<float4*>(qb + 4) = make_float4(accb[i][4], accb[i][5], accb[i][6], accb[i][7]);
+    *reinterpret_cast<float4*>(qg) = make_float4(accg[i][0], accg[i][1], accg[i][2], accg[i][3]);
+    *reinterpret_cast<float4*>(qg + 4) = make_float4(accg[i][4], accg[i][5], accg[i][6], accg[i][7]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 512) {
+    float tb = pg_sh[c], tg = pg_sh[Dp + c];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {            // wave order: fixed
+      tb += pg_sh[(w * 2 + 0) * Dp + c];
+      tg += pg_sh[(w * 2 + 1) * Dp + c];
+    }
+    ws[((int64_t)blockIdx.x * 2 + 0) * D + c] = tb;
+    ws[((int64_t)blockIdx.x * 2 + 1) * D + c] = tg;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Chunked column reduction over rows of a (rows, D) matrix, deterministic (fixed summation order):
 //   mode 0: sum[c] = S dy[r,c]
@@ -306,6 +368,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(int rows, int D, const 
 //   mode 3: sum[c] = S (x[r,c]-mean[c])^2                                        (BatchNorm variance)
 //   mode 4: sum[c] = S dy[r,c]*x[r,c]                                            (posenc alpha etc.)
 //   mode 6: sum[c] = S x[r,c];  dot[c] = S x[r,c]^2                              (BatchNorm mean and E[x^2] in ONE pass)
+//   mode 7 (grouped launch only): the chunk partials are already in ws[ws_chunks][2][D] (ln_bwd_vec_pg_kernel): stage 2 only
 // stage 1 writes ws[chunk][2][D]; stage 2 sums the chunks and multiplies by `scale`.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -504,7 +567,7 @@ __global__ __launch_bounds__(256) void colreduce_grouped_stage1(const cr_args a)
   __shared__ float sh[2][4][64];
   __shared__ float shv[2][4][512];
   const s2svc_colreduce_item& it = a.it[blockIdx.z];
-  if ((int)blockIdx.y >= a.chunks[blockIdx.z]) return;
+  if (it.mode == 7 || (int)blockIdx.y >= a.chunks[blockIdx.z]) return;
   if (cr_vec_ok(it.dtype, it.D, it.dy, it.x)) {          // (uniform) 16-byte variant: 512 columns per workgroup
     if ((int)blockIdx.x * 512 >= it.D) return;
     colreduce_stage1_vec_body(it.rows, it.D, it.mode, (const bf16_t*)it.dy, (const bf16_t*)it.x, it.mean, it.rstd, it.ws,
@@ -704,6 +767,48 @@ extern "C" int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, c
   return 0;
 }
 
+// LayerNorm backward + the first reduction stage of its parameter gradients in one launch (ln_bwd_vec_pg_kernel).
+// _pg_chunks: 0 if the shape / pointers are not eligible (the caller uses s2svc_layernorm_bwd + a mode-1 column reduction), else the
+// number of partial row pairs the launch writes to ws[chunks][2][D]; they enter s2svc_colreduce_grouped as a mode-7 item.
+static int ln_pg_rpw(int rows) {
+  static const int env = [] { const char* e = getenv("S2SVC_LN_PG_RPW"); return e ? atoi(e) : 0; }();
+  if (env > 0) return env;
+  int rpw = (rows + 2047) / 2048;                 // ~256 blocks of 8 waves
+  return rpw < 1 ? 1 : rpw;
+}
+extern "C" int s2svc_layernorm_bwd_pg_chunks(int dtype, int rows, int D, const void* dy, const void* s, const float* gamma,
+                                             const void* ds_extra, const void* ds, const void* dh) {
+  static const bool on = !(getenv("S2SVC_LN_PG") && getenv("S2SVC_LN_PG")[0] == '0');
+  if (!on || dtype != S2S_BF16 || D > 2048 || rows < 2048 || (int64_t)rows * D < 1500000) return 0;
+  if (!ln_vec_ok(D, dy, s, ds, dh, ds_extra) || ((uintptr_t)gamma) % 16) return 0;
+  const int rpw = ln_pg_rpw(rows);
+  return (rows + 8 * rpw - 1) / (8 * rpw);
+}
+
+extern "C" int s2svc_layernorm_bwd_pg(int dtype, int rows, int D, const void* dy, const void* s, const float* mean,
+                                      const float* rstd, const float* gamma, const void* ds_extra, float drop_p, float hscale,
+                                      const uint64_t* seed_base, uint64_t seed_off, void* ds, void* dh, float* ws, void* stream) {
+  const int chunks = s2svc_layernorm_bwd_pg_chunks(dtype, rows, D, dy, s, gamma, ds_extra, ds, dh);
+  S2S_REQUIRE(chunks > 0 && ws && ((uintptr_t)ws) % 16 == 0, "layernorm_bwd_pg: not eligible (check s2svc_layernorm_bwd_pg_chunks)");
+  hipStream_t st = (hipStream_t)stream;
+  const int rpw = ln_pg_rpw(rows);
+#define S2S_LN_PG(NV_)                                                                                                               \
+  do {                                                                                                                                \
+    const size_t lds = (size_t)8 * 2 * (NV_) * 512 * sizeof(float);                                                                   \
+    if (lds > 64 * 1024)                                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec_pg_kernel<NV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(ln_bwd_vec_pg_kernel<NV_>, dim3((unsigned)chunks), dim3(512), lds, st, rows, D, rpw, (const bf16_t*)dy,         \
+                       (const bf16_t*)s, mean, rstd, gamma, (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, \
+                       (bf16_t*)dh, ws);                                                                                             \
+  } while (0)
+  if (D <= 512) S2S_LN_PG(1);
+  else if (D <= 1024) S2S_LN_PG(2);
+  else S2S_LN_PG(4);
+#undef S2S_LN_PG
+  S2S_CHECK_LAUNCH("ln_bwd_vec_pg_kernel");
+  return 0;
+}
+
 extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void* dy, const void* x, const float* mean,
                                const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate,
                                float* ws, int ws_chunks, void* stream) {
@@ -738,26 +843,30 @@ extern "C" int s2svc_colreduce_grouped(const s2svc_colreduce_item* items, int n,
     cr_args a;
     std::memset(&a, 0, sizeof(a));
     a.n = (n - i0 < S2S_CR_MAX) ? n - i0 : S2S_CR_MAX;
-    int max_tiles = 1, max_tiles1 = 1, max_chunks = 1;
+    int max_tiles = 1, max_tiles1 = 1, max_chunks = 1, n_stage1 = 0;
     for (int i = 0; i < a.n; ++i) {
       const s2svc_colreduce_item& it = items[i0 + i];
       S2S_REQUIRE(it.rows >= 0 && it.D > 0 && it.ws && it.ws_chunks > 0, "colreduce_grouped: bad item");
-      S2S_REQUIRE(it.mode >= 0 && it.mode <= 6, "colreduce_grouped: bad mode");
+      S2S_REQUIRE(it.mode >= 0 && it.mode <= 7, "colreduce_grouped: bad mode");
       S2S_REQUIRE(it.dtype == S2S_F32 || it.dtype == S2S_BF16, "colreduce_grouped: bad dtype");
       int chunks = (it.rows + 63) / 64;
       if (chunks > it.ws_chunks) chunks = it.ws_chunks;
       if (chunks < 1) chunks = 1;
+      if (it.mode == 7) chunks = it.ws_chunks;           // partials ready: every one of them
       a.it[i] = it;
       a.chunks[i] = chunks;
       a.rpc[i] = (it.rows + chunks - 1) / chunks;
       const int tiles = (it.D + 63) / 64;
       const int tiles1 = cr_vec_ok_host(it.dtype, it.D, it.dy, it.x) ? (it.D + 511) / 512 : tiles;     // stage 1 (see its kernel)
       if (tiles > max_tiles) max_tiles = tiles;
-      if (tiles1 > max_tiles1) max_tiles1 = tiles1;
-      if (chunks > max_chunks) max_chunks = chunks;
+      if (it.mode != 7 && tiles1 > max_tiles1) max_tiles1 = tiles1;
+      if (it.mode != 7 && chunks > max_chunks) max_chunks = chunks;
+      if (it.mode != 7) ++n_stage1;
     }
-    hipLaunchKernelGGL(colreduce_grouped_stage1, dim3(max_tiles1, max_chunks, a.n), dim3(256), 0, st, a);
-    S2S_CHECK_LAUNCH("colreduce_grouped_stage1");
+    if (n_stage1 > 0) {
+      hipLaunchKernelGGL(colreduce_grouped_stage1, dim3(max_tiles1, max_chunks, a.n), dim3(256), 0, st, a);
+      S2S_CHECK_LAUNCH("colreduce_grouped_stage1");
+    }
     hipLaunchKernelGGL(colreduce_grouped_stage2, dim3(max_tiles, a.n), dim3(256), 0, st, a);
     S2S_CHECK_LAUNCH("colreduce_grouped_stage2");
   }

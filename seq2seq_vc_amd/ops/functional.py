@@ -641,11 +641,18 @@ class _AddLayerNorm(Function):
         eps, p, seed, hscale, fused = ctx.meta
         dy = _c(dy) if dy is not None else torch.zeros_like(s)
         extra = _c(ds_direct) if (fused and ds_direct is not None) else None
-        ds, dh = K.layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=extra, p=p, seed=seed,
-                                 want_dh=fused and (p > 0.0 or hscale != 1.0), hscale=hscale)
+        slotted = gamma.requires_grad and _slotted(gamma, beta)
+        ds, dh, part = K.layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=extra, p=p, seed=seed,
+                                       want_dh=fused and (p > 0.0 or hscale != 1.0), hscale=hscale, want_partials=True, partials_ok=slotted)
         dgamma = dbeta = None
         if gamma.requires_grad:
-            if _slotted(gamma, beta):
+            if part is not None:
+                # the backward kernel left the first reduction stage of d gamma / d beta (big sites: dy and the LayerNorm input are not
+                # read a second time); the second stage joins the batch's grouped column reductions
+                ws, chunks = part
+                b_slot, g_slot = beta._s2s_grad.view(-1), gamma._s2s_grad.view(-1)
+                _side_run(lambda: K.colreduce_partials(ws, chunks, s.shape[-1], b_slot, g_slot), keep=(ws,))
+            elif _slotted(gamma, beta):
                 _side_run(lambda: _reduce_to(beta, gamma, 1, dy, s, mean, rstd), keep=(dy, s, mean, rstd))
             else:
                 dbeta, dgamma = _reduce_to(beta, gamma, 1, dy, s, mean, rstd)

@@ -544,15 +544,43 @@ def layernorm_fwd(x, gamma, beta, eps, res=None, p=0.0, seed=(None, 0), need_sta
     return y, s, mean, rstd
 
 
-def layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=None, p=0.0, seed=(None, 0), want_dh=False, hscale=1.0):
+def layernorm_bwd(dy, s, mean, rstd, gamma, ds_extra=None, p=0.0, seed=(None, 0), want_dh=False, hscale=1.0, want_partials=False,
+                  partials_ok=True):
+    """-> (ds, dh) or, with want_partials, (ds, dh, partials): partials = (ws, chunks) when the launch also wrote the first
+    reduction stage of the parameter gradients (s2svc_layernorm_bwd_pg: big bf16 sites), else None (reduce dy / s separately)."""
     D = s.shape[-1]
     rows = s.numel() // D
     ds = torch.empty_like(s)
     dh = torch.empty_like(s) if want_dh else None
-    _lib.check(_lib.lib().s2svc_layernorm_bwd(dt(s), rows, D, ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma),
-                                              ptr(ds_extra), p, hscale, seed[0], seed[1], ptr(ds), ptr(dh), stream()),
+    L = _lib.lib()
+    if want_partials and partials_ok:
+        chunks = L.s2svc_layernorm_bwd_pg_chunks(dt(s), rows, D, ptr(dy), ptr(s), ptr(gamma), ptr(ds_extra), ptr(ds), ptr(dh))
+        if chunks > 0:
+            ws = torch.empty(chunks * 2 * D, dtype=torch.float32, device=s.device)
+            _lib.check(L.s2svc_layernorm_bwd_pg(dt(s), rows, D, ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma), ptr(ds_extra), p,
+                                                hscale, seed[0], seed[1], ptr(ds), ptr(dh), ptr(ws), stream()), "layernorm_bwd_pg")
+            return ds, dh, (ws, chunks)
+    _lib.check(L.s2svc_layernorm_bwd(dt(s), rows, D, ptr(dy), ptr(s), ptr(mean), ptr(rstd), ptr(gamma),
+                                     ptr(ds_extra), p, hscale, seed[0], seed[1], ptr(ds), ptr(dh), stream()),
                "layernorm_bwd")
-    return ds, dh
+    return (ds, dh, None) if want_partials else (ds, dh)
+
+
+def colreduce_partials(ws, chunks, D, out_sum, out_dot):
+    """Second reduction stage for partial row pairs ws[chunks][2][D] that a producer kernel already wrote (layernorm_bwd with
+    want_partials): out_sum / out_dot (fp32 gradient slots) += sum over the chunks.  Queued with the batch's grouped column
+    reductions when a recorder is active, else a grouped launch of its own."""
+    it = _lib.ColreduceItem()
+    it.dy, it.x, it.mean, it.rstd = None, None, None, None
+    it.out_sum, it.out_dot, it.ws = ptr(out_sum), ptr(out_dot), ptr(ws)
+    it.dtype, it.rows, it.D, it.mode, it.accumulate, it.ws_chunks, it.scale = _DT[torch.float32], chunks, D, 7, 1, chunks, 1.0
+    if _CR_RECORDER is not None:
+        _CR_RECORDER.append((it, (out_sum, out_dot, ws)))
+        return
+    if _Audit.on:
+        _audit_write("column reduction", ptr(out_sum), ptr(out_dot))
+    arr = (_lib.ColreduceItem * 1)(it)
+    _lib.check(_lib.lib().s2svc_colreduce_grouped(ctypes.addressof(arr), 1, stream()), "colreduce_grouped")
 
 
 _WS_CHUNKS = 64

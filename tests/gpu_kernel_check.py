@@ -613,6 +613,50 @@ def conv_in1_and_col2im(dtype):
 
 
 @case
+def layernorm_bwd_with_partial_gradients():
+    """s2svc_layernorm_bwd_pg (ln_bwd_vec_pg_kernel + colreduce mode 7): the LayerNorm backward pass of big bf16 sites that also
+    writes the first reduction stage of d gamma / d beta -- ds / dh bit-identical to the plain kernel (same row code), the parameter
+    gradients (partials summed by the grouped second stage, accumulating into slots) against the separate mode-1 reduction and fp32
+    torch; AAS-VC's decoder / encoder sites, ragged rows, D = 1000, residual-stream gradient added, dropped copy."""
+    res = []
+    dtype = torch.bfloat16
+    for (rows, D, seed, extra, p) in [(4096, 1536, 1, True, 0.2), (4096, 384, 2, False, 0.0), (4100, 1000, 3, True, 0.0), (2048, 1536, 4, False, 0.1)]:
+        s_in = rnd(rows, D, seed=seed, dtype=dtype)
+        dy = rnd(rows, D, seed=seed + 1, dtype=dtype)
+        gm = 1 + 0.1 * rnd(D, seed=seed + 2)
+        ex = rnd(rows, D, seed=seed + 3, dtype=dtype) if extra else None
+        sf = s_in.float()
+        mean, var = sf.mean(1), sf.var(1, unbiased=False)
+        rstd = torch.rsqrt(var + 1e-12)
+        sd = K.new_seed(s_in.device) if p > 0 else (None, 0)
+        ds0, dh0 = K.layernorm_bwd(dy, s_in, mean, rstd, gm, ds_extra=ex, p=p, seed=sd, want_dh=p > 0, hscale=1.0)
+        ds1, dh1, part = K.layernorm_bwd(dy, s_in, mean, rstd, gm, ds_extra=ex, p=p, seed=sd, want_dh=p > 0, hscale=1.0, want_partials=True)
+        res.append((part is not None, f"layernorm_bwd_pg takes {rows} x {D}"))
+        if part is None:
+            continue
+        res.append((bool(torch.equal(ds0, ds1)) and (dh0 is None or bool(torch.equal(dh0, dh1))), f"layernorm_bwd_pg {rows} x {D}: ds / dh bit-identical to the plain kernel"))
+        ws, chunks = part
+        db0, dg0 = rnd(D, seed=seed + 5), rnd(D, seed=seed + 6)
+        db, dg = db0.clone(), dg0.clone()
+        K.colreduce_partials(ws, chunks, D, db, dg)
+        xh = (sf - mean[:, None]) * rstd[:, None]
+        rb, rg = dy.float().sum(0), (dy.float() * xh).sum(0)
+        res.append(check(f"layernorm_bwd_pg {rows} x {D}: d beta (accumulated into its slot)", db, db0 + rb, torch.float32, rtol=1e-4, atol=1e-4 * float(rb.abs().max())))
+        res.append(check(f"layernorm_bwd_pg {rows} x {D}: d gamma", dg, dg0 + rg, torch.float32, rtol=1e-4, atol=1e-4 * float(rg.abs().max())))
+        sb, sg = K.colreduce(1, dy, s_in, mean, rstd, want_dot=True)
+        d = max(float((sb - (db - db0)).abs().max()) / float(rb.abs().max()), float((sg - (dg - dg0)).abs().max()) / float(rg.abs().max()))
+        res.append((d <= 1e-4, f"layernorm_bwd_pg {rows} x {D} vs the separate mode-1 reduction: largest relative difference {d:.2e} (<= 1e-4)"))
+        db2, dg2 = db0.clone(), dg0.clone()
+        _, _, part2 = K.layernorm_bwd(dy, s_in, mean, rstd, gm, ds_extra=ex, p=p, seed=sd, want_dh=p > 0, hscale=1.0, want_partials=True)
+        K.colreduce_partials(part2[0], part2[1], D, db2, dg2)
+        res.append((bool(torch.equal(db, db2) and torch.equal(dg, dg2)), f"layernorm_bwd_pg {rows} x {D}: repeated launches agree bit for bit"))
+    _, _, none = K.layernorm_bwd(rnd(2016, 384, seed=9, dtype=dtype), rnd(2016, 384, seed=10, dtype=dtype), torch.zeros(2016, device=DEV),
+                                 torch.ones(2016, device=DEV), torch.ones(384, device=DEV), want_partials=True)
+    res.append((none is None, "layernorm_bwd_pg declines the small (VTN-sized) sites: they keep the queued mode-1 reduction"))
+    return res
+
+
+@case
 @both_dtypes
 def layernorm(dtype):
     res = []
