@@ -210,6 +210,7 @@ def enable_side_streams(n=4, inline_batches=False, wgrad_background=(0, 0), batc
     anyway (AAS-VC: d = 1536) the forks cost more than the overlap gives (19.3 vs 20.9 ms/step).  Both need side_join()
     between backward and the optimiser step; n == 0 without inline_batches runs everything immediately."""
     K.set_wgrad_background(*wgrad_background)     # (cus, launches): ops.kernels, "Background weight gradients"
+    K.set_wgrad_cap(int(os.environ.get("S2SVC_W8_FORK_WGS", "64")) if n > 0 else 0)
     _Side.enabled = n > 0
     _Side.inline = (n == 0) and inline_batches
     _Side.batch = int(_SIDE_BATCH_ENV) if _SIDE_BATCH_ENV else int(batch) if batch else (64 if _Side.inline else 16)

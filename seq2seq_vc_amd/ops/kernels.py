@@ -417,6 +417,17 @@ def launch_group(descs, tile=128):
     _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(descs), tile, stream()), "s2svc_gemm_grouped")
 
 
+_W8_CAP = [0]
+
+
+def set_wgrad_cap(wgs):
+    """Workgroups of a grouped weight-gradient launch on the current stream (0 = one per unit).  ops.functional.enable_side_streams
+    sets 64 for FORKED gradient batches (VTN / TTS): the launch runs beside the latency-bound data-gradient chain, and a 144 KB-LDS
+    workgroup on every CU makes each small kernel of the chain wait for one -- measured 3.789 -> 3.773 ms per VTN step (five
+    interleaved repeats; 48 / 96 / 128 workgroups: 3.778 / 3.774 / 3.780).  Units are walked in order: bit-identical results."""
+    _W8_CAP[0] = max(0, int(wgs))
+
+
 def launch_wgrad_group(descs, bg_stream=None, bg_wgs=0):
     """The listed weight-gradient problems (every one s2svc_gemm_wgrad_ok) on the ragged 8-wave kernel, one grid per <= 40 of
     them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`).
@@ -432,6 +443,10 @@ def launch_wgrad_group(descs, bg_stream=None, bg_wgs=0):
                        "s2svc_gemm_wgrad_grouped_bg")
         return
     ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
+    if _W8_CAP[0] > 0:        # forked gradient batches: a capped grid leaves CUs to the chain the launch runs beside (set_wgrad_cap)
+        _lib.check(L.s2svc_gemm_wgrad_grouped_bg(ctypes.addressof(arr), len(descs), ptr(ws), stream(), _W8_CAP[0]),
+                   "s2svc_gemm_wgrad_grouped_bg")
+        return
     _lib.check(L.s2svc_gemm_wgrad_grouped(ctypes.addressof(arr), len(descs), ptr(ws), stream()), "s2svc_gemm_wgrad_grouped")
 
 
