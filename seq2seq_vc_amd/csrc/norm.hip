@@ -795,7 +795,8 @@ extern "C" int s2svc_layernorm_bwd_pg(int dtype, int rows, int D, const void* dy
 #define S2S_LN_PG(NV_)                                                                                                               \
   do {                                                                                                                                \
     const size_t lds = (size_t)8 * 2 * (NV_) * 512 * sizeof(float);                                                                   \
-    if (lds > 64 * 1024)                                                                                                              \
+    static bool attr_done_##NV_ = false;                                                                                              \
+    if (lds > 64 * 1024 && !attr_done_##NV_ && (attr_done_##NV_ = true))                                                              \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec_pg_kernel<NV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(ln_bwd_vec_pg_kernel<NV_>, dim3((unsigned)chunks), dim3(512), lds, st, rows, D, rpw, (const bf16_t*)dy,         \
                        (const bf16_t*)s, mean, rstd, gamma, (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, \
