@@ -555,9 +555,8 @@ def step_mfma(workload, ms):
 # =====================================================================================================================
 def bench_aasvc_single(dev, dtype, steps=20, warmup=3, cpu=True, batch=16):
     from seq2seq_vc_amd.ops import functional as Fn
-    from seq2seq_vc_amd.trainers import AASVCTrainer
-    # the schedule AASVCTrainer ships (trainers.AASVCTrainer.GRADIENT_WORK / WGRAD_BACKGROUND)
-    Fn.enable_side_streams(0, inline_batches=True, wgrad_background=AASVCTrainer.WGRAD_BACKGROUND)
+    # the schedule AASVCTrainer ships (trainers.AASVCTrainer.GRADIENT_WORK)
+    Fn.enable_side_streams(0, inline_batches=True)
     wl = Workload("aasvc", dev, dtype, batch, 1, 0)
     step, info = build_step(wl, None, 1, False, False, "fp32", True)
     info.pop("_probe", None)
@@ -858,9 +857,7 @@ def main():
         n_side, inline = (4, args.inline_batches) if args.workload == "vtn" else (0, True)
     else:
         n_side, inline = args.side_streams, args.inline_batches
-    from seq2seq_vc_amd.trainers import AASVCTrainer
-    Fn.enable_side_streams(n_side, inline_batches=inline,
-                           wgrad_background=AASVCTrainer.WGRAD_BACKGROUND if args.workload == "aasvc" else (0, 0))
+    Fn.enable_side_streams(n_side, inline_batches=inline)
     K.manual_seed(1234 + rank)
 
     B = args.batch or (32 if args.workload == "vtn" else 16)

@@ -135,9 +135,6 @@ int s2svc_tconv2d_weights(int O, int C, const float* w, void* out_bf16, void* st
    Two descriptors of one call must not write the same C / a_rowsum (they run concurrently). */
 int s2svc_gemm_grouped_ok(const s2svc_gemm_desc* desc /* host */);
 int s2svc_gemm_grouped(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream);
-/* the same with the problems of exact 256 x 128 tiles (the 8-wave kernel's) as a BACKGROUND launch on `bg_stream`: bg_cus
-   workgroups walk all their tiles and leave the other CUs to the kernels of `stream`; *n_bg = how many problems went there.
-   The caller orders bg_stream behind the producers of the operands and joins it before the results are read. */
 /* BATCHED problems of one operand-kind pair (A K-contiguous or row-contiguous, B row-contiguous; bf16, no split-K) as one
    grid: the batched products of an attention backward pass (ops/functional.py: _attn_common_bwd, _RelAttnPacked.backward;
    reference modules/transformer/attention.py:72-111, 262-305 differentiated).  0 = launched, 1 = not eligible as a group
@@ -155,14 +152,12 @@ int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs /* host */, int n, v
 int s2svc_gemm_wgrad_ok(const s2svc_gemm_desc* desc /* host */);
 int64_t s2svc_gemm_wgrad_ws_floats(const s2svc_gemm_desc* descs /* host */, int n);
 int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs /* host */, int n, float* ws, void* stream);
-/* the same as a BACKGROUND launch: at most `wgs_cap` workgroups walk the units (a quarter of the CUs, say) on `stream` and leave the
-   rest of the chip to the kernels of the stream beside it; same sums, same bits (wgs_cap <= 0: one workgroup per unit) */
+/* the same on a CAPPED grid: at most `wgs_cap` workgroups walk the units in order and leave the rest of the chip to the kernels of
+   the stream the launch runs beside (forked gradient batches); same sums, same bits (wgs_cap <= 0: one workgroup per unit) */
 int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, float* ws, void* stream, int wgs_cap);
 /* A/B switch (tests, benchmarks): on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles of 64 rows per chunk (<= 0: unchanged; default 64,
    S2SVC_GEMM_W8 / S2SVC_W8_KT_CHUNK); returns the previous on | kt_chunk << 8. */
 int s2svc_gemm_set_w8(int on, int kt_chunk);
-int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, int tile, void* stream, void* bg_stream, int bg_cus,
-                          int* n_bg /* host, may be NULL */);
 
 /* Kernel-family switch for tests / A-B timing of s2svc_gemm's bf16 path: the 256-row, 8-wave, phase-interleaved kernel
    (csrc/gemm_8ph.hip: K-contiguous dense or Conv2d-3x3-s2 A operand, dense B, K % 64 == 0, >= 128 tiles) is tried first.

@@ -816,30 +816,6 @@ __global__ __launch_bounds__(512) void gemm_8ph_tr_grouped_kernel(const p8_group
   else p8_tr_tile<STAGGER>(d, tile_m, t - tile_m * tiles_n, smem);
 }
 
-// The same as a BACKGROUND kernel: gridDim.x workgroups (a quarter of the CUs, say) walk all tiles of the group.  Weight
-// gradients are off the data-gradient chain; launched like this on their own stream they hold `gridDim.x` CUs for the whole
-// launch and leave the others to the chain (whose GEMMs over 4096 x 1536 k outputs are 192 k workgroups of the 256 x 128
-// kernel: one round on the remaining 192 CUs) -- a chip-filling launch beside the chain makes every chain kernel queue for
-// a CU behind ~100 us workgroups instead.  Same tile code, same sums: the bits do not depend on the launch shape.
-template <bool STAGGER, int BN>
-__global__ __launch_bounds__(512) void gemm_8ph_tr_grouped_persistent_kernel(const p8_group_args g) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * (BN == 256 ? 4 : 3) * 16384];
-  const int total = g.tile_start[P8_GROUP_MAX];
-#pragma unroll 1
-  for (int bt = (int)blockIdx.x; bt < total; bt += (int)gridDim.x) {
-    int p = 0;
-#pragma unroll
-    for (int i = 1; i < P8_GROUP_MAX; ++i) p += (i < g.n && g.tile_start[i] <= bt) ? 1 : 0;
-    const s2svc_gemm_desc& d = g.d[p];
-    const int t = bt - g.tile_start[p];
-    const int tiles_n = d.N / BN;
-    const int tile_m = t / tiles_n;
-    if (BN == 256) p8_tr_tile_q<STAGGER>(d, tile_m, t - tile_m * tiles_n, smem);
-    else p8_tr_tile<STAGGER>(d, tile_m, t - tile_m * tiles_n, smem);
-    __syncthreads();               // the next tile's first DMA overwrites the epilogue's staging tiles of all waves
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // RAGGED weight-gradient tiles ("W8", round 4): the same 256 x 128 two-phase schedule for ANY dense row-contiguous weight
 // gradient C[M, N] (+)= A^T . B (M, N multiples of 8; any K) -- VTN's 384 / 1152 / 1536 / 4608 / 7296-feature layers with
@@ -1308,7 +1284,7 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile
   __builtin_amdgcn_s_barrier();        // end of the unit: a further unit's DMAs may overwrite the C tiles
 }
 
-// one workgroup per unit, or -- gridDim.x < total: a BACKGROUND launch (ops.kernels.set_wgrad_background) -- gridDim.x workgroups that
+// one workgroup per unit, or -- gridDim.x < total: a CAPPED grid (ops.kernels.set_wgrad_cap: forked gradient batches) -- gridDim.x workgroups that
 // walk the units and leave the other CUs to the stream beside them
 __global__ __launch_bounds__(768) void gemm_w8ls_kernel(const w8_args g) {
   __shared__ __attribute__((aligned(1024))) char smem[3 * 3 * 16384];
@@ -1557,8 +1533,7 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
 // row-sums in different orders, and a staged backward pass (other flush points, other groups) must give the bits of the
 // uncut one (tests/gpu_model_check.py: stage_graphs_replay_equals_eager_full_size).  The tile width (256 / 128) does depend
 // on the group -- it changes the schedule, not the order of any sum.
-// bg_cus > 0: the background form (gemm_8ph_tr_grouped_persistent_kernel) with that many workgroups, on `stream`
-extern "C" int s2svc_gemm_grouped_try_8ph_bg(const s2svc_gemm_desc* descs, int n, void* stream, int bg_cus) {
+extern "C" int s2svc_gemm_grouped_try_8ph(const s2svc_gemm_desc* descs, int n, void* stream) {
   const int mode = p8_mode();
   if (mode == 0 || !p8_tr_mode() || n <= 0 || n > P8_GROUP_MAX) return 0;
   p8_group_args g;
@@ -1578,7 +1553,7 @@ extern "C" int s2svc_gemm_grouped_try_8ph_bg(const s2svc_gemm_desc* descs, int n
   if (m == 0) return 0;
   S2S_REQUIRE(t128 < (1ll << 30), "gemm_grouped: too many tiles");
   g.n = m;
-  const bool q = bg_cus > 0 ? (all256 && p8_force_bn() != 3) : p8_tr_take_q(all256, t256, t128);
+  const bool q = p8_tr_take_q(all256, t256, t128);
   int64_t total = 0;
   for (int i = 0; i < m; ++i) {
     g.tile_start[i] = (int32_t)total;
@@ -1586,18 +1561,6 @@ extern "C" int s2svc_gemm_grouped_try_8ph_bg(const s2svc_gemm_desc* descs, int n
   }
   for (int i = m; i <= P8_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
   hipStream_t st = (hipStream_t)stream;
-  if (bg_cus > 0) {
-    const unsigned wgs = (unsigned)(total < bg_cus ? total : bg_cus);
-    if (q) {
-      if (mode == 2) hipLaunchKernelGGL((gemm_8ph_tr_grouped_persistent_kernel<false, 256>), dim3(wgs), dim3(512), 0, st, g);
-      else hipLaunchKernelGGL((gemm_8ph_tr_grouped_persistent_kernel<true, 256>), dim3(wgs), dim3(512), 0, st, g);
-    } else {
-      if (mode == 2) hipLaunchKernelGGL((gemm_8ph_tr_grouped_persistent_kernel<false, 128>), dim3(wgs), dim3(512), 0, st, g);
-      else hipLaunchKernelGGL((gemm_8ph_tr_grouped_persistent_kernel<true, 128>), dim3(wgs), dim3(512), 0, st, g);
-    }
-    S2S_CHECK_LAUNCH("gemm_8ph_tr_grouped_persistent_kernel");
-    return mask;
-  }
   if (q) {
     if (mode == 2) hipLaunchKernelGGL((gemm_8ph_tr_grouped_kernel<false, 256>), dim3((unsigned)total), dim3(512), 0, st, g);
     else hipLaunchKernelGGL((gemm_8ph_tr_grouped_kernel<true, 256>), dim3((unsigned)total), dim3(512), 0, st, g);
@@ -1692,7 +1655,7 @@ extern "C" int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs, int n, flo
   return s2svc_gemm_wgrad_grouped_bg(descs, n, ws, stream, 0);
 }
 
-// wgs_cap > 0: a background launch of at most that many workgroups (they walk the units), on `stream`
+// wgs_cap > 0: a grid of at most that many workgroups (they walk the units in order)
 extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, float* ws, void* stream, int wgs_cap) {
   S2S_REQUIRE(descs && n > 0, "gemm_wgrad_grouped: bad args");
   hipStream_t st = (hipStream_t)stream;
@@ -1748,6 +1711,3 @@ extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, 
   return 0;
 }
 
-extern "C" int s2svc_gemm_grouped_try_8ph(const s2svc_gemm_desc* descs, int n, void* stream) {
-  return s2svc_gemm_grouped_try_8ph_bg(descs, n, stream, 0);
-}

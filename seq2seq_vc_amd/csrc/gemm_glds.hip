@@ -960,17 +960,9 @@ static bool tconv_group_ok(const s2svc_gemm_desc& d) {
   return true;
 }
 
-extern "C" int s2svc_gemm_grouped_try_8ph_bg(const s2svc_gemm_desc* descs, int n, void* stream, int bg_cus);
+extern "C" int s2svc_gemm_grouped_try_8ph(const s2svc_gemm_desc* descs, int n, void* stream);
 
 extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile, void* stream) {
-  return s2svc_gemm_grouped_bg(descs, n, tile, stream, nullptr, 0, nullptr);
-}
-
-// bg_cus > 0: the problems the 8-wave kernel takes run on `bg_stream` as a background launch of bg_cus workgroups (the caller
-// has made bg_stream wait for the producers of the operands, and joins it before the gradients are used); *n_bg = how many.
-extern "C" int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs, int n, int tile, void* stream, void* bg_stream, int bg_cus,
-                                     int* n_bg) {
-  if (n_bg) *n_bg = 0;
   S2S_REQUIRE(descs && n > 0 && (tile == 64 || tile == 128), "gemm_grouped: bad args");
   hipStream_t st = (hipStream_t)stream;
   if (tconv_group_ok(descs[0])) {
@@ -1000,10 +992,8 @@ extern "C" int s2svc_gemm_grouped_bg(const s2svc_gemm_desc* descs, int n, int ti
     }
     int taken = 0;                                  // problems of exact 256 x 128 tiles: the 8-wave kernel (gemm_8ph.hip)
     if (tr_enabled()) {
-      const bool bg = bg_cus > 0 && bg_stream != nullptr;
-      taken = s2svc_gemm_grouped_try_8ph_bg(descs + i0, cnt, bg ? bg_stream : stream, bg ? bg_cus : 0);
+      taken = s2svc_gemm_grouped_try_8ph(descs + i0, cnt, stream);
       if (taken < 0) return taken;
-      if (bg && n_bg) *n_bg += __builtin_popcount((unsigned)taken);
     }
     group_args g;
     std::memset(&g, 0, sizeof(g));

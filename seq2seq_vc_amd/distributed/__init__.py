@@ -222,16 +222,6 @@ class OverlappedBackward:
         buffer are final on the current stream."""
         if i == 0 and hasattr(self.opt, "join_prologue"):
             self.opt.join_prologue()                             # zero-filled gradients + refreshed weight copies (FlatAdam.begin_step)
-        if len(self.plan) > 1:
-            # background weight-gradient launches (ops.kernels.set_wgrad_background) pay when they can run on beside the rest of
-            # the backward pass; a stage ends with a join, and what is still running there is a tail at a quarter of the chip
-            # (AAS-VC, bench.py --split-backward: 13.58 ms with them, 12.64 without; one graph 12.37)
-            from ..ops import kernels as K
-            saved_bg, K._BG.cus = K._BG.cus, 0
-            try:
-                return self._run_stage(i, losses, scale)
-            finally:
-                K._BG.cus = saved_bg
         return self._run_stage(i, losses, scale)
 
     def _run_stage(self, i, losses, scale=None):

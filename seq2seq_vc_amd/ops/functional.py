@@ -176,8 +176,6 @@ def _taken_streams():
     h = {st.cuda_stream for st in _Side.streams}
     if _Branch.stream is not None:
         h.add(_Branch.stream.cuda_stream)
-    if K._BG.stream is not None:
-        h.add(K._BG.stream.cuda_stream)
     if torch.cuda.is_available():
         h.add(torch.cuda.current_stream().cuda_stream)
     return h
@@ -200,7 +198,7 @@ def distinct_stream(taken=None):
 _SIDE_BATCH_ENV = os.environ.get("S2SVC_SIDE_BATCH")
 
 
-def enable_side_streams(n=4, inline_batches=False, wgrad_background=(0, 0), batch=None):
+def enable_side_streams(n=4, inline_batches=False, batch=None):
     """batch: closures per gradient batch (default: 16 forked / 64 inline; S2SVC_SIDE_BATCH overrides).  Round 4 re-measured both with
     the 8-wave weight-gradient kernel that takes 40 problems per launch: VTN 12 -> 16: 3.95 -> 3.86 ms, AAS-VC 12 -> 48 ... 160:
     11.85 -> 11.6-11.7 ms (larger grids, fewer ragged last rounds; the operands stay alive a little longer).
@@ -209,7 +207,6 @@ def enable_side_streams(n=4, inline_batches=False, wgrad_background=(0, 0), batc
     that the dense weight-gradient GEMMs of a batch become one grouped launch -- for models whose kernels fill the chip
     anyway (AAS-VC: d = 1536) the forks cost more than the overlap gives (19.3 vs 20.9 ms/step).  Both need side_join()
     between backward and the optimiser step; n == 0 without inline_batches runs everything immediately."""
-    K.set_wgrad_background(*wgrad_background)     # (cus, launches): ops.kernels, "Background weight gradients"
     K.set_wgrad_cap(int(os.environ.get("S2SVC_W8_FORK_WGS", "64")) if n > 0 else 0)
     _Side.enabled = n > 0
     _Side.inline = (n == 0) and inline_batches
@@ -401,7 +398,6 @@ def side_join():
         for st in _Side.streams:
             main.wait_stream(st)
     _join_branch_stream()
-    K.bg_join()                      # background weight gradients (ops.kernels.set_wgrad_background)
     K.audit_reset()                  # (writer audit, ops.kernels._Audit: a join -- every slot may change hands)
     _Side.pending.clear()
     _Side.idx = 0

@@ -136,7 +136,7 @@ def pick_splitk(M, N, K, nbatch=1):
 # eager launches hide (the GPU happens to keep issue order) and a captured graph exposes (only edges order its branches) --
 # the signature of round 3's "second side stream" experiment, whose gradient norm moved under capture only.  With the audit on,
 # every accumulating launch records (slot pointer -> stream); a second writer from another stream raises unless a join
-# (ops.functional.side_join / bg_wait on that slot) came in between.
+# (ops.functional.side_join) came in between.
 # ----------------------------------------------------------------------------------------------
 class _Audit:
     on = os.environ.get("S2SVC_AUDIT_SLOTS", "0") == "1"
@@ -247,7 +247,6 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
             d.a_rowsum = a_rowsum.data_ptr()
             d.a_rowsum_accumulate = 1 if a_rowsum_accumulate else 0
         if _lib.lib().s2svc_gemm_wgrad_ok(ctypes.addressof(d)):
-            bg_wait(d.C, d.a_rowsum)
             if _Audit.on:
                 _audit_write("weight gradient (W8)", d.C, d.a_rowsum if a_rowsum_accumulate else None)
             launch_wgrad_group([d])
@@ -270,8 +269,6 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         raise TypeError("gemm bias must be fp32")
     if res is not None and res.dtype != out.dtype:
         raise TypeError("gemm residual must have the output dtype")
-    if _BG.dirty:
-        bg_wait(d.C, d.a_rowsum)
     if _Audit.on and (accumulate or a_rowsum_accumulate):
         _audit_write("gemm", d.C if accumulate else None, d.a_rowsum if a_rowsum_accumulate else None)
     _lib.check(_lib.lib().s2svc_gemm(ctypes.byref(d), stream()), "s2svc_gemm")
@@ -342,73 +339,9 @@ def flush_colreduce(queue):
                 group.append((it, keep))
         pending = rest
         arr = (_lib.ColreduceItem * len(group))(*[g[0] for g in group])
-        bg_wait(*[g[0].out_sum for g in group], *[g[0].out_dot for g in group])
         if _Audit.on:
             _audit_write("grouped column reduction", *[g[0].out_sum for g in group], *[g[0].out_dot for g in group])
         _lib.check(_lib.lib().s2svc_colreduce_grouped(ctypes.addressof(arr), len(group), stream()), "s2svc_colreduce_grouped")
-
-
-# ----------------------------------------------------------------------------------------------
-# Background weight gradients.  The grouped launches of the 8-wave kernel (exact 256 x 128 tiles: AAS-VC's 1536 / 3072 / 4608
-# feature layers, ~300 us per decoder layer) are independent of the data-gradient chain but fill the chip, so they used to run
-# in line on the chain's stream: a chip-filling launch on a side stream makes every kernel of the chain queue for a CU behind
-# ~100 us workgroups (measured in round 2: slower).  As a BACKGROUND launch -- `cus` persistent workgroups that walk all tiles,
-# on their own stream -- they hold a quarter of the CUs and the chain keeps the rest, which is what its GEMMs use anyway
-# (192 workgroups of 256 x 128 for 4096 x 1536 outputs).  Only the first `max_launches` grouped launches of a backward pass go
-# there: what is still running when the chain ends is a tail at a quarter of the chip.
-# ----------------------------------------------------------------------------------------------
-class _BG:
-    cus, max_launches = 0, 0
-    count = 0             # background launches since the last join
-    stream = None
-    dirty = False
-    keys = set()          # outputs (C / a_rowsum pointers) with a background launch in flight
-
-
-def _parse_bg(spec):
-    cus, _, n = spec.partition(":")
-    return int(cus or 0), int(n) if n else 1 << 30
-
-
-def set_wgrad_background(cus, max_launches=1 << 30):
-    """cus > 0: the first `max_launches` grouped 8-wave weight-gradient launches of every backward pass run as background
-    launches of `cus` workgroups (see above); 0 switches it off.  S2SVC_WGRAD_BG="cus:launches" overrides."""
-    env = os.environ.get("S2SVC_WGRAD_BG")
-    if env is not None:
-        cus, max_launches = _parse_bg(env)
-    _BG.cus, _BG.max_launches = int(cus), int(max_launches)
-
-
-def _bg_stream(cur):
-    from . import functional as Fn
-    st = _BG.stream
-    _BG.stream = None                                         # (_taken_streams lists it otherwise)
-    taken = Fn._taken_streams() | {cur.cuda_stream}
-    if st is None or st.cuda_stream in taken:
-        st = Fn.distinct_stream(taken)
-    _BG.stream = st
-    return st
-
-
-def bg_wait(*ptrs):
-    """The current stream is about to write `ptrs` (gradient slots): wait for a background launch that writes them too."""
-    if _BG.dirty and any(p in _BG.keys for p in ptrs if p):
-        torch.cuda.current_stream().wait_stream(_BG.stream)
-        if _Audit.on:
-            audit_reset([p for p in ptrs if p])
-
-
-def bg_join():
-    """The current stream waits for the background weight gradients (ops.functional.side_join: end of a backward pass / stage)."""
-    if _BG.dirty:
-        torch.cuda.current_stream().wait_stream(_BG.stream)
-    _BG.dirty, _BG.count = False, 0
-    _BG.keys = set()
-
-
-def _bg_candidates(part):
-    return [d for d in part if d.dtype == _DT[torch.bfloat16] and d.M % 256 == 0 and d.N % 128 == 0 and d.K % 64 == 0 and
-            (d.M // 128) * (d.N // 128) >= 64]
 
 
 def launch_group(descs, tile=128):
@@ -428,20 +361,12 @@ def set_wgrad_cap(wgs):
     _W8_CAP[0] = max(0, int(wgs))
 
 
-def launch_wgrad_group(descs, bg_stream=None, bg_wgs=0):
+def launch_wgrad_group(descs):
     """The listed weight-gradient problems (every one s2svc_gemm_wgrad_ok) on the ragged 8-wave kernel, one grid per <= 40 of
-    them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`).
-    bg_stream / bg_wgs: as a background launch of at most bg_wgs workgroups on that stream (the caller has ordered it behind the
-    producers of the operands and joins it before the gradients are read)."""
+    them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`)."""
     L = _lib.lib()
     arr = (_lib.GemmDesc * len(descs))(*descs)
     nws = L.s2svc_gemm_wgrad_ws_floats(ctypes.addressof(arr), len(descs))
-    if bg_stream is not None:
-        with torch.cuda.stream(bg_stream):
-            ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
-            _lib.check(L.s2svc_gemm_wgrad_grouped_bg(ctypes.addressof(arr), len(descs), ptr(ws), bg_stream.cuda_stream, int(bg_wgs)),
-                       "s2svc_gemm_wgrad_grouped_bg")
-        return
     ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
     if _W8_CAP[0] > 0:        # forked gradient batches: a capped grid leaves CUs to the chain the launch runs beside (set_wgrad_cap)
         _lib.check(L.s2svc_gemm_wgrad_grouped_bg(ctypes.addressof(arr), len(descs), ptr(ws), stream(), _W8_CAP[0]),
@@ -490,57 +415,18 @@ def flush_grouped(queue):
         w8 = [d for d in group if L.s2svc_gemm_wgrad_ok(ctypes.addressof(d))]
         if w8:
             group = [d for d in group if not any(d is w for w in w8)]
-            bg_wait(*[d.C for d in w8], *[d.a_rowsum for d in w8])
-            # the big exact-256 problems of the first `max_launches` batches of a backward pass (AAS-VC's decoder layers) as a
-            # BACKGROUND launch of `cus` workgroups on their own stream (see "Background weight gradients" below)
-            cand = _bg_candidates(w8) if (_BG.cus > 0 and _BG.count < _BG.max_launches) else []
-            rest = [d for d in w8 if not any(d is c for c in cand)]
-            if cand:
-                cur = torch.cuda.current_stream()
-                bg = _bg_stream(cur)
-                bg.wait_stream(cur)                         # the operands were produced on this stream
-                if _Audit.on:
-                    _audit_write("background weight gradient (W8)", *[d.C for d in cand], *[d.a_rowsum for d in cand], st=bg.cuda_stream)
-                launch_wgrad_group(cand, bg_stream=bg, bg_wgs=_BG.cus)
-                _BG.dirty = True
-                _BG.count += 1
-                for d in cand:
-                    _BG.keys.add(d.C)
-                    if d.a_rowsum:
-                        _BG.keys.add(d.a_rowsum)
-            if rest:
-                if _Audit.on:
-                    _audit_write("grouped weight gradient (W8)", *[d.C for d in rest], *[d.a_rowsum for d in rest])
-                launch_wgrad_group(rest)
+            if _Audit.on:
+                _audit_write("grouped weight gradient (W8)", *[d.C for d in w8], *[d.a_rowsum for d in w8])
+            launch_wgrad_group(w8)
         # big outputs (>= _GROUP_BIG_TILES 128x128 tiles each) share launches of 128x128 tiles, the rest of 64x64 tiles
         big = [d for d in group if _GROUP_TILE == 64 and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= _GROUP_BIG_TILES]
         small = [d for d in group if not any(d is b for b in big)]
         for part, tile in ((big, 128), (small, _GROUP_TILE)):
             if part:
                 arr = (_lib.GemmDesc * len(part))(*part)
-                cand = _bg_candidates(part) if (_BG.cus > 0 and _BG.count < _BG.max_launches) else []
-                bg_wait(*[d.C for d in part], *[d.a_rowsum for d in part])
-                if _Audit.on:       # (a background launch writes its slots on the background stream: recorded under that stream)
-                    cand_ids = {id(d) for d in cand}
-                    for d in part:
-                        bgst = _bg_stream(torch.cuda.current_stream()).cuda_stream if id(d) in cand_ids else None
-                        _audit_write("grouped weight gradient", d.C, d.a_rowsum, st=bgst)
-                if cand:
-                    cur = torch.cuda.current_stream()
-                    bg = _bg_stream(cur)
-                    bg.wait_stream(cur)                     # the operands were produced on this stream
-                    nbg = ctypes.c_int(0)
-                    _lib.check(_lib.lib().s2svc_gemm_grouped_bg(ctypes.addressof(arr), len(part), tile, cur.cuda_stream,
-                                                                bg.cuda_stream, _BG.cus, ctypes.byref(nbg)), "s2svc_gemm_grouped_bg")
-                    _BG.dirty = True                       # forked (part of a capture from here on): joined by bg_join either way
-                    if nbg.value:
-                        _BG.count += 1
-                        for d in cand:
-                            _BG.keys.add(d.C)
-                            if d.a_rowsum:
-                                _BG.keys.add(d.a_rowsum)
-                else:
-                    _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(part), tile, stream()), "s2svc_gemm_grouped")
+                if _Audit.on:
+                    _audit_write("grouped weight gradient", *[d.C for d in part], *[d.a_rowsum for d in part])
+                _lib.check(_lib.lib().s2svc_gemm_grouped(ctypes.addressof(arr), len(part), tile, stream()), "s2svc_gemm_grouped")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -83,14 +83,12 @@ class Trainer(object):
     # how parameter-gradient kernels are scheduled (ops/functional.py, "Side streams"): (side streams, inline batches)
     GRADIENT_WORK = (4, False)
     GRADIENT_BATCH = None           # closures per gradient batch (None: ops.functional.enable_side_streams' default, 16 forked / 64 inline)
-    WGRAD_BACKGROUND = (0, 0)       # (CUs, launches per backward pass) of the background weight-gradient launches (ops/kernels.py)
     DP_GRAD_PAYLOAD = "fp32"        # dtype of the data-parallel gradient exchange (config["dp_grad_payload"] overrides)
 
     def _schedule_gradient_work(self):
         if self.device.type == "cuda" and isinstance(self.optimizer, FlatAdam):
             n, inline = self.GRADIENT_WORK
             Fn.enable_side_streams(self.config.get("side_streams", n), inline_batches=self.config.get("inline_batches", inline),
-                                   wgrad_background=tuple(self.config.get("wgrad_background", self.WGRAD_BACKGROUND)),
                                    batch=self.config.get("gradient_batch", self.GRADIENT_BATCH))
 
     # -- data parallelism (reference: apex DistributedDataParallel wrap, bin/vc_train.py:423-431) ------------------------
@@ -322,10 +320,6 @@ class AASVCTrainer(Trainer):
     gradient accumulation divides the loss; zero_grad AFTER the optimiser step."""
 
     GRADIENT_WORK = (0, True)       # chip-filling kernels: batched on the issuing stream, not forked (17.6 vs 20.9 ms/step)
-    WGRAD_BACKGROUND = (0, 0)       # round 3 ran the first three grouped weight-gradient launches of a backward pass as background
-    #                                 launches of 64 workgroups (12.83 -> 12.55 ms); with the loader-specialised 8-wave kernel
-    #                                 (csrc/gemm_8ph.hip: w8ls_tile) in-line launches are faster than that: 12.1 (64:3) / 12.3 (64:4)
-    #                                 / 12.7 (48:4) against 11.9 ms with none -- off; config["wgrad_background"] = (cus, launches)
     DP_GRAD_PAYLOAD = "fp32"        # the reference's DDP all-reduces fp32 gradients: the parity setting is the default.  630 MB of fp32
     #                                 gradients per step (vc2) are 7 ms on one xGMI link against a 12 ms step: a multi-GPU recipe opts
     #                                 into config["dp_grad_payload"] = "bf16" (the exchange runs on a bf16 copy, ~3 significant digits

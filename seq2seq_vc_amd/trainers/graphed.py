@@ -262,8 +262,7 @@ class _Capture:
         from ..ops import functional as Fn
         main = torch.cuda.current_stream()
         pro = getattr(self.owner.t.optimizer, "_pro_stream", None)   # the step prologue (optim.FlatAdam.begin_step)
-        from ..ops import kernels as K
-        for st in [Fn._Branch.stream, pro, K._BG.stream] + list(Fn._Side.streams):      # belt and braces: nothing may still be forked off
+        for st in [Fn._Branch.stream, pro] + list(Fn._Side.streams):      # belt and braces: nothing may still be forked off
             if st is None:
                 continue
             with torch.cuda.stream(st):

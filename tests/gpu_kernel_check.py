@@ -1311,25 +1311,6 @@ def gemm_8phase_weight_gradients():
                            dw, in_dtype=dtype, accumulate=True, a_rowsum=db, a_rowsum_accumulate=True)
             K.flush_grouped(queue)
             results[mode] = outs
-        # the same group as BACKGROUND launches (persistent workgroups on their own stream, ops.kernels.set_wgrad_background):
-        # the bits of the in-line launch, whatever the number of workgroups and the tile width
-        for mode, cus in ((1, 16), (1, 64), (1 | (3 << 4), 40)):
-            L.s2svc_gemm_set_8ph(mode)
-            K.set_wgrad_background(cus, 4)
-            outs = [(p[2].clone(), p[3].clone()) for p in probs]
-            queue = []
-            with K.record_grouped(queue):
-                for (x, dy, _, _), (dw, db) in zip(probs, outs):
-                    K.gemm(K.operand(dy, dy.shape[1], layout=K.RC), K.operand(x, x.shape[1], layout=K.RC), dy.shape[1], x.shape[1], x.shape[0],
-                           dw, in_dtype=dtype, accumulate=True, a_rowsum=db, a_rowsum_accumulate=True)
-            K.flush_grouped(queue)
-            went = K._BG.count
-            K.bg_join()
-            K.set_wgrad_background(0)
-            torch.cuda.synchronize()
-            same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(outs, results[mode]))
-            res.append((went == 1 and same, f"8-wave grouped wgrad as a background launch of {cus} workgroups (mode {mode}): "
-                                            f"{went} background launch, identical to the in-line launch = {same}"))
         K._GROUP_TILE, K._GROUP_MAX_TILES, K._GROUP_BIG_TILES = saved
         for mode in (1, 1 | (3 << 4)):
             for i, ((x, dy, dw0, db0), (dw, db)) in enumerate(zip(probs, results[mode])):

@@ -515,7 +515,7 @@ def gradient_slot_writers_audit():
                 torch.manual_seed(0)
                 model = M.VTN(**bench.VTN_VC1).to(DEV).train()
             else:
-                Fn.enable_side_streams(0, inline_batches=True, wgrad_background=(64, 3))      # (the opt-in background launches too)
+                Fn.enable_side_streams(0, inline_batches=True)
                 xs, ilens, ys, labels, olens = bench.canonical_batch(16)
                 torch.manual_seed(0)
                 model = M.AASVC(**AASVC_VC2).to(DEV).train()
@@ -694,10 +694,6 @@ def aasvc_full_size_step_is_reproducible():
             L.ForwardSumLoss.forward = orig
             model.forward_sum_prefetch = None
         res.append((bool(hits) and all(hits), f"the criterion found the prefetched forward-sum result in {sum(hits)} of {len(hits)} calls"))
-        Fn.enable_side_streams(0, inline_batches=True, wgrad_background=(64, 3))
-        variant("weight gradients as background launches (64 workgroups, 3 launches)")
-        Fn.enable_side_streams(0, inline_batches=True, wgrad_background=(24, 100))
-        variant("weight gradients as background launches (24 workgroups, all launches)", n=2)
     finally:
         Fn.set_compute_dtype(torch.float32)
         Fn.enable_side_streams(0)
