@@ -856,17 +856,6 @@ struct w8_args {
 static_assert(sizeof(w8_prob) == 96, "w8_prob layout");
 static_assert(sizeof(w8_args) <= 4096, "kernel arguments are limited to 4 KB");
 
-// one unit = 2 DMA instructions of this wave; a lane reads the zero block unless its rows (ok[e]) and its k row (kin[e] < klim) exist
-__device__ __forceinline__ void w8_issue(const char* base, const uint32_t (&off)[2], const bool (&ok)[2], const int (&kin)[2], int klim,
-                                         char* lds_unit, int wave, const uint32_t (&px)[2]) {
-  const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const char* src = (ok[e] && kin[e] < klim) ? base + (uint32_t)(off[e] + px[e]) : z;
-    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_unit + (wave * 2 + e) * 1024), 16, 0, 0);
-  }
-}
-
 // fp32 C tile of one wave (64 x 32, staged in `cs` by epilogue_stage): accumulate into C, or store the chunk's partial
 __device__ __forceinline__ void w8_flush(const w8_prob& q, int chunk, int m_base, int n_base, const float* cs) {
   const int lane = threadIdx.x & 63;
@@ -888,225 +877,6 @@ __device__ __forceinline__ void w8_flush(const w8_prob& q, int chunk, int m_base
   }
 }
 
-template <bool STAGGER, bool PIPE>
-__device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n, int chunk, char* smem) {
-  constexpr int UNIT = 16384, BUF = 3 * UNIT;            // A.m0 | A.m1 | B
-  const int m0 = tile_m * 256, n0 = tile_n * 128;
-  const int ktiles = (q.K + 63) >> 6;
-  const int kt0 = chunk * q.kt_chunk;
-  const int nt = (ktiles - kt0 < q.kt_chunk) ? ktiles - kt0 : q.kt_chunk;          // K tiles of this chunk (>= 1)
-  const int64_t stepA = (int64_t)q.lda * 128, stepB = (int64_t)q.ldb * 128;        // bytes per K tile (64 k rows)
-  const char* Ab = reinterpret_cast<const char*>(q.A) + (int64_t)kt0 * stepA;
-  const char* Bb = reinterpret_cast<const char*>(q.B) + (int64_t)kt0 * stepB;
-  const int krem = q.K - kt0 * 64;                       // k rows that exist from the chunk's first one on
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  // DMA instruction s = wave * 2 + e of a unit = piece s (p8_tr_src): kin[e] = the lane's k row inside a K tile
-  int kin[2];
-  uint32_t offA[2][2], offB[2];
-  bool okA[2][2], okB[2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    int ur;                                               // unit row of the lane's 8 values
-    p8_tr_src(wave * 2 + e, lane, kin[e], ur);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = m0 + (ur >> 6) * 128 + h * 64 + (ur & 63);
-      okA[h][e] = row < q.M;                              // (M % 8 == 0: the 8 rows exist together)
-      offA[h][e] = (uint32_t)(((int64_t)kin[e] * q.lda + row) * 2);
-    }
-    okB[e] = n0 + ur < q.N;
-    offB[e] = (uint32_t)(((int64_t)kin[e] * q.ldb + n0 + ur) * 2);
-  }
-  int foA[4], foB[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) foA[i] = p8_tr_frag_off(wr * 4 + i, lane);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) foB[j] = p8_tr_frag_off(wc * 2 + j, lane);
-  // what this wave owns of the matrix: its column slice, the first / second 64 rows of its row block (uniform per wave)
-  const bool do_rowsum = q.rowsum != nullptr && tile_n == 0;      // uniform
-  // (the bias row sums are dealt to ALL four wave columns: a column slice past N still takes part in them)
-  const bool liveN = (n0 + wc * 32 < q.N) || do_rowsum;
-  const bool live0 = liveN && (m0 + wr * 128 < q.M), live1 = liveN && (m0 + wr * 128 + 64 < q.M);
-
-  f32x4_t acc[2][4][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[a][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  f32x4_t rs[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rs[a][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
-
-  // k rows of K tile t (chunk-relative) that exist: all 64, the head of the matrix's last tile, or none past the chunk
-#define W8_KOK(t) kin, (((t) < nt) ? krem - (t) * 64 : 0)
-  if constexpr (PIPE) {
-    // FRAGMENT PREFETCH (round 4): a wave fetches the fragments of phase p + 1 while it issues the MFMAs of phase p (two A register
-    // sets fa0 / fa1 alternate by phase, two B sets by K tile), so the LDS round trip of a phase hides behind that phase's matrix
-    // work instead of standing in front of it: ONE barrier per phase (lgkmcnt(0) + the counted vmcnt wait in front of it), no
-    // half-phase skew.  Measured before the change: 1.05 us per K tile for 0.43 us of MFMA issue per SIMD -- the four slots of a K
-    // tile each paid [read issue + LDS latency + barrier] before their MFMAs.
-    //   phase 1 of tile t: MFMA rows m0 (fa0 x fb) | fetch fa1 <- A.m1(t)             | DMA A.m0(t+2), B(t+2) -> cur | wait A.m0, B of t+1
-    //   phase 2 of tile t: MFMA rows m1 (fa1 x fb) | fetch fa0, fb' <- A.m0, B of t+1 | DMA A.m1(t+2) -> cur         | wait A.m1 of t+1
-    // RAW: a unit is fetched one phase after the phase whose vmcnt wait + barrier retired it.  WAR: a unit is re-filled one phase
-    // after the phase that fetched it (its lgkmcnt(0) + barrier retired the reads of every wave).
-    const uint32_t px0[2] = {0u, 0u};
-#define W8_ISSUE_A(T, H, DST) w8_issue(Ab + (int64_t)(T) * stepA, offA[H], okA[H], W8_KOK(T), DST, wave, px0)
-    W8_ISSUE_A(0, 0, smem + 0 * UNIT);
-    w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave, px0);
-    W8_ISSUE_A(0, 1, smem + 1 * UNIT);
-    W8_ISSUE_A(1, 0, smem + BUF + 0 * UNIT);
-    w8_issue(Bb + stepB, offB, okB, W8_KOK(1), smem + BUF + 2 * UNIT, wave, px0);
-    W8_ISSUE_A(1, 1, smem + BUF + 1 * UNIT);
-    p8_wait_vmcnt<6>();                // tile 0 has landed
-    __builtin_amdgcn_s_barrier();
-    bf16x8_t fa0[4][2], fa1[4][2], fbX[2][2], fbY[2][2];
-    if (live0) {
-      p8_read_tr<2>(smem + 2 * UNIT, foB, fbX);
-      p8_read_tr<4>(smem + 0 * UNIT, foA, fa0);
-    }
-    p8_wait_lgkm0();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();      // every wave has fetched A.m0 / B of tile 0: phase 1 of tile 0 may re-fill them
-#define W8_KTILE(t, FBU, FBL)                                                                                                   \
-    {                                                                                                                             \
-      char* cur = smem + ((t) & 1) * BUF;                                                                                         \
-      char* oth = smem + (((t) & 1) ^ 1) * BUF;                                                                                   \
-      const int mine = (wc - 2 * (t)) & 3;              /* row-sum pair (t, ks) belongs to wave column (2 t + ks) % 4 */          \
-      if (live1) p8_read_tr<4>(cur + 1 * UNIT, foA, fa1);                                                                         \
-      W8_ISSUE_A((t) + 2, 0, cur + 0 * UNIT);                                                                                     \
-      w8_issue(Bb + (int64_t)((t) + 2) * stepB, offB, okB, W8_KOK((t) + 2), cur + 2 * UNIT, wave, px0);                           \
-      __builtin_amdgcn_sched_barrier(0);                                                                                          \
-      if (live0) {                                                                                                                \
-        p8_mfma<4, 2>(fa0, FBU, acc[0]);                                                                                          \
-        if (do_rowsum && mine < 2) {                                                                                              \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                           \
-            rs[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa0[i][1] : fa0[i][0], ones, rs[0][i], 0, 0, 0);            \
-        }                                                                                                                         \
-      }                                                                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                                                          \
-      p8_wait_vmcnt<6>();                               /* A.m0, B of tile t + 1 have landed */                                   \
-      p8_wait_lgkm0();                                                                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                                                                          \
-      __builtin_amdgcn_s_barrier();                                                                                               \
-      __builtin_amdgcn_sched_barrier(0);                                                                                          \
-      if (live0) {                                                                                                                \
-        p8_read_tr<2>(oth + 2 * UNIT, foB, FBL);                                                                                  \
-        p8_read_tr<4>(oth + 0 * UNIT, foA, fa0);                                                                                  \
-      }                                                                                                                           \
-      W8_ISSUE_A((t) + 2, 1, cur + 1 * UNIT);                                                                                     \
-      __builtin_amdgcn_sched_barrier(0);                                                                                          \
-      if (live1) {                                                                                                                \
-        p8_mfma<4, 2>(fa1, FBU, acc[1]);                                                                                          \
-        if (do_rowsum && mine < 2) {                                                                                              \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                           \
-            rs[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa1[i][1] : fa1[i][0], ones, rs[1][i], 0, 0, 0);            \
-        }                                                                                                                         \
-      }                                                                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                                                          \
-      p8_wait_vmcnt<6>();                               /* A.m1 of tile t + 1 has landed */                                       \
-      p8_wait_lgkm0();                                                                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                                                                          \
-      __builtin_amdgcn_s_barrier();                                                                                               \
-      __builtin_amdgcn_sched_barrier(0);                                                                                          \
-    }
-    for (int t = 0; t < nt; t += 2) {
-      W8_KTILE(t, fbX, fbY);
-      if (t + 1 < nt) W8_KTILE(t + 1, fbY, fbX);
-    }
-#undef W8_KTILE
-#undef W8_ISSUE_A
-  } else {
-    const uint32_t px0[2] = {0u, 0u};
-  w8_issue(Ab, offA[0], okA[0], W8_KOK(0), smem + 0 * UNIT, wave, px0);
-  w8_issue(Bb, offB, okB, W8_KOK(0), smem + 2 * UNIT, wave, px0);
-  w8_issue(Ab, offA[1], okA[1], W8_KOK(0), smem + 1 * UNIT, wave, px0);
-  w8_issue(Ab + stepA, offA[0], okA[0], W8_KOK(1), smem + BUF + 0 * UNIT, wave, px0);
-  w8_issue(Bb + stepB, offB, okB, W8_KOK(1), smem + BUF + 2 * UNIT, wave, px0);
-  p8_wait_vmcnt<4>();                  // tile 0 has landed (A.m0, B of tile 1 may still be moving)
-  __builtin_amdgcn_s_barrier();
-  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
-
-  bf16x8_t fa[4][2], fb[2][2];
-  for (int t = 0; t < nt; ++t) {
-    char* cur = smem + (t & 1) * BUF;
-    char* oth = smem + ((t & 1) ^ 1) * BUF;
-    const int mine = (wc - 2 * t) & 3;                   // row-sum pair (t, ks) belongs to wave column (2 t + ks) % 4
-    // ---- phase 1: rows m0
-    if (live0) {
-      p8_read_tr<2>(cur + 2 * UNIT, foB, fb);
-      p8_read_tr<4>(cur + 0 * UNIT, foA, fa);
-    }
-    w8_issue(Ab + (int64_t)(t + 1) * stepA, offA[1], okA[1], W8_KOK(t + 1), oth + 1 * UNIT, wave, px0);      // A.m1 of tile t + 1
-    p8_wait_vmcnt<6>();                                                                               // A.m1 of tile t has landed
-    P8_PHASE_SYNC_IN();
-    if (live0) {
-      p8_mfma<4, 2>(fa, fb, acc[0]);
-      if (do_rowsum && mine < 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rs[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[0][i], 0, 0, 0);
-      }
-    }
-    P8_PHASE_SYNC_OUT();
-    // ---- phase 2: rows m1
-    if (live1) p8_read_tr<4>(cur + 1 * UNIT, foA, fa);
-    w8_issue(Ab + (int64_t)(t + 2) * stepA, offA[0], okA[0], W8_KOK(t + 2), cur + 0 * UNIT, wave, px0);      // A.m0 of tile t + 2
-    w8_issue(Bb + (int64_t)(t + 2) * stepB, offB, okB, W8_KOK(t + 2), cur + 2 * UNIT, wave, px0);            // B of tile t + 2
-    p8_wait_vmcnt<6>();                                                                               // A.m0, B of tile t + 1 have landed
-    P8_PHASE_SYNC_IN();
-    if (live1) {
-      p8_mfma<4, 2>(fa, fb, acc[1]);
-      if (do_rowsum && mine < 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rs[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mine ? fa[i][1] : fa[i][0], ones, rs[1][i], 0, 0, 0);
-      }
-    }
-    P8_PHASE_SYNC_OUT();
-  }
-  }
-#undef W8_KOK
-  if (!PIPE && STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
-  p8_wait_vmcnt<0>();
-  __syncthreads();
-  if (do_rowsum) {
-    float* part = reinterpret_cast<float*>(smem + 2 * BUF - 4096);         // [4 wc][256 rows], above the C tiles of the epilogue
-    const int lr = lane & 15, lg = lane >> 4;
-    if (lr == 0) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) part[wc * 256 + wr * 128 + a * 64 + i * 16 + lg * 4 + r] = rs[a][i][r];
-    }
-    __syncthreads();
-    if (threadIdx.x < 256) {
-      const int m = m0 + (int)threadIdx.x;
-      if (m < q.M) {
-        const float v = ((part[threadIdx.x] + part[256 + threadIdx.x]) + part[512 + threadIdx.x]) + part[768 + threadIdx.x];
-        if (q.nchunks > 1) q.rs_ws[(int64_t)chunk * q.M + m] = v;
-        else q.rowsum[m] = ((q.flags & 2) ? q.rowsum[m] : 0.f) + v;
-      }
-    }
-  }
-  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
-#pragma unroll 1
-  for (int a = 0; a < 2; ++a) {
-    if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
-    else epilogue_stage<64, 32>(acc[1], cs);
-    w8_flush(q, chunk, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // LOADER-SPECIALISED W8 tile (round 4, "LS"): 12 waves -- 8 CONSUMER waves (the 2 x 4 wave grid of the 256 x 128 tile: fragment
 // reads + MFMAs, nothing else) and 4 LOADER waves (one per SIMD: all LDS-DMA instructions, the address masks, the counted vmcnt
@@ -1119,7 +889,8 @@ __device__ __forceinline__ void w8_tile(const w8_prob& q, int tile_m, int tile_n
 //   barrier B(t) (t = 0 .. nt): loaders arrive when THEIR share of tile t has landed (counted vmcnt: the 12 instructions of the tile
 //   issued last may still be in flight) -- so tile t is complete for every reader behind B(t); consumers arrive at B(t + 1) with
 //   every read of tile t retired (lgkmcnt(0)) -- so behind B(t + 1) the loaders may overwrite stage t % 3 with tile t + 3.
-// Same LDS image, fragment offsets, masks, chunking, row sums and epilogue as w8_tile: the results are bit-identical to it.
+// Same LDS image, fragment offsets, masks, chunking, row sums and epilogue as the 8-wave tile it replaced (removed at the end of round 4
+// together with its fragment-prefetch variant: bit-identical results, 1.05 - 1.07 us per K tile).
 // Measured (tools/_scratch sweep, one problem of 72-96 tiles): 0.83 us per K tile against 1.07 (8 waves, fragment prefetch) and 1.05
 // (p8_tr_tile); a variant with four sub-phases and the next sub-phase's fragments requested ahead of the MFMAs needs 12 registers
 // more than the 168 that three waves per SIMD allow (spills: slower with the row sums, +3 % without) -- not kept.
@@ -1306,32 +1077,6 @@ __global__ __launch_bounds__(768) void gemm_w8ls_kernel(const w8_args g) {
     r -= chunk * per_chunk;
     const int tile_m = r / q.tiles_n;
     w8ls_tile(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
-  }
-}
-
-// one workgroup per unit; gridDim.x = total units (or a cap: the workgroups then walk the units)
-template <bool STAGGER, bool PIPE>
-__global__ __launch_bounds__(512) void gemm_w8_kernel(const w8_args g) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * 3 * 16384];
-#pragma unroll 1
-  for (int id = (int)blockIdx.x; id < g.total; id += (int)gridDim.x) {
-    int u = id;
-    if (gridDim.x == (unsigned)g.total) {                // XCD x gets the x-th contiguous run of units
-      const int q8 = g.total >> 3, r8 = g.total & 7;
-      const int xcd = id & 7, j = id >> 3;
-      u = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j;
-    }
-    int p = 0;
-#pragma unroll 1
-    for (int i = 1; i < g.n; ++i) p += (g.unit_start[i] <= u) ? 1 : 0;
-    const w8_prob& q = g.p[p];
-    int r = u - g.unit_start[p];
-    const int per_chunk = q.tiles_m * q.tiles_n;
-    const int chunk = r / per_chunk;
-    r -= chunk * per_chunk;
-    const int tile_m = r / q.tiles_n;
-    w8_tile<STAGGER, PIPE>(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
-    __syncthreads();               // (capped grid) the next unit's first DMA overwrites the epilogue's staging tiles
   }
 }
 
@@ -1696,13 +1441,8 @@ extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, 
     g.n = cnt;
     g.total = (int32_t)total;
     const unsigned wgs = (unsigned)((cap > 0 && total > cap) ? cap : total);
-    static const bool pipe = !getenv_off("S2SVC_W8_PIPE");
-    static const bool ls = !getenv_off("S2SVC_W8_LS");       // loader-specialised tile (12 waves): one workgroup per unit
-    if (ls) hipLaunchKernelGGL(gemm_w8ls_kernel, dim3(wgs), dim3(768), 0, st, g);
-    else if (pipe) hipLaunchKernelGGL((gemm_w8_kernel<false, true>), dim3(wgs), dim3(512), 0, st, g);
-    else if (mode == 2) hipLaunchKernelGGL((gemm_w8_kernel<false, false>), dim3(wgs), dim3(512), 0, st, g);
-    else hipLaunchKernelGGL((gemm_w8_kernel<true, false>), dim3(wgs), dim3(512), 0, st, g);
-    S2S_CHECK_LAUNCH("gemm_w8_kernel");
+    hipLaunchKernelGGL(gemm_w8ls_kernel, dim3(wgs), dim3(768), 0, st, g);
+    S2S_CHECK_LAUNCH("gemm_w8ls_kernel");
     if (any_split) {
       hipLaunchKernelGGL(w8_reduce_kernel, dim3(48, (unsigned)cnt), dim3(256), 0, st, g);
       S2S_CHECK_LAUNCH("w8_reduce_kernel");

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B runs of bench.py on ONE box: every line is "[workload] '<env switches>' <ms_per_step> <grad_norm>".
-#   gpurun -- 'bash tools/ab_bench.sh aasvc "" S2SVC_W8_LS=0 "S2SVC_AAS_FBRANCH=0 S2SVC_FS_PREFETCH=0"'
+#   gpurun -- 'bash tools/ab_bench.sh aasvc "" S2SVC_GEMM_W8=0 "S2SVC_AAS_FBRANCH=0 S2SVC_FS_PREFETCH=0"'
 #   EXTRA="--split-backward" bash tools/ab_bench.sh aasvc ...      (further bench.py flags)
 wl=$1; shift
 for envs in "$@" "$1"; do
