@@ -226,8 +226,11 @@ class FlatAdam:
     # 12.74 ms without; VTN 4.00 vs 4.00 ms.  The three passes launch enough workgroups to fill the chip, and the forward
     # pass is a chain of small dependent kernels that then queue for CUs behind them: what runs beside the chain is not free
     # even when it is HBM-bound and the chain is not.  So the overlap is OFF by default and the passes stay in line (refresh at
-    # the end of step(), zero-fill in begin_step() / zero_grad()); the switch stays for the next attempt (passes restricted to
-    # a quarter of the CUs).
+    # the end of step(), zero-fill in begin_step() / zero_grad()).  Round 4 made that next attempt -- only the transposed shadow and
+    # the zero-fill (both first needed by the backward pass) on the prologue stream, as CAPPED grids of 16 ... 2048 workgroups that
+    # walk the tiles: 16 / 32 / 64 workgroups cannot move 1.3 GB inside a forward pass (32.6 / 20.6 / 14.2 ms per AAS-VC step), 256 ...
+    # 2048 give 11.52-11.59 ms against 11.40 in line (VTN 3.79-3.82 vs 3.76): the passes cost the forward pass more than the
+    # in-line launches cost the step, whatever their shape -- removed again; the switch stays as the A/B aid it was.
     overlap_prologue = os.environ.get("S2SVC_PROLOGUE_OVERLAP", "0") == "1"
 
     def _prologue_stream(self, main):
