@@ -298,6 +298,55 @@ def test_gradient_cuts_split_the_backward_pass_without_changing_it():
         assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
 
 
+def test_branch_cut_with_shared_leaves_and_the_real_sdp_cut_points():
+    """The round-4 stage plans cut INSIDE an auxiliary-stream branch: two conditioning networks feed many consumers (x feeds both
+    flow stacks and, added to h_w, the posterior one), the cut carries (x, h_w) as a tuple, the flows' backward pass accumulates in
+    the detached leaves and a later stage resumes both networks in ONE autograd call (ops.functional.GradCuts; sdp.py: "sdp_cond" /
+    "sdp_cond_x"; distributed.OverlappedBackward with a cut as branch root).  CPU restatement of exactly that shape; and the model
+    sources hold the cut points the plans name."""
+    from seq2seq_vc_amd.ops import functional as Fn
+
+    torch.manual_seed(1)
+    wa, wb = torch.randn(4, 4, requires_grad=True), torch.randn(4, 4, requires_grad=True)      # the two conditioning networks
+    wf = [torch.randn(4, 4, requires_grad=True) for _ in range(3)]                              # consumers ("flows")
+    inp, w_in = torch.randn(7, 4), torch.randn(7, 4)
+
+    def net(which):
+        x, hw = torch.tanh(inp @ wa), torch.tanh(w_in @ wb)
+        if which == "both":
+            x, hw = Fn.cut_point((x, hw), "sdp_cond")
+        elif which == "x":
+            x = Fn.cut_point(x, "sdp_cond_x")
+        g = x + hw
+        post = torch.sigmoid(g @ wf[0]) + torch.sigmoid(g @ wf[1])                               # posterior flows: use x AND h_w
+        prior = torch.sigmoid(x @ wf[2]) * post.detach().mean()                                   # prior flows: use x only
+        return (post + prior).pow(2).sum()
+
+    ps = [wa, wb] + wf
+    net(None).backward()
+    ref = [t.grad.clone() for t in ps]
+    for which, name, late in (("both", "sdp_cond", (0, 1)), ("x", "sdp_cond_x", (0,))):
+        for t in ps:
+            t.grad = None
+        cuts = Fn.GradCuts([name])
+        with Fn.grad_cuts(cuts):
+            loss = net(which)
+        loss.backward()
+        assert all(ps[i].grad is None for i in late), "the networks below the cut must wait for their stage"
+        assert all(ps[i].grad is not None for i in range(2, 5))
+        cuts.resume(name)
+        for got, want in zip([t.grad for t in ps], ref):
+            assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+    root = os.path.join(ROOT, "seq2seq_vc_amd")
+    sdp_src = open(os.path.join(root, "sdp.py")).read()
+    assert 'cut_point((x, h_w), "sdp_cond")' in sdp_src and 'cut_point(x, "sdp_cond_x")' in sdp_src
+    assert '"cut:sdp_cond"' in open(os.path.join(root, "models", "aas_vc.py")).read()
+    vtn_src = open(os.path.join(root, "models", "vtn.py")).read()
+    assert 'cut_point(tuple(head), "decoder_head")' in vtn_src and '"cut:decoder_head"' in vtn_src
+    dist_src = open(os.path.join(root, "distributed", "__init__.py")).read()
+    assert 'branch_root.startswith("cut:")' in dist_src
+
+
 def test_lens_bank_keeps_lengths_out_of_a_captured_step():
     """modules.LensBank (captured trainer steps): every Lens made while a bank is active is a slot of one buffer and
     remembers its derivation; refresh() recomputes all slots from new root lengths; max() is the padded length; lengths
