@@ -130,7 +130,12 @@ def _vtn_cpu_step(sd, params, state, batch, it):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_vtn(batch, steps=1):
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def cpu_baseline_vtn(batch, steps=3):
     """fwd + loss + bwd + clip + Adam at the same shapes, fp32, train-mode dropout on: the oracle on the host cores at the best
     of three thread counts (a box with 128 hardware threads is SLOWER with all of them than with 16-32: VERDICT r2 weak #10), and
     on ONE thread -- the recipes export OMP_NUM_THREADS=1 (egs/arctic/vc1/path.sh:16) -- over a quarter of the batch."""
@@ -146,8 +151,11 @@ def cpu_baseline_vtn(batch, steps=1):
         for nt in _thread_candidates(info):
             torch.set_num_threads(nt)
             _vtn_cpu_step(sd, params, state, batch, 0)                         # warm-up at this thread count
-            sweep[nt] = sum(_vtn_cpu_step(sd, params, state, batch, 1 + i) for i in range(steps)) / steps
+            sweep[nt] = _vtn_cpu_step(sd, params, state, batch, 1)
         best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)                                            # the reported figure: MEDIAN of `steps` further steps
+        runs = [sweep[best]] + [_vtn_cpu_step(sd, params, state, batch, 2 + i) for i in range(steps - 1)]
+        sweep[best] = _median(runs)
         torch.set_num_threads(1)
         small = _slice_batch(batch, 8)
         t1 = _vtn_cpu_step(sd, params, state, small, 9)
@@ -155,8 +163,8 @@ def cpu_baseline_vtn(batch, steps=1):
         torch.set_num_threads(keep)
     t = sweep[best]
     return {"value": float(olens.sum()) / t, "unit": "mel-frames/sec", "cores": best, "kind": "port",
-            "sample": f"{steps} optimiser step(s) (after 1 warm-up) of the same VTN-vc1 B=32 batch, fp32, {t:.2f} s/step at {best} threads",
-            "ms_per_step": t * 1e3, **info,
+            "sample": f"median of {steps} optimiser steps (after 1 warm-up) of the same VTN-vc1 B=32 batch, fp32, {t:.2f} s/step at {best} threads",
+            "ms_per_step": t * 1e3, "steps_timed": steps, "s_per_step_runs": [round(r, 3) for r in runs], **info,
             "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
             "one_thread": {"value": float(small[4].sum()) / t1, "unit": "mel-frames/sec", "cores": 1,
                            "sample": f"1 optimiser step of the first 8 of the 32 utterance pairs, {t1:.2f} s (OMP_NUM_THREADS=1 as in egs/arctic/vc1/path.sh:16)"}}
@@ -178,7 +186,7 @@ def _aasvc_cpu_step(sd, params, state, batch, it):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_aasvc(batch, steps=1, threads=None):
+def cpu_baseline_aasvc(batch, steps=3, threads=None):
     """The AAS-VC training step of trainers/aas_vc.py:56-164 on the oracle: forward (incl. the C alignment search) + L1 +
     lambda*(forward-sum + bin) + duration NLL + backward + clip + Adam, fp32, dropout on; the better of 16 and 32 host threads (or
     `threads`) and ONE thread over two of the 16 utterance pairs."""
@@ -195,17 +203,19 @@ def cpu_baseline_aasvc(batch, steps=1, threads=None):
         for nt in cands:
             torch.set_num_threads(nt)
             _aasvc_cpu_step(sd, params, state, batch, 0)
-            sweep[nt] = sum(_aasvc_cpu_step(sd, params, state, batch, 1 + i) for i in range(steps)) / steps
+            sweep[nt] = _aasvc_cpu_step(sd, params, state, batch, 1)
         nt = min(sweep, key=sweep.get)
-        t = sweep[nt]
+        torch.set_num_threads(nt)
+        runs = [sweep[nt]] + [_aasvc_cpu_step(sd, params, state, batch, 2 + i) for i in range(steps - 1)]
+        t = sweep[nt] = _median(runs)
         torch.set_num_threads(1)
         small = _slice_batch(batch, 2)
         t1 = _aasvc_cpu_step(sd, params, state, small, 9)
     finally:
         torch.set_num_threads(keep)
     return {"value": float(olens.sum()) / t, "unit": "mel-frames/sec", "cores": nt, "kind": "port",
-            "sample": f"{steps} optimiser step(s) (after 1 warm-up) of the same AAS-VC-vc2 B=16 batch, fp32, {t:.2f} s/step at {nt} threads",
-            "ms_per_step": t * 1e3, **info, "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": f"median of {steps} optimiser steps (after 1 warm-up) of the same AAS-VC-vc2 B=16 batch, fp32, {t:.2f} s/step at {nt} threads",
+            "ms_per_step": t * 1e3, "steps_timed": steps, "s_per_step_runs": [round(r, 3) for r in runs], **info, "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
             "one_thread": {"value": float(small[4].sum()) / t1, "unit": "mel-frames/sec", "cores": 1,
                            "sample": f"1 optimiser step of the first 2 of the 16 utterance pairs, {t1:.2f} s"}}
 
@@ -756,49 +766,140 @@ def _by_time(workload):
         return json.load(f).get(workload)
 
 
-def _flat_front(out):
-    """The driver's record keeps top-level SCALARS (and only the key names of nested objects): the C3 / C5 figures and the rooflines
-    as flat keys in FRONT of the line; the nested objects follow unchanged."""
-    flat = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                "vs_baseline", "dtype", "data") if k in out}
+def _get(obj, *path):
+    for p in path:
+        if not isinstance(obj, dict) or p not in obj:
+            return None
+        obj = obj[p]
+    return obj if isinstance(obj, (int, float, str, bool)) else None
 
-    def put(key, obj, *path):
-        for p in path:
-            if not isinstance(obj, dict) or p not in obj:
-                return
-            obj = obj[p]
-        if isinstance(obj, (int, float, str, bool)) or obj is None:
-            flat[key] = obj
-    put("roofline_frac", out, "roofline", "frac")
-    put("roofline_kernel_us", out, "roofline", "avg_launch_us")
-    put("roofline_by_time_family", out, "roofline", "by_time", "family")
-    put("roofline_by_time_share", out, "roofline", "by_time", "share_of_kernel_time")
-    put("roofline_by_time_mfma_busy", out, "roofline", "by_time", "mfma_busy")
-    put("step_mfma_frac", out, "step_mfma", "frac_of_bf16_peak")
-    put("cpu_baseline_value", out, "cpu_baseline", "value")
-    put("cpu_baseline_cores", out, "cpu_baseline", "cores")
-    put("aasvc_ms_per_step", out, "aasvc", "ms_per_step")
-    put("aasvc_mel_frames_per_s", out, "aasvc", "value")
-    put("aasvc_roofline_frac", out, "aasvc", "roofline", "frac")
-    put("aasvc_step_mfma_frac", out, "aasvc", "step_mfma", "frac_of_bf16_peak")
-    put("aasvc_cpu_baseline", out, "aasvc", "cpu_baseline", "value")
-    put("aasvc_cpu_baseline_cores", out, "aasvc", "cpu_baseline", "cores")
-    put("decode_rtf", out, "decode", "value")
-    put("decode_us_per_step", out, "decode", "us_per_step")
-    put("decode_cpu_baseline_rtf", out, "decode", "cpu_baseline", "value")
-    put("trainer_hip_graph_ms_per_step", out, "trainer", "hip_graph_ms_per_step")
-    put("trainer_eager_ms_per_step", out, "trainer", "eager_ms_per_step")
-    put("mas_us_per_utterance", out, "alignment", "mas", "us_per_utterance")
-    put("forward_sum_us_per_utterance", out, "alignment", "forward_sum", "us_per_utterance")
+
+def _shape_line(out):
+    """Shape of the ONE JSON line.  The driver's record keeps the scalar fields of `config`, `roofline` and `cpu_baseline`, the
+    top-level scalars, only the NAMES of other nested objects, and the last 2 000 characters of the line.  So: the C3 (AAS-VC) / C5
+    (decode) / trainer figures are scalars INSIDE `config`, the by-time kernel family's share and MFMA-busy are scalars inside
+    `roofline`, the other CPU baselines scalars inside `cpu_baseline`; the verbose objects (memory_bound, alignment, the full
+    sub-benchmark objects, roofline.by_time's top-5 list) come FIRST and the line ENDS with the same figures as flat scalars."""
+    cfg, roof, cpu = out.get("config", {}), out.get("roofline") or {}, out.get("cpu_baseline")
+    extra = {
+        "aasvc_ms_per_step": _get(out, "aasvc", "ms_per_step"),
+        "aasvc_mel_frames_per_s": _get(out, "aasvc", "value"),
+        "aasvc_roofline_frac": _get(out, "aasvc", "roofline", "frac"),
+        "aasvc_roofline_kernel_us": _get(out, "aasvc", "roofline", "avg_launch_us"),
+        "aasvc_step_mfma_frac": _get(out, "aasvc", "step_mfma", "frac_of_bf16_peak"),
+        "aasvc_cpu_frames_per_s": _get(out, "aasvc", "cpu_baseline", "value"),
+        "aasvc_cpu_cores": _get(out, "aasvc", "cpu_baseline", "cores"),
+        "aasvc_speedup_vs_cpu": _get(out, "aasvc", "speedup_vs_cpu_baseline"),
+        "aasvc_by_time_family": _get(out, "aasvc", "roofline", "by_time", "family"),
+        "aasvc_by_time_mfma_busy": _get(out, "aasvc", "roofline", "by_time", "mfma_busy"),
+        "decode_rtf": _get(out, "decode", "value"),
+        "decode_us_per_step": _get(out, "decode", "us_per_step"),
+        "decode_cpu_rtf": _get(out, "decode", "cpu_baseline", "value"),
+        "trainer_hip_graph_ms_per_step": _get(out, "trainer", "hip_graph_ms_per_step"),
+        "trainer_eager_ms_per_step": _get(out, "trainer", "eager_ms_per_step"),
+        "mas_us_per_utterance": _get(out, "alignment", "mas", "us_per_utterance"),
+        "forward_sum_us_per_utterance": _get(out, "alignment", "forward_sum", "us_per_utterance"),
+        "step_mfma_frac": _get(out, "step_mfma", "frac_of_bf16_peak"),
+    }
+    extra = {k: v for k, v in extra.items() if v is not None}
+    cfg.update(extra)
+    by_time = roof.pop("by_time", None) if isinstance(roof, dict) else None
+    if isinstance(by_time, dict):
+        roof["by_time_family"] = by_time.get("family")
+        roof["by_time_share"] = by_time.get("share_of_kernel_time")
+        roof["by_time_mfma_busy"] = by_time.get("mfma_busy")
+        roof["by_time_launches_per_step"] = by_time.get("launches_per_step")
+        roof["by_time_source"] = by_time.get("source")
+    if isinstance(cpu, dict):
+        for k_src, k_dst in (("aasvc_cpu_frames_per_s", "aasvc_value"), ("aasvc_cpu_cores", "aasvc_cores"), ("decode_cpu_rtf", "decode_rtf")):
+            if k_src in extra:
+                cpu[k_dst] = extra[k_src]
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data")
+    line = {k: out[k] for k in head if k in out}
+    for k in ("memory_bound", "alignment", "aasvc", "decode", "trainer"):          # verbose objects first
+        if k in out:
+            line[k] = out[k]
+    if by_time is not None:
+        line["roofline_by_time"] = by_time
     for k, v in out.items():
-        if k not in flat:
-            flat[k] = v
-    return flat
+        if k not in line and k not in ("config", "roofline", "cpu_baseline"):
+            line[k] = v
+    line["config"] = cfg
+    if roof:
+        line["roofline"] = roof
+    if cpu is not None:
+        line["cpu_baseline"] = cpu
+    tail = {"roofline_frac": _get(roof, "frac"), "roofline_kernel_us": _get(roof, "avg_launch_us"),
+            "roofline_by_time_family": _get(roof, "by_time_family"), "roofline_by_time_share": _get(roof, "by_time_share"),
+            "roofline_by_time_mfma_busy": _get(roof, "by_time_mfma_busy"),
+            "cpu_baseline_value": _get(cpu, "value"), "cpu_baseline_cores": _get(cpu, "cores"), **extra}
+    for k, v in tail.items():                                                     # ... and the line ends with the flat scalars
+        if v is not None:
+            line[k] = v
+    return line
 
 
 def Fn_reset():
     from seq2seq_vc_amd.ops import functional as Fn
     Fn.enable_side_streams(0)
+
+
+def spawn_ranks(n, argv=None):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (RANK = LOCAL_RANK = 0..N-1,
+    WORLD_SIZE = N, rendezvous on a free port of 127.0.0.1 -- the env contract of torch.distributed.run and of the reference's
+    distributed/launch.py:119-173), wait for all of them and return the first non-zero exit code.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:                            # a dead rank leaves the others waiting in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dist_dry_run(world, rank):
+    """The launcher contract without a GPU (CPU test): join a gloo group, sum a 1 over the ranks, rank 0 prints what it saw."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    one = torch.ones(1)
+    dist.all_reduce(one)
+    ranks = torch.zeros(world)
+    ranks[rank] = 1.0
+    dist.all_reduce(ranks)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": int(one.item()), "world_size": world, "ranks_present": int(ranks.sum().item())}),
+              flush=True)
+    dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -820,23 +921,40 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code path (RCCL process group, staged backward, overlapped all-reduces) at world size 1")
     ap.add_argument("--grad-payload", default=None, choices=["fp32", "bf16"],
-                    help="dtype of the gradient exchange (default: fp32 for vtn = the trainers' default; bf16 for aasvc = the opt-in "
-                         "config['dp_grad_payload'] the AAS-VC multi-GPU recipe sets; reported in config.grad_payload)")
+                    help="dtype of the gradient exchange (default: the trainers' default, <Trainer>.DP_GRAD_PAYLOAD = fp32; bf16 is the "
+                         "opt-in config['dp_grad_payload']; reported in config.grad_payload)")
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="data parallel: one all-reduce per bucket, or reduce-scatter + all-gather")
     ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
     ap.add_argument("--side-streams", type=int, default=None, help="HIP side streams for parameter-gradient kernels (default: 4 for vtn, 0 + inline batches for aasvc)")
+    ap.add_argument("--dist-dry-run", action="store_true",
+                    help="launcher check without a GPU: every rank joins a gloo group, all-reduces a 1 and rank 0 prints the rank count")
     args = ap.parse_args()
 
+    # --gpus N is the number of ranks of the job.  Launched by torch.distributed.run (the driver's N > 1 command) the environment
+    # carries WORLD_SIZE = N already; launched bare (`python bench.py --gpus 4`) this process becomes the launcher of N ranks --
+    # one process per GPU, env rendezvous on 127.0.0.1, like the reference's distributed/launch.py:119-173.  A WORLD_SIZE that
+    # disagrees with --gpus is an error, never a silent 1-rank run.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher: "
+              f"`python bench.py --gpus {args.gpus}` starts the ranks itself)", file=sys.stderr)
+        raise SystemExit(2)
+    if args.dist_dry_run:
+        raise SystemExit(dist_dry_run(world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     dp = world > 1 or args.force_dist          # the data-parallel code path (also reachable at world size 1 for testing)
+    ranks_seen = 1
     if dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -844,6 +962,11 @@ def main():
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                   # n_gpus of the line = the ranks RCCL actually summed over
+        ranks_seen = int(one.item())
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: RCCL reduced over {ranks_seen} ranks, WORLD_SIZE is {world}")
 
     from seq2seq_vc_amd.ops import functional as Fn
     from seq2seq_vc_amd.ops import kernels as K
@@ -866,7 +989,8 @@ def main():
     # slice of the flat gradient buffer issued between the replays (overlap).  N = 1 keeps one graph (the cuts cost ~0.2 ms).
     staged = dp or args.split_backward
     if args.grad_payload is None:
-        args.grad_payload = "bf16" if args.workload == "aasvc" else "fp32"
+        from seq2seq_vc_amd import trainers as TR      # what the workload's product trainer defaults to (fp32 = the reference's DDP)
+        args.grad_payload = (TR.ARVCTrainer if args.workload == "vtn" else TR.AASVCTrainer).DP_GRAD_PAYLOAD
     step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
                             warmup_eager=max(2, args.warmup if args.no_graph else 2))
     probe = info.pop("_probe")
@@ -888,7 +1012,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "mel-frames/sec (train)", "value": frames / (dt / args.steps), "unit": "mel-frames/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl.desc, "batch_per_gpu": B, "global_batch": B * world, "T_src": 256, "T_tgt": 256, "mel_dim": 80,
                        "params_M": round(wl.params_m, 2), "parallelism": f"dp{world}", "split_backward": bool(staged),
@@ -917,7 +1041,7 @@ def main():
                     out[key] = {"error": f"{type(e).__name__}: {e}"}
                     print(f"[bench] sub-benchmark '{key}' failed: {type(e).__name__}: {e}", file=sys.stderr)
                 Fn.enable_side_streams(0)
-        out = _flat_front(out)
+        out = _shape_line(out)
         # RCCL writes its version banner to the C-level stdout; flush that buffer first so the JSON line stays the last line
         sys.stdout.flush()
         try:

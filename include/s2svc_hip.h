@@ -145,8 +145,9 @@ int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs /* host */, int n, v
    /root/reference trainers/ar_vc.py:99-107: loss.backward() fills every parameter's .grad), as ONE grid of (problem, K chunk,
    256 x 128 tile) units, up to 40 problems per launch.  A reduction longer than 64 K tiles of 64 rows is cut into chunks -- a
    function of K only -- whose fp32 partial tiles go through `ws` and are added in chunk order by a second launch (deterministic).
-     _ok        : 1 if the kernel takes `desc` (a function of the descriptor only; exact-256 problems with >= 64 tiles of
-                  128 x 128 stay with s2svc_gemm_grouped's 8-wave path);
+     _ok        : 1 if the kernel takes `desc` (a function of the descriptor only).  Since round 4 that includes the exact-256
+                  problems with >= 64 tiles of 128 x 128 (AAS-VC's decoder layers); only S2SVC_W8_EXACT=0 in the environment sends
+                  those back to s2svc_gemm_grouped's 8-wave exact-tile path;
      _ws_floats : fp32 elements of workspace the listed problems need (0 = none);
      _grouped   : launch; `ws` device memory (16-byte aligned) the caller keeps untouched until the launches have run. */
 int s2svc_gemm_wgrad_ok(const s2svc_gemm_desc* desc /* host */);

@@ -1356,7 +1356,6 @@ bool w8_ok(const s2svc_gemm_desc& d) {
   if ((int64_t)64 * d.A.ld * 2 + (int64_t)d.M * 2 >= (1ll << 32) || (int64_t)64 * d.B.ld * 2 + (int64_t)d.N * 2 >= (1ll << 32)) return false;
   if (((uintptr_t)d.C) % 16 || d.ldc % 4 || d.ldc < d.N) return false;
   if (d.bias || d.res || d.act != S2S_ACT_NONE || d.alpha != 1.0f || d.emask || d.drop_p > 0.f || d.c_map || d.c_pre) return false;
-  // the exact-256 problems with >= 64 tiles of 128 x 128 keep p8_tr_tile / p8_tr_tile_q (grouped or background launches)
   // the exact-256 problems with >= 64 tiles of 128 x 128 (AAS-VC's decoder) ran on p8_tr_tile / p8_tr_tile_q until the loader-
   // specialised tile beat both per flop (0.83 us per 256 x 128 K tile against 1.05); S2SVC_W8_EXACT=0 sends them back there
   static const bool exact_too = !getenv_off("S2SVC_W8_EXACT");

@@ -776,11 +776,31 @@ static int ln_pg_rpw(int rows) {
   int rpw = (rows + 2047) / 2048;                 // ~256 blocks of 8 waves
   return rpw < 1 ? 1 : rpw;
 }
+// > 64 KB of dynamic LDS needs the function attribute, per DEVICE (a second GPU in one process is a second function handle) and the
+// call can fail: the eligibility test asks here, so a failure sends the site to the plain backward kernel + separate reduction.
+template <int NV>
+static bool ln_pg_lds_ok() {
+  const size_t lds = (size_t)8 * 2 * NV * 512 * sizeof(float);
+  if (lds <= 64 * 1024) return true;
+  static int state[64] = {};                 // per device: 0 = not tried, 1 = set, -1 = refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (state[dev] == 0) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec_pg_kernel<NV>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) (void)hipGetLastError();
+    state[dev] = e == hipSuccess ? 1 : -1;
+  }
+  return state[dev] == 1;
+}
+static bool ln_pg_lds_ok_for(int D) { return D <= 512 ? ln_pg_lds_ok<1>() : D <= 1024 ? ln_pg_lds_ok<2>() : ln_pg_lds_ok<4>(); }
+
 extern "C" int s2svc_layernorm_bwd_pg_chunks(int dtype, int rows, int D, const void* dy, const void* s, const float* gamma,
                                              const void* ds_extra, const void* ds, const void* dh) {
   static const bool on = !(getenv("S2SVC_LN_PG") && getenv("S2SVC_LN_PG")[0] == '0');
   if (!on || dtype != S2S_BF16 || D > 2048 || rows < 2048 || (int64_t)rows * D < 1500000) return 0;
   if (!ln_vec_ok(D, dy, s, ds, dh, ds_extra) || ((uintptr_t)gamma) % 16) return 0;
+  if (!ln_pg_lds_ok_for(D)) return 0;
   const int rpw = ln_pg_rpw(rows);
   return (rows + 8 * rpw - 1) / (8 * rpw);
 }
@@ -795,9 +815,6 @@ extern "C" int s2svc_layernorm_bwd_pg(int dtype, int rows, int D, const void* dy
 #define S2S_LN_PG(NV_)                                                                                                               \
   do {                                                                                                                                \
     const size_t lds = (size_t)8 * 2 * (NV_) * 512 * sizeof(float);                                                                   \
-    static bool attr_done_##NV_ = false;                                                                                              \
-    if (lds > 64 * 1024 && !attr_done_##NV_ && (attr_done_##NV_ = true))                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_vec_pg_kernel<NV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(ln_bwd_vec_pg_kernel<NV_>, dim3((unsigned)chunks), dim3(512), lds, st, rows, D, rpw, (const bf16_t*)dy,         \
                        (const bf16_t*)s, mean, rstd, gamma, (const bf16_t*)ds_extra, drop_p, hscale, seed_base, seed_off, (bf16_t*)ds, \
                        (bf16_t*)dh, ws);                                                                                             \

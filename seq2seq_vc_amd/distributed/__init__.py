@@ -312,6 +312,8 @@ def allreduce_grads_(params, dist, world, group=None):
     if not ps:
         return
     dev, dt = ps[0].device, ps[0].dtype
+    for p in ps[1:]:                 # the buffer takes the WIDEST dtype of the set: fp32 gradients are never rounded through a bf16 /
+        dt = torch.promote_types(dt, p.dtype)     # fp16 neighbour's dtype on the way (each parameter gets its own dtype back below)
     has = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], dtype=dt, device=dev)
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in ps] + [has])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -52,6 +52,7 @@ class _Entry:
         self.bank = None
         self.graphs = []          # [(graph, stage index or None)]
         self.deltas = None
+        self.zero_due_after = None    # optimizer._zero_due as the captured step left it (host state a replay must reproduce)
         self.sightings = 0
 
 
@@ -188,6 +189,11 @@ class GraphedStep:
             e.bank.refresh({lname: src.tolist() for lname, src in e.lens_src.items()})
             t.steps += e.deltas[0]
             t.backward_steps += e.deltas[1]
+            if e.zero_due_after is not None:
+                # begin_step() / zero_grad(defer=True) ran as Python only at capture time: a replay must leave the flag the way the
+                # captured step did, or the next window's role key (Trainer._graph_regime) picks an accumulate graph without the
+                # zero-fill (only S2SVC_PROLOGUE_OVERLAP=1 ever sets the flag)
+                t.optimizer._zero_due = e.zero_due_after
             t._check_train_finish()
             t.optimizer._touch()        # the weights change without a Python-side optimizer.step(): cached decode sessions etc. go stale
         self._replay(e)
@@ -243,6 +249,8 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(self.stream)
         e.bank.closed = True
         e.deltas = (t.steps - before[0], t.backward_steps - before[1])
+        if hasattr(t.optimizer, "_zero_due"):
+            e.zero_due_after = bool(t.optimizer._zero_due)
 
 
 class _Capture:
