@@ -297,16 +297,24 @@ template <int WTM, int WTN>
 __device__ __forceinline__ void epilogue_flush_common(const s2svc_gemm_desc& d, int m_base, int n_base, const float* cs) {
   const int lane = threadIdx.x & 63;
   constexpr int LPR = WTN / 8, RPP = 64 / LPR;
+  // a lane keeps its 8 columns through the row loop: the bias is loaded ONCE, ahead of the loop (the rolled loop otherwise pays a
+  // dependent global load per iteration for the same eight values)
+  const int col = (lane % LPR) * 8, n = n_base + col;
+  if (n >= d.N) return;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (d.bias) {
+    b0 = *reinterpret_cast<const float4*>(d.bias + n);
+    b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+  }
 #pragma unroll 1
   for (int p = 0; p < WTM / RPP; ++p) {
-    const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
-    const int m = m_base + row, n = n_base + col;
-    if (m >= d.M || n >= d.N) continue;
+    const int row = p * RPP + lane / LPR;
+    const int m = m_base + row;
+    if (m >= d.M) continue;
     const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
     const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (d.bias) {
-      const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
     if (d.act == S2S_ACT_RELU) {
@@ -369,16 +377,24 @@ template <int WTM, int WTN>
 __device__ __forceinline__ void epilogue_flush_swish(const s2svc_gemm_desc& d, int m_base, int n_base, const float* cs) {
   const int lane = threadIdx.x & 63;
   constexpr int LPR = WTN / 8, RPP = 64 / LPR;
+  // a lane keeps its 8 columns through the row loop: the bias is loaded ONCE, ahead of the loop (the rolled loop otherwise pays a
+  // dependent global load per iteration for the same eight values)
+  const int col = (lane % LPR) * 8, n = n_base + col;
+  if (n >= d.N) return;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (d.bias) {
+    b0 = *reinterpret_cast<const float4*>(d.bias + n);
+    b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+  }
 #pragma unroll 1
   for (int p = 0; p < WTM / RPP; ++p) {
-    const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
-    const int m = m_base + row, n = n_base + col;
-    if (m >= d.M || n >= d.N) continue;
+    const int row = p * RPP + lane / LPR;
+    const int m = m_base + row;
+    if (m >= d.M) continue;
     const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
     const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (d.bias) {
-      const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
     if (d.c_pre) {                       // forward: the pre-activation leaves as it is, then Swish
@@ -439,15 +455,21 @@ template <int WTM, int WTN>
 __device__ __forceinline__ void epilogue_flush_common32(const s2svc_gemm_desc& d, int m_base, int n_base, const float* cs) {
   const int lane = threadIdx.x & 63;
   constexpr int LPR = WTN / 8, RPP = 64 / LPR;
+  const int col = (lane % LPR) * 8, n = n_base + col;        // (bias: once per lane, ahead of the rolled row loop -- see above)
+  if (n >= d.N) return;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (d.bias) {
+    b0 = *reinterpret_cast<const float4*>(d.bias + n);
+    b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+  }
 #pragma unroll 1
   for (int p = 0; p < WTM / RPP; ++p) {
-    const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
-    const int m = m_base + row, n = n_base + col;
-    if (m >= d.M || n >= d.N) continue;
+    const int row = p * RPP + lane / LPR;
+    const int m = m_base + row;
+    if (m >= d.M) continue;
     const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
     float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
     if (d.bias) {
-      const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
       lo.x += b0.x; lo.y += b0.y; lo.z += b0.z; lo.w += b0.w; hi.x += b1.x; hi.y += b1.y; hi.z += b1.z; hi.w += b1.w;
     }
     if (d.act == S2S_ACT_RELU) {
