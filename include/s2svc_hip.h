@@ -27,6 +27,9 @@ extern "C" {
 
 const char* s2svc_last_error(void);
 int s2svc_abi_version(void);
+/* Measurement aid: launches `workgroups` x `threads` of a kernel that stores one word per workgroup into `sink_1024_words`
+   (4 KB of device memory).  What a DEPENDENT launch costs on this stack whatever it does (bench.py "launch_floor_us"). */
+int s2svc_launch_floor(int workgroups, int threads, void* sink_1024_words, void* stream);
 
 /* ========================================================================================== */
 /* Generic tiled MFMA GEMM with implicit-convolution operand addressing.                      */

@@ -17,3 +17,18 @@ extern "C" const char* s2svc_last_error(void) {
   return out;
 }
 extern "C" int s2svc_abi_version(void) { return 1; }
+
+// The launch floor of this stack, measured rather than assumed: a kernel whose workgroups do nothing but store one word each.
+// bench.py times it inside the same graph loops as the memory-bound kernels (their bytes / s are rated against the HBM peak with
+// and without this floor), tools/gemm8_bench.py subtracts it from the fixed cost of a GEMM launch.
+namespace {
+__global__ void launch_floor_kernel(unsigned* __restrict__ sink) {
+  if (threadIdx.x == 0) sink[blockIdx.x & 1023] = blockIdx.x;
+}
+}  // namespace
+extern "C" int s2svc_launch_floor(int workgroups, int threads, void* sink_1024_words, void* stream) {
+  S2S_REQUIRE(workgroups > 0 && threads > 0 && threads <= 1024 && sink_1024_words, "launch_floor: bad args");
+  hipLaunchKernelGGL(launch_floor_kernel, dim3((unsigned)workgroups), dim3((unsigned)threads), 0, (hipStream_t)stream, (unsigned*)sink_1024_words);
+  S2S_CHECK_LAUNCH("launch_floor_kernel");
+  return 0;
+}

@@ -75,6 +75,11 @@ def advance_seed(device):
     SEED.tensor(device).add_(0x10001)
 
 
+def launch_floor(sink, workgroups=256, threads=256):
+    """One launch of the do-nothing kernel (s2svc_launch_floor): `sink` = 1024 int32 words of device memory."""
+    _lib.check(_lib.lib().s2svc_launch_floor(int(workgroups), int(threads), ptr(sink), stream()), "s2svc_launch_floor")
+
+
 def reset_op_counter():
     SEED.counter = 0
 

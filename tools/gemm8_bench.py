@@ -25,12 +25,52 @@ DENSE = [("4096^3", 4096, 4096, 4096), ("8192^3", 8192, 8192, 8192), ("aas 4096x
          ("aas 4096x1536x384", 4096, 1536, 384), ("vtn 2048x1536x384", 2048, 1536, 384), ("vtn 2016x384x7296", 2016, 384, 7296)]
 
 
+def ksweep(a):
+    """Where a short-K GEMM launch spends its time: t(K) = fixed + (K / 64) * per_tile, fitted over K; the fixed part against the
+    floor of a dependent do-nothing launch (s2svc_launch_floor) -- what is left is prologue (first operand tiles: one trip to HBM)
+    + epilogue."""
+    L = K._lib.lib()
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(1)
+    u = lambda *s: (torch.rand(*s, device="cuda", generator=g) * 2 - 1).to(dt)
+    sink = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    floor = {w: statistics.median(bench(lambda w=w: K.launch_floor(sink, w, 256 if w != 192 else 512), a.iters) for _ in range(a.rounds))
+             for w in (1, 192, 256, 2048)}
+    print("launch floor (do-nothing kernel, dependent launches of one graph), us per launch: " +
+          ", ".join(f"{w} workgroups {t:.2f}" for w, t in floor.items()))
+    prev = L.s2svc_gemm_set_8ph(1 | (3 << 4))           # 256 x 128 tiles forced
+    for (M, N) in ((4096, 1536), (4096, 4608)):
+        pts = []
+        for Kd in (128, 256, 384, 768, 1536, 3072, 4608):
+            x, w, y, b = u(M, Kd), u(N, Kd), torch.empty(M, N, dtype=dt, device="cuda"), torch.zeros(N, device="cuda")
+            fn = lambda: K.gemm(K.operand(x, Kd), K.operand(w, Kd), M, N, Kd, y, in_dtype=dt, bias=b)
+            us = statistics.median(bench(fn, a.iters) for _ in range(a.rounds))
+            pts.append((Kd // 64, us))
+            print(f"  {M} x {N} x {Kd:5d}: {us:7.2f} us  ({2.0 * M * N * Kd / us / 1e6 / 2500 * 100:5.1f} % of the bf16 peak)", flush=True)
+        n = len(pts)
+        sx, sy = sum(p[0] for p in pts), sum(p[1] for p in pts)
+        sxx, sxy = sum(p[0] * p[0] for p in pts), sum(p[0] * p[1] for p in pts)
+        slope = (n * sxy - sx * sy) / (n * sxx - sx * sx)
+        fixed = (sy - slope * sx) / n
+        tiles = ((M + 255) // 256) * ((N + 127) // 128)
+        rounds = (tiles + 255) // 256
+        ideal = 2.0 * 256 * 128 * 64 / (2500e12 / 256) * 1e6 * rounds      # us per K tile of one workgroup at the MFMA peak, per round
+        print(f"{M} x {N}: {tiles} workgroups ({rounds} round(s) on 256 CUs): fixed {fixed:.2f} us per launch (launch floor {floor[256]:.2f}) "
+              f"+ {slope:.3f} us per K tile of 64 (MFMA peak: {ideal:.3f})", flush=True)
+    L.s2svc_gemm_set_8ph(prev)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--modes", default="0,1,17,33,49")
+    ap.add_argument("--ksweep", action="store_true",
+                    help="instead: 4096 x 1536 x K for a range of K on the 256 x 128 8-wave kernel -> fixed cost per launch + us per K tile "
+                         "(least squares), beside the launch floor of a do-nothing kernel")
     a = ap.parse_args()
+    if a.ksweep:
+        return ksweep(a)
     modes = [int(m) for m in a.modes.split(",")]
     L = K._lib.lib()
     dt = torch.bfloat16
