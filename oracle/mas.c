@@ -3,7 +3,7 @@
  *
  * follows seq2seq_vc/modules/alignments.py:63-93 (_monotonic_alignment_search, numba nopython) and
  * :281-310 (viterbi_decode).  Q is float64; row 0 is a float64 running prefix sum (see DESIGN.md
- * "MAS row-0 precision").  Pinned by tests/golden/mas_kats.npz (paths produced by the reference itself).
+ * section 5, documented deviations).  Pinned by tests/golden/mas_kats.npz (paths produced by the reference itself).
  *
  *   gcc -O3 -shared -fPIC -o libmas_oracle.so mas.c
  */

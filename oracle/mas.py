@@ -2,7 +2,7 @@
 
 Follows seq2seq_vc/modules/alignments.py:63-93 (_monotonic_alignment_search) and :281-310
 (viterbi_decode).  Row 0 is an fp64 running prefix sum (the reference re-sums an fp32 slice per
-column; see DESIGN.md "MAS row-0 precision").  The C restatement in oracle/mas.c is the fast twin.
+column; see DESIGN.md section 5, documented deviations).  The C restatement in oracle/mas.c is the fast twin.
 """
 import numpy as np
 

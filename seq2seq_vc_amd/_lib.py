@@ -43,7 +43,7 @@ def build_library(force=False, verbose=True):
         # -fno-slp-vectorize: no compiler-formed packed-fp32 (v_pk_fma_f32 / v_pk_mul_f32 with op_sel operand swizzles).
         # With them the spline-gradient kernel of the duration predictor returned, a few times per thousand launches and
         # only while another stream kept the chip busy, a wrong element in the last partially active 16-lane row of a wave
-        # (same inputs, different output); without them 0 of 800 full AAS-VC steps differ ("Reproducibility").
+        # (same inputs, different output); without them 0 of 800 full AAS-VC steps differ (DESIGN.md section 5 "Hazard"; profiles/AB_LOG.md).
         # The step times are unchanged (the arithmetic that matters is MFMA and explicit 16-byte memory operations).
         # -fno-vectorize: the loop vectoriser forms the same packed operations in a few element-wise kernels.
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize",

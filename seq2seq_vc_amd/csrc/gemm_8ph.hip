@@ -881,7 +881,7 @@ __device__ __forceinline__ void w8_flush(const w8_prob& q, int chunk, int m_base
 // LOADER-SPECIALISED W8 tile (round 4, "LS"): 12 waves -- 8 CONSUMER waves (the 2 x 4 wave grid of the 256 x 128 tile: fragment
 // reads + MFMAs, nothing else) and 4 LOADER waves (one per SIMD: all LDS-DMA instructions, the address masks, the counted vmcnt
 // waits) over a ring of THREE K-tile stages (144 KB) with ONE s_barrier per K tile.
-// Why: timing builds of the 8-wave kernel with one of {MFMA, fragment reads, DMA} removed put the three at
+// Why: timing builds of the 8-wave kernel with one of {MFMA, fragment reads, DMA} removed (profiles/AB_LOG.md, round 4) put the three at
 // 0.44 / 0.27 / 0.35 us per K tile above a 0.18 us loop floor, and all three together at 1.04 us -- nearly their sum: a wave that issues
 // its share of the DMAs (6 instructions of 60-185 cycles each: MI355X_MICROARCH.md, "LDS-DMA piece issue cost") and waits for
 // its reads is not issuing MFMAs, and the two barriers per phase keep all eight waves in that lock step.  With the DMA issue on

@@ -11,7 +11,7 @@
 // stay -inf.  Backtrack from A[T_mel-1] = T_inp-1 with `Q[i-1,j] >= Q[i,j]` preferring i-1
 // (-inf >= -inf is true), i == 0 stays 0.  The decision the backtrack needs at column j is exactly
 // the comparison the forward step makes when it builds column j+1, so it is recorded there.
-// Deviation (documented in DESIGN.md): row 0 is an fp64 running prefix sum, O(T) instead of the
+// Deviation (documented in DESIGN.md section 5): row 0 is an fp64 running prefix sum, O(T) instead of the
 // reference's O(T^2) re-summation of an fp32 slice.
 #include "common.h"
 #include "../../include/s2svc_hip.h"

@@ -622,7 +622,7 @@ def aasvc_full_size_step_is_reproducible():
     """AAS-VC vc2 at its recipe size (157 M parameters, 16 utterance pairs) in the shipped training configuration --
     duration predictor on the auxiliary stream, parameter-gradient work in grouped inline batches: 60 forward+backward
     passes with the same seeds and injected flow noise give bit-identical outputs and gradients.  (This is the guard for
-    the packed-fp32 code-generation problem described in DESIGN.md "Reproducibility": before -fno-slp-vectorize about
+    the packed-fp32 code-generation problem described in DESIGN.md section 5 "Hazard" (full account: profiles/AB_LOG.md): before -fno-slp-vectorize about
     1 step in 40 had a wrong row in one flow-projection gradient.)"""
     import bench
     from seq2seq_vc_amd import losses as L

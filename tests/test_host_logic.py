@@ -32,7 +32,7 @@ def test_abi_library_loads_and_exports_declared_symbols():
 def test_shipped_library_holds_no_packed_fp32_instructions():
     """The library is built without the SLP / loop vectorisers: SLP-formed v_pk_{add,mul,fma}_f32 code gave a wrong high-half
     result in the last 16-lane quarter of a partially active wave, rarely and only inside a full training step (DESIGN.md
-    section 4; tools/repro_spline_slp.py).  Whatever the build flags say, the machine code must hold none of them."""
+    section 5 "Hazard"; tools/repro_spline_slp.py).  Whatever the build flags say, the machine code must hold none of them."""
     from tools import check_no_packed_f32 as chk
     if not os.path.exists(chk.OBJDUMP):
         pytest.skip("llvm-objdump not in this image")

@@ -2,7 +2,7 @@
 """Disassemble every gfx950 code object of the built library and count the packed-fp32 VALU instructions (v_pk_add_f32,
 v_pk_mul_f32, v_pk_fma_f32).  The library is built with -fno-slp-vectorize -fno-vectorize because SLP-formed packed fp32 code
 gave, rarely and only inside a full training step, a wrong HIGH-half result in the last 16-lane quarter of a partially active
-wave (tools/repro_spline_slp.py, profiles/r04_repro_spline_slp.txt): the shipped code must hold none.
+wave (DESIGN.md section 5 "Hazard", tools/repro_spline_slp.py, profiles/r04_repro_spline_slp.txt): the shipped code must hold none.
 
     python tools/check_no_packed_f32.py [path/to/libs2svc_hip.so]      # prints {"v_pk_*_f32": count, ...}; exit 1 if any
 """

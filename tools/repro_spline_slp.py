@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Reproducer for the packed-fp32 (SLP) hazard of DESIGN.md section 4 ("Reproducibility"): with clang's SLP vectoriser on, the
+"""Reproducer for the packed-fp32 (SLP) hazard of DESIGN.md section 5 ("Hazard"; full account in profiles/AB_LOG.md): with clang's SLP vectoriser on, the
 spline-gradient kernel of the stochastic duration predictor (csrc/sdp.hip: rq_spline_bwd_kernel) returned, in about 1 of 60 full
 AAS-VC steps and only while another stream kept the chip busy, a wrong element in the last partially active 16-lane row of a wave.
 The shipped library is built with -fno-slp-vectorize -fno-vectorize; this tool builds VARIANTS of the library on the GPU box
