@@ -1862,6 +1862,147 @@ def tts_full_size_c4():
 
 
 @case
+def every_recipe_config_one_step_vs_oracle_fp32():
+    """SURVEY 8(b) "run.sh recipes are drop-in", at run time: each DISTINCT (model class, model_params) of the reference's 13 recipe
+    YAMLs (tests/golden/recipe_configs.json: VTN with mel / PPG inputs and outputs (idim / odim 80 or 144), the TTS-pretraining and
+    auto-encoder variants, AAS-VC mel and PPG, FastSpeechVC, TransformerTTS) runs one forward + backward pass of its trainer's loss on
+    a small seeded batch in fp32 mode, with FlatAdam's flat buffers underneath as in training: losses against the CPU oracle, AAS-VC
+    durations bit-exact, and the flat gradient against the oracle's autograd."""
+    import json
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd.optim import FlatAdam
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "recipe_configs.json")) as f:
+        recipes = json.load(f)
+    res, seen = [], {}
+    for r in recipes:
+        key = (r["model_type"], json.dumps(r["model_params"], sort_keys=True))
+        seen.setdefault(key, []).append(r["recipe"])
+    try:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+        for (mt, pj), where in seen.items():
+            mc = dict(json.loads(pj))
+            if mt == "TransformerTTS":
+                mc.setdefault("idim", 78)
+            tag = f"{mt} [{', '.join(w.split('/conf/')[0].replace('egs/', '') + ':' + w.split('/')[-1] for w in where)}]"
+            torch.manual_seed(0)
+            model = getattr(M, mt)(**mc)
+            sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            model.to(DEV).train()
+            _kill_dropout(model)
+            opt = FlatAdam(model, lr=8e-5, grad_norm=1.0, warmup_steps=4000)
+            names = [k for k, _ in model.named_parameters()]
+            g = torch.Generator().manual_seed(len(res) + 5)
+            idim, odim = mc["idim"], mc["odim"]
+            B = 2
+            if mt in ("VTN", "TransformerTTS"):
+                rr = mc.get("decoder_reduction_factor", 1)
+                ilens, olens = torch.tensor([48, 37]), torch.tensor([6 * rr + 1, 4 * rr])
+                if mt == "VTN":
+                    xs = torch.randn(B, 48, idim, generator=g)
+                    xs[torch.arange(48)[None] >= ilens[:, None]] = 0.0
+                else:
+                    ilens = torch.tensor([21, 17])
+                    xs = torch.randint(1, idim - 1, (B, 21), generator=g)
+                    xs[torch.arange(21)[None] >= ilens[:, None]] = 0
+                Lm = int(olens.max())
+                ys = torch.randn(B, Lm, odim, generator=g)
+                ar = torch.arange(Lm)[None]
+                ys[ar >= olens[:, None]] = 0.0
+                labels = (ar >= (olens[:, None] - 1)).float()
+                fwd = OM.vtn_forward if mt == "VTN" else OM.tts_forward
+
+                def oracle_loss(s_, cast):
+                    o = fwd(s_, mc, cast(xs), ilens, cast(ys), cast(labels), olens, training=True, drop=False)
+                    a_, b_ = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+                    return a_ + b_, (float(a_.detach()), float(b_.detach()))
+                ref, (l1r, l2r) = _oracle_grads(oracle_loss, sd, names, torch.float32)
+                K.reset_op_counter()
+                opt.zero_grad()
+                out = model(xs.to(DEV), ilens, ys.to(DEV), labels.to(DEV), olens)
+                l1, l2 = L.Seq2SeqLoss(10.0)(out[0], out[1], out[2], out[3], out[4], out[5])
+                (l1 + l2).backward()
+                Fn.side_join()
+                res.append((abs(float(l1.detach()) - l1r) < 1e-4 and abs(float(l2.detach()) - l2r) < 1e-4, f"{tag}: l1 {float(l1.detach()):.6f}/{l1r:.6f} bce {float(l2.detach()):.6f}/{l2r:.6f}"))
+            elif mt == "AASVC":
+                red = mc.get("encoder_reduction_factor", 1) * mc.get("post_encoder_reduction_factor", 1)
+                ilens, olens = torch.tensor([48, 40]), torch.tensor([37, 29])
+                xs = torch.randn(B, 48, idim, generator=g)
+                xs[torch.arange(48)[None] >= ilens[:, None]] = 0.0
+                ys = torch.randn(B, 37, odim, generator=g)
+                ys[torch.arange(37)[None] >= olens[:, None]] = 0.0
+                noise = torch.randn(B, 2, 48 // red, generator=g)
+                dpd = mc.get("duration_predictor_input_dim") or idim
+                dpi = xs if dpd == idim else torch.randn(B, 48, dpd, generator=g)
+
+                def oracle_loss(s_, cast):
+                    ro = OM.aasvc_forward(s_, mc, cast(xs), ilens, cast(ys), olens, dp_inputs=cast(dpi), noise=cast(noise), training=True, drop=False)
+                    a_ = OM.l1_loss(ro["after_outs"], ro["before_outs"], ro["ys"], ro["olens"])
+                    f_ = OM.forward_sum_loss(ro["log_p_attn"], ro["ilens"], ro["olens_reduced"])
+                    d_ = ro["dur_nll"].sum() if "dur_nll" in ro else None
+                    tot = a_ + 2.0 * (f_ + ro["bin_loss"]) + (d_ if d_ is not None else 0.0)
+                    return tot, (float(a_.detach()), float(f_.detach()), ro["ds"].detach().float())
+                ref, (l1r, l2r, ds_ref) = _oracle_grads(oracle_loss, sd, names, torch.float32)
+                if hasattr(model.duration_predictor, "noise"):
+                    model.duration_predictor.noise = noise
+                K.reset_op_counter()
+                opt.zero_grad()
+                ret = model(xs.to(DEV), ilens, ys.to(DEV), olens, dpi.to(DEV), dp_lengths=ilens)
+                l1 = L.L1Loss()(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
+                l2 = L.ForwardSumLoss()(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
+                tot = l1 + 2.0 * (l2 + ret["bin_loss"])
+                if "dur_nll" in ret:
+                    tot = tot + torch.sum(ret["dur_nll"].float())
+                tot.backward()
+                Fn.side_join()
+                res.append(cmp(f"{tag}: durations (bit-exact)", ret["ds"].detach().float().cpu(), ds_ref, 0))
+                res.append((abs(float(l1.detach()) - l1r) < 1e-4 and abs(float(l2.detach()) - l2r) < 5e-4, f"{tag}: l1 {float(l1.detach()):.6f}/{l1r:.6f} forward-sum {float(l2.detach()):.5f}/{l2r:.5f}"))
+            else:       # FastSpeechVC: durations from a teacher, here seeded (sum = target length / teacher reduction factor handled by the model)
+                tr_ = mc.get("teacher_model_decoder_reduction_factor", 4)
+                er = mc.get("encoder_reduction_factor", 1)
+                ilens = torch.tensor([48, 40])
+                xs = torch.randn(B, 48, idim, generator=g)
+                xs[torch.arange(48)[None] >= ilens[:, None]] = 0.0
+                conv2d = mc.get("encoder_input_layer", "linear") == "conv2d"
+                tlen = [(((int(v) // er) - 1) // 2 - 1) // 2 if conv2d else int(v) // er for v in ilens]
+                ds = torch.zeros(B, max(tlen), dtype=torch.long)
+                for b in range(B):
+                    ds[b, : tlen[b]] = torch.randint(0, 3, (tlen[b],), generator=g)
+                    ds[b, 0] += 1
+                olens = ds.sum(1) * tr_
+                ys = torch.randn(B, int(olens.max()), odim, generator=g)
+                ys[torch.arange(int(olens.max()))[None] >= olens[:, None]] = 0.0
+                dlens = torch.tensor(tlen)
+
+                def oracle_loss(s_, cast):
+                    before, after, d_outs, il_, ol_, ys_ = OM.fastspeech_vc_forward(s_, mc, cast(xs), ilens, cast(ys), olens, ds=ds, dp_inputs=cast(xs),
+                                                                                    training=True, drop=False)
+                    a_ = OM.l1_loss(after, before, ys_, ol_)
+                    d_ = OM.duration_predictor_loss(d_outs, ds, il_)
+                    return a_ + d_, (float(a_.detach()), float(d_.detach()))
+                ref, (l1r, l2r) = _oracle_grads(oracle_loss, sd, names, torch.float32)
+                K.reset_op_counter()
+                opt.zero_grad()
+                before, after, d_outs, il_, ol_, ys_ = model(xs.to(DEV), ilens, ys.to(DEV), olens, ds, dlens, dp_inputs=xs.to(DEV), dp_lengths=ilens)
+                l1 = L.L1Loss()(after, before, ys_, ol_)
+                l2 = L.DurationPredictorLoss()(d_outs, ds.to(DEV), il_)
+                (l1 + l2).backward()
+                Fn.side_join()
+                res.append((abs(float(l1.detach()) - l1r) < 1e-4 and abs(float(l2.detach()) - l2r) < 1e-4, f"{tag}: l1 {float(l1.detach()):.6f}/{l1r:.6f} duration {float(l2.detach()):.6f}/{l2r:.6f}"))
+            torch.cuda.synchronize()
+            worst, top, nbad, total = _grad_table(model, names, ref, 2e-4)
+            res.append((nbad == 0, f"{tag}: {nbad} of {len(names)} parameter gradients above rel-L2 2e-4 vs the fp32 CPU oracle; worst: {top} (|g| = {total:.3f})"))
+            del opt, model
+            torch.cuda.empty_cache()
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
 def vtn_small_c1_vs_oracle():
     """BASELINE configs[0]: VTN-small (2+2 layers, d=256, 4 heads of 64, FFN 1024; other arguments at the constructor
     defaults, r=4), 8 utterance pairs: forward, losses and every parameter gradient against the CPU oracle (fp32), and the

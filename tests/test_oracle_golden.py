@@ -356,3 +356,39 @@ def test_mel_basis_against_the_published_slaney_formula():
             if len(nz) >= 8:                                                                       # wide enough to be sampled
                 assert abs(a[i].sum() * (sr / N) - 1.0) < 0.03                                     # unit area (Slaney normalisation)
                 assert abs(freqs[np.argmax(a[i])] - pts[i + 1]) <= sr / N                          # peak at the centre frequency
+
+
+def test_every_recipe_config_of_the_reference_builds_the_same_state_dict():
+    """"run.sh recipes are drop-in".  tests/golden/recipe_configs.json (tools/gen_recipe_configs.py) holds, for each of
+    the reference's 13 recipe YAMLs that name a model of the path, the file's model_params and the state_dict keys / shapes / dtypes
+    of the REFERENCE's model built from them.  The product's class of the same name, built from the same params, must give the same
+    keys in the same order with the same shapes and dtypes (checkpoints interchange by key; `init-mods` prefixes resolve), and the
+    recipe's trainer / collater / criterion names must resolve in seq2seq_vc_amd."""
+    import json
+    import seq2seq_vc_amd.collaters as C
+    import seq2seq_vc_amd.losses as L
+    import seq2seq_vc_amd.models as M
+    import seq2seq_vc_amd.trainers as T
+    with open(os.path.join(GOLD, "recipe_configs.json")) as f:
+        recipes = json.load(f)
+    assert len(recipes) == 13
+    seen = set()
+    for r in recipes:
+        torch.manual_seed(0)
+        model = getattr(M, r["model_type"])(**r["model_params"], **r["injected_params"])
+        sd = model.state_dict()
+        got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+        assert [g[0] for g in got] == [e[0] for e in r["state_dict"]], f"{r['recipe']}: state_dict keys / order differ"
+        bad = [(g, e) for g, e in zip(got, r["state_dict"]) if g != e]
+        assert not bad, f"{r['recipe']}: {bad[:3]}"
+        assert sum(p.numel() for p in model.parameters() if p.requires_grad) == r["n_trainable"], r["recipe"]
+        for prefix in (r["init_mods"] or []):                    # partial loading by module prefix (utils/model_io.py:12-111)
+            assert any(k.startswith(prefix + ".") for k in sd), f"{r['recipe']}: init-mods prefix {prefix} matches nothing"
+        if r["trainer_type"]:
+            assert hasattr(T, r["trainer_type"]), f"{r['recipe']}: trainer {r['trainer_type']}"
+        if r["collater_type"]:
+            assert hasattr(C, r["collater_type"]), f"{r['recipe']}: collater {r['collater_type']}"
+        for name, kw in (r["criterions"] or {}).items():
+            getattr(L, name)(**(kw or {}))
+        seen.add(r["model_type"])
+    assert seen == {"VTN", "AASVC", "TransformerTTS", "FastSpeechVC"}
