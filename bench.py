@@ -941,6 +941,10 @@ def main():
                     help="data parallel: one all-reduce per bucket, or reduce-scatter + all-gather")
     ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
     ap.add_argument("--side-streams", type=int, default=None, help="HIP side streams for parameter-gradient kernels (default: 4 for vtn, 0 + inline batches for aasvc)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N > 1 path (nccl == RCCL; gloo: test aid, the same code path without RCCL)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="test aid for a 1-GPU box: every rank runs on GPU 0 (RCCL refuses two ranks per device: use --dist-backend gloo)")
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="launcher check without a GPU: every rank joins a gloo group, all-reduces a 1 and rank 0 prints the rank count")
     args = ap.parse_args()
@@ -962,6 +966,10 @@ def main():
         raise SystemExit(dist_dry_run(world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.one_device:
+        if args.dist_backend == "nccl" and world > 1:
+            raise SystemExit("bench.py: --one-device puts every rank on GPU 0, which RCCL refuses: add --dist-backend gloo")
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
@@ -975,7 +983,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)                   # n_gpus of the line = the ranks RCCL actually summed over
         ranks_seen = int(one.item())
@@ -1030,6 +1041,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl.desc, "batch_per_gpu": B, "global_batch": B * world, "T_src": 256, "T_tgt": 256, "mel_dim": 80,
                        "params_M": round(wl.params_m, 2), "parallelism": f"dp{world}", "split_backward": bool(staged),
+                       **({"dist_backend": args.dist_backend, "one_device": bool(args.one_device)} if dp else {}),
                        "valid_target_frames_per_step": frames, **info},
             "final_losses": dict(zip(wl.loss_names, losses), grad_norm=stats["grad_norm"], opt_steps=stats["step"]),
             "step_mfma": step_mfma(args.workload, ms),

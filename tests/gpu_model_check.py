@@ -2249,6 +2249,57 @@ def dp_trainers_three_ranks_rs_ag():
 
 
 @case
+def bench_two_ranks_on_one_gpu():
+    """The benchmark's N > 1 path end to end on the one GPU of a test box (`--gpus N` was a dead flag): `python
+    bench.py --gpus 2` starts two ranks itself; with `--dist-backend gloo --one-device` both run on GPU 0 (RCCL refuses two ranks per
+    device: the collectives are gloo's, everything else -- launcher, rendezvous, staged capture, exchange between stage graphs,
+    barrier + max-over-ranks timing, rank 0's line -- is the path an 8-GPU run takes).  Checks: the line says n_gpus = 2, its frames
+    are the two shares of the canonical global batch, losses are finite, the staged plan ran with the trainers' fp32 payload; the same
+    for the AAS-VC workload; and a WORLD_SIZE that disagrees with --gpus exits 2."""
+    import json
+    import subprocess
+    import bench
+    res = []
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(*flags):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags, "--no-cpu-baseline", "--no-extras"], env=env,
+                           capture_output=True, text=True, timeout=900)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        return (json.loads(lines[-1]) if lines else None), r.returncode, r.stderr[-1500:]
+
+    for wl, B in (("vtn", 32), ("aasvc", 16)):
+        d, rc, err = run("--gpus", "2", "--dist-backend", "gloo", "--one-device", "--workload", wl, "--steps", "4", "--warmup", "2")
+        ok = d is not None and rc == 0
+        res.append((ok, f"bench.py --gpus 2 ({wl}, gloo, one device): exit code {rc}" + ("" if ok else "\n" + err)))
+        if not ok:
+            continue
+        olens = bench.canonical_batch(2 * B)[4]
+        frames = 0.0
+        for rnk in range(2):
+            ol = olens[rnk * B:(rnk + 1) * B].clone()
+            if int(ol.max()) < 256:
+                ol[0] = 256
+            frames += float(ol.sum())
+        cfg = d["config"]
+        res.append((d["n_gpus"] == 2 and cfg["parallelism"] == "dp2" and cfg["global_batch"] == 2 * B,
+                    f"{wl}: n_gpus {d['n_gpus']}, {cfg['parallelism']}, global batch {cfg['global_batch']}"))
+        res.append((abs(cfg["valid_target_frames_per_step"] - frames) < 0.5 and abs(d["value"] * d["ms_per_step"] * 1e-3 - frames) < 1e-3 * frames,
+                    f"{wl}: frames per step {cfg['valid_target_frames_per_step']:.0f} == both ranks' shares {frames:.0f}; value x time consistent"))
+        res.append((cfg["backward_stages"] >= 2 and cfg["split_backward"] and cfg["grad_payload"] == "fp32" and cfg["dist_backend"] == "gloo",
+                    f"{wl}: staged backward ({cfg['backward_stages']} stages), payload {cfg['grad_payload']}, buckets {cfg['grad_buckets_MB']} MB"))
+        fl = d["final_losses"]
+        res.append((all(v == v and abs(v) < 1e6 for v in fl.values()), f"{wl}: finite losses {fl}"))
+    # a WORLD_SIZE that disagrees with --gpus must fail loudly on the GPU box as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2,
+                       capture_output=True, text=True, timeout=300)
+    res.append((r.returncode == 2, f"--gpus 2 under WORLD_SIZE=1 exits {r.returncode} (2 expected)"))
+    return res
+
+
+@case
 def dp_trainer_bf16_payload():
     """The same AAS-VC run with the gradient exchange in bf16 (half the bytes on the links): parameters stay within bf16
     rounding of the fp32 exchange."""
