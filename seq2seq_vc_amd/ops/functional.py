@@ -196,6 +196,7 @@ def distinct_stream(taken=None):
 
 
 _SIDE_BATCH_ENV = os.environ.get("S2SVC_SIDE_BATCH")
+_JOIN_UNCAPPED = os.environ.get("S2SVC_JOIN_UNCAPPED", "1") != "0"       # A/B aid
 
 
 def enable_side_streams(n=4, inline_batches=False, batch=None):
@@ -393,7 +394,17 @@ def side_join():
             if st.cuda_stream != main.cuda_stream:
                 main.wait_stream(st)
     if _Side.enabled:
-        _side_flush()
+        if _JOIN_UNCAPPED:
+            # the batch flushed HERE runs behind the end of the data-gradient chain: there is nothing left to protect from a
+            # chip-filling weight-gradient grid, so its launches are not capped (ops.kernels.set_wgrad_cap)
+            cap = K.get_wgrad_cap()
+            K.set_wgrad_cap(0)
+            try:
+                _side_flush()
+            finally:
+                K.set_wgrad_cap(cap)
+        else:
+            _side_flush()
         main = torch.cuda.current_stream()
         for st in _Side.streams:
             main.wait_stream(st)

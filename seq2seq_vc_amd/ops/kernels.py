@@ -366,6 +366,10 @@ def set_wgrad_cap(wgs):
     _W8_CAP[0] = max(0, int(wgs))
 
 
+def get_wgrad_cap():
+    return _W8_CAP[0]
+
+
 def launch_wgrad_group(descs):
     """The listed weight-gradient problems (every one s2svc_gemm_wgrad_ok) on the ragged 8-wave kernel, one grid per <= 40 of
     them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`)."""
