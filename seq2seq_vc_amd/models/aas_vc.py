@@ -174,8 +174,10 @@ class AASVC(nn.Module):
         backward pass 1.2 ms -- with fewer than four layers beside it the branch is the critical path of the stage (measured on
         one MI355X, `bench.py --split-backward --stage-times`: stage graphs 10.97 + 2.04 ms with h = 0, 10.80 + 1.20 + 2.04 with
         h = 1, 10.28 + 1.17 + 1.26 + 2.02 with h = 2: every layer moved out of stage 1 adds ~1 ms to the step).  Buckets with two
-        stages: 573 | 57 MB fp32 (287 | 28 MB with the default bf16 payload); the first travels behind the encoder's 2.0 ms,
-        which hides it at >= 250 GB/s of all-reduce bus bandwidth, the second is exposed (as the last bucket of any plan is)."""
+        stages: 568 | 62 MB fp32 (half with the opt-in bf16 payload); the first travels behind the encoder's 1.9 ms -- a ring
+        all-reduce of S bytes over N ranks takes 2 (N - 1) / N x S / bus bandwidth, i.e. 3.3 ms at 300 GB/s and N = 8, of which
+        ~ 1.4 ms stay exposed (round 5, DESIGN.md section 7: the model and the plans with decoder cuts, which cost 0.45-0.8 ms per cut
+        on one GPU and come out even at 300 GB/s) --, the second is exposed (as the last bucket of any plan is)."""
         dec = list(self.decoder.encoders)
         tail = [m for m in (getattr(self.decoder, "after_norm", None), self.feat_out, self.postnet) if m is not None]
         side = [self.alignment_module, self.duration_predictor]
