@@ -563,7 +563,7 @@ def step_mfma(workload, ms):
 # =====================================================================================================================
 # sub-benchmarks reported beside the headline (N = 1)
 # =====================================================================================================================
-def bench_aasvc_single(dev, dtype, steps=20, warmup=3, cpu=True, batch=16):
+def bench_aasvc_single(dev, dtype, steps=40, warmup=8, cpu=True, batch=16):
     from seq2seq_vc_amd.ops import functional as Fn
     # the schedule AASVCTrainer ships (trainers.AASVCTrainer.GRADIENT_WORK)
     Fn.enable_side_streams(0, inline_batches=True)
