@@ -75,7 +75,7 @@ struct KcStage {
   bool scalar_ok;                 // uniform
   int st_k0, st_c0, st_kh, st_kw; // conv2d / tconv2d: the (tap, channel) position of k tile st_k0, walked without divisions
   __device__ __forceinline__ void init(const s2svc_operand& o, int r0, int R) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;      // (& 3: the 8-wave split-K kernel stages per 4-wave group)
     scalar_ok = false;
     st_k0 = -1; st_c0 = 0; st_kh = 0; st_kw = 0;
     if (SCALAR_KIND) {
@@ -131,7 +131,7 @@ struct KcStage {
     }
   }
   __device__ __forceinline__ void issue(const s2svc_operand& o, const bf16_t* base, int k0, int K, char* lds) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: the LDS destinations (M0) stay on the SALU
+    const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);      // scalar: the LDS destinations (M0) stay on the SALU
     if (SCALAR_KIND && scalar_ok && k0 + BKT <= K) {
       int64_t koff = k0;
       if (KIND == G_KC_CONV2D) {
@@ -772,6 +772,119 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const s2svc_gemm_desc d) 
                                 splitk, zs, zb);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Split-K INSIDE the workgroup (round 5): the all-DMA kernel for long reductions over few tiles -- the feed-forward and packed-
+// projection products of the VTN / TTS stacks with K = 1152 / 1536 (2016 x 384 x 1536: 378 tiles of 32 x 64, 24 K tiles).  Their
+// launch is a serial loop of K tiles at ~0.33 us each (one barrier, six fragment reads, four MFMAs per wave: all latency), 8 us of an
+// 11 us launch, with two thirds of every CU idle.  Here a workgroup is 8 waves = two groups of four; each group walks HALF of the K
+// range through its own LDS ring (same staging, same counted waits; the barriers are the workgroup's, both groups make the same number
+// of trips), then the second group's accumulators go through LDS and the first group adds them -- first half + second half, a fixed
+// order -- and runs the epilogue.  No second launch, no workspace, no atomics.  The result differs from the unsplit kernel's in fp32
+// summation order only; WHICH kernel a problem gets is a function of its shape.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(512) void gemm_dma_k2_kernel(const s2svc_gemm_desc d) {
+  constexpr int BK = 64;
+  constexpr int FM = BM / 32, FN = BN / 32;
+  constexpr int ABYTES = BM * BK * 2, BBYTES = BN * BK * 2, STAGE_BYTES = ABYTES + BBYTES, RING = NS * STAGE_BYTES;
+  constexpr int PER_TILE = KcStage<BM, G_KC_DENSE, BK>::NI + KcStage<BN, G_KC_DENSE, BK>::NI;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * RING];
+  static_assert(2 * RING >= 2 * BM * BN * 4, "the rings double as the partial-sum buffer and the fp32 C tiles");
+  int tile_m, tile_n;
+  tile_of_block(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const bf16_t* Ab = (const bf16_t*)d.A.ptr;
+  const bf16_t* Bb = (const bf16_t*)d.B.ptr;
+  const int ktiles = (d.K + BK - 1) / BK;
+  const int half = (ktiles + 1) / 2;
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3, lane = threadIdx.x & 63;
+  const int kt_begin = grp * half;
+  const int kt_end = (kt_begin + half < ktiles) ? kt_begin + half : ktiles;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  const int lr = lane & 15, lg = lane >> 4;
+  char* ring = smem + grp * RING;
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  KcStage<BM, G_KC_DENSE, BK> sa;
+  KcStage<BN, G_KC_DENSE, BK> sb;
+  sa.init(d.A, m0, d.M);
+  sb.init(d.B, n0, d.N);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    sa.issue(d.A, Ab, (kt_begin + s) * BK, (kt_begin + s) < kt_end ? d.K : 0, ring + s * STAGE_BYTES);
+    sb.issue(d.B, Bb, (kt_begin + s) * BK, (kt_begin + s) < kt_end ? d.K : 0, ring + s * STAGE_BYTES + ABYTES);
+  }
+  int cur = 0;
+  for (int it = 0; it < half; ++it) {                     // both groups make `half` trips (the second one's last may be empty)
+    const int kt = kt_begin + it;
+    wait_vmcnt<(NS - 2) * PER_TILE>();
+    __builtin_amdgcn_s_barrier();
+    {
+      int nxt = cur + NS - 1;
+      if (nxt >= NS) nxt -= NS;
+      const int kn = kt + NS - 1;
+      sa.issue(d.A, Ab, kn * BK, kn < kt_end ? d.K : 0, ring + nxt * STAGE_BYTES);
+      sb.issue(d.B, Bb, kn * BK, kn < kt_end ? d.K : 0, ring + nxt * STAGE_BYTES + ABYTES);
+    }
+    const char* As = ring + cur * STAGE_BYTES;
+    const char* Bs = As + ABYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(As + lds_off_t<BK>(wm + i * 16 + lr, ks * 4 + lg));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bs + lds_off_t<BK>(wn + j * 16 + lr, ks * 4 + lg));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  }
+  wait_vmcnt<0>();
+  __syncthreads();               // every wave is done with both rings
+  // second half -> LDS in register order (wave w of group 1 and wave w of group 0 hold the same output elements in the same
+  // registers: no layout arithmetic, conflict-free 4-byte accesses), first half adds and finishes the tile
+  float* part = reinterpret_cast<float*>(smem) + BM * BN;       // [wave][i][j][r][lane]
+  if (grp == 1) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(((wave * FM + i) * FN + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (grp == 1) return;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] += part[(((wave * FM + i) * FN + j) * 4 + r) * 64 + lane];
+  float* cs = reinterpret_cast<float*>(smem) + wave * (BM / 2) * (BN / 2);
+  epilogue_stage<BM / 2, BN / 2>(acc, cs);
+  epilogue_flush_common<BM / 2, BN / 2>(d, m0 + wm, n0 + wn, cs);
+}
+
+bool k2_enabled() {      // S2SVC_GEMM_K2=0: long reductions over few tiles stay on the 4-wave kernel (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_K2"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+int k2_min_tiles() {     // S2SVC_GEMM_K2_MIN: K tiles from which the split is taken (tuning aid)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("S2SVC_GEMM_K2_MIN"); v = e ? atoi(e) : 12; }
+  return v;
+}
+
 bool lean_enabled() {    // S2SVC_GEMM_LEAN=0: every launch carries the general epilogue (A/B switch)
   static int v = -1;
   if (v < 0) { const char* e = getenv("S2SVC_GEMM_LEAN"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -1101,6 +1214,11 @@ extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
     // five stages in flight (60 KB) instead of three -- with 2 tiles of lookahead (~0.7 us of MFMA work) every K tile waits for
     // its own DMA round trip; S2SVC_GEMM_DEEP=0 keeps three stages (A/B switch)
     const bool lean = lean_enabled() && epilogue_common_ok(d);
+    if (lean && k2_enabled() && splitk == 1 && d.nb0 * d.nb1 == 1 && (d.K + 63) / 64 >= k2_min_tiles()) {
+      hipLaunchKernelGGL((gemm_dma_k2_kernel<32, 64, 3>), dim3(grid.x, grid.y, 1), dim3(512), 0, st, d);
+      S2S_CHECK_LAUNCH("gemm_dma_k2_kernel");
+      return 1;
+    }
     if (deep_stages() && (d.K + 63) / 64 / splitk >= deep_min_tiles()) {
       if (lean) hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 5, 64, true>), grid, dim3(256), 0, st, d);
       else hipLaunchKernelGGL((gemm_dma_kernel<32, 64, G_KC_DENSE, G_KC_DENSE, 5, 64>), grid, dim3(256), 0, st, d);

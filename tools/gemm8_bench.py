@@ -58,6 +58,21 @@ def ksweep(a):
         print(f"{M} x {N}: {tiles} workgroups ({rounds} round(s) on 256 CUs): fixed {fixed:.2f} us per launch (launch floor {floor[256]:.2f}) "
               f"+ {slope:.3f} us per K tile of 64 (MFMA peak: {ideal:.3f})", flush=True)
     L.s2svc_gemm_set_8ph(prev)
+    # the small GEMMs of the VTN chain (4-wave LDS-DMA kernel, tiles of 32 / 64 rows by policy): the same fit
+    for (M, N) in ((2016, 384), (2016, 1152), (2016, 1536)):
+        pts = []
+        for Kd in (64, 128, 384, 768, 1536):
+            x, w, y, b = u(M, Kd), u(N, Kd), torch.empty(M, N, dtype=dt, device="cuda"), torch.zeros(N, device="cuda")
+            fn = lambda: K.gemm(K.operand(x, Kd), K.operand(w, Kd), M, N, Kd, y, in_dtype=dt, bias=b)
+            us = statistics.median(bench(fn, a.iters) for _ in range(a.rounds))
+            pts.append((Kd // 64, us))
+            print(f"  {M} x {N} x {Kd:5d}: {us:7.2f} us", flush=True)
+        n = len(pts)
+        sx, sy = sum(p[0] for p in pts), sum(p[1] for p in pts)
+        sxx, sxy = sum(p[0] * p[0] for p in pts), sum(p[0] * p[1] for p in pts)
+        slope = (n * sxy - sx * sy) / (n * sxx - sx * sx)
+        print(f"{M} x {N} (VTN chain, kernel by policy): fixed {(sy - slope * sx) / n:.2f} us per launch (launch floor {floor[256]:.2f}) + "
+              f"{slope:.3f} us per K tile of 64", flush=True)
 
 
 def main():
