@@ -20,14 +20,10 @@ constexpr int TP = 72;                       // pitch (elements) of the [*][64] 
 constexpr float NEG = -3.4028234663852886e38f;
 
 __device__ __forceinline__ float grp16_max(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return row16_max(v);          // DPP rotations, no LDS crossbar (common.h)
 }
 __device__ __forceinline__ float grp16_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return row16_sum(v);
 }
 __device__ __forceinline__ bf16x8_t zero8() { return (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0}; }
 // component r (wave-uniform, from a ROLLED loop) of an accumulator: these kernels run once per launch on a cold instruction

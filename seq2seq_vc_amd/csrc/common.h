@@ -37,15 +37,61 @@ template <> struct Cvt<bf16_t> {
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return Cvt<T>::ld(p); }
 template <typename T> __device__ __forceinline__ void stf(T* p, float v) { Cvt<T>::st(p, v); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Cross-lane reductions WITHOUT the LDS crossbar (round 5).  hipcc lowers every __shfl_xor to ds_bpermute_b32 (~100 cycles of
+// dependent latency each: 12 of them in a LayerNorm row, 4 per softmax row of the fused attention kernels -- a visible part of
+// kernels that run 3-5 us).  The partner at lane ^ 1 / ^ 2 is a DPP quad permute, at ^ 4 two bank-masked DPP row shifts, at ^ 8 a
+// DPP row rotation, at ^ 16 / ^ 32 gfx950's v_permlane16_swap / v_permlane32_swap (with both operands = v the two results hold
+// (even rows, even rows) / (odd rows, odd rows), resp. (low half, low half) / (high half, high half)): VALU instructions, and the
+// SAME partners in the SAME order as the butterflies they replace, so every sum keeps its bits.  All lanes must be active (they
+// are: every caller reduces under wave-uniform control flow).
+template <int CTRL, int BANKS = 0xf>
+__device__ __forceinline__ float dpp_mov(float v, float old = 0.f) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANKS, false));
+}
+__device__ __forceinline__ float xor1_of(float v) { return dpp_mov<0xB1>(v); }             // quad_perm:[1,0,3,2]
+__device__ __forceinline__ float xor2_of(float v) { return dpp_mov<0x4E>(v); }             // quad_perm:[2,3,0,1]
+__device__ __forceinline__ float xor4_of(float v) {                                        // quads 0 <-> 1, 2 <-> 3 of every row
+  const float t = dpp_mov<0x104, 0x5>(v);                                                  // row_shl:4 into banks 0, 2
+  return dpp_mov<0x114, 0xa>(v, t);                                                        // row_shr:4 into banks 1, 3
+}
+__device__ __forceinline__ float xor8_of(float v) { return dpp_mov<0x128>(v); }            // row_ror:8
+struct lane_pair { float a, b; };
+__device__ __forceinline__ lane_pair swap16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+__device__ __forceinline__ lane_pair swap32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+// v + partner: of the two swap results one is the lane's own value and the other its partner's, so a + b is the butterfly step
+__device__ __forceinline__ float xor1_sum(float v) { return v + xor1_of(v); }
+__device__ __forceinline__ float xor2_sum(float v) { return v + xor2_of(v); }
+__device__ __forceinline__ float xor4_sum(float v) { return v + xor4_of(v); }
+__device__ __forceinline__ float xor8_sum(float v) { return v + xor8_of(v); }
+__device__ __forceinline__ float xor16_sum(float v) { const lane_pair p = swap16(v); return p.a + p.b; }
+__device__ __forceinline__ float xor32_sum(float v) { const lane_pair p = swap32(v); return p.a + p.b; }
+__device__ __forceinline__ float row16_sum(float v) {        // every lane of a 16-lane row gets the row's sum (partners 1, 2, 4, 8)
+  return xor8_sum(xor4_sum(xor2_sum(xor1_sum(v))));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, xor1_of(v));
+  v = fmaxf(v, xor2_of(v));
+  v = fmaxf(v, xor4_of(v));
+  return fmaxf(v, xor8_of(v));
+}
+__device__ __forceinline__ float wave_sum(float v) {         // partners 32, 16, 8, 4, 2, 1: the order of the old butterfly
+  return xor1_sum(xor2_sum(xor4_sum(xor8_sum(xor16_sum(xor32_sum(v))))));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  lane_pair p = swap32(v);
+  v = fmaxf(p.a, p.b);
+  p = swap16(v);
+  v = fmaxf(p.a, p.b);
+  v = fmaxf(v, xor8_of(v));
+  v = fmaxf(v, xor4_of(v));
+  v = fmaxf(v, xor2_of(v));
+  return fmaxf(v, xor1_of(v));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

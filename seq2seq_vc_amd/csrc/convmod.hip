@@ -223,11 +223,8 @@ __global__ __launch_bounds__(256) void convmod_bwd_stats_kernel(int rows, int C,
   // lanes with the same vector lane v hold the wave's 8 rows: butterfly over lane bits 3..5
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-      a0[e] += __shfl_xor(a0[e], o, 64);
-      a1[e] += __shfl_xor(a1[e], o, 64);
-    }
+    a0[e] = xor32_sum(xor16_sum(xor8_sum(a0[e])));      // (DPP / permlane swaps instead of ds_bpermute, common.h)
+    a1[e] = xor32_sum(xor16_sum(xor8_sum(a1[e])));
   }
   if (lane < 8) {
 #pragma unroll
@@ -439,11 +436,8 @@ __device__ __forceinline__ void bn_chunk_reduce(float (&a0)[8], float (&a1)[8], 
   const int v = threadIdx.x & 7, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-      a0[e] += __shfl_xor(a0[e], o, 64);
-      a1[e] += __shfl_xor(a1[e], o, 64);
-    }
+    a0[e] = xor32_sum(xor16_sum(xor8_sum(a0[e])));      // (DPP / permlane swaps instead of ds_bpermute, common.h)
+    a1[e] = xor32_sum(xor16_sum(xor8_sum(a1[e])));
   }
   if (lane < 8) {
 #pragma unroll

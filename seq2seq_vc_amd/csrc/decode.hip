@@ -91,8 +91,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(int H, int dk, const T
           for (int e = 0; e < VEC; ++e) s += sq[v * VEC + e] * f[e];
         }
       }
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
+      s = xor2_sum(xor1_sum(s));           // the 4 lanes of a key (DPP quad permutes, common.h)
       if (c == 0 && j < n) sc[j] = s * scale;
     }
   }
@@ -341,8 +340,7 @@ __global__ __launch_bounds__(256) void ln_linear_skinny_kernel(const s2svc_gemm_
             for (int e = 0; e < F::VEC; ++e) { const float t = pass ? f[e] - mean[i] : f[e]; s += pass ? t * t : t; }
           }
         }
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
+        s = xor32_sum(xor16_sum(s));       // the four 16-lane rows (v_permlane16/32_swap, common.h)
         if (lg == 0) st_part[wave][i * 16 + lr] = s;
       }
       __syncthreads();

@@ -18,6 +18,16 @@
 
 namespace {
 
+// q of the lane below, for the dependent chain of the search: two 32-bit DPP moves instead of two ds_bpermute (~10 instead of
+// ~100 cycles per column of the recursion).  Lane 0 keeps its own value (the caller overwrites it).
+__device__ __forceinline__ double wave_shr1_d(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int slo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);      // wave_shr:1
+  const int shi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(shi, slo);
+}
+
+
 template <int S, bool DEC_LDS>  // S >= ceil(T_inp / 64) text slots per lane
 __global__ __launch_bounds__(64) void mas_kernel(int B, int Tf, int Tx, const float* __restrict__ logp,
                                                  const int32_t* __restrict__ text_lens,
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(64) void mas_kernel(int B, int Tf, int Tx, const fl
         double up[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          double t = __shfl_up(q[s], 1, 64);
+          double t = wave_shr1_d(q[s]);                      // lane l <- lane l - 1 (DPP wave_shr:1: VALU moves, no LDS crossbar)
           if (lane == 0) t = NINF;
           if (s > 0) {
             const double carry = __shfl(q[s - 1], 63, 64);

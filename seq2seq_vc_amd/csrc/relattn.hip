@@ -32,14 +32,10 @@ constexpr int SP = 264;       // pitch of the [64][256] bf16 staging tiles
 constexpr float NEG = -3.4028234663852886e38f;
 
 __device__ __forceinline__ float grp16_max(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return row16_max(v);          // DPP rotations, no LDS crossbar (common.h)
 }
 __device__ __forceinline__ float grp16_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return row16_sum(v);
 }
 
 struct ra_fwd_args {
