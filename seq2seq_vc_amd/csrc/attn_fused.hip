@@ -166,9 +166,12 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(int H, int T1, int 
       mx = fmaxf(mx, val[jn]);
     }
     mx = grp16_max(mx);
-    float sum = 0.f;
+    float sum = 0.f, ex[4];
 #pragma unroll
-    for (int jn = 0; jn < 4; ++jn) sum += expf(val[jn] - mx);
+    for (int jn = 0; jn < 4; ++jn) {       // (each exponential once: it is needed for the sum and for the probability)
+      ex[jn] = expf(val[jn] - mx);
+      sum += ex[jn];
+    }
     sum = grp16_sum(sum);
     const float inv = 1.f / sum;
     const int64_t arow = ((int64_t)(b * H + h) * T1 + i) * ld;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_fused_fwd_kernel(int H, int T1, int 
     for (int jn = 0; jn < 4; ++jn) {
       const int j = jn * 16 + lr;
       const bool ok = j < kl && (!causal || j <= i);
-      const float pr = ok ? expf(val[jn] - mx) * inv : 0.f;          // masked_fill(mask, 0.0) after the softmax
+      const float pr = ok ? ex[jn] * inv : 0.f;                      // masked_fill(mask, 0.0) after the softmax
       const bf16_t pb = f2bf(pr);
       if (i < T1 && j < ld) attn[arow + j] = pb;
       float pd = bf2f(pb);                                           // P.V consumes the stored (rounded) probabilities

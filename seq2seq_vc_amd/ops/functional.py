@@ -944,6 +944,9 @@ class _AttnPackedKV(Function):
         k, v = kv[..., :D], kv[..., D:]
         out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
         ctx.meta = (H, scale, p, seed, D)
+        # a column block of split_cols whose gradient can be written in place (see _GradSink): only on the fused kernels' path,
+        # which take row / batch strides for their outputs
+        ctx.gsink = getattr(kv, "_s2s_gsink", None) if (kv.stride(-1) == 1 and KAT.supported(q, k, v, H)) else None
         ctx.save_for_backward(q, kv, attn, _split_pdrop(ctx, pdrop))
         ctx.set_materialize_grads(False)
         return out, _user_attn(attn, k.shape[1])
@@ -954,20 +957,48 @@ class _AttnPackedKV(Function):
         H, scale, p, seed, D = ctx.meta
         k, v = kv[..., :D], kv[..., D:]
         dq = torch.empty_like(q)
-        dkv = torch.empty(kv.shape, dtype=kv.dtype, device=kv.device)
+        if ctx.gsink is not None and KAT.supported(q, k, v, H) and dctx is not None:
+            dkv = ctx.gsink[0].part(ctx.gsink[1])       # this block of the packed gradient, written where split_cols wants it
+        else:
+            dkv = torch.empty(kv.shape, dtype=kv.dtype, device=kv.device)
         _attn_common_bwd(dctx, dattn, attn, _pm(ctx, attn, pdrop), q, k, v, H, scale, p, seed,
                          outs=(dq, dkv[..., :D], dkv[..., D:]))
         return dq, dkv, None, None, None, None
 
 
+class _GradSink:
+    """The gradient of a tensor that split_cols cut into column blocks, allocated once and written IN PLACE by the consumers of
+    the blocks (the source-attention blocks of all decoder layers write dK | dV of their (B, T, 2D) block straight into the
+    (B, T, L * 2D) gradient of the batched projection): the backward pass of split_cols then has nothing to concatenate (one
+    18 us torch.cat of 18.6 MB on the VTN chain per step)."""
+    __slots__ = ("shape", "dtype", "device", "W", "buf")
+
+    def __init__(self, shape, dtype, device, W):
+        self.shape, self.dtype, self.device, self.W, self.buf = shape, dtype, device, W, None
+
+    def part(self, i):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+        return self.buf[..., i * self.W:(i + 1) * self.W]
+
+    def holds(self, grads):
+        """True if `grads` are exactly the blocks of the buffer, in order (every consumer wrote its block in place)."""
+        if self.buf is None:
+            return False
+        base, es = self.buf.data_ptr(), self.buf.element_size()
+        return all(g is not None and g.data_ptr() == base + i * self.W * es and g.shape == self.buf.shape[:-1] + (self.W,)
+                   and g.stride() == self.buf.stride() and g.dtype == self.dtype for i, g in enumerate(grads))
+
+
 class _SplitCols(Function):
-    """(..., n*W) -> n column blocks (..., W) as VIEWS (no copy); the backward concatenates the n gradients with one kernel.
+    """(..., n*W) -> n column blocks (..., W) as VIEWS (no copy); the backward pass returns the sink's buffer if every consumer wrote
+    its block's gradient in place (_GradSink), else it concatenates the n gradients with one kernel.
     (Plain slicing would make autograd build n zero-padded full-width gradients and n-1 adds.)"""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, sink):
         W = x.shape[-1] // n
-        ctx.n, ctx.W = n, W
+        ctx.n, ctx.W, ctx.sink = n, W, sink
         ctx.meta = (x.shape, x.dtype, x.device)
         ctx.set_materialize_grads(False)
         return tuple(x[..., i * W:(i + 1) * W] for i in range(n))
@@ -976,14 +1007,28 @@ class _SplitCols(Function):
     def backward(ctx, *grads):
         shape, dtype, device = ctx.meta
         if all(g is None for g in grads):
-            return None, None
+            return None, None, None
+        sink = ctx.sink
+        if sink is not None and sink.holds(grads):
+            buf, sink.buf = sink.buf, None
+            return buf, None, None
+        if sink is not None:
+            sink.buf = None
         blk = shape[:-1] + (ctx.W,)
         parts = [g if g is not None else torch.zeros(blk, dtype=dtype, device=device) for g in grads]
-        return torch.cat(parts, dim=-1), None
+        return torch.cat(parts, dim=-1), None, None
+
+
+_GRAD_SINK = os.environ.get("S2SVC_GRAD_SINK", "1") != "0"       # A/B aid
 
 
 def split_cols(x, n):
-    return _SplitCols.apply(x, n)
+    sink = _GradSink(tuple(x.shape), x.dtype, x.device, x.shape[-1] // n) if (_GRAD_SINK and x.requires_grad and x.is_contiguous()) else None
+    parts = _SplitCols.apply(x, n, sink)
+    if sink is not None:
+        for i, t in enumerate(parts):
+            t._s2s_gsink = (sink, i)
+    return parts
 
 
 def attention_packed_qkv(qkv, klen, causal, H, p=0.0):
