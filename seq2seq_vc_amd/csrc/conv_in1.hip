@@ -128,15 +128,18 @@ __global__ __launch_bounds__(256) void conv_in1_wgrad_vec_kernel(int B, int Tn, 
   // a pixel's window starts at an even column: with an even row pitch every row of it is 4-byte aligned and its 4th value
   // (read, not used) is still inside the row (2 f1 + 3 <= Fn - 1)
   const bool x_pairs = (Fn % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 3) == 0);
+  const uint32_t mgF = 0xFFFFFFFFu / (uint32_t)F1 + 1u, mgT = 0xFFFFFFFFu / (uint32_t)T1 + 1u;      // (F1, T1 >= 2: see the launcher)
   if (pl < PL) {
 #pragma unroll 2
     for (int64_t p = p0 + pl; p < p1; p += PL) {
       const uint4 gv = *reinterpret_cast<const uint4*>(dy + p * O + g * 8);
       uint4 yv = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
       if (y) yv = *reinterpret_cast<const uint4*>(y + p * O + g * 8);
-      const uint32_t pi = (uint32_t)p, q = pi / (uint32_t)F1;
+      // pixel -> (b, t1, f1) by multiply-high (exact: npix * F1 < 2^32 is checked by the launcher): the two integer divisions
+      // were ~80 of the ~200 instructions of an iteration of this VALU-bound loop
+      const uint32_t pi = (uint32_t)p, q = __umulhi(pi, mgF);
       const int f1 = (int)(pi - q * (uint32_t)F1);
-      const int b = (int)(q / (uint32_t)T1);
+      const int b = (int)__umulhi(q, mgT);
       const int t1 = (int)(q - (uint32_t)b * (uint32_t)T1);
       const bf16_t* xb = x + ((int64_t)b * Tn + 2 * t1) * Fn + 2 * f1;
       float xv[9];
@@ -246,7 +249,8 @@ extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, con
   chunks = (int)((npix + ppc - 1) / ppc);
   hipStream_t st = (hipStream_t)stream;
   const int og = O / 8;
-  if (dtype != S2S_F32 && O % 8 == 0 && og <= 256 && npix < (int64_t)1 << 31 && (uintptr_t)dy % 16 == 0 && (!y || (uintptr_t)y % 16 == 0))
+  if (dtype != S2S_F32 && O % 8 == 0 && og <= 256 && npix * (F1 > T1 ? F1 : T1) < ((int64_t)1 << 32) && F1 >= 2 && T1 >= 2 &&
+      (uintptr_t)dy % 16 == 0 && (!y || (uintptr_t)y % 16 == 0))
     hipLaunchKernelGGL(conv_in1_wgrad_vec_kernel, dim3(chunks), dim3(256), (size_t)og * 80 * sizeof(float), st, B, Tn, Fn, T1, F1, O,
                        (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, partial, ppc);
   else if (dtype == S2S_F32)
