@@ -166,7 +166,9 @@ int s2svc_gemm_set_w8(int on, int kt_chunk);
 /* Kernel-family switch for tests / A-B timing of s2svc_gemm's bf16 path: the 256-row, 8-wave, phase-interleaved kernel
    (csrc/gemm_8ph.hip: K-contiguous dense or Conv2d-3x3-s2 A operand, dense B, K % 64 == 0, >= 128 tiles) is tried first.
    mode & 15: 0 = never, 1 = default policy, 2 = policy without the half-phase skew of the two wave halves;
-   mode >> 4: 0 = tile geometry by policy, 1 = 256 x 256, 2 = 512 x 128, 3 = 256 x 128 forced (eligible problems only).
+   (mode >> 4) & 15: 0 = tile geometry by policy, 1 = 256 x 256, 2 = 512 x 128, 3 = 256 x 128 forced (eligible problems only);
+   (mode >> 8) & 15: 0 = unchanged, 1 + v sets the 256 x 96 p one-round geometry (gemm_8ph_kernel_n96, S2SVC_GEMM_N96): v = 0 never,
+   1 by policy (default), 2 wherever N % 96 p == 0 (widest p), 4 / 5 = the same with p = 2 / 3 only.
    Returns the previous mode (mode < 0: query only).  Results do not depend on the mode beyond fp32 summation order. */
 int s2svc_gemm_set_8ph(int mode);
 

@@ -41,13 +41,34 @@ enum { P8_DENSE = 0, P8_CONV2D = 1, P8_TCONV2D = 2 };
 template <int N> __device__ __forceinline__ void p8_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void p8_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ void p8_tile_of_block(int& bm, int& bn) {     // XCD-aware tile order (see gemm_glds.hip)
-  const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+// XCD-aware tile order (see gemm_glds.hip: XCD x gets the x-th contiguous run of tile ids) -- and, within the run, tiles walk DOWN
+// groups of GH tile rows before they move to the next tile column, so that the ~32 workgroups an XCD runs side by side cover a
+// compact GH x (32 / GH) block of tiles instead of a strip of one or two tile rows: the rows of A and B that block pulls through
+// the XCD's L2 are GH * BM + (32 / GH) * BN instead of 2 * BM + 16 * BN (packed Q|K|V on 256 x 288 tiles: 3200 instead of 5120).
+// GH = the power of two nearest sqrt(32 * BN / BM) from below in the sense GH^2 <= 2 * 32 * BN / BM; narrow grids (< 4 tile columns:
+// the Conv2d front-end) keep the row-major order.  Bijective for any grid.  Measured: 8192^3 on 256 x 256 tiles 802 -> 772 us
+// (54.8 -> 56.9 % of the bf16 peak), 4096^3 and everything of the two training steps unchanged (their operands fit the L2s either
+// way) -- GROUPED is set for the 256 x 256 / 512 x 128 kernel only.
+template <int BM, int BN, bool GROUPED = false>
+__device__ __forceinline__ void p8_tile_of_block(int& bm, int& bn) {
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
   int id = blockIdx.y * gx + blockIdx.x;
   if (gridDim.z == 1 || (nwg & 7) == 0) {
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = id & 7, j = id >> 3;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  if (GROUPED && gx >= 4) {
+    const int qe = (nwg >> 3) < 32 ? (nwg >> 3) : 32;              // workgroups of one XCD that run at the same time
+    const int t2 = 2 * qe * BN / BM;
+    int gh = 1;
+    while (gh * 2 <= gy && 4 * gh * gh <= t2) gh *= 2;
+    const int per = gh * gx, grp = id / per, within = id - grp * per;
+    const int rows = (gy - grp * gh) < gh ? (gy - grp * gh) : gh;   // the last group may be short
+    const int c = within / rows;
+    bm = grp * gh + (within - c * rows);
+    bn = c;
+    return;
   }
   bm = id / gx;
   bn = id - bm * gx;
@@ -238,7 +259,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
   const int zb = blockIdx.z;
   const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
   int tile_m, tile_n;
-  p8_tile_of_block(tile_m, tile_n);
+  p8_tile_of_block<BM, BN, true>(tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const char* Ab = reinterpret_cast<const char*>((const bf16_t*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1);
   const char* Bb = reinterpret_cast<const char*>((const bf16_t*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1);
@@ -376,7 +397,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
   const int zb = blockIdx.z;
   const int z0 = zb / d.nb1, z1 = zb - z0 * d.nb1;
   int tile_m, tile_n;
-  p8_tile_of_block(tile_m, tile_n);
+  p8_tile_of_block<256, 128>(tile_m, tile_n);
   const int m0 = tile_m * 256, n0 = tile_n * 128;
   const char* Ab = reinterpret_cast<const char*>((const bf16_t*)d.A.ptr + (int64_t)z0 * d.A.bs0 + (int64_t)z1 * d.A.bs1);
   const char* Bb = reinterpret_cast<const char*>((const bf16_t*)d.B.ptr + (int64_t)z0 * d.B.bs0 + (int64_t)z1 * d.B.bs1);
@@ -466,6 +487,145 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
     if (LEAN == 2) epilogue_flush_swish<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
     else if (LEAN == 1) epilogue_flush_common<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);       // (gemm_common.h: a fraction of the code)
     else epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, cs, 1, 0, zb);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 256 x (96 * PH) tiles, PH = 2 / 3: the geometry that gives M = 4096, N = 1536 * PH exactly 256 workgroups (one per CU, one round) --
+// the packed Q|K|V projection of the AAS-VC decoder (N = 4608) is 2.25 rounds of 256 x 128 tiles otherwise and pays for 3.
+// 8 waves as 4 (rows) x 2 (columns), wave tile 64 x (48 * PH); a K tile is PH phases of 4 x 3 fragments (24 MFMAs): phase 0
+// reads the wave's 4 A fragments (kept for the whole K tile) and the B fragments of its first 48 columns, phase p those of
+// columns 48 p .. 48 p + 47: (4 + 3 PH) / (12 PH) fragment reads per MFMA pair (0.36 at PH = 3).  Units: A = the 256 rows
+// (4 DMA instructions per wave), B.p = the 96 rows of phase p (rows 0..47: wave column 0, 48..95: wave column 1) = 12 DMA
+// instructions: waves 0..5 issue two each, waves 6 and 7 issue two from the zero block into 32 pad rows of the unit so that
+// the counted waits are the same in every wave (letting them issue nothing and wait for their A units only measured the same:
+// 52.7 vs 53.5, 51.3 vs 51.8 us).  Two stages; a unit is re-filled in the phase after the one
+// that read it, for the K tile two ahead (the rules of the kernels above); every phase waits for what the NEXT phase reads.
+// Dense operands, one problem, the common epilogue.
+// ---------------------------------------------------------------------------------------------------------
+template <int PH, bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_8ph_kernel_n96(const s2svc_gemm_desc d) {
+  static_assert(PH == 2 || PH == 3, "PH");   // (PH = 1, 256 x 96 on three stages, was built and measured: 28.8 vs 25.3 us at 4096 x 1536 x 1536)
+  constexpr int WN = 48 * PH, BN = 96 * PH;
+  constexpr int UA = 256 * 128, UB = 128 * 128;            // B unit: 96 rows + 32 pad rows
+  constexpr int BUF = UA + PH * UB;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+  int tile_m, tile_n;
+  p8_tile_of_block<256, BN>(tile_m, tile_n);
+  const int m0 = tile_m * 256, n0 = tile_n * BN;
+  const char* Ab = reinterpret_cast<const char*>(d.A.ptr);
+  const char* Bb = reinterpret_cast<const char*>(d.B.ptr);
+  const int nt = d.K / 64;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int half = wave >> 2;
+  const int lr = lane & 15, lg = lane >> 4;
+  const bool bwave = wave < 6;                              // this wave's B instructions move rows (the others: pad rows)
+
+  uint32_t offA[4], offB[PH][2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int ru = (wave * 4 + e) * 8 + (lane >> 3);
+    offA[e] = p8_rowoff<P8_DENSE>(d.A, m0 + ru, d.M, (lane & 7) ^ ((ru >> 1) & 7));
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int ru = (wave * 2 + e) * 8 + (lane >> 3);        // unit row; 96 .. 127: pad
+    const int c = (lane & 7) ^ ((ru >> 1) & 7);
+    const int w = ru >= 48 ? 1 : 0, j = ru - 48 * w;
+#pragma unroll
+    for (int p = 0; p < PH; ++p) offB[p][e] = bwave ? p8_rowoff<P8_DENSE>(d.B, n0 + w * WN + p * 48 + j, d.N, c) : 0u;
+  }
+  const int sw = (lr >> 1) & 7;
+  const int p0 = (lg ^ sw) << 4, p1 = ((4 + lg) ^ sw) << 4;
+  const int rdA = (wr * 64 + lr) * 128, rdB = (wc * 48 + lr) * 128;
+
+  f32x4_t acc[PH][4][3];
+#pragma unroll
+  for (int p = 0; p < PH; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[p][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#define N96_A(T, BUFP) p8_issue<4>((T) < nt ? Ab + (int64_t)(T) * 128 : nullptr, offA, (BUFP), wave)
+#define N96_B(T, P, BUFP) p8_issue<2>(((T) < nt && bwave) ? Bb + (int64_t)(T) * 128 : nullptr, offB[P], (BUFP) + UA + (P) * UB, wave)
+#define N96_WAIT(N, A_DUE) p8_wait_vmcnt<(N)>()
+  // prologue, in the order of the steady state: tile 0, then of tile 1 everything but its last B unit
+  N96_A(0, smem);
+#pragma unroll
+  for (int p = 0; p < PH; ++p) N96_B(0, p, smem);
+  N96_A(1, smem + BUF);
+#pragma unroll
+  for (int p = 0; p + 1 < PH; ++p) N96_B(1, p, smem + BUF);
+  // A + B.0 of tile 0 have landed: what was issued behind them may still be moving
+  N96_WAIT(PH == 2 ? 8 : 12, true);
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && half == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8_t fa[4][2], fb[3][2];
+  for (int t = 0; t < nt; ++t) {
+    char* cur = smem + (t & 1) * BUF;
+    char* oth = smem + ((t & 1) ^ 1) * BUF;
+    // ---- phase 0: columns 0 .. 47 of the wave
+    p8_read<3>(cur + UA, rdB, p0, p1, fb);
+    p8_read<4>(cur, rdA, p0, p1, fa);
+    N96_B(t + 1, PH - 1, oth);                              // the last B unit of tile t + 1 (read in the last phase of tile t - 1)
+    N96_WAIT(PH == 2 ? 8 : 12, false);                      // B.1 of tile t has landed
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 3>(fa, fb, acc[0]);
+    P8_PHASE_SYNC_OUT();
+    // ---- phase 1
+    p8_read<3>(cur + UA + UB, rdB, p0, p1, fb);
+    N96_A(t + 2, cur);                                      // A, B.0 of tile t + 2
+    N96_B(t + 2, 0, cur);
+    N96_WAIT(PH == 2 ? 8 : 16, PH == 2);                    // PH = 2: A, B.0 of tile t + 1; PH = 3: B.2 of tile t
+    P8_PHASE_SYNC_IN();
+    p8_mfma<4, 3>(fa, fb, acc[1]);
+    P8_PHASE_SYNC_OUT();
+    if (PH == 3) {
+      // ---- phase 2
+      p8_read<3>(cur + UA + 2 * UB, rdB, p0, p1, fb);
+      N96_B(t + 2, 1, cur);                                 // B.1 of tile t + 2
+      N96_WAIT(12, true);                                   // A, B.0 of tile t + 1
+      P8_PHASE_SYNC_IN();
+      p8_mfma<4, 3>(fa, fb, acc[PH - 1]);
+      P8_PHASE_SYNC_OUT();
+    }
+  }
+#undef N96_WAIT
+#undef N96_A
+#undef N96_B
+  if (STAGGER && half == 0) __builtin_amdgcn_s_barrier();
+  p8_wait_vmcnt<0>();
+  __syncthreads();
+  float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+  const int mw = m0 + wr * 64, nw = n0 + wc * WN;
+  // the wave's 3 PH column fragments leave in pairs (64 x 32) and, for an odd count, one single (64 x 16); rolled, one copy of
+  // each flush
+  constexpr int NJ = 3 * PH;
+#pragma unroll 1
+  for (int q = 0; q < NJ / 2; ++q) {
+    f32x4_t t2[4][2];
+#pragma unroll
+    for (int qq = 0; qq < NJ / 2; ++qq)
+      if (qq == q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          t2[i][0] = acc[(2 * qq) / 3][i][(2 * qq) % 3];
+          t2[i][1] = acc[(2 * qq + 1) / 3][i][(2 * qq + 1) % 3];
+        }
+      }
+    epilogue_stage<64, 32>(t2, cs);
+    epilogue_flush_common<64, 32>(d, mw, nw + q * 32, cs);
+  }
+  if (NJ & 1) {
+    f32x4_t t1[4][1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t1[i][0] = acc[PH - 1][i][2];
+    epilogue_stage<64, 16>(t1, cs);
+    epilogue_flush_common<64, 16>(d, mw, nw + (NJ - 1) * 16, cs);
   }
 }
 
@@ -788,7 +948,7 @@ template <bool STAGGER>
 __global__ __launch_bounds__(512) void gemm_8ph_tr_kernel(const s2svc_gemm_desc d) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 3 * 16384];
   int tile_m, tile_n;
-  p8_tile_of_block(tile_m, tile_n);
+  p8_tile_of_block<256, 128>(tile_m, tile_n);
   p8_tr_tile<STAGGER>(d, tile_m, tile_n, smem);
 }
 
@@ -1116,7 +1276,7 @@ template <bool STAGGER>
 __global__ __launch_bounds__(512) void gemm_8ph_tr_kernel_q(const s2svc_gemm_desc d) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 4 * 16384];
   int tile_m, tile_n;
-  p8_tile_of_block(tile_m, tile_n);
+  p8_tile_of_block<256, 256>(tile_m, tile_n);
   p8_tr_tile_q<STAGGER>(d, tile_m, tile_n, smem);
 }
 
@@ -1160,6 +1320,26 @@ int p8_min_tiles() {  // S2SVC_GEMM_8PH_MIN_TILES: take the kernel from this man
   return v;
 }
 
+int g_p8_n96 = -1;
+int p8_n96_mode() {     // S2SVC_GEMM_N96: 0 = off, 1 = by policy (default), 2 = wherever N is a multiple of 96 PH, 4 / 5 = PH = 2 / 3 only (tests / benchmarks)
+  if (g_p8_n96 < 0) { const char* e = getenv("S2SVC_GEMM_N96"); g_p8_n96 = e ? atoi(e) : 1; }
+  return g_p8_n96;
+}
+// phases (tile width / 96) of the one-round geometry for this problem, 0 = keep the geometry chosen so far (`tiles` workgroups)
+int p8_n96_phases(const s2svc_gemm_desc& d, int geo, int64_t tiles) {
+  const int md = p8_n96_mode();
+  if (md == 0 || d.K < 128 || d.N % 96) return 0;
+  const int64_t tm = (d.M + 255) / 256;
+  for (int ph = 3; ph >= 2; --ph) {
+    if (d.N % (96 * ph)) continue;
+    const int64_t t = tm * (d.N / (96 * ph));
+    if (md >= 2) { if (md == 2 || md == 2 + ph) return ph; continue; }
+    // by policy: one full round (>= 7/8 of the CUs) where the other geometry is short of one or runs over into the next
+    if (t <= 256 && t >= 224 && (geo == 0 || tiles < 224 || tiles > 256)) return ph;
+  }
+  return 0;
+}
+
 int g_p8_geo = -1;
 int p8_force_bn() {   // S2SVC_GEMM_8PH_GEO=1|2|3 / s2svc_gemm_set_8ph: force the tile geometry 256x256 / 512x128 / 256x128
   if (g_p8_geo < 0) { const char* e = getenv("S2SVC_GEMM_8PH_GEO"); g_p8_geo = e ? atoi(e) : 0; }
@@ -1193,10 +1373,15 @@ bool p8_operand_ok(const s2svc_operand& o, int rows, int K) {
 
 // A/B switch for tests and benchmarks: returns the previous mode (see p8_mode)
 extern "C" int s2svc_gemm_set_8ph(int mode) {
-  const int prev = p8_mode() | (p8_force_bn() << 4);
-  if (mode >= 0 && (mode & 15) <= 2 && (mode >> 4) <= 3) {
-    g_p8_mode = mode & 15;
-    g_p8_geo = mode >> 4;
+  const int prev = p8_mode() | (p8_force_bn() << 4) | ((p8_n96_mode() + 1) << 8);
+  if (mode >= 0) {
+    const int n96 = (mode >> 8) & 15;            // 0: leave; 1 + S2SVC_GEMM_N96 value otherwise
+    mode &= 255;
+    if ((mode & 15) <= 2 && (mode >> 4) <= 3) {
+      g_p8_mode = mode & 15;
+      g_p8_geo = mode >> 4;
+    }
+    if (n96 >= 1 && n96 <= 6) g_p8_n96 = n96 - 1;
   }
   return prev;
 }
@@ -1240,8 +1425,19 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   else if (d.M >= 2048 && t512 >= 160 && t512 <= 256) geo = 2;
   else if (t128 >= p8_min_tiles()) geo = 3;
   if (p8_force_bn() >= 1 && p8_force_bn() <= 3) geo = p8_force_bn();
-  if (geo == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  // 256 x 96 PH tiles where they fit the chip in ONE round and the geometry above does not (gemm_8ph_kernel_n96)
+  if (d.A.mode == S2SVC_OP_DENSE && nb == 1 && mode == 1 && (p8_force_bn() == 0 || p8_n96_mode() >= 2) && epilogue_common_ok(d)) {
+    const int ph = p8_n96_phases(d, geo, geo == 1 ? t256 : geo == 2 ? t512 : t128);
+    if (ph) {
+      dim3 grid((unsigned)((d.N + 96 * ph - 1) / (96 * ph)), (unsigned)((d.M + 255) / 256), 1);
+      if (ph == 3) hipLaunchKernelGGL((gemm_8ph_kernel_n96<3, true>), grid, dim3(512), 0, st, d);
+      else hipLaunchKernelGGL((gemm_8ph_kernel_n96<2, true>), grid, dim3(512), 0, st, d);
+      S2S_CHECK_LAUNCH("gemm_8ph_kernel_n96");
+      return 1;
+    }
+  }
+  if (geo == 0) return 0;
   const bool conv = d.A.mode == S2SVC_OP_CONV2D_S2, tconv = d.A.mode == S2SVC_OP_TCONV2D_S2;
   const int bm = geo == 2 ? 512 : 256, bn = geo == 1 ? 256 : 128;
   dim3 grid((unsigned)((d.N + bn - 1) / bn), (unsigned)((d.M + bm - 1) / bm), (unsigned)nb);

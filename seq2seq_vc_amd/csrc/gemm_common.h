@@ -167,10 +167,10 @@ __device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0,
   // NOT unrolled: the body is load/store bound, and unrolling it (8 passes x 8 values x RNG state) raised the
   // register demand of the whole kernel until hipcc spilled the MFMA accumulators inside the K loop (5x slower)
 #pragma unroll 1
-  for (int p = 0; p < WTM / RPP; ++p) {
+  for (int p = 0; p < (WTM + RPP - 1) / RPP; ++p) {       // (a 16 x 16 wave tile is half a pass: rows >= WTM idle)
     const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
     const int m = m_base + row, n = n_base + col;
-    if (m >= d.M || n >= d.N) continue;
+    if ((WTM % RPP != 0 && row >= WTM) || m >= d.M || n >= d.N) continue;
     const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
     const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -463,10 +463,10 @@ __device__ __forceinline__ void epilogue_flush_common32(const s2svc_gemm_desc& d
     b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
   }
 #pragma unroll 1
-  for (int p = 0; p < WTM / RPP; ++p) {
+  for (int p = 0; p < (WTM + RPP - 1) / RPP; ++p) {
     const int row = p * RPP + lane / LPR;
     const int m = m_base + row;
-    if (m >= d.M) continue;
+    if ((WTM % RPP != 0 && row >= WTM) || m >= d.M) continue;
     const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
     float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
     if (d.bias) {
@@ -497,10 +497,10 @@ __device__ __forceinline__ void epilogue_partials(const s2svc_gemm_desc& d, int 
   const int lane = threadIdx.x & 63;
   constexpr int LPR = WTN / 8, RPP = 64 / LPR;
 #pragma unroll 1
-  for (int p = 0; p < WTM / RPP; ++p) {
+  for (int p = 0; p < (WTM + RPP - 1) / RPP; ++p) {
     const int row = p * RPP + lane / LPR, col = (lane % LPR) * 8;
     const int m = m_base + row, n = n_base + col;
-    if (m >= d.M || n >= d.N) continue;
+    if ((WTM % RPP != 0 && row >= WTM) || m >= d.M || n >= d.N) continue;
     const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
     float* w = d.ws + ((int64_t)zs * d.M + m) * d.N + n;
     *reinterpret_cast<float4*>(w) = *reinterpret_cast<const float4*>(src);

@@ -317,12 +317,14 @@ template <typename T, int BM, int BN, int BK>
 void launch_modes(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   const bool arc = d.A.layout == S2SVC_LAYOUT_RC, brc = d.B.layout == S2SVC_LAYOUT_RC;
   static const bool lean_on = !(getenv("S2SVC_GEMM_LEAN") && getenv("S2SVC_GEMM_LEAN")[0] == '0');
-  if (lean_on && sizeof(T) == 4 && BM == 64 && d.A.mode == S2SVC_OP_DENSE && d.B.mode == S2SVC_OP_DENSE && epilogue_common32_ok(d)) {
-    if (!arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<float, 64, 64, 64, AM_KC, AM_KC, true>), grid, dim3(256), 0, st, d);
-    else if (!arc && brc) hipLaunchKernelGGL((gemm_fast_kernel<float, 64, 64, 64, AM_KC, AM_RC, true>), grid, dim3(256), 0, st, d);
-    else if (arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<float, 64, 64, 64, AM_RC, AM_KC, true>), grid, dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((gemm_fast_kernel<float, 64, 64, 64, AM_RC, AM_RC, true>), grid, dim3(256), 0, st, d);
-    return;
+  if constexpr (sizeof(T) == 4 && BM <= 64) {
+    if (lean_on && d.A.mode == S2SVC_OP_DENSE && d.B.mode == S2SVC_OP_DENSE && epilogue_common32_ok(d)) {
+      if (!arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<float, BM, BN, BK, AM_KC, AM_KC, true>), grid, dim3(256), 0, st, d);
+      else if (!arc && brc) hipLaunchKernelGGL((gemm_fast_kernel<float, BM, BN, BK, AM_KC, AM_RC, true>), grid, dim3(256), 0, st, d);
+      else if (arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<float, BM, BN, BK, AM_RC, AM_KC, true>), grid, dim3(256), 0, st, d);
+      else hipLaunchKernelGGL((gemm_fast_kernel<float, BM, BN, BK, AM_RC, AM_RC, true>), grid, dim3(256), 0, st, d);
+      return;
+    }
   }
   if (!arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_KC, AM_KC>), grid, dim3(256), 0, st, d);
   else if (!arc && brc) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, BK, AM_KC, AM_RC>), grid, dim3(256), 0, st, d);
@@ -367,9 +369,21 @@ extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream) {
     if (d.dtype == S2S_F32) launch_modes<float, 128, 128, 32>(d, grid, st);
     else launch_modes<bf16_t, 128, 128, 64>(d, grid, st);
   } else {
-    dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.nb0 * d.nb1 * splitk);
-    if (d.dtype == S2S_F32) launch_modes<float, 64, 64, 64>(d, grid, st);
-    else launch_modes<bf16_t, 64, 64, 128>(d, grid, st);
+    // fp32 problems that leave most of the chip idle on 64 x 64 tiles (the duration predictor's 1024 x 384 x 384 Linear layers:
+    // 96 workgroups; its 29-column spline projection: 16) take 32 x 32 tiles with K tiles of 128: the fp32 MFMA
+    // (v_mfma_f32_16x16x4f32, 256 flop / clk / CU) makes a 64 x 64 x 384 workgroup 5 us of matrix-pipe time on its own;
+    // a quarter of it per workgroup, on four times the workgroups.  Same order of every sum (k ascending), same bits.
+    static const bool t32_on = !(getenv("S2SVC_GEMM_F32_T32") && getenv("S2SVC_GEMM_F32_T32")[0] == '0');
+    const int64_t tiles64 = (int64_t)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nb0 * d.nb1 * splitk;
+    if (d.dtype == S2S_F32 && t32_on && d.tile_hint == 0 && tiles64 < 128 && d.K >= 128 && d.A.mode == S2SVC_OP_DENSE &&
+        d.B.mode == S2SVC_OP_DENSE && !d.a_rowsum) {
+      dim3 grid((d.N + 31) / 32, (d.M + 31) / 32, d.nb0 * d.nb1 * splitk);
+      launch_modes<float, 32, 32, 128>(d, grid, st);
+    } else {
+      dim3 grid((d.N + 63) / 64, (d.M + 63) / 64, d.nb0 * d.nb1 * splitk);
+      if (d.dtype == S2S_F32) launch_modes<float, 64, 64, 64>(d, grid, st);
+      else launch_modes<bf16_t, 64, 64, 128>(d, grid, st);
+    }
   }
   S2S_CHECK_LAUNCH("gemm_fast_kernel");
   return 1;

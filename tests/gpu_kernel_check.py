@@ -1127,6 +1127,113 @@ def mas_kernel():
 
 
 @case
+def gemm_fp32_small_tiles():
+    """fp32 GEMMs that underfill the chip on 64 x 64 tiles run on 32 x 32 tiles with K tiles of 128 (gemm_fast.hip; the duration
+    predictor's Linear layers, data gradients and its 29-column spline projection): against torch fp32 and BIT FOR BIT against the
+    64 x 64 kernel (tile hint 64) -- k ascends in the same order in both; K-contiguous and row-contiguous operands, bias / ReLU /
+    residual / accumulate, split-K partials, row / column / K tails."""
+    res = []
+    f32 = torch.float32
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        for (M, N, Kd, seed) in [(1024, 384, 384, 1), (1024, 29, 384, 2), (1000, 200, 136, 3), (70, 8, 640, 4), (1024, 192, 768, 5)]:
+            a, w = rnd(M, Kd, seed=seed), rnd(N, Kd, seed=seed + 50, scale=0.05)
+            bias, r = rnd(N, seed=seed + 60), rnd(M, N, seed=seed + 70)
+            ref = torch.relu(a.double() @ w.double().t() + bias.double()) + r.double()
+            outs = []
+            for tile in (64, 0):
+                c = torch.full((M, N), float("nan"), device=DEV)
+                K.gemm(K.operand(a, Kd), K.operand(w, Kd), M, N, Kd, c, in_dtype=f32, bias=bias, act="relu", res=r, tile=tile)
+                outs.append(c)
+            res.append(check(f"fp32 32x32 tiles {M}x{N}x{Kd} bias + relu + residual", outs[1], ref.float(), f32, rtol=1e-4, atol=1e-4))
+            res.append((bool(torch.equal(outs[0], outs[1])), f"fp32 32x32 tiles {M}x{N}x{Kd} == 64x64 kernel bit for bit"))
+            # data gradient: B row-contiguous, accumulate into C
+            if N % 4 == 0:
+                dy = rnd(M, N, seed=seed + 80)
+                outs = []
+                for tile in (64, 0):
+                    dx = rnd(M, Kd, seed=seed + 90)
+                    K.gemm(K.operand(dy, N), K.operand(w, Kd, layout=K.RC), M, Kd, N, dx, in_dtype=f32, accumulate=True, tile=tile)
+                    outs.append(dx)
+                ref = rnd(M, Kd, seed=seed + 90).double() + dy.double() @ w.double()
+                res.append(check(f"fp32 32x32 tiles dgrad {M}x{Kd}x{N} (RC weights, accumulate)", outs[1], ref.float(), f32, rtol=1e-4, atol=1e-4))
+                res.append((bool(torch.equal(outs[0], outs[1])), f"fp32 32x32 tiles dgrad {M}x{Kd}x{N} == 64x64 kernel bit for bit"))
+                # weight gradient: both operands row-contiguous, split-K 2 (partials + reduction kernel)
+                if Kd % 4 == 0 and M % 4 == 0:
+                    outs = []
+                    for tile in (64, 0):
+                        dw = torch.full((N, Kd), float("nan"), device=DEV)
+                        K.gemm(K.operand(dy, N, layout=K.RC), K.operand(a, Kd, layout=K.RC), N, Kd, M, dw, in_dtype=f32, splitk=2, tile=tile)
+                        outs.append(dw)
+                    res.append(check(f"fp32 32x32 tiles wgrad {N}x{Kd}x{M} split-K 2", outs[1], (dy.double().t() @ a.double()).float(), f32, rtol=1e-4, atol=1e-4))
+                    res.append((bool(torch.equal(outs[0], outs[1])), f"fp32 32x32 tiles wgrad {N}x{Kd}x{M} == 64x64 kernel bit for bit"))
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    return res
+
+
+@case
+def gemm_8phase_n96():
+    """The one-round geometry of the 8-wave kernel (gemm_8ph_kernel_n96: 256 x 96 p tiles, p = 2 / 3 phases per K tile, 4 x 2
+    waves, B units with pad rows): against torch fp32 matmul of the same bf16 inputs and BIT FOR BIT against the 256 x 128 kernel
+    (same K order per output element); odd / even / minimal numbers of K tiles (two LDS stages alternate), row and
+    column tails, the common epilogue's options (bias, relu, residual, dropout), repeated launches, and what the policy picks."""
+    res = []
+    dtype = torch.bfloat16
+    L = K._lib.lib()
+    prev = L.s2svc_gemm_set_8ph(-1)
+    OFF, P = 1 | (3 << 4) | (1 << 8), {2: 1 | (5 << 8), 3: 1 | (6 << 8)}
+    try:
+        for (M, N, Kd, seed) in [(4096, 4608, 1536, 1), (4096, 3072, 1536, 2), (4096, 1536, 384, 4), (1030, 288, 640, 5),
+                                 (2050, 192, 128, 6), (300, 384, 192, 7), (4096, 576, 320, 8), (515, 864, 128, 9), (256, 288, 4608, 10)]:
+            a, b = rnd(M, Kd, seed=seed, dtype=dtype), rnd(N, Kd, seed=seed + 100, dtype=dtype, scale=0.05)
+            bias = rnd(N, seed=seed + 200)
+            ref = a.float() @ b.float().t() + bias
+            L.s2svc_gemm_set_8ph(OFF)
+            c0 = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+            K.gemm(K.operand(a, Kd), K.operand(b, Kd), M, N, Kd, c0, in_dtype=dtype, bias=bias)
+            for ph in (2, 3):
+                if N % (96 * ph):
+                    continue
+                L.s2svc_gemm_set_8ph(P[ph])
+                c = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+                K.gemm(K.operand(a, Kd), K.operand(b, Kd), M, N, Kd, c, in_dtype=dtype, bias=bias)
+                res.append(check(f"8-phase n96 {M}x{N}x{Kd} tile 256x{96 * ph}", c, ref, dtype))
+                res.append((bool(torch.equal(c, c0)), f"8-phase n96 {M}x{N}x{Kd} 256x{96 * ph} == 256x128 kernel bit for bit"))
+        # epilogue options of the common epilogue
+        M, N, Kd = 4096, 4608, 256
+        a, b = rnd(M, Kd, seed=11, dtype=dtype), rnd(N, Kd, seed=12, dtype=dtype, scale=0.05)
+        r, bias = rnd(M, N, seed=13, dtype=dtype), rnd(N, seed=14)
+        for ph in (2, 3):
+            outs = []
+            for mode in (OFF, P[ph]):
+                L.s2svc_gemm_set_8ph(mode)
+                K.reset_op_counter()
+                c = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+                K.gemm(K.operand(a, Kd), K.operand(b, Kd), M, N, Kd, c, in_dtype=dtype, bias=bias, act="relu", res=r, drop_p=0.1)
+                outs.append(c)
+            res.append((bool(torch.equal(outs[0], outs[1])) and not bool(torch.isnan(outs[1].float()).any()),
+                        f"8-phase n96 256x{96 * ph}: bias + relu + dropout + residual == 256x128 kernel bit for bit"))
+        # repeated launches give identical bits
+        for ph, (M, N, Kd) in ((2, (4096, 3072, 1536)), (3, (4096, 4608, 1536))):
+            L.s2svc_gemm_set_8ph(P[ph])
+            a, b = rnd(M, Kd, seed=31, dtype=dtype), rnd(N, Kd, seed=32, dtype=dtype, scale=0.05)
+            first, bad = None, 0
+            for it in range(30):
+                c = torch.empty(M, N, dtype=dtype, device=DEV)
+                K.gemm(K.operand(a, Kd), K.operand(b, Kd), M, N, Kd, c, in_dtype=dtype)
+                if first is None:
+                    first = c
+                elif not torch.equal(first, c):
+                    bad += 1
+            res.append((bad == 0, f"8-phase n96 256x{96 * ph} {M}x{N}x{Kd}: 30 launches identical ({bad} differ)"))
+    finally:
+        L.s2svc_gemm_set_8ph(prev)
+    return res
+
+
+@case
 def gemm_8phase():
     """The 256-row / 8-wave / phase-interleaved bf16 GEMM (csrc/gemm_8ph.hip) in each of its three tile geometries
     (256 x 256, 512 x 128, 256 x 128) and both wave-half schedules (skewed / lockstep), on shapes with odd and even numbers

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B timing of the bf16 GEMM kernel families on the forward / data-gradient shapes of the two workloads:
 mode 0 = 128x128 4-wave kernel (gemm_glds.hip), 1 = 8-wave phase-interleaved kernel by policy (gemm_8ph.hip), 2 = the same
-without the half-phase skew, 17 / 33 / 49 = mode 1 with the tile geometry forced to 256x256 / 512x128 / 256x128.  Variants are interleaved in rounds inside ONE process (medians reported); every timing is
+without the half-phase skew, 17 / 33 / 49 = mode 1 with the tile geometry forced to 256x256 / 512x128 / 256x128; + 256 (v + 1) sets the
+one-round 256 x 96 p geometry (gemm_8ph_kernel_n96): 257 = policy without it, 513 = policy with it (the default), 769 = wherever N % 96 p == 0 (widest p), 1281 / 1537 = p = 2 / 3.  Variants are interleaved in rounds inside ONE process (medians reported); every timing is
 `--iters` launches replayed from one hipGraph with HIP events around the replay; operands uniform random in [-1, 1).
 
     python tools/gemm8_bench.py [--iters 50] [--rounds 5] [--modes 0,1,2]
@@ -79,7 +80,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--modes", default="0,1,17,33,49")
+    ap.add_argument("--modes", default="0,257,513,273,289,305,769")
     ap.add_argument("--ksweep", action="store_true",
                     help="instead: 4096 x 1536 x K for a range of K on the 256 x 128 8-wave kernel -> fixed cost per launch + us per K tile "
                          "(least squares), beside the launch floor of a do-nothing kernel")
