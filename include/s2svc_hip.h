@@ -472,6 +472,11 @@ int s2svc_expand_bwd(int dtype, int B, int T, int C, const void* dy, const float
 int s2svc_ln_act_fwd(int dtype, int rows, int D, int T, const void* x, const float* gamma, const float* beta, float eps, int act,
                      const void* res, const int32_t* lens, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y,
                      float* mean, float* rstd, void* stream);
+/* the first half of a DDS layer in one launch (fp32): u = depthwise Conv1d(x; dw_w (D, ks), dw_b, dilation dil, zero padding inside
+   the T frames of an utterance) -- flow.py:137-146 -- written out for the backward pass, y = act(LayerNorm(u)); D <= 512, ks odd */
+int s2svc_dw_ln_act_fwd(int B, int T, int D, int ks, int dil, const float* x, const float* dw_w, const float* dw_b,
+                        const float* gamma, const float* beta, float eps, int act, float* u, float* y, float* mean, float* rstd,
+                        void* stream);
 /* du = gradient at the LayerNorm output (feeds dgamma/dbeta via colreduce mode 1), dx = LN input grad, dres = mask*dy */
 int s2svc_ln_act_bwd(int dtype, int rows, int D, int T, const void* dy, const void* x, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, int act, const int32_t* lens, float drop_p,

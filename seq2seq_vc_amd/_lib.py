@@ -192,6 +192,7 @@ _SIGS = {
     "s2svc_expand_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_ln_act_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp,
                          c_vp, c_vp],
+    "s2svc_dw_ln_act_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_ln_act_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_u64, c_vp,
                          c_vp, c_vp, c_vp],
     "s2svc_rq_spline_fwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_f32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp],

@@ -126,6 +126,56 @@ __global__ __launch_bounds__(256) void ln_act_fwd_kernel(int rows, int D, int Tn
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
+// The first half of a DDS layer in one launch: u = depthwise Conv1d(x) (kernel ks, dilation dil, zero padding inside the
+// utterance's T frames; written out: the backward pass normalises it again), y = act(LayerNorm(u)).  A wave owns a frame: its
+// lanes read the ks frames t + (j - pad) dil of their channels (coalesced rows), accumulate bias + sum_j w[c][j] x in tap order
+// (the arithmetic of dwconv_fwd_vec_kernel), then the row statistics exactly as ln_act_fwd_kernel.
+template <typename T, int NV, int ACT = -1>
+__global__ __launch_bounds__(256) void dw_ln_act_fwd_kernel(int rows, int D, int Tn, int ks, int dil, const T* __restrict__ x,
+                                                            const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            int act_rt, T* __restrict__ u_out, T* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int act = ACT >= 0 ? ACT : act_rt;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = row / Tn, t = row - b * Tn;
+  const int pad = (ks - 1) / 2;
+  const int64_t base = (int64_t)row * D, bbase = (int64_t)b * Tn * D;
+  float v[NV];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = 0.f;
+    if (c < D) {
+      float a = dw_b ? dw_b[c] : 0.f;
+      for (int j = 0; j < ks; ++j) {
+        const int tt = t + (j - pad) * dil;
+        if (tt >= 0 && tt < Tn) a += dw_w[c * ks + j] * ldf(x + bbase + (int64_t)tt * D + c);
+      }
+      stf(u_out + base + c, a);
+      v[i] = a;
+    }
+    sum += v[i];
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float d = (lane + 64 * i) < D ? v[i] - mean : 0.f;
+    sq += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) stf(y + base + c, act_apply((v[i] - mean) * rstd * gamma[c] + beta[c], act));
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
 // du = valid * dy * dropmask * act'(u)  (gradient at the LN output u; dgamma / dbeta are column reductions of it),
 // dx = rstd*(du*gamma - mean(du*gamma) - xhat*mean(du*gamma*xhat)),  dres = valid * dy
 template <typename T, int NV, int ACT = -1>
@@ -578,6 +628,26 @@ extern "C" int s2svc_ln_act_fwd(int dtype, int rows, int D, int Tn, const void* 
   }
 #undef S2S_LNACT
   S2S_CHECK_LAUNCH("ln_act_fwd_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_dw_ln_act_fwd(int B, int Tn, int D, int ks, int dil, const float* x, const float* dw_w, const float* dw_b,
+                                   const float* gamma, const float* beta, float eps, int act, float* u, float* y, float* mean,
+                                   float* rstd, void* stream) {
+  S2S_REQUIRE(B >= 0 && Tn > 0 && D > 0 && D <= 512 && ks >= 1 && ks % 2 == 1 && dil >= 1 && x && dw_w && u && y && mean && rstd,
+              "dw_ln_act_fwd: bad arguments (fp32, D <= 512, odd kernel size)");
+  const int rows = B * Tn;
+  if (rows == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4), block(256);
+#define S2S_DWLN(...)                                                                                                         \
+  hipLaunchKernelGGL((dw_ln_act_fwd_kernel<float, __VA_ARGS__>), grid, block, 0, st, rows, D, Tn, ks, dil, x, dw_w, dw_b, gamma, beta, eps, \
+                     act, u, y, mean, rstd)
+  if (D <= 256 && act == S2S_ACT_GELU) S2S_DWLN(4, S2S_ACT_GELU);
+  else if (act == S2S_ACT_GELU) S2S_DWLN(8, S2S_ACT_GELU);
+  else S2S_DWLN(8);
+#undef S2S_DWLN
+  S2S_CHECK_LAUNCH("dw_ln_act_fwd_kernel");
   return 0;
 }
 

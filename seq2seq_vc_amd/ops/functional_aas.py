@@ -33,29 +33,35 @@ class _DwConv(Function):
         (x,) = ctx.saved_tensors
         weight, bias = ctx.params
         ks, dil = ctx.meta
-        dy = _c(dy)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if g_pass is not None and KA.dwconv_add_ok(dy, ks):
-                dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True, add=_c(g_pass))
-            else:
-                dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True)
-                if g_pass is not None:
-                    dx = dx + g_pass
-        dw = db = None
-        if weight.requires_grad:
-            slot = getattr(weight, "_s2s_grad", None)
-            if slot is not None and slot.is_contiguous():       # straight into the flat gradient buffer
-                KA.dwconv_wgrad(x, dy, ks, dil, out=slot)
-            else:
-                dw = _emit_vgrad(weight, KA.dwconv_wgrad(x, dy, ks, dil))
-        if bias is not None and bias.requires_grad:
-            dy2 = dy.view(-1, dy.shape[-1])
-            if _slotted(bias):                                    # queued: joins the grouped column reductions of the batch
-                _side_run(lambda: _reduce_to(bias, None, 0, dy2), keep=(dy2,))
-            else:
-                db, _ = _reduce_to(bias, None, 0, dy2)
+        dx, dw, db = dwconv_backward(x, _c(dy), weight, bias, ks, dil, g_pass, ctx.needs_input_grad[0])
         return dx, dw, db, None, None
+
+
+def dwconv_backward(x, dy, weight, bias, ks, dil, g_pass, need_dx):
+    """Data / weight / bias gradients of the depthwise convolution (shared with the fused DDS half-layer, functional_sdp._DwLnAct);
+    g_pass: a gradient for x that arrived over a pass-through output, summed inside the data-gradient kernel."""
+    dx = None
+    if need_dx:
+        if g_pass is not None and KA.dwconv_add_ok(dy, ks):
+            dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True, add=_c(g_pass))
+        else:
+            dx = KA.dwconv(dy, weight.detach(), None, ks, dil, flip=True)
+            if g_pass is not None:
+                dx = dx + g_pass
+    dw = db = None
+    if weight.requires_grad:
+        slot = getattr(weight, "_s2s_grad", None)
+        if slot is not None and slot.is_contiguous():       # straight into the flat gradient buffer
+            KA.dwconv_wgrad(x, dy, ks, dil, out=slot)
+        else:
+            dw = _emit_vgrad(weight, KA.dwconv_wgrad(x, dy, ks, dil))
+    if bias is not None and bias.requires_grad:
+        dy2 = dy.view(-1, dy.shape[-1])
+        if _slotted(bias):                                    # queued: joins the grouped column reductions of the batch
+            _side_run(lambda: _reduce_to(bias, None, 0, dy2), keep=(dy2,))
+        else:
+            db, _ = _reduce_to(bias, None, 0, dy2)
+    return dx, dw, db
 
 
 def dwconv1d(x, weight, bias=None, dilation=1):

@@ -112,6 +112,56 @@ def ln_act(x, gamma, beta, eps, act, res=None, lens=None, T=0, p=0.0):
     return _LnAct.apply(x, gamma, beta, eps, act, res, lens, T, p)
 
 
+_FUSE_DW_LN = __import__("os").environ.get("S2SVC_SDP_DW_LN", "1") != "0"       # A/B switch: dwconv + LN + act as one forward launch
+
+
+class _DwLnAct(Function):
+    """act(LayerNorm(depthwise_conv1d(x))) -- the first half of a DDS layer (flow.py:137-160) as ONE forward launch
+    (s2svc_dw_ln_act_fwd); the backward pass is the two modular ones in sequence (LayerNorm', then the convolution's gradients).
+    Second output: x itself (the residual's pass-through, see functional_aas._DwConv)."""
+
+    @staticmethod
+    def forward(ctx, x, dw_w, dw_b, dil, gamma, beta, eps, act):
+        x = _c(x)
+        ks = dw_w.shape[-1]
+        u, y, mean, rstd = KS.dw_ln_act_fwd(x, dw_w.detach(), dw_b.detach() if dw_b is not None else None, ks, dil, gamma.detach(),
+                                            beta.detach(), eps, act)
+        ctx.params = (dw_w, dw_b, gamma, beta)
+        ctx.meta = (ks, dil, act)
+        ctx.save_for_backward(x, u, mean, rstd)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, g_pass=None):
+        if dy is None:
+            return g_pass, None, None, None, None, None, None, None
+        from .functional_aas import dwconv_backward
+        x, u, mean, rstd = ctx.saved_tensors
+        dw_w, dw_b, gamma, beta = ctx.params
+        ks, dil, act = ctx.meta
+        du, dxu, _ = KS.ln_act_bwd(_c(dy), u, mean, rstd, gamma.detach(), beta.detach(), act)
+        D = u.shape[-1]
+        du2, u2 = du.view(-1, D), u.view(-1, D)
+        dgamma = dbeta = None
+        if _slotted(gamma, beta) and _QUEUE_LN:
+            _side_run(lambda: _reduce_to(beta, gamma, 1, du2, u2, mean, rstd), keep=(du2, u2, mean, rstd))
+        else:
+            dbeta, dgamma = _reduce_to(beta, gamma, 1, du2, u2, mean, rstd)
+        dx, dw, db = dwconv_backward(x, dxu, dw_w, dw_b, ks, dil, g_pass, ctx.needs_input_grad[0])
+        return dx, dw, db, None, dgamma, dbeta, None, None
+
+
+def dw_ln_act_ok(x, dw_w):
+    return (_FUSE_DW_LN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] <= 512 and dw_w.shape[-1] % 2 == 1
+            and dw_w.dtype == torch.float32)
+
+
+def dw_ln_act(x, dw_w, dw_b, dil, gamma, beta, eps, act):
+    """-> (act(LN(dwconv(x))), x): the second output is x for the residual connection (one consumer of x)."""
+    return _DwLnAct.apply(x, dw_w, dw_b, dil, gamma, beta, eps, act)
+
+
 class _Spline(Function):
     """xb' = RQ-spline(xb; h) on valid rows (ConvFlow, flow.py:294-308); log|det| rows go to shared.lad[which]."""
 

@@ -47,6 +47,18 @@ def ln_act_fwd(x, gamma, beta, eps, act, res=None, lens=None, T=0, p=0.0, seed=(
     return y, mean, rstd
 
 
+def dw_ln_act_fwd(x, dw_w, dw_b, ks, dil, gamma, beta, eps, act):
+    """x (B, T, D) fp32 -> (u = dwconv(x), y = act(LN(u)), mean, rstd): the first half of a DDS layer in one launch."""
+    _f32(x, dw_w, dw_b, gamma, beta)
+    B, T, D = x.shape
+    u, y = torch.empty_like(x), torch.empty_like(x)
+    mean = torch.empty(B * T, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B * T, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().s2svc_dw_ln_act_fwd(B, T, D, ks, dil, ptr(x), ptr(dw_w), ptr(dw_b), ptr(gamma), ptr(beta), eps, ACT[act], ptr(u),
+                                              ptr(y), ptr(mean), ptr(rstd), stream()), "dw_ln_act_fwd")
+    return u, y, mean, rstd
+
+
 def ln_act_bwd(dy, x, mean, rstd, gamma, beta, act, lens=None, T=0, p=0.0, seed=(None, 0), want_dres=False):
     D = x.shape[-1]
     rows = x.numel() // D

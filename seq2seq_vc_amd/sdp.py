@@ -92,11 +92,14 @@ class DilatedDepthSeparableConv(nn.Module):
         p = self.dropout_rate if self.training else 0.0
         for blk in self.convs:
             dw, ln1, pw, ln2 = blk[0], blk[2], blk[5], blk[7]
-            if FS._QUEUE_LN:
-                y, xr = FA.dwconv1d_pass(x, dw.weight, dw.bias, dilation=dw.dilation[0])      # xr = x for the residual (one consumer of x)
+            if FS._QUEUE_LN and FS.dw_ln_act_ok(x, dw.weight):                                  # one launch: conv -> LN -> GELU
+                y, xr = FS.dw_ln_act(x, dw.weight, dw.bias, dw.dilation[0], ln1.weight, ln1.bias, ln1.eps, "gelu")
             else:
-                y, xr = FA.dwconv1d(x, dw.weight, dw.bias, dilation=dw.dilation[0]), x
-            y = FS.ln_act(y, ln1.weight, ln1.bias, ln1.eps, "gelu")
+                if FS._QUEUE_LN:
+                    y, xr = FA.dwconv1d_pass(x, dw.weight, dw.bias, dilation=dw.dilation[0])  # xr = x for the residual (one consumer of x)
+                else:
+                    y, xr = FA.dwconv1d(x, dw.weight, dw.bias, dilation=dw.dilation[0]), x
+                y = FS.ln_act(y, ln1.weight, ln1.bias, ln1.eps, "gelu")
             y = Fn.linear(y, pw.weight, pw.bias)
             x = FS.ln_act(y, ln2.weight, ln2.bias, ln2.eps, "gelu", res=xr, lens=lens, T=T, p=p)
         return x

@@ -427,6 +427,45 @@ def sdp_ln_act_expand_mask(dtype):
 
 
 @case
+def dds_half_layer_fused():
+    """gelu(LayerNorm(depthwise_conv(x))) -- the first half of a DDS layer (flow.py:137-160) -- as one forward launch
+    (s2svc_dw_ln_act_fwd) against the two modular launches (bit for bit: the same arithmetic in the same order) and against torch;
+    gradients of x (with a residual pass-through), the convolution's and the LayerNorm's parameters against torch autograd."""
+    from seq2seq_vc_amd.ops import functional_sdp as FS
+    res = []
+    f32 = torch.float32
+    for (B, T, C, ks, dil, seed) in [(16, 64, 384, 3, 1, 1), (16, 64, 384, 3, 3, 2), (16, 64, 384, 3, 9, 3), (3, 37, 192, 3, 27, 4), (2, 5, 256, 5, 2, 5),
+                                      (1, 130, 200, 3, 1, 6)]:
+        x = rnd(B, T, C, seed=seed)
+        w, b = rnd(C, 1, ks, seed=seed + 1, scale=0.3), rnd(C, seed=seed + 2)
+        g, be = 1.0 + rnd(C, seed=seed + 3, scale=0.1), rnd(C, seed=seed + 4, scale=0.1)
+        dy, dr = rnd(B, T, C, seed=seed + 5), rnd(B, T, C, seed=seed + 6)
+        outs = []
+        for fused in (True, False):
+            xs = x.clone().requires_grad_(True)
+            ps = [t.clone().requires_grad_(True) for t in (w, b, g, be)]
+            if fused:
+                y, xr = FS.dw_ln_act(xs, ps[0], ps[1], dil, ps[2], ps[3], 1e-5, "gelu")
+            else:
+                u, xr = FA.dwconv1d_pass(xs, ps[0], ps[1], dilation=dil)
+                y = FS.ln_act(u, ps[2], ps[3], 1e-5, "gelu")
+            torch.autograd.backward([y, xr], [dy, dr])
+            outs.append([y.detach(), xs.grad] + [q.grad for q in ps])
+        names = ["y", "dx", "d conv weight", "d conv bias", "d gamma", "d beta"]
+        for n, a_, b_ in zip(names, outs[0], outs[1]):
+            res.append((bool(torch.equal(a_, b_)), f"dds half layer B{B} T{T} C{C} k{ks} d{dil}: fused {n} == modular bit for bit"))
+        xr_ = x.clone().requires_grad_(True)
+        pr = [t.clone().requires_grad_(True) for t in (w, b, g, be)]
+        ur = F.conv1d(xr_.transpose(1, 2), pr[0], pr[1], padding=(ks * dil - dil) // 2, dilation=dil, groups=C).transpose(1, 2)
+        yr = F.gelu(F.layer_norm(ur, (C,), pr[2], pr[3], 1e-5))
+        torch.autograd.backward([yr, xr_], [dy, dr])
+        for n, a_, b_ in zip(names, outs[0], [yr.detach(), xr_.grad] + [q.grad for q in pr]):
+            sc = max(1.0, float(b_.abs().max()))
+            res.append(check(f"dds half layer B{B} T{T} C{C} k{ks} d{dil}: fused {n} vs torch", a_, b_.reshape(a_.shape), f32, rtol=2e-4, atol=2e-4 * sc))
+    return res
+
+
+@case
 def sdp_rq_spline():
     """Rational-quadratic spline coupling: forward, inverse (round trip) and backward vs the oracle's torch formula."""
     from oracle import models as OM
