@@ -318,8 +318,10 @@ def dominant_kernel_roofline(dtype, iters=100, workload="vtn"):
     Timed with HIP events on the stream the kernel is launched on and rated against the MFMA peak of its dtype."""
     from seq2seq_vc_amd.ops import kernels as K
     peak = BF16_MFMA_PEAK_TFLOPS if dtype == torch.bfloat16 else F32_MFMA_PEAK_TFLOPS
-    if workload == "aasvc":
-        M, N, Kd = 4096, 1536, 1536
+    if workload in ("aasvc", "aasvc_qkv"):
+        # aasvc_qkv: the packed Q|K|V projection of the decoder's relative-position attention (attention.py:262-305; north_star
+        # names the QKV GEMMs): 4096 x 4608 x 1536 = 256 workgroups of 256 x 288 (gemm_8ph_kernel_n96<3>)
+        M, N, Kd = (4096, 1536, 1536) if workload == "aasvc" else (4096, 4608, 1536)
         x = torch.randn(M, Kd, device="cuda").to(dtype)
         w = (torch.randn(N, Kd, device="cuda") * 0.02).to(dtype)
         b = torch.zeros(N, device="cuda")
@@ -346,15 +348,17 @@ def dominant_kernel_roofline(dtype, iters=100, workload="vtn"):
     ach = flops / (ms * 1e-3) / 1e12
     if dtype != torch.bfloat16:
         kernel = "gemm_fast_kernel<float,128,128,32> (exact-fp32 MFMA)"
+    elif workload == "aasvc_qkv":
+        kernel = "gemm_8ph_kernel_n96<3> (bf16, 8 waves, 256x288 tile = one round of 256 workgroups, 3 phases per K tile)"
     elif workload == "aasvc":
         kernel = "gemm_8ph_kernel_128<DENSE> (bf16, 8 waves, 256x128 tile, 2 phases per K tile, LDS-DMA + counted vmcnt)"
     else:
         kernel = "gemm_8ph_kernel_q<CONV2D,4,2> (bf16, 8 waves, 512x128 tile, 4 phases per K tile, LDS-DMA + counted vmcnt)"
     alg_bytes = float((x.numel() + w.numel() + y.numel()) * x.element_size())
     return {"bound": "mfma", "kernel": f"{kernel} {shape}", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-            "traffic": _pmc_traffic(workload) if dtype == torch.bfloat16 else None, "algorithmic_bytes": alg_bytes,
+            "traffic": _pmc_traffic(workload) if dtype == torch.bfloat16 and workload != "aasvc_qkv" else None, "algorithmic_bytes": alg_bytes,
             "avg_launch_us": ms * 1e3, "flops_per_launch": flops, "timed": f"{iters} launches, {timed}, HIP events",
-            "by_time": _by_time(workload) if dtype == torch.bfloat16 else None}
+            "by_time": _by_time(workload) if dtype == torch.bfloat16 and workload != "aasvc_qkv" else None}
 
 
 # =====================================================================================================================
@@ -581,6 +585,9 @@ def bench_aasvc_single(dev, dtype, steps=40, warmup=8, cpu=True, batch=16):
     if not all(v == v and abs(v) < 1e6 for v in lb):
         raise SystemExit(f"bench: non-finite AAS-VC loss {lb}")
     out["roofline"] = dominant_kernel_roofline(dtype, workload="aasvc")
+    if dtype == torch.bfloat16:
+        q = dominant_kernel_roofline(dtype, workload="aasvc_qkv")
+        out["qkv_gemm"] = {k: q[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "flops_per_launch", "timed")}
     if cpu:
         out["cpu_baseline"] = cpu_baseline_aasvc(wl.cpu_batch)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
@@ -798,6 +805,8 @@ def _shape_line(out):
         "aasvc_mel_frames_per_s": _get(out, "aasvc", "value"),
         "aasvc_roofline_frac": _get(out, "aasvc", "roofline", "frac"),
         "aasvc_roofline_kernel_us": _get(out, "aasvc", "roofline", "avg_launch_us"),
+        "aasvc_qkv_gemm_frac": _get(out, "aasvc", "qkv_gemm", "frac"),
+        "aasvc_qkv_gemm_us": _get(out, "aasvc", "qkv_gemm", "avg_launch_us"),
         "aasvc_step_mfma_frac": _get(out, "aasvc", "step_mfma", "frac_of_bf16_peak"),
         "aasvc_cpu_frames_per_s": _get(out, "aasvc", "cpu_baseline", "value"),
         "aasvc_cpu_cores": _get(out, "aasvc", "cpu_baseline", "cores"),
