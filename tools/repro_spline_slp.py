@@ -16,7 +16,8 @@ The shipped library is built with -fno-slp-vectorize -fno-vectorize; this tool b
                seeds and injected flow noise; losses and the flat gradient buffer compared with the first pass.
 
 Variants (--variant): "shipped" (no SLP anywhere), "slp_sdp" (SLP on for sdp.hip only), "slp_all" (SLP on for every source),
-"slp_files" (SLP on for the sources listed in --files: bisection).
+"slp_files" (SLP on for the sources listed in --files: bisection), "slp_sdp_nopk" (SLP on for sdp.hip, packed-fp32 instruction
+selection off: -target-feature -packed-fp32-ops).
 
     python tools/repro_spline_slp.py --variant slp_sdp --mode step --n 300
     python tools/repro_spline_slp.py --variant slp_sdp --mode standalone --n 20000
@@ -50,12 +51,15 @@ def build_variant(variant, files=()):
     for f in sorted(os.listdir(CSRC)):
         if not f.endswith(".hip"):
             continue
-        slp = variant == "slp_all" or (variant == "slp_sdp" and f == "sdp.hip") or (variant == "slp_files" and f in files)
+        slp = variant == "slp_all" or (variant in ("slp_sdp", "slp_sdp_nopk") and f == "sdp.hip") or (variant == "slp_files" and f in files)
         if not slp:
             objs.append(os.path.join(CSRC, "build", f[:-4] + ".o"))          # the shipped object
             continue
         obj = os.path.join(d, f[:-4] + ".o")
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-c", os.path.join(CSRC, f), "-o", obj],
+        # slp_sdp_nopk: the SLP vectoriser stays ON but the target may not select packed-fp32 VALU instructions (v_pk_{mul,fma,add}_f32:
+        # 756 of them in sdp.hip with the feature, 0 without) -- separates "the vectorised IR is wrong" from "the packed instructions are"
+        nopk = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] if variant == "slp_sdp_nopk" else []
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", *nopk, "-c", os.path.join(CSRC, f), "-o", obj],
                        check=True)
         objs.append(obj)
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
@@ -325,7 +329,7 @@ def run_dirty(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="slp_sdp", choices=["shipped", "slp_sdp", "slp_all", "slp_files"])
+    ap.add_argument("--variant", default="slp_sdp", choices=["shipped", "slp_sdp", "slp_sdp_nopk", "slp_all", "slp_files"])
     ap.add_argument("--files", default="", help="slp_files: comma-separated sources built WITH the SLP / loop vectorisers (bisection)")
     ap.add_argument("--mode", default="step", choices=["step", "standalone", "dirty", "trace"])
     ap.add_argument("--n", type=int, default=300)
