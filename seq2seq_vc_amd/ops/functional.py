@@ -456,6 +456,9 @@ def _reduce_to(p_sum, p_dot, mode, dy, x=None, mean=None, rstd=None):
 # ================================================================================================
 # Linear (+bias, +activation)          reference: torch.nn.Linear call sites of the hot path
 # ================================================================================================
+_PAD_ODD_N = os.environ.get("S2SVC_PAD_ODD_N", "1") != "0"      # A/B switch: see _Linear.backward
+
+
 class _Linear(Function):
     """y = act(x W^T + b).  passthrough=True additionally returns an alias of x: a post-LN residual that takes x from there
     sends its gradient back through this node, where it rides in the epilogue of the data-gradient GEMM (dX = dY W + g_pass)
@@ -492,11 +495,20 @@ class _Linear(Function):
         dy2 = _c(dy).view(M, N)
         if ctx.act:
             dy2 = K.act_dropout_bwd(dy2, y, act=ctx.act)
+        ldy, zp, dy_rows = N, False, dy2
+        if _PAD_ODD_N and dtype == torch.float32 and N % 4 and dy2.is_cuda:
+            # rows of N fp32 values with N % 4 != 0 (the 29 spline parameters of a ConvFlow) keep both gradient GEMMs on the
+            # element-wise fallback kernel (19 + 37 us per flow): a zero-padded copy with rows of a whole number of 16-byte vectors
+            # puts them on the vectorised kernels (the pad columns contribute zeros to the reductions and are never stored)
+            ldy, zp = (N + 3) // 4 * 4, True
+            dyp = torch.zeros((M, ldy), dtype=dtype, device=dy2.device)
+            dyp[:, :N] = dy2
+            dy2 = dyp
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
             res = _c(g_pass).view(M, Kd).to(dtype) if g_pass is not None else None
-            K.gemm(K.operand(dy2, N), _dgrad_operand(weight, w, N, Kd, dtype), M, Kd, N, dx, in_dtype=dtype, res=res)
+            K.gemm(K.operand(dy2, ldy, zero_padded=zp), _dgrad_operand(weight, w, N, Kd, dtype), M, Kd, N, dx, in_dtype=dtype, res=res)
             dx = dx.view(ctx.xshape)
         dw = db = None
         if weight.requires_grad:
@@ -504,7 +516,7 @@ class _Linear(Function):
             rs, racc, db = _bias_sink(bias, N)     # bias gradient = row sums of dY^T, fused into the wgrad GEMM
 
             def wr(out, acc):
-                K.gemm(K.operand(dy2, N, layout=K.RC), K.operand(x2, Kd, layout=K.RC), N, Kd, M, out, in_dtype=dtype,
+                K.gemm(K.operand(dy2, ldy, layout=K.RC, zero_padded=zp), K.operand(x2, Kd, layout=K.RC), N, Kd, M, out, in_dtype=dtype,
                        splitk=sk, tile=tile, accumulate=acc, a_rowsum=rs, a_rowsum_accumulate=racc)
             if _slotted(weight, bias if ctx.has_bias else None):
                 _side_run(lambda: _emit_wgrad(weight, (N, Kd), wr), keep=(dy2, x2))
@@ -513,7 +525,7 @@ class _Linear(Function):
                 if dw is not None:
                     dw = dw.view(weight.shape)  # 1x1 Conv1d weights (N, K, 1) are accepted as Linear weights
         elif ctx.has_bias and bias.requires_grad:
-            db, _ = _reduce_to(bias, None, 0, dy2)
+            db, _ = _reduce_to(bias, None, 0, dy_rows)
         return dx, dw, db, None, None
 
 
