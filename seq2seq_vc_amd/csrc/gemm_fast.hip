@@ -357,7 +357,7 @@ extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream) {
   };
   if (!extent_ok(d.A, d.A.layout == S2SVC_LAYOUT_RC ? d.M : d.K)) return 0;
   if (!extent_ok(d.B, d.B.layout == S2SVC_LAYOUT_RC ? d.N : d.K)) return 0;
-  if (d.tile_hint != 0 && d.tile_hint != 64 && d.tile_hint != 128) return 0;
+  if (d.tile_hint != 0 && d.tile_hint != 32 && d.tile_hint != 64 && d.tile_hint != 128) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int splitk = d.splitk > 1 ? d.splitk : 1;
   const int64_t tiles128 = (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1 * splitk;
@@ -375,8 +375,8 @@ extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream) {
     // a quarter of it per workgroup, on four times the workgroups.  Same order of every sum (k ascending), same bits.
     static const bool t32_on = !(getenv("S2SVC_GEMM_F32_T32") && getenv("S2SVC_GEMM_F32_T32")[0] == '0');
     const int64_t tiles64 = (int64_t)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nb0 * d.nb1 * splitk;
-    if (d.dtype == S2S_F32 && t32_on && d.tile_hint == 0 && tiles64 < 128 && d.K >= 128 && d.A.mode == S2SVC_OP_DENSE &&
-        d.B.mode == S2SVC_OP_DENSE && !d.a_rowsum) {
+    const bool t32_ok = d.dtype == S2S_F32 && d.K >= 128 && d.A.mode == S2SVC_OP_DENSE && d.B.mode == S2SVC_OP_DENSE;
+    if (t32_ok && ((t32_on && d.tile_hint == 0 && tiles64 < 128 && !d.a_rowsum) || d.tile_hint == 32)) {      // (hint 32: ops.kernels.plan_gemm)
       dim3 grid((d.N + 31) / 32, (d.M + 31) / 32, d.nb0 * d.nb1 * splitk);
       launch_modes<float, 32, 32, 128>(d, grid, st);
     } else {

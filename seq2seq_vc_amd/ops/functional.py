@@ -512,7 +512,7 @@ class _Linear(Function):
             dx = dx.view(ctx.xshape)
         dw = db = None
         if weight.requires_grad:
-            tile, sk = K.plan_gemm(N, Kd, M)
+            tile, sk = K.plan_gemm(N, Kd, M, dtype=dtype)
             rs, racc, db = _bias_sink(bias, N)     # bias gradient = row sums of dY^T, fused into the wgrad GEMM
 
             def wr(out, acc):
@@ -585,7 +585,7 @@ class _FFNRelu(Function):
             dx = dx.view(xshape)
 
         def wgrad(weight, bias, g, a, n_out, n_in):
-            tile, sk = K.plan_gemm(n_out, n_in, M)
+            tile, sk = K.plan_gemm(n_out, n_in, M, dtype=dtype)
             rs, racc, db = _bias_sink(bias, n_out)
 
             def wr(out, acc):

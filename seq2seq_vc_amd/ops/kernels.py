@@ -112,12 +112,23 @@ def operand(t, ld, layout=KC, mode=DENSE, C=0, T=0, pad=0, T1=0, F1=0, T2=0, F2=
 _MAX_SPLITK = int(os.environ["S2SVC_MAX_SPLITK"]) if "S2SVC_MAX_SPLITK" in os.environ else None   # tuning aid
 
 
-def plan_gemm(M, N, K, nbatch=1, allow_split=True):
+_F32_T32 = os.environ.get("S2SVC_GEMM_F32_T32", "1") != "0"
+
+
+def plan_gemm(M, N, K, nbatch=1, allow_split=True, dtype=None):
     """Tiny cost model -> (tile, splitk) for the MFMA GEMM: estimated time = waves of resident workgroups x
     (k-tiles per workgroup x time per k-tile + fixed), plus the split-K reduction.  Numbers are microseconds
-    fitted to MI355X measurements of this kernel (profiles/)."""
+    fitted to MI355X measurements of this kernel (profiles/).
+    fp32 problems with few output tiles (the duration predictor's 384 x 384 weight gradients over 1024 rows): 32 x 32 tiles
+    (gemm_fast_kernel<float, 32, 32, 128>: the fp32 MFMA makes a 64 x 64 workgroup matrix-pipe bound) and only as much split-K
+    as it takes to reach ~100 workgroups -- 144 unsplit workgroups instead of 36 x 4 + a reduction launch."""
     if _MAX_SPLITK is not None:
         allow_split = allow_split and _MAX_SPLITK > 1
+    if dtype == torch.float32 and _F32_T32 and nbatch == 1 and K >= 256 and ((M + 63) // 64) * ((N + 63) // 64) < 64:
+        tiles32, sk = ((M + 31) // 32) * ((N + 31) // 32), 1
+        while allow_split and tiles32 * sk < 96 and K // (2 * sk) >= 256 and sk < 8:
+            sk *= 2
+        return 32, sk
     if M >= 128 and N >= 128 and ((M + 127) // 128) * ((N + 127) // 128) * nbatch >= 256:
         return 128, 1          # a full wave of 128x128 tiles: measured best for every operand layout (tools/gemm_bench.py --sweep)
     best = None

@@ -1168,6 +1168,13 @@ def gemm_fp32_small_tiles():
                         outs.append(dw)
                     res.append(check(f"fp32 32x32 tiles wgrad {N}x{Kd}x{M} split-K 2", outs[1], (dy.double().t() @ a.double()).float(), f32, rtol=1e-4, atol=1e-4))
                     res.append((bool(torch.equal(outs[0], outs[1])), f"fp32 32x32 tiles wgrad {N}x{Kd}x{M} == 64x64 kernel bit for bit"))
+                    # the tile hint of ops.kernels.plan_gemm (32): unsplit and split, with the fused bias gradient (row sums of dY^T)
+                    for sk in (1, 2):
+                        dw = torch.full((N, Kd), float("nan"), device=DEV)
+                        db = torch.full((N,), float("nan"), device=DEV)
+                        K.gemm(K.operand(dy, N, layout=K.RC), K.operand(a, Kd, layout=K.RC), N, Kd, M, dw, in_dtype=f32, splitk=sk, tile=32, a_rowsum=db)
+                        res.append(check(f"fp32 tile hint 32 wgrad {N}x{Kd}x{M} split-K {sk}", dw, (dy.double().t() @ a.double()).float(), f32, rtol=1e-4, atol=1e-4))
+                        res.append(check(f"fp32 tile hint 32 wgrad {N}x{Kd}x{M} split-K {sk}: fused bias gradient", db, dy.double().sum(0).float(), f32, rtol=1e-4, atol=1e-4))
     finally:
         torch.backends.cuda.matmul.allow_tf32 = prev
     return res
