@@ -16,6 +16,7 @@ from ..ops import kernels as K
 
 
 _HEAD_START = os.environ.get("S2SVC_NO_HEAD_START", "0") != "1"     # A/B switch: the decoder's head on the auxiliary stream
+_PROB_BRANCH = os.environ.get("S2SVC_PROB_BRANCH", "1") != "0"      # A/B switch: the stop-token projection on the auxiliary stream
 
 
 class _ARSeq2Seq(nn.Module):
@@ -129,8 +130,16 @@ class _ARSeq2Seq(nn.Module):
         else:
             zs, _ = self.decoder(Fn.to_compute(ys_in), olens_in_h, hs, hs_lens, causal=True)
         before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, odim)
-        logits = Fn.linear(zs, self.prob_out.weight, self.prob_out.bias).view(zs.size(0), -1)
-        after = Fn.add_dropout(before, self.postnet(before), 0.0) if self.postnet is not None else before
+        if _PROB_BRANCH and self.training and zs.is_cuda and torch.is_grad_enabled() and self.postnet is not None:
+            # the stop-token projection (384 -> r columns: a GEMM with one output column forward, a rank-1 product backward, both on
+            # slow general kernels) beside the Postnet instead of in front of it: the auxiliary stream is idle here, and autograd runs
+            # its backward node there too -- beside the Postnet's backward pass instead of between it and feat_out's
+            (logits,) = Fn.branch_run(lambda: (Fn.linear(zs, self.prob_out.weight, self.prob_out.bias).view(zs.size(0), -1),), uses=(zs,))
+            after = Fn.add_dropout(before, self.postnet(before), 0.0)
+            Fn.branch_join(logits)
+        else:
+            logits = Fn.linear(zs, self.prob_out.weight, self.prob_out.bias).view(zs.size(0), -1)
+            after = Fn.add_dropout(before, self.postnet(before), 0.0) if self.postnet is not None else before
         olens_out = olens
         if r > 1:
             if min(olens_h.host) < r:
