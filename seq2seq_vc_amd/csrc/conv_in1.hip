@@ -194,6 +194,105 @@ __global__ __launch_bounds__(256) void conv_in1_wgrad_vec_kernel(int B, int Tn, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same partial sums on the matrix cores (bf16, no ReLU mask: the consumer's data-gradient GEMM already applied it).
+// conv_in1_wgrad_vec_kernel is VALU-bound: 80 FMAs + unpacking + index arithmetic per 16 bytes of dy -- 64 us for the 122 MB of
+// VTN's dy (1.9 TB/s) as the very LAST kernel of the backward pass.  As a product it is  P[tap, o] = sum_pix xcol[pix, tap] *
+// dy[pix, o]  with 9 taps (+ a column of ones: the bias gradient) padded to the 16 rows of v_mfma_f32_16x16x32_bf16:
+//   * a workgroup walks its pixel chunk in blocks of 32 pixels (the K of one MFMA); the block of dy (32 x O bf16) goes through LDS
+//     (16-byte global loads, padded rows) because a B fragment needs 8 CONSECUTIVE PIXELS of one channel per lane (2-byte LDS reads);
+//   * A fragment: lane (tap = lane & 15, pixel group lane >> 4) gathers its 8 pixels' window values straight from x (L2-resident);
+//   * the four waves split the O / 16 channel groups; accumulators 16 taps x 16 channels per group.
+// Any lane -> k assignment is fine as long as A and B agree (both: pixel 8 (lane >> 4) + j), rows / columns are lane & 15.
+// Partials leave in the layout of the VALU kernel ([chunk][O][10]); conv_in1_wgrad_final_kernel is shared.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 ci_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short ci_u16x8_t;
+typedef __attribute__((ext_vector_type(4))) float ci_f32x4_t;
+
+// blockIdx.y = slice of 64 GPW channels: the LDS block of a slice of 192 channels is 12.5 KB, which still fits beside a 144 KB
+// workgroup of the weight-gradient GEMM that runs next to this kernel at the end of the backward pass (with all 384 channels in
+// one 25 KB block the two could not share a CU: VTN step +0.06 ms although the kernel alone was 15 us faster).
+template <int GPW>        // channel groups (of 16) per wave = 16-byte dy vectors per thread and block: a slice is 64 GPW channels
+__global__ __launch_bounds__(256) void conv_in1_wgrad_mfma_kernel(int B, int Tn, int Fn, int T1, int F1, int Ot,
+                                                                  const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                  float* __restrict__ partial, int pix_per_chunk) {
+  constexpr int O = 64 * GPW, PITCH = O + 8, VPR = O / 8;
+  __shared__ __attribute__((aligned(16))) bf16_t tile[32 * PITCH];
+  const int cbase = blockIdx.y * O;
+  dy += cbase;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kg = lane >> 4;
+  const int64_t npix = (int64_t)B * T1 * F1;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_chunk;
+  const int64_t p1 = (p0 + pix_per_chunk < npix) ? p0 + pix_per_chunk : npix;
+  ci_f32x4_t acc[GPW];
+#pragma unroll
+  for (int g = 0; g < GPW; ++g) acc[g] = (ci_f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const uint32_t mgF = 0xFFFFFFFFu / (uint32_t)F1 + 1u, mgT = 0xFFFFFFFFu / (uint32_t)T1 + 1u;
+  const int kh = n / 3, kw = n - kh * 3;                     // (taps 0 .. 8)
+  // this thread's GPW vectors of a dy block: vector v = tid + 256 i -> (row, 8-channel piece)
+  int vrow[GPW], vcol[GPW];
+#pragma unroll
+  for (int i = 0; i < GPW; ++i) {
+    const int v = tid + 256 * i;
+    vrow[i] = v / VPR;
+    vcol[i] = (v - vrow[i] * VPR) * 8;
+  }
+  uint4 vals[GPW];
+  ci_u16x8_t au;
+  // requests of one block: dy vectors into registers, this lane's tap over its 8 pixels (A fragment)
+#define CI_FETCH(P)                                                                                                          \
+  {                                                                                                                          \
+    const int64_t pb_ = (P);                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < GPW; ++i) {                                                                        \
+      vals[i] = make_uint4(0u, 0u, 0u, 0u);                                                                                  \
+      if (pb_ + vrow[i] < p1) vals[i] = *reinterpret_cast<const uint4*>(dy + (pb_ + vrow[i]) * Ot + vcol[i]);                \
+    }                                                                                                                        \
+    au = (ci_u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};                                                                               \
+    if (n < 10) {                                                                                                            \
+      const int64_t pf_ = pb_ + 8 * kg;                                                                                      \
+      const uint32_t pi_ = (uint32_t)pf_, q_ = __umulhi(pi_, mgF);                                                           \
+      int f1_ = (int)(pi_ - q_ * (uint32_t)F1);                                                                              \
+      int b_ = (int)__umulhi(q_, mgT);                                                                                       \
+      int t1_ = (int)(q_ - (uint32_t)b_ * (uint32_t)T1);                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                        \
+        if (pf_ + j < p1) au[j] = n == 9 ? (unsigned short)0x3f80 : x[((int64_t)b_ * Tn + 2 * t1_ + kh) * Fn + 2 * f1_ + kw]; \
+        if (++f1_ == F1) { f1_ = 0; if (++t1_ == T1) { t1_ = 0; ++b_; } }                                                    \
+      }                                                                                                                      \
+    }                                                                                                                        \
+  }
+  CI_FETCH(p0);
+  for (int64_t p = p0; p < p1; p += 32) {
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) *reinterpret_cast<uint4*>(tile + vrow[i] * PITCH + vcol[i]) = vals[i];
+    const ci_bf16x8_t a = __builtin_bit_cast(ci_bf16x8_t, au);
+    __syncthreads();
+    if (p + 32 < p1) CI_FETCH(p + 32);                       // in flight behind this block's fragment reads and MFMAs
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+      const int ch = (wave * GPW + g) * 16 + n;
+      ci_u16x8_t bu;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bu[j] = tile[(8 * kg + j) * PITCH + ch];
+      acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(ci_bf16x8_t, bu), acc[g], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#undef CI_FETCH
+  // D[row = 4 (lane >> 4) + r (tap), col = lane & 15 (channel)]
+#pragma unroll
+  for (int g = 0; g < GPW; ++g) {
+    const int ch = (wave * GPW + g) * 16 + n;
+    float* out = partial + ((int64_t)blockIdx.x * Ot + cbase + ch) * 10;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tap = 4 * kg + r;
+      if (tap < 10) out[tap] = acc[g][r];
+    }
+  }
+}
+
 // one wavefront per output element: lanes stride over the chunk partials (independent loads), fixed-order wave sum
 __global__ __launch_bounds__(256) void conv_in1_wgrad_final_kernel(int O, int chunks, const float* __restrict__ partial,
                                                                    float* __restrict__ dw, float* __restrict__ db, int accumulate) {
@@ -249,7 +348,18 @@ extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, con
   chunks = (int)((npix + ppc - 1) / ppc);
   hipStream_t st = (hipStream_t)stream;
   const int og = O / 8;
-  if (dtype != S2S_F32 && O % 8 == 0 && og <= 256 && npix * (F1 > T1 ? F1 : T1) < ((int64_t)1 << 32) && F1 >= 2 && T1 >= 2 &&
+  static const bool mfma_on = [] { const char* e = getenv("S2SVC_CONV_IN1_MFMA"); return !(e && e[0] == '0'); }();
+  if (mfma_on && dtype == S2S_BF16 && !y && O % 64 == 0 && npix * (F1 > T1 ? F1 : T1) < ((int64_t)1 << 32) && F1 >= 2 && T1 >= 2 &&
+      (uintptr_t)dy % 16 == 0) {
+    const int gq = O / 64, gpw = gq % 3 == 0 ? 3 : gq % 2 == 0 ? 2 : 1;
+    const dim3 grid((unsigned)chunks, (unsigned)(gq / gpw));
+#define CI_LAUNCH(G) hipLaunchKernelGGL(conv_in1_wgrad_mfma_kernel<G>, grid, dim3(256), 0, st, B, Tn, Fn, T1, F1, O, \
+                                        (const bf16_t*)x, (const bf16_t*)dy, partial, ppc)
+    if (gpw == 3) CI_LAUNCH(3);
+    else if (gpw == 2) CI_LAUNCH(2);
+    else CI_LAUNCH(1);
+#undef CI_LAUNCH
+  } else if (dtype != S2S_F32 && O % 8 == 0 && og <= 256 && npix * (F1 > T1 ? F1 : T1) < ((int64_t)1 << 32) && F1 >= 2 && T1 >= 2 &&
       (uintptr_t)dy % 16 == 0 && (!y || (uintptr_t)y % 16 == 0))
     hipLaunchKernelGGL(conv_in1_wgrad_vec_kernel, dim3(chunks), dim3(256), (size_t)og * 80 * sizeof(float), st, B, Tn, Fn, T1, F1, O,
                        (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, partial, ppc);

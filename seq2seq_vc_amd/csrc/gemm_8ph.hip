@@ -373,6 +373,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
   p8_wait_vmcnt<0>();                  // the zero-block DMAs issued past the end
   __syncthreads();                     // every wave is done with the operand stages: reuse them as fp32 C tiles
   float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+  const bool cmap_lean = KA == P8_TCONV2D && d.tile_hint != 65 && epilogue_cmap_ok(d);      // uniform (tile_hint 65: A/B aid, the general flush)
+  const c_map_t cmq = c_map_make(d);
   // the four 64 x 32 sub-tiles in a ROLLED loop: staging is per sub-tile (constant register indices), the flush code exists once
 #pragma unroll 1
   for (int q = 0; q < 4; ++q) {
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
       default: epilogue_stage<64, 32>(acc[1][1], cs); break;
     }
     if (LEAN) epilogue_flush_common<64, 32>(d, m0 + wr * 128 + (q >> 1) * 64, n0 + wc * 64 + (q & 1) * 32, cs);
+    else if (KA == P8_TCONV2D && cmap_lean) epilogue_flush_cmap<64, 32>(d, cmq, m0 + wr * 128 + (q >> 1) * 64, n0 + wc * 64 + (q & 1) * 32, cs);
     else epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + (q >> 1) * 64, n0 + wc * 64 + (q & 1) * 32, cs, 1, 0, zb);
   }
 }
@@ -480,12 +483,15 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
   p8_wait_vmcnt<0>();
   __syncthreads();
   float* cs = reinterpret_cast<float*>(smem) + wave * (64 * 32);
+  const bool cmap_lean = KA == P8_TCONV2D && d.tile_hint != 65 && epilogue_cmap_ok(d);      // uniform
+  const c_map_t cmq = c_map_make(d);
 #pragma unroll 1
   for (int a = 0; a < 2; ++a) {          // rolled: one copy of the flush code (see epilogue_stage)
     if (a == 0) epilogue_stage<64, 32>(acc[0], cs);
     else epilogue_stage<64, 32>(acc[1], cs);
     if (LEAN == 2) epilogue_flush_swish<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
     else if (LEAN == 1) epilogue_flush_common<64, 32>(d, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);       // (gemm_common.h: a fraction of the code)
+    else if (KA == P8_TCONV2D && cmap_lean) epilogue_flush_cmap<64, 32>(d, cmq, m0 + wr * 128 + a * 64, n0 + wc * 32, cs);
     else epilogue_flush<64, 32>(d, z0, z1, m0 + wr * 128 + a * 64, n0 + wc * 32, cs, 1, 0, zb);
   }
 }
@@ -1005,13 +1011,21 @@ struct w8_prob {
   float* rs_ws;                  // nchunks > 1 and rowsum: [nchunks][M]
   int32_t lda, ldb, ldc, M, N, K;
   int32_t tiles_m, tiles_n, nchunks, kt_chunk;
-  int32_t flags;                 // bit 0: accumulate into C, bit 1: accumulate into rowsum
+  int32_t flags;                 // bit 0: accumulate into C, bit 1: accumulate into rowsum, bit 2: B is the implicit im2col operand `cv`
   int32_t reserved_;
+};
+// B as the implicit im2col matrix of a Conv2d 3x3 stride 2 (S2SVC_OP_CONV2D_S2, row-contiguous): reduction row k = output pixel
+// (b, t2, f2), column n = tap * C + c  ->  x[b, 2 t2 + tap / 3, 2 f2 + tap % 3, c] (ld = q.ldb elements per input pixel).  C % 128 == 0, so
+// the 128 columns of a tile lie inside ONE tap: a loader lane's four source rows are four pixels, decomposed per K tile by two
+// multiply-high divisions each.  One geometry per launch (a Conv2d weight gradient is launched on its own).
+struct w8_conv {
+  int32_t T1, F1, T2, F2, C, reserved_;
 };
 struct w8_args {
   w8_prob p[W8_MAX];
   int32_t unit_start[W8_MAX + 1];
   int32_t n, total;
+  w8_conv cv;
 };
 static_assert(sizeof(w8_prob) == 96, "w8_prob layout");
 static_assert(sizeof(w8_args) <= 4096, "kernel arguments are limited to 4 KB");
@@ -1055,7 +1069,7 @@ __device__ __forceinline__ void w8_flush(const w8_prob& q, int chunk, int m_base
 // (p8_tr_tile); a variant with four sub-phases and the next sub-phase's fragments requested ahead of the MFMAs needs 12 registers
 // more than the 168 that three waves per SIMD allow (spills: slower with the row sums, +3 % without) -- not kept.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile_n, int chunk, char* smem) {
+__device__ __forceinline__ void w8ls_tile(const w8_prob& q, const w8_conv& cv, int tile_m, int tile_n, int chunk, char* smem) {
   constexpr int UNIT = 16384, BUF = 3 * UNIT, NS = 3;    // A.m0 | A.m1 | B per stage
   const int m0 = tile_m * 256, n0 = tile_n * 128;
   const int ktiles = (q.K + 63) >> 6;
@@ -1087,6 +1101,20 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile
       okB[i] = n0 + ur < q.N;
       offB[i] = (uint32_t)(((int64_t)kin[i] * q.ldb + n0 + ur) * 2);
     }
+    // implicit im2col B (flags bit 2): the tile's tap and first channel; source pixel of reduction row p decomposed per K tile
+    const bool convB = (q.flags & 4) != 0;               // uniform
+    const fastdiv_t dv_pb = fastdiv_make(convB ? cv.T2 * cv.F2 : 1), dv_f = fastdiv_make(convB ? cv.F2 : 1);
+    uint32_t colB[4] = {0u, 0u, 0u, 0u};
+    if (convB) {
+      const int tap = n0 / cv.C, c0 = n0 - tap * cv.C, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int kk, ur;
+        p8_tr_src(lw * 4 + i, lane, kk, ur);
+        colB[i] = (uint32_t)((((int64_t)kh * cv.F1 + kw) * q.ldb + c0 + ur) * 2);
+      }
+    }
+    const char* Bx = reinterpret_cast<const char*>(q.B);
     const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
     // the 12 DMA instructions of this loader for chunk-relative K tile T into stage T % 3
 #define W8LS_ISSUE(T)                                                                                                         \
@@ -1101,6 +1129,12 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, int tile_m, int tile
         const char* s0_ = (okA[0][i] && kok_) ? ab_ + offA[0][i] : z;                                                         \
         const char* s1_ = (okA[1][i] && kok_) ? ab_ + offA[1][i] : z;                                                         \
         const char* s2_ = (okB[i] && kok_) ? bb_ + offB[i] : z;                                                               \
+        if (convB && okB[i] && kok_) {                                                                                       \
+          const int p_ = (kt0 + tt_) * 64 + kin[i];                                                                           \
+          const int b_ = fastdiv(p_, dv_pb), r_ = p_ - b_ * (int)dv_pb.d;                                                     \
+          const int t2_ = fastdiv(r_, dv_f), f2_ = r_ - t2_ * (int)dv_f.d;                                                    \
+          s2_ = Bx + ((int64_t)(b_ * cv.T1 + 2 * t2_) * cv.F1 + 2 * f2_) * q.ldb * 2 + colB[i];                               \
+        }                                                                                                                     \
         __builtin_amdgcn_global_load_lds((gbl_void*)s0_, (lds_void*)(st_ + 0 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
         __builtin_amdgcn_global_load_lds((gbl_void*)s1_, (lds_void*)(st_ + 1 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
         __builtin_amdgcn_global_load_lds((gbl_void*)s2_, (lds_void*)(st_ + 2 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
@@ -1236,7 +1270,7 @@ __global__ __launch_bounds__(768) void gemm_w8ls_kernel(const w8_args g) {
     const int chunk = r / per_chunk;
     r -= chunk * per_chunk;
     const int tile_m = r / q.tiles_n;
-    w8ls_tile(q, tile_m, r - tile_m * q.tiles_n, chunk, smem);
+    w8ls_tile(q, g.cv, tile_m, r - tile_m * q.tiles_n, chunk, smem);
   }
 }
 
@@ -1425,6 +1459,10 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   else if (d.M >= 2048 && t512 >= 160 && t512 <= 256) geo = 2;
   else if (t128 >= p8_min_tiles()) geo = 3;
   if (p8_force_bn() >= 1 && p8_force_bn() <= 3) geo = p8_force_bn();
+  if (d.A.mode == S2SVC_OP_TCONV2D_S2) {       // S2SVC_TCONV_GEO=1|2|3: tile geometry of the transposed-convolution classes only (A/B aid)
+    static const int tg = [] { const char* e = getenv("S2SVC_TCONV_GEO"); return e ? atoi(e) : 0; }();
+    if (tg >= 1 && tg <= 3) geo = tg;
+  }
   hipStream_t st = (hipStream_t)stream;
   // 256 x 96 PH tiles where they fit the chip in ONE round and the geometry above does not (gemm_8ph_kernel_n96)
   if (d.A.mode == S2SVC_OP_DENSE && nb == 1 && mode == 1 && (p8_force_bn() == 0 || p8_n96_mode() >= 2) && epilogue_common_ok(d)) {
@@ -1529,8 +1567,16 @@ int w8_kt_chunk_env() {   // S2SVC_W8_KT_CHUNK / s2svc_gemm_set_w8: K tiles (of 
 // are cut by K.  Chunk length 64 K tiles (4096 rows): measured in the steps -- VTN's 2016 / 2048-row reductions are one chunk at 32 or 64
 // (3.80 ms either way; 16 / 8 / 4: 3.87 / 3.94 / 4.10), AAS-VC's 4096-row reductions run unsplit at 64 (11.47 vs 11.68 ms at 32: no
 // partial tiles, no reduction launch; 128: the same)
-void w8_chunks(int M, int N, int K, int& nchunks, int& kt_chunk) {
+void w8_chunks(int M, int N, int K, int& nchunks, int& kt_chunk, bool conv = false) {
   const int ktiles = (K + 63) / 64;
+  if (conv) {       // the Conv2d weight gradient: a long reduction (tens of thousands of pixels) over ~50 tiles.  VTN's 384 x 3456 over 38304
+    // pixels, stand-alone: chunks of 64 / 75 / 86 / 100 / 120 / 150 / 200 K tiles = 182 / 145 / 165 / 184 / 201 / 153 / 196 us (the 4-wave split-K
+    // kernel: 152); the VTN step is the same for all of them (3.65-3.67 ms) -- 75, S2SVC_W8_CONV_KT overrides
+    static const int ck = [] { const char* e = getenv("S2SVC_W8_CONV_KT"); return e ? atoi(e) : 75; }();
+    kt_chunk = ck < 1 ? 1 : ck;
+    nchunks = (ktiles + kt_chunk - 1) / kt_chunk;
+    return;
+  }
   if ((int64_t)((M + 255) / 256) * ((N + 127) / 128) >= 64) {
     nchunks = 1;
     kt_chunk = ktiles;
@@ -1546,10 +1592,21 @@ void w8_chunks(int M, int N, int K, int& nchunks, int& kt_chunk) {
 bool w8_ok(const s2svc_gemm_desc& d) {
   if (p8_mode() == 0 || !p8_tr_mode() || !w8_mode()) return false;
   if (d.dtype != S2S_BF16 || d.c_dtype != S2S_F32 || d.nb0 * d.nb1 != 1 || d.splitk > 1) return false;
-  if (d.A.layout != S2SVC_LAYOUT_RC || d.B.layout != S2SVC_LAYOUT_RC || d.A.mode != S2SVC_OP_DENSE || d.B.mode != S2SVC_OP_DENSE) return false;
+  if (d.A.layout != S2SVC_LAYOUT_RC || d.B.layout != S2SVC_LAYOUT_RC || d.A.mode != S2SVC_OP_DENSE) return false;
+  const bool convB = d.B.mode == S2SVC_OP_CONV2D_S2;         // the Conv2d 3x3 stride 2 weight gradient: B = implicit im2col of the layer's input
+  if (d.B.mode != S2SVC_OP_DENSE && !convB) return false;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.M % 8 || d.N % 8) return false;
-  if (((uintptr_t)d.A.ptr) % 16 || ((uintptr_t)d.B.ptr) % 16 || d.A.ld % 8 || d.B.ld % 8 || d.A.ld < d.M || d.B.ld < d.N) return false;
-  if ((int64_t)64 * d.A.ld * 2 + (int64_t)d.M * 2 >= (1ll << 32) || (int64_t)64 * d.B.ld * 2 + (int64_t)d.N * 2 >= (1ll << 32)) return false;
+  if (((uintptr_t)d.A.ptr) % 16 || ((uintptr_t)d.B.ptr) % 16 || d.A.ld % 8 || d.B.ld % 8 || d.A.ld < d.M) return false;
+  if ((int64_t)64 * d.A.ld * 2 + (int64_t)d.M * 2 >= (1ll << 32)) return false;
+  if (convB) {
+    static const bool conv_on = !getenv_off("S2SVC_W8_CONV");
+    if (!conv_on || d.B.C < 128 || d.B.C % 128 || d.N != 9 * d.B.C || d.B.ld < d.B.C) return false;
+    if (d.B.T1 <= 0 || d.B.F1 <= 0 || d.B.T2 <= 0 || d.B.F2 <= 0 || 2 * (d.B.T2 - 1) + 3 > d.B.T1 || 2 * (d.B.F2 - 1) + 3 > d.B.F1) return false;
+    if (d.K % (d.B.T2 * d.B.F2)) return false;               // whole images
+    if ((int64_t)(d.K + 64) * (d.B.T2 * d.B.F2) >= (1ll << 32)) return false;       // the multiply-high divisions are exact below that
+  } else {
+    if (d.B.ld < d.N || (int64_t)64 * d.B.ld * 2 + (int64_t)d.N * 2 >= (1ll << 32)) return false;
+  }
   if (((uintptr_t)d.C) % 16 || d.ldc % 4 || d.ldc < d.N) return false;
   if (d.bias || d.res || d.act != S2S_ACT_NONE || d.alpha != 1.0f || d.emask || d.drop_p > 0.f || d.c_map || d.c_pre) return false;
   // the exact-256 problems with >= 64 tiles of 128 x 128 (AAS-VC's decoder) ran on p8_tr_tile / p8_tr_tile_q until the loader-
@@ -1560,7 +1617,7 @@ bool w8_ok(const s2svc_gemm_desc& d) {
 }
 int64_t w8_ws_floats(const s2svc_gemm_desc& d) {
   int nc, kc;
-  w8_chunks(d.M, d.N, d.K, nc, kc);
+  w8_chunks(d.M, d.N, d.K, nc, kc, d.B.mode == S2SVC_OP_CONV2D_S2);
   if (nc <= 1) return 0;
   int64_t f = (int64_t)nc * d.M * d.N;
   if (d.a_rowsum) f += (((int64_t)nc * d.M + 3) / 4) * 4;
@@ -1608,7 +1665,7 @@ extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, 
     w8_args g;
     std::memset(&g, 0, sizeof(g));
     int64_t total = 0;
-    bool any_split = false;
+    bool any_split = false, have_cv = false;
     for (int i = 0; i < cnt; ++i) {
       const s2svc_gemm_desc& d = descs[i0 + i];
       S2S_REQUIRE(w8_ok(d), "gemm_wgrad_grouped: a descriptor is not eligible (check s2svc_gemm_wgrad_ok first)");
@@ -1618,9 +1675,16 @@ extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, 
       q.M = d.M; q.N = d.N; q.K = d.K;
       q.tiles_m = (d.M + 255) / 256; q.tiles_n = (d.N + 127) / 128;
       int nc, kc;
-      w8_chunks(d.M, d.N, d.K, nc, kc);
+      w8_chunks(d.M, d.N, d.K, nc, kc, d.B.mode == S2SVC_OP_CONV2D_S2);
       q.nchunks = nc; q.kt_chunk = kc;
       q.flags = (d.accumulate ? 1 : 0) | (d.a_rowsum_accumulate ? 2 : 0);
+      if (d.B.mode == S2SVC_OP_CONV2D_S2) {
+        const w8_conv cv = {d.B.T1, d.B.F1, d.B.T2, d.B.F2, d.B.C, 0};
+        S2S_REQUIRE(!have_cv || std::memcmp(&cv, &g.cv, sizeof(cv)) == 0, "gemm_wgrad_grouped: one Conv2d geometry per launch");
+        g.cv = cv;
+        have_cv = true;
+        q.flags |= 4;
+      }
       if (nc > 1) {
         S2S_REQUIRE(ws != nullptr && ((uintptr_t)ws) % 16 == 0, "gemm_wgrad_grouped: split reductions need a 16-byte aligned workspace");
         any_split = true;
@@ -1639,7 +1703,14 @@ extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, 
     hipLaunchKernelGGL(gemm_w8ls_kernel, dim3(wgs), dim3(768), 0, st, g);
     S2S_CHECK_LAUNCH("gemm_w8ls_kernel");
     if (any_split) {
-      hipLaunchKernelGGL(w8_reduce_kernel, dim3(48, (unsigned)cnt), dim3(256), 0, st, g);
+      // (grid.x only schedules: every output is summed by one thread in chunk order) -- more workgroups for big split outputs
+      // (the Conv2d weight gradient: 1.3 M outputs x 10 chunks)
+      int64_t big4 = 0;
+      for (int i = 0; i < cnt; ++i)
+        if (g.p[i].nchunks > 1 && (int64_t)g.p[i].M * g.p[i].N / 4 > big4) big4 = (int64_t)g.p[i].M * g.p[i].N / 4;
+      unsigned gx = big4 >= (1 << 18) ? (unsigned)(big4 / (256 * 4)) : 48u;
+      if (gx > 512) gx = 512;
+      hipLaunchKernelGGL(w8_reduce_kernel, dim3(gx, (unsigned)cnt), dim3(256), 0, st, g);
       S2S_CHECK_LAUNCH("w8_reduce_kernel");
     }
   }

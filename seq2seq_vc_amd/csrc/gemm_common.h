@@ -275,6 +275,58 @@ __device__ __forceinline__ void epilogue_flush(const s2svc_gemm_desc& d, int z0,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The ROW-MAPPED epilogue of the transposed-convolution classes (Conv2d data gradient: gemm_8ph.hip P8_TCONV2D): c_map rows, an
+// optional ReLU mask with C's row layout, bf16 C, nothing else.  The general flush loads the mask inside its rolled row loop --
+// a dependent trip to HBM per pass, 16 per wave of the 512 x 128 tile; its "fixed" cost was 30 us per class launch (6 K tiles: 38.7 us
+// stand-alone; the four classes 223 us with the mask against 164 without).  Here the passes of a sub-tile are unrolled and all of
+// their mask vectors are requested BEFORE the accumulators are read back from LDS: one exposed trip per sub-tile.
+// ---------------------------------------------------------------------------------------------------------
+__host__ __device__ inline bool epilogue_cmap_ok(const s2svc_gemm_desc& d) {
+  if (!d.c_map || d.c_dtype != S2S_BF16 || d.nb0 * d.nb1 != 1 || d.splitk > 1 || d.alpha != 1.0f || d.c_pre || d.accumulate) return false;
+  if (d.bias || d.res || d.act != S2S_ACT_NONE || d.drop_p > 0.f) return false;
+  if (d.emask && (d.emask_mode != 0 || d.ldm != d.ldc)) return false;
+  if (d.N % 8 || d.ldc % 8 || ((uintptr_t)d.C) % 16 || (d.emask && ((uintptr_t)d.emask) % 16)) return false;
+  return true;
+}
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void epilogue_flush_cmap(const s2svc_gemm_desc& d, const c_map_t& cm, int m_base, int n_base, const float* cs) {
+  const int lane = threadIdx.x & 63;
+  constexpr int LPR = WTN / 8, RPP = 64 / LPR, NP = WTM / RPP;
+  const int col = (lane % LPR) * 8, n = n_base + col;
+  if (n >= d.N) return;
+  int64_t off[NP];
+  uint4 ev[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int m = m_base + p * RPP + lane / LPR;
+    off[p] = m < d.M ? c_row_fast(d, cm, m) * d.ldc + n : -1;
+    ev[p] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    if (d.emask && off[p] >= 0) ev[p] = *reinterpret_cast<const uint4*>((const bf16_t*)d.emask + off[p]);
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (off[p] < 0) continue;
+    const int row = p * RPP + lane / LPR;
+    const float* src = cs + row * WTN + (col ^ (((row >> 2) & (WTN / 16 - 1)) << 4));
+    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const uint32_t w[4] = {ev[p].x, ev[p].y, ev[p].z, ev[p].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = __uint_as_float(w[e] << 16) > 0.f ? v[2 * e] : 0.f;
+      v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u) > 0.f ? v[2 * e + 1] : 0.f;
+    }
+    uint4 o;
+    o.x = f2bf2(v[0], v[1]);
+    o.y = f2bf2(v[2], v[3]);
+    o.z = f2bf2(v[4], v[5]);
+    o.w = f2bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>((bf16_t*)d.C + off[p]) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The COMMON epilogue: what the Linear layers of the training chains use and nothing else -- bias, ReLU, dropout, a ReLU mask
 // (emask mode 0), a residual, bf16 C, one problem (no batch, split-K, alpha, pre-activation output, row map, accumulation,
 // fp32 C, unaligned tails).  Same arithmetic and the same masks as epilogue_flush.  Why a second copy: the general flush carries

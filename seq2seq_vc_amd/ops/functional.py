@@ -1322,6 +1322,9 @@ _TCONV_GROUP = os.environ.get("S2SVC_TCONV_GROUP", "0") == "1"     # one grid fo
 #                                                                    (189 vs 190 us), so the plain launches stay the default
 
 
+_CONV_WGRAD_W8 = os.environ.get("S2SVC_CONV_WGRAD_W8", "1") != "0"      # A/B switch
+
+
 class _Conv2dS2(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, grad_premasked=False, input_is_relu=False):
@@ -1357,9 +1360,11 @@ class _Conv2dS2(Function):
                 dwp = torch.empty((O, 9 * C), dtype=torch.float32, device=x.device)
                 rs, racc, dbv = _bias_sink(bias, O)
                 tile, sk = K.plan_gemm(O, 9 * C, M2)
+                # bf16, C % 128 == 0: the ragged 8-wave weight-gradient kernel with the implicit im2col B operand (wgrad=True;
+                # csrc/gemm_8ph.hip "w8_conv"), otherwise the 4-wave split-K kernel
                 K.gemm(K.operand(dy, O, layout=K.RC),
                        K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M2, dwp,
-                       in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc)
+                       in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc, wgrad=_CONV_WGRAD_W8)
                 dwt = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32)
                 return _emit_vgrad(weight, dwt), dbv
             if _slotted(weight, bias):
@@ -1446,6 +1451,10 @@ def conv_in1_relu(x, weight, bias, grad_premasked=False):
     return _ConvIn1.apply(x, weight, bias, grad_premasked)
 
 
+_FC_DGRAD_T = os.environ.get("S2SVC_FC_DGRAD_T", "1") != "0"       # A/B switches (profiles/AB_LOG.md, round 5 part 3)
+_FC_WGRAD_W8 = os.environ.get("S2SVC_FC_WGRAD_W8", "1") != "0"
+
+
 class _LinearPermuted(Function):
     """y = x2d . Wp^T + b where Wp[d, f*C + c] = W[d, c*F + f]: the Linear after the conv2d front-end
     (subsampling.py:64-70 flattens (c, f); our activations are (f, c) channel-last)."""
@@ -1478,8 +1487,15 @@ class _LinearPermuted(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=x.device)
-            K.gemm(K.operand(dy, D), K.operand(wp, Kd, layout=K.RC), M, Kd, D, dx, in_dtype=dtype,
-                   emask=x.view(M, Kd) if ctx.input_is_relu else None)      # x = relu(u): hand back dL/du
+            mask = x.view(M, Kd) if ctx.input_is_relu else None              # x = relu(u): hand back dL/du
+            if _FC_DGRAD_T and dtype == torch.bfloat16:
+                # the permuted weight once more, TRANSPOSED ((f, c) rows of D values: a cached copy the optimiser keeps fresh):
+                # both operands K-contiguous, so the 2016 x 7296 x 384 product runs on the 8-wave kernel instead of the 4-wave
+                # kernel's transposing fragment reads (65 -> ~25 us at the end of VTN's backward chain)
+                wd = K.gather3_cached(weight, (Fd, C, D), (1, Fd, C * Fd), 0, dtype)
+                K.gemm(K.operand(dy, D), K.operand(wd, D), M, Kd, D, dx, in_dtype=dtype, emask=mask)
+            else:
+                K.gemm(K.operand(dy, D), K.operand(wp, Kd, layout=K.RC), M, Kd, D, dx, in_dtype=dtype, emask=mask)
             dx = dx.view(x.shape)
         dw = db = None
         if weight.requires_grad:
@@ -1488,7 +1504,7 @@ class _LinearPermuted(Function):
                 rs, racc, dbv = _bias_sink(bias, D)
                 tile, sk = K.plan_gemm(D, Kd, M)
                 K.gemm(K.operand(dy, D, layout=K.RC), K.operand(x, Kd, layout=K.RC), D, Kd, M, dwp, in_dtype=dtype,
-                       splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc)
+                       splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc, wgrad=_FC_WGRAD_W8)
                 dwt = K.gather3(dwp, (D, C, Fd), (Kd, 1, C), 0, torch.float32)
                 return _emit_vgrad(weight, dwt), dbv
             if _slotted(weight, bias):

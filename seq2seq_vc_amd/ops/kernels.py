@@ -202,12 +202,14 @@ def _audit_write(what, *ptrs, st=None):
 def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=None, alpha=1.0, nb0=1, nb1=1,
          ldc=None, cbs=(0, 0), rbs=(0, 0), out_offset=0, splitk=1, accumulate=False, a_rowsum=None,
          a_rowsum_accumulate=False, tile=0, emask=None, drop_p=0.0, seed=(None, 0), c_map=None, group=None, pre_out=None,
-         emask_mode=0):
+         emask_mode=0, wgrad=False):
     """C = act(alpha * A.B^T + bias) [* dropmask] [* (emask > 0)] + res   (see s2svc_gemm in include/s2svc_hip.h).
     c_map = (T1, F1, Tc, Fc, pt, pf): GEMM row (b, i, j) of the Tc x Fc class grid goes to row (b, 2i+pt, 2j+pf) of C.
     group = list: the descriptor is appended instead of launched (launch_group() runs the list as one grid).
     pre_out: a tensor like `out` that receives alpha * A.B^T + bias BEFORE the activation (Swish backward needs it);
-    emask_mode = 1: the stage multiplies by swish'(emask) (emask = that pre-activation) instead of masking by emask > 0."""
+    emask_mode = 1: the stage multiplies by swish'(emask) (emask = that pre-activation) instead of masking by emask > 0.
+    wgrad=True: a weight gradient into a TEMPORARY (no accumulation) takes the ragged 8-wave weight-gradient kernel as well
+    when its descriptor is eligible (dense row-contiguous bf16 operands, fp32 C) -- launched at once, never queued."""
     d = _lib.GemmDesc()
     if pre_out is not None:
         if c_map is not None or pre_out.dtype != out.dtype or pre_out.shape != out.shape or not pre_out.is_contiguous():
@@ -264,7 +266,7 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
             _RECORDER.append(d)
             return out
         d.splitk, d.a_rowsum = splitk, None
-    if accumulate and in_dtype == torch.bfloat16 and group is None:
+    if (accumulate or wgrad) and in_dtype == torch.bfloat16 and group is None:
         # a weight gradient launched on its own (no batch is being recorded: immediate mode): the same kernel, chunking and sums as in a
         # grouped launch (csrc/gemm_8ph.hip "W8") -- WHICH kernel a problem gets depends on its descriptor only
         d.splitk, d.ws = 1, None
@@ -274,7 +276,7 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
         if _lib.lib().s2svc_gemm_wgrad_ok(ctypes.addressof(d)):
             if _Audit.on:
                 _audit_write("weight gradient (W8)", d.C, d.a_rowsum if a_rowsum_accumulate else None)
-            launch_wgrad_group([d])
+            launch_wgrad_group([d], capped=accumulate)
             return out
         d.splitk, d.a_rowsum = splitk, None
     ws = None
@@ -390,14 +392,15 @@ def get_wgrad_cap():
     return _W8_CAP[0]
 
 
-def launch_wgrad_group(descs):
+def launch_wgrad_group(descs, capped=True):
     """The listed weight-gradient problems (every one s2svc_gemm_wgrad_ok) on the ragged 8-wave kernel, one grid per <= 40 of
-    them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`)."""
+    them (+ one reduction launch when a reduction is long enough to be cut into chunks: its partial tiles go through `ws`).
+    capped=False: a chip-filling problem launched on its own (the front-end's Conv2d / Linear weight gradients) ignores the cap."""
     L = _lib.lib()
     arr = (_lib.GemmDesc * len(descs))(*descs)
     nws = L.s2svc_gemm_wgrad_ws_floats(ctypes.addressof(arr), len(descs))
     ws = torch.empty(nws, dtype=torch.float32, device=torch.cuda.current_device()) if nws else None
-    if _W8_CAP[0] > 0:        # forked gradient batches: a capped grid leaves CUs to the chain the launch runs beside (set_wgrad_cap)
+    if capped and _W8_CAP[0] > 0:        # forked gradient batches: a capped grid leaves CUs to the chain the launch runs beside (set_wgrad_cap)
         _lib.check(L.s2svc_gemm_wgrad_grouped_bg(ctypes.addressof(arr), len(descs), ptr(ws), stream(), _W8_CAP[0]),
                    "s2svc_gemm_wgrad_grouped_bg")
         return
@@ -978,10 +981,13 @@ def conv_in1_fwd(x, w, bias):
     return y
 
 
+_CI_CHUNKS = int(os.environ.get("S2SVC_CONV_IN1_CHUNKS", "512"))       # tuning aid
+
+
 def conv_in1_wgrad(x, dy, dw, db, accumulate, y=None):
     B, T, Fd = x.shape
     O = dy.shape[-1]
-    chunks = 512
+    chunks = _CI_CHUNKS
     partial = torch.empty(chunks * O * 10, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().s2svc_conv_in1_wgrad(dt(x), B, T, Fd, O, ptr(x), ptr(dy), ptr(y), ptr(dw), ptr(db), 1 if accumulate else 0,
                                                ptr(partial), chunks, stream()), "conv_in1_wgrad")

@@ -480,6 +480,37 @@ def gemm_conv2d_dma_addressing():
 
 
 @case
+def conv2d_wgrad_on_w8():
+    """Conv2d 3x3 stride 2 weight gradient on the ragged 8-wave weight-gradient kernel (implicit im2col B operand, C % 128 == 0):
+    multi-chunk reductions (K tiles beyond one chunk), a reduction that ends inside a K tile, ragged O, bias row sums -- against
+    fp32 torch and against the 4-wave split-K kernel on the same operands."""
+    res = []
+    dtype = torch.bfloat16
+    for (B, T1, F1, C, O, seed) in [(2, 127, 39, 128, 72, 1), (5, 127, 39, 384, 384, 2), (3, 33, 21, 256, 200, 3), (1, 9, 7, 128, 64, 4)]:
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        M2 = B * T2 * F2
+        x = rnd(B, T1, F1, C, seed=seed, dtype=dtype)
+        dy = rnd(B, T2, F2, O, seed=seed + 20, dtype=dtype)
+        wr = torch.zeros(O, C, 3, 3, device=DEV, requires_grad=True)
+        yr = F.conv2d(x.float().permute(0, 3, 1, 2), wr, None, stride=2)
+        yr.backward(dy.float().permute(0, 3, 1, 2))
+        dbr = dy.float().sum((0, 1, 2))
+        tag = f"B{B} {T1}x{F1} C{C} O{O}"
+        outs = []
+        for w8 in (True, False):
+            dwp = torch.full((O, 9 * C), 7.0, dtype=torch.float32, device=DEV)      # (not accumulated into: the fill must vanish)
+            db = torch.full((O,), 3.0, dtype=torch.float32, device=DEV)
+            K.gemm(K.operand(dy, O, layout=K.RC), K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O,
+                   9 * C, M2, dwp, in_dtype=dtype, splitk=1, a_rowsum=db, a_rowsum_accumulate=False, wgrad=w8)
+            dw = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32).view(O, C, 3, 3)
+            sc = max(float(wr.grad.abs().max()), 1.0)
+            res.append(check(f"conv2d wgrad w8={int(w8)} {tag}", dw, wr.grad, torch.float32, rtol=1e-4, atol=2e-4 * sc))
+            res.append(check(f"conv2d wgrad w8={int(w8)} {tag} bias", db, dbr, torch.float32, rtol=1e-4, atol=2e-4 * max(float(dbr.abs().max()), 1.0)))
+            outs.append(dw)
+    return res
+
+
+@case
 def conv2d_dgrad_transposed():
     """Data gradient of the 3x3 stride-2 Conv2d as four implicit transposed-convolution GEMMs (one per parity class of
     input pixels, stored through the c_map) vs torch's conv2d input gradient and vs the dcols GEMM + col2im path, for
@@ -573,6 +604,44 @@ def conv2d_subsampling_frontend():
     res.append(check("frontend fwd[fp32]", y, yr, dtype))
     for n, a_, r in zip(["conv0.w", "conv0.b", "conv2.w", "conv2.b", "out.w", "out.b"], got, ws):
         res.append(check(f"frontend d{n}[fp32]", a_, r.grad, dtype, rtol=1e-4, atol=2e-5 * max(float(r.grad.abs().max()), 1.0)))
+    return res
+
+
+@case
+def linear_fc_permuted_backward_bf16():
+    """The Linear behind the Conv2d front-end (subsampling.py:64-70) at VTN's width, bf16: forward, data gradient (with relu' of the
+    input in the epilogue) and weight / bias gradients against fp32 math on the same stored operands -- on the default kernels
+    (transposed permuted weight copy on the 8-wave kernel; weight gradient on the ragged 8-wave kernel) and with both switched off."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    res = []
+    dtype = torch.bfloat16
+    for (M, C, Fd, D, seed) in [(2016, 384, 19, 384, 1), (300, 64, 19, 256, 2)]:
+        x = torch.relu(rnd(M, Fd * C, seed=seed, dtype=dtype))                       # (f, c) channel-last columns
+        w0 = rnd(D, C * Fd, seed=seed + 1, scale=0.02)
+        b0 = rnd(D, seed=seed + 2, scale=0.1)
+        dy = rnd(M, D, seed=seed + 3, dtype=dtype)
+        wq = w0.to(dtype).float()
+        wperm = wq.view(D, C, Fd).permute(0, 2, 1).reshape(D, Fd * C)               # columns in (f, c) order
+        yr = x.float() @ wperm.t() + b0
+        dxr = (dy.float() @ wperm) * (x.float() > 0)
+        dwr = (dy.float().t() @ x.float()).view(D, Fd, C).permute(0, 2, 1).reshape(D, C * Fd)
+        dbr = dy.float().sum(0)
+        saved = (Fn._FC_DGRAD_T, Fn._FC_WGRAD_W8)
+        try:
+            for dg, wg in ((True, True), (False, False)):
+                Fn._FC_DGRAD_T, Fn._FC_WGRAD_W8 = dg, wg
+                xx = x.clone().requires_grad_(True)
+                w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+                y = Fn.linear_fc_permuted(xx, w, b, C, Fd, input_is_relu=True)
+                y.backward(dy)
+                tag = f"fc_permuted[bf16] M{M} C{C} D{D} dgradT={int(dg)} w8={int(wg)}"
+                res.append(check(f"{tag} fwd", y, yr, dtype))
+                res.append(check(f"{tag} dx", xx.grad, dxr, dtype))
+                sc = max(float(dwr.abs().max()), 1.0)
+                res.append(check(f"{tag} dw", w.grad, dwr, torch.float32, rtol=1e-4, atol=2e-4 * sc))
+                res.append(check(f"{tag} db", b.grad, dbr, torch.float32, rtol=1e-4, atol=2e-4 * max(float(dbr.abs().max()), 1.0)))
+        finally:
+            Fn._FC_DGRAD_T, Fn._FC_WGRAD_W8 = saved
     return res
 
 
