@@ -36,7 +36,7 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 
 __device__ __attribute__((aligned(16))) uint4 g_zero16_8ph = {0u, 0u, 0u, 0u};
 
-enum { P8_DENSE = 0, P8_CONV2D = 1, P8_TCONV2D = 2 };
+enum { P8_DENSE = 0, P8_CONV2D = 1, P8_TCONV2D = 2, P8_CONV1D = 3 };
 
 template <int N> __device__ __forceinline__ void p8_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void p8_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -88,9 +88,19 @@ struct P8Walk {
   // tconv2d (one parity class of the stride-2 transposed convolution, S2SVC_OP_TCONV2D_S2): tap (kh, kw) = (ta, fb) of the
   // nt x nf taps of the class reads the output-gradient pixel (i - ta, j - fb); same order (taps innermost), the weight
   // rows are k = tap * C + c with tap = ta * nf + fb.
+  // conv1d (stride 1, 'same' padding, S2SVC_OP_CONV1D: round 5): tap kh of the 2 pad + 1 taps reads row r + kh - pad of the (B T, C)
+  // activations -- the row shift is part of this scalar offset, rows whose shifted frame leaves its utterance read the zero block
+  // (p8_rowmask1d); taps innermost over a 64-channel slice, weight rows k = tap * C + c.
   int kt, c0, kh, kw;
   __device__ __forceinline__ void init(const s2svc_operand& o, int kt0) {
     kt = kt0;
+    if (KIND == P8_CONV1D) {
+      const int ntap = 2 * o.pad + 1;
+      const int cs = kt0 / ntap;
+      c0 = cs * 64;
+      kh = kt0 - cs * ntap;
+      kw = 0;
+    }
     if (KIND == P8_CONV2D) {
       const int cs = kt0 / 9, tap = kt0 - cs * 9;
       c0 = cs * 64;
@@ -108,16 +118,18 @@ struct P8Walk {
   __device__ __forceinline__ int64_t off_bytes(const s2svc_operand& o) const {
     if (KIND == P8_CONV2D) return ((int64_t)(kh * o.F1 + kw) * o.ld + c0) * 2;
     if (KIND == P8_TCONV2D) return (-(int64_t)(kh * o.F2 + kw) * o.ld + c0) * 2;
+    if (KIND == P8_CONV1D) return ((int64_t)(kh - o.pad) * o.ld + c0) * 2;
     return (int64_t)kt * 128;
   }
   // the same K tile of the dense B operand (rows of K = taps * C elements, k = tap * C + c)
   __device__ __forceinline__ int64_t off_bytes_b(const s2svc_operand& o) const {
     if (KIND == P8_CONV2D) return ((int64_t)(kh * 3 + kw) * o.C + c0) * 2;
     if (KIND == P8_TCONV2D) return ((int64_t)(kh * (2 - (o.pad & 1)) + kw) * o.C + c0) * 2;
+    if (KIND == P8_CONV1D) return ((int64_t)kh * o.C + c0) * 2;
     return (int64_t)kt * 128;
   }
   // tconv2d: the bit of this tap in the per-row validity masks (p8_rowmask)
-  __device__ __forceinline__ int bit() const { return 1 << (2 * kh + kw); }
+  __device__ __forceinline__ int bit() const { return KIND == P8_CONV1D ? 1 << kh : 1 << (2 * kh + kw); }
   __device__ __forceinline__ void next(const s2svc_operand& o) {
     ++kt;
     if (KIND == P8_CONV2D) {
@@ -127,6 +139,12 @@ struct P8Walk {
           kh = 0;
           c0 += 64;
         }
+      }
+    }
+    if (KIND == P8_CONV1D) {
+      if (++kh == 2 * o.pad + 1) {
+        kh = 0;
+        c0 += 64;
       }
     }
     if (KIND == P8_TCONV2D) {
@@ -177,6 +195,20 @@ __device__ __forceinline__ int p8_rowmask(const s2svc_operand& o, int r, int R) 
   return m;
 }
 
+// conv1d: which of the 2 pad + 1 taps stay inside the utterance of tile row r (bit = tap)
+__device__ __forceinline__ int p8_rowmask1d(const s2svc_operand& o, int r, int R) {
+  if (r >= R) return 0;
+  const int t = r - (r / o.T) * o.T;
+  int m = 0;
+  for (int tap = 0; tap <= 2 * o.pad; ++tap)
+    if (t + tap - o.pad >= 0 && t + tap - o.pad < o.T) m |= 1 << tap;
+  return m;
+}
+template <int KA>
+__device__ __forceinline__ int p8_rowmask_of(const s2svc_operand& o, int r, int R) {
+  return KA == P8_TCONV2D ? p8_rowmask(o, r, R) : KA == P8_CONV1D ? p8_rowmask1d(o, r, R) : 0;
+}
+
 // one unit = NI DMA instructions of this wave; base == nullptr: the unit lies past the last K tile (the instructions are
 // still issued, from a zero block, so that the counted waits stay exact)
 template <int NI>
@@ -197,6 +229,9 @@ __device__ __forceinline__ void p8_issue_masked(const char* base, const uint32_t
   const char* z = reinterpret_cast<const char*>(&g_zero16_8ph);
 #pragma unroll
   for (int e = 0; e < NI; ++e) {
+    // (the select costs: the aligner's Conv1d 4096 x 1536 x 4608 takes 85.7 us with it and 68.6 us with no masking at all; a wave-uniform
+    // "every row of this instruction is valid" fast path was built and measured -- no gain for the Conv1d, the transposed-convolution classes
+    // 192 -> 214 us: the loop's scalar registers spill and the per-instruction branches break its schedule -- removed)
     const char* src = (base && (mask[e] & bit)) ? base + off[e] : z;
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_unit + (wave_s * NI + e) * 1024), 16, 0, 0);
   }
@@ -206,7 +241,7 @@ __device__ __forceinline__ void p8_issue_masked(const char* base, const uint32_t
 template <int KA, int NI>
 __device__ __forceinline__ void p8_issue_a(const char* base, const uint32_t (&off)[NI], const int (&mask)[NI], int bit, char* lds_unit,
                                            int wave_s) {
-  if (KA == P8_TCONV2D) p8_issue_masked<NI>(base, off, mask, bit, lds_unit, wave_s);
+  if (KA == P8_TCONV2D || KA == P8_CONV1D) p8_issue_masked<NI>(base, off, mask, bit, lds_unit, wave_s);
   else p8_issue<NI>(base, off, lds_unit, wave_s);
 }
 
@@ -281,7 +316,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_q(const s2svc_gemm_desc d
     for (int h = 0; h < 2; ++h) {
       const int row = m0 + (ru >> 6) * 128 + h * 64 + (ru & 63);
       offA[h][e] = p8_rowoff<KA>(d.A, row, d.M, c);
-      mA[h][e] = KA == P8_TCONV2D ? p8_rowmask(d.A, row, d.M) : 0;
+      mA[h][e] = p8_rowmask_of<KA>(d.A, row, d.M);
     }
   }
 #pragma unroll
@@ -420,7 +455,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel_128(const s2svc_gemm_desc
     for (int h = 0; h < 2; ++h) {
       const int row = m0 + (ru >> 6) * 128 + h * 64 + (ru & 63);
       offA[h][e] = p8_rowoff<KA>(d.A, row, d.M, c);
-      mA[h][e] = KA == P8_TCONV2D ? p8_rowmask(d.A, row, d.M) : 0;
+      mA[h][e] = p8_rowmask_of<KA>(d.A, row, d.M);
     }
     offB[e] = p8_rowoff<P8_DENSE>(d.B, n0 + ru, d.N, c);
   }
@@ -1018,8 +1053,10 @@ struct w8_prob {
 // (b, t2, f2), column n = tap * C + c  ->  x[b, 2 t2 + tap / 3, 2 f2 + tap % 3, c] (ld = q.ldb elements per input pixel).  C % 128 == 0, so
 // the 128 columns of a tile lie inside ONE tap: a loader lane's four source rows are four pixels, decomposed per K tile by two
 // multiply-high divisions each.  One geometry per launch (a Conv2d weight gradient is launched on its own).
+// kind 1: the implicit im2col matrix of a Conv1d (stride 1, 'same' padding, S2SVC_OP_CONV1D): reduction row k = frame (b, t), column
+// n = tap * C + c  ->  x[(k + tap - pad) * ldb + c] if 0 <= t + tap - pad < T, else 0  (T1 = T, F1 = pad).
 struct w8_conv {
-  int32_t T1, F1, T2, F2, C, reserved_;
+  int32_t T1, F1, T2, F2, C, kind;
 };
 struct w8_args {
   w8_prob p[W8_MAX];
@@ -1103,15 +1140,18 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, const w8_conv& cv, i
     }
     // implicit im2col B (flags bit 2): the tile's tap and first channel; source pixel of reduction row p decomposed per K tile
     const bool convB = (q.flags & 4) != 0;               // uniform
-    const fastdiv_t dv_pb = fastdiv_make(convB ? cv.T2 * cv.F2 : 1), dv_f = fastdiv_make(convB ? cv.F2 : 1);
+    const bool conv1 = convB && cv.kind == 1;            // uniform
+    const fastdiv_t dv_pb = fastdiv_make(!convB ? 1 : conv1 ? cv.T1 : cv.T2 * cv.F2), dv_f = fastdiv_make(convB && !conv1 ? cv.F2 : 1);
     uint32_t colB[4] = {0u, 0u, 0u, 0u};
+    int tshift = 0;                                      // conv1d: tap - pad
     if (convB) {
       const int tap = n0 / cv.C, c0 = n0 - tap * cv.C, kh = tap / 3, kw = tap - kh * 3;
+      tshift = tap - cv.F1;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int kk, ur;
         p8_tr_src(lw * 4 + i, lane, kk, ur);
-        colB[i] = (uint32_t)((((int64_t)kh * cv.F1 + kw) * q.ldb + c0 + ur) * 2);
+        colB[i] = conv1 ? (uint32_t)((c0 + ur) * 2) : (uint32_t)((((int64_t)kh * cv.F1 + kw) * q.ldb + c0 + ur) * 2);
       }
     }
     const char* Bx = reinterpret_cast<const char*>(q.B);
@@ -1132,8 +1172,13 @@ __device__ __forceinline__ void w8ls_tile(const w8_prob& q, const w8_conv& cv, i
         if (convB && okB[i] && kok_) {                                                                                       \
           const int p_ = (kt0 + tt_) * 64 + kin[i];                                                                           \
           const int b_ = fastdiv(p_, dv_pb), r_ = p_ - b_ * (int)dv_pb.d;                                                     \
-          const int t2_ = fastdiv(r_, dv_f), f2_ = r_ - t2_ * (int)dv_f.d;                                                    \
-          s2_ = Bx + ((int64_t)(b_ * cv.T1 + 2 * t2_) * cv.F1 + 2 * f2_) * q.ldb * 2 + colB[i];                               \
+          if (conv1) {                                                                                                        \
+            const int ts_ = r_ + tshift;                                                                                      \
+            s2_ = (ts_ >= 0 && ts_ < cv.T1) ? Bx + (int64_t)(p_ + tshift) * q.ldb * 2 + colB[i] : z;                          \
+          } else {                                                                                                            \
+            const int t2_ = fastdiv(r_, dv_f), f2_ = r_ - t2_ * (int)dv_f.d;                                                  \
+            s2_ = Bx + ((int64_t)(b_ * cv.T1 + 2 * t2_) * cv.F1 + 2 * f2_) * q.ldb * 2 + colB[i];                             \
+          }                                                                                                                   \
         }                                                                                                                     \
         __builtin_amdgcn_global_load_lds((gbl_void*)s0_, (lds_void*)(st_ + 0 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
         __builtin_amdgcn_global_load_lds((gbl_void*)s1_, (lds_void*)(st_ + 1 * UNIT + (lw * 4 + i) * 1024), 16, 0, 0);       \
@@ -1393,6 +1438,9 @@ bool p8_operand_ok(const s2svc_operand& o, int rows, int K) {
   } else if (o.mode == S2SVC_OP_CONV2D_S2) {
     if (o.C % 64 || o.C < 64 || K != 9 * o.C) return false;
     elems = (int64_t)(rows / (o.T2 * o.F2) + 1) * o.T1 * o.F1 * o.ld;
+  } else if (o.mode == S2SVC_OP_CONV1D) {           // stride 1, 'same' padding, odd kernel width 2 pad + 1 (an A-operand mode)
+    if (o.pad < 0 || o.pad > 7 || o.C % 64 || o.C < 64 || K != (2 * o.pad + 1) * o.C || o.T <= 0 || rows % o.T || o.ld < o.C) return false;
+    elems = (int64_t)(rows + o.pad) * o.ld;
   } else if (o.mode == S2SVC_OP_TCONV2D_S2) {       // one parity class of the transposed convolution (an A-operand mode)
     const int ntap = (2 - (o.pad >> 1)) * (2 - (o.pad & 1));
     if (o.pad < 0 || o.pad > 3 || o.C % 64 || o.C < 64 || K != ntap * o.C || o.T1 <= 0 || o.F1 <= 0) return false;
@@ -1476,6 +1524,19 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
     }
   }
   if (geo == 0) return 0;
+  if (d.A.mode == S2SVC_OP_CONV1D) {
+    // Conv1d as an implicit GEMM (the aligner's 1536 -> 1536 k3 layer over 4096 frames: 58 GF forward and data gradient, 0.24-0.28 of the
+    // peak on the 4-wave kernel): the common epilogue only, one problem; S2SVC_GEMM_8PH_CONV1D=0 switches it off
+    static const bool c1d_on = !getenv_off("S2SVC_GEMM_8PH_CONV1D");
+    if (!c1d_on || mode != 1 || nb != 1 || !epilogue_common_ok(d)) return 0;
+    const int bm1 = geo == 2 ? 512 : 256, bn1 = geo == 1 ? 256 : 128;
+    dim3 grid1((unsigned)((d.N + bn1 - 1) / bn1), (unsigned)((d.M + bm1 - 1) / bm1), 1);
+    if (geo == 1) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_CONV1D, 2, 4, true, true>), grid1, dim3(512), 0, st, d);
+    else if (geo == 2) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_CONV1D, 4, 2, true, true>), grid1, dim3(512), 0, st, d);
+    else hipLaunchKernelGGL((gemm_8ph_kernel_128<P8_CONV1D, true, 1>), grid1, dim3(512), 0, st, d);
+    S2S_CHECK_LAUNCH("gemm_8ph_kernel (conv1d)");
+    return 1;
+  }
   const bool conv = d.A.mode == S2SVC_OP_CONV2D_S2, tconv = d.A.mode == S2SVC_OP_TCONV2D_S2;
   const int bm = geo == 2 ? 512 : 256, bn = geo == 1 ? 256 : 128;
   dim3 grid((unsigned)((d.N + bn - 1) / bn), (unsigned)((d.M + bm - 1) / bm), (unsigned)nb);
@@ -1594,7 +1655,8 @@ bool w8_ok(const s2svc_gemm_desc& d) {
   if (d.dtype != S2S_BF16 || d.c_dtype != S2S_F32 || d.nb0 * d.nb1 != 1 || d.splitk > 1) return false;
   if (d.A.layout != S2SVC_LAYOUT_RC || d.B.layout != S2SVC_LAYOUT_RC || d.A.mode != S2SVC_OP_DENSE) return false;
   const bool convB = d.B.mode == S2SVC_OP_CONV2D_S2;         // the Conv2d 3x3 stride 2 weight gradient: B = implicit im2col of the layer's input
-  if (d.B.mode != S2SVC_OP_DENSE && !convB) return false;
+  const bool conv1B = d.B.mode == S2SVC_OP_CONV1D;           // the Conv1d weight gradient (big outputs only: the aligner's 1536 x 4608)
+  if (d.B.mode != S2SVC_OP_DENSE && !convB && !conv1B) return false;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.M % 8 || d.N % 8) return false;
   if (((uintptr_t)d.A.ptr) % 16 || ((uintptr_t)d.B.ptr) % 16 || d.A.ld % 8 || d.B.ld % 8 || d.A.ld < d.M) return false;
   if ((int64_t)64 * d.A.ld * 2 + (int64_t)d.M * 2 >= (1ll << 32)) return false;
@@ -1604,6 +1666,12 @@ bool w8_ok(const s2svc_gemm_desc& d) {
     if (d.B.T1 <= 0 || d.B.F1 <= 0 || d.B.T2 <= 0 || d.B.F2 <= 0 || 2 * (d.B.T2 - 1) + 3 > d.B.T1 || 2 * (d.B.F2 - 1) + 3 > d.B.F1) return false;
     if (d.K % (d.B.T2 * d.B.F2)) return false;               // whole images
     if ((int64_t)(d.K + 64) * (d.B.T2 * d.B.F2) >= (1ll << 32)) return false;       // the multiply-high divisions are exact below that
+  } else if (conv1B) {
+    static const bool conv1_on = !getenv_off("S2SVC_W8_CONV1D");
+    if (!conv1_on || d.B.C < 128 || d.B.C % 128 || d.B.pad < 0 || d.N != (2 * d.B.pad + 1) * d.B.C || d.B.ld < d.B.C) return false;
+    if (d.B.T <= 0 || d.K % d.B.T) return false;             // whole utterances
+    if ((int64_t)(d.K + 64) * d.B.T >= (1ll << 32)) return false;
+    if ((int64_t)((d.M + 255) / 256) * ((d.N + 127) / 128) < 64) return false;       // few tiles (the Postnet's 256 x 1280): the split-K 4-wave kernel
   } else {
     if (d.B.ld < d.N || (int64_t)64 * d.B.ld * 2 + (int64_t)d.N * 2 >= (1ll << 32)) return false;
   }
@@ -1678,8 +1746,9 @@ extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, 
       w8_chunks(d.M, d.N, d.K, nc, kc, d.B.mode == S2SVC_OP_CONV2D_S2);
       q.nchunks = nc; q.kt_chunk = kc;
       q.flags = (d.accumulate ? 1 : 0) | (d.a_rowsum_accumulate ? 2 : 0);
-      if (d.B.mode == S2SVC_OP_CONV2D_S2) {
-        const w8_conv cv = {d.B.T1, d.B.F1, d.B.T2, d.B.F2, d.B.C, 0};
+      if (d.B.mode == S2SVC_OP_CONV2D_S2 || d.B.mode == S2SVC_OP_CONV1D) {
+        const bool c1 = d.B.mode == S2SVC_OP_CONV1D;
+        const w8_conv cv = {c1 ? d.B.T : d.B.T1, c1 ? d.B.pad : d.B.F1, c1 ? 1 : d.B.T2, c1 ? 1 : d.B.F2, d.B.C, c1 ? 1 : 0};
         S2S_REQUIRE(!have_cv || std::memcmp(&cv, &g.cv, sizeof(cv)) == 0, "gemm_wgrad_grouped: one Conv2d geometry per launch");
         g.cv = cv;
         have_cv = true;

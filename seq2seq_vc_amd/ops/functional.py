@@ -1256,6 +1256,9 @@ def add_head_bias(q, u, v):
 # Conv1d (stride 1, 'same' padding, channel-last activations) as an implicit GEMM
 # reference: Postnet / AlignmentModule / DurationPredictor / FFN Conv1d call sites
 # ================================================================================================
+_CONV1D_WGRAD_W8 = os.environ.get("S2SVC_CONV1D_WGRAD_W8", "1") != "0"      # A/B switch
+
+
 class _Conv1d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act):
@@ -1296,8 +1299,11 @@ class _Conv1d(Function):
                 dwp = torch.empty((Cout, ks * Cin), dtype=torch.float32, device=x.device)
                 rs, racc, dbv = _bias_sink(bias, Cout)
                 tile, sk = K.plan_gemm(Cout, ks * Cin, B * T)
+                # wgrad=True: big bf16 outputs (the aligner's 1536 x 4608 over 4096 frames) run on the ragged 8-wave weight-gradient kernel
+                # with the implicit im2col B operand (csrc/gemm_8ph.hip "w8_conv" kind 1); everything else as before
                 K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad),
-                       Cout, ks * Cin, B * T, dwp, in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc)
+                       Cout, ks * Cin, B * T, dwp, in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc,
+                       wgrad=_CONV1D_WGRAD_W8)
                 dwt = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
                 return _emit_vgrad(weight, dwt), dbv
             if _slotted(weight, bias):

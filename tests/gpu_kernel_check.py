@@ -406,6 +406,64 @@ def gemm_conv1d(dtype):
 
 
 @case
+def gemm_conv1d_on_8wave_kernel():
+    """Conv1d (stride 1, 'same') as an implicit GEMM on the 8-wave kernel (bf16; csrc/gemm_8ph.hip P8_CONV1D): the three tile
+    geometries (256 x 128, 256 x 256, 512 x 128), kernel widths 3 and 5, utterance boundaries inside a tile (T = 96 / 160), bias +
+    ReLU and the plain data-gradient form -- against fp32 torch on the same stored operands and against the 4-wave kernel."""
+    res = []
+    dtype = torch.bfloat16
+    L = K._lib.lib()
+    for (B, T, Cin, Cout, ks, act, seed) in [(16, 256, 128, 1024, 3, "relu", 1), (64, 128, 64, 1536, 3, None, 2), (128, 128, 64, 640, 5, "relu", 3),
+                                             (32, 96, 192, 1152, 3, None, 4), (40, 160, 128, 1024, 5, "relu", 5)]:
+        pad = (ks - 1) // 2
+        x = rnd(B, T, Cin, seed=seed, dtype=dtype)
+        w = rnd(Cout, Cin, ks, seed=seed + 1, dtype=torch.float32, scale=0.05)
+        b = rnd(Cout, seed=seed + 2) if act else None
+        wp = K.gather3(w, (Cout, ks, Cin), (Cin * ks, 1, ks), 0, dtype)          # (O, k, I)
+        yr = F.conv1d(x.float().transpose(1, 2), w.to(dtype).float(), b, padding=pad).transpose(1, 2)
+        if act:
+            yr = torch.relu(yr)
+        outs = []
+        for on in (1, 0):
+            prev = L.s2svc_gemm_set_8ph(on)
+            y = torch.empty(B, T, Cout, dtype=dtype, device=DEV)
+            K.gemm(K.operand(x, Cin, mode=K.CONV1D, C=Cin, T=T, pad=pad), K.operand(wp, ks * Cin), B * T, Cout, ks * Cin, y,
+                   in_dtype=dtype, bias=b, act=act)
+            L.s2svc_gemm_set_8ph(prev)
+            res.append(check(f"conv1d on 8-wave={on} {B}x{T}x{Cin}->{Cout} k{ks} act={act}", y, yr, dtype))
+            outs.append(y)
+        res.append(check(f"conv1d 8-wave vs 4-wave {B}x{T}x{Cin}->{Cout} k{ks}", outs[0], outs[1].float(), dtype, rtol=1e-2, atol=1e-2))
+    return res
+
+
+@case
+def conv1d_wgrad_on_w8():
+    """Conv1d weight gradient on the ragged 8-wave weight-gradient kernel (implicit im2col B operand, kind 1): kernel widths 3 / 5,
+    utterance boundaries inside K tiles (T = 96), a reduction that ends inside a K tile, bias row sums -- against fp32 torch."""
+    res = []
+    dtype = torch.bfloat16
+    for (B, T, Cin, Cout, ks, seed) in [(16, 256, 1536, 1536, 3, 1), (5, 96, 256, 2048, 5, 2), (3, 50, 128, 4096, 3, 3)]:
+        pad = (ks - 1) // 2
+        x = rnd(B, T, Cin, seed=seed, dtype=dtype)
+        dy = rnd(B, T, Cout, seed=seed + 3, dtype=dtype)
+        wr = torch.zeros(Cout, Cin, ks, device=DEV, requires_grad=True)
+        yr = F.conv1d(x.float().transpose(1, 2), wr, None, padding=pad)
+        yr.backward(dy.float().transpose(1, 2))
+        dbr = dy.float().sum((0, 1))
+        for w8 in (True, False):
+            dwp = torch.full((Cout, ks * Cin), 7.0, dtype=torch.float32, device=DEV)
+            db = torch.full((Cout,), 3.0, dtype=torch.float32, device=DEV)
+            K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad), Cout,
+                   ks * Cin, B * T, dwp, in_dtype=dtype, splitk=1, a_rowsum=db, a_rowsum_accumulate=False, wgrad=w8)
+            dw = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
+            sc = max(float(wr.grad.abs().max()), 1.0)
+            tag = f"conv1d wgrad w8={int(w8)} {B}x{T} {Cin}->{Cout} k{ks}"
+            res.append(check(tag, dw, wr.grad, torch.float32, rtol=1e-4, atol=2e-4 * sc))
+            res.append(check(tag + " bias", db, dbr, torch.float32, rtol=1e-4, atol=2e-4 * max(float(dbr.abs().max()), 1.0)))
+    return res
+
+
+@case
 @both_dtypes
 def gemm_conv2d(dtype):
     res = []

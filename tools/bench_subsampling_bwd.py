@@ -113,6 +113,26 @@ def main():
     mb = dy1.numel() * 2 * 1e-6
     line("conv_in1 wgrad (dy only)", t(lambda: K.conv_in1_wgrad(x0, dy1, dw1, db1, True, y=None)), None, mb)
 
+    # ---- AAS-VC aligner: Conv1d(1536 -> 1536, k3) over 16 x 256 frames (forward / data-gradient form), 8-wave vs 4-wave kernel
+    Bx, Tx, Cx, ks = 16, 256, 1536, 3
+    xa, wa = u(Bx, Tx, Cx), u(Cx, ks * Cx) * 0.02
+    ya, ba = torch.empty(Bx, Tx, Cx, dtype=dt, device="cuda"), torch.zeros(Cx, device="cuda")
+    gfa = 2.0 * Bx * Tx * Cx * ks * Cx * 1e-9
+    for on, name in ((1, "8-wave"), (0, "4-wave")):
+        prev = L.s2svc_gemm_set_8ph(on)
+        line(f"aligner Conv1d 4096 x 1536 x 4608, {name} kernel",
+             t(lambda: K.gemm(K.operand(xa, Cx, mode=K.CONV1D, C=Cx, T=Tx, pad=1), K.operand(wa, ks * Cx), Bx * Tx, Cx, ks * Cx, ya, in_dtype=dt,
+                              bias=ba, act="relu")), gfa)
+        L.s2svc_gemm_set_8ph(prev)
+    dya = u(Bx, Tx, Cx)
+    dwa = torch.empty(Cx, ks * Cx, dtype=torch.float32, device="cuda")
+    dba = torch.zeros(Cx, device="cuda")
+    tile, sk = K.plan_gemm(Cx, ks * Cx, Bx * Tx)
+    for w8 in (False, True):
+        line(f"aligner Conv1d weight gradient 1536 x 4608 x 4096, w8={int(w8)} (plan tile {tile} split {sk})",
+             t(lambda: K.gemm(K.operand(dya, Cx, layout=K.RC), K.operand(xa, Cx, layout=K.RC, mode=K.CONV1D, C=Cx, T=Tx, pad=1), Cx, ks * Cx,
+                              Bx * Tx, dwa, in_dtype=dt, splitk=sk, tile=tile, a_rowsum=dba, a_rowsum_accumulate=True, wgrad=w8)), gfa)
+
 
 if __name__ == "__main__":
     main()
