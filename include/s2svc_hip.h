@@ -284,6 +284,10 @@ typedef struct s2svc_gather3_job {
   int32_t out_dtype;
 } s2svc_gather3_job;
 int s2svc_gather3_grouped(const s2svc_gather3_job* jobs /* host */, int n, void* stream);
+/* dst[o][b][a] (+)= src[o][a][b], fp32, o < n: a convolution weight gradient (C_out, taps, C_in) as the GEMM leaves it into the
+   parameter's (C_out, C_in, taps) layout (replaces the transposes autograd does inside conv backward: subsampling.py:58-63,
+   pre_postnets.py:108-165, alignments.py:28-60 call sites).  A * (B + 1) * 4 bytes must fit 64 KB. */
+int s2svc_permute_inner(int n, int A, int B, const float* src, float* dst, int accumulate, void* stream);
 int s2svc_rowscale(int dtype, int64_t rows, int D, const void* x, const float* s, void* out, void* stream);
 
 /* ========================================================================================== */

@@ -138,6 +138,7 @@ _SIGS = {
     "s2svc_glu_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_cast": [c_i32, c_i32, c_i64, c_vp, c_vp, c_vp],
     "s2svc_gather3_grouped": [c_vp, c_i32, c_vp],
+    "s2svc_permute_inner": [c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp],
     "s2svc_gather3": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     "s2svc_mas": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_mas_binloss_bwd": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],

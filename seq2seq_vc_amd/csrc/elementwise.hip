@@ -512,6 +512,39 @@ extern "C" int s2svc_gather3_grouped(const s2svc_gather3_job* jobs, int n, void*
   return 0;
 }
 
+// dst[o][b][a] (+)= src[o][a][b]  (fp32; o < n, a < A, b < B): a convolution weight gradient leaves its GEMM as (C_out, taps, C_in) and
+// belongs in the parameter's (C_out, C_in, taps) gradient slot.  One workgroup per o: the A x B matrix is read row-contiguous into LDS
+// and written row-contiguous from it (gather3 + axpby read 4 bytes per 1.5 KB-apart address: 17-39 us + 17-19 us for 1.3-2.8 M
+// elements at the end of VTN's backward pass, where every kernel's time is the step's time).
+namespace {
+__global__ __launch_bounds__(256) void permute_inner_kernel(int A, int B, const float* __restrict__ src, float* __restrict__ dst,
+                                                            int accumulate) {
+  extern __shared__ float pi_tile[];          // [A][B + 1]
+  const int64_t base = (int64_t)blockIdx.x * A * B;
+  const int n = A * B, pitch = B + 1;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int a = i / B, b = i - a * B;
+    pi_tile[a * pitch + b] = src[base + i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int b = i / A, a = i - b * A;
+    const float v = pi_tile[a * pitch + b];
+    dst[base + i] = accumulate ? dst[base + i] + v : v;
+  }
+}
+}  // namespace
+
+extern "C" int s2svc_permute_inner(int n, int A, int B, const float* src, float* dst, int accumulate, void* stream) {
+  S2S_REQUIRE(n >= 0 && A > 0 && B > 0 && (n == 0 || (src && dst)), "permute_inner: bad args");
+  S2S_REQUIRE((int64_t)A * (B + 1) * 4 <= 64 * 1024, "permute_inner: one A x B matrix must fit 64 KB of LDS");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(permute_inner_kernel, dim3((unsigned)n), dim3(256), (size_t)A * (B + 1) * sizeof(float), (hipStream_t)stream, A, B, src, dst,
+                     accumulate);
+  S2S_CHECK_LAUNCH("permute_inner_kernel");
+  return 0;
+}
+
 // out (contiguous, n0 x n1 x n2, out_dtype) = in[off + i0*s0 + i1*s1 + i2*s2] (in_dtype)
 extern "C" int s2svc_gather3(int in_dtype, int out_dtype, int n0, int n1, int n2, int64_t s0, int64_t s1, int64_t s2,
                              int64_t off, const void* in, void* out, void* stream) {

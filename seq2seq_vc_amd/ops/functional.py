@@ -83,6 +83,21 @@ def _emit_vgrad(param, value):
     return value.view(param.shape)
 
 
+_PERMUTE_FUSED = os.environ.get("S2SVC_PERMUTE_FUSED", "1") != "0"      # A/B switch
+
+
+def _emit_permuted(param, dwp, n, A, Bn):
+    """The weight gradient `dwp` (n, A, Bn) as its GEMM left it -> the parameter's (n, Bn, A) layout, accumulated into the flat-gradient
+    slot if the parameter has one: ONE launch through LDS (K.permute_inner) instead of an element-wise gather + an axpby."""
+    if _PERMUTE_FUSED and K.permute_inner_ok(A, Bn):
+        slot = getattr(param, "_s2s_grad", None)
+        if slot is not None:
+            K.permute_inner(dwp, n, A, Bn, out=slot, accumulate=True)
+            return None
+        return K.permute_inner(dwp, n, A, Bn).view(param.shape)
+    return _emit_vgrad(param, K.gather3(dwp, (n, Bn, A), (A * Bn, 1, Bn), 0, torch.float32))
+
+
 # ------------------------------------------------------------------------------------------------
 # Gradient cuts (data-parallel overlap).  A model's forward marks a few tensors with cut_point(x, name).  Normally that is
 # the identity.  Inside `with grad_cuts(GradCuts([...]))` the autograd graph is cut there: the consumer sees a detached leaf,
@@ -1304,8 +1319,7 @@ class _Conv1d(Function):
                 K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad),
                        Cout, ks * Cin, B * T, dwp, in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc,
                        wgrad=_CONV1D_WGRAD_W8)
-                dwt = K.gather3(dwp, (Cout, Cin, ks), (ks * Cin, 1, Cin), 0, torch.float32)
-                return _emit_vgrad(weight, dwt), dbv
+                return _emit_permuted(weight, dwp, Cout, ks, Cin), dbv
             if _slotted(weight, bias):
                 _side_run(work, keep=(dy, x))
             else:
@@ -1371,8 +1385,7 @@ class _Conv2dS2(Function):
                 K.gemm(K.operand(dy, O, layout=K.RC),
                        K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M2, dwp,
                        in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc, wgrad=_CONV_WGRAD_W8)
-                dwt = K.gather3(dwp, (O, C, 9), (9 * C, 1, C), 0, torch.float32)
-                return _emit_vgrad(weight, dwt), dbv
+                return _emit_permuted(weight, dwp, O, 9, C), dbv
             if _slotted(weight, bias):
                 # queued AND forked before the data-gradient GEMM below: this is the last big layer of the backward pass,
                 # its weight gradient would otherwise run alone after the main chain has ended.  (Sending the batch queued so
@@ -1511,8 +1524,7 @@ class _LinearPermuted(Function):
                 tile, sk = K.plan_gemm(D, Kd, M)
                 K.gemm(K.operand(dy, D, layout=K.RC), K.operand(x, Kd, layout=K.RC), D, Kd, M, dwp, in_dtype=dtype,
                        splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc, wgrad=_FC_WGRAD_W8)
-                dwt = K.gather3(dwp, (D, C, Fd), (Kd, 1, C), 0, torch.float32)
-                return _emit_vgrad(weight, dwt), dbv
+                return _emit_permuted(weight, dwp, D, Fd, C), dbv
             if _slotted(weight, bias):
                 _side_run(work, keep=(dy, x))
             else:

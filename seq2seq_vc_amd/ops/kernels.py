@@ -856,6 +856,22 @@ def gather3(x, n, strides, off, out_dtype):
     return y
 
 
+def permute_inner(src, n, A, Bn, out=None, accumulate=False):
+    """out[o][b][a] (+)= src[o][a][b] (fp32, o < n): a convolution weight gradient from its GEMM layout (C_out, taps, C_in) into the
+    parameter's (C_out, C_in, taps) -- straight into the flat-gradient slot when `out` is one (accumulate=True)."""
+    _need_cuda(src)
+    if src.dtype != torch.float32 or not src.is_contiguous():
+        raise TypeError("permute_inner: contiguous fp32 source")
+    if out is None:
+        out, accumulate = torch.empty(n * A * Bn, dtype=torch.float32, device=src.device), False
+    _lib.check(_lib.lib().s2svc_permute_inner(n, A, Bn, ptr(src), ptr(out), 1 if accumulate else 0, stream()), "permute_inner")
+    return out
+
+
+def permute_inner_ok(A, Bn):
+    return A * (Bn + 1) * 4 <= 64 * 1024
+
+
 # ----------------------------------------------------------------------------------------------
 # monotonic alignment search
 # ----------------------------------------------------------------------------------------------

@@ -437,6 +437,39 @@ def gemm_conv1d_on_8wave_kernel():
 
 
 @case
+def tconv2d_weight_matrices():
+    """The four parity-class weight matrices of the stride-2 transposed convolution (LDS-tiled kernel for O, C % 32 == 0, element-wise
+    otherwise) against an index-by-index torch construction: bit-exact (a bf16 rounding of the same fp32 values)."""
+    res = []
+    for (O, C, seed) in [(64, 64, 1), (384, 384, 2), (72, 64, 3), (96, 160, 4)]:
+        w = rnd(O, C, 3, 3, seed=seed, scale=0.3)
+        got = K.tconv2d_weights(w)
+        for cls in range(4):
+            pt, pf = cls >> 1, cls & 1
+            taps = [(pt + 2 * ta, pf + 2 * fb) for ta in range(2 - pt) for fb in range(2 - pf)]
+            ref = torch.stack([w[:, :, kh, kw].t() for kh, kw in taps], 1).reshape(C, len(taps) * O).to(torch.bfloat16)   # [c][tap * O + o]
+            ok = bool(torch.equal(got[cls], ref))
+            res.append((ok, f"tconv2d weights O{O} C{C} class {cls}: bit-exact={ok}"))
+    return res
+
+
+@case
+def permute_inner_accumulate():
+    """dst[o][b][a] (+)= src[o][a][b] through LDS (a convolution weight gradient into the parameter's layout): bit-exact against torch."""
+    res = []
+    for (n, A, Bn, seed) in [(384, 9, 384, 1), (384, 19, 384, 2), (1536, 3, 1536, 3), (7, 5, 33, 4), (3, 1, 8, 5)]:
+        src = rnd(n, A, Bn, seed=seed)
+        base = rnd(n, Bn, A, seed=seed + 1)
+        ref = src.permute(0, 2, 1).contiguous()
+        out = K.permute_inner(src, n, A, Bn).view(n, Bn, A)
+        res.append((bool(torch.equal(out, ref)), f"permute_inner n{n} A{A} B{Bn}: bit-exact={bool(torch.equal(out, ref))}"))
+        acc = base.clone()
+        K.permute_inner(src, n, A, Bn, out=acc, accumulate=True)
+        res.append((bool(torch.equal(acc, base + ref)), f"permute_inner accumulate n{n} A{A} B{Bn}: bit-exact={bool(torch.equal(acc, base + ref))}"))
+    return res
+
+
+@case
 def conv1d_wgrad_on_w8():
     """Conv1d weight gradient on the ragged 8-wave weight-gradient kernel (implicit im2col B operand, kind 1): kernel widths 3 / 5,
     utterance boundaries inside K tiles (T = 96), a reduction that ends inside a K tile, bias row sums -- against fp32 torch."""
