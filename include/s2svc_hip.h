@@ -151,6 +151,10 @@ int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs /* host */, int n, v
      _ok        : 1 if the kernel takes `desc` (a function of the descriptor only).  Since round 4 that includes the exact-256
                   problems with >= 64 tiles of 128 x 128 (AAS-VC's decoder layers); only S2SVC_W8_EXACT=0 in the environment sends
                   those back to s2svc_gemm_grouped's 8-wave exact-tile path;
+                  Round 5: B may also be the implicit im2col operand of a convolution weight gradient (S2SVC_LAYOUT_RC with
+                  S2SVC_OP_CONV2D_S2 or S2SVC_OP_CONV1D, C % 128 == 0, whole images / utterances in K; Conv1d only for outputs of
+                  >= 64 tiles) -- replaces autograd's conv weight gradients at subsampling.py:58-63 and alignments.py:28-60;
+                  at most one convolution geometry per _grouped call;
      _ws_floats : fp32 elements of workspace the listed problems need (0 = none);
      _grouped   : launch; `ws` device memory (16-byte aligned) the caller keeps untouched until the launches have run. */
 int s2svc_gemm_wgrad_ok(const s2svc_gemm_desc* desc /* host */);
