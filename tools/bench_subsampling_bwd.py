@@ -111,6 +111,8 @@ def main():
     dy1 = u(B, T1, F1, C)
     dw1, db1 = torch.zeros(C, 1, 3, 3, device="cuda"), torch.zeros(C, device="cuda")
     mb = dy1.numel() * 2 * 1e-6
+    w1, b1 = torch.rand(C, 1, 3, 3, device="cuda", generator=g) * 0.6 - 0.3, torch.zeros(C, device="cuda")
+    line("conv_in1 forward (122 MB store stream)", t(lambda: K.conv_in1_fwd(x0, w1, b1)), None, mb)
     line("conv_in1 wgrad (dy only)", t(lambda: K.conv_in1_wgrad(x0, dy1, dw1, db1, True, y=None)), None, mb)
 
     # ---- AAS-VC aligner: Conv1d(1536 -> 1536, k3) over 16 x 256 frames (forward / data-gradient form), 8-wave vs 4-wave kernel
