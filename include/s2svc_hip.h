@@ -17,6 +17,11 @@
  *   - dropout: a mask is a pure function of (seed, element index) (SplitMix64 output function over seed + index/4, 16 bits per element); kernels read
  *     seed = *seed_base + seed_off, seed_base in device memory (may be NULL), so a captured hipGraph
  *     draws fresh masks on every replay and backward kernels regenerate masks instead of loading them.
+ *   - absent rows (`int Tn, const int32_t* vlens`, ABI version 2): a captured training step allocates a (B, Tn, C) activation at a
+ *     PADDED length Tn, the reference computes on the batch cropped to its longest utterance (models/vtn.py:208-214,
+ *     models/aas_vc.py:523-524).  Entry points that mix along time or reduce over the batch take the B int32 lengths `vlens` in
+ *     device memory (graph DATA): row r = b * Tn + t with t >= vlens[b] is ABSENT -- excluded from every sum and count, read
+ *     as a convolution's zero padding, written as zero (outputs and data gradients).  vlens = NULL: every row is present.
  */
 #ifndef S2SVC_HIP_H
 #define S2SVC_HIP_H
@@ -193,7 +198,7 @@ int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, const void* 
 /* chunked column reductions over (rows, D); modes 0..6 see csrc/norm.hip (5: sum dy, sum dy*v[r] with v in `mean`; 6: sum x, sum x^2); ws >= ws_chunks*2*D floats */
 int s2svc_colreduce(int dtype, int rows, int D, int mode, const void* dy, const void* x, const float* mean,
                     const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate, float* ws,
-                    int ws_chunks, void* stream);
+                    int ws_chunks, int Tn, const int32_t* vlens /* absent rows; scale < 0: 1 / number of present rows */, void* stream);
 /* Several column reductions in two launches (stage 1, stage 2): the parameter gradients of the LayerNorm / BatchNorm /
    bias vectors of a few consecutive layers, queued by the host during backward.  Same semantics per item as
    s2svc_colreduce (ws >= ws_chunks*2*D floats each).  Two items of one call must not write the same out_sum / out_dot. */
@@ -221,19 +226,20 @@ int s2svc_layernorm_bwd_pg(int dtype, int rows, int D, const void* dy, const voi
                            uint64_t seed_off, void* ds, void* dh, float* ws, void* stream);
 int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean, const float* var, float* rstd,
                       float* run_mean, float* run_var, int64_t* num_batches, int var_is_ex2 /* var = E[x^2], colreduce mode 6 */,
-                      void* stream);
+                      int Tn, const int32_t* vlens /* absent rows: n = B * Tn -> the number of present rows */, void* stream);
 int s2svc_rstd_from_var(int C, float eps, const float* var, float* rstd, void* stream);
 /* The training-mode statistics of torch.nn.BatchNorm1d (pre_postnets.py:124,152, conformer/convolution.py:52,74) with the second
    reduction stage folded into the finalisation: 2 launches instead of 3 (ws >= ws_chunks*2*C floats).
    s2svc_bn_stats == s2svc_colreduce(mode 6, scale 1/rows) + s2svc_bn_finalize(var_is_ex2 = 1). */
 int s2svc_bn_stats(int dtype, int rows, int C, const void* x, float eps, float momentum, float* mean, float* rstd,
-                   float* run_mean, float* run_var, int64_t* num_batches, float* ws, int ws_chunks, void* stream);
+                   float* run_mean, float* run_var, int64_t* num_batches, float* ws, int ws_chunks, int Tn, const int32_t* vlens,
+                   void* stream);
 int s2svc_bn_apply(int dtype, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
                    const float* gamma, const float* beta, int act, float drop_p, const uint64_t* seed_base,
-                   uint64_t seed_off, void* y, void* pre_act, void* stream);
+                   uint64_t seed_off, void* y, void* pre_act, int Tn, const int32_t* vlens, void* stream);
 int s2svc_bn_bwd(int dtype, int64_t rows, int C, const void* dy, const void* x, const float* mean, const float* rstd,
                  const float* gamma, const float* sum_dy, const float* sum_dy_xhat, int use_batch_stats, void* dx,
-                 void* stream);
+                 int Tn, const int32_t* vlens, void* stream);
 
 /* ========================================================================================== */
 /* Attention probabilities: scale + relative shift + length/causal mask + softmax + dropout   */
@@ -306,8 +312,12 @@ int s2svc_conv_in1_fwd(int dtype, int B, int Tn, int Fn, int O, const void* x, c
 int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, const void* x, const void* dy, const void* y, float* dw,
                          float* db, int accumulate, float* partial, int max_chunks, void* stream);
 int s2svc_col2im_s2(int dtype, int B, int T1, int F1, int C, int T2, int F2, const void* dcols, void* dx, void* stream);
-int s2svc_interp_nearest(int dtype, int B, int Tin, int Tout, int C, const void* x, void* y, void* stream);
-int s2svc_interp_nearest_bwd(int dtype, int B, int Tin, int Tout, int C, const void* dy, void* dx, void* stream);
+/* ext_in / ext_out (device, one int32 each, or NULL): the lengths the reference's cropped tensors have when Tin / Tout are padded
+   lengths of a captured step -- they set the resampling ratio; output frames >= *ext_out are zero, input frames >= *ext_in unread. */
+int s2svc_interp_nearest(int dtype, int B, int Tin, int Tout, int C, const void* x, void* y, const int32_t* ext_in,
+                         const int32_t* ext_out, void* stream);
+int s2svc_interp_nearest_bwd(int dtype, int B, int Tin, int Tout, int C, const void* dy, void* dx, const int32_t* ext_in,
+                             const int32_t* ext_out, void* stream);
 int s2svc_dwconv(int dtype, int B, int Tn, int C, int ks, int dil, const void* x, const float* w, const float* bias,
                  void* y, int flip, void* stream);
 /* y = dwconv(x) + add (add: a tensor of y's shape or NULL): the data gradient of a depthwise convolution whose input also feeds a
@@ -327,17 +337,17 @@ int s2svc_dwconv_wgrad(int dtype, int B, int Tn, int C, int ks, int dil, const v
 int s2svc_convmod_supported(int C, int ks);
 int s2svc_convmod_fwd(int B, int Tn, int C, int ks, const void* y2, const float* w, const float* bias, void* z, float eps,
                       float momentum, float* mean, float* rstd, float* run_mean, float* run_var, int64_t* num_batches, float* ws,
-                      void* stream);
+                      const int32_t* vlens, void* stream);
 /* out = swish((z - mean) * rstd * gamma + beta), bf16, C % 64 == 0 */
 int s2svc_bn_swish_apply(int64_t rows, int C, const void* z, const float* mean, const float* rstd, const float* gamma,
-                         const float* beta, void* out, void* stream);
+                         const float* beta, void* out, int Tn, const int32_t* vlens, void* stream);
 /* da (B,Tn,C) bf16 = gradient of the Swish output -> dy2 (B,Tn,2C) bf16 = gradient of y2;  sdy / sdyx (C) = gradients of the
    BatchNorm bias / weight (also ADDED to dbeta_acc / dgamma_acc when given);  ws_w receives the per-tile partial sums of the
    depthwise weight and bias gradients, [B * ceil(Tn / 64)][C][ks + 1] (s2svc_convmod_wgrad_final sums them);
    ws_stats >= ceil(B * Tn / 64) * 2 * C floats. */
 int s2svc_convmod_bwd(int B, int Tn, int C, int ks, const void* da, const void* z, const void* y2, const float* w, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, void* dy2, float* sdy, float* sdyx,
-                      float* dgamma_acc, float* dbeta_acc, float* ws_stats, float* ws_w, void* stream);
+                      float* dgamma_acc, float* dbeta_acc, float* ws_stats, float* ws_w, const int32_t* vlens, void* stream);
 int s2svc_convmod_wgrad_final(int C, int ks, int chunks, const float* ws_w, float* dw, float* db, int accumulate, void* stream);
 
 /* BatchNorm1d (training mode) + activation + dropout on channel-last bf16 rows, C % 8 == 0, 16-byte accesses (csrc/convmod.hip).
@@ -348,12 +358,13 @@ int s2svc_convmod_wgrad_final(int C, int ks, int chunks, const float* ws_w, floa
        -> dx, sdy = d beta, sdyx = d gamma (also ADDED to dbeta_acc / dgamma_acc when given).  The activation / dropout derivative is
        recomputed in both passes (no intermediate tensor).  Dropout masks: element index = row * C + channel, as s2svc_bn_apply. */
 int s2svc_bn_stats_vec(int rows, int C, const void* x, float eps, float momentum, float* mean, float* rstd, float* run_mean,
-                       float* run_var, int64_t* num_batches, float* ws, void* stream);
+                       float* run_var, int64_t* num_batches, float* ws, int Tn, const int32_t* vlens, void* stream);
 int s2svc_bn_act_apply_vec(int rows, int C, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                           int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y, void* pre_act, void* stream);
+                           int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y, void* pre_act, int Tn,
+                           const int32_t* vlens, void* stream);
 int s2svc_bn_act_bwd_vec(int rows, int C, const void* dz, const void* saved, const void* x, const float* mean, const float* rstd,
                          const float* gamma, int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dx, float* sdy,
-                         float* sdyx, float* dgamma_acc, float* dbeta_acc, float* ws, void* stream);
+                         float* sdyx, float* dgamma_acc, float* dbeta_acc, float* ws, int Tn, const int32_t* vlens, void* stream);
 
 /* ========================================================================================== */
 /* AAS alignment: pairwise -L2 + masked log-softmax, monotonic alignment search, Gaussian     */

@@ -116,12 +116,12 @@ _SIGS = {
     "s2svc_layernorm_bwd_pg_chunks": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_layernorm_bwd_pg": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp],
     "s2svc_colreduce_grouped": [c_vp, c_i32, c_vp],
-    "s2svc_colreduce": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
-    "s2svc_bn_finalize": [c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
+    "s2svc_colreduce": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp],
+    "s2svc_bn_finalize": [c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp],
     "s2svc_rstd_from_var": [c_i32, c_f32, c_vp, c_vp, c_vp],
-    "s2svc_bn_apply": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
-    "s2svc_bn_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
-    "s2svc_bn_stats": [c_i32, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
+    "s2svc_bn_apply": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32, c_vp, c_vp],
+    "s2svc_bn_bwd": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp],
+    "s2svc_bn_stats": [c_i32, c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp],
     "s2svc_attn_softmax_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32, c_f32,
                                c_vp, c_u64, c_vp, c_vp, c_vp],
     "s2svc_attn_softmax_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32,
@@ -150,21 +150,21 @@ _SIGS = {
     "s2svc_adam_step": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp],
     "s2svc_transpose_tiles": [c_i64, c_vp, c_vp, c_vp, c_vp],
     "s2svc_col2im_s2": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
-    "s2svc_interp_nearest": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
-    "s2svc_interp_nearest_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "s2svc_interp_nearest": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_interp_nearest_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_dwconv": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_dwconv_add": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_dwconv_wgrad": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp],
     "s2svc_convmod_supported": [c_i32, c_i32],
-    "s2svc_convmod_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "s2svc_bn_swish_apply": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_convmod_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_bn_swish_apply": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
     "s2svc_convmod_bwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                          c_vp, c_vp],
+                          c_vp, c_vp, c_vp],
     "s2svc_convmod_wgrad_final": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp],
-    "s2svc_bn_stats_vec": [c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "s2svc_bn_act_apply_vec": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp],
+    "s2svc_bn_stats_vec": [c_i32, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp],
+    "s2svc_bn_act_apply_vec": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_i32, c_vp, c_vp],
     "s2svc_bn_act_bwd_vec": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                             c_vp],
+                             c_i32, c_vp, c_vp],
     "s2svc_pairwise_l2_logsoftmax": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_pairwise_l2_bwd_g": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_rowscale": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],

@@ -25,18 +25,21 @@ class ConvolutionModule(nn.Module):
         self.pointwise_conv2 = nn.Conv1d(channels, channels, kernel_size=1, stride=1, padding=0, bias=bias)
         self.activation = activation
 
-    def forward(self, x):
+    def forward(self, x, lens=None):
+        """lens: the Lens of x.  In a captured step on a batch shorter than its padded shape (modules.LensBank) its crop() marks the
+        frames the reference's tensor does not have: zero padding for the depthwise convolution, outside the BatchNorm statistics."""
         c1, c2, bn = self.pointwise_conv1, self.pointwise_conv2, self.norm
+        vl = Mo.crop_dev(lens) if self.training else None
         y = Fn.linear(x, c1.weight, c1.bias)           # 1x1 conv == Linear on channel-last ((N,K,1) weight accepted)
         if FA.convmod_core_ok(y, self.depthwise_conv.weight, self.training, self.activation):
             # bf16 training: GLU -> depthwise conv -> batch statistics -> BatchNorm + Swish on the fused kernels (csrc/convmod.hip)
             y = FA.convmod_core(y, self.depthwise_conv.weight, self.depthwise_conv.bias, bn.weight, bn.bias, bn.running_mean,
-                                bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum)
+                                bn.running_var, bn.num_batches_tracked, bn.eps, bn.momentum, vlens=vl)
             return Fn.linear(y, c2.weight, c2.bias)
-        y = Fn.glu(y)
+        y = Fn.crop_rows(Fn.glu(y), vl)
         y = FA.dwconv1d(y, self.depthwise_conv.weight, self.depthwise_conv.bias)
         y = Fn.batch_norm_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, self.training,
-                              self.activation, 0.0, bn.eps, bn.momentum)
+                              self.activation, 0.0, bn.eps, bn.momentum, vlens=vl)
         return Fn.linear(y, c2.weight, c2.bias)
 
 
@@ -73,12 +76,15 @@ class EncoderLayer(nn.Module):
         pre = self.normalize_before
         # every "x = res + scale*dropout(h)" is fused with the LayerNorm that follows it
         steps = []
+        def ff(mod):       # the Conv1d feed-forward mixes along time: it needs the lengths (modules.MultiLayeredConv1d)
+            return (lambda y: mod(y, klens)) if isinstance(mod, Mo.MultiLayeredConv1d) else (lambda y: mod(y))
+
         if self.feed_forward_macaron is not None:
-            steps.append((self.norm_ff_macaron, lambda y: self.feed_forward_macaron(y), self.ff_scale))
+            steps.append((self.norm_ff_macaron, ff(self.feed_forward_macaron), self.ff_scale))
         steps.append((self.norm_mha, lambda y: self._attn(y, pos_emb, klens), 1.0))
         if self.conv_module is not None:
-            steps.append((self.norm_conv, lambda y: self.conv_module(y), 1.0))
-        steps.append((self.norm_ff, lambda y: self.feed_forward(y), self.ff_scale))
+            steps.append((self.norm_conv, lambda y: self.conv_module(y, klens), 1.0))
+        steps.append((self.norm_ff, ff(self.feed_forward), self.ff_scale))
         if pre:
             y = steps[0][0](x)
             for i, (_, fn, scale) in enumerate(steps):

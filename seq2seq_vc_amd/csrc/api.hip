@@ -16,7 +16,7 @@ extern "C" const char* s2svc_last_error(void) {
   g_err[0] = 0;
   return out;
 }
-extern "C" int s2svc_abi_version(void) { return 1; }
+extern "C" int s2svc_abi_version(void) { return 2; }
 
 // The launch floor of this stack, measured rather than assumed: a kernel whose workgroups do nothing but store one word each.
 // bench.py times it inside the same graph loops as the memory-bound kernels (their bytes / s are rated against the HBM peak with

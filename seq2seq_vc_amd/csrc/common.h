@@ -160,6 +160,25 @@ __device__ __forceinline__ void dropout_scale8(uint64_t seed, uint64_t idx, floa
   }
 }
 
+// ---- absent rows (captured training steps on batches that do not fill their padded shape) ----
+// A (B, Tn, C) activation of a captured step is allocated at the PADDED length Tn, while the reference computes on the batch cropped to
+// its longest utterance (models/vtn.py:208-214, models/aas_vc.py:523-524).  Kernels that mix along time or over the batch (BatchNorm
+// statistics, the depthwise convolution of the Conformer module, nearest-neighbour resampling) take `vlens` (B int32, device memory,
+// graph DATA: modules.LensBank): row r = b * Tn + t is ABSENT when t >= vlens[b] -- it is excluded from every sum and count, read as
+// the convolution's zero padding, and written as zero on the way out (forward and backward).  vlens == nullptr: every row is present.
+__device__ __forceinline__ bool row_present(int r, int Tn, const int32_t* __restrict__ vlens) {
+  if (!vlens) return true;
+  const int b = r / Tn;
+  return r - b * Tn < vlens[b];
+}
+// number of present rows (every thread computes it: B is a batch size, the loads are uniform and cached)
+__device__ __forceinline__ int rows_present(int rows, int Tn, const int32_t* __restrict__ vlens) {
+  if (!vlens) return rows;
+  int n = 0;
+  for (int b = 0; b < rows / Tn; ++b) n += vlens[b] < Tn ? (vlens[b] > 0 ? vlens[b] : 0) : Tn;
+  return n;
+}
+
 // error plumbing shared by all translation units (defined in api.hip)
 extern "C" void s2svc_set_error(const char* msg);
 #define S2S_CHECK_LAUNCH(name)                                         \

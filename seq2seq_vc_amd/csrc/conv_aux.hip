@@ -79,31 +79,41 @@ __global__ void col2im_s2_vec_kernel(int B, int T1, int F1, int C, int T2, int F
 
 // nearest-neighbour resampling along time of channel-last rows: y[b, t, :] = x[b, floor(t*Tin/Tout), :]
 // (F.interpolate(mode="nearest") as used at models/aas_vc.py:340-349)
+// ext_in / ext_out (captured steps on batches that do not fill their padded shape, common.h "absent rows"): the lengths the reference's
+// cropped tensors have -- they set the scale; output frames >= *ext_out are written as zero, input frames >= *ext_in never read.
 template <typename T>
-__global__ void interp_nearest_kernel(int B, int Tin, int Tout, int C, const T* __restrict__ x, T* __restrict__ y) {
-  const int64_t n = (int64_t)B * Tout * C;
+__global__ void interp_nearest_kernel(int B, int Tin_cap, int Tout_cap, int C, const T* __restrict__ x, T* __restrict__ y,
+                                      const int32_t* __restrict__ ext_in, const int32_t* __restrict__ ext_out) {
+  const int64_t n = (int64_t)B * Tout_cap * C;
+  const int Tin = ext_in ? (ext_in[0] < Tin_cap ? (ext_in[0] > 0 ? ext_in[0] : 1) : Tin_cap) : Tin_cap;
+  const int Tout = ext_out ? (ext_out[0] < Tout_cap ? (ext_out[0] > 0 ? ext_out[0] : 1) : Tout_cap) : Tout_cap;
   const float scale = (float)Tin / (float)Tout;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const int64_t r = i / C;
-    const int t = (int)(r % Tout);
-    const int b = (int)(r / Tout);
+    const int t = (int)(r % Tout_cap);
+    const int b = (int)(r / Tout_cap);
     int src = (int)floorf((float)t * scale);
     if (src > Tin - 1) src = Tin - 1;
-    y[i] = x[((int64_t)b * Tin + src) * C + c];
+    if (t < Tout) y[i] = x[((int64_t)b * Tin_cap + src) * C + c];
+    else stf(y + i, 0.f);
   }
 }
 // backward: dx[b, s, :] = sum over t with src(t) == s of dy[b, t, :]
 template <typename T>
-__global__ void interp_nearest_bwd_kernel(int B, int Tin, int Tout, int C, const T* __restrict__ dy, T* __restrict__ dx) {
-  const int64_t n = (int64_t)B * Tin * C;
+__global__ void interp_nearest_bwd_kernel(int B, int Tin_cap, int Tout_cap, int C, const T* __restrict__ dy, T* __restrict__ dx,
+                                          const int32_t* __restrict__ ext_in, const int32_t* __restrict__ ext_out) {
+  const int64_t n = (int64_t)B * Tin_cap * C;
+  const int Tin = ext_in ? (ext_in[0] < Tin_cap ? (ext_in[0] > 0 ? ext_in[0] : 1) : Tin_cap) : Tin_cap;
+  const int Tout = ext_out ? (ext_out[0] < Tout_cap ? (ext_out[0] > 0 ? ext_out[0] : 1) : Tout_cap) : Tout_cap;
   const float scale = (float)Tin / (float)Tout;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const int64_t r = i / C;
-    const int s = (int)(r % Tin);
-    const int b = (int)(r / Tin);
+    const int s = (int)(r % Tin_cap);
+    const int b = (int)(r / Tin_cap);
     float acc = 0.f;
+    if (s >= Tin) { stf(dx + i, 0.f); continue; }
     // candidate output frames: t in [ceil(s/scale) - 1, ceil((s+1)/scale) + 1]
     int lo = (int)floorf((float)s / scale) - 1, hi = (int)ceilf((float)(s + 1) / scale) + 1;
     if (lo < 0) lo = 0;
@@ -111,7 +121,7 @@ __global__ void interp_nearest_bwd_kernel(int B, int Tin, int Tout, int C, const
     for (int t = lo; t <= hi; ++t) {
       int src = (int)floorf((float)t * scale);
       if (src > Tin - 1) src = Tin - 1;
-      if (src == s) acc += ldf(dy + ((int64_t)b * Tout + t) * C + c);
+      if (src == s) acc += ldf(dy + ((int64_t)b * Tout_cap + t) * C + c);
     }
     stf(dx + i, acc);
   }
@@ -139,26 +149,28 @@ extern "C" int s2svc_col2im_s2(int dtype, int B, int T1, int F1, int C, int T2, 
   return 0;
 }
 
-extern "C" int s2svc_interp_nearest(int dtype, int B, int Tin, int Tout, int C, const void* x, void* y, void* stream) {
+extern "C" int s2svc_interp_nearest(int dtype, int B, int Tin, int Tout, int C, const void* x, void* y, const int32_t* ext_in,
+                                    const int32_t* ext_out, void* stream) {
   const int64_t n = (int64_t)B * Tout * C;
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(interp_nearest_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tin, Tout, C, (const float*)x, (float*)y);
+    hipLaunchKernelGGL(interp_nearest_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tin, Tout, C, (const float*)x, (float*)y, ext_in, ext_out);
   else
-    hipLaunchKernelGGL(interp_nearest_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tin, Tout, C, (const bf16_t*)x, (bf16_t*)y);
+    hipLaunchKernelGGL(interp_nearest_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tin, Tout, C, (const bf16_t*)x, (bf16_t*)y, ext_in, ext_out);
   S2S_CHECK_LAUNCH("interp_nearest_kernel");
   return 0;
 }
 
-extern "C" int s2svc_interp_nearest_bwd(int dtype, int B, int Tin, int Tout, int C, const void* dy, void* dx, void* stream) {
+extern "C" int s2svc_interp_nearest_bwd(int dtype, int B, int Tin, int Tout, int C, const void* dy, void* dx, const int32_t* ext_in,
+                                        const int32_t* ext_out, void* stream) {
   const int64_t n = (int64_t)B * Tin * C;
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
-    hipLaunchKernelGGL(interp_nearest_bwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tin, Tout, C, (const float*)dy, (float*)dx);
+    hipLaunchKernelGGL(interp_nearest_bwd_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tin, Tout, C, (const float*)dy, (float*)dx, ext_in, ext_out);
   else
-    hipLaunchKernelGGL(interp_nearest_bwd_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tin, Tout, C, (const bf16_t*)dy, (bf16_t*)dx);
+    hipLaunchKernelGGL(interp_nearest_bwd_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, B, Tin, Tout, C, (const bf16_t*)dy, (bf16_t*)dx, ext_in, ext_out);
   S2S_CHECK_LAUNCH("interp_nearest_bwd_kernel");
   return 0;
 }

@@ -36,12 +36,13 @@ __device__ __forceinline__ void st8(float* p, const float (&f)[8]) {
 template <int KS>
 __global__ __launch_bounds__(256) void convmod_fwd_kernel(int Tn, int C, const bf16_t* __restrict__ y2, const float* __restrict__ w,
                                                           const float* __restrict__ bias, bf16_t* __restrict__ z,
-                                                          float* __restrict__ ws, int tchunks) {
+                                                          float* __restrict__ ws, int tchunks, const int32_t* __restrict__ vlens) {
   constexpr int PAD = (KS - 1) / 2, ROWS = TT + 2 * PAD, WIN = FR + KS - 1, NP = (ROWS + 31) / 32;
   __shared__ __attribute__((aligned(16))) float G[ROWS * CT];
   __shared__ float red[2][4][CT];
   const int c0 = blockIdx.x * CT;
   const int b = blockIdx.y / tchunks, t0 = (blockIdx.y % tchunks) * TT;
+  const int Te = vlens ? (vlens[b] < Tn ? vlens[b] : Tn) : Tn;      // frames >= Te are absent (common.h): zero padding, not in the statistics
   const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
   const int cl = threadIdx.x & 63, rq = threadIdx.x >> 6;
   const bf16_t* yb = y2 + (int64_t)b * Tn * 2 * C + c0 + v * 8;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void convmod_fwd_kernel(int Tn, int C, const b
     const int p = r8 + 32 * i, t = t0 - PAD + p;
     av[i] = make_uint4(0, 0, 0, 0);
     gv[i] = make_uint4(0, 0, 0, 0);
-    if (p < ROWS && t >= 0 && t < Tn) {
+    if (p < ROWS && t >= 0 && t < Te) {
       av[i] = *reinterpret_cast<const uint4*>(yb + (int64_t)t * 2 * C);
       gv[i] = *reinterpret_cast<const uint4*>(yb + (int64_t)t * 2 * C + C);
     }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void convmod_fwd_kernel(int Tn, int C, const b
 #pragma unroll
     for (int j = 0; j < KS; ++j) acc += wr[j] * win[o + j];
     out[o] = round_bf(acc);
-    if (t0 + rq * FR + o < Tn) { s0 += out[o]; s1 += out[o] * out[o]; }
+    if (t0 + rq * FR + o < Te) { s0 += out[o]; s1 += out[o] * out[o]; }
   }
   __syncthreads();
 #pragma unroll
@@ -111,10 +112,12 @@ __global__ __launch_bounds__(256) void convmod_fwd_kernel(int Tn, int C, const b
 }
 
 // sum of the chunk partials (sum z, sum z^2) -> mean, rstd, running statistics (the arithmetic of bn_stage2_finalize_kernel)
-__global__ __launch_bounds__(256) void convmod_bn_finalize_kernel(int C, int chunks, const float* __restrict__ ws, int n, float eps,
+__global__ __launch_bounds__(256) void convmod_bn_finalize_kernel(int C, int chunks, const float* __restrict__ ws, int rows, float eps,
                                                                   float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                                   float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                                  int64_t* __restrict__ num_batches) {
+                                                                  int64_t* __restrict__ num_batches, int Tn,
+                                                                  const int32_t* __restrict__ vlens) {
+  const int n = rows_present(rows, Tn, vlens);
   __shared__ float sh[2][4][64];
   const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -148,7 +151,8 @@ __global__ __launch_bounds__(256) void convmod_bn_finalize_kernel(int C, int chu
 // out = swish((z - mean) * rstd * gamma + beta), a workgroup = 64 channels x rows_per_wg rows
 __global__ __launch_bounds__(256) void bn_swish_apply_kernel(int rows, int C, const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, bf16_t* __restrict__ out, int rows_per_wg) {
+                                                             const float* __restrict__ beta, bf16_t* __restrict__ out, int rows_per_wg,
+                                                             int Tn, const int32_t* __restrict__ vlens) {
   const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
   const int c = blockIdx.x * CT + v * 8;
   const int r0 = blockIdx.y * rows_per_wg;
@@ -163,6 +167,10 @@ __global__ __launch_bounds__(256) void bn_swish_apply_kernel(int rows, int C, co
 #pragma unroll 4
   for (int r = r0 + r8; r < r1; r += 32) {
     float f[8];
+    if (!row_present(r, Tn, vlens)) {               // absent frame: zero for whatever reads it as a convolution's padding
+      *reinterpret_cast<uint4*>(out + (int64_t)r * C + c) = make_uint4(0, 0, 0, 0);
+      continue;
+    }
     unpack_bf16x8(*reinterpret_cast<const uint4*>(z + (int64_t)r * C + c), f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -183,7 +191,7 @@ __device__ __forceinline__ float dswish(float pre) {
 __global__ __launch_bounds__(256) void convmod_bwd_stats_kernel(int rows, int C, const bf16_t* __restrict__ da, const bf16_t* __restrict__ z,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ ws) {
+                                                                float* __restrict__ ws, int Tn, const int32_t* __restrict__ vlens) {
   __shared__ float sh[2][4][CT];
   const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int c = blockIdx.x * CT + v * 8;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void convmod_bwd_stats_kernel(int rows, int C,
     const int r = r0 + r8 + 32 * i;
     dv[i] = make_uint4(0, 0, 0, 0);
     zv[i] = make_uint4(0, 0, 0, 0);
-    if (r < rows) {
+    if (r < rows && row_present(r, Tn, vlens)) {
       dv[i] = *reinterpret_cast<const uint4*>(da + (int64_t)r * C + c);
       zv[i] = *reinterpret_cast<const uint4*>(z + (int64_t)r * C + c);
     }
@@ -266,13 +274,13 @@ __global__ __launch_bounds__(256) void convmod_sum2_kernel(int C, int chunks, co
 }
 
 template <int KS>
-__global__ __launch_bounds__(256) void convmod_bwd_kernel(int Tn, int C, float inv_n, const bf16_t* __restrict__ da,
+__global__ __launch_bounds__(256) void convmod_bwd_kernel(int Tn, int C, const bf16_t* __restrict__ da,
                                                           const bf16_t* __restrict__ z, const bf16_t* __restrict__ y2,
                                                           const float* __restrict__ w, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ sdy,
                                                           const float* __restrict__ sdyx, bf16_t* __restrict__ dy2,
-                                                          float* __restrict__ wsw, int tchunks) {
+                                                          float* __restrict__ wsw, int tchunks, const int32_t* __restrict__ vlens) {
   constexpr int PAD = (KS - 1) / 2, ROWS = TT + 2 * PAD, WIN = FR + KS - 1, NP = (ROWS + 31) / 32;
   constexpr int RED_ROWS = 4 * (KS + 1);
   constexpr int SM_ROWS = (2 * ROWS > TT + RED_ROWS) ? 2 * ROWS : TT + RED_ROWS;
@@ -288,6 +296,8 @@ __global__ __launch_bounds__(256) void convmod_bwd_kernel(int Tn, int C, float i
   const bf16_t* yb = y2 + (int64_t)b * Tn * 2 * C + cv;
   const bf16_t* dab = da + (int64_t)b * Tn * C + cv;
   const bf16_t* zb = z + (int64_t)b * Tn * C + cv;
+  const int Te = vlens ? (vlens[b] < Tn ? vlens[b] : Tn) : Tn;      // frames >= Te are absent (common.h)
+  const float inv_n = 1.0f / (float)rows_present((int)(gridDim.y / tchunks) * Tn, Tn, vlens);
   // ---- phase 1
   {
     float k_s[8], k_b[8], k_m[8], k_r[8], k_1[8], k_2[8], k_3[8];
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(256) void convmod_bwd_kernel(int Tn, int C, float i
       const int p = r8 + 32 * i, t = t0 - PAD + p;
       if (p < ROWS) {
         float dz[8], g[8];
-        if (t >= 0 && t < Tn) {
+        if (t >= 0 && t < Te) {
           float d[8], zz[8], a[8], gt[8];
           unpack_bf16x8(*reinterpret_cast<const uint4*>(dab + (int64_t)t * C), d);
           unpack_bf16x8(*reinterpret_cast<const uint4*>(zb + (int64_t)t * C), zz);
@@ -378,7 +388,10 @@ __global__ __launch_bounds__(256) void convmod_bwd_kernel(int Tn, int C, float i
 #pragma unroll
   for (int i = 0; i < TT / 32; ++i) {
     const int r = r8 + 32 * i, t = t0 + r;
-    if (t < Tn) {
+    if (t >= Te && t < Tn) {                       // absent frame: no gradient leaves it
+      *reinterpret_cast<uint4*>(ob + (int64_t)t * 2 * C) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(ob + (int64_t)t * 2 * C + C) = make_uint4(0, 0, 0, 0);
+    } else if (t < Tn) {
       float a[8], gt[8], d[8], oa[8], og[8];
       unpack_bf16x8(*reinterpret_cast<const uint4*>(yb + (int64_t)t * 2 * C), a);
       unpack_bf16x8(*reinterpret_cast<const uint4*>(yb + (int64_t)t * 2 * C + C), gt);
@@ -454,7 +467,8 @@ __device__ __forceinline__ void bn_chunk_reduce(float (&a0)[8], float (&a1)[8], 
   (void)c;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_vec_kernel(int rows, int C, const bf16_t* __restrict__ x, float* __restrict__ ws, int rpc) {
+__global__ __launch_bounds__(256) void bn_stats_vec_kernel(int rows, int C, const bf16_t* __restrict__ x, float* __restrict__ ws, int rpc,
+                                                           int Tn, const int32_t* __restrict__ vlens) {
   __shared__ float sh[2][4][CT];
   const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
   const int c = blockIdx.x * CT + v * 8;
@@ -466,6 +480,7 @@ __global__ __launch_bounds__(256) void bn_stats_vec_kernel(int rows, int C, cons
   if (c < C) {
 #pragma unroll 4
     for (int r = r0 + r8; r < r1; r += 32) {
+      if (!row_present(r, Tn, vlens)) continue;
       float f[8];
       unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (int64_t)r * C + c), f);
 #pragma unroll
@@ -480,7 +495,8 @@ __global__ __launch_bounds__(256) void bn_act_apply_vec_kernel(int rows, int C, 
                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int act, float p,
                                                                const uint64_t* seed_base, uint64_t seed_off, bf16_t* __restrict__ y,
-                                                               bf16_t* __restrict__ pre_act, int rows_per_wg) {
+                                                               bf16_t* __restrict__ pre_act, int rows_per_wg, int Tn,
+                                                               const int32_t* __restrict__ vlens) {
   const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
   const int c = blockIdx.x * CT + v * 8;
   if (c >= C) return;
@@ -497,6 +513,11 @@ __global__ __launch_bounds__(256) void bn_act_apply_vec_kernel(int rows, int C, 
   for (int r = r0 + r8; r < r1; r += 32) {
     const int64_t o = (int64_t)r * C + c;
     float f[8], mk[8];
+    if (!row_present(r, Tn, vlens)) {               // absent frame: the next convolution's zero padding
+      if (pre_act) *reinterpret_cast<uint4*>(pre_act + o) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(y + o) = make_uint4(0, 0, 0, 0);
+      continue;
+    }
     unpack_bf16x8(*reinterpret_cast<const uint4*>(x + o), f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] = (f[e] - m[e]) * rs[e] * ga[e] + be[e];
@@ -515,7 +536,8 @@ __global__ __launch_bounds__(256) void bn_act_apply_vec_kernel(int rows, int C, 
 __global__ __launch_bounds__(256) void bn_act_bwd_stats_kernel(int rows, int C, const bf16_t* __restrict__ dz, const bf16_t* __restrict__ saved,
                                                                const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, int act, float p,
-                                                               const uint64_t* seed_base, uint64_t seed_off, float* __restrict__ ws, int rpc) {
+                                                               const uint64_t* seed_base, uint64_t seed_off, float* __restrict__ ws, int rpc,
+                                                               int Tn, const int32_t* __restrict__ vlens) {
   __shared__ float sh[2][4][CT];
   const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
   const int c = blockIdx.x * CT + v * 8;
@@ -532,6 +554,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stats_kernel(int rows, int C, 
     ldp8(rstd + c, rs);
 #pragma unroll 2
     for (int r = r0 + r8; r < r1; r += 32) {
+      if (!row_present(r, Tn, vlens)) continue;
       const int64_t o = (int64_t)r * C + c;
       float g[8], sd[8], xx[8], mk[8];
       unpack_bf16x8(*reinterpret_cast<const uint4*>(dz + o), g);
@@ -551,16 +574,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stats_kernel(int rows, int C, 
 }
 
 // dx = gamma * rstd * (g - sum_g / N - xhat * sum_g_xhat / N), g recomputed as above
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(int rows, int C, float inv_n, const bf16_t* __restrict__ dz,
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(int rows, int C, const bf16_t* __restrict__ dz,
                                                                const bf16_t* __restrict__ saved, const bf16_t* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ sdy,
                                                                const float* __restrict__ sdyx, int act, float p,
                                                                const uint64_t* seed_base, uint64_t seed_off, bf16_t* __restrict__ dx,
-                                                               int rows_per_wg) {
+                                                               int rows_per_wg, int Tn, const int32_t* __restrict__ vlens) {
   const int v = threadIdx.x & 7, r8 = threadIdx.x >> 3;
   const int c = blockIdx.x * CT + v * 8;
   if (c >= C) return;
+  const float inv_n = 1.0f / (float)rows_present(rows, Tn, vlens);
   const int r0 = blockIdx.y * rows_per_wg;
   const int r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
@@ -577,6 +601,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(int rows, int C, 
   for (int r = r0 + r8; r < r1; r += 32) {
     const int64_t o = (int64_t)r * C + c;
     float g[8], sd[8], xx[8], mk[8];
+    if (!row_present(r, Tn, vlens)) {               // absent frame: no gradient leaves it
+      *reinterpret_cast<uint4*>(dx + o) = make_uint4(0, 0, 0, 0);
+      continue;
+    }
     unpack_bf16x8(*reinterpret_cast<const uint4*>(dz + o), g);
     if (saved) unpack_bf16x8(*reinterpret_cast<const uint4*>(saved + o), sd);
     unpack_bf16x8(*reinterpret_cast<const uint4*>(x + o), xx);
@@ -604,32 +632,33 @@ extern "C" int s2svc_convmod_supported(int C, int ks) { return (C > 0 && C % 64 
 
 extern "C" int s2svc_convmod_fwd(int B, int Tn, int C, int ks, const void* y2, const float* w, const float* bias, void* z, float eps,
                                  float momentum, float* mean, float* rstd, float* run_mean, float* run_var, int64_t* num_batches,
-                                 float* ws, void* stream) {
+                                 float* ws, const int32_t* vlens, void* stream) {
   S2S_REQUIRE(B > 0 && Tn > 0 && s2svc_convmod_supported(C, ks), "convmod_fwd: C must be a multiple of 64, kernel size 7 / 15 / 31");
   S2S_REQUIRE(y2 && w && z && mean && rstd && ws && aligned16(y2) && aligned16(z), "convmod_fwd: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int tchunks = (Tn + TT - 1) / TT;
   dim3 grid(C / CT, B * tchunks);
 #define S2S_CM_FWD(K)                                                                                                           \
-  hipLaunchKernelGGL(convmod_fwd_kernel<K>, grid, dim3(256), 0, st, Tn, C, (const bf16_t*)y2, w, bias, (bf16_t*)z, ws, tchunks)
+  hipLaunchKernelGGL(convmod_fwd_kernel<K>, grid, dim3(256), 0, st, Tn, C, (const bf16_t*)y2, w, bias, (bf16_t*)z, ws, tchunks, vlens)
   if (ks == 7) S2S_CM_FWD(7);
   else if (ks == 15) S2S_CM_FWD(15);
   else S2S_CM_FWD(31);
 #undef S2S_CM_FWD
   S2S_CHECK_LAUNCH("convmod_fwd_kernel");
   hipLaunchKernelGGL(convmod_bn_finalize_kernel, dim3(C / 64), dim3(256), 0, st, C, B * tchunks, ws, B * Tn, eps, momentum, mean, rstd,
-                     run_mean, run_var, num_batches);
+                     run_mean, run_var, num_batches, Tn, vlens);
   S2S_CHECK_LAUNCH("convmod_bn_finalize_kernel");
   return 0;
 }
 
 extern "C" int s2svc_bn_swish_apply(int64_t rows, int C, const void* z, const float* mean, const float* rstd, const float* gamma,
-                                    const float* beta, void* out, void* stream) {
+                                    const float* beta, void* out, int Tn, const int32_t* vlens, void* stream) {
   S2S_REQUIRE(rows > 0 && C > 0 && C % 64 == 0 && z && mean && rstd && gamma && beta && out && aligned16(z) && aligned16(out),
               "bn_swish_apply: bad args (bf16, C % 64 == 0)");
+  S2S_REQUIRE(!vlens || (Tn > 0 && rows % Tn == 0), "bn_swish_apply: vlens needs rows = B * Tn");
   const int rpw = 128;
   hipLaunchKernelGGL(bn_swish_apply_kernel, dim3(C / CT, (int)((rows + rpw - 1) / rpw)), dim3(256), 0, (hipStream_t)stream, (int)rows, C,
-                     (const bf16_t*)z, mean, rstd, gamma, beta, (bf16_t*)out, rpw);
+                     (const bf16_t*)z, mean, rstd, gamma, beta, (bf16_t*)out, rpw, Tn, vlens);
   S2S_CHECK_LAUNCH("bn_swish_apply_kernel");
   return 0;
 }
@@ -637,23 +666,23 @@ extern "C" int s2svc_bn_swish_apply(int64_t rows, int C, const void* z, const fl
 // ws_stats >= ceil(B*Tn / 64) * 2 * C floats, ws_w >= B * ceil(Tn / 64) * C * (ks + 1) floats
 extern "C" int s2svc_convmod_bwd(int B, int Tn, int C, int ks, const void* da, const void* z, const void* y2, const float* w,
                                  const float* mean, const float* rstd, const float* gamma, const float* beta, void* dy2, float* sdy,
-                                 float* sdyx, float* dgamma_acc, float* dbeta_acc, float* ws_stats, float* ws_w, void* stream) {
+                                 float* sdyx, float* dgamma_acc, float* dbeta_acc, float* ws_stats, float* ws_w, const int32_t* vlens,
+                                 void* stream) {
   S2S_REQUIRE(B > 0 && Tn > 0 && s2svc_convmod_supported(C, ks), "convmod_bwd: C must be a multiple of 64, kernel size 7 / 15 / 31");
   S2S_REQUIRE(da && z && y2 && w && mean && rstd && gamma && beta && dy2 && sdy && sdyx && ws_stats && ws_w && aligned16(da) &&
               aligned16(z) && aligned16(y2) && aligned16(dy2), "convmod_bwd: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int rows = B * Tn, chunks = (rows + 63) / 64;
   hipLaunchKernelGGL(convmod_bwd_stats_kernel, dim3(C / CT, chunks), dim3(256), 0, st, rows, C, (const bf16_t*)da, (const bf16_t*)z, mean,
-                     rstd, gamma, beta, ws_stats);
+                     rstd, gamma, beta, ws_stats, Tn, vlens);
   S2S_CHECK_LAUNCH("convmod_bwd_stats_kernel");
   hipLaunchKernelGGL(convmod_sum2_kernel, dim3(C / 64), dim3(256), 0, st, C, chunks, ws_stats, sdy, sdyx, dbeta_acc, dgamma_acc);
   S2S_CHECK_LAUNCH("convmod_sum2_kernel");
   const int tchunks = (Tn + TT - 1) / TT;
   dim3 grid(C / CT, B * tchunks);
-  const float inv_n = 1.0f / (float)rows;
 #define S2S_CM_BWD(K)                                                                                                              \
-  hipLaunchKernelGGL(convmod_bwd_kernel<K>, grid, dim3(256), 0, st, Tn, C, inv_n, (const bf16_t*)da, (const bf16_t*)z,             \
-                     (const bf16_t*)y2, w, mean, rstd, gamma, beta, sdy, sdyx, (bf16_t*)dy2, ws_w, tchunks)
+  hipLaunchKernelGGL(convmod_bwd_kernel<K>, grid, dim3(256), 0, st, Tn, C, (const bf16_t*)da, (const bf16_t*)z,                    \
+                     (const bf16_t*)y2, w, mean, rstd, gamma, beta, sdy, sdyx, (bf16_t*)dy2, ws_w, tchunks, vlens)
   if (ks == 7) S2S_CM_BWD(7);
   else if (ks == 15) S2S_CM_BWD(15);
   else S2S_CM_BWD(31);
@@ -674,26 +703,29 @@ extern "C" int s2svc_convmod_wgrad_final(int C, int ks, int chunks, const float*
 // ---- BatchNorm1d (training) + activation + dropout, bf16, C % 8 == 0 (see above) ----
 // mean / rstd of x (rows, C) + running statistics: two launches.  ws >= ceil(rows / 64) * 2 * C floats.
 extern "C" int s2svc_bn_stats_vec(int rows, int C, const void* x, float eps, float momentum, float* mean, float* rstd, float* run_mean,
-                                  float* run_var, int64_t* num_batches, float* ws, void* stream) {
+                                  float* run_var, int64_t* num_batches, float* ws, int Tn, const int32_t* vlens, void* stream) {
   S2S_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && x && mean && rstd && ws && aligned16(x), "bn_stats_vec: bad args (bf16, C % 8 == 0)");
+  S2S_REQUIRE(!vlens || (Tn > 0 && rows % Tn == 0), "bn_stats_vec: vlens needs rows = B * Tn");
   hipStream_t st = (hipStream_t)stream;
   const int rpc = bn_rows_per_chunk(rows), chunks = (rows + rpc - 1) / rpc, ct = (C + CT - 1) / CT;
-  hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(ct, chunks), dim3(256), 0, st, rows, C, (const bf16_t*)x, ws, rpc);
+  hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(ct, chunks), dim3(256), 0, st, rows, C, (const bf16_t*)x, ws, rpc, Tn, vlens);
   S2S_CHECK_LAUNCH("bn_stats_vec_kernel");
   hipLaunchKernelGGL(convmod_bn_finalize_kernel, dim3(ct), dim3(256), 0, st, C, chunks, ws, rows, eps, momentum, mean, rstd, run_mean,
-                     run_var, num_batches);
+                     run_var, num_batches, Tn, vlens);
   S2S_CHECK_LAUNCH("convmod_bn_finalize_kernel");
   return 0;
 }
 
 extern "C" int s2svc_bn_act_apply_vec(int rows, int C, const void* x, const float* mean, const float* rstd, const float* gamma,
                                       const float* beta, int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y,
-                                      void* pre_act, void* stream) {
+                                      void* pre_act, int Tn, const int32_t* vlens, void* stream) {
+  S2S_REQUIRE(!vlens || (Tn > 0 && rows % Tn == 0), "bn_act_apply_vec: vlens needs rows = B * Tn");
   S2S_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && x && mean && rstd && gamma && beta && y && aligned16(x) && aligned16(y) &&
               aligned16(pre_act), "bn_act_apply_vec: bad args (bf16, C % 8 == 0)");
   const int rpw = 128;
   hipLaunchKernelGGL(bn_act_apply_vec_kernel, dim3((C + CT - 1) / CT, (rows + rpw - 1) / rpw), dim3(256), 0, (hipStream_t)stream, rows, C,
-                     (const bf16_t*)x, mean, rstd, gamma, beta, act, drop_p, seed_base, seed_off, (bf16_t*)y, (bf16_t*)pre_act, rpw);
+                     (const bf16_t*)x, mean, rstd, gamma, beta, act, drop_p, seed_base, seed_off, (bf16_t*)y, (bf16_t*)pre_act, rpw, Tn,
+                     vlens);
   S2S_CHECK_LAUNCH("bn_act_apply_vec_kernel");
   return 0;
 }
@@ -703,20 +735,22 @@ extern "C" int s2svc_bn_act_apply_vec(int rows, int C, const void* x, const floa
 // given).  Three launches.  ws >= ceil(rows / 64) * 2 * C floats.
 extern "C" int s2svc_bn_act_bwd_vec(int rows, int C, const void* dz, const void* saved, const void* x, const float* mean, const float* rstd,
                                     const float* gamma, int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* dx,
-                                    float* sdy, float* sdyx, float* dgamma_acc, float* dbeta_acc, float* ws, void* stream) {
+                                    float* sdy, float* sdyx, float* dgamma_acc, float* dbeta_acc, float* ws, int Tn, const int32_t* vlens,
+                                    void* stream) {
+  S2S_REQUIRE(!vlens || (Tn > 0 && rows % Tn == 0), "bn_act_bwd_vec: vlens needs rows = B * Tn");
   S2S_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && dz && x && mean && rstd && gamma && dx && sdy && sdyx && ws && aligned16(dz) &&
               aligned16(saved) && aligned16(x) && aligned16(dx) && (saved || act == S2S_ACT_NONE), "bn_act_bwd_vec: bad args (bf16, C % 8 == 0)");
   hipStream_t st = (hipStream_t)stream;
   const int rpc = bn_rows_per_chunk(rows), chunks = (rows + rpc - 1) / rpc, ct = (C + CT - 1) / CT;
   hipLaunchKernelGGL(bn_act_bwd_stats_kernel, dim3(ct, chunks), dim3(256), 0, st, rows, C, (const bf16_t*)dz, (const bf16_t*)saved,
-                     (const bf16_t*)x, mean, rstd, act, drop_p, seed_base, seed_off, ws, rpc);
+                     (const bf16_t*)x, mean, rstd, act, drop_p, seed_base, seed_off, ws, rpc, Tn, vlens);
   S2S_CHECK_LAUNCH("bn_act_bwd_stats_kernel");
   hipLaunchKernelGGL(convmod_sum2_kernel, dim3(ct), dim3(256), 0, st, C, chunks, ws, sdy, sdyx, dbeta_acc, dgamma_acc);
   S2S_CHECK_LAUNCH("convmod_sum2_kernel");
   const int rpw = 128;
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ct, (rows + rpw - 1) / rpw), dim3(256), 0, st, rows, C, 1.0f / (float)rows,
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ct, (rows + rpw - 1) / rpw), dim3(256), 0, st, rows, C,
                      (const bf16_t*)dz, (const bf16_t*)saved, (const bf16_t*)x, mean, rstd, gamma, sdy, sdyx, act, drop_p, seed_base,
-                     seed_off, (bf16_t*)dx, rpw);
+                     seed_off, (bf16_t*)dx, rpw, Tn, vlens);
   S2S_CHECK_LAUNCH("bn_act_bwd_apply_kernel");
   return 0;
 }

@@ -371,11 +371,13 @@ __global__ __launch_bounds__(512) void ln_bwd_vec_pg_kernel(int rows, int D, int
 //   mode 7 (grouped launch only): the chunk partials are already in ws[ws_chunks][2][D] (ln_bwd_vec_pg_kernel): stage 2 only
 // stage 1 writes ws[chunk][2][D]; stage 2 sums the chunks and multiplies by `scale`.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// MASKED: rows r = b * Tn + t with t >= vlens[b] are absent (common.h) and skipped
+template <typename T, bool MASKED = false>
 __device__ __forceinline__ void colreduce_stage1_body(int rows, int D, int mode, const T* __restrict__ dy,
                                                       const T* __restrict__ x, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, float* __restrict__ ws,
-                                                      int rows_per_chunk, int bx, int chunk, float (&sh)[2][4][64]) {
+                                                      int rows_per_chunk, int bx, int chunk, float (&sh)[2][4][64], int Tn = 0,
+                                                      const int32_t* __restrict__ vlens = nullptr) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = bx * 64 + cl;
   const int r0 = chunk * rows_per_chunk;
@@ -385,6 +387,7 @@ __device__ __forceinline__ void colreduce_stage1_body(int rows, int D, int mode,
     float mc = 0.f, rc = 1.f;
     if (mode == 2 || mode == 3) { mc = mean[c]; rc = rstd ? rstd[c] : 1.f; }
     for (int r = r0 + rl; r < r1; r += 4) {
+      if (MASKED && !row_present(r, Tn, vlens)) continue;
       const int64_t o = (int64_t)r * D + c;
       if (mode == 0) {
         s0 += ldf(dy + o);
@@ -512,6 +515,15 @@ __global__ __launch_bounds__(256) void colreduce_stage1(int rows, int D, int mod
   colreduce_stage1_body<T>(rows, D, mode, dy, x, mean, rstd, ws, rows_per_chunk, blockIdx.x, blockIdx.y, sh);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void colreduce_stage1_masked(int rows, int D, int mode, const T* __restrict__ dy,
+                                                               const T* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ ws,
+                                                               int rows_per_chunk, int Tn, const int32_t* __restrict__ vlens) {
+  __shared__ float sh[2][4][64];
+  colreduce_stage1_body<T, true>(rows, D, mode, dy, x, mean, rstd, ws, rows_per_chunk, blockIdx.x, blockIdx.y, sh, Tn, vlens);
+}
+
 __global__ __launch_bounds__(256) void colreduce_stage1_vec(int rows, int D, int mode, const bf16_t* __restrict__ dy,
                                                             const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ ws,
@@ -546,9 +558,12 @@ __device__ __forceinline__ void colreduce_stage2_body(int D, int chunks, const f
   }
 }
 
+// scale < 0: the mean over the PRESENT rows (scale = 1 / their number, from rows / Tn / vlens)
 __global__ __launch_bounds__(256) void colreduce_stage2(int D, int chunks, const float* __restrict__ ws, float scale,
-                                                        float* __restrict__ out_sum, float* __restrict__ out_dot, int accumulate) {
+                                                        float* __restrict__ out_sum, float* __restrict__ out_dot, int accumulate,
+                                                        int rows, int Tn, const int32_t* __restrict__ vlens) {
   __shared__ float sh[2][4][64];
+  if (scale < 0.f) scale = 1.0f / (float)rows_present(rows, Tn, vlens);
   colreduce_stage2_body(D, chunks, ws, scale, out_sum, out_dot, accumulate, blockIdx.x, sh);
 }
 
@@ -599,11 +614,16 @@ template <typename T>
 __global__ void bn_apply_kernel(int64_t total, int C, const T* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, int act, float p, const uint64_t* seed_base, uint64_t seed_off, T* __restrict__ y,
-                                T* __restrict__ pre_act) {
+                                T* __restrict__ pre_act, int Tn, const int32_t* __restrict__ vlens) {
   const uint64_t seed = (seed_base ? *seed_base : 0ull) + seed_off;
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
+    if (vlens && !row_present((int)(i / C), Tn, vlens)) {      // absent frame (common.h): the next convolution's zero padding
+      if (pre_act) stf(pre_act + i, 0.f);
+      stf(y + i, 0.f);
+      continue;
+    }
     float v = (ldf(x + i) - mean[c]) * rstd[c] * gamma[c] + beta[c];
     if (pre_act) stf(pre_act + i, v);
     v = act_apply(v, act);
@@ -618,9 +638,15 @@ template <typename T>
 __global__ void bn_bwd_kernel(int64_t total, int C, float inv_n, const T* __restrict__ dy, const T* __restrict__ x,
                               const float* __restrict__ mean, const float* __restrict__ rstd,
                               const float* __restrict__ gamma, const float* __restrict__ sum_dy,
-                              const float* __restrict__ sum_dy_xhat, int use_batch_stats, T* __restrict__ dx) {
+                              const float* __restrict__ sum_dy_xhat, int use_batch_stats, T* __restrict__ dx, int Tn,
+                              const int32_t* __restrict__ vlens) {
+  if (vlens) inv_n = 1.0f / (float)rows_present((int)(total / C), Tn, vlens);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
+    if (vlens && !row_present((int)(i / C), Tn, vlens)) {      // absent frame: no gradient leaves it
+      stf(dx + i, 0.f);
+      continue;
+    }
     float g = ldf(dy + i);
     float v;
     if (use_batch_stats) {
@@ -637,8 +663,10 @@ __global__ void bn_bwd_kernel(int64_t total, int C, float inv_n, const T* __rest
 // unbiased variance in the running buffer).
 __global__ void bn_finalize_kernel(int C, int n, float eps, float momentum, const float* __restrict__ mean,
                                    const float* __restrict__ var, float* __restrict__ rstd, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var, int64_t* __restrict__ num_batches, int var_is_ex2) {
+                                   float* __restrict__ run_var, int64_t* __restrict__ num_batches, int var_is_ex2, int Tn,
+                                   const int32_t* __restrict__ vlens) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  n = rows_present(n, Tn, vlens);
   if (c == 0 && num_batches) *num_batches += 1;
   if (c >= C) return;
   float vc = var[c];
@@ -659,10 +687,12 @@ __global__ void bn_finalize_kernel(int C, int n, float eps, float momentum, cons
 __global__ __launch_bounds__(256) void bn_stage2_finalize_kernel(int C, int chunks, const float* __restrict__ ws, int n, float eps,
                                                                  float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                                                  float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                                 int64_t* __restrict__ num_batches) {
+                                                                 int64_t* __restrict__ num_batches, int Tn,
+                                                                 const int32_t* __restrict__ vlens) {
   __shared__ float sh[2][4][64];
   const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
+  n = rows_present(n, Tn, vlens);
   float t0 = 0.f, t1 = 0.f;
   if (c < C) {
 #pragma unroll 8
@@ -829,16 +859,24 @@ extern "C" int s2svc_layernorm_bwd_pg(int dtype, int rows, int D, const void* dy
 
 extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void* dy, const void* x, const float* mean,
                                const float* rstd, float scale, float* out_sum, float* out_dot, int accumulate,
-                               float* ws, int ws_chunks, void* stream) {
+                               float* ws, int ws_chunks, int Tn, const int32_t* vlens, void* stream) {
   S2S_REQUIRE(rows >= 0 && D > 0 && ws && ws_chunks > 0, "colreduce: bad args");
   S2S_REQUIRE(mode >= 0 && mode <= 6, "colreduce: bad mode");
+  S2S_REQUIRE(!vlens || (Tn > 0 && rows % Tn == 0 && mode != 1 && mode != 5), "colreduce: vlens needs rows = B * Tn (modes 0, 2, 3, 4, 6)");
+  S2S_REQUIRE(scale >= 0.f || rows > 0, "colreduce: scale < 0 (mean over the present rows) needs rows");
   hipStream_t st = (hipStream_t)stream;
   int chunks = (rows + 63) / 64;
   if (chunks > ws_chunks) chunks = ws_chunks;
   if (chunks < 1) chunks = 1;
   const int rpc = (rows + chunks - 1) / chunks;
   dim3 grid((D + 63) / 64, chunks), block(256);
-  if (cr_vec_ok_host(dtype, D, dy, x))
+  if (vlens && dtype == S2S_F32)
+    hipLaunchKernelGGL(colreduce_stage1_masked<float>, grid, block, 0, st, rows, D, mode, (const float*)dy, (const float*)x, mean,
+                       rstd, ws, rpc, Tn, vlens);
+  else if (vlens)
+    hipLaunchKernelGGL(colreduce_stage1_masked<bf16_t>, grid, block, 0, st, rows, D, mode, (const bf16_t*)dy, (const bf16_t*)x,
+                       mean, rstd, ws, rpc, Tn, vlens);
+  else if (cr_vec_ok_host(dtype, D, dy, x))
     hipLaunchKernelGGL(colreduce_stage1_vec, dim3((D + 511) / 512, chunks), block, 0, st, rows, D, mode, (const bf16_t*)dy,
                        (const bf16_t*)x, mean, rstd, ws, rpc);
   else if (dtype == S2S_F32)
@@ -849,7 +887,7 @@ extern "C" int s2svc_colreduce(int dtype, int rows, int D, int mode, const void*
                        mean, rstd, ws, rpc);
   S2S_CHECK_LAUNCH("colreduce_stage1");
   hipLaunchKernelGGL(colreduce_stage2, dim3((D + 63) / 64), dim3(256), 0, st, D, chunks, ws, scale, out_sum, out_dot,
-                     accumulate);
+                     accumulate, rows, Tn, vlens);
   S2S_CHECK_LAUNCH("colreduce_stage2");
   return 0;
 }
@@ -892,9 +930,11 @@ extern "C" int s2svc_colreduce_grouped(const s2svc_colreduce_item* items, int n,
 }
 
 extern "C" int s2svc_bn_finalize(int C, int n, float eps, float momentum, const float* mean, const float* var,
-                                 float* rstd, float* run_mean, float* run_var, int64_t* num_batches, int var_is_ex2, void* stream) {
+                                 float* rstd, float* run_mean, float* run_var, int64_t* num_batches, int var_is_ex2, int Tn,
+                                 const int32_t* vlens, void* stream) {
+  S2S_REQUIRE(!vlens || (Tn > 0 && n % Tn == 0), "bn_finalize: vlens needs n = B * Tn");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, n, eps, momentum,
-                     mean, var, rstd, run_mean, run_var, num_batches, var_is_ex2);
+                     mean, var, rstd, run_mean, run_var, num_batches, var_is_ex2, Tn, vlens);
   S2S_CHECK_LAUNCH("bn_finalize_kernel");
   return 0;
 }
@@ -903,15 +943,23 @@ extern "C" int s2svc_bn_finalize(int C, int n, float eps, float momentum, const 
 // then sum of the partials + variance + rstd + running statistics); ws >= ws_chunks*2*C floats.  Same values as
 // s2svc_colreduce(mode 6, scale 1/rows) + s2svc_bn_finalize(var_is_ex2 = 1), one launch less.
 extern "C" int s2svc_bn_stats(int dtype, int rows, int C, const void* x, float eps, float momentum, float* mean, float* rstd,
-                              float* run_mean, float* run_var, int64_t* num_batches, float* ws, int ws_chunks, void* stream) {
+                              float* run_mean, float* run_var, int64_t* num_batches, float* ws, int ws_chunks, int Tn,
+                              const int32_t* vlens, void* stream) {
   S2S_REQUIRE(rows > 0 && C > 0 && x && mean && rstd && ws && ws_chunks > 0, "bn_stats: bad args");
+  S2S_REQUIRE(!vlens || (Tn > 0 && rows % Tn == 0), "bn_stats: vlens needs rows = B * Tn");
   S2S_REQUIRE(dtype == S2S_F32 || dtype == S2S_BF16, "bn_stats: bad dtype");
   hipStream_t st = (hipStream_t)stream;
   int chunks = (rows + 63) / 64;
   if (chunks > ws_chunks) chunks = ws_chunks;
   const int rpc = (rows + chunks - 1) / chunks;
   dim3 grid((C + 63) / 64, chunks), block(256);
-  if (dtype == S2S_F32)
+  if (vlens && dtype == S2S_F32)
+    hipLaunchKernelGGL(colreduce_stage1_masked<float>, grid, block, 0, st, rows, C, 6, (const float*)nullptr, (const float*)x,
+                       (const float*)nullptr, (const float*)nullptr, ws, rpc, Tn, vlens);
+  else if (vlens)
+    hipLaunchKernelGGL(colreduce_stage1_masked<bf16_t>, grid, block, 0, st, rows, C, 6, (const bf16_t*)nullptr, (const bf16_t*)x,
+                       (const float*)nullptr, (const float*)nullptr, ws, rpc, Tn, vlens);
+  else if (dtype == S2S_F32)
     hipLaunchKernelGGL(colreduce_stage1<float>, grid, block, 0, st, rows, C, 6, (const float*)nullptr, (const float*)x,
                        (const float*)nullptr, (const float*)nullptr, ws, rpc);
   else
@@ -919,7 +967,7 @@ extern "C" int s2svc_bn_stats(int dtype, int rows, int C, const void* x, float e
                        (const float*)nullptr, (const float*)nullptr, ws, rpc);
   S2S_CHECK_LAUNCH("colreduce_stage1");
   hipLaunchKernelGGL(bn_stage2_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, C, chunks, ws, rows, eps, momentum, mean,
-                     rstd, run_mean, run_var, num_batches);
+                     rstd, run_mean, run_var, num_batches, Tn, vlens);
   S2S_CHECK_LAUNCH("bn_stage2_finalize_kernel");
   return 0;
 }
@@ -932,33 +980,35 @@ extern "C" int s2svc_rstd_from_var(int C, float eps, const float* var, float* rs
 
 extern "C" int s2svc_bn_apply(int dtype, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
                               const float* gamma, const float* beta, int act, float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* y,
-                              void* pre_act, void* stream) {
+                              void* pre_act, int Tn, const int32_t* vlens, void* stream) {
   const int64_t total = rows * C;
   if (total == 0) return 0;
+  S2S_REQUIRE(!vlens || (Tn > 0 && rows % Tn == 0 && rows < (1ll << 31)), "bn_apply: vlens needs rows = B * Tn");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, total, C, (const float*)x, mean,
-                       rstd, gamma, beta, act, drop_p, seed_base, seed_off, (float*)y, (float*)pre_act);
+                       rstd, gamma, beta, act, drop_p, seed_base, seed_off, (float*)y, (float*)pre_act, Tn, vlens);
   else
     hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, total, C, (const bf16_t*)x, mean,
-                       rstd, gamma, beta, act, drop_p, seed_base, seed_off, (bf16_t*)y, (bf16_t*)pre_act);
+                       rstd, gamma, beta, act, drop_p, seed_base, seed_off, (bf16_t*)y, (bf16_t*)pre_act, Tn, vlens);
   S2S_CHECK_LAUNCH("bn_apply_kernel");
   return 0;
 }
 
 extern "C" int s2svc_bn_bwd(int dtype, int64_t rows, int C, const void* dy, const void* x, const float* mean,
                             const float* rstd, const float* gamma, const float* sum_dy, const float* sum_dy_xhat,
-                            int use_batch_stats, void* dx, void* stream) {
+                            int use_batch_stats, void* dx, int Tn, const int32_t* vlens, void* stream) {
   const int64_t total = rows * C;
   if (total == 0) return 0;
+  S2S_REQUIRE(!vlens || (Tn > 0 && rows % Tn == 0 && rows < (1ll << 31)), "bn_bwd: vlens needs rows = B * Tn");
   hipStream_t st = (hipStream_t)stream;
   const float inv_n = 1.0f / (float)rows;
   if (dtype == S2S_F32)
     hipLaunchKernelGGL(bn_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, total, C, inv_n, (const float*)dy,
-                       (const float*)x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats, (float*)dx);
+                       (const float*)x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats, (float*)dx, Tn, vlens);
   else
     hipLaunchKernelGGL(bn_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, total, C, inv_n, (const bf16_t*)dy,
-                       (const bf16_t*)x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats, (bf16_t*)dx);
+                       (const bf16_t*)x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats, (bf16_t*)dx, Tn, vlens);
   S2S_CHECK_LAUNCH("bn_bwd_kernel");
   return 0;
 }

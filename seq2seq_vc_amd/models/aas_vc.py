@@ -32,20 +32,23 @@ class AlignmentModule(nn.Module):
         self.f_conv2 = nn.Conv1d(adim, adim, kernel_size=3, padding=1)
         self.f_conv3 = nn.Conv1d(adim, adim, kernel_size=1, padding=0)
 
-    def feats_branch(self, feats):
+    def feats_branch(self, feats, feat_lens=None):
         """The acoustic-feature side (f_conv1..3): depends on the target features only, so the training forward pass runs it on
-        the auxiliary stream beside the encoder (AASVC._forward) -- and autograd then runs its backward pass there too."""
+        the auxiliary stream beside the encoder (AASVC._forward) -- and autograd then runs its backward pass there too.
+        feat_lens: Lens of feats; in a captured step its crop() keeps the frames beyond the batch's longest utterance out of the taps
+        (the features themselves are zero there: batch padding)."""
+        vl = Mo.crop_dev(feat_lens)
         f = Fn.conv1d(feats, self.f_conv1.weight, self.f_conv1.bias, act="relu")
-        f = Fn.conv1d(f, self.f_conv2.weight, self.f_conv2.bias, act="relu")
+        f = Fn.conv1d(f, self.f_conv2.weight, self.f_conv2.bias, act="relu", vlens=vl)
         return Fn.linear(f, self.f_conv3.weight, self.f_conv3.bias)
 
-    def forward(self, text, feats, text_lens=None, f=None):
+    def forward(self, text, feats, text_lens=None, f=None, feat_lens=None):
         """text (B,T_text,adim), feats (B,T_feats,odim), text_lens: Lens -> log_p_attn (B,T_feats,T_text) fp32.
         f: the result of feats_branch(feats) if the caller has it already."""
-        t = Fn.conv1d(text, self.t_conv1.weight, self.t_conv1.bias, act="relu")
+        t = Fn.conv1d(text, self.t_conv1.weight, self.t_conv1.bias, act="relu", vlens=Mo.crop_dev(text_lens))
         t = Fn.linear(t, self.t_conv2.weight, self.t_conv2.bias)
         if f is None:
-            f = self.feats_branch(feats)
+            f = self.feats_branch(feats, feat_lens)
         return FA.pairwise_logsoftmax(f, t, None if text_lens is None else text_lens.dev)
 
 
@@ -228,7 +231,7 @@ class AASVC(nn.Module):
         f_pre = None
         if not is_inference and ys is not None and xs.is_cuda and _FBRANCH:
             # the alignment module's feature side needs nothing from the encoder: auxiliary stream, beside it (forward and backward)
-            f_pre = Fn.branch_run(lambda: self.alignment_module.feats_branch(Fn.to_compute(ys)), uses=(ys,))
+            f_pre = Fn.branch_run(lambda: self.alignment_module.feats_branch(Fn.to_compute(ys), olr), uses=(ys,))
         hs, _ = self.encoder(Fn.to_compute(xs), il)
         hs = Fn.cut_point(hs, "encoder_out")
         if self.encoder_input_layer == "conv2d":
@@ -247,6 +250,11 @@ class AASVC(nn.Module):
             the main stream (where it would stall everything queued behind it until the branch has finished)."""
             if self.duration_predictor_use_encoder_outputs:
                 return hs
+            if dplens is not None and Mo._BANK is not None:
+                # captured step: the projection's output and the encoder's have padded lengths; F.interpolate's ratio is the one
+                # of the reference's cropped tensors (graph data, modules.LensBank)
+                d, dl = self.duration_predictor_projection(Fn.to_compute(dp_inputs), Mo.Lens.of(dplens, dev))
+                return FA.interp_nearest(d, Th, Mo.crop_dev(dl), Mo.crop_dev(il))
             d, _ = self.duration_predictor_projection(Fn.to_compute(dp_inputs), None)
             return FA.interp_nearest(d, Th)
 
@@ -282,7 +290,7 @@ class AASVC(nn.Module):
                 Fn.branch_join(f_pre)
                 log_p_attn = self.alignment_module(hs, None, il_c, f=f_pre)
             else:
-                log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c)
+                log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c, feat_lens=olr)
             if self.forward_sum_prefetch is not None:
                 self.forward_sum_prefetch(log_p_attn, il, olr)
             ds, bin_loss = self.viterbi_func(log_p_attn, il_c, olr)
@@ -298,7 +306,10 @@ class AASVC(nn.Module):
             dec_lens = olr
         zs, _ = self.decoder(hs, dec_lens)
         before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, self.odim)
-        after = before if self.postnet is None else Fn.add_dropout(before, self.postnet(before), 0.0)
+        post_lens = None
+        if self.postnet is not None and dec_lens is not None and dec_lens.cap is not None:     # captured step: frames of `before`
+            post_lens = dec_lens if dr == 1 else dec_lens.map(lambda v, _r=dr: v * _r)
+        after = before if self.postnet is None else Fn.add_dropout(before, self.postnet(before, post_lens), 0.0)
         ret["before_outs"], ret["after_outs"] = before, after
         Fn.branch_join(ret.get("dur_nll"), *(getattr(log_p_attn, "_s2s_fs", None) or ())[:2])
         ret["ds"] = ds

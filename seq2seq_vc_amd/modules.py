@@ -32,15 +32,24 @@ class LensBank:
     `map` / `clamp` of another Lens).  Before a replay `refresh()` recomputes every slot on the host from the new batch's
     root lengths -- the same lambdas, in creation order -- and ships them with ONE copy; the kernels of the graph read the
     slots.  Host-side uses of the lengths must not differ between batches of one graph: `max()` of a banked Lens is its
-    `cap` (the padded length of the tensor it describes: the models then do not crop a batch to its longest utterance),
-    and lengths that reach a step without provenance raise instead of being baked in."""
+    `cap` (the padded length of the tensor it describes), and lengths that reach a step without provenance raise instead of
+    being baked in.
+
+    The reference crops a batch to its longest utterance before it computes (models/vtn.py:208-214, 269-271; the collater hands
+    models/aas_vc.py a batch padded to exactly that length), a captured step cannot (shapes are baked in).  So a banked Lens also
+    carries `ext`: the length the reference's CROPPED tensor has -- max of the root lengths, pushed through the same arithmetic as
+    the tensor shapes (`map(fn, ext_fn)`).  Frames between `ext` and `cap` are ABSENT: `Lens.crop()` is the slot (B copies of
+    `ext`, graph data like every other slot) that the kernels which mix along time or over the batch take as `vlens` -- Conv1d
+    with k > 1 (ops.functional.conv1d / crop_rows), BatchNorm (batch_norm_act), the Conformer convolution module
+    (functional_aas.convmod_core), nearest-neighbour resampling -- so that a captured step on a batch that does not fill its padded
+    shape computes exactly what the reference computes on the cropped batch."""
 
     def __init__(self, device, max_slots=96):
         self.device = torch.device(device)
         self.max_slots = max_slots
         self.B = None
         self.buf = None               # (max_slots, B) int32 on the device
-        self.entries = []             # creation order: (lens, source): source = ("root", name) | ("map", parent, fn)
+        self.entries = []             # creation order: (lens, source): ("root", name) | ("map", parent, fn, ext_fn, with_ext) | ("crop", parent)
         self.roots = {}               # id(tensor the trainer registered) -> Lens
         self.closed = False           # after the capture: no new slots
 
@@ -78,17 +87,26 @@ class LensBank:
 
     def refresh(self, root_values):
         """root_values: name -> B ints of the new batch.  Recomputes every slot and uploads them (current stream)."""
-        host = {}
-        for k, (lens, source) in enumerate(self.entries):
+        for k, (lens, source) in enumerate(self.entries):          # creation order: a parent precedes what was derived from it
             if source[0] == "root":
                 vals = tuple(int(v) for v in root_values[source[1]])
                 if max(vals) > lens.cap:
                     raise ValueError(f"LensBank: length {max(vals)} of '{source[1]}' exceeds the padded length {lens.cap} of this graph")
+                ext = max(vals)
             else:
-                vals = tuple(source[2](v) for v in host[id(source[1])])
-            host[id(lens)] = vals
-            lens.host = vals
+                vals, ext = _derive(source, len(lens.host))
+            lens.host, lens.ext = vals, ext
         self.upload()
+
+
+def _derive(source, B):
+    """(values, ext) of a banked Lens from its parent's CURRENT values: ("map", parent, fn, ext_fn, with_ext) | ("crop", parent)."""
+    parent = source[1]
+    if source[0] == "crop":
+        return (parent.ext,) * B, parent.ext
+    _, _, fn, ext_fn, with_ext = source
+    vals = tuple(fn(v, parent.ext) for v in parent.host) if with_ext else tuple(fn(v) for v in parent.host)
+    return vals, (ext_fn if ext_fn is not None else fn)(parent.ext)
 
 
 class lens_bank:
@@ -121,16 +139,17 @@ class Lens:
     value so that steady-state steps issue no H2D copies and stay hipGraph-capturable; a slot of the active LensBank
     when a training step is captured with lengths as data)."""
 
-    def __init__(self, values, device, _source=None, _cap=None):
+    def __init__(self, values, device, _source=None, _cap=None, _ext=None):
         if _BANK is not None:
             if _source is None:
                 raise RuntimeError("Lens: lengths without provenance inside a captured training step (register them with "
                                    "LensBank.root, derive them with Lens.map / Lens.clamp, or tag host tensors with tag_lens)")
-            self._init_banked(_BANK, values, _cap, _source)
+            self._init_banked(_BANK, values, _cap, _source, _ext)
             return
         self.host = tuple(int(v) for v in values)
         self.device = torch.device(device)
         self.cap = None
+        self.ext = None               # no bank: the models crop the batch themselves, every row of a tensor is present
         key = (self.host, self.device.type, self.device.index)
         t = _LENS_CACHE.get(key)
         if t is None:
@@ -140,10 +159,12 @@ class Lens:
             _LENS_CACHE[key] = t
         self.dev = t
 
-    def _init_banked(self, bank, values, cap, source):
+    def _init_banked(self, bank, values, cap, source, ext=None):
         self.host = tuple(int(v) for v in values)
         self.device = bank.device
         self.cap = int(cap)
+        self.ext = int(max(self.host) if ext is None else ext)      # a root: the reference crops to the longest utterance
+        self._crop = None
         self.dev = bank._slot(self, source)
 
     @staticmethod
@@ -162,16 +183,39 @@ class Lens:
             lens = lens.tolist()
         return Lens(lens, device)
 
-    def map(self, fn):
+    def map(self, fn, ext_fn=None, with_ext=False):
+        """Lengths fn(v) of a tensor derived from the one these lengths describe.  ext_fn: how the derived tensor's time axis
+        follows from this one's when that is not fn itself (Conv2dSubsampling: lengths ceil(v / 4), axis ((T - 1) // 2 - 1) // 2);
+        with_ext: fn(v, ext) also sees the cropped length of THIS tensor (banked lengths; else ext = what max() returns)."""
         if self.cap is not None:
-            return Lens([fn(v) for v in self.host], self.device, _source=("map", self, fn), _cap=fn(self.cap))
+            vals, ext = _derive(("map", self, fn, ext_fn, with_ext), len(self.host))
+            return Lens(vals, self.device, _source=("map", self, fn, ext_fn, with_ext), _cap=(ext_fn if ext_fn is not None else fn)(self.cap),
+                        _ext=ext)
+        if with_ext:
+            return Lens([fn(v, self.max()) for v in self.host], self.device)
         return Lens([fn(v) for v in self.host], self.device)
+
+    def crop(self):
+        """The `vlens` of the kernels that must not see the frames between the reference's cropped length and the padded length
+        (LensBank): B copies of `ext` in a slot of the bank.  None outside a bank (every frame of a tensor is present)."""
+        if self.cap is None:
+            return None
+        if self._crop is None:
+            self._crop = Lens((self.ext,) * len(self.host), self.device, _source=("crop", self), _cap=self.cap, _ext=self.ext)
+        return self._crop
 
     def max(self):
         return self.cap if self.cap is not None else max(self.host)
 
     def clamp(self, hi):
         return self.map(lambda v, _hi=hi: min(v, _hi))
+
+
+def crop_dev(lens):
+    """Device vector for the `vlens` argument of the time-mixing kernels, or None (no bank / no lengths)."""
+    if lens is None or lens.cap is None:
+        return None
+    return lens.crop().dev
 
 
 # ------------------------------------------------------------------------------------------------
@@ -257,6 +301,11 @@ class LegacyRelPositionalEncoding(PositionalEncoding):
         super().__init__(d_model, dropout_rate, max_len, reverse=True)
 
     def forward(self, x):
+        if _BANK is not None:
+            # the legacy table is sliced by the tensor's length (rows max_len - T .. max_len - 1 reversed) and the legacy rel_shift
+            # wraps rows at that length: both depend on the CROPPED length, which a captured step only has as data
+            raise NotImplementedError('config["hip_graph"]: legacy relative positional encoding is not supported in captured steps '
+                                      "(no recipe uses it); run this model with hip_graph off")
         p = self.dropout_rate if self.training else 0.0
         pe = K.cast(self.table(x.shape[1], x.device)[: x.shape[1]][None].contiguous(), x.dtype)
         return Fn.posenc(x, None, None, self.xscale, p), Fn.dropout(pe, p)
@@ -394,10 +443,12 @@ class MultiLayeredConv1d(nn.Module):
         self.w_2 = nn.Conv1d(hidden_chans, in_chans, kernel_size, stride=1, padding=(kernel_size - 1) // 2)
         self.dropout_rate = dropout_rate
 
-    def forward(self, x):
+    def forward(self, x, lens=None):
+        """lens: the Lens of x -- in a captured step its crop() keeps the frames the reference does not have out of the taps."""
         p = self.dropout_rate if self.training else 0.0
-        h = Fn.dropout(Fn.conv1d(x, self.w_1.weight, self.w_1.bias, act="relu"), p)
-        return Fn.conv1d(h, self.w_2.weight, self.w_2.bias)
+        vl = crop_dev(lens)
+        h = Fn.dropout(Fn.conv1d(x, self.w_1.weight, self.w_1.bias, act="relu", vlens=vl), p)
+        return Fn.conv1d(h, self.w_2.weight, self.w_2.bias, vlens=vl)
 
 
 class LayerNorm(nn.LayerNorm):
@@ -449,13 +500,16 @@ class EncoderLayer(nn.Module):
             y = self.norm1(x) if normed is None else normed
             a = self.self_attn(y, y, y, klens)
             y2, x = _res_norm(self.norm2, x, a, p)
-            f = self.feed_forward(y2)
+            f = self.feed_forward(y2, klens) if isinstance(self.feed_forward, MultiLayeredConv1d) else self.feed_forward(y2)
             return x, f  # caller adds f with dropout (fused into the next LayerNorm)
         # post-LN: x feeds the sublayer AND the residual; the residual takes it from the sublayer's pass-through alias so
         # that the two gradients meet inside the first data-gradient GEMM instead of in an element-wise add
         a, xr = _sub_pass(self.self_attn, x, x, x, klens)
         x, _ = _res_norm(self.norm1, xr, a, p)
-        f, xr = _sub_pass(self.feed_forward, x)
+        if isinstance(self.feed_forward, MultiLayeredConv1d):
+            f, xr = self.feed_forward(x, klens), x
+        else:
+            f, xr = _sub_pass(self.feed_forward, x)
         x, _ = _res_norm(self.norm2, xr, f, p)
         return x, None
 
@@ -550,8 +604,13 @@ class Conv2dSubsampling(nn.Module):
         the frame count the utterance has when it is processed alone, ((len-1)//2-1)//2."""
         if lens is None:
             return None
+        sub = lambda T: ((T - 1) // 2 - 1) // 2          # noqa: E731  -- frames of the subsampled axis
         if exact:
-            return lens.map(lambda v: min(((v - 1) // 2 - 1) // 2, t_out))
+            return lens.map(lambda v: min(sub(v), t_out), ext_fn=sub)
+        if lens.cap is not None:
+            # captured step: the reference's mask has sub(longest utterance) frames, not sub(padded length)
+            assert sub(lens.cap) == t_out
+            return lens.map(lambda v, e: min((v + 3) // 4, sub(e)), ext_fn=sub, with_ext=True)
         return lens.map(lambda v: min((v + 3) // 4, t_out))
 
     def forward(self, x, lens, exact_lens=False):
@@ -612,16 +671,21 @@ class Postnet(nn.Module):
             self.postnet += [nn.Sequential(*mods)]
         self.dropout_rate, self.use_batch_norm = dropout_rate, use_batch_norm
 
-    def forward(self, xs):
+    def forward(self, xs, lens=None):
+        """lens: the Lens of xs.  In a captured step on a batch shorter than its padded shape (LensBank) its crop() marks the frames
+        the reference's cropped tensor does not have: the convolutions read zero there, the BatchNorm statistics skip them."""
         n = len(self.postnet)
         p = self.dropout_rate if self.training else 0.0
+        vl = crop_dev(lens)
         for i, blk in enumerate(self.postnet):
             act = "tanh" if i != n - 1 else None
-            xs = Fn.conv1d(xs, blk[0].weight, None)
+            # a BatchNorm given vlens leaves zeros in the absent frames (and lets no gradient out of them): only the first
+            # convolution -- or every one when there is no BatchNorm -- has to clear them itself
+            xs = Fn.conv1d(xs, blk[0].weight, None, vlens=vl if (i == 0 or not self.use_batch_norm or not self.training) else None)
             if self.use_batch_norm:
                 bn = blk[1]
                 xs = Fn.batch_norm_act(xs, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                       self.training, act, p, bn.eps, bn.momentum)
+                                       self.training, act, p, bn.eps, bn.momentum, vlens=vl if self.training else None)
             else:
                 xs = Fn.act_dropout(xs, act, p)
         return xs

@@ -1329,8 +1329,34 @@ class _Conv1d(Function):
         return dx, dw, db, None
 
 
-def conv1d(x, weight, bias=None, act=None):
-    """x (B,T,Cin) channel-last; weight (Cout,Cin,k) torch layout; returns (B,T,Cout)."""
+class _CropRows(Function):
+    """Rows t >= vlens[b] of a (B, T, C) tensor are ABSENT (a captured training step on a batch shorter than its padded shape,
+    modules.Lens.crop): zero on the way in -- what a 'same'-padded convolution behind this op reads where the reference's cropped
+    tensor ends (models/vtn.py:208-214) -- and zero on the way back, so that no gradient leaves a frame the reference does not have."""
+
+    @staticmethod
+    def forward(ctx, x, vlens):
+        from . import kernels_sdp as KS
+        ctx.vlens = vlens
+        return KS.mask_rows(_c(x), vlens)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import kernels_sdp as KS
+        return KS.mask_rows(_c(dy), ctx.vlens), None
+
+
+def crop_rows(x, vlens):
+    """Identity when vlens is None (every row present)."""
+    return x if vlens is None else _CropRows.apply(x, vlens)
+
+
+def conv1d(x, weight, bias=None, act=None, vlens=None):
+    """x (B,T,Cin) channel-last; weight (Cout,Cin,k) torch layout; returns (B,T,Cout).
+    vlens (B int32, device; captured steps only): input frames t >= vlens[b] are absent -- read as zero padding (k > 1), and no
+    gradient flows back into them.  The OUTPUT frames beyond vlens are not cleared: whoever mixes along time next does that."""
+    if vlens is not None and weight.shape[-1] > 1:
+        x = crop_rows(x, vlens)
     return _Conv1d.apply(x, weight, bias, act)
 
 
@@ -1544,32 +1570,38 @@ def linear_fc_permuted(x, weight, bias, C, Fd, input_is_relu=False):
 # ================================================================================================
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, num_batches, training, act, p, eps, momentum):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, num_batches, training, act, p, eps, momentum, vlens=None):
         x = _c(x)
         C = x.shape[-1]
         rows = x.numel() // C
         seed = K.new_seed(x.device) if p > 0.0 else (None, 0)
+        if not training:
+            vlens = None
+        Tn = x.shape[-2] if vlens is not None else 0       # absent rows (include/s2svc_hip.h): out of the statistics, zero in y and dx
+        ctx.vl = (vlens, Tn)
         ctx.vec = training and K.bn_vec_ok(x)
         if ctx.vec:     # bf16: 16-byte kernels; the backward pass recomputes the activation / dropout derivative (csrc/convmod.hip)
-            mean, rstd = K.bn_stats_vec(x, rows, C, eps, momentum, run_mean, run_var, num_batches)
+            mean, rstd = K.bn_stats_vec(x, rows, C, eps, momentum, run_mean, run_var, num_batches, vlens=vlens, Tn=Tn)
             need_pre = act in ("swish", "gelu")
-            y, pre = K.bn_act_apply_vec(x, mean, rstd, gamma.detach(), beta.detach(), act=act, p=p, seed=seed, want_pre=need_pre)
+            y, pre = K.bn_act_apply_vec(x, mean, rstd, gamma.detach(), beta.detach(), act=act, p=p, seed=seed, want_pre=need_pre,
+                                        vlens=vlens, Tn=Tn)
             ctx.meta = (training, act, p, seed)
             ctx.params = (gamma, beta)
             ctx.save_for_backward(x, mean, rstd, (pre if need_pre else y) if (act or p > 0.0) else None)
             return y
         if training:
             if x.dtype == torch.bfloat16:      # one pass over x: mean and E[x^2] together (fp32 sums of bf16 values)
-                mean, rstd = K.bn_stats(x, rows, C, eps, momentum, run_mean, run_var, num_batches)
+                mean, rstd = K.bn_stats(x, rows, C, eps, momentum, run_mean, run_var, num_batches, vlens=vlens, Tn=Tn)
             else:                              # parity mode: the two-pass variance torch computes
-                mean, _ = K.colreduce(0, x.view(rows, C), scale=1.0 / rows)
-                var, _ = K.colreduce(3, None, x=x.view(rows, C), mean=mean, scale=1.0 / rows, rows=rows, D=C)
-                rstd = K.bn_finalize(mean, var, rows, eps, momentum, run_mean, run_var, num_batches)
+                sc = 1.0 / rows if vlens is None else -1.0          # < 0: 1 / (number of present rows), on the device
+                mean, _ = K.colreduce(0, x.view(rows, C), scale=sc, vlens=vlens, Tn=Tn)
+                var, _ = K.colreduce(3, None, x=x.view(rows, C), mean=mean, scale=sc, rows=rows, D=C, vlens=vlens, Tn=Tn)
+                rstd = K.bn_finalize(mean, var, rows, eps, momentum, run_mean, run_var, num_batches, vlens=vlens, Tn=Tn)
         else:
             mean = run_mean
             rstd = K.rstd_from_var(run_var, eps)
         need_pre = act in ("swish", "gelu")
-        y, pre = K.bn_apply(x, mean, rstd, gamma, beta, act=act, p=p, seed=seed, want_pre=need_pre)
+        y, pre = K.bn_apply(x, mean, rstd, gamma, beta, act=act, p=p, seed=seed, want_pre=need_pre, vlens=vlens, Tn=Tn)
         ctx.meta = (training, act, p, seed)
         ctx.params = (gamma, beta)
         ctx.save_for_backward(x, mean, rstd, pre if need_pre else y)
@@ -1583,31 +1615,35 @@ class _BatchNormAct(Function):
         C = x.shape[-1]
         rows = x.numel() // C
         dy = _c(dz)
+        vlens, Tn = ctx.vl
         if ctx.vec:
             g_slot = getattr(gamma, "_s2s_grad", None) if gamma.requires_grad else None
             b_slot = getattr(beta, "_s2s_grad", None) if beta.requires_grad else None
             both = g_slot is not None and b_slot is not None
             dx, sdy, sdyx = K.bn_act_bwd_vec(dy, saved, x, mean, rstd, gamma.detach(), act=act, p=p, seed=seed,
-                                             dgamma_acc=g_slot.view(-1) if both else None, dbeta_acc=b_slot.view(-1) if both else None)
+                                             dgamma_acc=g_slot.view(-1) if both else None, dbeta_acc=b_slot.view(-1) if both else None,
+                                             vlens=vlens, Tn=Tn)
             dgamma = dbeta = None
             if gamma.requires_grad and not both:
                 dgamma, dbeta = _emit_vgrad(gamma, sdyx), _emit_vgrad(beta, sdy)
-            return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+            return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
         if act or p > 0.0:
             dy = K.act_dropout_bwd(dy, saved, act=act, p=p, seed=seed)
-        sdy, sdyx = K.colreduce(2, dy.view(rows, C), x.view(rows, C), mean, rstd, want_dot=True)
-        dx = K.bn_bwd(dy, x, mean, rstd, gamma, sdy, sdyx, use_batch_stats=training)
+        sdy, sdyx = K.colreduce(2, dy.view(rows, C), x.view(rows, C), mean, rstd, want_dot=True, vlens=vlens, Tn=Tn)
+        dx = K.bn_bwd(dy, x, mean, rstd, gamma, sdy, sdyx, use_batch_stats=training, vlens=vlens, Tn=Tn)
         dgamma = dbeta = None
         if gamma.requires_grad:
             if _slotted(gamma, beta):      # the two accumulations into the gradient slots leave the data-gradient chain
                 _side_run(lambda: (_emit_vgrad(gamma, sdyx), _emit_vgrad(beta, sdy)), keep=(sdy, sdyx))
             else:
                 dgamma, dbeta = _emit_vgrad(gamma, sdyx), _emit_vgrad(beta, sdy)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, gamma, beta, run_mean, run_var, num_batches, training, act=None, p=0.0, eps=1e-5, momentum=0.1):
-    return _BatchNormAct.apply(x, gamma, beta, run_mean, run_var, num_batches, training, act, p, eps, momentum)
+def batch_norm_act(x, gamma, beta, run_mean, run_var, num_batches, training, act=None, p=0.0, eps=1e-5, momentum=0.1, vlens=None):
+    """vlens (B int32, device; x must be (B, T, C)): frames t >= vlens[b] are absent -- not in the batch statistics, zero in the
+    output and in the data gradient (captured steps on batches shorter than their padded shape; include/s2svc_hip.h)."""
+    return _BatchNormAct.apply(x, gamma, beta, run_mean, run_var, num_batches, training, act, p, eps, momentum, vlens)
 
 
 # ================================================================================================

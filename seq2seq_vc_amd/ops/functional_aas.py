@@ -79,14 +79,15 @@ class _ConvModCore(Function):
     separate ops take 5 and 8; only y2 and z are kept for the backward pass (g = glu(y2) and the pre-activation are recomputed)."""
 
     @staticmethod
-    def forward(ctx, y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps, momentum):
+    def forward(ctx, y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps, momentum, vlens=None):
         y2 = _c(y2)
         ks = dw_weight.shape[-1]
         z, mean, rstd = KA.convmod_fwd(y2, dw_weight.detach(), None if dw_bias is None else dw_bias.detach(), ks, eps, momentum,
-                                       run_mean, run_var, num_batches)
-        out = KA.bn_swish_apply(z, mean, rstd, gamma.detach(), beta.detach())
+                                       run_mean, run_var, num_batches, vlens=vlens)
+        out = KA.bn_swish_apply(z, mean, rstd, gamma.detach(), beta.detach(), vlens=vlens)
         ctx.params = (dw_weight, dw_bias, gamma, beta)
         ctx.ks = ks
+        ctx.vlens = vlens
         ctx.save_for_backward(y2, z, mean, rstd)
         return out
 
@@ -100,7 +101,8 @@ class _ConvModCore(Function):
         b_slot = getattr(beta, "_s2s_grad", None) if beta.requires_grad else None
         both = g_slot is not None and b_slot is not None
         dy2, sdy, sdyx, (ws_w, chunks) = KA.convmod_bwd(_c(da), z, y2, dw_weight.detach(), mean, rstd, gamma.detach(), beta.detach(), ks,
-                                                        g_slot.view(-1) if both else None, b_slot.view(-1) if both else None)
+                                                        g_slot.view(-1) if both else None, b_slot.view(-1) if both else None,
+                                                        vlens=ctx.vlens)
         dgamma = dbeta = None
         if not both:
             dgamma = _emit_vgrad(gamma, sdyx) if gamma.requires_grad else None
@@ -119,12 +121,13 @@ class _ConvModCore(Function):
                 dwv, dbv = KA.convmod_wgrad_final(ws_w, chunks, C, ks)
                 dw = _emit_vgrad(dw_weight, dwv) if need_w else None
                 db = _emit_vgrad(dw_bias, dbv) if need_b else None
-        return dy2, dw, db, dgamma, dbeta, None, None, None, None, None
+        return dy2, dw, db, dgamma, dbeta, None, None, None, None, None, None
 
 
-def convmod_core(y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps=1e-5, momentum=0.1):
-    """swish(batch_norm(dwconv1d(glu(y2)))) in training mode on the fused kernels; use convmod_core_ok() first."""
-    return _ConvModCore.apply(y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps, momentum)
+def convmod_core(y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps=1e-5, momentum=0.1, vlens=None):
+    """swish(batch_norm(dwconv1d(glu(y2)))) in training mode on the fused kernels; use convmod_core_ok() first.
+    vlens (B int32, device): frames t >= vlens[b] are absent (captured steps on batches shorter than their padded shape)."""
+    return _ConvModCore.apply(y2, dw_weight, dw_bias, gamma, beta, run_mean, run_var, num_batches, eps, momentum, vlens)
 
 
 def convmod_core_ok(y2, dw_weight, training, activation):
@@ -252,19 +255,21 @@ def forward_sum_loss_prefetched(log_p_attn, loss_b, grad):
 
 class _InterpNearest(Function):
     @staticmethod
-    def forward(ctx, x, Tout):
+    def forward(ctx, x, Tout, ext_in=None, ext_out=None):
         x = _c(x)
         ctx.Tin = x.shape[1]
-        return K.interp_nearest(x, Tout)
+        ctx.ext = (ext_in, ext_out)
+        return K.interp_nearest(x, Tout, ext_in, ext_out)
 
     @staticmethod
     def backward(ctx, dy):
-        return K.interp_nearest_bwd(_c(dy), ctx.Tin), None
+        return K.interp_nearest_bwd(_c(dy), ctx.Tin, *ctx.ext), None, None, None
 
 
-def interp_nearest(x, Tout):
-    """F.interpolate(x^T, size=Tout)^T per batch item on channel-last (B, T, C)  (models/aas_vc.py:340-349)."""
-    return _InterpNearest.apply(x, Tout)
+def interp_nearest(x, Tout, ext_in=None, ext_out=None):
+    """F.interpolate(x^T, size=Tout)^T per batch item on channel-last (B, T, C)  (models/aas_vc.py:340-349).
+    ext_in / ext_out: the cropped lengths as graph data when the tensors are padded (captured steps), see kernels.interp_nearest."""
+    return _InterpNearest.apply(x, Tout, ext_in, ext_out)
 
 
 class _LengthRegulate(Function):

@@ -520,13 +520,14 @@ _WS_CHUNKS = 64
 
 
 def colreduce(mode, dy, x=None, mean=None, rstd=None, scale=1.0, want_dot=False, rows=None, D=None, out_sum=None,
-              out_dot=None, accumulate=False):
+              out_dot=None, accumulate=False, vlens=None, Tn=0):
     """Deterministic column reduction; `out_sum`/`out_dot` (fp32, D) may be given (e.g. flat-gradient slots,
-    with accumulate=True) instead of being allocated."""
+    with accumulate=True) instead of being allocated.  vlens (B int32, device) with Tn: rows b * Tn + t, t >= vlens[b], are absent
+    (include/s2svc_hip.h); scale < 0 then means 1 / (number of present rows)."""
     t = dy if dy is not None else x
     D = t.shape[-1] if D is None else D
     rows = t.numel() // D if rows is None else rows
-    if _CR_RECORDER is not None and out_sum is not None and accumulate:
+    if _CR_RECORDER is not None and out_sum is not None and accumulate and vlens is None:
         # parameter-gradient reduction into a flat-gradient slot: queued for the grouped launch (flush_colreduce)
         ws = torch.empty(_WS_CHUNKS * 2 * D, dtype=torch.float32, device=t.device)
         it = _lib.ColreduceItem()
@@ -543,26 +544,26 @@ def colreduce(mode, dy, x=None, mean=None, rstd=None, scale=1.0, want_dot=False,
     if _Audit.on and accumulate:
         _audit_write("column reduction", ptr(out_sum), ptr(out_dot))
     _lib.check(_lib.lib().s2svc_colreduce(dt(t), rows, D, mode, ptr(dy), ptr(x), ptr(mean), ptr(rstd), scale, ptr(out_sum),
-                                          ptr(out_dot), 1 if accumulate else 0, ptr(ws), _WS_CHUNKS, stream()), "colreduce")
+                                          ptr(out_dot), 1 if accumulate else 0, ptr(ws), _WS_CHUNKS, Tn, ptr(vlens), stream()), "colreduce")
     return out_sum, out_dot
 
 
-def bn_finalize(mean, var, n, eps, momentum, run_mean=None, run_var=None, num_batches=None, var_is_ex2=False):
+def bn_finalize(mean, var, n, eps, momentum, run_mean=None, run_var=None, num_batches=None, var_is_ex2=False, vlens=None, Tn=0):
     """var_is_ex2: `var` holds E[x^2] (one-pass statistics, colreduce mode 6); the variance is E[x^2] - mean^2."""
     C = mean.numel()
     rstd = torch.empty_like(mean)
     _lib.check(_lib.lib().s2svc_bn_finalize(C, n, eps, momentum, ptr(mean), ptr(var), ptr(rstd), ptr(run_mean),
-                                            ptr(run_var), ptr(num_batches), 1 if var_is_ex2 else 0, stream()), "bn_finalize")
+                                            ptr(run_var), ptr(num_batches), 1 if var_is_ex2 else 0, Tn, ptr(vlens), stream()), "bn_finalize")
     return rstd
 
 
-def bn_stats(x, rows, C, eps, momentum, run_mean=None, run_var=None, num_batches=None):
+def bn_stats(x, rows, C, eps, momentum, run_mean=None, run_var=None, num_batches=None, vlens=None, Tn=0):
     """(mean, rstd) of training-mode BatchNorm over (rows, C), one pass over x, two launches (s2svc_bn_stats)."""
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = torch.empty(_WS_CHUNKS * 2 * C, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().s2svc_bn_stats(dt(x), rows, C, ptr(x), eps, momentum, ptr(mean), ptr(rstd), ptr(run_mean), ptr(run_var),
-                                         ptr(num_batches), ptr(ws), _WS_CHUNKS, stream()), "bn_stats")
+                                         ptr(num_batches), ptr(ws), _WS_CHUNKS, Tn, ptr(vlens), stream()), "bn_stats")
     return mean, rstd
 
 
@@ -572,13 +573,13 @@ def rstd_from_var(var, eps):
     return rstd
 
 
-def bn_apply(x, mean, rstd, gamma, beta, act=None, p=0.0, seed=(None, 0), want_pre=False):
+def bn_apply(x, mean, rstd, gamma, beta, act=None, p=0.0, seed=(None, 0), want_pre=False, vlens=None, Tn=0):
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
     pre = torch.empty_like(x) if want_pre else None
     _lib.check(_lib.lib().s2svc_bn_apply(dt(x), rows, C, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], p,
-                                         seed[0], seed[1], ptr(y), ptr(pre), stream()), "bn_apply")
+                                         seed[0], seed[1], ptr(y), ptr(pre), Tn, ptr(vlens), stream()), "bn_apply")
     return y, pre
 
 
@@ -588,25 +589,25 @@ def bn_vec_ok(x):
             and os.environ.get("S2SVC_NO_BN_VEC", "0") != "1")
 
 
-def bn_stats_vec(x, rows, C, eps, momentum, run_mean=None, run_var=None, num_batches=None):
+def bn_stats_vec(x, rows, C, eps, momentum, run_mean=None, run_var=None, num_batches=None, vlens=None, Tn=0):
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
     ws = torch.empty(((rows + 63) // 64) * 2 * C, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().s2svc_bn_stats_vec(rows, C, ptr(x), eps, momentum, ptr(mean), ptr(rstd), ptr(run_mean), ptr(run_var),
-                                             ptr(num_batches), ptr(ws), stream()), "bn_stats_vec")
+                                             ptr(num_batches), ptr(ws), Tn, ptr(vlens), stream()), "bn_stats_vec")
     return mean, rstd
 
 
-def bn_act_apply_vec(x, mean, rstd, gamma, beta, act=None, p=0.0, seed=(None, 0), want_pre=False):
+def bn_act_apply_vec(x, mean, rstd, gamma, beta, act=None, p=0.0, seed=(None, 0), want_pre=False, vlens=None, Tn=0):
     C = x.shape[-1]
     y = torch.empty_like(x)
     pre = torch.empty_like(x) if want_pre else None
     _lib.check(_lib.lib().s2svc_bn_act_apply_vec(x.numel() // C, C, ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ACT[act], p,
-                                                 seed[0], seed[1], ptr(y), ptr(pre), stream()), "bn_act_apply_vec")
+                                                 seed[0], seed[1], ptr(y), ptr(pre), Tn, ptr(vlens), stream()), "bn_act_apply_vec")
     return y, pre
 
 
-def bn_act_bwd_vec(dz, saved, x, mean, rstd, gamma, act=None, p=0.0, seed=(None, 0), dgamma_acc=None, dbeta_acc=None):
+def bn_act_bwd_vec(dz, saved, x, mean, rstd, gamma, act=None, p=0.0, seed=(None, 0), dgamma_acc=None, dbeta_acc=None, vlens=None, Tn=0):
     """-> dx, sdy (= d beta), sdyx (= d gamma); dgamma_acc / dbeta_acc: fp32 (C) gradient slots the sums are ADDED to."""
     C = x.shape[-1]
     rows = x.numel() // C
@@ -616,16 +617,16 @@ def bn_act_bwd_vec(dz, saved, x, mean, rstd, gamma, act=None, p=0.0, seed=(None,
     ws = torch.empty(((rows + 63) // 64) * 2 * C, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().s2svc_bn_act_bwd_vec(rows, C, ptr(dz), ptr(saved), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ACT[act], p,
                                                seed[0], seed[1], ptr(dx), ptr(sdy), ptr(sdyx), ptr(dgamma_acc), ptr(dbeta_acc),
-                                               ptr(ws), stream()), "bn_act_bwd_vec")
+                                               ptr(ws), Tn, ptr(vlens), stream()), "bn_act_bwd_vec")
     return dx, sdy, sdyx
 
 
-def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats=True):
+def bn_bwd(dy, x, mean, rstd, gamma, sum_dy, sum_dy_xhat, use_batch_stats=True, vlens=None, Tn=0):
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x)
     _lib.check(_lib.lib().s2svc_bn_bwd(dt(x), rows, C, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(sum_dy),
-                                       ptr(sum_dy_xhat), 1 if use_batch_stats else 0, ptr(dx), stream()), "bn_bwd")
+                                       ptr(sum_dy_xhat), 1 if use_batch_stats else 0, ptr(dx), Tn, ptr(vlens), stream()), "bn_bwd")
     return dx
 
 
@@ -974,17 +975,19 @@ def col2im_s2(dcols, B, T1, F1, C, T2, F2):
     return dx
 
 
-def interp_nearest(x, Tout):
+def interp_nearest(x, Tout, ext_in=None, ext_out=None):
+    """ext_in / ext_out (int32 device tensors, element 0 is read): the cropped lengths behind padded Tin / Tout (include/s2svc_hip.h)."""
     B, Tin, C = x.shape
     y = torch.empty((B, Tout, C), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib().s2svc_interp_nearest(dt(x), B, Tin, Tout, C, ptr(x), ptr(y), stream()), "interp_nearest")
+    _lib.check(_lib.lib().s2svc_interp_nearest(dt(x), B, Tin, Tout, C, ptr(x), ptr(y), ptr(ext_in), ptr(ext_out), stream()), "interp_nearest")
     return y
 
 
-def interp_nearest_bwd(dy, Tin):
+def interp_nearest_bwd(dy, Tin, ext_in=None, ext_out=None):
     B, Tout, C = dy.shape
     dx = torch.empty((B, Tin, C), dtype=dy.dtype, device=dy.device)
-    _lib.check(_lib.lib().s2svc_interp_nearest_bwd(dt(dy), B, Tin, Tout, C, ptr(dy), ptr(dx), stream()), "interp_nearest_bwd")
+    _lib.check(_lib.lib().s2svc_interp_nearest_bwd(dt(dy), B, Tin, Tout, C, ptr(dy), ptr(dx), ptr(ext_in), ptr(ext_out), stream()),
+               "interp_nearest_bwd")
     return dx
 
 

@@ -37,9 +37,9 @@ def convmod_supported(C, ks):
     return bool(_lib.lib().s2svc_convmod_supported(C, ks))
 
 
-def convmod_fwd(y2, w, bias, ks, eps, momentum, run_mean=None, run_var=None, num_batches=None):
+def convmod_fwd(y2, w, bias, ks, eps, momentum, run_mean=None, run_var=None, num_batches=None, vlens=None):
     """Conformer convolution module core, bf16 training: y2 (B,T,2C) -> z = dwconv(glu(y2)) (B,T,C) and its batch statistics
-    (mean, rstd) in two launches (csrc/convmod.hip)."""
+    (mean, rstd) in two launches (csrc/convmod.hip).  vlens (B int32, device): frames t >= vlens[b] are absent (include/s2svc_hip.h)."""
     B, T, C2 = y2.shape
     C = C2 // 2
     z = torch.empty((B, T, C), dtype=y2.dtype, device=y2.device)
@@ -47,19 +47,19 @@ def convmod_fwd(y2, w, bias, ks, eps, momentum, run_mean=None, run_var=None, num
     rstd = torch.empty(C, dtype=torch.float32, device=y2.device)
     ws = torch.empty(B * ((T + 63) // 64) * 2 * C, dtype=torch.float32, device=y2.device)
     _lib.check(_lib.lib().s2svc_convmod_fwd(B, T, C, ks, ptr(y2), ptr(w), ptr(bias), ptr(z), eps, momentum, ptr(mean), ptr(rstd),
-                                            ptr(run_mean), ptr(run_var), ptr(num_batches), ptr(ws), stream()), "convmod_fwd")
+                                            ptr(run_mean), ptr(run_var), ptr(num_batches), ptr(ws), ptr(vlens), stream()), "convmod_fwd")
     return z, mean, rstd
 
 
-def bn_swish_apply(z, mean, rstd, gamma, beta):
+def bn_swish_apply(z, mean, rstd, gamma, beta, vlens=None):
     C = z.shape[-1]
     out = torch.empty_like(z)
     _lib.check(_lib.lib().s2svc_bn_swish_apply(z.numel() // C, C, ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(out),
-                                               stream()), "bn_swish_apply")
+                                               z.shape[-2], ptr(vlens), stream()), "bn_swish_apply")
     return out
 
 
-def convmod_bwd(da, z, y2, w, mean, rstd, gamma, beta, ks, dgamma_acc=None, dbeta_acc=None):
+def convmod_bwd(da, z, y2, w, mean, rstd, gamma, beta, ks, dgamma_acc=None, dbeta_acc=None, vlens=None):
     """-> dy2 (B,T,2C), sdy, sdyx (C), (ws_w, chunks): the per-tile partial depthwise weight / bias gradients for
     convmod_wgrad_final.  dgamma_acc / dbeta_acc: fp32 (C) gradient slots to ADD the BatchNorm parameter gradients to."""
     B, T, C = z.shape
@@ -71,7 +71,7 @@ def convmod_bwd(da, z, y2, w, mean, rstd, gamma, beta, ks, dgamma_acc=None, dbet
     ws_w = torch.empty(chunks * C * (ks + 1), dtype=torch.float32, device=z.device)
     _lib.check(_lib.lib().s2svc_convmod_bwd(B, T, C, ks, ptr(da), ptr(z), ptr(y2), ptr(w), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
                                             ptr(dy2), ptr(sdy), ptr(sdyx), ptr(dgamma_acc), ptr(dbeta_acc), ptr(ws_stats), ptr(ws_w),
-                                            stream()), "convmod_bwd")
+                                            ptr(vlens), stream()), "convmod_bwd")
     return dy2, sdy, sdyx, (ws_w, chunks)
 
 

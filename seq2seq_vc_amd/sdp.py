@@ -36,8 +36,9 @@ class DurationPredictor(nn.Module):
 
     def _forward(self, xs, x_lens=None, is_inference=False):
         p = self.dropout_rate if self.training else 0.0
+        vl = Mo.crop_dev(x_lens)          # captured step: frames the reference's cropped batch does not have stay out of the taps
         for blk in self.conv:
-            xs = Fn.conv1d(xs, blk[0].weight, blk[0].bias, act="relu")
+            xs = Fn.conv1d(xs, blk[0].weight, blk[0].bias, act="relu", vlens=vl)
             xs = Fn.layer_norm(xs, blk[2].weight, blk[2].bias, blk[2].eps)   # LayerNorm over channels == last dim here
             xs = Fn.dropout(xs, p)
         out = Fn.linear(xs, self.linear.weight, self.linear.bias).squeeze(-1).float()   # (B, T) log-domain

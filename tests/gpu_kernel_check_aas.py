@@ -115,6 +115,135 @@ def conformer_conv_module_fused():
 
 
 @case
+def absent_rows_match_the_cropped_computation():
+    """`vlens` (include/s2svc_hip.h "absent rows"): a captured training step allocates (B, T, C) at a padded length; the frames
+    t >= vlens[b] (= the longest utterance of the batch, B copies) are not there in the reference (models/vtn.py:208-214).  Every
+    kernel that mixes along time or over the batch -- BatchNorm (16-byte bf16 kernels and the scalar fp32 / bf16 ones), the fused
+    Conformer convolution module, the unfused one, Conv1d k > 1, nearest-neighbour resampling -- must give on the PADDED tensor, with
+    garbage in the absent frames of every input and incoming gradient, what torch gives on the CROPPED tensor: values, running
+    statistics, data gradients (zero in the absent frames) and parameter gradients."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    res = []
+    bf = torch.bfloat16
+
+    def garbage(t, ext, seed):          # frames >= ext: values that would wreck a statistic if a kernel looked at them
+        t = t.clone()
+        t[:, ext:] = (37.0 * torch.randn(t[:, ext:].shape, generator=torch.Generator().manual_seed(seed))).to(t.device).to(t.dtype)
+        return t
+
+    def tail_is_zero(tag, t, ext):
+        return (bool((t[:, ext:] == 0).all()), f"{tag}: absent frames are zero")
+
+    # ---- BatchNorm + activation (Postnet: pre_postnets.py:108-165)
+    for dtype, C, act in [(torch.float32, 80, "tanh"), (torch.float32, 37, None), (bf, 80, "tanh"), (bf, 256, None), (bf, 36, "tanh"),
+                          (bf, 512, "swish")]:
+        B, T, ext = 4, 48, 37
+        vl = torch.full((B,), ext, dtype=torch.int32, device=DEV)
+        x = garbage(rnd(B, T, C, seed=C, dtype=dtype), ext, 1)
+        dz = garbage(rnd(B, T, C, seed=C + 1, dtype=dtype), ext, 2)
+        gamma, beta = 1.0 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.2)
+        xr = x[:, :ext].float().clone().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        pre = F.batch_norm(xr.transpose(1, 2), rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5).transpose(1, 2)
+        yr = {"tanh": torch.tanh, "swish": lambda v: v * torch.sigmoid(v), None: lambda v: v}[act](pre)
+        yr.backward(dz[:, :ext].float())
+        xx = x.clone().requires_grad_(True)
+        g2, b2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        m, v, nb = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+        y = Fn.batch_norm_act(xx, g2, b2, m, v, nb, True, act, 0.0, 1e-5, 0.1, vlens=vl)
+        y.backward(dz)
+        tag = f"BatchNorm+{act} {str(dtype)[6:]} C{C} ({'16-byte' if K.bn_vec_ok(x) else 'scalar'} kernels)"
+        a = 3e-5 if dtype == torch.float32 else 4e-2
+        res.append(check(f"{tag} y", y[:, :ext], yr, dtype, atol=a))
+        res.append(tail_is_zero(f"{tag} y", y, ext))
+        res.append(check(f"{tag} dx", xx.grad[:, :ext], xr.grad, dtype, atol=a, rtol=3e-2 if dtype == bf else 1e-4))
+        res.append(tail_is_zero(f"{tag} dx", xx.grad, ext))
+        res.append(check(f"{tag} d gamma", g2.grad, gr.grad, torch.float32, atol=2e-4 if dtype == torch.float32 else 0.3, rtol=2e-2))
+        res.append(check(f"{tag} d beta", b2.grad, br.grad, torch.float32, atol=2e-4 if dtype == torch.float32 else 0.3, rtol=2e-2))
+        res.append(check(f"{tag} running_mean", m, rm, torch.float32, atol=1e-5 if dtype == torch.float32 else 2e-3, rtol=1e-2))
+        res.append(check(f"{tag} running_var", v, rv, torch.float32, atol=1e-5 if dtype == torch.float32 else 2e-3, rtol=1e-2))
+
+    # ---- Conformer convolution module: fused bf16 kernels and the separate ones (conformer/convolution.py:56-79)
+    for dtype, (B, T, ext, C, ks) in [(bf, (3, 128, 70, 128, 15)), (bf, (2, 64, 64, 64, 7)), (bf, (2, 192, 131, 192, 31)), (torch.float32, (2, 48, 29, 24, 7)),
+                                      (bf, (16, 256, 201, 384, 15))]:
+        vl = torch.full((B,), ext, dtype=torch.int32, device=DEV)
+        y2 = garbage(rnd(B, T, 2 * C, seed=ks, dtype=dtype), ext, 5)
+        da = garbage(rnd(B, T, C, seed=ks + 1, dtype=dtype), ext, 6)
+        w, b = rnd(C, 1, ks, seed=7, scale=0.3), rnd(C, seed=8, scale=0.2)
+        gamma, beta = 1.0 + rnd(C, seed=9, scale=0.2), rnd(C, seed=10, scale=0.2)
+        yr = y2[:, :ext].float().clone().requires_grad_(True)
+        wr, br, gr, ber = (t.clone().requires_grad_(True) for t in (w, b, gamma, beta))
+        zr = F.conv1d(F.glu(yr, dim=-1).transpose(1, 2), wr, br, padding=(ks - 1) // 2, groups=C)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        pre = F.batch_norm(zr, rm, rv, gr, ber, training=True, momentum=0.1, eps=1e-5)
+        outr = (pre * torch.sigmoid(pre)).transpose(1, 2)
+        outr.backward(da[:, :ext].float())
+        for fused in ((True, False) if dtype == bf else (False,)):
+            ps = [t.clone().requires_grad_(True) for t in (w, b, gamma, beta)]
+            yy = y2.clone().requires_grad_(True)
+            m, v, nb = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+            if fused:
+                assert FA.convmod_core_ok(yy, ps[0], True, "swish")
+                out = FA.convmod_core(yy, ps[0], ps[1], ps[2], ps[3], m, v, nb, 1e-5, 0.1, vlens=vl)
+            else:
+                h = FA.dwconv1d(Fn.crop_rows(Fn.glu(yy), vl), ps[0], ps[1])
+                out = Fn.batch_norm_act(h, ps[2], ps[3], m, v, nb, True, "swish", 0.0, 1e-5, 0.1, vlens=vl)
+            out.backward(da)
+            tag = f"convmod {'fused' if fused else 'separate'} {str(dtype)[6:]} B{B} T{T} ext{ext} C{C} k{ks}"
+            bound = 2e-2 if dtype == bf else 2e-5
+            for name, got, ref in [("out", out[:, :ext], outr), ("dy2", yy.grad[:, :ext], yr.grad), ("d dw_weight", ps[0].grad, wr.grad),
+                                   ("d gamma", ps[2].grad, gr.grad), ("d beta", ps[3].grad, ber.grad)]:
+                e = _rel_l2(got, ref)
+                res.append((e <= bound, f"{tag} {name}: rel-L2 vs fp32 torch on the cropped tensor {e:.2e} (bound {bound:.0e})"))
+            res.append(tail_is_zero(f"{tag} out", out, ext))
+            res.append(tail_is_zero(f"{tag} dy2", yy.grad, ext))
+            res.append(check(f"{tag} running_var", v, rv, torch.float32, atol=2e-3 if dtype == bf else 1e-5, rtol=1e-2))
+
+    # ---- Conv1d k > 1 ('same' padding ends where the cropped tensor ends) ; alignments.py:28-60, pre_postnets.py:173-185
+    for dtype, (B, T, ext, Ci, Co, ks) in [(torch.float32, (3, 40, 23, 16, 24, 5)), (bf, (4, 64, 50, 80, 256, 5)), (bf, (2, 128, 97, 256, 256, 3))]:
+        vl = torch.full((B,), ext, dtype=torch.int32, device=DEV)
+        x = garbage(rnd(B, T, Ci, seed=ks, dtype=dtype), ext, 11)
+        w, b = rnd(Co, Ci, ks, seed=12, scale=0.1), rnd(Co, seed=13, scale=0.1)
+        dy = rnd(B, T, Co, seed=14, dtype=dtype)
+        dy[:, ext:] = 0          # what arrives from a consumer that keeps the absent frames out (BatchNorm / crop_rows behind it)
+        xr = x[:, :ext].float().clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = F.conv1d(xr.transpose(1, 2), wr, br, padding=(ks - 1) // 2).transpose(1, 2)
+        yr.backward(dy[:, :ext].float())
+        xx, w2, b2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = Fn.conv1d(xx, w2, b2, vlens=vl)
+        y.backward(dy)
+        tag = f"Conv1d k{ks} {str(dtype)[6:]} T{T} ext{ext}"
+        a = 5e-5 if dtype == torch.float32 else 6e-2
+        res.append(check(f"{tag} y", y[:, :ext], yr, dtype, atol=a))
+        res.append(check(f"{tag} dx", xx.grad[:, :ext], xr.grad, dtype, atol=a))
+        res.append(tail_is_zero(f"{tag} dx", xx.grad, ext))
+        e = _rel_l2(w2.grad, wr.grad)
+        res.append((e <= (1e-5 if dtype == torch.float32 else 1e-2), f"{tag} dW rel-L2 {e:.2e}"))
+
+    # ---- nearest-neighbour resampling with the reference's ratio (models/aas_vc.py:340-349)
+    for dtype in (torch.float32, bf):
+        for (B, Tin, ein, Tout, eout, C) in [(2, 31, 24, 32, 25, 48), (3, 15, 15, 16, 13, 8), (2, 47, 30, 48, 31, 384)]:
+            x = garbage(rnd(B, Tin, C, seed=Tin, dtype=dtype), ein, 15)
+            dy = garbage(rnd(B, Tout, C, seed=Tout, dtype=dtype), eout, 16)
+            xr = x[:, :ein].float().clone().requires_grad_(True)
+            yr = F.interpolate(xr.transpose(1, 2), size=eout).transpose(1, 2)
+            yr.backward(dy[:, :eout].float())
+            e_in = torch.full((B,), ein, dtype=torch.int32, device=DEV)
+            e_out = torch.full((B,), eout, dtype=torch.int32, device=DEV)
+            xx = x.clone().requires_grad_(True)
+            y = FA.interp_nearest(xx, Tout, e_in, e_out)
+            y.backward(dy)
+            tag = f"interp_nearest {str(dtype)[6:]} {Tin}({ein}) -> {Tout}({eout})"
+            res.append(check(f"{tag} y", y[:, :eout], yr, dtype, atol=0, rtol=0))
+            res.append(tail_is_zero(f"{tag} y", y, eout))
+            res.append(check(f"{tag} dx", xx.grad[:, :ein], xr.grad, dtype, atol=1e-6 if dtype == torch.float32 else 5e-2))
+            res.append(tail_is_zero(f"{tag} dx", xx.grad, ein))
+    return res
+
+
+@case
 def rel_attention_fused_vs_separate():
     """csrc/relattn.hip (relative-position self-attention, T <= 256, bf16: head bias + q.k + shifted q.pos + softmax + dropout in one
     launch, no (B,H,T,2T-1) tensor) against fp32 torch math on the same bf16 inputs, and -- dropout on, same seeds => same masks --

@@ -1003,6 +1003,186 @@ def trainers_replay_captured_steps():
 
 
 @case
+def captured_steps_on_short_batches_vs_oracle():
+    """VERDICT r5 #1.  config["hip_graph"] pads a batch to a multiple of graph_length_quantum frames; the reference computes on the
+    batch CROPPED to its longest utterance (models/vtn.py:208-214, 269-271; the collater hands models/aas_vc.py exactly that).  With
+    the cropped lengths as graph data (modules.LensBank: Lens.ext / crop()) the kernels that mix along time or over the batch --
+    Conv2d front-end frame count (subsampling.py:74-94), Postnet Conv1d k5 + BatchNorm (pre_postnets.py:173-185), the Conformer
+    depthwise convolution + BatchNorm (conformer/convolution.py:56-79), the aligner's Conv1d k3 (alignments.py:28-60), F.interpolate
+    of the duration predictor's input (aas_vc.py:340-349) -- treat the frames between the two lengths as absent.
+    ARVCTrainer (VTN), ARTTSTrainer, AASVCTrainer with hip_graph=True on three batches that share one padded shape and never fill
+    it: step 1 runs eagerly on the padded buffers, step 2 is captured, step 3 replayed.  Against the ORACLE's three trainer steps
+    (forward, losses, autograd, clip + WarmupLR + Adam: trainers/ar_vc.py:59-112, trainers/aas_vc.py:56-164) on the CROPPED batches:
+    logged losses of every step, the last step's parameter gradients, the parameters after three steps, BatchNorm running
+    statistics.  fp32 (the parity setting); then bf16 -- the kernels the benchmark times -- against the same oracle, loosely."""
+    from oracle import models as OM
+    from seq2seq_vc_amd import losses as L
+    from seq2seq_vc_amd import models as M
+    from seq2seq_vc_amd import trainers as T
+    from seq2seq_vc_amd.optim import FlatAdam
+    res = []
+    LR, WARM, Q = 1e-3, 10, 16
+    fixtures = {"vtn": "vtn_tiny_train", "tts": "tts_tiny_train", "aasvc": "aasvc_tiny_train"}
+
+    def make_batches(kind, mc, seed):
+        g = torch.Generator().manual_seed(seed)
+        B, out = 4, []
+        if kind == "tts":
+            in_max, out_max = [13, 11, 14], [41, 45, 38]          # padded to 16 tokens / 48 frames
+        else:
+            in_max, out_max = [57, 53, 61], [41, 45, 38]          # padded to 64 / 48 frames: sub(57) = 13 != sub(64) = 15, 57 // 4 != 64 // 4
+        for k in range(3):
+            ilens = torch.randint(in_max[k] // 2, in_max[k], (B,), generator=g)
+            olens = torch.randint(out_max[k] // 2, out_max[k], (B,), generator=g)
+            ilens[k % B], olens[(k + 1) % B] = in_max[k], out_max[k]
+            Ti, To = int(ilens.max()), int(olens.max())
+            ys = torch.randn(B, To, mc["odim"], generator=g)
+            xs = torch.randint(1, mc["idim"] - 1, (B, Ti), generator=g) if kind == "tts" else torch.randn(B, Ti, mc["idim"], generator=g)
+            for b in range(B):
+                xs[b, ilens[b]:] = 0
+                ys[b, olens[b]:] = 0
+            bt = {"xs": xs, "ilens": ilens, "ys": ys, "olens": olens}
+            if kind in ("vtn", "tts"):
+                bt["labels"] = (torch.arange(To)[None] >= (olens[:, None] - 1)).float()
+            else:
+                red = mc.get("encoder_reduction_factor", 1) * mc.get("post_encoder_reduction_factor", 1)
+                bt["dp_inputs"], bt["dplens"] = xs.clone(), ilens.clone()
+                bt["noise"] = torch.randn(B, 2, Ti // red, generator=g)          # the flow noise of the CROPPED text axis
+            out.append(bt)
+        return out
+
+    def oracle_run(kind, cfg, z, data):
+        mc = model_cfg(cfg)
+        sd = {k: v.clone() for k, v in sd_of(z).items()}
+        names = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+        for k in names:
+            sd[k].requires_grad_(True)
+        params = [sd[k] for k in names]
+        state = [(torch.zeros_like(p) , torch.zeros_like(p)) for p in params]
+        logs, grads = [], None
+        for it, bt in enumerate(data, 1):
+            if kind == "aasvc":
+                r = OM.aasvc_forward(sd, mc, bt["xs"], bt["ilens"], bt["ys"], bt["olens"], dp_inputs=bt["dp_inputs"], noise=bt["noise"],
+                                     training=True, drop=False)
+                l1 = OM.l1_loss(r["after_outs"], r["before_outs"], r["ys"], r["olens"])
+                fs = OM.forward_sum_loss(r["log_p_attn"], r["ilens"], r["olens_reduced"])
+                dur = r["dur_nll"].sum()
+                loss = l1 + cfg.get("__lambda_align__", 2.0) * (fs + r["bin_loss"]) + dur
+                logs.append({"train/l1_loss": float(l1), "train/forward_sum_loss": float(fs), "train/binary_loss": float(r["bin_loss"]),
+                             "train/duration_loss": float(dur), "train/loss": float(loss)})
+            else:
+                fwd = OM.tts_forward if kind == "tts" else OM.vtn_forward
+                o = fwd(sd, mc, bt["xs"], bt["ilens"], bt["ys"], bt["labels"], bt["olens"], training=True, drop=False)
+                l1, bce = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+                loss = l1 + bce
+                logs.append({"train/l1_loss": float(l1), "train/bce_loss": float(bce), "train/loss": float(loss)})
+            grads = torch.autograd.grad(loss, params, allow_unused=True)
+            grads = [gk if gk is not None else torch.zeros_like(p) for gk, p in zip(grads, params)]
+            with torch.no_grad():
+                OM.adam_step(params, grads, state, OM.warmup_lr(LR, it, WARM), it)
+        return sd, names, dict(zip(names, grads)), logs
+
+    def product_run(kind, cfg, z, data, dtype):
+        mc = model_cfg(cfg)
+        Fn.set_compute_dtype(dtype)
+        Fn.enable_side_streams(*((0, True) if kind == "aasvc" else (4, False)))
+        K.manual_seed(11)
+        model = {"vtn": M.VTN, "tts": M.TransformerTTS, "aasvc": M.AASVC}[kind](**mc)
+        model.load_state_dict(sd_of(z))
+        model.to(DEV).train()
+        for m in model.modules():
+            if hasattr(m, "dropout_rate"):
+                m.dropout_rate = 0.0
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        opt = FlatAdam(model, lr=LR, grad_norm=1.0, warmup_steps=WARM, bf16_shadow=(dtype == torch.bfloat16))
+        conf = {"train_max_steps": len(data), "log_interval_steps": 1, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": ".",
+                "graph_length_quantum": Q, "hip_graph": True}
+        logs = []
+        feed = data
+        if kind == "aasvc":
+            static = {}
+
+            def noise_of(shape, device):          # ONE static buffer per shape: the graph bakes its address, the loader refills it
+                if tuple(shape) not in static:
+                    static[tuple(shape)] = torch.zeros(shape, device=device)
+                return static[tuple(shape)]
+
+            model.duration_predictor._randn = noise_of
+            red = mc.get("encoder_reduction_factor", 1) * mc.get("post_encoder_reduction_factor", 1)
+
+            def loader():
+                for bt in data:
+                    n = bt["noise"]
+                    padded = -(-int(bt["ilens"].max()) // Q) * Q                       # the trainer's padded source length
+                    buf = noise_of((n.shape[0], 2, padded // red), DEV)
+                    buf.zero_()
+                    buf[:, :, : n.shape[2]].copy_(n)          # beyond the cropped text axis: frames the reference does not have
+                    yield {k: v for k, v in bt.items() if k != "noise"}
+
+            feed = loader()
+            conf.update({"criterions": ["L1Loss", "ForwardSumLoss", "StochasticDurationPredictorLoss"], "lambda_align": cfg.get("__lambda_align__", 2.0),
+                         "dp_train_start_steps": -1})
+            tr = T.AASVCTrainer(0, 0, {"train": feed}, None, model, None, {"L1Loss": L.L1Loss(), "ForwardSumLoss": L.ForwardSumLoss()},
+                                opt, None, conf, device=DEV)
+        else:
+            cls = T.ARTTSTrainer if kind == "tts" else T.ARVCTrainer
+            if kind == "tts":
+                feed = [(bt["xs"], bt["ilens"], bt["ys"], bt["labels"], bt["olens"]) for bt in data]
+            tr = cls(0, 0, {"train": feed}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None, conf, device=DEV)
+        tr.log_fn = lambda step, d: logs.append(dict(d))
+        tr.run()
+        torch.cuda.synchronize()
+        n_graphs = sum(len(e.graphs) for e in tr._graphed.entries.values())
+        sightings = [e.sightings for e in tr._graphed.entries.values()]
+        return model, logs, n_graphs, sightings
+
+    try:
+        for kind in ("vtn", "tts", "aasvc"):
+            cfg, z = load(fixtures[kind])
+            mc = model_cfg(cfg)
+            data = make_batches(kind, mc, {"vtn": 91, "tts": 92, "aasvc": 93}[kind])
+            sd_o, names, g_o, logs_o = oracle_run(kind, cfg, z, data)
+            for dtype in (torch.float32, torch.bfloat16):
+                fp = dtype == torch.float32
+                model, logs, n_graphs, sightings = product_run(kind, cfg, z, data, dtype)
+                tag = f"{kind} {'fp32' if fp else 'bf16'}"
+                res.append((n_graphs >= 1 and sightings == [3] and len(logs) == 3,
+                            f"{tag}: 3 steps on ONE padded shape (quantum {Q}), none of the batches fills it; {n_graphs} captured graph(s), 1 replay"))
+                for it, (a, b) in enumerate(zip(logs, logs_o), 1):
+                    worst = max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for k in b)
+                    res.append((worst <= (2e-5 if fp else 3e-2), f"{tag} step {it} ({'eager on padded buffers' if it == 1 else 'captured + replayed' if it == 2 else 'replayed'}): "
+                                f"logged losses vs the oracle on the cropped batch, worst rel. error {worst:.2e}  {[round(v, 5) for v in a.values()]}"))
+                got = dict(model.named_parameters())
+                num = sum(float(((got[k].grad.detach().cpu().double() if got[k].grad is not None else torch.zeros_like(g_o[k]).double()) - g_o[k].double()).pow(2).sum()) for k in names)
+                den = sum(float(g_o[k].double().pow(2).sum()) for k in names)
+                rel = (num / den) ** 0.5
+                res.append((rel <= (3e-4 if fp else 0.12), f"{tag}: all parameter gradients of step 3 (replayed graph), flat rel-L2 vs oracle autograd {rel:.2e}"))
+                if fp:
+                    worst, wname = 0.0, ""
+                    for k in names:
+                        mine = got[k].grad.detach().cpu() if got[k].grad is not None else torch.zeros_like(g_o[k])
+                        e = float((mine - g_o[k]).abs().max()) / (1.0 + float(g_o[k].abs().max()))
+                        if e > worst:
+                            worst, wname = e, k
+                    res.append((worst <= 3e-4, f"{tag}: worst single parameter gradient, max abs err / (1 + max|ref|) = {worst:.2e} ({wname})"))
+                worst = max(float((got[k].detach().cpu().float() - sd_o[k].detach()).abs().max()) for k in names)
+                res.append((worst <= (1e-6 if fp else 2.5 * LR), f"{tag}: parameters after 3 optimiser steps vs the oracle's trainer replay: max abs diff {worst:.2e}"
+                            + ("" if fp else f" (bf16: a sign flip of a near-zero gradient moves a parameter by up to 2 lr = {2 * LR:g} per step)")))
+                bufs = dict(model.named_buffers())
+                bn = [k for k in sd_o if "running_" in k]
+                worst = max(float((bufs[k].detach().cpu() - sd_o[k]).abs().max()) for k in bn) if bn else 0.0
+                res.append((worst <= (2e-6 if fp else 5e-3), f"{tag}: {len(bn)} BatchNorm running statistics after 3 steps vs oracle (frames beyond the longest "
+                            f"utterance are not counted): max abs diff {worst:.2e}"))
+                nbt = [k for k in sd_o if k.endswith("num_batches_tracked")]
+                res.append((all(int(bufs[k]) == int(sd_o[k]) for k in nbt), f"{tag}: num_batches_tracked equal ({len(nbt)} buffers)"))
+    finally:
+        Fn.set_compute_dtype(torch.float32)
+        Fn.enable_side_streams(0)
+    return res
+
+
+@case
 def trainers_captured_steps_full_size_soak():
     """tools/soak_trainer.py at the recipe sizes (VTN vc1 B = 32, AAS-VC vc2 B = 16, bf16, dropout on): batches of three padded
     shapes with ever-changing lengths; the trainer that replays hipGraphs ends with the parameters of the one that launches the

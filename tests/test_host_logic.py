@@ -383,6 +383,41 @@ def test_lens_bank_keeps_lengths_out_of_a_captured_step():
         root.map(lambda v: v)
 
 
+def test_lens_bank_tracks_the_cropped_length_the_reference_computes_on():
+    """A banked Lens carries `ext`, the length of the reference's CROPPED tensor (models/vtn.py:208-214: the batch is cut to its
+    longest utterance; subsampling.py:74-94: sub(T) = ((T - 1) // 2 - 1) // 2 frames), pushed through the same arithmetic as the
+    tensor shapes; crop() is a slot holding B copies of it (the `vlens` of the time-mixing kernels) and follows refresh()."""
+    from seq2seq_vc_amd import modules as Mo
+    sub = lambda T: ((T - 1) // 2 - 1) // 2          # noqa: E731
+    assert Mo.Lens([3, 5], "cpu").crop() is None and Mo.crop_dev(Mo.Lens([3, 5], "cpu")) is None and Mo.crop_dev(None) is None
+    bank = Mo.LensBank("cpu")
+    src = torch.tensor([100, 57, 81])
+    with Mo.lens_bank(bank):
+        root = bank.root("ilens", src, src.tolist(), cap=128)
+        assert (root.ext, root.cap, root.max()) == (100, 128, 128)
+        enc = Mo.Conv2dSubsampling.out_lens(root, sub(128))
+        # the reference: mask[:, :, :-2:2][:, :, :-2:2] of a (B, 1, 100) mask has sub(100) = 24 frames; frame t' is valid iff 4 t' < len
+        assert enc.host == (24, 15, 21) and enc.ext == 24 and enc.cap == sub(128) == 31
+        red = root.map(lambda v: v // 4)
+        trim = root.map(lambda v: v - v % 3)
+        assert (red.ext, red.cap, trim.ext, trim.cap) == (25, 32, 99, 126)
+        c = enc.crop()
+        assert c is enc.crop() and c.host == (24, 24, 24) and c.cap == 31 and Mo.crop_dev(enc).data_ptr() == c.dev.data_ptr()
+        assert root.crop().host == (100, 100, 100)
+    bank.upload()
+    assert bank.buf[bank.entries.index((c, ("crop", enc)))].tolist() == [24, 24, 24]
+    bank.refresh({"ilens": [60, 128, 9]})          # a batch that fills the padded shape: nothing is absent
+    assert enc.host == (15, 31, 3) and enc.ext == 31 and c.host == (31, 31, 31) and root.crop().host == (128,) * 3
+    assert (red.ext, trim.ext) == (32, 126)
+    bank.refresh({"ilens": [33, 34, 35]})
+    assert enc.ext == sub(35) == 8 and enc.host == (8, 8, 8) and c.host == (8, 8, 8)      # ceil(35 / 4) = 9 frames cut to the mask's 8
+    k = [i for i, (l, _) in enumerate(bank.entries) if l is c][0]
+    assert bank.buf[k].tolist() == [8, 8, 8]
+    # without a bank the lengths are what they were: the model has cropped the tensor, t_out is its real length
+    plain = Mo.Conv2dSubsampling.out_lens(Mo.Lens([100, 57, 81], "cpu"), sub(100))
+    assert plain.host == (24, 15, 21) and plain.ext is None
+
+
 def test_perm_registry_host_logic():
     """ops.kernels.PermRegistry (state of the step prologue / derived weight copies): the bookkeeping that needs no GPU -- a
     consumer that arrives while a refresh is due runs it first, join() forgets the events."""
