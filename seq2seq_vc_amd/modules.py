@@ -72,7 +72,9 @@ class LensBank:
             raise RuntimeError(f"LensBank: {B} lengths in a bank of batch size {self.B}, or more than {self.max_slots} slots")
         self.entries.append((lens, source))
         if not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
-            self.buf[k].copy_(torch.tensor(lens.host, dtype=torch.int32))     # eager ("traced") step: the kernels run now
+            # eager ("traced") step: the kernels run now.  (.data: a slot written while the forward pass is under way must not bump the
+            # version counter that autograd checks on the slots it has already saved for the backward pass)
+            self.buf.data[k].copy_(torch.tensor(lens.host, dtype=torch.int32))
         return self.buf[k]
 
     def upload(self):
@@ -83,7 +85,7 @@ class LensBank:
             stage = torch.tensor([lens.host for lens, _ in self.entries], dtype=torch.int32)
             if self.device.type == "cuda":
                 stage = stage.pin_memory()
-            self.buf[:n].copy_(stage, non_blocking=True)
+            self.buf.data[:n].copy_(stage, non_blocking=True)
 
     def refresh(self, root_values):
         """root_values: name -> B ints of the new batch.  Recomputes every slot and uploads them (current stream)."""

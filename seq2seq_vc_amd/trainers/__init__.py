@@ -55,11 +55,24 @@ class Trainer(object):
         self._setup_data_parallel()
         self._capture = None            # set while a staged step is being captured (trainers/graphed.py)
         self._graphed = None
-        if self.config.get("hip_graph", False) and self.device.type == "cuda":
-            if not isinstance(self.optimizer, FlatAdam):
-                raise ValueError('config["hip_graph"] needs the fused optimiser (optim.FlatAdam)')
-            from .graphed import GraphedStep
-            self._graphed = GraphedStep(self)
+        # Captured steps (trainers/graphed.py) are the DEFAULT wherever they apply (config["hip_graph"] absent or "auto"): they compute
+        # what the eager step computes -- the reference's step on the batch cropped to its longest utterance, GPU case
+        # captured_steps_on_short_batches_vs_oracle -- 3-4 x faster (the eager step is bound by the host).  True / "trace" demand
+        # them (and raise where they do not apply), False turns them off.
+        mode = self.config.get("hip_graph", "auto")
+        if mode and self.device.type == "cuda":
+            why = self._captured_steps_unavailable()
+            if mode == "auto":
+                if why is None:
+                    from .graphed import GraphedStep
+                    self._graphed = GraphedStep(self)
+                else:
+                    logging.info(f"hip_graph: eager steps ({why})")
+            else:
+                if not isinstance(self.optimizer, FlatAdam):
+                    raise ValueError('config["hip_graph"] needs the fused optimiser (optim.FlatAdam)')
+                from .graphed import GraphedStep
+                self._graphed = GraphedStep(self)
 
     # Captured steps (trainers/graphed.py): tensor field of the batch -> (its length field, padding value), None = no captured
     # step for this trainer; _graph_regime(): whatever host-side state changes WHAT a step launches (one set of graphs each).
@@ -68,6 +81,21 @@ class Trainer(object):
 
     def _graph_regime(self):
         return ()
+
+    def _captured_steps_unavailable(self):
+        """None if this trainer can replay its steps from hipGraphs, else the reason (config["hip_graph"] = "auto")."""
+        from ..schedulers import FusedWarmupLR
+        if not isinstance(self.optimizer, FlatAdam):
+            return "the optimiser is not optim.FlatAdam"
+        if self.GRAPH_BATCH is None:
+            return f"{type(self).__name__} has no captured step"
+        if self.gradient_accumulate_steps != 1 and not self.GRAPH_ACCUMULATE:
+            return "gradient accumulation without captured micro-steps"
+        if self.scheduler is not None and not isinstance(self.scheduler, FusedWarmupLR):
+            return "a host-side learning-rate scheduler"
+        if self.dist is not None and self.dp is None:
+            return "data parallelism without a staged backward pass (model.dp_plan)"
+        return None
 
     def _batch_dict(self, batch):
         if not isinstance(batch, dict):
@@ -253,6 +281,8 @@ class Trainer(object):
 
     def freeze_modules(self, modules):
         freeze_modules(self.model, modules)
+        if self._graphed is not None:        # what a step launches has changed: captured graphs of the old set are dropped
+            self._graphed.invalidate()
 
 
 class ARVCTrainer(Trainer):

@@ -5,11 +5,14 @@ here the eager step is bound by the host (VTN vc1: 13.5 ms eager, 4.6 ms replaye
 from hipGraphs.  What a graph bakes in is kept out of it:
 
   * shapes -- a batch is copied into static device buffers whose time axes are rounded up to a multiple of
-    config["graph_length_quantum"] (default 64 frames); one set of graphs per (regime, batch size, rounded lengths).  The
-    models then see the padded batch: they do not crop it to its longest utterance as the reference does (models/vtn.py:229-233),
-    which only BatchNorm statistics over padded frames can tell (documented deviation of this opt-in mode);
+    config["graph_length_quantum"] (default 64 frames); one set of graphs per (regime, batch size, rounded lengths);
   * lengths -- they are DATA of the graph (modules.LensBank): every length vector a kernel reads is a slot of one device buffer
-    that is recomputed on the host from the new batch's lengths and shipped with one copy before the replay;
+    that is recomputed on the host from the new batch's lengths and shipped with one copy before the replay.  That includes the
+    length the reference CROPS the batch to before it computes (its longest utterance: models/vtn.py:208-214, 269-271): the frames
+    between it and the padded length are absent for every kernel that mixes along time or over the batch (Lens.ext / crop(),
+    include/s2svc_hip.h "absent rows"), so a captured step computes what the reference computes on the cropped batch -- losses,
+    gradients, parameters after the optimiser step and BatchNorm buffers against the oracle:
+    tests/gpu_model_check.py captured_steps_on_short_batches_vs_oracle;
   * the host bookkeeping of a step (step counters, end of training) is replayed on the host.
 
 First sighting of a key: the step runs eagerly on the static buffers ("traced": same padding, same length handling) -- that
@@ -81,6 +84,13 @@ class GraphedStep:
                                       "(schedulers.FusedWarmupLR); a host-side scheduler would not run during replays")
         if trainer.dist is not None and trainer.dp is None:
             raise NotImplementedError('config["hip_graph"] with config["distributed"] needs a model with dp_plan() (staged backward)')
+
+    def invalidate(self):
+        """Forget every captured step (the set of trainable parameters changed: Trainer.freeze_modules)."""
+        for e in self.entries.values():
+            e.graphs, e.static, e.bank = [], {}, None
+        self.entries.clear()
+        self._stage.clear()
 
     # -- batch -> static buffers ------------------------------------------------------------------
     def _fields(self, batch):

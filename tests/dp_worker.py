@@ -88,6 +88,8 @@ def main():
     conf = dict(conf, distributed=True, rank=rank, dp_grad_payload=payload, dp_collective=collective)
     if graph_mode != "none":
         conf.update(hip_graph=(True if graph_mode == "graph" else "trace"), graph_length_quantum=8)
+    else:
+        conf.update(hip_graph=False)
     opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10)
     batch, sl = shares(kind, z, rank, world)
     cls = T.ARVCTrainer if kind == "vtn" else T.AASVCTrainer

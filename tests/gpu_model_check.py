@@ -901,8 +901,7 @@ def trainers_replay_captured_steps():
         opt = FlatAdam(model, lr=1e-3, grad_norm=1.0, warmup_steps=10)
         conf = {"train_max_steps": len(data), "log_interval_steps": 1, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": ".",
                 "graph_length_quantum": 16}
-        if mode is not None:
-            conf["hip_graph"] = mode
+        conf["hip_graph"] = mode if mode is not None else False          # None: the plain eager trainer (captured steps are the default)
         if distributed:
             conf["distributed"] = True
         conf.update(extra or {})
@@ -1021,8 +1020,23 @@ def captured_steps_on_short_batches_vs_oracle():
     from seq2seq_vc_amd import trainers as T
     from seq2seq_vc_amd.optim import FlatAdam
     res = []
-    LR, WARM, Q = 1e-3, 10, 16
+    # Adam's eps: with the default 1e-8 the update lr * m / (sqrt(v) + eps) is +-lr whatever |g| is, so a gradient element that is
+    # 1e-9 here and -1e-9 in the oracle (both "zero") moves a parameter by 2 lr -- the parameter comparison would measure that, not the
+    # step.  1e-4 keeps the comparison sharp where it means something: a gradient error d moves a parameter by <= lr * d / eps.
+    LR, WARM, Q, EPS = 1e-3, 10, 16, 1e-4
     fixtures = {"vtn": "vtn_tiny_train", "tts": "tts_tiny_train", "aasvc": "aasvc_tiny_train"}
+
+    def snapshotting(cls):
+        """The trainer class with a copy of the flat gradient buffer in front of the optimiser step (a node of the captured graph): the
+        AAS-VC trainer clears the gradients right after its step (trainers/aas_vc.py:141-149)."""
+        class Snap(cls):
+            def _optimizer_step(self):
+                if getattr(self, "grad_snap", None) is None:
+                    self.grad_snap = torch.zeros_like(self.optimizer.flat_g)
+                self.grad_snap.copy_(self.optimizer.flat_g)
+                super()._optimizer_step()
+        Snap.__name__ = cls.__name__
+        return Snap
 
     def make_batches(kind, mc, seed):
         g = torch.Generator().manual_seed(seed)
@@ -1079,7 +1093,7 @@ def captured_steps_on_short_batches_vs_oracle():
             grads = torch.autograd.grad(loss, params, allow_unused=True)
             grads = [gk if gk is not None else torch.zeros_like(p) for gk, p in zip(grads, params)]
             with torch.no_grad():
-                OM.adam_step(params, grads, state, OM.warmup_lr(LR, it, WARM), it)
+                OM.adam_step(params, grads, state, OM.warmup_lr(LR, it, WARM), it, eps=EPS)
         return sd, names, dict(zip(names, grads)), logs
 
     def product_run(kind, cfg, z, data, dtype):
@@ -1095,7 +1109,7 @@ def captured_steps_on_short_batches_vs_oracle():
                 m.dropout_rate = 0.0
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0
-        opt = FlatAdam(model, lr=LR, grad_norm=1.0, warmup_steps=WARM, bf16_shadow=(dtype == torch.bfloat16))
+        opt = FlatAdam(model, lr=LR, eps=EPS, grad_norm=1.0, warmup_steps=WARM, bf16_shadow=(dtype == torch.bfloat16))
         conf = {"train_max_steps": len(data), "log_interval_steps": 1, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": ".",
                 "graph_length_quantum": Q, "hip_graph": True}
         logs = []
@@ -1123,19 +1137,24 @@ def captured_steps_on_short_batches_vs_oracle():
             feed = loader()
             conf.update({"criterions": ["L1Loss", "ForwardSumLoss", "StochasticDurationPredictorLoss"], "lambda_align": cfg.get("__lambda_align__", 2.0),
                          "dp_train_start_steps": -1})
-            tr = T.AASVCTrainer(0, 0, {"train": feed}, None, model, None, {"L1Loss": L.L1Loss(), "ForwardSumLoss": L.ForwardSumLoss()},
-                                opt, None, conf, device=DEV)
+            tr = snapshotting(T.AASVCTrainer)(0, 0, {"train": feed}, None, model, None, {"L1Loss": L.L1Loss(), "ForwardSumLoss": L.ForwardSumLoss()},
+                                              opt, None, conf, device=DEV)
         else:
-            cls = T.ARTTSTrainer if kind == "tts" else T.ARVCTrainer
+            cls = snapshotting(T.ARTTSTrainer if kind == "tts" else T.ARVCTrainer)
             if kind == "tts":
                 feed = [(bt["xs"], bt["ilens"], bt["ys"], bt["labels"], bt["olens"]) for bt in data]
             tr = cls(0, 0, {"train": feed}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None, conf, device=DEV)
+        tr.grad_snap = torch.zeros_like(opt.flat_g)          # static: allocated before anything is captured
         tr.log_fn = lambda step, d: logs.append(dict(d))
         tr.run()
         torch.cuda.synchronize()
         n_graphs = sum(len(e.graphs) for e in tr._graphed.entries.values())
         sightings = [e.sightings for e in tr._graphed.entries.values()]
-        return model, logs, n_graphs, sightings
+        grads = {}
+        for name, p in model.named_parameters():
+            off = p._s2s_grad.data_ptr() - opt.flat_g.data_ptr()
+            grads[name] = tr.grad_snap[off // 4: off // 4 + p.numel()].view(p.shape).detach().cpu()
+        return model, logs, n_graphs, sightings, grads
 
     try:
         for kind in ("vtn", "tts", "aasvc"):
@@ -1145,7 +1164,7 @@ def captured_steps_on_short_batches_vs_oracle():
             sd_o, names, g_o, logs_o = oracle_run(kind, cfg, z, data)
             for dtype in (torch.float32, torch.bfloat16):
                 fp = dtype == torch.float32
-                model, logs, n_graphs, sightings = product_run(kind, cfg, z, data, dtype)
+                model, logs, n_graphs, sightings, g_p = product_run(kind, cfg, z, data, dtype)
                 tag = f"{kind} {'fp32' if fp else 'bf16'}"
                 res.append((n_graphs >= 1 and sightings == [3] and len(logs) == 3,
                             f"{tag}: 3 steps on ONE padded shape (quantum {Q}), none of the batches fills it; {n_graphs} captured graph(s), 1 replay"))
@@ -1154,26 +1173,25 @@ def captured_steps_on_short_batches_vs_oracle():
                     res.append((worst <= (2e-5 if fp else 3e-2), f"{tag} step {it} ({'eager on padded buffers' if it == 1 else 'captured + replayed' if it == 2 else 'replayed'}): "
                                 f"logged losses vs the oracle on the cropped batch, worst rel. error {worst:.2e}  {[round(v, 5) for v in a.values()]}"))
                 got = dict(model.named_parameters())
-                num = sum(float(((got[k].grad.detach().cpu().double() if got[k].grad is not None else torch.zeros_like(g_o[k]).double()) - g_o[k].double()).pow(2).sum()) for k in names)
+                num = sum(float((g_p[k].double() - g_o[k].double()).pow(2).sum()) for k in names)
                 den = sum(float(g_o[k].double().pow(2).sum()) for k in names)
                 rel = (num / den) ** 0.5
                 res.append((rel <= (3e-4 if fp else 0.12), f"{tag}: all parameter gradients of step 3 (replayed graph), flat rel-L2 vs oracle autograd {rel:.2e}"))
                 if fp:
                     worst, wname = 0.0, ""
                     for k in names:
-                        mine = got[k].grad.detach().cpu() if got[k].grad is not None else torch.zeros_like(g_o[k])
-                        e = float((mine - g_o[k]).abs().max()) / (1.0 + float(g_o[k].abs().max()))
+                        e = float((g_p[k] - g_o[k]).abs().max()) / (1.0 + float(g_o[k].abs().max()))
                         if e > worst:
                             worst, wname = e, k
                     res.append((worst <= 3e-4, f"{tag}: worst single parameter gradient, max abs err / (1 + max|ref|) = {worst:.2e} ({wname})"))
                 worst = max(float((got[k].detach().cpu().float() - sd_o[k].detach()).abs().max()) for k in names)
-                res.append((worst <= (1e-6 if fp else 2.5 * LR), f"{tag}: parameters after 3 optimiser steps vs the oracle's trainer replay: max abs diff {worst:.2e}"
-                            + ("" if fp else f" (bf16: a sign flip of a near-zero gradient moves a parameter by up to 2 lr = {2 * LR:g} per step)")))
+                res.append((worst <= (1e-6 if fp else 1e-3), f"{tag}: parameters after 3 optimiser steps (clip + WarmupLR + Adam, eps {EPS:g}) vs the oracle's "
+                            f"trainer replay: max abs diff {worst:.2e}"))
                 bufs = dict(model.named_buffers())
                 bn = [k for k in sd_o if "running_" in k]
-                worst = max(float((bufs[k].detach().cpu() - sd_o[k]).abs().max()) for k in bn) if bn else 0.0
+                worst = max(float(((bufs[k].detach().cpu() - sd_o[k]).abs() / (1.0 + sd_o[k].abs())).max()) for k in bn) if bn else 0.0
                 res.append((worst <= (2e-6 if fp else 5e-3), f"{tag}: {len(bn)} BatchNorm running statistics after 3 steps vs oracle (frames beyond the longest "
-                            f"utterance are not counted): max abs diff {worst:.2e}"))
+                            f"utterance are not counted): max |diff| / (1 + |ref|) {worst:.2e}"))
                 nbt = [k for k in sd_o if k.endswith("num_batches_tracked")]
                 res.append((all(int(bufs[k]) == int(sd_o[k]) for k in nbt), f"{tag}: num_batches_tracked equal ({len(nbt)} buffers)"))
     finally:

@@ -53,8 +53,7 @@ def run(workload, mode, data, dtype, dev, accum=1):
     K.manual_seed(1234)
     torch.manual_seed(0)
     conf = {"train_max_steps": len(data), "log_interval_steps": 10 ** 9, "save_interval_steps": 10 ** 9, "grad_norm": 1.0, "outdir": "."}
-    if mode:
-        conf["hip_graph"] = True
+    conf["hip_graph"] = bool(mode)          # (captured steps are the trainers' default; False = the eager step)
     if accum > 1:                           # micro-steps: the recipes' batch 2 x accumulation 8 (egs/hificaptain_jp/vc2/README.md:11)
         conf["gradient_accumulate_steps"] = accum
         conf["train_max_steps"] = len(data) // accum
