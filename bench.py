@@ -49,6 +49,10 @@ AASVC_VC2 = dict(
     init_type="xavier_uniform", transformer_enc_dropout_rate=0.2, transformer_enc_positional_dropout_rate=0.2,
     transformer_enc_attn_dropout_rate=0.2, transformer_dec_dropout_rate=0.2, transformer_dec_positional_dropout_rate=0.2,
     transformer_dec_attn_dropout_rate=0.2)
+TTS_V1 = dict(idim=78, odim=80, dprenet_layers=2, dprenet_units=256, adim=384, aheads=4, elayers=6, eunits=1536, dlayers=6,
+              dunits=1536, postnet_layers=5, postnet_filts=5, postnet_chans=256, use_batch_norm=True,
+              encoder_normalize_before=True, decoder_normalize_before=False, encoder_concat_after=False,
+              decoder_concat_after=False, decoder_reduction_factor=2)   # egs/ljspeech/tts1/conf/transformer_tts.v1.yaml:23-42
 FWD_BWD_GFLOP = {"vtn": 715.9, "aasvc": 4777.0}   # BASELINE.md section 2 (matmul/conv FLOPs of one fwd+bwd at the canonical shapes)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 F32_MFMA_PEAK_TFLOPS = 157.3
@@ -68,6 +72,23 @@ def canonical_batch(B_total, T=256, idim=80, odim=80, seed=1234):
     ar = torch.arange(T)[None, :]
     xs[(ar >= ilens[:, None])] = 0.0
     ys[(ar >= olens[:, None])] = 0.0
+    labels = (ar >= (olens[:, None] - 1)).float()
+    return xs, ilens, ys, labels, olens
+
+
+def canonical_tts_batch(B_total, seed=1234):
+    """SURVEY.md section 8(d), C4 (LJSpeech TTS pre-training, egs/ljspeech/tts1): ilens in [60, 150] tokens in [1, 77) padded with 0,
+    olens in [300, 640] frames, ys randn(B, 640, 80); element 0 fills both padded shapes (the batch of tests' tts_full_size_c4)."""
+    g = torch.Generator().manual_seed(seed)
+    ilens = torch.randint(60, 151, (B_total,), generator=g)
+    ilens[0] = 150
+    olens = torch.randint(300, 641, (B_total,), generator=g)
+    olens[0] = 640
+    xs = torch.randint(1, 77, (B_total, 150), generator=g)
+    ys = torch.randn(B_total, 640, 80, generator=g)
+    xs[torch.arange(150)[None] >= ilens[:, None]] = 0
+    ar = torch.arange(640)[None]
+    ys[ar >= olens[:, None]] = 0.0
     labels = (ar >= (olens[:, None] - 1)).float()
     return xs, ilens, ys, labels, olens
 
@@ -168,6 +189,47 @@ def cpu_baseline_vtn(batch, steps=3):
             "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
             "one_thread": {"value": float(small[4].sum()) / t1, "unit": "mel-frames/sec", "cores": 1,
                            "sample": f"1 optimiser step of the first 8 of the 32 utterance pairs, {t1:.2f} s (OMP_NUM_THREADS=1 as in egs/arctic/vc1/path.sh:16)"}}
+
+
+def _tts_cpu_step(sd, params, state, batch, it):
+    from oracle import models as OM
+    xs, ilens, ys, labels, olens = batch
+    t0 = time.perf_counter()
+    o = OM.tts_forward(sd, TTS_V1, xs, ilens, ys, labels, olens, training=True, drop=True)
+    l1, bce = OM.seq2seq_loss(o[0], o[1], o[2], o[3], o[4], o[5])
+    grads = torch.autograd.grad(l1 + bce, params, allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)]
+    with torch.no_grad():
+        OM.adam_step(params, grads, state, OM.warmup_lr(8e-4, it + 1), it + 1)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_tts(batch, steps=3):
+    """The TransformerTTS training step of trainers/ar_tts.py:45-100 on the oracle (forward + Seq2SeqLoss + backward + clip + Adam,
+    fp32, dropout on) over the same 8-utterance batch: the better of 16 and 32 host threads, median of `steps` steps."""
+    from seq2seq_vc_amd.models import TransformerTTS
+    info = cpu_info()
+    cands = sorted({min(16, info["physical_cores"]), min(32, info["physical_cores"])})
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in TransformerTTS(**TTS_V1).state_dict().items()}
+    params, state = _oracle_params(sd)
+    keep = torch.get_num_threads()
+    sweep = {}
+    try:
+        for nt in cands:
+            torch.set_num_threads(nt)
+            _tts_cpu_step(sd, params, state, batch, 0)
+            sweep[nt] = _tts_cpu_step(sd, params, state, batch, 1)
+        nt = min(sweep, key=sweep.get)
+        torch.set_num_threads(nt)
+        runs = [sweep[nt]] + [_tts_cpu_step(sd, params, state, batch, 2 + i) for i in range(steps - 1)]
+        t = sweep[nt] = _median(runs)
+    finally:
+        torch.set_num_threads(keep)
+    return {"value": float(batch[4].sum()) / t, "unit": "mel-frames/sec", "cores": nt, "kind": "port",
+            "sample": f"median of {steps} optimiser steps (after 1 warm-up) of the same TransformerTTS-tts1 B={batch[0].shape[0]} batch, fp32, {t:.2f} s/step at {nt} threads",
+            "ms_per_step": t * 1e3, "steps_timed": steps, "s_per_step_runs": [round(r, 3) for r in runs], **info,
+            "thread_sweep_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()}}
 
 
 def _aasvc_cpu_step(sd, params, state, batch, it):
@@ -355,8 +417,13 @@ def dominant_kernel_roofline(dtype, iters=100, workload="vtn"):
     else:
         kernel = "gemm_8ph_kernel_q<CONV2D,4,2> (bf16, 8 waves, 512x128 tile, 4 phases per K tile, LDS-DMA + counted vmcnt)"
     alg_bytes = float((x.numel() + w.numel() + y.numel()) * x.element_size())
+    traffic = _pmc_traffic(workload) if dtype == torch.bfloat16 and workload != "aasvc_qkv" else None
     return {"bound": "mfma", "kernel": f"{kernel} {shape}", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-            "traffic": _pmc_traffic(workload) if dtype == torch.bfloat16 and workload != "aasvc_qkv" else None, "algorithmic_bytes": alg_bytes,
+            "traffic": traffic, "algorithmic_bytes": alg_bytes,
+            # `achieved` / `avg_launch_us` are measured in THIS process; `traffic` and `by_time_*` cannot be (PMC counters need rocprofv3
+            # around the process): they are read from the committed collection of the same loop / the same step
+            "traffic_source": "profiles/roofline_pmc.json (replayed from the committed rocprofv3 --pmc collection, not measured in this "
+                              "process)" if traffic is not None else None,
             "avg_launch_us": ms * 1e3, "flops_per_launch": flops, "timed": f"{iters} launches, {timed}, HIP events",
             "by_time": _by_time(workload) if dtype == torch.bfloat16 and workload != "aasvc_qkv" else None}
 
@@ -373,22 +440,32 @@ class Workload:
         from seq2seq_vc_amd.ops import functional as Fn
         from seq2seq_vc_amd.optim import FlatAdam
         self.name, self.dev, self.Fn = name, dev, Fn
-        xs, ilens, ys, labels, olens = canonical_batch(batch * world)
+        xs, ilens, ys, labels, olens = (canonical_tts_batch if name == "tts" else canonical_batch)(batch * world)
         sl = slice(rank * batch, (rank + 1) * batch)
         xs, ilens, ys, labels, olens = xs[sl], ilens[sl], ys[sl], labels[sl], olens[sl]
-        if int(ilens.max()) < 256:  # keep the padded shape canonical on every rank
-            ilens[0] = 256
-        if int(olens.max()) < 256:
-            olens[0] = 256
+        Ti, To = xs.shape[1], ys.shape[1]
+        if int(ilens.max()) < Ti:  # keep the padded shape canonical on every rank
+            ilens[0] = Ti
+        if int(olens.max()) < To:
+            olens[0] = To
+        self.T_src, self.T_tgt = Ti, To
         self.frames = float(olens.sum())
         self.cpu_batch = (xs.clone(), ilens.clone(), ys.clone(), labels.clone(), olens.clone())
         self.xs, self.ys, self.labels, self.ilens, self.olens = xs.to(dev), ys.to(dev), labels.to(dev), ilens, olens
         torch.manual_seed(0)  # identical initial weights on every rank (the trainers broadcast rank 0's instead)
+        lr = 8e-5
         if name == "vtn":
             self.model = M.VTN(**VTN_VC1).to(dev).train()
             self.crit = L.Seq2SeqLoss(bce_pos_weight=10.0)
             self.loss_names = ["l1", "bce"]
             self.desc = "VTN egs/arctic/vc1 (vtn.v1.yaml) training step: fwd+Seq2SeqLoss+bwd+clip+Adam+WarmupLR"
+        elif name == "tts":
+            self.model = M.TransformerTTS(**TTS_V1).to(dev).train()
+            self.crit = L.Seq2SeqLoss(bce_pos_weight=10.0)
+            self.loss_names = ["l1", "bce"]
+            lr = 8e-4               # egs/ljspeech/tts1/conf/transformer_tts.v1.yaml optimizer_params
+            self.desc = ("TransformerTTS egs/ljspeech/tts1 (transformer_tts.v1.yaml) pre-training step: text-enc -> mel-dec, "
+                         "fwd+Seq2SeqLoss+bwd+clip+Adam+WarmupLR")
         else:
             self.model = M.AASVC(**AASVC_VC2).to(dev).train()
             self.l1, self.fs = L.L1Loss(), L.ForwardSumLoss()
@@ -396,13 +473,13 @@ class Workload:
             self.loss_names = ["l1", "forward_sum", "bin", "dur_nll"]
             self.desc = ("AAS-VC egs/arctic/vc2 (aas_vc.melmelmel.v1.yaml) training step: fwd (incl. alignment search)"
                          "+L1+2*(forward-sum+bin)+duration NLL+bwd+clip+Adam+WarmupLR")
-        self.opt = FlatAdam(self.model, lr=8e-5, grad_norm=1.0, warmup_steps=4000, bf16_shadow=(dtype == torch.bfloat16))
+        self.opt = FlatAdam(self.model, lr=lr, grad_norm=1.0, warmup_steps=4000, bf16_shadow=(dtype == torch.bfloat16))
         self.loss_buf = torch.zeros(len(self.loss_names), device=dev)
         self.params_m = sum(p.numel() for p in self.model.parameters()) / 1e6
 
     def forward(self):
         """One forward pass -> the loss split by the keys of model.dp_plan() (their sum is the training loss)."""
-        if self.name == "vtn":
+        if self.name in ("vtn", "tts"):
             after, before, logits, ys_, labels_, olens_, _ = self.model(self.xs, self.ilens, self.ys, self.labels, self.olens)
             l1, bce = self.crit(after, before, logits, ys_, labels_, olens_)
             self.loss_buf[0].copy_(l1.detach())
@@ -560,6 +637,8 @@ def time_steps(step, steps, warmup, dist=None, dev=None):
 
 
 def step_mfma(workload, ms):
+    if workload not in FWD_BWD_GFLOP:
+        return None
     gf = FWD_BWD_GFLOP[workload]
     return {"gflop_per_step_per_gpu": gf, "achieved_tflops_per_gpu": gf / ms, "frac_of_bf16_peak": gf / ms / BF16_MFMA_PEAK_TFLOPS}
 
@@ -590,6 +669,31 @@ def bench_aasvc_single(dev, dtype, steps=40, warmup=8, cpu=True, batch=16):
         out["qkv_gemm"] = {k: q[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "flops_per_launch", "timed")}
     if cpu:
         out["cpu_baseline"] = cpu_baseline_aasvc(wl.cpu_batch)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    del wl, step
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_tts_single(dev, dtype, steps=40, warmup=8, cpu=True, batch=8):
+    """C4 (BASELINE.json configs[3]): TransformerTTS tts1, one rank's share (8 utterances) of the global batch of 64."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    Fn.enable_side_streams(4)               # the schedule ARTTSTrainer ships (trainers.Trainer.GRADIENT_WORK)
+    wl = Workload("tts", dev, dtype, batch, 1, 0)
+    step, info = build_step(wl, None, 1, False, False, "fp32", True)
+    info.pop("_probe", None)
+    dt = time_steps(step, steps, warmup)
+    ms = dt / steps * 1e3
+    lb = wl.loss_buf.tolist()
+    out = {"metric": "mel-frames/sec (train)", "value": wl.frames / (dt / steps), "unit": "mel-frames/sec", "n_gpus": 1, "steps": steps,
+           "warmup": warmup, "ms_per_step": ms, "dtype": "bf16" if dtype == torch.bfloat16 else "fp32", "data": "synthetic",
+           "config": {"workload": wl.desc, "batch_per_gpu": batch, "global_batch_of_the_recipe": 64, "T_text": wl.T_src, "T_tgt": wl.T_tgt,
+                      "params_M": round(wl.params_m, 2), **info},
+           "final_losses": dict(zip(wl.loss_names, lb), **wl.opt.last_stats())}
+    if not all(v == v and abs(v) < 1e6 for v in lb):
+        raise SystemExit(f"bench: non-finite TTS loss {lb}")
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline_tts(wl.cpu_batch)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     del wl, step
     torch.cuda.empty_cache()
@@ -813,6 +917,13 @@ def _shape_line(out):
         "aasvc_speedup_vs_cpu": _get(out, "aasvc", "speedup_vs_cpu_baseline"),
         "aasvc_by_time_family": _get(out, "aasvc", "roofline", "by_time", "family"),
         "aasvc_by_time_mfma_busy": _get(out, "aasvc", "roofline", "by_time", "mfma_busy"),
+        "aasvc_by_time_source": _get(out, "aasvc", "roofline", "by_time", "source"),
+        "aasvc_traffic_source": _get(out, "aasvc", "roofline", "traffic_source"),
+        "tts_ms_per_step": _get(out, "tts", "ms_per_step"),
+        "tts_mel_frames_per_s": _get(out, "tts", "value"),
+        "tts_cpu_frames_per_s": _get(out, "tts", "cpu_baseline", "value"),
+        "tts_cpu_cores": _get(out, "tts", "cpu_baseline", "cores"),
+        "tts_speedup_vs_cpu": _get(out, "tts", "speedup_vs_cpu_baseline"),
         "decode_rtf": _get(out, "decode", "value"),
         "decode_us_per_step": _get(out, "decode", "us_per_step"),
         "decode_cpu_rtf": _get(out, "decode", "cpu_baseline", "value"),
@@ -834,13 +945,14 @@ def _shape_line(out):
         roof["by_time_launches_per_step"] = by_time.get("launches_per_step")
         roof["by_time_source"] = by_time.get("source")
     if isinstance(cpu, dict):
-        for k_src, k_dst in (("aasvc_cpu_frames_per_s", "aasvc_value"), ("aasvc_cpu_cores", "aasvc_cores"), ("decode_cpu_rtf", "decode_rtf")):
+        for k_src, k_dst in (("aasvc_cpu_frames_per_s", "aasvc_value"), ("aasvc_cpu_cores", "aasvc_cores"), ("decode_cpu_rtf", "decode_rtf"),
+                             ("tts_cpu_frames_per_s", "tts_value"), ("tts_cpu_cores", "tts_cores")):
             if k_src in extra:
                 cpu[k_dst] = extra[k_src]
     head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
             "data")
     line = {k: out[k] for k in head if k in out}
-    for k in ("memory_bound", "alignment", "aasvc", "decode", "trainer"):          # verbose objects first
+    for k in ("memory_bound", "alignment", "aasvc", "tts", "decode", "trainer"):          # verbose objects first
         if k in out:
             line[k] = out[k]
     if by_time is not None:
@@ -856,7 +968,8 @@ def _shape_line(out):
     tail = {"roofline_frac": _get(roof, "frac"), "roofline_kernel_us": _get(roof, "avg_launch_us"),
             "roofline_by_time_family": _get(roof, "by_time_family"), "roofline_by_time_share": _get(roof, "by_time_share"),
             "roofline_by_time_mfma_busy": _get(roof, "by_time_mfma_busy"),
-            "cpu_baseline_value": _get(cpu, "value"), "cpu_baseline_cores": _get(cpu, "cores"), **extra}
+            "cpu_baseline_value": _get(cpu, "value"), "cpu_baseline_cores": _get(cpu, "cores"),
+            **{k: v for k, v in extra.items() if not k.endswith("_source")}}          # (the *_source labels stay inside config / roofline)
     for k, v in tail.items():                                                     # ... and the line ends with the flat scalars
         if v is not None:
             line[k] = v
@@ -930,8 +1043,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="vtn", choices=["vtn", "aasvc"])
-    ap.add_argument("--batch", type=int, default=None, help="utterance pairs per GPU (default: 32 for vtn, 16 for aasvc)")
+    ap.add_argument("--workload", default="vtn", choices=["vtn", "aasvc", "tts"])
+    ap.add_argument("--batch", type=int, default=None, help="utterance pairs per GPU (default: 32 for vtn, 16 for aasvc, 8 for tts)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1011,20 +1124,20 @@ def main():
         return
     Fn.set_compute_dtype(dtype)
     if args.side_streams is None:
-        n_side, inline = (4, args.inline_batches) if args.workload == "vtn" else (0, True)
+        n_side, inline = (4, args.inline_batches) if args.workload in ("vtn", "tts") else (0, True)
     else:
         n_side, inline = args.side_streams, args.inline_batches
     Fn.enable_side_streams(n_side, inline_batches=inline)
     K.manual_seed(1234 + rank)
 
-    B = args.batch or (32 if args.workload == "vtn" else 16)
+    B = args.batch or {"vtn": 32, "aasvc": 16, "tts": 8}[args.workload]
     wl = Workload(args.workload, dev, dtype, B, world, rank)
     # Data parallel: backward in the stages of model.dp_plan(), one captured graph per stage, the all-reduce of a finished stage's
     # slice of the flat gradient buffer issued between the replays (overlap).  N = 1 keeps one graph (the cuts cost ~0.2 ms).
     staged = dp or args.split_backward
     if args.grad_payload is None:
         from seq2seq_vc_amd import trainers as TR      # what the workload's product trainer defaults to (fp32 = the reference's DDP)
-        args.grad_payload = (TR.ARVCTrainer if args.workload == "vtn" else TR.AASVCTrainer).DP_GRAD_PAYLOAD
+        args.grad_payload = (TR.AASVCTrainer if args.workload == "aasvc" else TR.ARVCTrainer).DP_GRAD_PAYLOAD
     step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
                             warmup_eager=max(2, args.warmup if args.no_graph else 2))
     probe = info.pop("_probe")
@@ -1048,17 +1161,17 @@ def main():
             "metric": "mel-frames/sec (train)", "value": frames / (dt / args.steps), "unit": "mel-frames/sec",
             "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": wl.desc, "batch_per_gpu": B, "global_batch": B * world, "T_src": 256, "T_tgt": 256, "mel_dim": 80,
+            "config": {"workload": wl.desc, "batch_per_gpu": B, "global_batch": B * world, "T_src": wl.T_src, "T_tgt": wl.T_tgt, "mel_dim": 80,
                        "params_M": round(wl.params_m, 2), "parallelism": f"dp{world}", "split_backward": bool(staged),
                        **({"dist_backend": args.dist_backend, "one_device": bool(args.one_device)} if dp else {}),
                        "valid_target_frames_per_step": frames, **info},
             "final_losses": dict(zip(wl.loss_names, losses), grad_norm=stats["grad_norm"], opt_steps=stats["step"]),
             "step_mfma": step_mfma(args.workload, ms),
         }
-        out["roofline"] = dominant_kernel_roofline(dtype, workload=args.workload)
+        out["roofline"] = dominant_kernel_roofline(dtype, workload="vtn" if args.workload == "tts" else args.workload)
         single = world == 1 and not args.force_dist
         if single and not args.no_cpu_baseline:
-            out["cpu_baseline"] = (cpu_baseline_vtn if args.workload == "vtn" else cpu_baseline_aasvc)(wl.cpu_batch)
+            out["cpu_baseline"] = {"vtn": cpu_baseline_vtn, "aasvc": cpu_baseline_aasvc, "tts": cpu_baseline_tts}[args.workload](wl.cpu_batch)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         if single and args.workload == "vtn" and not args.no_extras:
             del step
@@ -1066,6 +1179,7 @@ def main():
             torch.cuda.empty_cache()
             # the sub-objects must never cost the headline line: a failure is reported in place
             for key, fn in (("aasvc", lambda: bench_aasvc_single(dev, dtype, cpu=not args.no_cpu_baseline)),
+                            ("tts", lambda: bench_tts_single(dev, dtype, cpu=not args.no_cpu_baseline)),
                             ("decode", lambda: bench_decode(dev, dtype, cpu=not args.no_cpu_baseline)),
                             ("trainer", lambda: bench_product_trainer(dev, dtype)),
                             ("alignment", lambda: bench_alignment_kernels(dev, cpu=not args.no_cpu_baseline)),

@@ -1170,13 +1170,13 @@ def captured_steps_on_short_batches_vs_oracle():
                             f"{tag}: 3 steps on ONE padded shape (quantum {Q}), none of the batches fills it; {n_graphs} captured graph(s), 1 replay"))
                 for it, (a, b) in enumerate(zip(logs, logs_o), 1):
                     worst = max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for k in b)
-                    res.append((worst <= (2e-5 if fp else 3e-2), f"{tag} step {it} ({'eager on padded buffers' if it == 1 else 'captured + replayed' if it == 2 else 'replayed'}): "
+                    res.append((worst <= (2e-5 if fp else 2e-3), f"{tag} step {it} ({'eager on padded buffers' if it == 1 else 'captured + replayed' if it == 2 else 'replayed'}): "
                                 f"logged losses vs the oracle on the cropped batch, worst rel. error {worst:.2e}  {[round(v, 5) for v in a.values()]}"))
                 got = dict(model.named_parameters())
                 num = sum(float((g_p[k].double() - g_o[k].double()).pow(2).sum()) for k in names)
                 den = sum(float(g_o[k].double().pow(2).sum()) for k in names)
                 rel = (num / den) ** 0.5
-                res.append((rel <= (3e-4 if fp else 0.12), f"{tag}: all parameter gradients of step 3 (replayed graph), flat rel-L2 vs oracle autograd {rel:.2e}"))
+                res.append((rel <= (3e-4 if fp else 0.14), f"{tag}: all parameter gradients of step 3 (replayed graph), flat rel-L2 vs oracle autograd {rel:.2e}"))
                 if fp:
                     worst, wname = 0.0, ""
                     for k in names:
@@ -1185,15 +1185,29 @@ def captured_steps_on_short_batches_vs_oracle():
                             worst, wname = e, k
                     res.append((worst <= 3e-4, f"{tag}: worst single parameter gradient, max abs err / (1 + max|ref|) = {worst:.2e} ({wname})"))
                 worst = max(float((got[k].detach().cpu().float() - sd_o[k].detach()).abs().max()) for k in names)
-                res.append((worst <= (1e-6 if fp else 1e-3), f"{tag}: parameters after 3 optimiser steps (clip + WarmupLR + Adam, eps {EPS:g}) vs the oracle's "
+                res.append((worst <= (1e-6 if fp else 1.2e-3), f"{tag}: parameters after 3 optimiser steps (clip + WarmupLR + Adam, eps {EPS:g}) vs the oracle's "
                             f"trainer replay: max abs diff {worst:.2e}"))
                 bufs = dict(model.named_buffers())
                 bn = [k for k in sd_o if "running_" in k]
                 worst = max(float(((bufs[k].detach().cpu() - sd_o[k]).abs() / (1.0 + sd_o[k].abs())).max()) for k in bn) if bn else 0.0
-                res.append((worst <= (2e-6 if fp else 5e-3), f"{tag}: {len(bn)} BatchNorm running statistics after 3 steps vs oracle (frames beyond the longest "
+                res.append((worst <= (2e-6 if fp else 1e-3), f"{tag}: {len(bn)} BatchNorm running statistics after 3 steps vs oracle (frames beyond the longest "
                             f"utterance are not counted): max |diff| / (1 + |ref|) {worst:.2e}"))
                 nbt = [k for k in sd_o if k.endswith("num_batches_tracked")]
                 res.append((all(int(bufs[k]) == int(sd_o[k]) for k in nbt), f"{tag}: num_batches_tracked equal ({len(nbt)} buffers)"))
+            # control: the same comparison with the absent-row handling switched off (every frame of the padded tensors present: what
+            # captured steps did before round 6) must FAIL -- the batches above do tell the two computations apart
+            from seq2seq_vc_amd import modules as Mo
+            keep = Mo.crop_dev
+            Mo.crop_dev = lambda lens: None
+            try:
+                _, logs, _, _, g_p = product_run(kind, cfg, z, data, torch.float32)
+            finally:
+                Mo.crop_dev = keep
+            worst = max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for a, b in zip(logs, logs_o) for k in b)
+            num = sum(float((g_p[k].double() - g_o[k].double()).pow(2).sum()) for k in names)
+            rel = (num / sum(float(g_o[k].double().pow(2).sum()) for k in names)) ** 0.5
+            res.append((worst > 1e-3 and rel > 1e-2, f"{kind} control (padded frames visible, fp32): losses off by {worst:.2e}, gradients by {rel:.2e} rel-L2 -- "
+                        "the comparison above is sensitive to what it claims"))
     finally:
         Fn.set_compute_dtype(torch.float32)
         Fn.enable_side_streams(0)
@@ -1350,7 +1364,9 @@ def trainer_classes_run_the_same_steps():
         batch = {"xs": t("in.xs"), "ilens": t("in.ilens"), "ys": t("in.ys"), "labels": t("in.labels"), "olens": t("in.olens")}
         logs = []
         with tempfile.TemporaryDirectory() as tmp:
-            conf = {"train_max_steps": 3, "log_interval_steps": 1, "save_interval_steps": 2, "grad_norm": 1.0, "outdir": tmp}
+            # hip_graph False: the comparison with the hand-rolled loop is about the trainer's bookkeeping, to the last bit; the captured
+            # steps (the default) pad 60 -> 64 / 48 -> 64 frames, which reorders sums (captured_steps_on_short_batches_vs_oracle covers them)
+            conf = {"train_max_steps": 3, "log_interval_steps": 1, "save_interval_steps": 2, "grad_norm": 1.0, "outdir": tmp, "hip_graph": False}
             tr = T.ARVCTrainer(0, 0, {"train": [batch] * 5}, None, model, None, {"Seq2SeqLoss": L.Seq2SeqLoss(10.0)}, opt, None,
                                conf, device=DEV)
             tr.log_fn = lambda step, d: logs.append((step, dict(d)))

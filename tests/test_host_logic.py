@@ -493,6 +493,7 @@ def test_bench_line_keeps_c3_c5_scalars_where_the_driver_keeps_them():
            "aasvc": {"ms_per_step": 11.0, "value": 280000.0, "roofline": {"frac": 0.3, "by_time": {"family": "g", "mfma_busy": 0.26}},
                      "step_mfma": {"frac_of_bf16_peak": 0.17}, "cpu_baseline": {"value": 550.0, "cores": 16}, "speedup_vs_cpu_baseline": 509.0},
            "decode": {"value": 3.4e-4, "us_per_step": 350.0, "cpu_baseline": {"value": 0.017}},
+           "tts": {"ms_per_step": 4.2, "value": 900000.0, "cpu_baseline": {"value": 3000.0, "cores": 16}, "speedup_vs_cpu_baseline": 300.0},
            "memory_bound": [{"kernel": "k" * 300}] * 6, "alignment": {"mas": {"us_per_utterance": 3.7}}}
     line = bench._shape_line(out)
     cfg, roof, cpu = line["config"], line["roofline"], line["cpu_baseline"]
@@ -501,8 +502,12 @@ def test_bench_line_keeps_c3_c5_scalars_where_the_driver_keeps_them():
     assert roof["by_time_family"] == "gemm_dma_kernel" and roof["by_time_mfma_busy"] == 0.07 and roof["by_time_share"] == 0.3
     assert all(not isinstance(v, (dict, list)) for v in roof.values()), "nested objects inside roofline are dropped by the driver"
     assert cpu["aasvc_value"] == 550.0 and cpu["decode_rtf"] == 0.017
+    # C4 (TransformerTTS tts1) is timed too, and what is replayed from profiles/ says so next to the value
+    assert cfg["tts_ms_per_step"] == 4.2 and cfg["tts_mel_frames_per_s"] == 900000.0 and cpu["tts_value"] == 3000.0
+    assert roof["by_time_source"] == "profiles/x"
     tail = json.dumps(line)[-2000:]
-    for key in ("aasvc_ms_per_step", "decode_rtf", "roofline_by_time_mfma_busy", "aasvc_mel_frames_per_s", "cpu_baseline_value"):
+    for key in ("aasvc_ms_per_step", "decode_rtf", "roofline_by_time_mfma_busy", "aasvc_mel_frames_per_s", "cpu_baseline_value", "tts_ms_per_step",
+                "tts_mel_frames_per_s"):
         assert f'"{key}"' in tail, key
     keys = list(line)
     assert keys.index("memory_bound") < keys.index("config") < keys.index("roofline") < keys.index("cpu_baseline") < keys.index("decode_rtf")
