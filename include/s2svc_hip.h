@@ -270,6 +270,9 @@ int s2svc_posenc_fwd(int dtype, int64_t B, int T, int D, const void* x, float xs
 int s2svc_posenc_bwd(int dtype, int64_t B, int T, int D, const void* dy, float xscale, const float* pe, float p,
                      const uint64_t* seed_base, uint64_t seed_off, void* dx, float* dalpha, float* partials, void* stream);
 int s2svc_axpby(int dtype, int64_t n, float a, const void* x, float b, const void* y, void* out, void* stream);
+/* out = x0 + x1 (+ x2 (+ x3)), k = 2..4 inputs summed in that order (fp32 arithmetic): the gradients arriving at a tensor with several
+   consumers, in one launch (what autograd's accumulation does with k - 1 element-wise adds). */
+int s2svc_add_n(int dtype, int64_t n, int k, const void* x0, const void* x1, const void* x2, const void* x3, void* out, void* stream);
 int s2svc_add_head_bias(int dtype, int64_t rows, int D, const void* q, const float* u, const float* v, void* qu, void* qv,
                         void* stream);
 /* the same with q a column block of a packed Q|K|V projection (row stride ldq elements); qu, qv dense (rows, D) */

@@ -131,6 +131,7 @@ _SIGS = {
     "s2svc_posenc_fwd": [c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp],
     "s2svc_posenc_bwd": [c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp],
     "s2svc_axpby": [c_i32, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp],
+    "s2svc_add_n": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_add_head_bias": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_add_head_bias_ld": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_add_rows": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],

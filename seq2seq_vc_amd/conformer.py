@@ -86,7 +86,8 @@ class EncoderLayer(nn.Module):
             steps.append((self.norm_conv, lambda y: self.conv_module(y, klens), 1.0))
         steps.append((self.norm_ff, ff(self.feed_forward), self.ff_scale))
         if pre:
-            y = steps[0][0](x)
+            n0 = steps[0][0]          # x feeds this norm AND the first residual: the residual takes the norm's pass-through alias
+            y, x = Fn.layer_norm(x, n0.weight, n0.bias, n0.eps, passthrough=True)
             for i, (_, fn, scale) in enumerate(steps):
                 h = fn(y)
                 nxt = steps[i + 1][0] if i + 1 < len(steps) else (self.norm_final if self.conv_module is not None else None)

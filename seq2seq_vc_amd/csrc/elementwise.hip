@@ -166,6 +166,41 @@ __global__ void axpby_kernel(int64_t n, float a, const T* __restrict__ x, float 
   }
 }
 
+// out = x0 + x1 (+ x2 (+ x3)), summed in that order in fp32: the gradients that meet at a tensor with several consumers
+// (ops.functional.fan_out) in ONE launch, instead of the k - 1 element-wise adds autograd's accumulation issues
+template <typename T>
+__global__ void add_n_kernel(int64_t n, const T* __restrict__ x0, const T* __restrict__ x1, const T* __restrict__ x2,
+                             const T* __restrict__ x3, T* __restrict__ out) {
+  EW_LOOP(i, n) {
+    float v = ldf(x0 + i) + ldf(x1 + i);
+    if (x2) v += ldf(x2 + i);
+    if (x3) v += ldf(x3 + i);
+    stf(out + i, v);
+  }
+}
+// the same on 8 bf16 / 4 fp32 values per lane (n a multiple of 8, 16-byte aligned tensors)
+__global__ void add_n_vec_bf16_kernel(int64_t n8, const uint4* __restrict__ x0, const uint4* __restrict__ x1, const uint4* __restrict__ x2,
+                                      const uint4* __restrict__ x3, uint4* __restrict__ out) {
+  EW_LOOP(i, n8) {
+    float a[8], b[8];
+    unpack_bf16x8(x0[i], a);
+    unpack_bf16x8(x1[i], b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e];
+    if (x2) {
+      unpack_bf16x8(x2[i], b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += b[e];
+    }
+    if (x3) {
+      unpack_bf16x8(x3[i], b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += b[e];
+    }
+    out[i] = pack_bf16x8(a);
+  }
+}
+
 // qu = q + u[h,:], qv = q + v[h,:]     q: (rows, D = H*dk), u/v: fp32 (D)
 // reference: modules/transformer/attention.py:283-286
 template <typename T>
@@ -406,6 +441,27 @@ extern "C" int s2svc_axpby(int dtype, int64_t n, float a, const void* x, float b
   else
     hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, n, a, (const bf16_t*)x, b, (const bf16_t*)y, (bf16_t*)out);
   S2S_CHECK_LAUNCH("axpby_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_add_n(int dtype, int64_t n, int k, const void* x0, const void* x1, const void* x2, const void* x3, void* out,
+                           void* stream) {
+  if (n == 0) return 0;
+  S2S_REQUIRE(k >= 2 && k <= 4 && x0 && x1 && out && (k < 3 || x2) && (k < 4 || x3), "add_n: 2 to 4 inputs");
+  hipStream_t st = (hipStream_t)stream;
+  if (k < 3) x2 = nullptr;
+  if (k < 4) x3 = nullptr;
+  const uintptr_t al = (uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)x3 | (uintptr_t)out;
+  if (dtype == S2S_F32)
+    hipLaunchKernelGGL(add_n_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, n, (const float*)x0, (const float*)x1, (const float*)x2,
+                       (const float*)x3, (float*)out);
+  else if (n % 8 == 0 && al % 16 == 0)
+    hipLaunchKernelGGL(add_n_vec_bf16_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, n / 8, (const uint4*)x0, (const uint4*)x1,
+                       (const uint4*)x2, (const uint4*)x3, (uint4*)out);
+  else
+    hipLaunchKernelGGL(add_n_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, n, (const bf16_t*)x0, (const bf16_t*)x1, (const bf16_t*)x2,
+                       (const bf16_t*)x3, (bf16_t*)out);
+  S2S_CHECK_LAUNCH("add_n_kernel");
   return 0;
 }
 

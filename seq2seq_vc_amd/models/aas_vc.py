@@ -243,13 +243,22 @@ class AASVC(nn.Module):
             hs = hs.contiguous().view(b, tmax // pr, dim * pr)
             il = il.map(lambda v: v // pr)
         Th = hs.shape[1]
+        uses_hs = self.duration_predictor_use_encoder_outputs and self.duration_predictor_type != "stochastic"     # (the stochastic one detaches)
+        hs_dp = hs
+        if not is_inference and ys is not None:
+            # consumers of the encoder output: alignment module, length regulator (, deterministic duration predictor): one launch sums
+            # their gradients (Fn.fan_out) instead of autograd's element-wise adds
+            hs, hs_al, *rest = Fn.fan_out(hs, 3 if uses_hs else 2)
+            hs_dp = rest[0] if rest else hs.detach()
+        else:
+            hs_al = hs
 
         def dp_input():
             """Input of the duration predictor: the encoder output or the projection of `dp_inputs`.  The projection belongs to
             the duration branch: in training it runs inside branch_run, so that no node of the branch's backward pass sits on
             the main stream (where it would stall everything queued behind it until the branch has finished)."""
             if self.duration_predictor_use_encoder_outputs:
-                return hs
+                return hs_dp
             if dplens is not None and Mo._BANK is not None:
                 # captured step: the projection's output and the encoder's have padded lengths; F.interpolate's ratio is the one
                 # of the reference's cropped tensors (graph data, modules.LensBank)
@@ -288,12 +297,14 @@ class AASVC(nn.Module):
         else:
             if f_pre is not None:
                 Fn.branch_join(f_pre)
-                log_p_attn = self.alignment_module(hs, None, il_c, f=f_pre)
+                log_p_attn = self.alignment_module(hs_al, None, il_c, f=f_pre)
             else:
-                log_p_attn = self.alignment_module(hs, Fn.to_compute(ys), il_c, feat_lens=olr)
+                log_p_attn = self.alignment_module(hs_al, Fn.to_compute(ys), il_c, feat_lens=olr)
+            # two consumers: the alignment search's binarisation loss here, the forward-sum loss of the trainer (returned tensor)
+            log_p_attn, lp_search = Fn.fan_out(log_p_attn, 2)
             if self.forward_sum_prefetch is not None:
                 self.forward_sum_prefetch(log_p_attn, il, olr)
-            ds, bin_loss = self.viterbi_func(log_p_attn, il_c, olr)
+            ds, bin_loss = self.viterbi_func(lp_search, il_c, olr)
             if stochastic:
                 # ~330 small launches that depend on nothing the length regulator / decoder / postnet below produce: they
                 # run on the auxiliary stream beside them (forward here, backward through autograd's stream rule)
@@ -306,10 +317,13 @@ class AASVC(nn.Module):
             dec_lens = olr
         zs, _ = self.decoder(hs, dec_lens)
         before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, self.odim)
+        b_res = b_post = before
+        if self.postnet is not None:        # three consumers (loss, residual, Postnet): their gradients meet in one launch
+            before, b_res, b_post = Fn.fan_out(before, 3)
         post_lens = None
         if self.postnet is not None and dec_lens is not None and dec_lens.cap is not None:     # captured step: frames of `before`
             post_lens = dec_lens if dr == 1 else dec_lens.map(lambda v, _r=dr: v * _r)
-        after = before if self.postnet is None else Fn.add_dropout(before, self.postnet(before, post_lens), 0.0)
+        after = before if self.postnet is None else Fn.add_dropout(b_res, self.postnet(b_post, post_lens), 0.0)
         ret["before_outs"], ret["after_outs"] = before, after
         Fn.branch_join(ret.get("dur_nll"), *(getattr(log_p_attn, "_s2s_fs", None) or ())[:2])
         ret["ds"] = ds

@@ -130,6 +130,9 @@ class _ARSeq2Seq(nn.Module):
         else:
             zs, _ = self.decoder(Fn.to_compute(ys_in), olens_in_h, hs, hs_lens, causal=True)
         before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, odim)
+        b_post = b_res = before
+        if self.postnet is not None:        # three consumers (loss, residual, Postnet): their gradients meet in one launch
+            before, b_res, b_post = Fn.fan_out(before, 3)
         # captured step (modules.LensBank): `before` has olens_in * r frames per utterance; the Postnet must not see the frames the
         # reference's cropped batch does not have (vtn.py:208-214: ys is cropped to the longest utterance before anything runs)
         post_lens = None
@@ -140,11 +143,11 @@ class _ARSeq2Seq(nn.Module):
             # slow general kernels) beside the Postnet instead of in front of it: the auxiliary stream is idle here, and autograd runs
             # its backward node there too -- beside the Postnet's backward pass instead of between it and feat_out's
             (logits,) = Fn.branch_run(lambda: (Fn.linear(zs, self.prob_out.weight, self.prob_out.bias).view(zs.size(0), -1),), uses=(zs,))
-            after = Fn.add_dropout(before, self.postnet(before, post_lens), 0.0)
+            after = Fn.add_dropout(b_res, self.postnet(b_post, post_lens), 0.0)
             Fn.branch_join(logits)
         else:
             logits = Fn.linear(zs, self.prob_out.weight, self.prob_out.bias).view(zs.size(0), -1)
-            after = Fn.add_dropout(before, self.postnet(before, post_lens), 0.0) if self.postnet is not None else before
+            after = Fn.add_dropout(b_res, self.postnet(b_post, post_lens), 0.0) if self.postnet is not None else before
         olens_out = olens
         if r > 1:
             if min(olens_h.host) < r:

@@ -499,7 +499,10 @@ class EncoderLayer(nn.Module):
         Implemented as explicit residual/norm steps so every add+dropout+LN is ONE fused kernel."""
         p = self.dropout_rate if self.training else 0.0
         if self.normalize_before:
-            y = self.norm1(x) if normed is None else normed
+            if normed is None:        # x feeds the norm AND the residual: the residual takes the norm's pass-through alias
+                y, x = Fn.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, passthrough=True)
+            else:
+                y = normed
             a = self.self_attn(y, y, y, klens)
             y2, x = _res_norm(self.norm2, x, a, p)
             f = self.feed_forward(y2, klens) if isinstance(self.feed_forward, MultiLayeredConv1d) else self.feed_forward(y2)
@@ -532,7 +535,10 @@ class DecoderLayer(nn.Module):
         source attention.  -> (y, x): y feeds the source attention, x is the residual stream (post-LN: the same tensor)."""
         p = self.dropout_rate if self.training else 0.0
         if self.normalize_before:
-            y = self.norm1(x) if normed is None else normed
+            if normed is None:
+                y, x = Fn.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, passthrough=True)
+            else:
+                y = normed
             a = self.self_attn(y, y, y, tgt_lens, causal=causal)
             return _res_norm(self.norm2, x, a, p)
         a, xr = _sub_pass(self.self_attn, x, x, x, tgt_lens, causal=causal)

@@ -696,8 +696,75 @@ class _AddLayerNorm(Function):
         return ds, None, dgamma, dbeta, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-12):
-    return _AddLayerNorm.apply(x, None, gamma, beta, eps, 0.0, 1.0)
+class _LayerNormPass(Function):
+    """(LayerNorm(x), alias of x): a pre-LN layer feeds x to its first norm AND to the residual behind the first sub-layer.  With the
+    residual taken from the alias both gradients meet inside the LayerNorm backward kernel (its `ds_extra` operand) instead of in an
+    element-wise add of autograd's accumulation (8 x 7 us on the chain of an AAS-VC step: profiles/r05_aasvc_train_bf16_timeline.txt)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        y, _, mean, rstd = K.layernorm_fwd(x, gamma, beta, eps)
+        ctx.params = (gamma, beta)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dx_pass=None):
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        if dy is None:                                  # only the alias was used
+            return dx_pass, None, None, None
+        dy = _c(dy)
+        slotted = gamma.requires_grad and _slotted(gamma, beta)
+        ds, _, part = K.layernorm_bwd(dy, x, mean, rstd, gamma, ds_extra=_c(dx_pass) if dx_pass is not None else None,
+                                      want_partials=True, partials_ok=slotted)
+        dgamma = dbeta = None
+        if gamma.requires_grad:
+            if part is not None:
+                ws, chunks = part
+                b_slot, g_slot = beta._s2s_grad.view(-1), gamma._s2s_grad.view(-1)
+                _side_run(lambda: K.colreduce_partials(ws, chunks, x.shape[-1], b_slot, g_slot), keep=(ws,))
+            elif _slotted(gamma, beta):
+                _side_run(lambda: _reduce_to(beta, gamma, 1, dy, x, mean, rstd), keep=(dy, x, mean, rstd))
+            else:
+                dbeta, dgamma = _reduce_to(beta, gamma, 1, dy, x, mean, rstd)
+        return ds, dgamma, dbeta, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-12, passthrough=False):
+    """passthrough=True -> (LayerNorm(x), alias of x): take a residual that starts at x from the alias (see _LayerNormPass)."""
+    if passthrough and torch.is_grad_enabled() and x.requires_grad:
+        return _LayerNormPass.apply(x, gamma, beta, eps)
+    y = _AddLayerNorm.apply(x, None, gamma, beta, eps, 0.0, 1.0)
+    return (y, x) if passthrough else y
+
+
+class _FanOut(Function):
+    """n aliases of x for n consumers: their gradients arrive at ONE autograd node and are summed by one launch of s2svc_add_n (two
+    when n > 4) instead of by n - 1 element-wise adds of autograd's accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [_c(g) for g in grads if g is not None]
+        if not gs:
+            return None, None
+        while len(gs) > 1:
+            gs = [K.add_n(gs[:4])] + gs[4:]
+        return gs[0], None
+
+
+def fan_out(x, n):
+    """x for n consumers (see _FanOut); plain copies of the reference when no gradient is recorded."""
+    if n < 2 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return _FanOut.apply(x, n)
 
 
 def add_dropout_layer_norm(res, h, gamma, beta, eps=1e-12, p=0.0, hscale=1.0):

@@ -702,6 +702,15 @@ def axpby(a, x, b=0.0, y=None, out=None):
     return out
 
 
+def add_n(xs, out=None):
+    """Sum of 2..4 tensors of one shape / dtype in one launch (fp32 arithmetic, fixed order)."""
+    x0 = xs[0]
+    out = torch.empty_like(x0) if out is None else out
+    p = [ptr(t) for t in xs] + [None] * (4 - len(xs))
+    _lib.check(_lib.lib().s2svc_add_n(dt(x0), x0.numel(), len(xs), p[0], p[1], p[2], p[3], ptr(out), stream()), "add_n")
+    return out
+
+
 def add_head_bias(q, u, v):
     D = q.shape[-1]
     qu, qv = torch.empty_like(q), torch.empty_like(q)
