@@ -477,20 +477,22 @@ class Workload:
         self.loss_buf = torch.zeros(len(self.loss_names), device=dev)
         self.params_m = sum(p.numel() for p in self.model.parameters()) / 1e6
 
-    def forward(self):
-        """One forward pass -> the loss split by the keys of model.dp_plan() (their sum is the training loss)."""
+    def forward(self, staged=True):
+        """One forward pass -> the loss split by the keys of model.dp_plan() (their sum is the training loss); staged=False: one key."""
+        from seq2seq_vc_amd.ops import kernels as K
         if self.name in ("vtn", "tts"):
             after, before, logits, ys_, labels_, olens_, _ = self.model(self.xs, self.ilens, self.ys, self.labels, self.olens)
             l1, bce = self.crit(after, before, logits, ys_, labels_, olens_)
-            self.loss_buf[0].copy_(l1.detach())
-            self.loss_buf[1].copy_(bce.detach())
-            return {"loss": l1 + bce}
+            K.scalars_axpy([(l1.detach(), 1.0), (bce.detach(), 1.0)], self.loss_buf, beta=0.0)     # (logging: one launch of the library)
+            return {"loss": self.Fn.weighted_sum([(l1, 1.0), (bce, 1.0)])}
         ret = self.model(self.xs, self.ilens, self.ys, self.olens, self.xs, dp_lengths=self.ilens)
         l1 = self.l1(ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
         fs = self.fs(ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
-        dur = torch.sum(ret["dur_nll"].float())
-        self.loss_buf.copy_(torch.stack([l1.detach().float(), fs.detach().float(), ret["bin_loss"].detach().float(), dur.detach()]))
-        return {"decoder": l1, "align": 2.0 * (fs + ret["bin_loss"]) + dur}
+        dur = ret["dur_nll"]          # (B,): summed inside the launches below
+        K.scalars_axpy([(l1.detach(), 1.0), (fs.detach(), 1.0), (ret["bin_loss"].detach(), 1.0), (dur.detach(), 1.0)], self.loss_buf, beta=0.0)
+        if not staged:
+            return {"loss": self.Fn.weighted_sum([(l1, 1.0), (fs, 2.0), (ret["bin_loss"], 2.0), (dur, 1.0)])}
+        return {"decoder": l1, "align": self.Fn.weighted_sum([(fs, 2.0), (ret["bin_loss"], 2.0), (dur, 1.0)])}
 
 
 def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_eager=2, collective="allreduce"):
@@ -513,12 +515,9 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
 
     def fwd_bwd():
         begin()
-        losses = wl.forward()
-        total = None
-        for v in losses.values():
-            total = v if total is None else total + v
+        (total,) = wl.forward(staged=False).values()
         opt.join_prologue()
-        total.backward()
+        Fn.root_backward(total)
         Fn.side_join()
 
     def stage(i):

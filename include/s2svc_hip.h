@@ -270,6 +270,32 @@ int s2svc_posenc_fwd(int dtype, int64_t B, int T, int D, const void* x, float xs
 int s2svc_posenc_bwd(int dtype, int64_t B, int T, int D, const void* dy, float xscale, const float* pe, float p,
                      const uint64_t* seed_base, uint64_t seed_off, void* dx, float* dalpha, float* partials, void* stream);
 int s2svc_axpby(int dtype, int64_t n, float a, const void* x, float b, const void* y, void* out, void* stream);
+/* ---- scalar / index glue of a training step (csrc/glue.hip): what sits between the fused kernels, one small launch each ---- */
+#define S2SVC_SCALAR_TERMS_MAX 8
+typedef struct {
+  const float* x[S2SVC_SCALAR_TERMS_MAX]; /* term i: n[i] fp32 values (a scalar: n = 1) */
+  int32_t n[S2SVC_SCALAR_TERMS_MAX];
+  float w[S2SVC_SCALAR_TERMS_MAX];
+  int32_t k;                              /* number of terms */
+  int32_t reserved_;
+} s2svc_scalar_terms;
+/* *out = sum_i w[i] * sum_j x[i][j]: the training loss from its parts (trainers/aas_vc.py:100-139), means over the batch
+   (forward_sum_loss.py:70-76, alignments.py:303-309); one wavefront, fixed order. */
+int s2svc_weighted_sum(const s2svc_scalar_terms* terms /* host */, float* out, void* stream);
+/* its backward: x[i][j] (written!) = w[i] * *g */
+int s2svc_weighted_sum_bwd(const s2svc_scalar_terms* grads /* host; x[] are the OUTPUT buffers */, const float* g, void* stream);
+/* acc[i] = beta * acc[i] + w[i] * sum_j x[i][j]: the running sums of the logged losses (trainers/base.py:198-213) */
+int s2svc_scalars_axpy(const s2svc_scalar_terms* terms /* host */, float beta, float* acc, void* stream);
+int s2svc_fill_zero(void* p, int64_t nbytes, void* stream);
+/* *seed += inc (the device-resident dropout seed base, one bump per step) */
+int s2svc_seed_advance(uint64_t* seed, uint64_t inc, void* stream);
+/* out (rows, ldo) = [in (rows, N) | zeros] */
+int s2svc_pad_cols(int dtype, int64_t rows, int N, int ldo, const void* in, void* out, void* stream);
+/* teacher-forcing input of the AR decoder (models/vtn.py:236-243): out[b, t, :] = t == 0 ? 0 : ys[b, t * r - 1, :], ys fp32 with
+   batch stride ys_batch_stride elements, out (B, Tin, D) in out_dtype */
+int s2svc_decoder_input(int out_dtype, int B, int Tin, int r, int D, int64_t ys_batch_stride, const float* ys, void* out, void* stream);
+/* stop-token targets (models/vtn.py:253-260): out (B, T) = labels (row stride ld_labels) with a 1 at frame lens[b] - 1 */
+int s2svc_stop_labels(int B, int T, int64_t ld_labels, const float* labels, const int32_t* lens, float* out, void* stream);
 /* out = x0 + x1 (+ x2 (+ x3)), k = 2..4 inputs summed in that order (fp32 arithmetic): the gradients arriving at a tensor with several
    consumers, in one launch (what autograd's accumulation does with k - 1 element-wise adds). */
 int s2svc_add_n(int dtype, int64_t n, int k, const void* x0, const void* x1, const void* x2, const void* x3, void* out, void* stream);
@@ -521,9 +547,9 @@ int s2svc_sdp_mid_bwd(int B, int T, const float* zu, const float* z1, const floa
                       const float* dy0, const float* dy1, const float* dlz, float* dzu, float* dz1, float* part, void* stream);
 int s2svc_sdp_tail_fwd(int B, int T, const float* noise, const int32_t* lens, const float* zu, const float* lz,
                        const float* lad_q, const float* lad_p, const float* af, const float* bf, const float* logs_q,
-                       const float* logs_p, float* out, void* stream);
+                       const float* logs_p, float* out, int normalize /* 1: / sum_b min(lens[b], T), aas_vc.py:403 */, void* stream);
 int s2svc_sdp_tail_bwd(int B, int T, const float* g, const int32_t* lens, const float* zu, const float* af, const float* bf,
-                       float* d_af, float* d_bf, float* d_lz, float* d_zu, float* neg_g, float* part, void* stream);
+                       float* d_af, float* d_bf, float* d_lz, float* d_zu, float* neg_g, float* part, int normalize, void* stream);
 /* inference read-out: dur = ceil(exp((a - m0)*exp(-logs0)))*mask   (duration_predictor.py:300-304) */
 int s2svc_sdp_inverse_out(int B, int T, const float* a, const int32_t* lens, const float* m, const float* logs, float* dur,
                           void* stream);

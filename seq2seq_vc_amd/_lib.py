@@ -82,6 +82,10 @@ class GemmDesc(ctypes.Structure):
                 ("cm_pt", c_i32), ("cm_pf", c_i32), ("reserved3_", c_i32), ("c_pre", c_vp)]
 
 
+class ScalarTerms(ctypes.Structure):
+    _fields_ = [("x", c_vp * 8), ("n", c_i32 * 8), ("w", c_f32 * 8), ("k", c_i32), ("reserved_", c_i32)]
+
+
 class Gather3Job(ctypes.Structure):
     _fields_ = [("in_", c_vp), ("out", c_vp), ("s0", c_i64), ("s1", c_i64), ("s2", c_i64), ("off", c_i64), ("n0", c_i32),
                 ("n1", c_i32), ("n2", c_i32), ("out_dtype", c_i32)]
@@ -132,6 +136,14 @@ _SIGS = {
     "s2svc_posenc_bwd": [c_i32, c_i64, c_i32, c_i32, c_vp, c_f32, c_vp, c_f32, c_vp, c_u64, c_vp, c_vp, c_vp, c_vp],
     "s2svc_axpby": [c_i32, c_i64, c_f32, c_vp, c_f32, c_vp, c_vp, c_vp],
     "s2svc_add_n": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_weighted_sum": [ctypes.POINTER(ScalarTerms), c_vp, c_vp],
+    "s2svc_weighted_sum_bwd": [ctypes.POINTER(ScalarTerms), c_vp, c_vp],
+    "s2svc_scalars_axpy": [ctypes.POINTER(ScalarTerms), c_f32, c_vp, c_vp],
+    "s2svc_fill_zero": [c_vp, c_i64, c_vp],
+    "s2svc_seed_advance": [c_vp, c_u64, c_vp],
+    "s2svc_pad_cols": [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "s2svc_decoder_input": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp],
+    "s2svc_stop_labels": [c_i32, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp],
     "s2svc_add_head_bias": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_add_head_bias_ld": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_add_rows": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
@@ -203,8 +215,8 @@ _SIGS = {
     "s2svc_sdp_head_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_sdp_mid_fwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_sdp_mid_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "s2svc_sdp_tail_fwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
-    "s2svc_sdp_tail_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_sdp_tail_fwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
+    "s2svc_sdp_tail_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp],
     "s2svc_sdp_inverse_out": [c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_decode_posenc": [c_i32, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_decode_attn": [c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32,

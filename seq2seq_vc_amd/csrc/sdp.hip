@@ -506,12 +506,19 @@ __global__ __launch_bounds__(256) void sdp_mid_bwd_kernel(int Tn, const float* _
 //   logdet_p = sum_t -lz + sum_t mask*(logs_p0 + logs_p1) + sum_t lad_p
 //   nll      = sum_t 0.5*mask*(2*log(2pi) + a^2 + b^2) - logdet_p ;   out[b] = nll + logq
 // ------------------------------------------------------------------------------------------------
+// number of non-padded positions of the batch: sum_b min(lens[b], Tn)  (uniform loads, B is a batch size)
+__device__ __forceinline__ int sdp_total_frames(int B, int Tn, const int32_t* __restrict__ lens) {
+  int n = 0;
+  for (int b = 0; b < B; ++b) n += lens[b] < Tn ? (lens[b] > 0 ? lens[b] : 0) : Tn;
+  return n > 0 ? n : 1;
+}
+
 __global__ __launch_bounds__(256) void sdp_tail_fwd_kernel(int Tn, const float* __restrict__ noise, const int32_t* __restrict__ lens,
                                                            const float* __restrict__ zu, const float* __restrict__ lz,
                                                            const float* __restrict__ lad_q, const float* __restrict__ lad_p,
                                                            const float* __restrict__ af, const float* __restrict__ bf,
                                                            const float* __restrict__ logs_q, const float* __restrict__ logs_p,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, int normalize) {
   __shared__ float sh[4];
   const int b = blockIdx.x;
   const int n = lens[b] < Tn ? lens[b] : Tn;
@@ -529,20 +536,25 @@ __global__ __launch_bounds__(256) void sdp_tail_fwd_kernel(int Tn, const float* 
     acc += nll + logq;
   }
   acc = block_sum_256(acc, sh);
-  if (threadIdx.x == 0) out[b] = acc;
+  if (threadIdx.x == 0) {
+    // normalize: / the number of non-padded text positions of the whole batch (models/aas_vc.py:403: `/ torch.sum(h_masks)` applied here)
+    if (normalize) acc /= (float)sdp_total_frames((int)gridDim.x, Tn, lens);
+    out[b] = acc;
+  }
 }
 
+// (sdp_total_frames: defined above the forward kernel)
 // g[b] = d loss / d out[b].  d_af = g*a, d_bf = g*b, d_lz = +g, d_zu = -g*(1 - 2*sigmoid(z_u)) on valid rows;
 // the gradient of every lad row is -g[b] (handed to the spline backward as a per-utterance scalar);
 // the direct gradient of each of logs_q0, logs_q1, logs_p0, logs_p1 is sum_b -g[b]*frames[b]: part[b, 0..1] = -g*frames
 __global__ void sdp_tail_bwd_kernel(int B, int Tn, const float* __restrict__ g, const int32_t* __restrict__ lens,
                                     const float* __restrict__ zu, const float* __restrict__ af, const float* __restrict__ bf,
                                     float* __restrict__ d_af, float* __restrict__ d_bf, float* __restrict__ d_lz,
-                                    float* __restrict__ d_zu, float* __restrict__ neg_g, float* __restrict__ part) {
+                                    float* __restrict__ d_zu, float* __restrict__ neg_g, float* __restrict__ part, int normalize) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * Tn) return;
   const int b = i / Tn, t = i % Tn;
-  const float gb = g[b];
+  const float gb = normalize ? g[b] / (float)sdp_total_frames(B, Tn, lens) : g[b];
   const bool ok = t < lens[b];
   d_af[i] = ok ? gb * af[i] : 0.f;
   d_bf[i] = ok ? gb * bf[i] : 0.f;
@@ -735,9 +747,10 @@ extern "C" int s2svc_sdp_mid_bwd(int B, int Tn, const float* zu, const float* z1
 
 extern "C" int s2svc_sdp_tail_fwd(int B, int Tn, const float* noise, const int32_t* lens, const float* zu, const float* lz,
                                   const float* lad_q, const float* lad_p, const float* af, const float* bf, const float* logs_q,
-                                  const float* logs_p, float* out, void* stream) {
+                                  const float* logs_p, float* out, int normalize, void* stream) {
   if (B == 0) return 0;
-  hipLaunchKernelGGL(sdp_tail_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Tn, noise, lens, zu, lz, lad_q, lad_p, af, bf, logs_q, logs_p, out);
+  hipLaunchKernelGGL(sdp_tail_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, Tn, noise, lens, zu, lz, lad_q, lad_p, af, bf, logs_q, logs_p, out,
+                     normalize);
   S2S_CHECK_LAUNCH("sdp_tail_fwd_kernel");
   return 0;
 }
@@ -752,10 +765,10 @@ extern "C" int s2svc_sdp_inverse_out(int B, int Tn, const float* a, const int32_
 
 extern "C" int s2svc_sdp_tail_bwd(int B, int Tn, const float* g, const int32_t* lens, const float* zu, const float* af,
                                   const float* bf, float* d_af, float* d_bf, float* d_lz, float* d_zu, float* neg_g, float* part,
-                                  void* stream) {
+                                  int normalize, void* stream) {
   if (B * Tn == 0) return 0;
   hipLaunchKernelGGL(sdp_tail_bwd_kernel, dim3(blocks_for((int64_t)B * Tn)), dim3(256), 0, (hipStream_t)stream, B, Tn, g, lens, zu, af, bf,
-                     d_af, d_bf, d_lz, d_zu, neg_g, part);
+                     d_af, d_bf, d_lz, d_zu, neg_g, part, normalize);
   S2S_CHECK_LAUNCH("sdp_tail_bwd_kernel");
   return 0;
 }

@@ -240,16 +240,15 @@ class OverlappedBackward:
         elif branch_root is not None:                            # first: the calling stream is still empty
             loss = losses.get(branch_root[5:])
             if loss is not None and loss.requires_grad:
-                loss = loss * s if s != 1.0 else loss
                 if fork is not None:
-                    Fn.branch_backward(loss, fork, retain_graph=Fn._RETAIN)
+                    Fn.branch_backward(loss, fork, retain_graph=Fn._RETAIN, scale=s)
                 else:
-                    loss.backward(retain_graph=Fn._RETAIN)
+                    Fn.root_backward(loss, s, retain_graph=Fn._RETAIN)
         for root in ([roots] if isinstance(roots, str) else list(roots)):
             if root.startswith("loss:"):
                 loss = losses.get(root[5:])
                 if loss is not None and loss.requires_grad:
-                    (loss * s if s != 1.0 else loss).backward(retain_graph=Fn._RETAIN)
+                    Fn.root_backward(loss, s, retain_graph=Fn._RETAIN)
             else:
                 self.cuts.resume(root[4:])
         Fn.side_join()

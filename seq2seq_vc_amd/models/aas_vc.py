@@ -272,9 +272,6 @@ class AASVC(nn.Module):
         Tx = hs.shape[1]
         il_c = il.clamp(Tx)
         stochastic = self.duration_predictor_type == "stochastic"
-        def n_text():       # number of non-pad text positions (device scalar); only the duration branch divides by it
-            return torch.sum(torch.arange(Tx, device=dev)[None, :] < il_c.dev[:, None])
-
         if is_inference:
             log_p_attn, ds, bin_loss = None, None, 0.0
             if ys is not None:
@@ -308,7 +305,8 @@ class AASVC(nn.Module):
             if stochastic:
                 # ~330 small launches that depend on nothing the length regulator / decoder / postnet below produce: they
                 # run on the auxiliary stream beside them (forward here, backward through autograd's stream rule)
-                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dp_input(), il_c, w=ds) / n_text(),
+                # (normalize: / the number of non-pad text positions, aas_vc.py:403, inside the NLL kernel)
+                ret["dur_nll"] = Fn.branch_run(lambda: self.duration_predictor.forward_cl(dp_input(), il_c, w=ds, normalize=True),
                                                uses=(ds, hs, dp_inputs, il_c.dev))
             else:
                 d_outs = self.duration_predictor(dpi, il_c)

@@ -94,6 +94,8 @@ class _ARSeq2Seq(nn.Module):
         else:
             ys_in, olens_in_h = ys, olens_h
         def shifted():
+            if ys.is_cuda and ys.dtype == torch.float32 and ys.stride(2) == 1 and ys.stride(1) == ys.shape[2]:
+                return K.decoder_input(ys, r, Fn.compute_dtype())        # shift + stride r + cast, one launch (csrc/glue.hip)
             return torch.cat([ys_in.new_zeros((ys_in.shape[0], 1, ys_in.shape[2])), ys_in[:, :-1]], dim=1)
 
         head, stop = None, None
@@ -114,6 +116,8 @@ class _ARSeq2Seq(nn.Module):
         r = self.decoder_reduction_factor
         olens_out_h = olens_h.map(lambda v: v - v % r)
         mx = olens_out_h.max()
+        if labels.is_cuda and labels.dtype == torch.float32 and labels.stride(1) == 1:
+            return olens_out_h, K.stop_labels(labels, olens_out_h.dev, mx)
         idx = (olens_out_h.dev.long() - 1).unsqueeze(1)
         return olens_out_h, torch.scatter(labels[:, :mx], 1, idx, 1.0)
 

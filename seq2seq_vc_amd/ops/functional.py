@@ -365,7 +365,7 @@ def branch_join(*results):
         _Branch.active = False
 
 
-def branch_backward(loss, fork_event, retain_graph=False):
+def branch_backward(loss, fork_event, retain_graph=False, scale=1.0):
     """loss.backward() rooted on the auxiliary stream, which starts from `fork_event` (recorded on the calling stream at the
     start of a backward stage).  Call it BEFORE the stage's other roots and branch_wait() after them: the nodes of a
     sub-network that ran under branch_run() go to the auxiliary stream, the loss arithmetic and whatever else of this root ran on
@@ -373,12 +373,12 @@ def branch_backward(loss, fork_event, retain_graph=False):
     on the calling stream after other work puts its first nodes -- and with them the whole branch -- behind that work; one
     processed there before it stalls the caller at the first node that consumes a result of the branch.)"""
     if _Branch.stream is None or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
-        loss.backward(retain_graph=retain_graph)
+        root_backward(loss, scale, retain_graph)
         return
     _Branch.stream.wait_event(fork_event)
     _Branch.dirty = True
     with torch.cuda.stream(_Branch.stream):
-        loss.backward(retain_graph=retain_graph)
+        root_backward(loss, scale, retain_graph)
 
 
 def branch_resume(cuts, name, fork_event):
@@ -516,9 +516,7 @@ class _Linear(Function):
             # element-wise fallback kernel (19 + 37 us per flow): a zero-padded copy with rows of a whole number of 16-byte vectors
             # puts them on the vectorised kernels (the pad columns contribute zeros to the reductions and are never stored)
             ldy, zp = (N + 3) // 4 * 4, True
-            dyp = torch.zeros((M, ldy), dtype=dtype, device=dy2.device)
-            dyp[:, :N] = dy2
-            dy2 = dyp
+            dy2 = K.pad_cols(dy2, ldy)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=dy.device)
@@ -1716,6 +1714,54 @@ def batch_norm_act(x, gamma, beta, run_mean, run_var, num_batches, training, act
 # ================================================================================================
 # losses
 # ================================================================================================
+_CONST_SCALAR = {}
+
+
+def const_scalar(device, value=0.0):
+    """A constant 0-dim fp32 tensor per (device, value): made once, outside any capture (the first step of a shape runs eagerly),
+    so that roots of backward passes and absent loss terms cost no fill launch inside a captured step."""
+    device = torch.device(device)
+    key = (device.type, device.index, float(value))
+    if key not in _CONST_SCALAR:
+        _CONST_SCALAR[key] = torch.full((), float(value), dtype=torch.float32, device=device)
+    return _CONST_SCALAR[key]
+
+
+def _zero_scalar(device):
+    return const_scalar(device, 0.0)
+
+
+def root_backward(loss, scale=1.0, retain_graph=False):
+    """(scale * loss).backward() with the root gradient handed in as a cached constant: autograd's implicit ones_like and a
+    `loss * scale` would each be an ATen launch inside a captured step."""
+    if loss.dim() == 0 and loss.dtype == torch.float32:
+        loss.backward(gradient=const_scalar(loss.device, scale), retain_graph=retain_graph)
+    else:
+        (loss * scale if scale != 1.0 else loss).backward(retain_graph=retain_graph)
+
+
+class _WeightedSum(Function):
+    """sum_i w_i * sum(x_i) of fp32 tensors (scalars or small vectors) as ONE launch each way: the training loss from its parts
+    (trainers/ar_vc.py:86-97, trainers/aas_vc.py:100-139) without a chain of 0-dim ATen adds / muls and their autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, weights, *xs):
+        xs = [_c(x.float()) for x in xs]
+        ctx.meta = ([tuple(x.shape) for x in xs], list(weights))
+        return K.weighted_sum(list(zip(xs, weights)))
+
+    @staticmethod
+    def backward(ctx, g):
+        shapes, weights = ctx.meta
+        outs = K.weighted_sum_bwd(_c(g.float()), list(zip(shapes, weights)), g.device)
+        return (None,) + tuple(outs)
+
+
+def weighted_sum(terms):
+    """terms: [(tensor, weight)] (at most 8) -> 0-dim fp32 tensor sum_i weight_i * tensor_i.sum()."""
+    return _WeightedSum.apply(tuple(float(w) for _, w in terms), *[t for t, _ in terms])
+
+
 class _SeqLoss(Function):
     @staticmethod
     def forward(ctx, after, before, logits, ys, labels, olens_i32, pos_weight):
@@ -1727,6 +1773,7 @@ class _SeqLoss(Function):
         out = K.seq_loss_fwd(after, before, logits, ys, labels, olens_i32, pos_weight)
         ctx.pos_weight = pos_weight
         ctx.save_for_backward(after, before, logits, ys, labels, olens_i32, out)
+        ctx.set_materialize_grads(False)          # an unused loss (bce of the L1-only criterion) arrives as None, not as a zeros launch
         return out[0], out[1]
 
     @staticmethod
@@ -1735,9 +1782,9 @@ class _SeqLoss(Function):
         g1 = _c(g_l1.float()) if g_l1 is not None else None
         g2 = _c(g_bce.float()) if g_bce is not None else None
         if g1 is None:
-            g1 = torch.zeros((), dtype=torch.float32, device=before.device)
+            g1 = _zero_scalar(before.device)
         if g2 is None:
-            g2 = torch.zeros((), dtype=torch.float32, device=before.device)
+            g2 = _zero_scalar(before.device)
         da, db, dl = K.seq_loss_bwd(after, before, logits, ys, labels, olens_i32, ctx.pos_weight, out, g1, g2)
         return da, db, dl, None, None, None, None
 
@@ -1776,17 +1823,20 @@ class _Viterbi(Function):
         lp = _c(log_p_attn.float())
         ds, path, binmean = K.mas(lp, text_lens_i32, feat_lens_i32)
         B = lp.shape[0]
-        bin_loss = -(binmean.sum() / B)
+        bin_loss = K.weighted_sum([(binmean, -1.0 / B)])          # -(sum_b mean_t log p[b, t, path]) / B, one launch
         ctx.save_for_backward(path, feat_lens_i32)
         ctx.shape = lp.shape
         ctx.in_dtype = log_p_attn.dtype
         ctx.mark_non_differentiable(ds, path)
+        ctx.set_materialize_grads(False)
         return ds, bin_loss, path
 
     @staticmethod
     def backward(ctx, _dds, g, _dpath):
+        if g is None:
+            return None, None, None
         path, feat_lens_i32 = ctx.saved_tensors
-        dlogp = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        dlogp = K.zeros(ctx.shape, torch.float32, g.device)
         K.mas_binloss_bwd(path, feat_lens_i32, _c(g.float()), dlogp)
         return dlogp.to(ctx.in_dtype), None, None
 

@@ -161,7 +161,7 @@ class _PairwiseLogSoftmax(Function):
                nb0=B, nb1=1, cbs=(Tf * A, 0), alpha=-1.0, res=r1, rbs=(Tf * A, 0))
         # dtext[b,j,:] = text[b,j,:]*sum_i G[b,i,j] - sum_i G[b,i,j] feats[b,i,:]
         # column sums over the frame axis, one deterministic reduction per utterance: all of them as ONE grouped launch pair
-        cs = torch.zeros((B, Tx), dtype=torch.float32, device=feats.device)
+        cs = K.zeros((B, Tx), torch.float32, feats.device)
         queue = []
         with K.record_colreduce(queue):
             for b in range(B):
@@ -216,13 +216,13 @@ class _ForwardSum(Function):
         loss_b, grad = KA.forward_sum(lp, prior, text_lens_i32, feat_lens_i32, blank_prob)
         ctx.save_for_backward(grad)
         ctx.in_dtype = log_p_attn.dtype
-        return loss_b.sum() / lp.shape[0]
+        return K.weighted_sum([(loss_b, 1.0 / lp.shape[0])])
 
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
         # d loss / d log_p_attn = g * grad  (the scalar g lives on the device: broadcast it as a row scale)
-        gs = _c(g.float()).reshape(1).expand(grad.shape[0] * grad.shape[1]).contiguous()
+        (gs,) = K.weighted_sum_bwd(_c(g.float()), [((grad.shape[0] * grad.shape[1],), 1.0)], g.device)
         out = KA.rowscale(grad.view(-1, grad.shape[-1]), gs).view_as(grad)
         return out.to(ctx.in_dtype), None, None, None, None
 
@@ -239,12 +239,12 @@ class _ForwardSumPrefetched(Function):
     def forward(ctx, log_p_attn, loss_b, grad):
         ctx.save_for_backward(grad)
         ctx.in_dtype = log_p_attn.dtype
-        return loss_b.sum() / log_p_attn.shape[0]
+        return K.weighted_sum([(_c(loss_b.float()), 1.0 / log_p_attn.shape[0])])
 
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        gs = _c(g.float()).reshape(1).expand(grad.shape[0] * grad.shape[1]).contiguous()
+        (gs,) = K.weighted_sum_bwd(_c(g.float()), [((grad.shape[0] * grad.shape[1],), 1.0)], g.device)      # g on every row
         out = KA.rowscale(grad.view(-1, grad.shape[-1]), gs).view_as(grad)
         return out.to(ctx.in_dtype), None, None
 

@@ -249,26 +249,27 @@ class _Tail(Function):
     """Per-utterance nll + logq (duration_predictor.py:246-280)."""
 
     @staticmethod
-    def forward(ctx, noise, zu, lz, af, bf, logs_q, logs_p, lens, shared):
+    def forward(ctx, noise, zu, lz, af, bf, logs_q, logs_p, lens, shared, normalize=False):
         zu, lz, af, bf = _c(zu), _c(lz), _c(af), _c(bf)
         ctx.params = (logs_q, logs_p)
-        ctx.meta = (lens, shared)
+        ctx.meta = (lens, shared, normalize)
         ctx.save_for_backward(zu, af, bf)
         return KS.sdp_tail_fwd(noise, lens, zu, lz, shared.lad["q"], shared.lad["p"], af, bf, logs_q.detach().reshape(-1),
-                               logs_p.detach().reshape(-1))
+                               logs_p.detach().reshape(-1), normalize)
 
     @staticmethod
     def backward(ctx, g):
         zu, af, bf = ctx.saved_tensors
         logs_q, logs_p = ctx.params
-        lens, shared = ctx.meta
-        d_af, d_bf, d_lz, d_zu, neg_g, part = KS.sdp_tail_bwd(_c(g), lens, zu, af, bf)
+        lens, shared, normalize = ctx.meta
+        d_af, d_bf, d_lz, d_zu, neg_g, part = KS.sdp_tail_bwd(_c(g), lens, zu, af, bf, normalize)
         shared.neg_g = neg_g
         s, _ = K.colreduce(0, part)                       # (2,): the same scalar for both entries of a logs parameter
         dq = _emit_vgrad(logs_q, s) if logs_q.requires_grad else None
-        dp = _emit_vgrad(logs_p, s.clone()) if logs_p.requires_grad else None   # never hand one tensor to two leaves
-        return None, d_zu, d_lz, d_af, d_bf, dq, dp, None, None
+        dp = _emit_vgrad(logs_p, K.axpby(1.0, s)) if logs_p.requires_grad else None   # (a copy: never hand one tensor to two leaves)
+        return None, d_zu, d_lz, d_af, d_bf, dq, dp, None, None, None
 
 
-def tail(noise, zu, lz, af, bf, logs_q, logs_p, lens, shared):
-    return _Tail.apply(noise, zu, lz, af, bf, logs_q, logs_p, lens, shared)
+def tail(noise, zu, lz, af, bf, logs_q, logs_p, lens, shared, normalize=False):
+    """normalize: the per-utterance NLL divided by the number of non-padded text positions of the batch (models/aas_vc.py:403)."""
+    return _Tail.apply(noise, zu, lz, af, bf, logs_q, logs_p, lens, shared, normalize)

@@ -5,6 +5,7 @@ pointers to libs2svc_hip.so on torch's current HIP stream, and returns torch ten
 used for memory (caching allocator) and streams only.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -81,7 +82,96 @@ def manual_seed(seed, device=None):
 
 def advance_seed(device):
     """Bump the device-resident seed base (graph-capturable)."""
-    SEED.tensor(device).add_(0x10001)
+    t = SEED.tensor(device)
+    if t.is_cuda:
+        _lib.check(_lib.lib().s2svc_seed_advance(t.data_ptr(), 0x10001, stream()), "seed_advance")
+    else:
+        t.add_(0x10001)
+
+
+# ----------------------------------------------------------------------------------------------
+# scalar / index glue of a step (csrc/glue.hip): no ATen kernel inside a captured step
+# ----------------------------------------------------------------------------------------------
+def zero_(t):
+    """t.zero_() as a launch of this library (t contiguous)."""
+    if not t.is_contiguous():
+        raise ValueError("zero_: contiguous tensors only")
+    _lib.check(_lib.lib().s2svc_fill_zero(t.data_ptr(), t.numel() * t.element_size(), stream()), "fill_zero")
+    return t
+
+
+def zeros(shape, dtype, device):
+    return zero_(torch.empty(shape, dtype=dtype, device=device))
+
+
+def _terms(pairs):
+    """pairs: [(fp32 contiguous tensor, weight)] -> ScalarTerms (the tensors must outlive the launch: callers keep them)."""
+    if not 1 <= len(pairs) <= 8:
+        raise ValueError("1 to 8 terms")
+    t = _lib.ScalarTerms()
+    for i, (x, w) in enumerate(pairs):
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            raise TypeError("scalar terms are contiguous fp32 tensors")
+        t.x[i], t.n[i], t.w[i] = x.data_ptr(), x.numel(), float(w)
+    t.k = len(pairs)
+    return t
+
+
+def weighted_sum(pairs, out=None):
+    """sum_i w_i * sum(x_i) -> 0-dim fp32 tensor, one launch (fixed order)."""
+    out = torch.empty((), dtype=torch.float32, device=pairs[0][0].device) if out is None else out
+    t = _terms(pairs)
+    _lib.check(_lib.lib().s2svc_weighted_sum(ctypes.byref(t), ptr(out), stream()), "weighted_sum")
+    return out
+
+
+def weighted_sum_bwd(g, shapes_weights, device):
+    """-> [w_i * g broadcast to shape_i]: ONE buffer, one launch; the results are views of it."""
+    sizes = [int(math.prod(s)) for s, _ in shapes_weights]
+    buf = torch.empty(max(1, sum(sizes)), dtype=torch.float32, device=device)
+    outs, off = [], 0
+    for (s, _), n in zip(shapes_weights, sizes):
+        outs.append(buf[off:off + n].view(s))
+        off += n
+    t = _terms([(o.reshape(-1), w) for o, (_, w) in zip(outs, shapes_weights)])
+    _lib.check(_lib.lib().s2svc_weighted_sum_bwd(ctypes.byref(t), ptr(g), stream()), "weighted_sum_bwd")
+    return outs
+
+
+def scalars_axpy(pairs, acc, beta=1.0):
+    """acc[i] = beta * acc[i] + w_i * sum(x_i)   (acc: fp32, at least len(pairs) elements)."""
+    t = _terms(pairs)
+    _lib.check(_lib.lib().s2svc_scalars_axpy(ctypes.byref(t), float(beta), ptr(acc), stream()), "scalars_axpy")
+    return acc
+
+
+def pad_cols(x2, ldo):
+    """(rows, N) -> (rows, ldo) with zero columns behind N, one launch."""
+    rows, N = x2.shape
+    out = torch.empty((rows, ldo), dtype=x2.dtype, device=x2.device)
+    _lib.check(_lib.lib().s2svc_pad_cols(dt(x2), rows, N, ldo, ptr(x2), ptr(out), stream()), "pad_cols")
+    return out
+
+
+def decoder_input(ys, r, out_dtype):
+    """Teacher-forcing input (models/vtn.py:236-243): cat(zeros, ys[:, r-1::r][:, :-1]) in out_dtype, one launch.  ys (B, T, D) fp32."""
+    B, T, D = ys.shape
+    if ys.dtype != torch.float32 or ys.stride(2) != 1 or ys.stride(1) != D:
+        raise TypeError("decoder_input: fp32 (B, T, D) with contiguous frames")
+    Tin = T // r
+    out = torch.empty((B, Tin, D), dtype=out_dtype, device=ys.device)
+    _lib.check(_lib.lib().s2svc_decoder_input(_DT[out_dtype], B, Tin, r, D, ys.stride(0), ptr(ys), ptr(out), stream()), "decoder_input")
+    return out
+
+
+def stop_labels(labels, lens_i32, T):
+    """labels[:, :T] with a 1 at frame lens[b] - 1 (models/vtn.py:253-260), one launch."""
+    B = labels.shape[0]
+    if labels.dtype != torch.float32 or labels.stride(1) != 1:
+        raise TypeError("stop_labels: fp32 labels with contiguous rows")
+    out = torch.empty((B, T), dtype=torch.float32, device=labels.device)
+    _lib.check(_lib.lib().s2svc_stop_labels(B, T, labels.stride(0), ptr(labels), ptr(lens_i32), ptr(out), stream()), "stop_labels")
+    return out
 
 
 def launch_floor(sink, workgroups=256, threads=256):

@@ -127,23 +127,23 @@ def sdp_mid_bwd(zu, z1, w, lens, logs, dy0, dy1, dlz):
     return dzu, dz1, part
 
 
-def sdp_tail_fwd(noise, lens, zu, lz, lad_q, lad_p, af, bf, logs_q, logs_p):
+def sdp_tail_fwd(noise, lens, zu, lz, lad_q, lad_p, af, bf, logs_q, logs_p, normalize=False):
     _f32(noise, zu, lz, lad_q, lad_p, af, bf, logs_q, logs_p)
     B, T = zu.shape
     out = torch.empty(B, dtype=torch.float32, device=zu.device)
     _lib.check(_lib.lib().s2svc_sdp_tail_fwd(B, T, ptr(noise), ptr(lens), ptr(zu), ptr(lz), ptr(lad_q), ptr(lad_p), ptr(af), ptr(bf),
-                                             ptr(logs_q), ptr(logs_p), ptr(out), stream()), "sdp_tail_fwd")
+                                             ptr(logs_q), ptr(logs_p), ptr(out), 1 if normalize else 0, stream()), "sdp_tail_fwd")
     return out
 
 
-def sdp_tail_bwd(g, lens, zu, af, bf):
+def sdp_tail_bwd(g, lens, zu, af, bf, normalize=False):
     _f32(g)
     B, T = zu.shape
     d_af, d_bf, d_lz, d_zu = (torch.empty_like(zu) for _ in range(4))
     neg_g = torch.empty(B, dtype=torch.float32, device=zu.device)
     part = torch.empty((B, 2), dtype=torch.float32, device=zu.device)
     _lib.check(_lib.lib().s2svc_sdp_tail_bwd(B, T, ptr(g), ptr(lens), ptr(zu), ptr(af), ptr(bf), ptr(d_af), ptr(d_bf), ptr(d_lz),
-                                             ptr(d_zu), ptr(neg_g), ptr(part), stream()), "sdp_tail_bwd")
+                                             ptr(d_zu), ptr(neg_g), ptr(part), 1 if normalize else 0, stream()), "sdp_tail_bwd")
     return d_af, d_bf, d_lz, d_zu, neg_g, part
 
 

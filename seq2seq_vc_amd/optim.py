@@ -253,7 +253,7 @@ class FlatAdam:
             if reg.due:
                 self._refresh_transposed()
             if zero:
-                self.flat_g.zero_()
+                self._zero_gradients()
             return
         if not (reg.due or zero):
             return
@@ -268,15 +268,21 @@ class FlatAdam:
             else:
                 reg.ev_perm = None
             if zero:
-                self.flat_g.zero_()
+                self._zero_gradients()
             reg.ev_all.record()
 
     def join_prologue(self):
         """The current stream (the one that starts the backward pass) waits for the prologue."""
         if self._zero_due:                       # zero_grad(defer=True) without a begin_step() since
             self._zero_due = False
-            self.flat_g.zero_()
+            self._zero_gradients()
         self._perm_jobs.join()
+
+    def _zero_gradients(self):
+        if self.flat_g.is_cuda:
+            K.zero_(self.flat_g)                 # (a launch of this library: no ATen kernel inside a captured step)
+        else:
+            self.flat_g.zero_()
 
     def param_range(self, module):
         """[lo, hi) of the flat buffers covered by the parameters of `module`, or None if parameters of other modules
@@ -312,7 +318,7 @@ class FlatAdam:
             self._zero_due = True
         else:
             self._zero_due = False
-            self.flat_g.zero_()
+            self._zero_gradients()
 
     def step(self):
         self.join_prologue()                     # (no-op when the backward pass joined it, as it must)

@@ -188,8 +188,9 @@ class StochasticDurationPredictor(nn.Module):
         x = self.dds(x, lens)
         return FS.mask_rows(Fn.linear(x, self.proj.weight, self.proj.bias), lens)
 
-    def forward_cl(self, x, x_lens, w=None, inverse=False, noise_scale=1.0):
-        """x (B, T, C) channel-last, x_lens: modules.Lens, w (B, T) durations -> NLL (B,) | durations (B, T)."""
+    def forward_cl(self, x, x_lens, w=None, inverse=False, noise_scale=1.0, normalize=False):
+        """x (B, T, C) channel-last, x_lens: modules.Lens, w (B, T) durations -> NLL (B,) | durations (B, T).
+        normalize: NLL / (number of non-padded text positions of the batch), the division of models/aas_vc.py:403 inside the kernel."""
         lens = x_lens.dev
         B, T, _ = x.shape
         x = self._condition(x, lens)
@@ -205,20 +206,32 @@ class StochasticDurationPredictor(nn.Module):
         # pass (models/aas_vc.py: dp_plan).  Inactive (identity) outside distributed.OverlappedBackward.
         x, h_w = Fn.cut_point((x, h_w), "sdp_cond")              # both networks one stage later
         x = Fn.cut_point(x, "sdp_cond_x")                        # only the one behind x (the plan names ONE of the two cuts)
-        g_q = Fn.add_dropout(x, h_w, 0.0)
+        # tensors with several consumers go through Fn.fan_out: their gradients are summed by one launch of this library at ONE autograd
+        # node instead of by the engine's element-wise adds (16 per step here: x 5 x, g_q 4 x, every flow's pass-through half 2 x)
+        n_q = sum(isinstance(f, ConvFlow) for f in self.post_flows[1:])
+        n_p = sum(isinstance(f, ConvFlow) for f in self.flows[1:])
+        x_add, *x_p = Fn.fan_out(x, 1 + n_p)
+        g_q = Fn.fan_out(Fn.add_dropout(x_add, h_w, 0.0), n_q)
         noise = self._randn((B, 2, T), x.device)
         shared = FS.Shared()
         aff_q, aff_p = self.post_flows[0], self.flows[0]
         a, b = FS.head(noise, aff_q.m, aff_q.logs, lens)
+        k = 0
         for flow in self.post_flows[1:]:
             if isinstance(flow, ConvFlow):            # ConvFlow then Flip: (a, b) -> (spline(b | a), a)
-                a, b = flow(a, b, g_q, lens, shared, "q"), a
+                a_in, a_next = Fn.fan_out(a, 2)
+                a, b = flow(a_in, b, g_q[k], lens, shared, "q"), a_next
+                k += 1
         zu, z1 = a, b
+        zu, zu_tail = Fn.fan_out(zu, 2)
         a, b, lz = FS.mid(zu, z1, w, aff_p.m, aff_p.logs, lens)
+        k = 0
         for flow in self.flows[1:]:
             if isinstance(flow, ConvFlow):
-                a, b = flow(a, b, x, lens, shared, "p"), a
-        return FS.tail(noise, zu, lz, a, b, aff_q.logs, aff_p.logs, lens, shared)
+                a_in, a_next = Fn.fan_out(a, 2)
+                a, b = flow(a_in, b, x_p[k], lens, shared, "p"), a_next
+                k += 1
+        return FS.tail(noise, zu_tail, lz, a, b, aff_q.logs, aff_p.logs, lens, shared, normalize)
 
     @torch.no_grad()
     def _inverse(self, x, lens, B, T, noise_scale):

@@ -164,7 +164,7 @@ class Trainer(object):
             else:
                 self.dp.backward(parts, reduce=last_micro_step)
         else:
-            total.backward()
+            Fn.root_backward(total)
             Fn.side_join()
             if self.dist is not None and last_micro_step:
                 if isinstance(self.optimizer, FlatAdam):
@@ -203,7 +203,19 @@ class Trainer(object):
         if self.loss_acc is None:
             self.loss_names = list(losses)
             self.loss_acc = torch.zeros(len(self.loss_names), dtype=torch.float32, device=self.device)
-        vals = torch.stack([torch.as_tensor(losses[k], dtype=torch.float32, device=self.device).detach().reshape(())
+        if self.device.type == "cuda" and len(self.loss_names) <= 8:
+            # one launch of this library (csrc/glue.hip): acc[i] += sum(loss_i) / accumulation steps -- a term may be a vector (the
+            # per-utterance duration NLL), which is summed on the way
+            terms = []
+            for k in self.loss_names:
+                v = losses[k]
+                v = v.detach() if isinstance(v, torch.Tensor) else Fn.const_scalar(self.device, float(v))
+                if v.dtype != torch.float32 or not v.is_contiguous() or v.device != self.device:
+                    v = v.to(device=self.device, dtype=torch.float32).contiguous()
+                terms.append((v, 1.0 / self.gradient_accumulate_steps))
+            K.scalars_axpy(terms, self.loss_acc, beta=1.0)
+            return
+        vals = torch.stack([torch.as_tensor(losses[k], dtype=torch.float32, device=self.device).detach().sum().reshape(())
                             for k in self.loss_names])
         self.loss_acc += vals / self.gradient_accumulate_steps
 
@@ -296,12 +308,13 @@ class ARVCTrainer(Trainer):
         ilens, olens = batch["ilens"], batch["olens"]       # stay on the host (sizes only)
         after, before, logits, ys_, labels_, olens_, (att_ws, ilens_ds_st, olens_in) = self.model(xs, ilens, ys, labels, olens)
         l1, bce = self.criterion["Seq2SeqLoss"](after, before, logits, ys_, labels_, olens_)
-        loss = l1 + bce
+        terms = [(l1, 1.0), (bce, 1.0)]
         logs = {"train/l1_loss": l1, "train/bce_loss": bce}
         if self.config.get("use_guided_attn_loss", False):
             ga = self.criterion["guided_attn"](self._guided_attention_input(att_ws), ilens_ds_st, olens_in)
-            loss = loss + ga
+            terms.append((ga, 1.0))
             logs["train/guided_attn_loss"] = ga
+        loss = Fn.weighted_sum(terms)            # l1 + bce (+ guided attention): one launch each way (ar_vc.py:86-97)
         logs["train/loss"] = loss
         return loss, logs
 
@@ -376,31 +389,39 @@ class AASVCTrainer(Trainer):
         xs, ys, dp_inputs = batch["xs"].to(dev), batch["ys"].to(dev), batch["dp_inputs"].to(dev)
         with self._forward_context():
             ret = self.model(xs, batch["ilens"], ys, batch["olens"], dp_inputs, dp_lengths=batch["dplens"])
-            zero = torch.zeros((), device=dev)
+            # loss = l1 + lambda_align * (forward_sum + bin) + duration (aas_vc.py:100-139): the sums -- and the division by the
+            # accumulation steps (:141-143) -- are weights of ONE launch each way (Fn.weighted_sum), not a chain of 0-dim ATen ops
+            zero = Fn.const_scalar(dev, 0.0)
+            lam, gas = float(self.config["lambda_align"]), float(self.gradient_accumulate_steps)
             logs = {}
-            dec_loss = zero
+            dec_terms = []
             if "L1Loss" in self.config["criterions"]:
                 l1 = self.criterion["L1Loss"](ret["after_outs"], ret["before_outs"], ret["ys"], ret["olens"])
                 logs["train/l1_loss"] = l1
-                dec_loss = dec_loss + l1
+                dec_terms.append((l1, 1.0))
             fs = self.criterion["ForwardSumLoss"](ret["log_p_attn"], ret["ilens"], ret["olens_reduced"])
             logs["train/forward_sum_loss"], logs["train/binary_loss"] = fs, ret["bin_loss"]
-            align_loss = self.config["lambda_align"] * (fs + ret["bin_loss"])
+            align_terms = [(fs, lam), (ret["bin_loss"], lam)]
             dur = zero
             if self.steps > self.config.get("dp_train_start_steps", 0):
                 if "DurationPredictorLoss" in self.config["criterions"]:
                     dur = self.criterion["DurationPredictorLoss"](ret["d_outs"], ret["ds"], ret["ilens"])
+                    align_terms.append((dur, 1.0))
                 elif "StochasticDurationPredictorLoss" in self.config["criterions"]:
-                    dur = torch.sum(ret["dur_nll"].float())
+                    dur = ret["dur_nll"]                       # (B,): summed inside the weighted sum / the logging launch
+                    align_terms.append((dur, 1.0))
             logs["train/duration_loss"] = dur
-            align_loss = align_loss + dur
-            loss = dec_loss + align_loss
-            logs["train/loss"] = loss
+            if self.dp is not None:                            # staged backward pass: one root per key of model.dp_plan()
+                dec_loss = Fn.weighted_sum([(t, w / gas) for t, w in dec_terms]) if dec_terms else zero
+                align_loss = Fn.weighted_sum([(t, w / gas) for t, w in align_terms])
+                parts = {"decoder": dec_loss, "align": align_loss}
+                loss = None
+                logs["train/loss"] = Fn.weighted_sum([(t.detach(), w) for t, w in dec_terms + align_terms])
+            else:
+                parts = None
+                loss = Fn.weighted_sum([(t, w / gas) for t, w in dec_terms + align_terms])
+                logs["train/loss"] = loss if gas == 1.0 else Fn.weighted_sum([(t.detach(), w) for t, w in dec_terms + align_terms])
         self._accumulate(**logs)
-        parts = {"decoder": dec_loss, "align": align_loss}
-        if self.gradient_accumulate_steps > 1:
-            loss = loss / self.gradient_accumulate_steps
-            parts = {k: v / self.gradient_accumulate_steps for k, v in parts.items()}
         self.backward_steps += 1
         last = self.backward_steps % self.gradient_accumulate_steps == 0
         self._backward(loss, parts, last_micro_step=last)

@@ -51,6 +51,33 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         step()
         torch.cuda.synchronize()
+    # where they come from: torch.profiler's Python stacks are empty on this stack, so the same step runs once more under a
+    # TorchDispatchMode that sees every ATen call (forward: on the caller's Python stack; backward: inside the Function.backward frames)
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    VIEWS = ("view", "as_strided", "detach", "alias", "aten.t.", "transpose", "slice", "select", "unsqueeze", "squeeze", "expand",
+             "reshape", "empty", "permute", "_unsafe_view", "unbind", "split", "chunk", "narrow", "lift_fresh", "is_", "size", "stride",
+             "storage_offset", "numel", "dim", "record_stream", "_to_copy_meta", "sym_", "prim.", "_local_scalar_dense", "item")
+    calls = collections.Counter()
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if not any(v in name for v in VIEWS):
+                flat = [a for a in list(args) + list((kwargs or {}).values()) if isinstance(a, torch.Tensor)]
+                if any(t.is_cuda for t in flat) or "zeros" in name or "full" in name or "arange" in name or "randn" in name:
+                    fr = [f for f in traceback.extract_stack() if ROOT in f.filename and "aten_in_step" not in f.filename]
+                    where = f"{fr[-1].filename.replace(ROOT + '/', '')}:{fr[-1].lineno} {fr[-1].name}" if fr else "(autograd engine)"
+                    shp = ",".join("x".join(map(str, t.shape)) or "()" for t in flat[:3])
+                    calls[(name, where, shp)] += 1
+            return func(*args, **(kwargs or {}))
+
+    with Spy():
+        step()
+        torch.cuda.synchronize()
+    print(f"[aten_in_step] ATen calls on device tensors during one eager step, by call site ({sum(calls.values())} calls):")
+    for (name, where, shp), c in sorted(calls.items(), key=lambda t: (t[0][1], t[0][0])):
+        print(f"  {c:3d} x {name:34s} {shp:40s} {where}")
     seen = collections.Counter()
     total_kernels = 0
     for ev in prof.events():
