@@ -294,6 +294,10 @@ int s2svc_pad_cols(int dtype, int64_t rows, int N, int ldo, const void* in, void
 /* teacher-forcing input of the AR decoder (models/vtn.py:236-243): out[b, t, :] = t == 0 ? 0 : ys[b, t * r - 1, :], ys fp32 with
    batch stride ys_batch_stride elements, out (B, Tin, D) in out_dtype */
 int s2svc_decoder_input(int out_dtype, int B, int Tin, int r, int D, int64_t ys_batch_stride, const float* ys, void* out, void* stream);
+/* token batch with <eos> behind every sequence (models/transformer_tts.py:139-142): out (B, T + 1) = [xs[b, :lens[b]] | eos | pad ...] */
+int s2svc_append_eos(int B, int T, int64_t ldx, const int64_t* xs, const int32_t* lens, int64_t eos, int64_t pad, int64_t* out, void* stream);
+/* out (rows, D) dense = src (rows, D) with row stride lds */
+int s2svc_copy_rows(int dtype, int64_t rows, int D, int64_t lds, const void* src, void* out, void* stream);
 /* stop-token targets (models/vtn.py:253-260): out (B, T) = labels (row stride ld_labels) with a 1 at frame lens[b] - 1 */
 int s2svc_stop_labels(int B, int T, int64_t ld_labels, const float* labels, const int32_t* lens, float* out, void* stream);
 /* out = x0 + x1 (+ x2 (+ x3)), k = 2..4 inputs summed in that order (fp32 arithmetic): the gradients arriving at a tensor with several

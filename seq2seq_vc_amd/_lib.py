@@ -144,6 +144,8 @@ _SIGS = {
     "s2svc_pad_cols": [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_decoder_input": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp],
     "s2svc_stop_labels": [c_i32, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "s2svc_append_eos": [c_i32, c_i32, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp],
+    "s2svc_copy_rows": [c_i32, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp],
     "s2svc_add_head_bias": [c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_add_head_bias_ld": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "s2svc_add_rows": [c_i32, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],

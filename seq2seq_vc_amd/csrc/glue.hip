@@ -82,6 +82,25 @@ __global__ void stop_labels_kernel(int B, int T, int64_t ldl, const float* __res
   out[i] = (t == lens[b] - 1) ? 1.f : labels[(int64_t)b * ldl + t];
 }
 
+// text batch with <eos> behind every sequence (models/transformer_tts.py:139-142: F.pad(xs, [0, 1], value = pad) + in-place eos):
+// out (B, T + 1) = [xs[b, :len] | eos | pad ...]
+__global__ void append_eos_kernel(int B, int T, int64_t ldx, const int64_t* __restrict__ xs, const int32_t* __restrict__ lens, int64_t eos,
+                                  int64_t pad, int64_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * (T + 1)) return;
+  const int b = i / (T + 1), t = i - b * (T + 1);
+  out[i] = t == lens[b] ? eos : (t < T ? xs[(int64_t)b * ldx + t] : pad);
+}
+
+// out (rows, D) = src (rows, D) with row stride lds (a column block of a wider matrix made dense)
+template <typename T>
+__global__ void copy_rows_kernel(int64_t n, int D, int64_t lds, const T* __restrict__ src, T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D;
+    out[i] = src[r * lds + (i - r * D)];
+  }
+}
+
 inline int gl_blocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 bool terms_ok(const s2svc_scalar_terms* t) {
@@ -151,6 +170,26 @@ extern "C" int s2svc_decoder_input(int out_dtype, int B, int Tin, int r, int D, 
   else
     hipLaunchKernelGGL(decoder_input_kernel<bf16_t>, dim3(gl_blocks(n)), dim3(256), 0, st, n, Tin, r, D, ys_batch_stride, ys, (bf16_t*)out);
   S2S_CHECK_LAUNCH("decoder_input_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_append_eos(int B, int T, int64_t ldx, const int64_t* xs, const int32_t* lens, int64_t eos, int64_t pad, int64_t* out,
+                                void* stream) {
+  if (B == 0) return 0;
+  S2S_REQUIRE(xs && lens && out && ldx >= T, "append_eos: bad args");
+  hipLaunchKernelGGL(append_eos_kernel, dim3((B * (T + 1) + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, T, ldx, xs, lens, eos, pad, out);
+  S2S_CHECK_LAUNCH("append_eos_kernel");
+  return 0;
+}
+
+extern "C" int s2svc_copy_rows(int dtype, int64_t rows, int D, int64_t lds, const void* src, void* out, void* stream) {
+  const int64_t n = rows * D;
+  if (n == 0) return 0;
+  S2S_REQUIRE(src && out && lds >= D, "copy_rows: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S2S_F32) hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(gl_blocks(n)), dim3(256), 0, st, n, D, lds, (const float*)src, (float*)out);
+  else hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(gl_blocks(n)), dim3(256), 0, st, n, D, lds, (const bf16_t*)src, (bf16_t*)out);
+  S2S_CHECK_LAUNCH("copy_rows_kernel");
   return 0;
 }
 

@@ -7,6 +7,7 @@ from torch import nn
 
 from .. import modules as Mo
 from ..ops import functional as Fn
+from ..ops import kernels as K
 from .vtn import _ARSeq2Seq
 
 
@@ -47,8 +48,11 @@ class TransformerTTS(_ARSeq2Seq):
             xs = xs[:, : il.max()]
         if ol.max() != ys.shape[1]:
             ys, labels = ys[:, : ol.max()], labels[:, : ol.max()]
-        xs = TF.pad(xs, [0, 1], "constant", self.padding_idx)           # transformer_tts.py:139-142: append <eos>
-        xs = xs.scatter(1, il.dev.long().unsqueeze(1), self.eos)        # (no host round trip: capturable in a hipGraph)
+        if xs.is_cuda and xs.dtype == torch.int64 and xs.stride(1) == 1:     # transformer_tts.py:139-142: append <eos>, one launch
+            xs = K.append_eos(xs, il.dev, self.eos, self.padding_idx)
+        else:
+            xs = TF.pad(xs, [0, 1], "constant", self.padding_idx)
+            xs = xs.scatter(1, il.dev.long().unsqueeze(1), self.eos)        # (no host round trip: capturable in a hipGraph)
         il1 = il.map(lambda v: v + 1)
         pre = self._decoder_head(ys, olens)
         hs, hs_lens = self.encoder(xs, il1)

@@ -133,7 +133,13 @@ class _ARSeq2Seq(nn.Module):
             zs, _ = self.decoder(None, olens_in_h, hs, hs_lens, causal=True, head=head)
         else:
             zs, _ = self.decoder(Fn.to_compute(ys_in), olens_in_h, hs, hs_lens, causal=True)
-        before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, odim)
+        # zs feeds feat_out AND prob_out: prob_out takes it from feat_out's pass-through alias, so its gradient rides in feat_out's
+        # data-gradient GEMM instead of in an element-wise add of autograd's accumulation
+        if self.training and torch.is_grad_enabled() and zs.requires_grad:
+            before, zs = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias, passthrough=True)
+            before = before.view(zs.size(0), -1, odim)
+        else:
+            before = Fn.linear(zs, self.feat_out.weight, self.feat_out.bias).view(zs.size(0), -1, odim)
         b_post = b_res = before
         if self.postnet is not None:        # three consumers (loss, residual, Postnet): their gradients meet in one launch
             before, b_res, b_post = Fn.fan_out(before, 3)

@@ -37,7 +37,7 @@ def to_compute(x):
 
 
 def _c(x):
-    return x if x.is_contiguous() else x.contiguous()
+    return x if x.is_contiguous() else K.dense_rows(x)
 
 
 def _wcast(w, dtype):

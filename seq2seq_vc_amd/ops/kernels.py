@@ -164,6 +164,33 @@ def decoder_input(ys, r, out_dtype):
     return out
 
 
+def append_eos(xs, lens_i32, eos, pad):
+    """(B, T) int64 tokens -> (B, T + 1) with eos behind each sequence (models/transformer_tts.py:139-142), one launch."""
+    B, T = xs.shape
+    if xs.dtype != torch.int64 or xs.stride(1) != 1:
+        raise TypeError("append_eos: int64 tokens with contiguous rows")
+    out = torch.empty((B, T + 1), dtype=torch.int64, device=xs.device)
+    _lib.check(_lib.lib().s2svc_append_eos(B, T, xs.stride(0), ptr(xs), ptr(lens_i32), int(eos), int(pad), ptr(out), stream()), "append_eos")
+    return out
+
+
+def dense_rows(x):
+    """x.contiguous() for a tensor whose last dim is dense and whose leading dims share one row stride (a column block of a wider
+    matrix, e.g. one layer's K|V out of the batched projection), as a launch of this library; other layouts: torch."""
+    if x.is_contiguous():
+        return x
+    D = x.shape[-1]
+    lds = x.stride(-2) if x.dim() >= 2 else D
+    ok = x.is_cuda and x.dtype in _DT and x.stride(-1) == 1 and x.dim() >= 2
+    for d in range(x.dim() - 2):                 # leading dims must be laid out as one run of rows
+        ok = ok and x.stride(d) == x.stride(d + 1) * x.shape[d + 1]
+    if not ok:
+        return x.contiguous()
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().s2svc_copy_rows(dt(x), x.numel() // D, D, lds, ptr(x), ptr(out), stream()), "copy_rows")
+    return out
+
+
 def stop_labels(labels, lens_i32, T):
     """labels[:, :T] with a 1 at frame lens[b] - 1 (models/vtn.py:253-260), one launch."""
     B = labels.shape[0]
