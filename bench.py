@@ -984,16 +984,29 @@ def spawn_ranks(n, argv=None):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script on this node (RANK = LOCAL_RANK = 0..N-1,
     WORLD_SIZE = N, rendezvous on a free port of 127.0.0.1 -- the env contract of torch.distributed.run and of the reference's
     distributed/launch.py:119-173), wait for all of them and return the first non-zero exit code.  Rank 0 prints the JSON line."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    rc = 0
+    for attempt in range(3):           # the free port is found, released, then bound by rank 0: another process can take it in between
+        rc = _spawn_ranks_once(n, argv)
+        if rc != RC_RENDEZVOUS:
+            break
+        print(f"bench.py: rendezvous port was taken (attempt {attempt + 1}), retrying on another port", file=sys.stderr)
+    return rc
+
+
+RC_RENDEZVOUS = 75        # exit code of a rank whose init_process_group could not bind / reach the rendezvous port (EX_TEMPFAIL)
+
+
+def _spawn_ranks_once(n, argv):
     import socket
     import subprocess
-    argv = list(sys.argv[1:] if argv is None else argv)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), S2SVC_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
@@ -1018,12 +1031,22 @@ def spawn_ranks(n, argv=None):
     return rc
 
 
+def _init_group(dist, backend, rank, world, **kw):
+    """init_process_group; under spawn_ranks a bind failure of the rendezvous port exits with RC_RENDEZVOUS so that the launcher retries."""
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    except Exception as e:       # noqa: BLE001 -- torch raises RuntimeError / DistNetworkError with the errno in its text
+        if os.environ.get("S2SVC_BENCH_SPAWNED") and ("EADDRINUSE" in str(e) or "address already in use" in str(e).lower()):
+            raise SystemExit(RC_RENDEZVOUS)
+        raise
+
+
 def dist_dry_run(world, rank):
     """The launcher contract without a GPU (CPU test): join a gloo group, sum a 1 over the ranks, rank 0 prints what it saw."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("MASTER_PORT", "29533")       # a bare one-rank run only: launchers (torchrun, spawn_ranks) always set it
+    _init_group(dist, "gloo", rank, world)
     one = torch.ones(1)
     dist.all_reduce(one)
     ranks = torch.zeros(world)
@@ -1039,7 +1062,8 @@ def dist_dry_run(world, rank):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks of the job (default: WORLD_SIZE when a launcher set it, else 1)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="vtn", choices=["vtn", "aasvc", "tts"])
@@ -1074,6 +1098,8 @@ def main():
     # carries WORLD_SIZE = N already; launched bare (`python bench.py --gpus 4`) this process becomes the launcher of N ranks --
     # one process per GPU, env rendezvous on 127.0.0.1, like the reference's distributed/launch.py:119-173.  A WORLD_SIZE that
     # disagrees with --gpus is an error, never a silent 1-rank run.
+    if args.gpus is None:                     # `torchrun --nproc-per-node 8 bench.py` without --gpus: the launcher's world size
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1105,9 +1131,9 @@ def main():
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            _init_group(dist, "nccl", rank, world, device_id=dev)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            _init_group(dist, "gloo", rank, world)
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)                   # n_gpus of the line = the ranks RCCL actually summed over
         ranks_seen = int(one.item())

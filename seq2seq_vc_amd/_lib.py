@@ -22,16 +22,24 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def build_library(force=False, verbose=True):
-    """Compile csrc/*.hip -> csrc/libs2svc_hip.so for gfx950 (in-tree, so it travels to the GPU box)."""
+DEBUG_EXEC_LIB_PATH = os.path.join(CSRC, "libs2svc_hip_dbgexec.so")
+
+
+def build_library(force=False, verbose=True, debug_exec=False):
+    """Compile csrc/*.hip -> csrc/libs2svc_hip.so for gfx950 (in-tree, so it travels to the GPU box).
+    debug_exec: the same sources with -DS2SVC_DEBUG_EXEC (common.h: the DPP / v_permlane swap reductions trap when EXEC is not all
+    ones) -> csrc/libs2svc_hip_dbgexec.so, loaded through S2SVC_LIB by the GPU case `debug_exec_build_runs_clean` only."""
+    lib_path = DEBUG_EXEC_LIB_PATH if debug_exec else LIB_PATH
+    if not debug_exec and os.environ.get("S2SVC_LIB"):
+        lib_path = os.path.join(CSRC, "libs2svc_hip.so")        # never build over an alternative library named by S2SVC_LIB
     srcs = [os.path.join(CSRC, f) for f in sources()]
     deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
                    os.path.join(_HERE, "..", "include", "s2svc_hip.h")]
-    if not force and os.path.exists(LIB_PATH):
+    if not force and os.path.exists(lib_path):
         newest = max(os.path.getmtime(p) for p in deps)
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
-    objdir = os.path.join(CSRC, "build")
+        if os.path.getmtime(lib_path) >= newest:
+            return lib_path
+    objdir = os.path.join(CSRC, "build", "dbgexec") if debug_exec else os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
@@ -48,6 +56,8 @@ def build_library(force=False, verbose=True):
         # -fno-vectorize: the loop vectoriser forms the same packed operations in a few element-wise kernels.
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize",
                "-fno-vectorize", "-c", src, "-o", obj]
+        if debug_exec:
+            cmd.insert(2, "-DS2SVC_DEBUG_EXEC")
         if verbose:
             print("[s2svc build]", " ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)
@@ -55,11 +65,11 @@ def build_library(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
-    cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print("[s2svc build]", " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 c_i32, c_i64, c_f32, c_u64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_void_p

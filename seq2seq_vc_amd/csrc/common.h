@@ -42,10 +42,22 @@ template <typename T> __device__ __forceinline__ void stf(T* p, float v) { Cvt<T
 // kernels that run 3-5 us).  The partner at lane ^ 1 / ^ 2 is a DPP quad permute, at ^ 4 two bank-masked DPP row shifts, at ^ 8 a
 // DPP row rotation, at ^ 16 / ^ 32 gfx950's v_permlane16_swap / v_permlane32_swap (with both operands = v the two results hold
 // (even rows, even rows) / (odd rows, odd rows), resp. (low half, low half) / (high half, high half)): VALU instructions, and the
-// SAME partners in the SAME order as the butterflies they replace, so every sum keeps its bits.  All lanes must be active (they
-// are: every caller reduces under wave-uniform control flow).
+// SAME partners in the SAME order as the butterflies they replace, so every sum keeps its bits.  ALL 64 LANES MUST BE ACTIVE (they
+// are: every caller reduces under wave-uniform control flow): with an inactive partner a swap returns the lane's own value twice
+// (ds_bpermute returned 0), so a partial-wave sum would double-count.  A build with -DS2SVC_DEBUG_EXEC (S2SVC_DEBUG_EXEC=1 in the
+// environment of _lib.build_library; tests/gpu_kernel_check.py: debug_exec_build_runs_clean) traps in swap16 / swap32 / the DPP moves
+// when EXEC is not all ones.
+#ifdef S2SVC_DEBUG_EXEC
+#define S2S_ASSERT_FULL_EXEC()                                              \
+  do {                                                                      \
+    if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();            \
+  } while (0)
+#else
+#define S2S_ASSERT_FULL_EXEC() ((void)0)
+#endif
 template <int CTRL, int BANKS = 0xf>
 __device__ __forceinline__ float dpp_mov(float v, float old = 0.f) {
+  S2S_ASSERT_FULL_EXEC();
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANKS, false));
 }
 __device__ __forceinline__ float xor1_of(float v) { return dpp_mov<0xB1>(v); }             // quad_perm:[1,0,3,2]
@@ -57,10 +69,12 @@ __device__ __forceinline__ float xor4_of(float v) {                             
 __device__ __forceinline__ float xor8_of(float v) { return dpp_mov<0x128>(v); }            // row_ror:8
 struct lane_pair { float a, b; };
 __device__ __forceinline__ lane_pair swap16(float v) {
+  S2S_ASSERT_FULL_EXEC();
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return {__uint_as_float(r[0]), __uint_as_float(r[1])};
 }
 __device__ __forceinline__ lane_pair swap32(float v) {
+  S2S_ASSERT_FULL_EXEC();
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return {__uint_as_float(r[0]), __uint_as_float(r[1])};
 }

@@ -1063,12 +1063,18 @@ class _GradSink:
     the blocks (the source-attention blocks of all decoder layers write dK | dV of their (B, T, 2D) block straight into the
     (B, T, L * 2D) gradient of the batched projection): the backward pass of split_cols then has nothing to concatenate (one
     18 us torch.cat of 18.6 MB on the VTN chain per step)."""
-    __slots__ = ("shape", "dtype", "device", "W", "buf")
+    __slots__ = ("shape", "dtype", "device", "W", "buf", "claimed")
 
     def __init__(self, shape, dtype, device, W):
-        self.shape, self.dtype, self.device, self.W, self.buf = shape, dtype, device, W, None
+        self.shape, self.dtype, self.device, self.W, self.buf, self.claimed = shape, dtype, device, W, None, set()
 
     def part(self, i):
+        """Block i of the buffer for its ONE consumer.  A block that feeds a second consumer gets a fresh tensor instead: two
+        consumers writing the same view would leave autograd summing two aliases of one buffer (2 g2 instead of g1 + g2); with
+        the fresh tensor autograd's sum is a new tensor, holds() fails and _SplitCols concatenates the correct sums."""
+        if i in self.claimed:
+            return torch.empty(self.shape[:-1] + (self.W,), dtype=self.dtype, device=self.device)
+        self.claimed.add(i)
         if self.buf is None:
             self.buf = torch.empty(self.shape, dtype=self.dtype, device=self.device)
         return self.buf[..., i * self.W:(i + 1) * self.W]
@@ -1103,9 +1109,11 @@ class _SplitCols(Function):
         sink = ctx.sink
         if sink is not None and sink.holds(grads):
             buf, sink.buf = sink.buf, None
+            sink.claimed.clear()
             return buf, None, None
         if sink is not None:
             sink.buf = None
+            sink.claimed.clear()
         blk = shape[:-1] + (ctx.W,)
         parts = [g if g is not None else torch.zeros(blk, dtype=dtype, device=device) for g in grads]
         return torch.cat(parts, dim=-1), None, None

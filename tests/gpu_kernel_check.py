@@ -175,6 +175,34 @@ def attention_fused_vs_reference():
 
 
 @case
+def split_cols_block_consumed_twice():
+    """One column block of split_cols feeding TWO source-attention calls (no model does; Fn._GradSink hands every block's in-place
+    view to its first consumer only): the block's gradient must be g1 + g2, as with plain slicing."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    res = []
+    B, H, T1, T2, dk = 2, 4, 40, 48, 96
+    D = H * dk
+    dt_ = torch.bfloat16
+    q1, q2 = rnd(B, T1, D, seed=1, dtype=dt_), rnd(B, T1, D, seed=2, dtype=dt_)
+    kv_all = rnd(B, T2, 2 * 2 * D, seed=3, dtype=dt_)
+    klen = torch.tensor([T2, T2 - 5], dtype=torch.int32, device=DEV)
+    dy1, dy2, dy3 = rnd(B, T1, D, seed=4, dtype=dt_), rnd(B, T1, D, seed=5, dtype=dt_), rnd(B, T1, D, seed=6, dtype=dt_)
+    grads = []
+    for use_split in (True, False):
+        x = kv_all.clone().requires_grad_(True)
+        blocks = Fn.split_cols(x, 2) if use_split else (x[..., :2 * D], x[..., 2 * D:])
+        o1, _ = Fn.attention_packed_kv(q1, blocks[0], klen, False, H, 0.0)
+        o2, _ = Fn.attention_packed_kv(q2, blocks[0], klen, False, H, 0.0)        # block 0 a second time
+        o3, _ = Fn.attention_packed_kv(q1, blocks[1], klen, False, H, 0.0)
+        ((o1.float() * dy1.float()).sum() + (o2.float() * dy2.float()).sum() + (o3.float() * dy3.float()).sum()).backward()
+        grads.append(x.grad.detach().clone())
+    res.append(check("split_cols block used twice: gradient == plain slicing", grads[0], grads[1], dt_, atol=2e-2, rtol=2e-2))
+    g0 = grads[1][..., :2 * D].float().abs().mean().item()
+    res.append((g0 > 0, f"split_cols twice: block 0 gradient is non-trivial ({g0:.3e})"))
+    return res
+
+
+@case
 def ffn_relu_fused_vs_unfused():
     """_FFNRelu (masks in GEMM epilogues) against the three-op composition, fp32, dropout off (exact) and on (same statistics)."""
     from seq2seq_vc_amd.ops import functional as Fn
@@ -1717,10 +1745,35 @@ def bn_two_launch_statistics():
     return res
 
 
+@case
+def debug_exec_build_runs_clean():
+    """The library built with -DS2SVC_DEBUG_EXEC (the DPP / v_permlane16/32_swap reductions of csrc/common.h trap unless all 64 lanes
+    are active) runs the reduction-heavy kernel cases in a child process without trapping and with every check green."""
+    import subprocess
+    from seq2seq_vc_amd import _lib
+    if os.environ.get("S2SVC_LIB"):
+        return [(True, "debug-exec build: skipped inside a child that already runs an alternative library")]
+    if not os.path.exists(_lib.DEBUG_EXEC_LIB_PATH):
+        return [(False, f"{_lib.DEBUG_EXEC_LIB_PATH} is missing: __graft_entry__.build() makes it")]
+    only = "layernorm,layernorm_bwd_with_partial_gradients,attn_softmax,attention_fused_vs_reference,batchnorm,batchnorm_act_dropout_vectorised,colreduce_grouped,mas_kernel,bn_two_launch_statistics"
+    have = {c.__name__ for c in CASES}
+    only = ",".join(n for n in only.split(",") if n in have)
+    env = dict(os.environ, S2SVC_LIB=_lib.DEBUG_EXEC_LIB_PATH)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only", only], env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-600:]
+    npass = r.stdout.count("PASS ")
+    return [(r.returncode == 0 and npass > 20, f"debug-exec build, cases [{only}]: rc={r.returncode}, {npass} checks passed\n{tail if r.returncode else ''}")]
+
+
 def main():
     torch.manual_seed(0)
     nfail = 0
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     for fn in CASES:
+        if only is not None and fn.__name__ not in only:
+            continue
         try:
             results = fn()
         except Exception:

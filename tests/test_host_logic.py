@@ -466,6 +466,10 @@ def test_bench_gpus_flag_launches_that_many_ranks_and_refuses_a_mismatch():
     r = _run_bench(["--gpus", "1", "--dist-dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                                                       "MASTER_PORT": str(_free_port_for_tests())})
     assert r.returncode == 0 and '"n_gpus": 1' in r.stdout
+    # no --gpus under a launcher: the launcher's WORLD_SIZE is the job size (`torchrun --nproc-per-node 8 bench.py`)
+    r = _run_bench(["--dist-dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                        "MASTER_PORT": str(_free_port_for_tests())})
+    assert r.returncode == 0 and '"n_gpus": 1' in r.stdout, r.stderr[-2000:]
     # a rank that dies takes the job down with a non-zero exit code (no hang: the others are terminated)
     r = _run_bench(["--gpus", "2", "--dist-dry-run", "--workload", "nonsense"])
     assert r.returncode != 0
