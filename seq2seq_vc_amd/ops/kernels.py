@@ -34,11 +34,31 @@ _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_RAW_STREAM_OK = None        # None: not validated yet; True / False after the first call
+
+
+def _validate_raw_stream():
+    """The private accessors are used only after ONE check against the public API on a non-default stream (a torch release that
+    changes their signature or meaning falls back to the public path instead of handing launchers a wrong stream)."""
+    global _RAW_STREAM_OK
+    ok = False
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        try:
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                ok = int(_RAW_STREAM(_GET_DEVICE())) == int(torch.cuda.current_stream().cuda_stream) == int(side.cuda_stream)
+            ok = ok and int(_RAW_STREAM(_GET_DEVICE())) == int(torch.cuda.current_stream().cuda_stream)
+        except Exception:       # noqa: BLE001 -- any failure of the private path means: do not use it
+            ok = False
+    _RAW_STREAM_OK = ok
+    return ok
+
+
 def stream():
     """The raw hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() costs ~10 us of host time
     per call (device-index resolution through torch.cuda.is_available() -> device count); the raw accessor is what it ends in.
     Every launcher calls this: ~160 times per eager VTN step."""
-    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+    if _RAW_STREAM_OK or (_RAW_STREAM_OK is None and _validate_raw_stream()):
         return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
@@ -989,8 +1009,13 @@ def permute_inner(src, n, A, Bn, out=None, accumulate=False):
     _need_cuda(src)
     if src.dtype != torch.float32 or not src.is_contiguous():
         raise TypeError("permute_inner: contiguous fp32 source")
+    if src.numel() != n * A * Bn:
+        raise ValueError(f"permute_inner: source has {src.numel()} elements, n * A * Bn = {n * A * Bn}")
     if out is None:
         out, accumulate = torch.empty(n * A * Bn, dtype=torch.float32, device=src.device), False
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != n * A * Bn or out.device != src.device:
+        raise TypeError(f"permute_inner: `out` must be a contiguous fp32 tensor of {n * A * Bn} elements on {src.device} "
+                        f"(got {out.dtype}, contiguous={out.is_contiguous()}, {out.numel()} elements)")
     _lib.check(_lib.lib().s2svc_permute_inner(n, A, Bn, ptr(src), ptr(out), 1 if accumulate else 0, stream()), "permute_inner")
     return out
 

@@ -494,6 +494,15 @@ def permute_inner_accumulate():
         acc = base.clone()
         K.permute_inner(src, n, A, Bn, out=acc, accumulate=True)
         res.append((bool(torch.equal(acc, base + ref)), f"permute_inner accumulate n{n} A{A} B{Bn}: bit-exact={bool(torch.equal(acc, base + ref))}"))
+    # a slot of the wrong dtype / size / layout is refused, never written through
+    src = rnd(3, 2, 8, seed=9)
+    for nm, bad in (("bf16 slot", torch.zeros(48, dtype=torch.bfloat16, device=DEV)), ("short slot", torch.zeros(40, device=DEV)),
+                    ("strided slot", torch.zeros(96, device=DEV)[::2])):
+        try:
+            K.permute_inner(src, 3, 2, 8, out=bad, accumulate=True)
+            res.append((False, f"permute_inner accepted a {nm}"))
+        except TypeError:
+            res.append((True, f"permute_inner refuses a {nm}"))
     return res
 
 
