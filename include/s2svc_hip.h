@@ -154,8 +154,7 @@ int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs /* host */, int n, v
    256 x 128 tile) units, up to 40 problems per launch.  A reduction longer than 64 K tiles of 64 rows is cut into chunks -- a
    function of K only -- whose fp32 partial tiles go through `ws` and are added in chunk order by a second launch (deterministic).
      _ok        : 1 if the kernel takes `desc` (a function of the descriptor only).  Since round 4 that includes the exact-256
-                  problems with >= 64 tiles of 128 x 128 (AAS-VC's decoder layers); only S2SVC_W8_EXACT=0 in the environment sends
-                  those back to s2svc_gemm_grouped's 8-wave exact-tile path;
+                  problems with >= 64 tiles of 128 x 128 (AAS-VC's decoder layers);
                   Round 5: B may also be the implicit im2col operand of a convolution weight gradient (S2SVC_LAYOUT_RC with
                   S2SVC_OP_CONV2D_S2 or S2SVC_OP_CONV1D, C % 128 == 0, whole images / utterances in K; Conv1d only for outputs of
                   >= 64 tiles) -- replaces autograd's conv weight gradients at subsampling.py:58-63 and alignments.py:28-60;
@@ -168,15 +167,15 @@ int s2svc_gemm_wgrad_grouped(const s2svc_gemm_desc* descs /* host */, int n, flo
 /* the same on a CAPPED grid: at most `wgs_cap` workgroups walk the units in order and leave the rest of the chip to the kernels of
    the stream the launch runs beside (forked gradient batches); same sums, same bits (wgs_cap <= 0: one workgroup per unit) */
 int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs /* host */, int n, float* ws, void* stream, int wgs_cap);
-/* A/B switch (tests, benchmarks): on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles of 64 rows per chunk (<= 0: unchanged; default 64,
-   S2SVC_GEMM_W8 / S2SVC_W8_KT_CHUNK); returns the previous on | kt_chunk << 8. */
+/* A/B switch (tests, benchmarks): on = 0 / 1 (< 0: unchanged), kt_chunk = K tiles of 64 rows per chunk (<= 0: unchanged; default 64);
+   returns the previous on | kt_chunk << 8. */
 int s2svc_gemm_set_w8(int on, int kt_chunk);
 
 /* Kernel-family switch for tests / A-B timing of s2svc_gemm's bf16 path: the 256-row, 8-wave, phase-interleaved kernel
    (csrc/gemm_8ph.hip: K-contiguous dense or Conv2d-3x3-s2 A operand, dense B, K % 64 == 0, >= 128 tiles) is tried first.
    mode & 15: 0 = never, 1 = default policy, 2 = policy without the half-phase skew of the two wave halves;
    (mode >> 4) & 15: 0 = tile geometry by policy, 1 = 256 x 256, 2 = 512 x 128, 3 = 256 x 128 forced (eligible problems only);
-   (mode >> 8) & 15: 0 = unchanged, 1 + v sets the 256 x 96 p one-round geometry (gemm_8ph_kernel_n96, S2SVC_GEMM_N96): v = 0 never,
+   (mode >> 8) & 15: 0 = unchanged, 1 + v sets the 256 x 96 p one-round geometry (gemm_8ph_kernel_n96): v = 0 never,
    1 by policy (default), 2 wherever N % 96 p == 0 (widest p), 4 / 5 = the same with p = 2 / 3 only.
    Returns the previous mode (mode < 0: query only).  Results do not depend on the mode beyond fp32 summation order. */
 int s2svc_gemm_set_8ph(int mode);
@@ -488,17 +487,12 @@ int s2svc_attn_fused_bwd(int B, int H, int T1, int T2, int dk, const void* q, in
 /* backward of the same up to the gradient of the scaled scores and of matrix_bd.              */
 /*   fwd: attn / pdrop (B, H, T, ld) bf16 (pdrop = the dropped copy, NULL when drop_p == 0),   */
 /*        qu = q + pos_bias_u, qv = q + pos_bias_v (B, T, H*dk) for the backward GEMMs.        */
-/*   bwd: ds (B, H, T, ld) = d loss / d (scaled scores) * scale, dbd (B, H, T, Lq) = the same   */
-/*        values at column T-1-i+j of row i, zero elsewhere (complete rows).                   */
 /* ========================================================================================== */
 int s2svc_relattn_supported(int dtype, int T, int dk, int rel_mode);
 int s2svc_relattn_fwd(int B, int H, int T, int dk, const void* q, int64_t ldq, int64_t qbs, const void* k, int64_t ldk, int64_t kbs,
                       const void* pos, int64_t ldp, int L, const float* u, const float* v, const int32_t* klen, float scale,
                       float drop_p, const uint64_t* seed_base, uint64_t seed_off, void* attn, void* pdrop, int ld, void* qu, void* qv,
                       void* stream);
-int s2svc_relattn_bwd(int B, int H, int T, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv, int64_t vbs,
-                      const void* attn, const void* dattn, int ld, float scale, float drop_p, const uint64_t* seed_base,
-                      uint64_t seed_off, void* ds, void* dbd, int Lq, void* stream);
 
 /* ========================================================================================== */
 /* Token embedding of Transformer-TTS (models/transformer_tts.py:63-77, Embedding(idim, adim, */

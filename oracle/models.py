@@ -144,7 +144,7 @@ def alignment_module(p, text, feats, x_pad_mask):  # modules/alignments.py:28-60
 
 
 def viterbi_decode(log_p_attn, text_lens, feat_lens):  # modules/alignments.py:281-310 (differentiable bin_loss)
-    ds_np, _, paths, margin = _viterbi_np(log_p_attn.detach().numpy(), text_lens.numpy(), feat_lens.numpy())
+    ds_np, _, paths, margin = _viterbi_np(log_p_attn.detach().float().numpy(), text_lens.numpy(), feat_lens.numpy())
     B = log_p_attn.shape[0]
     bin_loss = 0
     for b in range(B):

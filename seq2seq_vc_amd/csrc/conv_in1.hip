@@ -352,7 +352,7 @@ extern "C" int s2svc_conv_in1_wgrad(int dtype, int B, int Tn, int Fn, int O, con
   chunks = (int)((npix + ppc - 1) / ppc);
   hipStream_t st = (hipStream_t)stream;
   const int og = O / 8;
-  static const bool mfma_on = [] { const char* e = getenv("S2SVC_CONV_IN1_MFMA"); return !(e && e[0] == '0'); }();
+  static const bool mfma_on = true;
   if (mfma_on && dtype == S2S_BF16 && !y && O % 64 == 0 && npix * (F1 > T1 ? F1 : T1) < ((int64_t)1 << 32) && F1 >= 2 && T1 >= 2 &&
       (uintptr_t)dy % 16 == 0) {
     const int gq = O / 64, gpw = gq % 3 == 0 ? 3 : gq % 2 == 0 ? 2 : 1;

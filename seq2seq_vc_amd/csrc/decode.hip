@@ -408,7 +408,7 @@ template <typename T, int NS>
 void launch_ln_linear_ns(const s2svc_gemm_desc& d, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, hipStream_t st) {
   dim3 grid((d.N + 15) / 16), block(256);
   const int mt = (d.M + 15) / 16;
-  static const bool lean_on = !(getenv("S2SVC_GEMM_LEAN") && getenv("S2SVC_GEMM_LEAN")[0] == '0');
+  static const bool lean_on = true;
   if (lean_on && mt <= 2 && epilogue_lean_ok(d)) {
     if (mt == 1) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 1, NS, true>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
     else hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 2, NS, true>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);

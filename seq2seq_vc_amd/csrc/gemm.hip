@@ -333,7 +333,7 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream);   
 
 static bool generic_forced() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_GENERIC"); v = (e && e[0] == '1') ? 1 : 0; }
+  if (v < 0) v = 0;
   return v == 1;
 }
 

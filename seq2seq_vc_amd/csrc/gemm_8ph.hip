@@ -1381,27 +1381,19 @@ bool p8_tr_ok(const s2svc_gemm_desc& d) {      // exact tiles of dense row-conti
   return true;
 }
 
-int p8_tr_mode() {     // S2SVC_GEMM_8PH_TR=0: weight gradients stay on the 4-wave kernels (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_8PH_TR"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v;
-}
+constexpr int p8_tr_mode() { return 1; }     // weight gradients on the 8-wave kernels (the 4-wave path was the A/B alternative through round 5)
 
 int g_p8_mode = -1;
-int p8_mode() {       // S2SVC_GEMM_8PH / s2svc_gemm_set_8ph: 0 = off, 1 = on (default), 2 = on without the half-phase skew of the wave halves
-  if (g_p8_mode < 0) { const char* e = getenv("S2SVC_GEMM_8PH"); g_p8_mode = e ? atoi(e) : 1; }
+int p8_mode() {       // s2svc_gemm_set_8ph: 0 = off, 1 = on (default), 2 = on without the half-phase skew of the wave halves
+  if (g_p8_mode < 0) g_p8_mode = 1;
   return g_p8_mode;
 }
 
-int p8_min_tiles() {  // S2SVC_GEMM_8PH_MIN_TILES: take the kernel from this many 256-row tiles on
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_8PH_MIN_TILES"); v = e ? atoi(e) : 128; }
-  return v;
-}
+constexpr int p8_min_tiles() { return 128; }  // take the kernel from this many 256-row tiles on
 
 int g_p8_n96 = -1;
-int p8_n96_mode() {     // S2SVC_GEMM_N96: 0 = off, 1 = by policy (default), 2 = wherever N is a multiple of 96 PH, 4 / 5 = PH = 2 / 3 only (tests / benchmarks)
-  if (g_p8_n96 < 0) { const char* e = getenv("S2SVC_GEMM_N96"); g_p8_n96 = e ? atoi(e) : 1; }
+int p8_n96_mode() {     // s2svc_gemm_set_8ph: 0 = off, 1 = by policy (default), 2 = wherever N is a multiple of 96 PH, 4 / 5 = PH = 2 / 3 only (tests / benchmarks)
+  if (g_p8_n96 < 0) g_p8_n96 = 1;
   return g_p8_n96;
 }
 // phases (tile width / 96) of the one-round geometry for this problem, 0 = keep the geometry chosen so far (`tiles` workgroups)
@@ -1420,14 +1412,9 @@ int p8_n96_phases(const s2svc_gemm_desc& d, int geo, int64_t tiles) {
 }
 
 int g_p8_geo = -1;
-int p8_force_bn() {   // S2SVC_GEMM_8PH_GEO=1|2|3 / s2svc_gemm_set_8ph: force the tile geometry 256x256 / 512x128 / 256x128
-  if (g_p8_geo < 0) { const char* e = getenv("S2SVC_GEMM_8PH_GEO"); g_p8_geo = e ? atoi(e) : 0; }
+int p8_force_bn() {   // s2svc_gemm_set_8ph (1|2|3): force the tile geometry 256x256 / 512x128 / 256x128
+  if (g_p8_geo < 0) g_p8_geo = 0;
   return g_p8_geo;
-}
-
-bool getenv_off(const char* name) {       // "<name>=0" switches a path off (A/B aid)
-  const char* e = getenv(name);
-  return e && e[0] == '0';
 }
 
 bool p8_operand_ok(const s2svc_operand& o, int rows, int K) {
@@ -1457,7 +1444,7 @@ bool p8_operand_ok(const s2svc_operand& o, int rows, int K) {
 extern "C" int s2svc_gemm_set_8ph(int mode) {
   const int prev = p8_mode() | (p8_force_bn() << 4) | ((p8_n96_mode() + 1) << 8);
   if (mode >= 0) {
-    const int n96 = (mode >> 8) & 15;            // 0: leave; 1 + S2SVC_GEMM_N96 value otherwise
+    const int n96 = (mode >> 8) & 15;            // 0: leave; 1 + the n96 mode otherwise (p8_n96_mode)
     mode &= 255;
     if ((mode & 15) <= 2 && (mode >> 4) <= 3) {
       g_p8_mode = mode & 15;
@@ -1489,7 +1476,7 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   if (mode == 0 || d.dtype != S2S_BF16 || d.splitk > 1 || d.a_rowsum || d.tile_hint == 64) return 0;
   if (d.K < 128 || d.K % 64 || d.M < 256 || d.N < 64) return 0;
   if (d.B.mode != S2SVC_OP_DENSE || !p8_operand_ok(d.A, d.M, d.K) || !p8_operand_ok(d.B, d.N, d.K)) return 0;
-  if (d.A.mode == S2SVC_OP_TCONV2D_S2 && (d.nb0 * d.nb1 != 1 || getenv_off("S2SVC_GEMM_8PH_TCONV"))) return 0;
+  if (d.A.mode == S2SVC_OP_TCONV2D_S2 && d.nb0 * d.nb1 != 1) return 0;
   const int64_t nb = (int64_t)d.nb0 * d.nb1;
   const int64_t t256 = (int64_t)((d.M + 255) / 256) * ((d.N + 255) / 256) * nb;       // 256 x 256 tiles
   const int64_t t512 = (int64_t)((d.M + 511) / 512) * ((d.N + 127) / 128) * nb;       // 512 x 128 tiles
@@ -1507,10 +1494,6 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   else if (d.M >= 2048 && t512 >= 160 && t512 <= 256) geo = 2;
   else if (t128 >= p8_min_tiles()) geo = 3;
   if (p8_force_bn() >= 1 && p8_force_bn() <= 3) geo = p8_force_bn();
-  if (d.A.mode == S2SVC_OP_TCONV2D_S2) {       // S2SVC_TCONV_GEO=1|2|3: tile geometry of the transposed-convolution classes only (A/B aid)
-    static const int tg = [] { const char* e = getenv("S2SVC_TCONV_GEO"); return e ? atoi(e) : 0; }();
-    if (tg >= 1 && tg <= 3) geo = tg;
-  }
   hipStream_t st = (hipStream_t)stream;
   // 256 x 96 PH tiles where they fit the chip in ONE round and the geometry above does not (gemm_8ph_kernel_n96)
   if (d.A.mode == S2SVC_OP_DENSE && nb == 1 && mode == 1 && (p8_force_bn() == 0 || p8_n96_mode() >= 2) && epilogue_common_ok(d)) {
@@ -1526,8 +1509,8 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
   if (geo == 0) return 0;
   if (d.A.mode == S2SVC_OP_CONV1D) {
     // Conv1d as an implicit GEMM (the aligner's 1536 -> 1536 k3 layer over 4096 frames: 58 GF forward and data gradient, 0.24-0.28 of the
-    // peak on the 4-wave kernel): the common epilogue only, one problem; S2SVC_GEMM_8PH_CONV1D=0 switches it off
-    static const bool c1d_on = !getenv_off("S2SVC_GEMM_8PH_CONV1D");
+    // peak on the 4-wave kernel): the common epilogue only, one problem
+    static const bool c1d_on = true;
     if (!c1d_on || mode != 1 || nb != 1 || !epilogue_common_ok(d)) return 0;
     const int bm1 = geo == 2 ? 512 : 256, bn1 = geo == 1 ? 256 : 128;
     dim3 grid1((unsigned)((d.N + bn1 - 1) / bn1), (unsigned)((d.M + bm1 - 1) / bm1), 1);
@@ -1552,12 +1535,12 @@ extern "C" int s2svc_gemm_try_8ph(const s2svc_gemm_desc* desc, void* stream) {
       else hipLaunchKernelGGL((KERNEL<P8_DENSE, ##__VA_ARGS__, true>), grid, dim3(512), 0, st, d);        \
     }                                                                                                     \
   } while (0)
-  static const bool lean_on = !getenv_off("S2SVC_GEMM_LEAN");
+  static const bool lean_on = true;
   if (lean_on && !conv && !tconv && mode != 2 && epilogue_common_ok(d)) {       // dense operands + the common epilogue: lean variants
     if (geo == 1) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_DENSE, 2, 4, true, true>), grid, dim3(512), 0, st, d);
     else if (geo == 2) hipLaunchKernelGGL((gemm_8ph_kernel_q<P8_DENSE, 4, 2, true, true>), grid, dim3(512), 0, st, d);
     else hipLaunchKernelGGL((gemm_8ph_kernel_128<P8_DENSE, true, 1>), grid, dim3(512), 0, st, d);
-  } else if (lean_on && geo == 3 && !conv && !tconv && mode != 2 && !getenv_off("S2SVC_GEMM_LEAN_SWISH") && epilogue_swish_ok(d)) {        // the Conformer feed-forward pair
+  } else if (lean_on && geo == 3 && !conv && !tconv && mode != 2 && epilogue_swish_ok(d)) {        // the Conformer feed-forward pair
     hipLaunchKernelGGL((gemm_8ph_kernel_128<P8_DENSE, true, 2>), grid, dim3(512), 0, st, d);
   } else if (geo == 1) P8_LAUNCH(gemm_8ph_kernel_q, 2, 4);
   else if (geo == 2) P8_LAUNCH(gemm_8ph_kernel_q, 4, 2);
@@ -1615,12 +1598,12 @@ extern "C" int s2svc_gemm_grouped_try_8ph(const s2svc_gemm_desc* descs, int n, v
 // ---- ragged weight gradients on the 8-wave kernel (W8) -----------------------------------------------------------
 namespace {
 int g_w8_mode = -1, g_w8_kt = -1;
-int w8_mode() {       // S2SVC_GEMM_W8=0 / s2svc_gemm_set_w8: these problems stay on gemm_grouped_kernel<64, 64> (A/B switch)
-  if (g_w8_mode < 0) { const char* e = getenv("S2SVC_GEMM_W8"); g_w8_mode = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1; }
+int w8_mode() {       // s2svc_gemm_set_w8(0, .): these problems stay on gemm_grouped_kernel<64, 64> (A/B switch)
+  if (g_w8_mode < 0) g_w8_mode = 1;
   return g_w8_mode;
 }
-int w8_kt_chunk_env() {   // S2SVC_W8_KT_CHUNK / s2svc_gemm_set_w8: K tiles (of 64 rows) per chunk; reductions up to this long run unsplit
-  if (g_w8_kt < 0) { const char* e = getenv("S2SVC_W8_KT_CHUNK"); g_w8_kt = e ? atoi(e) : 64; if (g_w8_kt < 1) g_w8_kt = 1; }
+int w8_kt_chunk_env() {   // s2svc_gemm_set_w8(., kt): K tiles (of 64 rows) per chunk; reductions up to this long run unsplit
+  if (g_w8_kt < 0) g_w8_kt = 64;
   return g_w8_kt;
 }
 // the chunking of a reduction: a function of the problem's OWN shape only (see the kernel's header) -- outputs of >= 64 tiles fill the
@@ -1632,8 +1615,8 @@ void w8_chunks(int M, int N, int K, int& nchunks, int& kt_chunk, bool conv = fal
   const int ktiles = (K + 63) / 64;
   if (conv) {       // the Conv2d weight gradient: a long reduction (tens of thousands of pixels) over ~50 tiles.  VTN's 384 x 3456 over 38304
     // pixels, stand-alone: chunks of 64 / 75 / 86 / 100 / 120 / 150 / 200 K tiles = 182 / 145 / 165 / 184 / 201 / 153 / 196 us (the 4-wave split-K
-    // kernel: 152); the VTN step is the same for all of them (3.65-3.67 ms) -- 75, S2SVC_W8_CONV_KT overrides
-    static const int ck = [] { const char* e = getenv("S2SVC_W8_CONV_KT"); return e ? atoi(e) : 75; }();
+    // kernel: 152); the VTN step is the same for all of them (3.65-3.67 ms) -- 75
+    static const int ck = 75;
     kt_chunk = ck < 1 ? 1 : ck;
     nchunks = (ktiles + kt_chunk - 1) / kt_chunk;
     return;
@@ -1661,13 +1644,13 @@ bool w8_ok(const s2svc_gemm_desc& d) {
   if (((uintptr_t)d.A.ptr) % 16 || ((uintptr_t)d.B.ptr) % 16 || d.A.ld % 8 || d.B.ld % 8 || d.A.ld < d.M) return false;
   if ((int64_t)64 * d.A.ld * 2 + (int64_t)d.M * 2 >= (1ll << 32)) return false;
   if (convB) {
-    static const bool conv_on = !getenv_off("S2SVC_W8_CONV");
+    static const bool conv_on = true;
     if (!conv_on || d.B.C < 128 || d.B.C % 128 || d.N != 9 * d.B.C || d.B.ld < d.B.C) return false;
     if (d.B.T1 <= 0 || d.B.F1 <= 0 || d.B.T2 <= 0 || d.B.F2 <= 0 || 2 * (d.B.T2 - 1) + 3 > d.B.T1 || 2 * (d.B.F2 - 1) + 3 > d.B.F1) return false;
     if (d.K % (d.B.T2 * d.B.F2)) return false;               // whole images
     if ((int64_t)(d.K + 64) * (d.B.T2 * d.B.F2) >= (1ll << 32)) return false;       // the multiply-high divisions are exact below that
   } else if (conv1B) {
-    static const bool conv1_on = !getenv_off("S2SVC_W8_CONV1D");
+    static const bool conv1_on = true;
     if (!conv1_on || d.B.C < 128 || d.B.C % 128 || d.B.pad < 0 || d.N != (2 * d.B.pad + 1) * d.B.C || d.B.ld < d.B.C) return false;
     if (d.B.T <= 0 || d.K % d.B.T) return false;             // whole utterances
     if ((int64_t)(d.K + 64) * d.B.T >= (1ll << 32)) return false;
@@ -1678,8 +1661,8 @@ bool w8_ok(const s2svc_gemm_desc& d) {
   if (((uintptr_t)d.C) % 16 || d.ldc % 4 || d.ldc < d.N) return false;
   if (d.bias || d.res || d.act != S2S_ACT_NONE || d.alpha != 1.0f || d.emask || d.drop_p > 0.f || d.c_map || d.c_pre) return false;
   // the exact-256 problems with >= 64 tiles of 128 x 128 (AAS-VC's decoder) ran on p8_tr_tile / p8_tr_tile_q until the loader-
-  // specialised tile beat both per flop (0.83 us per 256 x 128 K tile against 1.05); S2SVC_W8_EXACT=0 sends them back there
-  static const bool exact_too = !getenv_off("S2SVC_W8_EXACT");
+  // specialised tile beat both per flop (0.83 us per 256 x 128 K tile against 1.05)
+  static const bool exact_too = true;
   if (!exact_too && w8_mode() != 2 && p8_tr_ok(d) && (int64_t)(d.M / 128) * (d.N / 128) >= 64) return false;
   return true;
 }
@@ -1725,7 +1708,7 @@ extern "C" int s2svc_gemm_wgrad_grouped_bg(const s2svc_gemm_desc* descs, int n, 
   S2S_REQUIRE(descs && n > 0, "gemm_wgrad_grouped: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int mode = p8_mode();
-  static const int cap_env = [] { const char* e = getenv("S2SVC_W8_WGS"); return e ? atoi(e) : 0; }();
+  static const int cap_env = 0;
   const int cap = wgs_cap > 0 ? wgs_cap : cap_env;
   int64_t ws_off = 0;
   for (int i0 = 0; i0 < n; i0 += W8_MAX) {

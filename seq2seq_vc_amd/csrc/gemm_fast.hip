@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const s2svc_gemm_desc d)
 template <typename T, int BM, int BN, int BK>
 void launch_modes(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   const bool arc = d.A.layout == S2SVC_LAYOUT_RC, brc = d.B.layout == S2SVC_LAYOUT_RC;
-  static const bool lean_on = !(getenv("S2SVC_GEMM_LEAN") && getenv("S2SVC_GEMM_LEAN")[0] == '0');
+  static const bool lean_on = true;
   if constexpr (sizeof(T) == 4 && BM <= 64) {
     if (lean_on && d.A.mode == S2SVC_OP_DENSE && d.B.mode == S2SVC_OP_DENSE && epilogue_common32_ok(d)) {
       if (!arc && !brc) hipLaunchKernelGGL((gemm_fast_kernel<float, BM, BN, BK, AM_KC, AM_KC, true>), grid, dim3(256), 0, st, d);
@@ -373,7 +373,7 @@ extern "C" int s2svc_gemm_try_fast(const s2svc_gemm_desc* desc, void* stream) {
     // 96 workgroups; its 29-column spline projection: 16) take 32 x 32 tiles with K tiles of 128: the fp32 MFMA
     // (v_mfma_f32_16x16x4f32, 256 flop / clk / CU) makes a 64 x 64 x 384 workgroup 5 us of matrix-pipe time on its own;
     // a quarter of it per workgroup, on four times the workgroups.  Same order of every sum (k ascending), same bits.
-    static const bool t32_on = !(getenv("S2SVC_GEMM_F32_T32") && getenv("S2SVC_GEMM_F32_T32")[0] == '0');
+    static const bool t32_on = true;
     const int64_t tiles64 = (int64_t)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nb0 * d.nb1 * splitk;
     const bool t32_ok = d.dtype == S2S_F32 && d.K >= 128 && d.A.mode == S2SVC_OP_DENSE && d.B.mode == S2SVC_OP_DENSE;
     if (t32_ok && ((t32_on && d.tile_hint == 0 && tiles64 < 128 && !d.a_rowsum) || d.tile_hint == 32)) {      // (hint 32: ops.kernels.plan_gemm)

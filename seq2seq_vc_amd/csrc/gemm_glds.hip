@@ -9,7 +9,7 @@
 //   * Row-contiguous operands (activations in wgrad, weights in dgrad) are DMA-ed k-major into LDS and their fragments
 //     come from ds_read_b64_tr_b16 transpose reads (TrStage / tr_fragment below); a K-contiguous partner then reads the
 //     same permuted k positions with two ds_read_b64 (kc_fragment_perm).  The register-transpose path (RcStage: 8x8
-//     blocks, v_perm_b32, ds_write_b128 into the swizzled image) remains behind S2SVC_GEMM_NO_TR=1.
+//     blocks, v_perm_b32, ds_write_b128 into the swizzled image) remains in the file for operands the transpose read cannot take.
 //   * Two LDS buffers: tile t+1 is in flight (DMA + global loads) while the MFMAs consume tile t; one barrier per
 //     K tile.  Pieces outside the matrix / the conv input are fetched from a 16-byte zero block.
 //   * 128x128 or 64x64 output tile per 4-wave workgroup (2x2 waves, 4x4 / 2x2 MFMA 16x16x32 fragments per wave),
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_batched_kernel(const group_a
   gemm_glds_tile<BM, BN, AMODE, BMODE>(d, tile_m, r - tile_m * tiles_n, zb, 0, smem);
 }
 
-// The same with a CAPPED grid: gridDim.x workgroups walk all tiles (S2SVC_GROUP_WGS).  Weight-gradient launches run on side
+// The same with a CAPPED grid: gridDim.x workgroups walk all tiles.  Weight-gradient launches run on side
 // streams beside the data-gradient chain; one workgroup per tile (500-1300 of them) takes every CU slot for the length of the
 // launch and the chain's small kernels queue behind them, a capped grid leaves slots free.  Same tile code: same bits.
 template <int BM, int BN, int AMODE, int BMODE>
@@ -874,46 +874,18 @@ __global__ __launch_bounds__(512) void gemm_dma_k2_kernel(const s2svc_gemm_desc 
   epilogue_flush_common<BM / 2, BN / 2>(d, m0 + wm, n0 + wn, cs);
 }
 
-bool k2_enabled() {      // S2SVC_GEMM_K2=0: long reductions over few tiles stay on the 4-wave kernel (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_K2"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
-int k2_min_tiles() {     // S2SVC_GEMM_K2_MIN: K tiles from which the split is taken (tuning aid)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_K2_MIN"); v = e ? atoi(e) : 12; }
-  return v;
-}
+constexpr bool k2_enabled() { return true; }      // long reductions over few tiles: the 8-wave split-K kernel
+constexpr int k2_min_tiles() { return 12; }       // K tiles from which the split is taken
 
-bool lean_enabled() {    // S2SVC_GEMM_LEAN=0: every launch carries the general epilogue (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_LEAN"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+constexpr bool lean_enabled() { return true; }    // launches with the common epilogue carry the lean flush code
 
-int dma_stages() {       // S2SVC_GEMM_STAGES override (0 = built-in policy), see launch_kinds
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_STAGES"); v = e ? atoi(e) : 0; }
-  return v;
-}
+constexpr int dma_stages() { return 0; }          // 0 = the built-in stage policy, see launch_kinds
 
-bool deep_stages() {     // S2SVC_GEMM_DEEP=0: no 5-stage variant of the 32x64 kernel for long reductions (tuning aid)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_DEEP"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+constexpr bool deep_stages() { return true; }     // the 5-stage variant of the 32x64 kernel for long reductions
 
-int deep_min_tiles() {   // S2SVC_GEMM_DEEP_MIN: K tiles from which the 5-stage variant is taken (tuning aid)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_DEEP_MIN"); v = e ? atoi(e) : 16; }
-  return v;
-}
+constexpr int deep_min_tiles() { return 16; }     // K tiles from which the 5-stage variant is taken
 
-bool tr_enabled() {      // S2SVC_GEMM_NO_TR=1: row-contiguous operands through the register-transpose path (tuning aid)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_NO_TR"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
+constexpr bool tr_enabled() { return true; }      // row-contiguous operands through ds_read_b64_tr_b16
 
 int kind_of(const s2svc_operand& o) {
   if (o.mode == S2SVC_OP_TCONV2D_S2) return o.layout == S2SVC_LAYOUT_KC ? G_KC_TCONV2D : -1;
@@ -937,7 +909,7 @@ bool launch_kinds(const s2svc_gemm_desc& d, dim3 grid, hipStream_t st) {
   }
   // all-DMA operands: the 64x64 tile runs the 3-stage counted-wait pipeline (48 KB LDS, 3 workgroups per CU); the
   // 128x128 tile keeps two stages (64 KB, 2 workgroups per CU -- a third stage leaves one workgroup per CU and
-  // measured ~2x slower; BK = 32 with 3-4 stages measured 10-15 % slower).  S2SVC_GEMM_STAGES=2 forces two stages.
+  // measured ~2x slower; BK = 32 with 3-4 stages measured 10-15 % slower).
 #define S2S_DMA_CASE(KA, KB)                                                                        \
   if (ka == KA && kb == KB && !d.a_rowsum && BM == 64 && dma_stages() != 2) {                      \
     hipLaunchKernelGGL((gemm_dma_kernel<64, 64, KA, KB, 3, 64>), grid, dim3(256), 0, st, d);       \
@@ -979,23 +951,11 @@ bool operand_ok(const s2svc_operand& o) {
   return true;
 }
 
-int big_min_tiles() {     // S2SVC_GEMM_BIG_TILES: 128x128 tiles from this many of them on (tuning aid)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_BIG_TILES"); v = e ? atoi(e) : 192; }
-  return v;
-}
+constexpr int big_min_tiles() { return 192; }     // 128x128 tiles from this many of them on
 
-bool bm32_enabled() {    // S2SVC_GEMM_BM32=0: tuning aid
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_BM32"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+constexpr bool bm32_enabled() { return true; }
 
-bool disabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("S2SVC_GEMM_NO_GLDS"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
+constexpr bool disabled() { return false; }
 
 // the kernels split row indices into image positions with multiply-high divisions, exact while rows * extent < 2^32
 bool rows_fit_fastdiv(const s2svc_gemm_desc& d) {
@@ -1155,7 +1115,7 @@ extern "C" int s2svc_gemm_grouped(const s2svc_gemm_desc* descs, int n, int tile,
     }
     if (g.n == 0) continue;
     for (int i = g.n; i <= S2S_GROUP_MAX; ++i) g.tile_start[i] = (int32_t)total;
-    static const int cap = [] { const char* e = getenv("S2SVC_GROUP_WGS"); return e ? atoi(e) : 0; }();
+    static const int cap = 0;
     if (tr_enabled() && cap > 0 && total > cap) {
       if (tile == 128)
         hipLaunchKernelGGL((gemm_grouped_capped_kernel<128, 128, G_TR_DENSE, G_TR_DENSE>), dim3((unsigned)cap), dim3(256), 0, st, g);
@@ -1194,7 +1154,7 @@ extern "C" int s2svc_gemm_grouped_batched(const s2svc_gemm_desc* descs, int n, v
     total128 += (int64_t)((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nb0 * d.nb1;
   }
   // 128 x 128 tiles once they fill the chip (the rule of the plain launch, over the group), else 64 x 64
-  static const int force_tile = [] { const char* e = getenv("S2SVC_ATTN_GROUP_TILE"); return e ? atoi(e) : 0; }();      // A/B aid
+  static const int force_tile = 0;      // A/B aid
   const int tile = force_tile == 64 || force_tile == 128 ? force_tile : (total128 >= 256 ? 128 : 64);
   int64_t total = 0;
   for (int i = 0; i < n; ++i) {
@@ -1246,7 +1206,7 @@ extern "C" int s2svc_gemm_try_glds(const s2svc_gemm_desc* desc, void* stream) {
     dim3 grid((d.N + 63) / 64, (d.M + 31) / 32, d.nb0 * d.nb1 * splitk);
     // long reductions (K >= 1024: the feed-forward / packed-projection data gradients of VTN, 18-24 K tiles) with few workgroups:
     // five stages in flight (60 KB) instead of three -- with 2 tiles of lookahead (~0.7 us of MFMA work) every K tile waits for
-    // its own DMA round trip; S2SVC_GEMM_DEEP=0 keeps three stages (A/B switch)
+    // its own DMA round trip
     const bool lean = lean_enabled() && epilogue_common_ok(d);
     if (lean && k2_enabled() && splitk == 1 && d.nb0 * d.nb1 == 1 && (d.K + 63) / 64 >= k2_min_tiles()) {
       hipLaunchKernelGGL((gemm_dma_k2_kernel<32, 64, 3>), dim3(grid.x, grid.y, 1), dim3(512), 0, st, d);

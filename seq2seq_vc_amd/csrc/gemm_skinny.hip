@@ -104,7 +104,7 @@ template <typename T>
 void launch_skinny(const s2svc_gemm_desc& d, hipStream_t st) {
   dim3 grid((d.N + 15) / 16), block(256);
   const int mt = (d.M + 15) / 16;
-  static const bool lean_on = !(getenv("S2SVC_GEMM_LEAN") && getenv("S2SVC_GEMM_LEAN")[0] == '0');
+  static const bool lean_on = true;
   if (lean_on && mt <= 2 && epilogue_lean_ok(d)) {
     if (mt == 1) hipLaunchKernelGGL((gemm_skinny_kernel<T, 1, true>), grid, block, 0, st, d);
     else hipLaunchKernelGGL((gemm_skinny_kernel<T, 2, true>), grid, block, 0, st, d);

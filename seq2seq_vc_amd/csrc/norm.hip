@@ -801,7 +801,7 @@ extern "C" int s2svc_layernorm_bwd(int dtype, int rows, int D, const void* dy, c
 // _pg_chunks: 0 if the shape / pointers are not eligible (the caller uses s2svc_layernorm_bwd + a mode-1 column reduction), else the
 // number of partial row pairs the launch writes to ws[chunks][2][D]; they enter s2svc_colreduce_grouped as a mode-7 item.
 static int ln_pg_rpw(int rows) {
-  static const int env = [] { const char* e = getenv("S2SVC_LN_PG_RPW"); return e ? atoi(e) : 0; }();
+  static const int env = 0;
   if (env > 0) return env;
   int rpw = (rows + 2047) / 2048;                 // ~256 blocks of 8 waves
   return rpw < 1 ? 1 : rpw;
@@ -827,7 +827,7 @@ static bool ln_pg_lds_ok_for(int D) { return D <= 512 ? ln_pg_lds_ok<1>() : D <=
 
 extern "C" int s2svc_layernorm_bwd_pg_chunks(int dtype, int rows, int D, const void* dy, const void* s, const float* gamma,
                                              const void* ds_extra, const void* ds, const void* dh) {
-  static const bool on = !(getenv("S2SVC_LN_PG") && getenv("S2SVC_LN_PG")[0] == '0');
+  static const bool on = true;
   if (!on || dtype != S2S_BF16 || D > 2048 || rows < 2048 || (int64_t)rows * D < 1500000) return 0;
   if (!ln_vec_ok(D, dy, s, ds, dh, ds_extra) || ((uintptr_t)gamma) % 16) return 0;
   if (!ln_pg_lds_ok_for(D)) return 0;

@@ -154,8 +154,7 @@ extern "C" int s2svc_adam_step(int64_t n, float* params, const float* grads, flo
   const int64_t ub = (n / 4 + 255) / 256 > 0 ? (n / 4 + 255) / 256 : 1;
   // non-temporal loads / stores of the moments when a buffer is larger than the memory-side cache (256 MB): nothing of this pass is
   // read again before it is evicted (AAS-VC, 630 MB per buffer: 11.61 -> 11.58 ms per step; VTN, 122 MB: neutral, left cached)
-  static const int nt_env = [] { const char* e = getenv("S2SVC_ADAM_NT"); return e ? atoi(e) : -1; }();
-  const bool nt = nt_env >= 0 ? nt_env == 1 : n * 4 > (256ll << 20);
+  const bool nt = n * 4 > (256ll << 20);
   if (nt) hipLaunchKernelGGL(adam_update_kernel<true>, dim3((unsigned)ub), dim3(256), 0, st, n, params, grads, exp_avg, exp_avg_sq,
                              (bf16_t*)bf16_shadow, beta1, beta2, eps, state);
   else hipLaunchKernelGGL(adam_update_kernel<false>, dim3((unsigned)ub), dim3(256), 0, st, n, params, grads, exp_avg, exp_avg_sq,

@@ -6,8 +6,9 @@
 // kernel with the shift as index arithmetic (forward), and GEMM (dP) -> zero fill -> softmax backward with a scatter into dbd
 // (backward).  Here:
 //   relattn_fwd_kernel   q, k, pos, u, v -> attention map (+ its dropped copy) and qu = q + u, qv = q + v for the backward GEMMs
-//   relattn_bwd_kernel   dctx, v, attention map -> dS (gradient of the scaled scores) and dbd (the same values at their
-//                        un-shifted positions, complete zero-padded rows: the operand of the d qv / d pos GEMMs)
+// (A fused backward kernel -- dP, softmax backward and the un-shifted dbd rows in one launch per 64-row block -- existed through round 5
+// as an opt-in: correct, and slower than the batched GEMM + softmax-backward kernels it replaced, 30 / 46 vs 26 / 33 us at d_k = 192 / 768;
+// removed in round 6, profiles/AB_LOG.md.)
 // One workgroup per (utterance, head, block of 64 query rows); wave w owns the key columns 64 w .. 64 w + 63 of all 64 rows
 // (16 accumulator tiles of 16 x 16).  The position term of a row block needs the 319 position rows c0 .. c0 + 318,
 // c0 = T - 64 - i0; wave w multiplies its rows with 8 of the 20 tiles of that window and the shift
@@ -264,148 +265,6 @@ __global__ __launch_bounds__(256) void relattn_fwd_kernel(const ra_fwd_args a) {
   }
 }
 
-struct ra_bwd_args {
-  int H, T, dk, L, ld, Lq;
-  const bf16_t* dctx; int64_t ldo, obs;
-  const bf16_t* v; int64_t ldv, vbs;
-  const bf16_t* attn; const bf16_t* dattn;
-  float scale, p;
-  const uint64_t* seed_base; uint64_t seed_off;
-  bf16_t* ds; bf16_t* dbd;
-};
-
-constexpr int SB_V = 0, SB_O = 256 * 64, SB_BYTES = SB_O + 64 * 64;      // 20,480 B per stage
-
-__global__ __launch_bounds__(256) void relattn_bwd_kernel(const ra_bwd_args a) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int T = a.T, dk = a.dk, H = a.H;
-  int rb_, bh;
-  block_of(rb_, bh);
-  const int i0 = rb_ * 64;
-  const int b = bh / H, h = bh % H;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, lr = lane & 15, lg = lane >> 4;
-  const int nsteps = dk / 32;
-  // LDS-DMA pipeline as in the forward kernel: v rows (keys) and this block's dctx rows, 5 DMA instructions per wave and slice;
-  // clamped rows (P is 0 at keys j >= T, rows i >= T are never stored)
-  const int wu = __builtin_amdgcn_readfirstlane(w);
-  const char* vbase = reinterpret_cast<const char*>(a.v + (int64_t)b * a.vbs + h * dk);
-  const char* obase = reinterpret_cast<const char*>(a.dctx + (int64_t)b * a.obs + h * dk);
-  int64_t voff[4], ooff;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (w * 4 + i) * 16 + (lane >> 2);
-    voff[i] = ((int64_t)min(r, T - 1) * a.ldv + (((lane & 3) ^ swz32(r)) << 3)) * 2;
-  }
-  {
-    const int r = w * 16 + (lane >> 2);
-    ooff = ((int64_t)min(i0 + r, T - 1) * a.ldo + (((lane & 3) ^ swz32(r)) << 3)) * 2;
-  }
-  auto issue = [&](int s, int stage) {
-    unsigned char* st = smem + stage * SB_BYTES;
-    const int64_t dB = (int64_t)s * 64;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(vbase + voff[i] + dB), (lds_void*)(st + SB_V + (wu * 4 + i) * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void*)(obase + ooff + dB), (lds_void*)(st + SB_O + wu * 1024), 16, 0, 0);
-  };
-  f32x4_t dp[4][4];
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) dp[rt][jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  issue(0, 0);
-  issue(nsteps > 1 ? 1 : 0, 1);
-  int cur = 0;
-#pragma unroll 1
-  for (int s = 0; s < nsteps; ++s) {
-    wait_vmcnt<5>();
-    __builtin_amdgcn_s_barrier();
-    {
-      int nxt = cur + 2;
-      if (nxt >= FWD_STAGES) nxt -= FWD_STAGES;
-      issue(s + 2 < nsteps ? s + 2 : nsteps - 1, nxt);
-    }
-    const unsigned char* st = smem + cur * SB_BYTES;
-    bf16x8_t oa[4];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) oa[rt] = *reinterpret_cast<const bf16x8_t*>(st + SB_O + frag_off(rt * 16 + lr, lg));
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      const bf16x8_t vb = *reinterpret_cast<const bf16x8_t*>(st + SB_V + frag_off(64 * w + jt * 16 + lr, lg));
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) dp[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa[rt], vb, dp[rt][jt], 0, 0, 0);
-    }
-    cur = cur + 1 == FWD_STAGES ? 0 : cur + 1;
-  }
-  wait_vmcnt<0>();
-  __syncthreads();
-  // ---- dP -> fp32 tile DP[64][SP] in LDS.  Row il of DP is later overwritten, by the wave that owns it, with row il of dbd
-  //      (bf16, pitch 2 * SP elements = the same bytes): no second tile, no barrier in between.
-  float* DP = reinterpret_cast<float*>(smem);            // [64][SP] fp32 = [64][2 * SP] bf16
-  bf16_t* stP = reinterpret_cast<bf16_t*>(smem + 64 * SP * 4);   // [64][SP] P, then dS in place
-  bf16_t* stG = stP + 64 * SP;                           // [64][SP] external gradient of the map (only if given)
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) DP[(rt * 16 + 4 * lg + r) * SP + 64 * w + 16 * jt + lr] = dp[rt][jt][r];
-  const int nv = a.ld >> 3, nb = a.Lq >> 3;
-  for (int n = t; n < 64 * 32; n += 256) {
-    const int row = n >> 5, c8 = n & 31;
-    uint4 pvv = make_uint4(0, 0, 0, 0), gvv = make_uint4(0, 0, 0, 0);
-    if (i0 + row < T && c8 < nv) {
-      const int64_t o = ((int64_t)bh * T + i0 + row) * a.ld + c8 * 8;
-      pvv = *reinterpret_cast<const uint4*>(a.attn + o);
-      if (a.dattn) gvv = *reinterpret_cast<const uint4*>(a.dattn + o);
-    }
-    *reinterpret_cast<uint4*>(stP + row * SP + c8 * 8) = pvv;
-    if (a.dattn) *reinterpret_cast<uint4*>(stG + row * SP + c8 * 8) = gvv;
-  }
-  __syncthreads();
-  const uint64_t seed = (a.seed_base ? *a.seed_base : 0ull) + a.seed_off;
-  const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
-  // ---- softmax backward, one wave per row (ROLLED), a lane owns columns lane + 64 c
-#pragma unroll 1
-  for (int rr = 0; rr < 16; ++rr) {
-    const int il = w * 16 + rr, i = i0 + il;
-    const int64_t arow = ((int64_t)bh * T + i) * a.ld;
-    float pv[4], tt[4];
-    float dot = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int j = lane + 64 * c;
-      pv[c] = bf2f(stP[il * SP + j]);
-      const float m = (a.p > 0.f && j < a.ld) ? dropout_scale(seed, (uint64_t)(arow + j), a.p, inv_keep) : 1.f;
-      tt[c] = DP[il * SP + j] * m;
-      if (a.dattn) tt[c] += bf2f(stG[il * SP + j]);
-      dot += pv[c] * tt[c];
-    }
-    dot = wave_sum(dot);
-    bf16_t* rowB = reinterpret_cast<bf16_t*>(DP + il * SP);    // the row's dP values are in registers: its bytes become the dbd row
-    for (int n = lane; n < nb; n += 64) *reinterpret_cast<uint4*>(rowB + n * 8) = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int j = lane + 64 * c;
-      const bf16_t d = f2bf(pv[c] * (tt[c] - dot) * a.scale);
-      stP[il * SP + j] = d;
-      if (i < T && j < T) rowB[T - 1 - i + j] = d;
-    }
-  }
-  __syncthreads();
-  for (int n = t; n < 64 * 32; n += 256) {
-    const int row = n >> 5, c8 = n & 31;
-    if (i0 + row < T && c8 < nv)
-      *reinterpret_cast<uint4*>(a.ds + ((int64_t)bh * T + i0 + row) * a.ld + c8 * 8) = *reinterpret_cast<const uint4*>(stP + row * SP + c8 * 8);
-  }
-  for (int n = t; n < 64 * nb; n += 256) {
-    const int row = n / nb, c8 = n - row * nb;
-    if (i0 + row < T)
-      *reinterpret_cast<uint4*>(a.dbd + ((int64_t)bh * T + i0 + row) * a.Lq + c8 * 8) =
-          *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(DP + row * SP) + c8 * 8);
-  }
-}
-
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
@@ -446,32 +305,3 @@ extern "C" int s2svc_relattn_fwd(int B, int H, int T, int dk, const void* q, int
   return 0;
 }
 
-// dctx (B, T, .) / v (B, T, .) views (row strides ldo / ldv, batch strides obs / vbs); attn, dattn (or NULL), ds (B, H, T, ld);
-// dbd (B, H, T, Lq) with Lq = 2T - 1 rounded up to 8: complete rows, zero outside the shifted positions.
-extern "C" int s2svc_relattn_bwd(int B, int H, int T, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv,
-                                 int64_t vbs, const void* attn, const void* dattn, int ld, float scale, float drop_p,
-                                 const uint64_t* seed_base, uint64_t seed_off, void* ds, void* dbd, int Lq, void* stream) {
-  S2S_REQUIRE(s2svc_relattn_supported(S2S_BF16, T, dk, 1), "relattn_bwd: bf16, T <= 256, d_k % 32 == 0");
-  S2S_REQUIRE(dctx && v && attn && ds && dbd && ld >= T && ld % 8 == 0 && ld <= 256 && Lq >= 2 * T - 1 && Lq % 8 == 0 && Lq <= 512,
-              "relattn_bwd: bad args");
-  S2S_REQUIRE(ldo % 8 == 0 && obs % 8 == 0 && ldv % 8 == 0 && vbs % 8 == 0 && al16(dctx) && al16(v) && al16(attn) && al16(dattn) &&
-              al16(ds) && al16(dbd), "relattn_bwd: 16-byte aligned operands, strides multiples of 8");
-  if (B == 0) return 0;
-  ra_bwd_args a;
-  a.H = H; a.T = T; a.dk = dk; a.L = 2 * T - 1; a.ld = ld; a.Lq = Lq;
-  a.dctx = (const bf16_t*)dctx; a.ldo = ldo; a.obs = obs; a.v = (const bf16_t*)v; a.ldv = ldv; a.vbs = vbs;
-  a.attn = (const bf16_t*)attn; a.dattn = (const bf16_t*)dattn; a.scale = scale; a.p = drop_p; a.seed_base = seed_base;
-  a.seed_off = seed_off; a.ds = (bf16_t*)ds; a.dbd = (bf16_t*)dbd;
-  const size_t lds = (size_t)64 * SP * 4 + (size_t)64 * SP * 2 * (dattn ? 2 : 1);     // dP / dbd tile + P (+ external gradient) >= 3 operand stages (61,440 B)
-  static size_t attr_set = 0;
-  if (attr_set < lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(relattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      s2svc_set_error("relattn_bwd: cannot raise the dynamic LDS limit");
-      return -2;
-    }
-    attr_set = lds;
-  }
-  hipLaunchKernelGGL(relattn_bwd_kernel, dim3((T + 63) / 64, B * H), dim3(256), lds, (hipStream_t)stream, a);
-  S2S_CHECK_LAUNCH("relattn_bwd_kernel");
-  return 0;
-}

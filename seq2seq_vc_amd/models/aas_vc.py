@@ -172,7 +172,7 @@ class AASVC(nn.Module):
 
         Round 4: the stochastic predictor's two conditioning networks run in the LAST stage (cut "sdp_cond", see below).
 
-        Why two stages and not one per decoder layer (round 2's plan: 3 of 4 layers in stage 1, `S2SVC_AAS_DP_H=1`): the duration
+        Why two stages and not one per decoder layer (round 2's plan: 3 of 4 layers in stage 1, `dp_decoder_stages = 1`): the duration
         branch's backward pass is ~350 small dependent launches that take 4.4 ms beside the decoder's GEMMs, a decoder layer's
         backward pass 1.2 ms -- with fewer than four layers beside it the branch is the critical path of the stage (measured on
         one MI355X, `bench.py --split-backward --stage-times`: stage graphs 10.97 + 2.04 ms with h = 0, 10.80 + 1.20 + 2.04 with
@@ -186,13 +186,13 @@ class AASVC(nn.Module):
         side = [self.alignment_module, self.duration_predictor]
         if hasattr(self, "duration_predictor_projection"):
             side.append(self.duration_predictor_projection)
-        h = int(os.environ.get("S2SVC_AAS_DP_H", "0"))        # decoder layers that get a stage of their own (tuning aid)
+        h = int(getattr(self, "dp_decoder_stages", 0))        # decoder layers that get a stage of their own (trainer config `dp_decoder_stages`)
         h = max(0, min(h, len(dec) - 1))
         last = {"root": "cut:encoder_out", "modules": [self.encoder]}
         sdp = self.duration_predictor
         # 0: no cut, 1: the network behind x, 2: both conditioning networks.  bench.py --workload aasvc --split-backward, one box, ms per
         # staged step (stage graphs): 12.28 (9.49 + 1.45) / 12.00 (9.18 + 1.73) / 11.76-11.85 (8.87 + 1.91) against 11.46 for the one-graph step
-        sdp_cut = os.environ.get("S2SVC_AAS_DP_SDP_CUT", "2")
+        sdp_cut = "2"
         if self.duration_predictor_type == "stochastic" and sdp_cut != "0":
             # Round 4: the duration branch's backward pass (~ 4 ms of small launches on the auxiliary stream) had become the critical path
             # of stage 1 once the decoder's backward pass beside it got shorter; its last part -- the two conditioning networks

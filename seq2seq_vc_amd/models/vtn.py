@@ -5,7 +5,6 @@ Drop-in for `seq2seq_vc.models.VTN` (reference models/vtn.py): same constructor 
 state_dict keys.  All arithmetic runs in the HIP kernels behind seq2seq_vc_amd.ops.functional.
 """
 import logging
-import os
 
 import torch
 from torch import nn
@@ -15,8 +14,6 @@ from ..ops import functional as Fn
 from ..ops import kernels as K
 
 
-_HEAD_START = os.environ.get("S2SVC_NO_HEAD_START", "0") != "1"     # A/B switch: the decoder's head on the auxiliary stream
-_PROB_BRANCH = os.environ.get("S2SVC_PROB_BRANCH", "1") != "0"      # A/B switch: the stop-token projection on the auxiliary stream
 
 
 class _ARSeq2Seq(nn.Module):
@@ -45,37 +42,25 @@ class _ARSeq2Seq(nn.Module):
         A cut costs ~0.09 ms of the step (graph boundary + lost overlap; `bench.py --force-dist --stage-times`: stage graphs
         2.83 + 0.32 + 0.32 + 0.59 ms with the layer stack cut in the middle as well -- round 2's plan -- against 3.78 ms for the
         uncut backward pass), more than the middle cut saves: the 42.6 MB of the layer stack travel behind the input layer's
-        0.6 ms from 75 GB/s of all-reduce bandwidth on.  `S2SVC_VTN_DP_SPLIT=1` restores the middle cut.  One loss key: "loss"."""
+        0.6 ms from 75 GB/s of all-reduce bandwidth on.  One loss key: "loss"."""
         dec_side = [m for m in (self.decoder, self.feat_out, self.prob_out, self.postnet) if m is not None]
         enc = self.encoder
         layers = list(enc.encoders)
         tail = [m for m in (getattr(enc, "after_norm", None),) if m is not None]
         embed = [m for n, m in enc.named_children() if n not in ("encoders", "after_norm")]
-        h = len(layers) // 2
-        head_stage = {}
-        if _HEAD_START and os.environ.get("S2SVC_VTN_DP_HEAD_CUT", "1") != "0":
-            # Round 4: the decoder's head (input layer + positional encoding + the first layer's self-attention block: what ran on the
-            # auxiliary stream beside the encoder) is cut off the decoder's stage: its backward pass runs in the ENCODER's stage, on the
-            # auxiliary stream beside the layer stack's, as it does in the one-graph step; its parameters travel with that bucket.
-            d0 = self.decoder.decoders[0]
-            hm = [self.decoder.embed, d0.self_attn, d0.norm1] + ([d0.norm2] if d0.normalize_before else [])
-            hp = {id(p) for m in hm for p in m.parameters()}
-            dec_side = [p for m in dec_side for p in m.parameters() if id(p) not in hp]
-            head_stage = {"branch_root": "cut:decoder_head", "head": hm}
-        if h == 0 or not embed:
+        # Round 4: the decoder's head (input layer + positional encoding + the first layer's self-attention block: what runs on the
+        # auxiliary stream beside the encoder) is cut off the decoder's stage: its backward pass runs in the ENCODER's stage, on the
+        # auxiliary stream beside the layer stack's, as it does in the one-graph step; its parameters travel with that bucket.
+        d0 = self.decoder.decoders[0]
+        hm = [self.decoder.embed, d0.self_attn, d0.norm1] + ([d0.norm2] if d0.normalize_before else [])
+        hp = {id(p) for m in hm for p in m.parameters()}
+        dec_side = [p for m in dec_side for p in m.parameters() if id(p) not in hp]
+        if len(layers) < 2 or not embed:
             return [{"root": "loss:loss", "modules": dec_side},
-                    dict({"root": "cut:encoder_out", "modules": [enc] + head_stage.get("head", [])},
-                         **({"branch_root": head_stage["branch_root"]} if head_stage else {}))]
+                    {"root": "cut:encoder_out", "branch_root": "cut:decoder_head", "modules": [enc] + hm}]
         enc.cut_name = "encoder"            # names the cut points inside Encoder.forward / run_stack
-        if os.environ.get("S2SVC_VTN_DP_SPLIT", "0") == "1":
-            return [{"root": "loss:loss", "modules": dec_side},
-                    dict({"root": "cut:encoder_out", "modules": layers[h:] + tail + head_stage.get("head", [])},
-                         **({"branch_root": head_stage["branch_root"]} if head_stage else {})),
-                    {"root": f"cut:encoder.{h}", "modules": layers[:h]},
-                    {"root": "cut:encoder.0", "modules": embed}]
         return [{"root": "loss:loss", "modules": dec_side},
-                dict({"root": "cut:encoder_out", "modules": layers + tail + head_stage.get("head", [])},
-                     **({"branch_root": head_stage["branch_root"]} if head_stage else {})),
+                {"root": "cut:encoder_out", "branch_root": "cut:decoder_head", "modules": layers + tail + hm},
                 {"root": "cut:encoder.0", "modules": embed}]
 
     def _decoder_head(self, ys, olens, labels=None):
@@ -99,7 +84,7 @@ class _ARSeq2Seq(nn.Module):
             return torch.cat([ys_in.new_zeros((ys_in.shape[0], 1, ys_in.shape[2])), ys_in[:, :-1]], dim=1)
 
         head, stop = None, None
-        if _HEAD_START and self.training and ys.is_cuda and torch.is_grad_enabled():
+        if self.training and ys.is_cuda and torch.is_grad_enabled():
             def run():
                 y0 = shifted()
                 lab = self._stop_labels(labels, olens_h)[1] if labels is not None else None
@@ -148,7 +133,7 @@ class _ARSeq2Seq(nn.Module):
         post_lens = None
         if olens_in_h.cap is not None and self.postnet is not None:
             post_lens = olens_in_h if r == 1 else olens_in_h.map(lambda v: v * r)
-        if _PROB_BRANCH and self.training and zs.is_cuda and torch.is_grad_enabled() and self.postnet is not None:
+        if self.training and zs.is_cuda and torch.is_grad_enabled() and self.postnet is not None:
             # the stop-token projection (384 -> r columns: a GEMM with one output column forward, a rank-1 product backward, both on
             # slow general kernels) beside the Postnet instead of in front of it: the auxiliary stream is idle here, and autograd runs
             # its backward node there too -- beside the Postnet's backward pass instead of between it and feat_out's

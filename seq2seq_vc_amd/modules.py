@@ -409,9 +409,6 @@ class LegacyRelPositionMultiHeadedAttention(RelPositionMultiHeadedAttention):
 # ------------------------------------------------------------------------------------------------
 # feed-forward
 # ------------------------------------------------------------------------------------------------
-_FFN_SWISH_FUSED = os.environ.get("S2SVC_FFN_SWISH_FUSED", "1") != "0"      # tuning aid: 0 = linear / act_dropout / linear
-
-
 class PositionwiseFeedForward(nn.Module):
     """w_2(dropout(act(w_1 x)))  (positionwise_feed_forward.py:12-32); act 'relu' or 'swish'."""
 
@@ -425,7 +422,7 @@ class PositionwiseFeedForward(nn.Module):
     def forward(self, x, passthrough=False):
         """passthrough=True -> (y, alias of x) for a post-LN residual (Fn.linear)."""
         p = self.dropout_rate if self.training else 0.0
-        if self.activation == "relu" or (self.activation == "swish" and _FFN_SWISH_FUSED):   # activation + dropout (and their derivatives) in the GEMM epilogues
+        if self.activation in ("relu", "swish"):   # activation + dropout (and their derivatives) in the GEMM epilogues
             return Fn.ffn_act(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias, self.activation, p, passthrough)
         xp = None
         if passthrough:
@@ -464,13 +461,10 @@ class LayerNorm(nn.LayerNorm):
         return Fn.layer_norm(x, self.weight, self.bias, self.eps)
 
 
-_PASS = os.environ.get("S2SVC_NO_PASSTHROUGH", "0") != "1"     # tuning aid: residual gradients through autograd's add
-
-
 def _sub_pass(sub, x, *args, **kw):
     """sublayer(x, ...) -> (output, x for the residual).  MultiHeadedAttention / PositionwiseFeedForward hand back a
     pass-through alias of x (their first GEMM's backward absorbs the residual gradient); other sublayers get x itself."""
-    if (_PASS and type(sub) in (MultiHeadedAttention, PositionwiseFeedForward) and torch.is_grad_enabled() and x.requires_grad):
+    if (type(sub) in (MultiHeadedAttention, PositionwiseFeedForward) and torch.is_grad_enabled() and x.requires_grad):
         return sub(x, *args, passthrough=True, **kw)
     return sub(x, *args, **kw), x
 

@@ -83,13 +83,10 @@ def _emit_vgrad(param, value):
     return value.view(param.shape)
 
 
-_PERMUTE_FUSED = os.environ.get("S2SVC_PERMUTE_FUSED", "1") != "0"      # A/B switch
-
-
 def _emit_permuted(param, dwp, n, A, Bn):
     """The weight gradient `dwp` (n, A, Bn) as its GEMM left it -> the parameter's (n, Bn, A) layout, accumulated into the flat-gradient
     slot if the parameter has one: ONE launch through LDS (K.permute_inner) instead of an element-wise gather + an axpby."""
-    if _PERMUTE_FUSED and K.permute_inner_ok(A, Bn):
+    if K.permute_inner_ok(A, Bn):
         slot = getattr(param, "_s2s_grad", None)
         if slot is not None:
             K.permute_inner(dwp, n, A, Bn, out=slot, accumulate=True)
@@ -106,7 +103,6 @@ def _emit_permuted(param, dwp, n, A, Bn):
 # pass runs (distributed.OverlappedBackward); each piece can also be captured as its own hipGraph with the collectives
 # issued between the replays.  Values and gradients are exactly those of the uncut graph.
 # ------------------------------------------------------------------------------------------------
-_RETAIN = os.environ.get("S2SVC_CUT_RETAIN", "0") == "1"      # diagnostic: keep the autograd buffers of finished stages alive
 
 
 class GradCuts:
@@ -136,7 +132,7 @@ class GradCuts:
             return
         pairs = [(o, i.grad) for o, i in zip(outer, inner) if o is not None and o.requires_grad and i is not o and i.grad is not None]
         if pairs:
-            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs], retain_graph=_RETAIN)
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs], retain_graph=False)
 
     def clear(self):
         self.points.clear()
@@ -181,10 +177,9 @@ class _Side:
     origins = []     # the stream each queued closure was issued from
     inline = False   # no side streams, but batched (see enable_side_streams)
     inline_q = {}    # stream handle -> (stream, [closures])
-    batch = int(os.environ.get("S2SVC_SIDE_BATCH", "16"))
+    batch = 16
     grouped = []     # weight-gradient GEMM descriptors of the batch being flushed
     grouped_cr = []  # column reductions of the batch being flushed
-    group_wgrad = os.environ.get("S2SVC_NO_GROUPED_WGRAD", "0") != "1"
 
 
 def _taken_streams():
@@ -210,12 +205,8 @@ def distinct_stream(taken=None):
     raise RuntimeError("no distinct stream left in torch's stream pool")
 
 
-_SIDE_BATCH_ENV = os.environ.get("S2SVC_SIDE_BATCH")
-_JOIN_UNCAPPED = os.environ.get("S2SVC_JOIN_UNCAPPED", "1") != "0"       # A/B aid
-
-
 def enable_side_streams(n=4, inline_batches=False, batch=None):
-    """batch: closures per gradient batch (default: 16 forked / 64 inline; S2SVC_SIDE_BATCH overrides).  Round 4 re-measured both with
+    """batch: closures per gradient batch (default: 16 forked / 64 inline).  Round 4 re-measured both with
     the 8-wave weight-gradient kernel that takes 40 problems per launch: VTN 12 -> 16: 3.95 -> 3.86 ms, AAS-VC 12 -> 48 ... 160:
     11.85 -> 11.6-11.7 ms (larger grids, fewer ragged last rounds; the operands stay alive a little longer).
     n > 0: parameter-gradient work is forked to n side streams (small, latency-bound models: VTN).
@@ -223,10 +214,10 @@ def enable_side_streams(n=4, inline_batches=False, batch=None):
     that the dense weight-gradient GEMMs of a batch become one grouped launch -- for models whose kernels fill the chip
     anyway (AAS-VC: d = 1536) the forks cost more than the overlap gives (19.3 vs 20.9 ms/step).  Both need side_join()
     between backward and the optimiser step; n == 0 without inline_batches runs everything immediately."""
-    K.set_wgrad_cap(int(os.environ.get("S2SVC_W8_FORK_WGS", "64")) if n > 0 else 0)
+    K.set_wgrad_cap(64 if n > 0 else 0)
     _Side.enabled = n > 0
     _Side.inline = (n == 0) and inline_batches
-    _Side.batch = int(_SIDE_BATCH_ENV) if _SIDE_BATCH_ENV else int(batch) if batch else (64 if _Side.inline else 16)
+    _Side.batch = int(batch) if batch else (64 if _Side.inline else 16)
     old, others = _Side.streams, _taken_streams() - {st.cuda_stream for st in _Side.streams}
     if n > 0 and len(old) == n and len({st.cuda_stream for st in old}) == n and not ({st.cuda_stream for st in old} & others):
         pass                                     # keep the ones we have: every new Stream object eats a slot of torch's pool
@@ -272,10 +263,6 @@ def _run_batch(closures):
     """Run a batch of gradient closures on the current stream: their dense weight-gradient GEMMs become ONE grouped launch
     (no split-K, no reduction passes), their column reductions into gradient slots (LayerNorm / BatchNorm / bias vectors)
     two grouped launches; everything else they launch (conv weight gradients, ...) runs as issued."""
-    if not _Side.group_wgrad:
-        for fn in closures:
-            fn()
-        return
     with K.record_grouped(_Side.grouped), K.record_colreduce(_Side.grouped_cr):
         for fn in closures:
             fn()
@@ -321,6 +308,9 @@ def _side_flush():
 # the chain.  torch's autograd engine runs every backward node on the stream of its forward op, so the backward pass of
 # the branch overlaps as well; under hipGraph capture fork and join are two graph edges.
 # ------------------------------------------------------------------------------------------------
+_NO_BRANCH = os.environ.get("S2SVC_NO_BRANCH", "0") == "1"      # diagnostic: branches run in line on the issuing stream
+
+
 class _Branch:
     stream = None
     active = False
@@ -337,7 +327,7 @@ def branch_run(fn, uses=()):
     under the reader.  Eager launches hide this (the reader was launched first and the GPU keeps up); in a captured graph
     only dependencies order the two streams (seen as wrong duration-predictor gradients in the AAS-VC stage graphs: the
     alignment search's durations `ds`, saved by the flow's backward pass, held another tensor by the time it read them)."""
-    if not torch.cuda.is_available() or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
+    if not torch.cuda.is_available() or _NO_BRANCH:
         return fn()
     main = torch.cuda.current_stream()
     if _Branch.stream is None or _Branch.stream.cuda_stream == main.cuda_stream:
@@ -372,7 +362,7 @@ def branch_backward(loss, fork_event, retain_graph=False, scale=1.0):
     the calling stream goes there while it is still empty, and the other roots then queue beside the branch.  (A root processed
     on the calling stream after other work puts its first nodes -- and with them the whole branch -- behind that work; one
     processed there before it stalls the caller at the first node that consumes a result of the branch.)"""
-    if _Branch.stream is None or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
+    if _Branch.stream is None or _NO_BRANCH:
         root_backward(loss, scale, retain_graph)
         return
     _Branch.stream.wait_event(fork_event)
@@ -384,7 +374,7 @@ def branch_backward(loss, fork_event, retain_graph=False, scale=1.0):
 def branch_resume(cuts, name, fork_event):
     """cuts.resume(name) rooted on the auxiliary stream (see branch_backward): the part of a branch below a gradient cut, run one
     stage after the part above it."""
-    if _Branch.stream is None or os.environ.get("S2SVC_NO_BRANCH", "0") == "1":
+    if _Branch.stream is None or _NO_BRANCH:
         cuts.resume(name)
         return
     _Branch.stream.wait_event(fork_event)
@@ -395,7 +385,7 @@ def branch_resume(cuts, name, fork_event):
 
 def branch_wait():
     """The current stream waits for what has been queued on the auxiliary stream (end of a stage that used branch_backward)."""
-    if _Branch.stream is not None and os.environ.get("S2SVC_NO_BRANCH", "0") != "1":
+    if _Branch.stream is not None and not _NO_BRANCH:
         torch.cuda.current_stream().wait_stream(_Branch.stream)
 
 
@@ -409,17 +399,14 @@ def side_join():
             if st.cuda_stream != main.cuda_stream:
                 main.wait_stream(st)
     if _Side.enabled:
-        if _JOIN_UNCAPPED:
-            # the batch flushed HERE runs behind the end of the data-gradient chain: there is nothing left to protect from a
-            # chip-filling weight-gradient grid, so its launches are not capped (ops.kernels.set_wgrad_cap)
-            cap = K.get_wgrad_cap()
-            K.set_wgrad_cap(0)
-            try:
-                _side_flush()
-            finally:
-                K.set_wgrad_cap(cap)
-        else:
+        # the batch flushed HERE runs behind the end of the data-gradient chain: there is nothing left to protect from a
+        # chip-filling weight-gradient grid, so its launches are not capped (ops.kernels.set_wgrad_cap)
+        cap = K.get_wgrad_cap()
+        K.set_wgrad_cap(0)
+        try:
             _side_flush()
+        finally:
+            K.set_wgrad_cap(cap)
         main = torch.cuda.current_stream()
         for st in _Side.streams:
             main.wait_stream(st)
@@ -471,7 +458,6 @@ def _reduce_to(p_sum, p_dot, mode, dy, x=None, mean=None, rstd=None):
 # ================================================================================================
 # Linear (+bias, +activation)          reference: torch.nn.Linear call sites of the hot path
 # ================================================================================================
-_PAD_ODD_N = os.environ.get("S2SVC_PAD_ODD_N", "1") != "0"      # A/B switch: see _Linear.backward
 
 
 class _Linear(Function):
@@ -511,7 +497,7 @@ class _Linear(Function):
         if ctx.act:
             dy2 = K.act_dropout_bwd(dy2, y, act=ctx.act)
         ldy, zp, dy_rows = N, False, dy2
-        if _PAD_ODD_N and dtype == torch.float32 and N % 4 and dy2.is_cuda:
+        if dtype == torch.float32 and N % 4 and dy2.is_cuda:
             # rows of N fp32 values with N % 4 != 0 (the 29 spline parameters of a ConvFlow) keep both gradient GEMMs on the
             # element-wise fallback kernel (19 + 37 us per flow): a zero-padded copy with rows of a whole number of 16-byte vectors
             # puts them on the vectorised kernels (the pad columns contribute zeros to the reductions and are never stored)
@@ -1119,11 +1105,8 @@ class _SplitCols(Function):
         return torch.cat(parts, dim=-1), None, None
 
 
-_GRAD_SINK = os.environ.get("S2SVC_GRAD_SINK", "1") != "0"       # A/B aid
-
-
 def split_cols(x, n):
-    sink = _GradSink(tuple(x.shape), x.dtype, x.device, x.shape[-1] // n) if (_GRAD_SINK and x.requires_grad and x.is_contiguous()) else None
+    sink = _GradSink(tuple(x.shape), x.dtype, x.device, x.shape[-1] // n) if (x.requires_grad and x.is_contiguous()) else None
     parts = _SplitCols.apply(x, n, sink)
     if sink is not None:
         for i, t in enumerate(parts):
@@ -1287,16 +1270,8 @@ class _RelAttnPacked(Function):
         dqkv = torch.empty_like(qkv)
         dqu = torch.empty((B, T, D), dtype=dtype, device=qu.device)
         gkc, grc, keep = [], [], []      # the five batched products behind the softmax backward: two grids (K.launch_group_batched)
-        if ctx.fused_rel and KAT.rel_bwd_enabled():
-            dctx = _c(dctx) if dctx is not None else torch.zeros((B, T, D), dtype=dtype, device=qu.device)
-            ds, dbd = KAT.rel_bwd(dctx, vv, attn, _pad_like(dattn, attn), H, scale, p, seed, Lq)
-            _into(dqkv[..., 2 * D:], _pop(pm, T, H, K.RC), _bop(dctx, dk, K.RC), T, dk, T, dk, dtype, B, H, group=grc)     # dV = Pm^T dctx
-            _into(dqu, _pop(ds, T, H), _bop(k, dk, K.RC), T, dk, T, dk, dtype, B, H, group=gkc)                             # dQu = dS K
-            _into(dqkv[..., D:2 * D], _pop(ds, T, H, K.RC), _bop(qu, dk, K.RC), T, dk, T, dk, dtype, B, H, group=grc)       # dK = dS^T Qu
-            keep += [dctx, ds]
-        else:
-            _, _, _, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, vv, H, scale, p, seed, Lp=L, rel_mode=rel_mode, ldb=Lq,
-                                            outs=(dqu, dqkv[..., D:2 * D], dqkv[..., 2 * D:]), groups=(gkc, grc, keep))
+        _, _, _, dbd = _attn_common_bwd(dctx, dattn, attn, pm, qu, k, vv, H, scale, p, seed, Lp=L, rel_mode=rel_mode, ldb=Lq,
+                                        outs=(dqu, dqkv[..., D:2 * D], dqkv[..., 2 * D:]), groups=(gkc, grc, keep))
         dqv = torch.empty((B, T, D), dtype=dtype, device=qu.device)
         K.gemm(K.operand(dbd, Lq, bs0=H * T * Lq, bs1=T * Lq, zero_padded=True), K.operand(pos, D, layout=K.RC, bs0=0, bs1=dk), T, dk,
                L, dqv, in_dtype=dtype, nb0=B, nb1=H, ldc=D, cbs=(T * D, dk), group=gkc)
@@ -1344,7 +1319,6 @@ def add_head_bias(q, u, v):
 # Conv1d (stride 1, 'same' padding, channel-last activations) as an implicit GEMM
 # reference: Postnet / AlignmentModule / DurationPredictor / FFN Conv1d call sites
 # ================================================================================================
-_CONV1D_WGRAD_W8 = os.environ.get("S2SVC_CONV1D_WGRAD_W8", "1") != "0"      # A/B switch
 
 
 class _Conv1d(Function):
@@ -1391,7 +1365,7 @@ class _Conv1d(Function):
                 # with the implicit im2col B operand (csrc/gemm_8ph.hip "w8_conv" kind 1); everything else as before
                 K.gemm(K.operand(dy, Cout, layout=K.RC), K.operand(x, Cin, layout=K.RC, mode=K.CONV1D, C=Cin, T=T, pad=pad),
                        Cout, ks * Cin, B * T, dwp, in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc,
-                       wgrad=_CONV1D_WGRAD_W8)
+                       wgrad=True)
                 return _emit_permuted(weight, dwp, Cout, ks, Cin), dbv
             if _slotted(weight, bias):
                 _side_run(work, keep=(dy, x))
@@ -1436,12 +1410,9 @@ def conv1d(x, weight, bias=None, act=None, vlens=None):
 # ================================================================================================
 # Conv2d 3x3 stride 2 (+ReLU) on NHWC activations         reference: subsampling.py:58-63
 # ================================================================================================
-_TCONV = os.environ.get("S2SVC_NO_TCONV", "0") != "1"      # tuning aid: fall back to dcols GEMM + col2im
-_TCONV_GROUP = os.environ.get("S2SVC_TCONV_GROUP", "0") == "1"     # one grid for the four parity classes: measured equal
 #                                                                    (189 vs 190 us), so the plain launches stay the default
 
 
-_CONV_WGRAD_W8 = os.environ.get("S2SVC_CONV_WGRAD_W8", "1") != "0"      # A/B switch
 
 
 class _Conv2dS2(Function):
@@ -1483,7 +1454,7 @@ class _Conv2dS2(Function):
                 # csrc/gemm_8ph.hip "w8_conv"), otherwise the 4-wave split-K kernel
                 K.gemm(K.operand(dy, O, layout=K.RC),
                        K.operand(x, C, layout=K.RC, mode=K.CONV2D_S2, C=C, T1=T1, F1=F1, T2=T2, F2=F2), O, 9 * C, M2, dwp,
-                       in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc, wgrad=_CONV_WGRAD_W8)
+                       in_dtype=dtype, splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc, wgrad=True)
                 return _emit_permuted(weight, dwp, O, 9, C), dbv
             if _slotted(weight, bias):
                 # queued AND forked before the data-gradient GEMM below: this is the last big layer of the backward pass,
@@ -1496,13 +1467,12 @@ class _Conv2dS2(Function):
             else:
                 dw, db = work()
         dx = None
-        if ctx.needs_input_grad[0] and dtype == torch.bfloat16 and O % 8 == 0 and O >= 64 and C % 8 == 0 and _TCONV:
+        if ctx.needs_input_grad[0] and dtype == torch.bfloat16 and O % 8 == 0 and O >= 64 and C % 8 == 0:
             # transposed convolution as four implicit GEMMs, one per parity class (t1 % 2, f1 % 2) of input pixels: each
             # gathers its 4 / 2 / 2 / 1 taps of dY straight from HBM and stores into its pixels of dX (no dcols, no col2im)
             wts = K.tconv2d_weights(weight.detach())
             dx = torch.empty((B, T1, F1, C), dtype=dtype, device=x.device)
             mask = x if ctx.input_is_relu else None     # x = relu(u): the GEMMs hand back dL/du (mask rows follow the c_map)
-            descs = [] if (_TCONV_GROUP and mask is None) else None     # (opt-in) one grid for the four classes
             for cls, wt in enumerate(wts):
                 pt, pf = cls >> 1, cls & 1
                 Tc, Fc = (T1 - pt + 1) // 2, (F1 - pf + 1) // 2
@@ -1510,9 +1480,7 @@ class _Conv2dS2(Function):
                     continue
                 Kc = wt.shape[1]
                 K.gemm(K.operand(dy, O, mode=K.TCONV2D_S2, C=O, T1=Tc, F1=Fc, T2=T2, F2=F2, pad=cls), K.operand(wt, Kc),
-                       B * Tc * Fc, C, Kc, dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf), group=descs, emask=mask)
-            if descs:
-                K.launch_group(descs)
+                       B * Tc * Fc, C, Kc, dx, in_dtype=dtype, c_map=(T1, F1, Tc, Fc, pt, pf), emask=mask)
         elif ctx.needs_input_grad[0]:
             dcols = torch.empty((M2, 9 * C), dtype=dtype, device=x.device)
             K.gemm(K.operand(dy, O), K.operand(wp, 9 * C, layout=K.RC), M2, 9 * C, O, dcols, in_dtype=dtype)
@@ -1569,8 +1537,6 @@ def conv_in1_relu(x, weight, bias, grad_premasked=False):
     return _ConvIn1.apply(x, weight, bias, grad_premasked)
 
 
-_FC_DGRAD_T = os.environ.get("S2SVC_FC_DGRAD_T", "1") != "0"       # A/B switches (profiles/AB_LOG.md, round 5 part 3)
-_FC_WGRAD_W8 = os.environ.get("S2SVC_FC_WGRAD_W8", "1") != "0"
 
 
 class _LinearPermuted(Function):
@@ -1606,7 +1572,7 @@ class _LinearPermuted(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, Kd), dtype=dtype, device=x.device)
             mask = x.view(M, Kd) if ctx.input_is_relu else None              # x = relu(u): hand back dL/du
-            if _FC_DGRAD_T and dtype == torch.bfloat16:
+            if dtype == torch.bfloat16:
                 # the permuted weight once more, TRANSPOSED ((f, c) rows of D values: a cached copy the optimiser keeps fresh):
                 # both operands K-contiguous, so the 2016 x 7296 x 384 product runs on the 8-wave kernel instead of the 4-wave
                 # kernel's transposing fragment reads (65 -> ~25 us at the end of VTN's backward chain)
@@ -1622,7 +1588,7 @@ class _LinearPermuted(Function):
                 rs, racc, dbv = _bias_sink(bias, D)
                 tile, sk = K.plan_gemm(D, Kd, M)
                 K.gemm(K.operand(dy, D, layout=K.RC), K.operand(x, Kd, layout=K.RC), D, Kd, M, dwp, in_dtype=dtype,
-                       splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc, wgrad=_FC_WGRAD_W8)
+                       splitk=sk, tile=tile, a_rowsum=rs, a_rowsum_accumulate=racc, wgrad=True)
                 return _emit_permuted(weight, dwp, D, Fd, C), dbv
             if _slotted(weight, bias):
                 _side_run(work, keep=(dy, x))

@@ -18,7 +18,7 @@ from . import kernels_sdp as KS
 from .functional import _c, _emit_vgrad, _reduce_to, _side_run, _slotted
 
 
-_QUEUE_LN = __import__("os").environ.get("S2SVC_SDP_UNGROUPED", "0") != "1"      # A/B switch (also sdp.py: residual pass-through)
+_QUEUE_LN = True        # LayerNorm parameter gradients of the duration predictor join the grouped column reductions of their batch
 
 
 class Shared:
@@ -112,7 +112,6 @@ def ln_act(x, gamma, beta, eps, act, res=None, lens=None, T=0, p=0.0):
     return _LnAct.apply(x, gamma, beta, eps, act, res, lens, T, p)
 
 
-_FUSE_DW_LN = __import__("os").environ.get("S2SVC_SDP_DW_LN", "1") != "0"       # A/B switch: dwconv + LN + act as one forward launch
 
 
 class _DwLnAct(Function):
@@ -153,7 +152,7 @@ class _DwLnAct(Function):
 
 
 def dw_ln_act_ok(x, dw_w):
-    return (_FUSE_DW_LN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] <= 512 and dw_w.shape[-1] % 2 == 1
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] <= 512 and dw_w.shape[-1] % 2 == 1
             and dw_w.dtype == torch.float32)
 
 

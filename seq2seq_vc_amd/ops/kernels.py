@@ -246,10 +246,6 @@ def operand(t, ld, layout=KC, mode=DENSE, C=0, T=0, pad=0, T1=0, F1=0, T2=0, F2=
     return o
 
 
-_MAX_SPLITK = int(os.environ["S2SVC_MAX_SPLITK"]) if "S2SVC_MAX_SPLITK" in os.environ else None   # tuning aid
-
-
-_F32_T32 = os.environ.get("S2SVC_GEMM_F32_T32", "1") != "0"
 
 
 def plan_gemm(M, N, K, nbatch=1, allow_split=True, dtype=None):
@@ -259,9 +255,7 @@ def plan_gemm(M, N, K, nbatch=1, allow_split=True, dtype=None):
     fp32 problems with few output tiles (the duration predictor's 384 x 384 weight gradients over 1024 rows): 32 x 32 tiles
     (gemm_fast_kernel<float, 32, 32, 128>: the fp32 MFMA makes a 64 x 64 workgroup matrix-pipe bound) and only as much split-K
     as it takes to reach ~100 workgroups -- 144 unsplit workgroups instead of 36 x 4 + a reduction launch."""
-    if _MAX_SPLITK is not None:
-        allow_split = allow_split and _MAX_SPLITK > 1
-    if dtype == torch.float32 and _F32_T32 and nbatch == 1 and K >= 256 and ((M + 63) // 64) * ((N + 63) // 64) < 64:
+    if dtype == torch.float32 and nbatch == 1 and K >= 256 and ((M + 63) // 64) * ((N + 63) // 64) < 64:
         tiles32, sk = ((M + 31) // 32) * ((N + 31) // 32), 1
         while allow_split and tiles32 * sk < 96 and K // (2 * sk) >= 256 and sk < 8:
             sk *= 2
@@ -445,9 +439,9 @@ def gemm(A, B, M, N, K, out, *, in_dtype, bias=None, act=None, res=None, ldr=Non
 # <= 11 problems (s2svc_gemm_grouped).  The caller keeps the operand tensors alive until the flush.
 # ----------------------------------------------------------------------------------------------
 _RECORDER = None            # list of GemmDesc while recording
-_GROUP_TILE = int(os.environ.get("S2SVC_GROUP_TILE", "64"))      # output tile edge of the grouped kernel (64 / 128)
-_GROUP_MAX_TILES = int(os.environ.get("S2SVC_GROUP_MAX_TILES", "200"))
-_GROUP_BIG_TILES = int(os.environ.get("S2SVC_GROUP_BIG_TILES", "64"))
+_GROUP_TILE = 64             # output tile edge of the grouped kernel for small outputs
+_GROUP_MAX_TILES = 200
+_GROUP_BIG_TILES = 64
 
 
 class record_grouped:
@@ -544,15 +538,12 @@ def launch_wgrad_group(descs, capped=True):
     _lib.check(L.s2svc_gemm_wgrad_grouped(ctypes.addressof(arr), len(descs), ptr(ws), stream()), "s2svc_gemm_wgrad_grouped")
 
 
-_GROUP_BATCHED = os.environ.get("S2SVC_ATTN_GROUP", "1") != "0"      # A/B aid
-
-
 def launch_group_batched(descs):
     """The listed BATCHED problems (K.gemm(..., group=descs)) of one operand-kind pair as one grid (s2svc_gemm_grouped_batched:
     the batched products of an attention backward pass); one by one if the library does not take them as a group."""
     if not descs:
         return
-    if len(descs) > 1 and _GROUP_BATCHED:
+    if len(descs) > 1:
         arr = (_lib.GemmDesc * len(descs))(*descs)
         rc = _lib.lib().s2svc_gemm_grouped_batched(ctypes.addressof(arr), len(descs), stream())
         if rc == 0:
@@ -1151,7 +1142,7 @@ def conv_in1_fwd(x, w, bias):
     return y
 
 
-_CI_CHUNKS = int(os.environ.get("S2SVC_CONV_IN1_CHUNKS", "512"))       # tuning aid
+_CI_CHUNKS = 512
 
 
 def conv_in1_wgrad(x, dy, dw, db, accumulate, y=None):

@@ -6,7 +6,7 @@ import torch
 from .. import _lib
 from .kernels import _DT, ptr, stream
 
-_DISABLED = os.environ.get("S2SVC_NO_FUSED_ATTN", "0") == "1"     # A/B switch
+_DISABLED = False         # tests flip it: fused vs separate attention kernels
 
 
 def _strided_ok(t):
@@ -56,18 +56,10 @@ def fused_bwd(q, k, v, dout, attn, dattn, H, scale, p, seed, dq, dk_out, dv):
 # ----------------------------------------------------------------------------------------------
 # relative-position self-attention, T <= 256 (csrc/relattn.hip)
 # ----------------------------------------------------------------------------------------------
-_NO_REL = os.environ.get("S2SVC_NO_RELATTN", "0") == "1"           # A/B switch
-
-
-def rel_bwd_enabled():
-    """The fused backward kernel (dP + softmax' + dbd in one launch) is correct and tested, but measured SLOWER than the GEMM +
-    zero fill + softmax-backward kernels it replaces (30 / 46 vs 26 / 33 us at d_k = 192 / 768: its operand loop is bound by
-    global-load latency at one workgroup per CU, the GEMM streams through LDS-DMA): opt-in."""
-    return os.environ.get("S2SVC_RELATTN_BWD", "0") == "1"
 
 
 def rel_supported(q, k, v, pos, H, rel_mode):
-    if _NO_REL or os.environ.get("S2SVC_NO_RELATTN", "0") == "1" or q.dtype != torch.bfloat16:
+    if os.environ.get("S2SVC_NO_RELATTN", "0") == "1" or q.dtype != torch.bfloat16:        # (the switch: tests compare with the separate kernels)
         return False
     T, dk = q.shape[1], q.shape[-1] // H
     if not _lib.lib().s2svc_relattn_supported(_DT[q.dtype], T, dk, rel_mode) or pos.shape[1] != 2 * T - 1:
@@ -88,15 +80,3 @@ def rel_fwd(q, k, pos, u, v, klen, H, scale, p, seed):
                                             pos.stride(1), pos.shape[1], ptr(u), ptr(v), ptr(klen), scale, p, seed[0], seed[1],
                                             ptr(attn), ptr(pdrop), ld, ptr(qu), ptr(qv), stream()), "relattn_fwd")
     return attn, pdrop, qu, qv
-
-
-def rel_bwd(dctx, v, attn, dattn, H, scale, p, seed, Lq):
-    """-> ds (B,H,T,ld), dbd (B,H,T,Lq)  (what attn_softmax_bwd returns, without the dP tensor in between)."""
-    B, _, T, ld = attn.shape
-    dk = dctx.shape[-1] // H
-    ds = torch.empty_like(attn)
-    dbd = torch.empty((B, H, T, Lq), dtype=attn.dtype, device=attn.device)
-    _lib.check(_lib.lib().s2svc_relattn_bwd(B, H, T, dk, ptr(dctx), dctx.stride(1), dctx.stride(0), ptr(v), v.stride(1), v.stride(0),
-                                            ptr(attn), ptr(dattn), ld, scale, p, seed[0], seed[1], ptr(ds), ptr(dbd), Lq, stream()),
-               "relattn_bwd")
-    return ds, dbd

@@ -196,7 +196,7 @@ class FlatAdam:
             self.shadow.copy_(K.cast(self.flat_p, torch.bfloat16))
         self._refresh_transposed()
 
-    def _refresh_transposed(self, record_perm=False):
+    def _refresh_transposed(self):
         """Derived copies of the weights: the transposed bf16 shadow and the permuted convolution weights that the forward /
         backward passes registered (ops.kernels.gather3_cached) -- one launch each.  The permuted copies first: the forward pass
         needs them (PermRegistry.ev_perm), the transposed shadow only feeds data-gradient GEMMs."""
@@ -207,9 +207,6 @@ class FlatAdam:
             # a captured refresh updates exactly the copies registered NOW on every replay; copies that register later (first
             # evaluation in another dtype, a convolution first used later) are not in it
             reg.covered = len(reg) if reg.covered is None else min(reg.covered, len(reg))
-        if record_perm:                       # launched by begin_step on the prologue stream
-            reg.ev_perm = torch.cuda.Event()
-            reg.ev_perm.record()
         if self.shadow_t is not None:
             K.transpose_tiles(self.t_tiles, self.shadow, self.shadow_t)
 
@@ -217,29 +214,10 @@ class FlatAdam:
     # After an optimiser step three memory-bound passes stand between it and the next backward pass: the permuted convolution
     # weights (needed by the forward pass), the transposed bf16 shadow (data-gradient GEMMs) and the zero-fill of the flat
     # gradient buffer (weight-gradient kernels accumulate): 136 + 144 + 80 us of a 13 ms AAS-VC step, 32 + 27 + 18 us of a
-    # 4.0 ms VTN step when they run in line.  begin_step() -- first call of a training step -- is where the zero-fill happens;
-    # with S2SVC_PROLOGUE_OVERLAP=1 step() only marks the copies as due and begin_step() launches all three on a prologue
-    # stream beside the forward pass; consumers of a copy wait for its event (ops.kernels.PermRegistry.sync, called by
-    # gather3_cached / the data-gradient operand), and join_prologue() must run on the stream that starts the backward pass
-    # before it does (Trainer._backward, distributed.OverlappedBackward, bench.py do); captured, fork and join are two edges
-    # of the step's first graph.  MEASURED (round 3, one box, bench.py --workload aasvc): 13.04 / 13.00 ms with the overlap,
-    # 12.74 ms without; VTN 4.00 vs 4.00 ms.  The three passes launch enough workgroups to fill the chip, and the forward
-    # pass is a chain of small dependent kernels that then queue for CUs behind them: what runs beside the chain is not free
-    # even when it is HBM-bound and the chain is not.  So the overlap is OFF by default and the passes stay in line (refresh at
-    # the end of step(), zero-fill in begin_step() / zero_grad()).  Round 4 made that next attempt -- only the transposed shadow and
-    # the zero-fill (both first needed by the backward pass) on the prologue stream, as CAPPED grids of 16 ... 2048 workgroups that
-    # walk the tiles: 16 / 32 / 64 workgroups cannot move 1.3 GB inside a forward pass (32.6 / 20.6 / 14.2 ms per AAS-VC step), 256 ...
-    # 2048 give 11.52-11.59 ms against 11.40 in line (VTN 3.79-3.82 vs 3.76): the passes cost the forward pass more than the
-    # in-line launches cost the step, whatever their shape -- removed again; the switch stays as the A/B aid it was.
-    overlap_prologue = os.environ.get("S2SVC_PROLOGUE_OVERLAP", "0") == "1"
-
-    def _prologue_stream(self, main):
-        from .ops import functional as Fn
-        st = getattr(self, "_pro_stream", None)
-        taken = Fn._taken_streams() | {main.cuda_stream}
-        if st is None or st.cuda_stream in taken:
-            st = self._pro_stream = Fn.distinct_stream(taken)
-        return st
+    # 4.0 ms VTN step.  They run IN LINE: the refresh at the end of step(), the zero-fill in begin_step() / zero_grad().
+    # (Rounds 3-5 carried an opt-in that ran them on a prologue stream beside the forward pass: 13.0 vs 12.74 ms per AAS-VC step,
+    # VTN equal; as capped grids of 16 ... 2048 workgroups 11.52-11.59 vs 11.40 ms -- what runs beside the forward chain is not
+    # free even when it is HBM-bound.  Removed in round 6; profiles/AB_LOG.md.)
 
     def begin_step(self, zero=True):
         """First call of a training step (before the forward pass).  zero: True = clear the gradients, None = only if a
@@ -249,27 +227,10 @@ class FlatAdam:
             zero = self._zero_due
         self._zero_due = False
         self._began = True
-        if not (self.overlap_prologue and self.flat_p.is_cuda):
-            if reg.due:
-                self._refresh_transposed()
-            if zero:
-                self._zero_gradients()
-            return
-        if not (reg.due or zero):
-            return
-        main = torch.cuda.current_stream()
-        st = self._prologue_stream(main)
-        st.wait_stream(main)
-        reg.waited = set()
-        reg.ev_all = torch.cuda.Event()
-        with torch.cuda.stream(st):
-            if reg.due:
-                self._refresh_transposed(record_perm=True)
-            else:
-                reg.ev_perm = None
-            if zero:
-                self._zero_gradients()
-            reg.ev_all.record()
+        if reg.due:
+            self._refresh_transposed()
+        if zero:
+            self._zero_gradients()
 
     def join_prologue(self):
         """The current stream (the one that starts the backward pass) waits for the prologue."""
@@ -312,25 +273,16 @@ class FlatAdam:
         return [tuple(r) for r in ranges]
 
     def zero_grad(self, set_to_none=False, defer=False):
-        """defer=True: the zero-fill joins the next begin_step() (trainers that clear the gradients AFTER the optimiser
-        step); the gradients must not be read in between."""
-        if defer and self.overlap_prologue and self.flat_p.is_cuda:
-            self._zero_due = True
-        else:
-            self._zero_due = False
-            self._zero_gradients()
+        """The zero-fill of the flat gradient buffer, in line.  `defer` is accepted from the trainers that clear the gradients AFTER
+        the optimiser step (it used to move the fill into the next begin_step(); the fill is one launch either way)."""
+        self._zero_due = False
+        self._zero_gradients()
 
     def step(self):
         self.join_prologue()                     # (no-op when the backward pass joined it, as it must)
         K.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.shadow, self.state, self.partial, self.lr,
                     self.betas, self.eps, self.grad_norm, self.warmup_steps)
-        if self.overlap_prologue and self.flat_p.is_cuda and self._began:
-            # a caller that opens its steps with begin_step(): the refresh joins the next step's prologue (or runs at the first
-            # consumer of a copy, if none follows).  Everybody else -- zero_grad / forward / backward / step, possibly captured
-            # as ONE graph that must leave the copies fresh for its next replay -- gets the refresh here, in line
-            self._perm_jobs.due = True
-        else:
-            self._refresh_transposed()
+        self._refresh_transposed()           # in line: a captured step leaves the derived copies fresh for its next replay
         self._began = False
         self._touch()
 

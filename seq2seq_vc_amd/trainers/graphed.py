@@ -71,8 +71,8 @@ class GraphedStep:
         self.stream = torch.cuda.Stream(trainer.device)      # replaced by a distinct one at capture time if it aliases a stream in use
         # host batches reach the static buffers through two alternating device staging buffers filled on a COPY stream: the
         # host-to-device copy of batch n + 1 (5 MB for VTN vc1: ~0.2 ms of the step's stream when it is issued there) runs beside
-        # the graphs of batch n, the step's stream only does a device-to-device copy.  S2SVC_TRAINER_STAGE_H2D=0: copy in line
-        self.copy_stream = "lazy" if os.environ.get("S2SVC_TRAINER_STAGE_H2D", "1") != "0" else None
+        # the graphs of batch n, the step's stream only does a device-to-device copy
+        self.copy_stream = "lazy"
         self._stage = {}
         self.pool = torch.cuda.graph_pool_handle()     # one memory pool for the graphs of all shapes
         if trainer.gradient_accumulate_steps != 1 and not trainer.GRAPH_ACCUMULATE:
@@ -202,7 +202,7 @@ class GraphedStep:
             if e.zero_due_after is not None:
                 # begin_step() / zero_grad(defer=True) ran as Python only at capture time: a replay must leave the flag the way the
                 # captured step did, or the next window's role key (Trainer._graph_regime) picks an accumulate graph without the
-                # zero-fill (only S2SVC_PROLOGUE_OVERLAP=1 ever sets the flag)
+                # zero-fill (no path sets the flag since the prologue overlap was removed)
                 t.optimizer._zero_due = e.zero_due_after
             t._check_train_finish()
             t.optimizer._touch()        # the weights change without a Python-side optimizer.step(): cached decode sessions etc. go stale
@@ -279,8 +279,7 @@ class _Capture:
         g, stage = self.cur
         from ..ops import functional as Fn
         main = torch.cuda.current_stream()
-        pro = getattr(self.owner.t.optimizer, "_pro_stream", None)   # the step prologue (optim.FlatAdam.begin_step)
-        for st in [Fn._Branch.stream, pro] + list(Fn._Side.streams):      # belt and braces: nothing may still be forked off
+        for st in [Fn._Branch.stream] + list(Fn._Side.streams):      # belt and braces: nothing may still be forked off
             if st is None:
                 continue
             with torch.cuda.stream(st):
