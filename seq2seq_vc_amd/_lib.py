@@ -72,6 +72,30 @@ def build_library(force=False, verbose=True, debug_exec=False):
     return lib_path
 
 
+TORCH_OPS_LIB_PATH = os.path.join(CSRC, "libs2svc_torch_ops.so")
+
+
+def build_torch_ops(force=False, verbose=True):
+    """csrc/torch_ops.cpp -> csrc/libs2svc_torch_ops.so: the TORCH_LIBRARY registration of the kernels (torch.ops.s2svc.*).  Host-only
+    C++ against the torch headers, linked to libs2svc_hip.so (found at run time beside it: rpath $ORIGIN); g++, ~20 s."""
+    import torch
+    from torch.utils import cpp_extension as E
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    deps = [src, os.path.join(_HERE, "..", "include", "s2svc_hip.h")]
+    if not force and os.path.exists(TORCH_OPS_LIB_PATH) and os.path.getmtime(TORCH_OPS_LIB_PATH) >= max(os.path.getmtime(p) for p in deps):
+        return TORCH_OPS_LIB_PATH
+    tlib = E.library_paths()[0]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    cmd += [f"-I{p}" for p in E.include_paths()] + ["-I/opt/rocm/include", src, "-o", TORCH_OPS_LIB_PATH,
+                                                    f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+                                                    f"-L{CSRC}", "-ls2svc_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print("[s2svc build]", " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return TORCH_OPS_LIB_PATH
+
+
 c_i32, c_i64, c_f32, c_u64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64, ctypes.c_void_p
 
 

@@ -241,14 +241,14 @@ class OverlappedBackward:
             loss = losses.get(branch_root[5:])
             if loss is not None and loss.requires_grad:
                 if fork is not None:
-                    Fn.branch_backward(loss, fork, retain_graph=Fn._RETAIN, scale=s)
+                    Fn.branch_backward(loss, fork, retain_graph=False, scale=s)
                 else:
-                    Fn.root_backward(loss, s, retain_graph=Fn._RETAIN)
+                    Fn.root_backward(loss, s, retain_graph=False)
         for root in ([roots] if isinstance(roots, str) else list(roots)):
             if root.startswith("loss:"):
                 loss = losses.get(root[5:])
                 if loss is not None and loss.requires_grad:
-                    Fn.root_backward(loss, s, retain_graph=Fn._RETAIN)
+                    Fn.root_backward(loss, s, retain_graph=False)
             else:
                 self.cuts.resume(root[4:])
         Fn.side_join()

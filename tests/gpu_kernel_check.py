@@ -754,22 +754,16 @@ def linear_fc_permuted_backward_bf16():
         dxr = (dy.float() @ wperm) * (x.float() > 0)
         dwr = (dy.float().t() @ x.float()).view(D, Fd, C).permute(0, 2, 1).reshape(D, C * Fd)
         dbr = dy.float().sum(0)
-        saved = (Fn._FC_DGRAD_T, Fn._FC_WGRAD_W8)
-        try:
-            for dg, wg in ((True, True), (False, False)):
-                Fn._FC_DGRAD_T, Fn._FC_WGRAD_W8 = dg, wg
-                xx = x.clone().requires_grad_(True)
-                w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
-                y = Fn.linear_fc_permuted(xx, w, b, C, Fd, input_is_relu=True)
-                y.backward(dy)
-                tag = f"fc_permuted[bf16] M{M} C{C} D{D} dgradT={int(dg)} w8={int(wg)}"
-                res.append(check(f"{tag} fwd", y, yr, dtype))
-                res.append(check(f"{tag} dx", xx.grad, dxr, dtype))
-                sc = max(float(dwr.abs().max()), 1.0)
-                res.append(check(f"{tag} dw", w.grad, dwr, torch.float32, rtol=1e-4, atol=2e-4 * sc))
-                res.append(check(f"{tag} db", b.grad, dbr, torch.float32, rtol=1e-4, atol=2e-4 * max(float(dbr.abs().max()), 1.0)))
-        finally:
-            Fn._FC_DGRAD_T, Fn._FC_WGRAD_W8 = saved
+        xx = x.clone().requires_grad_(True)
+        w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = Fn.linear_fc_permuted(xx, w, b, C, Fd, input_is_relu=True)
+        y.backward(dy)
+        tag = f"fc_permuted[bf16] M{M} C{C} D{D}"
+        res.append(check(f"{tag} fwd", y, yr, dtype))
+        res.append(check(f"{tag} dx", xx.grad, dxr, dtype))
+        sc = max(float(dwr.abs().max()), 1.0)
+        res.append(check(f"{tag} dw", w.grad, dwr, torch.float32, rtol=1e-4, atol=2e-4 * sc))
+        res.append(check(f"{tag} db", b.grad, dbr, torch.float32, rtol=1e-4, atol=2e-4 * max(float(dbr.abs().max()), 1.0)))
     return res
 
 

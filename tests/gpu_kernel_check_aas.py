@@ -814,6 +814,118 @@ def stft_logmel_batched_and_device_collaters():
 
 
 @case
+def torch_library_ops_vs_launchers_and_torch():
+    """torch.ops.s2svc.* (TORCH_LIBRARY registration, csrc/torch_ops.cpp: C++ -> C ABI, no Python in the call) against the package's own
+    ctypes launchers (same kernels: bit-exact) and plain fp32 torch math, forward and -- through the registered autograd formulas --
+    backward."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    from seq2seq_vc_amd.ops import torch_library as TL
+    ops = TL.load()
+    res = []
+    bf = torch.bfloat16
+    # alignment search: durations / path bit-exact against the launcher
+    B, Tf, Tx = 4, 50, 16
+    lp = torch.log_softmax(rnd(B, Tf, Tx, seed=1), dim=-1)
+    tl, fl = torch.tensor([16, 12, 9, 16], device=DEV), torch.tensor([50, 41, 30, 44], device=DEV)
+    ds, path, bm = ops.mas_forward(lp, tl, fl)
+    ds0, path0, bm0 = K.mas(lp, tl.int(), fl.int())
+    res.append((bool(torch.equal(ds, ds0) and torch.equal(path, path0) and torch.equal(bm, bm0)), "s2svc::mas_forward == K.mas bit for bit"))
+    # pairwise -L2 + log-softmax and its backward helper
+    f, t = rnd(B, Tf, 96, seed=2, dtype=bf), rnd(B, Tx, 96, seed=3, dtype=bf)
+    a, d_ = ops.pairwise_l2_logsoftmax(f, t, tl)
+    a0, d0 = KA.pairwise_l2_logsoftmax(f, t, tl.int())
+    res.append((bool(torch.equal(a, a0) and torch.equal(d_, d0)), "s2svc::pairwise_l2_logsoftmax == launcher bit for bit"))
+    dl = rnd(B, Tf, Tx, seed=4)
+    G, rs = ops.pairwise_l2_logsoftmax_bwd(a, d_, dl, tl, bf)
+    G0, rs0 = KA.pairwise_l2_bwd_g(a0, d0, dl, tl.int(), bf)
+    res.append((bool(torch.equal(G, G0) and torch.equal(rs, rs0)), "s2svc::pairwise_l2_logsoftmax_bwd == launcher bit for bit"))
+    P = ops.gaussian_upsample_probs(ds, tl, fl, Tf, 0.1, torch.float32)
+    res.append((bool(torch.equal(P, KA.gauss_upsample_probs(ds, tl.int(), fl.int(), Tf, torch.float32))), "s2svc::gaussian_upsample_probs == launcher"))
+    # forward-sum loss: value and gradient vs F.ctc_loss (forward_sum_loss.py:68-74)
+    prior = ops.betabinom_prior(tl, fl, Tf, Tx)
+    x = lp.clone().requires_grad_(True)
+    loss_b, _ = ops.ctc_forward_sum(x, prior, tl, fl, -1.0)
+    loss_b.sum().backward()
+    xr = lp.clone().requires_grad_(True)
+    tot = 0
+    for b in range(B):
+        n, m = int(tl[b]), int(fl[b])
+        z = F.pad((xr[b, :m, :n] + prior[b, :m, :n]), (1, 0), value=-1.0)
+        z = F.log_softmax(z, dim=-1).unsqueeze(1)
+        tot = tot + F.ctc_loss(z, torch.arange(1, n + 1, device=DEV).unsqueeze(0), torch.tensor([m], device=DEV), torch.tensor([n], device=DEV), zero_infinity=True)
+    tot.backward()
+    res.append(check("s2svc::ctc_forward_sum sum of per-utterance losses vs F.ctc_loss", loss_b.sum(), tot.detach(), torch.float32, rtol=1e-4, atol=1e-4))
+    res.append(check("s2svc::ctc_forward_sum autograd vs F.ctc_loss", x.grad, xr.grad, torch.float32, rtol=1e-3, atol=1e-5))
+    # masked L1 + BCE (seq2seq_loss.py:30-59) with autograd
+    Bm, Tm, D = 3, 40, 80
+    ol = torch.tensor([40, 33, 17], device=DEV)
+    ys, lab = rnd(Bm, Tm, D, seed=5), (torch.arange(Tm, device=DEV)[None] >= (ol[:, None] - 1)).float()
+    aft, bef, lg = (rnd(Bm, Tm, D, seed=6).requires_grad_(True), rnd(Bm, Tm, D, seed=7).requires_grad_(True), rnd(Bm, Tm, seed=8).requires_grad_(True))
+    st = ops.masked_l1_bce(aft, bef, lg, ys, lab, ol, 10.0)
+    (st[0] + 0.5 * st[1]).backward()
+    m = (torch.arange(Tm, device=DEV)[None] < ol[:, None])
+    ar, br, lr_ = (v.detach().clone().requires_grad_(True) for v in (aft, bef, lg))
+    l1r = F.l1_loss(ar[m], ys[m]) + F.l1_loss(br[m], ys[m])
+    bcer = F.binary_cross_entropy_with_logits(lr_[m], lab[m], pos_weight=torch.tensor(10.0, device=DEV))
+    (l1r + 0.5 * bcer).backward()
+    res.append(check("s2svc::masked_l1_bce l1 / bce vs torch", st[:2], torch.stack([l1r, bcer]).detach(), torch.float32, rtol=1e-5, atol=1e-5))
+    for nm, g_, r_ in (("d after", aft.grad, ar.grad), ("d before", bef.grad, br.grad), ("d logits", lg.grad, lr_.grad)):
+        res.append(check(f"s2svc::masked_l1_bce autograd {nm}", g_, r_, torch.float32, rtol=1e-4, atol=1e-7))
+    # guided attention loss (guided_attention_loss.py:142-165)
+    att = torch.softmax(rnd(2, 4, 30, 20, seed=9), dim=-1).requires_grad_(True)
+    il, ol2 = torch.tensor([20, 13], device=DEV), torch.tensor([30, 22], device=DEV)
+    ga = ops.guided_attn_loss(att, il, ol2, 0.4, 1.0)
+    ga[0].backward()
+    to, ti = torch.arange(30, device=DEV)[None, :, None].float(), torch.arange(20, device=DEV)[None, None, :].float()
+    W = 1.0 - torch.exp(-((ti / il[:, None, None]) - (to / ol2[:, None, None])) ** 2 / (2 * 0.4 ** 2))
+    valid = ((to < ol2[:, None, None]) & (ti < il[:, None, None]))
+    attr = att.detach().clone().requires_grad_(True)
+    gar = (W[:, None] * attr)[valid[:, None].expand(2, 4, 30, 20)].mean()
+    gar.backward()
+    res.append(check("s2svc::guided_attn_loss vs torch", ga[0], gar.detach(), torch.float32, rtol=1e-5, atol=1e-6))
+    res.append(check("s2svc::guided_attn_loss autograd", att.grad, attr.grad, torch.float32, rtol=1e-4, atol=1e-8))
+    # fused attention forward / backward == the package's attention_core (same kernels, same seeds: bit-exact)
+    Bq, H, T1, T2, dk = 2, 4, 63, 64, 96
+    q, k, v = (rnd(Bq, T1 if i == 0 else T2, H * dk, seed=10 + i, dtype=bf) for i in range(3))
+    kl = torch.tensor([64, 51], device=DEV)
+    dy = rnd(Bq, T1, H * dk, seed=14, dtype=bf)
+    qa, ka, va = (t_.clone().requires_grad_(True) for t_ in (q, k, v))
+    ctx_, att_ = ops.attn_fwd(qa, ka, va, kl, False, H, 1 / math.sqrt(dk), 0.0, None, 0)
+    (ctx_.float() * dy.float()).sum().backward()
+    qb, kb, vb = (t_.clone().requires_grad_(True) for t_ in (q, k, v))
+    ctx0, att0 = Fn.attention_core(qb, kb, vb, kl.int(), False, H, 0.0)
+    (ctx0.float() * dy.float()).sum().backward()
+    same = torch.equal(ctx_, ctx0) and torch.equal(att_[..., :T2], att0) and all(torch.equal(a_.grad, b_.grad) for a_, b_ in ((qa, qb), (ka, kb), (va, vb)))
+    res.append((bool(same), "s2svc::attn_fwd + registered autograd == Fn.attention_core forward and gradients, bit for bit"))
+    # residual + LayerNorm (layer_norm.py:12-42 + the residual lines of encoder_layer.py:96-113)
+    for dtype in (torch.float32, bf):
+        xx, rr = rnd(6, 50, 384, seed=15, dtype=dtype).requires_grad_(True), rnd(6, 50, 384, seed=16, dtype=dtype).requires_grad_(True)
+        gm, bt = rnd(384, seed=17) * 0.1 + 1.0, rnd(384, seed=18) * 0.1
+        y, s_, mean, rstd = ops.ln_residual_dropout(xx, rr, gm, bt, 1e-12, 0.0, 1.0, None, 0)
+        dyl = rnd(6, 50, 384, seed=19, dtype=dtype)
+        (y.float() * dyl.float()).sum().backward()
+        xr_, rr_ = xx.detach().float().requires_grad_(True), rr.detach().float().requires_grad_(True)
+        yr = F.layer_norm(xr_ + rr_, (384,), gm, bt, 1e-12)
+        (yr * dyl.float()).sum().backward()
+        res.append(check(f"s2svc::ln_residual_dropout[{dtype}] y vs torch", y, yr.detach(), dtype))
+        res.append(check(f"s2svc::ln_residual_dropout[{dtype}] autograd d x", xx.grad, xr_.grad, dtype, atol=None if dtype == torch.float32 else 8e-2))
+        res.append(check(f"s2svc::ln_residual_dropout[{dtype}] autograd d res", rr.grad, rr_.grad, dtype, atol=None if dtype == torch.float32 else 8e-2))
+        # Linear + activation on the MFMA GEMM kernels
+        w, b_ = rnd(256, 384, seed=20, dtype=dtype, scale=0.05), rnd(256, seed=21)
+        yl = ops.gemm_bias_act(xx.detach(), w, b_, "relu")
+        res.append(check(f"s2svc::gemm_bias_act[{dtype}] vs torch", yl, torch.relu(xx.detach().float() @ w.float().t() + b_), dtype))
+        # BatchNorm statistics + running buffers
+        rm, rv, nb = torch.zeros(384, device=DEV), torch.ones(384, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+        mean_c, rstd_c = ops.batchnorm_stats(xx.detach(), 1e-5, 0.1, rm, rv, nb)
+        xf = xx.detach().float().view(-1, 384)
+        res.append(check(f"s2svc::batchnorm_stats[{dtype}] mean", mean_c, xf.mean(0), torch.float32, rtol=1e-4, atol=1e-4))
+        res.append(check(f"s2svc::batchnorm_stats[{dtype}] rstd", rstd_c, 1 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5), torch.float32, rtol=1e-3, atol=1e-4))
+        res.append(check(f"s2svc::batchnorm_stats[{dtype}] running_var", rv, 0.9 + 0.1 * xf.var(0, unbiased=True), torch.float32, rtol=1e-3, atol=1e-4))
+        res.append((int(nb) == 1, "s2svc::batchnorm_stats advances num_batches_tracked"))
+    return res
+
+
+@case
 def c_abi_driver_without_python():
     """the MAS / forward-sum / STFT entry points driven from a C++ binary (tools/cabi_driver.cpp: hipMalloc'ed buffers,
     the functions called as include/s2svc_hip.h declares them) -- alignment-search known answers KAT1 / KAT2, the CTC loss against a

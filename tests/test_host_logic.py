@@ -537,3 +537,24 @@ def test_allreduce_grads_promotes_to_the_widest_dtype():
     allreduce_grads_([a, b], _FakeDist, 2)
     assert _FakeDist.seen == torch.float32
     assert torch.equal(b.grad, torch.full((4,), 1.0 + 2.0 ** -20)) and a.grad.dtype == torch.bfloat16
+
+
+def test_torch_library_registration_loads_and_lists_every_schema():
+    """the kernels are registered with the torch dispatcher (TORCH_LIBRARY in csrc/torch_ops.cpp).  Without a
+    GPU: the registration library loads, every op carries the schema string ops/torch_library.py documents, autograd formulas are
+    attached, and a call on CPU tensors is refused by the dispatcher (no CPU implementation exists -- no fallback)."""
+    import torch
+    from seq2seq_vc_amd import _lib
+    from seq2seq_vc_amd.ops import torch_library as TL
+    _lib.build_torch_ops(verbose=False)
+    ops = TL.load()
+    for name, schema in TL.SCHEMAS.items():
+        assert str(getattr(ops, name).default._schema) == schema, name
+    assert ops.abi_version() == _lib.lib().s2svc_abi_version()
+    with pytest.raises(NotImplementedError):
+        ops.mas_forward(torch.zeros(1, 4, 3), torch.tensor([3]), torch.tensor([4]))
+    with pytest.raises(NotImplementedError):
+        ops.gemm_bias_act(torch.zeros(4, 8), torch.zeros(2, 8), None, "relu")
+    # every *_bwd op has its forward op, and the differentiable forward ops have an autograd kernel registered
+    for fwd in ("ctc_forward_sum", "masked_l1_bce", "guided_attn_loss", "attn_fwd", "ln_residual_dropout"):
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"s2svc::{fwd}", "Autograd"), fwd
