@@ -43,13 +43,14 @@ def _register_autograd():
     ops = torch.ops.s2svc
     reg = torch.library.register_autograd
 
-    # ---- ctc_forward_sum: the forward pass leaves d loss_b / d log_p_attn; only `loss_per_utt` is differentiable -----------------
+    # ---- ctc_forward_sum: the pass leaves `grad` = d (mean_b loss_per_utt[b]) / d log_p_attn (what forward_sum_loss.py:58-76 returns
+    #      is that mean); only `loss_per_utt` is differentiable: d loss_per_utt[b] / d log_p_attn[b] = B * grad[b] ------------------
     def fs_setup(ctx, inputs, output):
         ctx.save_for_backward(output[1])
 
     def fs_bwd(ctx, g_loss, _g_grad):
         (grad,) = ctx.saved_tensors
-        return grad * g_loss.view(-1, 1, 1), None, None, None, None
+        return grad * (g_loss.view(-1, 1, 1) * float(grad.shape[0])), None, None, None, None
     reg("s2svc::ctc_forward_sum", fs_bwd, setup_context=fs_setup)
 
     # ---- masked_l1_bce -> stats (l1, bce, count): gradients of the first two -----------------------------------------------------
