@@ -584,37 +584,14 @@ int s2svc_decode_advance(int32_t* pos, uint64_t* seed_base, uint64_t seed_stride
 int s2svc_decode_ln_linear_supported(int dtype, int M, int K);
 int s2svc_decode_ln_linear(const s2svc_gemm_desc* desc /* host */, const float* gamma, const float* beta, float eps, void* y_out,
                            int64_t ldy, void* stream);
-/* Round 6 (csrc/decode_fused.hip): the same step in fewer, shorter launches.
-   _attn_proj: one attention sublayer of one position INCLUDING its share of the output projection (attention.py:63-111 +
-     linear_out for one query row): part[b, h, :] (fp32, (B, H, D)) = Wo[:, h dk : (h + 1) dk] . softmax(q_h K_h^T scale) V_h.
-     bf16; every cache row up to the capacity Tk and the head's weight slice are staged in LDS by LDS-DMA before anything is
-     looked at (ONE trip to memory per launch); knew / vnew != NULL: self-attention, this step's rows are used at *pos and
-     appended to the caches; else keys 0 .. klen[b] - 1; att as s2svc_decode_attn.  _supported: dk in {32, 64, 96, 128} and
-     (2 Tk + D) dk bf16 + ~4 KB within 156 KB of LDS.
-   _ln_linear_parts: s2svc_decode_ln_linear whose input rows are A[m, :] + pbias + sum_{p < nparts} parts[p * pstride + m * pbs + :]
-     (the residual + bias + the H partials of _attn_proj: pstride = D, pbs = H * D), rounded to the compute dtype -- the
-     out-projection launch of decoder_layer.py:104-127 is gone; s_out != NULL also receives that sum (pre-LN residual stream).
-   _prenet: (Linear -> ReLU -> dropout) x (nl - 1) + the input Linear + positional encoding of one position in one launch, a
-     workgroup per utterance (pre_postnets.py:53-66, embedding.py:115-125); dropout masks = those of s2svc_gemm's epilogue stage
-     with seed *seed_base + seed_off[l] and element index b * N[l] + n.
-   _emit_advance: s2svc_decode_emit on a packed feat_out | prob_out projection (row stride ldf) + s2svc_decode_advance by the last
-     workgroup to finish (`ticket`: one zero-initialised device uint32, zero again afterwards). */
-int s2svc_decode_attn_proj_supported(int dtype, int H, int dk, int D, int Tk);
-int s2svc_decode_attn_proj(int B, int H, int dk, const void* q, int64_t ldq, void* kcache, void* vcache, int64_t ldt, int64_t cbs,
-                           const void* knew, const void* vnew, int64_t ldn, const int32_t* pos, const int32_t* klen, int Tk, float scale,
-                           const void* wo, int64_t ldw, float* part, float* att, int64_t att_bs, int64_t att_hs, int64_t att_ps,
-                           void* stream);
-int s2svc_decode_ln_linear_parts(const s2svc_gemm_desc* desc /* host */, const float* gamma, const float* beta, float eps, void* y_out,
-                                 int64_t ldy, const float* parts, int nparts, int64_t pstride, int64_t pbs, const float* pbias,
-                                 void* s_out, int64_t lds, void* stream);
-int s2svc_decode_prenet(int dtype, int B, int nl, const void* const* w /* host array of device pointers */,
-                        const float* const* bias /* host array */, const int32_t* N /* host */, const int32_t* K /* host */, float drop_p,
-                        const uint64_t* seed_base, const uint64_t* seed_off /* host */, const void* x, int64_t ldx, float xscale,
-                        const float* alpha, const float* pe, const int32_t* pos, void* y, int64_t ldy, void* stream);
+/* Round 6 (csrc/decode_fused.hip): s2svc_decode_emit on ONE packed feat_out | prob_out projection (feat / logit rows with stride ldf)
+   + s2svc_decode_advance by the last workgroup to finish (`ticket`: one zero-initialised device uint32, zero again afterwards)
+   + pe_next != NULL: pe_next[0 .. D) = alpha * pe[(*pos + 1) * D + .] in `dtype` -- the positional-encoding row of the NEXT position,
+   which the input Linear of the next step adds as a residual with row stride 0 (embedding.py:115-125; no s2svc_decode_posenc launch). */
 int s2svc_decode_emit_advance(int dtype, int B, int r, int odim, const void* feat, const void* logit, int64_t ldf, float threshold,
                               const int32_t* minlen, const int32_t* maxlen, int32_t* pos, float* outs, int64_t outs_bs, float* probs,
                               int64_t probs_bs, void* prev, int32_t* stop_at, uint64_t* seed_base, uint64_t seed_stride,
-                              uint32_t* ticket, void* stream);
+                              uint32_t* ticket, const float* pe, const float* alpha, int D, int pe_rows, void* pe_next, void* stream);
 
 /* ========================================================================================== */
 /* Optimiser: grad-norm -> clip -> WarmupLR -> Adam (+ bf16 shadow) over one flat buffer       */

@@ -258,14 +258,8 @@ _SIGS = {
     "s2svc_decode_emit": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp,
                           c_vp],
     "s2svc_decode_advance": [c_vp, c_vp, c_u64, c_vp],
-    "s2svc_decode_attn_proj_supported": [c_i32, c_i32, c_i32, c_i32, c_i32],
-    "s2svc_decode_attn_proj": [c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i32, c_f32,
-                               c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp],
-    "s2svc_decode_ln_linear_parts": [ctypes.POINTER(GemmDesc), c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp],
-    "s2svc_decode_prenet": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp,
-                            c_i64, c_vp],
     "s2svc_decode_emit_advance": [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp,
-                                  c_vp, c_vp, c_u64, c_vp, c_vp],
+                                  c_vp, c_vp, c_u64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp],
     "s2svc_reflect_pad": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "s2svc_magnitude": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "s2svc_log_clamp": [c_i64, c_i32, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp],

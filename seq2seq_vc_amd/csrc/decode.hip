@@ -291,20 +291,12 @@ template <> struct DFrag<float> {
   static __device__ __forceinline__ type pack(const float (&f)[4]) { return (type){f[0], f[1], f[2], f[3]}; }
 };
 
-// The sublayer sum as an INPUT stage (round 6, s2svc_decode_ln_linear_parts): row m of A becomes
-//     A[m, k] + pbias[k] + sum_{p < nparts} parts[p * pstride + m * K + k]        (rounded to T: what the unfused path stored)
-// -- residual + bias + the per-head partial output projections csrc/decode_fused.hip leaves -- before the LayerNorm sees it;
-// s_out != NULL: workgroup 0 also writes that sum (the residual stream of a pre-LN layer).
-struct ln_parts_t {
-  const float* parts; int nparts; int64_t pstride, pbs; const float* pbias; void* s_out; int64_t lds;
-};
-
 // NS = k-steps per wave held in registers (the whole K range of a wave is loaded up front: one exposed memory latency per
 // launch; the LayerNorm statistics come from those registers -- two-pass, partial sums through LDS across the four waves)
 template <typename T, int MT, int NS, bool LEAN = false>       // LEAN: see gemm_skinny_kernel
 __global__ __launch_bounds__(256) void ln_linear_skinny_kernel(const s2svc_gemm_desc d, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, T* __restrict__ y_out,
-                                                               int64_t ldy, const ln_parts_t lp) {
+                                                               int64_t ldy) {
   typedef DFrag<T> F;
   typedef typename F::type frag_t;
   __shared__ float red[3][MT][256];
@@ -329,36 +321,6 @@ __global__ __launch_bounds__(256) void ln_linear_skinny_kernel(const s2svc_gemm_
     for (int i = 0; i < MT; ++i) {
       const int row = i * 16 + lr;
       a[u][i] = (kin && row < d.M) ? *reinterpret_cast<const frag_t*>(A + (int64_t)row * d.A.ld + k) : F::zero();
-    }
-  }
-  if (lp.parts) {       // (uniform) the sublayer sum: residual rows + bias + partial projections, rounded as the unfused path stored it
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      const int k = (ks0 + u) * F::KSTEP + lg * F::VEC;
-      if (u < per && (ks0 + u) < ksteps && k < d.K) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int row = i * 16 + lr;
-          if (row < d.M) {
-            float f[F::VEC];
-            F::unpack(a[u][i], f);
-            if (lp.pbias) {
-#pragma unroll
-              for (int e = 0; e < F::VEC; ++e) f[e] += lp.pbias[k + e];
-            }
-            for (int q = 0; q < lp.nparts; ++q) {
-              const float* pp = lp.parts + (int64_t)q * lp.pstride + (int64_t)row * lp.pbs + k;
-#pragma unroll
-              for (int e = 0; e < F::VEC; e += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(pp + e);
-                f[e] += v.x; f[e + 1] += v.y; f[e + 2] += v.z; f[e + 3] += v.w;
-              }
-            }
-            a[u][i] = F::pack(f);
-            if (lp.s_out && blockIdx.x == 0) *reinterpret_cast<frag_t*>((T*)lp.s_out + (int64_t)row * lp.lds + k) = a[u][i];
-          }
-        }
-      }
     }
   }
   if (gamma) {
@@ -443,29 +405,29 @@ __global__ __launch_bounds__(256) void ln_linear_skinny_kernel(const s2svc_gemm_
 }
 
 template <typename T, int NS>
-void launch_ln_linear_ns(const s2svc_gemm_desc& d, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, const ln_parts_t& lp, hipStream_t st) {
+void launch_ln_linear_ns(const s2svc_gemm_desc& d, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, hipStream_t st) {
   dim3 grid((d.N + 15) / 16), block(256);
   const int mt = (d.M + 15) / 16;
   static const bool lean_on = true;
   if (lean_on && mt <= 2 && epilogue_lean_ok(d)) {
-    if (mt == 1) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 1, NS, true>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy, lp);
-    else hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 2, NS, true>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy, lp);
+    if (mt == 1) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 1, NS, true>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+    else hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 2, NS, true>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
     return;
   }
-  if (mt == 1) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 1, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy, lp);
-  else if (mt == 2) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 2, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy, lp);
-  else if (mt == 3) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 3, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy, lp);
-  else hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 4, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy, lp);
+  if (mt == 1) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 1, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+  else if (mt == 2) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 2, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+  else if (mt == 3) hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 3, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
+  else hipLaunchKernelGGL((ln_linear_skinny_kernel<T, 4, NS>), grid, block, 0, st, d, gamma, beta, eps, (T*)y_out, ldy);
 }
 
 // k-steps per wave: K = 384 -> 3 (bf16) / 6 (fp32); up to K = 512 (bf16) / 256.. handled by the larger instantiations
 template <typename T>
-bool launch_ln_linear(const s2svc_gemm_desc& d, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, const ln_parts_t& lp, hipStream_t st) {
+bool launch_ln_linear(const s2svc_gemm_desc& d, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy, hipStream_t st) {
   const int kstep = DFrag<T>::KSTEP;
   const int per = ((d.K + kstep - 1) / kstep + 3) / 4;
-  if (per <= 3) launch_ln_linear_ns<T, 3>(d, gamma, beta, eps, y_out, ldy, lp, st);
-  else if (per <= 6) launch_ln_linear_ns<T, 6>(d, gamma, beta, eps, y_out, ldy, lp, st);
-  else if (per <= 12 && d.M <= 32) launch_ln_linear_ns<T, 12>(d, gamma, beta, eps, y_out, ldy, lp, st);
+  if (per <= 3) launch_ln_linear_ns<T, 3>(d, gamma, beta, eps, y_out, ldy, st);
+  else if (per <= 6) launch_ln_linear_ns<T, 6>(d, gamma, beta, eps, y_out, ldy, st);
+  else if (per <= 12 && d.M <= 32) launch_ln_linear_ns<T, 12>(d, gamma, beta, eps, y_out, ldy, st);
   else return false;
   return true;
 }
@@ -483,8 +445,8 @@ extern "C" int s2svc_decode_ln_linear_supported(int dtype, int M, int K) {
   return per <= 6 || (per <= 12 && M <= 32);
 }
 
-static int decode_ln_linear_impl(const s2svc_gemm_desc* desc, const float* gamma, const float* beta, float eps, void* y_out, int64_t ldy,
-                                 const ln_parts_t& lp, void* stream) {
+extern "C" int s2svc_decode_ln_linear(const s2svc_gemm_desc* desc, const float* gamma, const float* beta, float eps, void* y_out,
+                                      int64_t ldy, void* stream) {
   S2S_REQUIRE(desc != nullptr, "decode_ln_linear: null desc");
   const s2svc_gemm_desc& d = *desc;
   S2S_REQUIRE(d.M > 0 && d.M <= 64 && d.N > 0 && d.K > 0 && d.nb0 * d.nb1 <= 1 && d.splitk <= 1 && !d.a_rowsum && !d.c_map,
@@ -496,31 +458,10 @@ static int decode_ln_linear_impl(const s2svc_gemm_desc* desc, const float* gamma
   S2S_REQUIRE(d.K % vec == 0 && d.A.ld % vec == 0 && d.B.ld % vec == 0 && (!y_out || ldy % vec == 0), "decode_ln_linear: K / strides must be whole 16-byte vectors");
   S2S_REQUIRE(((uintptr_t)d.A.ptr) % 16 == 0 && ((uintptr_t)d.B.ptr) % 16 == 0 && ((uintptr_t)y_out) % 16 == 0, "decode_ln_linear: 16-byte aligned operands");
   S2S_REQUIRE(d.drop_p < 1.f && (!(d.drop_p > 0.f || d.emask) || d.ldc == d.N), "decode_ln_linear: the dropout stage needs a contiguous C");
-  if (lp.parts)
-    S2S_REQUIRE(lp.nparts > 0 && lp.nparts <= 16 && ((uintptr_t)lp.parts) % 16 == 0 && lp.pstride % 4 == 0 && lp.pbs % 4 == 0 && d.K % 4 == 0 &&
-                    ((uintptr_t)lp.s_out) % 16 == 0 && (!lp.s_out || lp.lds % vec == 0),
-                "decode_ln_linear_parts: 16-byte aligned partials, strides multiples of 4 floats");
   hipStream_t st = (hipStream_t)stream;
-  const bool ok = d.dtype == S2S_F32 ? launch_ln_linear<float>(d, gamma, beta, eps, y_out, ldy, lp, st)
-                                     : launch_ln_linear<bf16_t>(d, gamma, beta, eps, y_out, ldy, lp, st);
+  const bool ok = d.dtype == S2S_F32 ? launch_ln_linear<float>(d, gamma, beta, eps, y_out, ldy, st)
+                                     : launch_ln_linear<bf16_t>(d, gamma, beta, eps, y_out, ldy, st);
   S2S_REQUIRE(ok, "decode_ln_linear: K too large for the register-resident form (use s2svc_layernorm_fwd + s2svc_gemm)");
   S2S_CHECK_LAUNCH("ln_linear_skinny_kernel");
   return 0;
-}
-
-extern "C" int s2svc_decode_ln_linear(const s2svc_gemm_desc* desc, const float* gamma, const float* beta, float eps, void* y_out,
-                                      int64_t ldy, void* stream) {
-  const ln_parts_t none = {nullptr, 0, 0, 0, nullptr, nullptr, 0};
-  return decode_ln_linear_impl(desc, gamma, beta, eps, y_out, ldy, none, stream);
-}
-
-// The same with the sublayer sum as its input stage: the rows the LayerNorm (or, gamma == NULL, the plain projection) sees are
-//     A[m, :] + pbias + sum_{p < nparts} parts[p * pstride + m * pbs + :]      (fp32 partials, e.g. the (B, H, D) output of
-// s2svc_decode_attn_proj: pstride = D, pbs = H * D), rounded to the compute dtype; s_out != NULL receives that sum (row stride lds).
-extern "C" int s2svc_decode_ln_linear_parts(const s2svc_gemm_desc* desc, const float* gamma, const float* beta, float eps, void* y_out,
-                                            int64_t ldy, const float* parts, int nparts, int64_t pstride, int64_t pbs, const float* pbias,
-                                            void* s_out, int64_t lds, void* stream) {
-  S2S_REQUIRE(parts != nullptr, "decode_ln_linear_parts: parts required");
-  const ln_parts_t lp = {parts, nparts, pstride, pbs, pbias, s_out, lds};
-  return decode_ln_linear_impl(desc, gamma, beta, eps, y_out, ldy, lp, stream);
 }

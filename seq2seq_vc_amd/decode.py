@@ -7,11 +7,10 @@ Replaces the generation loop of the reference (models/vtn.py:334-394, models/tra
   in every layer, re-projects the source K/V in every layer, grows `ys` with `torch.cat`, walks
   `named_modules()` for the attention weights and reads the stop probability on the host (one sync per step);
 * here: source K/V are projected once, self-attention K/V are appended to a static cache, the step index, the
-  per-utterance stop test and the dropout seed live on the device, and one step (~60 kernel launches: 8 per layer) is
-  captured ONCE as a hipGraph and replayed; the host polls the stop flags every `poll` steps.  Round 6 (bf16, `FUSED_STEP`):
-  39 launches per step instead of 56 -- the attention kernels carry their share of the output projection, Prenet + input
-  Linear + positional encoding are one launch, feat_out | prob_out one projection, the step counter advances in the emit
-  kernel (csrc/decode_fused.hip).  Several
+  per-utterance stop test and the dropout seed live on the device, and one step (53 kernel launches for VTN vc1: 8 per layer;
+  round 6: feat_out | prob_out are one projection, the emit kernel also advances the step counter and leaves the NEXT position's
+  positional-encoding row, which the input Linear of the next step adds as a residual -- 56 launches before) is
+  captured ONCE as a hipGraph and replayed; the host polls the stop flags every `poll` steps.  Several
   utterances decode in lockstep (one row each); rows are independent, so a batch gives the same frames as
   utterance-by-utterance decoding.
 
@@ -27,9 +26,6 @@ from . import modules as Mo
 from .ops import functional as Fn
 from .ops import kernels as K
 from .ops import kernels_decode as KD
-
-
-FUSED_STEP = True          # tests flip it: the 56-launch step of rounds 1-5 (also what fp32 parity runs use)
 
 
 def _round_up(n, m):
@@ -86,17 +82,14 @@ class ARDecodeSession:
         self.minlen, self.maxlen, self.klen = z(B, dt=torch.int32), z(B, dt=torch.int32), z(B, dt=torch.int32)
         self.threshold = None
         self.graph = None
+        # round 6: one packed feat_out | prob_out projection; emit + advance in one launch; the positional row as a residual of the input Linear
+        self.w_fp = torch.cat([self.feat_out[0], self.prob_out[0]], 0).contiguous()
+        self.b_fp = torch.cat([self.feat_out[1], self.prob_out[1]], 0).contiguous()
+        self.ticket = z(1, dt=torch.int32)
+        self.pe_cur = z(1, D)                                   # alpha * pe[pos] in the compute dtype, kept current by the emit kernel
+        w_e, b_e = self.embed_lin                               # (x W^T + b) * xscale + alpha * pe: xscale rides in the GEMM's alpha and bias
+        self.embed_bias = None if b_e is None else (b_e * self.xscale).contiguous()
         self._ll_ok = {}               # (batch, K) -> the fused LayerNorm + projection kernel applies (see _ll)
-        # round 6: the fused step (csrc/decode_fused.hip) where its kernels take the shapes
-        self.fused = (FUSED_STEP and dtype == torch.bfloat16 and len(self.prenet) + 1 <= 4
-                      and KD.attn_proj_supported(dtype, self.H, self.dk, Lcap) and KD.attn_proj_supported(dtype, self.H, self.dk, Tcap)
-                      and KD.ln_linear_supported(dtype, B, D))
-        if self.fused:
-            self.part = [z(B, self.H, D, dt=torch.float32) for _ in range(2)]          # self- / source-attention partial projections
-            self.w_fp = torch.cat([self.feat_out[0], self.prob_out[0]], 0).contiguous()
-            self.b_fp = torch.cat([self.feat_out[1], self.prob_out[1]], 0).contiguous()
-            self.ticket = z(1, dt=torch.int32)
-            self.prenet_plan = KD.PrenetPlan(self.prenet + [self.embed_lin])
 
     @staticmethod
     def _version(model):
@@ -154,62 +147,7 @@ class ARDecodeSession:
         return K.gemm(K.operand(y, Kd), K.operand(w, Kd), x.shape[0], N, Kd, out, in_dtype=self.dtype, bias=bias, act=act, res=res,
                       drop_p=drop_p, seed=seed)
 
-    def _step_fused(self):
-        """39 launches: prenet | per layer [qkv, self-attention + out-projection partials, q_src (adds them), source attention +
-        partials, w_1 (adds them), w_2] | feat_out + prob_out | emit + advance."""
-        B, H, dk, D = self.B, self.H, self.dk, self.D
-        ll, lin = KD.ln_linear, self._lin
-        sc = 1.0 / math.sqrt(dk)
-        new = lambda: torch.empty((B, D), dtype=self.dtype, device=self.device)
-        seeds = [K.new_seed(self.device) for _ in self.prenet] if self.prenet_p > 0.0 else []
-        x = KD.decode_prenet(self.prenet_plan, self.prev, self.prenet_p if seeds else 0.0, seeds, self.xscale, self.alpha, self.pe, self.pos, new())
-        ps, pc = self.part
-
-        def self_attn(i, qkv, L):
-            KD.decode_attn_proj(qkv, 0, 3 * D, self.kc[i], 0, self.vc[i], 0, D, self.Lcap * D, qkv, D, 2 * D, 3 * D, self.pos, None,
-                                self.Lcap, sc, L["o"][0], ps, B, H, dk)
-
-        def src_attn(i, q, L):
-            a = self.att[i]
-            KD.decode_attn_proj(q, 0, D, self.src_kv[i], 0, self.src_kv[i], D, 2 * D, self.Tcap * 2 * D, None, 0, 0, 0, self.pos, self.klen,
-                                self.Tcap, sc, L["o_src"][0], pc, B, H, dk, att=a, att_strides=(a.stride(0), a.stride(1), a.stride(2)))
-
-        if self.pre_ln:       # x is the residual stream; a consumer adds the waiting sublayer output to it and writes it back (s_out)
-            for i, L in enumerate(self.layers):
-                n1, n2, n3 = L["norms"]
-                self_attn(i, ll(x, L["w_qkv"], L["b_qkv"], norm=n1), L)
-                x2 = new()
-                q = ll(x, L["q_src"][0], L["q_src"][1], norm=n2, parts=ps, pbias=L["o"][1], s_out=x2)
-                src_attn(i, q, L)
-                x3 = new()
-                h = ll(x2, L["w1"][0], L["w1"][1], norm=n3, act="relu", parts=pc, pbias=L["o_src"][1], s_out=x3)
-                x = lin(h, L["w2"], res=x3)
-            last, norm, tail = x, self.after_norm, {}
-        else:                 # post-norm: x = LN(residual + sublayer); the LayerNorm is applied by the sum's consumer, which writes x (y_out)
-            s, norm = None, None
-            for i, L in enumerate(self.layers):
-                n1, n2, n3 = L["norms"]
-                if s is None:
-                    qkv = lin(x, (L["w_qkv"], L["b_qkv"]))
-                else:
-                    x = new()
-                    qkv = ll(s, L["w_qkv"], L["b_qkv"], norm=norm, y_out=x)
-                self_attn(i, qkv, L)
-                x1 = new()
-                q = ll(x, L["q_src"][0], L["q_src"][1], norm=n1, y_out=x1, parts=ps, pbias=L["o"][1])
-                src_attn(i, q, L)
-                x2 = new()
-                h = ll(x1, L["w1"][0], L["w1"][1], norm=n2, act="relu", y_out=x2, parts=pc, pbias=L["o_src"][1])
-                s = lin(h, L["w2"], res=x2)
-                norm = n3
-            last = s
-        out = ll(last, self.w_fp, self.b_fp, norm=norm)
-        KD.decode_emit_advance(out, self.r, self.odim, self.threshold, self.minlen, self.maxlen, self.pos, self.outs, self.probs, self.prev,
-                               self.stop_at, K.SEED.tensor(self.device).data_ptr(), 0x10001, self.ticket)
-
     def _step(self):
-        if self.fused:
-            return self._step_fused()
         ll, lin = self._ll, self._lin            # LayerNorm / dropout fused into the projection | plain skinny projection
         x = self.prev
         for wb in self.prenet:                                  # Linear-ReLU-dropout in one launch, dropout ALWAYS on (F9)
@@ -217,8 +155,10 @@ class ARDecodeSession:
                 x = ll(x, wb[0], wb[1], act="relu", drop_p=self.prenet_p, seed=K.new_seed(self.device))
             else:
                 x = lin(x, wb, act="relu")
-        x = lin(x, self.embed_lin)
-        x = KD.decode_posenc(x, self.xscale, self.alpha, self.pe, self.pos, torch.empty_like(x))
+        w_e = self.embed_lin[0]
+        x = K.gemm(K.operand(x, w_e.shape[1]), K.operand(w_e, w_e.shape[1]), self.B, w_e.shape[0], w_e.shape[1],
+                   torch.empty((self.B, w_e.shape[0]), dtype=self.dtype, device=self.device), in_dtype=self.dtype, bias=self.embed_bias,
+                   alpha=self.xscale, res=self.pe_cur, ldr=0)     # + alpha * pe[pos] (embedding.py:115-125): the row the last emit left
         new = lambda: torch.empty((self.B, self.D), dtype=self.dtype, device=self.device)
         if self.pre_ln:       # decoder_layer.py:85-132 with normalize_before: x += f(LN(x)); x is the residual stream
             for i, L in enumerate(self.layers):
@@ -248,16 +188,18 @@ class ARDecodeSession:
                 s = lin(h, L["w2"], res=x)
                 norm = n3
             last = s
-        feat = ll(last, self.feat_out[0], self.feat_out[1], norm=norm)
-        logit = ll(last, self.prob_out[0], self.prob_out[1], norm=norm)
-        KD.decode_emit(feat, logit, self.r, self.odim, self.threshold, self.minlen, self.maxlen, self.pos, self.outs, self.probs,
-                       self.prev, self.stop_at)
-        KD.decode_advance(self.pos, K.SEED.tensor(self.device).data_ptr(), 0x10001)
+        out = ll(last, self.w_fp, self.b_fp, norm=norm)
+        KD.decode_emit_advance(out, self.r, self.odim, self.threshold, self.minlen, self.maxlen, self.pos, self.outs, self.probs, self.prev,
+                               self.stop_at, K.SEED.tensor(self.device).data_ptr(), 0x10001, self.ticket, pe=self.pe, alpha=self.alpha,
+                               pe_next=self.pe_cur)
 
     def _reset(self):
         self.pos.zero_()
         self.stop_at.zero_()
         self.prev.zero_()
+        self.ticket.zero_()
+        a = self.alpha if self.alpha is not None else 1.0
+        self.pe_cur.copy_((self.pe[0:1] * a).to(self.dtype))       # position 0 (the emit kernel writes the rows of the later ones)
 
     def _capture(self):
         """Warm up eagerly on a side stream (lazy initialisation), then capture one step."""

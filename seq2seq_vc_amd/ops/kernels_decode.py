@@ -40,66 +40,27 @@ def decode_advance(pos, seed_base_ptr=None, seed_stride=0):
     _lib.check(_lib.lib().s2svc_decode_advance(ptr(pos), seed_base_ptr, seed_stride, stream()), "decode_advance")
 
 
+def decode_emit_advance(out, r, odim, threshold, minlen, maxlen, pos, outs, probs, prev, stop_at, seed_base_ptr, seed_stride, ticket,
+                        pe=None, alpha=None, pe_next=None):
+    """decode_emit + decode_advance (+ the next position's positional row -> pe_next) in one launch (csrc/decode_fused.hip).
+    out (B, r * odim + r): the packed feat_out | prob_out projection of this position."""
+    B = out.shape[0]
+    D, rows = (pe.shape[1], pe.shape[0]) if pe_next is not None else (0, 0)
+    _lib.check(_lib.lib().s2svc_decode_emit_advance(dt(out), B, r, odim, ptr(out), _p(out, r * odim), out.stride(0), threshold, ptr(minlen),
+                                                    ptr(maxlen), ptr(pos), ptr(outs), outs.stride(0), ptr(probs), probs.stride(0),
+                                                    ptr(prev), ptr(stop_at), seed_base_ptr, seed_stride, ptr(ticket),
+                                                    ptr(pe) if pe_next is not None else None, ptr(alpha), D, rows, ptr(pe_next), stream()),
+               "decode_emit_advance")
+
+
 def ln_linear_supported(dtype, M, K):
     """True if the fused LayerNorm + skinny projection kernel takes an (M, K) input (decode.py falls back to LayerNorm + GEMM)."""
     return bool(_lib.lib().s2svc_decode_ln_linear_supported(_DT[dtype], M, K))
 
 
-def attn_proj_supported(dtype, H, dk, Tk):
-    return bool(_lib.lib().s2svc_decode_attn_proj_supported(_DT[dtype], H, dk, H * dk, Tk))
-
-
-def decode_attn_proj(q, q_off, ldq, kc, k_off, vc, v_off, ldt, cbs, new, knew_off, vnew_off, ldn, pos, klen, Tk, scale, wo, part, B, H, dk,
-                     att=None, att_strides=(0, 0, 0)):
-    """decode_attn + the head's share of the output projection `wo` (D, D): part (B, H, D) fp32 (csrc/decode_fused.hip)."""
-    _lib.check(_lib.lib().s2svc_decode_attn_proj(B, H, dk, _p(q, q_off), ldq, _p(kc, k_off), _p(vc, v_off), ldt, cbs,
-                                                 _p(new, knew_off) if new is not None else None,
-                                                 _p(new, vnew_off) if new is not None else None, ldn, ptr(pos), ptr(klen), Tk, scale,
-                                                 ptr(wo), wo.stride(0), ptr(part), ptr(att), att_strides[0], att_strides[1],
-                                                 att_strides[2], stream()), "decode_attn_proj")
-    return part
-
-
-class PrenetPlan:
-    """Host-side argument arrays of s2svc_decode_prenet (device pointers of the layers' weights / biases, their shapes)."""
-
-    def __init__(self, layers):
-        n = len(layers)
-        self.keep = layers
-        self.n = n
-        self.w = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in layers])
-        self.b = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for _, b in layers])
-        self.N = (ctypes.c_int32 * n)(*[w.shape[0] for w, _ in layers])
-        self.K = (ctypes.c_int32 * n)(*[w.shape[1] for w, _ in layers])
-        self.dtype = layers[0][0].dtype
-
-
-def decode_prenet(plan, x, drop_p, seeds, xscale, alpha, pe, pos, y):
-    """y = posenc(Linear_n(dropout(relu(Linear_i(...)))))  for one position (csrc/decode_fused.hip); seeds: list of (base tensor, offset)
-    per dropout layer (ops.kernels.new_seed)."""
-    B = x.shape[0]
-    offs = (ctypes.c_uint64 * plan.n)(*([s[1] for s in seeds] + [0] * (plan.n - len(seeds))))
-    base = seeds[0][0] if seeds else None
-    _lib.check(_lib.lib().s2svc_decode_prenet(_DT[plan.dtype], B, plan.n, ctypes.addressof(plan.w), ctypes.addressof(plan.b),
-                                              ctypes.addressof(plan.N), ctypes.addressof(plan.K), drop_p, base, ctypes.addressof(offs),
-                                              ptr(x), x.stride(0), xscale, ptr(alpha), ptr(pe), ptr(pos), ptr(y), y.stride(0), stream()),
-               "decode_prenet")
-    return y
-
-
-def decode_emit_advance(out, r, odim, threshold, minlen, maxlen, pos, outs, probs, prev, stop_at, seed_base_ptr, seed_stride, ticket):
-    """out (B, r * odim + r): the packed feat_out | prob_out projection of this position."""
-    B = out.shape[0]
-    _lib.check(_lib.lib().s2svc_decode_emit_advance(dt(out), B, r, odim, ptr(out), _p(out, r * odim), out.stride(0), threshold, ptr(minlen),
-                                                    ptr(maxlen), ptr(pos), ptr(outs), outs.stride(0), ptr(probs), probs.stride(0),
-                                                    ptr(prev), ptr(stop_at), seed_base_ptr, seed_stride, ptr(ticket), stream()),
-               "decode_emit_advance")
-
-
-def ln_linear(x, w, bias, *, norm=None, act=None, res=None, y_out=None, drop_p=0.0, seed=(None, 0), parts=None, pbias=None, s_out=None):
+def ln_linear(x, w, bias, *, norm=None, act=None, res=None, y_out=None, drop_p=0.0, seed=(None, 0)):
     """out = act(LN(x) . w^T + bias) [dropout] (+ res) in ONE launch; norm = (gamma, beta, eps) or None (plain linear);
-    y_out: a tensor that receives LN(x) as well.  x (M <= 64, K), w (N, K) in the compute dtype; bias / gamma / beta fp32.
-    parts (M, P, K) fp32 (+ pbias (K) fp32): the rows the LayerNorm sees are x + pbias + sum_p parts[:, p] (s_out receives them)."""
+    y_out: a tensor that receives LN(x) as well.  x (M <= 64, K), w (N, K) in the compute dtype; bias / gamma / beta fp32."""
     M, Kd = x.shape
     N = w.shape[0]
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
@@ -112,12 +73,6 @@ def ln_linear(x, w, bias, *, norm=None, act=None, res=None, y_out=None, drop_p=0
     if drop_p > 0.0:
         d.drop_p, d.seed_base, d.seed_off = drop_p, seed[0], seed[1]
     g, b, eps = (None, None, 0.0) if norm is None else norm
-    if parts is not None:
-        _lib.check(_lib.lib().s2svc_decode_ln_linear_parts(ctypes.byref(d), ptr(g), ptr(b), float(eps), ptr(y_out),
-                                                           y_out.stride(0) if y_out is not None else 0, ptr(parts), parts.shape[1],
-                                                           parts.stride(1), parts.stride(0), ptr(pbias), ptr(s_out),
-                                                           s_out.stride(0) if s_out is not None else 0, stream()), "decode_ln_linear_parts")
-        return out
     _lib.check(_lib.lib().s2svc_decode_ln_linear(ctypes.byref(d), ptr(g), ptr(b), float(eps), ptr(y_out),
                                                  y_out.stride(0) if y_out is not None else 0, stream()), "decode_ln_linear")
     return out

@@ -1749,116 +1749,37 @@ def bn_two_launch_statistics():
 
 
 @case
-def decode_fused_step_kernels():
-    """csrc/decode_fused.hip against fp32 torch math on the same bf16 operands: attention + projection partials (self: cache append, the
-    new row used from registers; source: key lengths, attention map), the sublayer sum as the input stage of the LayerNorm + projection
-    kernel, the one-launch prenet (values, dropout statistics, positional encoding) and emit + advance."""
+def decode_emit_advance_kernel():
+    """csrc/decode_fused.hip: frames / stop probabilities / stop test of one position from ONE packed feat_out | prob_out projection, the
+    step counter and the dropout seed advanced by the last workgroup, the ticket reset, and alpha * pe[pos + 1] left for the next step."""
     from seq2seq_vc_amd.ops import kernels_decode as KD
     res = []
-    bf = torch.bfloat16
-    for (B, H, dk, Tk, posv, seed) in [(16, 4, 96, 128, 37, 1), (3, 2, 64, 64, 0, 2), (5, 4, 96, 64, 63, 3), (2, 8, 32, 192, 100, 4), (2, 2, 128, 96, 5, 5)]:
-        D = H * dk
-        if not KD.attn_proj_supported(bf, H, dk, Tk):
-            res.append((False, f"attn_proj_supported H{H} dk{dk} Tk{Tk}"))
-            continue
-        qkv = rnd(B, 3 * D, seed=seed, dtype=bf)
-        kc, vc = rnd(B, Tk, D, seed=seed + 10, dtype=bf), rnd(B, Tk, D, seed=seed + 20, dtype=bf)
-        wo = rnd(D, D, seed=seed + 30, dtype=bf, scale=0.05)
-        pos = torch.tensor([posv], dtype=torch.int32, device=DEV)
-        part = torch.full((B, H, D), float("nan"), device=DEV)
-        kc0, vc0 = kc.clone(), vc.clone()
-        KD.decode_attn_proj(qkv, 0, 3 * D, kc, 0, vc, 0, D, Tk * D, qkv, D, 2 * D, 3 * D, pos, None, Tk, 1 / math.sqrt(dk), wo, part, B, H, dk)
-        q, kn, vn = (qkv[:, i * D:(i + 1) * D].float() for i in range(3))
-        kr, vr = kc0.float().clone(), vc0.float().clone()
-        kr[:, posv], vr[:, posv] = kn, vn
-        n = posv + 1
-        qh = q.view(B, H, 1, dk)
-        kh, vh = kr[:, :n].view(B, n, H, dk).transpose(1, 2), vr[:, :n].view(B, n, H, dk).transpose(1, 2)
-        pr = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(dk), -1)
-        ctx = (pr @ vh).squeeze(2)                                                     # (B, H, dk)
-        ref = torch.einsum("bhd,nhd->bhn", ctx, wo.float().view(D, H, dk))
-        res.append(check(f"decode_attn_proj self B{B} H{H} dk{dk} Tk{Tk} pos{posv}: partial projections", part, ref, torch.float32, rtol=2e-4, atol=2e-4))
-        appended = torch.equal(kc[:, posv], qkv[:, D:2 * D]) and torch.equal(vc[:, posv], qkv[:, 2 * D:])
-        rows = [j for j in range(Tk) if j != posv]
-        untouched = torch.equal(kc[:, rows], kc0[:, rows]) and torch.equal(vc[:, rows], vc0[:, rows])
-        res.append((bool(appended and untouched), f"decode_attn_proj self: cache row {posv} appended, the others untouched"))
-        # source attention: key lengths + the attention map row at *pos
-        klen = torch.tensor([Tk, max(1, Tk - 7), max(1, Tk // 2), 1, Tk][:B] + [Tk] * max(0, B - 5), dtype=torch.int32, device=DEV)
-        kv = rnd(B, Tk, 2 * D, seed=seed + 40, dtype=bf)
-        qs = rnd(B, D, seed=seed + 50, dtype=bf)
-        Lq = posv + 3
-        att = torch.zeros(B, H, Lq, Tk, device=DEV)
-        part2 = torch.full((B, H, D), float("nan"), device=DEV)
-        KD.decode_attn_proj(qs, 0, D, kv, 0, kv, D, 2 * D, Tk * 2 * D, None, 0, 0, 0, pos, klen, Tk, 1 / math.sqrt(dk), wo, part2, B, H, dk,
-                            att=att, att_strides=(att.stride(0), att.stride(1), att.stride(2)))
-        kh = kv[..., :D].float().view(B, Tk, H, dk).transpose(1, 2)
-        vh = kv[..., D:].float().view(B, Tk, H, dk).transpose(1, 2)
-        scr = (qs.float().view(B, H, 1, dk) @ kh.transpose(-1, -2) / math.sqrt(dk)).squeeze(2)
-        mask = torch.arange(Tk, device=DEV)[None, None] < klen[:, None, None]
-        prs = torch.softmax(scr.masked_fill(~mask, float("-inf")), -1)
-        refs = torch.einsum("bhd,nhd->bhn", (prs.unsqueeze(2) @ vh).squeeze(2), wo.float().view(D, H, dk))
-        res.append(check(f"decode_attn_proj source B{B} H{H} dk{dk} Tk{Tk}: partial projections", part2, refs, torch.float32, rtol=2e-4, atol=2e-4))
-        res.append(check(f"decode_attn_proj source: attention map row {posv}", att[:, :, posv], prs, torch.float32, rtol=1e-4, atol=1e-6))
-        res.append((float(att[:, :, :posv].abs().max()) == 0.0 if posv else True, "decode_attn_proj source: other map rows untouched"))
-        # the sublayer sum as the input stage of LayerNorm + projection (post-LN: y_out = LN(sum); pre-LN: s_out = sum)
-        for dtype in (bf, torch.float32):
-            x, w = rnd(B, D, seed=seed + 60, dtype=dtype), rnd(2 * D, D, seed=seed + 61, dtype=dtype, scale=0.05)
-            bias, pb = rnd(2 * D, seed=seed + 62), rnd(D, seed=seed + 63)
-            gm, bt = rnd(D, seed=seed + 64) * 0.1 + 1.0, rnd(D, seed=seed + 65) * 0.1
-            if not KD.ln_linear_supported(dtype, B, D):
-                continue
-            y_out, s_out = torch.empty_like(x), torch.empty_like(x)
-            out = KD.ln_linear(x, w, bias, norm=(gm, bt, 1e-12), act="relu", y_out=y_out, parts=part, pbias=pb, s_out=s_out)
-            sr = (x.float() + pb + part.sum(1)).to(dtype).float()
-            yr = F.layer_norm(sr, (D,), gm, bt, 1e-12)
-            res.append(check(f"ln_linear parts[{dtype}] B{B} D{D}: the sum (s_out)", s_out, sr, dtype, atol=1e-6 if dtype == torch.float32 else 2e-2))
-            res.append(check(f"ln_linear parts[{dtype}]: LN(sum) (y_out)", y_out, yr, dtype))
-            res.append(check(f"ln_linear parts[{dtype}]: projection", out, torch.relu(yr.to(dtype).float() @ w.float().t() + bias), dtype, atol=None if dtype == torch.float32 else 6e-2))
-    # prenet + input Linear + positional encoding in one launch
-    for dtype in (bf, torch.float32):
-        B, odim, U, D = 16, 80, 256, 384
-        layers = [(rnd(U, odim, seed=70, dtype=dtype, scale=0.1), rnd(U, seed=71) * 0.1), (rnd(U, U, seed=72, dtype=dtype, scale=0.1), rnd(U, seed=73) * 0.1),
-                  (rnd(D, U, seed=74, dtype=dtype, scale=0.1), rnd(D, seed=75) * 0.1)]
-        plan = KD.PrenetPlan(layers)
-        xin = rnd(B, odim, seed=76, dtype=dtype)
-        pe, alpha = rnd(200, D, seed=77), torch.tensor([0.7], device=DEV)
-        pos = torch.tensor([11], dtype=torch.int32, device=DEV)
-        y = KD.decode_prenet(plan, xin, 0.0, [], 1.0, alpha, pe, pos, torch.empty(B, D, dtype=dtype, device=DEV))
-        h = xin.float()
-        for li, (w, b) in enumerate(layers):
-            h = h @ w.float().t() + b
-            if li < 2:
-                h = torch.relu(h)
-            h = h.to(dtype).float()
-        res.append(check(f"decode_prenet[{dtype}] dropout off", y, h + 0.7 * pe[11], dtype, atol=None if dtype == torch.float32 else 6e-2))
-        K.manual_seed(5)
-        seeds = [K.new_seed(torch.device(DEV)) for _ in range(2)]
-        y1 = KD.decode_prenet(plan, xin, 0.5, seeds, 1.0, alpha, pe, pos, torch.empty(B, D, dtype=dtype, device=DEV))
-        y2 = KD.decode_prenet(plan, xin, 0.5, seeds, 1.0, alpha, pe, pos, torch.empty(B, D, dtype=dtype, device=DEV))
-        res.append((bool(torch.equal(y1, y2)) and not bool(torch.equal(y1, y)), f"decode_prenet[{dtype}] dropout 0.5: same seeds -> same output, differs from dropout off"))
-        # the masks are those of the unfused path: layer by layer through the skinny projection kernel with the same seeds
-        hh = xin
-        for li, (w, b) in enumerate(layers[:2]):
-            hh = KD.ln_linear(hh, w, b, act="relu", drop_p=0.5, seed=seeds[li])
-        hh = hh.float() @ layers[2][0].float().t() + layers[2][1]
-        res.append(check(f"decode_prenet[{dtype}] dropout 0.5 vs the layer-by-layer launches (same masks)", y1, hh.to(dtype).float() + 0.7 * pe[11], dtype,
-                         atol=1e-4 if dtype == torch.float32 else 8e-2))
-    # emit + advance
-    B, r, odim = 16, 4, 80
-    out = rnd(B, r * odim + r, seed=80, dtype=bf)
-    pos = torch.tensor([6], dtype=torch.int32, device=DEV)
-    outs, probs = torch.zeros(B, 40, odim, device=DEV), torch.zeros(B, 40, device=DEV)
-    prev, stop_at = torch.zeros(B, odim, dtype=bf, device=DEV), torch.zeros(B, dtype=torch.int32, device=DEV)
-    minlen, maxlen = torch.zeros(B, dtype=torch.int32, device=DEV), torch.full((B,), 7, dtype=torch.int32, device=DEV)
-    maxlen[3] = 100
-    ticket = torch.zeros(1, dtype=torch.int32, device=DEV)
-    seedt = K.SEED.tensor(torch.device(DEV))
-    s0 = int(seedt.item())
-    KD.decode_emit_advance(out, r, odim, 2.0, minlen, maxlen, pos, outs, probs, prev, stop_at, seedt.data_ptr(), 0x10001, ticket)
-    ok = (int(pos) == 7 and int(ticket) == 0 and int(seedt.item()) == s0 + 0x10001 and torch.equal(outs[:, 24:28].reshape(B, -1), out[:, :r * odim].float())
-          and torch.equal(prev, out[:, (r - 1) * odim:r * odim]) and torch.allclose(probs[:, 24:28], torch.sigmoid(out[:, r * odim:].float()), atol=1e-6)
-          and stop_at.tolist() == [7, 7, 7, 0] + [7] * 12)
-    res.append((bool(ok), f"decode_emit_advance: frames / probs / prev written, pos 6 -> {int(pos)}, seed advanced, ticket reset, stop test {stop_at.tolist()[:5]}"))
+    for dtype in (torch.bfloat16, torch.float32):
+        B, r, odim, D = 16, 4, 80, 384
+        out = rnd(B, r * odim + r, seed=80, dtype=dtype)
+        pos = torch.tensor([6], dtype=torch.int32, device=DEV)
+        outs, probs = torch.zeros(B, 40, odim, device=DEV), torch.zeros(B, 40, device=DEV)
+        prev, stop_at = torch.zeros(B, odim, dtype=dtype, device=DEV), torch.zeros(B, dtype=torch.int32, device=DEV)
+        minlen, maxlen = torch.zeros(B, dtype=torch.int32, device=DEV), torch.full((B,), 7, dtype=torch.int32, device=DEV)
+        maxlen[3] = 100
+        ticket = torch.zeros(1, dtype=torch.int32, device=DEV)
+        pe, alpha = rnd(10, D, seed=81), torch.tensor([0.7], device=DEV)
+        pe_next = torch.zeros(1, D, dtype=dtype, device=DEV)
+        seedt = K.SEED.tensor(torch.device(DEV))
+        s0 = int(seedt.item())
+        KD.decode_emit_advance(out, r, odim, 2.0, minlen, maxlen, pos, outs, probs, prev, stop_at, seedt.data_ptr(), 0x10001, ticket,
+                               pe=pe, alpha=alpha, pe_next=pe_next)
+        ok = (int(pos) == 7 and int(ticket) == 0 and int(seedt.item()) == s0 + 0x10001
+              and torch.equal(outs[:, 24:28].reshape(B, -1), out[:, :r * odim].float())
+              and torch.equal(prev, out[:, (r - 1) * odim:r * odim]) and torch.allclose(probs[:, 24:28], torch.sigmoid(out[:, r * odim:].float()), atol=1e-6)
+              and stop_at.tolist() == [7, 7, 7, 0] + [7] * 12 and torch.equal(pe_next[0], (0.7 * pe[7]).to(dtype)))
+        res.append((bool(ok), f"decode_emit_advance[{dtype}]: frames / probs / prev written, pos 6 -> {int(pos)}, seed advanced, ticket reset, "
+                              f"stop test {stop_at.tolist()[:5]}, next positional row"))
+        # at the last row of the table the positional row is left alone (the host never replays past the capacity)
+        pos.fill_(9)
+        keep = pe_next.clone()
+        KD.decode_emit_advance(out, r, odim, 2.0, minlen, maxlen, pos, outs[:, :40], probs, prev, stop_at, None, 0, ticket, pe=pe, alpha=alpha, pe_next=pe_next)
+        res.append((bool(torch.equal(pe_next, keep)) and int(pos) == 10, f"decode_emit_advance[{dtype}]: no read past the positional table"))
     return res
 
 
