@@ -495,13 +495,20 @@ class Workload:
         return {"decoder": l1, "align": self.Fn.weighted_sum([(fs, 2.0), (ret["bin_loss"], 2.0), (dur, 1.0)])}
 
 
-def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_eager=2, collective="allreduce"):
+def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_eager=2, collective="allreduce", stage_mode="marks"):
     """Returns (step(), info).  Unstaged: graph 1 = zero + forward + loss + backward, graph 2 = clip + Adam + WarmupLR.
-    Staged (data parallel): one graph per stage of model.dp_plan(); after each replay the all-reduce of that stage's slice of
-    the flat gradient buffer is issued; the optimiser graph follows the join."""
-    from seq2seq_vc_amd.distributed import OverlappedBackward, allreduce_mean_
+    Staged (data parallel), stage_mode "marks" (round 6, the default): ONE graph holds every stage of model.dp_plan() with an
+    event-record node behind each (OverlappedBackward.mark); after the replay's launch the all-reduce of every stage's slice of the
+    flat gradient buffer is issued from the communication stream behind its mark -- it travels while the same graph runs the later
+    stages.  stage_mode "graphs" (rounds 2-5): one graph per stage, the exchange issued between the replays.  The optimiser graph
+    follows the join."""
+    from seq2seq_vc_amd.distributed import FlushExchange, OverlappedBackward, allreduce_mean_
     from seq2seq_vc_amd.ops import kernels as K
     Fn, opt, dev = wl.Fn, wl.opt, wl.dev
+    fx = None
+    if staged and stage_mode == "flush":       # the UNCUT backward pass, the exchange behind the flushes of its gradient batches
+        staged = False
+        fx = FlushExchange(opt, dist, world, payload=payload, force=force_dist)
     ob = OverlappedBackward(wl.model, opt, dist, world, payload=payload, force=force_dist, collective=collective) if staged else None
     stage16 = None
     if not staged and (dist is not None or force_dist) and payload == "bf16":
@@ -513,12 +520,19 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
         K.advance_seed(dev)
         opt.begin_step()            # zero_grad + the refresh of the derived weight copies, beside the forward pass
 
-    def fwd_bwd():
+    def fwd_bwd(record=True):
         begin()
         (total,) = wl.forward(staged=False).values()
         opt.join_prologue()
-        Fn.root_backward(total)
-        Fn.side_join()
+        if fx is not None and record:
+            with fx.recording():                # a mark behind every flushed gradient batch
+                Fn.root_backward(total, fx.scale)
+                Fn.side_join()
+        else:
+            Fn.root_backward(total, fx.scale if fx is not None else 1.0)
+            Fn.side_join()
+        if fx is not None:
+            fx.mark_end()
 
     def stage(i):
         if i == 0:
@@ -535,12 +549,19 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
                 stage(i)
                 ob.begin_reduce(i)
             ob.finish()
+        elif fx is not None:
+            fwd_bwd()
+            fx.issue()
+            fx.finish()
         else:
             fwd_bwd()
             if (dist is not None or force_dist):
                 allreduce_mean_(opt.flat_g, dist, world, force=force_dist, stage_bf16=stage16)
         opt.step()
 
+    if fx is not None:              # which slices of the flat gradient buffer are final behind which flush: one instrumented eager pass
+        fx.learn(lambda: fwd_bwd(record=False))
+        opt.zero_grad()
     side = torch.cuda.Stream()      # warm-up on a side stream so that a later capture sees a quiet default stream
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -552,13 +573,21 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
     graphs, g_opt = [], None
     if use_graph:
         try:
-            for i in range(n_stages):
+            if staged and stage_mode == "marks":
                 g = torch.cuda.CUDAGraph()
-                kw = {"pool": graphs[0].pool()} if graphs else {}
-                # thread_local: RCCL's watchdog thread polls events while this thread captures (N > 1)
-                with torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
-                    stage(i) if staged else fwd_bwd()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    for i in range(n_stages):
+                        stage(i)
+                        ob.mark(i)               # an event-record node: "stage i's gradients are final" of THIS replay
                 graphs.append(g)
+            else:
+                for i in range(n_stages):
+                    g = torch.cuda.CUDAGraph()
+                    kw = {"pool": graphs[0].pool()} if graphs else {}
+                    # thread_local: RCCL's watchdog thread polls events while this thread captures (N > 1)
+                    with torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
+                        stage(i) if staged else fwd_bwd()
+                    graphs.append(g)
             g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
                 opt.step()
@@ -567,17 +596,26 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
             use_graph = False
             torch.cuda.synchronize()
 
-    post_reduce = (dist is not None or force_dist) and not staged
+    post_reduce = (dist is not None or force_dist) and not staged and fx is None
 
     def step():
         if not use_graph:
             step_eager()
             return
-        if staged:
+        if staged and stage_mode == "marks":
+            graphs[0].replay()
+            for i in range(n_stages):
+                ob.begin_reduce(i, after_mark=True)      # behind mark i of this replay, beside the later stages of the same graph
+            ob.finish()
+        elif staged:
             for i, g in enumerate(graphs):
                 g.replay()
                 ob.begin_reduce(i)       # this stage's gradients travel while the next stage's graph runs
             ob.finish()
+        elif fx is not None:
+            graphs[0].replay()
+            fx.issue()                   # every bucket behind the mark of the flush that finished it, beside the rest of the same graph
+            fx.finish()
         else:
             graphs[0].replay()
             if post_reduce:
@@ -587,7 +625,7 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
     def probe(reps=20):
         """Milliseconds of each piece of the staged step run ALONE (device-synchronised between pieces, so nothing overlaps):
         the stage graphs, the gradient exchange issued after each, the join, the optimiser graph."""
-        if not (use_graph and staged):
+        if not (use_graph and staged) or stage_mode == "marks":
             return None
         names = [f"graph{i}" for i in range(n_stages)] + [f"reduce{i}" for i in range(n_stages)] + ["finish", "opt"]
         acc = dict.fromkeys(names, 0.0)
@@ -607,11 +645,51 @@ def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_e
             timed("opt", g_opt.replay)
         return {k: round(v, 3) for k, v in acc.items()}
 
-    info = {"hip_graph": bool(use_graph), "backward_stages": n_stages, "_probe": probe,
-            "grad_buckets_MB": [round(b / 1e6, 1) for b in ob.bucket_bytes()] if staged else
+    def check_exchange():
+        """Flush mode: the overlapped exchange of ONE replayed (or eager) pass against a blocking all-reduce of the same local gradients
+        (the dropout seed is pinned so that both passes draw the same masks) -> max |difference| over the flat gradient buffer, and
+        whether the plan covers every element exactly once."""
+        if fx is None:
+            return None
+        seed = K.SEED.tensor(dev)
+        s0 = seed.clone()
+        rng = torch.cuda.get_rng_state(dev)          # (the stochastic duration predictor draws its noise with torch.randn)
+
+        def local_pass():
+            seed.copy_(s0)
+            torch.cuda.set_rng_state(rng, dev)
+            if use_graph:
+                graphs[0].replay()
+            else:
+                fwd_bwd()
+        torch.cuda.synchronize()
+        local_pass()
+        torch.cuda.synchronize()
+        ref = opt.flat_g.clone()
+        if dist is not None:
+            dist.all_reduce(ref)
+        torch.cuda.synchronize()
+        local_pass()
+        fx.issue()
+        fx.finish()
+        torch.cuda.synchronize()
+        diff = float((opt.flat_g - ref).abs().max())
+        cover = torch.zeros(opt.numel, dtype=torch.int32, device=dev)
+        per_bucket = []
+        for _, rs in fx.plan:
+            m = 0.0
+            for lo, hi in rs:
+                cover[lo:hi] += 1
+                m = max(m, float((opt.flat_g[lo:hi] - ref[lo:hi]).abs().max()))
+            per_bucket.append(m)
+        return {"max_abs_diff": diff, "per_bucket_max_abs_diff": per_bucket, "covered_once": bool((cover == 1).all()), "buckets": len(fx.plan), "flushes": fx.n_flushes,
+                "grad_abs_max": float(ref.abs().max())}
+
+    info = {"hip_graph": bool(use_graph), "backward_stages": n_stages, "_check": check_exchange, "stage_mode": stage_mode if (staged or fx is not None) else None, "_probe": probe,
+            "grad_buckets_MB": [round(b / 1e6, 1) for b in ob.bucket_bytes()] if staged else [round(b / 1e6, 1) for b in fx.bucket_bytes()] if fx is not None else
                                ([round(opt.numel * (2 if stage16 is not None else 4) / 1e6, 1)] if post_reduce else None),
-            "grad_payload": payload if (staged or post_reduce) else None,
-            "collective": collective if staged else ("allreduce" if post_reduce else None)}
+            "grad_payload": payload if (staged or post_reduce or fx is not None) else None,
+            "collective": collective if staged else ("allreduce" if (post_reduce or fx is not None) else None)}
     return step, info
 
 
@@ -1082,6 +1160,13 @@ def main():
     ap.add_argument("--grad-payload", default=None, choices=["fp32", "bf16"],
                     help="dtype of the gradient exchange (default: the trainers' default, <Trainer>.DP_GRAD_PAYLOAD = fp32; bf16 is the "
                          "opt-in config['dp_grad_payload']; reported in config.grad_payload)")
+    ap.add_argument("--stage-mode", default="marks", choices=["marks", "graphs", "flush"],
+                    help="data parallel under capture: ONE graph with an event-record node behind every backward stage (the exchange of a stage "
+                         "starts at its mark, beside the later stages of the same graph) or one graph per stage (rounds 2-5)")
+    ap.add_argument("--check-exchange", action="store_true",
+                    help="--stage-mode flush: compare the overlapped exchange of one pass with a blocking all-reduce of the same gradients")
+    ap.add_argument("--dp-decoder-stages", type=int, default=0,
+                    help="aasvc: this many decoder layers get a backward stage (gradient bucket) of their own")
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="data parallel: one all-reduce per bucket, or reduce-scatter + all-gather")
     ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
@@ -1163,10 +1248,15 @@ def main():
     if args.grad_payload is None:
         from seq2seq_vc_amd import trainers as TR      # what the workload's product trainer defaults to (fp32 = the reference's DDP)
         args.grad_payload = (TR.AASVCTrainer if args.workload == "aasvc" else TR.ARVCTrainer).DP_GRAD_PAYLOAD
+    if args.dp_decoder_stages:
+        wl.model.dp_decoder_stages = args.dp_decoder_stages      # AAS-VC: decoder layers with a stage (= a bucket) of their own
     step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
-                            warmup_eager=max(2, args.warmup if args.no_graph else 2))
+                            warmup_eager=max(2, args.warmup if args.no_graph else 2), stage_mode=args.stage_mode)
     probe = info.pop("_probe")
+    check = info.pop("_check")
     dt = time_steps(step, args.steps, args.warmup, dist if dp else None, dev)
+    if args.check_exchange:
+        info["exchange_check"] = check()
     if args.stage_times:
         info["stage_ms_alone"] = probe()
     if dp:

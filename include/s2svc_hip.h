@@ -36,6 +36,15 @@ int s2svc_abi_version(void);
    (4 KB of device memory).  What a DEPENDENT launch costs on this stack whatever it does (bench.py "launch_floor_us"). */
 int s2svc_launch_floor(int workgroups, int threads, void* sink_1024_words, void* stream);
 
+/* Hand-off points inside a captured graph (the data-parallel backward pass: apex DDP's per-bucket hooks, bin/vc_train.py:423-431, have
+   no counterpart in a graph): _record on a CAPTURING stream adds an event-record node (hipEventRecordExternal; returns 1), on an
+   ordinary stream it is hipEventRecord (returns 0); _stream_wait_event issued after the graph's launch makes `stream` wait for that
+   point of that launch.  `ev` is an opaque handle from _event_create (host memory). */
+int s2svc_event_create(void** out /* host */);
+int s2svc_event_destroy(void* ev);
+int s2svc_event_record(void* ev, void* stream);
+int s2svc_stream_wait_event(void* stream, void* ev);
+
 /* ========================================================================================== */
 /* Generic tiled MFMA GEMM with implicit-convolution operand addressing.                      */
 /*   C[z][m,n] = act(alpha * sum_k A_z(m,k) * B_z(n,k) + bias[n]) + res_z[m,n]                 */

@@ -143,6 +143,10 @@ _SIGS = {
     "s2svc_gemm_set_w8": [c_i32, c_i32],
     "s2svc_gemm_set_8ph": [c_i32],
     "s2svc_launch_floor": [c_i32, c_i32, c_vp, c_vp],
+    "s2svc_event_create": [c_vp],
+    "s2svc_event_destroy": [c_vp],
+    "s2svc_event_record": [c_vp, c_vp],
+    "s2svc_stream_wait_event": [c_vp, c_vp],
     "s2svc_decode_ln_linear_supported": [c_i32, c_i32, c_i32],
     "s2svc_decode_ln_linear": [ctypes.POINTER(GemmDesc), c_vp, c_vp, c_f32, c_vp, c_i64, c_vp],
     "s2svc_length_regulate_index": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],

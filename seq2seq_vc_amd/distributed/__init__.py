@@ -208,6 +208,8 @@ class OverlappedBackward:
         self.scale = 1.0 / self.world
         self.stage_buf = torch.empty(optimizer.numel, dtype=torch.bfloat16, device=optimizer.flat_g.device) if payload == "bf16" else None
         self.handles, self.pending_bf16 = [], []
+        self.marks = {}             # stage -> ops.kernels.GraphMark recorded behind the stage (mark())
+        self.comm_stream = None     # the stream the exchanges are issued from when they wait for marks
 
     # -- pieces ---------------------------------------------------------------------------------------------
     def forward_context(self):
@@ -255,9 +257,35 @@ class OverlappedBackward:
         if fork is not None:
             Fn.branch_wait()
 
-    def begin_reduce(self, i):
+    def mark(self, i):
+        """Record "stage i's gradients are final" on the current stream.  Inside a capture this is an event-record NODE of the
+        graph (ops.kernels.GraphMark): the stages of a backward pass can then share ONE graph and the exchange of stage i still
+        starts when stage i is done, while the same graph runs stage i + 1 (`begin_reduce(i, after_mark=True)` after the replay)
+        -- the granularity of the exchange is no longer paid for in graph boundaries (apex DDP's per-bucket
+        hooks, bin/vc_train.py:423-431, are what this stands in for)."""
+        if not self.active() or not self.opt.flat_g.is_cuda:
+            return
+        from ..ops import kernels as K
+        m = self.marks.get(i)
+        if m is None:
+            m = self.marks[i] = K.GraphMark()
+        m.record()
+
+    def begin_reduce(self, i, after_mark=False):
+        """after_mark: issue the exchange from the communication stream, behind mark i (the current stream may already hold the
+        rest of the step: a graph that contains later stages); finish() joins as usual."""
         if not self.active():
             return
+        if after_mark and i in self.marks:
+            if self.comm_stream is None:
+                self.comm_stream = Fn.distinct_stream()
+            self.marks[i].wait(self.comm_stream)
+            with torch.cuda.stream(self.comm_stream):
+                self._begin_reduce(i)
+            return
+        self._begin_reduce(i)
+
+    def _begin_reduce(self, i):
         from ..ops import kernels as K
         for lo, hi in self.ranges[i]:
             if self.stage_buf is not None:
@@ -296,6 +324,200 @@ class OverlappedBackward:
     def bucket_bytes(self):
         e = 2 if self.payload == "bf16" else 4
         return [sum(hi - lo for lo, hi in rs) * e for rs in self.ranges]
+
+
+class FlushExchange:
+    """The gradient exchange at the granularity of GRADIENT-BATCH FLUSHES of an UNCUT backward pass (round 6).
+
+    OverlappedBackward cuts the backward pass into stages; every cut is a join of the parameter-gradient work (and of the branch on
+    the auxiliary stream), and those joins -- not the graph boundaries: one graph with event-record nodes costs the same as one
+    graph per stage -- are what a finer plan pays for (AAS-VC with a stage per decoder layer: 12.7 vs 10.8 ms).  Here nothing is
+    cut.  The parameter-gradient closures of a backward pass are flushed in batches anyway (ops.functional._side_run); behind every
+    flush a mark is recorded on the flushing stream (ops.kernels.GraphMark: an event-record node when the step is captured), and the
+    slices of the flat gradient buffer that are FINAL at a flush -- learned once, from an instrumented eager pass that snapshots the
+    buffer behind every flush -- are all-reduced from the communication stream behind that mark, while the same graph keeps running
+    the rest of the backward pass.  What apex DDP's per-bucket hooks (bin/vc_train.py:423-431) do, at the batch granularity the
+    schedule already has, with no new synchronisation in the backward pass.
+
+        fx = FlushExchange(optimizer, dist, world)
+        fx.learn(run)                  # run(): zero-fill + forward + backward + side_join, eager, on the REAL shapes
+        ... capture or run `run()` with fx.recording(): marks behind every flush, fx.mark_end() behind the join ...
+        fx.issue(); fx.finish()        # after the graph's launch (or the eager pass): exchanges behind their marks, then the join
+
+    The plan (which ranges travel behind which flush) is rank 0's, broadcast: every rank issues the same collectives in the same
+    order whatever its data.  A change of the schedule (batch size, streams, model) needs a new learn()."""
+
+    def __init__(self, optimizer, dist, world, payload="fp32", chunk_numel=32 * 1024 * 1024, group=None, force=False,
+                 min_bucket_numel=4 * 1024 * 1024):
+        if not hasattr(optimizer, "flat_g"):
+            raise TypeError("FlushExchange needs optim.FlatAdam (gradients in one flat buffer)")
+        if payload not in ("fp32", "bf16"):
+            raise ValueError("payload must be 'fp32' or 'bf16'")
+        self.opt, self.dist, self.world, self.group = optimizer, dist, max(1, int(world)), group
+        self.payload, self.chunk, self.force, self.min_bucket = payload, chunk_numel, force, int(min_bucket_numel)
+        self.scale = 1.0 / self.world
+        self.stage_buf = torch.empty(optimizer.numel, dtype=torch.bfloat16, device=optimizer.flat_g.device) if payload == "bf16" else None
+        self.plan = None            # [(flush ordinal or None = behind the join, [(lo, hi), ...])]
+        self.marks, self.mark_streams, self.end_mark = [], [], None
+        self.n = 0                  # flush ordinal inside the current pass
+        self.mode = None            # "learn" | "mark"
+        self.snap, self.last_change = None, None
+        self.comm_stream = None
+        self.handles, self.pending_bf16 = [], []
+
+    def active(self):
+        return self.world > 1 or self.force
+
+    # -- the hook behind every flush -------------------------------------------------------------------------------------------
+    def _on_flush(self):
+        if self.mode == "learn":
+            torch.cuda.synchronize()
+            cur = self.opt.flat_g
+            changed = (cur != self.snap)
+            csum = torch.cumsum(changed.to(torch.int32), 0)
+            hi = csum[self.p_hi - 1]
+            lo = torch.where(self.p_lo > 0, csum[(self.p_lo - 1).clamp_min(0)], torch.zeros_like(hi))
+            touched = (hi - lo) > 0
+            self.last_change[touched] = self.n
+            self.snap = cur.clone()
+        elif self.mode == "mark":
+            from ..ops import kernels as K
+            if self.n >= len(self.marks):
+                self.marks.append(K.GraphMark())
+                self.mark_streams.append(None)
+            self.marks[self.n].record()
+            self.mark_streams[self.n] = torch.cuda.current_stream().cuda_stream
+        self.n += 1
+
+    def recording(self):
+        """Context: flushes of the backward pass inside it leave marks."""
+        fx = self
+
+        class _Ctx:
+            def __enter__(self_):
+                fx.mode, fx.n = "mark", 0
+                Fn._Side.on_flush = fx._on_flush
+
+            def __exit__(self_, *exc):
+                Fn._Side.on_flush = None
+                fx.mode = None
+                if exc[0] is None and fx.plan is not None and fx.n != fx.n_flushes:
+                    raise RuntimeError(f"FlushExchange: this pass flushed {fx.n} gradient batches, the learned plan has {fx.n_flushes} "
+                                       "(the schedule changed: learn() again)")
+        return _Ctx()
+
+    def mark_end(self):
+        """Behind the join of the backward pass (ops.functional.side_join) on the current stream: everything is final."""
+        if not self.active():
+            return
+        from ..ops import kernels as K
+        if self.end_mark is None:
+            self.end_mark = K.GraphMark()
+        self.end_mark.record()
+
+    # -- the plan -------------------------------------------------------------------------------------------------------------------
+    def learn(self, run):
+        """run(): one eager training pass up to and including side_join (zero-filled gradients at its start)."""
+        opt = self.opt
+        order = sorted(zip(opt.offsets, opt.params), key=lambda t: t[0])
+        los = [o for o, _ in order]
+        his = los[1:] + [opt.numel]                                # up to the next parameter (absorbs the alignment padding)
+        dev = opt.flat_g.device
+        self.p_lo = torch.tensor(los, dtype=torch.int64, device=dev)
+        self.p_hi = torch.tensor(his, dtype=torch.int64, device=dev)
+        self.last_change = torch.full((len(los),), -1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        self.snap = torch.zeros_like(opt.flat_g)
+        self.mode, self.n = "learn", 0
+        Fn._Side.on_flush = self._on_flush
+        try:
+            run()
+        finally:
+            Fn._Side.on_flush = None
+            self.mode = None
+        torch.cuda.synchronize()
+        self.n_flushes = self.n
+        last = self.last_change.tolist()
+        self.snap = self.last_change = None
+        if self.dist is not None and self.world > 1:               # rank 0's plan for everybody: identical collectives on every rank
+            box = [last, self.n_flushes]
+            self.dist.broadcast_object_list(box, src=0, group=self.group)
+            if box[1] != self.n_flushes:
+                raise RuntimeError("FlushExchange: the ranks flush different numbers of gradient batches")
+            last = box[0]
+        # ranges per flush ordinal; parameters no flush touched (or touched behind the last flush) travel behind the join
+        by_flush = {}
+        for (lo, hi), n in zip(zip(los, his), last):
+            by_flush.setdefault(n if n >= 0 else None, []).append((lo, hi))
+        plan, held, held_n = [], [], 0
+        for n in sorted(k for k in by_flush if k is not None):
+            held += by_flush[n]
+            held_n += sum(hi - lo for lo, hi in by_flush[n])
+            if held_n >= self.min_bucket:
+                plan.append((n, self._merge(held)))
+                held, held_n = [], 0
+        tail = held + by_flush.get(None, [])
+        if tail:
+            plan.append((None, self._merge(tail)))
+        self.plan = plan
+        return plan
+
+    @staticmethod
+    def _merge(ranges):
+        out = []
+        for lo, hi in sorted(ranges):
+            if out and out[-1][1] == lo:
+                out[-1][1] = hi
+            else:
+                out.append([lo, hi])
+        return [tuple(r) for r in out]
+
+    def bucket_bytes(self):
+        e = 2 if self.payload == "bf16" else 4
+        return [sum(hi - lo for lo, hi in rs) * e for _, rs in (self.plan or [])]
+
+    # -- after the graph's launch (or the eager pass) -----------------------------------------------------------------------------------
+    def issue(self):
+        if not self.active():
+            return
+        if self.plan is None:
+            raise RuntimeError("FlushExchange.issue() before learn()")
+        from ..ops import kernels as K
+        if self.comm_stream is None:
+            self.comm_stream = Fn.distinct_stream()
+        comm = self.comm_stream
+        for n, ranges in self.plan:
+            if n is None:
+                self.end_mark.wait(comm)
+            else:
+                seen = set()
+                for k in range(n, -1, -1):                       # the latest mark at or before flush n of every flushing stream
+                    sh = self.mark_streams[k]
+                    if sh not in seen:
+                        seen.add(sh)
+                        self.marks[k].wait(comm)
+            with torch.cuda.stream(comm):
+                for lo, hi in ranges:
+                    if self.stage_buf is not None:
+                        K.cast(self.opt.flat_g[lo:hi], torch.bfloat16, out=self.stage_buf[lo:hi])
+                        buf = self.stage_buf[lo:hi]
+                        self.pending_bf16.append((lo, hi))
+                    else:
+                        buf = self.opt.flat_g[lo:hi]
+                    self.handles += [_Waiter(h) for h in allreduce_sum_begin(buf, self.dist, self.world, self.chunk, self.group, force=True)]
+
+    def finish(self):
+        """The current stream waits for every exchange (and, with the bf16 payload, converts the buckets back)."""
+        for h in self.handles:
+            h.finish()
+        self.handles = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.pending_bf16:
+            from ..ops import kernels as K
+            for lo, hi in self.pending_bf16:
+                K.cast(self.stage_buf[lo:hi], torch.float32, out=self.opt.flat_g[lo:hi])
+            self.pending_bf16 = []
 
 
 def allreduce_grads_(params, dist, world, group=None):

@@ -180,6 +180,7 @@ class _Side:
     batch = 16
     grouped = []     # weight-gradient GEMM descriptors of the batch being flushed
     grouped_cr = []  # column reductions of the batch being flushed
+    on_flush = None  # callable(): called on the flushing stream behind every flushed batch (distributed.FlushExchange)
 
 
 def _taken_streams():
@@ -277,6 +278,8 @@ def _inline_flush(key):
     st, q = _Side.inline_q.pop(key)
     with torch.cuda.stream(st):
         _run_batch(q)
+        if _Side.on_flush is not None:
+            _Side.on_flush()
     return st
 
 
@@ -299,6 +302,8 @@ def _side_flush():
     _Side.origins = []
     with torch.cuda.stream(st):
         _run_batch(_Side.queue)
+        if _Side.on_flush is not None:
+            _Side.on_flush()
     _Side.queue = []
 
 

@@ -286,6 +286,37 @@ def pick_splitk(M, N, K, nbatch=1):
 
 
 # ----------------------------------------------------------------------------------------------
+# Hand-off points inside a captured graph (s2svc_event_* of the C ABI): see distributed.OverlappedBackward.mark
+# ----------------------------------------------------------------------------------------------
+class GraphMark:
+    """An event that, recorded on a CAPTURING stream, becomes an event-record node of the graph: every replay records it when the work
+    captured before it has run, and `wait(stream)` issued after the replay's launch makes `stream` wait for that point of that
+    replay (torch.cuda.Event(external=True) is refused on ROCm builds of torch; HIP itself supports it)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().s2svc_event_create(ctypes.byref(h)), "event_create")
+        self.handle = h.value
+
+    def record(self, stream_handle=None):
+        """-> True if the record became a graph node (the stream is capturing)."""
+        rc = _lib.lib().s2svc_event_record(self.handle, stream() if stream_handle is None else stream_handle)
+        if rc < 0:
+            _lib.check(rc, "event_record")
+        return rc == 1
+
+    def wait(self, torch_stream):
+        _lib.check(_lib.lib().s2svc_stream_wait_event(torch_stream.cuda_stream, self.handle), "stream_wait_event")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().s2svc_event_destroy(self.handle)
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+# ----------------------------------------------------------------------------------------------
 # Writer audit (S2SVC_AUDIT_SLOTS=1 / audit_slots(True); tests).  Gradient slots are accumulated into by several kernels of a
 # backward pass (weight-gradient GEMMs, fused bias row sums, column reductions) that run on the issuing stream, on side streams
 # or as background launches.  Two accumulating writers of ONE slot on DIFFERENT streams with no wait between them are a race that
