@@ -495,20 +495,22 @@ class Workload:
         return {"decoder": l1, "align": self.Fn.weighted_sum([(fs, 2.0), (ret["bin_loss"], 2.0), (dur, 1.0)])}
 
 
-def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_eager=2, collective="allreduce", stage_mode="marks"):
+def build_step(wl, dist, world, staged, force_dist, payload, use_graph, warmup_eager=2, collective="allreduce", stage_mode="flush",
+               min_bucket_mb=16.0):
     """Returns (step(), info).  Unstaged: graph 1 = zero + forward + loss + backward, graph 2 = clip + Adam + WarmupLR.
-    Staged (data parallel), stage_mode "marks" (round 6, the default): ONE graph holds every stage of model.dp_plan() with an
-    event-record node behind each (OverlappedBackward.mark); after the replay's launch the all-reduce of every stage's slice of the
-    flat gradient buffer is issued from the communication stream behind its mark -- it travels while the same graph runs the later
-    stages.  stage_mode "graphs" (rounds 2-5): one graph per stage, the exchange issued between the replays.  The optimiser graph
-    follows the join."""
+    Data parallel, stage_mode "flush" (round 6, the default): the UNCUT backward pass in one graph with an event-record node behind
+    every flushed gradient batch (distributed.FlushExchange); after the replay's launch every bucket of the flat gradient buffer is
+    all-reduced from the communication stream behind the mark of the flush that finished it, beside the rest of the same graph.
+    stage_mode "marks": the stages of model.dp_plan() in ONE graph with a mark behind each (the stage joins stay);
+    stage_mode "graphs" (rounds 2-5): one graph per stage, the exchange issued between the replays.  The optimiser graph follows
+    the join."""
     from seq2seq_vc_amd.distributed import FlushExchange, OverlappedBackward, allreduce_mean_
     from seq2seq_vc_amd.ops import kernels as K
     Fn, opt, dev = wl.Fn, wl.opt, wl.dev
     fx = None
     if staged and stage_mode == "flush":       # the UNCUT backward pass, the exchange behind the flushes of its gradient batches
         staged = False
-        fx = FlushExchange(opt, dist, world, payload=payload, force=force_dist)
+        fx = FlushExchange(opt, dist, world, payload=payload, force=force_dist, min_bucket_numel=int(min_bucket_mb * 262144))
     ob = OverlappedBackward(wl.model, opt, dist, world, payload=payload, force=force_dist, collective=collective) if staged else None
     stage16 = None
     if not staged and (dist is not None or force_dist) and payload == "bf16":
@@ -1160,9 +1162,11 @@ def main():
     ap.add_argument("--grad-payload", default=None, choices=["fp32", "bf16"],
                     help="dtype of the gradient exchange (default: the trainers' default, <Trainer>.DP_GRAD_PAYLOAD = fp32; bf16 is the "
                          "opt-in config['dp_grad_payload']; reported in config.grad_payload)")
-    ap.add_argument("--stage-mode", default="marks", choices=["marks", "graphs", "flush"],
-                    help="data parallel under capture: ONE graph with an event-record node behind every backward stage (the exchange of a stage "
-                         "starts at its mark, beside the later stages of the same graph) or one graph per stage (rounds 2-5)")
+    ap.add_argument("--stage-mode", default="flush", choices=["flush", "marks", "graphs"],
+                    help="data parallel: flush = the uncut backward pass, every gradient bucket exchanged behind the flush of the gradient batch "
+                         "that finished it (event-record nodes inside ONE graph); marks = the stages of model.dp_plan() in one graph with a mark "
+                         "behind each; graphs = one graph per stage, the exchange between the replays (rounds 2-5)")
+    ap.add_argument("--min-bucket-mb", type=float, default=16.0, help="--stage-mode flush: smallest gradient bucket (MB of fp32)")
     ap.add_argument("--check-exchange", action="store_true",
                     help="--stage-mode flush: compare the overlapped exchange of one pass with a blocking all-reduce of the same gradients")
     ap.add_argument("--dp-decoder-stages", type=int, default=0,
@@ -1251,7 +1255,7 @@ def main():
     if args.dp_decoder_stages:
         wl.model.dp_decoder_stages = args.dp_decoder_stages      # AAS-VC: decoder layers with a stage (= a bucket) of their own
     step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
-                            warmup_eager=max(2, args.warmup if args.no_graph else 2), stage_mode=args.stage_mode)
+                            warmup_eager=max(2, args.warmup if args.no_graph else 2), stage_mode=args.stage_mode, min_bucket_mb=args.min_bucket_mb)
     probe = info.pop("_probe")
     check = info.pop("_check")
     dt = time_steps(step, args.steps, args.warmup, dist if dp else None, dev)

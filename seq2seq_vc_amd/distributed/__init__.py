@@ -358,6 +358,7 @@ class FlushExchange:
         self.scale = 1.0 / self.world
         self.stage_buf = torch.empty(optimizer.numel, dtype=torch.bfloat16, device=optimizer.flat_g.device) if payload == "bf16" else None
         self.plan = None            # [(flush ordinal or None = behind the join, [(lo, hi), ...])]
+        self.plans, self.key = {}, None
         self.marks, self.mark_streams, self.end_mark = [], [], None
         self.n = 0                  # flush ordinal inside the current pass
         self.mode = None            # "learn" | "mark"
@@ -418,6 +419,25 @@ class FlushExchange:
     # -- the plan -------------------------------------------------------------------------------------------------------------------
     def learn(self, run):
         """run(): one eager training pass up to and including side_join (zero-filled gradients at its start)."""
+        self.learn_begin()
+        try:
+            run()
+        finally:
+            Fn._Side.on_flush = None
+            self.mode = None
+        return self.learn_end()
+
+    def select(self, key):
+        """Several schedules in one run (a trainer whose step changes with the training regime: the duration loss switching on):
+        one plan per key; -> True if the plan of `key` is known."""
+        if key != self.key:
+            self.plans[self.key] = (self.plan, getattr(self, "n_flushes", 0))
+            self.key = key
+            self.plan, self.n_flushes = self.plans.get(key, (None, 0))
+        return self.plan is not None
+
+    def learn_begin(self):
+        """The backward pass that follows (eager, from zero-filled gradients) is instrumented; learn_end() behind its side_join."""
         opt = self.opt
         order = sorted(zip(opt.offsets, opt.params), key=lambda t: t[0])
         los = [o for o, _ in order]
@@ -427,14 +447,15 @@ class FlushExchange:
         self.p_hi = torch.tensor(his, dtype=torch.int64, device=dev)
         self.last_change = torch.full((len(los),), -1, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
-        self.snap = torch.zeros_like(opt.flat_g)
+        self.snap = opt.flat_g.clone()          # zeros, or what earlier micro-steps of an accumulation window left
         self.mode, self.n = "learn", 0
         Fn._Side.on_flush = self._on_flush
-        try:
-            run()
-        finally:
-            Fn._Side.on_flush = None
-            self.mode = None
+        self._los, self._his = los, his
+
+    def learn_end(self):
+        Fn._Side.on_flush = None
+        self.mode = None
+        los, his = self._los, self._his
         torch.cuda.synchronize()
         self.n_flushes = self.n
         last = self.last_change.tolist()

@@ -93,7 +93,7 @@ class Trainer(object):
             return "gradient accumulation without captured micro-steps"
         if self.scheduler is not None and not isinstance(self.scheduler, FusedWarmupLR):
             return "a host-side learning-rate scheduler"
-        if self.dist is not None and self.dp is None:
+        if self.dist is not None and self.dp is None and getattr(self, "fx", None) is None:
             return "data parallelism without a staged backward pass (model.dp_plan)"
         return None
 
@@ -125,7 +125,7 @@ class Trainer(object):
         starts from rank 0's parameters and buffers, and every optimiser step averages the gradients over the ranks -- with
         FlatAdam stage by stage, overlapped with the backward pass (distributed.OverlappedBackward); with a torch optimiser
         one coalesced all-reduce of p.grad after backward.  BatchNorm statistics stay rank-local, rank 0 checkpoints."""
-        self.dist, self.world, self.dp = None, 1, None
+        self.dist, self.world, self.dp, self.fx = None, 1, None, None
         if not self.config.get("distributed", False):
             return
         import torch.distributed as dist
@@ -135,7 +135,12 @@ class Trainer(object):
         self.dist, self.world = dist, dist.get_world_size()
         self.config.setdefault("rank", dist.get_rank())
         D.broadcast_model_(self._net(), self.optimizer, dist, self.world)
-        if isinstance(self.optimizer, FlatAdam) and hasattr(self._net(), "dp_plan"):
+        if isinstance(self.optimizer, FlatAdam) and self.config.get("dp_exchange", "stages") == "flush":
+            # round 6: the UNCUT backward pass, every bucket exchanged behind the flush of the gradient batch that finished it
+            # (distributed.FlushExchange): no joins inside the backward pass, buckets at the granularity of the gradient batches
+            self.fx = D.FlushExchange(self.optimizer, dist, self.world, payload=self.config.get("dp_grad_payload", self.DP_GRAD_PAYLOAD),
+                                      min_bucket_numel=int(self.config.get("dp_min_bucket_mb", 16.0) * 262144))
+        elif isinstance(self.optimizer, FlatAdam) and hasattr(self._net(), "dp_plan"):
             self.dp = D.OverlappedBackward(self._net(), self.optimizer, dist, self.world,
                                            payload=self.config.get("dp_grad_payload", self.DP_GRAD_PAYLOAD),
                                            collective=self.config.get("dp_collective", "allreduce"))
@@ -163,6 +168,30 @@ class Trainer(object):
                 self._capture.staged_backward(self.dp, parts)
             else:
                 self.dp.backward(parts, reduce=last_micro_step)
+        elif self.fx is not None:
+            fx = self.fx
+            scale = 1.0 / self.world             # SUM exchange of gradients of loss / world == the mean the reference's DDP takes
+            if not last_micro_step:              # an accumulation micro-step: no exchange
+                Fn.root_backward(total, scale)
+                Fn.side_join()
+            elif not fx.select(self._graph_regime()):      # first step of this regime (eager): learn the plan while it runs
+                fx.learn_begin()
+                try:
+                    Fn.root_backward(total, scale)
+                    Fn.side_join()
+                finally:
+                    fx.learn_end()
+                for h in D.allreduce_sum_begin(self.optimizer.flat_g, self.dist, self.world):
+                    h.wait()
+            elif self._capture is not None:      # being captured: marks become nodes of the graph, the exchange follows its launch
+                self._capture.flush_backward(fx, total, scale)
+            else:
+                with fx.recording():
+                    Fn.root_backward(total, scale)
+                    Fn.side_join()
+                fx.mark_end()
+                fx.issue()
+                fx.finish()
         else:
             Fn.root_backward(total)
             Fn.side_join()

@@ -82,7 +82,7 @@ class GraphedStep:
         if trainer.scheduler is not None and not isinstance(trainer.scheduler, FusedWarmupLR):
             raise NotImplementedError('config["hip_graph"]: the learning-rate schedule must live in the fused optimiser step '
                                       "(schedulers.FusedWarmupLR); a host-side scheduler would not run during replays")
-        if trainer.dist is not None and trainer.dp is None:
+        if trainer.dist is not None and trainer.dp is None and getattr(trainer, "fx", None) is None:
             raise NotImplementedError('config["hip_graph"] with config["distributed"] needs a model with dp_plan() (staged backward)')
 
     def invalidate(self):
@@ -209,13 +209,18 @@ class GraphedStep:
         self._replay(e)
 
     def _replay(self, e):
-        dp = self.t.dp
+        dp, fx = self.t.dp, getattr(self.t, "fx", None)
         for g, stage in e.graphs:
             if stage == "opt" and dp is not None:
                 dp.finish()
+            if stage == "opt" and fx is not None and any(s == "fx" for _, s in e.graphs):
+                fx.finish()
             g.replay()
             if isinstance(stage, int) and dp is not None:
                 dp.begin_reduce(stage)
+            if stage == "fx" and fx is not None:
+                fx.select(e.fx_key)
+                fx.issue()                       # every bucket behind the mark of the flush that finished it (nodes of the graph just launched)
 
     # -- capture ------------------------------------------------------------------------------------
     def _capture(self, e, static_batch):
@@ -229,7 +234,7 @@ class GraphedStep:
             self.stream = Fn.distinct_stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         cap = _Capture(self, e, mode)
-        t._capture = cap if t.dp is not None else None
+        t._capture = cap if (t.dp is not None or getattr(t, "fx", None) is not None) else None
         # no cyclic garbage collection while the stream captures: the destructor of a CUDAGraph / stream of an earlier life calls
         # the runtime, which refuses during a capture (seen as an abort from the autograd thread)
         gc_was_on = gc.isenabled()
@@ -289,6 +294,19 @@ class _Capture:
         g.capture_end()
         self.entry.graphs.append((g, stage))
         self.cur = None
+
+    def flush_backward(self, fx, total, scale):
+        """The uncut backward pass with a mark (an event-record node) behind every flushed gradient batch closes the first graph;
+        what follows (the optimiser) is its own graph, replayed behind the exchange."""
+        from ..ops import functional as Fn
+        self.cur = (self.cur[0], "fx")
+        self.entry.fx_key = fx.key           # the plan (training regime) this graph's marks belong to
+        with fx.recording():
+            Fn.root_backward(total, scale)
+            Fn.side_join()
+        fx.mark_end()
+        self.end()
+        self.begin("opt")
 
     def staged_backward(self, dp, parts):
         """forward + stage 0 close the first graph; every further stage is its own graph; what follows (the optimiser) too."""

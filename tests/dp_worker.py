@@ -1,6 +1,6 @@
 """One rank of a data-parallel trainer run (spawned by gpu_model_check.dp_trainers_two_ranks).
 
-    python tests/dp_worker.py <vtn|aasvc> <rank> <world> <port> <out.pt> [payload] [none|trace|graph] [allreduce|rs_ag]
+    python tests/dp_worker.py <vtn|aasvc> <rank> <world> <port> <out.pt> [payload] [none|trace|graph] [allreduce|rs_ag] [stages|flush]
 
 The last argument runs the trainer with config["hip_graph"] ("trace": the eager reference of the captured step, "graph":
 stage graphs replayed with the all-reduces between them; trainers/graphed.py), 5 steps through Trainer._step.
@@ -72,6 +72,7 @@ def main():
     payload = sys.argv[6] if len(sys.argv) > 6 else "fp32"
     graph_mode = sys.argv[7] if len(sys.argv) > 7 else "none"
     collective = sys.argv[8] if len(sys.argv) > 8 else "allreduce"
+    exchange = sys.argv[9] if len(sys.argv) > 9 else "stages"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     import gpu_model_check as mc
@@ -85,7 +86,9 @@ def main():
     K.manual_seed(7)
     cfg, z = mc.load("vtn_tiny_train" if kind == "vtn" else "aasvc_tiny_train")
     model, crit, conf = build(kind, z, cfg, perturb=(rank != 0))
-    conf = dict(conf, distributed=True, rank=rank, dp_grad_payload=payload, dp_collective=collective)
+    conf = dict(conf, distributed=True, rank=rank, dp_grad_payload=payload, dp_collective=collective, dp_exchange=exchange)
+    if exchange == "flush":        # gradient batches of 4 closures (VTN: forked to two side streams): several flushes = several buckets
+        conf.update(side_streams=2 if kind == "vtn" else 0, inline_batches=kind != "vtn", gradient_batch=4, dp_min_bucket_mb=0.05)
     if graph_mode != "none":
         conf.update(hip_graph=(True if graph_mode == "graph" else "trace"), graph_length_quantum=8)
     else:
@@ -117,6 +120,7 @@ def main():
     torch.cuda.synchronize()
     torch.save({"flat_p": opt.flat_p.detach().cpu(), "buffers": {k: v.detach().cpu() for k, v in model.named_buffers()},
                 "logs": logs, "stages": len(tr.dp.plan) if tr.dp is not None else 0, "steps": tr.steps,
+                "fx_buckets": [] if tr.fx is None else tr.fx.bucket_bytes(), "fx_flushes": 0 if tr.fx is None else tr.fx.n_flushes,
                 "graphs": 0 if tr._graphed is None else sum(len(e.graphs) for e in tr._graphed.entries.values()),
                 "bucket_bytes": tr.dp.bucket_bytes() if tr.dp is not None else []}, out)
     dist.barrier()

@@ -2452,13 +2452,14 @@ def dp_trainers_two_ranks():
         Fn.enable_side_streams(0)
 
 
-def _dp_two_ranks_run(kind, mode, port):
+def _dp_two_ranks_run(kind, mode, port, exchange="stages"):
     import subprocess
     import tempfile
     here = os.path.dirname(os.path.abspath(__file__))
     with tempfile.TemporaryDirectory() as tmp:
         outs = [os.path.join(tmp, f"r{r}.pt") for r in range(2)]
-        procs = [subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py"), kind, str(r), "2", str(port), outs[r], "fp32", mode],
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py"), kind, str(r), "2", str(port), outs[r], "fp32", mode,
+                                   "allreduce", exchange],
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
         logs = []
         for p in procs:
@@ -2498,6 +2499,33 @@ def dp_trainers_two_ranks_captured_steps():
 
 
 @case
+def dp_trainers_two_ranks_flush_exchange():
+    """config["dp_exchange"] = "flush" (distributed.FlushExchange: the UNCUT backward pass, every bucket of the flat gradient buffer
+    exchanged behind the flush of the gradient batch that finished it; the plan learned during the first step), 2 ranks over gloo on this
+    GPU: the captured steps (marks = event-record nodes of the graph, exchanges issued behind them after the launch) == the same run
+    launched eagerly, bit for bit; both ranks hold identical parameters; and the parameters agree with the staged exchange's
+    (distributed.OverlappedBackward) up to the summation order of grouped weight-gradient launches."""
+    res = []
+    base = 28500 + (os.getpid() % 150) * 6
+    for j, kind in enumerate(("vtn", "aasvc")):
+        tr, e1 = _dp_two_ranks_run(kind, "trace", base + 3 * j, exchange="flush")
+        gr, e2 = _dp_two_ranks_run(kind, "graph", base + 3 * j + 1, exchange="flush")
+        st, e3 = _dp_two_ranks_run(kind, "trace", base + 3 * j + 2, exchange="stages")
+        ok = tr is not None and gr is not None and st is not None
+        res.append((ok, f"dp flush[{kind}] all six rank processes finished" + ("" if ok else ":\n" + e1 + e2 + e3)))
+        if not ok:
+            continue
+        res.append((bool(torch.equal(gr[0]["flat_p"], gr[1]["flat_p"])) and len(gr[0]["fx_buckets"]) >= 2,
+                    f"dp flush[{kind}] ranks hold identical parameters after {gr[0]['steps']} steps ({gr[0]['fx_flushes']} flushes, buckets "
+                    f"{[round(b / 1e6, 3) for b in gr[0]['fx_buckets']]} MB, {gr[0]['graphs']} graphs per rank)"))
+        d = float((gr[0]["flat_p"] - tr[0]["flat_p"]).abs().max())
+        res.append((bool(torch.equal(gr[0]["flat_p"], tr[0]["flat_p"])), f"dp flush[{kind}] captured == eager: max diff {d:.3e}"))
+        d2 = float((tr[0]["flat_p"] - st[0]["flat_p"]).abs().max())
+        res.append((d2 <= 2e-5, f"dp flush[{kind}] vs the staged exchange after 5 steps: max parameter difference {d2:.3e} (<= 2e-5)"))
+    return res
+
+
+@case
 def dp_trainers_three_ranks_rs_ag():
     """Three ranks (a world size that does not divide the buckets: the reduce-scatter shards are padded) with every bucket
     exchanged as reduce-scatter + all-gather (config["dp_collective"] = "rs_ag"; over gloo the reduce-scatter is emulated,
@@ -2531,7 +2559,7 @@ def bench_two_ranks_on_one_gpu():
         return (json.loads(lines[-1]) if lines else None), r.returncode, r.stderr[-1500:]
 
     for wl, B in (("vtn", 32), ("aasvc", 16)):
-        d, rc, err = run("--gpus", "2", "--dist-backend", "gloo", "--one-device", "--workload", wl, "--steps", "4", "--warmup", "2")
+        d, rc, err = run("--gpus", "2", "--dist-backend", "gloo", "--one-device", "--workload", wl, "--steps", "4", "--warmup", "2", "--stage-mode", "graphs")
         ok = d is not None and rc == 0
         res.append((ok, f"bench.py --gpus 2 ({wl}, gloo, one device): exit code {rc}" + ("" if ok else "\n" + err)))
         if not ok:
@@ -2552,6 +2580,18 @@ def bench_two_ranks_on_one_gpu():
                     f"{wl}: staged backward ({cfg['backward_stages']} stages), payload {cfg['grad_payload']}, buckets {cfg['grad_buckets_MB']} MB"))
         fl = d["final_losses"]
         res.append((all(v == v and abs(v) < 1e6 for v in fl.values()), f"{wl}: finite losses {fl}"))
+    # the default exchange (round 6: --stage-mode flush): the overlapped exchange of a replayed pass == a blocking all-reduce of the same
+    # local gradients, every element of the flat buffer in exactly one bucket
+    for wl in ("vtn", "aasvc"):
+        d, rc, err = run("--gpus", "2", "--dist-backend", "gloo", "--one-device", "--workload", wl, "--steps", "3", "--warmup", "1", "--check-exchange")
+        ok = d is not None and rc == 0
+        res.append((ok, f"bench.py --gpus 2 ({wl}, flush exchange): exit code {rc}" + ("" if ok else "\n" + err)))
+        if ok:
+            c = d["config"]
+            ck = c.get("exchange_check") or {}
+            res.append((c.get("stage_mode") == "flush" and c.get("hip_graph") and ck.get("max_abs_diff") == 0.0 and ck.get("covered_once") and ck.get("buckets", 0) >= 3,
+                        f"{wl}: flush exchange, captured: {ck.get('buckets')} buckets {c.get('grad_buckets_MB')} MB over {ck.get('flushes')} flushes, "
+                        f"max |overlapped - blocking| = {ck.get('max_abs_diff')} (gradients up to {ck.get('grad_abs_max'):.3f}), covered once: {ck.get('covered_once')}"))
     # a WORLD_SIZE that disagrees with --gpus must fail loudly on the GPU box as well
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2,
