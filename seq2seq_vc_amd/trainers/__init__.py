@@ -135,7 +135,8 @@ class Trainer(object):
         self.dist, self.world = dist, dist.get_world_size()
         self.config.setdefault("rank", dist.get_rank())
         D.broadcast_model_(self._net(), self.optimizer, dist, self.world)
-        if isinstance(self.optimizer, FlatAdam) and self.config.get("dp_exchange", "stages") == "flush":
+        exchange = self.config.get("dp_exchange", "flush" if self.config.get("dp_collective", "allreduce") == "allreduce" else "stages")
+        if isinstance(self.optimizer, FlatAdam) and exchange == "flush" and self.optimizer.flat_g.is_cuda:
             # round 6: the UNCUT backward pass, every bucket exchanged behind the flush of the gradient batch that finished it
             # (distributed.FlushExchange): no joins inside the backward pass, buckets at the granularity of the gradient batches
             self.fx = D.FlushExchange(self.optimizer, dist, self.world, payload=self.config.get("dp_grad_payload", self.DP_GRAD_PAYLOAD),

@@ -985,14 +985,23 @@ def trainers_replay_captured_steps():
                 mc = model_cfg(cfg)
                 Fn.enable_side_streams(*((4, False) if kind == "vtn" else (0, True)))
                 data = batches(kind, mc["idim"], mc["odim"], 6, 31)
-                p_t, l_t, _, _ = run(kind, "trace", data, distributed=True)
-                p_g, l_g, _, n_g = run(kind, True, data, distributed=True)
+                st = {"dp_exchange": "stages"}
+                p_t, l_t, _, _ = run(kind, "trace", data, distributed=True, extra=st)
+                p_g, l_g, _, n_g = run(kind, True, data, distributed=True, extra=st)
                 res.append((torch.equal(p_t, p_g) and n_g >= 3, f"{kind}: staged capture ({n_g} graphs), replayed vs traced eager: max diff {float((p_t - p_g).abs().max()):.3e}"))
+                # the default exchange (round 6, distributed.FlushExchange): the uncut backward pass with marks inside ONE graph + the optimiser graph
+                p_tf, _, _, _ = run(kind, "trace", data, distributed=True)
+                p_gf, _, _, n_gf = run(kind, True, data, distributed=True)
+                res.append((torch.equal(p_tf, p_gf) and n_gf >= 2, f"{kind}: flush exchange, captured ({n_gf} graphs) vs traced eager: max diff {float((p_tf - p_gf).abs().max()):.3e}"))
             data = batches("aasvc", mc["idim"], mc["odim"], 12, 43)
-            acc = {"gradient_accumulate_steps": 3, "train_max_steps": 4}
+            acc = {"gradient_accumulate_steps": 3, "train_max_steps": 4, "dp_exchange": "stages"}
             p_t, _, _, _ = run("aasvc", "trace", data, distributed=True, extra=acc)
             p_g, _, s_g, n_g = run("aasvc", True, data, distributed=True, extra=acc)
             res.append((torch.equal(p_t, p_g) and s_g == 4, f"aasvc accumulate 3, staged capture ({n_g} graphs): replayed vs traced eager: max diff {float((p_t - p_g).abs().max()):.3e}"))
+            accf = {"gradient_accumulate_steps": 3, "train_max_steps": 4}
+            p_tf, _, _, _ = run("aasvc", "trace", data, distributed=True, extra=accf)
+            p_gf, _, s_gf, n_gf = run("aasvc", True, data, distributed=True, extra=accf)
+            res.append((torch.equal(p_tf, p_gf) and s_gf == 4, f"aasvc accumulate 3, flush exchange, captured ({n_gf} graphs) vs traced eager: max diff {float((p_tf - p_gf).abs().max()):.3e}"))
         finally:
             dist.destroy_process_group()
     finally:

@@ -17,11 +17,20 @@ prof() {  # prof <dir> <rocprofv3 args...> -- <command...>
 
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py --workload aasvc > "$OUT/bench_aasvc.json" 2>> "$OUT/bench.err"
-python bench.py --force-dist --no-cpu-baseline --stage-times > "$OUT/bench_force_dist.json" 2>> "$OUT/bench.err"
-python bench.py --workload aasvc --force-dist --no-cpu-baseline --stage-times > "$OUT/bench_aasvc_force_dist.json" 2>> "$OUT/bench.err"
-python bench.py --workload aasvc --split-backward --no-cpu-baseline --no-extras --stage-times > "$OUT/bench_aasvc_split_backward.json" 2>> "$OUT/bench.err"
+python bench.py --workload tts --no-extras > "$OUT/bench_tts.json" 2>> "$OUT/bench.err"
+# the data-parallel step at world size 1: mechanism alone (--split-backward: marks, no collectives) and with the FORCED exchange, per stage mode
+for wl in vtn aasvc; do
+  for mode in flush marks graphs; do
+    python bench.py --workload $wl --split-backward --stage-mode $mode --no-cpu-baseline --no-extras > "$OUT/bench_${wl}_split_${mode}.json" 2>> "$OUT/bench.err"
+    python bench.py --workload $wl --force-dist --stage-mode $mode --no-cpu-baseline --no-extras > "$OUT/bench_${wl}_force_dist_${mode}.json" 2>> "$OUT/bench.err"
+  done
+done
+python bench.py --workload aasvc --split-backward --stage-mode flush --min-bucket-mb 1 --no-cpu-baseline --no-extras > "$OUT/bench_aasvc_split_flush_min1.json" 2>> "$OUT/bench.err"
+python bench.py --workload aasvc --split-backward --stage-mode graphs --dp-decoder-stages 3 --no-cpu-baseline --no-extras > "$OUT/bench_aasvc_split_graphs_h3.json" 2>> "$OUT/bench.err"
+python bench.py --workload aasvc --split-backward --stage-mode graphs --no-cpu-baseline --no-extras --stage-times > "$OUT/bench_aasvc_split_backward.json" 2>> "$OUT/bench.err"
 python tools/bench_decode.py > "$OUT/bench_decode.json" 2>> "$OUT/bench.err"
 python tools/kernel_code_sizes.py > "$OUT/kernel_code_sizes.txt" 2>&1
+python tools/aten_in_step.py > "$OUT/aten_in_step.txt" 2>&1
 python tools/gemm_bench.py > "$OUT/gemm_bench.txt" 2>&1
 python tools/gemm8_bench.py > "$OUT/gemm8_bench.txt" 2>&1
 python tools/bench_frontend.py --cpu > "$OUT/bench_frontend.json" 2>> "$OUT/bench.err"
@@ -36,7 +45,7 @@ python tools/rocpd_stats.py "$(db /tmp/prof_aas)" > "$OUT/aasvc_train_bf16_kerne
 python tools/rocpd_timeline.py "$(db /tmp/prof_aas)" 3 > "$OUT/aasvc_train_bf16_timeline.txt" 2>&1
 prof /tmp/prof_dec --kernel-trace --stats -d /tmp/prof_dec -o dec -- python "$R/tools/bench_decode.py" --iters 2
 python tools/rocpd_stats.py "$(db /tmp/prof_dec)" > "$OUT/decode_kernel_stats.txt" 2>&1
-python tools/rocpd_timeline.py "$(db /tmp/prof_dec)" 5 decode_advance > "$OUT/decode_step_timeline.txt" 2>&1
+python tools/rocpd_timeline.py "$(db /tmp/prof_dec)" 5 decode_emit_advance > "$OUT/decode_step_timeline.txt" 2>&1
 
 # dominant kernel of the headline workload (and of AAS-VC): timing + counters
 for wl in vtn aasvc; do
