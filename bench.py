@@ -732,6 +732,7 @@ def bench_aasvc_single(dev, dtype, steps=40, warmup=8, cpu=True, batch=16):
     wl = Workload("aasvc", dev, dtype, batch, 1, 0)
     step, info = build_step(wl, None, 1, False, False, "fp32", True)
     info.pop("_probe", None)
+    info.pop("_check", None)
     dt = time_steps(step, steps, warmup)
     ms = dt / steps * 1e3
     lb = wl.loss_buf.tolist()
@@ -761,6 +762,7 @@ def bench_tts_single(dev, dtype, steps=40, warmup=8, cpu=True, batch=8):
     wl = Workload("tts", dev, dtype, batch, 1, 0)
     step, info = build_step(wl, None, 1, False, False, "fp32", True)
     info.pop("_probe", None)
+    info.pop("_check", None)
     dt = time_steps(step, steps, warmup)
     ms = dt / steps * 1e3
     lb = wl.loss_buf.tolist()
