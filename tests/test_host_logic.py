@@ -558,3 +558,24 @@ def test_torch_library_registration_loads_and_lists_every_schema():
     # every *_bwd op has its forward op, and the differentiable forward ops have an autograd kernel registered
     for fwd in ("ctc_forward_sum", "masked_l1_bce", "guided_attn_loss", "attn_fwd", "ln_residual_dropout"):
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f"s2svc::{fwd}", "Autograd"), fwd
+
+
+def test_committed_step_timelines_hold_no_aten_kernels():
+    """a captured training step launches no ATen kernel -- checked on the kernel-name lists of the committed rocprofv3
+    timelines of this round (tools/rocpd_timeline.py over `bench.py` under rocprofv3 --kernel-trace).  The one exception is the draw of the
+    stochastic duration predictor (duration_predictor.py:247-254: torch.randn): its normal_ kernel and the two int64 fills with which
+    torch's graph-safe generator hands seed and offset to a replay."""
+    prof = os.path.join(ROOT, "profiles")
+    allowed = ("distribution_elementwise_grid_stride_kernel", "FillFunctorIl")
+    seen = {}
+    for wl, budget in (("vtn", 0), ("aasvc", 3)):
+        path = os.path.join(prof, f"r06_{wl}_train_bf16_timeline.txt")
+        assert os.path.exists(path), path
+        lines = [ln for ln in open(path) if "at6native" in ln or "at::native" in ln]
+        bad = [ln.strip()[-120:] for ln in lines if not any(a in ln for a in allowed)]
+        assert not bad, f"{wl}: ATen kernels in the captured step: {bad[:5]}"
+        assert len(lines) <= budget, f"{wl}: {len(lines)} ATen launches (allowed {budget})"
+        seen[wl] = len(lines)
+        n = [ln for ln in open(path) if ln.startswith("# step:")]
+        assert n, "timeline header missing"
+    assert seen == {"vtn": 0, "aasvc": seen["aasvc"]}
