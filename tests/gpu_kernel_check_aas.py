@@ -474,6 +474,23 @@ def embedding_and_duration_loss(dtype):
         yr.backward(dy.float())
         res.append(check(f"embedding dW[{dtype}]", w.grad, wr.grad, dtype, atol=1e-5 if dtype == torch.float32 else 0.1))
         res.append(check(f"embedding dW[padding_idx] == 0 [{dtype}]", w.grad[0], torch.zeros(D), torch.float32, atol=0.0))
+        # the C4 shape and a long token list (several 2048-token rounds of the in-order compaction, a vocabulary row with thousands of
+        # hits, D that is not a multiple of 256): sums in token order, i.e. bit-exact against a sequential fp32 reference
+        for (Vv, Dd, n_tok, seed) in [(78, 384, 8 * 151, 5), (11, 300, 5003, 6)]:
+            g2 = torch.Generator().manual_seed(seed)
+            ix = torch.randint(0, Vv, (1, n_tok), generator=g2)
+            ix[0, ::3] = 1                                       # a heavy row
+            w2 = rnd(Vv, Dd, seed=seed).requires_grad_(True)
+            y2 = Fn.embedding(ix.to(DEV), w2, 0)
+            dy2 = rnd(1, n_tok, Dd, seed=seed + 1, dtype=dtype)
+            y2.backward(dy2)
+            ref = torch.zeros(Vv, Dd)
+            dyc = dy2.float().cpu()[0]
+            for i in range(n_tok):                               # sequential, in token order (fp32)
+                v_ = int(ix[0, i])
+                if v_ != 0:
+                    ref[v_] += dyc[i]
+            res.append((bool(torch.equal(w2.grad.cpu(), ref)), f"embedding dW[{dtype}] V{Vv} D{Dd} n{n_tok}: bit-exact against the sequential sum in token order"))
     finally:
         Fn.set_compute_dtype(torch.float32)
     if dtype == torch.float32:
