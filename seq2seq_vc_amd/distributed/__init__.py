@@ -344,8 +344,9 @@ class FlushExchange:
         ... capture or run `run()` with fx.recording(): marks behind every flush, fx.mark_end() behind the join ...
         fx.issue(); fx.finish()        # after the graph's launch (or the eager pass): exchanges behind their marks, then the join
 
-    The plan (which ranges travel behind which flush) is rank 0's, broadcast: every rank issues the same collectives in the same
-    order whatever its data.  A change of the schedule (batch size, streams, model) needs a new learn()."""
+    The plan (which ranges travel behind which flush) is the same on every rank -- a parameter counts as final behind the latest
+    flush that changed it on ANY rank (a MAX all-reduce of the learned table) -- so every rank issues the same collectives in the
+    same order whatever its data.  A change of the schedule (batch size, streams, model) needs a new learn()."""
 
     def __init__(self, optimizer, dist, world, payload="fp32", chunk_numel=32 * 1024 * 1024, group=None, force=False,
                  min_bucket_numel=4 * 1024 * 1024):
@@ -458,14 +459,18 @@ class FlushExchange:
         los, his = self._los, self._his
         torch.cuda.synchronize()
         self.n_flushes = self.n
+        if self.dist is not None and self.world > 1:
+            # ONE plan for every rank (identical collectives in identical order), safe for every rank's data: a parameter is final
+            # behind the LATEST flush that changed it on ANY rank (a contribution that happens to be exactly zero on one rank -- dead
+            # units, an absent branch -- must not let that rank's view release the bucket early)
+            info = torch.cat([self.last_change, torch.tensor([self.n_flushes, -self.n_flushes], dtype=torch.int64, device=self.last_change.device)])
+            self.dist.all_reduce(info, op=self.dist.ReduceOp.MAX, group=self.group)
+            nmax, nmin = int(info[-2]), -int(info[-1])
+            if nmax != self.n_flushes or nmin != self.n_flushes:
+                raise RuntimeError(f"FlushExchange: the ranks flush different numbers of gradient batches ({nmin} .. {nmax})")
+            self.last_change = info[:-2]
         last = self.last_change.tolist()
         self.snap = self.last_change = None
-        if self.dist is not None and self.world > 1:               # rank 0's plan for everybody: identical collectives on every rank
-            box = [last, self.n_flushes]
-            self.dist.broadcast_object_list(box, src=0, group=self.group)
-            if box[1] != self.n_flushes:
-                raise RuntimeError("FlushExchange: the ranks flush different numbers of gradient batches")
-            last = box[0]
         # ranges per flush ordinal; parameters no flush touched (or touched behind the last flush) travel behind the join
         by_flush = {}
         for (lo, hi), n in zip(zip(los, his), last):
