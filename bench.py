@@ -1256,8 +1256,19 @@ def main():
         args.grad_payload = (TR.AASVCTrainer if args.workload == "aasvc" else TR.ARVCTrainer).DP_GRAD_PAYLOAD
     if args.dp_decoder_stages:
         wl.model.dp_decoder_stages = args.dp_decoder_stages      # AAS-VC: decoder layers with a stage (= a bucket) of their own
-    step, info = build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
-                            warmup_eager=max(2, args.warmup if args.no_graph else 2), stage_mode=args.stage_mode, min_bucket_mb=args.min_bucket_mb)
+    def build(stage_mode):
+        return build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
+                          warmup_eager=max(2, args.warmup if args.no_graph else 2), stage_mode=stage_mode, min_bucket_mb=args.min_bucket_mb)
+    try:
+        step, info = build(args.stage_mode)
+    except Exception as e:  # noqa: BLE001 -- the flush exchange has only ever run on one GPU: fall back to the stage graphs of rounds 2-5, loudly
+        if not (staged and args.stage_mode == "flush"):
+            raise
+        print(f"[bench] --stage-mode flush failed ({type(e).__name__}: {e}); falling back to --stage-mode graphs", file=sys.stderr)
+        torch.cuda.synchronize()
+        wl.Fn._Side.on_flush = None
+        step, info = build("graphs")
+        info["stage_mode_fallback_from"] = "flush"
     probe = info.pop("_probe")
     check = info.pop("_check")
     dt = time_steps(step, args.steps, args.warmup, dist if dp else None, dev)
