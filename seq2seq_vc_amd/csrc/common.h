@@ -44,8 +44,8 @@ template <typename T> __device__ __forceinline__ void stf(T* p, float v) { Cvt<T
 // (even rows, even rows) / (odd rows, odd rows), resp. (low half, low half) / (high half, high half)): VALU instructions, and the
 // SAME partners in the SAME order as the butterflies they replace, so every sum keeps its bits.  ALL 64 LANES MUST BE ACTIVE (they
 // are: every caller reduces under wave-uniform control flow): with an inactive partner a swap returns the lane's own value twice
-// (ds_bpermute returned 0), so a partial-wave sum would double-count.  A build with -DS2SVC_DEBUG_EXEC (S2SVC_DEBUG_EXEC=1 in the
-// environment of _lib.build_library; tests/gpu_kernel_check.py: debug_exec_build_runs_clean) traps in swap16 / swap32 / the DPP moves
+// (ds_bpermute returned 0), so a partial-wave sum would double-count.  A build with -DS2SVC_DEBUG_EXEC (_lib.build_library(debug_exec=True)
+// -> libs2svc_hip_dbgexec.so, made by __graft_entry__.build(); tests/gpu_kernel_check.py: debug_exec_build_runs_clean) traps in swap16 / swap32 / the DPP moves
 // when EXEC is not all ones.
 #ifdef S2SVC_DEBUG_EXEC
 #define S2S_ASSERT_FULL_EXEC()                                              \

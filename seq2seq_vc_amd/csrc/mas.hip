@@ -19,7 +19,8 @@
 namespace {
 
 // q of the lane below, for the dependent chain of the search: two 32-bit DPP moves instead of two ds_bpermute (~10 instead of
-// ~100 cycles per column of the recursion).  Lane 0 keeps its own value (the caller overwrites it).
+// ~100 cycles per column of the recursion).  Lane 0 keeps its own value (the caller overwrites it).  Like the reductions of common.h
+// this is a DPP move: every lane of the wave must be active where it is called (the kernel is one full wave under uniform control flow).
 __device__ __forceinline__ double wave_shr1_d(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
   const int slo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);      // wave_shr:1
