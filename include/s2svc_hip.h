@@ -504,6 +504,26 @@ int s2svc_relattn_fwd(int B, int H, int T, int dk, const void* q, int64_t ldq, i
                       void* stream);
 
 /* ========================================================================================== */
+/* Attention map of plain multi-head attention, medium sequences (csrc/attn_map.hip): bf16,   */
+/* T2 <= 512 keys, d_k % 32 == 0.  replaces: modules/transformer/attention.py:63-93 (scores / */
+/* sqrt(d_k), masked_fill(min), softmax, masked_fill(0), dropout) as one launch; the context   */
+/* P.V stays a GEMM.  q (B, T1, .) / k (B, T2, .) views (row strides ldq / ldk, batch strides  */
+/* qbs / kbs, head h at columns h * dk); klen (B) int32 or NULL; causal: keys j <= i only;     */
+/* attn / pdrop (B, H, T1, ld) bf16, ld = T2 rounded up to 8, pad columns zero (pdrop = the    */
+/* dropped copy, NULL when drop_p == 0); masks as s2svc_attn_softmax_fwd draws them.           */
+/* ========================================================================================== */
+int s2svc_attn_map_supported(int dtype, int T1, int T2, int dk);
+int s2svc_attn_map_fwd(int B, int H, int T1, int T2, int dk, const void* q, int64_t ldq, int64_t qbs, const void* k, int64_t ldk,
+                       int64_t kbs, const int32_t* klen, int causal, float scale, float drop_p, const uint64_t* seed_base,
+                       uint64_t seed_off, void* attn, void* pdrop, int ld, void* stream);
+/* backward of the same up to the gradient of the scaled scores: ds = attn * (dP * mask + dattn - rowsum(attn * (dP * mask + dattn)))  */
+/* * scale with dP = dctx . v^T computed on chip (replaces one batched GEMM + s2svc_attn_softmax_bwd); dctx (B, T1, .) / v (B, T2, .)  */
+/* views, attn the stored map, dattn the gradient that reached the map itself (or NULL), ds (B, H, T1, ld) bf16, pad columns zero.     */
+int s2svc_attn_map_bwd(int B, int H, int T1, int T2, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv,
+                       int64_t vbs, const void* attn, const void* dattn, float scale, float drop_p, const uint64_t* seed_base,
+                       uint64_t seed_off, void* ds, int ld, void* stream);
+
+/* ========================================================================================== */
 /* Token embedding of Transformer-TTS (models/transformer_tts.py:63-77, Embedding(idim, adim, */
 /* padding_idx=0)): y[i,:] = W[idx[i],:] ; dW[v,:] = sum_{idx[i]==v} dy[i,:], dW[padding]=0     */
 /* ========================================================================================== */

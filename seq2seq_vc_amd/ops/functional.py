@@ -937,10 +937,14 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
         KAT.fused_bwd(q, k, v, dctx, attn, _pad_like(dattn, attn), H, scale, p, seed, dq, dkk, dv)
         return dq, dkk, dv, None
     gkc, grc, keep = groups if groups is not None else ([], [], [])
-    # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
-    dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
-    ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode, dattn=_pad_like(dattn, attn), T2=T2,
-                                 ldb=ldb)
+    if not Lp and attn.is_contiguous() and KAT.map_supported(dctx, v, H):
+        # up to 512 keys, bf16: dP = dctx . v^T and the softmax backward in ONE launch, dP never in memory (csrc/attn_map.hip)
+        ds, dbd = KAT.map_bwd(dctx, v, attn, _pad_like(dattn, attn), H, scale, p, seed), None
+    else:
+        # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
+        dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
+        ds, dbd = K.attn_softmax_bwd(attn, dp, scale, p=p, seed=seed, Lp=Lp, rel_mode=rel_mode, dattn=_pad_like(dattn, attn), T2=T2,
+                                     ldb=ldb)
     # dV[b,j,hd] = sum_i pm[b,h,i,j] dctx[b,i,hd]
     _into(dv, _pop(pm, T1, H, K.RC), _bop(dctx, dk, K.RC), T2, dk, T1, dk, dtype, B, H, group=grc)
     # dQ[b,i,hd] = sum_j dS[b,h,i,j] k[b,j,hd]
@@ -977,8 +981,11 @@ def _attn_fwd_views(q, k, v, klen, causal, H, p):
     if KAT.supported(q, k, v, H):       # short sequences, bf16: scores + mask + softmax + dropout + P.V in ONE launch
         out, attn = KAT.fused_fwd(q, k, v, klen, causal, H, scale, p, seed)
         return out, attn, _FUSED, scale, seed
-    scores = _qk(q, k, B, H, T1, T2, dk, D, dtype)
-    attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed, T2=T2)
+    if KAT.map_supported(q, k, H):      # up to 512 keys, bf16: scores + mask + softmax + dropout in ONE launch (csrc/attn_map.hip)
+        attn, pdrop = KAT.map_fwd(q, k, klen, causal, H, scale, p, seed)
+    else:
+        scores = _qk(q, k, B, H, T1, T2, dk, D, dtype)
+        attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed, T2=T2)
     out = _pv(pdrop if pdrop is not None else attn, v, B, H, T1, T2, dk, D, dtype)
     return out, attn, pdrop, scale, seed
 

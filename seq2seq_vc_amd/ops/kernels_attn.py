@@ -54,6 +54,48 @@ def fused_bwd(q, k, v, dout, attn, dattn, H, scale, p, seed, dq, dk_out, dv):
 
 
 # ----------------------------------------------------------------------------------------------
+# attention map of plain attention in one launch, T2 <= 512 (csrc/attn_map.hip)
+# ----------------------------------------------------------------------------------------------
+_MAP_DISABLED = os.environ.get("S2SVC_NO_ATTNMAP", "0") == "1"       # (the switch: A/B against scores GEMM + softmax kernel)
+
+
+def map_supported(q, k, H):
+    if _MAP_DISABLED or q.dtype != torch.bfloat16:
+        return False
+    dk = q.shape[-1] // H
+    if not _lib.lib().s2svc_attn_map_supported(_DT[q.dtype], q.shape[1], k.shape[1], dk):
+        return False
+    return _strided_ok(q) and _strided_ok(k)
+
+
+def map_fwd(q, k, klen, causal, H, scale, p, seed):
+    """q (B,T1,D), k (B,T2,D) (possibly column slices of packed projections) -> attn, pdrop (B,H,T1,ld) (pdrop None when p == 0)."""
+    B, T1, D = q.shape
+    T2 = k.shape[1]
+    dk = D // H
+    ld = (T2 + 7) // 8 * 8
+    attn = torch.empty((B, H, T1, ld), dtype=q.dtype, device=q.device)
+    pdrop = torch.empty_like(attn) if p > 0.0 else None
+    _lib.check(_lib.lib().s2svc_attn_map_fwd(B, H, T1, T2, dk, ptr(q), q.stride(1), q.stride(0), ptr(k), k.stride(1), k.stride(0),
+                                             ptr(klen), 1 if causal else 0, scale, p, seed[0], seed[1], ptr(attn), ptr(pdrop), ld,
+                                             stream()), "attn_map_fwd")
+    return attn, pdrop
+
+
+def map_bwd(dctx, v, attn, dattn, H, scale, p, seed):
+    """dctx (B,T1,D), v (B,T2,D) views; attn (and dattn or None) (B,H,T1,ld) -> gradient of the scaled scores (B,H,T1,ld)."""
+    B, T1, D = dctx.shape
+    T2 = v.shape[1]
+    ld = attn.shape[-1]
+    if dattn is not None and (dattn.shape != attn.shape or not dattn.is_contiguous()):
+        raise ValueError("attention map backward: dattn must have the stored map's padded layout")
+    ds = torch.empty_like(attn)
+    _lib.check(_lib.lib().s2svc_attn_map_bwd(B, H, T1, T2, D // H, ptr(dctx), dctx.stride(1), dctx.stride(0), ptr(v), v.stride(1), v.stride(0),
+                                             ptr(attn), ptr(dattn), scale, p, seed[0], seed[1], ptr(ds), ld, stream()), "attn_map_bwd")
+    return ds
+
+
+# ----------------------------------------------------------------------------------------------
 # relative-position self-attention, T <= 256 (csrc/relattn.hip)
 # ----------------------------------------------------------------------------------------------
 

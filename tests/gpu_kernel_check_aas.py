@@ -316,6 +316,109 @@ def rel_attention_fused_vs_separate():
 
 
 @case
+def attention_map_one_launch_vs_separate():
+    """csrc/attn_map.hip (plain attention, up to 512 keys, bf16: scores + mask + softmax + dropout in one launch) against fp32 torch math
+    on the same bf16 inputs (attention.py:63-93) and -- same seeds => same dropout masks -- against scores GEMM + softmax kernel; then
+    the self- and source-attention Functions (forward through either path, the same backward) with the kernel on and off."""
+    from seq2seq_vc_amd.ops import functional as Fn
+    from seq2seq_vc_amd.ops import kernels_attn as KAT
+    res = []
+    bf = torch.bfloat16
+    #            B  H  T1   T2   dk  causal
+    shapes = [(3, 4, 151, 151, 96, False), (3, 4, 320, 320, 96, True), (2, 4, 320, 151, 96, False), (2, 2, 70, 100, 64, False),
+              (2, 2, 200, 65, 32, False), (1, 3, 37, 512, 64, False), (2, 2, 400, 400, 64, True), (2, 1, 129, 257, 128, False),
+              (1, 2, 1, 300, 32, False), (2, 2, 66, 9, 32, False)]
+    for n, (B, H, T1, T2, dk, causal) in enumerate(shapes):
+        D = H * dk
+        tag = f"attn-map B{B} H{H} T1 {T1} T2 {T2} dk{dk}{' causal' if causal else ''}"
+        q = rnd(B, T1, D, seed=900 + n, dtype=bf, scale=0.8)
+        kv = rnd(B, T2, 2 * D, seed=950 + n, dtype=bf, scale=0.8)
+        k = kv[..., :D]                                            # a column block of a packed projection, as the models hand it over
+        klen = torch.tensor([T2, max(1, T2 - 7), max(1, T2 // 2)][:B], dtype=torch.int32, device=DEV)
+        scale = 1 / math.sqrt(dk)
+        ok_shape = KAT.map_supported(q, k, H)
+        res.append((ok_shape, f"{tag}: takes the one-launch kernel"))
+        if not ok_shape:
+            continue
+        qh = q.float().view(B, T1, H, dk).transpose(1, 2)
+        kh = k.float().reshape(B, T2, H, dk).transpose(1, 2)
+        mask = torch.arange(T2, device=DEV)[None, None, None, :] < klen[:, None, None, None]
+        if causal:
+            mask = mask & (torch.arange(T2, device=DEV)[None, :] <= torch.arange(T1, device=DEV)[:, None])[None, None]
+        sc = (qh @ kh.transpose(-1, -2) * scale).masked_fill(~mask, torch.finfo(torch.float32).min)
+        prob = torch.softmax(sc, -1).masked_fill(~mask, 0.0)
+        for p in (0.0, 0.1):
+            K.manual_seed(77)
+            seed = K.new_seed(q.device) if p > 0 else (None, 0)
+            a1, d1 = KAT.map_fwd(q, k, klen, causal, H, scale, p, seed)
+            scores = Fn._qk(q, k, B, H, T1, T2, dk, D, bf)
+            a0, d0 = K.attn_softmax_fwd(scores, bf, scale, klen=klen, causal=causal, p=p, seed=seed, T2=T2)
+            e1, e0 = _rel_l2(a1[..., :T2], prob), _rel_l2(a0[..., :T2], prob)
+            res.append((e1 <= 1e-2 and e1 <= 1.5 * e0 + 1e-3, f"{tag} p={p} map: rel-L2 vs fp32 torch {e1:.2e} (separate kernels {e0:.2e})"))
+            res.append((bool((a1[..., T2:] == 0).all()) and bool(((a1 == 0) == (a0 == 0))[..., :T2].float().mean() > 0.999),
+                        f"{tag} p={p}: pad columns zero, masked positions agree"))
+            if p > 0:
+                # the masks are a function of (seed, element index): wherever both maps are non-zero the dropped copies agree on kept / dropped
+                both = (a1 != 0) & (a0 != 0)
+                agree = bool((((d1 == 0) == (d0 == 0)) | ~both).all())
+                kept = float((d1[both] != 0).float().mean())
+                res.append((agree and abs(kept - (1 - p)) < 0.02, f"{tag} p={p}: same dropout masks as the softmax kernel: {agree}, kept {kept:.3f}"))
+                res.append((_rel_l2(d1, d0) <= 1.5e-2, f"{tag} p={p} dropped copy: rel-L2 vs separate {_rel_l2(d1, d0):.2e}"))
+            # backward kernel: dS from (d context, v, the stored map[, a gradient on the map itself]) vs batched GEMM + softmax-backward kernel
+            v = kv[..., D:]
+            dctx = rnd(B, T1, D, seed=970 + n, dtype=bf)
+            for with_dattn in (False, True):
+                da = (rnd(B, H, T1, a0.shape[-1], seed=990 + n, dtype=bf, scale=0.5) * (a0 != 0)) if with_dattn else None
+                ds1 = KAT.map_bwd(dctx, v, a0, da, H, scale, p, seed)
+                dp = Fn._qk(dctx, v, B, H, T1, T2, dk, D, bf)
+                ds0, _ = K.attn_softmax_bwd(a0, dp, scale, p=p, seed=seed, dattn=da, T2=T2)
+                # fp32 torch on the same stored map / masks: dS = P (t - sum P t) scale, t = dP mask + dattn
+                keepm = torch.where(a0 != 0, d0.float() / a0.float().clamp_min(1e-30), torch.zeros((), device=DEV)) if p > 0 else torch.ones_like(a0, dtype=torch.float32)
+                keepm = torch.where(keepm > 0.5, torch.full_like(keepm, 1 / (1 - p)), torch.zeros_like(keepm)) if p > 0 else keepm
+                vh = v.float().reshape(B, T2, H, dk).transpose(1, 2)
+                dph = dctx.float().view(B, T1, H, dk).transpose(1, 2) @ vh.transpose(-1, -2)
+                t_ = dph * keepm[..., :T2] + (da.float()[..., :T2] if with_dattn else 0.0)
+                P_ = a0.float()[..., :T2]
+                dsr = P_ * (t_ - (P_ * t_).sum(-1, keepdim=True)) * scale
+                e1, e0 = _rel_l2(ds1[..., :T2], dsr), _rel_l2(ds0[..., :T2], dsr)
+                res.append((e1 <= 1e-2 and e1 <= 1.5 * e0 + 1e-3 and bool((ds1[..., T2:] == 0).all()),
+                            f"{tag} p={p} dS{' (+ d map)' if with_dattn else ''}: rel-L2 vs fp32 torch {e1:.2e} (separate kernels {e0:.2e}), pad columns zero"))
+    # through the Functions: forward by either path, one backward
+    def run(fn, on, *xs):
+        KAT._MAP_DISABLED = not on
+        K.manual_seed(55)
+        K.reset_op_counter()
+        ys = [x.clone().requires_grad_(True) for x in xs]
+        o, a = fn(*ys)
+        ((o.float() * dy.float()).sum() + (a.float() * wa).sum()).backward()       # (a loss on the map itself, as guided attention has)
+        return [o.detach(), a.detach()] + [y.grad for y in ys]
+    was = KAT._MAP_DISABLED
+    try:
+        for (B, H, T1, T2, dk, causal, p) in [(3, 4, 151, 151, 96, False, 0.1), (3, 4, 320, 320, 96, True, 0.1), (3, 4, 320, 151, 96, False, 0.1),
+                                              (2, 2, 100, 100, 64, False, 0.0)]:
+            D = H * dk
+            klen = torch.tensor([T2, max(1, T2 - 7), max(1, T2 // 2)][:B], dtype=torch.int32, device=DEV)
+            dy = rnd(B, T1, D, seed=7, dtype=bf)
+            wa = rnd(B, H, T1, T2, seed=6, scale=0.5) if p > 0 else torch.zeros((), device=DEV)
+            if T1 == T2:
+                qkv = rnd(B, T1, 3 * D, seed=8, dtype=bf, scale=0.8)
+                r1 = run(lambda x: Fn.attention_packed_qkv(x, klen, causal, H, p), True, qkv)
+                r0 = run(lambda x: Fn.attention_packed_qkv(x, klen, causal, H, p), False, qkv)
+                names = ("out", "attn", "d qkv")
+            else:
+                q, kv = rnd(B, T1, D, seed=9, dtype=bf, scale=0.8), rnd(B, T2, 2 * D, seed=10, dtype=bf, scale=0.8)
+                r1 = run(lambda x, y: Fn.attention_packed_kv(x, y, klen, causal, H, p), True, q, kv)
+                r0 = run(lambda x, y: Fn.attention_packed_kv(x, y, klen, causal, H, p), False, q, kv)
+                names = ("out", "attn", "d q", "d kv")
+            for nm, g1, g0 in zip(names, r1, r0):
+                e = _rel_l2(g1, g0)
+                res.append((e <= 2e-2, f"attention Function T1 {T1} T2 {T2} p={p}{' causal' if causal else ''} {nm}: one launch vs separate rel-L2 {e:.2e}"))
+    finally:
+        KAT._MAP_DISABLED = was
+    return res
+
+
+@case
 @both_dtypes
 def pairwise_distance_logsoftmax(dtype):
     res = []

@@ -491,10 +491,11 @@ def training_steps_equivalence_fp32():
 
 @case
 def environment_switches_keep_the_step():
-    """Every environment switch the library still reads (round 6: 11) that changes WHERE or HOW a step runs is flipped
+    """Every environment switch the library still reads (round 6: 12) that changes WHERE or HOW a step runs is flipped
     here on a whole AAS-VC / VTN training run of bench.py in a child process: the losses after 3 optimiser steps equal the default
     run's (the schedule changes, the arithmetic does not; split-K vs one-pass grouped launches differ <= 1e-6 relative).
-    S2SVC_LIB / S2SVC_NO_RELATTN / S2SVC_NO_CONVMOD / S2SVC_NO_BN_VEC are flipped by the kernel cases, S2SVC_REFERENCE /
+    S2SVC_LIB / S2SVC_NO_RELATTN / S2SVC_NO_ATTNMAP (as kernels_attn._MAP_DISABLED) / S2SVC_NO_CONVMOD / S2SVC_NO_BN_VEC are flipped by the
+    kernel cases, S2SVC_REFERENCE /
     S2SVC_BENCH_SPAWNED by tools/gen_golden.py and bench.py's launcher."""
     import json
     import subprocess

@@ -43,6 +43,9 @@ python tools/rocpd_timeline.py "$(db /tmp/prof_step)" 3 > "$OUT/vtn_train_bf16_t
 prof /tmp/prof_aas --kernel-trace --stats -d /tmp/prof_aas -o aas -- python "$R/bench.py" --workload aasvc --no-cpu-baseline --steps 24 --warmup 3
 python tools/rocpd_stats.py "$(db /tmp/prof_aas)" > "$OUT/aasvc_train_bf16_kernel_stats.txt" 2>&1
 python tools/rocpd_timeline.py "$(db /tmp/prof_aas)" 3 > "$OUT/aasvc_train_bf16_timeline.txt" 2>&1
+prof /tmp/prof_tts --kernel-trace --stats -d /tmp/prof_tts -o tts -- python "$R/bench.py" --workload tts --no-cpu-baseline --no-extras --steps 24 --warmup 3
+python tools/rocpd_stats.py "$(db /tmp/prof_tts)" > "$OUT/tts_train_bf16_kernel_stats.txt" 2>&1
+python tools/rocpd_timeline.py "$(db /tmp/prof_tts)" 3 > "$OUT/tts_train_bf16_timeline.txt" 2>&1
 prof /tmp/prof_dec --kernel-trace --stats -d /tmp/prof_dec -o dec -- python "$R/tools/bench_decode.py" --iters 2
 python tools/rocpd_stats.py "$(db /tmp/prof_dec)" > "$OUT/decode_kernel_stats.txt" 2>&1
 python tools/rocpd_timeline.py "$(db /tmp/prof_dec)" 5 decode_emit_advance > "$OUT/decode_step_timeline.txt" 2>&1
