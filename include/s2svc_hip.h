@@ -519,9 +519,11 @@ int s2svc_attn_map_fwd(int B, int H, int T1, int T2, int dk, const void* q, int6
 /* backward of the same up to the gradient of the scaled scores: ds = attn * (dP * mask + dattn - rowsum(attn * (dP * mask + dattn)))  */
 /* * scale with dP = dctx . v^T computed on chip (replaces one batched GEMM + s2svc_attn_softmax_bwd); dctx (B, T1, .) / v (B, T2, .)  */
 /* views, attn the stored map, dattn the gradient that reached the map itself (or NULL), ds (B, H, T1, ld) bf16, pad columns zero.     */
+/* dbd != NULL: relative-position self-attention (attention.py:237-260 "new" rel_shift, T1 == T2): dbd (B, H, T1, ldb) bf16 receives   */
+/* the gradient of matrix_bd BEFORE the shift (dbd[b,h,i,T1-1-i+j] = ds[b,h,i,j], zero elsewhere; ldb >= 2 T1 - 1, a multiple of 8).   */
 int s2svc_attn_map_bwd(int B, int H, int T1, int T2, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv,
                        int64_t vbs, const void* attn, const void* dattn, float scale, float drop_p, const uint64_t* seed_base,
-                       uint64_t seed_off, void* ds, int ld, void* stream);
+                       uint64_t seed_off, void* ds, int ld, void* dbd, int ldb, void* stream);
 
 /* ========================================================================================== */
 /* Token embedding of Transformer-TTS (models/transformer_tts.py:63-77, Embedding(idim, adim, */

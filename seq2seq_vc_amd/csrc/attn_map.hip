@@ -31,6 +31,9 @@ struct am_args {
   bf16_t* attn; bf16_t* pdrop;
   // backward (MODE 1): q = d context, k = v; p_in the stored map, dattn the gradient that reached the map itself (or NULL), ds the output
   const bf16_t* p_in; const bf16_t* dattn; bf16_t* ds;
+  // ... and, for relative-position attention (T1 == T2, the "new" rel_shift), the same values where the shift took them from:
+  // dbd[b, h, i, T1 - 1 - i + j] = dS[b, h, i, j], every other element of the (B, H, T1, ldb) tensor zero
+  bf16_t* dbd; int ldb;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -262,6 +265,24 @@ __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
       if (MODE == 0 && a.pdrop) *reinterpret_cast<uint4*>(a.pdrop + o) = *reinterpret_cast<const uint4*>(rowA + SP + c8 * 8);
     }
   }
+  if (MODE == 1 && a.dbd) {                           // whole rows, zeros included: no fill launch in front of this kernel
+    const int nvb = a.ldb >> 3;
+    for (int n = t; n < 64 * nvb; n += NT) {
+      const int row = n / nvb, c8 = n - row * nvb;
+      const int i = i0 + row;
+      if (i >= T1) break;
+      const unsigned short* rowA = reinterpret_cast<const unsigned short*>(S + row * SP);
+      const int j0 = c8 * 8 - (T1 - 1 - i);
+      uint32_t o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ja = j0 + 2 * e, jb = ja + 1;
+        const uint32_t lo = (ja >= 0 && ja < T2) ? rowA[ja] : 0u, hi = (jb >= 0 && jb < T2) ? rowA[jb] : 0u;
+        o4[e] = lo | (hi << 16);
+      }
+      *reinterpret_cast<uint4*>(a.dbd + ((int64_t)bh * T1 + i) * a.ldb + c8 * 8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    }
+  }
 }
 
 bool am_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -305,7 +326,7 @@ extern "C" int s2svc_attn_map_fwd(int B, int H, int T1, int T2, int dk, const vo
   a.q = (const bf16_t*)q; a.ldq = ldq; a.qbs = qbs; a.k = (const bf16_t*)k; a.ldk = ldk; a.kbs = kbs;
   a.klen = klen; a.causal = causal; a.scale = scale; a.p = drop_p; a.seed_base = seed_base; a.seed_off = seed_off;
   a.attn = (bf16_t*)attn; a.pdrop = drop_p > 0.f ? (bf16_t*)pdrop : nullptr;
-  a.p_in = nullptr; a.dattn = nullptr; a.ds = nullptr;
+  a.p_in = nullptr; a.dattn = nullptr; a.ds = nullptr; a.dbd = nullptr; a.ldb = 0;
   const int rc = T2 <= 128 ? am_launch<2, 0>(a, B, (hipStream_t)stream) : T2 <= 256 ? am_launch<4, 0>(a, B, (hipStream_t)stream) : am_launch<8, 0>(a, B, (hipStream_t)stream);
   if (rc) return rc;
   S2S_CHECK_LAUNCH("attn_map_kernel<fwd>");
@@ -315,9 +336,12 @@ extern "C" int s2svc_attn_map_fwd(int B, int H, int T1, int T2, int dk, const vo
 // The gradient of the scaled scores in one launch: dS = P (dP mask + dattn - rowsum(P (dP mask + dattn))) scale with dP = dctx . v^T
 // never leaving the chip.  dctx (B, T1, .) / v (B, T2, .) views as q / k above; attn (B, H, T1, ld) the stored map; dattn the gradient
 // that reached the map itself (same layout) or NULL; ds (B, H, T1, ld) bf16 out (pad columns zero); masks regenerated from the seed.
+// dbd != NULL (relative-position self-attention, T1 == T2, "new" rel_shift): dbd (B, H, T1, ldb) bf16, ldb >= 2 T1 - 1 a multiple of 8,
+// receives dS at the positions the shift read (dbd[b, h, i, T1 - 1 - i + j] = dS[b, h, i, j]) and zeros elsewhere.
 extern "C" int s2svc_attn_map_bwd(int B, int H, int T1, int T2, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv,
                                   int64_t vbs, const void* attn, const void* dattn, float scale, float drop_p, const uint64_t* seed_base,
-                                  uint64_t seed_off, void* ds, int ld, void* stream) {
+                                  uint64_t seed_off, void* ds, int ld, void* dbd, int ldb, void* stream) {
+  S2S_REQUIRE(!dbd || (T1 == T2 && ldb >= 2 * T1 - 1 && ldb % 8 == 0 && am_al16(dbd)), "attn_map_bwd: dbd needs T1 == T2, ldb >= 2 T1 - 1, ldb % 8 == 0");
   S2S_REQUIRE(s2svc_attn_map_supported(S2S_BF16, T1, T2, dk), "attn_map_bwd: bf16, T2 <= 512, d_k % 32 == 0");
   S2S_REQUIRE(B >= 0 && H > 0 && dctx && v && attn && ds && ld >= T2 && ld % 8 == 0 && ld <= ((T2 + 63) / 64) * 64 && drop_p < 1.f, "attn_map_bwd: bad args");
   S2S_REQUIRE(ldo % 8 == 0 && obs % 8 == 0 && ldv % 8 == 0 && vbs % 8 == 0 && am_al16(dctx) && am_al16(v) && am_al16(ds),
@@ -328,7 +352,7 @@ extern "C" int s2svc_attn_map_bwd(int B, int H, int T1, int T2, int dk, const vo
   a.q = (const bf16_t*)dctx; a.ldq = ldo; a.qbs = obs; a.k = (const bf16_t*)v; a.ldk = ldv; a.kbs = vbs;
   a.klen = nullptr; a.causal = 0; a.scale = scale; a.p = drop_p; a.seed_base = seed_base; a.seed_off = seed_off;
   a.attn = nullptr; a.pdrop = nullptr;
-  a.p_in = (const bf16_t*)attn; a.dattn = (const bf16_t*)dattn; a.ds = (bf16_t*)ds;
+  a.p_in = (const bf16_t*)attn; a.dattn = (const bf16_t*)dattn; a.ds = (bf16_t*)ds; a.dbd = (bf16_t*)dbd; a.ldb = ldb;
   const int rc = T2 <= 128 ? am_launch<2, 1>(a, B, (hipStream_t)stream) : T2 <= 256 ? am_launch<4, 1>(a, B, (hipStream_t)stream) : am_launch<8, 1>(a, B, (hipStream_t)stream);
   if (rc) return rc;
   S2S_CHECK_LAUNCH("attn_map_kernel<bwd>");

@@ -937,9 +937,11 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
         KAT.fused_bwd(q, k, v, dctx, attn, _pad_like(dattn, attn), H, scale, p, seed, dq, dkk, dv)
         return dq, dkk, dv, None
     gkc, grc, keep = groups if groups is not None else ([], [], [])
-    if not Lp and attn.is_contiguous() and KAT.map_supported(dctx, v, H):
-        # up to 512 keys, bf16: dP = dctx . v^T and the softmax backward in ONE launch, dP never in memory (csrc/attn_map.hip)
-        ds, dbd = KAT.map_bwd(dctx, v, attn, _pad_like(dattn, attn), H, scale, p, seed), None
+    rel_ok = not Lp or (rel_mode == 1 and T1 == T2 and Lp == 2 * T1 - 1 and ldb is not None and ldb % 8 == 0)
+    if rel_ok and attn.is_contiguous() and KAT.map_supported(dctx, v, H):
+        # up to 512 keys, bf16: dP = dctx . v^T, the softmax backward and (rel-pos) the un-shift in ONE launch, dP never in memory,
+        # no zero fill of dbd (csrc/attn_map.hip)
+        ds, dbd = KAT.map_bwd(dctx, v, attn, _pad_like(dattn, attn), H, scale, p, seed, ldb=ldb if Lp else 0)
     else:
         # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
         dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)

@@ -82,17 +82,20 @@ def map_fwd(q, k, klen, causal, H, scale, p, seed):
     return attn, pdrop
 
 
-def map_bwd(dctx, v, attn, dattn, H, scale, p, seed):
-    """dctx (B,T1,D), v (B,T2,D) views; attn (and dattn or None) (B,H,T1,ld) -> gradient of the scaled scores (B,H,T1,ld)."""
+def map_bwd(dctx, v, attn, dattn, H, scale, p, seed, ldb=0):
+    """dctx (B,T1,D), v (B,T2,D) views; attn (and dattn or None) (B,H,T1,ld) -> gradient of the scaled scores (B,H,T1,ld) and, with
+    ldb > 0 (relative-position self-attention, "new" rel_shift), the gradient of the unshifted position term (B,H,T1,ldb)."""
     B, T1, D = dctx.shape
     T2 = v.shape[1]
     ld = attn.shape[-1]
     if dattn is not None and (dattn.shape != attn.shape or not dattn.is_contiguous()):
         raise ValueError("attention map backward: dattn must have the stored map's padded layout")
     ds = torch.empty_like(attn)
+    dbd = torch.empty((B, H, T1, ldb), dtype=attn.dtype, device=attn.device) if ldb else None
     _lib.check(_lib.lib().s2svc_attn_map_bwd(B, H, T1, T2, D // H, ptr(dctx), dctx.stride(1), dctx.stride(0), ptr(v), v.stride(1), v.stride(0),
-                                             ptr(attn), ptr(dattn), scale, p, seed[0], seed[1], ptr(ds), ld, stream()), "attn_map_bwd")
-    return ds
+                                             ptr(attn), ptr(dattn), scale, p, seed[0], seed[1], ptr(ds), ld, ptr(dbd), ldb, stream()),
+               "attn_map_bwd")
+    return ds, dbd
 
 
 # ----------------------------------------------------------------------------------------------

@@ -276,6 +276,7 @@ def rel_attention_fused_vs_separate():
 
         def run(fused, p):
             os.environ["S2SVC_NO_RELATTN"] = "0" if fused else "1"
+            KAT._MAP_DISABLED = not fused          # (the backward's dP + softmax-backward + un-shift kernel, csrc/attn_map.hip)
             K.manual_seed(321)
             K.reset_op_counter()
             x, pp, uu, vv_ = (t_.clone().requires_grad_(True) for t_ in (qkv, pos, u, v))
@@ -285,6 +286,7 @@ def rel_attention_fused_vs_separate():
             (o.float() * dy.float()).sum().backward()
             return o.detach(), a.detach(), x.grad, pp.grad, uu.grad, vv_.grad
         real_group = K.launch_group_batched
+        map_was = KAT._MAP_DISABLED
         try:
             f0, s0, f1, s1 = run(True, 0.0), run(False, 0.0), run(True, 0.2), run(False, 0.2)
             # the five batched products of the backward pass as two grids (s2svc_gemm_grouped_batched) vs one launch each
@@ -297,6 +299,7 @@ def rel_attention_fused_vs_separate():
             f3, s3 = run(True, 0.2), run(False, 0.2)
         finally:
             K.launch_group_batched = real_group
+            KAT._MAP_DISABLED = map_was
             os.environ.pop("S2SVC_NO_RELATTN", None)
         same = all(torch.equal(a, b) for a, b in zip(f1, f3)) and all(torch.equal(a, b) for a, b in zip(s1, s3))
         res.append((same, f"rel-attn B{B} H{H} T{T} dk{dk}: grouped batched products == one launch each, bit for bit: {same}"))
@@ -369,9 +372,18 @@ def attention_map_one_launch_vs_separate():
             dctx = rnd(B, T1, D, seed=970 + n, dtype=bf)
             for with_dattn in (False, True):
                 da = (rnd(B, H, T1, a0.shape[-1], seed=990 + n, dtype=bf, scale=0.5) * (a0 != 0)) if with_dattn else None
-                ds1 = KAT.map_bwd(dctx, v, a0, da, H, scale, p, seed)
+                rel = T1 == T2 and with_dattn            # also as relative-position attention's backward: dS un-shifted into dbd
+                Lp = 2 * T1 - 1 if rel else 0
+                ldb = (Lp + 7) // 8 * 8
+                ds1, dbd1 = KAT.map_bwd(dctx, v, a0, da, H, scale, p, seed, ldb=ldb)
                 dp = Fn._qk(dctx, v, B, H, T1, T2, dk, D, bf)
-                ds0, _ = K.attn_softmax_bwd(a0, dp, scale, p=p, seed=seed, dattn=da, T2=T2)
+                ds0, dbd0 = K.attn_softmax_bwd(a0, dp, scale, p=p, seed=seed, dattn=da, T2=T2, Lp=Lp, rel_mode=1 if rel else 0, ldb=ldb)
+                if rel:
+                    ii, jj = torch.arange(T1, device=DEV)[:, None], torch.arange(T2, device=DEV)[None, :]
+                    back = torch.gather(dbd1, 3, (T1 - 1 - ii + jj)[None, None].expand(B, H, T1, T2))
+                    placed = torch.equal(back, ds1[..., :T2]) and abs(float(dbd1.float().abs().sum()) - float(ds1.float().abs().sum())) <= 1e-3 * float(ds1.float().abs().sum())
+                    res.append((placed and _rel_l2(dbd1, dbd0) <= 1.5e-2, f"{tag} p={p} dbd: dS at [i, T-1-i+j], zero elsewhere (no fill launch): {placed}; "
+                                                                       f"rel-L2 vs softmax-backward kernel {_rel_l2(dbd1, dbd0):.2e}"))
                 # fp32 torch on the same stored map / masks: dS = P (t - sum P t) scale, t = dP mask + dattn
                 keepm = torch.where(a0 != 0, d0.float() / a0.float().clamp_min(1e-30), torch.zeros((), device=DEV)) if p > 0 else torch.ones_like(a0, dtype=torch.float32)
                 keepm = torch.where(keepm > 0.5, torch.full_like(keepm, 1 / (1 - p)), torch.zeros_like(keepm)) if p > 0 else keepm
