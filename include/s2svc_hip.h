@@ -513,17 +513,24 @@ int s2svc_relattn_fwd(int B, int H, int T, int dk, const void* q, int64_t ldq, i
 /* dropped copy, NULL when drop_p == 0); masks as s2svc_attn_softmax_fwd draws them.           */
 /* ========================================================================================== */
 int s2svc_attn_map_supported(int dtype, int T1, int T2, int dk);
+/* 1 when the launches below can also carry the product of their finished tile with a (T2, d_k) matrix of the head (d_k in {64, 96,   */
+/* 128}): forward the context ctx = (dropped map) . v (attention.py:95-111 up to the output projection), backward dq = dS . k.        */
+int s2svc_attn_map_product_supported(int dk);
+/* v != NULL: ctx (B, T1, .) view (row stride ldc, batch stride cbs) receives the context in the same launch. */
 int s2svc_attn_map_fwd(int B, int H, int T1, int T2, int dk, const void* q, int64_t ldq, int64_t qbs, const void* k, int64_t ldk,
                        int64_t kbs, const int32_t* klen, int causal, float scale, float drop_p, const uint64_t* seed_base,
-                       uint64_t seed_off, void* attn, void* pdrop, int ld, void* stream);
+                       uint64_t seed_off, void* attn, void* pdrop, int ld, const void* v, int64_t ldv, int64_t vbs, void* ctx,
+                       int64_t ldc, int64_t cbs, void* stream);
 /* backward of the same up to the gradient of the scaled scores: ds = attn * (dP * mask + dattn - rowsum(attn * (dP * mask + dattn)))  */
 /* * scale with dP = dctx . v^T computed on chip (replaces one batched GEMM + s2svc_attn_softmax_bwd); dctx (B, T1, .) / v (B, T2, .)  */
 /* views, attn the stored map, dattn the gradient that reached the map itself (or NULL), ds (B, H, T1, ld) bf16, pad columns zero.     */
 /* dbd != NULL: relative-position self-attention (attention.py:237-260 "new" rel_shift, T1 == T2): dbd (B, H, T1, ldb) bf16 receives   */
 /* the gradient of matrix_bd BEFORE the shift (dbd[b,h,i,T1-1-i+j] = ds[b,h,i,j], zero elsewhere; ldb >= 2 T1 - 1, a multiple of 8).   */
+/* k != NULL: dq (B, T1, .) view (row stride lddq, batch stride dqbs) receives ds . k in the same launch.                              */
 int s2svc_attn_map_bwd(int B, int H, int T1, int T2, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv,
                        int64_t vbs, const void* attn, const void* dattn, float scale, float drop_p, const uint64_t* seed_base,
-                       uint64_t seed_off, void* ds, int ld, void* dbd, int ldb, void* stream);
+                       uint64_t seed_off, void* ds, int ld, void* dbd, int ldb, const void* k, int64_t ldk, int64_t kbs, void* dq,
+                       int64_t lddq, int64_t dqbs, void* stream);
 
 /* ========================================================================================== */
 /* Token embedding of Transformer-TTS (models/transformer_tts.py:63-77, Embedding(idim, adim, */

@@ -236,10 +236,11 @@ _SIGS = {
     "s2svc_relattn_fwd": [c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_f32,
                           c_f32, c_vp, c_u64, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp],
     "s2svc_attn_map_supported": [c_i32, c_i32, c_i32, c_i32],
+    "s2svc_attn_map_product_supported": [c_i32],
     "s2svc_attn_map_fwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i32, c_f32, c_f32, c_vp, c_u64,
-                           c_vp, c_vp, c_i32, c_vp],
+                           c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
     "s2svc_attn_map_bwd": [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_f32, c_f32, c_vp, c_u64,
-                           c_vp, c_i32, c_vp, c_i32, c_vp],
+                           c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp],
     "s2svc_duration_loss_fwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp],
     "s2svc_duration_loss_bwd": [c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp],
     "s2svc_embedding_fwd": [c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],

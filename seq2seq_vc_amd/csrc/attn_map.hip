@@ -34,7 +34,16 @@ struct am_args {
   // ... and, for relative-position attention (T1 == T2, the "new" rel_shift), the same values where the shift took them from:
   // dbd[b, h, i, T1 - 1 - i + j] = dS[b, h, i, j], every other element of the (B, H, T1, ldb) tensor zero
   bf16_t* dbd; int ldb;
+  // second product (DK2 > 0): out2[i, h d_k + .] = tile[i, :] . m2[:, h d_k + .] with the tile this workgroup just finished -- forward:
+  // the (dropped) map times v = the context; backward: dS times k = dq.  m2 (B, T2, .) view, out2 (B, T1, .) view
+  const bf16_t* m2; int64_t ldm2, m2bs;
+  bf16_t* out2; int64_t ldo2, o2bs;
 };
+
+typedef __attribute__((ext_vector_type(4))) uint32_t am_u32x4_t;
+typedef __attribute__((ext_vector_type(4))) short am_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short am_s16x8_t;
+typedef __attribute__((address_space(3))) am_s16x4_t am_lds_s16x4_t;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -57,7 +66,7 @@ __device__ __forceinline__ void am_block_of(int& rb, int& pair) {
   }
 }
 
-template <int NW, int MODE>
+template <int NW, int MODE, int DK2>
 __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
   constexpr int NT = 64 * NW;                        // threads = key columns a workgroup covers
   constexpr int ST_K = 0, ST_Q = NT * 64, ST_BYTES = ST_Q + 64 * 64;
@@ -149,6 +158,22 @@ __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
   }
   am_wait_vmcnt<0>();                                // the copies issued past the end
   __syncthreads();                                   // operand slices are dead: LDS becomes the score tile
+  // second product: its matrix (NT key rows x DK2, this head's columns) is fetched into registers NOW -- in the order of the LDS image it
+  // will be written to once the tile is dead (1 KiB sub-tiles [32 keys][16 columns], the layout ds_read_b64_tr_b16 reads: gemm_glds.hip)
+  // -- so that the trip runs under the row pass.  Keys past T2 are clamped: their tile columns are exactly zero.
+  constexpr int NP = DK2 > 0 ? DK2 / 8 : 1;
+  am_u32x4_t m2r[NP];
+  if constexpr (DK2 > 0) {
+    const char* mb = reinterpret_cast<const char*>(a.m2 + (int64_t)b * a.m2bs + h * DK2);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int pidx = t + NT * i;
+      const int sidx = pidx >> 6, l = pidx & 63;
+      const int ks = sidx / (DK2 / 16), mt = sidx - ks * (DK2 / 16);
+      const int r = min(ks * 32 + (l >> 1), T2 - 1);
+      m2r[i] = *reinterpret_cast<const am_u32x4_t*>(mb + ((int64_t)r * a.ldm2 + mt * 16 + (l & 1) * 8) * 2);
+    }
+  }
   float* S = reinterpret_cast<float*>(smem);
   const uint64_t seed = (a.seed_base ? *a.seed_base : 0ull) + a.seed_off;
   const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
@@ -283,26 +308,109 @@ __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
       *reinterpret_cast<uint4*>(a.dbd + ((int64_t)bh * T1 + i) * a.ldb + c8 * 8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     }
   }
+  if constexpr (DK2 > 0) {
+    // ---- out2 = tile . m2.  A wave takes RT row tiles of 16 rows and 1 / CS of the 16-column tiles; its A fragments come from the
+    //      bf16 rows in LDS (in the k order the transposing read delivers: 4 lg .. 4 lg + 3 and 16 + 4 lg .. of every 32 keys), then
+    //      the tile is dead and LDS takes the image of m2 out of the registers
+    constexpr int RT = NW >= 4 ? 1 : 4 / NW, CS = NW > 4 ? NW / 4 : 1, KH = NT / 32, MT = DK2 / 16 / CS;
+    const int rt0 = NW >= 4 ? w / CS : w * RT, c0 = (w % CS) * MT;
+    const int sel = (MODE == 0 && a.pdrop) ? SP * 2 : 0;            // forward with dropout: the dropped copy is what meets v
+    bf16x8_t af[RT][KH];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const unsigned char* rowp = reinterpret_cast<const unsigned char*>(S + ((rt0 + rt) * 16 + lr) * SP) + sel + 8 * lg;
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks) {
+        const am_s16x4_t lo = *reinterpret_cast<const am_s16x4_t*>(rowp + ks * 64);
+        const am_s16x4_t hi = *reinterpret_cast<const am_s16x4_t*>(rowp + ks * 64 + 32);
+        const am_s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[rt][ks] = __builtin_bit_cast(bf16x8_t, v8);
+      }
+    }
+    __syncthreads();                                   // fragments taken, the stores above have read their rows
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<am_u32x4_t*>(smem + (size_t)(t + NT * i) * 16) = m2r[i];
+    __syncthreads();
+    f32x4_t o[RT][MT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) o[rt][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // (the MT fragments of the next 32 keys are read while this step's MFMAs run: one LDS latency per step, not one per fragment)
+    bf16x8_t bq[2][MT];
+    auto load_b = [&](int ks, bf16x8_t (&dst)[MT]) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned char* pp = smem + (ks * (DK2 / 16) + c0 + mt) * 1024 + (lg * 4 + (lr >> 2)) * 32 + (lr & 3) * 8;
+        const am_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((am_lds_s16x4_t*)pp);
+        const am_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((am_lds_s16x4_t*)(pp + 512));
+        const am_s16x8_t v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        dst[mt] = __builtin_bit_cast(bf16x8_t, v8);
+      }
+    };
+    load_b(0, bq[0]);
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+      if (ks + 1 < KH) load_b(ks + 1, bq[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise folds the reads back in front of their MFMAs)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) o[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt][ks], bq[ks & 1][mt], o[rt][mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16_t* ob = a.out2 + (int64_t)b * a.o2bs + h * DK2;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + (rt0 + rt) * 16 + 4 * lg + r;
+        if (i < T1) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) ob[(int64_t)i * a.ldo2 + (c0 + mt) * 16 + lr] = f2bf(o[rt][mt][r]);
+        }
+      }
+  }
 }
 
 bool am_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <int NW, int MODE>
+template <int NW, int MODE, int DK2>
 int am_launch(const am_args& a, int B, hipStream_t st) {
   constexpr int NT = 64 * NW;
   constexpr size_t stages = (size_t)3 * (NT * 64 + 64 * 64), tile = (size_t)64 * (NT + 8) * 4;
+  static_assert((size_t)NT * DK2 * 2 <= tile, "the second product's matrix must fit the dead tile");
   const size_t lds = stages > tile ? stages : tile;
   static size_t attr_set = 0;
   if (lds > 64 * 1024 && attr_set < lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_map_kernel<NW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_map_kernel<NW, MODE, DK2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       s2svc_set_error("attn_map: cannot raise the dynamic LDS limit");
       return -2;
     }
     attr_set = lds;
   }
-  hipLaunchKernelGGL((attn_map_kernel<NW, MODE>), dim3((a.T1 + 63) / 64, B * a.H), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((attn_map_kernel<NW, MODE, DK2>), dim3((a.T1 + 63) / 64, B * a.H), dim3(NT), lds, st, a);
   return 0;
 }
+
+template <int MODE, int DK2>
+int am_launch_nw(const am_args& a, int B, hipStream_t st) {
+  return a.T2 <= 128 ? am_launch<2, MODE, DK2>(a, B, st) : a.T2 <= 256 ? am_launch<4, MODE, DK2>(a, B, st) : am_launch<8, MODE, DK2>(a, B, st);
+}
+
+template <int MODE>
+int am_dispatch(const am_args& a, int B, hipStream_t st) {
+  if (!a.m2) return am_launch_nw<MODE, 0>(a, B, st);
+  switch (a.dk) {
+    case 64: return am_launch_nw<MODE, 64>(a, B, st);
+    case 96: return am_launch_nw<MODE, 96>(a, B, st);
+    case 128: return am_launch_nw<MODE, 128>(a, B, st);
+  }
+  s2svc_set_error("attn_map: the second product needs d_k in {64, 96, 128}");
+  return -1;
+}
+
+bool am_view_ok(const void* p, int64_t ld, int64_t bs) { return p && am_al16(p) && ld % 8 == 0 && bs % 8 == 0; }
 
 }  // namespace
 
@@ -310,16 +418,21 @@ extern "C" int s2svc_attn_map_supported(int dtype, int T1, int T2, int dk) {
   return (dtype == S2S_BF16 && T1 >= 1 && T2 >= 1 && T2 <= 512 && dk >= 32 && dk % 32 == 0) ? 1 : 0;
 }
 
+extern "C" int s2svc_attn_map_product_supported(int dk) { return (dk == 64 || dk == 96 || dk == 128) ? 1 : 0; }
+
 // q (B, T1, .) / k (B, T2, .) views with row strides ldq / ldk and batch strides qbs / kbs (elements), head h at columns h * dk;
-// klen (B) int32 or NULL; attn / pdrop (B, H, T1, ld) bf16, ld = T2 rounded up to 8 (pdrop NULL when drop_p == 0)
+// klen (B) int32 or NULL; attn / pdrop (B, H, T1, ld) bf16, ld = T2 rounded up to 8 (pdrop NULL when drop_p == 0).
+// v != NULL (s2svc_attn_map_product_supported(dk)): ctx (B, T1, .) view receives the context (dropped map) . v in the same launch.
 extern "C" int s2svc_attn_map_fwd(int B, int H, int T1, int T2, int dk, const void* q, int64_t ldq, int64_t qbs, const void* k, int64_t ldk,
                                   int64_t kbs, const int32_t* klen, int causal, float scale, float drop_p, const uint64_t* seed_base,
-                                  uint64_t seed_off, void* attn, void* pdrop, int ld, void* stream) {
+                                  uint64_t seed_off, void* attn, void* pdrop, int ld, const void* v, int64_t ldv, int64_t vbs, void* ctx,
+                                  int64_t ldc, int64_t cbs, void* stream) {
   S2S_REQUIRE(s2svc_attn_map_supported(S2S_BF16, T1, T2, dk), "attn_map_fwd: bf16, T2 <= 512, d_k % 32 == 0");
   S2S_REQUIRE(B >= 0 && H > 0 && q && k && attn && ld >= T2 && ld % 8 == 0 && ld <= ((T2 + 63) / 64) * 64 && (drop_p == 0.f || pdrop) && drop_p < 1.f,
               "attn_map_fwd: bad args");
   S2S_REQUIRE(ldq % 8 == 0 && qbs % 8 == 0 && ldk % 8 == 0 && kbs % 8 == 0 && am_al16(q) && am_al16(k) && am_al16(attn) && am_al16(pdrop),
               "attn_map_fwd: 16-byte aligned operands, strides multiples of 8");
+  S2S_REQUIRE(!v || (am_view_ok(v, ldv, vbs) && ctx && s2svc_attn_map_product_supported(dk)), "attn_map_fwd: context product needs v, ctx, d_k in {64, 96, 128}");
   if (B == 0) return 0;
   am_args a;
   a.H = H; a.T1 = T1; a.T2 = T2; a.dk = dk; a.ld = ld;
@@ -327,7 +440,8 @@ extern "C" int s2svc_attn_map_fwd(int B, int H, int T1, int T2, int dk, const vo
   a.klen = klen; a.causal = causal; a.scale = scale; a.p = drop_p; a.seed_base = seed_base; a.seed_off = seed_off;
   a.attn = (bf16_t*)attn; a.pdrop = drop_p > 0.f ? (bf16_t*)pdrop : nullptr;
   a.p_in = nullptr; a.dattn = nullptr; a.ds = nullptr; a.dbd = nullptr; a.ldb = 0;
-  const int rc = T2 <= 128 ? am_launch<2, 0>(a, B, (hipStream_t)stream) : T2 <= 256 ? am_launch<4, 0>(a, B, (hipStream_t)stream) : am_launch<8, 0>(a, B, (hipStream_t)stream);
+  a.m2 = (const bf16_t*)v; a.ldm2 = ldv; a.m2bs = vbs; a.out2 = (bf16_t*)ctx; a.ldo2 = ldc; a.o2bs = cbs;
+  const int rc = am_dispatch<0>(a, B, (hipStream_t)stream);
   if (rc) return rc;
   S2S_CHECK_LAUNCH("attn_map_kernel<fwd>");
   return 0;
@@ -338,14 +452,17 @@ extern "C" int s2svc_attn_map_fwd(int B, int H, int T1, int T2, int dk, const vo
 // that reached the map itself (same layout) or NULL; ds (B, H, T1, ld) bf16 out (pad columns zero); masks regenerated from the seed.
 // dbd != NULL (relative-position self-attention, T1 == T2, "new" rel_shift): dbd (B, H, T1, ldb) bf16, ldb >= 2 T1 - 1 a multiple of 8,
 // receives dS at the positions the shift read (dbd[b, h, i, T1 - 1 - i + j] = dS[b, h, i, j]) and zeros elsewhere.
+// k != NULL (s2svc_attn_map_product_supported(dk)): dq (B, T1, .) view receives dS . k in the same launch.
 extern "C" int s2svc_attn_map_bwd(int B, int H, int T1, int T2, int dk, const void* dctx, int64_t ldo, int64_t obs, const void* v, int64_t ldv,
                                   int64_t vbs, const void* attn, const void* dattn, float scale, float drop_p, const uint64_t* seed_base,
-                                  uint64_t seed_off, void* ds, int ld, void* dbd, int ldb, void* stream) {
+                                  uint64_t seed_off, void* ds, int ld, void* dbd, int ldb, const void* k, int64_t ldk, int64_t kbs, void* dq,
+                                  int64_t lddq, int64_t dqbs, void* stream) {
   S2S_REQUIRE(!dbd || (T1 == T2 && ldb >= 2 * T1 - 1 && ldb % 8 == 0 && am_al16(dbd)), "attn_map_bwd: dbd needs T1 == T2, ldb >= 2 T1 - 1, ldb % 8 == 0");
   S2S_REQUIRE(s2svc_attn_map_supported(S2S_BF16, T1, T2, dk), "attn_map_bwd: bf16, T2 <= 512, d_k % 32 == 0");
   S2S_REQUIRE(B >= 0 && H > 0 && dctx && v && attn && ds && ld >= T2 && ld % 8 == 0 && ld <= ((T2 + 63) / 64) * 64 && drop_p < 1.f, "attn_map_bwd: bad args");
   S2S_REQUIRE(ldo % 8 == 0 && obs % 8 == 0 && ldv % 8 == 0 && vbs % 8 == 0 && am_al16(dctx) && am_al16(v) && am_al16(ds),
               "attn_map_bwd: 16-byte aligned operands, strides multiples of 8");
+  S2S_REQUIRE(!k || (am_view_ok(k, ldk, kbs) && dq && s2svc_attn_map_product_supported(dk)), "attn_map_bwd: dq product needs k, dq, d_k in {64, 96, 128}");
   if (B == 0) return 0;
   am_args a;
   a.H = H; a.T1 = T1; a.T2 = T2; a.dk = dk; a.ld = ld;
@@ -353,7 +470,8 @@ extern "C" int s2svc_attn_map_bwd(int B, int H, int T1, int T2, int dk, const vo
   a.klen = nullptr; a.causal = 0; a.scale = scale; a.p = drop_p; a.seed_base = seed_base; a.seed_off = seed_off;
   a.attn = nullptr; a.pdrop = nullptr;
   a.p_in = (const bf16_t*)attn; a.dattn = (const bf16_t*)dattn; a.ds = (bf16_t*)ds; a.dbd = (bf16_t*)dbd; a.ldb = ldb;
-  const int rc = T2 <= 128 ? am_launch<2, 1>(a, B, (hipStream_t)stream) : T2 <= 256 ? am_launch<4, 1>(a, B, (hipStream_t)stream) : am_launch<8, 1>(a, B, (hipStream_t)stream);
+  a.m2 = (const bf16_t*)k; a.ldm2 = ldk; a.m2bs = kbs; a.out2 = (bf16_t*)dq; a.ldo2 = lddq; a.o2bs = dqbs;
+  const int rc = am_dispatch<1>(a, B, (hipStream_t)stream);
   if (rc) return rc;
   S2S_CHECK_LAUNCH("attn_map_kernel<bwd>");
   return 0;

@@ -937,11 +937,15 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
         KAT.fused_bwd(q, k, v, dctx, attn, _pad_like(dattn, attn), H, scale, p, seed, dq, dkk, dv)
         return dq, dkk, dv, None
     gkc, grc, keep = groups if groups is not None else ([], [], [])
+    dq_fused = False
     rel_ok = not Lp or (rel_mode == 1 and T1 == T2 and Lp == 2 * T1 - 1 and ldb is not None and ldb % 8 == 0)
     if rel_ok and attn.is_contiguous() and KAT.map_supported(dctx, v, H):
         # up to 512 keys, bf16: dP = dctx . v^T, the softmax backward and (rel-pos) the un-shift in ONE launch, dP never in memory,
         # no zero fill of dbd (csrc/attn_map.hip)
-        ds, dbd = KAT.map_bwd(dctx, v, attn, _pad_like(dattn, attn), H, scale, p, seed, ldb=ldb if Lp else 0)
+        # ... and, for d_k in {64, 96, 128}, dq = dS . k as the same launch's second product
+        dq_fused = dq.stride(2) == 1 and KAT.map_product_ok(k, H)
+        ds, dbd = KAT.map_bwd(dctx, v, attn, _pad_like(dattn, attn), H, scale, p, seed, ldb=ldb if Lp else 0,
+                              k=k if dq_fused else None, dq=dq if dq_fused else None)
     else:
         # dP[b,h,i,j] = sum_d dctx[b,i,hd] v[b,j,hd]
         dp = _qk(dctx, v, B, H, T1, T2, dk, D, dtype)
@@ -950,7 +954,8 @@ def _attn_common_bwd(dctx, dattn, attn, pm, q, k, v, H, scale, p, seed, Lp=0, re
     # dV[b,j,hd] = sum_i pm[b,h,i,j] dctx[b,i,hd]
     _into(dv, _pop(pm, T1, H, K.RC), _bop(dctx, dk, K.RC), T2, dk, T1, dk, dtype, B, H, group=grc)
     # dQ[b,i,hd] = sum_j dS[b,h,i,j] k[b,j,hd]
-    _into(dq, _pop(ds, T1, H), _bop(k, dk, K.RC), T1, dk, T2, dk, dtype, B, H, group=gkc)
+    if not dq_fused:
+        _into(dq, _pop(ds, T1, H), _bop(k, dk, K.RC), T1, dk, T2, dk, dtype, B, H, group=gkc)
     # dK[b,j,hd] = sum_i dS[b,h,i,j] q[b,i,hd]
     _into(dkk, _pop(ds, T1, H, K.RC), _bop(q, dk, K.RC), T2, dk, T1, dk, dtype, B, H, group=grc)
     keep += [dctx, ds, dbd, pm, q, k, v]
@@ -984,7 +989,10 @@ def _attn_fwd_views(q, k, v, klen, causal, H, p):
         out, attn = KAT.fused_fwd(q, k, v, klen, causal, H, scale, p, seed)
         return out, attn, _FUSED, scale, seed
     if KAT.map_supported(q, k, H):      # up to 512 keys, bf16: scores + mask + softmax + dropout in ONE launch (csrc/attn_map.hip)
-        attn, pdrop = KAT.map_fwd(q, k, klen, causal, H, scale, p, seed)
+        # ... and, for d_k in {64, 96, 128}, the context (dropped map) . v as the same launch's second product
+        attn, pdrop, out = KAT.map_fwd(q, k, klen, causal, H, scale, p, seed, v=v if KAT.map_product_ok(v, H) else None)
+        if out is not None:
+            return out, attn, pdrop, scale, seed
     else:
         scores = _qk(q, k, B, H, T1, T2, dk, D, dtype)
         attn, pdrop = K.attn_softmax_fwd(scores, dtype, scale, klen=klen, causal=causal, p=p, seed=seed, T2=T2)

@@ -68,33 +68,46 @@ def map_supported(q, k, H):
     return _strided_ok(q) and _strided_ok(k)
 
 
-def map_fwd(q, k, klen, causal, H, scale, p, seed):
-    """q (B,T1,D), k (B,T2,D) (possibly column slices of packed projections) -> attn, pdrop (B,H,T1,ld) (pdrop None when p == 0)."""
+def map_product_ok(m, H):
+    """The map launches can also carry their tile's product with this (B, T2, D) view (v forward, k backward)."""
+    return bool(_lib.lib().s2svc_attn_map_product_supported(m.shape[-1] // H)) and _strided_ok(m)
+
+
+def map_fwd(q, k, klen, causal, H, scale, p, seed, v=None):
+    """q (B,T1,D), k (B,T2,D) (possibly column slices of packed projections) -> attn, pdrop (B,H,T1,ld) (pdrop None when p == 0), and
+    with v (map_product_ok) the context (B,T1,D) = (dropped map) . v of the same launch (else None)."""
     B, T1, D = q.shape
     T2 = k.shape[1]
     dk = D // H
     ld = (T2 + 7) // 8 * 8
     attn = torch.empty((B, H, T1, ld), dtype=q.dtype, device=q.device)
     pdrop = torch.empty_like(attn) if p > 0.0 else None
+    ctx = torch.empty((B, T1, D), dtype=q.dtype, device=q.device) if v is not None else None
     _lib.check(_lib.lib().s2svc_attn_map_fwd(B, H, T1, T2, dk, ptr(q), q.stride(1), q.stride(0), ptr(k), k.stride(1), k.stride(0),
                                              ptr(klen), 1 if causal else 0, scale, p, seed[0], seed[1], ptr(attn), ptr(pdrop), ld,
-                                             stream()), "attn_map_fwd")
-    return attn, pdrop
+                                             ptr(v), v.stride(1) if v is not None else 0, v.stride(0) if v is not None else 0,
+                                             ptr(ctx), D, T1 * D, stream()), "attn_map_fwd")
+    return attn, pdrop, ctx
 
 
-def map_bwd(dctx, v, attn, dattn, H, scale, p, seed, ldb=0):
+def map_bwd(dctx, v, attn, dattn, H, scale, p, seed, ldb=0, k=None, dq=None):
     """dctx (B,T1,D), v (B,T2,D) views; attn (and dattn or None) (B,H,T1,ld) -> gradient of the scaled scores (B,H,T1,ld) and, with
-    ldb > 0 (relative-position self-attention, "new" rel_shift), the gradient of the unshifted position term (B,H,T1,ldb)."""
+    ldb > 0 (relative-position self-attention, "new" rel_shift), the gradient of the unshifted position term (B,H,T1,ldb).
+    With k (map_product_ok) and dq (a (B,T1,D) view, last dim contiguous): dq = dS . k in the same launch."""
     B, T1, D = dctx.shape
     T2 = v.shape[1]
     ld = attn.shape[-1]
     if dattn is not None and (dattn.shape != attn.shape or not dattn.is_contiguous()):
         raise ValueError("attention map backward: dattn must have the stored map's padded layout")
+    if (k is None) != (dq is None) or (dq is not None and (dq.stride(2) != 1 or dq.shape != dctx.shape)):
+        raise ValueError("attention map backward: k and dq come together, dq (B,T1,D) with its last dim contiguous")
     ds = torch.empty_like(attn)
     dbd = torch.empty((B, H, T1, ldb), dtype=attn.dtype, device=attn.device) if ldb else None
     _lib.check(_lib.lib().s2svc_attn_map_bwd(B, H, T1, T2, D // H, ptr(dctx), dctx.stride(1), dctx.stride(0), ptr(v), v.stride(1), v.stride(0),
-                                             ptr(attn), ptr(dattn), scale, p, seed[0], seed[1], ptr(ds), ld, ptr(dbd), ldb, stream()),
-               "attn_map_bwd")
+                                             ptr(attn), ptr(dattn), scale, p, seed[0], seed[1], ptr(ds), ld, ptr(dbd), ldb,
+                                             ptr(k), k.stride(1) if k is not None else 0, k.stride(0) if k is not None else 0,
+                                             ptr(dq), dq.stride(1) if dq is not None else 0, dq.stride(0) if dq is not None else 0,
+                                             stream()), "attn_map_bwd")
     return ds, dbd
 
 

@@ -353,7 +353,16 @@ def attention_map_one_launch_vs_separate():
         for p in (0.0, 0.1):
             K.manual_seed(77)
             seed = K.new_seed(q.device) if p > 0 else (None, 0)
-            a1, d1 = KAT.map_fwd(q, k, klen, causal, H, scale, p, seed)
+            a1, d1, _ = KAT.map_fwd(q, k, klen, causal, H, scale, p, seed)
+            if KAT.map_product_ok(kv[..., D:], H):
+                # the context as the launch's second product: same map, same masks, (dropped map) . v against the batched GEMM
+                a2, d2, c2 = KAT.map_fwd(q, k, klen, causal, H, scale, p, seed, v=kv[..., D:])
+                c0 = Fn._pv(d1 if d1 is not None else a1, kv[..., D:], B, H, T1, T2, dk, D, bf)
+                cr = ((d1 if d1 is not None else a1).float()[..., :T2] @ kv[..., D:].float().reshape(B, T2, H, dk).transpose(1, 2)).transpose(1, 2).reshape(B, T1, D)
+                same_map = torch.equal(a2, a1) and (d1 is None or torch.equal(d2, d1))
+                e2, e0c = _rel_l2(c2, cr), _rel_l2(c0, cr)
+                res.append((same_map and e2 <= 6e-3 and e2 <= 1.5 * e0c + 1e-3,
+                            f"{tag} p={p} context in the same launch: map unchanged {same_map}, rel-L2 vs fp32 product {e2:.2e} (batched GEMM {e0c:.2e})"))
             scores = Fn._qk(q, k, B, H, T1, T2, dk, D, bf)
             a0, d0 = K.attn_softmax_fwd(scores, bf, scale, klen=klen, causal=causal, p=p, seed=seed, T2=T2)
             e1, e0 = _rel_l2(a1[..., :T2], prob), _rel_l2(a0[..., :T2], prob)
@@ -376,6 +385,18 @@ def attention_map_one_launch_vs_separate():
                 Lp = 2 * T1 - 1 if rel else 0
                 ldb = (Lp + 7) // 8 * 8
                 ds1, dbd1 = KAT.map_bwd(dctx, v, a0, da, H, scale, p, seed, ldb=ldb)
+                if KAT.map_product_ok(k, H):
+                    dq2 = torch.full((B, T1, 3 * D), 7.0, dtype=bf, device=DEV)      # a column block of a packed gradient
+                    ds2, dbd2 = KAT.map_bwd(dctx, v, a0, da, H, scale, p, seed, ldb=ldb, k=k, dq=dq2[..., D:2 * D])
+                    dqr = (ds1.float()[..., :T2] @ k.float().reshape(B, T2, H, dk).transpose(1, 2)).transpose(1, 2).reshape(B, T1, D)
+                    dq0 = torch.empty((B, T1, D), dtype=bf, device=DEV)
+                    Fn._into(dq0, Fn._pop(ds1, T1, H), Fn._bop(k, dk, K.RC), T1, dk, T2, dk, bf, B, H)
+                    same = torch.equal(ds2, ds1) and (dbd1 is None or torch.equal(dbd2, dbd1))
+                    untouched = bool((dq2[..., :D] == 7).all()) and bool((dq2[..., 2 * D:] == 7).all())
+                    e2, e0q = _rel_l2(dq2[..., D:2 * D], dqr), _rel_l2(dq0, dqr)
+                    res.append((same and untouched and e2 <= 6e-3 and e2 <= 1.5 * e0q + 1e-3,
+                                f"{tag} p={p} dq in the same launch{' (+ d map)' if with_dattn else ''}: dS unchanged {same}, neighbours untouched "
+                                f"{untouched}, rel-L2 vs fp32 product {e2:.2e} (batched GEMM {e0q:.2e})"))
                 dp = Fn._qk(dctx, v, B, H, T1, T2, dk, D, bf)
                 ds0, dbd0 = K.attn_softmax_bwd(a0, dp, scale, p=p, seed=seed, dattn=da, T2=T2, Lp=Lp, rel_mode=1 if rel else 0, ldb=ldb)
                 if rel:
