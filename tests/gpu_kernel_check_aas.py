@@ -330,7 +330,7 @@ def attention_map_one_launch_vs_separate():
     #            B  H  T1   T2   dk  causal
     shapes = [(3, 4, 151, 151, 96, False), (3, 4, 320, 320, 96, True), (2, 4, 320, 151, 96, False), (2, 2, 70, 100, 64, False),
               (2, 2, 200, 65, 32, False), (1, 3, 37, 512, 64, False), (2, 2, 400, 400, 64, True), (2, 1, 129, 257, 128, False),
-              (1, 2, 1, 300, 32, False), (2, 2, 66, 9, 32, False)]
+              (1, 2, 1, 300, 32, False), (2, 2, 66, 9, 32, False), (2, 2, 100, 200, 128, False), (2, 2, 90, 120, 96, True), (1, 2, 50, 60, 128, False)]
     for n, (B, H, T1, T2, dk, causal) in enumerate(shapes):
         D = H * dk
         tag = f"attn-map B{B} H{H} T1 {T1} T2 {T2} dk{dk}{' causal' if causal else ''}"
