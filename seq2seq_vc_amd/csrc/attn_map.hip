@@ -1,15 +1,22 @@
-// Attention map of plain multi-head attention for medium-length sequences in ONE launch:
-//     attn[b, h, i, j] = softmax_j(q_i . k_j / sqrt(d_k) masked to j < klen[b] (and j <= i when causal)),  pdrop = dropout(attn)
-// -- bf16, T2 <= 512 keys, any T1, d_k a multiple of 32.  reference: modules/transformer/attention.py:63-93 (scores, masked_fill with
-// the dtype's minimum, softmax, masked_fill with 0, dropout); the context P.V stays a GEMM of its own.
+// Attention of medium-length sequences around ONE score tile per launch -- bf16, T2 <= 512 keys, any T1, d_k a multiple of 32.
+// reference: modules/transformer/attention.py:63-93 (scores, masked_fill with the dtype's minimum, softmax, masked_fill with 0,
+// dropout), :95-111 (the context), and their backward; the backward of :237-303 (relative-position attention) up to dS / dbd.
+//   MODE 0   attn[b, h, i, j] = softmax_j(q_i . k_j / sqrt(d_k) masked to j < klen[b] (and j <= i when causal)), pdrop = dropout(attn)
+//            [+ DK2: ctx = pdrop . v]
+//   MODE 1   dP = dctx . v^T on chip;  dS = P (dP mask + dattn - rowsum(P (dP mask + dattn))) scale
+//            [+ dbd: dS un-shifted into the gradient of the position term]  [+ DK2: dq = dS . k]
 // Round 6: the Transformer-TTS blocks (T up to 320 x 151: above the 64 frames of attn_fused.hip, no position term for relattn.hip) ran
-// this as scores GEMM (fp32 (B, H, T1, T2) to HBM) + softmax kernel: two dependent launches and an 8-byte-per-element round trip per
-// attention site of a chain that is bound by its launch count.  The kernel is relattn.hip's forward without the position term and with
-// NW wavefronts (2: T2 <= 128, 4: T2 <= 256, 8: T2 <= 512): one workgroup per (utterance, head, block of 64 query rows), wave w owns the key columns
-// 64 w .. 64 w + 63 (16 accumulator tiles); q rows and k rows are streamed in 32-wide slices of d_k by LDS-DMA through three stages with
-// counted `s_waitcnt vmcnt` + one raw barrier per slice; the scores meet in an fp32 LDS tile, one wave per row does the softmax, the
-// bf16 rows leave in 16-byte stores.  Same output layout ((B, H, T1, ld), ld = T2 rounded up to 8, pad columns zero) and the same dropout
-// masks (a function of the seed and the element index in that layout) as softmax.hip: the backward pass does not know which forward ran.
+// the forward as scores GEMM (fp32 (B, H, T1, T2) to HBM) + softmax kernel + context GEMM and the backward as dP GEMM + softmax
+// backward + three products: dependent launches and 8-byte-per-element round trips on a chain that is bound by its launch count
+// (C4 step 3.96 -> 3.40 ms with this file, profiles/AB_LOG.md round 6 item 12).  The kernel is relattn.hip's forward without the position
+// term and with NW wavefronts (2: T2 <= 128, 4: T2 <= 256, 8: T2 <= 512): one workgroup per (utterance, head, block of 64 query rows),
+// wave w owns the key columns 64 w .. 64 w + 63 (16 accumulator tiles); the two operands of the score product (q, k forward; dctx, v
+// backward) are streamed in 32-wide slices of d_k by LDS-DMA through three stages with counted `s_waitcnt vmcnt` + one raw barrier per
+// slice; the scores meet in an fp32 LDS tile, one wave per row does the softmax (or its backward), the bf16 rows leave in 16-byte stores.
+// DK2 in {64, 96, 128}: the finished bf16 tile is then the A operand of a second product with the head's (keys x d_k) matrix, which was
+// fetched into registers under the row pass and is laid over the dead tile for `ds_read_b64_tr_b16` (see below).
+// Same output layout ((B, H, T1, ld), ld = T2 rounded up to 8, pad columns zero) and the same dropout masks (a function of the seed and
+// the element index in that layout) as softmax.hip / attn_fused.hip: forward and backward may come from different kernel families.
 #include "common.h"
 #include "../../include/s2svc_hip.h"
 
