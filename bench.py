@@ -1259,12 +1259,21 @@ def main():
     def build(stage_mode):
         return build_step(wl, dist, world, staged, args.force_dist, args.grad_payload, not args.no_graph, collective=args.collective,
                           warmup_eager=max(2, args.warmup if args.no_graph else 2), stage_mode=stage_mode, min_bucket_mb=args.min_bucket_mb)
+    err = None
     try:
         step, info = build(args.stage_mode)
     except Exception as e:  # noqa: BLE001 -- the flush exchange has only ever run on one GPU: fall back to the stage graphs of rounds 2-5, loudly
         if not (staged and args.stage_mode == "flush"):
             raise
-        print(f"[bench] --stage-mode flush failed ({type(e).__name__}: {e}); falling back to --stage-mode graphs", file=sys.stderr)
+        err = e
+    failed = err is not None
+    if dp and staged and args.stage_mode == "flush":      # the ranks fall back TOGETHER (a rank on another exchange would hang the rest)
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = bool(flag.item())
+    if failed:
+        why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed"
+        print(f"[bench] --stage-mode flush failed ({why}); falling back to --stage-mode graphs", file=sys.stderr)
         torch.cuda.synchronize()
         wl.Fn._Side.on_flush = None
         step, info = build("graphs")
