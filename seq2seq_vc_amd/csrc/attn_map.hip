@@ -77,7 +77,10 @@ template <int NW, int MODE, int DK2>
 __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
   constexpr int NT = 64 * NW;                        // threads = key columns a workgroup covers
   constexpr int ST_K = 0, ST_Q = NT * 64, ST_BYTES = ST_Q + 64 * 64;
-  constexpr int SP = NT + 8;                         // pitch (elements) of the bf16 rows; the fp32 score rows use the same count
+  // fp32 score rows of SP = NT + 4 floats: rows 4 apart (the lane groups of an accumulator store) sit 16 banks apart -- with NT + 8 they met
+  // on the same banks (SQ_LDS_BANK_CONFLICT 27-36 % of the LDS cycles, profiles/r06_attn_map_pmc.txt).  The same bytes later hold the
+  // row's two bf16 rows: the map at byte 0, its dropped copy at element RD = NT + 8 (16-byte aligned): 2 * (NT + 8) + 2 * NT = 4 * SP bytes
+  constexpr int SP = NT + 4, RD = NT + 8;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int T1 = a.T1, T2 = a.T2, dk = a.dk, H = a.H;
   int rb_, bh;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
   bf16_t* const gout = MODE == 0 ? a.attn : a.ds;
   if constexpr (MODE == 0) {
     // ---- scale, mask -> fp32 score tile S[64][SP].  Row il is later overwritten, by the wave that owns it, with the bf16 rows of the
-    //      map (first half of the row's bytes) and of its dropped copy (second half): SP * 4 bytes = 2 rows of SP bf16
+    //      map (from byte 0) and of its dropped copy (from element RD)
     const int kl0 = a.klen ? a.klen[b] : T2;
     const int kl = kl0 < T2 ? kl0 : T2;
 #pragma unroll
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
       const float inv = 1.f / sum;
       const int64_t arow = ((int64_t)bh * T1 + i0 + il) * a.ld;
       bf16_t* rowA = reinterpret_cast<bf16_t*>(S + il * SP);      // LDS operations of one wave execute in order: the row was read above
-      bf16_t* rowD = rowA + SP;
+      bf16_t* rowD = rowA + RD;
 #pragma unroll
       for (int c = 0; c < NW; ++c) {
         const int j = lane + 64 * c;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
       const int64_t o = ((int64_t)bh * T1 + i0 + row) * a.ld + c8 * 8;
       const bf16_t* rowA = reinterpret_cast<const bf16_t*>(S + row * SP);
       *reinterpret_cast<uint4*>(gout + o) = *reinterpret_cast<const uint4*>(rowA + c8 * 8);
-      if (MODE == 0 && a.pdrop) *reinterpret_cast<uint4*>(a.pdrop + o) = *reinterpret_cast<const uint4*>(rowA + SP + c8 * 8);
+      if (MODE == 0 && a.pdrop) *reinterpret_cast<uint4*>(a.pdrop + o) = *reinterpret_cast<const uint4*>(rowA + RD + c8 * 8);
     }
   }
   if (MODE == 1 && a.dbd) {                           // whole rows, zeros included: no fill launch in front of this kernel
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void attn_map_kernel(const am_args a) {
     //      the tile is dead and LDS takes the image of m2 out of the registers
     constexpr int RT = NW >= 4 ? 1 : 4 / NW, CS = NW > 4 ? NW / 4 : 1, KH = NT / 32, MT = DK2 / 16 / CS;
     const int rt0 = NW >= 4 ? w / CS : w * RT, c0 = (w % CS) * MT;
-    const int sel = (MODE == 0 && a.pdrop) ? SP * 2 : 0;            // forward with dropout: the dropped copy is what meets v
+    const int sel = (MODE == 0 && a.pdrop) ? RD * 2 : 0;            // forward with dropout: the dropped copy is what meets v
     bf16x8_t af[RT][KH];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -385,7 +388,7 @@ bool am_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 template <int NW, int MODE, int DK2>
 int am_launch(const am_args& a, int B, hipStream_t st) {
   constexpr int NT = 64 * NW;
-  constexpr size_t stages = (size_t)3 * (NT * 64 + 64 * 64), tile = (size_t)64 * (NT + 8) * 4;
+  constexpr size_t stages = (size_t)3 * (NT * 64 + 64 * 64), tile = (size_t)64 * (NT + 4) * 4;
   static_assert((size_t)NT * DK2 * 2 <= tile, "the second product's matrix must fit the dead tile");
   const size_t lds = stages > tile ? stages : tile;
   static size_t attr_set = 0;
