@@ -4,6 +4,9 @@ PARITY UNPINNED: the reference delegates the arithmetic to librosa (setup.cfg:5 
 not installed here) and holds no test vectors for it.  This file restates librosa's documented algorithm
 (librosa.stft center=True / reflect padding / periodic Hann; librosa.filters.mel Slaney scale + Slaney area
 normalisation) with an FFT-based formulation that is independent of the product's DFT-as-GEMM path.
+Cross-checks that exist (tests/test_oracle_golden.py, none of them the reference's own vectors, hence still "unpinned"): torch.stft,
+scipy.signal.stft, the published Slaney constants and closed forms, and -- round 6 -- the port of librosa's `stft` / `filters.mel` in
+huggingface transformers 5.15 (`transformers.audio_utils`): filter bank equal to 2e-16, log-mel to 2e-8 in float64.
 """
 import numpy as np
 

@@ -332,6 +332,29 @@ def test_logmel_against_independent_stft_implementations():
         assert np.abs(got32 - want).max() < 2e-4
 
 
+def test_logmel_against_the_librosa_port_of_transformers():
+    """A third implementation of the two librosa calls the reference makes (bin/preprocess.py:63-82): `transformers.audio_utils`
+    (`mel_filter_bank(norm="slaney", mel_scale="slaney")`, `spectrogram(center=True, pad_mode="reflect", power=1.0, log_mel="log10")`),
+    which its authors adapted from librosa and check against it.  oracle/logmel.py agrees with it to rounding in float64 at the
+    reference's recipe settings (16 kHz / 24 kHz, fmin 80, fmax 7600) -- not a pin in the sense of the reference's own vectors (the
+    header of oracle/logmel.py keeps saying "parity unpinned"), but the restatement and an independent port of librosa meet."""
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    from oracle import logmel as LM
+    rng = np.random.default_rng(11)
+    for sr, nfft, hop, nm, fmin, fmax in ((16000, 1024, 256, 80, 80, 7600), (24000, 2048, 300, 80, 80, 7600), (22050, 1024, 256, 80, 0, None)):
+        fb_t = audio_utils.mel_filter_bank(nfft // 2 + 1, nm, float(fmin), float(fmax if fmax else sr / 2), sr, norm="slaney", mel_scale="slaney")
+        fb_o = LM.mel_filterbank64(sr, nfft, nm, fmin, fmax if fmax else sr / 2)
+        assert np.abs(fb_o - fb_t.T).max() < 1e-14
+        n = sr + 123
+        x = rng.standard_normal(n) * 0.1 + 0.3 * np.sin(2 * np.pi * 440.0 * np.arange(n) / sr)
+        ours = LM.logmelfilterbank(x, sr, nfft, hop, nm, fmin, fmax, dtype=np.float64)
+        win = audio_utils.window_function(nfft, "hann", periodic=True)
+        theirs = audio_utils.spectrogram(x, win, nfft, hop, nfft, power=1.0, center=True, pad_mode="reflect", mel_filters=fb_t,
+                                         mel_floor=1e-10, log_mel="log10", dtype=np.float64).T
+        assert ours.shape == theirs.shape, (ours.shape, theirs.shape)
+        assert np.abs(ours - theirs).max() < 1e-6, np.abs(ours - theirs).max()
+
+
 def test_mel_basis_against_the_published_slaney_formula():
     """librosa.filters.mel(htk=False, norm="slaney") (bin/preprocess.py:76-82) = the mel scale of Slaney's Auditory Toolbox --
     linear below 1 kHz at 200/3 Hz per mel, above it 27 steps per factor 6.4 -- and triangles of unit AREA.  Checked: the
