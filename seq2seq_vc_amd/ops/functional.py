@@ -1037,16 +1037,19 @@ class _AttnPackedKV(Function):
     def forward(ctx, q, kv, klen, causal, H, p):
         q = _c(q)
         D = q.shape[-1]
-        # a column slice of the decoder's batched K/V projection (split_cols) is used in place when the fused kernel,
-        # which takes row and batch strides, runs; everything else wants a dense (B, T2, 2D) tensor
-        if not (kv.stride(-1) == 1 and KAT.supported(q, kv[..., :D], kv[..., D:], H)):
+        # a column slice of the decoder's batched K/V projection (split_cols) is used in place when the kernels that take row and
+        # batch strides run (the one-launch kernel of short sequences; round 6: the attention-map kernel of medium ones, whose
+        # neighbours are GEMM descriptors with strides of their own); everything else wants a dense (B, T2, 2D) tensor
+        in_place = kv.stride(-1) == 1 and (KAT.supported(q, kv[..., :D], kv[..., D:], H)
+                                           or (KAT.map_supported(q, kv[..., :D], H) and KAT.view_ok(kv[..., D:])))
+        if not in_place:
             kv = _c(kv)
         k, v = kv[..., :D], kv[..., D:]
         out, attn, pdrop, scale, seed = _attn_fwd_views(q, k, v, klen, causal, H, p)
         ctx.meta = (H, scale, p, seed, D)
-        # a column block of split_cols whose gradient can be written in place (see _GradSink): only on the fused kernels' path,
-        # which take row / batch strides for their outputs
-        ctx.gsink = getattr(kv, "_s2s_gsink", None) if (kv.stride(-1) == 1 and KAT.supported(q, k, v, H)) else None
+        # a column block of split_cols whose gradient can be written in place (see _GradSink): on the same paths (their backward
+        # kernels / descriptors take row and batch strides for dK and dV)
+        ctx.gsink = getattr(kv, "_s2s_gsink", None) if in_place else None
         ctx.save_for_backward(q, kv, attn, _split_pdrop(ctx, pdrop))
         ctx.set_materialize_grads(False)
         return out, _user_attn(attn, k.shape[1])
@@ -1057,7 +1060,7 @@ class _AttnPackedKV(Function):
         H, scale, p, seed, D = ctx.meta
         k, v = kv[..., :D], kv[..., D:]
         dq = torch.empty_like(q)
-        if ctx.gsink is not None and KAT.supported(q, k, v, H) and dctx is not None:
+        if ctx.gsink is not None and dctx is not None:
             dkv = ctx.gsink[0].part(ctx.gsink[1])       # this block of the packed gradient, written where split_cols wants it
         else:
             dkv = torch.empty(kv.shape, dtype=kv.dtype, device=kv.device)

@@ -14,6 +14,9 @@ def _strided_ok(t):
     return t.stride(2) == 1 and t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
 
 
+view_ok = _strided_ok
+
+
 def supported(q, k, v, H):
     if _DISABLED or q.dtype != torch.bfloat16:
         return False

@@ -446,6 +446,40 @@ def attention_map_one_launch_vs_separate():
             for nm, g1, g0 in zip(names, r1, r0):
                 e = _rel_l2(g1, g0)
                 res.append((e <= 2e-2, f"attention Function T1 {T1} T2 {T2} p={p}{' causal' if causal else ''} {nm}: one launch vs separate rel-L2 {e:.2e}"))
+        # the decoder's batched K/V projection: n source-attention blocks read their (B, T2, 2D) column block of ONE (B, T2, n 2D)
+        # tensor in place and write dK | dV into the block of its gradient (no copy forward, no concatenation backward: _GradSink)
+        B, H, T1, T2, dk, p, n = 3, 4, 320, 151, 96, 0.1, 3
+        D = H * dk
+        klen = torch.tensor([T2, T2 - 7, T2 // 2], dtype=torch.int32, device=DEV)
+        kv_all0 = rnd(B, T2, n * 2 * D, seed=21, dtype=bf, scale=0.8)
+        qs0 = [rnd(B, T1, D, seed=30 + i, dtype=bf, scale=0.8) for i in range(n)]
+        dys = [rnd(B, T1, D, seed=40 + i, dtype=bf) for i in range(n)]
+
+        def run_split(on):
+            KAT._MAP_DISABLED = not on
+            K.manual_seed(66)
+            K.reset_op_counter()
+            kv_all = kv_all0.clone().requires_grad_(True)
+            qs = [q_.clone().requires_grad_(True) for q_ in qs0]
+            blocks = Fn.split_cols(kv_all, n)
+            in_place = []
+            loss = 0.0
+            for q_, blk, dy_ in zip(qs, blocks, dys):
+                o, _ = Fn.attention_packed_kv(q_, blk, klen, False, H, p)
+                in_place.append(o.grad_fn.gsink is not None)
+                loss = loss + (o.float() * dy_.float()).sum()
+            sink = blocks[0]._s2s_gsink[0]
+            loss.backward()
+            return kv_all.grad, [q_.grad for q_ in qs], in_place, sink
+
+        g1, q1, ip1, sink1 = run_split(True)
+        g0, q0, ip0, _ = run_split(False)
+        res.append((all(ip1) and not any(ip0), f"split_cols blocks used in place by the attention-map path: {ip1} (separate kernels: {ip0})"))
+        res.append((sink1.buf is None and g1.is_contiguous(), "the packed gradient is the sink's buffer (handed over, nothing concatenated)"))
+        e = _rel_l2(g1, g0)
+        res.append((e <= 2e-2, f"d (batched K/V projection) written in place vs copies + concatenation: rel-L2 {e:.2e}"))
+        eq = max(_rel_l2(a_, b_) for a_, b_ in zip(q1, q0))
+        res.append((eq <= 2e-2, f"d q of the {n} blocks: rel-L2 {eq:.2e}"))
     finally:
         KAT._MAP_DISABLED = was
     return res

@@ -568,7 +568,7 @@ def test_committed_step_timelines_hold_no_aten_kernels():
     prof = os.path.join(ROOT, "profiles")
     allowed = ("distribution_elementwise_grid_stride_kernel", "FillFunctorIl")
     seen = {}
-    for wl, budget in (("vtn", 0), ("aasvc", 3)):
+    for wl, budget in (("vtn", 0), ("tts", 0), ("aasvc", 3)):
         path = os.path.join(prof, f"r06_{wl}_train_bf16_timeline.txt")
         assert os.path.exists(path), path
         lines = [ln for ln in open(path) if "at6native" in ln or "at::native" in ln]
@@ -578,4 +578,4 @@ def test_committed_step_timelines_hold_no_aten_kernels():
         seen[wl] = len(lines)
         n = [ln for ln in open(path) if ln.startswith("# step:")]
         assert n, "timeline header missing"
-    assert seen == {"vtn": 0, "aasvc": seen["aasvc"]}
+    assert seen == {"vtn": 0, "tts": 0, "aasvc": seen["aasvc"]}
