@@ -1176,6 +1176,7 @@ def main():
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="data parallel: one all-reduce per bucket, or reduce-scatter + all-gather")
     ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
+    ap.add_argument("--grad-batch", type=int, default=None, help="closures per parameter-gradient batch (default: 16 forked / 64 inline, ops.functional.enable_side_streams)")
     ap.add_argument("--side-streams", type=int, default=None, help="HIP side streams for parameter-gradient kernels (default: 4 for vtn, 0 + inline batches for aasvc)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend of the N > 1 path (nccl == RCCL; gloo: test aid, the same code path without RCCL)")
@@ -1243,7 +1244,7 @@ def main():
         n_side, inline = (4, args.inline_batches) if args.workload in ("vtn", "tts") else (0, True)
     else:
         n_side, inline = args.side_streams, args.inline_batches
-    Fn.enable_side_streams(n_side, inline_batches=inline)
+    Fn.enable_side_streams(n_side, inline_batches=inline, batch=args.grad_batch)
     K.manual_seed(1234 + rank)
 
     B = args.batch or {"vtn": 32, "aasvc": 16, "tts": 8}[args.workload]
