@@ -76,6 +76,22 @@ def canonical_batch(B_total, T=256, idim=80, odim=80, seed=1234):
     return xs, ilens, ys, labels, olens
 
 
+def canonical_batch_T(B_total, T, idim=80, odim=80, seed=1234):
+    """canonical_batch's draw at another padded length T: lens in [T / 2, T], element 0 forced to T (bench.py --frames)."""
+    g = torch.Generator().manual_seed(seed)
+    ilens = torch.randint(T // 2, T + 1, (B_total,), generator=g)
+    ilens[0] = T
+    olens = torch.randint(T // 2, T + 1, (B_total,), generator=g)
+    olens[0] = T
+    xs = torch.randn(B_total, T, idim, generator=g)
+    ys = torch.randn(B_total, T, odim, generator=g)
+    ar = torch.arange(T)[None, :]
+    xs[(ar >= ilens[:, None])] = 0.0
+    ys[(ar >= olens[:, None])] = 0.0
+    labels = (ar >= (olens[:, None] - 1)).float()
+    return xs, ilens, ys, labels, olens
+
+
 def canonical_tts_batch(B_total, seed=1234):
     """SURVEY.md section 8(d), C4 (LJSpeech TTS pre-training, egs/ljspeech/tts1): ilens in [60, 150] tokens in [1, 77) padded with 0,
     olens in [300, 640] frames, ys randn(B, 640, 80); element 0 fills both padded shapes (the batch of tests' tts_full_size_c4)."""
@@ -434,13 +450,16 @@ def dominant_kernel_roofline(dtype, iters=100, workload="vtn"):
 class Workload:
     """Model + fused optimiser + criterion on the canonical synthetic batch of this rank."""
 
-    def __init__(self, name, dev, dtype, batch, world, rank):
+    def __init__(self, name, dev, dtype, batch, world, rank, frames=None):
         from seq2seq_vc_amd import losses as L
         from seq2seq_vc_amd import models as M
         from seq2seq_vc_amd.ops import functional as Fn
         from seq2seq_vc_amd.optim import FlatAdam
         self.name, self.dev, self.Fn = name, dev, Fn
-        xs, ilens, ys, labels, olens = (canonical_tts_batch if name == "tts" else canonical_batch)(batch * world)
+        if frames and name != "tts":            # --frames: the same draw at another padded length (lens in [T / 2, T]); NOT the canonical workload
+            xs, ilens, ys, labels, olens = canonical_batch_T(batch * world, int(frames))
+        else:
+            xs, ilens, ys, labels, olens = (canonical_tts_batch if name == "tts" else canonical_batch)(batch * world)
         sl = slice(rank * batch, (rank + 1) * batch)
         xs, ilens, ys, labels, olens = xs[sl], ilens[sl], ys[sl], labels[sl], olens[sl]
         Ti, To = xs.shape[1], ys.shape[1]
@@ -1176,6 +1195,8 @@ def main():
     ap.add_argument("--collective", default="allreduce", choices=["allreduce", "rs_ag"],
                     help="data parallel: one all-reduce per bucket, or reduce-scatter + all-gather")
     ap.add_argument("--inline-batches", action="store_true", help="with --side-streams 0: queue the gradient work and run it in batches on its own stream")
+    ap.add_argument("--frames", type=int, default=None, help="vtn / aasvc: padded utterance length in frames instead of the canonical 256 (a side measurement: "
+                                                              "the line's config.T_src / T_tgt say so; lengths in [T / 2, T])")
     ap.add_argument("--grad-batch", type=int, default=None, help="closures per parameter-gradient batch (default: 16 forked / 64 inline, ops.functional.enable_side_streams)")
     ap.add_argument("--side-streams", type=int, default=None, help="HIP side streams for parameter-gradient kernels (default: 4 for vtn, 0 + inline batches for aasvc)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -1248,7 +1269,7 @@ def main():
     K.manual_seed(1234 + rank)
 
     B = args.batch or {"vtn": 32, "aasvc": 16, "tts": 8}[args.workload]
-    wl = Workload(args.workload, dev, dtype, B, world, rank)
+    wl = Workload(args.workload, dev, dtype, B, world, rank, frames=args.frames)
     # Data parallel: backward in the stages of model.dp_plan(), one captured graph per stage, the all-reduce of a finished stage's
     # slice of the flat gradient buffer issued between the replays (overlap).  N = 1 keeps one graph (the cuts cost ~0.2 ms).
     staged = dp or args.split_backward
